@@ -1,0 +1,186 @@
+"""TEST INFRASTRUCTURE ONLY -- writes tests/golden/*.npz from the REFERENCE ITSELF.
+
+Runs the reference's own Python (OpenDrift v1.14.10 under /root/reference) through
+oracle/refshim.py + oracle/refdriver.py on small seeded cases shaped like
+BASELINE.json's configs and stores inputs + per-step live float64 lon/lat/z.
+The fixtures travel to the GPU box; /root/reference does not.
+
+    python oracle/gen_golden.py            # all scenarios
+    python oracle/gen_golden.py c2 c4      # selected
+"""
+import os
+import sys
+from datetime import datetime, timedelta
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import refshim  # noqa: E402
+
+assert refshim.install(), 'reference tree not found'
+from oracle.refdriver import RefStepper, RecordingRandom  # noqa: E402
+from opendrift_amd import synthetic as synth  # noqa: E402
+from opendrift.models.oceandrift import OceanDrift  # noqa: E402
+from opendrift.readers import reader_constant, reader_double_gyre  # noqa: E402
+from opendrift.readers.basereader.structured import StructuredReader  # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+T0 = datetime(2020, 1, 1)
+
+
+class GridReader(StructuredReader):
+    """In-memory StructuredReader (Reader plugin surface B2, cf. reader_constant_2d.py:20-49)
+    with time levels and optional z levels; returns the whole domain as the block."""
+
+    def __init__(self, proj4, x, y, times, arrays, z=None, name='synthetic_grid'):
+        self.proj4 = proj4
+        self.x, self.y = x, y
+        self.xmin, self.xmax, self.ymin, self.ymax = x.min(), x.max(), y.min(), y.max()
+        self.delta_x, self.delta_y = x[1] - x[0], y[1] - y[0]
+        self.numx, self.numy = len(x), len(y)
+        self.times = list(times)
+        self.start_time, self.end_time = times[0], times[-1]
+        self.time_step = times[1] - times[0] if len(times) > 1 else None
+        self.z = z
+        self.arrays = arrays  # {var: [nt, (nz,) ny, nx]}
+        self.variables = list(arrays.keys())
+        self.name = name
+        super().__init__()
+
+    def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
+        it = self.times.index(time)
+        out = {'x': self.x, 'y': self.y, 'time': time,
+               'z': self.z if self.z is not None else 0}
+        for v in requested_variables:
+            out[v] = np.array(self.arrays[v][it], copy=True)
+        return out
+
+
+def _run(o, dt, steps, record_random=False):
+    st = RefStepper(o, dt, steps)
+    N = st.n_total
+    lon = np.empty((steps + 1, N))
+    lat = np.empty((steps + 1, N))
+    z = np.empty((steps + 1, N))
+    status = np.empty((steps + 1, N), np.int32)
+    sch = o.elements_scheduled
+    lon[0], lat[0] = sch.lon, sch.lat
+    z[0] = np.atleast_1d(sch.z) * np.ones(N)
+    status[0] = 0
+    draws = []
+    for k in range(steps):
+        if record_random:
+            with RecordingRandom() as rr:
+                st.step()
+            draws.append(rr.draws)
+        else:
+            st.step()
+        lon[k + 1], lat[k + 1], z[k + 1], status[k + 1] = st.state()
+    return dict(lon=lon, lat=lat, z=z, status=status), draws
+
+
+def _base(scheme):
+    o = OceanDrift(loglevel=50)
+    o.set_config('general:use_auto_landmask', False)
+    o.set_config('drift:advection_scheme', scheme)
+    return o
+
+
+def c1_constant():
+    """C1: OceanDrift + reader_constant, Euler, 24 h (BASELINE.json configs[0])."""
+    o = _base('euler')
+    o.add_reader(reader_constant.Reader({'x_sea_water_velocity': 0.3, 'y_sea_water_velocity': 0.2}))
+    o.set_config('environment:constant:land_binary_mask', 0)
+    np.random.seed(0)
+    o.seed_elements(lon=4.0, lat=60.0, number=200, radius=5000, time=T0)
+    res, _ = _run(o, 3600, 24)
+    np.savez_compressed(os.path.join(GOLD, 'c1_constant_euler.npz'), u=0.3, v=0.2, dt=3600.0, **res)
+
+
+def c2_double_gyre():
+    """C2: analytic double gyre, Euler/RK2/RK4, dt=0.1 s (examples/example_double_gyre.py:20)."""
+    rng = np.random.default_rng(0)
+    N = 400
+    for scheme, steps in (('euler', 20), ('runge-kutta', 20), ('runge-kutta4', 100)):
+        o = _base(scheme)
+        r = reader_double_gyre.Reader(initial_time=T0, epsilon=0.25, omega=0.628, A=0.1)
+        o.add_reader(r)
+        o.set_config('environment:fallback:land_binary_mask', 0)
+        x = rng.uniform(0.05, 1.95, N)
+        y = rng.uniform(0.05, 0.95, N)
+        lon, lat = r.xy2lonlat(x, y)
+        o.seed_elements(lon=lon, lat=lat, time=T0)
+        res, _ = _run(o, 0.1, steps)
+        np.savez_compressed(os.path.join(GOLD, 'c2_double_gyre_%s.npz' % scheme.replace('-', '')),
+                            A=0.1, epsilon=0.25, omega=0.628, dt=0.1, **res)
+
+
+def c3_grid3d():
+    """C3-shaped: 3D z-level lon/lat grid (u,v,w,K + depth), RK4 + vertical mixing + vertical advection."""
+    g = synth.grid3d(nx=48, ny=40, nz=8, nt=3, seed=1)
+    times = [T0 + timedelta(seconds=float(t)) for t in g['t']]
+    arrays = {k: g[k] for k in ('x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity',
+                                'ocean_vertical_diffusivity', 'sea_floor_depth_below_sea_level',
+                                'land_binary_mask')}
+    o = _base('runge-kutta4')
+    o.add_reader(GridReader('+proj=latlong', g['x'], g['y'], times, arrays, z=g['z']))
+    o.set_config('drift:vertical_mixing', True)
+    o.set_config('vertical_mixing:timestep', 60)
+    o.set_config('vertical_mixing:diffusivitymodel', 'environment')
+    o.set_config('drift:vertical_advection', True)
+    o.set_config('general:coastline_action', 'previous')
+    rng = np.random.default_rng(2)
+    N = 300
+    lon = rng.uniform(g['x'][4], g['x'][-5], N)
+    lat = rng.uniform(g['y'][4], g['y'][-5], N)
+    zz = rng.uniform(-40, -1, N)
+    np.random.seed(0)
+    o.seed_elements(lon=lon, lat=lat, z=zz, time=T0)
+    res, draws = _run(o, 600, 8, record_random=True)
+    uni = np.array([np.stack([d[1] for d in step if d[0] == 'random']) for step in draws])
+    np.savez_compressed(os.path.join(GOLD, 'c3_grid3d_rk4_vmix.npz'), dt=600.0, dt_mix=60.0,
+                        uniforms=uni, **{('g_' + k): v for k, v in g.items()}, **res)
+
+
+def c4_stere():
+    """C4-shaped: NorKyst-like polar-stereographic 2D grid (current, wind, Stokes, landmask with NaN
+    current on land), RK4 + horizontal diffusion + stranding."""
+    g = synth.grid_stere(nx=70, ny=50, nt=3, seed=3)
+    times = [T0 + timedelta(seconds=float(t)) for t in g['t']]
+    arrays = {k: g[k] for k in ('x_sea_water_velocity', 'y_sea_water_velocity', 'x_wind', 'y_wind',
+                                'sea_surface_wave_stokes_drift_x_velocity',
+                                'sea_surface_wave_stokes_drift_y_velocity', 'land_binary_mask')}
+    o = _base('runge-kutta4')
+    r = GridReader(synth.NORKYST_PROJ4, g['x'], g['y'], times, arrays)
+    o.add_reader(r)
+    o.set_config('environment:constant:horizontal_diffusivity', 10)
+    o.set_config('general:coastline_action', 'stranding')
+    o.set_config('general:coastline_approximation_precision', None)
+    o.set_config('drift:stokes_drift', True)
+    rng = np.random.default_rng(4)
+    N = 400
+    x = rng.uniform(g['x'][5], g['x'][-6], N)
+    y = rng.uniform(g['y'][5], g['y'][-6], N)
+    lon, lat = r.xy2lonlat(x, y)
+    np.random.seed(0)
+    o.seed_elements(lon=lon, lat=lat, time=T0, wind_drift_factor=0.03)
+    res, draws = _run(o, 900, 10, record_random=True)
+    nrm = [[d[1] for d in step if d[0] == 'normal'] for step in draws]
+    nmax = max(len(a) for s in nrm for a in s)
+    normals = np.full((len(nrm), 2, nmax), np.nan)
+    for k, s in enumerate(nrm):
+        for j, a in enumerate(s[:2]):
+            normals[k, j, :len(a)] = a
+    np.savez_compressed(os.path.join(GOLD, 'c4_stere_rk4_hdiff_strand.npz'), dt=900.0, normals=normals,
+                        wdf=0.03, **{('g_' + k): v for k, v in g.items()}, **res)
+
+
+SCEN = dict(c1=c1_constant, c2=c2_double_gyre, c3=c3_grid3d, c4=c4_stere)
+
+if __name__ == '__main__':
+    os.makedirs(GOLD, exist_ok=True)
+    for name in (sys.argv[1:] or list(SCEN)):
+        print('generating', name)
+        SCEN[name]()
