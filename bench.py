@@ -1,0 +1,301 @@
+#!/usr/bin/env python
+"""bench.py -- particle-steps/s of the MI355X hot path on BASELINE.json's workloads.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4] [--particles P]
+
+A "step" is one pass of the per-timestep hot path over all particles of this rank with the
+inputs already resident in HBM (field blocks uploaded, particle SoA on device):
+  c3 (default, "RK4, 3D interp"): Environment sample (u,v,w,depth,ssh,landmask) -> coastline
+      -> RK4 advect_ocean_current (3 more 3D field evaluations + 4 geodesics) -> vertical_mixing
+      (10 Visser sub-steps from the K profile) -> vertical_advection; 10 M particles, synthetic
+      ROMS-shaped 1024x1024x12 z-level block, 2 time levels interpolated.
+  c2: analytic double gyre, 1 M particles, RK4.
+  c4: NorKyst-800-shaped 2602x902 polar-stereographic surface block (current, wind, Stokes,
+      landmask), RK4 + wind + Stokes + horizontal diffusion + stranding + compaction.
+One JSON line is printed by rank 0.  N>1: one process per GPU (torchrun), particles sharded,
+field blocks broadcast once from rank 0 over RCCL; weak scaling (per-GPU work fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+U, V, W = 'x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity'
+KZ, DEPTH, SSH, LAND = ('ocean_vertical_diffusivity', 'sea_floor_depth_below_sea_level',
+                        'sea_surface_height', 'land_binary_mask')
+XW, YW = 'x_wind', 'y_wind'
+SX, SY = 'sea_surface_wave_stokes_drift_x_velocity', 'sea_surface_wave_stokes_drift_y_velocity'
+HD = 'horizontal_diffusivity'
+
+# algorithmic bytes per particle
+BYTES = {
+    'c2': dict(step=48, advect=56),
+    'c3': dict(step=908, advect=3 * 128 + 56),
+    'c4': dict(step=436, advect=3 * 64 + 56),
+}
+HBM_PEAK = 8.0e12
+
+
+def make_fields(workload, small=False):
+    from opendrift_amd import synthetic as synth
+    if workload == 'c3':
+        n = (128, 96, 8) if small else (1024, 1024, 12)
+        g = synth.grid3d(nx=n[0], ny=n[1], nz=n[2], nt=3, seed=0)
+        names = [U, V, W, KZ, DEPTH, LAND]
+        return dict(g=g, names=names, proj=None, z=g['z'])
+    if workload == 'c4':
+        n = (260, 90) if small else (2602, 902)
+        g = synth.grid_stere(nx=n[0], ny=n[1], nt=3, seed=0)
+        names = [U, V, XW, YW, SX, SY, LAND]
+        return dict(g=g, names=names, proj=synth.NORKYST_PROJ, z=None)
+    return None
+
+
+def seed_particles(workload, fields, n, rng):
+    if workload == 'c2':
+        from opendrift_amd.projection import stere_equit_sphere_inverse
+        x = rng.uniform(0.05, 1.95, n)
+        y = rng.uniform(0.05, 0.95, n)
+        lon, lat = stere_equit_sphere_inverse(x, y, 6.371e6)
+        return lon, lat, np.zeros(n)
+    g = fields['g']
+    if workload == 'c3':
+        lon = rng.uniform(g['x'][8], g['x'][int(0.9 * len(g['x']))], n)
+        lat = rng.uniform(g['y'][8], g['y'][-9], n)
+        return lon, lat, -rng.uniform(0, 50, n)
+    from opendrift_amd.projection import stere_polar_inverse
+    x = rng.uniform(g['x'][8], g['x'][int(0.9 * len(g['x']))], n)
+    y = rng.uniform(g['y'][8], g['y'][-9], n)
+    lon, lat = stere_polar_inverse(x, y, **fields['proj'])
+    return lon, lat, np.zeros(n)
+
+
+class Workload:
+    """Device-side step of one workload (the product path: opendrift_amd -> libodrift_hip.so)."""
+
+    def __init__(self, name, ctx, fields, dist_info):
+        from opendrift_amd import distributed as D
+        self.name, self.ctx, self.fields = name, ctx, fields
+        rank, local_rank, world = dist_info
+        if name == 'c2':
+            sid = ctx.add_double_gyre(A=0.1, epsilon=0.25, omega=0.628, t0=0.0)
+            ctx.bind(U, [sid], 0.0)
+            ctx.bind(V, [sid], 0.0)
+            self.dt, self.tmax = 0.1, 1e9
+            return
+        g = fields['g']
+        sid = ctx.add_grid(g['x'], g['y'], z=fields['z'], proj=fields['proj'])
+        for slot in range(3):
+            arrays = {k: g[k][slot] for k in fields['names']} if rank == 0 else None
+            shapes = {k: g[k][slot].shape for k in fields['names']}
+            if world > 1 or True:
+                # rank 0 owns the host Reader; the block travels to every GPU once per time level
+                import torch
+                if torch.cuda.is_available():
+                    tens = D.broadcast_block(arrays, shapes=shapes, src=0)
+                    torch.cuda.synchronize()
+                    ctx.upload_block_device(sid, slot, float(g['t'][slot]),
+                                            {k: t.data_ptr() for k, t in tens.items()},
+                                            {k: (t.shape[0] if t.dim() == 3 else 1) for k, t in tens.items()})
+                    del tens
+                    continue
+            ctx.upload_block(sid, slot, float(g['t'][slot]), {k: g[k][slot] for k in fields['names']})
+        for k in fields['names']:
+            ctx.bind(k, [sid], {LAND: np.nan, DEPTH: 10000.0}.get(k, 0.0))
+        ctx.bind(SSH, [], 0.0)
+        if name == 'c3':
+            self.dt, self.dt_mix, self.tmax = 600.0, 60.0, 2 * 3600.0 - 600.0
+            self.vars = [U, V, W, DEPTH, SSH, LAND]
+        else:
+            cs = ctx.add_constant({HD: 10.0})
+            ctx.bind(HD, [cs], 0.0)
+            self.dt, self.tmax = 900.0, 2 * 3600.0 - 900.0
+            self.vars = [U, V, XW, YW, SX, SY, LAND, HD]
+
+    def time_of(self, k):
+        return (k * self.dt) % self.tmax if self.tmax < 1e8 else k * self.dt
+
+    def step(self, P, k):
+        t = self.time_of(k)
+        if self.name == 'c2':
+            P.env_sample([U, V], t)
+            P.advect('runge-kutta4', t, self.dt)
+        elif self.name == 'c3':
+            P.env_sample(self.vars, t)
+            P.coastline('previous')
+            P.advect('runge-kutta4', t, self.dt)
+            P.vmix(t, self.dt, self.dt_mix, step=k)
+            P.vertical_advection(self.dt)
+        else:
+            P.env_sample(self.vars, t)
+            P.coastline('stranding', stranded_code=1)
+            P.compact()
+            P.advect('runge-kutta4', t, self.dt)
+            P.advect_wind(self.dt, wind_drift_depth=0.1)
+            P.stokes_drift(self.dt, profile=2, hs_mode=1, tp_mode=1)
+            P.hdiffusion(self.dt, step=k)
+
+    def advect_only(self, P, k):
+        P.advect('runge-kutta4', self.time_of(k), self.dt)
+
+
+def cpu_baseline(name, fields, n_cpu, rng):
+    """The CPU oracle (C port of the reference path, 1 core) on a bounded sample of the workload."""
+    from oracle import oracle as orc
+    wb = orc.WorldBuilder()
+    if name == 'c2':
+        wb.add_double_gyre(A=0.1, epsilon=0.25, omega=0.628, t0=0.0)
+        dt = 0.1
+    else:
+        g = fields['g']
+        proj = orc.make_proj()
+        if fields['proj']:
+            p = fields['proj']
+            f = 1.0 / p['rf']
+            proj = orc.make_proj(orc.PROJ_STERE_POLAR, a=p['a'], es=f * (2 - f), lat0=p['lat0'], lon0=p['lon0'],
+                                 lat_ts=p['lat_ts'])
+        levels = [(float(g['t'][k]), {orc.VAR[n]: g[n][k] for n in fields['names']}) for k in range(3)]
+        wb.add_grid(proj, g['x'], g['y'], levels, z=fields['z'])
+        for n in fields['names']:
+            wb.set_fallback(orc.VAR[n], {LAND: np.nan, DEPTH: 10000.0}.get(n, 0.0))
+        wb.set_fallback(orc.VAR[SSH], 0.0)
+        if name == 'c4':
+            wb.add_constant({orc.VAR[HD]: 10.0})
+        dt = 600.0 if name == 'c3' else 900.0
+    w = wb.finish()
+    lon, lat, z = seed_particles(name, fields, n_cpu, rng)
+    mv, cdf = np.ones(n_cpu, np.int32), np.ones(n_cpu, np.float32)
+    wdf = np.full(n_cpu, 0.02, np.float32)
+
+    def step(k):
+        t = (k * dt) % 6000.0
+        if name == 'c2':
+            u, v = orc.get_environment(w, [0, 1], lon, lat, z, t)
+            orc.advect_ocean_current(w, 2, lon, lat, z, mv, cdf, u, v, t, dt)
+        elif name == 'c3':
+            ids = [orc.VAR[n] for n in (U, V, W, DEPTH, SSH, LAND)]
+            u, v, ww, dep, ssh, land = orc.get_environment(w, ids, lon, lat, z, t)
+            Kp = orc.get_profile(w, orc.VAR[KZ], lon, lat, t, len(fields['z']))
+            orc.advect_ocean_current(w, 2, lon, lat, z, mv, cdf, u, v, t, dt)
+            uni = np.random.default_rng(k).uniform(size=(10, n_cpu))
+            orc.vertical_mixing(z, mv, np.zeros(n_cpu, np.float32), dep, ssh, fields['z'], Kp, dt, 60.0, 0, uni)
+            orc.vertical_advection(z, mv, ww, dt)
+        else:
+            ids = [orc.VAR[n] for n in (U, V, XW, YW, SX, SY, LAND, HD)]
+            u, v, xw, yw, sx, sy, land, hd = orc.get_environment(w, ids, lon, lat, z, t)
+            orc.advect_ocean_current(w, 2, lon, lat, z, mv, cdf, u, v, t, dt)
+            orc.advect_wind(lon, lat, z, mv, wdf, xw, yw, u, v, 0.1, 0, 1.0, dt)
+            orc.stokes_drift(lon, lat, z, mv, sx, sy, sx, sy, xw, yw, 1, 1, 2, 1.0, dt)
+            r = np.random.default_rng(k)
+            orc.horizontal_diffusion(lon, lat, mv, hd, r.standard_normal(n_cpu), r.standard_normal(n_cpu), dt)
+
+    step(0)  # warm-up: also performs the reference's one-off NaN dilation of the cached blocks
+    nsteps, t0 = 0, time.perf_counter()
+    while nsteps < 3 or (time.perf_counter() - t0 < 12.0 and nsteps < 50):
+        step(1 + nsteps)
+        nsteps += 1
+    el = time.perf_counter() - t0
+    return dict(value=n_cpu * nsteps / el, unit='particle-steps/s', cores=1, kind='port',
+                sample='%d particles x %d steps of the same workload (oracle/*.c, gcc -O2, 1 thread, %.1f s)'
+                       % (n_cpu, nsteps, el))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default=os.environ.get('ODR_WORKLOAD', 'c3'), choices=['c2', 'c3', 'c4'])
+    ap.add_argument('--particles', type=int, default=0, help='particles per GPU (default: the config size)')
+    ap.add_argument('--small', action='store_true', help='small field block (debug)')
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--cpu-particles', type=int, default=200000)
+    a = ap.parse_args()
+
+    import torch
+    from opendrift_amd import distributed as D
+    from opendrift_amd.device import Context
+    import __graft_entry__ as G
+    rank, local_rank, world = D.init()
+    if rank == 0:
+        G.build()
+    D.barrier()
+    assert torch.cuda.is_available(), 'bench.py needs a GPU: the product path has no CPU fallback'
+    torch.cuda.set_device(local_rank)
+
+    n = a.particles or {'c2': 1_000_000, 'c3': 10_000_000, 'c4': 6_250_000}[a.workload]
+    fields = make_fields(a.workload, a.small)
+    ctx = Context(device=local_rank, seed=0)
+    wl = Workload(a.workload, ctx, fields, (rank, local_rank, world))
+    rng = np.random.default_rng(1000 + rank)
+    lon, lat, z = seed_particles(a.workload, fields, n, rng)
+    lo, hi = D.shard_range(n * world, rank, world)     # global particle IDs of this shard
+    P = ctx.particles(n)
+    P.append(lon, lat, z=z, id=np.arange(lo, hi, dtype=np.int32))
+
+    for k in range(a.warmup):
+        wl.step(P, k)
+    ctx.sync()
+    torch.cuda.synchronize()
+    D.barrier()
+    n0 = len(P)
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        wl.step(P, a.warmup + k)
+    ctx.sync()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    D.barrier()
+    n1 = len(P)
+    el_max = float(D.allreduce_scalars([el], 'max')[0])
+    units = float(D.allreduce_scalars([0.5 * (n0 + n1) * a.steps], 'sum')[0])
+
+    # dominant kernel (fused RK4 advection) timed with HIP events on the context stream
+    reps = 10
+    P.env_sample([U, V], wl.time_of(0))
+    wl.advect_only(P, 0)
+    ctx.sync()
+    ctx.timer_begin()
+    for k in range(reps):
+        wl.advect_only(P, k)
+    k_ms = ctx.timer_end() / reps
+    nact = len(P)
+    ach = BYTES[a.workload]['advect'] * nact / (k_ms * 1e-3)
+
+    if rank == 0:
+        out = {
+            'metric': 'particle-steps/sec (RK4, 3D interp)', 'value': units / el_max, 'unit': 'particle-steps/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * el_max / a.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': {'c2': 'C2: OceanDrift, analytic double gyre, RK4',
+                                    'c3': 'C3: OceanDrift 3D, synthetic ROMS-shaped z-level grid 1024x1024x12 (u,v,w,K), '
+                                          'RK4 + vertical_mixing(60 s) + vertical_advection',
+                                    'c4': 'C4: OpenOil-advection on NorKyst-800-shaped 2602x902 stere grid, RK4 + wind + '
+                                          'Stokes + horizontal diffusion + stranding'}[a.workload],
+                       'particles_per_gpu': n, 'particles_total': n * world, 'time_step_s': wl.dt,
+                       'parallelism': 'particle-sharded x%d, field block broadcast once per time level' % world},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_advect<RK4>', 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9,
+                         'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': None,
+                         'kernel_ms': k_ms, 'algorithmic_bytes_per_particle': BYTES[a.workload]['advect'],
+                         'step_bytes_per_particle': BYTES[a.workload]['step'],
+                         'step_frac': BYTES[a.workload]['step'] * (units / el_max) / world / HBM_PEAK},
+        }
+        if not a.no_cpu and world == 1:
+            out['cpu_baseline'] = cpu_baseline(a.workload, fields, a.cpu_particles, np.random.default_rng(5))
+        print(json.dumps(out), flush=True)
+    P.close()
+    ctx.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

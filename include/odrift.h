@@ -1,0 +1,194 @@
+/* odrift.h -- C ABI of libodrift_hip.so: the MI355X-native particle-advection
+ * hot path behind OpenDrift's model / reader API.
+ *
+ * The reference (OpenDrift v1.14.10) is pure Python and has NO FFI for this
+ * path; its boundary is class inheritance + duck typing.  Each entry point below
+ * therefore names the reference METHOD it replaces (file:line under
+ * /root/reference).  The binding a maintainer adds on the reference side is a
+ * ctypes stub; it is shown in INTEGRATION.md and shipped in
+ * opendrift_amd/_abi.py.
+ *
+ * Conventions: every function returns 0 on success, a negative odr_status on
+ * error (odr_last_error() gives a thread-local message).  Opaque handles own
+ * all device memory; host buffers belong to the caller and may be freed as soon
+ * as the call returns.  Calls are asynchronous on the context's HIP stream
+ * unless they return data to the host.  One host thread per context.  No torch
+ * types, no callbacks.
+ */
+#ifndef ODRIFT_H
+#define ODRIFT_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct odr_ctx odr_ctx;
+typedef struct odr_particles odr_particles;
+
+typedef enum {
+  ODR_OK = 0,
+  ODR_ERR_INVALID = -1,  /* bad argument (ValueError on the Python side) */
+  ODR_ERR_HIP = -2,      /* HIP runtime failure */
+  ODR_ERR_CAPACITY = -3, /* particle capacity / slot / table exhausted */
+  ODR_ERR_STATE = -4     /* call made in the wrong order (WrongMode analogue) */
+} odr_status;
+
+/* ---- environment variables on the path (CF standard names, OceanDrift.required_variables,
+ *      opendrift/models/oceandrift.py:60-88) ---- */
+enum {
+  ODR_VAR_X_SEA_WATER_VELOCITY = 0,
+  ODR_VAR_Y_SEA_WATER_VELOCITY = 1,
+  ODR_VAR_X_WIND = 2,
+  ODR_VAR_Y_WIND = 3,
+  ODR_VAR_UPWARD_SEA_WATER_VELOCITY = 4,
+  ODR_VAR_OCEAN_VERTICAL_DIFFUSIVITY = 5,
+  ODR_VAR_STOKES_DRIFT_X_VELOCITY = 6,
+  ODR_VAR_STOKES_DRIFT_Y_VELOCITY = 7,
+  ODR_VAR_LAND_BINARY_MASK = 8,
+  ODR_VAR_SEA_FLOOR_DEPTH = 9,
+  ODR_VAR_SEA_SURFACE_HEIGHT = 10,
+  ODR_VAR_HORIZONTAL_DIFFUSIVITY = 11,
+  ODR_VAR_SIGNIFICANT_WAVE_HEIGHT = 12,
+  ODR_VAR_WAVE_PERIOD = 13,
+  ODR_VAR_MIXED_LAYER_THICKNESS = 14,
+  ODR_NVAR = 16
+};
+
+/* ---- projections of a reader (pyproj.Proj(reader.proj4), basereader/__init__.py:119-137) ---- */
+enum { ODR_PROJ_LATLONG = 0, ODR_PROJ_STERE_EQUIT_SPHERE = 1, ODR_PROJ_STERE_POLAR = 2 };
+typedef struct {
+  int32_t kind;
+  double a, es;                  /* semi-major axis, eccentricity squared */
+  double lat0_deg, lon0_deg, lat_ts_deg, k0, x0, y0;
+} odr_proj_desc;
+
+enum { ODR_SCHEME_EULER = 0, ODR_SCHEME_RK2 = 1, ODR_SCHEME_RK4 = 2 };
+enum { ODR_RNG_DEVICE = 0, ODR_RNG_HOST = 1 }; /* Philox on device | numbers drawn by the caller (np.random parity) */
+enum { ODR_COAST_NONE = 0, ODR_COAST_STRANDING = 1, ODR_COAST_PREVIOUS = 2 };
+enum { ODR_ANALYTIC_DOUBLE_GYRE = 1, ODR_ANALYTIC_OSCILLATING = 2 };
+
+/* ---------------------------------------------------------------- lifecycle */
+int odr_ctx_create(int device, uint64_t seed, odr_ctx **out);
+int odr_ctx_destroy(odr_ctx *ctx);
+int odr_sync(odr_ctx *ctx);
+int odr_set_stream(odr_ctx *ctx, void *hip_stream); /* adopt a caller-owned hipStream_t (NULL = own stream) */
+const char *odr_last_error(void);
+const char *odr_version(void);
+
+/* ------------------------------------------------- particle state (SoA in HBM)
+ * replaces LagrangianArray (opendrift/elements/elements.py:22-254): one array per
+ * property; lon/lat/z float64, ID/status/moving int32, drift factors float32. */
+int odr_particles_create(odr_ctx *ctx, int64_t capacity, odr_particles **out);
+int odr_particles_destroy(odr_ctx *ctx, odr_particles *p);
+/* release_elements (basemodel/__init__.py:909-934) / LagrangianArray.extend (elements.py:170-195):
+ * append n elements to the active set.  NULL optional arrays take the defaults
+ * moving=1, wind_drift_factor=0.02, current_drift_factor=1, terminal_velocity=0. */
+int odr_particles_append(odr_ctx *ctx, odr_particles *p, int64_t n, const double *lon,
+                         const double *lat, const double *z, const int32_t *id,
+                         const int32_t *moving, const float *wind_drift_factor,
+                         const float *current_drift_factor, const float *terminal_velocity);
+int odr_particles_count(odr_ctx *ctx, odr_particles *p, int64_t *n_active, int64_t *n_deactivated);
+/* host copy of the live state (state_to_buffer input, basemodel/__init__.py:2384-2403); any pointer may be NULL */
+int odr_particles_download(odr_ctx *ctx, odr_particles *p, double *lon, double *lat, double *z,
+                           int32_t *id, int32_t *status, int32_t *moving);
+int odr_particles_download_deactivated(odr_ctx *ctx, odr_particles *p, double *lon, double *lat,
+                                       double *z, int32_t *id, int32_t *status);
+/* overwrite properties of the active set from the host (model subclasses that update elements on the host) */
+int odr_particles_upload(odr_ctx *ctx, odr_particles *p, const double *lon, const double *lat,
+                         const double *z, const int32_t *moving, const float *wind_drift_factor,
+                         const float *current_drift_factor, const float *terminal_velocity);
+/* raw device pointers (for torch.distributed / zero-copy consumers): name in
+ * {"lon","lat","z","id","status","moving","env:<var_id>"} */
+int odr_particles_device_ptr(odr_ctx *ctx, odr_particles *p, const char *name, void **dptr);
+
+/* ------------------------------------------------------- field sources (readers)
+ * A source is the device image of one Reader.  Priority lists per variable follow
+ * Environment.priority_list (environment.py:339-374). */
+/* reader_constant.Reader / environment:constant:<var> (reader_constant.py:60-82, environment.py:172-182) */
+int odr_source_constant(odr_ctx *ctx, int nvars, const int32_t *var_ids, const double *values,
+                        int32_t *source_id);
+/* ContinuousReader analytic fields: reader_double_gyre.py:55-79 params {A, epsilon, omega, t0_epoch};
+ * reader_oscillating.py:49-59 params {var_id, amplitude, period_seconds, t0_epoch} */
+int odr_source_analytic(odr_ctx *ctx, int kind, const double *params, int nparams,
+                        int32_t *source_id);
+/* StructuredReader on a regular grid in its own projection (basereader/structured.py).
+ * domain = {xmin,xmax,ymin,ymax,zmin,zmax}; lon_mode 1: [-180,180), 2: [0,360) (variables.py:259-280);
+ * z = block z levels (NULL / nz<=1 for surface fields). */
+int odr_source_grid(odr_ctx *ctx, const odr_proj_desc *proj, const double *domain6,
+                    int lon_mode, int mod360_x, int nz, const double *z, int32_t *source_id);
+/* One time level = one ReaderBlock (interpolation/structured.py:15-94).  data[k] is a host
+ * float32 array [var_nz[k], ny, nx] (var_nz 1 => 2D).  xy8 = {x0, xspan, y0, yspan, xmin,
+ * xrange, ymin, yrange} with the spans formed in the dtype of the reader's x/y arrays
+ * (interpolators.py:32-33,110-111).  The upload masks |v|>1e9, fills NaN towards the
+ * seafloor and pre-dilates NaN cells 10x (interpolators.py:9-20,127-137). */
+int odr_block_upload(odr_ctx *ctx, int32_t source_id, int32_t slot, double t_epoch, int nvars,
+                     const int32_t *var_ids, const float *const *data, const int32_t *var_nz,
+                     int ny, int nx, const double *xy8);
+/* same, the float32 data already live in device memory (RCCL-broadcast blocks) */
+int odr_block_upload_device(odr_ctx *ctx, int32_t source_id, int32_t slot, double t_epoch,
+                            int nvars, const int32_t *var_ids, const void *const *dev_data,
+                            const int32_t *var_nz, int ny, int nx, const double *xy8);
+int odr_block_drop(odr_ctx *ctx, int32_t source_id, int32_t slot);
+/* priority list + fallback of one variable (environment.py:592-595,782-791); NaN = no fallback */
+int odr_env_bind(odr_ctx *ctx, int32_t var_id, int nsources, const int32_t *source_ids,
+                 float fallback);
+
+/* ------------------------------------------------------------ hot-path stages */
+/* Environment.get_environment (environment.py:499-923): sample var_ids at the particles'
+ * (lon,lat,z) and time into the device environment (float32).  out_host[k] (optional)
+ * receives a copy.  Also records the sample positions as the "previous" state
+ * (update_previous_state, basemodel/__init__.py:642-668). */
+int odr_env_sample(odr_ctx *ctx, odr_particles *p, int nvars, const int32_t *var_ids,
+                   double t_epoch, float *const *out_host);
+int odr_env_download(odr_ctx *ctx, odr_particles *p, int32_t var_id, float *out_host);
+int odr_env_upload(odr_ctx *ctx, odr_particles *p, int32_t var_id, const float *host);
+/* drift:current_uncertainty / wind_uncertainty (environment.py:869-891): env[x]+=N(0,std), env[y]+=N(0,std) */
+int odr_env_add_noise(odr_ctx *ctx, odr_particles *p, int32_t var_x, int32_t var_y, double std,
+                      int rng_mode, const double *host_nx, const double *host_ny, uint64_t step);
+/* PhysicsMethods.advect_ocean_current (physics_methods.py:611-691) + update_positions
+ * (basemodel/__init__.py:4631-4657), all sub-stages fused in one kernel. */
+int odr_advect(odr_ctx *ctx, odr_particles *p, int scheme, double t_epoch, double dt, double factor);
+/* update_positions with caller-supplied velocities (models that compute them on the host) */
+int odr_update_positions(odr_ctx *ctx, odr_particles *p, const double *x_vel, const double *y_vel,
+                         int velocities_are_float32, double dt);
+/* advect_wind (physics_methods.py:712-791) */
+int odr_advect_wind(odr_ctx *ctx, odr_particles *p, double dt, double wind_drift_depth,
+                    int relative_wind, double factor);
+/* stokes_drift (physics_methods.py:793-848); profile 0 monochromatic, 1 exponential, 2 Phillips;
+ * hs_mode/tp_mode 0 environment, 1 from wind, 2 scalar default */
+int odr_stokes_drift(odr_ctx *ctx, odr_particles *p, double dt, int profile, int hs_mode,
+                     int tp_mode, double factor);
+/* horizontal_diffusion (basemodel/__init__.py:1746-1772) */
+int odr_hdiffusion(odr_ctx *ctx, odr_particles *p, double dt, int rng_mode,
+                   const double *host_nx, const double *host_ny, uint64_t step);
+/* OceanDrift.vertical_mixing (oceandrift.py:397-571), environment diffusivity profiles sampled at
+ * the positions of the last odr_env_sample; host_uniforms[i_sub*n + i] in ODR_RNG_HOST mode */
+int odr_vmix(odr_ctx *ctx, odr_particles *p, double t_epoch, double dt, double dt_mix,
+             int mix_at_surface, int rng_mode, const double *host_uniforms, uint64_t step);
+/* vertical_advection (oceandrift.py:315-350) / vertical_buoyancy (:352-368) */
+int odr_vertical_advection(odr_ctx *ctx, odr_particles *p, double dt, int at_surface);
+int odr_vertical_buoyancy(odr_ctx *ctx, odr_particles *p, double dt);
+/* interact_with_coastline (basemodel/__init__.py:670-746, approximation precision None) and
+ * interact_with_seafloor 'lift_to_seafloor' (:748-783) on the current environment */
+int odr_coastline(odr_ctx *ctx, odr_particles *p, int action, int stranded_code, int64_t *n_on_land);
+int odr_seafloor(odr_ctx *ctx, odr_particles *p, int64_t *n_below);
+/* deactivate elements flagged by the host (deactivate_elements, :1774-1795) */
+int odr_deactivate(odr_ctx *ctx, odr_particles *p, const uint8_t *mask_host, int32_t status_code);
+/* remove_deactivated_elements (:1797-1826) = LagrangianArray.move_elements (elements.py:197-228):
+ * stable compaction of status==0 elements, the rest appended to the deactivated store */
+int odr_compact(odr_ctx *ctx, odr_particles *p, int64_t *n_active);
+/* counts and min/max used for the per-step log line and early-outs (:2212-2233):
+ * out16 = {n_active, lon_min, lon_max, lat_min, lat_max, z_min, z_max, D_max, stokes_sum_max,
+ *          wind_speed_max, wdf_surface_max, n_surface, hs_max, tp_max, 0, 0} */
+int odr_reduce_scalars(odr_ctx *ctx, odr_particles *p, double wind_drift_depth, double *out16);
+
+/* kernel timing hook for bench.py: HIP events recorded on the context stream around the
+ * launches issued between begin and end; returns milliseconds */
+int odr_timer_begin(odr_ctx *ctx);
+int odr_timer_end(odr_ctx *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODRIFT_H */

@@ -1,0 +1,117 @@
+"""ctypes binding of libodrift_hip.so (include/odrift.h).  This is the stub a maintainer of the
+reference would add: plain pointers and sizes, no torch types.
+
+The product path fails loudly when the HIP library is missing -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libodrift_hip.so')
+
+NVAR = 16
+VARIABLES = {
+    'x_sea_water_velocity': 0, 'y_sea_water_velocity': 1, 'x_wind': 2, 'y_wind': 3,
+    'upward_sea_water_velocity': 4, 'ocean_vertical_diffusivity': 5,
+    'sea_surface_wave_stokes_drift_x_velocity': 6, 'sea_surface_wave_stokes_drift_y_velocity': 7,
+    'land_binary_mask': 8, 'sea_floor_depth_below_sea_level': 9, 'sea_surface_height': 10,
+    'horizontal_diffusivity': 11, 'sea_surface_wave_significant_height': 12,
+    'sea_surface_wave_period_at_variance_spectral_density_maximum': 13,
+    'ocean_mixed_layer_thickness': 14,
+}
+VARIABLE_NAMES = {v: k for k, v in VARIABLES.items()}
+PROJ_LATLONG, PROJ_STERE_EQUIT_SPHERE, PROJ_STERE_POLAR = 0, 1, 2
+SCHEME = {'euler': 0, 'runge-kutta': 1, 'runge-kutta4': 2}
+RNG_DEVICE, RNG_HOST = 0, 1
+COAST = {'none': 0, 'stranding': 1, 'previous': 2}
+ANALYTIC_DOUBLE_GYRE, ANALYTIC_OSCILLATING = 1, 2
+
+
+class ProjDesc(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('a', C.c_double), ('es', C.c_double), ('lat0_deg', C.c_double),
+                ('lon0_deg', C.c_double), ('lat_ts_deg', C.c_double), ('k0', C.c_double),
+                ('x0', C.c_double), ('y0', C.c_double)]
+
+
+class OdrError(RuntimeError):
+    pass
+
+
+_P = C.POINTER
+_dp, _fp, _ip, _i64p = _P(C.c_double), _P(C.c_float), _P(C.c_int32), _P(C.c_int64)
+_vp = C.c_void_p
+
+_SIGNATURES = {
+    'odr_ctx_create': [C.c_int, C.c_uint64, _P(_vp)],
+    'odr_ctx_destroy': [_vp],
+    'odr_sync': [_vp],
+    'odr_set_stream': [_vp, _vp],
+    'odr_particles_create': [_vp, C.c_int64, _P(_vp)],
+    'odr_particles_destroy': [_vp, _vp],
+    'odr_particles_append': [_vp, _vp, C.c_int64, _dp, _dp, _dp, _ip, _ip, _fp, _fp, _fp],
+    'odr_particles_count': [_vp, _vp, _i64p, _i64p],
+    'odr_particles_download': [_vp, _vp, _dp, _dp, _dp, _ip, _ip, _ip],
+    'odr_particles_download_deactivated': [_vp, _vp, _dp, _dp, _dp, _ip, _ip],
+    'odr_particles_upload': [_vp, _vp, _dp, _dp, _dp, _ip, _fp, _fp, _fp],
+    'odr_particles_device_ptr': [_vp, _vp, C.c_char_p, _P(_vp)],
+    'odr_source_constant': [_vp, C.c_int, _ip, _dp, _ip],
+    'odr_source_analytic': [_vp, C.c_int, _dp, C.c_int, _ip],
+    'odr_source_grid': [_vp, _P(ProjDesc), _dp, C.c_int, C.c_int, C.c_int, _dp, _ip],
+    'odr_block_upload': [_vp, C.c_int32, C.c_int32, C.c_double, C.c_int, _ip, _P(_fp), _ip, C.c_int,
+                         C.c_int, _dp],
+    'odr_block_upload_device': [_vp, C.c_int32, C.c_int32, C.c_double, C.c_int, _ip, _P(_vp), _ip,
+                                C.c_int, C.c_int, _dp],
+    'odr_block_drop': [_vp, C.c_int32, C.c_int32],
+    'odr_env_bind': [_vp, C.c_int32, C.c_int, _ip, C.c_float],
+    'odr_env_sample': [_vp, _vp, C.c_int, _ip, C.c_double, _P(_fp)],
+    'odr_env_download': [_vp, _vp, C.c_int32, _fp],
+    'odr_env_upload': [_vp, _vp, C.c_int32, _fp],
+    'odr_env_add_noise': [_vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_int, _dp, _dp, C.c_uint64],
+    'odr_advect': [_vp, _vp, C.c_int, C.c_double, C.c_double, C.c_double],
+    'odr_update_positions': [_vp, _vp, _dp, _dp, C.c_int, C.c_double],
+    'odr_advect_wind': [_vp, _vp, C.c_double, C.c_double, C.c_int, C.c_double],
+    'odr_stokes_drift': [_vp, _vp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double],
+    'odr_hdiffusion': [_vp, _vp, C.c_double, C.c_int, _dp, _dp, C.c_uint64],
+    'odr_vmix': [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _dp, C.c_uint64],
+    'odr_vertical_advection': [_vp, _vp, C.c_double, C.c_int],
+    'odr_vertical_buoyancy': [_vp, _vp, C.c_double],
+    'odr_coastline': [_vp, _vp, C.c_int, C.c_int, _i64p],
+    'odr_seafloor': [_vp, _vp, _i64p],
+    'odr_deactivate': [_vp, _vp, _P(C.c_uint8), C.c_int32],
+    'odr_compact': [_vp, _vp, _i64p],
+    'odr_reduce_scalars': [_vp, _vp, C.c_double, _dp],
+    'odr_timer_begin': [_vp],
+    'odr_timer_end': [_vp, _fp],
+}
+EXPORTS = sorted(list(_SIGNATURES) + ['odr_last_error', 'odr_version'])
+
+_lib = None
+
+
+def load():
+    """Load the shared library (no compute).  Raises OdrError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OdrError('libodrift_hip.so is missing: run `python -c "import __graft_entry__ as g; '
+                       'g.build()"` (hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.odr_last_error.restype = C.c_char_p
+    lib.odr_last_error.argtypes = []
+    lib.odr_version.restype = C.c_char_p
+    lib.odr_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().odr_last_error().decode()
+        if rc == -1:
+            raise ValueError(msg)
+        raise OdrError('odrift error %d: %s' % (rc, msg))

@@ -1,0 +1,372 @@
+// Device-side field sources: projections, analytic readers, gridded ReaderBlock
+// sampling (bilinear / nearest / z-lerp / time-lerp), vector rotation and the
+// Environment priority-list walk.  One call = what one particle receives from
+// Environment.get_environment (opendrift/models/basemodel/environment.py:499-923).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "odr_geodesic.hip.h"
+
+namespace odr {
+
+constexpr int NVAR = 16;
+constexpr int MAXLEVELS = 4;
+constexpr int MAXSRC = 8;
+constexpr int MAXNZ = 64;
+constexpr int MAXLIST = 4;
+
+enum { VAR_U = 0, VAR_V = 1, VAR_XWIND = 2, VAR_YWIND = 3, VAR_W = 4, VAR_KZ = 5, VAR_SX = 6,
+       VAR_SY = 7, VAR_LAND = 8, VAR_DEPTH = 9, VAR_SSH = 10, VAR_HDIFF = 11, VAR_HS = 12,
+       VAR_TP = 13, VAR_MLD = 14 };
+enum { SRC_CONSTANT = 0, SRC_DOUBLE_GYRE = 1, SRC_OSCILLATING = 2, SRC_GRID = 3 };
+enum { PROJ_LATLONG = 0, PROJ_STERE_EQUIT_SPHERE = 1, PROJ_STERE_POLAR = 2 };
+
+struct DevProj {
+  int kind, south;
+  double a, es, e, lon0, lat0, x0, y0, k0, akm1;
+};
+
+struct DevBlock {
+  int ny, nx, valid, pad;
+  double x0, xspan, y0, yspan;      // Linear2DInterpolator index map (interpolators.py:110-111)
+  double xmin, xrange, ymin, yrange;  // Nearest2DInterpolator index map (interpolators.py:32-37)
+  double t;
+  const float *data[NVAR];          // pre-dilated device arrays [var_nz, ny, nx]
+  int var_nz[NVAR];
+};
+
+struct DevSource {
+  int kind, lon_mode, mod360_x, nlevels, nz, always_valid;
+  DevProj proj;
+  double xmin, xmax, ymin, ymax, zmin, zmax;
+  double const_val[NVAR];
+  double params[8];
+  double z[MAXNZ];
+  int level_slot[MAXLEVELS];  // slots sorted by time
+  DevBlock slot[MAXLEVELS];
+};
+
+struct DevWorld {
+  int nsrc, pad;
+  int nlist[NVAR];
+  int list[NVAR][MAXLIST];
+  float fallback[NVAR];
+  DevSource src[MAXSRC];
+};
+
+static constexpr double kPi = 3.14159265358979323846264338327950288;
+static constexpr double kHalfPi = 1.57079632679489661923;
+
+__device__ __forceinline__ double np_mod(double x, double m) {  // numpy.mod
+  double r = fmod(x, m);
+  if (r != 0 && ((r < 0) != (m < 0))) r += m;
+  return r;
+}
+
+// ---------------------------------------------------------------- projections
+// pyproj.Proj forward / inverse for the reader projections on the path
+// (variables.py:111-143); formulas: Snyder PP1395 ch. 21.
+__device__ __forceinline__ double wrap_pi(double lam) {
+  if (fabs(lam) <= kPi + 1e-12) return lam;
+  lam += kPi;
+  lam -= 2 * kPi * floor(lam / (2 * kPi));
+  lam -= kPi;
+  return lam;
+}
+
+__device__ __forceinline__ double tsfn(double phi, double sinphi, double e) {
+  double es = e * sinphi;
+  return tan(0.5 * (kHalfPi - phi)) / pow((1 - es) / (1 + es), 0.5 * e);
+}
+
+__device__ __forceinline__ void proj_fwd(const DevProj &p, double lon_deg, double lat_deg,
+                                         double &x, double &y) {
+  if (p.kind == PROJ_LATLONG) { x = lon_deg; y = lat_deg; return; }
+  double lam = wrap_pi(lon_deg * kDeg - p.lon0), phi = lat_deg * kDeg;
+  double sinlam, coslam, sinphi, cosphi, X, Y;
+  sincos(lam, &sinlam, &coslam);
+  sincos(phi, &sinphi, &cosphi);
+  if (p.kind == PROJ_STERE_EQUIT_SPHERE) {
+    double k = p.akm1 / (1 + cosphi * coslam);
+    X = k * cosphi * sinlam;
+    Y = k * sinphi;
+  } else {
+    double rho;
+    if (p.south) { phi = -phi; coslam = -coslam; sinphi = -sinphi; }
+    if (p.es == 0) rho = p.akm1 * tan(0.5 * (kHalfPi - phi));
+    else rho = fabs(phi - kHalfPi) < 1e-15 ? 0.0 : p.akm1 * tsfn(phi, sinphi, p.e);
+    X = rho * sinlam;
+    Y = -rho * coslam;
+  }
+  x = p.a * X + p.x0;
+  y = p.a * Y + p.y0;
+}
+
+__device__ __forceinline__ void proj_inv(const DevProj &p, double x, double y, double &lon_deg,
+                                         double &lat_deg) {
+  if (p.kind == PROJ_LATLONG) { lon_deg = x; lat_deg = y; return; }
+  double X = (x - p.x0) / p.a, Y = (y - p.y0) / p.a;
+  double rh = hypot(X, Y), lam = 0, phi = 0;
+  if (p.kind == PROJ_STERE_EQUIT_SPHERE) {
+    double c = 2 * atan(rh / p.akm1), sinc, cosc;
+    sincos(c, &sinc, &cosc);
+    phi = fabs(rh) <= 1e-10 ? 0.0 : asin(Y * sinc / rh);
+    if (cosc != 0 || X != 0) lam = atan2(X * sinc, cosc * rh);
+  } else if (p.es == 0) {
+    double c = 2 * atan(rh / p.akm1), cosc = cos(c);
+    if (!p.south) Y = -Y;
+    phi = fabs(rh) <= 1e-10 ? p.lat0 : asin(p.south ? -cosc : cosc);
+    lam = (X == 0 && Y == 0) ? 0.0 : atan2(X, Y);
+  } else {
+    // conformal-latitude inverse, fixed-point iteration (contraction ~ e^2 per sweep)
+    double tp = rh / p.akm1, phi_l = kHalfPi - 2 * atan(tp), halfe = 0.5 * p.e;
+    if (!p.south) Y = -Y;
+#pragma unroll 1
+    for (int i = 0; i < 8; ++i) {
+      double es = p.e * sin(phi_l);
+      phi = kHalfPi - 2 * atan(tp * pow((1 - es) / (1 + es), halfe));
+      if (fabs(phi - phi_l) < 1e-15) break;
+      phi_l = phi;
+    }
+    if (p.south) phi = -phi;
+    lam = (X == 0 && Y == 0) ? 0.0 : atan2(X, Y);
+  }
+  lon_deg = wrap_pi(lam + p.lon0) / kDeg;
+  lat_deg = phi / kDeg;
+}
+
+// rotate_vectors (variables.py:59-109): azimuth of the reader's +y axis from a 10 m
+// finite difference, as the forward azimuth of the WGS84 geodesic between the two
+// points.  For a 10 m line the Gauss mid-latitude solution (azimuth at the mid point
+// minus half the meridian convergence) equals Karney's inverse to O((s/R)^3) ~ 1e-18 rad.
+__device__ __forceinline__ double rotation_angle(const DevProj &p, double x, double y) {
+  double lo1, la1, lo2, la2;
+  proj_inv(p, x, y, lo1, la1);
+  proj_inv(p, x, y + 10.0, lo2, la2);
+  const GeodConst &g = c_geod;
+  double phim = 0.5 * (la1 + la2) * kDeg, sphi, cphi;
+  sincos(phim, &sphi, &cphi);
+  double w2 = 1 - g.e2 * sphi * sphi, w = sqrt(w2);
+  double M = g.a * (1 - g.e2) / (w2 * w), N = g.a / w;
+  double dlam = ang_normalize(lo2 - lo1) * kDeg, dphi = (la2 - la1) * kDeg;
+  double az_mid = atan2(dlam * N * cphi, dphi * M);
+  double az1 = az_mid - 0.5 * dlam * sphi;
+  return -az1;  // rot_angle_rad = -rot_angle_vectors_rad
+}
+
+// ------------------------------------------------------ gridded block sampling
+// scipy.ndimage.map_coordinates(order=1) on a float32 layer that was pre-dilated 10x at
+// upload: coordinates are clamped (the reference's retry pass uses mode='nearest'), the
+// 2x2 footprint accumulates (v*wy)*wx in float64 in row-major order and rounds to float32.
+__device__ __forceinline__ float bilinear_f32(const float *__restrict__ a, int ny, int nx,
+                                              double yi, double xi) {
+  yi = fmin(fmax(yi, 0.0), (double)(ny - 1));
+  xi = fmin(fmax(xi, 0.0), (double)(nx - 1));
+  double fy = floor(yi), fx = floor(xi);
+  int y0 = (int)fy, x0 = (int)fx;
+  double ty = yi - fy, tx = xi - fx;
+  int y1 = y0 + 1 > ny - 1 ? (ny >= 2 ? ny - 2 : 0) : y0 + 1;  // index n mirrors to n-2 (weight 0)
+  int x1 = x0 + 1 > nx - 1 ? (nx >= 2 ? nx - 2 : 0) : x0 + 1;
+  const float *r0 = a + (size_t)y0 * nx, *r1 = a + (size_t)y1 * nx;
+  double v00 = r0[x0], v01 = r0[x1], v10 = r1[x0], v11 = r1[x1];
+  double wy0 = 1 - ty, wx0 = 1 - tx;
+  double t = __dmul_rn(__dmul_rn(v00, wy0), wx0);
+  t = __dadd_rn(t, __dmul_rn(__dmul_rn(v01, wy0), tx));
+  t = __dadd_rn(t, __dmul_rn(__dmul_rn(v10, ty), wx0));
+  t = __dadd_rn(t, __dmul_rn(__dmul_rn(v11, ty), tx));
+  return (float)t;
+}
+
+__device__ __forceinline__ int nearest_index(double v, double vmin, double vrange, int n) {
+  double r = rint((v - vmin) / vrange * n);
+  if (!(r >= 0) || r >= n) return n - 1;
+  return (int)r;
+}
+
+// Linear1DInterpolator (interpolators.py:174-197): scipy interp1d(zgrid -> index), int8 floor.
+__device__ __forceinline__ void zinterp(const double *zg, int nz, double z, int &ia, int &ib,
+                                        double &wa) {
+  bool asc = zg[1] > zg[0];
+  double zmin = asc ? zg[0] : zg[nz - 1], zmax = asc ? zg[nz - 1] : zg[0];
+  // zgrid.min()/max(): monotone grids only
+  z = z < zmin ? zmin : z;
+  z = z > zmax ? zmax : z;
+  int hi = 0;
+  while (hi < nz && (asc ? zg[hi] : zg[nz - 1 - hi]) < z) ++hi;
+  hi = hi < 1 ? 1 : hi;
+  hi = hi > nz - 1 ? nz - 1 : hi;
+  int lo = hi - 1;
+  double xl = asc ? zg[lo] : zg[nz - 1 - lo], xh = asc ? zg[hi] : zg[nz - 1 - hi];
+  double yl = asc ? lo : nz - 1 - lo, yh = asc ? hi : nz - 1 - hi;
+  double slope = __ddiv_rn(yh - yl, xh - xl);
+  double zi = __dadd_rn(__dmul_rn(slope, z - xl), yl);
+  ia = (int)(signed char)(long long)floor(zi);
+  ia = ia < 0 ? 0 : ia;
+  ib = ia + 1 < nz - 1 ? ia + 1 : nz - 1;
+  wa = 1 - (zi - ia);
+}
+
+// value of one variable from one block; f32class = the reference hands back float32 (2D layer)
+__device__ __forceinline__ double block_value(const DevBlock &b, const DevSource &s, int var,
+                                              double x, double y, double z, bool &f32class) {
+  const float *d = b.data[var];
+  if (var == VAR_LAND) {
+    f32class = true;
+    int xi = nearest_index(x, b.xmin, b.xrange, b.nx);
+    int yi = nearest_index(y, b.ymin, b.yrange, b.ny);
+    return d[(size_t)yi * b.nx + xi];
+  }
+  double xi = __dmul_rn(__ddiv_rn(x - b.x0, b.xspan), (double)(b.nx - 1));
+  double yi = __dmul_rn(__ddiv_rn(y - b.y0, b.yspan), (double)(b.ny - 1));
+  int nzv = b.var_nz[var];
+  if (nzv <= 1) {
+    f32class = true;
+    return bilinear_f32(d, b.ny, b.nx, yi, xi);
+  }
+  f32class = false;
+  int ia, ib;
+  double wa;
+  zinterp(s.z, s.nz, z, ia, ib, wa);
+  size_t plane = (size_t)b.ny * b.nx;
+  double va = bilinear_f32(d + plane * ia, b.ny, b.nx, yi, xi);
+  double vb = bilinear_f32(d + plane * ib, b.ny, b.nx, yi, xi);
+  return __dadd_rn(__dmul_rn(va, wa), __dmul_rn(vb, 1 - wa));
+}
+
+// time bracket on the resident levels: nearest_time (variables.py:402-443)
+__device__ __forceinline__ void bracket(const DevSource &s, double t, int &ib, int &ia) {
+  int b = 0;
+  for (int k = 0; k < s.nlevels; ++k)
+    if (s.slot[s.level_slot[k]].t <= t) b = k;
+  ib = s.level_slot[b];
+  ia = (b + 1 < s.nlevels && s.slot[ib].t != t) ? s.level_slot[b + 1] : -1;
+}
+
+// One reader.get_variables_interpolated (variables.py:860-920) for one particle and the
+// NV variables of a group.  Returns false when the reader does not cover the position.
+template <int NV>
+__device__ __forceinline__ bool source_sample(const DevSource &s, const int (&vars)[NV], double lon,
+                                              double lat, double z, double t, double (&val)[NV]) {
+  if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
+  else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
+  double x, y;
+  proj_fwd(s.proj, lon, lat, x, y);
+  double xchk = x;
+  if (s.proj.kind == PROJ_LATLONG) {
+    if (s.lon_mode == 1) xchk = np_mod(x + 180.0, 360.0) - 180.0;
+    else if (s.lon_mode == 2) xchk = np_mod(x, 360.0);
+  }
+  if (!(xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin &&
+        z <= s.zmax))
+    return false;
+  if (s.kind == SRC_CONSTANT) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) val[v] = s.const_val[vars[v]];
+  } else if (s.kind == SRC_OSCILLATING) {
+    double phase = ((t - s.params[3]) / s.params[2]) * kPi;
+    double value = s.params[1] * sin(phase);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) val[v] = value;
+  } else if (s.kind == SRC_DOUBLE_GYRE) {
+    // reader_double_gyre.get_variables (reader_double_gyre.py:55-79)
+    double A = s.params[0], eps = s.params[1], om = s.params[2], tt = t - s.params[3];
+    double sn = sin(om * tt);
+    double a = eps * sn, b = 1 - 2 * eps * sn;
+    double f = a * x * x + b * x, dfdx = 2 * a * x + b;
+    double sf, cf, sy, cy;
+    sincos(kPi * f, &sf, &cf);
+    sincos(kPi * y, &sy, &cy);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (vars[v] == VAR_U) val[v] = -kPi * A * sf * cy;
+      else if (vars[v] == VAR_V) val[v] = kPi * A * cf * sy * dfdx;
+      else val[v] = 0.0;
+    }
+  } else {
+    // StructuredReader._get_variables_interpolated_ (structured.py:202-400)
+    if (s.mod360_x) x = np_mod(x, 360.0);
+    int ib, ia;
+    bracket(s, t, ib, ia);
+    bool all_static = true;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+      if (vars[v] != VAR_LAND && vars[v] != VAR_DEPTH) all_static = false;
+    if (all_static || s.always_valid) ia = -1;
+    const DevBlock &bb = s.slot[ib];
+    if (ia < 0) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        bool f32c;
+        val[v] = block_value(bb, s, vars[v], x, y, z, f32c);
+      }
+    } else {
+      const DevBlock &ba = s.slot[ia];
+      double w = __ddiv_rn(t - bb.t, ba.t - bb.t);  // structured.py:353-354
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        bool fb, fa;
+        double vb = block_value(bb, s, vars[v], x, y, z, fb);
+        double va = block_value(ba, s, vars[v], x, y, z, fa);
+        if (fb && fa) {  // float32 arrays * python floats stay float32 (:362-364)
+          float pq = __fadd_rn(__fmul_rn((float)vb, (float)(1 - w)), __fmul_rn((float)va, (float)w));
+          val[v] = pq;
+        } else {
+          val[v] = __dadd_rn(__dmul_rn(vb, 1 - w), __dmul_rn(va, w));
+        }
+      }
+    }
+  }
+  // rotate x/y vector pairs to the lon/lat CRS (variables.py:799-837)
+  if (s.proj.kind != PROJ_LATLONG) {
+    bool need = false;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+      if (vars[v] == VAR_U || vars[v] == VAR_XWIND || vars[v] == VAR_SX) need = true;
+    if (need) {
+      double rot = rotation_angle(s.proj, x, y), sn, cs;
+      sincos(rot, &sn, &cs);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        int partner = vars[v] == VAR_U ? VAR_V : vars[v] == VAR_XWIND ? VAR_YWIND
+                                              : vars[v] == VAR_SX ? VAR_SY : -1;
+        if (partner < 0) continue;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+          if (vars[u] != partner) continue;
+          double uu = val[v], vv = val[u];
+          val[v] = __dsub_rn(__dmul_rn(uu, cs), __dmul_rn(vv, sn));
+          val[u] = __dadd_rn(__dmul_rn(uu, sn), __dmul_rn(vv, cs));
+        }
+      }
+    }
+  }
+  return true;
+}
+
+// Environment.get_environment for one particle and one variable group (variables that
+// share a priority list): walk the readers until every variable is finite
+// (environment.py:597-762), then the fallback (:782-791).  out = float32 environment.
+template <int NV>
+__device__ __forceinline__ void env_group(const DevWorld &W, const int (&vars)[NV], double lon,
+                                          double lat, double z, double t, float (&out)[NV]) {
+#pragma unroll
+  for (int v = 0; v < NV; ++v) out[v] = W.fallback[vars[v]];
+  int nl = W.nlist[vars[0]];
+  for (int k = 0; k < nl; ++k) {
+    const DevSource &s = W.src[W.list[vars[0]][k]];
+    double val[NV];
+    bool covered = source_sample<NV>(s, vars, lon, lat, z, t, val);
+    bool bad = !covered;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      float f = covered ? (float)val[v] : __builtin_nanf("");
+      out[v] = f;  // masked_invalid(...).astype('float32') overwrites every group variable
+      if (!isfinite(f)) bad = true;
+    }
+    if (!bad) break;
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+    if (!isfinite(out[v]) && isfinite(W.fallback[vars[v]])) out[v] = W.fallback[vars[v]];
+}
+
+}  // namespace odr

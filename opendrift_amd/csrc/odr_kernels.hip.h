@@ -1,0 +1,695 @@
+// HIP kernels of the particle-advection hot path (gfx950 / MI355X).
+//
+// Layout: structure-of-arrays particle state resident in HBM, one thread per
+// particle, 256-thread workgroups (4 waves of 64), every state array read and
+// written fully coalesced (8 B or 4 B per lane).  Field blocks are read through
+// the vector L1 / per-XCD L2 / Infinity Cache; the 2x2(x2z x2t) footprints of a
+// wave's particles land on few cache lines when the particles are spatially
+// coherent.  No MFMA: the path is gather + f64 scalar math.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocrand/rocrand_kernel.h>
+#include "odr_field.hip.h"
+
+namespace odr {
+
+constexpr int BLOCK = 256;
+
+struct PView {  // device pointers of the active set
+  long long n;
+  double *lon, *lat, *z, *plon, *plat;
+  int *id, *status, *moving;
+  float *wdf, *cdf, *tv;
+  float *env[NVAR];
+};
+
+// ------------------------------------------------------------ float32 rounding points
+// np.degrees(np.arctan2(x_vel, y_vel)) in float32 (physics_methods.py:629,
+// basemodel/__init__.py:4645): correctly rounded float32 arctan2,
+// times float32(180)/float32(pi) exactly as NumPy's float32 degrees loop does.
+__device__ __forceinline__ float azimuth_f32(float xv, float yv) {
+  float a = (float)atan2((double)xv, (double)yv);
+  return __fmul_rn(a, 180.0f / 3.14159274101257324f);
+}
+__device__ __forceinline__ float speed_f32(float xv, float yv) {
+  return __fsqrt_rn(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)));
+}
+
+// update_positions (basemodel/__init__.py:4631-4657), float32 velocities
+__device__ __forceinline__ void move_f32(double &lon, double &lat, float u, float v, int moving,
+                                         double dt) {
+  float az = azimuth_f32(u, v);
+  double vel = (double)speed_f32(u, v) * (double)moving;  // f32 * int32 array -> float64
+  double lo, la;
+  geod_direct(lat, lon, (double)az, vel * dt, la, lo);
+  lon = lo;
+  lat = la;
+}
+// float64 velocities (advect_wind / stokes_drift / horizontal_diffusion callers)
+__device__ __forceinline__ void move_f64(double &lon, double &lat, double u, double v, int moving,
+                                         double dt) {
+  double az = atan2(u, v) * (180.0 / kPi);
+  double vel = sqrt(__dadd_rn(__dmul_rn(u, u), __dmul_rn(v, v))) * (double)moving;
+  double lo, la;
+  geod_direct(lat, lon, az, vel * dt, la, lo);
+  lon = lo;
+  lat = la;
+}
+
+// RK sub-stage position: geod.fwd(lon, lat, az, speed*dt*.5) with dist in float32
+// (physics_methods.py:629-635)
+__device__ __forceinline__ void stage_pos(double lon, double lat, float u, float v, float dtf,
+                                          double &lon2, double &lat2) {
+  float az = azimuth_f32(u, v);
+  float dist = __fmul_rn(__fmul_rn(speed_f32(u, v), dtf), 0.5f);
+  geod_direct(lat, lon, (double)az, (double)dist, lat2, lon2);
+}
+
+// ------------------------------------------------------------------ environment
+// Environment.get_environment for one variable group of NV variables
+template <int NV>
+struct GroupVars { int v[NV]; };
+
+template <int NV>
+__global__ __launch_bounds__(BLOCK) void k_env_group(const DevWorld *__restrict__ W, PView p,
+                                                     GroupVars<NV> gv, double t, int record_prev) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  int vars[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) vars[k] = gv.v[k];
+  double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
+  float out[NV];
+  env_group<NV>(*W, vars, lon, lat, z, t, out);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) p.env[vars[k]][i] = out[k];
+  if (record_prev) { p.plon[i] = lon; p.plat[i] = lat; }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_fill_f32(float *a, long long n, float v) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n) a[i] = v;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_record_prev(PView p) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < p.n) { p.plon[i] = p.lon[i]; p.plat[i] = p.lat[i]; }
+}
+
+// --------------------------------------------------------------------- advection
+// PhysicsMethods.advect_ocean_current (physics_methods.py:611-691) with every RK
+// sub-stage -- geodesic to the stage position, reader front door, block gathers,
+// time/z interpolation, vector rotation, float32 environment cast -- fused in one
+// kernel; the particle never leaves registers between stages.
+template <int SCHEME>
+__global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W, PView p, double t,
+                                                  double dt, float factor) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  const int uv[2] = {VAR_U, VAR_V};
+  double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
+  float u1 = p.env[VAR_U][i], v1 = p.env[VAR_V][i];
+  float f = __fmul_rn(factor, p.cdf[i]);  // factor*cdf, float32
+  int moving = p.moving[i];
+  float fu, fv;
+  if (SCHEME == 0) {
+    fu = __fmul_rn(f, u1);
+    fv = __fmul_rn(f, v1);
+  } else {
+    float dtf = (float)dt;
+    double lon2, lat2;
+    float k2[2];
+    stage_pos(lon, lat, u1, v1, dtf, lon2, lat2);
+    env_group<2>(*W, uv, lon2, lat2, z, t + dt / 2, k2);
+    if (SCHEME == 1) {
+      fu = __fmul_rn(f, k2[0]);
+      fv = __fmul_rn(f, k2[1]);
+    } else {
+      float k3[2], k4[2];
+      stage_pos(lon, lat, k2[0], k2[1], dtf, lon2, lat2);
+      env_group<2>(*W, uv, lon2, lat2, z, t + dt / 2, k3);
+      stage_pos(lon, lat, k3[0], k3[1], dtf, lon2, lat2);  // dt*.5 again: reference quirk (:662)
+      env_group<2>(*W, uv, lon2, lat2, z, t + dt, k4);
+      // (x_vel + 2*x_vel2 + 2*x_vel3 + x_vel4)/6.0 in float32, left to right (:674-675)
+      float su = __fadd_rn(u1, __fmul_rn(2.0f, k2[0]));
+      float sv = __fadd_rn(v1, __fmul_rn(2.0f, k2[1]));
+      su = __fadd_rn(su, __fmul_rn(2.0f, k3[0]));
+      sv = __fadd_rn(sv, __fmul_rn(2.0f, k3[1]));
+      su = __fadd_rn(su, k4[0]);
+      sv = __fadd_rn(sv, k4[1]);
+      su = __fdiv_rn(su, 6.0f);
+      sv = __fdiv_rn(sv, 6.0f);
+      fu = __fmul_rn(su, f);
+      fv = __fmul_rn(sv, f);
+    }
+  }
+  move_f32(lon, lat, fu, fv, moving, dt);
+  p.lon[i] = lon;
+  p.lat[i] = lat;
+}
+
+// update_positions with velocities supplied by the caller
+__global__ __launch_bounds__(BLOCK) void k_update_positions(PView p, const double *u, const double *v,
+                                                            int is_f32, double dt) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  double lon = p.lon[i], lat = p.lat[i];
+  if (is_f32) move_f32(lon, lat, (float)u[i], (float)v[i], p.moving[i], dt);
+  else move_f64(lon, lat, u[i], v[i], p.moving[i], dt);
+  p.lon[i] = lon;
+  p.lat[i] = lat;
+}
+
+// -------------------------------------------------------------------- reductions
+// red[] slots
+enum { R_NACT = 0, R_LONMIN, R_LONMAX, R_LATMIN, R_LATMAX, R_ZMIN, R_ZMAX, R_DMAX, R_STOKESMAX,
+       R_WSPEEDMAX, R_WDFMAX, R_NSURF, R_HSMAX, R_TPMAX, R_RELWSPEEDMAX, R_SPARE, R_N };
+
+__device__ __forceinline__ void atomic_max_d(double *addr, double v) {
+  unsigned long long *a = (unsigned long long *)addr, old = *a, assumed;
+  do {
+    assumed = old;
+    if (__longlong_as_double((long long)assumed) >= v) break;
+    old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
+  } while (assumed != old);
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// min is stored as max of the negated value; red must be pre-filled with -inf (sums with 0)
+__global__ __launch_bounds__(BLOCK) void k_reduce(PView p, double wind_drift_depth, int relative_wind,
+                                                  double *red) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  const double ninf = -__builtin_inf();
+  double v[R_N];
+#pragma unroll
+  for (int k = 0; k < R_N; ++k) v[k] = ninf;
+  v[R_NACT] = 0;
+  v[R_NSURF] = 0;
+  if (i < p.n) {
+    double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
+    v[R_NACT] = 1;
+    v[R_LONMIN] = -lon; v[R_LONMAX] = lon; v[R_LATMIN] = -lat; v[R_LATMAX] = lat;
+    v[R_ZMIN] = -z; v[R_ZMAX] = z;
+    if (p.env[VAR_HDIFF]) v[R_DMAX] = p.env[VAR_HDIFF][i];
+    if (p.env[VAR_SX] && p.env[VAR_SY]) v[R_STOKESMAX] = __fadd_rn(p.env[VAR_SX][i], p.env[VAR_SY][i]);
+    if (p.env[VAR_HS]) v[R_HSMAX] = p.env[VAR_HS][i];
+    if (p.env[VAR_TP]) v[R_TPMAX] = p.env[VAR_TP][i];
+    if (p.env[VAR_XWIND] && p.env[VAR_YWIND]) {
+      // advect_wind bookkeeping (physics_methods.py:738-775)
+      double wdd = fabs(wind_drift_depth);
+      bool surf = z >= -wdd;
+      if (surf) {
+        float xw = p.env[VAR_XWIND][i], yw = p.env[VAR_YWIND][i];
+        double wdf = p.wdf[i];
+        if (wind_drift_depth != 0) {
+          wdf = wdf * (wdd + z) / wdd;
+          if (z > 0) wdf = p.wdf[i];
+        }
+        v[R_NSURF] = 1;
+        v[R_WDFMAX] = wdf;
+        v[R_WSPEEDMAX] = speed_f32(xw, yw);
+        if (relative_wind && p.env[VAR_U]) {
+          xw = __fsub_rn(xw, p.env[VAR_U][i]);
+          yw = __fsub_rn(yw, p.env[VAR_V][i]);
+        }
+        v[R_RELWSPEEDMAX] = speed_f32(xw, yw);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < R_N; ++k) {
+    bool is_sum = (k == R_NACT || k == R_NSURF);
+    double r = is_sum ? wave_sum(v[k]) : wave_max(v[k]);
+    if ((threadIdx.x & 63) == 0) {
+      if (is_sum) { if (r != 0) atomicAdd(&red[k], r); }
+      else if (r > ninf) atomic_max_d(&red[k], r);
+    }
+  }
+}
+
+__global__ void k_red_init(double *red) {
+  int k = threadIdx.x;
+  if (k < R_N) red[k] = (k == R_NACT || k == R_NSURF) ? 0.0 : -__builtin_inf();
+}
+
+// ------------------------------------------------------------------- wind / Stokes
+// advect_wind (physics_methods.py:712-791).  red[] carries the global early-out tests.
+__global__ __launch_bounds__(BLOCK) void k_advect_wind(PView p, double dt, double wind_drift_depth,
+                                                       int relative_wind, double factor,
+                                                       const double *__restrict__ red) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  if (red[R_NSURF] == 0 || red[R_WDFMAX] == 0 || red[R_RELWSPEEDMAX] == 0) return;  // :741-747, :775-780
+  double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
+  double wdd = fabs(wind_drift_depth);
+  bool surf = z >= -wdd;
+  double wdf = p.wdf[i];
+  if (wind_drift_depth != 0) {
+    wdf = wdf * (wdd + z) / wdd;  // float64 (:756)
+    if (z > 0) wdf = p.wdf[i];
+  }
+  if (!surf) wdf = 0.0;
+  float xw = p.env[VAR_XWIND][i], yw = p.env[VAR_YWIND][i];
+  if (relative_wind) {
+    xw = __fsub_rn(xw, p.env[VAR_U][i]);
+    yw = __fsub_rn(yw, p.env[VAR_V][i]);
+  }
+  double xu = __dmul_rn(__dmul_rn((double)xw, wdf), factor);
+  double xv = __dmul_rn(__dmul_rn((double)yw, wdf), factor);
+  move_f64(lon, lat, xu, xv, p.moving[i], dt);
+  p.lon[i] = lon;
+  p.lat[i] = lat;
+}
+
+// NumPy dtype classes of a stokes-profile operand: python scalar (weak), float32, float64
+struct TVal { double v; int k; };
+__device__ __forceinline__ TVal tv_(double v, int k) { TVal r; r.v = v; r.k = k; return r; }
+__device__ __forceinline__ TVal tmul(TVal a, TVal b) {
+  TVal r; r.k = a.k > b.k ? a.k : b.k;
+  r.v = r.k == 1 ? (double)__fmul_rn((float)a.v, (float)b.v) : __dmul_rn(a.v, b.v);
+  return r;
+}
+__device__ __forceinline__ TVal tdiv(TVal a, TVal b) {
+  TVal r; r.k = a.k > b.k ? a.k : b.k;
+  r.v = r.k == 1 ? (double)__fdiv_rn((float)a.v, (float)b.v) : __ddiv_rn(a.v, b.v);
+  return r;
+}
+
+// stokes_drift (physics_methods.py:793-848) with the Breivik profiles (:336-416)
+__global__ __launch_bounds__(BLOCK) void k_stokes(PView p, double dt, int profile, int hs_mode,
+                                                  int tp_mode, double factor,
+                                                  const double *__restrict__ red) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  if (red[R_STOKESMAX] == 0) return;  // "No Stokes drift velocity available" (:799-804)
+  double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
+  float sx = p.env[VAR_SX][i], sy = p.env[VAR_SY][i];
+  float speed = speed_f32(sx, sy);
+  float ws = 0.f;
+  if (hs_mode == 1 || tp_mode == 1) ws = speed_f32(p.env[VAR_XWIND][i], p.env[VAR_YWIND][i]);
+  TVal H, T;
+  if (hs_mode == 0) H = tv_(p.env[VAR_HS][i], 1);
+  else if (hs_mode == 1) H = tv_(__fmul_rn((float)0.0246, __fmul_rn(ws, ws)), 1);
+  else H = tv_(1, 0);
+  if (tp_mode == 0) T = tv_(p.env[VAR_TP][i], 1);
+  else if (tp_mode == 1) {
+    double omega = 5;
+    if (ws > 0) omega = __fdiv_rn((float)(0.877 * 9.81), __fmul_rn((float)1.17, ws));
+    T = tv_(__ddiv_rn(2 * kPi, omega), 2);
+  } else T = tv_(8, 0);
+  TVal mwf = tdiv(tv_(2. * kPi, 0), T);
+  TVal transport = tdiv(tmul(mwf, tmul(H, H)), tv_(16, 0));
+  TVal num = tv_(speed, 1);
+  if (profile == 2) num = tmul(num, tv_(1 - 2 * 1.0 / 3, 0));
+  TVal km = tdiv(num, tmul(tv_(2, 0), transport));
+  double az = fabs(z), unit;
+  if (profile == 0) unit = exp(__dmul_rn(tmul(tv_(2, 0), km).v, z));
+  else if (profile == 1) {
+    TVal ke = tdiv(km, tv_(3, 0));
+    unit = exp(__dmul_rn(tmul(tv_(2.0, 0), ke).v, z)) / (1.0 - __dmul_rn(tmul(tv_(8.0, 0), ke).v, z));
+  } else {
+    double k2 = tmul(tv_(2, 0), km).v, c2 = tmul(tv_(2 * kPi, 0), km).v;
+    unit = __dsub_rn(exp(__dmul_rn(k2, z)),
+                     __dmul_rn(sqrt(__dmul_rn(c2, az)), erfc(sqrt(__dmul_rn(k2, az)))));
+  }
+  double su = speed == 0 ? 0.0 : __dmul_rn(__dmul_rn((double)sx, unit), factor);
+  double sv = speed == 0 ? 0.0 : __dmul_rn(__dmul_rn((double)sy, unit), factor);
+  move_f64(lon, lat, su, sv, p.moving[i], dt);
+  p.lon[i] = lon;
+  p.lat[i] = lat;
+}
+
+// --------------------------------------------------------------- random numbers
+// Philox4x32-10 (rocRAND device API), counter = (particle ID, step, stream): results do
+// not depend on how particles are sharded over GPUs or ordered in memory.
+constexpr unsigned long long RNG_STEP_STRIDE = 8192;
+constexpr unsigned long long RNG_OFF_VMIX = 0, RNG_OFF_HDIFF = 4096, RNG_OFF_NOISE = 4352;
+
+__device__ __forceinline__ void rng_init(rocrand_state_philox4x32_10 &st, unsigned long long seed,
+                                         int id, unsigned long long step, unsigned long long off) {
+  rocrand_init(seed, (unsigned long long)(unsigned)id, step * RNG_STEP_STRIDE + off, &st);
+}
+
+// horizontal_diffusion (basemodel/__init__.py:1746-1772)
+__global__ __launch_bounds__(BLOCK) void k_hdiff(PView p, double dt, int rng_mode,
+                                                 const double *__restrict__ hnx,
+                                                 const double *__restrict__ hny,
+                                                 unsigned long long seed, unsigned long long step,
+                                                 const double *__restrict__ red) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  if (red[R_DMAX] == 0) return;  // "Horizontal diffusivity is 0, no random walk." (:1754)
+  double lon = p.lon[i], lat = p.lat[i];
+  double nx, ny;
+  if (rng_mode == 1) { nx = hnx[i]; ny = hny[i]; }
+  else {
+    rocrand_state_philox4x32_10 st;
+    rng_init(st, seed, p.id[i], step, RNG_OFF_HDIFF);
+    double2 g = rocrand_normal_double2(&st);
+    nx = g.x; ny = g.y;
+  }
+  float s = __fsqrt_rn(__fdiv_rn(__fmul_rn(2.0f, p.env[VAR_HDIFF][i]), (float)fabs(dt)));
+  int moving = p.moving[i];
+  double xu = __dmul_rn(__dmul_rn((double)moving, (double)s), nx);
+  double xv = __dmul_rn(__dmul_rn((double)moving, (double)s), ny);
+  move_f64(lon, lat, xu, xv, moving, dt);
+  p.lon[i] = lon;
+  p.lat[i] = lat;
+}
+
+// drift:current_uncertainty / wind_uncertainty (environment.py:869-891)
+__global__ __launch_bounds__(BLOCK) void k_env_noise(PView p, int vx, int vy, double std, int rng_mode,
+                                                     const double *__restrict__ hnx,
+                                                     const double *__restrict__ hny,
+                                                     unsigned long long seed, unsigned long long step) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  double nx, ny;
+  if (rng_mode == 1) { nx = hnx[i]; ny = hny[i]; }  // np.random.normal(0, std, N) already scaled
+  else {
+    rocrand_state_philox4x32_10 st;
+    rng_init(st, seed, p.id[i], step, RNG_OFF_NOISE + 4ull * (unsigned)vx);
+    double2 g = rocrand_normal_double2(&st);
+    nx = g.x * std; ny = g.y * std;
+  }
+  // float32 array += float64 array: computed in float64, cast back to float32
+  p.env[vx][i] = (float)__dadd_rn((double)p.env[vx][i], nx);
+  p.env[vy][i] = (float)__dadd_rn((double)p.env[vy][i], ny);
+}
+
+// ---------------------------------------------------------------- vertical mixing
+// OceanDrift.vertical_mixing (oceandrift.py:397-571), diffusivity model 'environment'.
+// The diffusivity profile of each particle (all block levels at the position of the last
+// environment sample, time-interpolated in float64: structured.py:366-385) is gathered
+// once into LDS ([level][thread]: bank = thread, conflict free for per-thread dynamic level
+// indices) and the whole ntimes_mix random walk runs out of registers + LDS.
+__global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, PView p, double t,
+                                                double dt, double dt_mix_cfg, int mix_at_surface,
+                                                int rng_mode, const double *__restrict__ huni,
+                                                unsigned long long seed, unsigned long long step) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *Kp = (double *)smem;  // [nzp][BLOCK]
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  const int tid = threadIdx.x;
+  // K source: first GRID reader of the priority list, else fallback (2 levels [0, -profiles_depth])
+  const DevSource *src = nullptr;
+  for (int k = 0; k < W->nlist[VAR_KZ]; ++k) {
+    const DevSource &s = W->src[W->list[VAR_KZ][k]];
+    if (s.kind == SRC_GRID) { src = &s; break; }
+  }
+  const int nzp = src ? (src->nz > 1 ? src->nz : 1) : 1;
+  const float Kfb = W->fallback[VAR_KZ];
+  bool active = i < p.n;
+  if (active) {
+    bool cov = false;
+    double xi = 0, yi = 0, wgt = 0;
+    int ib = 0, ia = -1;
+    if (src) {
+      double lon = p.plon[i], lat = p.plat[i], x, y;
+      if (src->lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
+      else if (src->lon_mode == 2) lon = np_mod(lon, 360.0);
+      proj_fwd(src->proj, lon, lat, x, y);
+      cov = x >= src->xmin && x <= src->xmax && y >= src->ymin && y <= src->ymax;
+      if (src->mod360_x) x = np_mod(x, 360.0);
+      bracket(*src, t, ib, ia);
+      const DevBlock &bb = src->slot[ib];
+      xi = __dmul_rn(__ddiv_rn(x - bb.x0, bb.xspan), (double)(bb.nx - 1));
+      yi = __dmul_rn(__ddiv_rn(y - bb.y0, bb.yspan), (double)(bb.ny - 1));
+      if (ia >= 0) wgt = __ddiv_rn(t - bb.t, src->slot[ia].t - bb.t);
+    }
+    for (int k = 0; k < nzp; ++k) {
+      double val = Kfb;
+      if (src && cov) {
+        const DevBlock &bb = src->slot[ib];
+        size_t plane = (size_t)bb.ny * bb.nx;
+        double v0 = bilinear_f32(bb.data[VAR_KZ] + plane * k, bb.ny, bb.nx, yi, xi), vv;
+        if (ia >= 0) {
+          const DevBlock &ba = src->slot[ia];
+          double v1 = bilinear_f32(ba.data[VAR_KZ] + plane * k, ba.ny, ba.nx, yi, xi);
+          vv = __dadd_rn(__dmul_rn(v0, 1 - wgt), __dmul_rn(v1, wgt));
+        } else vv = v0;
+        if (isfinite(vv)) val = vv;
+      }
+      Kp[k * BLOCK + tid] = val;
+    }
+  }
+  if (!active) return;  // no barrier needed: every thread touches only its own LDS column
+  const double *zp = src ? src->z : nullptr;
+  const double sgn = dt > 0 ? 1.0 : (dt < 0 ? -1.0 : 0.0);
+  const double dt_mix = dt_mix_cfg * sgn;
+  const int ntimes = abs((int)(dt / dt_mix));
+  const double r = 1.0 / 3;
+  double z = p.z[i];
+  const int moving = p.moving[i];
+  const float Zmin = __fmul_rn(-1.f, __fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH][i]));  // float32 (:408)
+  const double wstep = (double)__fmul_rn(p.tv[i], (float)dt_mix) * (double)moving;
+  const bool uniform_z = [&] {
+    if (nzp < 3) return true;
+    for (int k = 1; k < nzp - 1; ++k)
+      if ((zp[k + 1] - zp[k]) != (zp[1] - zp[0])) return false;
+    return true;
+  }();
+  rocrand_state_philox4x32_10 st;
+  if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
+  for (int it = 0; it < ntimes; ++it) {
+    const bool surface = z == 0;
+    // z_index = interp1d(-mixing_z, range, bounds_error=False, fill_value=(0, nz-1)) (:485-488)
+    double d = -z, idx;
+    if (nzp == 1) idx = 0;
+    else if (d < -zp[0]) idx = 0;
+    else if (d > -zp[nzp - 1]) idx = nzp - 1;
+    else {
+      int hi = 0;
+      while (hi < nzp && -zp[hi] < d) ++hi;
+      hi = hi < 1 ? 1 : (hi > nzp - 1 ? nzp - 1 : hi);
+      double xl = -zp[hi - 1], xh = -zp[hi];
+      idx = __dadd_rn(__dmul_rn(__ddiv_rn(1.0, xh - xl), d - xl), (double)(hi - 1));
+    }
+    const int zi = (int)(unsigned short)(long long)rint(idx);  // np.round(..).astype(np.uint16)
+    const double Kz = Kp[zi * BLOCK + tid];
+    // dK/dz = -np.gradient(Kprofiles, mixing_z, axis=0)[zi], |.|<1e-10 -> 0 (:501-502)
+    double gK = 0;
+    if (nzp >= 2) {
+      if (zi == 0) gK = __ddiv_rn(Kp[BLOCK + tid] - Kp[tid], zp[1] - zp[0]);
+      else if (zi == nzp - 1)
+        gK = __ddiv_rn(Kp[(nzp - 1) * BLOCK + tid] - Kp[(nzp - 2) * BLOCK + tid], zp[nzp - 1] - zp[nzp - 2]);
+      else if (uniform_z)
+        gK = __ddiv_rn(Kp[(zi + 1) * BLOCK + tid] - Kp[(zi - 1) * BLOCK + tid], __dmul_rn(2., zp[1] - zp[0]));
+      else {
+        double dx1 = zp[zi] - zp[zi - 1], dx2 = zp[zi + 1] - zp[zi];
+        double a = __ddiv_rn(-dx2, __dmul_rn(dx1, dx1 + dx2));
+        double b = __ddiv_rn(dx2 - dx1, __dmul_rn(dx1, dx2));
+        double c = __ddiv_rn(dx1, __dmul_rn(dx2, dx1 + dx2));
+        gK = __dadd_rn(__dadd_rn(__dmul_rn(a, Kp[(zi - 1) * BLOCK + tid]), __dmul_rn(b, Kz)),
+                       __dmul_rn(c, Kp[(zi + 1) * BLOCK + tid]));
+      }
+    }
+    double dK = -gK;
+    if (fabs(dK) < 1e-10) dK = 0;
+    double u01 = rng_mode == 1 ? huni[(size_t)it * p.n + i] : rocrand_uniform_double(&st);
+    double R = __dsub_rn(__dmul_rn(2.0, u01), 1.0);
+    // z - moving*(dKdz*dt_mix - R*sqrt(Kz*|dt_mix|*2/r)) (:527-528)
+    double rw = __dmul_rn(R, sqrt(__ddiv_rn(__dmul_rn(__dmul_rn(Kz, fabs(dt_mix)), 2.0), r)));
+    z = __dsub_rn(z, __dmul_rn((double)moving, __dsub_rn(__dmul_rn(dK, dt_mix), rw)));
+    if (z >= 0) z = -z;                                                       // reflect from surface
+    if (z < (double)Zmin && moving == 1) z = __dsub_rn((double)__fmul_rn(2.f, Zmin), z);  // reflect from seafloor
+    z = __dadd_rn(z, wstep);                                                  // buoyancy
+    if (!mix_at_surface && surface) z = 0.0;
+    if (z > 0) z = 0.0;                                                       // surface_stick
+    if (z < (double)Zmin) z = (double)Zmin;                                   // lift_to_seafloor
+  }
+  p.z[i] = z;
+}
+
+// vertical_advection (oceandrift.py:315-350)
+__global__ __launch_bounds__(BLOCK) void k_vadvect(PView p, double dt, int at_surface) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  double z = p.z[i];
+  if (at_surface ? z <= 0 : z < 0) {
+    double zz = __dadd_rn(z, __dmul_rn(__dmul_rn((double)p.moving[i], (double)p.env[VAR_W][i]), dt));
+    p.z[i] = zz < 0 ? zz : 0.0;
+  }
+}
+
+// vertical_buoyancy (oceandrift.py:352-368) with lift_to_seafloor
+__global__ __launch_bounds__(BLOCK) void k_vbuoy(PView p, double dt) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  double z = p.z[i];
+  if (z < 0) {
+    double zz = __dadd_rn(z, (double)__fmul_rn(p.tv[i], (float)dt));
+    z = zz < 0 ? zz : 0.0;
+  }
+  float Zmin = __fmul_rn(-1.f, __fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH][i]));
+  if (z < (double)Zmin) z = (double)Zmin;
+  p.z[i] = z;
+}
+
+// ------------------------------------------------------------ coastline / seafloor
+// interact_with_coastline (basemodel/__init__.py:670-746), precision None
+__global__ __launch_bounds__(BLOCK) void k_coast(PView p, int action, int code,
+                                                 unsigned long long *n_hit) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  bool hit = false;
+  if (i < p.n && p.env[VAR_LAND][i] == 1.0f) {
+    hit = true;
+    if (action == 1) {
+      if (p.z[i] <= 0) {  // deactivate_elements(reason='stranded') (:1774-1795)
+        if (p.status[i] == 0) p.status[i] = code;
+        p.moving[i] = 0;
+      }
+    } else if (action == 2) {
+      p.lon[i] = p.plon[i];
+      p.lat[i] = p.plat[i];
+    }
+  }
+  unsigned long long b = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_hit, (unsigned long long)__popcll(b));
+}
+
+// interact_with_seafloor 'lift_to_seafloor' (:748-783)
+__global__ __launch_bounds__(BLOCK) void k_seafloor(PView p, unsigned long long *n_hit) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  bool hit = false;
+  if (i < p.n) {
+    float floorz = -__fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH] ? p.env[VAR_SSH][i] : 0.f);
+    if (p.z[i] < (double)floorz) { p.z[i] = (double)floorz; hit = true; }
+  }
+  unsigned long long b = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_hit, (unsigned long long)__popcll(b));
+}
+
+__global__ __launch_bounds__(BLOCK) void k_deactivate(PView p, const unsigned char *mask, int code) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n || !mask[i]) return;
+  if (p.status[i] == 0) p.status[i] = code;
+  p.moving[i] = 0;
+}
+
+// ------------------------------------------------------- stable stream compaction
+// remove_deactivated_elements = LagrangianArray.move_elements (elements.py:197-228):
+// order-preserving partition.  Pass 1 counts actives per 256-block, pass 2 scans the
+// block counts (single workgroup), pass 3 scatters every property.
+__global__ __launch_bounds__(BLOCK) void k_cmp_count(const int *status, long long n, unsigned *bcount) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  bool keep = i < n && status[i] == 0;
+  unsigned long long b = __ballot(keep);
+  __shared__ unsigned wc[BLOCK / 64];
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = (unsigned)__popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) bcount[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+__global__ __launch_bounds__(1024) void k_cmp_scan(unsigned *bcount, long long nblocks,
+                                                   unsigned long long *total) {
+  __shared__ unsigned long long part[1024];
+  const int tid = threadIdx.x;
+  long long per = (nblocks + 1023) / 1024, lo = tid * per, hi = lo + per < nblocks ? lo + per : nblocks;
+  unsigned long long s = 0;
+  for (long long k = lo; k < hi; ++k) s += bcount[k];
+  part[tid] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+    unsigned long long v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  unsigned long long run = tid ? part[tid - 1] : 0;
+  for (long long k = lo; k < hi; ++k) { unsigned c = bcount[k]; bcount[k] = (unsigned)run; run += c; }
+  if (tid == 1023) *total = part[1023];
+}
+
+struct CmpArrays {
+  int n64, n32;
+  const double *src64[8]; double *dst64[8]; double *dead64[8];
+  const int *src32[32];   int *dst32[32];   int *dead32[32];
+};
+
+__global__ __launch_bounds__(BLOCK) void k_cmp_scatter(const int *status, long long n,
+                                                       const unsigned *boff, CmpArrays A,
+                                                       long long dead_base) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  bool valid = i < n, keep = valid && status[i] == 0;
+  unsigned long long b = __ballot(keep);
+  __shared__ unsigned wc[BLOCK / 64];
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) wc[w] = (unsigned)__popcll(b);
+  __syncthreads();
+  unsigned before = 0;
+  for (int k = 0; k < w; ++k) before += wc[k];
+  unsigned rank_keep = boff[blockIdx.x] + before + (unsigned)__popcll(b & ((1ull << lane) - 1));
+  if (!valid) return;
+  // rank among the removed = i - (number kept before i)
+  long long kept_before = (long long)boff[blockIdx.x] + before + __popcll(b & ((1ull << lane) - 1));
+  long long dst = keep ? (long long)rank_keep : dead_base + (i - kept_before);
+  for (int k = 0; k < A.n64; ++k) {
+    double v = A.src64[k][i];
+    if (keep) A.dst64[k][dst] = v; else if (A.dead64[k]) A.dead64[k][dst] = v;
+  }
+  for (int k = 0; k < A.n32; ++k) {
+    int v = A.src32[k][i];
+    if (keep) A.dst32[k][dst] = v; else if (A.dead32[k]) A.dead32[k][dst] = v;
+  }
+}
+
+// ---------------------------------------------------------------- block preparation
+// ReaderBlock.__init__ (interpolation/structured.py:50-63): mask non-finite and |v|>1e9
+__global__ __launch_bounds__(BLOCK) void k_blk_mask(float *a, size_t n) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  float v = a[i];
+  if (!isfinite(v) || v < -1e9f || v > 1e9f) a[i] = __builtin_nanf("");
+}
+// fill_NaN_towards_seafloor (interpolators.py:203-211): layer k <- layer k-1, sequential in k
+__global__ __launch_bounds__(BLOCK) void k_blk_fill_seafloor(float *a, int nz, size_t plane) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= plane) return;
+  float prev = a[i];
+  for (int k = 1; k < nz; ++k) {
+    float v = a[k * plane + i];
+    if (isnan(v)) { v = prev; a[k * plane + i] = v; }
+    prev = v;
+  }
+}
+// expand_numpy_array (interpolators.py:9-20): one grey_dilation(size=3) of the NaN cells,
+// src -> dst, all layers of a variable in one launch.  any_finite[layer] guards the
+// reference's "Only NaNs, returning".
+__global__ __launch_bounds__(BLOCK) void k_blk_dilate(const float *__restrict__ src, float *__restrict__ dst,
+                                                      int nz, int ny, int nx) {
+  size_t plane = (size_t)ny * nx, i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= plane * nz) return;
+  size_t rem = i % plane;
+  int y = (int)(rem / nx), x = (int)(rem % nx);
+  const float *s = src + (i - rem);
+  float v = src[i];
+  if (!isfinite(v)) {
+    float best = 0;
+    bool have = false;
+    for (int dy = -1; dy <= 1; ++dy) {
+      int yy = y + dy;
+      if (yy < 0 || yy >= ny) continue;
+      for (int dx = -1; dx <= 1; ++dx) {
+        int xx = x + dx;
+        if (xx < 0 || xx >= nx) continue;
+        float c = s[(size_t)yy * nx + xx];
+        if (isfinite(c) && (!have || c > best)) { best = c; have = true; }
+      }
+    }
+    v = have ? best : __builtin_nanf("");
+  }
+  dst[i] = v;
+}
+
+}  // namespace odr

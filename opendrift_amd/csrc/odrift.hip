@@ -1,0 +1,862 @@
+// libodrift_hip.so -- host side of the C ABI declared in include/odrift.h.
+// One context = one HIP stream + the device image of the Environment (field sources,
+// priority lists) ; one particle set = SoA arrays in HBM.  Everything is launched on the
+// context stream; only calls that hand data back to the host synchronise.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/odrift.h"
+#include "odr_kernels.hip.h"
+
+using namespace odr;
+
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(x)                                                                          \
+  do {                                                                                     \
+    hipError_t e_ = (x);                                                                   \
+    if (e_ != hipSuccess) return fail(ODR_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_));   \
+  } while (0)
+#define REQUIRE(c, ...) do { if (!(c)) return fail(ODR_ERR_INVALID, __VA_ARGS__); } while (0)
+
+struct odr_ctx {
+  int device;
+  unsigned long long seed;
+  hipStream_t stream, own_stream;
+  DevWorld hw;      // host image
+  DevWorld *dw;     // device image
+  bool dirty;
+  std::vector<void *> block_bufs[MAXSRC][MAXLEVELS];  // owned device arrays per slot
+  double *red;      // device reduction slots
+  unsigned long long *counter;
+  hipEvent_t ev0, ev1;
+  int nsrc;
+};
+
+struct odr_particles {
+  long long cap, n, ndead, dead_cap;
+  double *d64[5];       // lon lat z plon plat
+  double *alt64[5];
+  int *i32[3];          // id status moving
+  int *alti32[3];
+  float *f32[3];        // wdf cdf tv
+  float *altf32[3];
+  float *env[NVAR];
+  float *altenv[NVAR];
+  double *dead64[3];    // lon lat z of the deactivated store
+  int *deadi32[2];      // id status
+  unsigned *bcount;
+  void *scratch;
+  size_t scratch_bytes;
+};
+
+static inline unsigned nblk(long long n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+static PView view(const odr_particles *p) {
+  PView v;
+  v.n = p->n;
+  v.lon = p->d64[0]; v.lat = p->d64[1]; v.z = p->d64[2]; v.plon = p->d64[3]; v.plat = p->d64[4];
+  v.id = p->i32[0]; v.status = p->i32[1]; v.moving = p->i32[2];
+  v.wdf = p->f32[0]; v.cdf = p->f32[1]; v.tv = p->f32[2];
+  for (int k = 0; k < NVAR; ++k) v.env[k] = p->env[k];
+  return v;
+}
+
+static int flush_world(odr_ctx *c) {
+  if (c->dirty) {
+    HIPCHK(hipMemcpyAsync(c->dw, &c->hw, sizeof(DevWorld), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // hw is pageable and may change right after
+    c->dirty = false;
+  }
+  return 0;
+}
+
+static int ensure_env(odr_ctx *c, odr_particles *p, int var) {
+  if (!p->env[var]) {
+    HIPCHK(hipMalloc((void **)&p->env[var], sizeof(float) * (size_t)p->cap));
+    HIPCHK(hipMemsetAsync(p->env[var], 0, sizeof(float) * (size_t)p->cap, c->stream));
+  }
+  return 0;
+}
+
+static int scratch(odr_ctx *c, odr_particles *p, size_t bytes, void **out) {
+  if (p->scratch_bytes < bytes) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (p->scratch) HIPCHK(hipFree(p->scratch));
+    HIPCHK(hipMalloc(&p->scratch, bytes));
+    p->scratch_bytes = bytes;
+  }
+  *out = p->scratch;
+  return 0;
+}
+
+const char *odr_last_error(void) { return g_err.c_str(); }
+const char *odr_version(void) { return "odrift-hip 0.1 (gfx950)"; }
+
+static void geod_consts(GeodConst &g) {
+  // WGS84 (pyproj.Geod(ellps='WGS84')); A3/C3 coefficient polynomials in n, Karney (2013) eqs. 24-25
+  g.a = 6378137.0;
+  g.f = 1 / 298.257223563;
+  g.f1 = 1 - g.f;
+  g.e2 = g.f * (2 - g.f);
+  g.ep2 = g.e2 / (g.f1 * g.f1);
+  g.n = g.f / (2 - g.f);
+  g.b = g.a * g.f1;
+  const double n = g.n;
+  g.A3x[0] = -3.0 / 128;
+  g.A3x[1] = (-2 * n - 3) / 64;
+  g.A3x[2] = ((-n - 3) * n - 1) / 16;
+  g.A3x[3] = ((3 * n - 1) * n - 2) / 8;
+  g.A3x[4] = (n - 1) / 2;
+  g.A3x[5] = 1;
+  double *c = g.C3x;
+  c[0] = 3.0 / 128;              c[1] = (2 * n + 5) / 128;        c[2] = ((-n + 3) * n + 3) / 64;
+  c[3] = ((-n + 0) * n + 1) / 8; c[4] = (-n + 1) / 4;
+  c[5] = 5.0 / 256;              c[6] = (n + 3) / 128;            c[7] = ((-3 * n - 2) * n + 3) / 64;
+  c[8] = ((n - 3) * n + 2) / 32;
+  c[9] = 7.0 / 512;              c[10] = (-10 * n + 9) / 384;     c[11] = ((5 * n - 9) * n + 5) / 192;
+  c[12] = 7.0 / 512;             c[13] = (-14 * n + 7) / 512;
+  c[14] = 21.0 / 2560;
+}
+
+int odr_ctx_create(int device, uint64_t seed, odr_ctx **out) {
+  REQUIRE(out, "out is NULL");
+  HIPCHK(hipSetDevice(device));
+  odr_ctx *c = new odr_ctx();
+  c->device = device;
+  c->seed = seed;
+  HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  memset(&c->hw, 0, sizeof(DevWorld));
+  for (int v = 0; v < NVAR; ++v) c->hw.fallback[v] = NAN;
+  HIPCHK(hipMalloc((void **)&c->dw, sizeof(DevWorld)));
+  HIPCHK(hipMalloc((void **)&c->red, sizeof(double) * R_N));
+  HIPCHK(hipMalloc((void **)&c->counter, sizeof(unsigned long long) * 4));
+  HIPCHK(hipEventCreate(&c->ev0));
+  HIPCHK(hipEventCreate(&c->ev1));
+  c->dirty = true;
+  c->nsrc = 0;
+  GeodConst g;
+  geod_consts(g);
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_geod), &g, sizeof(GeodConst)));
+  *out = c;
+  return 0;
+}
+
+int odr_ctx_destroy(odr_ctx *c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (int s = 0; s < MAXSRC; ++s)
+    for (int l = 0; l < MAXLEVELS; ++l)
+      for (void *b : c->block_bufs[s][l]) (void)hipFree(b);
+  (void)hipFree(c->dw);
+  (void)hipFree(c->red);
+  (void)hipFree(c->counter);
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return 0;
+}
+
+int odr_sync(odr_ctx *c) {
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int odr_set_stream(odr_ctx *c, void *s) {
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return 0;
+}
+
+int odr_timer_begin(odr_ctx *c) {
+  HIPCHK(hipEventRecord(c->ev0, c->stream));
+  return 0;
+}
+int odr_timer_end(odr_ctx *c, float *ms) {
+  HIPCHK(hipEventRecord(c->ev1, c->stream));
+  HIPCHK(hipEventSynchronize(c->ev1));
+  HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return 0;
+}
+
+// ------------------------------------------------------------------ particles
+int odr_particles_create(odr_ctx *c, int64_t capacity, odr_particles **out) {
+  REQUIRE(capacity > 0 && out, "capacity must be positive");
+  HIPCHK(hipSetDevice(c->device));
+  odr_particles *p = new odr_particles();
+  memset(p, 0, sizeof(*p));
+  p->cap = capacity;
+  p->dead_cap = capacity;
+  for (int k = 0; k < 5; ++k) HIPCHK(hipMalloc((void **)&p->d64[k], sizeof(double) * (size_t)capacity));
+  for (int k = 0; k < 3; ++k) HIPCHK(hipMalloc((void **)&p->i32[k], sizeof(int) * (size_t)capacity));
+  for (int k = 0; k < 3; ++k) HIPCHK(hipMalloc((void **)&p->f32[k], sizeof(float) * (size_t)capacity));
+  HIPCHK(hipMalloc((void **)&p->bcount, sizeof(unsigned) * (size_t)(nblk(capacity) + 1)));
+  *out = p;
+  return 0;
+}
+
+int odr_particles_destroy(odr_ctx *c, odr_particles *p) {
+  if (!p) return 0;
+  (void)hipStreamSynchronize(c->stream);
+  auto fr = [](void *q) { if (q) (void)hipFree(q); };
+  for (int k = 0; k < 5; ++k) { fr(p->d64[k]); fr(p->alt64[k]); }
+  for (int k = 0; k < 3; ++k) { fr(p->i32[k]); fr(p->f32[k]); fr(p->alti32[k]); fr(p->altf32[k]); fr(p->dead64[k]); }
+  for (int k = 0; k < 2; ++k) fr(p->deadi32[k]);
+  for (int k = 0; k < NVAR; ++k) { fr(p->env[k]); fr(p->altenv[k]); }
+  fr(p->bcount);
+  fr(p->scratch);
+  delete p;
+  return 0;
+}
+
+template <class T>
+static int put(odr_ctx *c, T *dst, const T *src, long long n, T dflt) {
+  if (src) {
+    HIPCHK(hipMemcpyAsync(dst, src, sizeof(T) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  } else {
+    std::vector<T> tmp((size_t)n, dflt);
+    HIPCHK(hipMemcpyAsync(dst, tmp.data(), sizeof(T) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
+int odr_particles_append(odr_ctx *c, odr_particles *p, int64_t n, const double *lon, const double *lat,
+                         const double *z, const int32_t *id, const int32_t *moving, const float *wdf,
+                         const float *cdf, const float *tv) {
+  REQUIRE(n >= 0 && lon && lat, "lon/lat required");
+  if (p->n + n > p->cap) return fail(ODR_ERR_CAPACITY, "capacity %lld exceeded (%lld + %lld)", p->cap, p->n, (long long)n);
+  if (n == 0) return 0;
+  long long o = p->n;
+  int rc;
+  if ((rc = put<double>(c, p->d64[0] + o, lon, n, 0.0))) return rc;
+  if ((rc = put<double>(c, p->d64[1] + o, lat, n, 0.0))) return rc;
+  if ((rc = put<double>(c, p->d64[2] + o, z, n, 0.0))) return rc;
+  if ((rc = put<double>(c, p->d64[3] + o, lon, n, 0.0))) return rc;
+  if ((rc = put<double>(c, p->d64[4] + o, lat, n, 0.0))) return rc;
+  if (id) { if ((rc = put<int>(c, p->i32[0] + o, id, n, 0))) return rc; }
+  else {
+    std::vector<int> ids((size_t)n);
+    for (long long k = 0; k < n; ++k) ids[(size_t)k] = (int)(o + p->ndead + k);
+    HIPCHK(hipMemcpyAsync(p->i32[0] + o, ids.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  if ((rc = put<int>(c, p->i32[1] + o, nullptr, n, 0))) return rc;
+  if ((rc = put<int>(c, p->i32[2] + o, moving, n, 1))) return rc;
+  if ((rc = put<float>(c, p->f32[0] + o, wdf, n, 0.02f))) return rc;
+  if ((rc = put<float>(c, p->f32[1] + o, cdf, n, 1.0f))) return rc;
+  if ((rc = put<float>(c, p->f32[2] + o, tv, n, 0.0f))) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  p->n += n;
+  return 0;
+}
+
+int odr_particles_count(odr_ctx *, odr_particles *p, int64_t *na, int64_t *nd) {
+  if (na) *na = p->n;
+  if (nd) *nd = p->ndead;
+  return 0;
+}
+
+template <class T>
+static int get(odr_ctx *c, T *dst, const T *src, long long n) {
+  if (dst && n > 0) HIPCHK(hipMemcpyAsync(dst, src, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  return 0;
+}
+
+int odr_particles_download(odr_ctx *c, odr_particles *p, double *lon, double *lat, double *z, int32_t *id,
+                           int32_t *status, int32_t *moving) {
+  int rc;
+  if ((rc = get(c, lon, p->d64[0], p->n)) || (rc = get(c, lat, p->d64[1], p->n)) ||
+      (rc = get(c, z, p->d64[2], p->n)) || (rc = get(c, id, p->i32[0], p->n)) ||
+      (rc = get(c, status, p->i32[1], p->n)) || (rc = get(c, moving, p->i32[2], p->n)))
+    return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int odr_particles_download_deactivated(odr_ctx *c, odr_particles *p, double *lon, double *lat, double *z,
+                                       int32_t *id, int32_t *status) {
+  if (p->ndead == 0) return 0;
+  int rc;
+  if ((rc = get(c, lon, p->dead64[0], p->ndead)) || (rc = get(c, lat, p->dead64[1], p->ndead)) ||
+      (rc = get(c, z, p->dead64[2], p->ndead)) || (rc = get(c, id, p->deadi32[0], p->ndead)) ||
+      (rc = get(c, status, p->deadi32[1], p->ndead)))
+    return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int odr_particles_upload(odr_ctx *c, odr_particles *p, const double *lon, const double *lat, const double *z,
+                         const int32_t *moving, const float *wdf, const float *cdf, const float *tv) {
+  size_t n = (size_t)p->n;
+  if (lon) HIPCHK(hipMemcpyAsync(p->d64[0], lon, 8 * n, hipMemcpyHostToDevice, c->stream));
+  if (lat) HIPCHK(hipMemcpyAsync(p->d64[1], lat, 8 * n, hipMemcpyHostToDevice, c->stream));
+  if (z) HIPCHK(hipMemcpyAsync(p->d64[2], z, 8 * n, hipMemcpyHostToDevice, c->stream));
+  if (moving) HIPCHK(hipMemcpyAsync(p->i32[2], moving, 4 * n, hipMemcpyHostToDevice, c->stream));
+  if (wdf) HIPCHK(hipMemcpyAsync(p->f32[0], wdf, 4 * n, hipMemcpyHostToDevice, c->stream));
+  if (cdf) HIPCHK(hipMemcpyAsync(p->f32[1], cdf, 4 * n, hipMemcpyHostToDevice, c->stream));
+  if (tv) HIPCHK(hipMemcpyAsync(p->f32[2], tv, 4 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int odr_particles_device_ptr(odr_ctx *c, odr_particles *p, const char *name, void **dptr) {
+  REQUIRE(name && dptr, "name/dptr NULL");
+  static const char *n64[5] = {"lon", "lat", "z", "plon", "plat"};
+  static const char *n32[3] = {"id", "status", "moving"};
+  for (int k = 0; k < 5; ++k) if (!strcmp(name, n64[k])) { *dptr = p->d64[k]; return 0; }
+  for (int k = 0; k < 3; ++k) if (!strcmp(name, n32[k])) { *dptr = p->i32[k]; return 0; }
+  if (!strncmp(name, "env:", 4)) {
+    int v = atoi(name + 4);
+    REQUIRE(v >= 0 && v < NVAR, "bad variable id");
+    int rc = ensure_env(c, p, v);
+    if (rc) return rc;
+    *dptr = p->env[v];
+    return 0;
+  }
+  return fail(ODR_ERR_INVALID, "unknown array '%s'", name);
+}
+
+// --------------------------------------------------------------------- sources
+static void proj_init(DevProj &p, const odr_proj_desc *d) {
+  memset(&p, 0, sizeof p);
+  if (!d) { p.kind = PROJ_LATLONG; p.a = 1; p.k0 = 1; return; }
+  p.kind = d->kind;
+  p.a = d->a;
+  p.es = d->es;
+  p.e = sqrt(d->es);
+  p.lon0 = d->lon0_deg * kDeg;
+  p.lat0 = d->lat0_deg * kDeg;
+  p.x0 = d->x0;
+  p.y0 = d->y0;
+  p.k0 = d->k0;
+  p.south = d->lat0_deg < 0;
+  p.akm1 = 2 * d->k0;
+  if (d->kind == PROJ_STERE_POLAR) {  // Snyder 21-33/21-34 scale constant
+    double phits = fabs(d->lat_ts_deg) * kDeg, e = p.e;
+    if (d->es == 0) {
+      p.akm1 = fabs(phits - kHalfPi) >= 1e-10 ? cos(phits) / tan(0.5 * (kHalfPi - phits)) : 2 * d->k0;
+    } else if (fabs(phits - kHalfPi) < 1e-10) {
+      p.akm1 = 2 * d->k0 / sqrt(pow(1 + e, 1 + e) * pow(1 - e, 1 - e));
+    } else {
+      double t = sin(phits), es = e * t;
+      double ts = tan(0.5 * (kHalfPi - phits)) / pow((1 - es) / (1 + es), 0.5 * e);
+      p.akm1 = cos(phits) / ts;
+      t *= e;
+      p.akm1 /= sqrt(1 - t * t);
+    }
+  }
+}
+
+static int new_source(odr_ctx *c, int kind, int32_t *sid) {
+  if (c->nsrc >= MAXSRC) return fail(ODR_ERR_CAPACITY, "at most %d field sources", MAXSRC);
+  DevSource &s = c->hw.src[c->nsrc];
+  memset(&s, 0, sizeof s);
+  s.kind = kind;
+  proj_init(s.proj, nullptr);
+  s.xmin = -180; s.xmax = 180; s.ymin = -90; s.ymax = 90;
+  s.zmin = -INFINITY; s.zmax = INFINITY;
+  s.lon_mode = 1;
+  *sid = c->nsrc++;
+  c->hw.nsrc = c->nsrc;
+  c->dirty = true;
+  return 0;
+}
+
+int odr_source_constant(odr_ctx *c, int nvars, const int32_t *var_ids, const double *values, int32_t *sid) {
+  REQUIRE(nvars > 0 && var_ids && values && sid, "bad arguments");
+  int rc = new_source(c, SRC_CONSTANT, sid);
+  if (rc) return rc;
+  DevSource &s = c->hw.src[*sid];
+  for (int k = 0; k < nvars; ++k) {
+    REQUIRE(var_ids[k] >= 0 && var_ids[k] < NVAR, "bad variable id %d", var_ids[k]);
+    s.const_val[var_ids[k]] = values[k];
+  }
+  return 0;
+}
+
+int odr_source_analytic(odr_ctx *c, int kind, const double *params, int nparams, int32_t *sid) {
+  REQUIRE(params && nparams >= 4 && nparams <= 8 && sid, "bad arguments");
+  REQUIRE(kind == ODR_ANALYTIC_DOUBLE_GYRE || kind == ODR_ANALYTIC_OSCILLATING, "unknown analytic kind %d", kind);
+  int rc = new_source(c, kind == ODR_ANALYTIC_DOUBLE_GYRE ? SRC_DOUBLE_GYRE : SRC_OSCILLATING, sid);
+  if (rc) return rc;
+  DevSource &s = c->hw.src[*sid];
+  for (int k = 0; k < nparams; ++k) s.params[k] = params[k];
+  if (kind == ODR_ANALYTIC_DOUBLE_GYRE) {
+    // reader_double_gyre.py:28-41: +proj=stere +lat_0=0 +lon_0=0 +lat_ts=0 +a=6.371e6 +e=0, x in [0,2], y in [0,1]
+    odr_proj_desc d = {ODR_PROJ_STERE_EQUIT_SPHERE, 6.371e6, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0};
+    proj_init(s.proj, &d);
+    s.xmin = 0; s.xmax = 2; s.ymin = 0; s.ymax = 1;
+    s.lon_mode = 2;
+  }
+  return 0;
+}
+
+int odr_source_grid(odr_ctx *c, const odr_proj_desc *proj, const double *dom, int lon_mode, int mod360_x,
+                    int nz, const double *z, int32_t *sid) {
+  REQUIRE(dom && sid, "bad arguments");
+  REQUIRE(nz <= MAXNZ, "at most %d z levels", MAXNZ);
+  int rc = new_source(c, SRC_GRID, sid);
+  if (rc) return rc;
+  DevSource &s = c->hw.src[*sid];
+  proj_init(s.proj, proj);
+  s.xmin = dom[0]; s.xmax = dom[1]; s.ymin = dom[2]; s.ymax = dom[3]; s.zmin = dom[4]; s.zmax = dom[5];
+  s.lon_mode = lon_mode;
+  s.mod360_x = mod360_x;
+  s.nz = (nz > 1 && z) ? nz : 1;
+  for (int k = 0; k < s.nz && z; ++k) s.z[k] = z[k];
+  return 0;
+}
+
+static void sort_levels(DevSource &s) {
+  s.nlevels = 0;
+  for (int l = 0; l < MAXLEVELS; ++l) if (s.slot[l].valid) s.level_slot[s.nlevels++] = l;
+  for (int a = 1; a < s.nlevels; ++a)
+    for (int b = a; b > 0 && s.slot[s.level_slot[b]].t < s.slot[s.level_slot[b - 1]].t; --b) {
+      int t = s.level_slot[b]; s.level_slot[b] = s.level_slot[b - 1]; s.level_slot[b - 1] = t;
+    }
+}
+
+static int block_upload(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, int nvars, const int32_t *var_ids,
+                        const void *const *data, bool on_device, const int32_t *var_nz, int ny, int nx,
+                        const double *xy8) {
+  REQUIRE(sid >= 0 && sid < c->nsrc && c->hw.src[sid].kind == SRC_GRID, "source %d is not a grid source", sid);
+  REQUIRE(slot >= 0 && slot < MAXLEVELS, "slot must be in [0,%d)", MAXLEVELS);
+  REQUIRE(nvars > 0 && var_ids && data && var_nz && xy8 && ny > 1 && nx > 1, "bad block arguments");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  DevSource &s = c->hw.src[sid];
+  for (void *b : c->block_bufs[sid][slot]) HIPCHK(hipFree(b));
+  c->block_bufs[sid][slot].clear();
+  DevBlock &b = s.slot[slot];
+  memset(&b, 0, sizeof b);
+  b.ny = ny; b.nx = nx; b.valid = 1;
+  b.x0 = xy8[0]; b.xspan = xy8[1]; b.y0 = xy8[2]; b.yspan = xy8[3];
+  b.xmin = xy8[4]; b.xrange = xy8[5]; b.ymin = xy8[6]; b.yrange = xy8[7];
+  b.t = t_epoch;
+  size_t plane = (size_t)ny * nx;
+  for (int k = 0; k < nvars; ++k) {
+    int v = var_ids[k], nzv = var_nz[k] > 1 ? var_nz[k] : 1;
+    REQUIRE(v >= 0 && v < NVAR, "bad variable id %d", v);
+    REQUIRE(nzv == 1 || nzv == s.nz, "variable %d has %d levels, source has %d", v, nzv, s.nz);
+    size_t n = plane * nzv;
+    float *buf, *tmp;
+    HIPCHK(hipMalloc((void **)&buf, sizeof(float) * n));
+    HIPCHK(hipMalloc((void **)&tmp, sizeof(float) * n));
+    HIPCHK(hipMemcpyAsync(buf, data[k], sizeof(float) * n, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                          c->stream));
+    unsigned g = (unsigned)((n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_blk_mask, dim3(g), dim3(BLOCK), 0, c->stream, buf, n);
+    if (nzv > 1)
+      hipLaunchKernelGGL(k_blk_fill_seafloor, dim3((unsigned)((plane + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,
+                         c->stream, buf, nzv, plane);
+    if (v != VAR_LAND) {
+      // the reference dilates on demand, <=10 sweeps per interpolator call (interpolators.py:127-137);
+      // 10 sweeps up front give identical samples
+      float *a = buf, *bb2 = tmp;
+      for (int it = 0; it < 10; ++it) {
+        hipLaunchKernelGGL(k_blk_dilate, dim3(g), dim3(BLOCK), 0, c->stream, a, bb2, nzv, ny, nx);
+        float *t2 = a; a = bb2; bb2 = t2;
+      }
+      // 10 swaps -> result is back in buf
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(tmp));
+    b.data[v] = buf;
+    b.var_nz[v] = nzv;
+    c->block_bufs[sid][slot].push_back(buf);
+  }
+  sort_levels(s);
+  c->dirty = true;
+  return 0;
+}
+
+int odr_block_upload(odr_ctx *c, int32_t sid, int32_t slot, double t, int nvars, const int32_t *var_ids,
+                     const float *const *data, const int32_t *var_nz, int ny, int nx, const double *xy8) {
+  return block_upload(c, sid, slot, t, nvars, var_ids, (const void *const *)data, false, var_nz, ny, nx, xy8);
+}
+int odr_block_upload_device(odr_ctx *c, int32_t sid, int32_t slot, double t, int nvars, const int32_t *var_ids,
+                            const void *const *dev_data, const int32_t *var_nz, int ny, int nx, const double *xy8) {
+  return block_upload(c, sid, slot, t, nvars, var_ids, dev_data, true, var_nz, ny, nx, xy8);
+}
+
+int odr_block_drop(odr_ctx *c, int32_t sid, int32_t slot) {
+  REQUIRE(sid >= 0 && sid < c->nsrc && slot >= 0 && slot < MAXLEVELS, "bad source/slot");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (void *b : c->block_bufs[sid][slot]) HIPCHK(hipFree(b));
+  c->block_bufs[sid][slot].clear();
+  memset(&c->hw.src[sid].slot[slot], 0, sizeof(DevBlock));
+  sort_levels(c->hw.src[sid]);
+  c->dirty = true;
+  return 0;
+}
+
+int odr_env_bind(odr_ctx *c, int32_t var, int ns, const int32_t *sids, float fallback) {
+  REQUIRE(var >= 0 && var < NVAR, "bad variable id %d", var);
+  REQUIRE(ns >= 0 && ns <= MAXLIST, "at most %d readers per variable", MAXLIST);
+  for (int k = 0; k < ns; ++k) REQUIRE(sids[k] >= 0 && sids[k] < c->nsrc, "unknown source %d", sids[k]);
+  c->hw.nlist[var] = ns;
+  for (int k = 0; k < ns; ++k) c->hw.list[var][k] = sids[k];
+  c->hw.fallback[var] = fallback;
+  c->dirty = true;
+  return 0;
+}
+
+// ----------------------------------------------------------------- environment
+template <int NV>
+static void launch_group(odr_ctx *c, odr_particles *p, const int *vars, double t, int rec) {
+  GroupVars<NV> gv;
+  for (int k = 0; k < NV; ++k) gv.v[k] = vars[k];
+  hipLaunchKernelGGL(k_env_group<NV>, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, c->dw, view(p), gv, t, rec);
+}
+
+int odr_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t, float *const *out_host) {
+  REQUIRE(nvars > 0 && nvars <= NVAR && var_ids, "bad variable list");
+  HIPCHK(hipSetDevice(c->device));
+  int rc;
+  for (int k = 0; k < nvars; ++k) {
+    REQUIRE(var_ids[k] >= 0 && var_ids[k] < NVAR, "bad variable id %d", var_ids[k]);
+    if ((rc = ensure_env(c, p, var_ids[k]))) return rc;
+  }
+  if ((rc = flush_world(c))) return rc;
+  if (p->n > 0) {
+    // variable groups = variables sharing the same priority list (get_reader_groups, environment.py:339-374)
+    bool done[NVAR] = {false};
+    int rec = 1;
+    for (int a = 0; a < nvars; ++a) {
+      int va = var_ids[a];
+      if (done[va]) continue;
+      int grp[NVAR], ng = 0;
+      for (int b2 = a; b2 < nvars; ++b2) {
+        int vb = var_ids[b2];
+        if (done[vb]) continue;
+        bool same = c->hw.nlist[vb] == c->hw.nlist[va];
+        for (int k = 0; same && k < c->hw.nlist[va]; ++k) same = c->hw.list[vb][k] == c->hw.list[va][k];
+        if (same) { grp[ng++] = vb; done[vb] = true; }
+      }
+      if (c->hw.nlist[va] == 0) {  // no reader: fallback only
+        for (int k = 0; k < ng; ++k)
+          hipLaunchKernelGGL(k_fill_f32, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->env[grp[k]], p->n,
+                             c->hw.fallback[grp[k]]);
+        continue;
+      }
+      for (int o = 0; o < ng;) {  // chunks of <= 4 variables per launch
+        int m = ng - o >= 4 ? 4 : ng - o;
+        // keep vector pairs together so that rotation sees both components
+        if (m == 4 && o + 4 < ng) {
+          int last = grp[o + 3];
+          if (last == VAR_U || last == VAR_XWIND || last == VAR_SX) m = 3;
+        }
+        switch (m) {
+          case 1: launch_group<1>(c, p, grp + o, t, rec); break;
+          case 2: launch_group<2>(c, p, grp + o, t, rec); break;
+          case 3: launch_group<3>(c, p, grp + o, t, rec); break;
+          default: launch_group<4>(c, p, grp + o, t, rec); break;
+        }
+        rec = 0;
+        o += m;
+      }
+    }
+    if (rec) hipLaunchKernelGGL(k_record_prev, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p));
+    HIPCHK(hipGetLastError());
+  }
+  if (out_host) {
+    for (int k = 0; k < nvars; ++k)
+      if (out_host[k] && p->n > 0)
+        HIPCHK(hipMemcpyAsync(out_host[k], p->env[var_ids[k]], sizeof(float) * (size_t)p->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
+int odr_env_download(odr_ctx *c, odr_particles *p, int32_t var, float *out) {
+  REQUIRE(var >= 0 && var < NVAR && out, "bad arguments");
+  if (!p->env[var]) return fail(ODR_ERR_STATE, "variable %d has not been sampled", var);
+  if (p->n > 0) HIPCHK(hipMemcpyAsync(out, p->env[var], sizeof(float) * (size_t)p->n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int odr_env_upload(odr_ctx *c, odr_particles *p, int32_t var, const float *host) {
+  REQUIRE(var >= 0 && var < NVAR && host, "bad arguments");
+  int rc = ensure_env(c, p, var);
+  if (rc) return rc;
+  if (p->n > 0) HIPCHK(hipMemcpyAsync(p->env[var], host, sizeof(float) * (size_t)p->n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int host_to_scratch(odr_ctx *c, odr_particles *p, const double *a, const double *b, size_t n, double **da, double **db) {
+  void *s;
+  int rc = scratch(c, p, sizeof(double) * n * 2, &s);
+  if (rc) return rc;
+  *da = (double *)s;
+  *db = *da + n;
+  HIPCHK(hipMemcpyAsync(*da, a, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  if (b) HIPCHK(hipMemcpyAsync(*db, b, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int odr_env_add_noise(odr_ctx *c, odr_particles *p, int32_t vx, int32_t vy, double std, int rng_mode,
+                      const double *hnx, const double *hny, uint64_t step) {
+  REQUIRE(vx >= 0 && vx < NVAR && vy >= 0 && vy < NVAR, "bad variable ids");
+  if (!p->env[vx] || !p->env[vy]) return fail(ODR_ERR_STATE, "variables not sampled");
+  if (p->n == 0) return 0;
+  double *da = nullptr, *db = nullptr;
+  if (rng_mode == ODR_RNG_HOST) {
+    REQUIRE(hnx && hny, "host normals required in ODR_RNG_HOST mode");
+    int rc = host_to_scratch(c, p, hnx, hny, (size_t)p->n, &da, &db);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_env_noise, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), vx, vy, std, rng_mode, da, db,
+                     c->seed, (unsigned long long)step);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// -------------------------------------------------------------------- advection
+int odr_advect(odr_ctx *c, odr_particles *p, int scheme, double t, double dt, double factor) {
+  REQUIRE(scheme >= 0 && scheme <= 2, "Drift scheme not recognised: %d", scheme);
+  if (!p->env[VAR_U] || !p->env[VAR_V]) return fail(ODR_ERR_STATE, "odr_env_sample of the current must precede odr_advect");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = flush_world(c);
+  if (rc) return rc;
+  if (p->n == 0) return 0;
+  dim3 g(nblk(p->n)), b(BLOCK);
+  PView v = view(p);
+  if (scheme == 0) hipLaunchKernelGGL(k_advect<0>, g, b, 0, c->stream, c->dw, v, t, dt, (float)factor);
+  else if (scheme == 1) hipLaunchKernelGGL(k_advect<1>, g, b, 0, c->stream, c->dw, v, t, dt, (float)factor);
+  else hipLaunchKernelGGL(k_advect<2>, g, b, 0, c->stream, c->dw, v, t, dt, (float)factor);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int odr_update_positions(odr_ctx *c, odr_particles *p, const double *u, const double *v, int is_f32, double dt) {
+  REQUIRE(u && v, "velocities required");
+  if (p->n == 0) return 0;
+  double *da, *db;
+  int rc = host_to_scratch(c, p, u, v, (size_t)p->n, &da, &db);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_update_positions, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), da, db, is_f32, dt);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind) {
+  hipLaunchKernelGGL(k_red_init, dim3(1), dim3(64), 0, c->stream, c->red);
+  if (p->n > 0)
+    hipLaunchKernelGGL(k_reduce, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), wdd, relwind, c->red);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int odr_reduce_scalars(odr_ctx *c, odr_particles *p, double wdd, double *out16) {
+  REQUIRE(out16, "out16 NULL");
+  int rc = reduce(c, p, wdd, 0);
+  if (rc) return rc;
+  double r[R_N];
+  HIPCHK(hipMemcpyAsync(r, c->red, sizeof r, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 16; ++k) out16[k] = k < R_N ? r[k] : 0;
+  out16[R_LONMIN] = -r[R_LONMIN];
+  out16[R_LATMIN] = -r[R_LATMIN];
+  out16[R_ZMIN] = -r[R_ZMIN];
+  return 0;
+}
+
+int odr_advect_wind(odr_ctx *c, odr_particles *p, double dt, double wdd, int relwind, double factor) {
+  if (!p->env[VAR_XWIND] || !p->env[VAR_YWIND]) return fail(ODR_ERR_STATE, "wind has not been sampled");
+  if (relwind && (!p->env[VAR_U] || !p->env[VAR_V])) return fail(ODR_ERR_STATE, "current has not been sampled");
+  if (p->n == 0) return 0;
+  int rc = reduce(c, p, wdd, relwind);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_advect_wind, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, wdd, relwind, factor, c->red);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int odr_stokes_drift(odr_ctx *c, odr_particles *p, double dt, int profile, int hs_mode, int tp_mode, double factor) {
+  REQUIRE(profile >= 0 && profile <= 2 && hs_mode >= 0 && hs_mode <= 2 && tp_mode >= 0 && tp_mode <= 2, "bad stokes options");
+  if (!p->env[VAR_SX] || !p->env[VAR_SY]) return fail(ODR_ERR_STATE, "Stokes drift has not been sampled");
+  if ((hs_mode == 0 && !p->env[VAR_HS]) || (tp_mode == 0 && !p->env[VAR_TP])) return fail(ODR_ERR_STATE, "Hs/Tp not sampled");
+  if ((hs_mode == 1 || tp_mode == 1) && (!p->env[VAR_XWIND] || !p->env[VAR_YWIND])) return fail(ODR_ERR_STATE, "wind not sampled");
+  if (p->n == 0) return 0;
+  int rc = reduce(c, p, 0.0, 0);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_stokes, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, profile, hs_mode, tp_mode, factor, c->red);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int odr_hdiffusion(odr_ctx *c, odr_particles *p, double dt, int rng_mode, const double *hnx, const double *hny, uint64_t step) {
+  if (!p->env[VAR_HDIFF]) return fail(ODR_ERR_STATE, "horizontal_diffusivity has not been sampled");
+  if (p->n == 0) return 0;
+  double *da = nullptr, *db = nullptr;
+  int rc;
+  if (rng_mode == ODR_RNG_HOST) {
+    REQUIRE(hnx && hny, "host normals required in ODR_RNG_HOST mode");
+    if ((rc = host_to_scratch(c, p, hnx, hny, (size_t)p->n, &da, &db))) return rc;
+  }
+  if ((rc = reduce(c, p, 0.0, 0))) return rc;
+  hipLaunchKernelGGL(k_hdiff, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, rng_mode, da, db, c->seed,
+                     (unsigned long long)step, c->red);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, int mix_at_surface, int rng_mode,
+             const double *huni, uint64_t step) {
+  REQUIRE(dt_mix > 0 && dt != 0, "bad time steps");
+  if (!p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
+  int rc = ensure_env(c, p, VAR_SSH);
+  if (rc) return rc;
+  if ((rc = flush_world(c))) return rc;
+  if (p->n == 0) return 0;
+  int nzp = 1;
+  for (int k = 0; k < c->hw.nlist[VAR_KZ]; ++k) {
+    const DevSource &s = c->hw.src[c->hw.list[VAR_KZ][k]];
+    if (s.kind == SRC_GRID) { nzp = s.nz > 1 ? s.nz : 1; break; }
+  }
+  double *du = nullptr;
+  if (rng_mode == ODR_RNG_HOST) {
+    REQUIRE(huni, "host uniforms required in ODR_RNG_HOST mode");
+    int ntimes = abs((int)(dt / (dt_mix * (dt > 0 ? 1 : -1))));
+    void *s;
+    size_t n = (size_t)ntimes * (size_t)p->n;
+    if ((rc = scratch(c, p, sizeof(double) * n, &s))) return rc;
+    du = (double *)s;
+    HIPCHK(hipMemcpyAsync(du, huni, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  size_t lds = sizeof(double) * (size_t)nzp * BLOCK;
+  hipLaunchKernelGGL(k_vmix, dim3(nblk(p->n)), dim3(BLOCK), lds, c->stream, c->dw, view(p), t, dt, dt_mix, mix_at_surface,
+                     rng_mode, du, c->seed, (unsigned long long)step);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int odr_vertical_advection(odr_ctx *c, odr_particles *p, double dt, int at_surface) {
+  if (!p->env[VAR_W]) return fail(ODR_ERR_STATE, "upward_sea_water_velocity has not been sampled");
+  if (p->n == 0) return 0;
+  hipLaunchKernelGGL(k_vadvect, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, at_surface);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int odr_vertical_buoyancy(odr_ctx *c, odr_particles *p, double dt) {
+  if (!p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
+  int rc = ensure_env(c, p, VAR_SSH);
+  if (rc) return rc;
+  if (p->n == 0) return 0;
+  hipLaunchKernelGGL(k_vbuoy, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int read_counter(odr_ctx *c, int64_t *out) {
+  if (out) {
+    unsigned long long v;
+    HIPCHK(hipMemcpyAsync(&v, c->counter, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = (int64_t)v;
+  }
+  return 0;
+}
+
+int odr_coastline(odr_ctx *c, odr_particles *p, int action, int code, int64_t *n_on_land) {
+  REQUIRE(action >= 0 && action <= 2, "bad coastline action");
+  if (n_on_land) *n_on_land = 0;
+  if (action == 0 || p->n == 0) return 0;
+  if (!p->env[VAR_LAND]) return fail(ODR_ERR_STATE, "land_binary_mask has not been sampled");
+  HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_coast, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), action, code, c->counter);
+  HIPCHK(hipGetLastError());
+  return read_counter(c, n_on_land);
+}
+
+int odr_seafloor(odr_ctx *c, odr_particles *p, int64_t *n_below) {
+  if (n_below) *n_below = 0;
+  if (p->n == 0) return 0;
+  if (!p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
+  HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_seafloor, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), c->counter);
+  HIPCHK(hipGetLastError());
+  return read_counter(c, n_below);
+}
+
+int odr_deactivate(odr_ctx *c, odr_particles *p, const uint8_t *mask, int32_t code) {
+  REQUIRE(mask, "mask NULL");
+  if (p->n == 0) return 0;
+  void *s;
+  int rc = scratch(c, p, (size_t)p->n, &s);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(s, mask, (size_t)p->n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  hipLaunchKernelGGL(k_deactivate, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), (const unsigned char *)s, code);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int odr_compact(odr_ctx *c, odr_particles *p, int64_t *n_active) {
+  HIPCHK(hipSetDevice(c->device));
+  if (p->n == 0) { if (n_active) *n_active = 0; return 0; }
+  size_t cap = (size_t)p->cap;
+  // lazily allocate the ping-pong set and the deactivated store
+  for (int k = 0; k < 5; ++k) if (!p->alt64[k]) HIPCHK(hipMalloc((void **)&p->alt64[k], 8 * cap));
+  for (int k = 0; k < 3; ++k) {
+    if (!p->alti32[k]) HIPCHK(hipMalloc((void **)&p->alti32[k], 4 * cap));
+    if (!p->altf32[k]) HIPCHK(hipMalloc((void **)&p->altf32[k], 4 * cap));
+    if (!p->dead64[k]) HIPCHK(hipMalloc((void **)&p->dead64[k], 8 * cap));
+  }
+  for (int k = 0; k < 2; ++k) if (!p->deadi32[k]) HIPCHK(hipMalloc((void **)&p->deadi32[k], 4 * cap));
+  for (int k = 0; k < NVAR; ++k) if (p->env[k] && !p->altenv[k]) HIPCHK(hipMalloc((void **)&p->altenv[k], 4 * cap));
+  unsigned nb = nblk(p->n);
+  hipLaunchKernelGGL(k_cmp_count, dim3(nb), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount);
+  hipLaunchKernelGGL(k_cmp_scan, dim3(1), dim3(1024), 0, c->stream, p->bcount, (long long)nb, c->counter + 1);
+  unsigned long long kept;
+  HIPCHK(hipMemcpyAsync(&kept, c->counter + 1, sizeof kept, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if ((long long)kept == p->n) { if (n_active) *n_active = p->n; return 0; }  // "No elements to deactivate"
+  CmpArrays A;
+  memset(&A, 0, sizeof A);
+  for (int k = 0; k < 5; ++k) {
+    A.src64[k] = p->d64[k]; A.dst64[k] = p->alt64[k];
+    A.dead64[k] = k < 3 ? p->dead64[k] : nullptr;
+  }
+  A.n64 = 5;
+  int m = 0;
+  for (int k = 0; k < 3; ++k, ++m) { A.src32[m] = p->i32[k]; A.dst32[m] = p->alti32[k]; A.dead32[m] = k < 2 ? p->deadi32[k] : nullptr; }
+  for (int k = 0; k < 3; ++k, ++m) { A.src32[m] = (const int *)p->f32[k]; A.dst32[m] = (int *)p->altf32[k]; }
+  for (int k = 0; k < NVAR; ++k)
+    if (p->env[k]) { A.src32[m] = (const int *)p->env[k]; A.dst32[m] = (int *)p->altenv[k]; ++m; }
+  A.n32 = m;
+  hipLaunchKernelGGL(k_cmp_scatter, dim3(nb), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount, A, p->ndead);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 5; ++k) std::swap(p->d64[k], p->alt64[k]);
+  for (int k = 0; k < 3; ++k) { std::swap(p->i32[k], p->alti32[k]); std::swap(p->f32[k], p->altf32[k]); }
+  for (int k = 0; k < NVAR; ++k) if (p->env[k]) std::swap(p->env[k], p->altenv[k]);
+  p->ndead += p->n - (long long)kept;
+  p->n = (long long)kept;
+  if (n_active) *n_active = p->n;
+  return 0;
+}
+

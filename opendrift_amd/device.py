@@ -1,0 +1,330 @@
+"""Thin NumPy-facing wrapper over the C ABI (include/odrift.h).
+
+`Context` is the device image of OpenDrift's Environment (readers + priority lists);
+`Particles` is the device image of a LagrangianArray.  All arithmetic happens in
+libodrift_hip.so; this file only marshals arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import VARIABLES, check
+
+_dp, _fp, _ip = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+
+
+def _vid(v):
+    return v if isinstance(v, (int, np.integer)) else VARIABLES[v]
+
+
+def _d(a, n=None):
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (n,)) if n is not None
+                             else np.asarray(a, dtype=np.float64))
+    return a, a.ctypes.data_as(_dp)
+
+
+def _f(a, n=None):
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float32), (n,)) if n is not None
+                             else np.asarray(a, dtype=np.float32))
+    return a, a.ctypes.data_as(_fp)
+
+
+def _i(a, n=None):
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.int32), (n,)) if n is not None
+                             else np.asarray(a, dtype=np.int32))
+    return a, a.ctypes.data_as(_ip)
+
+
+def proj_desc(proj):
+    """dict(kind='latlong'|'stere_equit_sphere'|'stere_polar', a, rf|es, lat0, lon0, lat_ts, k0, x0, y0)"""
+    if proj is None or proj.get('kind', 'latlong') == 'latlong':
+        return None
+    kind = {'stere_equit_sphere': _abi.PROJ_STERE_EQUIT_SPHERE, 'stere_polar': _abi.PROJ_STERE_POLAR}[proj['kind']]
+    if 'es' in proj:
+        es = proj['es']
+    else:
+        rf = proj.get('rf', 0.0)
+        f = 0.0 if not rf else 1.0 / rf
+        es = f * (2 - f)
+    return _abi.ProjDesc(kind, proj.get('a', 6378137.0), es, proj.get('lat0', 0.0), proj.get('lon0', 0.0),
+                         proj.get('lat_ts', 90.0), proj.get('k0', 1.0), proj.get('x0', 0.0), proj.get('y0', 0.0))
+
+
+class Context:
+    def __init__(self, device=0, seed=0):
+        self.lib = _abi.load()
+        self.h = C.c_void_p()
+        check(self.lib.odr_ctx_create(device, seed, C.byref(self.h)))
+        self.device = device
+        self._grids = {}
+
+    def close(self):
+        if self.h:
+            self.lib.odr_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self.lib.odr_sync(self.h))
+
+    def set_stream(self, stream_ptr):
+        check(self.lib.odr_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    # ---- sources ----
+    def add_constant(self, values):
+        ids, pi = _i([_vid(k) for k in values])
+        vals, pv = _d([float(v) for v in values.values()])
+        sid = C.c_int32()
+        check(self.lib.odr_source_constant(self.h, len(ids), pi, pv, C.byref(sid)))
+        return sid.value
+
+    def add_double_gyre(self, A=0.25, epsilon=0.1, omega=0.628, t0=0.0):
+        prm, pp = _d([A, epsilon, omega, t0])
+        sid = C.c_int32()
+        check(self.lib.odr_source_analytic(self.h, _abi.ANALYTIC_DOUBLE_GYRE, pp, 4, C.byref(sid)))
+        return sid.value
+
+    def add_oscillating(self, variable, amplitude, period_s, t0):
+        prm, pp = _d([_vid(variable), amplitude, period_s, t0])
+        sid = C.c_int32()
+        check(self.lib.odr_source_analytic(self.h, _abi.ANALYTIC_OSCILLATING, pp, 4, C.byref(sid)))
+        return sid.value
+
+    def add_grid(self, x, y, z=None, proj=None, lon_mode=1, mod360_x=0, domain=None):
+        """x, y: the reader's coordinate arrays in the dtype it hands out (float32 for file readers)."""
+        x, y = np.asarray(x), np.asarray(y)
+        if domain is None:
+            domain = (float(x.min()), float(x.max()), float(y.min()), float(y.max()), -np.inf, np.inf)
+        dom, pd = _d(domain)
+        nz = 0 if z is None else int(np.size(z))
+        zz, pz = _d(np.atleast_1d(z)) if nz > 1 else (None, None)
+        desc = proj_desc(proj)
+        sid = C.c_int32()
+        check(self.lib.odr_source_grid(self.h, C.byref(desc) if desc is not None else None, pd, lon_mode,
+                                       mod360_x, nz, pz, C.byref(sid)))
+        # index maps with the spans formed in the coordinate dtype (interpolators.py:32-33,110-111)
+        xy8 = np.array([float(x[0]), float(x[-1] - x[0]), float(y[0]), float(y[-1] - y[0]),
+                        float(x.min()), float(x.max() - x.min()), float(y.min()), float(y.max() - y.min())])
+        self._grids[sid.value] = dict(xy8=xy8, ny=len(y), nx=len(x), nz=max(nz, 1))
+        return sid.value
+
+    def upload_block(self, sid, slot, t_epoch, arrays):
+        """arrays: {variable: float32 [ny,nx] or [nz,ny,nx]} -- one ReaderBlock / time level."""
+        g = self._grids[sid]
+        names = list(arrays)
+        ids, pi = _i([_vid(k) for k in names])
+        keep = [np.ascontiguousarray(np.ma.filled(arrays[k], np.nan) if isinstance(arrays[k], np.ma.MaskedArray)
+                                     else arrays[k], dtype=np.float32) for k in names]
+        for a in keep:
+            assert a.shape[-2:] == (g['ny'], g['nx']), 'block shape %s does not match grid' % (a.shape,)
+        nzs, pn = _i([a.shape[0] if a.ndim == 3 else 1 for a in keep])
+        ptrs = (_fp * len(keep))(*[a.ctypes.data_as(_fp) for a in keep])
+        xy8, px = _d(g['xy8'])
+        check(self.lib.odr_block_upload(self.h, sid, slot, float(t_epoch), len(keep), pi, ptrs, pn, g['ny'],
+                                        g['nx'], px))
+
+    def upload_block_device(self, sid, slot, t_epoch, dev_ptrs, var_nz):
+        """dev_ptrs: {variable: device pointer (int)} of float32 arrays already in HBM."""
+        g = self._grids[sid]
+        names = list(dev_ptrs)
+        ids, pi = _i([_vid(k) for k in names])
+        nzs, pn = _i([var_nz[k] for k in names])
+        ptrs = (C.c_void_p * len(names))(*[C.c_void_p(int(dev_ptrs[k])) for k in names])
+        xy8, px = _d(g['xy8'])
+        check(self.lib.odr_block_upload_device(self.h, sid, slot, float(t_epoch), len(names), pi, ptrs, pn,
+                                               g['ny'], g['nx'], px))
+
+    def drop_block(self, sid, slot):
+        check(self.lib.odr_block_drop(self.h, sid, slot))
+
+    def bind(self, variable, source_ids, fallback=np.nan):
+        ids, pi = _i(list(source_ids)) if len(source_ids) else (None, None)
+        check(self.lib.odr_env_bind(self.h, _vid(variable), len(source_ids), pi,
+                                    np.nan if fallback is None else float(fallback)))
+
+    def particles(self, capacity):
+        return Particles(self, capacity)
+
+    def timer_begin(self):
+        check(self.lib.odr_timer_begin(self.h))
+
+    def timer_end(self):
+        ms = C.c_float()
+        check(self.lib.odr_timer_end(self.h, C.byref(ms)))
+        return ms.value
+
+
+class Particles:
+    def __init__(self, ctx, capacity):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.h = C.c_void_p()
+        check(self.lib.odr_particles_create(ctx.h, int(capacity), C.byref(self.h)))
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.lib.odr_particles_destroy(self.ctx.h, self.h)
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.count()[0]
+
+    def count(self):
+        a, d = C.c_int64(), C.c_int64()
+        check(self.lib.odr_particles_count(self.ctx.h, self.h, C.byref(a), C.byref(d)))
+        return a.value, d.value
+
+    def append(self, lon, lat, z=None, id=None, moving=None, wind_drift_factor=None,
+               current_drift_factor=None, terminal_velocity=None):
+        lon = np.atleast_1d(np.asarray(lon, dtype=np.float64))
+        n = lon.size
+        a = [_d(lon, n), _d(lat, n), _d(z, n), _i(id, n), _i(moving, n), _f(wind_drift_factor, n),
+             _f(current_drift_factor, n), _f(terminal_velocity, n)]
+        check(self.lib.odr_particles_append(self.ctx.h, self.h, n, *[p for _, p in a]))
+
+    def upload(self, lon=None, lat=None, z=None, moving=None, wind_drift_factor=None,
+               current_drift_factor=None, terminal_velocity=None):
+        n = len(self)
+        a = [_d(lon, n), _d(lat, n), _d(z, n), _i(moving, n), _f(wind_drift_factor, n),
+             _f(current_drift_factor, n), _f(terminal_velocity, n)]
+        check(self.lib.odr_particles_upload(self.ctx.h, self.h, *[p for _, p in a]))
+
+    def download(self):
+        n = len(self)
+        out = dict(lon=np.empty(n), lat=np.empty(n), z=np.empty(n), ID=np.empty(n, np.int32),
+                   status=np.empty(n, np.int32), moving=np.empty(n, np.int32))
+        check(self.lib.odr_particles_download(
+            self.ctx.h, self.h, out['lon'].ctypes.data_as(_dp), out['lat'].ctypes.data_as(_dp),
+            out['z'].ctypes.data_as(_dp), out['ID'].ctypes.data_as(_ip), out['status'].ctypes.data_as(_ip),
+            out['moving'].ctypes.data_as(_ip)))
+        return out
+
+    def download_deactivated(self):
+        n = self.count()[1]
+        out = dict(lon=np.empty(n), lat=np.empty(n), z=np.empty(n), ID=np.empty(n, np.int32),
+                   status=np.empty(n, np.int32))
+        check(self.lib.odr_particles_download_deactivated(
+            self.ctx.h, self.h, out['lon'].ctypes.data_as(_dp), out['lat'].ctypes.data_as(_dp),
+            out['z'].ctypes.data_as(_dp), out['ID'].ctypes.data_as(_ip), out['status'].ctypes.data_as(_ip)))
+        return out
+
+    def device_ptr(self, name):
+        p = C.c_void_p()
+        check(self.lib.odr_particles_device_ptr(self.ctx.h, self.h, name.encode(), C.byref(p)))
+        return p.value
+
+    # ---- hot-path stages ----
+    def env_sample(self, variables, t_epoch, download=False):
+        ids, pi = _i([_vid(v) for v in variables])
+        if download:
+            n = len(self)
+            outs = [np.empty(n, np.float32) for _ in variables]
+            ptrs = (_fp * len(outs))(*[o.ctypes.data_as(_fp) for o in outs])
+            check(self.lib.odr_env_sample(self.ctx.h, self.h, len(ids), pi, float(t_epoch), ptrs))
+            return dict(zip(variables, outs))
+        check(self.lib.odr_env_sample(self.ctx.h, self.h, len(ids), pi, float(t_epoch), None))
+
+    def env_download(self, variable):
+        out = np.empty(len(self), np.float32)
+        check(self.lib.odr_env_download(self.ctx.h, self.h, _vid(variable), out.ctypes.data_as(_fp)))
+        return out
+
+    def env_upload(self, variable, values):
+        a, p = _f(values, len(self))
+        check(self.lib.odr_env_upload(self.ctx.h, self.h, _vid(variable), p))
+
+    def env_add_noise(self, var_x, var_y, std, step=0, normals=None):
+        n = len(self)
+        if normals is not None:
+            (ax, px), (ay, py) = _d(normals[0], n), _d(normals[1], n)
+            check(self.lib.odr_env_add_noise(self.ctx.h, self.h, _vid(var_x), _vid(var_y), float(std),
+                                             _abi.RNG_HOST, px, py, step))
+        else:
+            check(self.lib.odr_env_add_noise(self.ctx.h, self.h, _vid(var_x), _vid(var_y), float(std),
+                                             _abi.RNG_DEVICE, None, None, step))
+
+    def advect(self, scheme, t_epoch, dt, factor=1.0):
+        s = scheme if isinstance(scheme, int) else _abi.SCHEME.get(scheme, -1)
+        if s < 0:
+            raise ValueError('Drift scheme not recognised: ' + str(scheme))
+        check(self.lib.odr_advect(self.ctx.h, self.h, s, float(t_epoch), float(dt), float(factor)))
+
+    def update_positions(self, x_vel, y_vel, dt):
+        n = len(self)
+        is32 = int(np.asarray(x_vel).dtype == np.float32)
+        (a, pa), (b, pb) = _d(x_vel, n), _d(y_vel, n)
+        check(self.lib.odr_update_positions(self.ctx.h, self.h, pa, pb, is32, float(dt)))
+
+    def advect_wind(self, dt, wind_drift_depth=0.1, relative_wind=False, factor=1.0):
+        check(self.lib.odr_advect_wind(self.ctx.h, self.h, float(dt), float(wind_drift_depth),
+                                       int(relative_wind), float(factor)))
+
+    def stokes_drift(self, dt, profile=2, hs_mode=0, tp_mode=0, factor=1.0):
+        check(self.lib.odr_stokes_drift(self.ctx.h, self.h, float(dt), profile, hs_mode, tp_mode, float(factor)))
+
+    def hdiffusion(self, dt, step=0, normals=None):
+        n = len(self)
+        if normals is not None:
+            (ax, px), (ay, py) = _d(normals[0], n), _d(normals[1], n)
+            check(self.lib.odr_hdiffusion(self.ctx.h, self.h, float(dt), _abi.RNG_HOST, px, py, step))
+        else:
+            check(self.lib.odr_hdiffusion(self.ctx.h, self.h, float(dt), _abi.RNG_DEVICE, None, None, step))
+
+    def vmix(self, t_epoch, dt, dt_mix, mix_at_surface=False, step=0, uniforms=None):
+        if uniforms is not None:
+            u, pu = _d(np.ascontiguousarray(uniforms))
+            check(self.lib.odr_vmix(self.ctx.h, self.h, float(t_epoch), float(dt), float(dt_mix),
+                                    int(mix_at_surface), _abi.RNG_HOST, pu, step))
+        else:
+            check(self.lib.odr_vmix(self.ctx.h, self.h, float(t_epoch), float(dt), float(dt_mix),
+                                    int(mix_at_surface), _abi.RNG_DEVICE, None, step))
+
+    def vertical_advection(self, dt, at_surface=False):
+        check(self.lib.odr_vertical_advection(self.ctx.h, self.h, float(dt), int(at_surface)))
+
+    def vertical_buoyancy(self, dt):
+        check(self.lib.odr_vertical_buoyancy(self.ctx.h, self.h, float(dt)))
+
+    def coastline(self, action, stranded_code=1):
+        a = action if isinstance(action, int) else _abi.COAST[action]
+        n = C.c_int64()
+        check(self.lib.odr_coastline(self.ctx.h, self.h, a, stranded_code, C.byref(n)))
+        return n.value
+
+    def seafloor(self):
+        n = C.c_int64()
+        check(self.lib.odr_seafloor(self.ctx.h, self.h, C.byref(n)))
+        return n.value
+
+    def deactivate(self, mask, status_code):
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        check(self.lib.odr_deactivate(self.ctx.h, self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)), status_code))
+
+    def compact(self):
+        n = C.c_int64()
+        check(self.lib.odr_compact(self.ctx.h, self.h, C.byref(n)))
+        return n.value
+
+    def reduce_scalars(self, wind_drift_depth=0.1):
+        out = np.empty(16)
+        check(self.lib.odr_reduce_scalars(self.ctx.h, self.h, float(wind_drift_depth), out.ctypes.data_as(_dp)))
+        keys = ['n_active', 'lon_min', 'lon_max', 'lat_min', 'lat_max', 'z_min', 'z_max', 'D_max',
+                'stokes_sum_max', 'wind_speed_max', 'wdf_surface_max', 'n_surface', 'hs_max', 'tp_max']
+        return dict(zip(keys, out))

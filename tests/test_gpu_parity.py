@@ -1,0 +1,352 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs, and against golden vectors produced by the reference itself (tests/golden/*.npz).
+
+Tolerances (stated, north star: trajectories within 1e-6 deg of the CPU reference):
+  * float32 environment values from gridded blocks: bit-exact vs the oracle (scipy-exact bilinear);
+  * positions vs the oracle: <= 1e-10 deg per step (float64 geodesic, FMA contraction differences);
+  * positions vs the reference golden vectors: <= 1e-7 deg over the stored windows -- NumPy's
+    float32 arctan2 on the generating host is 1 ulp off the correctly rounded value in ~38 % of the
+    cases (oracle/step.c azimuth_f32), which moves a particle by <= |step| * 2.4e-7.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+from scenarios import Scenario
+from opendrift_amd import synthetic as synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+U, V = 'x_sea_water_velocity', 'y_sea_water_velocity'
+
+
+def _maxerr(a, b):
+    return float(np.nanmax(np.abs(np.asarray(a) - np.asarray(b)))) if np.size(a) else 0.0
+
+
+# ------------------------------------------------------------------ a13: update_positions / geodesic
+def test_update_positions_matches_oracle_geodesic(ctx):
+    rng = np.random.default_rng(1)
+    n = 20000
+    lon = rng.uniform(-180, 180, n)
+    lat = rng.uniform(-89, 89, n)
+    speed = 10 ** rng.uniform(-4, 2.5, n)
+    ang = rng.uniform(-np.pi, np.pi, n)
+    u, v = speed * np.sin(ang), speed * np.cos(ang)
+    moving = (rng.uniform(size=n) > 0.05).astype(np.int32)
+    for dtype, dt in ((np.float64, 3600.0), (np.float32, 900.0), (np.float64, -3600.0)):
+        P = ctx.particles(n)
+        P.append(lon, lat, moving=moving)
+        uu, vv = u.astype(dtype), v.astype(dtype)
+        P.update_positions(uu, vv, dt)
+        got = P.download()
+        lo, la = lon.copy(), lat.copy()
+        orc.update_positions(lo, la, uu, vv, moving, dt)
+        dlon = np.abs(got['lon'] - lo)
+        dlon = np.minimum(dlon, 360 - dlon)
+        assert dlon.max() < 1e-11 and _maxerr(got['lat'], la) < 1e-11
+        P.close()
+
+
+# ------------------------------------------------------------------ C1 / C2 golden (reference itself)
+def test_c1_constant_euler_golden(ctx):
+    g = golden('c1_constant_euler.npz')
+    sc = Scenario([('constant', {U: 0.3, V: 0.2})], fallbacks={'land_binary_mask': 0.0})
+    sc.device(ctx)
+    w = sc.oracle_world()
+    lon0, lat0 = g['lon'][0], g['lat'][0]
+    n = lon0.size
+    P = ctx.particles(n)
+    P.append(lon0, lat0)
+    lo, la, z = lon0.copy(), lat0.copy(), np.zeros(n)
+    worst_ref = worst_orc = 0.0
+    for k in range(g['lon'].shape[0] - 1):
+        t = k * 3600.0
+        P.env_sample([U, V], t)
+        P.advect('euler', t, 3600.0)
+        got = P.download()
+        ue, ve = orc.get_environment(w, [0, 1], lo, la, z, t)
+        orc.advect_ocean_current(w, 0, lo, la, z, np.ones(n, np.int32), np.ones(n, np.float32), ue, ve, t, 3600.0)
+        worst_orc = max(worst_orc, _maxerr(got['lon'], lo), _maxerr(got['lat'], la))
+        worst_ref = max(worst_ref, _maxerr(got['lon'], g['lon'][k + 1]), _maxerr(got['lat'], g['lat'][k + 1]))
+    assert worst_orc < 1e-10, worst_orc
+    assert worst_ref < 1e-7, worst_ref
+
+
+@pytest.mark.parametrize('name,scheme', [('euler', 'euler'), ('rungekutta', 'runge-kutta'),
+                                         ('rungekutta4', 'runge-kutta4')])
+def test_c2_double_gyre_golden(ctx, name, scheme):
+    g = golden('c2_double_gyre_%s.npz' % name)
+    prm = dict(A=float(g['A']), epsilon=float(g['epsilon']), omega=float(g['omega']), t0=0.0)
+    sc = Scenario([('double_gyre', prm)], fallbacks={'land_binary_mask': 0.0})
+    sc.device(ctx)
+    w = sc.oracle_world()
+    n = g['lon'].shape[1]
+    dt = float(g['dt'])
+    P = ctx.particles(n)
+    P.append(g['lon'][0], g['lat'][0])
+    lo, la, z = g['lon'][0].copy(), g['lat'][0].copy(), np.zeros(n)
+    isch = {'euler': 0, 'runge-kutta': 1, 'runge-kutta4': 2}[scheme]
+    worst_ref = worst_orc = 0.0
+    for k in range(g['lon'].shape[0] - 1):
+        t = k * dt
+        P.env_sample([U, V], t)
+        P.advect(scheme, t, dt)
+        got = P.download()
+        ue, ve = orc.get_environment(w, [0, 1], lo, la, z, t)
+        orc.advect_ocean_current(w, isch, lo, la, z, np.ones(n, np.int32), np.ones(n, np.float32), ue, ve, t, dt)
+        worst_orc = max(worst_orc, _maxerr(got['lon'], lo), _maxerr(got['lat'], la))
+        worst_ref = max(worst_ref, _maxerr(got['lon'], g['lon'][k + 1]), _maxerr(got['lat'], g['lat'][k + 1]))
+    # the whole gyre spans 1.8e-5 deg: also report in reader metres
+    p = orc.make_proj(orc.PROJ_STERE_EQUIT_SPHERE, a=6.371e6, es=0.0)
+    x, y = orc.proj_fwd(p, got['lon'], got['lat'])
+    xr, yr = orc.proj_fwd(p, g['lon'][-1], g['lat'][-1])
+    print('c2 %s: vs oracle %.2e deg, vs reference %.2e deg = %.2e m' %
+          (scheme, worst_orc, worst_ref, max(_maxerr(x, xr), _maxerr(y, yr))))
+    assert worst_orc < 1e-12, worst_orc
+    assert worst_ref < 1e-9, worst_ref
+    assert max(_maxerr(x, xr), _maxerr(y, yr)) < 1e-3
+
+
+# ------------------------------------------------------------------ a5-a9: gridded blocks
+def _grid3d_scenario(g, nlev=3):
+    names = [U, V, 'upward_sea_water_velocity', 'ocean_vertical_diffusivity',
+             'sea_floor_depth_below_sea_level', 'land_binary_mask']
+    levels = [(float(g['t'][k]), {n: g[n][k] for n in names}) for k in range(nlev)]
+    return Scenario([('grid', dict(x=g['x'], y=g['y'], z=g['z'], levels=levels))],
+                    fallbacks={U: 0.0, V: 0.0, 'upward_sea_water_velocity': 0.0,
+                               'ocean_vertical_diffusivity': 0.0, 'sea_floor_depth_below_sea_level': 10000.0})
+
+
+def test_grid3d_environment_bit_exact(ctx):
+    g = synth.grid3d(nx=96, ny=80, nz=8, nt=3, seed=5)
+    sc = _grid3d_scenario(g)
+    sc.device(ctx)
+    w = sc.oracle_world()
+    rng = np.random.default_rng(7)
+    n = 30000
+    lon = rng.uniform(g['x'][0] - 0.05, g['x'][-1] + 0.05, n)   # a few outside the domain
+    lat = rng.uniform(g['y'][0] - 0.05, g['y'][-1] + 0.05, n)
+    z = -rng.uniform(0, 120, n)
+    lon[:50] = g['x'][rng.integers(0, 96, 50)]                   # exactly on grid nodes / edges
+    lat[:50] = g['y'][rng.integers(0, 80, 50)]
+    lon[50:60], lat[50:60] = g['x'][-1], g['y'][-1]
+    names = [U, V, 'upward_sea_water_velocity', 'ocean_vertical_diffusivity',
+             'sea_floor_depth_below_sea_level', 'land_binary_mask']
+    P = ctx.particles(n)
+    P.append(lon, lat, z=z)
+    for t in (0.0, 1234.5, 3600.0, 5000.0):
+        got = P.env_sample(names, t, download=True)
+        ref = orc.get_environment(w, [orc.VAR[k] for k in names], lon, lat, z, t)
+        for k, r in zip(names, ref):
+            a = got[k]
+            same = (a == r) | (np.isnan(a) & np.isnan(r))
+            assert same.all(), (k, t, int((~same).sum()), a[~same][:4], r[~same][:4])
+        w = sc.oracle_world()   # the oracle's blocks are mutated by the NaN dilation: rebuild
+
+
+def test_grid_stere_environment(ctx):
+    g = synth.grid_stere(nx=120, ny=90, nt=3, seed=9)
+    names = [U, V, 'x_wind', 'y_wind', 'sea_surface_wave_stokes_drift_x_velocity',
+             'sea_surface_wave_stokes_drift_y_velocity', 'land_binary_mask']
+    levels = [(float(g['t'][k]), {n: g[n][k] for n in names}) for k in range(3)]
+    sc = Scenario([('grid', dict(x=g['x'], y=g['y'], proj=synth.NORKYST_PROJ, levels=levels))],
+                  fallbacks={U: 0.0, V: 0.0})
+    sc.device(ctx)
+    w = sc.oracle_world()
+    rng = np.random.default_rng(11)
+    n = 20000
+    p = orc.make_proj(orc.PROJ_STERE_POLAR, a=6371000.0, es=(2 - 1 / 298.257223563) / 298.257223563,
+                      lat0=90.0, lon0=70.0, lat_ts=60.0)
+    lon, lat = orc.proj_inv(p, rng.uniform(g['x'][0] - 500, g['x'][-1] + 500, n),
+                            rng.uniform(g['y'][0] - 500, g['y'][-1] + 500, n))
+    P = ctx.particles(n)
+    P.append(lon, lat)
+    for t in (0.0, 900.0, 3600.0):
+        got = P.env_sample(names, t, download=True)
+        ref = orc.get_environment(w, [orc.VAR[k] for k in names], lon, lat, np.zeros(n), t)
+        for k, r in zip(names, ref):
+            a = got[k]
+            assert (np.isnan(a) == np.isnan(r)).all(), k
+            assert _maxerr(a, r) < 2e-6, (k, _maxerr(a, r))   # rotated in f64, rounded to f32: <= 1 ulp of ~10 m/s
+        w = sc.oracle_world()
+
+
+def test_rk4_on_grid3d_matches_oracle(ctx):
+    g = synth.grid3d(nx=96, ny=80, nz=8, nt=3, seed=5)
+    sc = _grid3d_scenario(g)
+    sc.device(ctx)
+    rng = np.random.default_rng(13)
+    n = 20000
+    lon = rng.uniform(g['x'][3], g['x'][-4], n)
+    lat = rng.uniform(g['y'][3], g['y'][-4], n)
+    z = -rng.uniform(0, 60, n)
+    cdf = rng.uniform(0.8, 1.0, n).astype(np.float32)
+    P = ctx.particles(n)
+    P.append(lon, lat, z=z, current_drift_factor=cdf)
+    lo, la = lon.copy(), lat.copy()
+    mv = np.ones(n, np.int32)
+    for k, scheme in enumerate(('euler', 'runge-kutta', 'runge-kutta4', 'runge-kutta4')):
+        t = 600.0 * k + 2700
+        w = sc.oracle_world()
+        P.env_sample([U, V], t)
+        P.advect(scheme, t, 600.0)
+        ue, ve = orc.get_environment(w, [0, 1], lo, la, z, t)
+        orc.advect_ocean_current(w, {'euler': 0, 'runge-kutta': 1, 'runge-kutta4': 2}[scheme], lo, la, z, mv,
+                                 cdf, ue, ve, t, 600.0)
+        got = P.download()
+        assert _maxerr(got['lon'], lo) < 1e-10 and _maxerr(got['lat'], la) < 1e-10, (scheme, _maxerr(got['lon'], lo))
+
+
+# ------------------------------------------------------------------ a12 / a14 / a15 / a16
+def test_wind_stokes_hdiff_match_oracle(ctx):
+    rng = np.random.default_rng(17)
+    n = 20000
+    lon = rng.uniform(3, 6, n)
+    lat = rng.uniform(59, 62, n)
+    z = np.where(rng.uniform(size=n) < 0.5, 0.0, -rng.uniform(0, 0.3, n))
+    wdf = rng.uniform(0, 0.04, n).astype(np.float32)
+    env = {
+        'x_wind': rng.normal(5, 3, n).astype(np.float32), 'y_wind': rng.normal(-2, 3, n).astype(np.float32),
+        U: rng.normal(0, 0.3, n).astype(np.float32), V: rng.normal(0, 0.3, n).astype(np.float32),
+        'sea_surface_wave_stokes_drift_x_velocity': rng.normal(0.05, 0.03, n).astype(np.float32),
+        'sea_surface_wave_stokes_drift_y_velocity': rng.normal(0.0, 0.03, n).astype(np.float32),
+        'sea_surface_wave_significant_height': rng.uniform(0.5, 3, n).astype(np.float32),
+        'sea_surface_wave_period_at_variance_spectral_density_maximum': rng.uniform(4, 12, n).astype(np.float32),
+        'horizontal_diffusivity': rng.uniform(0, 20, n).astype(np.float32),
+    }
+    mv = np.ones(n, np.int32)
+    P = ctx.particles(n)
+    P.append(lon, lat, z=z, wind_drift_factor=wdf)
+    for k, v in env.items():
+        P.env_upload(k, v)
+    lo, la = lon.copy(), lat.copy()
+    # wind, relative and absolute
+    for rel in (0, 1):
+        P.advect_wind(900.0, wind_drift_depth=0.1, relative_wind=bool(rel))
+        orc.advect_wind(lo, la, z, mv, wdf, env['x_wind'], env['y_wind'], env[U], env[V], 0.1, rel, 1.0, 900.0)
+        got = P.download()
+        assert _maxerr(got['lon'], lo) < 1e-11 and _maxerr(got['lat'], la) < 1e-11, ('wind', rel)
+    # Stokes drift: the three Breivik profiles x the Hs/Tp provenance modes
+    for profile in (0, 1, 2):
+        for hs_mode, tp_mode in ((0, 0), (1, 1), (2, 2), (0, 1)):
+            P.stokes_drift(900.0, profile=profile, hs_mode=hs_mode, tp_mode=tp_mode)
+            orc.stokes_drift(lo, la, z, mv, env['sea_surface_wave_stokes_drift_x_velocity'],
+                             env['sea_surface_wave_stokes_drift_y_velocity'],
+                             env['sea_surface_wave_significant_height'],
+                             env['sea_surface_wave_period_at_variance_spectral_density_maximum'],
+                             env['x_wind'], env['y_wind'], hs_mode, tp_mode, profile, 1.0, 900.0)
+            got = P.download()
+            assert _maxerr(got['lon'], lo) < 1e-10 and _maxerr(got['lat'], la) < 1e-10, ('stokes', profile, hs_mode)
+    # horizontal diffusion with np.random normals handed over (parity mode)
+    np.random.seed(0)
+    nx, ny = np.random.normal(scale=1, size=n), np.random.normal(scale=1, size=n)
+    P.hdiffusion(900.0, normals=(nx, ny))
+    orc.horizontal_diffusion(lo, la, mv, env['horizontal_diffusivity'], nx, ny, 900.0)
+    got = P.download()
+    assert _maxerr(got['lon'], lo) < 1e-11 and _maxerr(got['lat'], la) < 1e-11
+    # device Philox mode: statistics of the displacement
+    before = P.download()
+    P.hdiffusion(900.0, step=3)
+    after = P.download()
+    dy = (after['lat'] - before['lat']) * 111e3
+    sig = np.sqrt(2 * env['horizontal_diffusivity'] * 900.0)
+    zscore = dy[sig > 1] / sig[sig > 1]
+    assert abs(zscore.mean()) < 0.03 and abs(zscore.std() - 1) < 0.03
+
+
+def test_early_outs_leave_positions_untouched(ctx):
+    n = 1000
+    lon = np.linspace(185, 190, n)     # outside [-180,180]: an executed geodesic would renormalise it
+    P = ctx.particles(n)
+    P.append(lon, np.full(n, 60.0))
+    for k in ('x_wind', 'y_wind', U, V, 'sea_surface_wave_stokes_drift_x_velocity',
+              'sea_surface_wave_stokes_drift_y_velocity', 'horizontal_diffusivity'):
+        P.env_upload(k, np.zeros(n, np.float32))
+    P.advect_wind(900.0)
+    P.stokes_drift(900.0, hs_mode=2, tp_mode=2)
+    P.hdiffusion(900.0)
+    assert (P.download()['lon'] == lon).all()
+
+
+def test_vertical_mixing_matches_oracle(ctx):
+    g = synth.grid3d(nx=64, ny=48, nz=8, nt=3, seed=21, coast=False)
+    sc = _grid3d_scenario(g)
+    sc.device(ctx)
+    w = sc.oracle_world()
+    rng = np.random.default_rng(23)
+    n = 5000
+    lon = rng.uniform(g['x'][2], g['x'][-3], n)
+    lat = rng.uniform(g['y'][2], g['y'][-3], n)
+    z0 = -rng.uniform(0, 90, n)
+    z0[:200] = 0.0
+    tv = rng.normal(0, 0.002, n).astype(np.float32)
+    t, dt, dt_mix = 1800.0, 600.0, 60.0
+    names = ['sea_floor_depth_below_sea_level', 'sea_surface_height', 'upward_sea_water_velocity']
+    for mix_at_surface in (False, True):
+        P = ctx.particles(n)
+        P.append(lon, lat, z=z0, terminal_velocity=tv)
+        env = P.env_sample(names, t, download=True)
+        uni = np.random.default_rng(3).uniform(size=(10, n))
+        P.vmix(t, dt, dt_mix, mix_at_surface=mix_at_surface, uniforms=uni)
+        P.vertical_advection(dt)
+        got = P.download()
+        Kp = orc.get_profile(w, orc.VAR['ocean_vertical_diffusivity'], lon, lat, t, len(g['z']))
+        zz = z0.copy()
+        orc.vertical_mixing(zz, np.ones(n, np.int32), tv, env[names[0]], env[names[1]], g['z'], Kp, dt, dt_mix,
+                            int(mix_at_surface), uni)
+        orc.vertical_advection(zz, np.ones(n, np.int32), env[names[2]], dt)
+        assert _maxerr(got['z'], zz) < 1e-9, _maxerr(got['z'], zz)
+        P.close()
+    # Philox mode: reproducible and identical regardless of particle order (counter = ID)
+    P = ctx.particles(n)
+    P.append(lon, lat, z=z0, terminal_velocity=tv)
+    P.env_sample(names, t)
+    P.vmix(t, dt, dt_mix, step=5)
+    a = P.download()['z']
+    perm = rng.permutation(n)
+    Q = ctx.particles(n)
+    Q.append(lon[perm], lat[perm], z=z0[perm], terminal_velocity=tv[perm], id=perm.astype(np.int32))
+    Q.env_sample(names, t)
+    Q.vmix(t, dt, dt_mix, step=5)
+    b = Q.download()['z']
+    assert (a[perm] == b).all()
+    assert a.min() >= -env['sea_floor_depth_below_sea_level'].max() - 1 and a.max() <= 0
+
+
+def test_coastline_and_compaction(ctx):
+    rng = np.random.default_rng(29)
+    n = 100000
+    lon, lat = rng.uniform(0, 10, n), rng.uniform(60, 66, n)
+    z = np.where(rng.uniform(size=n) < 0.9, 0.0, 1.0)
+    land = (rng.uniform(size=n) < 0.3).astype(np.float32)
+    P = ctx.particles(n)
+    P.append(lon, lat, z=z)
+    P.env_upload('land_binary_mask', land)
+    P.env_upload(U, np.arange(n, dtype=np.float32))
+    hit = P.coastline('stranding', stranded_code=2)
+    assert hit == int(land.sum())
+    st = np.zeros(n, np.int32)
+    mv = np.ones(n, np.int32)
+    orc.coastline(1, land, lon.copy(), lat.copy(), z, lon, lat, st, mv, 2)
+    got = P.download()
+    assert (got['status'] == st).all() and (got['moving'] == mv).all()
+    kept = P.compact()
+    assert kept == int((st == 0).sum())
+    got = P.download()
+    dead = P.download_deactivated()
+    assert (got['ID'] == np.nonzero(st == 0)[0]).all()            # order preserving (move_elements)
+    assert (dead['ID'] == np.nonzero(st != 0)[0]).all()
+    assert (got['lon'] == lon[st == 0]).all() and (dead['lat'] == lat[st != 0]).all()
+    assert (P.env_download(U) == np.nonzero(st == 0)[0].astype(np.float32)).all()   # environment follows
+    assert P.compact() == kept                                     # nothing more to remove
+    # 'previous': back to the position of the last environment sample
+    Q = ctx.particles(n)
+    Q.append(lon, lat)
+    Q.env_sample([U], 0.0) if False else None
+    Q.env_upload('land_binary_mask', land)
+    Q.update_positions(np.full(n, 0.5), np.full(n, 0.5), 600.0)
+    Q.coastline('previous')
+    g2 = Q.download()
+    assert (g2['lon'][land == 1] == lon[land == 1]).all() and (g2['lon'][land == 0] != lon[land == 0]).all()
