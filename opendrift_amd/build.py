@@ -15,7 +15,7 @@ def build(force=False, verbose=False):
     if (not force and os.path.exists(LIB)
             and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)):
         return LIB
-    cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+    cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
            '-I' + os.path.join(os.path.dirname(HERE), 'include'), '-o', LIB, SRC]
     if verbose:
         print(' '.join(cmd))

@@ -80,6 +80,7 @@ __device__ __forceinline__ double tsfn(double phi, double sinphi, double e) {
 
 __device__ __forceinline__ void proj_fwd(const DevProj &p, double lon_deg, double lat_deg,
                                          double &x, double &y) {
+#pragma clang fp contract(fast)
   if (p.kind == PROJ_LATLONG) { x = lon_deg; y = lat_deg; return; }
   double lam = wrap_pi(lon_deg * kDeg - p.lon0), phi = lat_deg * kDeg;
   double sinlam, coslam, sinphi, cosphi, X, Y;
@@ -103,6 +104,7 @@ __device__ __forceinline__ void proj_fwd(const DevProj &p, double lon_deg, doubl
 
 __device__ __forceinline__ void proj_inv(const DevProj &p, double x, double y, double &lon_deg,
                                          double &lat_deg) {
+#pragma clang fp contract(fast)
   if (p.kind == PROJ_LATLONG) { lon_deg = x; lat_deg = y; return; }
   double X = (x - p.x0) / p.a, Y = (y - p.y0) / p.a;
   double rh = hypot(X, Y), lam = 0, phi = 0;
@@ -139,6 +141,7 @@ __device__ __forceinline__ void proj_inv(const DevProj &p, double x, double y, d
 // points.  For a 10 m line the Gauss mid-latitude solution (azimuth at the mid point
 // minus half the meridian convergence) equals Karney's inverse to O((s/R)^3) ~ 1e-18 rad.
 __device__ __forceinline__ double rotation_angle(const DevProj &p, double x, double y) {
+#pragma clang fp contract(fast)
   double lo1, la1, lo2, la2;
   proj_inv(p, x, y, lo1, la1);
   proj_inv(p, x, y + 10.0, lo2, la2);

@@ -68,6 +68,8 @@ __device__ __forceinline__ double atan2d(double y, double x) {
 // sum_{k=1..6} c[k] sin(2 k x), Clenshaw (c1..c6 passed by value -> registers)
 __device__ __forceinline__ double sin_series6(double sinx, double cosx, double c1, double c2,
                                                double c3, double c4, double c5, double c6) {
+  #pragma clang fp contract(fast)
+  #pragma clang fp contract(fast)
   double ar = 2 * (cosx - sinx) * (cosx + sinx);
   double y1 = c6;                 // k = 6
   double y0 = ar * y1 + c5;       // k = 5
@@ -80,6 +82,8 @@ __device__ __forceinline__ double sin_series6(double sinx, double cosx, double c
 // sum_{k=1..5}
 __device__ __forceinline__ double sin_series5(double sinx, double cosx, double c1, double c2,
                                                double c3, double c4, double c5) {
+  #pragma clang fp contract(fast)
+  #pragma clang fp contract(fast)
   double ar = 2 * (cosx - sinx) * (cosx + sinx);
   double y0 = c5;                 // odd count: y0 = c[5]
   double y1 = ar * y0 + c4;
@@ -92,6 +96,9 @@ __device__ __forceinline__ double sin_series5(double sinx, double cosx, double c
 // Direct problem.  lat/lon/azi in degrees, s12 in metres.  lon2 in [-180,180].
 __device__ __forceinline__ void geod_direct(double lat1, double lon1, double azi1, double s12,
                                              double &lat2, double &lon2) {
+  // the TU is built with -ffp-contract=off so that the float32 rounding points of the
+  // reference stay exact; the geodesic series are float64 and may fuse multiply-adds
+#pragma clang fp contract(fast)
   const GeodConst &g = c_geod;
   double salp1, calp1, sbet1, cbet1;
   azi1 = ang_normalize(azi1);

@@ -32,7 +32,7 @@ __device__ __forceinline__ float azimuth_f32(float xv, float yv) {
   return __fmul_rn(a, 180.0f / 3.14159274101257324f);
 }
 __device__ __forceinline__ float speed_f32(float xv, float yv) {
-  return __fsqrt_rn(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)));
+  return sqrtf(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)));  // IEEE sqrt (the __fsqrt_rn alias is native_sqrt)
 }
 
 // update_positions (basemodel/__init__.py:4631-4657), float32 velocities
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(BLOCK) void k_hdiff(PView p, double dt, int rng_mod
     double2 g = rocrand_normal_double2(&st);
     nx = g.x; ny = g.y;
   }
-  float s = __fsqrt_rn(__fdiv_rn(__fmul_rn(2.0f, p.env[VAR_HDIFF][i]), (float)fabs(dt)));
+  float s = sqrtf(__fdiv_rn(__fmul_rn(2.0f, p.env[VAR_HDIFF][i]), (float)fabs(dt)));
   int moving = p.moving[i];
   double xu = __dmul_rn(__dmul_rn((double)moving, (double)s), nx);
   double xv = __dmul_rn(__dmul_rn((double)moving, (double)s), ny);

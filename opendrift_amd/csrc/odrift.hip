@@ -557,22 +557,21 @@ int odr_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_i
                              c->hw.fallback[grp[k]]);
         continue;
       }
-      for (int o = 0; o < ng;) {  // chunks of <= 4 variables per launch
-        int m = ng - o >= 4 ? 4 : ng - o;
-        // keep vector pairs together so that rotation sees both components
-        if (m == 4 && o + 4 < ng) {
-          int last = grp[o + 3];
-          if (last == VAR_U || last == VAR_XWIND || last == VAR_SX) m = 3;
-        }
-        switch (m) {
-          case 1: launch_group<1>(c, p, grp + o, t, rec); break;
-          case 2: launch_group<2>(c, p, grp + o, t, rec); break;
-          case 3: launch_group<3>(c, p, grp + o, t, rec); break;
-          default: launch_group<4>(c, p, grp + o, t, rec); break;
-        }
-        rec = 0;
-        o += m;
+      // the whole group goes through one launch: the reference decides "static variables only"
+      // and the missing-data mask per reader call on the full group (structured.py:224-229,
+      // environment.py:727-746)
+      switch (ng) {
+        case 1: launch_group<1>(c, p, grp, t, rec); break;
+        case 2: launch_group<2>(c, p, grp, t, rec); break;
+        case 3: launch_group<3>(c, p, grp, t, rec); break;
+        case 4: launch_group<4>(c, p, grp, t, rec); break;
+        case 5: launch_group<5>(c, p, grp, t, rec); break;
+        case 6: launch_group<6>(c, p, grp, t, rec); break;
+        case 7: launch_group<7>(c, p, grp, t, rec); break;
+        case 8: launch_group<8>(c, p, grp, t, rec); break;
+        default: return fail(ODR_ERR_CAPACITY, "at most 8 variables may share one reader list (%d)", ng);
       }
+      rec = 0;
     }
     if (rec) hipLaunchKernelGGL(k_record_prev, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p));
     HIPCHK(hipGetLastError());
