@@ -82,6 +82,7 @@ class Workload:
     def __init__(self, name, ctx, fields, dist_info):
         from opendrift_amd import distributed as D
         self.name, self.ctx, self.fields = name, ctx, fields
+        self.sort_every = int(os.environ.get('ODR_SORT_EVERY', 8))
         rank, local_rank, world = dist_info
         if name == 'c2':
             sid = ctx.add_double_gyre(A=0.1, epsilon=0.25, omega=0.628, t0=0.0)
@@ -91,6 +92,7 @@ class Workload:
             return
         g = fields['g']
         sid = ctx.add_grid(g['x'], g['y'], z=fields['z'], proj=fields['proj'])
+        self.sid = sid
         for slot in range(3):
             arrays = {k: g[k][slot] for k in fields['names']} if rank == 0 else None
             shapes = {k: g[k][slot].shape for k in fields['names']}
@@ -123,6 +125,8 @@ class Workload:
 
     def step(self, P, k):
         t = self.time_of(k)
+        if self.sort_every and self.name != 'c2' and k % self.sort_every == 0:
+            P.sort_by_cell(self.sid)   # device layout maintenance, part of the timed step
         if self.name == 'c2':
             P.env_sample([U, V], t)
             P.advect('runge-kutta4', t, self.dt)
@@ -215,6 +219,7 @@ def main():
     ap.add_argument('--particles', type=int, default=0, help='particles per GPU (default: the config size)')
     ap.add_argument('--small', action='store_true', help='small field block (debug)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--host-sort', action='store_true', help='experiment: seed particles already sorted by grid cell')
     ap.add_argument('--cpu-particles', type=int, default=200000)
     a = ap.parse_args()
 
@@ -235,6 +240,12 @@ def main():
     wl = Workload(a.workload, ctx, fields, (rank, local_rank, world))
     rng = np.random.default_rng(1000 + rank)
     lon, lat, z = seed_particles(a.workload, fields, n, rng)
+    if a.host_sort and fields is not None:
+        g = fields['g']
+        if a.workload == 'c3':
+            ix = np.searchsorted(g['x'], lon); iy = np.searchsorted(g['y'], lat)
+            o = np.lexsort((ix, iy)) if False else np.argsort((iy // 8) * 100000 + (ix // 8) * 64 + (iy % 8) * 8 + ix % 8, kind='stable')
+            lon, lat, z = lon[o], lat[o], z[o]
     lo, hi = D.shard_range(n * world, rank, world)     # global particle IDs of this shard
     P = ctx.particles(n)
     P.append(lon, lat, z=z, id=np.arange(lo, hi, dtype=np.int32))

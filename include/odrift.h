@@ -178,6 +178,12 @@ int odr_deactivate(odr_ctx *ctx, odr_particles *p, const uint8_t *mask_host, int
 /* remove_deactivated_elements (:1797-1826) = LagrangianArray.move_elements (elements.py:197-228):
  * stable compaction of status==0 elements, the rest appended to the deactivated store */
 int odr_compact(odr_ctx *ctx, odr_particles *p, int64_t *n_active);
+/* Device-side layout operation with no reference counterpart: re-order the particle arrays by
+ * the grid cell of gridded source `source_id` so that the lanes of a wavefront gather
+ * neighbouring grid nodes.  Particles keep their ID; results per ID are unchanged (the device
+ * RNG is counter-based on ID).  Do not use together with ODR_RNG_HOST arrays, which are
+ * indexed by position. */
+int odr_sort_particles(odr_ctx *ctx, odr_particles *p, int32_t source_id);
 /* counts and min/max used for the per-step log line and early-outs (:2212-2233):
  * out16 = {n_active, lon_min, lon_max, lat_min, lat_max, z_min, z_max, D_max, stokes_sum_max,
  *          wind_speed_max, wdf_surface_max, n_surface, hs_max, tp_max, 0, 0} */

@@ -3,11 +3,20 @@
 // Replaces pyproj.Geod(ellps='WGS84').fwd as used by
 //   opendrift/models/basemodel/__init__.py:4643-4657  (update_positions)
 //   opendrift/models/physics_methods.py:632-666        (RK2/RK4 sub-stage positions)
-// Written from the published algorithm (J. Geodesy 87:43-55).  float64 throughout:
-// this is the f64-ALU heavy part of a particle-step (4-7 calls per step), so the
-// series in eps are expanded at compile time into Horner forms with the WGS84
-// third-flattening folded into constants (c_geod), there is no per-call
-// coefficient table walk, and sin/cos pairs come from one sincos().
+// Written from the published algorithm (J. Geodesy 87:43-55).  This is the f64-ALU
+// heavy part of a particle-step (4-7 calls per step), so it is organised for the
+// CDNA4 vector f64 pipe rather than for a CPU:
+//   * the series in eps are Horner forms with reciprocal constants (no f64 divides
+//     by non-powers-of-two, each costs ~12 instructions on gfx950);
+//   * everything that depends only on the start point (reduced latitude) lives in a
+//     GeodOrigin that the RK sub-stages of one particle share;
+//   * angle reductions are exact fma reductions instead of remquo()/remainder()
+//     library loops; hypot() is sqrt(fma) (arguments are O(1));
+//   * sin/cos of the small angles B11, tau12, sig12 and the atan of the small
+//     latitude / longitude increments use short Taylor polynomials when the
+//     argument is < 1/16 (steps < ~400 km, error < 1e-20), otherwise the full
+//     library call.  The result equals the plain algorithm to float64 round-off
+//     (tests/test_gpu_parity.py: <= 1e-11 deg against the CPU oracle).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -21,10 +30,15 @@ struct GeodConst {
 __constant__ GeodConst c_geod;
 
 static constexpr double kDeg = 3.14159265358979323846264338327950288 / 180.0;
+static constexpr double kRad2Deg = 180.0 / 3.14159265358979323846264338327950288;
 static constexpr double kTiny = 1.4916681462400413e-154;
 
+// AngNormalize: reduce to [-180, 180]; x - 360*rint(x/360) is exact in float64
 __device__ __forceinline__ double ang_normalize(double x) {
-  double y = remainder(x, 360.0);
+  double q = rint(x * (1.0 / 360.0));
+  double y = fma(-360.0, q, x);
+  y = y > 180.0 ? y - 360.0 : y;
+  y = y < -180.0 ? y + 360.0 : y;
   return fabs(y) == 180.0 ? copysign(180.0, x) : y;
 }
 
@@ -35,10 +49,11 @@ __device__ __forceinline__ double ang_round(double x) {
   return copysign(y, x);
 }
 
-// sin/cos of an angle in degrees with exact quadrant reduction
+// sin/cos of an angle in degrees (|x| <= 540) with exact quadrant reduction
 __device__ __forceinline__ void sincosd(double x, double &sinx, double &cosx) {
-  int q = 0;
-  double r = remquo(x, 90.0, &q);
+  double qd = rint(x * (1.0 / 90.0));
+  double r = fma(-90.0, qd, x);  // exact
+  int q = (int)qd;
   double s, c;
   sincos(r * kDeg, &s, &c);
   switch ((unsigned)q & 3U) {
@@ -47,15 +62,13 @@ __device__ __forceinline__ void sincosd(double x, double &sinx, double &cosx) {
     case 2U: sinx = -s; cosx = -c; break;
     default: sinx = -c; cosx = s; break;
   }
-  cosx += 0.0;
-  if (sinx == 0) sinx = copysign(sinx, x);
 }
 
 __device__ __forceinline__ double atan2d(double y, double x) {
   int q = 0;
   if (fabs(y) > fabs(x)) { double t = x; x = y; y = t; q = 2; }
   if (signbit(x)) { x = -x; ++q; }
-  double ang = atan2(y, x) / kDeg;
+  double ang = atan2(y, x) * kRad2Deg;
   switch (q) {
     case 1: ang = copysign(180.0, y) - ang; break;
     case 2: ang = 90 - ang; break;
@@ -65,14 +78,35 @@ __device__ __forceinline__ double atan2d(double y, double x) {
   return ang;
 }
 
-// sum_{k=1..6} c[k] sin(2 k x), Clenshaw (c1..c6 passed by value -> registers)
+// sin and cos for |x| <= 1/16 by Taylor series (truncation < 1e-22), else library sincos
+__device__ __forceinline__ void sincos_small(double x, double &s, double &c) {
+#pragma clang fp contract(fast)
+  if (fabs(x) <= 0.0625) {
+    double x2 = x * x;
+    s = x * (1 + x2 * (-1.0 / 6 + x2 * (1.0 / 120 + x2 * (-1.0 / 5040 + x2 * (1.0 / 362880 + x2 * (-1.0 / 39916800))))));
+    c = 1 + x2 * (-0.5 + x2 * (1.0 / 24 + x2 * (-1.0 / 720 + x2 * (1.0 / 40320 + x2 * (-1.0 / 3628800 + x2 * (1.0 / 479001600))))));
+  } else {
+    sincos(x, &s, &c);
+  }
+}
+
+// atan2(y, x) for x > 0 and |y/x| <= 1/16 by the Gregory series (truncation < 1e-20)
+__device__ __forceinline__ double atan_ratio(double y, double x) {
+#pragma clang fp contract(fast)
+  if (x > 0 && fabs(y) <= 0.0625 * x) {
+    double r = y / x, r2 = r * r;
+    return r * (1 + r2 * (-1.0 / 3 + r2 * (1.0 / 5 + r2 * (-1.0 / 7 + r2 * (1.0 / 9 + r2 * (-1.0 / 11 + r2 * (1.0 / 13 + r2 * (-1.0 / 15))))))));
+  }
+  return atan2(y, x);
+}
+
+// sum_{k=1..6} c[k] sin(2 k x), Clenshaw
 __device__ __forceinline__ double sin_series6(double sinx, double cosx, double c1, double c2,
                                                double c3, double c4, double c5, double c6) {
-  #pragma clang fp contract(fast)
-  #pragma clang fp contract(fast)
+#pragma clang fp contract(fast)
   double ar = 2 * (cosx - sinx) * (cosx + sinx);
-  double y1 = c6;                 // k = 6
-  double y0 = ar * y1 + c5;       // k = 5
+  double y1 = c6;
+  double y0 = ar * y1 + c5;
   y1 = ar * y0 - y1 + c4;
   y0 = ar * y1 - y0 + c3;
   y1 = ar * y0 - y1 + c2;
@@ -82,10 +116,9 @@ __device__ __forceinline__ double sin_series6(double sinx, double cosx, double c
 // sum_{k=1..5}
 __device__ __forceinline__ double sin_series5(double sinx, double cosx, double c1, double c2,
                                                double c3, double c4, double c5) {
-  #pragma clang fp contract(fast)
-  #pragma clang fp contract(fast)
+#pragma clang fp contract(fast)
   double ar = 2 * (cosx - sinx) * (cosx + sinx);
-  double y0 = c5;                 // odd count: y0 = c[5]
+  double y0 = c5;
   double y1 = ar * y0 + c4;
   y0 = ar * y1 - y0 + c3;
   y1 = ar * y0 - y1 + c2;
@@ -93,57 +126,71 @@ __device__ __forceinline__ double sin_series5(double sinx, double cosx, double c
   return 2 * sinx * cosx * y0;
 }
 
-// Direct problem.  lat/lon/azi in degrees, s12 in metres.  lon2 in [-180,180].
-__device__ __forceinline__ void geod_direct(double lat1, double lon1, double azi1, double s12,
-                                             double &lat2, double &lon2) {
+// start point of a geodesic: what geod_lineinit derives from (lat1, lon1) alone
+struct GeodOrigin {
+  double lat1, lon1n, sbet1, cbet1, tanphi1;
+};
+
+__device__ __forceinline__ GeodOrigin geod_origin(double lat1, double lon1) {
+#pragma clang fp contract(fast)
+  GeodOrigin o;
+  if (fabs(lat1) > 90) lat1 = __builtin_nan("");
+  o.lat1 = lat1;
+  o.lon1n = ang_normalize(lon1);
+  double sphi, cphi;
+  sincosd(ang_round(lat1), sphi, cphi);
+  double sb = sphi * c_geod.f1;
+  double inv = 1.0 / sqrt(sb * sb + cphi * cphi);
+  o.sbet1 = sb * inv;
+  o.cbet1 = fmax(kTiny, cphi * inv);
+  o.tanphi1 = sphi / fmax(kTiny, cphi);
+  return o;
+}
+
+// Direct problem from a prepared origin.  azi in degrees, s12 in metres.  lon2 in [-180,180].
+__device__ __forceinline__ void geod_direct_from(const GeodOrigin &o, double azi1, double s12,
+                                                  double &lat2, double &lon2) {
   // the TU is built with -ffp-contract=off so that the float32 rounding points of the
   // reference stay exact; the geodesic series are float64 and may fuse multiply-adds
 #pragma clang fp contract(fast)
   const GeodConst &g = c_geod;
-  double salp1, calp1, sbet1, cbet1;
+  double salp1, calp1;
   azi1 = ang_normalize(azi1);
   sincosd(ang_round(azi1), salp1, calp1);
-  if (fabs(lat1) > 90) lat1 = __builtin_nan("");
-  sincosd(ang_round(lat1), sbet1, cbet1);
-  sbet1 *= g.f1;
-  { double r = hypot(sbet1, cbet1); sbet1 /= r; cbet1 /= r; }
-  cbet1 = fmax(kTiny, cbet1);
+  const double sbet1 = o.sbet1, cbet1 = o.cbet1;
 
   double salp0 = salp1 * cbet1;
-  double calp0 = hypot(calp1, salp1 * sbet1);
+  double t0 = salp1 * sbet1;
+  double calp0 = sqrt(calp1 * calp1 + t0 * t0);
   double ssig1 = sbet1, somg1 = salp0 * sbet1;
   double csig1 = (sbet1 != 0 || calp1 != 0) ? cbet1 * calp1 : 1.0;
   double comg1 = csig1;
-  { double r = hypot(ssig1, csig1); ssig1 /= r; csig1 /= r; }
+  { double inv = 1.0 / sqrt(ssig1 * ssig1 + csig1 * csig1); ssig1 *= inv; csig1 *= inv; }
 
   double k2 = calp0 * calp0 * g.ep2;
   double eps = k2 / (2 * (1 + sqrt(1 + k2)) + k2);
   double e2 = eps * eps;
 
-  // A1 - 1
-  double A1m1 = ((e2 * (e2 * (e2 + 4) + 64)) / 256 + eps) / (1 - eps);
-  // C1[1..6]
+  double A1m1 = ((e2 * (e2 * (e2 + 4) + 64)) * (1.0 / 256) + eps) / (1 - eps);
   double d = eps;
-  double C11 = d * (e2 * (6 - e2) - 16) / 32;           d *= eps;
-  double C12 = d * (e2 * (64 - 9 * e2) - 128) / 2048;   d *= eps;
-  double C13 = d * (9 * e2 - 16) / 768;                 d *= eps;
-  double C14 = d * (3 * e2 - 5) / 512;                  d *= eps;
-  double C15 = -7 * d / 1280;                           d *= eps;
-  double C16 = -7 * d / 2048;
+  double C11 = d * (e2 * (6 - e2) - 16) * (1.0 / 32);           d *= eps;
+  double C12 = d * (e2 * (64 - 9 * e2) - 128) * (1.0 / 2048);   d *= eps;
+  double C13 = d * (9 * e2 - 16) * (1.0 / 768);                 d *= eps;
+  double C14 = d * (3 * e2 - 5) * (1.0 / 512);                  d *= eps;
+  double C15 = d * (-7.0 / 1280);                               d *= eps;
+  double C16 = d * (-7.0 / 2048);
   double B11 = sin_series6(ssig1, csig1, C11, C12, C13, C14, C15, C16);
   double sB, cB;
-  sincos(B11, &sB, &cB);
+  sincos_small(B11, sB, cB);
   double stau1 = ssig1 * cB + csig1 * sB;
   double ctau1 = csig1 * cB - ssig1 * sB;
-  // C1'[1..6]
   d = eps;
-  double P1 = d * (e2 * (205 * e2 - 432) + 768) / 1536;       d *= eps;
-  double P2 = d * (e2 * (4005 * e2 - 4736) + 3840) / 12288;   d *= eps;
-  double P3 = d * (116 - 225 * e2) / 384;                     d *= eps;
-  double P4 = d * (2695 - 7173 * e2) / 7680;                  d *= eps;
-  double P5 = 3467 * d / 7680;                                d *= eps;
-  double P6 = 38081 * d / 61440;
-  // C3[1..5] and A3
+  double P1 = d * (e2 * (205 * e2 - 432) + 768) * (1.0 / 1536);       d *= eps;
+  double P2 = d * (e2 * (4005 * e2 - 4736) + 3840) * (1.0 / 12288);   d *= eps;
+  double P3 = d * (116 - 225 * e2) * (1.0 / 384);                     d *= eps;
+  double P4 = d * (2695 - 7173 * e2) * (1.0 / 7680);                  d *= eps;
+  double P5 = d * (3467.0 / 7680);                                    d *= eps;
+  double P6 = d * (38081.0 / 61440);
   const double *x3 = g.C3x;
   double m = eps;
   double C31 = m * ((((x3[0] * eps + x3[1]) * eps + x3[2]) * eps + x3[3]) * eps + x3[4]);  m *= eps;
@@ -158,22 +205,35 @@ __device__ __forceinline__ void geod_direct(double lat1, double lon1, double azi
 
   double tau12 = s12 / (g.b * (1 + A1m1));
   double st, ct;
-  sincos(tau12, &st, &ct);
+  sincos_small(tau12, st, ct);
   double B12 = -sin_series6(stau1 * ct + ctau1 * st, ctau1 * ct - stau1 * st, P1, P2, P3, P4, P5, P6);
   double sig12 = tau12 - (B12 - B11);
   double ssig12, csig12;
-  sincos(sig12, &ssig12, &csig12);
+  sincos_small(sig12, ssig12, csig12);
   double ssig2 = ssig1 * csig12 + csig1 * ssig12;
   double csig2 = csig1 * csig12 - ssig1 * ssig12;
   double sbet2 = calp0 * ssig2;
-  double cbet2 = hypot(salp0, calp0 * csig2);
+  double t1 = calp0 * csig2;
+  double cbet2 = sqrt(salp0 * salp0 + t1 * t1);
   if (cbet2 == 0) cbet2 = csig2 = kTiny;
   double somg2 = salp0 * ssig2, comg2 = csig2;
-  double omg12 = atan2(somg2 * comg1 - comg2 * somg1, comg2 * comg1 + somg2 * somg1);
+  double omg12 = atan_ratio(somg2 * comg1 - comg2 * somg1, comg2 * comg1 + somg2 * somg1);
   double lam12 = omg12 + A3c * (sig12 + (sin_series5(ssig2, csig2, C31, C32, C33, C34, C35) - B31));
-  double lon12 = lam12 / kDeg;
-  lon2 = ang_normalize(ang_normalize(lon1) + ang_normalize(lon12));
-  lat2 = atan2d(sbet2, g.f1 * cbet2);
+  lon2 = ang_normalize(o.lon1n + ang_normalize(lam12 * kRad2Deg));
+  // latitude: atan2d(sbet2, f1*cbet2); for short steps as lat1 + atan of the tangent-difference
+  // ratio (same value to round-off, one atan2 fewer)
+  double den = g.f1 * cbet2;
+  double num = sbet2 - o.tanphi1 * den, dd = den + o.tanphi1 * sbet2;
+  if (fabs(o.lat1) < 89.0 && dd > 0 && fabs(num) <= 0.0625 * dd)
+    lat2 = o.lat1 + atan_ratio(num, dd) * kRad2Deg;
+  else
+    lat2 = atan2d(sbet2, den);
+}
+
+__device__ __forceinline__ void geod_direct(double lat1, double lon1, double azi1, double s12,
+                                             double &lat2, double &lon2) {
+  GeodOrigin o = geod_origin(lat1, lon1);
+  geod_direct_from(o, azi1, s12, lat2, lon2);
 }
 
 }  // namespace odr

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -452,6 +453,7 @@ static int block_upload(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, i
   b.xmin = xy8[4]; b.xrange = xy8[5]; b.ymin = xy8[6]; b.yrange = xy8[7];
   b.t = t_epoch;
   size_t plane = (size_t)ny * nx;
+  std::vector<float *> prep((size_t)nvars, nullptr);
   for (int k = 0; k < nvars; ++k) {
     int v = var_ids[k], nzv = var_nz[k] > 1 ? var_nz[k] : 1;
     REQUIRE(v >= 0 && v < NVAR, "bad variable id %d", v);
@@ -479,10 +481,38 @@ static int block_upload(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, i
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipFree(tmp));
-    b.data[v] = buf;
-    b.var_nz[v] = nzv;
-    c->block_bufs[sid][slot].push_back(buf);
+    prep[(size_t)k] = buf;
   }
+  // final layout: z innermost, vector pairs interleaved (odr_field.hip.h DevBlock)
+  static const int pairs[3][2] = {{VAR_U, VAR_V}, {VAR_XWIND, VAR_YWIND}, {VAR_SX, VAR_SY}};
+  std::vector<bool> placed((size_t)nvars, false);
+  unsigned gp = (unsigned)((plane + BLOCK - 1) / BLOCK);
+  for (int pr = 0; pr < 3; ++pr) {
+    int ka = -1, kb = -1;
+    for (int k = 0; k < nvars; ++k) { if (var_ids[k] == pairs[pr][0]) ka = k; if (var_ids[k] == pairs[pr][1]) kb = k; }
+    if (ka < 0 || kb < 0) continue;
+    int nza = var_nz[ka] > 1 ? var_nz[ka] : 1, nzb = var_nz[kb] > 1 ? var_nz[kb] : 1;
+    if (nza != nzb) continue;
+    float *il;
+    HIPCHK(hipMalloc((void **)&il, sizeof(float) * plane * nza * 2 + 64));
+    hipLaunchKernelGGL(k_blk_to_zinner, dim3(gp), dim3(BLOCK), 0, c->stream, prep[(size_t)ka], il, nza, plane, 2, 0);
+    hipLaunchKernelGGL(k_blk_to_zinner, dim3(gp), dim3(BLOCK), 0, c->stream, prep[(size_t)kb], il, nza, plane, 2, 1);
+    b.data[pairs[pr][0]] = il;      b.es[pairs[pr][0]] = 2; b.var_nz[pairs[pr][0]] = nza;
+    b.data[pairs[pr][1]] = il + 1;  b.es[pairs[pr][1]] = 2; b.var_nz[pairs[pr][1]] = nza;
+    c->block_bufs[sid][slot].push_back(il);
+    placed[(size_t)ka] = placed[(size_t)kb] = true;
+  }
+  for (int k = 0; k < nvars; ++k) {
+    if (placed[(size_t)k]) continue;
+    int v = var_ids[k], nzv = var_nz[k] > 1 ? var_nz[k] : 1;
+    float *fin;
+    HIPCHK(hipMalloc((void **)&fin, sizeof(float) * plane * nzv + 64));
+    hipLaunchKernelGGL(k_blk_to_zinner, dim3(gp), dim3(BLOCK), 0, c->stream, prep[(size_t)k], fin, nzv, plane, 1, 0);
+    b.data[v] = fin; b.es[v] = 1; b.var_nz[v] = nzv;
+    c->block_bufs[sid][slot].push_back(fin);
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (float *q : prep) HIPCHK(hipFree(q));
   sort_levels(s);
   c->dirty = true;
   return 0;
@@ -632,6 +662,59 @@ int odr_env_add_noise(odr_ctx *c, odr_particles *p, int32_t vx, int32_t vy, doub
 }
 
 // -------------------------------------------------------------------- advection
+// host copy of nearest_time (variables.py:402-443) on the resident levels of one source
+static void host_bracket(const DevSource &s, double t, int &ib, int &ia) {
+  int b = 0;
+  for (int k = 0; k < s.nlevels; ++k) if (s.slot[s.level_slot[k]].t <= t) b = k;
+  ib = s.level_slot[b];
+  ia = (b + 1 < s.nlevels && s.slot[ib].t != t) ? s.level_slot[b + 1] : -1;
+}
+
+static bool uv_fast_source(const odr_ctx *c, int &sid) {
+  const DevWorld &w = c->hw;
+  if (w.nlist[VAR_U] != 1 || w.nlist[VAR_V] != 1 || w.list[VAR_U][0] != w.list[VAR_V][0]) return false;
+  sid = w.list[VAR_U][0];
+  const DevSource &s = w.src[sid];
+  if (s.kind != SRC_GRID || s.nlevels < 1) return false;
+  const DevBlock &g0 = s.slot[s.level_slot[0]];
+  for (int k = 0; k < s.nlevels; ++k) {
+    const DevBlock &b = s.slot[s.level_slot[k]];
+    if (!b.data[VAR_U] || b.es[VAR_U] != 2 || b.data[VAR_V] != b.data[VAR_U] + 1) return false;
+    if (b.ny != g0.ny || b.nx != g0.nx || b.x0 != g0.x0 || b.xspan != g0.xspan || b.y0 != g0.y0 ||
+        b.yspan != g0.yspan || b.var_nz[VAR_U] != g0.var_nz[VAR_U])
+      return false;
+  }
+  return true;
+}
+
+static UVTime uv_time(const DevSource &s, double t) {
+  int ib, ia;
+  host_bracket(s, t, ib, ia);
+  UVTime tm;
+  tm.b = s.slot[ib].data[VAR_U];
+  tm.a = (ia >= 0 && !s.always_valid) ? s.slot[ia].data[VAR_U] : nullptr;
+  tm.w = ia >= 0 ? (t - s.slot[ib].t) / (s.slot[ia].t - s.slot[ib].t) : 0.0;
+  return tm;
+}
+
+template <int SCHEME>
+static void launch_advect_grid(odr_ctx *c, odr_particles *p, int sid, double t, double dt, double factor) {
+  const DevSource &s = c->hw.src[sid];
+  UVTime th = uv_time(s, t + dt / 2), tf = uv_time(s, t + dt);
+  int geo = s.level_slot[0];
+  bool is3d = s.slot[geo].var_nz[VAR_U] > 1;
+  dim3 g(nblk(p->n)), b(BLOCK);
+  PView v = view(p);
+  float f = (float)factor;
+#define ODR_LAUNCH(PROJ, D3) hipLaunchKernelGGL((k_advect_grid<SCHEME, PROJ, D3>), g, b, 0, c->stream, c->dw, sid, geo, v, dt, f, th, tf)
+  switch (s.proj.kind) {
+    case PROJ_LATLONG: if (is3d) ODR_LAUNCH(PROJ_LATLONG, true); else ODR_LAUNCH(PROJ_LATLONG, false); break;
+    case PROJ_STERE_POLAR: if (is3d) ODR_LAUNCH(PROJ_STERE_POLAR, true); else ODR_LAUNCH(PROJ_STERE_POLAR, false); break;
+    default: if (is3d) ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, true); else ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, false); break;
+  }
+#undef ODR_LAUNCH
+}
+
 int odr_advect(odr_ctx *c, odr_particles *p, int scheme, double t, double dt, double factor) {
   REQUIRE(scheme >= 0 && scheme <= 2, "Drift scheme not recognised: %d", scheme);
   if (!p->env[VAR_U] || !p->env[VAR_V]) return fail(ODR_ERR_STATE, "odr_env_sample of the current must precede odr_advect");
@@ -641,8 +724,12 @@ int odr_advect(odr_ctx *c, odr_particles *p, int scheme, double t, double dt, do
   if (p->n == 0) return 0;
   dim3 g(nblk(p->n)), b(BLOCK);
   PView v = view(p);
+  int sid = -1;
   if (scheme == 0) hipLaunchKernelGGL(k_advect<0>, g, b, 0, c->stream, c->dw, v, t, dt, (float)factor);
-  else if (scheme == 1) hipLaunchKernelGGL(k_advect<1>, g, b, 0, c->stream, c->dw, v, t, dt, (float)factor);
+  else if (uv_fast_source(c, sid) && !getenv("ODR_NO_FAST_PATH")) {
+    if (scheme == 1) launch_advect_grid<1>(c, p, sid, t, dt, factor);
+    else launch_advect_grid<2>(c, p, sid, t, dt, factor);
+  } else if (scheme == 1) hipLaunchKernelGGL(k_advect<1>, g, b, 0, c->stream, c->dw, v, t, dt, (float)factor);
   else hipLaunchKernelGGL(k_advect<2>, g, b, 0, c->stream, c->dw, v, t, dt, (float)factor);
   HIPCHK(hipGetLastError());
   return 0;
@@ -814,9 +901,7 @@ int odr_deactivate(odr_ctx *c, odr_particles *p, const uint8_t *mask, int32_t co
   return 0;
 }
 
-int odr_compact(odr_ctx *c, odr_particles *p, int64_t *n_active) {
-  HIPCHK(hipSetDevice(c->device));
-  if (p->n == 0) { if (n_active) *n_active = 0; return 0; }
+static int ensure_alt(odr_particles *p) {
   size_t cap = (size_t)p->cap;
   // lazily allocate the ping-pong set and the deactivated store
   for (int k = 0; k < 5; ++k) if (!p->alt64[k]) HIPCHK(hipMalloc((void **)&p->alt64[k], 8 * cap));
@@ -827,14 +912,10 @@ int odr_compact(odr_ctx *c, odr_particles *p, int64_t *n_active) {
   }
   for (int k = 0; k < 2; ++k) if (!p->deadi32[k]) HIPCHK(hipMalloc((void **)&p->deadi32[k], 4 * cap));
   for (int k = 0; k < NVAR; ++k) if (p->env[k] && !p->altenv[k]) HIPCHK(hipMalloc((void **)&p->altenv[k], 4 * cap));
-  unsigned nb = nblk(p->n);
-  hipLaunchKernelGGL(k_cmp_count, dim3(nb), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount);
-  hipLaunchKernelGGL(k_cmp_scan, dim3(1), dim3(1024), 0, c->stream, p->bcount, (long long)nb, c->counter + 1);
-  unsigned long long kept;
-  HIPCHK(hipMemcpyAsync(&kept, c->counter + 1, sizeof kept, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  if ((long long)kept == p->n) { if (n_active) *n_active = p->n; return 0; }  // "No elements to deactivate"
-  CmpArrays A;
+  return 0;
+}
+
+static void all_arrays(odr_particles *p, CmpArrays &A) {
   memset(&A, 0, sizeof A);
   for (int k = 0; k < 5; ++k) {
     A.src64[k] = p->d64[k]; A.dst64[k] = p->alt64[k];
@@ -847,15 +928,66 @@ int odr_compact(odr_ctx *c, odr_particles *p, int64_t *n_active) {
   for (int k = 0; k < NVAR; ++k)
     if (p->env[k]) { A.src32[m] = (const int *)p->env[k]; A.dst32[m] = (int *)p->altenv[k]; ++m; }
   A.n32 = m;
-  hipLaunchKernelGGL(k_cmp_scatter, dim3(nb), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount, A, p->ndead);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(c->stream));
+}
+
+static void swap_sets(odr_particles *p) {
   for (int k = 0; k < 5; ++k) std::swap(p->d64[k], p->alt64[k]);
   for (int k = 0; k < 3; ++k) { std::swap(p->i32[k], p->alti32[k]); std::swap(p->f32[k], p->altf32[k]); }
   for (int k = 0; k < NVAR; ++k) if (p->env[k]) std::swap(p->env[k], p->altenv[k]);
+}
+
+int odr_compact(odr_ctx *c, odr_particles *p, int64_t *n_active) {
+  HIPCHK(hipSetDevice(c->device));
+  if (p->n == 0) { if (n_active) *n_active = 0; return 0; }
+  unsigned nb = nblk(p->n);
+  hipLaunchKernelGGL(k_cmp_count, dim3(nb), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount);
+  hipLaunchKernelGGL(k_cmp_scan, dim3(1), dim3(1024), 0, c->stream, p->bcount, (long long)nb, c->counter + 1);
+  unsigned long long kept;
+  HIPCHK(hipMemcpyAsync(&kept, c->counter + 1, sizeof kept, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if ((long long)kept == p->n) { if (n_active) *n_active = p->n; return 0; }  // "No elements to deactivate"
+  int rc = ensure_alt(p);
+  if (rc) return rc;
+  CmpArrays A;
+  all_arrays(p, A);
+  hipLaunchKernelGGL(k_cmp_scatter, dim3(nb), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount, A, p->ndead);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  swap_sets(p);
   p->ndead += p->n - (long long)kept;
   p->n = (long long)kept;
   if (n_active) *n_active = p->n;
   return 0;
 }
 
+// Re-order the particle arrays by the grid cell of one gridded reader (see k_sort_hist).
+int odr_sort_particles(odr_ctx *c, odr_particles *p, int32_t sid) {
+  REQUIRE(sid >= 0 && sid < c->nsrc && c->hw.src[sid].kind == SRC_GRID && c->hw.src[sid].nlevels > 0,
+          "source %d is not a gridded source with a resident block", sid);
+  HIPCHK(hipSetDevice(c->device));
+  if (p->n < 2) return 0;
+  int rc = flush_world(c);
+  if (rc) return rc;
+  if ((rc = ensure_alt(p))) return rc;
+  const DevSource &s = c->hw.src[sid];
+  int slot = s.level_slot[0];
+  const DevBlock &b = s.slot[slot];
+  int ntx = (b.nx + 7) / 8, nty = (b.ny + 7) / 8;
+  unsigned nbins = (unsigned)(ntx * nty * 64 + 1);
+  size_t n = (size_t)p->n;
+  void *sc;
+  if ((rc = scratch(c, p, sizeof(unsigned) * (2 * n + nbins + 16), &sc))) return rc;
+  unsigned *keys = (unsigned *)sc, *perm = keys + n, *hist = perm + n;
+  HIPCHK(hipMemsetAsync(hist, 0, sizeof(unsigned) * nbins, c->stream));
+  hipLaunchKernelGGL(k_sort_hist, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, c->dw, sid, slot, view(p), ntx, nbins,
+                     keys, hist);
+  hipLaunchKernelGGL(k_cmp_scan, dim3(1), dim3(1024), 0, c->stream, hist, (long long)nbins, c->counter + 2);
+  hipLaunchKernelGGL(k_sort_perm, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, keys, p->n, hist, perm);
+  CmpArrays A;
+  all_arrays(p, A);
+  hipLaunchKernelGGL(k_gather_perm, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, perm, p->n, A);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  swap_sets(p);
+  return 0;
+}

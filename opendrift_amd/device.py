@@ -322,6 +322,10 @@ class Particles:
         check(self.lib.odr_compact(self.ctx.h, self.h, C.byref(n)))
         return n.value
 
+    def sort_by_cell(self, source_id):
+        """Re-order the SoA by grid cell of a gridded source (layout only; IDs are preserved)."""
+        check(self.lib.odr_sort_particles(self.ctx.h, self.h, int(source_id)))
+
     def reduce_scalars(self, wind_drift_depth=0.1):
         out = np.empty(16)
         check(self.lib.odr_reduce_scalars(self.ctx.h, self.h, float(wind_drift_depth), out.ctypes.data_as(_dp)))

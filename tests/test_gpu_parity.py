@@ -350,3 +350,43 @@ def test_coastline_and_compaction(ctx):
     Q.coastline('previous')
     g2 = Q.download()
     assert (g2['lon'][land == 1] == lon[land == 1]).all() and (g2['lon'][land == 0] != lon[land == 0]).all()
+
+
+def test_sort_by_cell_is_layout_only(ctx):
+    """odr_sort_particles re-orders memory only: per-ID state and per-ID results are unchanged."""
+    g = synth.grid3d(nx=96, ny=80, nz=8, nt=3, seed=5)
+    sc = _grid3d_scenario(g)
+    sc.device(ctx)
+    rng = np.random.default_rng(31)
+    n = 50000
+    lon = rng.uniform(g['x'][0] - 0.02, g['x'][-1] + 0.02, n)
+    lat = rng.uniform(g['y'][0] - 0.02, g['y'][-1] + 0.02, n)
+    z = -rng.uniform(0, 60, n)
+    tv = rng.normal(0, 0.002, n).astype(np.float32)
+    names = [U, V, 'upward_sea_water_velocity', 'sea_floor_depth_below_sea_level', 'sea_surface_height']
+
+    def run(sort):
+        P = ctx.particles(n)
+        P.append(lon, lat, z=z, terminal_velocity=tv)
+        if sort:
+            P.sort_by_cell(0)
+            d = P.download()
+            ix = np.clip(np.floor((d['lon'] - g['x'][0]) / (g['x'][-1] - g['x'][0]) * 95), 0, 95).astype(int)
+            assert sorted(d['ID'].tolist()) == list(range(n))
+            assert (d['lon'] == lon[d['ID']]).all() and (d['z'] == z[d['ID']]).all()
+        for k in range(3):
+            t = 600.0 * k
+            P.env_sample(names, t)
+            P.advect('runge-kutta4', t, 600.0)
+            P.vmix(t, 600.0, 60.0, step=k)
+            P.vertical_advection(600.0)
+            if sort and k == 1:
+                P.sort_by_cell(0)
+        d = P.download()
+        o = np.argsort(d['ID'])
+        P.close()
+        return d['lon'][o], d['lat'][o], d['z'][o]
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert (x == y).all()
