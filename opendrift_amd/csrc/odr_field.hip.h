@@ -503,4 +503,131 @@ __device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBloc
   vo = isfinite(fv) ? fv : (isfinite(fbv) ? fbv : fv);
 }
 
+
+// ---------------------------------------------------------- fast environment group
+// Main-loop Environment.get_environment for a variable group served by ONE gridded reader:
+// projection, coverage, fractional indices, the vertical bracket and the (host-resolved)
+// time bracket are computed once per particle and shared by all variables of the group;
+// 3D variables fetch their two z levels with one 8-byte load per corner (16 bytes for an
+// interleaved vector pair), 2D variables their two x nodes per row.
+constexpr int MAXG = 8;
+struct EnvGroupDesc {
+  int nv, sid, geo_slot, pad;
+  int var[MAXG];
+  int nz[MAXG];          // 1 => 2D
+  int es[MAXG];          // 2 => interleaved with its vector partner
+  int partner[MAXG];     // index in this group of the y-component to rotate with, or -1
+  const float *b[MAXG];  // before / after arrays (a == nullptr: no time interpolation)
+  const float *a[MAXG];
+  float fallback[MAXG];
+  double w;
+  int all_static, pad2;
+};
+struct __attribute__((aligned(4))) F2 { float x, y; };
+
+// one variable at one time level -> value in the reference's dtype class
+__device__ __forceinline__ double var_level(const float *__restrict__ d, int var, int nzv, int es,
+                                            const DevBlock &g, int snz, double x, double y, double yi,
+                                            double xi, const ZBracket &zb, bool &f32class) {
+  const size_t ns = (size_t)nzv * es;
+  if (var == VAR_LAND) {
+    f32class = true;
+    int ix = nearest_index(x, g.xmin, g.xrange, g.nx);
+    int iy = nearest_index(y, g.ymin, g.yrange, g.ny);
+    return d[((size_t)iy * g.nx + ix) * ns];
+  }
+  yi = fmin(fmax(yi, 0.0), (double)(g.ny - 1));
+  xi = fmin(fmax(xi, 0.0), (double)(g.nx - 1));
+  double fy = floor(yi), fx = floor(xi);
+  int y0 = (int)fy, x0 = (int)fx;
+  double ty = yi - fy, tx = xi - fx, wy0 = 1 - ty, wx0 = 1 - tx;
+  int y1 = y0 + 1 > g.ny - 1 ? (g.ny >= 2 ? g.ny - 2 : 0) : y0 + 1;
+  int x1 = x0 + 1 > g.nx - 1 ? (g.nx >= 2 ? g.nx - 2 : 0) : x0 + 1;
+  const float *p00 = d + ((size_t)y0 * g.nx + x0) * ns, *p01 = d + ((size_t)y0 * g.nx + x1) * ns;
+  const float *p10 = d + ((size_t)y1 * g.nx + x0) * ns, *p11 = d + ((size_t)y1 * g.nx + x1) * ns;
+  if (nzv <= 1) {
+    f32class = true;
+    return bil4(p00[0], p01[0], p10[0], p11[0], wy0, ty, wx0, tx);
+  }
+  f32class = false;
+  float a00, a01, a10, a11, b00, b01, b10, b11;  // level iz0 (a) and iz0+1 (b)
+  const size_t k0 = (size_t)zb.iz0 * es;
+  if (es == 1) {
+    F2 q00 = *(const F2 *)(p00 + k0), q01 = *(const F2 *)(p01 + k0);
+    F2 q10 = *(const F2 *)(p10 + k0), q11 = *(const F2 *)(p11 + k0);
+    a00 = q00.x; b00 = q00.y; a01 = q01.x; b01 = q01.y; a10 = q10.x; b10 = q10.y; a11 = q11.x; b11 = q11.y;
+  } else {
+    a00 = p00[k0]; b00 = p00[k0 + es]; a01 = p01[k0]; b01 = p01[k0 + es];
+    a10 = p10[k0]; b10 = p10[k0 + es]; a11 = p11[k0]; b11 = p11[k0 + es];
+  }
+  float vb = bil4(b00, b01, b10, b11, wy0, ty, wx0, tx);
+  float va = (zb.same && snz > 1) ? vb : bil4(a00, a01, a10, a11, wy0, ty, wx0, tx);
+  return __dadd_rn(__dmul_rn((double)va, zb.wa), __dmul_rn((double)vb, 1 - zb.wa));
+}
+
+template <int PROJ>
+__device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroupDesc &G, double lon,
+                                               double lat, double z, float *out /*[MAXG]*/) {
+  const DevSource &s = W.src[G.sid];
+  const DevBlock &geo = s.slot[G.geo_slot];
+  if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
+  else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
+  double x, y;
+  if (PROJ == PROJ_LATLONG) { x = lon; y = lat; }
+  else proj_fwd(s.proj, lon, lat, x, y);
+  double xchk = x;
+  if (PROJ == PROJ_LATLONG) {
+    if (s.lon_mode == 1) xchk = np_mod(x + 180.0, 360.0) - 180.0;
+    else if (s.lon_mode == 2) xchk = np_mod(x, 360.0);
+  }
+  const bool covered = xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin && z <= s.zmax;
+  double val[MAXG];
+  if (covered) {
+    if (s.mod360_x) x = np_mod(x, 360.0);
+    const double xi = __dmul_rn(__ddiv_rn(x - geo.x0, geo.xspan), (double)(geo.nx - 1));
+    const double yi = __dmul_rn(__ddiv_rn(y - geo.y0, geo.yspan), (double)(geo.ny - 1));
+    ZBracket zb;
+    zb.iz0 = 0; zb.same = 0; zb.wa = 1;
+    if (s.nz > 1) zb = zbracket(s, z);
+#pragma unroll
+    for (int k = 0; k < MAXG; ++k) {
+      if (k >= G.nv) break;
+      bool fb, fa;
+      double vb = var_level(G.b[k], G.var[k], G.nz[k], G.es[k], geo, s.nz, x, y, yi, xi, zb, fb);
+      if (G.a[k] && !G.all_static) {
+        double va = var_level(G.a[k], G.var[k], G.nz[k], G.es[k], geo, s.nz, x, y, yi, xi, zb, fa);
+        if (fb && fa) vb = __fadd_rn(__fmul_rn((float)vb, (float)(1 - G.w)), __fmul_rn((float)va, (float)G.w));
+        else vb = __dadd_rn(__dmul_rn(vb, 1 - G.w), __dmul_rn(va, G.w));
+      }
+      val[k] = vb;
+    }
+    if (PROJ != PROJ_LATLONG) {
+      bool need = false;
+#pragma unroll
+      for (int k = 0; k < MAXG; ++k) if (k < G.nv && G.partner[k] >= 0) need = true;
+      if (need) {
+        double rot = rotation_angle(s.proj, x, y), sn, cs;
+        sincos(rot, &sn, &cs);
+#pragma unroll
+        for (int k = 0; k < MAXG; ++k) {
+          if (k >= G.nv || G.partner[k] < 0) continue;
+#pragma unroll
+          for (int u = 0; u < MAXG; ++u) {
+            if (u != G.partner[k]) continue;
+            double uu = val[k], vv = val[u];
+            val[k] = __dsub_rn(__dmul_rn(uu, cs), __dmul_rn(vv, sn));
+            val[u] = __dadd_rn(__dmul_rn(uu, sn), __dmul_rn(vv, cs));
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXG; ++k) {
+    if (k >= G.nv) break;
+    float f = covered ? (float)val[k] : __builtin_nanf("");
+    out[k] = isfinite(f) ? f : (isfinite(G.fallback[k]) ? G.fallback[k] : f);
+  }
+}
+
 }  // namespace odr

@@ -88,6 +88,21 @@ __global__ __launch_bounds__(BLOCK) void k_env_group(const DevWorld *__restrict_
   if (record_prev) { p.plon[i] = lon; p.plat[i] = lat; }
 }
 
+// fast version: the whole group comes from one gridded reader (odr_field.hip.h)
+template <int PROJ>
+__global__ __launch_bounds__(BLOCK) void k_env_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
+                                                    int record_prev) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
+  float out[MAXG];
+  env_group_fast<PROJ>(*W, G, lon, lat, z, out);
+#pragma unroll
+  for (int k = 0; k < MAXG; ++k)
+    if (k < G.nv) p.env[G.var[k]][i] = out[k];
+  if (record_prev) { p.plon[i] = lon; p.plat[i] = lat; }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_fill_f32(float *a, long long n, float v) {
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   if (i < n) a[i] = v;
@@ -660,6 +675,28 @@ __global__ __launch_bounds__(1024) void k_cmp_scan(unsigned *bcount, long long n
   unsigned long long run = tid ? part[tid - 1] : 0;
   for (long long k = lo; k < hi; ++k) { unsigned c = bcount[k]; bcount[k] = (unsigned)run; run += c; }
   if (tid == 1023) *total = part[1023];
+}
+
+// two-level exclusive scan for large bin counts (sort histogram): per-1024 block sums,
+// scan of the sums by k_cmp_scan, then add back
+__global__ __launch_bounds__(1024) void k_scan_local(unsigned *a, long long n, unsigned *bsum) {
+  __shared__ unsigned sh[1024];
+  long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
+  unsigned v = i < n ? a[i] : 0;
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    unsigned t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  if (i < n) a[i] = sh[threadIdx.x] - v;  // exclusive within the block
+  if (threadIdx.x == 1023) bsum[blockIdx.x] = sh[1023];
+}
+__global__ __launch_bounds__(1024) void k_scan_add(unsigned *a, long long n, const unsigned *boff) {
+  long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
+  if (i < n) a[i] += boff[blockIdx.x];
 }
 
 struct CmpArrays {

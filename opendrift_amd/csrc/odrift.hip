@@ -549,6 +549,59 @@ int odr_env_bind(odr_ctx *c, int32_t var, int ns, const int32_t *sids, float fal
   return 0;
 }
 
+static void host_bracket(const DevSource &s, double t, int &ib, int &ia);
+
+// fast path of odr_env_sample: a group served by one gridded reader with a uniform grid
+static bool launch_env_grid(odr_ctx *c, odr_particles *p, const int *grp, int ng, double t, int rec) {
+  const DevWorld &w = c->hw;
+  if (ng > MAXG || w.nlist[grp[0]] != 1) return false;
+  int sid = w.list[grp[0]][0];
+  const DevSource &s = w.src[sid];
+  if (s.kind != SRC_GRID || s.nlevels < 1) return false;
+  const DevBlock &g0 = s.slot[s.level_slot[0]];
+  for (int k = 0; k < s.nlevels; ++k) {
+    const DevBlock &b = s.slot[s.level_slot[k]];
+    if (b.ny != g0.ny || b.nx != g0.nx || b.x0 != g0.x0 || b.xspan != g0.xspan || b.y0 != g0.y0 ||
+        b.yspan != g0.yspan || b.xmin != g0.xmin || b.xrange != g0.xrange || b.ymin != g0.ymin || b.yrange != g0.yrange)
+      return false;
+  }
+  int ib, ia;
+  host_bracket(s, t, ib, ia);
+  EnvGroupDesc G;
+  memset(&G, 0, sizeof G);
+  G.nv = ng; G.sid = sid; G.geo_slot = s.level_slot[0];
+  G.all_static = 1;
+  for (int k = 0; k < ng; ++k) {
+    int v = grp[k];
+    const DevBlock &bb = s.slot[ib];
+    if (!bb.data[v]) return false;
+    G.var[k] = v; G.nz[k] = bb.var_nz[v]; G.es[k] = bb.es[v];
+    G.b[k] = bb.data[v];
+    G.a[k] = nullptr;
+    if (ia >= 0 && !s.always_valid) {
+      const DevBlock &ba = s.slot[ia];
+      if (!ba.data[v] || ba.var_nz[v] != bb.var_nz[v] || ba.es[v] != bb.es[v]) return false;
+      G.a[k] = ba.data[v];
+    }
+    G.fallback[k] = w.fallback[v];
+    G.partner[k] = -1;
+    if (v != VAR_LAND && v != VAR_DEPTH) G.all_static = 0;
+  }
+  for (int k = 0; k < ng; ++k) {
+    int pv = grp[k] == VAR_U ? VAR_V : grp[k] == VAR_XWIND ? VAR_YWIND : grp[k] == VAR_SX ? VAR_SY : -1;
+    for (int u = 0; pv >= 0 && u < ng; ++u) if (grp[u] == pv) G.partner[k] = u;
+  }
+  G.w = ia >= 0 ? (t - s.slot[ib].t) / (s.slot[ia].t - s.slot[ib].t) : 0.0;
+  dim3 g(nblk(p->n)), b(BLOCK);
+  PView v = view(p);
+  switch (s.proj.kind) {
+    case PROJ_LATLONG: hipLaunchKernelGGL(k_env_grid<PROJ_LATLONG>, g, b, 0, c->stream, c->dw, v, G, rec); break;
+    case PROJ_STERE_POLAR: hipLaunchKernelGGL(k_env_grid<PROJ_STERE_POLAR>, g, b, 0, c->stream, c->dw, v, G, rec); break;
+    default: hipLaunchKernelGGL(k_env_grid<PROJ_STERE_EQUIT_SPHERE>, g, b, 0, c->stream, c->dw, v, G, rec); break;
+  }
+  return true;
+}
+
 // ----------------------------------------------------------------- environment
 template <int NV>
 static void launch_group(odr_ctx *c, odr_particles *p, const int *vars, double t, int rec) {
@@ -587,6 +640,7 @@ int odr_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_i
                              c->hw.fallback[grp[k]]);
         continue;
       }
+      if (!getenv("ODR_NO_FAST_PATH") && launch_env_grid(c, p, grp, ng, t, rec)) { rec = 0; continue; }
       // the whole group goes through one launch: the reference decides "static variables only"
       // and the missing-data mask per reader call on the full group (structured.py:224-229,
       // environment.py:727-746)
@@ -976,12 +1030,18 @@ int odr_sort_particles(odr_ctx *c, odr_particles *p, int32_t sid) {
   unsigned nbins = (unsigned)(ntx * nty * 64 + 1);
   size_t n = (size_t)p->n;
   void *sc;
-  if ((rc = scratch(c, p, sizeof(unsigned) * (2 * n + nbins + 16), &sc))) return rc;
+  if ((rc = scratch(c, p, sizeof(unsigned) * (2 * n + nbins + nbins / 1024 + 64), &sc))) return rc;
   unsigned *keys = (unsigned *)sc, *perm = keys + n, *hist = perm + n;
   HIPCHK(hipMemsetAsync(hist, 0, sizeof(unsigned) * nbins, c->stream));
   hipLaunchKernelGGL(k_sort_hist, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, c->dw, sid, slot, view(p), ntx, nbins,
                      keys, hist);
-  hipLaunchKernelGGL(k_cmp_scan, dim3(1), dim3(1024), 0, c->stream, hist, (long long)nbins, c->counter + 2);
+  {
+    unsigned nsb = (nbins + 1023) / 1024;
+    unsigned *bsum = hist + nbins;  // scratch tail
+    hipLaunchKernelGGL(k_scan_local, dim3(nsb), dim3(1024), 0, c->stream, hist, (long long)nbins, bsum);
+    hipLaunchKernelGGL(k_cmp_scan, dim3(1), dim3(1024), 0, c->stream, bsum, (long long)nsb, c->counter + 2);
+    hipLaunchKernelGGL(k_scan_add, dim3(nsb), dim3(1024), 0, c->stream, hist, (long long)nbins, bsum);
+  }
   hipLaunchKernelGGL(k_sort_perm, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, keys, p->n, hist, perm);
   CmpArrays A;
   all_arrays(p, A);
