@@ -134,8 +134,7 @@ class Workload:
             P.env_sample(self.vars, t)
             P.coastline('previous')
             P.advect('runge-kutta4', t, self.dt)
-            P.vmix(t, self.dt, self.dt_mix, step=k)
-            P.vertical_advection(self.dt)
+            P.vmix(t, self.dt, self.dt_mix, step=k, fuse_vertical_advection=False)
         else:
             P.env_sample(self.vars, t)
             P.coastline('stranding', stranded_code=1)

@@ -166,6 +166,9 @@ int odr_hdiffusion(odr_ctx *ctx, odr_particles *p, double dt, int rng_mode,
  * the positions of the last odr_env_sample; host_uniforms[i_sub*n + i] in ODR_RNG_HOST mode */
 int odr_vmix(odr_ctx *ctx, odr_particles *p, double t_epoch, double dt, double dt_mix,
              int mix_at_surface, int rng_mode, const double *host_uniforms, uint64_t step);
+/* performance hint: apply vertical_advection (oceandrift.py:315-350) inside the next odr_vmix
+ * kernel (OceanDrift.update() calls them back to back, oceandrift.py:201-208) */
+int odr_vmix_fuse_vertical_advection(odr_ctx *ctx, int at_surface);
 /* vertical_advection (oceandrift.py:315-350) / vertical_buoyancy (:352-368) */
 int odr_vertical_advection(odr_ctx *ctx, odr_particles *p, double dt, int at_surface);
 int odr_vertical_buoyancy(odr_ctx *ctx, odr_particles *p, double dt);

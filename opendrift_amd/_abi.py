@@ -73,6 +73,7 @@ _SIGNATURES = {
     'odr_stokes_drift': [_vp, _vp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double],
     'odr_hdiffusion': [_vp, _vp, C.c_double, C.c_int, _dp, _dp, C.c_uint64],
     'odr_vmix': [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _dp, C.c_uint64],
+    'odr_vmix_fuse_vertical_advection': [_vp, C.c_int],
     'odr_vertical_advection': [_vp, _vp, C.c_double, C.c_int],
     'odr_vertical_buoyancy': [_vp, _vp, C.c_double],
     'odr_coastline': [_vp, _vp, C.c_int, C.c_int, _i64p],

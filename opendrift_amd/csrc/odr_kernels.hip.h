@@ -456,27 +456,44 @@ __global__ __launch_bounds__(BLOCK) void k_env_noise(PView p, int vx, int vy, do
 // ---------------------------------------------------------------- vertical mixing
 // OceanDrift.vertical_mixing (oceandrift.py:397-571), diffusivity model 'environment'.
 // The diffusivity profile of each particle (all block levels at the position of the last
-// environment sample, time-interpolated in float64: structured.py:366-385) is gathered
-// once into LDS ([level][thread]: bank = thread, conflict free for per-thread dynamic level
-// indices) and the whole ntimes_mix random walk runs out of registers + LDS.
+// environment sample, time-interpolated in float64: structured.py:366-385) is gathered once
+// -- z-innermost columns, 16-byte loads -- into LDS ([level][thread]: bank = thread, conflict
+// free for per-thread dynamic level indices) together with -dK/dz per level, and the whole
+// ntimes_mix random walk runs out of registers + LDS.  vertical_advection (:315-350) is fused
+// at the end when `vadv` >= 0 (same particle, same z).
+__device__ __forceinline__ void kcolumn(const float *__restrict__ col, int nz, float *out /*[MAXNZ]*/) {
+  int k = 0;
+  for (; k + 4 <= nz; k += 4) {
+    F4 q = *(const F4 *)(col + k);
+    out[k] = q.x; out[k + 1] = q.y; out[k + 2] = q.z; out[k + 3] = q.w;
+  }
+  for (; k < nz; ++k) out[k] = col[k];
+}
+
+template <int NZMAX>
 __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, PView p, double t,
                                                 double dt, double dt_mix_cfg, int mix_at_surface,
                                                 int rng_mode, const double *__restrict__ huni,
-                                                unsigned long long seed, unsigned long long step) {
+                                                unsigned long long seed, unsigned long long step,
+                                                int vadv /* -1 none, 0 below surface, 1 incl. surface */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *Kp = (double *)smem;  // [nzp][BLOCK]
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   const int tid = threadIdx.x;
-  // K source: first GRID reader of the priority list, else fallback (2 levels [0, -profiles_depth])
+  // K source: first GRID reader of the priority list, else the fallback constant
   const DevSource *src = nullptr;
   for (int k = 0; k < W->nlist[VAR_KZ]; ++k) {
     const DevSource &s = W->src[W->list[VAR_KZ][k]];
     if (s.kind == SRC_GRID) { src = &s; break; }
   }
   const int nzp = src ? (src->nz > 1 ? src->nz : 1) : 1;
+  double *Kp = (double *)smem;           // [nzp][BLOCK]
+  double *dsh = Kp + (size_t)nzp * BLOCK;  // [nzp] level depths -mixing_z
   const float Kfb = W->fallback[VAR_KZ];
-  bool active = i < p.n;
-  if (active) {
+  const double *zp = src ? src->z : nullptr;
+  if (tid < nzp && zp) dsh[tid] = -zp[tid];
+  __syncthreads();
+  if (i >= p.n) return;  // no barrier below: every thread touches only its own LDS column
+  {
     bool cov = false;
     double xi = 0, yi = 0, wgt = 0;
     int ib = 0, ia = -1;
@@ -493,24 +510,64 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
       yi = __dmul_rn(__ddiv_rn(y - bb.y0, bb.yspan), (double)(bb.ny - 1));
       if (ia >= 0) wgt = __ddiv_rn(t - bb.t, src->slot[ia].t - bb.t);
     }
-    for (int k = 0; k < nzp; ++k) {
-      double val = Kfb;
-      if (src && cov) {
-        const DevBlock &bb = src->slot[ib];
-        const size_t ns = (size_t)bb.var_nz[VAR_KZ] * bb.es[VAR_KZ];
-        double v0 = bilinear_f32(bb.data[VAR_KZ] + (size_t)k * bb.es[VAR_KZ], bb.ny, bb.nx, ns, yi, xi), vv;
-        if (ia >= 0) {
-          const DevBlock &ba = src->slot[ia];
-          double v1 = bilinear_f32(ba.data[VAR_KZ] + (size_t)k * ba.es[VAR_KZ], ba.ny, ba.nx, ns, yi, xi);
-          vv = __dadd_rn(__dmul_rn(v0, 1 - wgt), __dmul_rn(v1, wgt));
-        } else vv = v0;
-        if (isfinite(vv)) val = vv;
+    if (src && cov && src->slot[ib].es[VAR_KZ] == 1 && NZMAX > 1) {
+      const DevBlock &bb = src->slot[ib];
+      const int ny = bb.ny, nx = bb.nx;
+      yi = fmin(fmax(yi, 0.0), (double)(ny - 1));
+      xi = fmin(fmax(xi, 0.0), (double)(nx - 1));
+      double fy = floor(yi), fx = floor(xi);
+      int y0 = (int)fy, x0 = (int)fx;
+      double ty = yi - fy, tx = xi - fx, wy0 = 1 - ty, wx0 = 1 - tx;
+      int y1 = y0 + 1 > ny - 1 ? (ny >= 2 ? ny - 2 : 0) : y0 + 1;
+      int x1 = x0 + 1 > nx - 1 ? (nx >= 2 ? nx - 2 : 0) : x0 + 1;
+      size_t o00 = ((size_t)y0 * nx + x0) * nzp, o01 = ((size_t)y0 * nx + x1) * nzp;
+      size_t o10 = ((size_t)y1 * nx + x0) * nzp, o11 = ((size_t)y1 * nx + x1) * nzp;
+      float c00[NZMAX], c01[NZMAX], c10[NZMAX], c11[NZMAX];
+      const float *d = bb.data[VAR_KZ];
+      kcolumn(d + o00, nzp, c00); kcolumn(d + o01, nzp, c01);
+      kcolumn(d + o10, nzp, c10); kcolumn(d + o11, nzp, c11);
+#pragma unroll
+      for (int k = 0; k < NZMAX; ++k)
+        if (k < nzp) Kp[k * BLOCK + tid] = (double)bil4(c00[k], c01[k], c10[k], c11[k], wy0, ty, wx0, tx);
+      if (ia >= 0) {
+        const float *da = src->slot[ia].data[VAR_KZ];
+        kcolumn(da + o00, nzp, c00); kcolumn(da + o01, nzp, c01);
+        kcolumn(da + o10, nzp, c10); kcolumn(da + o11, nzp, c11);
+#pragma unroll
+        for (int k = 0; k < NZMAX; ++k)
+          if (k < nzp) {
+            double v1 = (double)bil4(c00[k], c01[k], c10[k], c11[k], wy0, ty, wx0, tx);
+            Kp[k * BLOCK + tid] = __dadd_rn(__dmul_rn(Kp[k * BLOCK + tid], 1 - wgt), __dmul_rn(v1, wgt));
+          }
       }
-      Kp[k * BLOCK + tid] = val;
+      for (int k = 0; k < nzp; ++k)
+        if (!isfinite(Kp[k * BLOCK + tid])) Kp[k * BLOCK + tid] = Kfb;
+    } else {
+      for (int k = 0; k < nzp; ++k) {
+        double val = Kfb;
+        if (src && cov) {
+          const DevBlock &bb = src->slot[ib];
+          const size_t ns = (size_t)bb.var_nz[VAR_KZ] * bb.es[VAR_KZ];
+          double v0 = bilinear_f32(bb.data[VAR_KZ] + (size_t)k * bb.es[VAR_KZ], bb.ny, bb.nx, ns, yi, xi), vv;
+          if (ia >= 0) {
+            const DevBlock &ba = src->slot[ia];
+            double v1 = bilinear_f32(ba.data[VAR_KZ] + (size_t)k * ba.es[VAR_KZ], ba.ny, ba.nx, ns, yi, xi);
+            vv = __dadd_rn(__dmul_rn(v0, 1 - wgt), __dmul_rn(v1, wgt));
+          } else vv = v0;
+          if (isfinite(vv)) val = vv;
+        }
+        Kp[k * BLOCK + tid] = val;
+      }
     }
   }
-  if (!active) return;  // no barrier needed: every thread touches only its own LDS column
-  const double *zp = src ? src->z : nullptr;
+  // Level of a particle: zi = round(interp1d(-mixing_z, range)(-z)) (oceandrift.py:485-488,513).
+  // The rounded linear index only changes at the mid-depths between levels, so zi is the
+  // number of mid-depths passed (ties: np.round is half-to-even) -- a compare chain on
+  // wave-uniform constants instead of a dependent table walk.  -dK/dz*dt_mix and
+  // sqrt(K*|dt_mix|*2/r) of the current level are re-derived only when zi changes.
+  bool uniform_z = true;
+  for (int k = 1; k < nzp - 1; ++k)
+    if ((zp[k + 1] - zp[k]) != (zp[1] - zp[0])) uniform_z = false;
   const double sgn = dt > 0 ? 1.0 : (dt < 0 ? -1.0 : 0.0);
   const double dt_mix = dt_mix_cfg * sgn;
   const int ntimes = abs((int)(dt / dt_mix));
@@ -519,60 +576,63 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
   const int moving = p.moving[i];
   const float Zmin = __fmul_rn(-1.f, __fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH][i]));  // float32 (:408)
   const double wstep = (double)__fmul_rn(p.tv[i], (float)dt_mix) * (double)moving;
-  const bool uniform_z = [&] {
-    if (nzp < 3) return true;
-    for (int k = 1; k < nzp - 1; ++k)
-      if ((zp[k + 1] - zp[k]) != (zp[1] - zp[0])) return false;
-    return true;
-  }();
   rocrand_state_philox4x32_10 st;
   if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
+  double2 u2 = make_double2(0.0, 0.0);
+  int zi_cur = -1;
+  double sig = 0, dKdt = 0;
   for (int it = 0; it < ntimes; ++it) {
     const bool surface = z == 0;
-    // z_index = interp1d(-mixing_z, range, bounds_error=False, fill_value=(0, nz-1)) (:485-488)
-    double d = -z, idx;
-    if (nzp == 1) idx = 0;
-    else if (d < -zp[0]) idx = 0;
-    else if (d > -zp[nzp - 1]) idx = nzp - 1;
-    else {
-      int hi = 0;
-      while (hi < nzp && -zp[hi] < d) ++hi;
-      hi = hi < 1 ? 1 : (hi > nzp - 1 ? nzp - 1 : hi);
-      double xl = -zp[hi - 1], xh = -zp[hi];
-      idx = __dadd_rn(__dmul_rn(__ddiv_rn(1.0, xh - xl), d - xl), (double)(hi - 1));
-    }
-    const int zi = (int)(unsigned short)(long long)rint(idx);  // np.round(..).astype(np.uint16)
-    const double Kz = Kp[zi * BLOCK + tid];
-    // dK/dz = -np.gradient(Kprofiles, mixing_z, axis=0)[zi], |.|<1e-10 -> 0 (:501-502)
-    double gK = 0;
-    if (nzp >= 2) {
-      if (zi == 0) gK = __ddiv_rn(Kp[BLOCK + tid] - Kp[tid], zp[1] - zp[0]);
-      else if (zi == nzp - 1)
-        gK = __ddiv_rn(Kp[(nzp - 1) * BLOCK + tid] - Kp[(nzp - 2) * BLOCK + tid], zp[nzp - 1] - zp[nzp - 2]);
-      else if (uniform_z)
-        gK = __ddiv_rn(Kp[(zi + 1) * BLOCK + tid] - Kp[(zi - 1) * BLOCK + tid], __dmul_rn(2., zp[1] - zp[0]));
-      else {
-        double dx1 = zp[zi] - zp[zi - 1], dx2 = zp[zi + 1] - zp[zi];
-        double a = __ddiv_rn(-dx2, __dmul_rn(dx1, dx1 + dx2));
-        double b = __ddiv_rn(dx2 - dx1, __dmul_rn(dx1, dx2));
-        double c = __ddiv_rn(dx1, __dmul_rn(dx2, dx1 + dx2));
-        gK = __dadd_rn(__dadd_rn(__dmul_rn(a, Kp[(zi - 1) * BLOCK + tid]), __dmul_rn(b, Kz)),
-                       __dmul_rn(c, Kp[(zi + 1) * BLOCK + tid]));
+    const double d = -z;
+    int zi = 0;
+#pragma unroll
+    for (int k = 0; k < (NZMAX > 1 ? NZMAX - 1 : MAXNZ - 1); ++k)
+      if (k < nzp - 1) {
+        double mid = dsh[k] + 0.5 * (dsh[k + 1] - dsh[k]);
+        zi += ((k & 1) ? d >= mid : d > mid) ? 1 : 0;
       }
+    if (zi != zi_cur) {
+      zi_cur = zi;
+      const double Kz = Kp[zi * BLOCK + tid];
+      double gK = 0;  // np.gradient(Kprofiles, mixing_z, axis=0)[zi] (oceandrift.py:501)
+      if (nzp >= 2) {
+        if (zi == 0) gK = __ddiv_rn(Kp[BLOCK + tid] - Kz, zp[1] - zp[0]);
+        else if (zi == nzp - 1) gK = __ddiv_rn(Kz - Kp[(nzp - 2) * BLOCK + tid], zp[nzp - 1] - zp[nzp - 2]);
+        else if (uniform_z)
+          gK = __ddiv_rn(Kp[(zi + 1) * BLOCK + tid] - Kp[(zi - 1) * BLOCK + tid], __dmul_rn(2., zp[1] - zp[0]));
+        else {
+          double dx1 = -(dsh[zi] - dsh[zi - 1]), dx2 = -(dsh[zi + 1] - dsh[zi]);
+          double a = __ddiv_rn(-dx2, __dmul_rn(dx1, dx1 + dx2));
+          double b = __ddiv_rn(dx2 - dx1, __dmul_rn(dx1, dx2));
+          double c = __ddiv_rn(dx1, __dmul_rn(dx2, dx1 + dx2));
+          gK = __dadd_rn(__dadd_rn(__dmul_rn(a, Kp[(zi - 1) * BLOCK + tid]), __dmul_rn(b, Kz)),
+                         __dmul_rn(c, Kp[(zi + 1) * BLOCK + tid]));
+        }
+      }
+      double dK = -gK;
+      if (fabs(dK) < 1e-10) dK = 0;  // gradK[np.abs(gradK)<1e-10] = 0 (:502)
+      dKdt = __dmul_rn(dK, dt_mix);
+      sig = sqrt(__ddiv_rn(__dmul_rn(__dmul_rn(Kz, fabs(dt_mix)), 2.0), r));
     }
-    double dK = -gK;
-    if (fabs(dK) < 1e-10) dK = 0;
-    double u01 = rng_mode == 1 ? huni[(size_t)it * p.n + i] : rocrand_uniform_double(&st);
+    double u01;
+    if (rng_mode == 1) u01 = huni[(size_t)it * p.n + i];
+    else {  // one Philox4x32-10 block = two float64 uniforms
+      if ((it & 1) == 0) u2 = rocrand_uniform_double2(&st);
+      u01 = (it & 1) ? u2.y : u2.x;
+    }
     double R = __dsub_rn(__dmul_rn(2.0, u01), 1.0);
     // z - moving*(dKdz*dt_mix - R*sqrt(Kz*|dt_mix|*2/r)) (:527-528)
-    double rw = __dmul_rn(R, sqrt(__ddiv_rn(__dmul_rn(__dmul_rn(Kz, fabs(dt_mix)), 2.0), r)));
-    z = __dsub_rn(z, __dmul_rn((double)moving, __dsub_rn(__dmul_rn(dK, dt_mix), rw)));
+    z = __dsub_rn(z, __dmul_rn((double)moving, __dsub_rn(dKdt, __dmul_rn(R, sig))));
     if (z >= 0) z = -z;                                                       // reflect from surface
     if (z < (double)Zmin && moving == 1) z = __dsub_rn((double)__fmul_rn(2.f, Zmin), z);  // reflect from seafloor
     z = __dadd_rn(z, wstep);                                                  // buoyancy
     if (!mix_at_surface && surface) z = 0.0;
     if (z > 0) z = 0.0;                                                       // surface_stick
     if (z < (double)Zmin) z = (double)Zmin;                                   // lift_to_seafloor
+  }
+  if (vadv >= 0 && (vadv ? z <= 0 : z < 0)) {  // vertical_advection (oceandrift.py:315-350)
+    double zz = __dadd_rn(z, __dmul_rn(__dmul_rn((double)moving, (double)p.env[VAR_W][i]), dt));
+    z = zz < 0 ? zz : 0.0;
   }
   p.z[i] = z;
 }

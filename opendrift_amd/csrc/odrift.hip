@@ -46,6 +46,7 @@ struct odr_ctx {
   unsigned long long *counter;
   hipEvent_t ev0, ev1;
   int nsrc;
+  int fuse_vadv;
 };
 
 struct odr_particles {
@@ -151,6 +152,7 @@ int odr_ctx_create(int device, uint64_t seed, odr_ctx **out) {
   HIPCHK(hipEventCreate(&c->ev1));
   c->dirty = true;
   c->nsrc = 0;
+  c->fuse_vadv = -1;
   GeodConst g;
   geod_consts(g);
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_geod), &g, sizeof(GeodConst)));
@@ -886,10 +888,24 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
     HIPCHK(hipMemcpyAsync(du, huni, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
   }
-  size_t lds = sizeof(double) * (size_t)nzp * BLOCK;
-  hipLaunchKernelGGL(k_vmix, dim3(nblk(p->n)), dim3(BLOCK), lds, c->stream, c->dw, view(p), t, dt, dt_mix, mix_at_surface,
-                     rng_mode, du, c->seed, (unsigned long long)step);
+  size_t lds = sizeof(double) * ((size_t)nzp * BLOCK + (size_t)nzp);
+  dim3 g(nblk(p->n)), b(BLOCK);
+  PView v = view(p);
+  unsigned long long st = (unsigned long long)step;
+  int vadv = c->fuse_vadv;
+  c->fuse_vadv = -1;
+  if (vadv >= 0 && !p->env[VAR_W]) return fail(ODR_ERR_STATE, "upward_sea_water_velocity has not been sampled");
+  if (nzp <= 16) hipLaunchKernelGGL(k_vmix<16>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv);
+  else if (nzp <= 32) hipLaunchKernelGGL(k_vmix<32>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv);
+  else hipLaunchKernelGGL(k_vmix<1>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// odr_vmix followed by odr_vertical_advection in one kernel (same particle, same z): request
+// the fusion for the next odr_vmix call
+int odr_vmix_fuse_vertical_advection(odr_ctx *c, int at_surface) {
+  c->fuse_vadv = at_surface ? 1 : 0;
   return 0;
 }
 

@@ -287,7 +287,9 @@ class Particles:
         else:
             check(self.lib.odr_hdiffusion(self.ctx.h, self.h, float(dt), _abi.RNG_DEVICE, None, None, step))
 
-    def vmix(self, t_epoch, dt, dt_mix, mix_at_surface=False, step=0, uniforms=None):
+    def vmix(self, t_epoch, dt, dt_mix, mix_at_surface=False, step=0, uniforms=None, fuse_vertical_advection=None):
+        if fuse_vertical_advection is not None:   # True: include surface elements, False: z<0 only
+            check(self.lib.odr_vmix_fuse_vertical_advection(self.ctx.h, int(bool(fuse_vertical_advection))))
         if uniforms is not None:
             u, pu = _d(np.ascontiguousarray(uniforms))
             check(self.lib.odr_vmix(self.ctx.h, self.h, float(t_epoch), float(dt), float(dt_mix),
