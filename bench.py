@@ -133,6 +133,7 @@ class Workload:
         elif self.name == 'c3':
             P.env_sample(self.vars, t)
             P.coastline('previous')
+            P.store_previous()
             P.advect('runge-kutta4', t, self.dt)
             P.vmix(t, self.dt, self.dt_mix, step=k, fuse_vertical_advection=False)
         else:

@@ -130,6 +130,10 @@ int odr_block_upload_device(odr_ctx *ctx, int32_t source_id, int32_t slot, doubl
                             int nvars, const int32_t *var_ids, const void *const *dev_data,
                             const int32_t *var_nz, int ny, int nx, const double *xy8);
 int odr_block_drop(odr_ctx *ctx, int32_t source_id, int32_t slot);
+/* reader.start_time / end_time / always_valid (covers_time, variables.py:392-400): outside the
+ * interval the reader is skipped and the next reader / the fallback applies */
+int odr_source_time_coverage(odr_ctx *ctx, int32_t source_id, double t_start_epoch, double t_end_epoch,
+                             int always_valid);
 /* priority list + fallback of one variable (environment.py:592-595,782-791); NaN = no fallback */
 int odr_env_bind(odr_ctx *ctx, int32_t var_id, int nsources, const int32_t *source_ids,
                  float fallback);
@@ -137,8 +141,8 @@ int odr_env_bind(odr_ctx *ctx, int32_t var_id, int nsources, const int32_t *sour
 /* ------------------------------------------------------------ hot-path stages */
 /* Environment.get_environment (environment.py:499-923): sample var_ids at the particles'
  * (lon,lat,z) and time into the device environment (float32).  out_host[k] (optional)
- * receives a copy.  Also records the sample positions as the "previous" state
- * (update_previous_state, basemodel/__init__.py:642-668). */
+ * receives a copy.  The sample positions are remembered for the vertical profiles used by
+ * odr_vmix (environment_profiles are taken at these positions, oceandrift.py:431-447). */
 int odr_env_sample(odr_ctx *ctx, odr_particles *p, int nvars, const int32_t *var_ids,
                    double t_epoch, float *const *out_host);
 int odr_env_download(odr_ctx *ctx, odr_particles *p, int32_t var_id, float *out_host);
@@ -172,9 +176,17 @@ int odr_vmix_fuse_vertical_advection(odr_ctx *ctx, int at_surface);
 /* vertical_advection (oceandrift.py:315-350) / vertical_buoyancy (:352-368) */
 int odr_vertical_advection(odr_ctx *ctx, odr_particles *p, double dt, int at_surface);
 int odr_vertical_buoyancy(odr_ctx *ctx, odr_particles *p, double dt);
+/* update_previous_state (basemodel/__init__.py:642-668): store lon/lat for the 'previous'
+ * coastline / seafloor actions.  Newly appended elements start with previous = own position
+ * (release_elements, :925-929). */
+int odr_store_previous(odr_ctx *ctx, odr_particles *p);
 /* interact_with_coastline (basemodel/__init__.py:670-746, approximation precision None) and
  * interact_with_seafloor 'lift_to_seafloor' (:748-783) on the current environment */
-int odr_coastline(odr_ctx *ctx, odr_particles *p, int action, int stranded_code, int64_t *n_on_land);
+int odr_coastline(odr_ctx *ctx, odr_particles *p, int action, int stranded_code,
+                  int seeded_on_land_code /* 'previous': deactivate age==0 elements on land, 0 = off */,
+                  int64_t *n_on_land);
+/* increase_age_and_retire (basemodel/__init__.py:2342-2352); max_age_seconds <= 0: no retirement */
+int odr_increase_age(odr_ctx *ctx, odr_particles *p, double dt, double max_age_seconds, int retired_code);
 int odr_seafloor(odr_ctx *ctx, odr_particles *p, int64_t *n_below);
 /* deactivate elements flagged by the host (deactivate_elements, :1774-1795) */
 int odr_deactivate(odr_ctx *ctx, odr_particles *p, const uint8_t *mask_host, int32_t status_code);

@@ -76,7 +76,10 @@ _SIGNATURES = {
     'odr_vmix_fuse_vertical_advection': [_vp, C.c_int],
     'odr_vertical_advection': [_vp, _vp, C.c_double, C.c_int],
     'odr_vertical_buoyancy': [_vp, _vp, C.c_double],
-    'odr_coastline': [_vp, _vp, C.c_int, C.c_int, _i64p],
+    'odr_store_previous': [_vp, _vp],
+    'odr_coastline': [_vp, _vp, C.c_int, C.c_int, C.c_int, _i64p],
+    'odr_increase_age': [_vp, _vp, C.c_double, C.c_double, C.c_int],
+    'odr_source_time_coverage': [_vp, C.c_int32, C.c_double, C.c_double, C.c_int],
     'odr_seafloor': [_vp, _vp, _i64p],
     'odr_deactivate': [_vp, _vp, _P(C.c_uint8), C.c_int32],
     'odr_compact': [_vp, _vp, _i64p],

@@ -43,6 +43,7 @@ struct DevSource {
   int kind, lon_mode, mod360_x, nlevels, nz, always_valid;
   DevProj proj;
   double xmin, xmax, ymin, ymax, zmin, zmax;
+  double tmin, tmax;  // covers_time (variables.py:392-400)
   double const_val[NVAR];
   double params[8];
   double z[MAXNZ];
@@ -161,26 +162,37 @@ __device__ __forceinline__ double rotation_angle(const DevProj &p, double x, dou
   return -az1;  // rot_angle_rad = -rot_angle_vectors_rad
 }
 
+// Footprint of scipy.ndimage.map_coordinates(order=1) along one axis in the form the reference
+// finally delivers: a NaN of the first (mode='constant') pass is always retried with
+// mode='nearest' (interpolators.py:122-137), and on finite data both modes agree, so the device
+// uses the 'nearest' footprint throughout: start = floor(c), t = c - start, both indices clamped
+// to [0, n-1] (the coordinate itself is not clamped -- probed against SciPy 1.15.3).
+struct Axis { int i0, i1; double t; };
+__device__ __forceinline__ Axis axis_fp(double c, int n) {
+  Axis a;
+  double f = floor(c);
+  a.t = c - f;
+  f = fmin(fmax(f, -1.0), (double)n);
+  int i = (int)f;
+  a.i0 = min(max(i, 0), n - 1);
+  a.i1 = min(max(i + 1, 0), n - 1);
+  return a;
+}
+
 // ------------------------------------------------------ gridded block sampling
 // scipy.ndimage.map_coordinates(order=1) on a float32 layer that was pre-dilated 10x at
 // upload: coordinates are clamped (the reference's retry pass uses mode='nearest'), the
 // 2x2 footprint accumulates (v*wy)*wx in float64 in row-major order and rounds to float32.
 __device__ __forceinline__ float bilinear_f32(const float *__restrict__ a, int ny, int nx,
                                               size_t ns, double yi, double xi) {
-  yi = fmin(fmax(yi, 0.0), (double)(ny - 1));
-  xi = fmin(fmax(xi, 0.0), (double)(nx - 1));
-  double fy = floor(yi), fx = floor(xi);
-  int y0 = (int)fy, x0 = (int)fx;
-  double ty = yi - fy, tx = xi - fx;
-  int y1 = y0 + 1 > ny - 1 ? (ny >= 2 ? ny - 2 : 0) : y0 + 1;  // index n mirrors to n-2 (weight 0)
-  int x1 = x0 + 1 > nx - 1 ? (nx >= 2 ? nx - 2 : 0) : x0 + 1;
-  const float *r0 = a + (size_t)y0 * nx * ns, *r1 = a + (size_t)y1 * nx * ns;
-  double v00 = r0[x0 * ns], v01 = r0[x1 * ns], v10 = r1[x0 * ns], v11 = r1[x1 * ns];
-  double wy0 = 1 - ty, wx0 = 1 - tx;
+  Axis ay = axis_fp(yi, ny), ax = axis_fp(xi, nx);
+  const float *r0 = a + (size_t)ay.i0 * nx * ns, *r1 = a + (size_t)ay.i1 * nx * ns;
+  double v00 = r0[ax.i0 * ns], v01 = r0[ax.i1 * ns], v10 = r1[ax.i0 * ns], v11 = r1[ax.i1 * ns];
+  double wy0 = 1 - ay.t, wx0 = 1 - ax.t;
   double t = __dmul_rn(__dmul_rn(v00, wy0), wx0);
-  t = __dadd_rn(t, __dmul_rn(__dmul_rn(v01, wy0), tx));
-  t = __dadd_rn(t, __dmul_rn(__dmul_rn(v10, ty), wx0));
-  t = __dadd_rn(t, __dmul_rn(__dmul_rn(v11, ty), tx));
+  t = __dadd_rn(t, __dmul_rn(__dmul_rn(v01, wy0), ax.t));
+  t = __dadd_rn(t, __dmul_rn(__dmul_rn(v10, ay.t), wx0));
+  t = __dadd_rn(t, __dmul_rn(__dmul_rn(v11, ay.t), ax.t));
   return (float)t;
 }
 
@@ -254,6 +266,7 @@ __device__ __forceinline__ void bracket(const DevSource &s, double t, int &ib, i
 template <int NV>
 __device__ __forceinline__ bool source_sample(const DevSource &s, const int (&vars)[NV], double lon,
                                               double lat, double z, double t, double (&val)[NV]) {
+  if (!s.always_valid && (t < s.tmin || t > s.tmax)) return false;  // OutsideTemporalCoverageError
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
   double x, y;
@@ -416,14 +429,10 @@ template <bool IS3D>
 __device__ __forceinline__ void uv_level(const float *__restrict__ uv, int ny, int nx, int nz,
                                          double yi, double xi, const ZBracket &zb, double &u, double &v,
                                          bool &f32class) {
-  yi = fmin(fmax(yi, 0.0), (double)(ny - 1));
-  xi = fmin(fmax(xi, 0.0), (double)(nx - 1));
-  double fy = floor(yi), fx = floor(xi);
-  int y0 = (int)fy, x0 = (int)fx;
-  double ty = yi - fy, tx = xi - fx, wy0 = 1 - ty, wx0 = 1 - tx;
-  int y1 = y0 + 1 > ny - 1 ? (ny >= 2 ? ny - 2 : 0) : y0 + 1;
+  const Axis ay = axis_fp(yi, ny), ax = axis_fp(xi, nx);
+  const int y0 = ay.i0, y1 = ay.i1, x0 = ax.i0, x1 = ax.i1;
+  const double ty = ay.t, tx = ax.t, wy0 = 1 - ty, wx0 = 1 - tx;
   if (IS3D) {
-    int x1 = x0 + 1 > nx - 1 ? (nx >= 2 ? nx - 2 : 0) : x0 + 1;
     size_t ns = (size_t)nz * 2, k0 = (size_t)zb.iz0 * 2;
     F4 q00 = *(const F4 *)(uv + ((size_t)y0 * nx + x0) * ns + k0);
     F4 q01 = *(const F4 *)(uv + ((size_t)y0 * nx + x1) * ns + k0);
@@ -442,12 +451,13 @@ __device__ __forceinline__ void uv_level(const float *__restrict__ uv, int ny, i
     v = __dadd_rn(__dmul_rn((double)va, zb.wa), __dmul_rn((double)vb, 1 - zb.wa));
     f32class = false;
   } else {
-    bool edge = x0 + 1 > nx - 1;            // x0 == nx-1: partner index mirrors to nx-2, weight 0
-    int xl = edge ? (nx >= 2 ? nx - 2 : 0) : x0;
+    // one 16-byte load per row: nodes (xl, xl+1); the footprint nodes x0, x1 are among them
+    int xl = min(x0, nx >= 2 ? nx - 2 : 0);
     F4 r0 = *(const F4 *)(uv + ((size_t)y0 * nx + xl) * 2);
     F4 r1 = *(const F4 *)(uv + ((size_t)y1 * nx + xl) * 2);
-    float u00 = edge ? r0.z : r0.x, u01 = edge ? r0.x : r0.z, v00 = edge ? r0.w : r0.y, v01 = edge ? r0.y : r0.w;
-    float u10 = edge ? r1.z : r1.x, u11 = edge ? r1.x : r1.z, v10 = edge ? r1.w : r1.y, v11 = edge ? r1.y : r1.w;
+    bool h0 = x0 != xl, h1 = x1 != xl;
+    float u00 = h0 ? r0.z : r0.x, v00 = h0 ? r0.w : r0.y, u01 = h1 ? r0.z : r0.x, v01 = h1 ? r0.w : r0.y;
+    float u10 = h0 ? r1.z : r1.x, v10 = h0 ? r1.w : r1.y, u11 = h1 ? r1.z : r1.x, v11 = h1 ? r1.w : r1.y;
     u = bil4(u00, u01, u10, u11, wy0, ty, wx0, tx);
     v = bil4(v00, v01, v10, v11, wy0, ty, wx0, tx);
     f32class = true;
@@ -536,13 +546,9 @@ __device__ __forceinline__ double var_level(const float *__restrict__ d, int var
     int iy = nearest_index(y, g.ymin, g.yrange, g.ny);
     return d[((size_t)iy * g.nx + ix) * ns];
   }
-  yi = fmin(fmax(yi, 0.0), (double)(g.ny - 1));
-  xi = fmin(fmax(xi, 0.0), (double)(g.nx - 1));
-  double fy = floor(yi), fx = floor(xi);
-  int y0 = (int)fy, x0 = (int)fx;
-  double ty = yi - fy, tx = xi - fx, wy0 = 1 - ty, wx0 = 1 - tx;
-  int y1 = y0 + 1 > g.ny - 1 ? (g.ny >= 2 ? g.ny - 2 : 0) : y0 + 1;
-  int x1 = x0 + 1 > g.nx - 1 ? (g.nx >= 2 ? g.nx - 2 : 0) : x0 + 1;
+  const Axis ay = axis_fp(yi, g.ny), ax = axis_fp(xi, g.nx);
+  const int y0 = ay.i0, y1 = ay.i1, x0 = ax.i0, x1 = ax.i1;
+  const double ty = ay.t, tx = ax.t, wy0 = 1 - ty, wx0 = 1 - tx;
   const float *p00 = d + ((size_t)y0 * g.nx + x0) * ns, *p01 = d + ((size_t)y0 * g.nx + x1) * ns;
   const float *p10 = d + ((size_t)y1 * g.nx + x0) * ns, *p11 = d + ((size_t)y1 * g.nx + x1) * ns;
   if (nzv <= 1) {

@@ -17,9 +17,10 @@ constexpr int BLOCK = 256;
 
 struct PView {  // device pointers of the active set
   long long n;
-  double *lon, *lat, *z, *plon, *plat;
+  double *lon, *lat, *z, *plon, *plat;  // plon/plat: update_previous_state (basemodel/__init__.py:642-668)
+  double *slon, *slat;                  // position of the last environment sample (profiles)
   int *id, *status, *moving;
-  float *wdf, *cdf, *tv;
+  float *wdf, *cdf, *tv, *age;
   float *env[NVAR];
 };
 
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_group(const DevWorld *__restrict_
   env_group<NV>(*W, vars, lon, lat, z, t, out);
 #pragma unroll
   for (int k = 0; k < NV; ++k) p.env[vars[k]][i] = out[k];
-  if (record_prev) { p.plon[i] = lon; p.plat[i] = lat; }
+  if (record_prev) { p.slon[i] = lon; p.slat[i] = lat; }
 }
 
 // fast version: the whole group comes from one gridded reader (odr_field.hip.h)
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_grid(const DevWorld *__restrict__
 #pragma unroll
   for (int k = 0; k < MAXG; ++k)
     if (k < G.nv) p.env[G.var[k]][i] = out[k];
-  if (record_prev) { p.plon[i] = lon; p.plat[i] = lat; }
+  if (record_prev) { p.slon[i] = lon; p.slat[i] = lat; }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_fill_f32(float *a, long long n, float v) {
@@ -108,9 +109,11 @@ __global__ __launch_bounds__(BLOCK) void k_fill_f32(float *a, long long n, float
   if (i < n) a[i] = v;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_record_prev(PView p) {
+__global__ __launch_bounds__(BLOCK) void k_record_prev(PView p, int which) {
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-  if (i < p.n) { p.plon[i] = p.lon[i]; p.plat[i] = p.lat[i]; }
+  if (i >= p.n) return;
+  if (which == 0) { p.slon[i] = p.lon[i]; p.slat[i] = p.lat[i]; }
+  else { p.plon[i] = p.lon[i]; p.plat[i] = p.lat[i]; }
 }
 
 // --------------------------------------------------------------------- advection
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
     double xi = 0, yi = 0, wgt = 0;
     int ib = 0, ia = -1;
     if (src) {
-      double lon = p.plon[i], lat = p.plat[i], x, y;
+      double lon = p.slon[i], lat = p.slat[i], x, y;
       if (src->lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
       else if (src->lon_mode == 2) lon = np_mod(lon, 360.0);
       proj_fwd(src->proj, lon, lat, x, y);
@@ -513,13 +516,9 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
     if (src && cov && src->slot[ib].es[VAR_KZ] == 1 && NZMAX > 1) {
       const DevBlock &bb = src->slot[ib];
       const int ny = bb.ny, nx = bb.nx;
-      yi = fmin(fmax(yi, 0.0), (double)(ny - 1));
-      xi = fmin(fmax(xi, 0.0), (double)(nx - 1));
-      double fy = floor(yi), fx = floor(xi);
-      int y0 = (int)fy, x0 = (int)fx;
-      double ty = yi - fy, tx = xi - fx, wy0 = 1 - ty, wx0 = 1 - tx;
-      int y1 = y0 + 1 > ny - 1 ? (ny >= 2 ? ny - 2 : 0) : y0 + 1;
-      int x1 = x0 + 1 > nx - 1 ? (nx >= 2 ? nx - 2 : 0) : x0 + 1;
+      const Axis ay = axis_fp(yi, ny), ax = axis_fp(xi, nx);
+      const int y0 = ay.i0, y1 = ay.i1, x0 = ax.i0, x1 = ax.i1;
+      const double ty = ay.t, tx = ax.t, wy0 = 1 - ty, wx0 = 1 - tx;
       size_t o00 = ((size_t)y0 * nx + x0) * nzp, o01 = ((size_t)y0 * nx + x1) * nzp;
       size_t o10 = ((size_t)y1 * nx + x0) * nzp, o11 = ((size_t)y1 * nx + x1) * nzp;
       float c00[NZMAX], c01[NZMAX], c10[NZMAX], c11[NZMAX];
@@ -664,7 +663,7 @@ __global__ __launch_bounds__(BLOCK) void k_vbuoy(PView p, double dt) {
 
 // ------------------------------------------------------------ coastline / seafloor
 // interact_with_coastline (basemodel/__init__.py:670-746), precision None
-__global__ __launch_bounds__(BLOCK) void k_coast(PView p, int action, int code,
+__global__ __launch_bounds__(BLOCK) void k_coast(PView p, int action, int code, int seeded_code,
                                                  unsigned long long *n_hit) {
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   bool hit = false;
@@ -676,12 +675,29 @@ __global__ __launch_bounds__(BLOCK) void k_coast(PView p, int action, int code,
         p.moving[i] = 0;
       }
     } else if (action == 2) {
+      if (seeded_code > 0 && p.age[i] == 0.0f) {  // reason='seeded_on_land' (:715-719)
+        if (p.status[i] == 0) p.status[i] = seeded_code;
+        p.moving[i] = 0;
+      }
       p.lon[i] = p.plon[i];
       p.lat[i] = p.plat[i];
     }
   }
   unsigned long long b = __ballot(hit);
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_hit, (unsigned long long)__popcll(b));
+}
+
+// increase_age_and_retire (basemodel/__init__.py:2342-2352): age_seconds += dt (float32);
+// elements older than drift:max_age_seconds are deactivated with reason 'retired'
+__global__ __launch_bounds__(BLOCK) void k_age(PView p, float dt, float max_age, int retired_code) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  float a = __fadd_rn(p.age[i], dt);
+  p.age[i] = a;
+  if (max_age > 0 && a >= max_age) {
+    if (p.status[i] == 0) p.status[i] = retired_code;
+    p.moving[i] = 0;
+  }
 }
 
 // interact_with_seafloor 'lift_to_seafloor' (:748-783)
@@ -761,7 +777,7 @@ __global__ __launch_bounds__(1024) void k_scan_add(unsigned *a, long long n, con
 
 struct CmpArrays {
   int n64, n32;
-  const double *src64[8]; double *dst64[8]; double *dead64[8];
+  const double *src64[8]; double *dst64[8]; double *dead64[8];  // lon lat z plon plat slon slat
   const int *src32[32];   int *dst32[32];   int *dead32[32];
 };
 

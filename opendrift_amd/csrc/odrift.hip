@@ -51,12 +51,12 @@ struct odr_ctx {
 
 struct odr_particles {
   long long cap, n, ndead, dead_cap;
-  double *d64[5];       // lon lat z plon plat
-  double *alt64[5];
+  double *d64[7];       // lon lat z plon plat slon slat
+  double *alt64[7];
   int *i32[3];          // id status moving
   int *alti32[3];
-  float *f32[3];        // wdf cdf tv
-  float *altf32[3];
+  float *f32[4];        // wdf cdf tv age_seconds
+  float *altf32[4];
   float *env[NVAR];
   float *altenv[NVAR];
   double *dead64[3];    // lon lat z of the deactivated store
@@ -72,8 +72,9 @@ static PView view(const odr_particles *p) {
   PView v;
   v.n = p->n;
   v.lon = p->d64[0]; v.lat = p->d64[1]; v.z = p->d64[2]; v.plon = p->d64[3]; v.plat = p->d64[4];
+  v.slon = p->d64[5]; v.slat = p->d64[6];
   v.id = p->i32[0]; v.status = p->i32[1]; v.moving = p->i32[2];
-  v.wdf = p->f32[0]; v.cdf = p->f32[1]; v.tv = p->f32[2];
+  v.wdf = p->f32[0]; v.cdf = p->f32[1]; v.tv = p->f32[2]; v.age = p->f32[3];
   for (int k = 0; k < NVAR; ++k) v.env[k] = p->env[k];
   return v;
 }
@@ -207,9 +208,9 @@ int odr_particles_create(odr_ctx *c, int64_t capacity, odr_particles **out) {
   memset(p, 0, sizeof(*p));
   p->cap = capacity;
   p->dead_cap = capacity;
-  for (int k = 0; k < 5; ++k) HIPCHK(hipMalloc((void **)&p->d64[k], sizeof(double) * (size_t)capacity));
+  for (int k = 0; k < 7; ++k) HIPCHK(hipMalloc((void **)&p->d64[k], sizeof(double) * (size_t)capacity));
   for (int k = 0; k < 3; ++k) HIPCHK(hipMalloc((void **)&p->i32[k], sizeof(int) * (size_t)capacity));
-  for (int k = 0; k < 3; ++k) HIPCHK(hipMalloc((void **)&p->f32[k], sizeof(float) * (size_t)capacity));
+  for (int k = 0; k < 4; ++k) HIPCHK(hipMalloc((void **)&p->f32[k], sizeof(float) * (size_t)capacity));
   HIPCHK(hipMalloc((void **)&p->bcount, sizeof(unsigned) * (size_t)(nblk(capacity) + 1)));
   *out = p;
   return 0;
@@ -219,8 +220,9 @@ int odr_particles_destroy(odr_ctx *c, odr_particles *p) {
   if (!p) return 0;
   (void)hipStreamSynchronize(c->stream);
   auto fr = [](void *q) { if (q) (void)hipFree(q); };
-  for (int k = 0; k < 5; ++k) { fr(p->d64[k]); fr(p->alt64[k]); }
-  for (int k = 0; k < 3; ++k) { fr(p->i32[k]); fr(p->f32[k]); fr(p->alti32[k]); fr(p->altf32[k]); fr(p->dead64[k]); }
+  for (int k = 0; k < 7; ++k) { fr(p->d64[k]); fr(p->alt64[k]); }
+  for (int k = 0; k < 3; ++k) { fr(p->i32[k]); fr(p->alti32[k]); fr(p->dead64[k]); }
+  for (int k = 0; k < 4; ++k) { fr(p->f32[k]); fr(p->altf32[k]); }
   for (int k = 0; k < 2; ++k) fr(p->deadi32[k]);
   for (int k = 0; k < NVAR; ++k) { fr(p->env[k]); fr(p->altenv[k]); }
   fr(p->bcount);
@@ -254,6 +256,8 @@ int odr_particles_append(odr_ctx *c, odr_particles *p, int64_t n, const double *
   if ((rc = put<double>(c, p->d64[2] + o, z, n, 0.0))) return rc;
   if ((rc = put<double>(c, p->d64[3] + o, lon, n, 0.0))) return rc;
   if ((rc = put<double>(c, p->d64[4] + o, lat, n, 0.0))) return rc;
+  if ((rc = put<double>(c, p->d64[5] + o, lon, n, 0.0))) return rc;
+  if ((rc = put<double>(c, p->d64[6] + o, lat, n, 0.0))) return rc;
   if (id) { if ((rc = put<int>(c, p->i32[0] + o, id, n, 0))) return rc; }
   else {
     std::vector<int> ids((size_t)n);
@@ -266,6 +270,7 @@ int odr_particles_append(odr_ctx *c, odr_particles *p, int64_t n, const double *
   if ((rc = put<float>(c, p->f32[0] + o, wdf, n, 0.02f))) return rc;
   if ((rc = put<float>(c, p->f32[1] + o, cdf, n, 1.0f))) return rc;
   if ((rc = put<float>(c, p->f32[2] + o, tv, n, 0.0f))) return rc;
+  if ((rc = put<float>(c, p->f32[3] + o, nullptr, n, 0.0f))) return rc;  // age_seconds = 0
   HIPCHK(hipStreamSynchronize(c->stream));
   p->n += n;
   return 0;
@@ -376,6 +381,7 @@ static int new_source(odr_ctx *c, int kind, int32_t *sid) {
   proj_init(s.proj, nullptr);
   s.xmin = -180; s.xmax = 180; s.ymin = -90; s.ymax = 90;
   s.zmin = -INFINITY; s.zmax = INFINITY;
+  s.tmin = -INFINITY; s.tmax = INFINITY;
   s.lon_mode = 1;
   *sid = c->nsrc++;
   c->hw.nsrc = c->nsrc;
@@ -560,6 +566,7 @@ static bool launch_env_grid(odr_ctx *c, odr_particles *p, const int *grp, int ng
   int sid = w.list[grp[0]][0];
   const DevSource &s = w.src[sid];
   if (s.kind != SRC_GRID || s.nlevels < 1) return false;
+  if (!s.always_valid && (t < s.tmin || t > s.tmax)) return false;
   const DevBlock &g0 = s.slot[s.level_slot[0]];
   for (int k = 0; k < s.nlevels; ++k) {
     const DevBlock &b = s.slot[s.level_slot[k]];
@@ -659,7 +666,7 @@ int odr_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_i
       }
       rec = 0;
     }
-    if (rec) hipLaunchKernelGGL(k_record_prev, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p));
+    if (rec) hipLaunchKernelGGL(k_record_prev, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), 0);
     HIPCHK(hipGetLastError());
   }
   if (out_host) {
@@ -726,12 +733,13 @@ static void host_bracket(const DevSource &s, double t, int &ib, int &ia) {
   ia = (b + 1 < s.nlevels && s.slot[ib].t != t) ? s.level_slot[b + 1] : -1;
 }
 
-static bool uv_fast_source(const odr_ctx *c, int &sid) {
+static bool uv_fast_source(const odr_ctx *c, int &sid, double t_lo, double t_hi) {
   const DevWorld &w = c->hw;
   if (w.nlist[VAR_U] != 1 || w.nlist[VAR_V] != 1 || w.list[VAR_U][0] != w.list[VAR_V][0]) return false;
   sid = w.list[VAR_U][0];
   const DevSource &s = w.src[sid];
   if (s.kind != SRC_GRID || s.nlevels < 1) return false;
+  if (!s.always_valid && (t_lo < s.tmin || t_hi > s.tmax)) return false;  // generic path handles uncovered times
   const DevBlock &g0 = s.slot[s.level_slot[0]];
   for (int k = 0; k < s.nlevels; ++k) {
     const DevBlock &b = s.slot[s.level_slot[k]];
@@ -782,7 +790,7 @@ int odr_advect(odr_ctx *c, odr_particles *p, int scheme, double t, double dt, do
   PView v = view(p);
   int sid = -1;
   if (scheme == 0) hipLaunchKernelGGL(k_advect<0>, g, b, 0, c->stream, c->dw, v, t, dt, (float)factor);
-  else if (uv_fast_source(c, sid) && !getenv("ODR_NO_FAST_PATH")) {
+  else if (uv_fast_source(c, sid, t < t + dt ? t : t + dt, t < t + dt ? t + dt : t) && !getenv("ODR_NO_FAST_PATH")) {
     if (scheme == 1) launch_advect_grid<1>(c, p, sid, t, dt, factor);
     else launch_advect_grid<2>(c, p, sid, t, dt, factor);
   } else if (scheme == 1) hipLaunchKernelGGL(k_advect<1>, g, b, 0, c->stream, c->dw, v, t, dt, (float)factor);
@@ -937,13 +945,37 @@ static int read_counter(odr_ctx *c, int64_t *out) {
   return 0;
 }
 
-int odr_coastline(odr_ctx *c, odr_particles *p, int action, int code, int64_t *n_on_land) {
+// update_previous_state (basemodel/__init__.py:642-668): remember lon/lat for 'previous' actions
+int odr_store_previous(odr_ctx *c, odr_particles *p) {
+  if (p->n == 0) return 0;
+  hipLaunchKernelGGL(k_record_prev, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), 1);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int odr_source_time_coverage(odr_ctx *c, int32_t sid, double t_start, double t_end, int always_valid) {
+  REQUIRE(sid >= 0 && sid < c->nsrc, "unknown source %d", sid);
+  c->hw.src[sid].tmin = t_start;
+  c->hw.src[sid].tmax = t_end;
+  c->hw.src[sid].always_valid = always_valid;
+  c->dirty = true;
+  return 0;
+}
+
+int odr_increase_age(odr_ctx *c, odr_particles *p, double dt, double max_age_seconds, int retired_code) {
+  if (p->n == 0) return 0;
+  hipLaunchKernelGGL(k_age, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), (float)dt, (float)max_age_seconds, retired_code);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int odr_coastline(odr_ctx *c, odr_particles *p, int action, int code, int seeded_on_land_code, int64_t *n_on_land) {
   REQUIRE(action >= 0 && action <= 2, "bad coastline action");
   if (n_on_land) *n_on_land = 0;
   if (action == 0 || p->n == 0) return 0;
   if (!p->env[VAR_LAND]) return fail(ODR_ERR_STATE, "land_binary_mask has not been sampled");
   HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
-  hipLaunchKernelGGL(k_coast, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), action, code, c->counter);
+  hipLaunchKernelGGL(k_coast, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), action, code, seeded_on_land_code, c->counter);
   HIPCHK(hipGetLastError());
   return read_counter(c, n_on_land);
 }
@@ -974,12 +1006,12 @@ int odr_deactivate(odr_ctx *c, odr_particles *p, const uint8_t *mask, int32_t co
 static int ensure_alt(odr_particles *p) {
   size_t cap = (size_t)p->cap;
   // lazily allocate the ping-pong set and the deactivated store
-  for (int k = 0; k < 5; ++k) if (!p->alt64[k]) HIPCHK(hipMalloc((void **)&p->alt64[k], 8 * cap));
+  for (int k = 0; k < 7; ++k) if (!p->alt64[k]) HIPCHK(hipMalloc((void **)&p->alt64[k], 8 * cap));
   for (int k = 0; k < 3; ++k) {
     if (!p->alti32[k]) HIPCHK(hipMalloc((void **)&p->alti32[k], 4 * cap));
-    if (!p->altf32[k]) HIPCHK(hipMalloc((void **)&p->altf32[k], 4 * cap));
     if (!p->dead64[k]) HIPCHK(hipMalloc((void **)&p->dead64[k], 8 * cap));
   }
+  for (int k = 0; k < 4; ++k) if (!p->altf32[k]) HIPCHK(hipMalloc((void **)&p->altf32[k], 4 * cap));
   for (int k = 0; k < 2; ++k) if (!p->deadi32[k]) HIPCHK(hipMalloc((void **)&p->deadi32[k], 4 * cap));
   for (int k = 0; k < NVAR; ++k) if (p->env[k] && !p->altenv[k]) HIPCHK(hipMalloc((void **)&p->altenv[k], 4 * cap));
   return 0;
@@ -987,22 +1019,23 @@ static int ensure_alt(odr_particles *p) {
 
 static void all_arrays(odr_particles *p, CmpArrays &A) {
   memset(&A, 0, sizeof A);
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < 7; ++k) {
     A.src64[k] = p->d64[k]; A.dst64[k] = p->alt64[k];
     A.dead64[k] = k < 3 ? p->dead64[k] : nullptr;
   }
-  A.n64 = 5;
+  A.n64 = 7;
   int m = 0;
   for (int k = 0; k < 3; ++k, ++m) { A.src32[m] = p->i32[k]; A.dst32[m] = p->alti32[k]; A.dead32[m] = k < 2 ? p->deadi32[k] : nullptr; }
-  for (int k = 0; k < 3; ++k, ++m) { A.src32[m] = (const int *)p->f32[k]; A.dst32[m] = (int *)p->altf32[k]; }
+  for (int k = 0; k < 4; ++k, ++m) { A.src32[m] = (const int *)p->f32[k]; A.dst32[m] = (int *)p->altf32[k]; }
   for (int k = 0; k < NVAR; ++k)
     if (p->env[k]) { A.src32[m] = (const int *)p->env[k]; A.dst32[m] = (int *)p->altenv[k]; ++m; }
   A.n32 = m;
 }
 
 static void swap_sets(odr_particles *p) {
-  for (int k = 0; k < 5; ++k) std::swap(p->d64[k], p->alt64[k]);
-  for (int k = 0; k < 3; ++k) { std::swap(p->i32[k], p->alti32[k]); std::swap(p->f32[k], p->altf32[k]); }
+  for (int k = 0; k < 7; ++k) std::swap(p->d64[k], p->alt64[k]);
+  for (int k = 0; k < 3; ++k) std::swap(p->i32[k], p->alti32[k]);
+  for (int k = 0; k < 4; ++k) std::swap(p->f32[k], p->altf32[k]);
   for (int k = 0; k < NVAR; ++k) if (p->env[k]) std::swap(p->env[k], p->altenv[k]);
 }
 

@@ -146,6 +146,9 @@ class Context:
         check(self.lib.odr_block_upload_device(self.h, sid, slot, float(t_epoch), len(names), pi, ptrs, pn,
                                                g['ny'], g['nx'], px))
 
+    def set_time_coverage(self, sid, t_start, t_end, always_valid=False):
+        check(self.lib.odr_source_time_coverage(self.h, sid, float(t_start), float(t_end), int(always_valid)))
+
     def drop_block(self, sid, slot):
         check(self.lib.odr_block_drop(self.h, sid, slot))
 
@@ -304,11 +307,17 @@ class Particles:
     def vertical_buoyancy(self, dt):
         check(self.lib.odr_vertical_buoyancy(self.ctx.h, self.h, float(dt)))
 
-    def coastline(self, action, stranded_code=1):
+    def store_previous(self):
+        check(self.lib.odr_store_previous(self.ctx.h, self.h))
+
+    def coastline(self, action, stranded_code=1, seeded_on_land_code=0):
         a = action if isinstance(action, int) else _abi.COAST[action]
         n = C.c_int64()
-        check(self.lib.odr_coastline(self.ctx.h, self.h, a, stranded_code, C.byref(n)))
+        check(self.lib.odr_coastline(self.ctx.h, self.h, a, stranded_code, seeded_on_land_code, C.byref(n)))
         return n.value
+
+    def increase_age(self, dt, max_age_seconds=0.0, retired_code=0):
+        check(self.lib.odr_increase_age(self.ctx.h, self.h, float(dt), float(max_age_seconds), retired_code))
 
     def seafloor(self):
         n = C.c_int64()

@@ -48,22 +48,28 @@ void orc_fill_nan_towards_seafloor(float *a, int nz, int ny, int nx) {
       if (isnan(a[k * plane + i])) a[k * plane + i] = a[(k - 1) * plane + i];
 }
 
-/* map_coordinates(order=1) footprint along one axis.  mode constant: coordinate
- * outside [0,n-1] => cval; index n reached only with weight 0 and mirrored to
- * n-2.  mode nearest: coordinate clamped, index n -> n-1. */
+/* map_coordinates(order=1) footprint along one axis (probed against SciPy 1.15.3).
+ * mode constant: coordinate outside [0,n-1] => cval; index n is reached only with weight 0 and
+ * is mirrored to n-2.  mode nearest: the coordinate is NOT clamped -- start = floor(c),
+ * t = c - start, and both footprint indices are clamped to [0,n-1]. */
 static int axis(double c, int n, int mode_nearest, int *i0, int *i1, double *t) {
   double fl;
-  if (mode_nearest) {
-    if (c < 0) c = 0;
-    if (c > n - 1) c = n - 1;
-  } else if (!(c >= 0 && c <= n - 1)) {
-    return 0;
-  }
+  if (!mode_nearest && !(c >= 0 && c <= n - 1)) return 0;
+  if (c != c) return 0;
   fl = floor(c);
-  *i0 = (int)fl;
   *t = c - fl;
+  if (fl < -1) fl = -1;
+  if (fl > n) fl = n;
+  *i0 = (int)fl;
   *i1 = *i0 + 1;
-  if (*i1 > n - 1) *i1 = mode_nearest ? n - 1 : (n >= 2 ? n - 2 : 0);
+  if (mode_nearest) {
+    if (*i0 < 0) *i0 = 0;
+    if (*i0 > n - 1) *i0 = n - 1;
+    if (*i1 < 0) *i1 = 0;
+    if (*i1 > n - 1) *i1 = n - 1;
+  } else if (*i1 > n - 1) {
+    *i1 = n >= 2 ? n - 2 : 0;
+  }
   return 1;
 }
 

@@ -81,6 +81,7 @@ typedef struct {
   int nlevels;               /* GRID: resident time levels, ascending t */
   orc_block level[ORC_MAXLEVELS];
   int always_valid;
+  double tmin, tmax;  /* covers_time (variables.py:392-400): reader start_time / end_time */
 } orc_source;
 
 typedef struct {
@@ -146,7 +147,8 @@ void orc_vertical_advection(long n, double *z, const int *moving, const float *w
 /* interact_with_coastline 'stranding' / 'previous' (basemodel/__init__.py:670-746), precision None */
 void orc_coastline(long n, int action, const float *land, double *lon, double *lat,
                    const double *z, const double *prev_lon, const double *prev_lat,
-                   int *status, int *moving, int stranded_code);
+                   int *status, int *moving, int stranded_code, const float *age_seconds,
+                   int seeded_on_land_code);
 
 #ifdef __cplusplus
 }

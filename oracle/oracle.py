@@ -56,7 +56,8 @@ class Source(C.Structure):
                 ('zmin', C.c_double), ('zmax', C.c_double),
                 ('lon_mode', C.c_int), ('mod360_x', C.c_int), ('has_var', C.c_int * NVAR),
                 ('const_val', C.c_double * NVAR), ('params', C.c_double * 8),
-                ('nlevels', C.c_int), ('level', Block * MAXLEVELS), ('always_valid', C.c_int)]
+                ('nlevels', C.c_int), ('level', Block * MAXLEVELS), ('always_valid', C.c_int),
+                ('tmin', C.c_double), ('tmax', C.c_double)]
 
 
 class World(C.Structure):
@@ -177,6 +178,7 @@ class WorldBuilder:
         s.zmin = domain[4] if len(domain) > 4 else -np.inf
         s.zmax = domain[5] if len(domain) > 5 else np.inf
         s.lon_mode = lon_mode
+        s.tmin, s.tmax = -np.inf, np.inf
         for v in variables:
             s.has_var[v] = 1
         self.sources.append(s)
@@ -203,13 +205,15 @@ class WorldBuilder:
         s.params[0], s.params[1], s.params[2], s.params[3] = var, amplitude, period_s, t0
         return idx
 
-    def add_grid(self, proj, x, y, levels, z=None, lon_mode=1, mod360_x=0):
+    def add_grid(self, proj, x, y, levels, z=None, lon_mode=1, mod360_x=0, time_coverage=None):
         """levels: list of (t_epoch, {var_id: float32 array [ny,nx] or [nz,ny,nx]}); x, y in the
         dtype the reader hands out (float32 for the file readers)."""
         variables = sorted(levels[0][1].keys())
         dom = (float(x.min()), float(x.max()), float(y.min()), float(y.max()))
         idx, s = self._new(SRC_GRID, proj, dom, lon_mode, variables)
         s.mod360_x = mod360_x
+        if time_coverage is not None:
+            s.tmin, s.tmax = float(time_coverage[0]), float(time_coverage[1])
         s.nlevels = len(levels)
         zz = None
         if z is not None and np.size(z) > 1:
@@ -338,8 +342,11 @@ def vertical_advection(z, moving, w, dt, at_surface=0):
                                  _p(_f(w), C.c_float), C.c_double(dt), C.c_int(at_surface))
 
 
-def coastline(action, land, lon, lat, z, prev_lon, prev_lat, status, moving, stranded_code):
+def coastline(action, land, lon, lat, z, prev_lon, prev_lat, status, moving, stranded_code, age_seconds=None,
+              seeded_on_land_code=0):
+    age = _f(age_seconds) if age_seconds is not None else None
     lib().orc_coastline(C.c_long(lon.size), C.c_int(action), _p(_f(land), C.c_float), _p(lon, C.c_double),
                         _p(lat, C.c_double), _p(_d(z), C.c_double), _p(_d(prev_lon), C.c_double),
                         _p(_d(prev_lat), C.c_double), _p(status, C.c_int), _p(moving, C.c_int),
-                        C.c_int(stranded_code))
+                        C.c_int(stranded_code), _p(age, C.c_float) if age is not None else None,
+                        C.c_int(seeded_on_land_code))

@@ -195,6 +195,10 @@ static void source_call(const orc_source *s, int nv, const int *vars, long m,
   long j, nc = 0;
   int v;
   for (v = 0; v < nv; ++v) for (j = 0; j < m; ++j) out[v][j] = NAN;
+  if (!s->always_valid && (t < s->tmin || t > s->tmax)) { /* OutsideTemporalCoverageError, variables.py:730-733 */
+    free(x); free(y); free(zc); free(cov);
+    return;
+  }
   for (j = 0; j < m; ++j) {
     double lo = lon[idx[j]], la = lat[idx[j]], xx, yy, xchk;
     if (s->lon_mode == 1) lo = np_mod(lo + 180, 360) - 180; /* modulate_longitude */
@@ -678,7 +682,8 @@ void orc_vertical_advection(long n, double *z, const int *moving, const float *w
  * action 1 = stranding, 2 = previous */
 void orc_coastline(long n, int action, const float *land, double *lon, double *lat,
                    const double *z, const double *prev_lon, const double *prev_lat,
-                   int *status, int *moving, int stranded_code) {
+                   int *status, int *moving, int stranded_code, const float *age_seconds,
+                   int seeded_on_land_code) {
   long i;
   for (i = 0; i < n; ++i) {
     if (land[i] != 1) continue;
@@ -688,7 +693,11 @@ void orc_coastline(long n, int action, const float *land, double *lon, double *l
         moving[i] = 0;
       }
     } else if (action == 2) {
-      lon[i] = prev_lon[i];
+      if (seeded_on_land_code > 0 && age_seconds && age_seconds[i] == 0) { /* :715-719 */
+        if (status[i] == 0) status[i] = seeded_on_land_code;
+        moving[i] = 0;
+      }
+      lon[i] = prev_lon[i]; /* on_land includes the elements just deactivated (:720-730) */
       lat[i] = prev_lat[i];
     }
   }

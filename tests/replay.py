@@ -1,0 +1,229 @@
+"""Replays the reference loop body (basemodel/__init__.py:2193-2284 + OceanDrift.update,
+oceandrift.py:185-211) on two interchangeable back ends:
+
+  OracleBackend -- NumPy arrays + the C oracle (CPU checker)
+  DeviceBackend -- opendrift_amd.device (the product path)
+
+so that the same scenario script is compared with the golden vectors written by the
+reference itself (oracle/gen_golden.py).
+"""
+import numpy as np
+
+from oracle import oracle as orc
+
+V = orc.VAR
+U, VV, W = 'x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity'
+KZ, DEPTH, SSH, LAND = ('ocean_vertical_diffusivity', 'sea_floor_depth_below_sea_level',
+                        'sea_surface_height', 'land_binary_mask')
+XW, YW = 'x_wind', 'y_wind'
+SX, SY = 'sea_surface_wave_stokes_drift_x_velocity', 'sea_surface_wave_stokes_drift_y_velocity'
+HS, HD = 'sea_surface_wave_significant_height', 'horizontal_diffusivity'
+
+
+class OracleBackend:
+    def __init__(self, scenario, lon, lat, z, wdf=0.02):
+        self.sc = scenario
+        n = len(lon)
+        self.lon, self.lat, self.z = lon.copy(), lat.copy(), np.array(z, dtype=np.float64) * np.ones(n)
+        self.ID = np.arange(n, dtype=np.int32)
+        self.status = np.zeros(n, np.int32)
+        self.moving = np.ones(n, np.int32)
+        self.wdf = np.full(n, wdf, np.float32)
+        self.cdf = np.ones(n, np.float32)
+        self.tv = np.zeros(n, np.float32)
+        self.age = np.zeros(n, np.float32)
+        self.plon, self.plat = lon.copy(), lat.copy()
+        self.dead = dict(ID=[], lon=[], lat=[], z=[], status=[])
+        self.env = {}
+
+    def sample(self, names, t, profile=None, nzp=0):
+        w = self.sc.oracle_world()  # fresh blocks: the oracle's NaN dilation is stateful
+        vals = orc.get_environment(w, [V[k] for k in names], self.lon, self.lat, self.z, t)
+        self.env = dict(zip(names, vals))
+        if profile:
+            self.Kp = orc.get_profile(w, V[profile], self.lon, self.lat, t, nzp)
+        self._w = w
+
+    def coast(self, action, code=1, seeded_code=0):
+        orc.coastline({'stranding': 1, 'previous': 2}[action], self.env[LAND], self.lon, self.lat, self.z,
+                      self.plon, self.plat, self.status, self.moving, code, self.age, seeded_code)
+
+    def increase_age(self, dt):
+        self.age = (self.age + np.float32(dt)).astype(np.float32)
+
+    def seafloor(self):
+        floor = -(self.env[DEPTH] + self.env.get(SSH, np.float32(0)))
+        below = self.z < floor
+        self.z[below] = floor[below]
+
+    def compact(self):
+        keep = self.status == 0
+        if keep.all():
+            return
+        for k in ('ID', 'lon', 'lat', 'z', 'status'):
+            self.dead[k].append(getattr(self, k)[~keep])
+        for k in ('lon', 'lat', 'z', 'ID', 'status', 'moving', 'wdf', 'cdf', 'tv', 'age', 'plon', 'plat'):
+            setattr(self, k, getattr(self, k)[keep])
+        self.env = {k: v[keep] for k, v in self.env.items()}
+        if hasattr(self, 'Kp'):
+            self.Kp = np.ascontiguousarray(self.Kp[:, keep])
+
+    def store_previous(self):
+        self.plon, self.plat = self.lon.copy(), self.lat.copy()
+
+    def advect(self, scheme, t, dt):
+        w = self.sc.oracle_world()
+        orc.advect_ocean_current(w, {'euler': 0, 'runge-kutta': 1, 'runge-kutta4': 2}[scheme], self.lon, self.lat,
+                                 self.z, self.moving, self.cdf, self.env[U], self.env[VV], t, dt)
+
+    def wind(self, dt, wdd=0.1, relative=False):
+        orc.advect_wind(self.lon, self.lat, self.z, self.moving, self.wdf, self.env[XW], self.env[YW],
+                        self.env[U], self.env[VV], wdd, int(relative), 1.0, dt)
+
+    def stokes(self, dt, profile=2, hs_mode=1, tp_mode=1):
+        z = np.zeros_like(self.env[SX])
+        orc.stokes_drift(self.lon, self.lat, self.z, self.moving, self.env[SX], self.env[SY],
+                         self.env.get(HS, z), z, self.env[XW], self.env[YW], hs_mode, tp_mode, profile, 1.0, dt)
+
+    def hdiff(self, dt, normals):
+        n = len(self.lon)
+        orc.horizontal_diffusion(self.lon, self.lat, self.moving, self.env[HD], normals[0][:n], normals[1][:n], dt)
+
+    def vmix(self, t, dt, dt_mix, zlevels, uniforms, vadv=True):
+        orc.vertical_mixing(self.z, self.moving, self.tv, self.env[DEPTH], self.env[SSH], zlevels, self.Kp, dt,
+                            dt_mix, 0, uniforms)
+        if vadv:
+            orc.vertical_advection(self.z, self.moving, self.env[W], dt)
+
+    def state(self, n_total):
+        lon, lat, z = np.full(n_total, np.nan), np.full(n_total, np.nan), np.full(n_total, np.nan)
+        status = np.full(n_total, -1, np.int32)
+        lon[self.ID], lat[self.ID], z[self.ID], status[self.ID] = self.lon, self.lat, self.z, self.status
+        for ID, lo, la, zz, st in zip(*[self.dead[k] for k in ('ID', 'lon', 'lat', 'z', 'status')]):
+            lon[ID], lat[ID], z[ID], status[ID] = lo, la, zz, st
+        return lon, lat, z, status
+
+
+class DeviceBackend:
+    def __init__(self, scenario, ctx, lon, lat, z, wdf=0.02):
+        self.sc, self.ctx = scenario, ctx
+        scenario.device(ctx)
+        n = len(lon)
+        self.P = ctx.particles(n)
+        self.P.append(lon, lat, z=np.array(z, dtype=np.float64) * np.ones(n), wind_drift_factor=np.full(n, wdf, np.float32))
+
+    def sample(self, names, t, profile=None, nzp=0):
+        self.P.env_sample(names, t)
+
+    def coast(self, action, code=1, seeded_code=0):
+        self.P.coastline(action, stranded_code=code, seeded_on_land_code=seeded_code)
+
+    def increase_age(self, dt):
+        self.P.increase_age(dt)
+
+    def seafloor(self):
+        self.P.seafloor()
+
+    def compact(self):
+        self.P.compact()
+
+    def store_previous(self):
+        self.P.store_previous()
+
+    def advect(self, scheme, t, dt):
+        self.P.advect(scheme, t, dt)
+
+    def wind(self, dt, wdd=0.1, relative=False):
+        self.P.advect_wind(dt, wind_drift_depth=wdd, relative_wind=relative)
+
+    def stokes(self, dt, profile=2, hs_mode=1, tp_mode=1):
+        self.P.stokes_drift(dt, profile=profile, hs_mode=hs_mode, tp_mode=tp_mode)
+
+    def hdiff(self, dt, normals):
+        n = len(self.P)
+        self.P.hdiffusion(dt, normals=(normals[0][:n], normals[1][:n]))
+
+    def vmix(self, t, dt, dt_mix, zlevels, uniforms, vadv=True):
+        self.P.vmix(t, dt, dt_mix, uniforms=uniforms, fuse_vertical_advection=False if vadv else None)
+
+    def state(self, n_total):
+        a, d = self.P.download(), self.P.download_deactivated()
+        lon, lat, z = np.full(n_total, np.nan), np.full(n_total, np.nan), np.full(n_total, np.nan)
+        status = np.full(n_total, -1, np.int32)
+        for s in (a, d):
+            lon[s['ID']], lat[s['ID']], z[s['ID']], status[s['ID']] = s['lon'], s['lat'], s['z'], s['status']
+        return lon, lat, z, status
+
+
+def replay_c3(B, g, nsteps):
+    """C3-shaped golden: RK4 + vertical mixing + vertical advection, coastline 'previous'."""
+    dt, dt_mix = float(g['dt']), float(g['dt_mix'])
+    n = g['lon'].shape[1]
+    out = []
+    names = [U, VV, W, DEPTH, SSH, LAND]
+    for k in range(nsteps):
+        t = k * dt
+        B.sample(names, t, profile=KZ, nzp=len(g['g_z']))
+        B.coast('previous', seeded_code=1)   # status_categories: ['active', 'seeded_on_land']
+        B.seafloor()
+        B.increase_age(dt)
+        B.compact()
+        B.store_previous()
+        B.advect('runge-kutta4', t, dt)
+        B.vmix(t, dt, dt_mix, g['g_z'], g['uniforms'][k])
+        out.append(B.state(n))
+    return out
+
+
+def replay_c4(B, g, nsteps):
+    """C4-shaped golden: stere grid, RK4 + wind + Stokes + horizontal diffusion + stranding."""
+    dt = float(g['dt'])
+    n = g['lon'].shape[1]
+    out = []
+    names = [U, VV, XW, YW, SX, SY, LAND, HD, HS]
+    for k in range(nsteps):
+        t = k * dt
+        B.sample(names, t)
+        B.coast('stranding', code=1)         # status_categories: ['active', 'stranded', 'missing_data']
+        B.increase_age(dt)
+        B.compact()
+        B.store_previous()
+        B.advect('runge-kutta4', t, dt)
+        B.wind(dt, wdd=0.1)
+        B.stokes(dt, profile=2, hs_mode=1, tp_mode=1)
+        B.hdiff(dt, g['normals'][k])
+        out.append(B.state(n))
+    return out
+
+
+def scenario_c3(g):
+    from scenarios import Scenario
+    names = [U, VV, W, KZ, DEPTH, LAND]
+    levels = [(float(g['g_t'][k]), {nm: g['g_' + nm][k] for nm in names}) for k in range(len(g['g_t']))]
+    return Scenario([('grid', dict(x=g['g_x'], y=g['g_y'], z=g['g_z'], levels=levels))],
+                    fallbacks={U: 0.0, VV: 0.0, W: 0.0, KZ: 0.0, DEPTH: 10000.0, SSH: 0.0})
+
+
+def scenario_c4(g):
+    from scenarios import Scenario
+    from opendrift_amd import synthetic as synth
+    names = [U, VV, XW, YW, SX, SY, LAND]
+    levels = [(float(g['g_t'][k]), {nm: g['g_' + nm][k] for nm in names}) for k in range(len(g['g_t']))]
+    return Scenario([('grid', dict(x=g['g_x'], y=g['g_y'], proj=synth.NORKYST_PROJ, levels=levels,
+                                   time_coverage=(float(g['g_t'][0]), float(g['g_t'][-1])))),
+                     ('constant', {HD: 10.0})],
+                    fallbacks={U: 0.0, VV: 0.0, XW: 0.0, YW: 0.0, SX: 0.0, SY: 0.0, HD: 0.0, HS: 0.0})
+
+
+def compare(states, g, tol_pos, tol_z=None):
+    worst = dict(lon=0.0, lat=0.0, z=0.0)
+    for k, (lon, lat, z, status) in enumerate(states):
+        ref = {q: g[q][k + 1] for q in ('lon', 'lat', 'z', 'status')}
+        assert (np.isnan(lon) == np.isnan(ref['lon'])).all()
+        assert ((status != 0) == (ref['status'] != 0)).all(), 'step %d: deactivation sets differ' % k
+        for q, a in (('lon', lon), ('lat', lat), ('z', z)):
+            worst[q] = max(worst[q], float(np.nanmax(np.abs(a - ref[q]))))
+    assert worst['lon'] < tol_pos and worst['lat'] < tol_pos, worst
+    if tol_z is not None:
+        assert worst['z'] < tol_z, worst
+    return worst

@@ -38,7 +38,8 @@ class Scenario:
             elif kind == 'grid':
                 levels = [(t, {V[k]: arr for k, arr in arrays.items()}) for t, arrays in a['levels']]
                 wb.add_grid(_orc_proj(a.get('proj')), a['x'], a['y'], levels, z=a.get('z'),
-                            lon_mode=a.get('lon_mode', 1), mod360_x=a.get('mod360_x', 0))
+                            lon_mode=a.get('lon_mode', 1), mod360_x=a.get('mod360_x', 0),
+                            time_coverage=a.get('time_coverage'))
         for k, v in self.fallbacks.items():
             wb.set_fallback(V[k], v)
         for k, ids in self.priority.items():
@@ -64,6 +65,8 @@ class Scenario:
                                    lon_mode=a.get('lon_mode', 1), mod360_x=a.get('mod360_x', 0))
                 for slot, (t, arrays) in enumerate(a['levels']):
                     ctx.upload_block(sid, slot, t, arrays)
+                if a.get('time_coverage') is not None:
+                    ctx.set_time_coverage(sid, *a['time_coverage'])
                 names = list(a['levels'][0][1])
             for n in names:
                 lists.setdefault(n, []).append(sid)

@@ -346,6 +346,7 @@ def test_coastline_and_compaction(ctx):
     Q.append(lon, lat)
     Q.env_sample([U], 0.0) if False else None
     Q.env_upload('land_binary_mask', land)
+    Q.store_previous()
     Q.update_positions(np.full(n, 0.5), np.full(n, 0.5), 600.0)
     Q.coastline('previous')
     g2 = Q.download()
@@ -390,3 +391,38 @@ def test_sort_by_cell_is_layout_only(ctx):
     a, b = run(False), run(True)
     for x, y in zip(a, b):
         assert (x == y).all()
+
+
+# ------------------------------------------------------------------ C3 / C4 golden (reference itself)
+def _states_close(a, b, tol_pos, tol_z):
+    for (lo1, la1, z1, s1), (lo2, la2, z2, s2) in zip(a, b):
+        assert (s1 == s2).all()
+        assert _maxerr(lo1, lo2) < tol_pos and _maxerr(la1, la2) < tol_pos and _maxerr(z1, z2) < tol_z, \
+            (_maxerr(lo1, lo2), _maxerr(la1, la2), _maxerr(z1, z2))
+
+
+def test_c3_golden_device(ctx):
+    """RK4 + 3D interpolation + vertical mixing + vertical advection + coastline 'previous' +
+    seeded_on_land deactivation + compaction: device vs the reference's golden vectors and vs the oracle."""
+    import replay
+    g = golden('c3_grid3d_rk4_vmix.npz')
+    nst = g['lon'].shape[0] - 1
+    D = replay.DeviceBackend(replay.scenario_c3(g), ctx, g['lon'][0], g['lat'][0], g['z'][0])
+    dev = replay.replay_c3(D, g, nst)
+    worst = replay.compare(dev, g, tol_pos=1e-7, tol_z=1e-5)
+    O = replay.OracleBackend(replay.scenario_c3(g), g['lon'][0], g['lat'][0], g['z'][0])
+    _states_close(dev, replay.replay_c3(O, g, nst), 1e-10, 1e-8)
+    print('c3 device vs reference:', worst)
+
+
+def test_c4_golden_device(ctx):
+    """Polar-stereographic reader (projection + vector rotation), RK4 + wind + Stokes + horizontal
+    diffusion + stranding + compaction + RK stages beyond the reader's time coverage."""
+    import replay
+    g = golden('c4_stere_rk4_hdiff_strand.npz')
+    D = replay.DeviceBackend(replay.scenario_c4(g), ctx, g['lon'][0], g['lat'][0], g['z'][0], wdf=float(g['wdf']))
+    dev = replay.replay_c4(D, g, 9)
+    worst = replay.compare(dev, g, tol_pos=1e-7)
+    O = replay.OracleBackend(replay.scenario_c4(g), g['lon'][0], g['lat'][0], g['z'][0], wdf=float(g['wdf']))
+    _states_close(dev, replay.replay_c4(O, g, 9), 2e-9, 1e-12)
+    print('c4 device vs reference:', worst)

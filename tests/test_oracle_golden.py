@@ -1,0 +1,148 @@
+"""CPU: the oracle (oracle/*.c) against golden vectors written by the REFERENCE ITSELF
+(oracle/gen_golden.py runs OpenDrift v1.14.10's own update()/get_environment()/ReaderBlock code)
+and against the un-vendored arithmetic it restates (SciPy directly, mpmath for the geodesic).
+
+Position tolerance vs the reference: NumPy's float32 arctan2 on the generating host is 1 ulp off
+the correctly rounded value in ~38 % of the calls (<= 2.4e-7 rad in azimuth), which displaces a
+particle by <= 2.4e-7 * |step|; over the stored windows this stays below 1e-7 deg, two orders
+inside the 1e-6 deg north-star tolerance.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+import replay
+from oracle import oracle as orc
+
+
+def test_geodesic_known_answers():
+    """oracle/geodesic.c vs 34-digit mpmath evaluation of Karney's closed-form integrals
+    (oracle/validate_geodesic.py wrote tests/golden/geodesic_kat.npz)."""
+    rows = golden('geodesic_kat.npz')['rows']
+    lo, la, a2 = orc.geod_fwd(rows[:, 1], rows[:, 0], rows[:, 2], rows[:, 3])
+    dlon = lo - rows[:, 5]
+    dlon -= 360 * np.round(dlon / 360)
+    assert np.abs(la - rows[:, 4]).max() < 5e-14 and np.abs(dlon).max() < 5e-14
+
+
+def test_geodesic_reference_test_values():
+    """Coarse known answers of the reference's own tests: test_models.py:61-64 (1 m/s north-east
+    components for 2 h) and test_environment.py:30-51 (1 m/s east for 1 h from 3E,60N -> 3.0645E)."""
+    lo, la, _ = orc.geod_fwd(3.0, 60.0, 90.0, 3600.0)
+    assert abs(lo[0] - 3.0645) < 5e-4 and abs(la[0] - 60.0) < 1e-3
+    lo, la, _ = orc.geod_fwd(4.0, 60.0, 0.0, 7200.0)
+    assert abs(la[0] - 60.0646) < 1e-3
+
+
+def test_geodesic_inverse_roundtrip():
+    rng = np.random.default_rng(0)
+    n = 300
+    lon, lat = rng.uniform(-170, 170, n), rng.uniform(-80, 80, n)
+    az, s = rng.uniform(-180, 180, n), 10 ** rng.uniform(0, 4.5, n)
+    lo, la, _ = orc.geod_fwd(lon, lat, az, s)
+    az2, s2 = orc.geod_inv(lon, lat, lo, la)
+    d = az2 - az
+    d -= 360 * np.round(d / 360)
+    assert np.abs(s2 - s).max() < 1e-6 and np.abs(d * s).max() < 1e-4   # metres / metre-degrees
+
+
+def test_bilinear_matches_scipy_bitwise():
+    from scipy.ndimage import map_coordinates
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((37, 53)).astype(np.float32)
+    a[rng.uniform(size=a.shape) < 0.08] = np.nan
+    n = 20000
+    yi, xi = rng.uniform(-0.5, 36.5, n), rng.uniform(-0.5, 52.5, n)
+    yi[:30], xi[:30] = np.round(yi[:30]).clip(0, 36), np.round(xi[:30]).clip(0, 52)   # exact nodes incl. edges
+    ref = map_coordinates(a, [yi, xi], cval=np.nan, order=1)
+    lib = orc.lib()
+    import ctypes as C
+    lib.orc_bilinear_f32.restype = C.c_float
+    got = np.array([lib.orc_bilinear_f32(a.ctypes.data_as(C.POINTER(C.c_float)), 37, 53, C.c_double(y), C.c_double(x), 0)
+                    for y, x in zip(yi[:3000], xi[:3000])], np.float32)
+    r = ref[:3000]
+    assert ((got == r) | (np.isnan(got) & np.isnan(r))).all()
+    ref2 = map_coordinates(a, [yi, xi], cval=np.nan, order=1, mode='nearest')
+    got2 = np.array([lib.orc_bilinear_f32(a.ctypes.data_as(C.POINTER(C.c_float)), 37, 53, C.c_double(y), C.c_double(x), 1)
+                     for y, x in zip(yi[:3000], xi[:3000])], np.float32)
+    r2 = ref2[:3000]
+    assert ((got2 == r2) | (np.isnan(got2) & np.isnan(r2))).all()
+
+
+def test_dilation_matches_scipy():
+    from scipy.ndimage import grey_dilation
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((40, 30)).astype(np.float32)
+    a[rng.uniform(size=a.shape) < 0.4] = np.nan
+    a[:6, :5] = np.nan
+    b = a.copy()
+    # expand_numpy_array, interpolators.py:9-20
+    mask = ~np.isfinite(b)
+    minval = np.finfo(np.float32).min
+    b[mask] = minval
+    b[mask] = grey_dilation(b, size=3)[mask]
+    b[b == minval] = np.nan
+    orc.dilate_nan_once(a)
+    assert ((a == b) | (np.isnan(a) & np.isnan(b))).all()
+
+
+def test_ten_fold_predilation_equals_on_demand_dilation():
+    """sampling a block dilated 10x up front with clamped coordinates gives the values
+    of Linear2DInterpolator's stateful dilate-and-retry loop (interpolators.py:127-137)."""
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((60, 80)).astype(np.float32)
+    a[:, 60:] = np.nan
+    a[20:28, 30:36] = np.nan
+    n = 5000
+    yi, xi = rng.uniform(-0.3, 59.3, n), rng.uniform(-0.3, 72.0, n)   # up to 12 cells inland
+    stateful = orc.linear2d_call(a.copy(), yi, xi)
+    pre = a.copy()
+    for _ in range(10):
+        orc.dilate_nan_once(pre)
+    import ctypes as C
+    lib = orc.lib()
+    lib.orc_bilinear_f32.restype = C.c_float
+    got = np.array([lib.orc_bilinear_f32(pre.ctypes.data_as(C.POINTER(C.c_float)), 60, 80, C.c_double(y), C.c_double(x), 1)
+                    for y, x in zip(yi, xi)], np.float32)
+    assert ((got == stateful) | (np.isnan(got) & np.isnan(stateful))).all()
+    assert np.isnan(stateful).sum() > 0      # deeper than 10 cells inland stays NaN in both
+
+
+def test_c1_c2_golden_vs_oracle():
+    from scenarios import Scenario
+    g = golden('c1_constant_euler.npz')
+    w = Scenario([('constant', {replay.U: 0.3, replay.VV: 0.2})]).oracle_world()
+    lon, lat = g['lon'][0].copy(), g['lat'][0].copy()
+    n = lon.size
+    z, mv, cdf = np.zeros(n), np.ones(n, np.int32), np.ones(n, np.float32)
+    for k in range(24):
+        u, v = orc.get_environment(w, [0, 1], lon, lat, z, k * 3600.0)
+        orc.advect_ocean_current(w, 0, lon, lat, z, mv, cdf, u, v, k * 3600.0, 3600.0)
+        assert max(np.abs(lon - g['lon'][k + 1]).max(), np.abs(lat - g['lat'][k + 1]).max()) < 1e-7
+    for name, scheme in (('euler', 0), ('rungekutta', 1), ('rungekutta4', 2)):
+        g = golden('c2_double_gyre_%s.npz' % name)
+        w = Scenario([('double_gyre', dict(A=0.1, epsilon=0.25, omega=0.628, t0=0.0))]).oracle_world()
+        lon, lat = g['lon'][0].copy(), g['lat'][0].copy()
+        n = lon.size
+        z, mv, cdf = np.zeros(n), np.ones(n, np.int32), np.ones(n, np.float32)
+        for k in range(g['lon'].shape[0] - 1):
+            u, v = orc.get_environment(w, [0, 1], lon, lat, z, k * 0.1)
+            orc.advect_ocean_current(w, scheme, lon, lat, z, mv, cdf, u, v, k * 0.1, 0.1)
+        assert max(np.abs(lon - g['lon'][-1]).max(), np.abs(lat - g['lat'][-1]).max()) < 1e-9
+
+
+def test_c3_golden_vs_oracle():
+    g = golden('c3_grid3d_rk4_vmix.npz')
+    B = replay.OracleBackend(replay.scenario_c3(g), g['lon'][0], g['lat'][0], g['z'][0])
+    worst = replay.compare(replay.replay_c3(B, g, g['lon'].shape[0] - 1), g, tol_pos=1e-7, tol_z=1e-6)
+    print('c3 oracle vs reference:', worst)
+
+
+def test_c4_golden_vs_oracle():
+    g = golden('c4_stere_rk4_hdiff_strand.npz')
+    B = replay.OracleBackend(replay.scenario_c4(g), g['lon'][0], g['lat'][0], g['z'][0], wdf=float(g['wdf']))
+    # 9 of the 10 stored steps: in the last one the model time has left the reader's time coverage and
+    # the reference deactivates everything as 'missing_data' (host bookkeeping, not on the device path);
+    # step 8 still exercises the uncovered RK sub-stage times (fallback velocity)
+    worst = replay.compare(replay.replay_c4(B, g, 9), g, tol_pos=1e-7)
+    print('c4 oracle vs reference:', worst)
