@@ -1,0 +1,565 @@
+"""OceanDrift model API on the MI355X hot path.
+
+Mirrors the reference's model surface: the constructor, set_config /
+get_config, add_reader, seed_elements, run, the live state (`elements`, `environment`, `time`,
+`steps_calculation`, num_elements_*), `status_categories`, and the overridable hooks
+(`update`, `prepare_run`, `advect_ocean_current`, `advect_wind`, `stokes_drift`,
+`vertical_mixing`, `update_positions`, `horizontal_diffusion`, `interact_with_coastline`, ...)
+with the reference's names and argument meaning:
+
+    opendrift/models/basemodel/__init__.py  OpenDriftSimulation (run loop :2193-2284)
+    opendrift/models/oceandrift.py          OceanDrift.update (:185-211), required_variables (:61-83)
+    opendrift/models/physics_methods.py     advect_ocean_current / advect_wind / stokes_drift
+
+Every per-particle operation is a call into libodrift_hip.so; this file is orchestration only.
+Out of scope (host-side features of the reference that are not on the path): plotting, netCDF
+export, the GSHHG global landmask (`general:use_auto_landmask`), lazy readers.
+"""
+import logging
+from datetime import datetime, timedelta
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _abi
+from .config import Configurable, CONFIG_LEVEL_BASIC, CONFIG_LEVEL_ADVANCED, CONFIG_LEVEL_ESSENTIAL
+from .device import Context
+from .readers import BaseReader, ConstantReader, DeviceReaderBinding, _epoch
+
+logger = logging.getLogger('opendrift_amd')
+
+
+class WrongMode(Exception):
+    """opendrift/errors.py:1-3"""
+
+
+class OpenDriftSimulation(Configurable):
+    required_variables = {}
+    element_properties = {}   # name -> default (in addition to the LagrangianArray core variables)
+
+    def __init__(self, seed=0, loglevel=None, device=0, rng='device', iomodule=None, logfile=None):
+        super().__init__()
+        if loglevel is not None:
+            logger.setLevel(loglevel)
+        self.mode = 'Config'
+        self._ctx, self._device, self._seed = None, device, seed or 0   # the device context is created on first use
+        self.rng = rng                       # 'device' (Philox by ID) | 'numpy' (np.random in reference call order)
+        if seed is not None:
+            np.random.seed(seed)             # basemodel/__init__.py:326
+        self.status_categories = ['active']
+        self.readers = {}                    # name -> DeviceReaderBinding (created by _finalize_environment)
+        self._readers_host = {}              # name -> (reader, variables) as given to add_reader
+        self.priority_list = {}              # variable -> [reader names]
+        self.required_variables = {k: dict(v) for k, v in type(self).required_variables.items()}
+        self._sched = None                   # scheduled elements (host arrays, seeding order = ID)
+        self.P = None
+        self.steps_calculation = 0
+        self.time = self.start_time = self.time_step = None
+        self.newly_seeded = 0
+        self.sort_every = 8
+        self._add_config({
+            'general:use_auto_landmask': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_ADVANCED,
+                                          'description': 'GSHHG landmask (not available on the device path)'},
+            'general:coastline_action': {'type': 'enum', 'enum': ['none', 'stranding', 'previous'],
+                                         'default': 'stranding', 'level': CONFIG_LEVEL_BASIC, 'description': ''},
+            'general:coastline_approximation_precision': {'type': 'float', 'default': None, 'min': 0.0001, 'max': 0.005,
+                                                          'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'general:time_step_minutes': {'type': 'float', 'min': .01, 'max': 1440, 'default': 60,
+                                          'level': CONFIG_LEVEL_BASIC, 'description': ''},
+            'general:time_step_output_minutes': {'type': 'float', 'min': 1, 'max': 1440, 'default': None,
+                                                 'level': CONFIG_LEVEL_BASIC, 'description': ''},
+            'seed:number': {'type': 'int', 'default': 1, 'min': 1, 'max': 100000000000,
+                            'level': CONFIG_LEVEL_ESSENTIAL, 'description': ''},
+            'drift:max_age_seconds': {'type': 'float', 'default': None, 'min': 0, 'max': 1e12,
+                                      'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'drift:advection_scheme': {'type': 'enum', 'enum': ['euler', 'runge-kutta', 'runge-kutta4'],
+                                       'default': 'euler', 'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'drift:current_uncertainty': {'type': 'float', 'default': 0, 'min': 0, 'max': 5,
+                                          'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'drift:wind_uncertainty': {'type': 'float', 'default': 0, 'min': 0, 'max': 5,
+                                       'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'drift:relative_wind': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'drift:max_speed': {'type': 'float', 'default': 1, 'min': 0, 'max': 100,
+                                'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'readers:max_number_of_fails': {'type': 'int', 'default': 1, 'min': 0, 'max': 1e6,
+                                            'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+        })
+        for v, spec in self.required_variables.items():   # environment.py:41-76
+            self._add_config({
+                'environment:constant:%s' % v: {'type': 'float', 'default': None, 'min': -1e12, 'max': 1e12,
+                                                'level': CONFIG_LEVEL_BASIC, 'description': ''},
+                'environment:fallback:%s' % v: {'type': 'float', 'default': spec.get('fallback'), 'min': -1e12,
+                                                'max': 1e12, 'level': CONFIG_LEVEL_BASIC, 'description': ''}})
+        for prop, default in self.element_properties.items():
+            self._add_config({'seed:%s' % prop: {'type': 'float', 'default': default, 'min': -1e12, 'max': 1e12,
+                                                 'level': CONFIG_LEVEL_ESSENTIAL, 'description': ''}})
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = Context(device=self._device, seed=self._seed)
+        return self._ctx
+
+    # ------------------------------------------------------------------ mode machine (:136-190)
+    def _require(self, *modes):
+        if self.mode not in modes:
+            raise WrongMode('Cannot call this method in mode %s (allowed: %s)' % (self.mode, modes))
+
+    def set_config(self, key, value):
+        self._require('Config')
+        super().set_config(key, value)
+
+    # ------------------------------------------------------------------ readers (:613-632)
+    def add_reader(self, readers, variables=None, first=False):
+        self._require('Config')
+        if not isinstance(readers, (list, tuple)):
+            readers = [readers]
+        for r in readers:
+            if not (hasattr(r, 'get_variables') and hasattr(r, 'variables')):
+                raise TypeError('Please provide Reader object')
+            name = r.name
+            i = 1
+            while name in self._readers_host:
+                i += 1
+                name = '%s_%d' % (r.name, i)
+            vs = [v for v in (variables or r.variables)]
+            if getattr(r, 'device_kind', None) == 'double_gyre':
+                vs = ['x_sea_water_velocity', 'y_sea_water_velocity', 'land_binary_mask']
+            self._readers_host[name] = (r, vs)
+            for v in vs:
+                lst = self.priority_list.setdefault(v, [])
+                if first:
+                    lst.insert(0, name)
+                else:
+                    lst.append(name)
+
+    def _finalize_environment(self, t0, t1):
+        """Environment.finalize (environment.py:139-211): constant readers from config, priority lists,
+        fallbacks; the first blocks of the gridded readers are uploaded here."""
+        consts = {v: self.get_config('environment:constant:%s' % v) for v in self.required_variables}
+        consts = {v: c for v, c in consts.items() if c is not None}
+        if consts:   # environment.py:172-182: constant reader with highest priority
+            self._readers_host['constant_reader_config'] = (ConstantReader(consts), list(consts))
+            for v in consts:
+                self.priority_list.setdefault(v, []).insert(0, 'constant_reader_config')
+        for name, (r, vs) in self._readers_host.items():
+            self.readers[name] = DeviceReaderBinding(self.ctx, r, variables=vs)
+        if self.get_config('general:use_auto_landmask'):
+            raise NotImplementedError('general:use_auto_landmask needs the GSHHG dataset; add a reader or a '
+                                      'constant/fallback for land_binary_mask (out of scope, DESIGN.md 8)')
+        for b in self.readers.values():
+            b.ensure_levels(t0, t1)
+        for v in self.required_variables:
+            ids = [self.readers[n].sid for n in self.priority_list.get(v, []) if self.readers[n].sid is not None]
+            self.ctx.bind(v, ids[:4], self.get_config('environment:fallback:%s' % v))
+
+    # ------------------------------------------------------------------ seeding (:1033-1330)
+    def seed_elements(self, lon, lat, time, radius=0, number=None, number_per_point=None,
+                      radius_type='gaussian', **kwargs):
+        self._require('Config', 'Ready')
+        lon, lat = np.atleast_1d(lon).ravel().astype(float), np.atleast_1d(lat).ravel().astype(float)
+        radius = np.atleast_1d(radius).ravel()
+        time = list(np.atleast_1d(time))
+        if lat.max() > 90 or lat.min() < -90:
+            raise ValueError('Latitude must be between -90 and 90 degrees')
+        if len(lon) != len(lat):
+            raise ValueError('Lon and lat must have same lengths')
+        if len(lon) > 1:
+            if number_per_point is not None:
+                if number is not None:
+                    raise ValueError('Both number and number_per_point is provided')
+                number = number_per_point * len(lon)
+            if number is not None:
+                if number % len(lon) != 0:
+                    raise ValueError('Lon and lat have length %s, but number is %s, which is not a multiple'
+                                     % (len(lon), number))
+                npp = int(number / len(lon))
+                if npp > 1:
+                    lon, lat = np.repeat(lon, npp), np.repeat(lat, npp)
+            number = len(lon)
+        else:
+            if number is None:
+                number = len(time) if len(time) > 2 else self.get_config('seed:number')
+            lon, lat = lon * np.ones(number), lat * np.ones(number)
+        if len(time) != number and len(time) > 1:
+            if len(time) == 2:
+                td = (time[1] - time[0]) / (number - 1)
+                time = [time[0] + i * td for i in range(number)]
+            else:
+                raise ValueError('Time array has length %s, must be 1, 2 or %s' % (len(time), number))
+        if len(time) == 1:
+            time = time * number
+        if radius.max() > 0:   # :1151-1170
+            if radius_type == 'gaussian':
+                x = np.random.randn(number) * radius
+                y = np.random.randn(number) * radius
+                az, dist = np.degrees(np.arctan2(x, y)), np.sqrt(x * x + y * y)
+            elif radius_type == 'uniform':
+                az = np.random.rand(number) * 360
+                dist = np.sqrt(np.random.uniform(0, 1, number)) * radius
+            else:
+                raise ValueError('radius_type must be gaussian or uniform')
+            lon, lat = self._geod_fwd(lon, lat, az, dist)
+        z = kwargs.pop('z', None)
+        if z is None:
+            z = self.get_config('seed:z') if 'seed:z' in self._config else 0.0
+        props = {}
+        for prop in self.element_properties:
+            val = kwargs.pop(prop, None)
+            props[prop] = np.float32(self.get_config('seed:%s' % prop) if val is None else val) * np.ones(number, np.float32)
+        if kwargs:
+            raise TypeError('Redundant arguments: %s' % list(kwargs))
+        # LagrangianArray stores lon/lat/z as float32 at seeding (elements.py:71-88,156-158)
+        new = dict(lon=np.float32(lon).astype(np.float64), lat=np.float32(lat).astype(np.float64),
+                   z=(np.float32(z) * np.ones(number, np.float32)).astype(np.float64),
+                   time=np.array(time, dtype=object), **props)
+        if self._sched is None:
+            self._sched = new
+        else:
+            for k in new:
+                self._sched[k] = np.concatenate([self._sched[k], new[k]])
+        self._sched['ID'] = np.arange(len(self._sched['lon']), dtype=np.int32)
+        st = min(self._sched['time'])
+        self.start_time = st if self.start_time is None else min(self.start_time, st)
+        if self.mode == 'Config':
+            self.mode = 'Ready'
+
+    def _geod_fwd(self, lon, lat, az, dist):
+        """pyproj.Geod.fwd on the device (the only geodesic in the product is the HIP one)."""
+        n = len(lon)
+        T = self.ctx.particles(n)
+        T.append(lon, lat)
+        a = np.radians(az)
+        T.update_positions(dist * np.sin(a), dist * np.cos(a), 1.0)
+        d = T.download()
+        T.close()
+        return d['lon'], d['lat']
+
+    # ------------------------------------------------------------------ counts (:841-867)
+    def num_elements_active(self):
+        return len(self.P) if self.P is not None else 0
+
+    def num_elements_deactivated(self):
+        return self.P.count()[1] if self.P is not None else 0
+
+    def num_elements_scheduled(self):
+        return 0 if self._sched is None else int(self._released_mask().size - self._released_mask().sum())
+
+    def num_elements_total(self):
+        return 0 if self._sched is None else len(self._sched['lon'])
+
+    def _released_mask(self):
+        if not hasattr(self, '_released'):
+            self._released = np.zeros(len(self._sched['lon']), bool)
+        return self._released
+
+    @property
+    def elements(self):
+        """Live float64 state of the active elements (device order), like o.elements in the reference."""
+        d = self.P.download()
+        return SimpleNamespace(**d)
+
+    @property
+    def elements_deactivated(self):
+        return SimpleNamespace(**self.P.download_deactivated())
+
+    @property
+    def environment(self):
+        return SimpleNamespace(**{v: self.P.env_download(v) for v in self._sampled})
+
+    # ------------------------------------------------------------------ loop pieces
+    def release_elements(self):   # :909-934
+        s, rel = self._sched, self._released_mask()
+        if self.time_step.total_seconds() >= 0:
+            idx = np.array([(not rel[i]) and self.time <= s['time'][i] < self.time + self.time_step
+                            for i in range(len(rel))]) if not self._all_at_start else ~rel
+        else:
+            idx = np.array([(not rel[i]) and self.time >= s['time'][i] > self.time + self.time_step
+                            for i in range(len(rel))])
+        n = int(idx.sum())
+        self.newly_seeded = n
+        if n == 0:
+            return
+        kw = {p: s[p][idx] for p in self.element_properties if p in ('wind_drift_factor', 'current_drift_factor',
+                                                                     'terminal_velocity')}
+        self.P.append(s['lon'][idx], s['lat'][idx], z=s['z'][idx], id=s['ID'][idx], **kw)
+        rel[idx] = True
+
+    def deactivate_elements(self, mask, reason='deactivated'):   # :1774-1795
+        if reason not in self.status_categories:
+            self.status_categories.append(reason)
+        self.P.deactivate(mask, self.status_categories.index(reason))
+
+    def _status_code(self, reason):
+        if reason not in self.status_categories:
+            self.status_categories.append(reason)
+        return self.status_categories.index(reason)
+
+    def interact_with_coastline(self, final=False):   # :670-746
+        action = self.get_config('general:coastline_action')
+        if action == 'none' or 'land_binary_mask' not in self._sampled or self.num_elements_active() == 0:
+            return
+        if self.get_config('general:coastline_approximation_precision'):
+            raise NotImplementedError('coastline_approximation_precision needs the GSHHG landmask (out of scope)')
+        if final:
+            self.P.env_sample(['land_binary_mask'], _epoch(self.time))
+        if action == 'stranding':
+            self.P.coastline('stranding', stranded_code=self._status_code('stranded'))
+        else:
+            self.P.coastline('previous', seeded_on_land_code=self._status_code('seeded_on_land')
+                             if self.newly_seeded else 0)
+
+    def interact_with_seafloor(self):   # :748-783, 'lift_to_seafloor'
+        if 'sea_floor_depth_below_sea_level' not in self.priority_list or self.num_elements_active() == 0:
+            return
+        if self.get_config('general:seafloor_action', 'lift_to_seafloor') == 'lift_to_seafloor':
+            self.P.seafloor()
+
+    def update_positions(self, x_vel, y_vel):   # :4631-4669
+        self._require('Run')
+        self.P.update_positions(x_vel, y_vel, self.time_step.total_seconds())
+
+    def horizontal_diffusion(self):   # :1746-1772
+        if 'horizontal_diffusivity' not in self.required_variables or self.num_elements_active() == 0:
+            return
+        dt = self.time_step.total_seconds()
+        if self.rng == 'numpy':
+            if self.P.reduce_scalars()['D_max'] == 0:
+                return
+            n = self.num_elements_active()
+            self.P.hdiffusion(dt, normals=(np.random.normal(scale=1, size=n), np.random.normal(scale=1, size=n)))
+        else:
+            self.P.hdiffusion(dt, step=self.steps_calculation)
+
+    def get_environment(self):
+        """Environment.get_environment for all required variables (:2238-2246) + uncertainty (:869-891)."""
+        t = _epoch(self.time)
+        names = list(self.required_variables)
+        self.P.env_sample(names, t)
+        self._sampled = names
+        n = self.num_elements_active()
+        for (vx, vy, key) in (('x_sea_water_velocity', 'y_sea_water_velocity', 'drift:current_uncertainty'),
+                              ('x_wind', 'y_wind', 'drift:wind_uncertainty')):
+            std = self.get_config(key)
+            if std and std > 0 and vx in names and vy in names:
+                if self.rng == 'numpy':
+                    self.P.env_add_noise(vx, vy, std, normals=(np.random.normal(0, std, n), np.random.normal(0, std, n)))
+                else:
+                    self.P.env_add_noise(vx, vy, std, step=self.steps_calculation)
+
+    def prepare_run(self):
+        pass
+
+    def update(self):
+        raise NotImplementedError('Any trajectory model implementation must define an update method.')
+
+    # ------------------------------------------------------------------ run (:1828-2340)
+    def run(self, time_step=None, steps=None, time_step_output=None, duration=None, end_time=None,
+            outfile=None, export_variables=None, export_buffer_length=100, stop_on_error=False):
+        self._require('Ready')
+        if self._sched is None:
+            raise ValueError('Please seed elements before starting a run.')
+        if outfile is not None:
+            raise NotImplementedError('netCDF export is host-side I/O outside the hot path')
+        if sum(x is not None for x in (steps, duration, end_time)) != 1:
+            raise ValueError('Exactly one of the keywords steps, duration and end_time must be provided')
+        if time_step is None:
+            time_step = timedelta(minutes=self.get_config('general:time_step_minutes'))
+        if not isinstance(time_step, timedelta):
+            time_step = timedelta(seconds=time_step)
+        self.time_step = time_step
+        if time_step_output is None:
+            m = self.get_config('general:time_step_output_minutes')
+            time_step_output = time_step if m is None else timedelta(minutes=m)
+        if not isinstance(time_step_output, timedelta):
+            time_step_output = timedelta(seconds=time_step_output)
+        if time_step.total_seconds() < 0:
+            self.start_time = max(self._sched['time'])
+        if duration is not None:
+            steps = int(round(duration.total_seconds() / abs(time_step.total_seconds())))
+        elif end_time is not None:
+            steps = int(round(abs((end_time - self.start_time).total_seconds() / time_step.total_seconds())))
+        self.expected_steps_calculation = steps
+        out_every = max(1, int(round(abs(time_step_output.total_seconds() / time_step.total_seconds()))))
+        # skip_if conditionals of required_variables (:1899-1906)
+        for vn, var in list(self.required_variables.items()):
+            if 'skip_if' in var:
+                key, op, val = var['skip_if']
+                if self.get_config(key) is val:
+                    self.required_variables.pop(vn)
+        self.time = self.start_time
+        self._all_at_start = all(t == self.start_time for t in self._sched['time'])
+        self._finalize_environment(self.start_time, self.start_time + steps * time_step)
+        n_total = self.num_elements_total()
+        self.P = self.ctx.particles(n_total)
+        self.mode = 'Run'
+        self.prepare_run()
+        nout = steps // out_every + 1
+        hist = {k: np.full((n_total, nout), np.nan, np.float32) for k in ('lon', 'lat', 'z')}  # float32 history (:2094)
+        hist['status'] = np.full((n_total, nout), -1, np.int32)
+        times = []
+        grid_sid = next((b.sid for b in self.readers.values() if b.is_grid() and b.sid is not None), None)
+        for i in range(steps):
+            try:
+                if self.rng == 'device' and grid_sid is not None and self.sort_every and i % self.sort_every == 0 \
+                        and self.num_elements_active() > 65536:
+                    self.P.sort_by_cell(grid_sid)     # device layout maintenance, before release
+                self.release_elements()
+                if self.num_elements_active() == 0 and self.num_elements_scheduled() > 0:
+                    self.steps_calculation += 1
+                    self.time = self.time + self.time_step
+                    continue
+                for b in self.readers.values():
+                    b.ensure_levels(self.time, self.time + self.time_step)
+                self.get_environment()
+                self.interact_with_coastline()
+                self.interact_with_seafloor()
+                if i % out_every == 0:
+                    self._state_to_buffer(hist, i // out_every, times)
+                max_age = self.get_config('drift:max_age_seconds')
+                self.P.increase_age(self.time_step.total_seconds(), max_age or 0.0,
+                                    self._status_code('retired') if max_age else 0)
+                self.P.compact()
+                self.P.store_previous()
+                if self.num_elements_active() > 0:
+                    self.update()
+                elif self.num_elements_scheduled() == 0:
+                    raise ValueError('No more active or scheduled elements, quitting.')
+                self.horizontal_diffusion()
+                self.time = self.time + self.time_step
+                self.steps_calculation += 1
+            except Exception as e:
+                if stop_on_error or self.steps_calculation <= 1:
+                    raise
+                logger.warning('The simulation stopped before requested end time was reached: %s', e)
+                break
+        self.interact_with_coastline(final=True)
+        if (self.steps_calculation % out_every) == 0 and self.steps_calculation // out_every < nout:
+            self._state_to_buffer(hist, self.steps_calculation // out_every, times)
+        self.mode = 'Result'
+        self.result = dict(time=times, **hist)
+        return self.result
+
+    def _state_to_buffer(self, hist, k, times):   # :2384-2499 (host copy of the live state at output steps)
+        times.append(self.time)
+        for d in (self.P.download(), self.P.download_deactivated()):
+            if len(d['ID']) == 0:
+                continue
+            for q in ('lon', 'lat', 'z'):
+                hist[q][d['ID'], k] = d[q]
+            hist['status'][d['ID'], k] = d['status']
+
+
+class OceanDrift(OpenDriftSimulation):
+    """opendrift/models/oceandrift.py:54-211"""
+    element_properties = {'wind_drift_factor': 0.02, 'current_drift_factor': 1.0, 'terminal_velocity': 0.0}
+    required_variables = {
+        'x_sea_water_velocity': {'fallback': 0},
+        'y_sea_water_velocity': {'fallback': 0},
+        'sea_surface_height': {'fallback': 0},
+        'x_wind': {'fallback': 0},
+        'y_wind': {'fallback': 0},
+        'upward_sea_water_velocity': {'fallback': 0, 'skip_if': ['drift:vertical_advection', 'is', False]},
+        'ocean_vertical_diffusivity': {'fallback': 0, 'skip_if': ['drift:vertical_mixing', 'is', False],
+                                       'profiles': True},
+        'horizontal_diffusivity': {'fallback': 0},
+        'sea_surface_wave_significant_height': {'fallback': 0},
+        'sea_surface_wave_stokes_drift_x_velocity': {'fallback': 0, 'skip_if': ['drift:stokes_drift', 'is', False]},
+        'sea_surface_wave_stokes_drift_y_velocity': {'fallback': 0, 'skip_if': ['drift:stokes_drift', 'is', False]},
+        'ocean_mixed_layer_thickness': {'fallback': 50, 'skip_if': ['drift:vertical_mixing', 'is', False]},
+        'sea_floor_depth_below_sea_level': {'fallback': 10000},
+        'land_binary_mask': {'fallback': None},
+    }
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._add_config({   # oceandrift.py:118-183
+            'drift:vertical_advection': {'type': 'bool', 'default': True, 'level': CONFIG_LEVEL_BASIC, 'description': ''},
+            'drift:vertical_advection_at_surface': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_ADVANCED,
+                                                    'description': ''},
+            'drift:vertical_mixing': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_BASIC, 'description': ''},
+            'drift:vertical_mixing_at_surface': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_ADVANCED,
+                                                 'description': ''},
+            'vertical_mixing:timestep': {'type': 'float', 'min': 0.1, 'max': 3600, 'default': 60,
+                                         'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'vertical_mixing:diffusivitymodel': {'type': 'enum', 'default': 'environment',
+                                                 'enum': ['environment', 'stepfunction', 'windspeed_Sundby1983',
+                                                          'windspeed_Large1994', 'constant'],
+                                                 'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'drift:wind_drift_depth': {'type': 'float', 'default': 0.1, 'min': 0, 'max': 10,
+                                       'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'drift:stokes_drift': {'type': 'bool', 'default': True, 'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'drift:stokes_drift_profile': {'type': 'enum', 'default': 'Phillips',
+                                           'enum': ['monochromatic', 'exponential', 'Phillips', 'windsea_swell'],
+                                           'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'general:seafloor_action': {'type': 'enum', 'default': 'lift_to_seafloor',
+                                        'enum': ['none', 'lift_to_seafloor', 'deactivate', 'previous'],
+                                        'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'seed:z': {'type': 'float', 'default': 0, 'min': -10000, 'max': 0, 'level': CONFIG_LEVEL_ESSENTIAL,
+                       'description': ''},
+        })
+        self._set_config_default('drift:max_speed', 2)
+
+    # ---- PhysicsMethods (physics_methods.py:611-848)
+    def advect_ocean_current(self, factor=1):
+        self.P.advect(self.get_config('drift:advection_scheme'), _epoch(self.time),
+                      self.time_step.total_seconds(), factor)
+
+    def advect_wind(self, factor=1):
+        self.P.advect_wind(self.time_step.total_seconds(), self.get_config('drift:wind_drift_depth'),
+                           self.get_config('drift:relative_wind'), factor)
+
+    def stokes_drift(self, factor=1):
+        if self.get_config('drift:stokes_drift') is False:
+            return
+        profile = {'monochromatic': 0, 'exponential': 1, 'Phillips': 2}.get(self.get_config('drift:stokes_drift_profile'))
+        if profile is None:
+            raise NotImplementedError('windsea_swell Stokes profile is not on the device path')
+        r = self.P.reduce_scalars(self.get_config('drift:wind_drift_depth'))
+        if r['stokes_sum_max'] == 0:
+            return
+        # provenance of Hs / Tp (physics_methods.py:893-943, :809-814)
+        hs_mode = 0 if r['hs_max'] > 0 else (1 if r['wind_speed_max'] > 0 else 2)
+        tp_mode = 1 if r['wind_speed_max'] >= 0 else 2   # Tp is not an OceanDrift variable: from wind (omega=5 when calm)
+        self.P.stokes_drift(self.time_step.total_seconds(), profile, hs_mode, tp_mode, factor)
+
+    def vertical_mixing(self):   # oceandrift.py:397-571, diffusivity model 'environment'
+        if self.get_config('drift:vertical_mixing') is False:
+            return
+        if self.get_config('vertical_mixing:diffusivitymodel') not in ('environment', 'constant'):
+            raise NotImplementedError('wind-parameterised diffusivity profiles are not on the device path')
+        dt, dt_mix = self.time_step.total_seconds(), self.get_config('vertical_mixing:timestep')
+        fuse = None
+        if self.get_config('drift:vertical_advection') and type(self).vertical_advection is OceanDrift.vertical_advection:
+            fuse = bool(self.get_config('drift:vertical_advection_at_surface'))
+            self._vadv_fused = True
+        kw = dict(mix_at_surface=self.get_config('drift:vertical_mixing_at_surface'), fuse_vertical_advection=fuse)
+        if self.rng == 'numpy':
+            n, nt = self.num_elements_active(), abs(int(dt / dt_mix))
+            uni = np.stack([np.random.random(n) for _ in range(nt)])
+            self.P.vmix(_epoch(self.time), dt, dt_mix, uniforms=uni, **kw)
+        else:
+            self.P.vmix(_epoch(self.time), dt, dt_mix, step=self.steps_calculation, **kw)
+
+    def vertical_buoyancy(self):   # :352-368
+        self.P.vertical_buoyancy(self.time_step.total_seconds())
+
+    def vertical_advection(self):   # :315-350
+        if self.get_config('drift:vertical_advection') is False or getattr(self, '_vadv_fused', False):
+            self._vadv_fused = False
+            return
+        self.P.vertical_advection(self.time_step.total_seconds(), self.get_config('drift:vertical_advection_at_surface'))
+
+    def update_terminal_velocity(self, Tprofiles=None, Sprofiles=None, z_index=None):
+        pass
+
+    def update(self):   # oceandrift.py:185-211
+        self.advect_ocean_current()
+        self.advect_wind()
+        self.stokes_drift()
+        self.update_terminal_velocity()
+        if self.get_config('drift:vertical_mixing') is True:
+            self.vertical_mixing()
+        else:
+            self.vertical_buoyancy()
+        self.vertical_advection()

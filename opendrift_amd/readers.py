@@ -1,0 +1,244 @@
+"""Reader plugin surface -- host side.
+
+Same contract as the reference's readers (opendrift/readers/basereader/): a reader sets
+`proj4`, `xmin/xmax/ymin/ymax`, `variables`, `start_time/end_time/time_step` (or `times`),
+optionally `z`, and implements
+
+    get_variables(requested_variables, time=None, x=None, y=None, z=None) -> dict
+
+returning, for a StructuredReader, one block {'x','y','z','time', var: [ny,nx] | [nz,ny,nx]}
+(basereader/structured.py:125-147), or, for a ContinuousReader, arrays at the exact positions
+(basereader/continuous.py:20-29).  `get_variables` stays on the host, so existing reader code
+works unmodified; the interception point is the ReaderBlock: when a new time level is needed
+its block is uploaded once (interpolation/structured.py:15-94 becomes odr_block_upload) and
+every ReaderBlock.interpolate becomes a device gather.  Analytic readers that the device
+evaluates in closed form (constant, double gyre, oscillating) are recognised by `device_kind`.
+"""
+from datetime import datetime, timedelta
+
+import numpy as np
+
+from . import projection
+
+
+def _epoch(t):
+    return (t - datetime(1970, 1, 1)).total_seconds()
+
+
+class BaseReader:
+    """Attributes of basereader/__init__.py:107-118 + variables.ReaderDomain (variables.py:20-46)."""
+    name = 'reader'
+    proj4 = '+proj=latlong'
+    xmin = xmax = ymin = ymax = None
+    zmin, zmax = -np.inf, np.inf
+    start_time = end_time = time_step = times = None
+    always_valid = False
+    z = None
+    variables = []
+    device_kind = None   # 'constant' | 'double_gyre' | 'oscillating' | None (gridded)
+
+    def __init__(self):
+        self.proj = projection.Proj(self.proj4)
+        self.is_lazy = False
+        self.number_of_fails = 0
+        if self.start_time is not None and self.time_step is not None and self.times is None:
+            n = int(round((self.end_time - self.start_time).total_seconds() / self.time_step.total_seconds())) + 1
+            self.times = [self.start_time + k * self.time_step for k in range(n)]
+
+    # ---- variables.py:111-143
+    def lonlat2xy(self, lon, lat):
+        return self.proj(lon, lat)
+
+    def xy2lonlat(self, x, y):
+        return self.proj(x, y, inverse=True)
+
+    def covers_time(self, time):   # variables.py:392-400
+        if self.always_valid or self.start_time is None:
+            return True
+        return self.start_time <= time <= self.end_time
+
+    def nearest_time(self, time):  # variables.py:402-443 -> indices of the bracketing levels
+        if self.times is None or len(self.times) == 1:
+            return 0, 0
+        import bisect
+        ib = max(0, bisect.bisect_right(self.times, time) - 1)
+        ia = ib if self.times[ib] == time else min(ib + 1, len(self.times) - 1)
+        return ib, ia
+
+    def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
+        raise NotImplementedError
+
+
+class ContinuousReader(BaseReader):
+    pass
+
+
+class StructuredReader(BaseReader):
+    pass
+
+
+class ConstantReader(ContinuousReader):
+    """reader_constant.Reader (readers/reader_constant.py): the same value everywhere."""
+    device_kind = 'constant'
+
+    def __init__(self, parameter_value_map=None, **kwargs):
+        m = dict(parameter_value_map or kwargs)
+        if 'element_ID' in m:
+            raise NotImplementedError('per-element constants are not on the device path')
+        self._parameter_value_map = {k: float(np.atleast_1d(v)[0]) for k, v in m.items()}
+        self.variables = list(self._parameter_value_map)
+        self.proj4 = '+proj=latlong'
+        self.xmin, self.xmax, self.ymin, self.ymax = -180, 180, -90, 90
+        self.name = 'constant_reader'
+        super().__init__()
+
+    def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
+        out = {'time': time, 'x': x, 'y': y, 'z': z}
+        for v in requested_variables:
+            out[v] = self._parameter_value_map[v] * np.ones(np.shape(x))
+        return out
+
+
+class DoubleGyreReader(ContinuousReader):
+    """reader_double_gyre.Reader (readers/reader_double_gyre.py:24-79)."""
+    device_kind = 'double_gyre'
+
+    def __init__(self, initial_time=datetime(2000, 1, 1), epsilon=0.1, omega=0.628, A=0.25,
+                 proj4='+proj=stere +lat_0=0 +lon_0=0 +lat_ts=0 +units=m +a=6.371e+06 +e=0 +no_defs'):
+        self.name = 'double_gyre'
+        self.proj4 = proj4
+        self.xmin, self.xmax, self.ymin, self.ymax = 0., 2., 0., 1.
+        self.A, self.epsilon, self.omega, self.initial_time = A, epsilon, omega, initial_time
+        self.variables = ['x_sea_water_velocity', 'y_sea_water_velocity']
+        super().__init__()
+
+    def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
+        t = (time - self.initial_time).total_seconds()
+        a = self.epsilon * np.sin(self.omega * t)
+        b = 1 - 2 * self.epsilon * np.sin(self.omega * t)
+        f = a * x * x + b * x
+        dfdx = 2 * a * x + b
+        return {'x_sea_water_velocity': -np.pi * self.A * np.sin(np.pi * f) * np.cos(np.pi * y),
+                'y_sea_water_velocity': np.pi * self.A * np.cos(np.pi * f) * np.sin(np.pi * y) * dfdx,
+                'land_binary_mask': np.zeros(np.shape(x)), 'time': time, 'x': x, 'y': y}
+
+
+class OscillatingReader(ContinuousReader):
+    """reader_oscillating.Reader (readers/reader_oscillating.py:23-59)."""
+    device_kind = 'oscillating'
+
+    def __init__(self, variable, amplitude, period=timedelta(hours=24), phase=0, zero_time=datetime(2017, 1, 1)):
+        self.variables = [variable]
+        self.amplitude, self.period_seconds, self.zero_time = amplitude, period.total_seconds(), zero_time
+        self.proj4 = '+proj=latlong +datum=WGS84'
+        self.xmin, self.xmax, self.ymin, self.ymax = -180, 180, -90, 90
+        self.name = 'oscillating_reader'
+        super().__init__()
+
+    def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
+        phase = ((time - self.zero_time).total_seconds() / self.period_seconds) * np.pi
+        return {'time': time, 'x': x, 'y': y, 'z': z,
+                self.variables[0]: self.amplitude * np.sin(phase) * np.ones(np.shape(x))}
+
+
+class GridReader(StructuredReader):
+    """In-memory StructuredReader with time levels and optional z levels (the shape of
+    reader_constant_2d.py:20-49 / reader_netCDF_CF_generic / reader_ROMS_native output blocks).
+    arrays: {variable: [nt, ny, nx] or [nt, nz, ny, nx]}."""
+
+    def __init__(self, x, y, times, arrays, z=None, proj4='+proj=latlong', name='grid_reader'):
+        self.proj4, self.name = proj4, name
+        self.x, self.y, self.z = np.asarray(x), np.asarray(y), (None if z is None else np.asarray(z, dtype=np.float64))
+        self.xmin, self.xmax = float(self.x.min()), float(self.x.max())
+        self.ymin, self.ymax = float(self.y.min()), float(self.y.max())
+        self.times = list(times)
+        self.start_time, self.end_time = self.times[0], self.times[-1]
+        self.time_step = (self.times[1] - self.times[0]) if len(self.times) > 1 else None
+        self.arrays = arrays
+        self.variables = list(arrays)
+        super().__init__()
+
+    def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
+        it = self.times.index(time)
+        out = {'x': self.x, 'y': self.y, 'time': time, 'z': self.z if self.z is not None else 0}
+        for v in requested_variables:
+            out[v] = self.arrays[v][it]
+        return out
+
+
+class DeviceReaderBinding:
+    """Device image of one reader: constant/analytic source, or a grid source whose time levels
+    (ReaderBlocks) are uploaded on demand.  Stands where StructuredReader keeps
+    var_block_before/after (structured.py:121-123)."""
+    NSLOTS = 4
+
+    def __init__(self, ctx, reader, variables=None):
+        self.ctx, self.reader = ctx, reader
+        self.variables = [v for v in (variables or reader.variables)]
+        self.slots = {}      # time index -> slot
+        kind = getattr(reader, 'device_kind', None)
+        if kind == 'constant':
+            self.sid = ctx.add_constant({v: reader._parameter_value_map[v] for v in self.variables})
+        elif kind == 'double_gyre':
+            self.sid = ctx.add_double_gyre(A=reader.A, epsilon=reader.epsilon, omega=reader.omega,
+                                           t0=_epoch(reader.initial_time))
+            self.variables = ['x_sea_water_velocity', 'y_sea_water_velocity', 'land_binary_mask']
+        elif kind == 'oscillating':
+            self.sid = ctx.add_oscillating(reader.variables[0], reader.amplitude, reader.period_seconds,
+                                           _epoch(reader.zero_time))
+        else:
+            self.sid = None  # created with the first block (the grid comes with it)
+        if kind and reader.start_time is not None:
+            ctx.set_time_coverage(self.sid, _epoch(reader.start_time), _epoch(reader.end_time), reader.always_valid)
+
+    def is_grid(self):
+        return getattr(self.reader, 'device_kind', None) is None
+
+    def ensure_levels(self, t0, t1, extent=None, broadcast=None):
+        """Make the time levels bracketing [t0, t1] resident (datetime arguments)."""
+        r = self.reader
+        if not self.is_grid():
+            return
+        lo, hi = (t0, t1) if t0 <= t1 else (t1, t0)
+        if r.times is None:
+            need = [0]
+        else:
+            if not (r.covers_time(lo) or r.covers_time(hi)):
+                return
+            lo_c, hi_c = max(lo, r.start_time), min(hi, r.end_time)
+            need = list(range(r.nearest_time(lo_c)[0], r.nearest_time(hi_c)[1] + 1))
+        need = need[-self.NSLOTS:]
+        for k in list(self.slots):
+            if k not in need and len(self.slots) + len([n for n in need if n not in self.slots]) > self.NSLOTS:
+                self.ctx.drop_block(self.sid, self.slots.pop(k))
+        for k in need:
+            if k in self.slots:
+                continue
+            time = r.times[k] if r.times is not None else None
+            x = y = None
+            if extent is not None:
+                x, y = np.array(extent[0]), np.array(extent[1])
+            block = r.get_variables(self.variables, time, x, y, np.array([0.0]))
+            if broadcast is not None:
+                block = broadcast(block)
+            bx, by = np.asarray(block['x']), np.asarray(block['y'])
+            bz = block.get('z', None)
+            if self.sid is None:
+                proj = projection.parse_proj4(r.proj4)
+                zz = np.atleast_1d(bz) if bz is not None and np.size(bz) > 1 else None
+                lon_mode = 1
+                if proj['kind'] == 'latlong' and r.xmin is not None and r.xmin >= 0 and r.xmax > 180:
+                    lon_mode = 2
+                dom = (float(r.xmin), float(r.xmax), float(r.ymin), float(r.ymax), float(r.zmin), float(r.zmax))
+                self.sid = self.ctx.add_grid(bx, by, z=zz, proj=proj, lon_mode=lon_mode, domain=dom)
+                if r.start_time is not None:
+                    self.ctx.set_time_coverage(self.sid, _epoch(r.start_time), _epoch(r.end_time), r.always_valid)
+            else:
+                g = self.ctx._grids[self.sid]
+                if (len(by), len(bx)) != (g['ny'], g['nx']):
+                    raise ValueError('reader %s changed its block shape between time levels' % r.name)
+            free = [s for s in range(self.NSLOTS) if s not in self.slots.values()]
+            slot = free[0]
+            arrays = {v: block[v] for v in self.variables}
+            self.ctx.upload_block(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays)
+            self.slots[k] = slot

@@ -1,0 +1,118 @@
+"""GPU: the OceanDrift model API (opendrift_amd.oceandrift) run end to end -- seed_elements, add_reader,
+set_config, run() -- against the golden vectors of the reference's own runs (oracle/gen_golden.py used the
+same calls on the reference's OceanDrift)."""
+from datetime import datetime, timedelta
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from opendrift_amd import readers, synthetic as synth
+from opendrift_amd.oceandrift import OceanDrift
+
+pytestmark = pytest.mark.gpu
+T0 = datetime(2020, 1, 1)
+
+
+def _final(o, n):
+    lon, lat, z = np.full(n, np.nan), np.full(n, np.nan), np.full(n, np.nan)
+    for d in (o.elements, o.elements_deactivated):
+        lon[d.ID], lat[d.ID], z[d.ID] = d.lon, d.lat, d.z
+    return lon, lat, z
+
+
+def test_c1_run_constant_euler(has_gpu):
+    g = golden('c1_constant_euler.npz')
+    o = OceanDrift(loglevel=50, seed=0)
+    o.add_reader(readers.ConstantReader({'x_sea_water_velocity': 0.3, 'y_sea_water_velocity': 0.2}))
+    o.set_config('environment:constant:land_binary_mask', 0)
+    o.set_config('drift:advection_scheme', 'euler')
+    np.random.seed(0)
+    o.seed_elements(lon=4.0, lat=60.0, number=200, radius=5000, time=T0)
+    # the seeding cloud itself: np.random + device geodesic, float32-quantised like LagrangianArray
+    assert np.abs(o._sched['lon'] - g['lon'][0]).max() < 1e-6 and np.abs(o._sched['lat'] - g['lat'][0]).max() < 1e-6
+    res = o.run(time_step=3600, steps=24)
+    lon, lat, _ = _final(o, 200)
+    assert np.abs(lon - g['lon'][-1]).max() < 1e-6 and np.abs(lat - g['lat'][-1]).max() < 1e-6
+    assert res['lon'].dtype == np.float32 and res['lon'].shape == (200, 25)
+    assert np.abs(res['lon'][:, 10] - g['lon'][10]).max() < 1e-5     # float32 history buffer
+    assert o.steps_calculation == 24 and o.num_elements_active() == 200 and o.mode == 'Result'
+
+
+def test_c2_run_double_gyre_rk4():
+    g = golden('c2_double_gyre_rungekutta4.npz')
+    o = OceanDrift(loglevel=50)
+    o.add_reader(readers.DoubleGyreReader(initial_time=T0, epsilon=0.25, omega=0.628, A=0.1))
+    o.set_config('environment:fallback:land_binary_mask', 0)
+    o.set_config('drift:advection_scheme', 'runge-kutta4')
+    o.seed_elements(lon=g['lon'][0], lat=g['lat'][0], time=T0)
+    o.run(time_step=0.1, steps=100)
+    lon, lat, _ = _final(o, g['lon'].shape[1])
+    assert np.abs(lon - g['lon'][-1]).max() < 1e-9 and np.abs(lat - g['lat'][-1]).max() < 1e-9
+
+
+def _grid_reader(g, names, proj4='+proj=latlong', z=None):
+    times = [T0 + timedelta(seconds=float(t)) for t in g['g_t']]
+    return readers.GridReader(g['g_x'], g['g_y'], times, {k: g['g_' + k] for k in names}, z=z, proj4=proj4)
+
+
+def test_c3_run_grid3d_vmix_numpy_rng():
+    """rng='numpy': np.random is drawn in the reference's call order, so the stochastic run reproduces the
+    reference's trajectories (vertical mixing included), not just their statistics."""
+    g = golden('c3_grid3d_rk4_vmix.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity',
+             'ocean_vertical_diffusivity', 'sea_floor_depth_below_sea_level', 'land_binary_mask']
+    o = OceanDrift(loglevel=50, seed=0, rng='numpy')
+    o.add_reader(_grid_reader(g, names, z=g['g_z']))
+    o.set_config('drift:advection_scheme', 'runge-kutta4')
+    o.set_config('drift:vertical_mixing', True)
+    o.set_config('vertical_mixing:timestep', 60)
+    o.set_config('general:coastline_action', 'previous')
+    o.seed_elements(lon=g['lon'][0], lat=g['lat'][0], z=g['z'][0], time=T0)
+    o.run(time_step=600, steps=8)
+    lon, lat, z = _final(o, g['lon'].shape[1])
+    assert np.abs(lon - g['lon'][-1]).max() < 1e-7 and np.abs(lat - g['lat'][-1]).max() < 1e-7
+    assert np.abs(z - g['z'][-1]).max() < 1e-5
+    assert o.status_categories == ['active', 'seeded_on_land'] and o.num_elements_deactivated() == 4
+
+
+def test_c4_run_stere_hdiff_stranding_numpy_rng():
+    g = golden('c4_stere_rk4_hdiff_strand.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'x_wind', 'y_wind',
+             'sea_surface_wave_stokes_drift_x_velocity', 'sea_surface_wave_stokes_drift_y_velocity', 'land_binary_mask']
+    o = OceanDrift(loglevel=50, seed=0, rng='numpy')
+    o.add_reader(_grid_reader(g, names, proj4=synth.NORKYST_PROJ4))
+    o.set_config('drift:advection_scheme', 'runge-kutta4')
+    o.set_config('environment:constant:horizontal_diffusivity', 10)
+    o.set_config('general:coastline_action', 'stranding')
+    o.seed_elements(lon=g['lon'][0], lat=g['lat'][0], time=T0, wind_drift_factor=float(g['wdf']))
+    o.run(time_step=900, steps=8)
+    lon, lat, _ = _final(o, g['lon'].shape[1])
+    k = 8
+    assert np.abs(lon - g['lon'][k]).max() < 1e-7 and np.abs(lat - g['lat'][k]).max() < 1e-7
+    assert o.num_elements_deactivated() == int((g['status'][k] != 0).sum())
+    assert 'stranded' in o.status_categories
+
+
+def test_device_rng_run_is_reproducible_and_order_independent():
+    g = golden('c3_grid3d_rk4_vmix.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity',
+             'ocean_vertical_diffusivity', 'sea_floor_depth_below_sea_level', 'land_binary_mask']
+
+    def run(sort_every):
+        o = OceanDrift(loglevel=50, seed=7)
+        o.sort_every = sort_every
+        o.add_reader(_grid_reader(g, names, z=g['g_z']))
+        o.set_config('drift:advection_scheme', 'runge-kutta4')
+        o.set_config('drift:vertical_mixing', True)
+        o.set_config('general:coastline_action', 'previous')
+        o.set_config('environment:constant:horizontal_diffusivity', 5)
+        n = 70000
+        rng = np.random.default_rng(1)
+        o.seed_elements(lon=rng.uniform(1, 8, n), lat=rng.uniform(60.5, 65.5, n), z=-rng.uniform(0, 40, n), time=T0)
+        o.run(time_step=600, steps=6)
+        return _final(o, n)
+
+    a, b = run(0), run(2)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
