@@ -279,6 +279,12 @@ def main():
     nact = len(P)
     ach = BYTES[a.workload]['advect'] * nact / (k_ms * 1e-3)
 
+    traffic = None
+    pj = os.path.join(ROOT, 'profiles', 'r01_%s_pmc.json' % a.workload)
+    if os.path.exists(pj):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/)
+        pm = json.load(open(pj))
+        if pm.get('particles') == n:
+            traffic = (pm['FETCH_SIZE_bytes'] + pm['WRITE_SIZE_bytes']) / 1e9
     if rank == 0:
         out = {
             'metric': 'particle-steps/sec (RK4, 3D interp)', 'value': units / el_max, 'unit': 'particle-steps/s',
@@ -293,7 +299,8 @@ def main():
                        'particles_per_gpu': n, 'particles_total': n * world, 'time_step_s': wl.dt,
                        'parallelism': 'particle-sharded x%d, field block broadcast once per time level' % world},
             'roofline': {'bound': 'hbm', 'kernel': 'k_advect<RK4>', 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9,
-                         'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': None,
+                         'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': traffic, 'traffic_unit': 'GB per launch (PMC)',
+                         'algorithmic_gb_per_launch': BYTES[a.workload]['advect'] * nact / 1e9,
                          'kernel_ms': k_ms, 'algorithmic_bytes_per_particle': BYTES[a.workload]['advect'],
                          'step_bytes_per_particle': BYTES[a.workload]['step'],
                          'step_frac': BYTES[a.workload]['step'] * (units / el_max) / world / HBM_PEAK},

@@ -1,0 +1,67 @@
+"""CPU, world_size 2, gloo: the N>1 plumbing of the particle-sharded path (opendrift_amd.distributed):
+block broadcast from the rank that owns the host Reader, shard partition, scalar all-reduce."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from opendrift_amd import distributed as D, synthetic
+    r, lr, w = D.init(backend='gloo')
+    assert (r, w) == (rank, world)
+    g = synthetic.grid3d(nx=24, ny=16, nz=4, nt=2, seed=3)
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'land_binary_mask']
+    arrays = {k: g[k][0] for k in names} if rank == 0 else None      # only rank 0 "reads" the block
+    tens = D.broadcast_block(arrays, src=0)
+    ok = all(np.array_equal(tens[k].numpy(), g[k][0], equal_nan=True) for k in names)
+    lo, hi = D.shard_range(1001, rank, world)
+    tot = D.allreduce_scalars([hi - lo, float(rank)], 'sum')
+    mx = D.allreduce_scalars([float(lo)], 'max')
+    D.barrier()
+    q.put((rank, ok, lo, hi, tot.tolist(), mx.tolist()))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_broadcast_shard_allreduce_gloo_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, ok0, lo0, hi0, tot0, mx0), (r1, ok1, lo1, hi1, tot1, mx1) = res
+    assert ok0 and ok1                                   # every rank holds the identical block
+    assert (lo0, hi0, lo1, hi1) == (0, 501, 501, 1001)   # contiguous, exhaustive, disjoint
+    assert tot0 == tot1 == [1001.0, 1.0] and mx0 == mx1 == [501.0]
+
+
+def test_shard_range_properties():
+    from opendrift_amd.distributed import shard_range
+    for n in (0, 1, 7, 1000, 12345677):
+        for w in (1, 2, 3, 8):
+            edges = [shard_range(n, r, w) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[k][1] == edges[k + 1][0] for k in range(w - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
