@@ -23,6 +23,7 @@ enum { PROJ_LATLONG = 0, PROJ_STERE_EQUIT_SPHERE = 1, PROJ_STERE_POLAR = 2 };
 struct DevProj {
   int kind, south;
   double a, es, e, lon0, lat0, x0, y0, k0, akm1;
+  double cchi[4];  // conformal -> geodetic latitude series (Snyder 3-5), used by rotation_angle
 };
 
 struct DevBlock {
@@ -79,9 +80,13 @@ __device__ __forceinline__ double wrap_pi(double lam) {
   return lam;
 }
 
+// Snyder 15-9: t = tan(pi/4 - phi/2) / ((1 - e sin phi)/(1 + e sin phi))^(e/2)
+//             = tan(pi/4 - phi/2) * exp(e * atanh(e sin phi))      (|e sin phi| < 0.09: 7-term series)
 __device__ __forceinline__ double tsfn(double phi, double sinphi, double e) {
-  double es = e * sinphi;
-  return tan(0.5 * (kHalfPi - phi)) / pow((1 - es) / (1 + es), 0.5 * e);
+#pragma clang fp contract(fast)
+  double es = e * sinphi, q = es * es;
+  double ath = es * (1 + q * (1.0 / 3 + q * (1.0 / 5 + q * (1.0 / 7 + q * (1.0 / 9 + q * (1.0 / 11 + q * (1.0 / 13)))))));
+  return tan(0.5 * (kHalfPi - phi)) * exp(e * ath);
 }
 
 __device__ __forceinline__ void proj_fwd(const DevProj &p, double lon_deg, double lat_deg,
@@ -146,17 +151,54 @@ __device__ __forceinline__ void proj_inv(const DevProj &p, double x, double y, d
 // finite difference, as the forward azimuth of the WGS84 geodesic between the two
 // points.  For a 10 m line the Gauss mid-latitude solution (azimuth at the mid point
 // minus half the meridian convergence) equals Karney's inverse to O((s/R)^3) ~ 1e-18 rad.
-__device__ __forceinline__ double rotation_angle(const DevProj &p, double x, double y) {
+// Only the DIFFERENCES (dphi, dlam) of the two inverse projections enter, so the polar
+// ellipsoidal case uses the closed series for the geodetic latitude (Snyder eq. 3-5,
+// 2e-12 rad, the error is common to both points) instead of the fixed-point iteration.
+__device__ __forceinline__ void proj_inv_diff(const DevProj &p, double x, double y, double dy, double &phim,
+                                              double &dphi, double &dlam) {
 #pragma clang fp contract(fast)
+  if (p.kind == PROJ_STERE_POLAR && p.es != 0) {
+    double X = (x - p.x0) / p.a, Y1 = (y - p.y0) / p.a, Y2 = (y + dy - p.y0) / p.a;
+    if (!p.south) { Y1 = -Y1; Y2 = -Y2; }
+    double ph[2], lam[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      double Y = k ? Y2 : Y1;
+      double chi = kHalfPi - 2 * atan(sqrt(X * X + Y * Y) / p.akm1);
+      double s2, c2;
+      sincos(2 * chi, &s2, &c2);
+      // sum c_k sin(2k chi), Clenshaw on the multiple angles
+      double ar = 2 * c2, y1 = p.cchi[3], y0 = ar * y1 + p.cchi[2];
+      y1 = ar * y0 - y1 + p.cchi[1];
+      y0 = ar * y1 - y0 + p.cchi[0];
+      ph[k] = chi + s2 * y0;
+      lam[k] = atan2(X, Y);
+    }
+    double sgn = p.south ? -1.0 : 1.0;
+    phim = 0.5 * sgn * (ph[0] + ph[1]);
+    dphi = sgn * (ph[1] - ph[0]);
+    dlam = lam[1] - lam[0];
+    if (dlam > kPi) dlam -= 2 * kPi;
+    if (dlam < -kPi) dlam += 2 * kPi;
+    return;
+  }
   double lo1, la1, lo2, la2;
   proj_inv(p, x, y, lo1, la1);
-  proj_inv(p, x, y + 10.0, lo2, la2);
+  proj_inv(p, x, y + dy, lo2, la2);
+  phim = 0.5 * (la1 + la2) * kDeg;
+  dphi = (la2 - la1) * kDeg;
+  dlam = ang_normalize(lo2 - lo1) * kDeg;
+}
+
+__device__ __forceinline__ double rotation_angle(const DevProj &p, double x, double y) {
+#pragma clang fp contract(fast)
+  double phim, dphi, dlam;
+  proj_inv_diff(p, x, y, 10.0, phim, dphi, dlam);
   const GeodConst &g = c_geod;
-  double phim = 0.5 * (la1 + la2) * kDeg, sphi, cphi;
+  double sphi, cphi;
   sincos(phim, &sphi, &cphi);
   double w2 = 1 - g.e2 * sphi * sphi, w = sqrt(w2);
   double M = g.a * (1 - g.e2) / (w2 * w), N = g.a / w;
-  double dlam = ang_normalize(lo2 - lo1) * kDeg, dphi = (la2 - la1) * kDeg;
   double az_mid = atan2(dlam * N * cphi, dphi * M);
   double az1 = az_mid - 0.5 * dlam * sphi;
   return -az1;  // rot_angle_rad = -rot_angle_vectors_rad

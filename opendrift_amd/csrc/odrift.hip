@@ -357,6 +357,13 @@ static void proj_init(DevProj &p, const odr_proj_desc *d) {
   p.k0 = d->k0;
   p.south = d->lat0_deg < 0;
   p.akm1 = 2 * d->k0;
+  {
+    double e2 = d->es, e4 = e2 * e2, e6 = e4 * e2, e8 = e4 * e4;  // Snyder eq. 3-5
+    p.cchi[0] = e2 / 2 + 5 * e4 / 24 + e6 / 12 + 13 * e8 / 360;
+    p.cchi[1] = 7 * e4 / 48 + 29 * e6 / 240 + 811 * e8 / 11520;
+    p.cchi[2] = 7 * e6 / 120 + 81 * e8 / 1120;
+    p.cchi[3] = 4279 * e8 / 161280;
+  }
   if (d->kind == PROJ_STERE_POLAR) {  // Snyder 21-33/21-34 scale constant
     double phits = fabs(d->lat_ts_deg) * kDeg, e = p.e;
     if (d->es == 0) {
@@ -813,7 +820,8 @@ int odr_update_positions(odr_ctx *c, odr_particles *p, const double *u, const do
 static int reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind) {
   hipLaunchKernelGGL(k_red_init, dim3(1), dim3(64), 0, c->stream, c->red);
   if (p->n > 0)
-    hipLaunchKernelGGL(k_reduce, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), wdd, relwind, c->red);
+    hipLaunchKernelGGL(k_reduce, dim3(nblk(p->n) < 2048u ? nblk(p->n) : 2048u), dim3(BLOCK), 0, c->stream, view(p), wdd,
+                       relwind, c->red);
   HIPCHK(hipGetLastError());
   return 0;
 }
