@@ -116,3 +116,26 @@ def test_device_rng_run_is_reproducible_and_order_independent():
     a, b = run(0), run(2)
     for x, y in zip(a, b):
         assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_openoil_advection_equals_reference_path():
+    """OpenOil.update with weathering off = advect_oil (openoil.py:1179-1239): on the C4-shaped case the
+    reference's OceanDrift-equivalent golden vectors apply."""
+    from opendrift_amd.openoil import OpenOil
+    g = golden('c4_stere_rk4_hdiff_strand.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'x_wind', 'y_wind',
+             'sea_surface_wave_stokes_drift_x_velocity', 'sea_surface_wave_stokes_drift_y_velocity', 'land_binary_mask']
+    o = OpenOil(loglevel=50, seed=0, rng='numpy')
+    assert o.get_config('drift:max_speed') == 1.3 and o.get_config('seed:wind_drift_factor') == 0.03
+    o.add_reader(_grid_reader(g, names, proj4=synth.NORKYST_PROJ4))
+    o.set_config('drift:advection_scheme', 'runge-kutta4')
+    o.set_config('drift:vertical_mixing', False)
+    o.set_config('drift:current_uncertainty', 0)
+    o.set_config('drift:wind_uncertainty', 0)
+    o.set_config('environment:constant:horizontal_diffusivity', 10)
+    o.seed_elements(lon=g['lon'][0], lat=g['lat'][0], time=T0)      # wind_drift_factor 0.03 is OpenOil's default
+    o.run(time_step=900, steps=8)
+    lon, lat, _ = _final(o, g['lon'].shape[1])
+    assert np.abs(lon - g['lon'][8]).max() < 1e-7 and np.abs(lat - g['lat'][8]).max() < 1e-7
+    with pytest.raises(NotImplementedError):
+        OpenOil(loglevel=50).set_config('processes:evaporation', True)
