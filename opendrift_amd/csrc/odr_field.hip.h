@@ -48,6 +48,7 @@ struct DevSource {
   double const_val[NVAR];
   double params[8];
   double z[MAXNZ];
+  double zmid[MAXNZ];  // mid-depths -(z[k] + z[k+1])/2 formed as d[k] + 0.5*(d[k+1]-d[k]), d = -z (k_vmix level search)
   int level_slot[MAXLEVELS];  // slots sorted by time
   DevBlock slot[MAXLEVELS];
 };

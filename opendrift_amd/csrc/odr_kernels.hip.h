@@ -597,7 +597,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
 #pragma unroll
     for (int k = 0; k < (NZMAX > 1 ? NZMAX - 1 : MAXNZ - 1); ++k)
       if (k < nzp - 1) {
-        double mid = dsh[k] + 0.5 * (dsh[k + 1] - dsh[k]);
+        const double mid = src->zmid[k];   // wave-uniform (scalar load)
         zi += ((k & 1) ? d >= mid : d > mid) ? 1 : 0;
       }
     if (zi != zi_cur) {

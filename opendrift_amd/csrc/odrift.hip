@@ -438,6 +438,7 @@ int odr_source_grid(odr_ctx *c, const odr_proj_desc *proj, const double *dom, in
   s.mod360_x = mod360_x;
   s.nz = (nz > 1 && z) ? nz : 1;
   for (int k = 0; k < s.nz && z; ++k) s.z[k] = z[k];
+  for (int k = 0; k + 1 < s.nz && z; ++k) s.zmid[k] = -z[k] + 0.5 * (-z[k + 1] - (-z[k]));
   return 0;
 }
 
