@@ -163,6 +163,16 @@ int odr_advect_wind(odr_ctx *ctx, odr_particles *p, double dt, double wind_drift
  * hs_mode/tp_mode 0 environment, 1 from wind, 2 scalar default */
 int odr_stokes_drift(odr_ctx *ctx, odr_particles *p, double dt, int profile, int hs_mode,
                      int tp_mode, double factor);
+/* model-specific float32 element properties (slots 0..8); for LeewayObj (models/leeway.py:50-131):
+ * 0 downwind_slope 1 crosswind_slope 2 downwind_offset 3 crosswind_offset 4 downwind_eps
+ * 5 crosswind_eps 6 jibe_probability 7 orientation 8 capsized.  set: elements [offset, offset+count) */
+int odr_particles_set_property(odr_ctx *ctx, odr_particles *p, int slot, int64_t offset, int64_t count,
+                               const float *host);
+int odr_particles_get_property(odr_ctx *ctx, odr_particles *p, int slot, float *host);
+/* Leeway.update (models/leeway.py:430-494, processes:capsizing off): leeway from wind, current,
+ * jibing; host_uniforms[i] = np.random.random draws in ODR_RNG_HOST mode */
+int odr_leeway(odr_ctx *ctx, odr_particles *p, double dt, double capsize_leeway_fraction, int rng_mode,
+               const double *host_uniforms, uint64_t step);
 /* horizontal_diffusion (basemodel/__init__.py:1746-1772) */
 int odr_hdiffusion(odr_ctx *ctx, odr_particles *p, double dt, int rng_mode,
                    const double *host_nx, const double *host_ny, uint64_t step);

@@ -71,6 +71,9 @@ _SIGNATURES = {
     'odr_update_positions': [_vp, _vp, _dp, _dp, C.c_int, C.c_double],
     'odr_advect_wind': [_vp, _vp, C.c_double, C.c_double, C.c_int, C.c_double],
     'odr_stokes_drift': [_vp, _vp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double],
+    'odr_particles_set_property': [_vp, _vp, C.c_int, C.c_int64, C.c_int64, _fp],
+    'odr_particles_get_property': [_vp, _vp, C.c_int, _fp],
+    'odr_leeway': [_vp, _vp, C.c_double, C.c_double, C.c_int, _dp, C.c_uint64],
     'odr_hdiffusion': [_vp, _vp, C.c_double, C.c_int, _dp, _dp, C.c_uint64],
     'odr_vmix': [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _dp, C.c_uint64],
     'odr_vmix_fuse_vertical_advection': [_vp, C.c_int],

@@ -21,6 +21,7 @@ struct PView {  // device pointers of the active set
   double *slon, *slat;                  // position of the last environment sample (profiles)
   int *id, *status, *moving;
   float *wdf, *cdf, *tv, *age;
+  float *aux[9];  // model-specific float32 element properties (Leeway: LeewayObj, leeway.py:50-131)
   float *env[NVAR];
 };
 
@@ -788,7 +789,7 @@ __global__ __launch_bounds__(1024) void k_scan_add(unsigned *a, long long n, con
 struct CmpArrays {
   int n64, n32;
   const double *src64[8]; double *dst64[8]; double *dead64[8];  // lon lat z plon plat slon slat
-  const int *src32[32];   int *dst32[32];   int *dead32[32];
+  const int *src32[40];   int *dst32[40];   int *dead32[40];
 };
 
 __global__ __launch_bounds__(BLOCK) void k_cmp_scatter(const int *status, long long n,
@@ -815,6 +816,56 @@ __global__ __launch_bounds__(BLOCK) void k_cmp_scatter(const int *status, long l
   for (int k = 0; k < A.n32; ++k) {
     int v = A.src32[k][i];
     if (keep) A.dst32[k][dst] = v; else if (A.dead32[k]) A.dead32[k][dst] = v;
+  }
+}
+
+// ---------------------------------------------------------------------- Leeway
+// Leeway.update (models/leeway.py:430-494) without capsizing: downwind / crosswind leeway from
+// the wind (float32 arithmetic of the LeewayObj properties), update_positions(-x_leeway,
+// y_leeway), update_positions(current), then random jibing (sign flip of crosswind_slope).
+enum { AUX_DW_SLOPE = 0, AUX_CW_SLOPE, AUX_DW_OFFSET, AUX_CW_OFFSET, AUX_DW_EPS, AUX_CW_EPS, AUX_JIBE_P,
+       AUX_ORIENTATION, AUX_CAPSIZED };
+constexpr unsigned long long RNG_OFF_JIBE = 4608;
+
+__global__ __launch_bounds__(BLOCK) void k_leeway(PView p, double dt, float capsize_fraction, int rng_mode,
+                                                  const double *__restrict__ huni, unsigned long long seed,
+                                                  unsigned long long step) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  float xw = p.env[VAR_XWIND][i], yw = p.env[VAR_YWIND][i];
+  float windspeed = speed_f32(xw, yw);
+  float winddir = (float)atan2((double)xw, (double)yw);          // np.arctan2 on float32
+  float dwe = p.aux[AUX_DW_EPS][i], cwe = p.aux[AUX_CW_EPS][i];
+  float cws = p.aux[AUX_CW_SLOPE][i];
+  // ((slope + eps/20.0)*windspeed + offset + eps/2.0)*.01, float32 left to right (:458-466)
+  float dw = __fmul_rn(__fadd_rn(__fadd_rn(__fmul_rn(__fadd_rn(p.aux[AUX_DW_SLOPE][i], __fdiv_rn(dwe, 20.0f)), windspeed),
+                                           p.aux[AUX_DW_OFFSET][i]), __fdiv_rn(dwe, 2.0f)), (float).01);
+  float cw = __fmul_rn(__fadd_rn(__fadd_rn(__fmul_rn(__fadd_rn(cws, __fdiv_rn(cwe, 20.0f)), windspeed),
+                                           p.aux[AUX_CW_OFFSET][i]), __fdiv_rn(cwe, 2.0f)), (float).01);
+  float sinth = (float)sin((double)winddir), costh = (float)cos((double)winddir);
+  float yl = __fadd_rn(__fmul_rn(dw, costh), __fmul_rn(cw, sinth));
+  float xl = __fadd_rn(__fmul_rn(-dw, sinth), __fmul_rn(cw, costh));
+  if (p.aux[AUX_CAPSIZED][i] == 1.0f) { xl = __fmul_rn(xl, capsize_fraction); yl = __fmul_rn(yl, capsize_fraction); }
+  double lon = p.lon[i], lat = p.lat[i];
+  int moving = p.moving[i];
+  move_f32(lon, lat, -xl, yl, moving, dt);                        // :472
+  move_f32(lon, lat, p.env[VAR_U][i], p.env[VAR_V][i], moving, dt);  // :475-476
+  p.lon[i] = lon;
+  p.lat[i] = lat;
+  // jibing (:478-487): rate = -log(1-p)/3600, probability per step 1-exp(-rate*|dt|), float32
+  float jp = p.aux[AUX_JIBE_P][i];
+  float rate = __fdiv_rn(-(float)log((double)__fsub_rn(1.0f, jp)), 3600.0f);
+  float pstep = __fsub_rn(1.0f, (float)exp((double)__fmul_rn(-rate, (float)fabs(dt))));
+  double u01;
+  if (rng_mode == 1) u01 = huni[i];
+  else {
+    rocrand_state_philox4x32_10 st;
+    rng_init(st, seed, p.id[i], step, RNG_OFF_JIBE);
+    u01 = rocrand_uniform_double2(&st).x;
+  }
+  if ((double)pstep > u01) {
+    p.aux[AUX_CW_SLOPE][i] = -cws;
+    p.aux[AUX_ORIENTATION][i] = 1.0f - p.aux[AUX_ORIENTATION][i];
   }
 }
 

@@ -59,6 +59,8 @@ struct odr_particles {
   float *altf32[4];
   float *env[NVAR];
   float *altenv[NVAR];
+  float *aux[9];
+  float *altaux[9];
   double *dead64[3];    // lon lat z of the deactivated store
   int *deadi32[2];      // id status
   unsigned *bcount;
@@ -76,6 +78,7 @@ static PView view(const odr_particles *p) {
   v.id = p->i32[0]; v.status = p->i32[1]; v.moving = p->i32[2];
   v.wdf = p->f32[0]; v.cdf = p->f32[1]; v.tv = p->f32[2]; v.age = p->f32[3];
   for (int k = 0; k < NVAR; ++k) v.env[k] = p->env[k];
+  for (int k = 0; k < 9; ++k) v.aux[k] = p->aux[k];
   return v;
 }
 
@@ -225,6 +228,7 @@ int odr_particles_destroy(odr_ctx *c, odr_particles *p) {
   for (int k = 0; k < 4; ++k) { fr(p->f32[k]); fr(p->altf32[k]); }
   for (int k = 0; k < 2; ++k) fr(p->deadi32[k]);
   for (int k = 0; k < NVAR; ++k) { fr(p->env[k]); fr(p->altenv[k]); }
+  for (int k = 0; k < 9; ++k) { fr(p->aux[k]); fr(p->altaux[k]); }
   fr(p->bcount);
   fr(p->scratch);
   delete p;
@@ -818,6 +822,46 @@ int odr_update_positions(odr_ctx *c, odr_particles *p, const double *u, const do
   return 0;
 }
 
+// model-specific float32 element properties (LagrangianArray subclasses): slots 0..8, for Leeway
+// {downwind_slope, crosswind_slope, downwind_offset, crosswind_offset, downwind_eps, crosswind_eps,
+//  jibe_probability, orientation, capsized} (leeway.py:50-131)
+int odr_particles_set_property(odr_ctx *c, odr_particles *p, int slot, int64_t offset, int64_t count, const float *host) {
+  REQUIRE(slot >= 0 && slot < 9 && host && offset >= 0 && count >= 0 && offset + count <= p->n, "bad property range");
+  if (!p->aux[slot]) {
+    HIPCHK(hipMalloc((void **)&p->aux[slot], sizeof(float) * (size_t)p->cap));
+    HIPCHK(hipMemsetAsync(p->aux[slot], 0, sizeof(float) * (size_t)p->cap, c->stream));
+  }
+  if (count) HIPCHK(hipMemcpyAsync(p->aux[slot] + offset, host, sizeof(float) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int odr_particles_get_property(odr_ctx *c, odr_particles *p, int slot, float *host) {
+  REQUIRE(slot >= 0 && slot < 9 && host, "bad property slot");
+  if (!p->aux[slot]) return fail(ODR_ERR_STATE, "property slot %d has not been set", slot);
+  if (p->n) HIPCHK(hipMemcpyAsync(host, p->aux[slot], sizeof(float) * (size_t)p->n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// Leeway.update (models/leeway.py:430-494, capsizing off)
+int odr_leeway(odr_ctx *c, odr_particles *p, double dt, double capsize_fraction, int rng_mode, const double *huni,
+               uint64_t step) {
+  for (int k = 0; k < 9; ++k) if (!p->aux[k]) return fail(ODR_ERR_STATE, "Leeway property slot %d has not been set", k);
+  if (!p->env[VAR_XWIND] || !p->env[VAR_YWIND] || !p->env[VAR_U] || !p->env[VAR_V])
+    return fail(ODR_ERR_STATE, "wind and current must be sampled before odr_leeway");
+  if (p->n == 0) return 0;
+  double *du = nullptr, *dummy = nullptr;
+  if (rng_mode == ODR_RNG_HOST) {
+    REQUIRE(huni, "host uniforms required in ODR_RNG_HOST mode");
+    int rc = host_to_scratch(c, p, huni, nullptr, (size_t)p->n, &du, &dummy);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_leeway, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, (float)capsize_fraction, rng_mode,
+                     du, c->seed, (unsigned long long)step);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static int reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind) {
   hipLaunchKernelGGL(k_red_init, dim3(1), dim3(64), 0, c->stream, c->red);
   if (p->n > 0)
@@ -1023,6 +1067,7 @@ static int ensure_alt(odr_particles *p) {
   for (int k = 0; k < 4; ++k) if (!p->altf32[k]) HIPCHK(hipMalloc((void **)&p->altf32[k], 4 * cap));
   for (int k = 0; k < 2; ++k) if (!p->deadi32[k]) HIPCHK(hipMalloc((void **)&p->deadi32[k], 4 * cap));
   for (int k = 0; k < NVAR; ++k) if (p->env[k] && !p->altenv[k]) HIPCHK(hipMalloc((void **)&p->altenv[k], 4 * cap));
+  for (int k = 0; k < 9; ++k) if (p->aux[k] && !p->altaux[k]) HIPCHK(hipMalloc((void **)&p->altaux[k], 4 * cap));
   return 0;
 }
 
@@ -1038,6 +1083,8 @@ static void all_arrays(odr_particles *p, CmpArrays &A) {
   for (int k = 0; k < 4; ++k, ++m) { A.src32[m] = (const int *)p->f32[k]; A.dst32[m] = (int *)p->altf32[k]; }
   for (int k = 0; k < NVAR; ++k)
     if (p->env[k]) { A.src32[m] = (const int *)p->env[k]; A.dst32[m] = (int *)p->altenv[k]; ++m; }
+  for (int k = 0; k < 9; ++k)
+    if (p->aux[k]) { A.src32[m] = (const int *)p->aux[k]; A.dst32[m] = (int *)p->altaux[k]; ++m; }
   A.n32 = m;
 }
 
@@ -1046,6 +1093,7 @@ static void swap_sets(odr_particles *p) {
   for (int k = 0; k < 3; ++k) std::swap(p->i32[k], p->alti32[k]);
   for (int k = 0; k < 4; ++k) std::swap(p->f32[k], p->altf32[k]);
   for (int k = 0; k < NVAR; ++k) if (p->env[k]) std::swap(p->env[k], p->altenv[k]);
+  for (int k = 0; k < 9; ++k) if (p->aux[k]) std::swap(p->aux[k], p->altaux[k]);
 }
 
 int odr_compact(odr_ctx *c, odr_particles *p, int64_t *n_active) {

@@ -282,6 +282,22 @@ class Particles:
     def stokes_drift(self, dt, profile=2, hs_mode=0, tp_mode=0, factor=1.0):
         check(self.lib.odr_stokes_drift(self.ctx.h, self.h, float(dt), profile, hs_mode, tp_mode, float(factor)))
 
+    def set_property(self, slot, values, offset=0):
+        a, pa = _f(np.atleast_1d(values))
+        check(self.lib.odr_particles_set_property(self.ctx.h, self.h, slot, int(offset), a.size, pa))
+
+    def get_property(self, slot):
+        out = np.empty(len(self), np.float32)
+        check(self.lib.odr_particles_get_property(self.ctx.h, self.h, slot, out.ctypes.data_as(_fp)))
+        return out
+
+    def leeway(self, dt, capsize_fraction=0.4, step=0, uniforms=None):
+        if uniforms is not None:
+            u, pu = _d(uniforms, len(self))
+            check(self.lib.odr_leeway(self.ctx.h, self.h, float(dt), float(capsize_fraction), _abi.RNG_HOST, pu, step))
+        else:
+            check(self.lib.odr_leeway(self.ctx.h, self.h, float(dt), float(capsize_fraction), _abi.RNG_DEVICE, None, step))
+
     def hdiffusion(self, dt, step=0, normals=None):
         n = len(self)
         if normals is not None:

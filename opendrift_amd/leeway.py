@@ -1,0 +1,104 @@
+"""Leeway (search and rescue) model on the device path.
+
+Mirrors opendrift/models/leeway.py: `LeewayObj` element properties (:50-131), required variables
+(:146-173), `seed_elements` with the per-element perturbation of the leeway coefficients
+(:290-400) and `update()` (:430-494: leeway from wind + ambient current, Euler by construction, then
+random jibing) -- the update is one HIP kernel (odr_leeway).
+
+The object-class table OBJECTPROP.DAT is a data file of the reference and is not shipped: pass the nine
+coefficients of the class as `leeway_coefficients=dict(DWSLOPE=..., DWOFFSET=..., DWSTD=..., CWRSLOPE=...,
+CWROFFSET=..., CWRSTD=..., CWLSLOPE=..., CWLOFFSET=..., CWLSTD=...)` or read them with
+`read_objectprop(path_to_OBJECTPROP.DAT)[object_type]`.  Capsizing (`processes:capsizing`) and the ASCII
+export are host bookkeeping outside the path.
+"""
+import numpy as np
+
+from .config import CONFIG_LEVEL_BASIC, CONFIG_LEVEL_ADVANCED
+from .oceandrift import OpenDriftSimulation
+
+RIGHT, LEFT = 0, 1
+
+
+def read_objectprop(path):
+    """Parse an OBJECTPROP.DAT (layout of leeway.py:190-222): {object_type (1-based): coefficients}."""
+    lines = open(path).readlines()
+    n = int(lines[0])
+    out = {}
+    for i in range(n):
+        arr = [float(x) for x in lines[i * 3 + 3].split()]
+        out[i + 1] = dict(OBJKEY=lines[i * 3 + 1].strip(), Description=lines[i * 3 + 2].strip(),
+                          DWSLOPE=arr[0], DWOFFSET=arr[1], DWSTD=arr[2], CWRSLOPE=arr[3], CWROFFSET=arr[4],
+                          CWRSTD=arr[5], CWLSLOPE=arr[6], CWLOFFSET=arr[7], CWLSTD=arr[8])
+    return out
+
+
+class Leeway(OpenDriftSimulation):
+    element_properties = {'jibe_probability': 0.04, 'current_drift_factor': 1.0}
+    # slot order of odr_particles_set_property (include/odrift.h)
+    aux_properties = ['downwind_slope', 'crosswind_slope', 'downwind_offset', 'crosswind_offset', 'downwind_eps',
+                      'crosswind_eps', 'jibe_probability', 'orientation', 'capsized']
+    required_variables = {
+        'x_wind': {'fallback': None},
+        'y_wind': {'fallback': None},
+        'x_sea_water_velocity': {'fallback': None},
+        'y_sea_water_velocity': {'fallback': None},
+        'sea_surface_wave_stokes_drift_x_velocity': {'fallback': 0, 'skip_if': ['drift:stokes_drift', 'is', False]},
+        'sea_surface_wave_stokes_drift_y_velocity': {'fallback': 0, 'skip_if': ['drift:stokes_drift', 'is', False]},
+        'land_binary_mask': {'fallback': None},
+    }
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._add_config({
+            'processes:capsizing': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_BASIC, 'description': ''},
+            'capsizing:leeway_fraction': {'type': 'float', 'default': 0.4, 'min': 0, 'max': 1,
+                                          'level': CONFIG_LEVEL_BASIC, 'description': ''},
+            'drift:stokes_drift': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+        })
+        self._set_config_default('drift:max_speed', 5)
+
+    def seed_elements(self, lon, lat, object_type=None, leeway_coefficients=None, **kwargs):
+        """leeway.py:290-400.  Either `leeway_coefficients` (class table row, perturbed per element like the
+        reference) or explicit per-element arrays downwind_slope=..., crosswind_slope=..., ... """
+        explicit = {k: kwargs.pop(k) for k in list(kwargs) if k in self.aux_properties and k != 'jibe_probability'}
+        n_before = 0 if self._sched is None else len(self._sched['lon'])
+        jibe = kwargs.pop('jibe_probability', None)
+        super().seed_elements(lon, lat, **kwargs)
+        number = len(self._sched['lon']) - n_before
+        if leeway_coefficients is not None:
+            c = leeway_coefficients
+            orientation = np.r_[:number] % 2          # odd numbered particles are left-drifting (:318-320)
+            ones = np.ones(number)
+            downwind_slope, downwind_offset = ones * c['DWSLOPE'], ones * c['DWOFFSET']
+            epsdw = np.zeros(number)
+            for i in range(number):                   # avoid negative downwind slopes (:331-339)
+                epsdw[i] = np.random.randn(1)[0] * c['DWSTD']
+                while downwind_slope[i] + epsdw[i] / 20.0 < 0.0:
+                    epsdw[i] = np.random.randn(1)[0] * c['DWSTD']
+            rcw = np.random.randn(number)
+            crosswind_slope = np.where(orientation == RIGHT, c['CWRSLOPE'], c['CWLSLOPE'])
+            crosswind_offset = np.where(orientation == RIGHT, c['CWROFFSET'], c['CWLOFFSET'])
+            crosswind_eps = np.where(orientation == RIGHT, rcw * c['CWRSTD'], rcw * c['CWLSTD'])
+            props = dict(downwind_slope=downwind_slope, crosswind_slope=crosswind_slope,
+                         downwind_offset=downwind_offset, crosswind_offset=crosswind_offset, downwind_eps=epsdw,
+                         crosswind_eps=crosswind_eps, orientation=orientation, capsized=np.zeros(number))
+        else:
+            defaults = dict(downwind_slope=1, crosswind_slope=1, downwind_offset=0, crosswind_offset=0, downwind_eps=0,
+                            crosswind_eps=0, orientation=1, capsized=0)     # LeewayObj defaults (:50-131)
+            props = {k: np.asarray(explicit.get(k, v), dtype=np.float64) * np.ones(number) for k, v in defaults.items()}
+        if jibe is not None:
+            self._sched['jibe_probability'][n_before:] = np.float32(jibe)
+        for k, v in props.items():
+            v = np.asarray(v, dtype=np.float32)
+            self._sched[k] = v if n_before == 0 else np.concatenate([self._sched[k], v])
+
+    def update(self):   # leeway.py:430-494
+        if self.get_config('processes:capsizing'):
+            raise NotImplementedError('capsizing is host bookkeeping outside the hot path')
+        dt = self.time_step.total_seconds()
+        frac = self.get_config('capsizing:leeway_fraction')
+        if self.rng == 'numpy':
+            self.P.leeway(dt, frac, uniforms=np.random.random(self.num_elements_active()))
+        else:
+            self.P.leeway(dt, frac, step=self.steps_calculation)
+        self.stokes_drift()

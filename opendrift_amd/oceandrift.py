@@ -282,7 +282,10 @@ class OpenDriftSimulation(Configurable):
             return
         kw = {p: s[p][idx] for p in self.element_properties if p in ('wind_drift_factor', 'current_drift_factor',
                                                                      'terminal_velocity')}
+        n_before = self.num_elements_active()
         self.P.append(s['lon'][idx], s['lat'][idx], z=s['z'][idx], id=s['ID'][idx], **kw)
+        for slot, name in enumerate(getattr(self, 'aux_properties', [])):   # model-specific float32 properties
+            self.P.set_property(slot, s[name][idx], offset=n_before)
         rel[idx] = True
 
     def deactivate_elements(self, mask, reason='deactivated'):   # :1774-1795
@@ -346,6 +349,29 @@ class OpenDriftSimulation(Configurable):
                     self.P.env_add_noise(vx, vy, std, normals=(np.random.normal(0, std, n), np.random.normal(0, std, n)))
                 else:
                     self.P.env_add_noise(vx, vy, std, step=self.steps_calculation)
+
+    # ---- PhysicsMethods (physics_methods.py:611-848)
+    def advect_ocean_current(self, factor=1):
+        self.P.advect(self.get_config('drift:advection_scheme'), _epoch(self.time),
+                      self.time_step.total_seconds(), factor)
+
+    def advect_wind(self, factor=1):
+        self.P.advect_wind(self.time_step.total_seconds(), self.get_config('drift:wind_drift_depth', 0.1),
+                           self.get_config('drift:relative_wind'), factor)
+
+    def stokes_drift(self, factor=1):
+        if self.get_config('drift:stokes_drift') is False:
+            return
+        profile = {'monochromatic': 0, 'exponential': 1, 'Phillips': 2}.get(self.get_config('drift:stokes_drift_profile', 'Phillips'))
+        if profile is None:
+            raise NotImplementedError('windsea_swell Stokes profile is not on the device path')
+        r = self.P.reduce_scalars(self.get_config('drift:wind_drift_depth', 0.1))
+        if r['stokes_sum_max'] == 0:
+            return
+        # provenance of Hs / Tp (physics_methods.py:893-943, :809-814)
+        hs_mode = 0 if r['hs_max'] > 0 else (1 if r['wind_speed_max'] > 0 else 2)
+        tp_mode = 1 if r['wind_speed_max'] >= 0 else 2   # Tp is not an OceanDrift variable: from wind (omega=5 when calm)
+        self.P.stokes_drift(self.time_step.total_seconds(), profile, hs_mode, tp_mode, factor)
 
     def prepare_run(self):
         pass
@@ -499,29 +525,6 @@ class OceanDrift(OpenDriftSimulation):
                        'description': ''},
         })
         self._set_config_default('drift:max_speed', 2)
-
-    # ---- PhysicsMethods (physics_methods.py:611-848)
-    def advect_ocean_current(self, factor=1):
-        self.P.advect(self.get_config('drift:advection_scheme'), _epoch(self.time),
-                      self.time_step.total_seconds(), factor)
-
-    def advect_wind(self, factor=1):
-        self.P.advect_wind(self.time_step.total_seconds(), self.get_config('drift:wind_drift_depth'),
-                           self.get_config('drift:relative_wind'), factor)
-
-    def stokes_drift(self, factor=1):
-        if self.get_config('drift:stokes_drift') is False:
-            return
-        profile = {'monochromatic': 0, 'exponential': 1, 'Phillips': 2}.get(self.get_config('drift:stokes_drift_profile'))
-        if profile is None:
-            raise NotImplementedError('windsea_swell Stokes profile is not on the device path')
-        r = self.P.reduce_scalars(self.get_config('drift:wind_drift_depth'))
-        if r['stokes_sum_max'] == 0:
-            return
-        # provenance of Hs / Tp (physics_methods.py:893-943, :809-814)
-        hs_mode = 0 if r['hs_max'] > 0 else (1 if r['wind_speed_max'] > 0 else 2)
-        tp_mode = 1 if r['wind_speed_max'] >= 0 else 2   # Tp is not an OceanDrift variable: from wind (omega=5 when calm)
-        self.P.stokes_drift(self.time_step.total_seconds(), profile, hs_mode, tp_mode, factor)
 
     def vertical_mixing(self):   # oceandrift.py:397-571, diffusivity model 'environment'
         if self.get_config('drift:vertical_mixing') is False:

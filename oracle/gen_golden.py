@@ -177,7 +177,46 @@ def c4_stere():
                         wdf=0.03, **{('g_' + k): v for k, v in g.items()}, **res)
 
 
-SCEN = dict(c1=c1_constant, c2=c2_double_gyre, c3=c3_grid3d, c4=c4_stere)
+def c5_leeway():
+    """C5-shaped: Leeway (object class 1, PIW-1) on the C4 stere grid with per-element wind / current
+    uncertainty; Euler by construction (leeway.py:472-476); jibing."""
+    from opendrift.models.leeway import Leeway
+    g = synth.grid_stere(nx=70, ny=50, nt=3, seed=5)
+    times = [T0 + timedelta(seconds=float(t)) for t in g['t']]
+    arrays = {k: g[k] for k in ('x_sea_water_velocity', 'y_sea_water_velocity', 'x_wind', 'y_wind', 'land_binary_mask')}
+    o = Leeway(loglevel=50)
+    o.set_config('general:use_auto_landmask', False)
+    r = GridReader(synth.NORKYST_PROJ4, g['x'], g['y'], times, arrays)
+    o.add_reader(r)
+    o.set_config('drift:wind_uncertainty', 2.0)
+    o.set_config('drift:current_uncertainty', 0.1)
+    o.set_config('general:coastline_action', 'stranding')
+    o.set_config('seed:jibe_probability', 0.5)      # make jibing visible within a few steps
+    rng = np.random.default_rng(6)
+    N = 300
+    x = rng.uniform(g['x'][5], g['x'][int(0.8 * len(g['x']))], N)
+    y = rng.uniform(g['y'][5], g['y'][-6], N)
+    lon, lat = r.xy2lonlat(x, y)
+    np.random.seed(0)
+    o.seed_elements(lon=lon, lat=lat, time=T0, object_type=1)
+    sch = o.elements_scheduled
+    props = {k: np.array(getattr(sch, k) * np.ones(N), dtype=np.float32) for k in (
+        'downwind_slope', 'crosswind_slope', 'downwind_offset', 'crosswind_offset', 'downwind_eps', 'crosswind_eps',
+        'jibe_probability', 'orientation', 'capsized')}
+    res, draws = _run(o, 600, 8, record_random=True)
+    nrm = [[d[1] for d in step if d[0] == 'normal'] for step in draws]
+    uni = [[d[1] for d in step if d[0] == 'random'] for step in draws]
+    normals = np.full((len(nrm), 4, N), np.nan)
+    uniforms = np.full((len(uni), N), np.nan)
+    for k in range(len(nrm)):
+        for j, a in enumerate(nrm[k][:4]):
+            normals[k, j, :len(a)] = a
+        uniforms[k, :len(uni[k][0])] = uni[k][0]
+    np.savez_compressed(os.path.join(GOLD, 'c5_leeway_stere.npz'), dt=600.0, normals=normals, uniforms=uniforms,
+                        **{('p_' + k): v for k, v in props.items()}, **{('g_' + k): v for k, v in g.items()}, **res)
+
+
+SCEN = dict(c1=c1_constant, c2=c2_double_gyre, c3=c3_grid3d, c4=c4_stere, c5=c5_leeway)
 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)

@@ -350,3 +350,12 @@ def coastline(action, land, lon, lat, z, prev_lon, prev_lat, status, moving, str
                         _p(_d(prev_lat), C.c_double), _p(status, C.c_int), _p(moving, C.c_int),
                         C.c_int(stranded_code), _p(age, C.c_float) if age is not None else None,
                         C.c_int(seeded_on_land_code))
+
+
+def leeway(lon, lat, moving, aux, xwind, ywind, u, v, dt, capsize_fraction, uniforms):
+    """aux: list of 9 float32 arrays (mutated: crosswind_slope / orientation flip on jibing)."""
+    n = lon.size
+    ptrs = (C.POINTER(C.c_float) * 9)(*[_p(a, C.c_float) for a in aux])
+    lib().orc_leeway(C.c_long(n), _p(lon, C.c_double), _p(lat, C.c_double), _p(_i(moving), C.c_int), ptrs,
+                     _p(_f(xwind), C.c_float), _p(_f(ywind), C.c_float), _p(_f(u), C.c_float), _p(_f(v), C.c_float),
+                     C.c_double(dt), C.c_double(capsize_fraction), _p(_d(uniforms), C.c_double))

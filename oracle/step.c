@@ -702,3 +702,37 @@ void orc_coastline(long n, int action, const float *land, double *lon, double *l
     }
   }
 }
+
+/* ------------------------------------------------------------------ */
+/* Leeway.update, models/leeway.py:430-494 (processes:capsizing off)    */
+/* ------------------------------------------------------------------ */
+void orc_leeway(long n, double *lon, double *lat, const int *moving, float *const *aux,
+                const float *xwind, const float *ywind, const float *u, const float *v, double dt,
+                double capsize_fraction, const double *uniforms) {
+  float *xl = (float *)malloc(sizeof(float) * (size_t)n), *yl = (float *)malloc(sizeof(float) * (size_t)n);
+  long i;
+  for (i = 0; i < n; ++i) {
+    float ws = speed_f32(xwind[i], ywind[i]);
+    float wd = (float)atan2((double)xwind[i], (double)ywind[i]);
+    volatile float a = aux[4][i] / 20.0f, b = aux[5][i] / 20.0f, ha = aux[4][i] / 2.0f, hb = aux[5][i] / 2.0f;
+    volatile float dw = aux[0][i] + a, cw = aux[1][i] + b;
+    volatile float sn = (float)sin((double)wd), cs = (float)cos((double)wd), t1, t2, t3, t4;
+    dw = dw * ws; dw = dw + aux[2][i]; dw = dw + ha; dw = dw * (float).01;
+    cw = cw * ws; cw = cw + aux[3][i]; cw = cw + hb; cw = cw * (float).01;
+    t1 = dw * cs; t2 = cw * sn; t3 = -dw * sn; t4 = cw * cs;
+    yl[i] = t1 + t2;
+    xl[i] = t3 + t4;
+    if (aux[8][i] == 1.0f) { xl[i] = xl[i] * (float)capsize_fraction; yl[i] = yl[i] * (float)capsize_fraction; }
+    xl[i] = -xl[i];
+  }
+  orc_update_positions_f32(n, lon, lat, xl, yl, moving, dt);
+  orc_update_positions_f32(n, lon, lat, u, v, moving, dt);
+  for (i = 0; i < n; ++i) {
+    volatile float om = 1.0f - aux[6][i];
+    volatile float rate = -(float)log((double)om) / 3600.0f;
+    volatile float arg = -rate * (float)fabs(dt);
+    volatile float ps = 1.0f - (float)exp((double)arg);
+    if ((double)ps > uniforms[i]) { aux[1][i] = -aux[1][i]; aux[7][i] = 1.0f - aux[7][i]; }
+  }
+  free(xl); free(yl);
+}

@@ -18,6 +18,8 @@ KZ, DEPTH, SSH, LAND = ('ocean_vertical_diffusivity', 'sea_floor_depth_below_sea
 XW, YW = 'x_wind', 'y_wind'
 SX, SY = 'sea_surface_wave_stokes_drift_x_velocity', 'sea_surface_wave_stokes_drift_y_velocity'
 HS, HD = 'sea_surface_wave_significant_height', 'horizontal_diffusivity'
+LEEWAY_PROPS = ['downwind_slope', 'crosswind_slope', 'downwind_offset', 'crosswind_offset', 'downwind_eps',
+                'crosswind_eps', 'jibe_probability', 'orientation', 'capsized']
 
 
 class OracleBackend:
@@ -67,6 +69,8 @@ class OracleBackend:
         self.env = {k: v[keep] for k, v in self.env.items()}
         if hasattr(self, 'Kp'):
             self.Kp = np.ascontiguousarray(self.Kp[:, keep])
+        if hasattr(self, 'aux'):
+            self.aux = [np.ascontiguousarray(a[keep]) for a in self.aux]
 
     def store_previous(self):
         self.plon, self.plat = self.lon.copy(), self.lat.copy()
@@ -88,6 +92,19 @@ class OracleBackend:
     def hdiff(self, dt, normals):
         n = len(self.lon)
         orc.horizontal_diffusion(self.lon, self.lat, self.moving, self.env[HD], normals[0][:n], normals[1][:n], dt)
+
+    def set_leeway(self, props):
+        self.aux = [np.array(props[k], dtype=np.float32) for k in LEEWAY_PROPS]
+
+    def noise(self, vx, vy, nx, ny):   # environment.py:869-891: float32 += float64
+        n = len(self.lon)
+        self.env[vx] = (self.env[vx].astype(np.float64) + nx[:n]).astype(np.float32)
+        self.env[vy] = (self.env[vy].astype(np.float64) + ny[:n]).astype(np.float32)
+
+    def leeway(self, dt, uniforms, frac=0.4):
+        n = len(self.lon)
+        orc.leeway(self.lon, self.lat, self.moving, self.aux, self.env[XW], self.env[YW], self.env[U], self.env[VV],
+                   dt, frac, uniforms[:n])
 
     def vmix(self, t, dt, dt_mix, zlevels, uniforms, vadv=True):
         orc.vertical_mixing(self.z, self.moving, self.tv, self.env[DEPTH], self.env[SSH], zlevels, self.Kp, dt,
@@ -143,6 +160,17 @@ class DeviceBackend:
         n = len(self.P)
         self.P.hdiffusion(dt, normals=(normals[0][:n], normals[1][:n]))
 
+    def set_leeway(self, props):
+        for slot, k in enumerate(LEEWAY_PROPS):
+            self.P.set_property(slot, np.asarray(props[k], dtype=np.float32))
+
+    def noise(self, vx, vy, nx, ny):
+        n = len(self.P)
+        self.P.env_add_noise(vx, vy, 1.0, normals=(nx[:n], ny[:n]))
+
+    def leeway(self, dt, uniforms, frac=0.4):
+        self.P.leeway(dt, frac, uniforms=uniforms[:len(self.P)])
+
     def vmix(self, t, dt, dt_mix, zlevels, uniforms, vadv=True):
         self.P.vmix(t, dt, dt_mix, uniforms=uniforms, fuse_vertical_advection=False if vadv else None)
 
@@ -194,6 +222,36 @@ def replay_c4(B, g, nsteps):
         B.hdiff(dt, g['normals'][k])
         out.append(B.state(n))
     return out
+
+
+def replay_c5(B, g, nsteps):
+    """C5-shaped golden: Leeway on a stere grid, wind / current uncertainty, stranding, jibing."""
+    dt = float(g['dt'])
+    n = g['lon'].shape[1]
+    B.set_leeway({k: g['p_' + k] for k in LEEWAY_PROPS})
+    out = []
+    names = [XW, YW, U, VV, LAND]
+    for k in range(nsteps):
+        t = k * dt
+        B.sample(names, t)
+        B.noise(U, VV, g['normals'][k][0], g['normals'][k][1])
+        B.noise(XW, YW, g['normals'][k][2], g['normals'][k][3])
+        B.coast('stranding', code=1)
+        B.increase_age(dt)
+        B.compact()
+        B.store_previous()
+        B.leeway(dt, g['uniforms'][k])
+        out.append(B.state(n))
+    return out
+
+
+def scenario_c5(g):
+    from scenarios import Scenario
+    from opendrift_amd import synthetic as synth
+    names = [U, VV, XW, YW, LAND]
+    levels = [(float(g['g_t'][k]), {nm: g['g_' + nm][k] for nm in names}) for k in range(len(g['g_t']))]
+    return Scenario([('grid', dict(x=g['g_x'], y=g['g_y'], proj=synth.NORKYST_PROJ, levels=levels,
+                                   time_coverage=(float(g['g_t'][0]), float(g['g_t'][-1]))))])
 
 
 def scenario_c3(g):

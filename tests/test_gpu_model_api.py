@@ -139,3 +139,34 @@ def test_openoil_advection_equals_reference_path():
     assert np.abs(lon - g['lon'][8]).max() < 1e-7 and np.abs(lat - g['lat'][8]).max() < 1e-7
     with pytest.raises(NotImplementedError):
         OpenOil(loglevel=50).set_config('processes:evaporation', True)
+
+
+def test_c5_leeway_model_run_numpy_rng():
+    from opendrift_amd.leeway import Leeway
+    g = golden('c5_leeway_stere.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'x_wind', 'y_wind', 'land_binary_mask']
+    o = Leeway(loglevel=50, seed=0, rng='numpy')
+    o.add_reader(_grid_reader(g, names, proj4=synth.NORKYST_PROJ4))
+    o.set_config('drift:wind_uncertainty', 2.0)
+    o.set_config('drift:current_uncertainty', 0.1)
+    props = {k: g['p_' + k] for k in ('downwind_slope', 'crosswind_slope', 'downwind_offset', 'crosswind_offset',
+                                      'downwind_eps', 'crosswind_eps', 'orientation', 'capsized')}
+    o.seed_elements(lon=g['lon'][0], lat=g['lat'][0], time=T0, jibe_probability=0.5, **props)
+    np.random.seed(0)
+    # the reference consumed np.random at seeding (coefficient perturbation); replay its stream position
+    o2 = Leeway(loglevel=50, seed=0, rng='numpy')
+    np.random.seed(0)
+    dwstd = float(g['p_downwind_eps'][0]) / np.random.randn(1)[0]       # class table value (OBJECTPROP.DAT is not shipped)
+    coeff = dict(DWSLOPE=float(g['p_downwind_slope'][0]), DWOFFSET=float(g['p_downwind_offset'][0]), DWSTD=dwstd,
+                 CWRSLOPE=float(g['p_crosswind_slope'][0]), CWROFFSET=float(g['p_crosswind_offset'][0]), CWRSTD=1.0,
+                 CWLSLOPE=float(g['p_crosswind_slope'][1]), CWLOFFSET=float(g['p_crosswind_offset'][1]), CWLSTD=1.0)
+    np.random.seed(0)
+    o2.seed_elements(lon=g['lon'][0], lat=g['lat'][0], time=T0, leeway_coefficients=coeff)
+    assert (o2._sched['orientation'] == g['p_orientation']).all()
+    assert np.abs(o2._sched['crosswind_slope'] - g['p_crosswind_slope']).max() < 1e-6
+    assert np.abs(o2._sched['downwind_eps'] - g['p_downwind_eps']).max() < 1e-4     # same draws, same re-draw rule
+    ratio = g['p_crosswind_eps'] / o2._sched['crosswind_eps']
+    assert np.ptp(ratio[::2]) < 1e-3 * abs(ratio[0]) and np.ptp(ratio[1::2]) < 1e-3 * abs(ratio[1])
+    o.run(time_step=600, steps=8)
+    lon, lat, _ = _final(o, g['lon'].shape[1])
+    assert np.abs(lon - g['lon'][-1]).max() < 1e-7 and np.abs(lat - g['lat'][-1]).max() < 1e-7

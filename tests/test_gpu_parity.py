@@ -426,3 +426,18 @@ def test_c4_golden_device(ctx):
     O = replay.OracleBackend(replay.scenario_c4(g), g['lon'][0], g['lat'][0], g['z'][0], wdf=float(g['wdf']))
     _states_close(dev, replay.replay_c4(O, g, 9), 2e-9, 1e-12)
     print('c4 device vs reference:', worst)
+
+
+def test_c5_leeway_golden_device(ctx):
+    """Leeway.update kernel + environment uncertainty (host-drawn normals) + jibing vs the reference's Leeway."""
+    import replay
+    g = golden('c5_leeway_stere.npz')
+    nst = g['lon'].shape[0] - 1
+    D = replay.DeviceBackend(replay.scenario_c5(g), ctx, g['lon'][0], g['lat'][0], g['z'][0])
+    dev = replay.replay_c5(D, g, nst)
+    worst = replay.compare(dev, g, tol_pos=1e-7)
+    O = replay.OracleBackend(replay.scenario_c5(g), g['lon'][0], g['lat'][0], g['z'][0])
+    _states_close(dev, replay.replay_c5(O, g, nst), 2e-9, 1e-12)
+    cw = D.P.get_property(1)
+    assert (np.sign(cw) != np.sign(g['p_crosswind_slope'][D.P.download()['ID']])).any()    # some elements jibed
+    print('c5 device vs reference:', worst)

@@ -146,3 +146,10 @@ def test_c4_golden_vs_oracle():
     # step 8 still exercises the uncovered RK sub-stage times (fallback velocity)
     worst = replay.compare(replay.replay_c4(B, g, 9), g, tol_pos=1e-7)
     print('c4 oracle vs reference:', worst)
+
+
+def test_c5_leeway_golden_vs_oracle():
+    g = golden('c5_leeway_stere.npz')
+    B = replay.OracleBackend(replay.scenario_c5(g), g['lon'][0], g['lat'][0], g['z'][0])
+    worst = replay.compare(replay.replay_c5(B, g, g['lon'].shape[0] - 1), g, tol_pos=1e-7)
+    print('c5 oracle vs reference:', worst)
