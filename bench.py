@@ -38,6 +38,7 @@ BYTES = {
     'c2': dict(step=48, advect=56),
     'c3': dict(step=908, advect=3 * 128 + 56),
     'c4': dict(step=436, advect=3 * 64 + 56),
+    'c5': dict(step=220, advect=88),
 }
 HBM_PEAK = 8.0e12
 
@@ -49,10 +50,10 @@ def make_fields(workload, small=False):
         g = synth.grid3d(nx=n[0], ny=n[1], nz=n[2], nt=3, seed=0)
         names = [U, V, W, KZ, DEPTH, LAND]
         return dict(g=g, names=names, proj=None, z=g['z'])
-    if workload == 'c4':
+    if workload in ('c4', 'c5'):
         n = (260, 90) if small else (2602, 902)
         g = synth.grid_stere(nx=n[0], ny=n[1], nt=3, seed=0)
-        names = [U, V, XW, YW, SX, SY, LAND]
+        names = [U, V, XW, YW, SX, SY, LAND] if workload == 'c4' else [U, V, XW, YW, LAND]
         return dict(g=g, names=names, proj=synth.NORKYST_PROJ, z=None)
     return None
 
@@ -114,6 +115,9 @@ class Workload:
         if name == 'c3':
             self.dt, self.dt_mix, self.tmax = 600.0, 60.0, 2 * 3600.0 - 600.0
             self.vars = [U, V, W, DEPTH, SSH, LAND]
+        elif name == 'c5':
+            self.dt, self.tmax = 600.0, 2 * 3600.0 - 600.0
+            self.vars = [XW, YW, U, V, LAND]
         else:
             cs = ctx.add_constant({HD: 10.0})
             ctx.bind(HD, [cs], 0.0)
@@ -136,6 +140,13 @@ class Workload:
             P.store_previous()
             P.advect('runge-kutta4', t, self.dt)
             P.vmix(t, self.dt, self.dt_mix, step=k, fuse_vertical_advection=False)
+        elif self.name == 'c5':   # Leeway ensemble members: Euler by construction (leeway.py:472-476)
+            P.env_sample(self.vars, t)
+            P.env_add_noise(U, V, 0.1, step=k)        # drift:current_uncertainty
+            P.env_add_noise(XW, YW, 2.0, step=k)      # drift:wind_uncertainty
+            P.coastline('stranding', stranded_code=1)
+            P.compact()
+            P.leeway(self.dt, 0.4, step=k)
         else:
             P.env_sample(self.vars, t)
             P.coastline('stranding', stranded_code=1)
@@ -146,7 +157,10 @@ class Workload:
             P.hdiffusion(self.dt, step=k)
 
     def advect_only(self, P, k):
-        P.advect('runge-kutta4', self.time_of(k), self.dt)
+        if self.name == 'c5':
+            P.leeway(self.dt, 0.4, step=k)
+        else:
+            P.advect('runge-kutta4', self.time_of(k), self.dt)
 
 
 def cpu_baseline(name, fields, n_cpu, rng):
@@ -173,6 +187,8 @@ def cpu_baseline(name, fields, n_cpu, rng):
             wb.add_constant({orc.VAR[HD]: 10.0})
         dt = 600.0 if name == 'c3' else 900.0
     w = wb.finish()
+    if name == 'c5':
+        raise SystemExit('cpu baseline for c5: run tests/test_oracle_golden.py::test_c5 (not timed in bench)')
     lon, lat, z = seed_particles(name, fields, n_cpu, rng)
     mv, cdf = np.ones(n_cpu, np.int32), np.ones(n_cpu, np.float32)
     wdf = np.full(n_cpu, 0.02, np.float32)
@@ -215,7 +231,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default=os.environ.get('ODR_WORKLOAD', 'c3'), choices=['c2', 'c3', 'c4'])
+    ap.add_argument('--workload', default=os.environ.get('ODR_WORKLOAD', 'c3'), choices=['c2', 'c3', 'c4', 'c5'])
     ap.add_argument('--particles', type=int, default=0, help='particles per GPU (default: the config size)')
     ap.add_argument('--small', action='store_true', help='small field block (debug)')
     ap.add_argument('--no-cpu', action='store_true')
@@ -234,7 +250,7 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a GPU: the product path has no CPU fallback'
     torch.cuda.set_device(local_rank)
 
-    n = a.particles or {'c2': 1_000_000, 'c3': 10_000_000, 'c4': 6_250_000}[a.workload]
+    n = a.particles or {'c2': 1_000_000, 'c3': 10_000_000, 'c4': 6_250_000, 'c5': 10_000_000}[a.workload]
     fields = make_fields(a.workload, a.small)
     ctx = Context(device=local_rank, seed=0)
     wl = Workload(a.workload, ctx, fields, (rank, local_rank, world))
@@ -249,6 +265,13 @@ def main():
     lo, hi = D.shard_range(n * world, rank, world)     # global particle IDs of this shard
     P = ctx.particles(n)
     P.append(lon, lat, z=z, id=np.arange(lo, hi, dtype=np.int32))
+    if a.workload == 'c5':   # LeewayObj coefficients of a PIW-like class, perturbed per element (leeway.py:318-372)
+        r5 = np.random.default_rng(7 + rank)
+        ori = (np.arange(n) % 2).astype(np.float32)
+        for slot, val in enumerate([np.full(n, 0.96), np.where(ori == 0, 0.54, -0.54), np.zeros(n), np.zeros(n),
+                                    np.abs(r5.standard_normal(n)) * 12.0, r5.standard_normal(n) * 9.4,
+                                    np.full(n, 0.04), ori, np.zeros(n)]):
+            P.set_property(slot, val.astype(np.float32))
 
     for k in range(a.warmup):
         wl.step(P, k)
@@ -295,10 +318,12 @@ def main():
                                     'c3': 'C3: OceanDrift 3D, synthetic ROMS-shaped z-level grid 1024x1024x12 (u,v,w,K), '
                                           'RK4 + vertical_mixing(60 s) + vertical_advection',
                                     'c4': 'C4: OpenOil-advection on NorKyst-800-shaped 2602x902 stere grid, RK4 + wind + '
-                                          'Stokes + horizontal diffusion + stranding'}[a.workload],
+                                          'Stokes + horizontal diffusion + stranding',
+                                    'c5': 'C5: Leeway ensemble members (2 x 5 M per GPU) on the NorKyst-800-shaped grid, '
+                                          'wind/current uncertainty, stranding'}[a.workload],
                        'particles_per_gpu': n, 'particles_total': n * world, 'time_step_s': wl.dt,
                        'parallelism': 'particle-sharded x%d, field block broadcast once per time level' % world},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_advect<RK4>', 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9,
+            'roofline': {'bound': 'hbm', 'kernel': 'k_leeway' if a.workload == 'c5' else 'k_advect<RK4>', 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9,
                          'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': traffic, 'traffic_unit': 'GB per launch (PMC)',
                          'algorithmic_gb_per_launch': BYTES[a.workload]['advect'] * nact / 1e9,
                          'kernel_ms': k_ms, 'algorithmic_bytes_per_particle': BYTES[a.workload]['advect'],
