@@ -205,6 +205,54 @@ __device__ __forceinline__ double rotation_angle(const DevProj &p, double x, dou
   return -az1;  // rot_angle_rad = -rot_angle_vectors_rad
 }
 
+// cos / sin of rot_angle_rad = -(azimuth of the reader's +y axis) without any transcendental call
+// for the polar ellipsoidal stereographic projection: with t = tan(pi/4 - chi/2) = rho/akm1 the
+// differences of the two inverse projections are
+//   dlam = atan2(X (Y1 - Y2), X^2 + Y1 Y2),   dchi = -2 atan((t2 - t1) / (1 + t1 t2)),
+//   dphi = dchi (1 + sum 2k c_k cos 2k chi_m)                       (Snyder eq. 3-5 differentiated)
+// both atans have arguments ~1e-6 (10 m over the earth radius -> Gregory series), sin/cos of chi_m are
+// rational in t_m, sin/cos of the multiples by recurrence, and the geodetic mid latitude is
+// chi_m + delta with |delta| < 3.4e-3 (angle-addition with a short Taylor series).
+__device__ __forceinline__ void rotation_cs(const DevProj &p, double x, double y, double &cs, double &sn) {
+#pragma clang fp contract(fast)
+  if (!(p.kind == PROJ_STERE_POLAR && p.es != 0)) {
+    double rot = rotation_angle(p, x, y);
+    sincos(rot, &sn, &cs);
+    return;
+  }
+  const GeodConst &g = c_geod;
+  const double inva = fast_rcp(p.a);
+  double X = (x - p.x0) * inva, Y1 = (y - p.y0) * inva, Y2 = (y + 10.0 - p.y0) * inva;
+  if (!p.south) { Y1 = -Y1; Y2 = -Y2; }
+  double r1 = fast_sqrt(X * X + Y1 * Y1), r2 = fast_sqrt(X * X + Y2 * Y2);
+  double dlam = atan_ratio(X * (Y1 - Y2), X * X + Y1 * Y2);
+  double ik = fast_rcp(p.akm1);
+  double t1 = r1 * ik, t2 = r2 * ik;
+  double dt = (Y2 - Y1) * (Y2 + Y1) * fast_rcp(r1 + r2) * ik;
+  double dchi = -2 * atan_ratio(dt, 1 + t1 * t2);
+  double tm = 0.5 * (t1 + t2), q = fast_rcp(1 + tm * tm);
+  double sch = (1 - tm * tm) * q, cch = 2 * tm * q;            // sin, cos of chi_m
+  double c2 = cch * cch - sch * sch, s2 = 2 * sch * cch;       // cos, sin of 2 chi_m
+  double c4 = 2 * c2 * c2 - 1, s4 = 2 * s2 * c2;
+  double c6 = 2 * c2 * c4 - c2, s6 = 2 * c2 * s4 - s2;
+  double c8 = 2 * c2 * c6 - c4, s8 = 2 * c2 * s6 - s4;
+  double dphi = dchi * (1 + 2 * p.cchi[0] * c2 + 4 * p.cchi[1] * c4 + 6 * p.cchi[2] * c6 + 8 * p.cchi[3] * c8);
+  double dl = p.cchi[0] * s2 + p.cchi[1] * s4 + p.cchi[2] * s6 + p.cchi[3] * s8;   // phi_m - chi_m
+  double d2 = dl * dl;
+  double sd = dl * (1 - d2 * (1.0 / 6 - d2 * (1.0 / 120))), cd = 1 - d2 * (0.5 - d2 * (1.0 / 24));
+  double sphi = sch * cd + cch * sd, cphi = cch * cd - sch * sd;
+  if (p.south) { sphi = -sphi; dphi = -dphi; }
+  double w2 = 1 - g.e2 * sphi * sphi, iw = fast_rsqrt(w2);
+  double N = g.a * iw, M = g.a * (1 - g.e2) * iw * iw * iw;
+  double se = dlam * N * cphi, snn = dphi * M;
+  double ih = fast_rsqrt(se * se + snn * snn);
+  double saz = se * ih, caz = snn * ih;                         // azimuth of the 10 m chord at its mid point
+  double eps = 0.5 * dlam * sphi;                               // half the meridian convergence
+  double ce = 1 - 0.5 * eps * eps;
+  cs = caz * ce + saz * eps;                                    // cos(-(az_mid - eps))
+  sn = -(saz * ce - caz * eps);                                 // sin(-(az_mid - eps))
+}
+
 // Footprint of scipy.ndimage.map_coordinates(order=1) along one axis in the form the reference
 // finally delivers: a NaN of the first (mode='constant') pass is always retried with
 // mode='nearest' (interpolators.py:122-137), and on finite data both modes agree, so the device
@@ -386,8 +434,8 @@ __device__ __forceinline__ bool source_sample(const DevSource &s, const int (&va
     for (int v = 0; v < NV; ++v)
       if (vars[v] == VAR_U || vars[v] == VAR_XWIND || vars[v] == VAR_SX) need = true;
     if (need) {
-      double rot = rotation_angle(s.proj, x, y), sn, cs;
-      sincos(rot, &sn, &cs);
+      double sn, cs;
+      rotation_cs(s.proj, x, y, cs, sn);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         int partner = vars[v] == VAR_U ? VAR_V : vars[v] == VAR_XWIND ? VAR_YWIND
@@ -543,8 +591,8 @@ __device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBloc
       }
     }
     if (PROJ != PROJ_LATLONG) {
-      double rot = rotation_angle(s.proj, x, y), sn, cs;
-      sincos(rot, &sn, &cs);
+      double sn, cs;
+      rotation_cs(s.proj, x, y, cs, sn);
       double uu = u, vv = v;
       u = __dsub_rn(__dmul_rn(uu, cs), __dmul_rn(vv, sn));
       v = __dadd_rn(__dmul_rn(uu, sn), __dmul_rn(vv, cs));
@@ -655,8 +703,8 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
 #pragma unroll
       for (int k = 0; k < MAXG; ++k) if (k < G.nv && G.partner[k] >= 0) need = true;
       if (need) {
-        double rot = rotation_angle(s.proj, x, y), sn, cs;
-        sincos(rot, &sn, &cs);
+        double sn, cs;
+        rotation_cs(s.proj, x, y, cs, sn);
 #pragma unroll
         for (int k = 0; k < MAXG; ++k) {
           if (k >= G.nv || G.partner[k] < 0) continue;
