@@ -36,8 +36,9 @@ HD = 'horizontal_diffusivity'
 # algorithmic bytes per particle
 BYTES = {
     'c2': dict(step=48, advect=56),
-    'c3': dict(step=908, advect=3 * 128 + 56),
-    'c4': dict(step=436, advect=3 * 64 + 56),
+    # fused = k_step_grid: environment sample of the group + coastline + previous + RK4
+    'c3': dict(step=908, advect=3 * 128 + 56, fused=(128 + 64 + 32 + 8) + 100 + 3 * 128),
+    'c4': dict(step=436, advect=3 * 64 + 56, fused=(3 * 64 + 8) + 92 + 3 * 64),
     'c5': dict(step=220, advect=88),
 }
 HBM_PEAK = 8.0e12
@@ -83,7 +84,8 @@ class Workload:
     def __init__(self, name, ctx, fields, dist_info):
         from opendrift_amd import distributed as D
         self.name, self.ctx, self.fields = name, ctx, fields
-        self.sort_every = int(os.environ.get('ODR_SORT_EVERY', 8))
+        self.sort_every = int(os.environ.get('ODR_SORT_EVERY', 16))
+        self.fused = not os.environ.get('ODR_UNFUSED')   # one launch for sample+coastline+previous+advect
         rank, local_rank, world = dist_info
         if name == 'c2':
             sid = ctx.add_double_gyre(A=0.1, epsilon=0.25, omega=0.628, t0=0.0)
@@ -135,10 +137,14 @@ class Workload:
             P.env_sample([U, V], t)
             P.advect('runge-kutta4', t, self.dt)
         elif self.name == 'c3':
-            P.env_sample(self.vars, t)
-            P.coastline('previous')
-            P.store_previous()
-            P.advect('runge-kutta4', t, self.dt)
+            if self.fused:
+                P.env_coast_advect(self.vars, t, 'runge-kutta4', self.dt, coastline='previous', store_previous=True,
+                                   count=False)
+            else:
+                P.env_sample(self.vars, t)
+                P.coastline('previous')
+                P.store_previous()
+                P.advect('runge-kutta4', t, self.dt)
             P.vmix(t, self.dt, self.dt_mix, step=k, fuse_vertical_advection=False)
         elif self.name == 'c5':   # Leeway ensemble members: Euler by construction (leeway.py:472-476)
             P.env_sample(self.vars, t)
@@ -148,17 +154,27 @@ class Workload:
             P.compact()
             P.leeway(self.dt, 0.4, step=k)
         else:
-            P.env_sample(self.vars, t)
-            P.coastline('stranding', stranded_code=1)
-            P.compact()
-            P.advect('runge-kutta4', t, self.dt)
+            if self.fused:
+                P.env_coast_advect(self.vars, t, 'runge-kutta4', self.dt, coastline='stranding', stranded_code=1,
+                                   store_previous=False)
+                P.compact()
+            else:
+                P.env_sample(self.vars, t)
+                P.coastline('stranding', stranded_code=1)
+                P.compact()
+                P.advect('runge-kutta4', t, self.dt)
             P.advect_wind(self.dt, wind_drift_depth=0.1)
             P.stokes_drift(self.dt, profile=2, hs_mode=1, tp_mode=1)
             P.hdiffusion(self.dt, step=k)
 
     def advect_only(self, P, k):
+        """The dominant kernel alone (timed with HIP events for the roofline object)."""
         if self.name == 'c5':
             P.leeway(self.dt, 0.4, step=k)
+        elif self.fused and self.name in ('c3', 'c4'):
+            P.env_coast_advect([v for v in self.vars if v not in (SSH, HD)], self.time_of(k), 'runge-kutta4', self.dt,
+                               coastline='previous' if self.name == 'c3' else 'stranding',
+                               store_previous=self.name == 'c3', count=False)
         else:
             P.advect('runge-kutta4', self.time_of(k), self.dt)
 
@@ -300,7 +316,9 @@ def main():
         wl.advect_only(P, k)
     k_ms = ctx.timer_end() / reps
     nact = len(P)
-    ach = BYTES[a.workload]['advect'] * nact / (k_ms * 1e-3)
+    kfused = wl.fused and a.workload in ('c3', 'c4')
+    kbytes = BYTES[a.workload]['fused' if kfused else 'advect']
+    ach = kbytes * nact / (k_ms * 1e-3)
 
     traffic = None
     pj = os.path.join(ROOT, 'profiles', 'r01_%s_pmc.json' % a.workload)
@@ -323,10 +341,10 @@ def main():
                                           'wind/current uncertainty, stranding'}[a.workload],
                        'particles_per_gpu': n, 'particles_total': n * world, 'time_step_s': wl.dt,
                        'parallelism': 'particle-sharded x%d, field block broadcast once per time level' % world},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_leeway' if a.workload == 'c5' else 'k_advect<RK4>', 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9,
+            'roofline': {'bound': 'hbm', 'kernel': 'k_leeway' if a.workload == 'c5' else ('k_step_grid<RK4>' if kfused else 'k_advect<RK4>'), 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9,
                          'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': traffic, 'traffic_unit': 'GB per launch (PMC)',
-                         'algorithmic_gb_per_launch': BYTES[a.workload]['advect'] * nact / 1e9,
-                         'kernel_ms': k_ms, 'algorithmic_bytes_per_particle': BYTES[a.workload]['advect'],
+                         'algorithmic_gb_per_launch': kbytes * nact / 1e9,
+                         'kernel_ms': k_ms, 'algorithmic_bytes_per_particle': kbytes,
                          'step_bytes_per_particle': BYTES[a.workload]['step'],
                          'step_frac': BYTES[a.workload]['step'] * (units / el_max) / world / HBM_PEAK},
         }

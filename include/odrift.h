@@ -153,6 +153,17 @@ int odr_env_add_noise(odr_ctx *ctx, odr_particles *p, int32_t var_x, int32_t var
 /* PhysicsMethods.advect_ocean_current (physics_methods.py:611-691) + update_positions
  * (basemodel/__init__.py:4631-4657), all sub-stages fused in one kernel. */
 int odr_advect(odr_ctx *ctx, odr_particles *p, int scheme, double t_epoch, double dt, double factor);
+/* One iteration of the run() loop up to and including the current advection
+ * (basemodel/__init__.py:2136-2248): odr_env_sample(var_ids, t) -> odr_coastline(action, codes) ->
+ * odr_store_previous (if store_previous) -> odr_advect(scheme, t, dt, factor), fused into ONE kernel
+ * when the group holding x/y_sea_water_velocity comes from one gridded reader (else the four calls are
+ * made in that order).  Elements the coastline deactivates ('stranded', 'seeded_on_land') are
+ * flagged and left where the coastline put them -- the reference removes them before update() --
+ * so  fused call + odr_compact  is bit-identical to  sample, coastline, compact, store_previous,
+ * advect. */
+int odr_env_coast_advect(odr_ctx *ctx, odr_particles *p, int nvars, const int32_t *var_ids, double t_epoch,
+                         int coastline_action, int stranded_code, int seeded_on_land_code,
+                         int store_previous, int scheme, double dt, double factor, int64_t *n_on_land);
 /* update_positions with caller-supplied velocities (models that compute them on the host) */
 int odr_update_positions(odr_ctx *ctx, odr_particles *p, const double *x_vel, const double *y_vel,
                          int velocities_are_float32, double dt);

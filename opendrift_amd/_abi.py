@@ -68,6 +68,8 @@ _SIGNATURES = {
     'odr_env_upload': [_vp, _vp, C.c_int32, _fp],
     'odr_env_add_noise': [_vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_int, _dp, _dp, C.c_uint64],
     'odr_advect': [_vp, _vp, C.c_int, C.c_double, C.c_double, C.c_double],
+    'odr_env_coast_advect': [_vp, _vp, C.c_int, _ip, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.c_double, C.c_double, _P(C.c_int64)],
     'odr_update_positions': [_vp, _vp, _dp, _dp, C.c_int, C.c_double],
     'odr_advect_wind': [_vp, _vp, C.c_double, C.c_double, C.c_int, C.c_double],
     'odr_stokes_drift': [_vp, _vp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double],

@@ -30,6 +30,7 @@ struct DevBlock {
   int ny, nx, valid, pad;
   double x0, xspan, y0, yspan;      // Linear2DInterpolator index map (interpolators.py:110-111)
   double xmin, xrange, ymin, yrange;  // Nearest2DInterpolator index map (interpolators.py:32-37)
+  double ixspan, iyspan, ixrange, iyrange;  // correctly rounded reciprocals (host) for div_cr()
   double t;
   // pre-dilated device arrays, z innermost: element (k, y, x) of variable v lives at
   // data[v][((y*nx + x)*var_nz[v] + k) * es[v]].  x/y_sea_water_velocity (and the other vector
@@ -48,6 +49,15 @@ struct DevSource {
   double const_val[NVAR];
   double params[8];
   double z[MAXNZ];
+  // Linear1DInterpolator (interp1d) per ascending interval j: node depth, slope (+-1/dz, IEEE
+  // division done once on the host) and the index value at the node
+  double zi_x[MAXNZ], zi_slope[MAXNZ], zi_y[MAXNZ];
+  double zasc[MAXNZ];  // z levels in ascending order
+  // np.gradient(K, mixing_z) constants (oceandrift.py:501): edge / uniform-interior divisors with
+  // their reciprocals, and the second-order coefficients of non-uniform interior levels
+  double vg_d[3], vg_id[3];
+  double vg_a[MAXNZ], vg_b[MAXNZ], vg_c[MAXNZ];
+  int vg_uniform, vg_pad;
   double zmid[MAXNZ];  // mid-depths -(z[k] + z[k+1])/2 formed as d[k] + 0.5*(d[k+1]-d[k]), d = -z (k_vmix level search)
   int level_slot[MAXLEVELS];  // slots sorted by time
   DevBlock slot[MAXLEVELS];
@@ -63,6 +73,21 @@ struct DevWorld {
 
 static constexpr double kPi = 3.14159265358979323846264338327950288;
 static constexpr double kHalfPi = 1.57079632679489661923;
+
+// Correctly rounded a / b for a divisor whose correctly rounded reciprocal ib = RN(1/b) is
+// known (wave-uniform grid constants, computed once on the host): quotient estimate plus two
+// exact-residual corrections (Markstein).  5 instructions instead of the ~25 of the IEEE divide
+// expansion, same bits (tests/test_gpu_parity.py compares environment values bit for bit).
+__device__ __forceinline__ double div_cr(double a, double b, double ib) {
+  double q = a * ib;
+  q = fma(fma(-b, q, a), ib, q);
+  q = fma(fma(-b, q, a), ib, q);
+  return q;
+}
+__device__ __forceinline__ float div_cr_f32(float a, float b, float ib) {
+  float q = a * ib;
+  return fmaf(fmaf(-b, q, a), ib, q);
+}
 
 __device__ __forceinline__ double np_mod(double x, double m) {  // numpy.mod
   double r = fmod(x, m);
@@ -287,29 +312,27 @@ __device__ __forceinline__ float bilinear_f32(const float *__restrict__ a, int n
   return (float)t;
 }
 
-__device__ __forceinline__ int nearest_index(double v, double vmin, double vrange, int n) {
-  double r = rint((v - vmin) / vrange * n);
+__device__ __forceinline__ int nearest_index(double v, double vmin, double vrange, double ivrange, int n) {
+  double r = rint(__dmul_rn(div_cr(v - vmin, vrange, ivrange), (double)n));
   if (!(r >= 0) || r >= n) return n - 1;
   return (int)r;
 }
 
 // Linear1DInterpolator (interpolators.py:174-197): scipy interp1d(zgrid -> index), int8 floor.
-__device__ __forceinline__ void zinterp(const double *zg, int nz, double z, int &ia, int &ib,
-                                        double &wa) {
-  bool asc = zg[1] > zg[0];
-  double zmin = asc ? zg[0] : zg[nz - 1], zmax = asc ? zg[nz - 1] : zg[0];
-  // zgrid.min()/max(): monotone grids only
+// The interval is found by counting the (wave-uniform) levels below z; its node, slope and index
+// value come from the per-source tables the host filled with the same IEEE operations interp1d
+// performs -- no per-particle divide and no dependent table walk.
+__device__ __forceinline__ void zinterp(const DevSource &s, double z, int &ia, int &ib, double &wa) {
+  const int nz = s.nz;
+  const double zmin = s.zasc[0], zmax = s.zasc[nz - 1];  // zgrid.min()/max(): monotone grids only
   z = z < zmin ? zmin : z;
   z = z > zmax ? zmax : z;
   int hi = 0;
-  while (hi < nz && (asc ? zg[hi] : zg[nz - 1 - hi]) < z) ++hi;
+  for (int k = 0; k < nz; ++k) hi += s.zasc[k] < z ? 1 : 0;
   hi = hi < 1 ? 1 : hi;
   hi = hi > nz - 1 ? nz - 1 : hi;
-  int lo = hi - 1;
-  double xl = asc ? zg[lo] : zg[nz - 1 - lo], xh = asc ? zg[hi] : zg[nz - 1 - hi];
-  double yl = asc ? lo : nz - 1 - lo, yh = asc ? hi : nz - 1 - hi;
-  double slope = __ddiv_rn(yh - yl, xh - xl);
-  double zi = __dadd_rn(__dmul_rn(slope, z - xl), yl);
+  const int lo = hi - 1;
+  double zi = __dadd_rn(__dmul_rn(s.zi_slope[lo], z - s.zi_x[lo]), s.zi_y[lo]);
   ia = (int)(signed char)(long long)floor(zi);
   ia = ia < 0 ? 0 : ia;
   ib = ia + 1 < nz - 1 ? ia + 1 : nz - 1;
@@ -324,12 +347,12 @@ __device__ __forceinline__ double block_value(const DevBlock &b, const DevSource
   const size_t ns = (size_t)nzv * es;
   if (var == VAR_LAND) {
     f32class = true;
-    int xi = nearest_index(x, b.xmin, b.xrange, b.nx);
-    int yi = nearest_index(y, b.ymin, b.yrange, b.ny);
+    int xi = nearest_index(x, b.xmin, b.xrange, b.ixrange, b.nx);
+    int yi = nearest_index(y, b.ymin, b.yrange, b.iyrange, b.ny);
     return d[((size_t)yi * b.nx + xi) * ns];
   }
-  double xi = __dmul_rn(__ddiv_rn(x - b.x0, b.xspan), (double)(b.nx - 1));
-  double yi = __dmul_rn(__ddiv_rn(y - b.y0, b.yspan), (double)(b.ny - 1));
+  double xi = __dmul_rn(div_cr(x - b.x0, b.xspan, b.ixspan), (double)(b.nx - 1));
+  double yi = __dmul_rn(div_cr(y - b.y0, b.yspan, b.iyspan), (double)(b.ny - 1));
   if (nzv <= 1) {
     f32class = true;
     return bilinear_f32(d, b.ny, b.nx, ns, yi, xi);
@@ -337,7 +360,7 @@ __device__ __forceinline__ double block_value(const DevBlock &b, const DevSource
   f32class = false;
   int ia, ib;
   double wa;
-  zinterp(s.z, s.nz, z, ia, ib, wa);
+  zinterp(s, z, ia, ib, wa);
   double va = bilinear_f32(d + (size_t)ia * es, b.ny, b.nx, ns, yi, xi);
   double vb = bilinear_f32(d + (size_t)ib * es, b.ny, b.nx, ns, yi, xi);
   return __dadd_rn(__dmul_rn(va, wa), __dmul_rn(vb, 1 - wa));
@@ -501,7 +524,7 @@ struct ZBracket { int iz0, same; double wa; };  // levels (ia, ib): ia = iz0 + (
 __device__ __forceinline__ ZBracket zbracket(const DevSource &s, double z) {
   ZBracket zb;
   int ia, ib;
-  zinterp(s.z, s.nz, z, ia, ib, zb.wa);
+  zinterp(s, z, ia, ib, zb.wa);
   zb.same = ia == ib;                       // clamped at the deepest level
   zb.iz0 = zb.same ? (ia > 0 ? ia - 1 : 0) : ia;
   return zb;
@@ -573,8 +596,8 @@ __device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBloc
   float fu = __builtin_nanf(""), fv = __builtin_nanf("");
   if (xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin && z <= s.zmax) {
     if (s.mod360_x) x = np_mod(x, 360.0);
-    double xi = __dmul_rn(__ddiv_rn(x - geo.x0, geo.xspan), (double)(geo.nx - 1));
-    double yi = __dmul_rn(__ddiv_rn(y - geo.y0, geo.yspan), (double)(geo.ny - 1));
+    double xi = __dmul_rn(div_cr(x - geo.x0, geo.xspan, geo.ixspan), (double)(geo.nx - 1));
+    double yi = __dmul_rn(div_cr(y - geo.y0, geo.yspan, geo.iyspan), (double)(geo.ny - 1));
     double ub, vb;
     bool f32c;
     uv_level<IS3D>(tm.b, geo.ny, geo.nx, s.nz, yi, xi, zb, ub, vb, f32c);
@@ -633,8 +656,8 @@ __device__ __forceinline__ double var_level(const float *__restrict__ d, int var
   const size_t ns = (size_t)nzv * es;
   if (var == VAR_LAND) {
     f32class = true;
-    int ix = nearest_index(x, g.xmin, g.xrange, g.nx);
-    int iy = nearest_index(y, g.ymin, g.yrange, g.ny);
+    int ix = nearest_index(x, g.xmin, g.xrange, g.ixrange, g.nx);
+    int iy = nearest_index(y, g.ymin, g.yrange, g.iyrange, g.ny);
     return d[((size_t)iy * g.nx + ix) * ns];
   }
   const Axis ay = axis_fp(yi, g.ny), ax = axis_fp(xi, g.nx);
@@ -681,8 +704,8 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
   double val[MAXG];
   if (covered) {
     if (s.mod360_x) x = np_mod(x, 360.0);
-    const double xi = __dmul_rn(__ddiv_rn(x - geo.x0, geo.xspan), (double)(geo.nx - 1));
-    const double yi = __dmul_rn(__ddiv_rn(y - geo.y0, geo.yspan), (double)(geo.ny - 1));
+    const double xi = __dmul_rn(div_cr(x - geo.x0, geo.xspan, geo.ixspan), (double)(geo.nx - 1));
+    const double yi = __dmul_rn(div_cr(y - geo.y0, geo.yspan, geo.iyspan), (double)(geo.ny - 1));
     ZBracket zb;
     zb.iz0 = 0; zb.same = 0; zb.wa = 1;
     if (s.nz > 1) zb = zbracket(s, z);

@@ -128,7 +128,7 @@ __device__ __forceinline__ float rk4_mix(float k1, float k2, float k3, float k4)
   float s = __fadd_rn(k1, __fmul_rn(2.0f, k2));
   s = __fadd_rn(s, __fmul_rn(2.0f, k3));
   s = __fadd_rn(s, k4);
-  return __fdiv_rn(s, 6.0f);
+  return div_cr_f32(s, 6.0f, 1.0f / 6.0f);  // == s / 6.0f, correctly rounded
 }
 
 // generic version: any mix of readers behind the (u,v) priority list
@@ -174,18 +174,9 @@ __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W
 // fast version: (u,v) from one gridded reader, interleaved z-innermost blocks, host-resolved
 // time brackets (odr_field.hip.h "fast (u,v) path")
 template <int SCHEME, int PROJ, bool IS3D>
-__global__ __launch_bounds__(BLOCK) void k_advect_grid(const DevWorld *__restrict__ W, int sid, int geo_slot,
-                                                       PView p, double dt, float factor, UVTime th,
-                                                       UVTime tf) {
-  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= p.n) return;
-  const DevSource &s = W->src[sid];
-  const DevBlock &geo = s.slot[geo_slot];
-  const float fbu = W->fallback[VAR_U], fbv = W->fallback[VAR_V];
-  double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
-  float u1 = p.env[VAR_U][i], v1 = p.env[VAR_V][i];
-  float f = __fmul_rn(factor, p.cdf[i]);
-  int moving = p.moving[i];
+__device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBlock &geo, double &lon, double &lat,
+                                                 double z, float u1, float v1, float f, int moving, double dt,
+                                                 const UVTime &th, const UVTime &tf, float fbu, float fbv) {
   float fu, fv;
   GeodOrigin o = geod_origin(lat, lon);
   if (SCHEME == 0) {
@@ -214,8 +205,89 @@ __global__ __launch_bounds__(BLOCK) void k_advect_grid(const DevWorld *__restric
     }
   }
   move_f32_from(o, lon, lat, fu, fv, moving, dt);
+}
+
+template <int SCHEME, int PROJ, bool IS3D>
+__global__ __launch_bounds__(BLOCK) void k_advect_grid(const DevWorld *__restrict__ W, int sid, int geo_slot,
+                                                       PView p, double dt, float factor, UVTime th,
+                                                       UVTime tf) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  const DevSource &s = W->src[sid];
+  const DevBlock &geo = s.slot[geo_slot];
+  double lon = p.lon[i], lat = p.lat[i];
+  advect_grid_body<SCHEME, PROJ, IS3D>(s, geo, lon, lat, p.z[i], p.env[VAR_U][i], p.env[VAR_V][i],
+                                       __fmul_rn(factor, p.cdf[i]), p.moving[i], dt, th, tf, W->fallback[VAR_U],
+                                       W->fallback[VAR_V]);
   p.lon[i] = lon;
   p.lat[i] = lat;
+}
+
+// One launch for  get_environment -> interact_with_coastline -> update_previous_state ->
+// advect_ocean_current  (the run() loop order, basemodel/__init__.py:2136-2248) when the group that
+// holds the current comes from one gridded reader: same arithmetic as the four separate kernels
+// (k_env_grid, k_coast, k_record_prev, k_advect_grid), but the particle stays in registers, and the
+// latency-bound block gathers of the environment sample overlap with the float64 geodesics of other
+// waves.  The host orders the group so that slot 0 = x_sea_water_velocity, 1 = y_sea_water_velocity
+// and, if `land_slot` == 2, 2 = land_binary_mask.
+struct StepDesc {
+  int coast_action, stranded_code, seeded_code, land_slot;  // land_slot: 2 or -1 (read p.env[LAND])
+  int store_previous, geo_slot_uv, pad0, pad1;
+};
+
+template <int SCHEME, int PROJ, bool IS3D>
+__global__ __launch_bounds__(BLOCK) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
+                                                     StepDesc S, double dt, float factor, UVTime th, UVTime tf,
+                                                     unsigned long long *n_hit) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  bool hit = false;
+  if (i < p.n) {
+    double lon = p.lon[i], lat = p.lat[i];
+    const double z = p.z[i];
+    float out[MAXG];
+    env_group_fast<PROJ>(*W, G, lon, lat, z, out);
+#pragma unroll
+    for (int k = 0; k < MAXG; ++k)
+      if (k < G.nv) p.env[G.var[k]][i] = out[k];
+    p.slon[i] = lon;
+    p.slat[i] = lat;
+    int moving = p.moving[i];
+    bool skip = false;  // deactivated by the coastline: the reference removes it before update()
+    if (S.coast_action) {  // k_coast
+      const float land = S.land_slot == 2 ? out[2] : p.env[VAR_LAND][i];
+      if (land == 1.0f) {
+        hit = true;
+        int st = p.status[i];
+        if (S.coast_action == 1) {
+          if (z <= 0) {
+            if (st == 0) p.status[i] = st = S.stranded_code;
+            p.moving[i] = moving = 0;
+          }
+        } else {
+          if (S.seeded_code > 0 && p.age[i] == 0.0f) {
+            if (st == 0) p.status[i] = st = S.seeded_code;
+            p.moving[i] = moving = 0;
+          }
+          lon = p.plon[i];
+          lat = p.plat[i];
+        }
+        skip = st != 0;
+      }
+    }
+    if (S.store_previous) { p.plon[i] = lon; p.plat[i] = lat; }
+    if (!skip) {
+      const DevSource &s = W->src[G.sid];
+      advect_grid_body<SCHEME, PROJ, IS3D>(s, s.slot[S.geo_slot_uv], lon, lat, z, out[0], out[1],
+                                           __fmul_rn(factor, p.cdf[i]), moving, dt, th, tf, W->fallback[VAR_U],
+                                           W->fallback[VAR_V]);
+    }
+    p.lon[i] = lon;
+    p.lat[i] = lat;
+  }
+  if (S.coast_action) {
+    unsigned long long b = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_hit, (unsigned long long)__popcll(b));
+  }
 }
 
 // update_positions with velocities supplied by the caller
@@ -501,10 +573,11 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
   }
   const int nzp = src ? (src->nz > 1 ? src->nz : 1) : 1;
   double *Kp = (double *)smem;           // [nzp][BLOCK]
-  double *dsh = Kp + (size_t)nzp * BLOCK;  // [nzp] level depths -mixing_z
+  double *gsh = Kp + (size_t)nzp * BLOCK;  // [3][nzp] second-order np.gradient coefficients per level
   const float Kfb = W->fallback[VAR_KZ];
-  const double *zp = src ? src->z : nullptr;
-  if (tid < nzp && zp) dsh[tid] = -zp[tid];
+  if (tid < nzp && src) {
+    gsh[tid] = src->vg_a[tid]; gsh[nzp + tid] = src->vg_b[tid]; gsh[2 * nzp + tid] = src->vg_c[tid];
+  }
   __syncthreads();
   if (i >= p.n) return;  // no barrier below: every thread touches only its own LDS column
   {
@@ -520,8 +593,8 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
       if (src->mod360_x) x = np_mod(x, 360.0);
       bracket(*src, t, ib, ia);
       const DevBlock &bb = src->slot[ib];
-      xi = __dmul_rn(__ddiv_rn(x - bb.x0, bb.xspan), (double)(bb.nx - 1));
-      yi = __dmul_rn(__ddiv_rn(y - bb.y0, bb.yspan), (double)(bb.ny - 1));
+      xi = __dmul_rn(div_cr(x - bb.x0, bb.xspan, bb.ixspan), (double)(bb.nx - 1));
+      yi = __dmul_rn(div_cr(y - bb.y0, bb.yspan, bb.iyspan), (double)(bb.ny - 1));
       if (ia >= 0) wgt = __ddiv_rn(t - bb.t, src->slot[ia].t - bb.t);
     }
     if (src && cov && src->slot[ib].es[VAR_KZ] == 1 && NZMAX > 1) {
@@ -575,13 +648,11 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
   // number of mid-depths passed (ties: np.round is half-to-even) -- a compare chain on
   // wave-uniform constants instead of a dependent table walk.  -dK/dz*dt_mix and
   // sqrt(K*|dt_mix|*2/r) of the current level are re-derived only when zi changes.
-  bool uniform_z = true;
-  for (int k = 1; k < nzp - 1; ++k)
-    if ((zp[k + 1] - zp[k]) != (zp[1] - zp[0])) uniform_z = false;
+  const bool uniform_z = src ? src->vg_uniform != 0 : true;
   const double sgn = dt > 0 ? 1.0 : (dt < 0 ? -1.0 : 0.0);
   const double dt_mix = dt_mix_cfg * sgn;
   const int ntimes = abs((int)(dt / dt_mix));
-  const double r = 1.0 / 3;
+  const double r = 1.0 / 3, ir = 1.0 / r;
   double z = p.z[i];
   const int moving = p.moving[i];
   const float Zmin = __fmul_rn(-1.f, __fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH][i]));  // float32 (:408)
@@ -606,23 +677,19 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
       const double Kz = Kp[zi * BLOCK + tid];
       double gK = 0;  // np.gradient(Kprofiles, mixing_z, axis=0)[zi] (oceandrift.py:501)
       if (nzp >= 2) {
-        if (zi == 0) gK = __ddiv_rn(Kp[BLOCK + tid] - Kz, zp[1] - zp[0]);
-        else if (zi == nzp - 1) gK = __ddiv_rn(Kz - Kp[(nzp - 2) * BLOCK + tid], zp[nzp - 1] - zp[nzp - 2]);
+        // divisors are level constants: host reciprocals + exact-residual correction (div_cr)
+        if (zi == 0) gK = div_cr(Kp[BLOCK + tid] - Kz, src->vg_d[0], src->vg_id[0]);
+        else if (zi == nzp - 1) gK = div_cr(Kz - Kp[(nzp - 2) * BLOCK + tid], src->vg_d[1], src->vg_id[1]);
         else if (uniform_z)
-          gK = __ddiv_rn(Kp[(zi + 1) * BLOCK + tid] - Kp[(zi - 1) * BLOCK + tid], __dmul_rn(2., zp[1] - zp[0]));
-        else {
-          double dx1 = -(dsh[zi] - dsh[zi - 1]), dx2 = -(dsh[zi + 1] - dsh[zi]);
-          double a = __ddiv_rn(-dx2, __dmul_rn(dx1, dx1 + dx2));
-          double b = __ddiv_rn(dx2 - dx1, __dmul_rn(dx1, dx2));
-          double c = __ddiv_rn(dx1, __dmul_rn(dx2, dx1 + dx2));
-          gK = __dadd_rn(__dadd_rn(__dmul_rn(a, Kp[(zi - 1) * BLOCK + tid]), __dmul_rn(b, Kz)),
-                         __dmul_rn(c, Kp[(zi + 1) * BLOCK + tid]));
-        }
+          gK = div_cr(Kp[(zi + 1) * BLOCK + tid] - Kp[(zi - 1) * BLOCK + tid], src->vg_d[2], src->vg_id[2]);
+        else
+          gK = __dadd_rn(__dadd_rn(__dmul_rn(gsh[zi], Kp[(zi - 1) * BLOCK + tid]), __dmul_rn(gsh[nzp + zi], Kz)),
+                         __dmul_rn(gsh[2 * nzp + zi], Kp[(zi + 1) * BLOCK + tid]));
       }
       double dK = -gK;
       if (fabs(dK) < 1e-10) dK = 0;  // gradK[np.abs(gradK)<1e-10] = 0 (:502)
       dKdt = __dmul_rn(dK, dt_mix);
-      sig = sqrt(__ddiv_rn(__dmul_rn(__dmul_rn(Kz, fabs(dt_mix)), 2.0), r));
+      sig = sqrt(div_cr(__dmul_rn(__dmul_rn(Kz, fabs(dt_mix)), 2.0), r, ir));
     }
     double u01;
     if (rng_mode == 1) u01 = huni[(size_t)it * p.n + i];
@@ -639,6 +706,142 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
     if (!mix_at_surface && surface) z = 0.0;
     if (z > 0) z = 0.0;                                                       // surface_stick
     if (z < (double)Zmin) z = (double)Zmin;                                   // lift_to_seafloor
+  }
+  if (vadv >= 0 && (vadv ? z <= 0 : z < 0)) {  // vertical_advection (oceandrift.py:315-350)
+    double zz = __dadd_rn(z, __dmul_rn(__dmul_rn((double)moving, (double)p.env[VAR_W][i]), dt));
+    z = zz < 0 ? zz : 0.0;
+  }
+  p.z[i] = z;
+}
+
+// Fast version for the common case -- the diffusivity comes from one gridded reader with a
+// plain (not interleaved) z-innermost K array.  The host resolves source, time bracket and
+// weight (VMixDesc); NQ = number of 4-level quads per column is a compile-time constant, so the
+// 8 column gathers are straight-line 16-byte loads that are all in flight together (the generic
+// kernel's run-time loops serialise them: one memory round trip per load), the level
+// boundaries live in scalar registers and the np.gradient divisors are host constants.
+struct VMixDesc {
+  int sid, nzp, geo_slot, pad;
+  const float *kb, *ka;  // K arrays of the bracketing time levels (ka == nullptr: on a time level)
+  double wgt;            // weight_after (structured.py:353-354)
+  float Kfb, pad2;
+};
+
+template <int NQ, bool TL>
+__global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__ W, PView p, VMixDesc D,
+                                                    double dt, double dt_mix_cfg, int mix_at_surface,
+                                                    int rng_mode, const double *__restrict__ huni,
+                                                    unsigned long long seed, unsigned long long step,
+                                                    int vadv) {
+  constexpr int NL = 4 * NQ;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  const int tid = threadIdx.x;
+  const DevSource &s = W->src[D.sid];
+  const int nzp = D.nzp;
+  double *Kp = (double *)smem;              // [NL][BLOCK]
+  double *gsh = Kp + (size_t)NL * BLOCK;    // [3][NL]
+  if (tid < nzp) {
+    gsh[tid] = s.vg_a[tid]; gsh[NL + tid] = s.vg_b[tid]; gsh[2 * NL + tid] = s.vg_c[tid];
+  }
+  __syncthreads();
+  if (i >= p.n) return;  // no barrier below: every thread touches only its own LDS column
+  const double Kfb = (double)D.Kfb;
+  {
+    double lon = p.slon[i], lat = p.slat[i], x, y;
+    if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
+    else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
+    proj_fwd(s.proj, lon, lat, x, y);
+    const bool cov = x >= s.xmin && x <= s.xmax && y >= s.ymin && y <= s.ymax;
+    if (s.mod360_x) x = np_mod(x, 360.0);
+    const DevBlock &bb = s.slot[D.geo_slot];
+    const double xi = __dmul_rn(div_cr(x - bb.x0, bb.xspan, bb.ixspan), (double)(bb.nx - 1));
+    const double yi = __dmul_rn(div_cr(y - bb.y0, bb.yspan, bb.iyspan), (double)(bb.ny - 1));
+    const int ny = bb.ny, nx = bb.nx;
+    const Axis ay = axis_fp(yi, ny), ax = axis_fp(xi, nx);
+    const double ty = ay.t, tx = ax.t, wy0 = 1 - ty, wx0 = 1 - tx, wgt = D.wgt;
+    // uncovered particles gather node (0,0) and discard it: keeps the loads unconditional
+    const size_t o00 = cov ? ((size_t)ay.i0 * nx + ax.i0) * nzp : 0, o01 = cov ? ((size_t)ay.i0 * nx + ax.i1) * nzp : 0;
+    const size_t o10 = cov ? ((size_t)ay.i1 * nx + ax.i0) * nzp : 0, o11 = cov ? ((size_t)ay.i1 * nx + ax.i1) * nzp : 0;
+    const float *kb = D.kb, *ka = TL ? D.ka : D.kb;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const F4 b00 = *(const F4 *)(kb + o00 + 4 * q), b01 = *(const F4 *)(kb + o01 + 4 * q);
+      const F4 b10 = *(const F4 *)(kb + o10 + 4 * q), b11 = *(const F4 *)(kb + o11 + 4 * q);
+      double v[4];
+      v[0] = (double)bil4(b00.x, b01.x, b10.x, b11.x, wy0, ty, wx0, tx);
+      v[1] = (double)bil4(b00.y, b01.y, b10.y, b11.y, wy0, ty, wx0, tx);
+      v[2] = (double)bil4(b00.z, b01.z, b10.z, b11.z, wy0, ty, wx0, tx);
+      v[3] = (double)bil4(b00.w, b01.w, b10.w, b11.w, wy0, ty, wx0, tx);
+      if (TL) {
+        const F4 a00 = *(const F4 *)(ka + o00 + 4 * q), a01 = *(const F4 *)(ka + o01 + 4 * q);
+        const F4 a10 = *(const F4 *)(ka + o10 + 4 * q), a11 = *(const F4 *)(ka + o11 + 4 * q);
+        double w[4];
+        w[0] = (double)bil4(a00.x, a01.x, a10.x, a11.x, wy0, ty, wx0, tx);
+        w[1] = (double)bil4(a00.y, a01.y, a10.y, a11.y, wy0, ty, wx0, tx);
+        w[2] = (double)bil4(a00.z, a01.z, a10.z, a11.z, wy0, ty, wx0, tx);
+        w[3] = (double)bil4(a00.w, a01.w, a10.w, a11.w, wy0, ty, wx0, tx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __dadd_rn(__dmul_rn(v[j], 1 - wgt), __dmul_rn(w[j], wgt));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Kp[(4 * q + j) * BLOCK + tid] = (cov && isfinite(v[j])) ? v[j] : Kfb;
+    }
+  }
+  // level boundaries (see k_vmix) in scalar registers; levels past the profile never match
+  double zm[NL - 1];
+#pragma unroll
+  for (int k = 0; k < NL - 1; ++k) zm[k] = k < nzp - 1 ? s.zmid[k] : __builtin_inf();
+  const bool uniform_z = s.vg_uniform != 0;
+  const double gd0 = s.vg_d[0], gi0 = s.vg_id[0], gd1 = s.vg_d[1], gi1 = s.vg_id[1], gd2 = s.vg_d[2], gi2 = s.vg_id[2];
+  const double sgn = dt > 0 ? 1.0 : (dt < 0 ? -1.0 : 0.0);
+  const double dt_mix = dt_mix_cfg * sgn;
+  const int ntimes = abs((int)(dt / dt_mix));
+  const double r = 1.0 / 3, ir = 1.0 / r;
+  double z = p.z[i];
+  const int moving = p.moving[i];
+  const float Zmin = __fmul_rn(-1.f, __fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH][i]));  // float32 (:408)
+  const double wstep = (double)__fmul_rn(p.tv[i], (float)dt_mix) * (double)moving;
+  rocrand_state_philox4x32_10 st;
+  if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
+  double2 u2 = make_double2(0.0, 0.0);
+  int zi_cur = -1;
+  double sig = 0, dKdt = 0;
+  for (int it = 0; it < ntimes; ++it) {
+    const bool surface = z == 0;
+    const double d = -z;
+    int zi = 0;
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) zi += ((k & 1) ? d >= zm[k] : d > zm[k]) ? 1 : 0;
+    if (zi != zi_cur) {
+      zi_cur = zi;
+      const double Kz = Kp[zi * BLOCK + tid];
+      double gK;  // np.gradient(Kprofiles, mixing_z, axis=0)[zi] (oceandrift.py:501)
+      if (zi == 0) gK = div_cr(Kp[BLOCK + tid] - Kz, gd0, gi0);
+      else if (zi == nzp - 1) gK = div_cr(Kz - Kp[(nzp - 2) * BLOCK + tid], gd1, gi1);
+      else if (uniform_z) gK = div_cr(Kp[(zi + 1) * BLOCK + tid] - Kp[(zi - 1) * BLOCK + tid], gd2, gi2);
+      else
+        gK = __dadd_rn(__dadd_rn(__dmul_rn(gsh[zi], Kp[(zi - 1) * BLOCK + tid]), __dmul_rn(gsh[NL + zi], Kz)),
+                       __dmul_rn(gsh[2 * NL + zi], Kp[(zi + 1) * BLOCK + tid]));
+      double dK = -gK;
+      if (fabs(dK) < 1e-10) dK = 0;  // gradK[np.abs(gradK)<1e-10] = 0 (:502)
+      dKdt = __dmul_rn(dK, dt_mix);
+      sig = sqrt(div_cr(__dmul_rn(__dmul_rn(Kz, fabs(dt_mix)), 2.0), r, ir));
+    }
+    double u01;
+    if (rng_mode == 1) u01 = huni[(size_t)it * p.n + i];
+    else {  // one Philox4x32-10 block = two float64 uniforms
+      if ((it & 1) == 0) u2 = rocrand_uniform_double2(&st);
+      u01 = (it & 1) ? u2.y : u2.x;
+    }
+    double R = __dsub_rn(__dmul_rn(2.0, u01), 1.0);
+    z = __dsub_rn(z, __dmul_rn((double)moving, __dsub_rn(dKdt, __dmul_rn(R, sig))));
+    if (z >= 0) z = -z;
+    if (z < (double)Zmin && moving == 1) z = __dsub_rn((double)__fmul_rn(2.f, Zmin), z);
+    z = __dadd_rn(z, wstep);
+    if (!mix_at_surface && surface) z = 0.0;
+    if (z > 0) z = 0.0;
+    if (z < (double)Zmin) z = (double)Zmin;
   }
   if (vadv >= 0 && (vadv ? z <= 0 : z < 0)) {  // vertical_advection (oceandrift.py:315-350)
     double zz = __dadd_rn(z, __dmul_rn(__dmul_rn((double)moving, (double)p.env[VAR_W][i]), dt));

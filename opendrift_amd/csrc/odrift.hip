@@ -443,6 +443,31 @@ int odr_source_grid(odr_ctx *c, const odr_proj_desc *proj, const double *dom, in
   s.nz = (nz > 1 && z) ? nz : 1;
   for (int k = 0; k < s.nz && z; ++k) s.z[k] = z[k];
   for (int k = 0; k + 1 < s.nz && z; ++k) s.zmid[k] = -z[k] + 0.5 * (-z[k + 1] - (-z[k]));
+  if (s.nz > 1) {  // np.gradient(Kprofiles, mixing_z, axis=0) constants for k_vmix
+    const int n = s.nz;
+    s.vg_d[0] = z[1] - z[0]; s.vg_d[1] = z[n - 1] - z[n - 2]; s.vg_d[2] = 2. * (z[1] - z[0]);
+    for (int k = 0; k < 3; ++k) s.vg_id[k] = 1.0 / s.vg_d[k];
+    s.vg_uniform = 1;
+    for (int k = 1; k < n - 1; ++k)
+      if ((z[k + 1] - z[k]) != (z[1] - z[0])) s.vg_uniform = 0;
+    for (int k = 1; k < n - 1; ++k) {
+      double dx1 = -(-z[k] - (-z[k - 1])), dx2 = -(-z[k + 1] - (-z[k]));
+      s.vg_a[k] = -dx2 / (dx1 * (dx1 + dx2));
+      s.vg_b[k] = (dx2 - dx1) / (dx1 * dx2);
+      s.vg_c[k] = dx1 / (dx2 * (dx1 + dx2));
+    }
+  }
+  if (s.nz > 1) {  // interp1d(zgrid, range(nz)) tables (Linear1DInterpolator, interpolators.py:174-197)
+    const bool asc = z[1] > z[0];
+    const int n = s.nz;
+    for (int k = 0; k < n; ++k) s.zasc[k] = asc ? z[k] : z[n - 1 - k];
+    for (int lo = 0; lo + 1 < n; ++lo) {
+      double yl = asc ? lo : n - 1 - lo, yh = asc ? lo + 1 : n - 2 - lo;
+      s.zi_x[lo] = s.zasc[lo];
+      s.zi_slope[lo] = (yh - yl) / (s.zasc[lo + 1] - s.zasc[lo]);
+      s.zi_y[lo] = yl;
+    }
+  }
   return 0;
 }
 
@@ -471,6 +496,7 @@ static int block_upload(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, i
   b.ny = ny; b.nx = nx; b.valid = 1;
   b.x0 = xy8[0]; b.xspan = xy8[1]; b.y0 = xy8[2]; b.yspan = xy8[3];
   b.xmin = xy8[4]; b.xrange = xy8[5]; b.ymin = xy8[6]; b.yrange = xy8[7];
+  b.ixspan = 1.0 / b.xspan; b.iyspan = 1.0 / b.yspan; b.ixrange = 1.0 / b.xrange; b.iyrange = 1.0 / b.yrange;
   b.t = t_epoch;
   size_t plane = (size_t)ny * nx;
   std::vector<float *> prep((size_t)nvars, nullptr);
@@ -572,7 +598,7 @@ int odr_env_bind(odr_ctx *c, int32_t var, int ns, const int32_t *sids, float fal
 static void host_bracket(const DevSource &s, double t, int &ib, int &ia);
 
 // fast path of odr_env_sample: a group served by one gridded reader with a uniform grid
-static bool launch_env_grid(odr_ctx *c, odr_particles *p, const int *grp, int ng, double t, int rec) {
+static bool build_env_group(const odr_ctx *c, const int *grp, int ng, double t, EnvGroupDesc &G) {
   const DevWorld &w = c->hw;
   if (ng > MAXG || w.nlist[grp[0]] != 1) return false;
   int sid = w.list[grp[0]][0];
@@ -588,7 +614,6 @@ static bool launch_env_grid(odr_ctx *c, odr_particles *p, const int *grp, int ng
   }
   int ib, ia;
   host_bracket(s, t, ib, ia);
-  EnvGroupDesc G;
   memset(&G, 0, sizeof G);
   G.nv = ng; G.sid = sid; G.geo_slot = s.level_slot[0];
   G.all_static = 1;
@@ -613,6 +638,13 @@ static bool launch_env_grid(odr_ctx *c, odr_particles *p, const int *grp, int ng
     for (int u = 0; pv >= 0 && u < ng; ++u) if (grp[u] == pv) G.partner[k] = u;
   }
   G.w = ia >= 0 ? (t - s.slot[ib].t) / (s.slot[ia].t - s.slot[ib].t) : 0.0;
+  return true;
+}
+
+static bool launch_env_grid(odr_ctx *c, odr_particles *p, const int *grp, int ng, double t, int rec) {
+  EnvGroupDesc G;
+  if (!build_env_group(c, grp, ng, t, G)) return false;
+  const DevSource &s = c->hw.src[G.sid];
   dim3 g(nblk(p->n)), b(BLOCK);
   PView v = view(p);
   switch (s.proj.kind) {
@@ -631,7 +663,16 @@ static void launch_group(odr_ctx *c, odr_particles *p, const int *vars, double t
   hipLaunchKernelGGL(k_env_group<NV>, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, c->dw, view(p), gv, t, rec);
 }
 
+static int env_sample_impl(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t,
+                           float *const *out_host, bool record_positions);
+
 int odr_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t, float *const *out_host) {
+  return env_sample_impl(c, p, nvars, var_ids, t, out_host, true);
+}
+
+// record_positions: remember the sample position (slon/slat) for the profiles of odr_vmix
+static int env_sample_impl(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t,
+                           float *const *out_host, bool record_positions) {
   REQUIRE(nvars > 0 && nvars <= NVAR && var_ids, "bad variable list");
   HIPCHK(hipSetDevice(c->device));
   int rc;
@@ -643,7 +684,7 @@ int odr_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_i
   if (p->n > 0) {
     // variable groups = variables sharing the same priority list (get_reader_groups, environment.py:339-374)
     bool done[NVAR] = {false};
-    int rec = 1;
+    int rec = record_positions ? 1 : 0;
     for (int a = 0; a < nvars; ++a) {
       int va = var_ids[a];
       if (done[va]) continue;
@@ -811,6 +852,93 @@ int odr_advect(odr_ctx *c, odr_particles *p, int scheme, double t, double dt, do
   return 0;
 }
 
+static int read_counter(odr_ctx *c, int64_t *out);
+
+// get_environment -> interact_with_coastline -> update_previous_state -> advect_ocean_current in
+// one launch (k_step_grid) when the current comes from one gridded reader; otherwise exactly the
+// four separate entry points, in that order.  Results are bit-identical either way
+// (tests/test_gpu_parity.py::test_fused_step_equals_separate_calls).
+template <int SCHEME>
+static void launch_step_grid(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, StepDesc S, double t, double dt,
+                             double factor) {
+  const DevSource &s = c->hw.src[G.sid];
+  UVTime th = uv_time(s, t + dt / 2), tf = uv_time(s, t + dt);
+  S.geo_slot_uv = s.level_slot[0];
+  bool is3d = s.slot[S.geo_slot_uv].var_nz[VAR_U] > 1;
+  dim3 g(nblk(p->n)), b(BLOCK);
+  PView v = view(p);
+  float f = (float)factor;
+#define ODR_LAUNCH(PROJ, D3) hipLaunchKernelGGL((k_step_grid<SCHEME, PROJ, D3>), g, b, 0, c->stream, c->dw, v, G, S, dt, f, th, tf, c->counter)
+  switch (s.proj.kind) {
+    case PROJ_LATLONG: if (is3d) ODR_LAUNCH(PROJ_LATLONG, true); else ODR_LAUNCH(PROJ_LATLONG, false); break;
+    case PROJ_STERE_POLAR: if (is3d) ODR_LAUNCH(PROJ_STERE_POLAR, true); else ODR_LAUNCH(PROJ_STERE_POLAR, false); break;
+    default: if (is3d) ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, true); else ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, false); break;
+  }
+#undef ODR_LAUNCH
+}
+
+int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t,
+                         int coast_action, int stranded_code, int seeded_on_land_code, int store_previous,
+                         int scheme, double dt, double factor, int64_t *n_on_land) {
+  REQUIRE(nvars > 0 && nvars <= NVAR && var_ids, "bad variable list");
+  REQUIRE(scheme >= 0 && scheme <= 2, "Drift scheme not recognised: %d", scheme);
+  REQUIRE(coast_action >= 0 && coast_action <= 2, "bad coastline action");
+  HIPCHK(hipSetDevice(c->device));
+  if (n_on_land) *n_on_land = 0;
+  int rc;
+  bool has_u = false, has_v = false, has_land = false;
+  for (int k = 0; k < nvars; ++k) {
+    REQUIRE(var_ids[k] >= 0 && var_ids[k] < NVAR, "bad variable id %d", var_ids[k]);
+    has_u |= var_ids[k] == VAR_U; has_v |= var_ids[k] == VAR_V; has_land |= var_ids[k] == VAR_LAND;
+  }
+  REQUIRE(has_u && has_v, "the variable list must hold x/y_sea_water_velocity");
+  if (coast_action && !has_land && !p->env[VAR_LAND]) return fail(ODR_ERR_STATE, "land_binary_mask has not been sampled");
+  if ((rc = flush_world(c))) return rc;
+  // the group of the current: variables of the list that share its priority list
+  int grp[NVAR], ng = 0, rest[NVAR], nrest = 0;
+  auto same_list = [&](int a, int b) {
+    if (c->hw.nlist[a] != c->hw.nlist[b]) return false;
+    for (int k = 0; k < c->hw.nlist[a]; ++k) if (c->hw.list[a][k] != c->hw.list[b][k]) return false;
+    return true;
+  };
+  bool land_in_group = has_land && same_list(VAR_LAND, VAR_U);
+  grp[ng++] = VAR_U; grp[ng++] = VAR_V;
+  if (land_in_group) grp[ng++] = VAR_LAND;
+  bool seen[NVAR] = {false};
+  seen[VAR_U] = seen[VAR_V] = true;
+  if (land_in_group) seen[VAR_LAND] = true;
+  for (int k = 0; k < nvars; ++k) {
+    int v = var_ids[k];
+    if (seen[v]) continue;
+    seen[v] = true;
+    if (same_list(v, VAR_U)) grp[ng++] = v; else rest[nrest++] = v;
+  }
+  EnvGroupDesc G;
+  int sid = -1;
+  bool fuse = p->n > 0 && !getenv("ODR_NO_FAST_PATH") && same_list(VAR_V, VAR_U) && ng <= MAXG &&
+              uv_fast_source(c, sid, t < t + dt ? t : t + dt, t < t + dt ? t + dt : t) &&
+              build_env_group(c, grp, ng, t, G) && G.sid == sid;
+  if (!fuse) {
+    if ((rc = odr_env_sample(c, p, nvars, var_ids, t, nullptr))) return rc;
+    if ((rc = odr_coastline(c, p, coast_action, stranded_code, seeded_on_land_code, n_on_land))) return rc;
+    if (store_previous && (rc = odr_store_previous(c, p))) return rc;
+    return odr_advect(c, p, scheme, t, dt, factor);
+  }
+  for (int k = 0; k < ng; ++k) if ((rc = ensure_env(c, p, grp[k]))) return rc;
+  if (nrest && (rc = env_sample_impl(c, p, nrest, rest, t, nullptr, false))) return rc;  // k_step_grid records the positions
+  StepDesc S;
+  memset(&S, 0, sizeof S);
+  S.coast_action = coast_action; S.stranded_code = stranded_code; S.seeded_code = seeded_on_land_code;
+  S.land_slot = land_in_group ? 2 : -1;
+  S.store_previous = store_previous;
+  if (coast_action) HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
+  if (scheme == 0) launch_step_grid<0>(c, p, G, S, t, dt, factor);
+  else if (scheme == 1) launch_step_grid<1>(c, p, G, S, t, dt, factor);
+  else launch_step_grid<2>(c, p, G, S, t, dt, factor);
+  HIPCHK(hipGetLastError());
+  return coast_action ? read_counter(c, n_on_land) : 0;
+}
+
 int odr_update_positions(odr_ctx *c, odr_particles *p, const double *u, const double *v, int is_f32, double dt) {
   REQUIRE(u && v, "velocities required");
   if (p->n == 0) return 0;
@@ -949,14 +1077,61 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
     HIPCHK(hipMemcpyAsync(du, huni, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
   }
-  size_t lds = sizeof(double) * ((size_t)nzp * BLOCK + (size_t)nzp);
+  size_t lds = sizeof(double) * ((size_t)nzp * BLOCK + 3 * (size_t)nzp);
   dim3 g(nblk(p->n)), b(BLOCK);
   PView v = view(p);
   unsigned long long st = (unsigned long long)step;
   int vadv = c->fuse_vadv;
   c->fuse_vadv = -1;
   if (vadv >= 0 && !p->env[VAR_W]) return fail(ODR_ERR_STATE, "upward_sea_water_velocity has not been sampled");
-  if (nzp <= 16) hipLaunchKernelGGL(k_vmix<16>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv);
+  // fast column kernel: K from one gridded reader, plain z-innermost array on every resident level
+  int ksid = -1;
+  for (int k = 0; k < c->hw.nlist[VAR_KZ]; ++k)
+    if (c->hw.src[c->hw.list[VAR_KZ][k]].kind == SRC_GRID) { ksid = c->hw.list[VAR_KZ][k]; break; }
+  bool fast = ksid >= 0 && nzp > 1 && !getenv("ODR_NO_FAST_PATH");
+  VMixDesc D;
+  memset(&D, 0, sizeof D);
+  if (fast) {
+    const DevSource &s = c->hw.src[ksid];
+    fast = s.nlevels >= 1;
+    for (int k = 0; k < s.nlevels && fast; ++k) {
+      const DevBlock &bk = s.slot[s.level_slot[k]], &g0 = s.slot[s.level_slot[0]];
+      if (!bk.data[VAR_KZ] || bk.es[VAR_KZ] != 1 || bk.var_nz[VAR_KZ] != nzp || bk.ny != g0.ny || bk.nx != g0.nx ||
+          bk.x0 != g0.x0 || bk.xspan != g0.xspan || bk.y0 != g0.y0 || bk.yspan != g0.yspan)
+        fast = false;
+    }
+    if (fast) {
+      int ib, ia;
+      host_bracket(s, t, ib, ia);
+      D.sid = ksid; D.nzp = nzp; D.geo_slot = ib;
+      D.kb = s.slot[ib].data[VAR_KZ];
+      D.ka = ia >= 0 ? s.slot[ia].data[VAR_KZ] : nullptr;
+      D.wgt = ia >= 0 ? (t - s.slot[ib].t) / (s.slot[ia].t - s.slot[ib].t) : 0.0;
+      D.Kfb = c->hw.fallback[VAR_KZ];
+    }
+  }
+  if (fast) {
+    const int nq = (nzp + 3) / 4;
+    const bool tl = D.ka != nullptr;
+#define VMIX_COL(NQ)                                                                                              \
+  do {                                                                                                            \
+    size_t l2 = sizeof(double) * ((size_t)(4 * NQ) * BLOCK + 3 * (size_t)(4 * NQ));                               \
+    if (tl) hipLaunchKernelGGL((k_vmix_col<NQ, true>), g, b, l2, c->stream, c->dw, v, D, dt, dt_mix,              \
+                               mix_at_surface, rng_mode, du, c->seed, st, vadv);                                  \
+    else hipLaunchKernelGGL((k_vmix_col<NQ, false>), g, b, l2, c->stream, c->dw, v, D, dt, dt_mix,                \
+                            mix_at_surface, rng_mode, du, c->seed, st, vadv);                                     \
+  } while (0)
+    // the smallest instantiated quad count >= nq; over-read stays inside the 64-byte array padding
+    if (nq <= 1) VMIX_COL(1);
+    else if (nq == 2) VMIX_COL(2);
+    else if (nq == 3) VMIX_COL(3);
+    else if (nq == 4) VMIX_COL(4);
+    else if (nq <= 6) VMIX_COL(6);
+    else if (nq <= 8) VMIX_COL(8);
+    else if (nq <= 12) VMIX_COL(12);
+    else VMIX_COL(16);
+#undef VMIX_COL
+  } else if (nzp <= 16) hipLaunchKernelGGL(k_vmix<16>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv);
   else if (nzp <= 32) hipLaunchKernelGGL(k_vmix<32>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv);
   else hipLaunchKernelGGL(k_vmix<1>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv);
   HIPCHK(hipGetLastError());

@@ -269,6 +269,21 @@ class Particles:
             raise ValueError('Drift scheme not recognised: ' + str(scheme))
         check(self.lib.odr_advect(self.ctx.h, self.h, s, float(t_epoch), float(dt), float(factor)))
 
+    def env_coast_advect(self, variables, t_epoch, scheme, dt, coastline='none', stranded_code=1,
+                         seeded_on_land_code=0, store_previous=True, factor=1.0, count=True):
+        """env_sample -> coastline -> store_previous -> advect in one launch (odr_env_coast_advect).
+        count=False skips reading back the number of elements on land (no host synchronisation)."""
+        s = scheme if isinstance(scheme, int) else _abi.SCHEME.get(scheme, -1)
+        if s < 0:
+            raise ValueError('Drift scheme not recognised: ' + str(scheme))
+        a = coastline if isinstance(coastline, int) else _abi.COAST[coastline]
+        ids, pi = _i([_vid(v) for v in variables])
+        n = C.c_int64()
+        check(self.lib.odr_env_coast_advect(self.ctx.h, self.h, len(ids), pi, float(t_epoch), a, stranded_code,
+                                            seeded_on_land_code, int(bool(store_previous)), s, float(dt),
+                                            float(factor), C.byref(n) if count else None))
+        return n.value if count else None
+
     def update_positions(self, x_vel, y_vel, dt):
         n = len(self)
         is32 = int(np.asarray(x_vel).dtype == np.float32)

@@ -1,0 +1,103 @@
+"""odr_env_coast_advect (one launch: get_environment -> interact_with_coastline ->
+update_previous_state -> advect_ocean_current) must equal the four separate C-ABI calls bit for
+bit, on every path: fused kernel (gridded reader, lat/lon 3-D and polar-stereographic 2-D) and the
+sequential fallback (analytic reader)."""
+import numpy as np
+import pytest
+
+from scenarios import Scenario
+from opendrift_amd import synthetic as synth
+
+pytestmark = pytest.mark.gpu
+
+U, V = 'x_sea_water_velocity', 'y_sea_water_velocity'
+W, KZ = 'upward_sea_water_velocity', 'ocean_vertical_diffusivity'
+DEPTH, SSH, LAND = 'sea_floor_depth_below_sea_level', 'sea_surface_height', 'land_binary_mask'
+XW, YW = 'x_wind', 'y_wind'
+
+
+def _same(a, b, what):
+    for k in ('lon', 'lat', 'z', 'status', 'moving', 'ID'):
+        eq = (a[k] == b[k]) | ((a[k] != a[k]) & (b[k] != b[k]))
+        assert eq.all(), (what, k, int((~eq).sum()))
+
+
+def _run_pair(ctx, lon, lat, z, variables, times, dt, coastline, codes, schemes):
+    n = len(lon)
+    P, Q = ctx.particles(n), ctx.particles(n)
+    for X in (P, Q):
+        X.append(lon, lat, z=z)
+        X.store_previous()
+    for k, t in enumerate(times):
+        scheme = schemes[k % len(schemes)]
+        P.env_sample(variables, t)              # the run() loop order of the reference
+        n1 = P.coastline(coastline, **codes)
+        P.compact()
+        P.store_previous()
+        P.advect(scheme, t, dt)
+        n2 = Q.env_coast_advect(variables, t, scheme, dt, coastline=coastline, store_previous=True, **codes)
+        Q.compact()
+        assert n1 == n2 and len(P) == len(Q), (k, n1, n2, len(P), len(Q))
+        _same(P.download(), Q.download(), 'step %d' % k)
+        da, db = P.download_deactivated(), Q.download_deactivated()
+        for q in ('lon', 'lat', 'z', 'status', 'ID'):
+            assert (da[q] == db[q]).all(), (k, 'deactivated', q)
+        for v in variables:
+            a, b = P.env_download(v), Q.env_download(v)
+            assert ((a == b) | (np.isnan(a) & np.isnan(b))).all(), (k, v)
+        for X in (P, Q):
+            X.increase_age(dt)
+    return n1
+
+
+def test_fused_equals_separate_latlon_3d_previous(ctx):
+    g = synth.grid3d(nx=96, ny=80, nz=8, nt=3, seed=5)
+    names = [U, V, W, KZ, DEPTH, LAND]
+    levels = [(float(g['t'][k]), {n: g[n][k] for n in names}) for k in range(3)]
+    sc = Scenario([('grid', dict(x=g['x'], y=g['y'], z=g['z'], levels=levels)), ('constant', {XW: 3.0, YW: -2.0})],
+                  fallbacks={U: 0.0, V: 0.0, W: 0.0, KZ: 0.0, DEPTH: 10000.0, SSH: 0.0})
+    sc.device(ctx)
+    rng = np.random.default_rng(3)
+    n = 50000
+    lon = rng.uniform(g['x'][0] - 0.02, g['x'][-1] + 0.02, n)
+    lat = rng.uniform(g['y'][0] - 0.02, g['y'][-1] + 0.02, n)
+    z = -rng.uniform(0, 80, n)
+    hits = _run_pair(ctx, lon, lat, z, [U, V, W, DEPTH, SSH, LAND, XW, YW], [0.0, 600.0, 1800.0, 3000.0, 3600.0, 4200.0],
+                     600.0, 'previous', dict(seeded_on_land_code=5), ['runge-kutta4', 'runge-kutta', 'euler'])
+    assert hits >= 0
+
+
+def test_fused_equals_separate_stere_2d_stranding(ctx):
+    from oracle import oracle as orc
+    g = synth.grid_stere(nx=120, ny=90, nt=3, seed=9)
+    names = [U, V, XW, YW, LAND]
+    levels = [(float(g['t'][k]), {n: g[n][k] for n in names}) for k in range(3)]
+    sc = Scenario([('grid', dict(x=g['x'], y=g['y'], proj=synth.NORKYST_PROJ, levels=levels))],
+                  fallbacks={U: 0.0, V: 0.0, XW: 0.0, YW: 0.0})
+    sc.device(ctx)
+    rng = np.random.default_rng(4)
+    n = 40000
+    p = orc.make_proj(orc.PROJ_STERE_POLAR, a=6371000.0, es=(2 - 1 / 298.257223563) / 298.257223563,
+                      lat0=90.0, lon0=70.0, lat_ts=60.0)
+    lon, lat = orc.proj_inv(p, rng.uniform(g['x'][1], g['x'][-2], n), rng.uniform(g['y'][1], g['y'][-2], n))
+    hits = _run_pair(ctx, lon, lat, np.zeros(n), [U, V, XW, YW, LAND], [0.0, 900.0, 1800.0, 3600.0], 900.0,
+                     'stranding', dict(stranded_code=3), ['runge-kutta4', 'runge-kutta'])
+    assert hits > 0      # the synthetic coast strands some elements: the flagged ones must not have moved
+
+
+def test_fallback_path_equals_separate_analytic(ctx):
+    sid = ctx.add_double_gyre(A=0.1, epsilon=0.25, omega=0.628, t0=0.0)
+    ctx.bind(U, [sid], 0.0)
+    ctx.bind(V, [sid], 0.0)
+    from opendrift_amd.projection import stere_equit_sphere_inverse
+    rng = np.random.default_rng(6)
+    n = 20000
+    lon, lat = stere_equit_sphere_inverse(rng.uniform(0.05, 1.95, n), rng.uniform(0.05, 0.95, n), 6.371e6)
+    _run_pair(ctx, lon, lat, np.zeros(n), [U, V], [0.0, 0.1, 0.2], 0.1, 'none', {}, ['runge-kutta4'])
+
+
+def test_missing_current_is_an_error(ctx):
+    P = ctx.particles(4)
+    P.append(np.zeros(4), np.zeros(4))
+    with pytest.raises(ValueError):
+        P.env_coast_advect([XW, YW], 0.0, 'euler', 600.0)

@@ -1,10 +1,15 @@
 #!/usr/bin/env python
 """Dump the kernel summary of a rocprofv3 (rocpd sqlite) result: python tools/rocpd_summary.py x.db [out.txt]"""
+import glob
+import os
 import sqlite3
 import sys
 
 
 def main(db, out=None):
+    if os.path.isdir(db):   # rocprofv3 -d <dir>: take the newest database below it
+        dbs = sorted(glob.glob(os.path.join(db, '**', '*.db'), recursive=True), key=os.path.getmtime)
+        db = dbs[-1]
     c = sqlite3.connect(db)
     rows = list(c.execute('select name, total_calls, total_duration, average, percentage from top_kernels'))
     lines = ['%-110s %8s %14s %12s %7s' % ('kernel', 'calls', 'total_us', 'avg_us', '%')]
