@@ -90,6 +90,9 @@ __device__ __forceinline__ float div_cr_f32(float a, float b, float ib) {
 }
 
 __device__ __forceinline__ double np_mod(double x, double m) {  // numpy.mod
+  // |x| < m (m > 0): fmod returns x itself -- the usual case for longitudes -- without the
+  // library's exponent-ladder loop
+  if (m > 0 && fabs(x) < m) return x < 0 ? x + m : x;
   double r = fmod(x, m);
   if (r != 0 && ((r < 0) != (m < 0))) r += m;
   return r;

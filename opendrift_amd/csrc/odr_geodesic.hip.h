@@ -26,13 +26,14 @@
 namespace odr {
 
 struct GeodConst {
-  double a, f, f1, e2, ep2, n, b;
+  double a, f, f1, e2, ep2, n, b, ib;  // ib = 1/b
   double A3x[6];
   double C3x[15];
 };
 __constant__ GeodConst c_geod;
 
 static constexpr double kDeg = 3.14159265358979323846264338327950288 / 180.0;
+static constexpr double kDegLo = 2.9486522708701687e-19;  // pi/180 - kDeg
 static constexpr double kRad2Deg = 180.0 / 3.14159265358979323846264338327950288;
 static constexpr double kTiny = 1.4916681462400413e-154;
 
@@ -118,11 +119,24 @@ __device__ __forceinline__ double atan2d(double y, double x) {
   return ang;
 }
 
-// sin and cos of the small angles B11, tau12, sig12: reduced-range kernel up to pi/4 (steps up to
-// ~5000 km), else the library call
+// sin and cos of the small angles tau12, sig12: Taylor forms for |x| <= 1/64 (steps up to ~99 km:
+// truncation x^9/9! < 1e-20 relative, x^8/8! < 9e-20), the reduced-range kernel up to pi/4 (steps
+// up to ~5000 km), else the library call
 __device__ __forceinline__ void sincos_small(double x, double &s, double &c) {
-  if (fabs(x) <= 0.78539816339744830962) sincos_q(x, s, c);
+#pragma clang fp contract(fast)
+  if (fabs(x) <= 0.015625) {
+    double z = x * x;
+    s = fma(x * z, -1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040)), x);
+    c = 1 + z * (-0.5 + z * (1.0 / 24 + z * (-1.0 / 720)));
+  } else if (fabs(x) <= 0.78539816339744830962) sincos_q(x, s, c);
   else sincos(x, &s, &c);
+}
+// |x| <= 1e-3 (B11 = sum C1k sin 2k sigma, |B11| <= eps/2 < 8.4e-4): truncation < 2e-22
+__device__ __forceinline__ void sincos_tiny(double x, double &s, double &c) {
+#pragma clang fp contract(fast)
+  double z = x * x;
+  s = fma(x * z, -1.0 / 6 + z * (1.0 / 120), x);
+  c = 1 + z * (-0.5 + z * (1.0 / 24));
 }
 
 // atan2(y, x) for x > 0 and |y/x| <= 1/16 by the Gregory series (truncation < 1e-20)
@@ -182,16 +196,14 @@ __device__ __forceinline__ GeodOrigin geod_origin(double lat1, double lon1) {
   return o;
 }
 
-// Direct problem from a prepared origin.  azi in degrees, s12 in metres.  lon2 in [-180,180].
-__device__ __forceinline__ void geod_direct_from(const GeodOrigin &o, double azi1, double s12,
-                                                  double &lat2, double &lon2) {
+// Direct problem from a prepared origin and the sine / cosine of the azimuth.  s12 in metres.
+// lon2 in [-180,180].
+__device__ __forceinline__ void geod_direct_sc(const GeodOrigin &o, double salp1, double calp1, double s12,
+                                                double &lat2, double &lon2) {
   // the TU is built with -ffp-contract=off so that the float32 rounding points of the
   // reference stay exact; the geodesic series are float64 and may fuse multiply-adds
 #pragma clang fp contract(fast)
   const GeodConst &g = c_geod;
-  double salp1, calp1;
-  azi1 = ang_normalize(azi1);
-  sincosd(ang_round(azi1), salp1, calp1);
   const double sbet1 = o.sbet1, cbet1 = o.cbet1;
 
   double salp0 = salp1 * cbet1;
@@ -202,11 +214,14 @@ __device__ __forceinline__ void geod_direct_from(const GeodOrigin &o, double azi
   double comg1 = csig1;
   { double inv = fast_rsqrt(ssig1 * ssig1 + csig1 * csig1); ssig1 *= inv; csig1 *= inv; }
 
+  // eps = k2 / (2 (1 + sqrt(1 + k2)) + k2) by its Maclaurin series: k2 <= e'^2 = 0.00674, the x^8
+  // term is < 1e-19 (no square root, no reciprocal)
   double k2 = calp0 * calp0 * g.ep2;
-  double eps = k2 * fast_rcp(2 * (1 + fast_sqrt(1 + k2)) + k2);
+  double eps = k2 * (0.25 + k2 * (-0.125 + k2 * (5.0 / 64 + k2 * (-7.0 / 128 + k2 * (21.0 / 512 + k2 * (-33.0 / 1024 + k2 * (429.0 / 16384)))))));
   double e2 = eps * eps;
-
-  double A1m1 = ((e2 * (e2 * (e2 + 4) + 64)) * (1.0 / 256) + eps) * fast_rcp(1 - eps);
+  // 1 / (1 + A1m1) = (1 - eps) / (1 + eps^2/4 + eps^4/64 + eps^6/256)
+  //               = (1 - eps) (1 - eps^2/4 + 3 eps^4/64) + O(eps^6 = 2e-17)
+  double iA1 = (1 - eps) * (1 + e2 * (-0.25 + e2 * (3.0 / 64)));
   double d = eps;
   double C11 = d * (e2 * (6 - e2) - 16) * (1.0 / 32);           d *= eps;
   double C12 = d * (e2 * (64 - 9 * e2) - 128) * (1.0 / 2048);   d *= eps;
@@ -216,7 +231,7 @@ __device__ __forceinline__ void geod_direct_from(const GeodOrigin &o, double azi
   double C16 = d * (-7.0 / 2048);
   double B11 = sin_series6(ssig1, csig1, C11, C12, C13, C14, C15, C16);
   double sB, cB;
-  sincos_small(B11, sB, cB);
+  sincos_tiny(B11, sB, cB);
   double stau1 = ssig1 * cB + csig1 * sB;
   double ctau1 = csig1 * cB - ssig1 * sB;
   d = eps;
@@ -238,7 +253,7 @@ __device__ __forceinline__ void geod_direct_from(const GeodOrigin &o, double azi
   double A3c = -g.f * salp0 * A3;
   double B31 = sin_series5(ssig1, csig1, C31, C32, C33, C34, C35);
 
-  double tau12 = s12 * fast_rcp(g.b * (1 + A1m1));
+  double tau12 = s12 * (g.ib * iA1);
   double st, ct;
   sincos_small(tau12, st, ct);
   double B12 = -sin_series6(stau1 * ct + ctau1 * st, ctau1 * ct - stau1 * st, P1, P2, P3, P4, P5, P6);
@@ -263,6 +278,15 @@ __device__ __forceinline__ void geod_direct_from(const GeodOrigin &o, double azi
     lat2 = o.lat1 + atan_ratio(num, dd) * kRad2Deg;
   else
     lat2 = atan2d(sbet2, den);
+}
+
+// azimuth in degrees (float64 callers: advect_wind, stokes_drift, horizontal diffusion)
+__device__ __forceinline__ void geod_direct_from(const GeodOrigin &o, double azi1, double s12,
+                                                  double &lat2, double &lon2) {
+  double salp1, calp1;
+  azi1 = ang_normalize(azi1);
+  sincosd(ang_round(azi1), salp1, calp1);
+  geod_direct_sc(o, salp1, calp1, s12, lat2, lon2);
 }
 
 __device__ __forceinline__ void geod_direct(double lat1, double lon1, double azi1, double s12,

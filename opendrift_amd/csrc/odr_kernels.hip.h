@@ -37,12 +37,37 @@ __device__ __forceinline__ float speed_f32(float xv, float yv) {
   return sqrtf(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv)));  // IEEE sqrt (the __fsqrt_rn alias is native_sqrt)
 }
 
+// Sine and cosine of the float32 azimuth the reference hands to geod.fwd.  With theta = atan2(x, y)
+// in float64, sin / cos of theta are x/h and y/h (no trigonometric call), and the two float32
+// roundings (arctan2, degrees) move the angle by delta = az_f32 * pi/180 - theta, |delta| < 4e-7:
+//   sin(theta + delta) = sin theta (1 - delta^2/2) + cos theta delta     (delta^3/6 < 1e-20).
+// Same value as sincosd(az_f32) to float64 round-off, ~25 instructions instead of ~75.
+__device__ __forceinline__ void azimuth_sincos_f32(float xv, float yv, double &salp, double &calp) {
+#pragma clang fp contract(fast)
+  const double x = (double)xv, y = (double)yv;
+  const double theta = atan2(x, y);
+  const float azf = __fmul_rn((float)theta, 180.0f / 3.14159274101257324f);  // == azimuth_f32(xv, yv)
+  const double az = (double)azf;
+  const double h2 = x * x + y * y;
+  if (!(h2 > 0)) {  // calm: the azimuth is 0 or 180 exactly (or NaN)
+    salp = (theta != theta) ? theta : 0.0;
+    calp = (theta != theta) ? theta : (az == 0.0 ? 1.0 : -1.0);
+    return;
+  }
+  const double delta = fma(az, kDeg, -theta) + az * kDegLo;
+  const double rh = fast_rsqrt(h2);
+  const double st = x * rh, ct = y * rh, c2 = 1 - 0.5 * delta * delta;
+  salp = fma(ct, delta, st * c2);
+  calp = fma(-st, delta, ct * c2);
+}
+
 // update_positions (basemodel/__init__.py:4631-4657), float32 velocities
 __device__ __forceinline__ void move_f32_from(const GeodOrigin &o, double &lon, double &lat, float u,
                                               float v, int moving, double dt) {
-  float az = azimuth_f32(u, v);
+  double salp, calp;
+  azimuth_sincos_f32(u, v, salp, calp);
   double vel = (double)speed_f32(u, v) * (double)moving;  // f32 * int32 array -> float64
-  geod_direct_from(o, (double)az, vel * dt, lat, lon);
+  geod_direct_sc(o, salp, calp, vel * dt, lat, lon);
 }
 __device__ __forceinline__ void move_f32(double &lon, double &lat, float u, float v, int moving,
                                          double dt) {
@@ -64,9 +89,10 @@ __device__ __forceinline__ void move_f64(double &lon, double &lat, double u, dou
 // (physics_methods.py:629-635); the origin is shared by all stages of a particle
 __device__ __forceinline__ void stage_pos(const GeodOrigin &o, float u, float v, float dtf,
                                           double &lon2, double &lat2) {
-  float az = azimuth_f32(u, v);
+  double salp, calp;
+  azimuth_sincos_f32(u, v, salp, calp);
   float dist = __fmul_rn(__fmul_rn(speed_f32(u, v), dtf), 0.5f);
-  geod_direct_from(o, (double)az, (double)dist, lat2, lon2);
+  geod_direct_sc(o, salp, calp, (double)dist, lat2, lon2);
 }
 
 // ------------------------------------------------------------------ environment

@@ -122,6 +122,7 @@ static void geod_consts(GeodConst &g) {
   g.ep2 = g.e2 / (g.f1 * g.f1);
   g.n = g.f / (2 - g.f);
   g.b = g.a * g.f1;
+  g.ib = 1.0 / g.b;
   const double n = g.n;
   g.A3x[0] = -3.0 / 128;
   g.A3x[1] = (-2 * n - 3) / 64;
