@@ -32,10 +32,15 @@ struct DevBlock {
   double xmin, xrange, ymin, yrange;  // Nearest2DInterpolator index map (interpolators.py:32-37)
   double ixspan, iyspan, ixrange, iyrange;  // correctly rounded reciprocals (host) for div_cr()
   double t;
-  // pre-dilated device arrays, z innermost: element (k, y, x) of variable v lives at
-  // data[v][((y*nx + x)*var_nz[v] + k) * es[v]].  x/y_sea_water_velocity (and the other vector
-  // pairs) are interleaved (es = 2): one 16-byte load fetches (u,v) at two adjacent z levels
-  // (3D) or at two adjacent x nodes (2D).
+  // Pre-dilated device data, ONE allocation per time level laid out as node records: `rec`
+  // floats per grid node hold every variable of the reader at that node, z innermost.  Element
+  // (k, y, x) of variable v lives at data[v][(y*nx + x)*rec + k*es[v]] with data[v] = base + the
+  // variable's offset in the record.  x/y_sea_water_velocity (and the other vector pairs) are
+  // interleaved (es = 2): one 16-byte load fetches (u,v) at two adjacent z levels.  All variables
+  // of a particle's 2x2 footprint share four node offsets, and neighbouring variables share
+  // cache lines.
+  const float *base;
+  int rec, small;  // small: node count < 2^24 and the block < 4 GiB -> 24-bit / 32-bit offset math
   const float *data[NVAR];
   int var_nz[NVAR];
   int es[NVAR];
@@ -347,7 +352,7 @@ __device__ __forceinline__ double block_value(const DevBlock &b, const DevSource
                                               double x, double y, double z, bool &f32class) {
   const float *d = b.data[var];
   const int nzv = b.var_nz[var], es = b.es[var];
-  const size_t ns = (size_t)nzv * es;
+  const size_t ns = (size_t)b.rec;
   if (var == VAR_LAND) {
     f32class = true;
     int xi = nearest_index(x, b.xmin, b.xrange, b.ixrange, b.nx);
@@ -542,19 +547,38 @@ __device__ __forceinline__ float bil4(double v00, double v01, double v10, double
   return (float)t;
 }
 
-template <bool IS3D>
-__device__ __forceinline__ void uv_level(const float *__restrict__ uv, int ny, int nx, int nz,
-                                         double yi, double xi, const ZBracket &zb, double &u, double &v,
-                                         bool &f32class) {
+// 2x2 footprint of a particle in a block: byte offsets of the four node records and the
+// weights -- shared by every variable and both time levels of a reader call.  24-bit multiplies
+// (full rate on CDNA; the host guarantees node count < 2^24 and block size < 4 GiB on this path).
+struct Foot {
+  unsigned o00, o01, o10, o11;
+  double wy0, ty, wx0, tx;
+};
+__device__ __forceinline__ Foot footprint(double yi, double xi, int ny, int nx, unsigned rec_bytes) {
   const Axis ay = axis_fp(yi, ny), ax = axis_fp(xi, nx);
-  const int y0 = ay.i0, y1 = ay.i1, x0 = ax.i0, x1 = ax.i1;
-  const double ty = ay.t, tx = ax.t, wy0 = 1 - ty, wx0 = 1 - tx;
+  const unsigned r0 = __umul24((unsigned)ay.i0, (unsigned)nx), r1 = __umul24((unsigned)ay.i1, (unsigned)nx);
+  Foot f;
+  f.o00 = __umul24(r0 + (unsigned)ax.i0, rec_bytes); f.o01 = __umul24(r0 + (unsigned)ax.i1, rec_bytes);
+  f.o10 = __umul24(r1 + (unsigned)ax.i0, rec_bytes); f.o11 = __umul24(r1 + (unsigned)ax.i1, rec_bytes);
+  f.ty = ay.t; f.tx = ax.t; f.wy0 = 1 - ay.t; f.wx0 = 1 - ax.t;
+  return f;
+}
+struct __attribute__((aligned(4))) F2 { float x, y; };
+// load at a 32-bit byte offset from a wave-uniform base (scalar base + vector offset addressing)
+template <typename T>
+__device__ __forceinline__ T ld_off(const float *__restrict__ base, unsigned byte_off) {
+  return *(const T *)((const char *)base + byte_off);
+}
+
+// (u,v) of an interleaved pair at one time level; `uv` = address of the pair in node record 0
+template <bool IS3D>
+__device__ __forceinline__ void uv_level(const float *__restrict__ uv, int nz, const Foot &ft,
+                                         const ZBracket &zb, double &u, double &v, bool &f32class) {
+  const double ty = ft.ty, tx = ft.tx, wy0 = ft.wy0, wx0 = ft.wx0;
   if (IS3D) {
-    size_t ns = (size_t)nz * 2, k0 = (size_t)zb.iz0 * 2;
-    F4 q00 = *(const F4 *)(uv + ((size_t)y0 * nx + x0) * ns + k0);
-    F4 q01 = *(const F4 *)(uv + ((size_t)y0 * nx + x1) * ns + k0);
-    F4 q10 = *(const F4 *)(uv + ((size_t)y1 * nx + x0) * ns + k0);
-    F4 q11 = *(const F4 *)(uv + ((size_t)y1 * nx + x1) * ns + k0);
+    const unsigned kb = (unsigned)zb.iz0 * 8u;
+    const F4 q00 = ld_off<F4>(uv, ft.o00 + kb), q01 = ld_off<F4>(uv, ft.o01 + kb);
+    const F4 q10 = ld_off<F4>(uv, ft.o10 + kb), q11 = ld_off<F4>(uv, ft.o11 + kb);
     // level "above" (ia) and "below" (ib): (x,y) = level iz0, (z,w) = level iz0+1
     float ua, va, ub, vb;
     ub = bil4(q00.z, q01.z, q10.z, q11.z, wy0, ty, wx0, tx);
@@ -568,15 +592,10 @@ __device__ __forceinline__ void uv_level(const float *__restrict__ uv, int ny, i
     v = __dadd_rn(__dmul_rn((double)va, zb.wa), __dmul_rn((double)vb, 1 - zb.wa));
     f32class = false;
   } else {
-    // one 16-byte load per row: nodes (xl, xl+1); the footprint nodes x0, x1 are among them
-    int xl = min(x0, nx >= 2 ? nx - 2 : 0);
-    F4 r0 = *(const F4 *)(uv + ((size_t)y0 * nx + xl) * 2);
-    F4 r1 = *(const F4 *)(uv + ((size_t)y1 * nx + xl) * 2);
-    bool h0 = x0 != xl, h1 = x1 != xl;
-    float u00 = h0 ? r0.z : r0.x, v00 = h0 ? r0.w : r0.y, u01 = h1 ? r0.z : r0.x, v01 = h1 ? r0.w : r0.y;
-    float u10 = h0 ? r1.z : r1.x, v10 = h0 ? r1.w : r1.y, u11 = h1 ? r1.z : r1.x, v11 = h1 ? r1.w : r1.y;
-    u = bil4(u00, u01, u10, u11, wy0, ty, wx0, tx);
-    v = bil4(v00, v01, v10, v11, wy0, ty, wx0, tx);
+    const F2 q00 = ld_off<F2>(uv, ft.o00), q01 = ld_off<F2>(uv, ft.o01);
+    const F2 q10 = ld_off<F2>(uv, ft.o10), q11 = ld_off<F2>(uv, ft.o11);
+    u = bil4(q00.x, q01.x, q10.x, q11.x, wy0, ty, wx0, tx);
+    v = bil4(q00.y, q01.y, q10.y, q11.y, wy0, ty, wx0, tx);
     f32class = true;
   }
 }
@@ -603,11 +622,12 @@ __device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBloc
     double yi = __dmul_rn(div_cr(y - geo.y0, geo.yspan, geo.iyspan), (double)(geo.ny - 1));
     double ub, vb;
     bool f32c;
-    uv_level<IS3D>(tm.b, geo.ny, geo.nx, s.nz, yi, xi, zb, ub, vb, f32c);
+    const Foot ft = footprint(yi, xi, geo.ny, geo.nx, (unsigned)geo.rec * 4u);
+    uv_level<IS3D>(tm.b, s.nz, ft, zb, ub, vb, f32c);
     double u = ub, v = vb;
     if (tm.a) {
       double ua, va;
-      uv_level<IS3D>(tm.a, geo.ny, geo.nx, s.nz, yi, xi, zb, ua, va, f32c);
+      uv_level<IS3D>(tm.a, s.nz, ft, zb, ua, va, f32c);
       if (f32c) {
         u = __fadd_rn(__fmul_rn((float)ub, (float)(1 - tm.w)), __fmul_rn((float)ua, (float)tm.w));
         v = __fadd_rn(__fmul_rn((float)vb, (float)(1 - tm.w)), __fmul_rn((float)va, (float)tm.w));
@@ -633,55 +653,54 @@ __device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBloc
 
 // ---------------------------------------------------------- fast environment group
 // Main-loop Environment.get_environment for a variable group served by ONE gridded reader:
-// projection, coverage, fractional indices, the vertical bracket and the (host-resolved)
-// time bracket are computed once per particle and shared by all variables of the group;
-// 3D variables fetch their two z levels with one 8-byte load per corner (16 bytes for an
-// interleaved vector pair), 2D variables their two x nodes per row.
+// projection, coverage, fractional indices, the 2x2 footprint, the vertical bracket and the
+// (host-resolved) time bracket are computed once per particle and shared by all variables of
+// the group; every variable is then a few loads at (footprint offset + its offset in the node
+// record): 16 bytes for an interleaved 3D vector pair (both components, two z levels), 8 bytes
+// for a 3D scalar or a 2D pair, 4 bytes for a 2D scalar.
 constexpr int MAXG = 8;
 struct EnvGroupDesc {
-  int nv, sid, geo_slot, pad;
+  int nv, sid, geo_slot, all_static;
+  const float *bb, *ba;  // node-record bases of the bracketing time levels (ba == nullptr: on a time level)
+  double w;
   int var[MAXG];
+  int off[MAXG];         // float offset of the variable in the node record
   int nz[MAXG];          // 1 => 2D
   int es[MAXG];          // 2 => interleaved with its vector partner
   int partner[MAXG];     // index in this group of the y-component to rotate with, or -1
-  const float *b[MAXG];  // before / after arrays (a == nullptr: no time interpolation)
-  const float *a[MAXG];
+  int kind[MAXG];        // 0 scalar; 1 x-component of an interleaved pair whose y-component is slot k+1; 2 that y-component
   float fallback[MAXG];
-  double w;
-  int all_static, pad2;
+  int has_land, pad;
 };
-struct __attribute__((aligned(4))) F2 { float x, y; };
 
-// one variable at one time level -> value in the reference's dtype class
-__device__ __forceinline__ double var_level(const float *__restrict__ d, int var, int nzv, int es,
-                                            const DevBlock &g, int snz, double x, double y, double yi,
-                                            double xi, const ZBracket &zb, bool &f32class) {
-  const size_t ns = (size_t)nzv * es;
+// one scalar variable at one time level -> value in the reference's dtype class; d = address of
+// the variable in node record 0
+__device__ __forceinline__ double var_level(const float *__restrict__ d, int var, int nzv, int es, int snz,
+                                            unsigned near_off, const Foot &ft, const ZBracket &zb,
+                                            bool &f32class) {
   if (var == VAR_LAND) {
     f32class = true;
-    int ix = nearest_index(x, g.xmin, g.xrange, g.ixrange, g.nx);
-    int iy = nearest_index(y, g.ymin, g.yrange, g.iyrange, g.ny);
-    return d[((size_t)iy * g.nx + ix) * ns];
+    return ld_off<float>(d, near_off);
   }
-  const Axis ay = axis_fp(yi, g.ny), ax = axis_fp(xi, g.nx);
-  const int y0 = ay.i0, y1 = ay.i1, x0 = ax.i0, x1 = ax.i1;
-  const double ty = ay.t, tx = ax.t, wy0 = 1 - ty, wx0 = 1 - tx;
-  const float *p00 = d + ((size_t)y0 * g.nx + x0) * ns, *p01 = d + ((size_t)y0 * g.nx + x1) * ns;
-  const float *p10 = d + ((size_t)y1 * g.nx + x0) * ns, *p11 = d + ((size_t)y1 * g.nx + x1) * ns;
+  const double ty = ft.ty, tx = ft.tx, wy0 = ft.wy0, wx0 = ft.wx0;
   if (nzv <= 1) {
     f32class = true;
-    return bil4(p00[0], p01[0], p10[0], p11[0], wy0, ty, wx0, tx);
+    return bil4(ld_off<float>(d, ft.o00), ld_off<float>(d, ft.o01), ld_off<float>(d, ft.o10),
+                ld_off<float>(d, ft.o11), wy0, ty, wx0, tx);
   }
   f32class = false;
   float a00, a01, a10, a11, b00, b01, b10, b11;  // level iz0 (a) and iz0+1 (b)
-  const size_t k0 = (size_t)zb.iz0 * es;
+  const unsigned kb = (unsigned)zb.iz0 * 4u * (unsigned)es;
   if (es == 1) {
-    F2 q00 = *(const F2 *)(p00 + k0), q01 = *(const F2 *)(p01 + k0);
-    F2 q10 = *(const F2 *)(p10 + k0), q11 = *(const F2 *)(p11 + k0);
+    const F2 q00 = ld_off<F2>(d, ft.o00 + kb), q01 = ld_off<F2>(d, ft.o01 + kb);
+    const F2 q10 = ld_off<F2>(d, ft.o10 + kb), q11 = ld_off<F2>(d, ft.o11 + kb);
     a00 = q00.x; b00 = q00.y; a01 = q01.x; b01 = q01.y; a10 = q10.x; b10 = q10.y; a11 = q11.x; b11 = q11.y;
-  } else {
-    a00 = p00[k0]; b00 = p00[k0 + es]; a01 = p01[k0]; b01 = p01[k0 + es];
-    a10 = p10[k0]; b10 = p10[k0 + es]; a11 = p11[k0]; b11 = p11[k0 + es];
+  } else {  // one component of an interleaved pair on its own
+    const unsigned sb = 4u * (unsigned)es;
+    a00 = ld_off<float>(d, ft.o00 + kb); b00 = ld_off<float>(d, ft.o00 + kb + sb);
+    a01 = ld_off<float>(d, ft.o01 + kb); b01 = ld_off<float>(d, ft.o01 + kb + sb);
+    a10 = ld_off<float>(d, ft.o10 + kb); b10 = ld_off<float>(d, ft.o10 + kb + sb);
+    a11 = ld_off<float>(d, ft.o11 + kb); b11 = ld_off<float>(d, ft.o11 + kb + sb);
   }
   float vb = bil4(b00, b01, b10, b11, wy0, ty, wx0, tx);
   float va = (zb.same && snz > 1) ? vb : bil4(a00, a01, a10, a11, wy0, ty, wx0, tx);
@@ -712,13 +731,43 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
     ZBracket zb;
     zb.iz0 = 0; zb.same = 0; zb.wa = 1;
     if (s.nz > 1) zb = zbracket(s, z);
+    // shared by all variables and both time levels: bilinear footprint, nearest node (land mask)
+    const unsigned rec_bytes = (unsigned)geo.rec * 4u;
+    const Foot ft = footprint(yi, xi, geo.ny, geo.nx, rec_bytes);
+    unsigned near_off = 0;
+    if (G.has_land)
+      near_off = __umul24(__umul24((unsigned)nearest_index(y, geo.ymin, geo.yrange, geo.iyrange, geo.ny), (unsigned)geo.nx) +
+                              (unsigned)nearest_index(x, geo.xmin, geo.xrange, geo.ixrange, geo.nx),
+                          rec_bytes);
+    const bool tl = G.ba != nullptr && !G.all_static;
 #pragma unroll
     for (int k = 0; k < MAXG; ++k) {
       if (k >= G.nv) break;
+      if (G.kind[k] == 2) continue;  // done with its x-component
       bool fb, fa;
-      double vb = var_level(G.b[k], G.var[k], G.nz[k], G.es[k], geo, s.nz, x, y, yi, xi, zb, fb);
-      if (G.a[k] && !G.all_static) {
-        double va = var_level(G.a[k], G.var[k], G.nz[k], G.es[k], geo, s.nz, x, y, yi, xi, zb, fa);
+      if (G.kind[k] == 1 && k + 1 < MAXG) {  // interleaved vector pair: one load serves both components
+        double ub, vb2;
+        if (G.nz[k] > 1) uv_level<true>(G.bb + G.off[k], s.nz, ft, zb, ub, vb2, fb);
+        else uv_level<false>(G.bb + G.off[k], s.nz, ft, zb, ub, vb2, fb);
+        if (tl) {
+          double ua, va2;
+          if (G.nz[k] > 1) uv_level<true>(G.ba + G.off[k], s.nz, ft, zb, ua, va2, fa);
+          else uv_level<false>(G.ba + G.off[k], s.nz, ft, zb, ua, va2, fa);
+          if (fb && fa) {
+            ub = __fadd_rn(__fmul_rn((float)ub, (float)(1 - G.w)), __fmul_rn((float)ua, (float)G.w));
+            vb2 = __fadd_rn(__fmul_rn((float)vb2, (float)(1 - G.w)), __fmul_rn((float)va2, (float)G.w));
+          } else {
+            ub = __dadd_rn(__dmul_rn(ub, 1 - G.w), __dmul_rn(ua, G.w));
+            vb2 = __dadd_rn(__dmul_rn(vb2, 1 - G.w), __dmul_rn(va2, G.w));
+          }
+        }
+        val[k] = ub;
+        val[k + 1] = vb2;
+        continue;
+      }
+      double vb = var_level(G.bb + G.off[k], G.var[k], G.nz[k], G.es[k], s.nz, near_off, ft, zb, fb);
+      if (tl) {
+        double va = var_level(G.ba + G.off[k], G.var[k], G.nz[k], G.es[k], s.nz, near_off, ft, zb, fa);
         if (fb && fa) vb = __fadd_rn(__fmul_rn((float)vb, (float)(1 - G.w)), __fmul_rn((float)va, (float)G.w));
         else vb = __dadd_rn(__dmul_rn(vb, 1 - G.w), __dmul_rn(va, G.w));
       }
@@ -732,15 +781,11 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
         double sn, cs;
         rotation_cs(s.proj, x, y, cs, sn);
 #pragma unroll
-        for (int k = 0; k < MAXG; ++k) {
+        for (int k = 0; k + 1 < MAXG; ++k) {  // the host places the y-component right after its x-component
           if (k >= G.nv || G.partner[k] < 0) continue;
-#pragma unroll
-          for (int u = 0; u < MAXG; ++u) {
-            if (u != G.partner[k]) continue;
-            double uu = val[k], vv = val[u];
-            val[k] = __dsub_rn(__dmul_rn(uu, cs), __dmul_rn(vv, sn));
-            val[u] = __dadd_rn(__dmul_rn(uu, sn), __dmul_rn(vv, cs));
-          }
+          double uu = val[k], vv = val[k + 1];
+          val[k] = __dsub_rn(__dmul_rn(uu, cs), __dmul_rn(vv, sn));
+          val[k + 1] = __dadd_rn(__dmul_rn(uu, sn), __dmul_rn(vv, cs));
         }
       }
     }

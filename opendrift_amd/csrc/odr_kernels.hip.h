@@ -629,8 +629,9 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
       const Axis ay = axis_fp(yi, ny), ax = axis_fp(xi, nx);
       const int y0 = ay.i0, y1 = ay.i1, x0 = ax.i0, x1 = ax.i1;
       const double ty = ay.t, tx = ax.t, wy0 = 1 - ty, wx0 = 1 - tx;
-      size_t o00 = ((size_t)y0 * nx + x0) * nzp, o01 = ((size_t)y0 * nx + x1) * nzp;
-      size_t o10 = ((size_t)y1 * nx + x0) * nzp, o11 = ((size_t)y1 * nx + x1) * nzp;
+      const size_t rec = (size_t)bb.rec;
+      size_t o00 = ((size_t)y0 * nx + x0) * rec, o01 = ((size_t)y0 * nx + x1) * rec;
+      size_t o10 = ((size_t)y1 * nx + x0) * rec, o11 = ((size_t)y1 * nx + x1) * rec;
       float c00[NZMAX], c01[NZMAX], c10[NZMAX], c11[NZMAX];
       const float *d = bb.data[VAR_KZ];
       kcolumn(d + o00, nzp, c00); kcolumn(d + o01, nzp, c01);
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
         double val = Kfb;
         if (src && cov) {
           const DevBlock &bb = src->slot[ib];
-          const size_t ns = (size_t)bb.var_nz[VAR_KZ] * bb.es[VAR_KZ];
+          const size_t ns = (size_t)bb.rec;
           double v0 = bilinear_f32(bb.data[VAR_KZ] + (size_t)k * bb.es[VAR_KZ], bb.ny, bb.nx, ns, yi, xi), vv;
           if (ia >= 0) {
             const DevBlock &ba = src->slot[ia];
@@ -787,8 +788,9 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__
     const Axis ay = axis_fp(yi, ny), ax = axis_fp(xi, nx);
     const double ty = ay.t, tx = ax.t, wy0 = 1 - ty, wx0 = 1 - tx, wgt = D.wgt;
     // uncovered particles gather node (0,0) and discard it: keeps the loads unconditional
-    const size_t o00 = cov ? ((size_t)ay.i0 * nx + ax.i0) * nzp : 0, o01 = cov ? ((size_t)ay.i0 * nx + ax.i1) * nzp : 0;
-    const size_t o10 = cov ? ((size_t)ay.i1 * nx + ax.i0) * nzp : 0, o11 = cov ? ((size_t)ay.i1 * nx + ax.i1) * nzp : 0;
+    const size_t rec = (size_t)bb.rec;
+    const size_t o00 = cov ? ((size_t)ay.i0 * nx + ax.i0) * rec : 0, o01 = cov ? ((size_t)ay.i0 * nx + ax.i1) * rec : 0;
+    const size_t o10 = cov ? ((size_t)ay.i1 * nx + ax.i0) * rec : 0, o11 = cov ? ((size_t)ay.i1 * nx + ax.i1) * rec : 0;
     const float *kb = D.kb, *ka = TL ? D.ka : D.kb;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -1189,13 +1191,15 @@ __global__ __launch_bounds__(BLOCK) void k_blk_dilate(const float *__restrict__ 
   dst[i] = v;
 }
 
-// final device layout of a block variable: [nz][ny][nx] (reader order) -> z innermost
-// [ny][nx][nz] with element stride es (2 when interleaved with its vector partner)
-__global__ __launch_bounds__(BLOCK) void k_blk_to_zinner(const float *__restrict__ src, float *__restrict__ dst,
-                                                        int nz, size_t plane, int es, int eo) {
+// final device layout of a block: one record per grid node holding every variable of the reader
+// at that node, z innermost -- element (k, node) of a variable at record offset `off` lives at
+// dst[node * rec + off + k * es + eo] (es = 2, eo = 0/1 for the two components of a vector pair).
+// src is the reader's [nz][ny][nx] array.
+__global__ __launch_bounds__(BLOCK) void k_blk_to_record(const float *__restrict__ src, float *__restrict__ dst,
+                                                        int nz, size_t plane, int rec, int off, int es, int eo) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;  // node index y*nx + x
   if (i >= plane) return;
-  for (int k = 0; k < nz; ++k) dst[(i * nz + k) * es + eo] = src[k * plane + i];
+  for (int k = 0; k < nz; ++k) dst[i * rec + off + k * es + eo] = src[k * plane + i];
 }
 
 }  // namespace odr

@@ -530,34 +530,44 @@ static int block_upload(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, i
     HIPCHK(hipFree(tmp));
     prep[(size_t)k] = buf;
   }
-  // final layout: z innermost, vector pairs interleaved (odr_field.hip.h DevBlock)
+  // final layout: one node record per grid point (odr_field.hip.h DevBlock): interleaved vector pairs
+  // first, then the other 3D variables, then the 2D ones; record length padded to 16 bytes
   static const int pairs[3][2] = {{VAR_U, VAR_V}, {VAR_XWIND, VAR_YWIND}, {VAR_SX, VAR_SY}};
-  std::vector<bool> placed((size_t)nvars, false);
-  unsigned gp = (unsigned)((plane + BLOCK - 1) / BLOCK);
+  std::vector<int> off((size_t)nvars, -1), es((size_t)nvars, 1), eo((size_t)nvars, 0);
+  int rec = 0;
   for (int pr = 0; pr < 3; ++pr) {
     int ka = -1, kb = -1;
     for (int k = 0; k < nvars; ++k) { if (var_ids[k] == pairs[pr][0]) ka = k; if (var_ids[k] == pairs[pr][1]) kb = k; }
     if (ka < 0 || kb < 0) continue;
     int nza = var_nz[ka] > 1 ? var_nz[ka] : 1, nzb = var_nz[kb] > 1 ? var_nz[kb] : 1;
     if (nza != nzb) continue;
-    float *il;
-    HIPCHK(hipMalloc((void **)&il, sizeof(float) * plane * nza * 2 + 64));
-    hipLaunchKernelGGL(k_blk_to_zinner, dim3(gp), dim3(BLOCK), 0, c->stream, prep[(size_t)ka], il, nza, plane, 2, 0);
-    hipLaunchKernelGGL(k_blk_to_zinner, dim3(gp), dim3(BLOCK), 0, c->stream, prep[(size_t)kb], il, nza, plane, 2, 1);
-    b.data[pairs[pr][0]] = il;      b.es[pairs[pr][0]] = 2; b.var_nz[pairs[pr][0]] = nza;
-    b.data[pairs[pr][1]] = il + 1;  b.es[pairs[pr][1]] = 2; b.var_nz[pairs[pr][1]] = nza;
-    c->block_bufs[sid][slot].push_back(il);
-    placed[(size_t)ka] = placed[(size_t)kb] = true;
+    off[(size_t)ka] = rec; off[(size_t)kb] = rec; es[(size_t)ka] = es[(size_t)kb] = 2; eo[(size_t)kb] = 1;
+    rec += 2 * nza;
   }
+  for (int pass = 0; pass < 2; ++pass)   // 3D scalars, then 2D scalars
+    for (int k = 0; k < nvars; ++k) {
+      int nzv = var_nz[k] > 1 ? var_nz[k] : 1;
+      if (off[(size_t)k] >= 0 || (pass == 0) != (nzv > 1)) continue;
+      off[(size_t)k] = rec;
+      rec += nzv;
+    }
+  rec = (rec + 3) & ~3;
+  float *base;
+  HIPCHK(hipMalloc((void **)&base, sizeof(float) * plane * (size_t)rec + 64));
+  HIPCHK(hipMemsetAsync(base, 0, sizeof(float) * plane * (size_t)rec + 64, c->stream));
+  unsigned gp = (unsigned)((plane + BLOCK - 1) / BLOCK);
   for (int k = 0; k < nvars; ++k) {
-    if (placed[(size_t)k]) continue;
     int v = var_ids[k], nzv = var_nz[k] > 1 ? var_nz[k] : 1;
-    float *fin;
-    HIPCHK(hipMalloc((void **)&fin, sizeof(float) * plane * nzv + 64));
-    hipLaunchKernelGGL(k_blk_to_zinner, dim3(gp), dim3(BLOCK), 0, c->stream, prep[(size_t)k], fin, nzv, plane, 1, 0);
-    b.data[v] = fin; b.es[v] = 1; b.var_nz[v] = nzv;
-    c->block_bufs[sid][slot].push_back(fin);
+    hipLaunchKernelGGL(k_blk_to_record, dim3(gp), dim3(BLOCK), 0, c->stream, prep[(size_t)k], base, nzv, plane, rec,
+                       off[(size_t)k], es[(size_t)k], eo[(size_t)k]);
+    b.data[v] = base + off[(size_t)k] + eo[(size_t)k];
+    b.es[v] = es[(size_t)k];
+    b.var_nz[v] = nzv;
   }
+  b.base = base;
+  b.rec = rec;
+  b.small = plane < (1u << 24) && (double)plane * rec * 4.0 < 4294967296.0 && rec * 4 < (1 << 24);
+  c->block_bufs[sid][slot].push_back(base);
   HIPCHK(hipStreamSynchronize(c->stream));
   for (float *q : prep) HIPCHK(hipFree(q));
   sort_levels(s);
@@ -616,27 +626,47 @@ static bool build_env_group(const odr_ctx *c, const int *grp, int ng, double t, 
   int ib, ia;
   host_bracket(s, t, ib, ia);
   memset(&G, 0, sizeof G);
-  G.nv = ng; G.sid = sid; G.geo_slot = s.level_slot[0];
-  G.all_static = 1;
+  // order: the caller's, except that the y-component of a vector pair follows its x-component
+  static const int pairs[3][2] = {{VAR_U, VAR_V}, {VAR_XWIND, VAR_YWIND}, {VAR_SX, VAR_SY}};
+  auto in_group = [&](int v) { for (int k = 0; k < ng; ++k) if (grp[k] == v) return true; return false; };
+  auto pair_y = [&](int v) { for (auto &pr : pairs) if (pr[0] == v) return pr[1]; return -1; };
+  auto pair_x = [&](int v) { for (auto &pr : pairs) if (pr[1] == v) return pr[0]; return -1; };
+  int ord[NVAR], no = 0;
   for (int k = 0; k < ng; ++k) {
     int v = grp[k];
-    const DevBlock &bb = s.slot[ib];
+    if (pair_x(v) >= 0 && in_group(pair_x(v))) continue;  // placed with its x-component
+    ord[no++] = v;
+    if (pair_y(v) >= 0 && in_group(pair_y(v))) ord[no++] = pair_y(v);
+  }
+  G.nv = ng; G.sid = sid; G.geo_slot = s.level_slot[0];
+  G.all_static = 1;
+  const DevBlock &bb = s.slot[ib];
+  const DevBlock *ba = (ia >= 0 && !s.always_valid) ? &s.slot[ia] : nullptr;
+  if (!bb.small || bb.rec != g0.rec || (ba && (ba->rec != bb.rec || !ba->small))) return false;
+  G.bb = bb.base;
+  G.ba = ba ? ba->base : nullptr;
+  for (int k = 0; k < ng; ++k) {
+    int v = ord[k];
     if (!bb.data[v]) return false;
     G.var[k] = v; G.nz[k] = bb.var_nz[v]; G.es[k] = bb.es[v];
-    G.b[k] = bb.data[v];
-    G.a[k] = nullptr;
-    if (ia >= 0 && !s.always_valid) {
-      const DevBlock &ba = s.slot[ia];
-      if (!ba.data[v] || ba.var_nz[v] != bb.var_nz[v] || ba.es[v] != bb.es[v]) return false;
-      G.a[k] = ba.data[v];
-    }
+    G.off[k] = (int)(bb.data[v] - bb.base);
+    if (ba && (!ba->data[v] || ba->var_nz[v] != bb.var_nz[v] || ba->es[v] != bb.es[v] ||
+               (int)(ba->data[v] - ba->base) != G.off[k]))
+      return false;
     G.fallback[k] = w.fallback[v];
     G.partner[k] = -1;
+    if (v == VAR_LAND) G.has_land = 1;
     if (v != VAR_LAND && v != VAR_DEPTH) G.all_static = 0;
   }
   for (int k = 0; k < ng; ++k) {
-    int pv = grp[k] == VAR_U ? VAR_V : grp[k] == VAR_XWIND ? VAR_YWIND : grp[k] == VAR_SX ? VAR_SY : -1;
-    for (int u = 0; pv >= 0 && u < ng; ++u) if (grp[u] == pv) G.partner[k] = u;
+    int pv = pair_y(G.var[k]);
+    if (pv >= 0 && k + 1 < ng && G.var[k + 1] == pv) {
+      G.partner[k] = k + 1;
+      // interleaved in the node record: one 16-byte load serves both components
+      if (G.es[k] == 2 && G.es[k + 1] == 2 && G.off[k + 1] == G.off[k] + 1 && G.nz[k] == G.nz[k + 1]) {
+        G.kind[k] = 1; G.kind[k + 1] = 2;
+      }
+    }
   }
   G.w = ia >= 0 ? (t - s.slot[ib].t) / (s.slot[ia].t - s.slot[ib].t) : 0.0;
   return true;
@@ -797,7 +827,7 @@ static bool uv_fast_source(const odr_ctx *c, int &sid, double t_lo, double t_hi)
   const DevBlock &g0 = s.slot[s.level_slot[0]];
   for (int k = 0; k < s.nlevels; ++k) {
     const DevBlock &b = s.slot[s.level_slot[k]];
-    if (!b.data[VAR_U] || b.es[VAR_U] != 2 || b.data[VAR_V] != b.data[VAR_U] + 1) return false;
+    if (!b.data[VAR_U] || b.es[VAR_U] != 2 || b.data[VAR_V] != b.data[VAR_U] + 1 || !b.small || b.rec != g0.rec) return false;
     if (b.ny != g0.ny || b.nx != g0.nx || b.x0 != g0.x0 || b.xspan != g0.xspan || b.y0 != g0.y0 ||
         b.yspan != g0.yspan || b.var_nz[VAR_U] != g0.var_nz[VAR_U])
       return false;
@@ -1097,7 +1127,7 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
     fast = s.nlevels >= 1;
     for (int k = 0; k < s.nlevels && fast; ++k) {
       const DevBlock &bk = s.slot[s.level_slot[k]], &g0 = s.slot[s.level_slot[0]];
-      if (!bk.data[VAR_KZ] || bk.es[VAR_KZ] != 1 || bk.var_nz[VAR_KZ] != nzp || bk.ny != g0.ny || bk.nx != g0.nx ||
+      if (!bk.data[VAR_KZ] || bk.es[VAR_KZ] != 1 || bk.var_nz[VAR_KZ] != nzp || bk.rec != g0.rec || bk.ny != g0.ny || bk.nx != g0.nx ||
           bk.x0 != g0.x0 || bk.xspan != g0.xspan || bk.y0 != g0.y0 || bk.yspan != g0.yspan)
         fast = false;
     }
