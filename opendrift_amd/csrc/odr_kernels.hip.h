@@ -1050,6 +1050,46 @@ __global__ __launch_bounds__(BLOCK) void k_cmp_scatter(const int *status, long l
   }
 }
 
+// In-place compaction (the default): the deactivated elements are copied to the deactivated store
+// and the holes they leave among the first `kept` slots are filled with the active elements of the
+// tail -- O(#removed) data movement instead of rewriting every array.  Deterministic pairing: the
+// k-th hole (by index) takes the k-th active tail element counted from the end.  The relative order
+// of the survivors changes (IDs identify elements; the reference's move_elements order is not part
+// of any result).
+__global__ __launch_bounds__(BLOCK) void k_cmp_lists(const int *status, long long n, const unsigned *boff,
+                                                     long long kept, CmpArrays A, long long dead_base,
+                                                     unsigned *holes, unsigned *fills) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  bool valid = i < n, keep = valid && status[i] == 0;
+  unsigned long long b = __ballot(keep);
+  __shared__ unsigned wc[BLOCK / 64];
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) wc[w] = (unsigned)__popcll(b);
+  __syncthreads();
+  unsigned before = 0;
+  for (int k = 0; k < w; ++k) before += wc[k];
+  if (!valid) return;
+  long long kept_before = (long long)boff[blockIdx.x] + before + __popcll(b & ((1ull << lane) - 1));
+  if (!keep) {
+    long long r = i - kept_before;  // rank among the removed
+    for (int k = 0; k < A.n64; ++k) if (A.dead64[k]) A.dead64[k][dead_base + r] = A.src64[k][i];
+    for (int k = 0; k < A.n32; ++k) if (A.dead32[k]) A.dead32[k][dead_base + r] = A.src32[k][i];
+    if (i < kept) holes[r] = (unsigned)i;
+  } else if (i >= kept) {
+    fills[kept - kept_before - 1] = (unsigned)i;  // active elements after i
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cmp_move(const unsigned *__restrict__ holes, const unsigned *__restrict__ fills,
+                                                    long long cnt, CmpArrays A) {
+  long long k = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (k >= cnt) return;
+  unsigned d = holes[k], s = fills[k];
+  if (d == 0xFFFFFFFFu || s == 0xFFFFFFFFu) return;
+  for (int a = 0; a < A.n64; ++a) const_cast<double *>(A.src64[a])[d] = A.src64[a][s];
+  for (int a = 0; a < A.n32; ++a) const_cast<int *>(A.src32[a])[d] = A.src32[a][s];
+}
+
 // ---------------------------------------------------------------------- Leeway
 // Leeway.update (models/leeway.py:430-494) without capsizing: downwind / crosswind leeway from
 // the wind (float32 arithmetic of the LeewayObj properties), update_positions(-x_leeway,

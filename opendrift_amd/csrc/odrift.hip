@@ -47,6 +47,12 @@ struct odr_ctx {
   hipEvent_t ev0, ev1;
   int nsrc;
   int fuse_vadv;
+  // reductions cached between the horizontal movers of one step (advect_wind -> stokes_drift -> horizontal
+  // diffusion read the same maxima: environment, z and properties do not change in between)
+  const odr_particles *red_owner;
+  unsigned long long red_epoch;
+  double red_wdd;
+  int red_rel;
 };
 
 struct odr_particles {
@@ -66,6 +72,8 @@ struct odr_particles {
   unsigned *bcount;
   void *scratch;
   size_t scratch_bytes;
+  unsigned long long epoch;  // bumped by every call that changes z, the environment, properties or the element set
+  bool external;
 };
 
 static inline unsigned nblk(long long n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
@@ -221,6 +229,7 @@ int odr_particles_create(odr_ctx *c, int64_t capacity, odr_particles **out) {
 }
 
 int odr_particles_destroy(odr_ctx *c, odr_particles *p) {
+  if (c->red_owner == p) c->red_owner = nullptr;
   if (!p) return 0;
   (void)hipStreamSynchronize(c->stream);
   auto fr = [](void *q) { if (q) (void)hipFree(q); };
@@ -251,6 +260,7 @@ static int put(odr_ctx *c, T *dst, const T *src, long long n, T dflt) {
 int odr_particles_append(odr_ctx *c, odr_particles *p, int64_t n, const double *lon, const double *lat,
                          const double *z, const int32_t *id, const int32_t *moving, const float *wdf,
                          const float *cdf, const float *tv) {
+  p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(n >= 0 && lon && lat, "lon/lat required");
   if (p->n + n > p->cap) return fail(ODR_ERR_CAPACITY, "capacity %lld exceeded (%lld + %lld)", p->cap, p->n, (long long)n);
   if (n == 0) return 0;
@@ -318,6 +328,7 @@ int odr_particles_download_deactivated(odr_ctx *c, odr_particles *p, double *lon
 
 int odr_particles_upload(odr_ctx *c, odr_particles *p, const double *lon, const double *lat, const double *z,
                          const int32_t *moving, const float *wdf, const float *cdf, const float *tv) {
+  p->epoch++;  // invalidates the cached reductions (reduce())
   size_t n = (size_t)p->n;
   if (lon) HIPCHK(hipMemcpyAsync(p->d64[0], lon, 8 * n, hipMemcpyHostToDevice, c->stream));
   if (lat) HIPCHK(hipMemcpyAsync(p->d64[1], lat, 8 * n, hipMemcpyHostToDevice, c->stream));
@@ -331,6 +342,7 @@ int odr_particles_upload(odr_ctx *c, odr_particles *p, const double *lon, const 
 }
 
 int odr_particles_device_ptr(odr_ctx *c, odr_particles *p, const char *name, void **dptr) {
+  p->external = true;  // the caller may write the arrays: never reuse cached reductions
   REQUIRE(name && dptr, "name/dptr NULL");
   static const char *n64[5] = {"lon", "lat", "z", "plon", "plat"};
   static const char *n32[3] = {"id", "status", "moving"};
@@ -704,6 +716,7 @@ int odr_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_i
 // record_positions: remember the sample position (slon/slat) for the profiles of odr_vmix
 static int env_sample_impl(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t,
                            float *const *out_host, bool record_positions) {
+  p->epoch++;
   REQUIRE(nvars > 0 && nvars <= NVAR && var_ids, "bad variable list");
   HIPCHK(hipSetDevice(c->device));
   int rc;
@@ -771,6 +784,7 @@ int odr_env_download(odr_ctx *c, odr_particles *p, int32_t var, float *out) {
 }
 
 int odr_env_upload(odr_ctx *c, odr_particles *p, int32_t var, const float *host) {
+  p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(var >= 0 && var < NVAR && host, "bad arguments");
   int rc = ensure_env(c, p, var);
   if (rc) return rc;
@@ -793,6 +807,7 @@ static int host_to_scratch(odr_ctx *c, odr_particles *p, const double *a, const 
 
 int odr_env_add_noise(odr_ctx *c, odr_particles *p, int32_t vx, int32_t vy, double std, int rng_mode,
                       const double *hnx, const double *hny, uint64_t step) {
+  p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(vx >= 0 && vx < NVAR && vy >= 0 && vy < NVAR, "bad variable ids");
   if (!p->env[vx] || !p->env[vy]) return fail(ODR_ERR_STATE, "variables not sampled");
   if (p->n == 0) return 0;
@@ -911,6 +926,7 @@ static void launch_step_grid(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G
 int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t,
                          int coast_action, int stranded_code, int seeded_on_land_code, int store_previous,
                          int scheme, double dt, double factor, int64_t *n_on_land) {
+  p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(nvars > 0 && nvars <= NVAR && var_ids, "bad variable list");
   REQUIRE(scheme >= 0 && scheme <= 2, "Drift scheme not recognised: %d", scheme);
   REQUIRE(coast_action >= 0 && coast_action <= 2, "bad coastline action");
@@ -985,6 +1001,7 @@ int odr_update_positions(odr_ctx *c, odr_particles *p, const double *u, const do
 // {downwind_slope, crosswind_slope, downwind_offset, crosswind_offset, downwind_eps, crosswind_eps,
 //  jibe_probability, orientation, capsized} (leeway.py:50-131)
 int odr_particles_set_property(odr_ctx *c, odr_particles *p, int slot, int64_t offset, int64_t count, const float *host) {
+  p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(slot >= 0 && slot < 9 && host && offset >= 0 && count >= 0 && offset + count <= p->n, "bad property range");
   if (!p->aux[slot]) {
     HIPCHK(hipMalloc((void **)&p->aux[slot], sizeof(float) * (size_t)p->cap));
@@ -1021,7 +1038,11 @@ int odr_leeway(odr_ctx *c, odr_particles *p, double dt, double capsize_fraction,
   return 0;
 }
 
-static int reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind) {
+static int reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind, bool wind_args_matter = true) {
+  if (!p->external && c->red_owner == p && c->red_epoch == p->epoch &&
+      (!wind_args_matter || (c->red_wdd == wdd && c->red_rel == relwind)))
+    return 0;
+  c->red_owner = p; c->red_epoch = p->epoch; c->red_wdd = wdd; c->red_rel = relwind;
   hipLaunchKernelGGL(k_red_init, dim3(1), dim3(64), 0, c->stream, c->red);
   if (p->n > 0)
     hipLaunchKernelGGL(k_reduce, dim3(nblk(p->n) < 2048u ? nblk(p->n) : 2048u), dim3(BLOCK), 0, c->stream, view(p), wdd,
@@ -1032,6 +1053,7 @@ static int reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind) {
 
 int odr_reduce_scalars(odr_ctx *c, odr_particles *p, double wdd, double *out16) {
   REQUIRE(out16, "out16 NULL");
+  c->red_owner = nullptr;  // lon/lat extremes change with every mover: always recomputed
   int rc = reduce(c, p, wdd, 0);
   if (rc) return rc;
   double r[R_N];
@@ -1061,7 +1083,7 @@ int odr_stokes_drift(odr_ctx *c, odr_particles *p, double dt, int profile, int h
   if ((hs_mode == 0 && !p->env[VAR_HS]) || (tp_mode == 0 && !p->env[VAR_TP])) return fail(ODR_ERR_STATE, "Hs/Tp not sampled");
   if ((hs_mode == 1 || tp_mode == 1) && (!p->env[VAR_XWIND] || !p->env[VAR_YWIND])) return fail(ODR_ERR_STATE, "wind not sampled");
   if (p->n == 0) return 0;
-  int rc = reduce(c, p, 0.0, 0);
+  int rc = reduce(c, p, 0.0, 0, false);
   if (rc) return rc;
   hipLaunchKernelGGL(k_stokes, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, profile, hs_mode, tp_mode, factor, c->red);
   HIPCHK(hipGetLastError());
@@ -1077,7 +1099,7 @@ int odr_hdiffusion(odr_ctx *c, odr_particles *p, double dt, int rng_mode, const 
     REQUIRE(hnx && hny, "host normals required in ODR_RNG_HOST mode");
     if ((rc = host_to_scratch(c, p, hnx, hny, (size_t)p->n, &da, &db))) return rc;
   }
-  if ((rc = reduce(c, p, 0.0, 0))) return rc;
+  if ((rc = reduce(c, p, 0.0, 0, false))) return rc;
   hipLaunchKernelGGL(k_hdiff, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, rng_mode, da, db, c->seed,
                      (unsigned long long)step, c->red);
   HIPCHK(hipGetLastError());
@@ -1086,6 +1108,7 @@ int odr_hdiffusion(odr_ctx *c, odr_particles *p, double dt, int rng_mode, const 
 
 int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, int mix_at_surface, int rng_mode,
              const double *huni, uint64_t step) {
+  p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(dt_mix > 0 && dt != 0, "bad time steps");
   if (!p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
   int rc = ensure_env(c, p, VAR_SSH);
@@ -1177,6 +1200,7 @@ int odr_vmix_fuse_vertical_advection(odr_ctx *c, int at_surface) {
 }
 
 int odr_vertical_advection(odr_ctx *c, odr_particles *p, double dt, int at_surface) {
+  p->epoch++;  // invalidates the cached reductions (reduce())
   if (!p->env[VAR_W]) return fail(ODR_ERR_STATE, "upward_sea_water_velocity has not been sampled");
   if (p->n == 0) return 0;
   hipLaunchKernelGGL(k_vadvect, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, at_surface);
@@ -1185,6 +1209,7 @@ int odr_vertical_advection(odr_ctx *c, odr_particles *p, double dt, int at_surfa
 }
 
 int odr_vertical_buoyancy(odr_ctx *c, odr_particles *p, double dt) {
+  p->epoch++;  // invalidates the cached reductions (reduce())
   if (!p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
   int rc = ensure_env(c, p, VAR_SSH);
   if (rc) return rc;
@@ -1222,6 +1247,7 @@ int odr_source_time_coverage(odr_ctx *c, int32_t sid, double t_start, double t_e
 }
 
 int odr_increase_age(odr_ctx *c, odr_particles *p, double dt, double max_age_seconds, int retired_code) {
+  p->epoch++;  // invalidates the cached reductions (reduce())
   if (p->n == 0) return 0;
   hipLaunchKernelGGL(k_age, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), (float)dt, (float)max_age_seconds, retired_code);
   HIPCHK(hipGetLastError());
@@ -1229,6 +1255,7 @@ int odr_increase_age(odr_ctx *c, odr_particles *p, double dt, double max_age_sec
 }
 
 int odr_coastline(odr_ctx *c, odr_particles *p, int action, int code, int seeded_on_land_code, int64_t *n_on_land) {
+  p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(action >= 0 && action <= 2, "bad coastline action");
   if (n_on_land) *n_on_land = 0;
   if (action == 0 || p->n == 0) return 0;
@@ -1240,6 +1267,7 @@ int odr_coastline(odr_ctx *c, odr_particles *p, int action, int code, int seeded
 }
 
 int odr_seafloor(odr_ctx *c, odr_particles *p, int64_t *n_below) {
+  p->epoch++;  // invalidates the cached reductions (reduce())
   if (n_below) *n_below = 0;
   if (p->n == 0) return 0;
   if (!p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
@@ -1250,6 +1278,7 @@ int odr_seafloor(odr_ctx *c, odr_particles *p, int64_t *n_below) {
 }
 
 int odr_deactivate(odr_ctx *c, odr_particles *p, const uint8_t *mask, int32_t code) {
+  p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(mask, "mask NULL");
   if (p->n == 0) return 0;
   void *s;
@@ -1303,6 +1332,7 @@ static void swap_sets(odr_particles *p) {
 }
 
 int odr_compact(odr_ctx *c, odr_particles *p, int64_t *n_active) {
+  p->epoch++;  // invalidates the cached reductions (reduce())
   HIPCHK(hipSetDevice(c->device));
   if (p->n == 0) { if (n_active) *n_active = 0; return 0; }
   unsigned nb = nblk(p->n);
@@ -1312,15 +1342,27 @@ int odr_compact(odr_ctx *c, odr_particles *p, int64_t *n_active) {
   HIPCHK(hipMemcpyAsync(&kept, c->counter + 1, sizeof kept, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if ((long long)kept == p->n) { if (n_active) *n_active = p->n; return 0; }  // "No elements to deactivate"
-  int rc = ensure_alt(p);
+  int rc = ensure_alt(p);  // (allocates the deactivated store)
   if (rc) return rc;
   CmpArrays A;
   all_arrays(p, A);
-  hipLaunchKernelGGL(k_cmp_scatter, dim3(nb), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount, A, p->ndead);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(c->stream));
-  swap_sets(p);
-  p->ndead += p->n - (long long)kept;
+  long long removed = p->n - (long long)kept;
+  if (getenv("ODR_ORDERED_COMPACT")) {  // order-preserving variant: rewrites every array
+    hipLaunchKernelGGL(k_cmp_scatter, dim3(nb), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount, A, p->ndead);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    swap_sets(p);
+  } else {
+    void *sc;
+    if ((rc = scratch(c, p, sizeof(unsigned) * 2 * (size_t)removed, &sc))) return rc;
+    unsigned *holes = (unsigned *)sc, *fills = holes + removed;
+    HIPCHK(hipMemsetAsync(sc, 0xFF, sizeof(unsigned) * 2 * (size_t)removed, c->stream));
+    hipLaunchKernelGGL(k_cmp_lists, dim3(nb), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount, (long long)kept, A,
+                       p->ndead, holes, fills);
+    hipLaunchKernelGGL(k_cmp_move, dim3(nblk(removed)), dim3(BLOCK), 0, c->stream, holes, fills, removed, A);
+    HIPCHK(hipGetLastError());
+  }
+  p->ndead += removed;
   p->n = (long long)kept;
   if (n_active) *n_active = p->n;
   return 0;

@@ -256,7 +256,7 @@ class Particles:
     def env_add_noise(self, var_x, var_y, std, step=0, normals=None):
         n = len(self)
         if normals is not None:
-            (ax, px), (ay, py) = _d(normals[0], n), _d(normals[1], n)
+            (ax, px), (ay, py) = _d(self._host_order(normals[0]), n), _d(self._host_order(normals[1]), n)
             check(self.lib.odr_env_add_noise(self.ctx.h, self.h, _vid(var_x), _vid(var_y), float(std),
                                              _abi.RNG_HOST, px, py, step))
         else:
@@ -306,9 +306,28 @@ class Particles:
         check(self.lib.odr_particles_get_property(self.ctx.h, self.h, slot, out.ctypes.data_as(_fp)))
         return out
 
+    def ids(self):
+        n = len(self)
+        out = np.empty(n, np.int32)
+        check(self.lib.odr_particles_download(self.ctx.h, self.h, None, None, None, out.ctypes.data_as(_ip), None, None))
+        return out
+
+    def _host_order(self, arr):
+        """Host-drawn random numbers (RNG_HOST parity mode) arrive in the reference's element order,
+        i.e. ascending ID of the active elements; in-place compaction and spatial sorting permute the
+        device arrays, so the numbers are gathered into device order first."""
+        n = len(self)
+        a = np.asarray(arr)[..., :n]
+        if not getattr(self, '_permuted', False):
+            return a
+        ids = self.ids()
+        rank = np.empty(n, np.int64)
+        rank[np.argsort(ids, kind='stable')] = np.arange(n)
+        return np.ascontiguousarray(a[..., rank])
+
     def leeway(self, dt, capsize_fraction=0.4, step=0, uniforms=None):
         if uniforms is not None:
-            u, pu = _d(uniforms, len(self))
+            u, pu = _d(self._host_order(uniforms), len(self))
             check(self.lib.odr_leeway(self.ctx.h, self.h, float(dt), float(capsize_fraction), _abi.RNG_HOST, pu, step))
         else:
             check(self.lib.odr_leeway(self.ctx.h, self.h, float(dt), float(capsize_fraction), _abi.RNG_DEVICE, None, step))
@@ -316,7 +335,7 @@ class Particles:
     def hdiffusion(self, dt, step=0, normals=None):
         n = len(self)
         if normals is not None:
-            (ax, px), (ay, py) = _d(normals[0], n), _d(normals[1], n)
+            (ax, px), (ay, py) = _d(self._host_order(normals[0]), n), _d(self._host_order(normals[1]), n)
             check(self.lib.odr_hdiffusion(self.ctx.h, self.h, float(dt), _abi.RNG_HOST, px, py, step))
         else:
             check(self.lib.odr_hdiffusion(self.ctx.h, self.h, float(dt), _abi.RNG_DEVICE, None, None, step))
@@ -325,7 +344,7 @@ class Particles:
         if fuse_vertical_advection is not None:   # True: include surface elements, False: z<0 only
             check(self.lib.odr_vmix_fuse_vertical_advection(self.ctx.h, int(bool(fuse_vertical_advection))))
         if uniforms is not None:
-            u, pu = _d(np.ascontiguousarray(uniforms))
+            u, pu = _d(np.ascontiguousarray(self._host_order(uniforms)))
             check(self.lib.odr_vmix(self.ctx.h, self.h, float(t_epoch), float(dt), float(dt_mix),
                                     int(mix_at_surface), _abi.RNG_HOST, pu, step))
         else:
@@ -360,13 +379,19 @@ class Particles:
         check(self.lib.odr_deactivate(self.ctx.h, self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)), status_code))
 
     def compact(self):
+        """Remove the deactivated elements (remove_deactivated_elements).  In place: the survivors are
+        permuted (holes filled from the tail); elements are identified by their ID."""
+        n0 = len(self)
         n = C.c_int64()
         check(self.lib.odr_compact(self.ctx.h, self.h, C.byref(n)))
+        if n.value != n0:
+            self._permuted = True
         return n.value
 
     def sort_by_cell(self, source_id):
         """Re-order the SoA by grid cell of a gridded source (layout only; IDs are preserved)."""
         check(self.lib.odr_sort_particles(self.ctx.h, self.h, int(source_id)))
+        self._permuted = True
 
     def reduce_scalars(self, wind_drift_depth=0.1):
         out = np.empty(16)

@@ -336,10 +336,15 @@ def test_coastline_and_compaction(ctx):
     assert kept == int((st == 0).sum())
     got = P.download()
     dead = P.download_deactivated()
-    assert (got['ID'] == np.nonzero(st == 0)[0]).all()            # order preserving (move_elements)
+    # in-place compaction: holes are filled from the tail, so the survivors are a permutation
+    # (elements are identified by ID); the deactivated store keeps the index order
+    assert (np.sort(got['ID']) == np.nonzero(st == 0)[0]).all()
     assert (dead['ID'] == np.nonzero(st != 0)[0]).all()
-    assert (got['lon'] == lon[st == 0]).all() and (dead['lat'] == lat[st != 0]).all()
-    assert (P.env_download(U) == np.nonzero(st == 0)[0].astype(np.float32)).all()   # environment follows
+    assert (got['lon'] == lon[got['ID']]).all() and (got['lat'] == lat[got['ID']]).all()
+    assert (dead['lat'] == lat[st != 0]).all()
+    assert (P.env_download(U) == got['ID'].astype(np.float32)).all()   # environment follows its element
+    stay = np.nonzero(st[:kept] == 0)[0]
+    assert (got['ID'][stay] == stay).all()                          # only the holes were refilled
     assert P.compact() == kept                                     # nothing more to remove
     # 'previous': back to the position of the last environment sample
     Q = ctx.particles(n)
