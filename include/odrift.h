@@ -230,6 +230,32 @@ int odr_reduce_scalars(odr_ctx *ctx, odr_particles *p, double wind_drift_depth, 
 int odr_timer_begin(odr_ctx *ctx);
 int odr_timer_end(odr_ctx *ctx, float *ms);
 
+/* ---------------------------------------------------------------- output history
+ * state_to_buffer (basemodel/__init__.py:2384-2499) and the float32 result buffer it fills
+ * (:2084-2105): every exported variable is a float32 [trajectory, time] array initialised with NaN;
+ * at an output time all elements present are written at (ID, time) -- float64 / int32 properties are
+ * cast to float32 by the assignment -- and between output times only the deactivated elements are,
+ * into the slot of the next output time (:2390-2397).  The buffer stays in HBM; a flush copies it to
+ * pinned host memory on a second stream while the simulation continues.
+ * Variable codes: an ODR_VAR_* id (environment variable) or one of ODR_HIST_*. */
+enum {
+  ODR_HIST_LON = 1000, ODR_HIST_LAT, ODR_HIST_Z, ODR_HIST_STATUS, ODR_HIST_MOVING, ODR_HIST_AGE_SECONDS,
+  ODR_HIST_WIND_DRIFT_FACTOR, ODR_HIST_CURRENT_DRIFT_FACTOR, ODR_HIST_TERMINAL_VELOCITY,
+  ODR_HIST_PROPERTY0 = 2000 /* + slot of odr_particles_set_property */
+};
+typedef struct odr_history odr_history;
+int odr_history_create(odr_ctx *ctx, int64_t n_trajectories, int32_t n_times, int32_t nvars,
+                       const int32_t *var_codes, odr_history **out);
+int odr_history_destroy(odr_ctx *ctx, odr_history *h);
+int odr_history_record(odr_ctx *ctx, odr_particles *p, odr_history *h, int32_t time_index, int only_deactivated);
+/* asynchronous: extract time slots [t0, t0+nt) of every variable into pinned host memory as
+ * [trajectory][time] float32 (the reference's dims); _wait blocks; _host_ptr is valid until the next flush */
+int odr_history_flush(odr_ctx *ctx, odr_history *h, int32_t t0, int32_t nt);
+int odr_history_wait(odr_ctx *ctx, odr_history *h);
+int odr_history_host_ptr(odr_ctx *ctx, odr_history *h, int32_t var_index, float **ptr, int32_t *nt);
+int odr_history_reset(odr_ctx *ctx, odr_history *h);   /* new buffer: NaN (:2493-2499) */
+int odr_history_minmax(odr_ctx *ctx, odr_history *h, int32_t var_index, double *minval, double *maxval); /* :2409-2414 */
+
 #ifdef __cplusplus
 }
 #endif

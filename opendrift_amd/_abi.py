@@ -24,6 +24,11 @@ PROJ_LATLONG, PROJ_STERE_EQUIT_SPHERE, PROJ_STERE_POLAR = 0, 1, 2
 SCHEME = {'euler': 0, 'runge-kutta': 1, 'runge-kutta4': 2}
 RNG_DEVICE, RNG_HOST = 0, 1
 COAST = {'none': 0, 'stranding': 1, 'previous': 2}
+# odr_history variable codes of the element properties (include/odrift.h ODR_HIST_*); environment
+# variables use their ODR_VAR_* id
+HIST = {'lon': 1000, 'lat': 1001, 'z': 1002, 'status': 1003, 'moving': 1004, 'age_seconds': 1005,
+        'wind_drift_factor': 1006, 'current_drift_factor': 1007, 'terminal_velocity': 1008}
+HIST_PROPERTY0 = 2000
 ANALYTIC_DOUBLE_GYRE, ANALYTIC_OSCILLATING = 1, 2
 
 
@@ -92,6 +97,14 @@ _SIGNATURES = {
     'odr_reduce_scalars': [_vp, _vp, C.c_double, _dp],
     'odr_timer_begin': [_vp],
     'odr_timer_end': [_vp, _fp],
+    'odr_history_create': [_vp, C.c_int64, C.c_int32, C.c_int32, _ip, _P(_vp)],
+    'odr_history_destroy': [_vp, _vp],
+    'odr_history_record': [_vp, _vp, _vp, C.c_int32, C.c_int],
+    'odr_history_flush': [_vp, _vp, C.c_int32, C.c_int32],
+    'odr_history_wait': [_vp, _vp],
+    'odr_history_host_ptr': [_vp, _vp, C.c_int32, _P(_fp), _P(C.c_int32)],
+    'odr_history_reset': [_vp, _vp],
+    'odr_history_minmax': [_vp, _vp, C.c_int32, _dp, _dp],
 }
 EXPORTS = sorted(list(_SIGNATURES) + ['odr_last_error', 'odr_version'])
 

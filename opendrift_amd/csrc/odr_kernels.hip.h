@@ -1231,6 +1231,71 @@ __global__ __launch_bounds__(BLOCK) void k_blk_dilate(const float *__restrict__ 
   dst[i] = v;
 }
 
+// ------------------------------------------------------------------ output history
+// state_to_buffer (basemodel/__init__.py:2384-2403) on the device: the float32 result buffer
+// (:2084-2105: every exported variable is a float32 [trajectory, time] array initialised with NaN)
+// stays resident in HBM as [time][trajectory][stride] records, one record per element and output
+// time holding all exported variables -- the scatter by ID is one contiguous record per element.
+// At an output step every element present is written (active ones and those deactivated during the
+// step, which the reference removes only afterwards); between output steps only deactivated
+// elements are written, into the slot of the next output time (:2390-2397, method='backfill').
+enum { HK_F64 = 0, HK_I32 = 1, HK_F32 = 2 };
+constexpr int HIST_MAXV = 28;
+struct HistVars {
+  int nvars, stride;
+  const void *src[HIST_MAXV];
+  int kind[HIST_MAXV];
+};
+
+__global__ __launch_bounds__(BLOCK) void k_hist_record(long long n, const int *__restrict__ id,
+                                                       const int *__restrict__ status, HistVars H,
+                                                       float *__restrict__ slab, long long ntraj,
+                                                       int only_deactivated) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  if (only_deactivated && status[i] == 0) return;
+  const long long tr = id[i];
+  if (tr < 0 || tr >= ntraj) return;
+  float *rec = slab + tr * H.stride;
+  for (int v = 0; v < H.nvars; ++v) {
+    float x;
+    if (H.kind[v] == HK_F64) x = (float)((const double *)H.src[v])[i];   // float64 -> float32 array assignment
+    else if (H.kind[v] == HK_I32) x = (float)((const int *)H.src[v])[i];
+    else x = ((const float *)H.src[v])[i];
+    rec[v] = x;
+  }
+}
+
+// one variable of the buffer in the reference's (trajectory, time) layout: out[(tr - tr0) * nt + t]
+__global__ __launch_bounds__(BLOCK) void k_hist_extract(const float *__restrict__ buf, long long ntraj, int stride,
+                                                        int v, int t0, int nt, long long tr0, long long ntr,
+                                                        float *__restrict__ out) {
+  long long k = (long long)blockIdx.x * BLOCK + threadIdx.x;  // over ntr * nt, time fastest
+  if (k >= ntr * nt) return;
+  long long tr = tr0 + k / nt;
+  int t = t0 + (int)(k % nt);
+  out[k] = buf[((long long)t * ntraj + tr) * stride + v];
+}
+
+// var.min(skipna=True) / var.max(skipna=True) over the buffer (:2412-2414); red = {max(-x), max(x)}
+__global__ __launch_bounds__(BLOCK) void k_hist_minmax(const float *__restrict__ buf, long long nrec, int stride, int v,
+                                                       double *red) {
+  double mn = -__builtin_inf(), mx = -__builtin_inf();
+  for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < nrec; k += (long long)gridDim.x * BLOCK) {
+    float x = buf[k * stride + v];
+    if (x == x) { mn = fmax(mn, -(double)x); mx = fmax(mx, (double)x); }
+  }
+  mn = wave_max(mn); mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) {
+    if (mn > -__builtin_inf()) atomic_max_d(&red[0], mn);
+    if (mx > -__builtin_inf()) atomic_max_d(&red[1], mx);
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_fill_u32(unsigned *a, size_t n, unsigned v) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) a[i] = v;
+}
+
 // final device layout of a block: one record per grid node holding every variable of the reader
 // at that node, z innermost -- element (k, node) of a variable at record offset `off` lives at
 // dst[node * rec + off + k * es + eo] (es = 2, eo = 0/1 for the two components of a vector pair).

@@ -4,6 +4,7 @@
 // context stream; only calls that hand data back to the host synchronise.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1403,5 +1404,182 @@ int odr_sort_particles(odr_ctx *c, odr_particles *p, int32_t sid) {
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   swap_sets(p);
+  return 0;
+}
+
+// ------------------------------------------------------------------ output history
+// state_to_buffer replacement: the float32 result buffer of run()
+// (basemodel/__init__.py:2084-2105) lives in HBM; odr_history_record is one scatter kernel on the
+// context stream; odr_history_flush extracts every variable in the reference's (trajectory, time)
+// layout on a second stream into pinned host memory, overlapping with the following steps.
+struct odr_history {
+  long long ntraj;
+  int ntimes, nvars, stride;
+  int codes[HIST_MAXV];
+  float *buf;            // [ntimes][ntraj][stride]
+  float *stage;          // device staging of one extracted variable chunk
+  size_t stage_floats;
+  float *host;           // pinned: [nvars][ntraj][flush_nt]
+  size_t host_floats;
+  int flush_nt;
+  hipStream_t copy_stream;
+  hipEvent_t recorded, flushed;
+  double *red;           // 2 doubles
+};
+
+static int hist_fill_nan(odr_ctx *c, odr_history *h, hipStream_t st) {
+  size_t n = (size_t)h->ntimes * (size_t)h->ntraj * (size_t)h->stride;
+  hipLaunchKernelGGL(k_fill_u32, dim3(4096), dim3(BLOCK), 0, st, (unsigned *)h->buf, n, 0x7FC00000u);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int odr_history_create(odr_ctx *c, int64_t n_trajectories, int32_t n_times, int32_t nvars, const int32_t *var_codes,
+                       odr_history **out) {
+  REQUIRE(n_trajectories > 0 && n_times > 0 && nvars > 0 && nvars <= HIST_MAXV && var_codes && out, "bad history shape");
+  for (int k = 0; k < nvars; ++k) {
+    int cde = var_codes[k];
+    bool ok = (cde >= 0 && cde < NVAR) || (cde >= ODR_HIST_LON && cde <= ODR_HIST_TERMINAL_VELOCITY) ||
+              (cde >= ODR_HIST_PROPERTY0 && cde < ODR_HIST_PROPERTY0 + 9);
+    REQUIRE(ok, "unknown history variable code %d", cde);
+  }
+  HIPCHK(hipSetDevice(c->device));
+  odr_history *h = new odr_history();
+  memset(h, 0, sizeof *h);
+  h->ntraj = n_trajectories; h->ntimes = n_times; h->nvars = nvars; h->stride = (nvars + 3) & ~3;
+  for (int k = 0; k < nvars; ++k) h->codes[k] = var_codes[k];
+  HIPCHK(hipMalloc((void **)&h->buf, sizeof(float) * (size_t)n_times * (size_t)n_trajectories * (size_t)h->stride));
+  HIPCHK(hipMalloc((void **)&h->red, 2 * sizeof(double)));
+  HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&h->recorded, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->flushed, hipEventDisableTiming));
+  int rc = hist_fill_nan(c, h, c->stream);
+  if (rc) return rc;
+  *out = h;
+  return 0;
+}
+
+int odr_history_destroy(odr_ctx *c, odr_history *h) {
+  if (!h) return 0;
+  HIPCHK(hipSetDevice(c->device));
+  (void)hipStreamSynchronize(h->copy_stream);
+  (void)hipStreamSynchronize(c->stream);
+  if (h->buf) (void)hipFree(h->buf);
+  if (h->stage) (void)hipFree(h->stage);
+  if (h->host) (void)hipHostFree(h->host);
+  if (h->red) (void)hipFree(h->red);
+  (void)hipStreamDestroy(h->copy_stream);
+  (void)hipEventDestroy(h->recorded);
+  (void)hipEventDestroy(h->flushed);
+  delete h;
+  return 0;
+}
+
+int odr_history_record(odr_ctx *c, odr_particles *p, odr_history *h, int32_t time_index, int only_deactivated) {
+  REQUIRE(h && time_index >= 0 && time_index < h->ntimes, "time index %d outside the buffer (%d)", time_index, h ? h->ntimes : 0);
+  if (p->n == 0) return 0;
+  HistVars H;
+  memset(&H, 0, sizeof H);
+  H.nvars = h->nvars; H.stride = h->stride;
+  for (int k = 0; k < h->nvars; ++k) {
+    int cde = h->codes[k];
+    const void *src = nullptr;
+    int kind = HK_F32;
+    if (cde >= 0 && cde < NVAR) src = p->env[cde];
+    else if (cde == ODR_HIST_LON) { src = p->d64[0]; kind = HK_F64; }
+    else if (cde == ODR_HIST_LAT) { src = p->d64[1]; kind = HK_F64; }
+    else if (cde == ODR_HIST_Z) { src = p->d64[2]; kind = HK_F64; }
+    else if (cde == ODR_HIST_STATUS) { src = p->i32[1]; kind = HK_I32; }
+    else if (cde == ODR_HIST_MOVING) { src = p->i32[2]; kind = HK_I32; }
+    else if (cde == ODR_HIST_AGE_SECONDS) src = p->f32[3];
+    else if (cde == ODR_HIST_WIND_DRIFT_FACTOR) src = p->f32[0];
+    else if (cde == ODR_HIST_CURRENT_DRIFT_FACTOR) src = p->f32[1];
+    else if (cde == ODR_HIST_TERMINAL_VELOCITY) src = p->f32[2];
+    else src = p->aux[cde - ODR_HIST_PROPERTY0];
+    if (!src) return fail(ODR_ERR_STATE, "history variable %d has not been sampled / set", cde);
+    H.src[k] = src; H.kind[k] = kind;
+  }
+  // a flush in flight reads the buffer on the copy stream: records of later time slots may proceed,
+  // but never overwrite a slot before its flush has finished
+  HIPCHK(hipStreamWaitEvent(c->stream, h->flushed, 0));
+  float *slab = h->buf + (size_t)time_index * (size_t)h->ntraj * (size_t)h->stride;
+  hipLaunchKernelGGL(k_hist_record, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->n, p->i32[0], p->i32[1], H, slab,
+                     h->ntraj, only_deactivated);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Start copying time slots [t0, t0+nt) of every variable to pinned host memory in the reference's
+// (trajectory, time) layout; returns immediately.  odr_history_wait blocks until the copy is done;
+// odr_history_host_ptr gives the pinned array of one variable ([ntraj][nt] float32), valid until the next flush.
+int odr_history_flush(odr_ctx *c, odr_history *h, int32_t t0, int32_t nt) {
+  REQUIRE(h && t0 >= 0 && nt > 0 && t0 + nt <= h->ntimes, "bad time range");
+  HIPCHK(hipSetDevice(c->device));
+  size_t per_var = (size_t)h->ntraj * (size_t)nt;
+  if (h->host_floats < per_var * (size_t)h->nvars) {
+    HIPCHK(hipStreamSynchronize(h->copy_stream));
+    if (h->host) HIPCHK(hipHostFree(h->host));
+    HIPCHK(hipHostMalloc((void **)&h->host, sizeof(float) * per_var * (size_t)h->nvars, hipHostMallocDefault));
+    h->host_floats = per_var * (size_t)h->nvars;
+  }
+  h->flush_nt = nt;
+  const size_t chunk_tr = std::max<size_t>(1, std::min<size_t>((size_t)h->ntraj, ((size_t)1 << 27) / (size_t)nt));  // <= 512 MiB staging
+  if (h->stage_floats < chunk_tr * (size_t)nt * 2) {
+    HIPCHK(hipStreamSynchronize(h->copy_stream));
+    if (h->stage) HIPCHK(hipFree(h->stage));
+    HIPCHK(hipMalloc((void **)&h->stage, sizeof(float) * chunk_tr * (size_t)nt * 2));  // double buffered
+    h->stage_floats = chunk_tr * (size_t)nt * 2;
+  }
+  HIPCHK(hipEventRecord(h->recorded, c->stream));
+  HIPCHK(hipStreamWaitEvent(h->copy_stream, h->recorded, 0));
+  int flip = 0;
+  for (int v = 0; v < h->nvars; ++v)
+    for (size_t tr0 = 0; tr0 < (size_t)h->ntraj; tr0 += chunk_tr) {
+      size_t ntr = std::min(chunk_tr, (size_t)h->ntraj - tr0);
+      float *st = h->stage + (size_t)flip * chunk_tr * (size_t)nt;
+      flip ^= 1;
+      hipLaunchKernelGGL(k_hist_extract, dim3(nblk((long long)(ntr * nt))), dim3(BLOCK), 0, h->copy_stream, h->buf, h->ntraj,
+                         h->stride, v, t0, nt, (long long)tr0, (long long)ntr, st);
+      HIPCHK(hipMemcpyAsync(h->host + (size_t)v * per_var + tr0 * (size_t)nt, st, sizeof(float) * ntr * (size_t)nt,
+                            hipMemcpyDeviceToHost, h->copy_stream));
+    }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(h->flushed, h->copy_stream));
+  return 0;
+}
+
+int odr_history_wait(odr_ctx *c, odr_history *h) {
+  REQUIRE(h, "history NULL");
+  HIPCHK(hipStreamSynchronize(h->copy_stream));
+  return 0;
+}
+
+int odr_history_host_ptr(odr_ctx *c, odr_history *h, int32_t var_index, float **ptr, int32_t *nt) {
+  REQUIRE(h && var_index >= 0 && var_index < h->nvars && ptr, "bad variable index");
+  if (!h->host) return fail(ODR_ERR_STATE, "odr_history_flush has not been called");
+  *ptr = h->host + (size_t)var_index * (size_t)h->ntraj * (size_t)h->flush_nt;
+  if (nt) *nt = h->flush_nt;
+  return 0;
+}
+
+// NaN-fill the buffer for the next export_buffer_length output times (:2493-2499)
+int odr_history_reset(odr_ctx *c, odr_history *h) {
+  REQUIRE(h, "history NULL");
+  HIPCHK(hipStreamWaitEvent(c->stream, h->flushed, 0));
+  return hist_fill_nan(c, h, c->stream);
+}
+
+// var.min(skipna=True), var.max(skipna=True) over the whole buffer (:2409-2414); NaN when nothing was written
+int odr_history_minmax(odr_ctx *c, odr_history *h, int32_t var_index, double *minval, double *maxval) {
+  REQUIRE(h && var_index >= 0 && var_index < h->nvars && minval && maxval, "bad arguments");
+  double init[2] = {-INFINITY, -INFINITY}, r[2];
+  HIPCHK(hipMemcpyAsync(h->red, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+  long long nrec = (long long)h->ntimes * h->ntraj;
+  hipLaunchKernelGGL(k_hist_minmax, dim3(2048), dim3(BLOCK), 0, c->stream, h->buf, nrec, h->stride, var_index, h->red);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(r, h->red, sizeof r, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *minval = r[0] == -INFINITY ? NAN : -r[0];
+  *maxval = r[1] == -INFINITY ? NAN : r[1];
   return 0;
 }

@@ -157,6 +157,9 @@ class Context:
         check(self.lib.odr_env_bind(self.h, _vid(variable), len(source_ids), pi,
                                     np.nan if fallback is None else float(fallback)))
 
+    def history(self, n_trajectories, n_times, variables):
+        return History(self, n_trajectories, n_times, variables)
+
     def particles(self, capacity):
         return Particles(self, capacity)
 
@@ -399,3 +402,55 @@ class Particles:
         keys = ['n_active', 'lon_min', 'lon_max', 'lat_min', 'lat_max', 'z_min', 'z_max', 'D_max',
                 'stokes_sum_max', 'wind_speed_max', 'wdf_surface_max', 'n_surface', 'hs_max', 'tp_max']
         return dict(zip(keys, out))
+
+
+class History:
+    """Device-resident float32 result buffer (state_to_buffer, basemodel/__init__.py:2084-2105,2384-2499):
+    `variables` = element property names ('lon', 'lat', 'z', 'status', ...), environment variable names, or
+    ('property', slot).  record() scatters the current state at (ID, time index); flush() copies time slots to
+    pinned host memory asynchronously; array(var) returns the [trajectory, time] float32 view of the last flush."""
+
+    def __init__(self, ctx, n_trajectories, n_times, variables):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.variables = list(variables)
+        self.n_trajectories, self.n_times = int(n_trajectories), int(n_times)
+        codes = []
+        for v in self.variables:
+            if isinstance(v, tuple):
+                codes.append(_abi.HIST_PROPERTY0 + int(v[1]))
+            elif v in _abi.HIST:
+                codes.append(_abi.HIST[v])
+            else:
+                codes.append(_vid(v))
+        a, pa = _i(codes)
+        self.h = C.c_void_p()
+        check(self.lib.odr_history_create(ctx.h, self.n_trajectories, self.n_times, len(codes), pa, C.byref(self.h)))
+
+    def record(self, particles, time_index, only_deactivated=False):
+        check(self.lib.odr_history_record(self.ctx.h, particles.h, self.h, int(time_index), int(bool(only_deactivated))))
+
+    def flush(self, t0=0, nt=None):
+        check(self.lib.odr_history_flush(self.ctx.h, self.h, int(t0), int(self.n_times - t0 if nt is None else nt)))
+
+    def wait(self):
+        check(self.lib.odr_history_wait(self.ctx.h, self.h))
+
+    def array(self, variable):
+        """[trajectory, time] float32 view of pinned host memory (valid until the next flush)."""
+        k = self.variables.index(variable)
+        p, nt = _fp(), C.c_int32()
+        check(self.lib.odr_history_host_ptr(self.ctx.h, self.h, k, C.byref(p), C.byref(nt)))
+        return np.ctypeslib.as_array(p, shape=(self.n_trajectories, nt.value))
+
+    def minmax(self, variable):
+        lo, hi = C.c_double(), C.c_double()
+        check(self.lib.odr_history_minmax(self.ctx.h, self.h, self.variables.index(variable), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def reset(self):
+        check(self.lib.odr_history_reset(self.ctx.h, self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.odr_history_destroy(self.ctx.h, self.h)
+            self.h = None

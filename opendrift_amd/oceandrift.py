@@ -421,8 +421,10 @@ class OpenDriftSimulation(Configurable):
         self.mode = 'Run'
         self.prepare_run()
         nout = steps // out_every + 1
-        hist = {k: np.full((n_total, nout), np.nan, np.float32) for k in ('lon', 'lat', 'z')}  # float32 history (:2094)
-        hist['status'] = np.full((n_total, nout), -1, np.int32)
+        # float32 result buffer on the device (basemodel/__init__.py:2084-2105): element properties and
+        # environment variables, [trajectory, time], NaN where an element does not exist
+        hvars = self._history_variables(export_variables)
+        self._hist = _ResultBuffer(self.ctx, n_total, nout, min(nout, max(1, int(export_buffer_length))), hvars)
         times = []
         grid_sid = next((b.sid for b in self.readers.values() if b.is_grid() and b.sid is not None), None)
         for i in range(steps):
@@ -440,8 +442,7 @@ class OpenDriftSimulation(Configurable):
                 self.get_environment()
                 self.interact_with_coastline()
                 self.interact_with_seafloor()
-                if i % out_every == 0:
-                    self._state_to_buffer(hist, i // out_every, times)
+                self._state_to_buffer(i, out_every, times)
                 max_age = self.get_config('drift:max_age_seconds')
                 self.P.increase_age(self.time_step.total_seconds(), max_age or 0.0,
                                     self._status_code('retired') if max_age else 0)
@@ -460,20 +461,77 @@ class OpenDriftSimulation(Configurable):
                 logger.warning('The simulation stopped before requested end time was reached: %s', e)
                 break
         self.interact_with_coastline(final=True)
-        if (self.steps_calculation % out_every) == 0 and self.steps_calculation // out_every < nout:
-            self._state_to_buffer(hist, self.steps_calculation // out_every, times)
+        self._state_to_buffer(self.steps_calculation, out_every, times, final=True)
         self.mode = 'Result'
-        self.result = dict(time=times, **hist)
+        self.result = dict(time=times, **self._hist.finish(len(times)))
+        self.result_minmax = self._hist.minmax
         return self.result
 
-    def _state_to_buffer(self, hist, k, times):   # :2384-2499 (host copy of the live state at output steps)
-        times.append(self.time)
-        for d in (self.P.download(), self.P.download_deactivated()):
-            if len(d['ID']) == 0:
-                continue
-            for q in ('lon', 'lat', 'z'):
-                hist[q][d['ID'], k] = d[q]
-            hist['status'][d['ID'], k] = d['status']
+    def _history_variables(self, export_variables):
+        """Variables of the result buffer (:2068-2105): every element property and every required environment
+        variable, or `export_variables` + ['lon', 'lat', 'status']."""
+        elem = ['lon', 'lat', 'z', 'status', 'moving', 'age_seconds', 'wind_drift_factor', 'current_drift_factor',
+                'terminal_velocity']
+        aux = list(getattr(self, 'aux_properties', []))
+        env = list(self.required_variables)
+        if export_variables is not None:
+            keep = set(export_variables) | {'lon', 'lat', 'status'}
+            elem, aux, env = [v for v in elem if v in keep], [v for v in aux if v in keep], [v for v in env if v in keep]
+        self._hist_aux = {name: ('property', list(getattr(self, 'aux_properties', [])).index(name)) for name in aux}
+        return elem + aux + env
+
+    def _state_to_buffer(self, step, out_every, times, final=False):   # :2384-2403, on the device
+        k = step // out_every
+        if step % out_every == 0:            # output time: every element present
+            if k < self._hist.ntimes:
+                if len(self.P) > 0:
+                    self._hist.record(self.P, k, False, self._hist_aux)
+                while len(times) <= k:       # result.time is a regular axis (:2088-2090)
+                    times.append(self.start_time + len(times) * out_every * self.time_step)
+        elif not final and k + 1 < self._hist.ntimes and len(self.P) > 0:
+            self._hist.record(self.P, k + 1, True, self._hist_aux)   # deactivated -> next output time (backfill)
+
+
+class _ResultBuffer:
+    """export_buffer_length output times on the device (device.History); when full it is flushed to host
+    chunks asynchronously and reset (:2489-2499)."""
+
+    def __init__(self, ctx, ntraj, ntimes, nbuf, variables):
+        self.ctx, self.ntraj, self.ntimes, self.nbuf, self.variables = ctx, ntraj, ntimes, nbuf, list(variables)
+        self.base, self.used, self.chunks, self.H, self.minmax = 0, 0, [], None, {}
+
+    def _open(self, aux):
+        if self.H is None:
+            self.H = self.ctx.history(self.ntraj, self.nbuf, [aux.get(v, v) for v in self.variables])
+
+    def record(self, P, k, only_deactivated, aux):
+        self._open(aux)
+        while k - self.base >= self.nbuf:
+            self._flush(self.nbuf)
+        self.H.record(P, k - self.base, only_deactivated)
+        self.used = max(self.used, k - self.base + 1)
+
+    def _flush(self, nt):
+        for v, name in zip(self.H.variables, self.variables):
+            lo, hi = self.H.minmax(v)
+            old = self.minmax.get(name)
+            self.minmax[name] = (lo, hi) if old is None else (np.fmin(old[0], lo), np.fmax(old[1], hi))
+        self.H.flush(0, nt)
+        self.H.wait()
+        self.chunks.append({name: self.H.array(v).copy() for v, name in zip(self.H.variables, self.variables)})
+        self.H.reset()
+        self.base += nt
+        self.used = 0
+
+    def finish(self, ntimes_written):
+        if self.H is None:
+            return {v: np.full((self.ntraj, ntimes_written), np.nan, np.float32) for v in self.variables}
+        n_last = max(0, ntimes_written - self.base)
+        if n_last > 0:
+            self._flush(min(n_last, self.nbuf))
+        self.H.close()
+        out = {v: np.concatenate([c[v] for c in self.chunks], axis=1)[:, :ntimes_written] for v in self.variables}
+        return out
 
 
 class OceanDrift(OpenDriftSimulation):

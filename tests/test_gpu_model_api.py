@@ -94,6 +94,50 @@ def test_c4_run_stere_hdiff_stranding_numpy_rng():
     assert 'stranded' in o.status_categories
 
 
+def test_result_buffer_follows_state_to_buffer_semantics():
+    """run() result = the reference's float32 [trajectory, time] buffer (basemodel/__init__.py:2084-2105,2384-2403)
+    kept on the device: golden positions at every output time, the state at deactivation written once and NaN
+    afterwards, identical with a 3-slot export buffer (flush + reset while running)."""
+    g = golden('c4_stere_rk4_hdiff_strand.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'x_wind', 'y_wind',
+             'sea_surface_wave_stokes_drift_x_velocity', 'sea_surface_wave_stokes_drift_y_velocity', 'land_binary_mask']
+
+    def run(**kw):
+        o = OceanDrift(loglevel=50, seed=0, rng='numpy')
+        o.add_reader(_grid_reader(g, names, proj4=synth.NORKYST_PROJ4))
+        o.set_config('drift:advection_scheme', 'runge-kutta4')
+        o.set_config('environment:constant:horizontal_diffusivity', 10)
+        o.set_config('general:coastline_action', 'stranding')
+        np.random.seed(0)
+        o.seed_elements(lon=g['lon'][0], lat=g['lat'][0], time=T0, wind_drift_factor=float(g['wdf']))
+        return o, o.run(time_step=900, steps=8, **kw)
+
+    o, res = run(export_variables=['z', 'x_wind'])
+    n = g['lon'].shape[1]
+    assert set(res) == {'time', 'lon', 'lat', 'z', 'status', 'x_wind'} and len(res['time']) == 9
+    assert res['lon'].shape == (n, 9) and all(res[k].dtype == np.float32 for k in ('lon', 'lat', 'z', 'status', 'x_wind'))
+    st = g['status']          # golden row k = live state after k steps; a non-zero status appears in the row
+    #                           after the step whose coastline check deactivated the element
+    for k in range(9):
+        present = st[k] == 0                             # still in the arrays when step k samples the environment
+        assert np.isnan(res['lon'][~present, k]).all() and np.isfinite(res['lon'][present, k]).all()
+        assert np.abs(res['lon'][present, k] - g['lon'][k][present]).max() < 2e-5
+        assert np.abs(res['lat'][present, k] - g['lat'][k][present]).max() < 1e-5
+        if k < 8:                                        # written with the status the coastline check of step k gave it
+            assert ((res['status'][present, k] != 0) == (st[k + 1][present] != 0)).all()
+    gone = np.nonzero(st[8] != 0)[0]                    # deactivated by the end of step 7
+    assert len(gone) > 0
+    for e in gone[:50]:
+        kd = int(np.argmax(st[:, e] != 0)) - 1           # output time of the step that deactivated it
+        assert res['status'][e, kd] > 0 and np.isnan(res['status'][e, kd + 1:]).all() and np.isfinite(res['lon'][e, :kd + 1]).all()
+    lo, hi = o.result_minmax['lon']
+    assert lo == np.nanmin(res['lon']) and hi == np.nanmax(res['lon'])
+    o2, res2 = run(export_variables=['z', 'x_wind'], export_buffer_length=3)
+    for k in ('lon', 'lat', 'z', 'status', 'x_wind'):
+        assert np.array_equal(res[k], res2[k], equal_nan=True), k
+    assert o2.result_minmax['lon'] == o.result_minmax['lon']
+
+
 def test_device_rng_run_is_reproducible_and_order_independent():
     g = golden('c3_grid3d_rk4_vmix.npz')
     names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity',
