@@ -1247,6 +1247,7 @@ struct HistVars {
   int kind[HIST_MAXV];
 };
 
+template <int NQ>  // record length in 16-byte quads: the record is assembled in registers and stored with NQ 16-byte writes
 __global__ __launch_bounds__(BLOCK) void k_hist_record(long long n, const int *__restrict__ id,
                                                        const int *__restrict__ status, HistVars H,
                                                        float *__restrict__ slab, long long ntraj,
@@ -1256,14 +1257,20 @@ __global__ __launch_bounds__(BLOCK) void k_hist_record(long long n, const int *_
   if (only_deactivated && status[i] == 0) return;
   const long long tr = id[i];
   if (tr < 0 || tr >= ntraj) return;
-  float *rec = slab + tr * H.stride;
-  for (int v = 0; v < H.nvars; ++v) {
-    float x;
-    if (H.kind[v] == HK_F64) x = (float)((const double *)H.src[v])[i];   // float64 -> float32 array assignment
-    else if (H.kind[v] == HK_I32) x = (float)((const int *)H.src[v])[i];
-    else x = ((const float *)H.src[v])[i];
+  float rec[4 * NQ];
+#pragma unroll
+  for (int v = 0; v < 4 * NQ; ++v) {
+    float x = __builtin_nanf("");
+    if (v < H.nvars) {
+      if (H.kind[v] == HK_F64) x = (float)((const double *)H.src[v])[i];   // float64 -> float32 array assignment
+      else if (H.kind[v] == HK_I32) x = (float)((const int *)H.src[v])[i];
+      else x = ((const float *)H.src[v])[i];
+    }
     rec[v] = x;
   }
+  float4 *dst = (float4 *)(slab + tr * (4 * NQ));
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
 }
 
 // one variable of the buffer in the reference's (trajectory, time) layout: out[(tr - tr0) * nt + t]

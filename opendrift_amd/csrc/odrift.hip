@@ -1503,8 +1503,18 @@ int odr_history_record(odr_ctx *c, odr_particles *p, odr_history *h, int32_t tim
   // but never overwrite a slot before its flush has finished
   HIPCHK(hipStreamWaitEvent(c->stream, h->flushed, 0));
   float *slab = h->buf + (size_t)time_index * (size_t)h->ntraj * (size_t)h->stride;
-  hipLaunchKernelGGL(k_hist_record, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->n, p->i32[0], p->i32[1], H, slab,
-                     h->ntraj, only_deactivated);
+#define HIST_REC(NQ) hipLaunchKernelGGL(k_hist_record<NQ>, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->n, p->i32[0], p->i32[1], \
+                                        H, slab, h->ntraj, only_deactivated)
+  switch (h->stride / 4) {
+    case 1: HIST_REC(1); break;
+    case 2: HIST_REC(2); break;
+    case 3: HIST_REC(3); break;
+    case 4: HIST_REC(4); break;
+    case 5: HIST_REC(5); break;
+    case 6: HIST_REC(6); break;
+    default: HIST_REC(7); break;
+  }
+#undef HIST_REC
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -10,7 +10,7 @@ Follows opendrift/models/basemodel/__init__.py:
   * min / max        :2409-2414 -- var.min(skipna=True), var.max(skipna=True);
   * new buffer       :2493-2499 -- all variables reset to NaN.
 Parity note: the reference's own state_to_buffer needs xarray (not installed here), so this
-restatement is NOT pinned by running the reference: "parity unpinned" for this row (DESIGN.md section 9).
+restatement is NOT pinned by running the reference: "parity unpinned" for this row (DESIGN.md section 8).
 """
 import numpy as np
 
