@@ -256,6 +256,22 @@ int odr_history_host_ptr(odr_ctx *ctx, odr_history *h, int32_t var_index, float 
 int odr_history_reset(odr_ctx *ctx, odr_history *h);   /* new buffer: NaN (:2493-2499) */
 int odr_history_minmax(odr_ctx *ctx, odr_history *h, int32_t var_index, double *minval, double *maxval); /* :2409-2414 */
 
+/* ---------------------------------------------------------------- ROMS sigma grid
+ * The sigma -> z regridding reader_ROMS_native.get_variables applies to every 4-D variable of a block
+ * (reader_ROMS_native.py:512-538,617-684) with roppy (readers/roppy/depth.py): sdepth (:31-113, rho points,
+ * Vtransform 1 | 2, S = NULL: -1 + (k + 0.5)/N), z_rho -= zeta, positive z_rho -> NaN; multi_zslice (:213-284),
+ * values > 1e9 -> NaN.  float64 arithmetic in NumPy's operation order.  H, zeta: [ny][nx] host arrays. */
+typedef struct odr_sgrid odr_sgrid;
+int odr_sgrid_create(odr_ctx *ctx, int32_t ny, int32_t nx, int32_t N, const double *H, const double *zeta_or_null,
+                     double Hc, const double *Cs_r, const double *S_or_null, int32_t Vtransform, odr_sgrid **out);
+int odr_sgrid_destroy(odr_ctx *ctx, odr_sgrid *g);
+int odr_sgrid_download_zrho(odr_ctx *ctx, odr_sgrid *g, double *out /* [N][ny][nx] */);
+/* field [N][ny][nx] float32 (is_f64 = 0) or float64, host or device memory -> *out_dev32: device float32
+ * [kmax][ny][nx] in result slot out_slot (0..7; valid until the next call with the same slot -- one slot per
+ * variable of a block, then pass the pointers to odr_block_upload_device); out_host64 (optional): the float64 result */
+int odr_sgrid_zslice(odr_ctx *ctx, odr_sgrid *g, const void *field, int is_f64, int on_device, int32_t kmax,
+                     const double *Z, int32_t out_slot, void **out_dev32, double *out_host64);
+
 #ifdef __cplusplus
 }
 #endif

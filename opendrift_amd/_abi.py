@@ -97,6 +97,10 @@ _SIGNATURES = {
     'odr_reduce_scalars': [_vp, _vp, C.c_double, _dp],
     'odr_timer_begin': [_vp],
     'odr_timer_end': [_vp, _fp],
+    'odr_sgrid_create': [_vp, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.c_double, _dp, _dp, C.c_int32, _P(_vp)],
+    'odr_sgrid_destroy': [_vp, _vp],
+    'odr_sgrid_download_zrho': [_vp, _vp, _dp],
+    'odr_sgrid_zslice': [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int32, _dp, C.c_int32, _P(_vp), _dp],
     'odr_history_create': [_vp, C.c_int64, C.c_int32, C.c_int32, _ip, _P(_vp)],
     'odr_history_destroy': [_vp, _vp],
     'odr_history_record': [_vp, _vp, _vp, C.c_int32, C.c_int],

@@ -1303,6 +1303,62 @@ __global__ __launch_bounds__(BLOCK) void k_fill_u32(unsigned *a, size_t n, unsig
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) a[i] = v;
 }
 
+// ------------------------------------------------------------- ROMS sigma -> z regridding
+// What reader_ROMS_native.get_variables does to every 4-D variable of a block before handing it to
+// the ReaderBlock, one thread per water column, float64 in NumPy's
+// operation order:
+//   k_roms_zrho : roppy sdepth (depth.py:31-113, stagger 'rho', Vtransform 1 / 2) minus zeta, positive
+//                 depths -> NaN (reader_ROMS_native.py:512-538);
+//   k_roms_zslice: roppy multi_zslice (depth.py:213-284) + "R > 1e9 -> NaN" (:683-684); the float32
+//                 result goes straight into the block upload.
+__global__ __launch_bounds__(BLOCK) void k_roms_zrho(const double *__restrict__ H, const double *__restrict__ zeta,
+                                                     double Hc, const double *__restrict__ C,
+                                                     const double *__restrict__ S, int N, long long M,
+                                                     int vtransform, double *__restrict__ zr) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= M) return;
+  const double h = H[i], ze = zeta ? zeta[i] : 0.0;
+  const double denom = __dadd_rn(1.0, __ddiv_rn(Hc, h));
+  for (int k = 0; k < N; ++k) {
+    double zo;
+    if (vtransform == 1) zo = __dadd_rn(__dmul_rn(Hc, __dsub_rn(S[k], C[k])), __dmul_rn(C[k], h));
+    else zo = __ddiv_rn(__dadd_rn(__dmul_rn(Hc, S[k]), __dmul_rn(C[k], h)), denom);
+    double z = __dsub_rn(__dadd_rn(zo, __dmul_rn(ze, __dadd_rn(1.0, __ddiv_rn(zo, h)))), ze);
+    zr[(long long)k * M + i] = z;
+  }
+}
+// np.nanmax(z_rho) > 0 -> z_rho[z_rho > 0] = NaN (two passes: the flag is global)
+__global__ __launch_bounds__(BLOCK) void k_roms_zrho_positive(double *__restrict__ zr, long long n, int *flag, int apply) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  if (zr[i] > 0) {
+    if (apply) zr[i] = __builtin_nan("");
+    else *flag = 1;
+  }
+}
+
+template <typename TF>
+__global__ __launch_bounds__(BLOCK) void k_roms_zslice(const TF *__restrict__ F, const double *__restrict__ zr,
+                                                       const double *__restrict__ Z, int N, int kmax, long long M,
+                                                       float *__restrict__ out32, double *__restrict__ out64) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= M) return;
+  for (int j = 0; j < kmax; ++j) {
+    const double z = Z[j];
+    int c = 0;
+    for (int k = 0; k < N; ++k) c += zr[(long long)k * M + i] < z ? 1 : 0;   // NaN compares false, as in NumPy
+    c = c < 1 ? 1 : (c > N - 1 ? N - 1 : c);
+    const double s0 = zr[(long long)(c - 1) * M + i], s1 = zr[(long long)c * M + i];
+    double a = __ddiv_rn(__dsub_rn(z, s0), __dsub_rn(s1, s0));
+    a = a < 0.0 ? 0.0 : (a > 1.0 ? 1.0 : a);                               // np.clip keeps NaN
+    const double f0 = (double)F[(long long)(c - 1) * M + i], f1 = (double)F[(long long)c * M + i];
+    double r = __dadd_rn(__dmul_rn(__dsub_rn(1.0, a), f0), __dmul_rn(a, f1));
+    if (r > 1e9) r = __builtin_nan("");
+    if (out32) out32[(long long)j * M + i] = (float)r;
+    if (out64) out64[(long long)j * M + i] = r;
+  }
+}
+
 // final device layout of a block: one record per grid node holding every variable of the reader
 // at that node, z innermost -- element (k, node) of a variable at record offset `off` lives at
 // dst[node * rec + off + k * es + eo] (es = 2, eo = 0/1 for the two components of a vector pair).

@@ -1593,3 +1593,136 @@ int odr_history_minmax(odr_ctx *c, odr_history *h, int32_t var_index, double *mi
   *maxval = r[1] == -INFINITY ? NAN : r[1];
   return 0;
 }
+
+// ------------------------------------------------------------------ ROMS sigma grid
+// the sigma -> z regridding of ROMS-native blocks on the device.  An odr_sgrid holds
+// the depths of the s-levels of one grid (z_rho, computed once like the reader's z_rho_tot); odr_sgrid_zslice
+// regrids one 3-D variable per call into a float32 [kmax][ny][nx] device array that odr_block_upload_device takes.
+struct odr_sgrid {
+  int N, ny, nx;
+  double *zr;       // [N][ny*nx]
+  double *Z;        // device copy of the last z levels
+  int kmax_cap;
+  void *fbuf;       // device staging of a host-supplied field
+  size_t fbuf_bytes;
+  float *out32[8];  // result slots (several regridded variables alive for one block upload)
+  size_t out_elems[8];
+  double *out64;
+  size_t out64_elems;
+};
+
+int odr_sgrid_create(odr_ctx *c, int32_t ny, int32_t nx, int32_t N, const double *H, const double *zeta, double Hc,
+                     const double *Cs, const double *S, int32_t vtransform, odr_sgrid **out) {
+  REQUIRE(ny > 0 && nx > 0 && N >= 2 && N <= 4096 && H && Cs && out, "bad s-grid arguments");
+  REQUIRE(vtransform == 1 || vtransform == 2, "Unknown Vtransform");
+  HIPCHK(hipSetDevice(c->device));
+  odr_sgrid *g = new odr_sgrid();
+  memset(g, 0, sizeof *g);
+  g->N = N; g->ny = ny; g->nx = nx;
+  const long long M = (long long)ny * nx;
+  std::vector<double> s((size_t)N);
+  for (int k = 0; k < N; ++k) s[(size_t)k] = S ? S[k] : -1.0 + ((double)k + 0.5) / (double)N;   // depth.py:92-100
+  double *dH, *dz = nullptr, *dC, *dS;
+  int *flag;
+  HIPCHK(hipMalloc((void **)&dH, sizeof(double) * (size_t)M));
+  HIPCHK(hipMalloc((void **)&dC, sizeof(double) * (size_t)N));
+  HIPCHK(hipMalloc((void **)&dS, sizeof(double) * (size_t)N));
+  HIPCHK(hipMalloc((void **)&flag, sizeof(int)));
+  HIPCHK(hipMalloc((void **)&g->zr, sizeof(double) * (size_t)M * (size_t)N));
+  HIPCHK(hipMemcpyAsync(dH, H, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dC, Cs, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dS, s.data(), sizeof(double) * (size_t)N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+  if (zeta) {
+    HIPCHK(hipMalloc((void **)&dz, sizeof(double) * (size_t)M));
+    HIPCHK(hipMemcpyAsync(dz, zeta, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, c->stream));
+  }
+  hipLaunchKernelGGL(k_roms_zrho, dim3(nblk(M)), dim3(BLOCK), 0, c->stream, dH, dz, Hc, dC, dS, N, M, vtransform, g->zr);
+  hipLaunchKernelGGL(k_roms_zrho_positive, dim3(nblk(M * N)), dim3(BLOCK), 0, c->stream, g->zr, M * N, flag, 0);
+  int hflag = 0;
+  HIPCHK(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (hflag) hipLaunchKernelGGL(k_roms_zrho_positive, dim3(nblk(M * N)), dim3(BLOCK), 0, c->stream, g->zr, M * N, flag, 1);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  (void)hipFree(dH); (void)hipFree(dC); (void)hipFree(dS); (void)hipFree(flag);
+  if (dz) (void)hipFree(dz);
+  *out = g;
+  return 0;
+}
+
+int odr_sgrid_destroy(odr_ctx *c, odr_sgrid *g) {
+  if (!g) return 0;
+  HIPCHK(hipSetDevice(c->device));
+  (void)hipStreamSynchronize(c->stream);
+  if (g->zr) (void)hipFree(g->zr);
+  if (g->Z) (void)hipFree(g->Z);
+  if (g->fbuf) (void)hipFree(g->fbuf);
+  for (int k = 0; k < 8; ++k) if (g->out32[k]) (void)hipFree(g->out32[k]);
+  if (g->out64) (void)hipFree(g->out64);
+  delete g;
+  return 0;
+}
+
+int odr_sgrid_download_zrho(odr_ctx *c, odr_sgrid *g, double *out) {
+  REQUIRE(g && out, "bad arguments");
+  HIPCHK(hipMemcpyAsync(out, g->zr, sizeof(double) * (size_t)g->N * g->ny * g->nx, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// field: [N][ny][nx] float32 (is_f64 = 0) or float64, on the host or (on_device) in device memory.
+// Results: *out_dev32 = device float32 [kmax][ny][nx] (valid until the next call on this s-grid; feed it to
+// odr_block_upload_device); out_host64 (optional) receives the float64 values the reference computes.
+int odr_sgrid_zslice(odr_ctx *c, odr_sgrid *g, const void *field, int is_f64, int on_device, int32_t kmax,
+                     const double *Z, int32_t out_slot, void **out_dev32, double *out_host64) {
+  REQUIRE(g && field && kmax > 0 && Z && out_slot >= 0 && out_slot < 8, "bad arguments");
+  HIPCHK(hipSetDevice(c->device));
+  const long long M = (long long)g->ny * g->nx;
+  const size_t fbytes = (is_f64 ? 8 : 4) * (size_t)M * (size_t)g->N;
+  const void *dF = field;
+  if (!on_device) {
+    if (g->fbuf_bytes < fbytes) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (g->fbuf) HIPCHK(hipFree(g->fbuf));
+      HIPCHK(hipMalloc(&g->fbuf, fbytes));
+      g->fbuf_bytes = fbytes;
+    }
+    HIPCHK(hipMemcpyAsync(g->fbuf, field, fbytes, hipMemcpyHostToDevice, c->stream));
+    dF = g->fbuf;
+  }
+  if (g->kmax_cap < kmax) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (g->Z) HIPCHK(hipFree(g->Z));
+    HIPCHK(hipMalloc((void **)&g->Z, sizeof(double) * (size_t)kmax));
+    g->kmax_cap = kmax;
+  }
+  HIPCHK(hipMemcpyAsync(g->Z, Z, sizeof(double) * (size_t)kmax, hipMemcpyHostToDevice, c->stream));
+  const size_t oel = (size_t)M * (size_t)kmax;
+  if (g->out_elems[out_slot] < oel) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (g->out32[out_slot]) HIPCHK(hipFree(g->out32[out_slot]));
+    HIPCHK(hipMalloc((void **)&g->out32[out_slot], sizeof(float) * oel));
+    g->out_elems[out_slot] = oel;
+  }
+  if (out_host64 && g->out64_elems < oel) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (g->out64) HIPCHK(hipFree(g->out64));
+    HIPCHK(hipMalloc((void **)&g->out64, sizeof(double) * oel));
+    g->out64_elems = oel;
+  }
+  double *o64 = out_host64 ? g->out64 : nullptr;
+  if (is_f64)
+    hipLaunchKernelGGL(k_roms_zslice<double>, dim3(nblk(M)), dim3(BLOCK), 0, c->stream, (const double *)dF, g->zr, g->Z,
+                       g->N, kmax, M, g->out32[out_slot], o64);
+  else
+    hipLaunchKernelGGL(k_roms_zslice<float>, dim3(nblk(M)), dim3(BLOCK), 0, c->stream, (const float *)dF, g->zr, g->Z,
+                       g->N, kmax, M, g->out32[out_slot], o64);
+  HIPCHK(hipGetLastError());
+  if (out_host64) {
+    HIPCHK(hipMemcpyAsync(out_host64, g->out64, sizeof(double) * oel, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  if (out_dev32) *out_dev32 = g->out32[out_slot];
+  return 0;
+}

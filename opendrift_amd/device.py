@@ -454,3 +454,51 @@ class History:
         if self.h:
             self.lib.odr_history_destroy(self.ctx.h, self.h)
             self.h = None
+
+
+class SigmaGrid:
+    """ROMS s-coordinate grid on the device (odr_sgrid_*): depths of the rho s-levels (roppy sdepth) and the
+    sigma -> z regridding of 3-D variables (roppy multi_zslice) as done by reader_ROMS_native.get_variables."""
+
+    def __init__(self, ctx, H, Hc, Cs_r, zeta=None, S=None, Vtransform=1):
+        self.ctx, self.lib = ctx, ctx.lib
+        H = np.ascontiguousarray(H, dtype=np.float64)
+        self.ny, self.nx = H.shape
+        Cs = np.ascontiguousarray(Cs_r, dtype=np.float64)
+        self.N = len(Cs)
+        ze = None if zeta is None else np.ascontiguousarray(zeta, dtype=np.float64)
+        Sa = None if S is None else np.ascontiguousarray(S, dtype=np.float64)
+        self.h = C.c_void_p()
+        check(self.lib.odr_sgrid_create(ctx.h, self.ny, self.nx, self.N, H.ctypes.data_as(_dp),
+                                        None if ze is None else ze.ctypes.data_as(_dp), float(Hc), Cs.ctypes.data_as(_dp),
+                                        None if Sa is None else Sa.ctypes.data_as(_dp), int(Vtransform), C.byref(self.h)))
+
+    def z_rho(self):
+        out = np.empty((self.N, self.ny, self.nx))
+        check(self.lib.odr_sgrid_download_zrho(self.ctx.h, self.h, out.ctypes.data_as(_dp)))
+        return out
+
+    def zslice(self, field, Z, want_float64=False, slot=0):
+        """field [N, ny, nx] (float32 / float64 host array, or an int device pointer to float32) -> device pointer
+        of the float32 [len(Z), ny, nx] result in result slot `slot` (0..7: one per variable of a block, for
+        Context.upload_block_device) and, if asked, the float64 values."""
+        Z = np.ascontiguousarray(np.atleast_1d(Z), dtype=np.float64)
+        out64 = np.empty((len(Z), self.ny, self.nx)) if want_float64 else None
+        dev = C.c_void_p()
+        if isinstance(field, (int, np.integer)):
+            check(self.lib.odr_sgrid_zslice(self.ctx.h, self.h, C.c_void_p(int(field)), 0, 1, len(Z), Z.ctypes.data_as(_dp),
+                                            int(slot), C.byref(dev), None if out64 is None else out64.ctypes.data_as(_dp)))
+        else:
+            f = np.ascontiguousarray(field)
+            if f.dtype not in (np.float32, np.float64):
+                f = f.astype(np.float64)
+            assert f.shape == (self.N, self.ny, self.nx), (f.shape, (self.N, self.ny, self.nx))
+            check(self.lib.odr_sgrid_zslice(self.ctx.h, self.h, f.ctypes.data_as(C.c_void_p), int(f.dtype == np.float64), 0,
+                                            len(Z), Z.ctypes.data_as(_dp), int(slot), C.byref(dev),
+                                            None if out64 is None else out64.ctypes.data_as(_dp)))
+        return (dev.value, out64) if want_float64 else dev.value
+
+    def close(self):
+        if self.h:
+            self.lib.odr_sgrid_destroy(self.ctx.h, self.h)
+            self.h = None
