@@ -1337,25 +1337,39 @@ __global__ __launch_bounds__(BLOCK) void k_roms_zrho_positive(double *__restrict
   }
 }
 
-template <typename TF>
+// KMAX = compile-time bound of the number of z levels: the counts C[j] = #(S < Z[j]) of all levels are
+// accumulated in registers during ONE sweep over the column's s-level depths (each read once, coalesced
+// across the wave); the two bracketing levels of every z are then re-read (cache hits).
+template <typename TF, int KMAX>
 __global__ __launch_bounds__(BLOCK) void k_roms_zslice(const TF *__restrict__ F, const double *__restrict__ zr,
                                                        const double *__restrict__ Z, int N, int kmax, long long M,
                                                        float *__restrict__ out32, double *__restrict__ out64) {
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= M) return;
-  for (int j = 0; j < kmax; ++j) {
-    const double z = Z[j];
-    int c = 0;
-    for (int k = 0; k < N; ++k) c += zr[(long long)k * M + i] < z ? 1 : 0;   // NaN compares false, as in NumPy
-    c = c < 1 ? 1 : (c > N - 1 ? N - 1 : c);
-    const double s0 = zr[(long long)(c - 1) * M + i], s1 = zr[(long long)c * M + i];
-    double a = __ddiv_rn(__dsub_rn(z, s0), __dsub_rn(s1, s0));
-    a = a < 0.0 ? 0.0 : (a > 1.0 ? 1.0 : a);                               // np.clip keeps NaN
-    const double f0 = (double)F[(long long)(c - 1) * M + i], f1 = (double)F[(long long)c * M + i];
-    double r = __dadd_rn(__dmul_rn(__dsub_rn(1.0, a), f0), __dmul_rn(a, f1));
-    if (r > 1e9) r = __builtin_nan("");
-    if (out32) out32[(long long)j * M + i] = (float)r;
-    if (out64) out64[(long long)j * M + i] = r;
+  double zl[KMAX];
+  int cnt[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) { zl[j] = j < kmax ? Z[j] : -__builtin_inf(); cnt[j] = 0; }
+  for (int k = 0; k < N; ++k) {
+    const double sv = zr[(long long)k * M + i];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) cnt[j] += sv < zl[j] ? 1 : 0;   // NaN compares false, as in NumPy
+  }
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    if (j < kmax) {
+      const double z = zl[j];
+      int c = cnt[j];
+      c = c < 1 ? 1 : (c > N - 1 ? N - 1 : c);
+      const double s0 = zr[(long long)(c - 1) * M + i], s1 = zr[(long long)c * M + i];
+      double a = __ddiv_rn(__dsub_rn(z, s0), __dsub_rn(s1, s0));
+      a = a < 0.0 ? 0.0 : (a > 1.0 ? 1.0 : a);                               // np.clip keeps NaN
+      const double f0 = (double)F[(long long)(c - 1) * M + i], f1 = (double)F[(long long)c * M + i];
+      double r = __dadd_rn(__dmul_rn(__dsub_rn(1.0, a), f0), __dmul_rn(a, f1));
+      if (r > 1e9) r = __builtin_nan("");
+      if (out32) out32[(long long)j * M + i] = (float)r;
+      if (out64) out64[(long long)j * M + i] = r;
+    }
   }
 }
 

@@ -1712,12 +1712,17 @@ int odr_sgrid_zslice(odr_ctx *c, odr_sgrid *g, const void *field, int is_f64, in
     g->out64_elems = oel;
   }
   double *o64 = out_host64 ? g->out64 : nullptr;
-  if (is_f64)
-    hipLaunchKernelGGL(k_roms_zslice<double>, dim3(nblk(M)), dim3(BLOCK), 0, c->stream, (const double *)dF, g->zr, g->Z,
-                       g->N, kmax, M, g->out32[out_slot], o64);
-  else
-    hipLaunchKernelGGL(k_roms_zslice<float>, dim3(nblk(M)), dim3(BLOCK), 0, c->stream, (const float *)dF, g->zr, g->Z,
-                       g->N, kmax, M, g->out32[out_slot], o64);
+  // z levels in chunks of at most 64 (compile-time register arrays of 8 / 16 / 32 / 64 counters)
+  for (int j0 = 0; j0 < kmax; j0 += 64) {
+    const int kc = std::min(64, kmax - j0);
+    float *o32 = g->out32[out_slot] + (size_t)j0 * (size_t)M;
+    double *o64c = o64 ? o64 + (size_t)j0 * (size_t)M : nullptr;
+#define ZSL(T, K) hipLaunchKernelGGL((k_roms_zslice<T, K>), dim3(nblk(M)), dim3(BLOCK), 0, c->stream, (const T *)dF, g->zr, \
+                                     g->Z + j0, g->N, kc, M, o32, o64c)
+    if (is_f64) { if (kc <= 8) ZSL(double, 8); else if (kc <= 16) ZSL(double, 16); else if (kc <= 32) ZSL(double, 32); else ZSL(double, 64); }
+    else { if (kc <= 8) ZSL(float, 8); else if (kc <= 16) ZSL(float, 16); else if (kc <= 32) ZSL(float, 32); else ZSL(float, 64); }
+#undef ZSL
+  }
   HIPCHK(hipGetLastError());
   if (out_host64) {
     HIPCHK(hipMemcpyAsync(out_host64, g->out64, sizeof(double) * oel, hipMemcpyDeviceToHost, c->stream));
