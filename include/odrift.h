@@ -125,7 +125,8 @@ int odr_source_grid(odr_ctx *ctx, const odr_proj_desc *proj, const double *domai
 int odr_block_upload(odr_ctx *ctx, int32_t source_id, int32_t slot, double t_epoch, int nvars,
                      const int32_t *var_ids, const float *const *data, const int32_t *var_nz,
                      int ny, int nx, const double *xy8);
-/* same, the float32 data already live in device memory (RCCL-broadcast blocks) */
+/* same, the float32 data already live in device memory (RCCL-broadcast blocks, odr_sgrid_zslice results); with
+ * unified addressing each data[k] may individually be a host or a device pointer in either call */
 int odr_block_upload_device(odr_ctx *ctx, int32_t source_id, int32_t slot, double t_epoch,
                             int nvars, const int32_t *var_ids, const void *const *dev_data,
                             const int32_t *var_nz, int ny, int nx, const double *xy8);

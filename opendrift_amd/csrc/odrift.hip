@@ -522,8 +522,8 @@ static int block_upload(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, i
     float *buf, *tmp;
     HIPCHK(hipMalloc((void **)&buf, sizeof(float) * n));
     HIPCHK(hipMalloc((void **)&tmp, sizeof(float) * n));
-    HIPCHK(hipMemcpyAsync(buf, data[k], sizeof(float) * n, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                          c->stream));
+    (void)on_device;  // unified addressing: every data[k] may be a host or a device pointer
+    HIPCHK(hipMemcpyAsync(buf, data[k], sizeof(float) * n, hipMemcpyDefault, c->stream));
     unsigned g = (unsigned)((n + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(k_blk_mask, dim3(g), dim3(BLOCK), 0, c->stream, buf, n);
     if (nzv > 1)

@@ -136,12 +136,15 @@ class Context:
                                         g['nx'], px))
 
     def upload_block_device(self, sid, slot, t_epoch, dev_ptrs, var_nz):
-        """dev_ptrs: {variable: device pointer (int)} of float32 arrays already in HBM."""
+        """dev_ptrs: {variable: device pointer (int) of a float32 array already in HBM, or a host NumPy array};
+        var_nz: levels per variable (needed for the device pointers)."""
         g = self._grids[sid]
         names = list(dev_ptrs)
         ids, pi = _i([_vid(k) for k in names])
-        nzs, pn = _i([var_nz[k] for k in names])
-        ptrs = (C.c_void_p * len(names))(*[C.c_void_p(int(dev_ptrs[k])) for k in names])
+        keep = {k: np.ascontiguousarray(np.ma.filled(v, np.nan) if isinstance(v, np.ma.MaskedArray) else v, dtype=np.float32)
+                for k, v in dev_ptrs.items() if not isinstance(v, (int, np.integer))}
+        nzs, pn = _i([(keep[k].shape[0] if keep[k].ndim == 3 else 1) if k in keep else var_nz[k] for k in names])
+        ptrs = (C.c_void_p * len(names))(*[C.c_void_p(keep[k].ctypes.data if k in keep else int(dev_ptrs[k])) for k in names])
         xy8, px = _d(g['xy8'])
         check(self.lib.odr_block_upload_device(self.h, sid, slot, float(t_epoch), len(names), pi, ptrs, pn,
                                                g['ny'], g['nx'], px))

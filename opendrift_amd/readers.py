@@ -166,6 +166,48 @@ class GridReader(StructuredReader):
         return out
 
 
+ROMS_ZLEVELS = np.array([0, -.5, -1, -3, -5, -10, -25, -50, -75, -100, -150, -200, -250, -300, -400, -500, -600, -700,
+                         -800, -900, -1000, -1500, -2000, -2500, -3000, -3500, -4000, -4500, -5000, -5500, -6000, -6500,
+                         -7000, -7500, -8000], dtype=np.float64)   # reader_ROMS_native.py:134-138
+
+
+class SigmaGridReader(StructuredReader):
+    """In-memory reader with the vertical structure of reader_ROMS_native: 3-D variables live on N terrain-following
+    s-levels (arrays3d: {variable: [nt, N, ny, nx]}), 2-D ones on the grid (arrays2d: {variable: [nt, ny, nx]}); `h`
+    bottom depth, `hc`, `Cs_r`, `Vtransform` as in a ROMS file.  Blocks handed to the model are on the reader's fixed
+    z levels (`zlevels`, default: the reference's list down to the deepest node), regridded per time level as
+    reader_ROMS_native.get_variables does (:617-684) -- on the device (`s_levels = True` tells the binding that
+    get_variables returns s-level arrays plus the target levels)."""
+    s_levels = True
+
+    def __init__(self, x, y, times, arrays3d, arrays2d, h, hc, Cs_r, Vtransform=2, zlevels=None, proj4='+proj=latlong',
+                 name='sigma_grid_reader'):
+        self.proj4, self.name = proj4, name
+        self.x, self.y = np.asarray(x), np.asarray(y)
+        self.h = np.ascontiguousarray(h, dtype=np.float64)
+        self.hc, self.Cs_r, self.Vtransform = float(hc), np.asarray(Cs_r, dtype=np.float64), int(Vtransform)
+        if zlevels is None:
+            deeper = np.nonzero(ROMS_ZLEVELS < -float(self.h.max()))[0]
+            zlevels = ROMS_ZLEVELS[:deeper[0] + 1] if len(deeper) else ROMS_ZLEVELS
+        self.z = np.asarray(zlevels, dtype=np.float64)
+        self.xmin, self.xmax = float(self.x.min()), float(self.x.max())
+        self.ymin, self.ymax = float(self.y.min()), float(self.y.max())
+        self.times = list(times)
+        self.start_time, self.end_time = self.times[0], self.times[-1]
+        self.time_step = (self.times[1] - self.times[0]) if len(self.times) > 1 else None
+        self.arrays3d, self.arrays2d = dict(arrays3d), dict(arrays2d)
+        self.variables = list(self.arrays3d) + list(self.arrays2d)
+        super().__init__()
+
+    def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
+        it = self.times.index(time)
+        out = {'x': self.x, 'y': self.y, 'time': time, 'z': self.z,
+               's_level_variables': [v for v in requested_variables if v in self.arrays3d]}
+        for v in requested_variables:
+            out[v] = self.arrays3d[v][it] if v in self.arrays3d else self.arrays2d[v][it]
+        return out
+
+
 class DeviceReaderBinding:
     """Device image of one reader: constant/analytic source, or a grid source whose time levels
     (ReaderBlocks) are uploaded on demand.  Stands where StructuredReader keeps
@@ -239,6 +281,21 @@ class DeviceReaderBinding:
                     raise ValueError('reader %s changed its block shape between time levels' % r.name)
             free = [s for s in range(self.NSLOTS) if s not in self.slots.values()]
             slot = free[0]
-            arrays = {v: block[v] for v in self.variables}
-            self.ctx.upload_block(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays)
+            if getattr(r, 's_levels', False):
+                # ROMS-type reader: the block arrives on s-levels and is regridded to the z levels on the device
+                # (reader_ROMS_native.py:617-684); the float32 result never visits the host
+                if getattr(self, 'sgrid', None) is None:
+                    from .device import SigmaGrid
+                    self.sgrid = SigmaGrid(self.ctx, r.h, r.hc, r.Cs_r, Vtransform=r.Vtransform)
+                arrays, nzv = {}, {}
+                for i, v in enumerate([v for v in self.variables if v in block['s_level_variables']]):
+                    arrays[v] = self.sgrid.zslice(block[v], bz, slot=i)
+                    nzv[v] = len(bz)
+                for v in self.variables:
+                    if v not in arrays:
+                        arrays[v] = block[v]
+                self.ctx.upload_block_device(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays, nzv)
+            else:
+                arrays = {v: block[v] for v in self.variables}
+                self.ctx.upload_block(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays)
             self.slots[k] = slot
