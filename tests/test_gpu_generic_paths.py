@@ -1,0 +1,126 @@
+"""The generic kernels (any mix of readers behind a priority list: k_env_group, k_advect, k_vmix, ordered
+compaction) and the single-gridded-reader fast paths (k_env_grid, k_step_grid / k_advect_grid, k_vmix_col,
+in-place compaction) must give the same bits: ODR_NO_FAST_PATH / ODR_ORDERED_COMPACT switch between them."""
+import os
+
+import numpy as np
+import pytest
+
+from scenarios import Scenario
+from opendrift_amd import synthetic as synth
+
+pytestmark = pytest.mark.gpu
+
+U, V = 'x_sea_water_velocity', 'y_sea_water_velocity'
+W, KZ = 'upward_sea_water_velocity', 'ocean_vertical_diffusivity'
+DEPTH, SSH, LAND = 'sea_floor_depth_below_sea_level', 'sea_surface_height', 'land_binary_mask'
+XW, YW = 'x_wind', 'y_wind'
+SX, SY = 'sea_surface_wave_stokes_drift_x_velocity', 'sea_surface_wave_stokes_drift_y_velocity'
+
+
+class generic:
+    def __enter__(self):
+        os.environ['ODR_NO_FAST_PATH'] = '1'
+
+    def __exit__(self, *a):
+        os.environ.pop('ODR_NO_FAST_PATH', None)
+
+
+def _eq(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+def _both(ctx, lon, lat, z, fn):
+    """Run fn(P) on two identical particle sets, once per path; returns the two downloads."""
+    out = []
+    for use_generic in (False, True):
+        P = ctx.particles(len(lon))
+        P.append(lon, lat, z=z)
+        if use_generic:
+            with generic():
+                extra = fn(P)
+        else:
+            extra = fn(P)
+        out.append((P.download(), extra))
+    return out
+
+
+def test_grid3d_sample_advect_mix_same_bits(ctx):
+    g = synth.grid3d(nx=96, ny=80, nz=8, nt=3, seed=5)
+    names = [U, V, W, KZ, DEPTH, LAND]
+    levels = [(float(g['t'][k]), {n: g[n][k] for n in names}) for k in range(3)]
+    Scenario([('grid', dict(x=g['x'], y=g['y'], z=g['z'], levels=levels))],
+             fallbacks={U: 0.0, V: 0.0, W: 0.0, KZ: 0.0, DEPTH: 10000.0, SSH: 0.0}).device(ctx)
+    rng = np.random.default_rng(1)
+    n = 40000
+    lon = rng.uniform(g['x'][0] - 0.03, g['x'][-1] + 0.03, n)
+    lat = rng.uniform(g['y'][0] - 0.03, g['y'][-1] + 0.03, n)
+    z = -rng.uniform(0, 100, n)
+    uni = rng.uniform(size=(10, n))
+
+    def fn(P):
+        env = {}
+        for k, (t, scheme) in enumerate([(0.0, 'runge-kutta4'), (1500.0, 'runge-kutta'), (3600.0, 'euler'), (4000.0, 'runge-kutta4')]):
+            env[k] = P.env_sample([U, V, W, KZ, DEPTH, SSH, LAND], t, download=True)
+            P.advect(scheme, t, 600.0)
+            P.vmix(t, 600.0, 60.0, uniforms=uni, fuse_vertical_advection=False)
+        return env
+
+    (a, ea), (b, eb) = _both(ctx, lon, lat, z, fn)
+    for q in ('lon', 'lat', 'z'):
+        assert _eq(a[q], b[q]), q
+    for k in ea:
+        for v in ea[k]:
+            assert _eq(ea[k][v], eb[k][v]), (k, v)
+
+
+def test_stere2d_sample_advect_same_bits(ctx):
+    from oracle import oracle as orc
+    g = synth.grid_stere(nx=120, ny=90, nt=3, seed=9)
+    names = [U, V, XW, YW, SX, SY, LAND]
+    levels = [(float(g['t'][k]), {n: g[n][k] for n in names}) for k in range(3)]
+    Scenario([('grid', dict(x=g['x'], y=g['y'], proj=synth.NORKYST_PROJ, levels=levels))],
+             fallbacks={U: 0.0, V: 0.0, XW: 0.0, YW: 0.0, SX: 0.0, SY: 0.0}).device(ctx)
+    rng = np.random.default_rng(2)
+    n = 30000
+    p = orc.make_proj(orc.PROJ_STERE_POLAR, a=6371000.0, es=(2 - 1 / 298.257223563) / 298.257223563,
+                      lat0=90.0, lon0=70.0, lat_ts=60.0)
+    lon, lat = orc.proj_inv(p, rng.uniform(g['x'][0] - 300, g['x'][-1] + 300, n), rng.uniform(g['y'][0] - 300, g['y'][-1] + 300, n))
+
+    def fn(P):
+        env = {}
+        for k, (t, scheme) in enumerate([(0.0, 'runge-kutta4'), (900.0, 'runge-kutta'), (3600.0, 'runge-kutta4')]):
+            env[k] = P.env_sample(names, t, download=True)
+            P.advect(scheme, t, 900.0)
+        return env
+
+    (a, ea), (b, eb) = _both(ctx, lon, lat, np.zeros(n), fn)
+    assert _eq(a['lon'], b['lon']) and _eq(a['lat'], b['lat'])
+    for k in ea:
+        for v in ea[k]:
+            assert _eq(ea[k][v], eb[k][v]), (k, v)
+
+
+def test_ordered_and_in_place_compaction_keep_the_same_elements(ctx):
+    rng = np.random.default_rng(3)
+    n = 60000
+    lon, lat = rng.uniform(0, 10, n), rng.uniform(60, 66, n)
+    kill = rng.uniform(size=n) < 0.2
+    res = []
+    for ordered in (False, True):
+        P = ctx.particles(n)
+        P.append(lon, lat)
+        P.env_upload(U, np.arange(n, dtype=np.float32))
+        P.deactivate(kill, 2)
+        if ordered:
+            os.environ['ODR_ORDERED_COMPACT'] = '1'
+        try:
+            P.compact()
+        finally:
+            os.environ.pop('ODR_ORDERED_COMPACT', None)
+        d, dead, u = P.download(), P.download_deactivated(), P.env_download(U)
+        o = np.argsort(d['ID'])
+        res.append((d['ID'][o], d['lon'][o], u[o], dead['ID'], dead['lon']))
+    for x, y in zip(*res):
+        assert _eq(x, y)
+    assert (res[1][0] == np.nonzero(~kill)[0]).all()
