@@ -567,7 +567,14 @@ struct __attribute__((aligned(4))) F2 { float x, y; };
 // load at a 32-bit byte offset from a wave-uniform base (scalar base + vector offset addressing)
 template <typename T>
 __device__ __forceinline__ T ld_off(const float *__restrict__ base, unsigned byte_off) {
+#ifdef ODR_ABLATE_LOADS   // what-if build: no field gathers (tools/ab_bench.sh)
+  T t;
+  float *f = (float *)&t;
+  for (unsigned k = 0; k < sizeof(T) / 4; ++k) f[k] = (float)(byte_off & 1023u) * 1e-4f + (float)k;
+  return t;
+#else
   return *(const T *)((const char *)base + byte_off);
+#endif
 }
 
 // (u,v) of an interleaved pair at one time level; `uv` = address of the pair in node record 0

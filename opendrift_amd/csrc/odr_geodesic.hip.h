@@ -37,6 +37,20 @@ static constexpr double kDegLo = 2.9486522708701687e-19;  // pi/180 - kDeg
 static constexpr double kRad2Deg = 180.0 / 3.14159265358979323846264338327950288;
 static constexpr double kTiny = 1.4916681462400413e-154;
 
+// a * b + k for a literal / constant-memory k.  (Tried: VOP3 v_fma_f64 with k as a scalar-register addend via
+// inline asm, which removes the two v_mov_b32 the compiler spends per 64-bit literal -- 12 % fewer vector
+// instructions, but 4 % SLOWER in an A/B run on the same box: the Horner chains are latency-bound at ~4 waves
+// per SIMD and the moves were filling their bubbles.  ODR_SGPR_FMA keeps the experiment buildable.)
+__device__ __forceinline__ double fma_k(double a, double b, double k) {
+#ifdef ODR_SGPR_FMA
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+  return d;
+#else
+  return fma(a, b, k);
+#endif
+}
+
 // float64 reciprocal / reciprocal square root from the hardware seeds (v_rcp_f64 / v_rsq_f64)
 // plus two Newton steps: ~8 instructions instead of the ~19 (divide) / ~31 (sqrt) of the IEEE
 // expansions.  Used only inside the geodesic / projection code, whose results are compared
@@ -66,9 +80,9 @@ __device__ __forceinline__ void sincos_q(double x, double &s, double &c) {
                C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
   double z = x * x;
-  double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-  s = x + (z * x) * (S1 + z * rs);
-  double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  double rs = fma_k(fma_k(fma_k(fma_k(z, S6, S5), z, S4), z, S3), z, S2);
+  s = x + (z * x) * fma_k(z, rs, S1);
+  double rc = z * fma_k(fma_k(fma_k(fma_k(fma_k(z, C6, C5), z, C4), z, C3), z, C2), z, C1);
   double hz = 0.5 * z;
   double w = 1.0 - hz;
   c = w + (((1.0 - w) - hz) + z * rc);
@@ -126,8 +140,8 @@ __device__ __forceinline__ void sincos_small(double x, double &s, double &c) {
 #pragma clang fp contract(fast)
   if (fabs(x) <= 0.015625) {
     double z = x * x;
-    s = fma(x * z, -1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040)), x);
-    c = 1 + z * (-0.5 + z * (1.0 / 24 + z * (-1.0 / 720)));
+    s = fma(x * z, fma_k(fma_k(z, -1.0 / 5040, 1.0 / 120), z, -1.0 / 6), x);
+    c = fma(z, fma_k(fma_k(z, -1.0 / 720, 1.0 / 24), z, -0.5), 1.0);
   } else if (fabs(x) <= 0.78539816339744830962) sincos_q(x, s, c);
   else sincos(x, &s, &c);
 }
@@ -135,8 +149,8 @@ __device__ __forceinline__ void sincos_small(double x, double &s, double &c) {
 __device__ __forceinline__ void sincos_tiny(double x, double &s, double &c) {
 #pragma clang fp contract(fast)
   double z = x * x;
-  s = fma(x * z, -1.0 / 6 + z * (1.0 / 120), x);
-  c = 1 + z * (-0.5 + z * (1.0 / 24));
+  s = fma(x * z, fma_k(z, 1.0 / 120, -1.0 / 6), x);
+  c = fma(z, fma_k(z, 1.0 / 24, -0.5), 1.0);
 }
 
 // atan2(y, x) for x > 0 and |y/x| <= 1/16 by the Gregory series (truncation < 1e-20)
@@ -144,9 +158,48 @@ __device__ __forceinline__ double atan_ratio(double y, double x) {
 #pragma clang fp contract(fast)
   if (x > 0 && fabs(y) <= 0.0625 * x) {
     double r = y * fast_rcp(x), r2 = r * r;
-    return r * (1 + r2 * (-1.0 / 3 + r2 * (1.0 / 5 + r2 * (-1.0 / 7 + r2 * (1.0 / 9 + r2 * (-1.0 / 11 + r2 * (1.0 / 13 + r2 * (-1.0 / 15))))))));
+    double g = fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(r2, -1.0 / 15, 1.0 / 13), r2, -1.0 / 11), r2, 1.0 / 9), r2, -1.0 / 7), r2, 1.0 / 5), r2, -1.0 / 3);
+    return fma(r * r2, g, r);
   }
   return atan2(y, x);
+}
+
+// atan2 for finite arguments that are not both zero, to < 1 ulp: r = min/max by a Newton reciprocal with one
+// exact-residual correction, atan(r) = r + r z q(z), z = r^2, q = degree-19 interpolant of (atan(r)/r - 1)/z
+// on [0, 1] (max relative error 1.6e-17), octant reconstruction.  The coefficients live in constant memory and
+// reach the FMAs as scalar operands: the library routine spends 46 of its 102 vector instructions on
+// materialising 64-bit literals.
+__constant__ double c_atanq[20] = {
+    -0.33333333333333330252, 0.19999999999997532204, -0.14285714285384131545, 0.11111111093490828096,
+    -0.090909085908919342252, 0.07692298971033216917, -0.066665646992891042112, 0.058815068777936560666,
+    -0.05257973334284110807, 0.047377495795277789723, -0.042603566326016521328, 0.037494868125352471116,
+    -0.03127718906699638479, 0.023696731580048622013, -0.015535152475414176125, 0.0083689311784501621357,
+    -0.00349588597391630952, 0.0010496035084968515073, -0.00019996189377901382062, 0.000018061954618612152202};
+__device__ __forceinline__ double atan2_fin(double y, double x) {
+#pragma clang fp contract(fast)
+  const double ay = fabs(y), ax = fabs(x);
+  const double mx = fmax(ay, ax), mn = fmin(ay, ax);
+  const double rr = fast_rcp(mx);
+  double r = mn * rr;
+  r = fma(fma(-mx, r, mn), rr, r);
+  const double z = r * r;
+#ifdef ODR_ATAN_HORNER
+  double q = c_atanq[19];
+#pragma unroll
+  for (int k = 18; k >= 0; --k) q = fma_k(q, z, c_atanq[k]);
+#else
+  // even / odd halves in w = z^2: two independent Horner chains of depth 9 instead of one of depth 19
+  // (the evaluation is latency-bound, not issue-bound)
+  const double w = z * z;
+  double qe = c_atanq[18], qo = c_atanq[19];
+#pragma unroll
+  for (int k = 16; k >= 0; k -= 2) { qe = fma_k(qe, w, c_atanq[k]); qo = fma_k(qo, w, c_atanq[k + 1]); }
+  double q = fma(qo, z, qe);
+#endif
+  double a = fma(r * z, q, r);
+  a = ay > ax ? 1.57079632679489661923 - a : a;
+  a = signbit(x) ? 3.14159265358979323846 - a : a;
+  return copysign(a, y);
 }
 
 // sum_{k=1..6} c[k] sin(2 k x), Clenshaw
@@ -204,6 +257,11 @@ __device__ __forceinline__ void geod_direct_sc(const GeodOrigin &o, double salp1
   // reference stay exact; the geodesic series are float64 and may fuse multiply-adds
 #pragma clang fp contract(fast)
   const GeodConst &g = c_geod;
+#ifdef ODR_ABLATE_GEOD   // what-if build: a flat-earth step instead of the geodesic (tools/ab_bench.sh)
+  lat2 = o.lat1 + s12 * calp1 * 8.98e-6;
+  lon2 = o.lon1n + s12 * salp1 * 8.98e-6 * o.cbet1;
+  return;
+#endif
   const double sbet1 = o.sbet1, cbet1 = o.cbet1;
 
   double salp0 = salp1 * cbet1;
@@ -217,16 +275,16 @@ __device__ __forceinline__ void geod_direct_sc(const GeodOrigin &o, double salp1
   // eps = k2 / (2 (1 + sqrt(1 + k2)) + k2) by its Maclaurin series: k2 <= e'^2 = 0.00674, the x^8
   // term is < 1e-19 (no square root, no reciprocal)
   double k2 = calp0 * calp0 * g.ep2;
-  double eps = k2 * (0.25 + k2 * (-0.125 + k2 * (5.0 / 64 + k2 * (-7.0 / 128 + k2 * (21.0 / 512 + k2 * (-33.0 / 1024 + k2 * (429.0 / 16384)))))));
+  double eps = k2 * fma_k(fma_k(fma_k(fma_k(fma_k(fma_k(k2, 429.0 / 16384, -33.0 / 1024), k2, 21.0 / 512), k2, -7.0 / 128), k2, 5.0 / 64), k2, -0.125), k2, 0.25);
   double e2 = eps * eps;
   // 1 / (1 + A1m1) = (1 - eps) / (1 + eps^2/4 + eps^4/64 + eps^6/256)
   //               = (1 - eps) (1 - eps^2/4 + 3 eps^4/64) + O(eps^6 = 2e-17)
-  double iA1 = (1 - eps) * (1 + e2 * (-0.25 + e2 * (3.0 / 64)));
+  double iA1 = (1 - eps) * fma(e2, fma_k(e2, 3.0 / 64, -0.25), 1.0);
   double d = eps;
-  double C11 = d * (e2 * (6 - e2) - 16) * (1.0 / 32);           d *= eps;
-  double C12 = d * (e2 * (64 - 9 * e2) - 128) * (1.0 / 2048);   d *= eps;
-  double C13 = d * (9 * e2 - 16) * (1.0 / 768);                 d *= eps;
-  double C14 = d * (3 * e2 - 5) * (1.0 / 512);                  d *= eps;
+  double C11 = d * fma_k(e2, 6 - e2, -16.0) * (1.0 / 32);                 d *= eps;
+  double C12 = d * fma_k(e2, fma_k(e2, -9.0, 64.0), -128.0) * (1.0 / 2048);  d *= eps;
+  double C13 = d * fma_k(e2, 9.0, -16.0) * (1.0 / 768);                   d *= eps;
+  double C14 = d * fma_k(e2, 3.0, -5.0) * (1.0 / 512);                    d *= eps;
   double C15 = d * (-7.0 / 1280);                               d *= eps;
   double C16 = d * (-7.0 / 2048);
   double B11 = sin_series6(ssig1, csig1, C11, C12, C13, C14, C15, C16);
@@ -235,21 +293,21 @@ __device__ __forceinline__ void geod_direct_sc(const GeodOrigin &o, double salp1
   double stau1 = ssig1 * cB + csig1 * sB;
   double ctau1 = csig1 * cB - ssig1 * sB;
   d = eps;
-  double P1 = d * (e2 * (205 * e2 - 432) + 768) * (1.0 / 1536);       d *= eps;
-  double P2 = d * (e2 * (4005 * e2 - 4736) + 3840) * (1.0 / 12288);   d *= eps;
-  double P3 = d * (116 - 225 * e2) * (1.0 / 384);                     d *= eps;
-  double P4 = d * (2695 - 7173 * e2) * (1.0 / 7680);                  d *= eps;
+  double P1 = d * fma_k(e2, fma_k(e2, 205.0, -432.0), 768.0) * (1.0 / 1536);     d *= eps;
+  double P2 = d * fma_k(e2, fma_k(e2, 4005.0, -4736.0), 3840.0) * (1.0 / 12288); d *= eps;
+  double P3 = d * fma_k(e2, -225.0, 116.0) * (1.0 / 384);                        d *= eps;
+  double P4 = d * fma_k(e2, -7173.0, 2695.0) * (1.0 / 7680);                     d *= eps;
   double P5 = d * (3467.0 / 7680);                                    d *= eps;
   double P6 = d * (38081.0 / 61440);
   const double *x3 = g.C3x;
   double m = eps;
-  double C31 = m * ((((x3[0] * eps + x3[1]) * eps + x3[2]) * eps + x3[3]) * eps + x3[4]);  m *= eps;
-  double C32 = m * (((x3[5] * eps + x3[6]) * eps + x3[7]) * eps + x3[8]);                  m *= eps;
-  double C33 = m * ((x3[9] * eps + x3[10]) * eps + x3[11]);                                m *= eps;
-  double C34 = m * (x3[12] * eps + x3[13]);                                                m *= eps;
+  double C31 = m * fma_k(fma_k(fma_k(fma_k(eps, x3[0], x3[1]), eps, x3[2]), eps, x3[3]), eps, x3[4]);  m *= eps;
+  double C32 = m * fma_k(fma_k(fma_k(eps, x3[5], x3[6]), eps, x3[7]), eps, x3[8]);                     m *= eps;
+  double C33 = m * fma_k(fma_k(eps, x3[9], x3[10]), eps, x3[11]);                                      m *= eps;
+  double C34 = m * fma_k(eps, x3[12], x3[13]);                                                         m *= eps;
   double C35 = m * x3[14];
   const double *a3 = g.A3x;
-  double A3 = ((((a3[0] * eps + a3[1]) * eps + a3[2]) * eps + a3[3]) * eps + a3[4]) * eps + a3[5];
+  double A3 = fma_k(fma_k(fma_k(fma_k(fma_k(eps, a3[0], a3[1]), eps, a3[2]), eps, a3[3]), eps, a3[4]), eps, a3[5]);
   double A3c = -g.f * salp0 * A3;
   double B31 = sin_series5(ssig1, csig1, C31, C32, C33, C34, C35);
 

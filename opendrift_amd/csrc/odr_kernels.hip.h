@@ -13,7 +13,24 @@
 
 namespace odr {
 
-constexpr int BLOCK = 256;
+#ifndef ODR_BLOCK
+#define ODR_BLOCK 256
+#endif
+constexpr int BLOCK = ODR_BLOCK;  // threads per workgroup (A/B builds may override)
+
+// XCD-aware block order.  Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2), so with
+// the natural order the eight L2s all stream the whole (spatially sorted) particle range and every field tile is
+// fetched by all of them.  pid() gives XCD x the x-th contiguous eighth of the range instead: the particles of one
+// region -- and the field records they gather -- stay in one L2.
+__device__ __forceinline__ long long pid() {
+#ifdef ODR_NO_XCD_REMAP
+  return (long long)blockIdx.x * BLOCK + threadIdx.x;
+#else
+  const unsigned nb = gridDim.x, b = blockIdx.x, per = nb >> 3, rem = nb & 7u, x = b & 7u, j = b >> 3;
+  const unsigned lb = x * per + (x < rem ? x : rem) + j;
+  return (long long)lb * BLOCK + threadIdx.x;
+#endif
+}
 
 struct PView {  // device pointers of the active set
   long long n;
@@ -45,15 +62,19 @@ __device__ __forceinline__ float speed_f32(float xv, float yv) {
 __device__ __forceinline__ void azimuth_sincos_f32(float xv, float yv, double &salp, double &calp) {
 #pragma clang fp contract(fast)
   const double x = (double)xv, y = (double)yv;
-  const double theta = atan2(x, y);
-  const float azf = __fmul_rn((float)theta, 180.0f / 3.14159274101257324f);  // == azimuth_f32(xv, yv)
-  const double az = (double)azf;
   const double h2 = x * x + y * y;
-  if (!(h2 > 0)) {  // calm: the azimuth is 0 or 180 exactly (or NaN)
-    salp = (theta != theta) ? theta : 0.0;
-    calp = (theta != theta) ? theta : (az == 0.0 ? 1.0 : -1.0);
+  if (!(h2 > 0) || h2 > 1.7e308) {  // calm (azimuth 0 or 180 exactly), NaN or infinite velocities: library semantics
+    const double th = atan2(x, y);
+    const double azd = (double)__fmul_rn((float)th, 180.0f / 3.14159274101257324f);
+    if (th != th) { salp = calp = th; return; }
+    if (h2 > 0) { sincosd(azd, salp, calp); return; }
+    salp = 0.0;
+    calp = azd == 0.0 ? 1.0 : -1.0;
     return;
   }
+  const double theta = atan2_fin(x, y);
+  const float azf = __fmul_rn((float)theta, 180.0f / 3.14159274101257324f);  // == azimuth_f32(xv, yv)
+  const double az = (double)azf;
   const double delta = fma(az, kDeg, -theta) + az * kDegLo;
   const double rh = fast_rsqrt(h2);
   const double st = x * rh, ct = y * rh, c2 = 1 - 0.5 * delta * delta;
@@ -120,7 +141,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_group(const DevWorld *__restrict_
 template <int PROJ>
 __global__ __launch_bounds__(BLOCK) void k_env_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
                                                     int record_prev) {
-  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  long long i = pid();
   if (i >= p.n) return;
   double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
   float out[MAXG];
@@ -237,7 +258,7 @@ template <int SCHEME, int PROJ, bool IS3D>
 __global__ __launch_bounds__(BLOCK) void k_advect_grid(const DevWorld *__restrict__ W, int sid, int geo_slot,
                                                        PView p, double dt, float factor, UVTime th,
                                                        UVTime tf) {
-  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  long long i = pid();
   if (i >= p.n) return;
   const DevSource &s = W->src[sid];
   const DevBlock &geo = s.slot[geo_slot];
@@ -265,7 +286,7 @@ template <int SCHEME, int PROJ, bool IS3D>
 __global__ __launch_bounds__(BLOCK) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
                                                      StepDesc S, double dt, float factor, UVTime th, UVTime tf,
                                                      unsigned long long *n_hit) {
-  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  long long i = pid();
   bool hit = false;
   if (i < p.n) {
     double lon = p.lon[i], lat = p.lat[i];
@@ -762,7 +783,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__
                                                     int vadv) {
   constexpr int NL = 4 * NQ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  long long i = pid();
   const int tid = threadIdx.x;
   const DevSource &s = W->src[D.sid];
   const int nzp = D.nzp;

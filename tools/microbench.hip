@@ -24,6 +24,23 @@ __global__ void mb_azimuth_sincos(const float *uv, double *out) {
   azimuth_sincos_f32(uv[i], uv[i + N], s, c);
   out[i] = s + c;
 }
+__global__ void mb_atan2_lib(const float *uv, double *out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  out[i] = atan2((double)uv[i], (double)uv[i + N]);
+}
+__global__ void mb_atan2_fin(const float *uv, double *out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  out[i] = atan2_fin((double)uv[i], (double)uv[i + N]);
+}
+// accuracy of atan2_fin against the library: out[0] = max |diff| in ulps, out[1] = count of different float32 roundings
+__global__ void mb_atan2_check(const float *uv, unsigned long long *res) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double a = atan2_fin((double)uv[i], (double)uv[i + N]), b = atan2((double)uv[i], (double)uv[i + N]);
+  double ulp = fabs(b) * 2.220446049250313e-16;
+  unsigned long long d = (unsigned long long)(fabs(a - b) / ulp * 16.0);   // 1/16 ulp units
+  atomicMax(&res[0], d);
+  if ((float)a != (float)b) atomicAdd(&res[1], 1ull);
+}
 __global__ void mb_speed(const float *uv, double *out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   out[i] = speed_f32(uv[i], uv[i + N]);
@@ -162,6 +179,8 @@ int main() {
     hipLaunchKernelGGL(mb_origin, g, b, 0, 0, din, dout);
     hipLaunchKernelGGL(mb_azimuth_sincos, g, b, 0, 0, duv, dout);
     hipLaunchKernelGGL(mb_speed, g, b, 0, 0, duv, dout);
+    hipLaunchKernelGGL(mb_atan2_lib, g, b, 0, 0, duv, dout);
+    hipLaunchKernelGGL(mb_atan2_fin, g, b, 0, 0, duv, dout);
     hipLaunchKernelGGL(mb_direct_sc, g, b, 0, 0, din, duv, dout);
     hipLaunchKernelGGL(mb_zbracket, g, b, 0, 0, c->dw, din, dout);
     hipLaunchKernelGGL(mb_uv3d, g, b, 0, 0, c->dw, t0, din, dout);
@@ -170,6 +189,13 @@ int main() {
     hipLaunchKernelGGL(mb_projfwd_polar, g, b, 0, 0, c->dw, din, dout);
     hipLaunchKernelGGL(mb_rotcs_polar, g, b, 0, 0, c->dw, din, dout);
     hipLaunchKernelGGL(mb_philox2, g, b, 0, 0, dout, 5ull);
+  }
+  {
+    unsigned long long *dres, hres[2] = {0, 0};
+    hipMalloc(&dres, 16); hipMemcpy(dres, hres, 16, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(mb_atan2_check, g, b, 0, 0, duv, dres);
+    hipMemcpy(hres, dres, 16, hipMemcpyDeviceToHost);
+    printf("atan2_fin vs library over %d random float32 pairs: max diff %.3f ulp, %llu different float32 roundings\n", N, hres[0] / 16.0, hres[1]);
   }
   hipDeviceSynchronize();
   std::vector<double> o(N);
