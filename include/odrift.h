@@ -214,6 +214,10 @@ int odr_seafloor(odr_ctx *ctx, odr_particles *p, int64_t *n_below);
 int odr_deactivate(odr_ctx *ctx, odr_particles *p, const uint8_t *mask_host, int32_t status_code);
 /* remove_deactivated_elements (:1797-1826) = LagrangianArray.move_elements (elements.py:197-228):
  * stable compaction of status==0 elements, the rest appended to the deactivated store */
+/* deactivate_outside (basemodel/__init__.py:2354-2382): drift:deactivate_west_of/east_of/south_of/north_of;
+ * a NaN bound is "not set" */
+int odr_deactivate_outside(odr_ctx *ctx, odr_particles *p, double west, double east, double south, double north,
+                           int32_t status_code);
 int odr_compact(odr_ctx *ctx, odr_particles *p, int64_t *n_active);
 /* Device-side layout operation with no reference counterpart: re-order the particle arrays by
  * the grid cell of gridded source `source_id` so that the lanes of a wavefront gather

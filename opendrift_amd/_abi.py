@@ -92,6 +92,7 @@ _SIGNATURES = {
     'odr_source_time_coverage': [_vp, C.c_int32, C.c_double, C.c_double, C.c_int],
     'odr_seafloor': [_vp, _vp, _i64p],
     'odr_deactivate': [_vp, _vp, _P(C.c_uint8), C.c_int32],
+    'odr_deactivate_outside': [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32],
     'odr_compact': [_vp, _vp, _i64p],
     'odr_sort_particles': [_vp, _vp, C.c_int32],
     'odr_reduce_scalars': [_vp, _vp, C.c_double, _dp],

@@ -1071,6 +1071,22 @@ __global__ __launch_bounds__(BLOCK) void k_cmp_scatter(const int *status, long l
   }
 }
 
+// deactivate_outside (basemodel/__init__.py:2354-2382): elements beyond the user's validity domain
+// (drift:deactivate_west_of / east_of / south_of / north_of) get the status 'outside'
+__global__ __launch_bounds__(BLOCK) void k_deactivate_outside(PView p, double W, double E, double S, double N,
+                                                              int useW, int useE, int useS, int useN, int wrap360,
+                                                              int code) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  double lon = p.lon[i], lat = p.lat[i];
+  if (wrap360 && lon < 0) lon += 360.0;  // E given in the 0-360 convention and elements wrapped to -180..180 (:2359-2370)
+  bool out = (useW && lon < W) || (useE && lon > E) || (useS && lat < S) || (useN && lat > N);
+  if (out) {
+    if (p.status[i] == 0) p.status[i] = code;
+    p.moving[i] = 0;
+  }
+}
+
 // In-place compaction (the default): the deactivated elements are copied to the deactivated store
 // and the holes they leave among the first `kept` slots are filled with the active elements of the
 // tail -- O(#removed) data movement instead of rewriting every array.  Deterministic pairing: the

@@ -1292,6 +1292,19 @@ int odr_deactivate(odr_ctx *c, odr_particles *p, const uint8_t *mask, int32_t co
   return 0;
 }
 
+// deactivate_outside (basemodel/__init__.py:2354-2382); NaN bound = not set
+int odr_deactivate_outside(odr_ctx *c, odr_particles *p, double west, double east, double south, double north,
+                           int32_t code) {
+  p->epoch++;
+  if (p->n == 0) return 0;
+  const int uW = west == west, uE = east == east, uS = south == south, uN = north == north;
+  if (!(uW || uE || uS || uN)) return 0;
+  hipLaunchKernelGGL(k_deactivate_outside, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), west, east, south, north,
+                     uW, uE, uS, uN, (uE && east > 180.0) ? 1 : 0, code);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static int ensure_alt(odr_particles *p) {
   size_t cap = (size_t)p->cap;
   // lazily allocate the ping-pong set and the deactivated store

@@ -384,6 +384,10 @@ class Particles:
         m = np.ascontiguousarray(mask, dtype=np.uint8)
         check(self.lib.odr_deactivate(self.ctx.h, self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)), status_code))
 
+    def deactivate_outside(self, west, east, south, north, status_code):
+        f = lambda v: np.nan if v is None else float(v)
+        check(self.lib.odr_deactivate_outside(self.ctx.h, self.h, f(west), f(east), f(south), f(north), int(status_code)))
+
     def compact(self):
         """Remove the deactivated elements (remove_deactivated_elements).  In place: the survivors are
         permuted (holes filled from the tail); elements are identified by their ID."""

@@ -72,6 +72,14 @@ class OpenDriftSimulation(Configurable):
                             'level': CONFIG_LEVEL_ESSENTIAL, 'description': ''},
             'drift:max_age_seconds': {'type': 'float', 'default': None, 'min': 0, 'max': 1e12,
                                       'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'drift:deactivate_north_of': {'type': 'float', 'default': None, 'min': -90, 'max': 90,
+                                          'level': CONFIG_LEVEL_ADVANCED, 'description': ''},   # :477-516
+            'drift:deactivate_south_of': {'type': 'float', 'default': None, 'min': -90, 'max': 90,
+                                          'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'drift:deactivate_east_of': {'type': 'float', 'default': None, 'min': -360, 'max': 360,
+                                         'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'drift:deactivate_west_of': {'type': 'float', 'default': None, 'min': -360, 'max': 360,
+                                         'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
             'drift:advection_scheme': {'type': 'enum', 'enum': ['euler', 'runge-kutta', 'runge-kutta4'],
                                        'default': 'euler', 'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
             'drift:current_uncertainty': {'type': 'float', 'default': 0, 'min': 0, 'max': 5,
@@ -288,6 +296,11 @@ class OpenDriftSimulation(Configurable):
             self.P.set_property(slot, s[name][idx], offset=n_before)
         rel[idx] = True
 
+    def deactivate_outside(self):   # :2354-2382, validity domain of :2169-2179
+        dom = [self.get_config('drift:deactivate_%s_of' % k) for k in ('west', 'east', 'south', 'north')]
+        if dom != [None, None, None, None]:
+            self.P.deactivate_outside(*dom, status_code=self._status_code('outside'))
+
     def deactivate_elements(self, mask, reason='deactivated'):   # :1774-1795
         if reason not in self.status_categories:
             self.status_categories.append(reason)
@@ -434,12 +447,14 @@ class OpenDriftSimulation(Configurable):
                     self.P.sort_by_cell(grid_sid)     # device layout maintenance, before release
                 self.release_elements()
                 if self.num_elements_active() == 0 and self.num_elements_scheduled() > 0:
+                    self._state_to_buffer(i, out_every, times)   # (:2208)
                     self.steps_calculation += 1
                     self.time = self.time + self.time_step
                     continue
                 for b in self.readers.values():
                     b.ensure_levels(self.time, self.time + self.time_step)
                 self.get_environment()
+                self.deactivate_outside()
                 self.interact_with_coastline()
                 self.interact_with_seafloor()
                 self._state_to_buffer(i, out_every, times)

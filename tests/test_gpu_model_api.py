@@ -214,3 +214,51 @@ def test_c5_leeway_model_run_numpy_rng():
     o.run(time_step=600, steps=8)
     lon, lat, _ = _final(o, g['lon'].shape[1])
     assert np.abs(lon - g['lon'][-1]).max() < 1e-7 and np.abs(lat - g['lat'][-1]).max() < 1e-7
+
+
+# ---- known answers of the reference's own tests (tests/models/test_run.py), no files needed ----
+def test_reference_kat_retirement():
+    """tests/models/test_run.py:759-770"""
+    o = OceanDrift(loglevel=50)
+    o.set_config('drift:max_age_seconds', 5000)
+    o.set_config('environment:fallback:x_sea_water_velocity', .5)
+    o.set_config('environment:fallback:y_sea_water_velocity', .3)
+    o.set_config('environment:fallback:land_binary_mask', 0)
+    now = datetime(2024, 5, 17, 12, 0, 0)
+    o.seed_elements(lon=0, lat=60, number=10, time=[now, now + timedelta(seconds=6000)])
+    o.run(time_step=1000, duration=timedelta(seconds=7000))
+    assert o.num_elements_deactivated() == 5
+
+
+def test_reference_kat_outside_domain():
+    """tests/models/test_run.py:772-790: 768 of 1000 elements leave the validity domain in 5 hours"""
+    o = OceanDrift(loglevel=50)
+    now = datetime(2024, 5, 17, 12, 0, 0)
+    o.add_reader([readers.OscillatingReader('x_sea_water_velocity', amplitude=1, zero_time=now),
+                  readers.OscillatingReader('y_sea_water_velocity', amplitude=1, zero_time=now)])
+    o.set_config('drift:deactivate_east_of', 2.1)
+    o.set_config('drift:deactivate_west_of', 1.9)
+    o.set_config('drift:deactivate_south_of', 59.9)
+    o.set_config('drift:deactivate_north_of', 60.1)
+    o.set_config('environment:fallback:land_binary_mask', 0)
+    o.seed_elements(lon=2, lat=60, number=1000, time=now, radius=10000)
+    o.run(duration=timedelta(hours=5))
+    assert o.num_elements_deactivated() == 768
+    assert o.num_elements_active() == 232
+    assert 'outside' in o.status_categories
+
+
+def test_reference_kat_seed_time_backwards_run():
+    """tests/models/test_run.py:792-804"""
+    o = OceanDrift(loglevel=50)
+    o.set_config('drift:max_age_seconds', 2000)
+    o.set_config('environment:fallback:x_sea_water_velocity', .5)
+    o.set_config('environment:fallback:y_sea_water_velocity', .3)
+    o.set_config('environment:fallback:land_binary_mask', 0)
+    time = [datetime(2018, 1, 1, i) for i in range(10)]
+    o.seed_elements(lon=0, lat=60, time=time)
+    o.seed_elements(lon=1, lat=60, time=datetime(2018, 1, 1, 7))
+    o.run(end_time=datetime(2018, 1, 1, 2), time_step=-1800)
+    assert o.num_elements_scheduled() == 3
+    assert o.num_elements_active() == 8
+    assert o.steps_calculation == 14
