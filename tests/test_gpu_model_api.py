@@ -262,3 +262,33 @@ def test_reference_kat_seed_time_backwards_run():
     assert o.num_elements_scheduled() == 3
     assert o.num_elements_active() == 8
     assert o.steps_calculation == 14
+
+
+def test_reference_kat_wind_and_current_drift_factor():
+    """tests/models/test_models.py:44-64"""
+    lat, lon = 60, 4
+    res = []
+    for wdf, cdf in ((0, 1), (0.02, .3)):
+        o = OceanDrift(loglevel=50)
+        o.set_config('general:use_auto_landmask', False)
+        o.set_config('environment:constant:land_binary_mask', 0)
+        o.set_config('environment:constant:x_wind', 5)
+        o.set_config('environment:constant:y_sea_water_velocity', 1)
+        o.seed_elements(lon=lon, lat=lat, time=datetime(2024, 5, 17), wind_drift_factor=wdf, current_drift_factor=cdf)
+        o.run(duration=timedelta(hours=2))
+        res.append((o.elements.lon[0], o.elements.lat[0]))
+    assert abs(res[0][1] - (lat + 0.0646)) < 5e-4 and abs(res[0][0] - lon) < 5e-8
+    assert abs(res[1][1] - (lat + 0.0646 * .3)) < 5e-4 and abs(res[1][0] - (lon + 0.0129)) < 5e-4
+
+
+def test_reference_kat_previous():
+    """tests/models/test_environment.py:30-51 (the parts about positions)"""
+    for action in ('none', 'previous'):
+        o = OceanDrift(loglevel=50)
+        o.set_config('general:coastline_action', action)
+        o.set_config('drift:vertical_advection', False)
+        o.set_config('environment:constant:land_binary_mask', 0)
+        o.set_config('environment:constant:x_sea_water_velocity', 1)
+        o.seed_elements(lon=3, lat=60, time=datetime(2024, 5, 17))
+        o.run(steps=1)
+        assert o.elements.lon[0] == pytest.approx(3.0645, .001)
