@@ -253,6 +253,10 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--host-sort', action='store_true', help='experiment: seed particles already sorted by grid cell')
     ap.add_argument('--cpu-particles', type=int, default=200000)
+    ap.add_argument('--block-every', type=int, default=0,
+                    help='re-upload one field time level from host memory every N steps inside the timed region '
+                         '(PCIe-inclusive rate, DESIGN.md section 5; 0 = inputs resident, the headline)')
+    ap.add_argument('--block-async', action='store_true', help='with --block-every: odr_block_upload_async from pinned arrays')
     a = ap.parse_args()
 
     import torch
@@ -289,14 +293,35 @@ def main():
                                     np.full(n, 0.04), ori, np.zeros(n)]):
             P.set_property(slot, val.astype(np.float32))
 
+    pinned = None
+    if a.block_every and a.block_async and a.workload != 'c2':
+        pinned = {kk: ctx.pin(np.ascontiguousarray(fields['g'][kk])) for kk in fields['names']}
     for k in range(a.warmup):
         wl.step(P, k)
+    if a.block_every and a.workload != 'c2':   # untimed: scratch pools and recyclable blocks of the upload pipeline exist
+        g = fields['g']
+        for rep in range(2):
+            for slot in range(3):
+                arrs = {kk: (pinned[kk][slot] if pinned else g[kk][slot]) for kk in fields['names']}
+                ctx.upload_block_async(wl.sid, slot, float(g['t'][slot]), arrs)
+                ctx.commit_block(wl.sid, slot)
+                wl.step(P, a.warmup)
     ctx.sync()
     torch.cuda.synchronize()
     D.barrier()
     n0 = len(P)
     t0 = time.perf_counter()
     for k in range(a.steps):
+        if a.block_every and a.workload != 'c2':   # a new reader time level arrives every block_every steps
+            g = fields['g']
+            j = k // a.block_every
+            if a.block_async:     # staged one period ahead on the upload stream from pinned arrays, committed when due
+                if k % a.block_every == 0:
+                    if j > 0:
+                        ctx.commit_block(wl.sid, (j - 1) % 3)
+                    ctx.upload_block_async(wl.sid, j % 3, float(g['t'][j % 3]), {kk: pinned[kk][j % 3] for kk in fields['names']})
+            elif k % a.block_every == 0:
+                ctx.upload_block(wl.sid, j % 3, float(g['t'][j % 3]), {kk: g[kk][j % 3] for kk in fields['names']})
         wl.step(P, a.warmup + k)
     ctx.sync()
     torch.cuda.synchronize()

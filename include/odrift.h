@@ -130,6 +130,18 @@ int odr_block_upload(odr_ctx *ctx, int32_t source_id, int32_t slot, double t_epo
 int odr_block_upload_device(odr_ctx *ctx, int32_t source_id, int32_t slot, double t_epoch,
                             int nvars, const int32_t *var_ids, const void *const *dev_data,
                             const int32_t *var_nz, int ny, int nx, const double *xy8);
+/* Asynchronous upload: odr_block_upload_async only ENQUEUES the copy and the preparation kernels on the context's
+ * upload stream and returns; the simulation continues on the compute stream.  The staged block becomes the content
+ * of its slot with odr_block_commit (the compute stream then waits for the upload's event; the block it replaces
+ * is released once the compute stream has passed).  data[k] must stay valid until the commit and should be
+ * page-locked (odr_host_register) or device memory, otherwise the copies are staged synchronously by the runtime.
+ * odr_block_upload = upload_async + wait + commit. */
+int odr_block_upload_async(odr_ctx *ctx, int32_t source_id, int32_t slot, double t_epoch, int nvars,
+                           const int32_t *var_ids, const void *const *data, const int32_t *var_nz,
+                           int ny, int nx, const double *xy8);
+int odr_block_commit(odr_ctx *ctx, int32_t source_id, int32_t slot);
+int odr_host_register(odr_ctx *ctx, void *ptr, uint64_t bytes);   /* hipHostRegister: reader arrays that are uploaded repeatedly */
+int odr_host_unregister(odr_ctx *ctx, void *ptr);
 int odr_block_drop(odr_ctx *ctx, int32_t source_id, int32_t slot);
 /* reader.start_time / end_time / always_valid (covers_time, variables.py:392-400): outside the
  * interval the reader is skipped and the next reader / the fallback applies */

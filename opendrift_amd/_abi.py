@@ -66,6 +66,10 @@ _SIGNATURES = {
                          C.c_int, _dp],
     'odr_block_upload_device': [_vp, C.c_int32, C.c_int32, C.c_double, C.c_int, _ip, _P(_vp), _ip,
                                 C.c_int, C.c_int, _dp],
+    'odr_block_upload_async': [_vp, C.c_int32, C.c_int32, C.c_double, C.c_int, _ip, _P(_vp), _ip, C.c_int, C.c_int, _dp],
+    'odr_block_commit': [_vp, C.c_int32, C.c_int32],
+    'odr_host_register': [_vp, _vp, C.c_uint64],
+    'odr_host_unregister': [_vp, _vp],
     'odr_block_drop': [_vp, C.c_int32, C.c_int32],
     'odr_env_bind': [_vp, C.c_int32, C.c_int, _ip, C.c_float],
     'odr_env_sample': [_vp, _vp, C.c_int, _ip, C.c_double, _P(_fp)],

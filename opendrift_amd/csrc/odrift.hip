@@ -35,6 +35,9 @@ static int fail(int code, const char *fmt, ...) {
   } while (0)
 #define REQUIRE(c, ...) do { if (!(c)) return fail(ODR_ERR_INVALID, __VA_ARGS__); } while (0)
 
+struct Staged { DevBlock blk; float *base; size_t bytes; };       // uploaded, not yet committed
+struct Retired { void *ptr; size_t bytes; hipEvent_t ev; };       // replaced block, freed once the compute stream passed
+
 struct odr_ctx {
   int device;
   unsigned long long seed;
@@ -43,6 +46,15 @@ struct odr_ctx {
   DevWorld *dw;     // device image
   bool dirty;
   std::vector<void *> block_bufs[MAXSRC][MAXLEVELS];  // owned device arrays per slot
+  size_t block_bytes[MAXSRC][MAXLEVELS];
+  // upload pipeline (stage_block / odr_block_commit)
+  hipStream_t up_stream;
+  hipEvent_t up_done, up_dep;
+  float *prep[2];
+  size_t prep_floats;
+  Staged staged[MAXSRC][MAXLEVELS];
+  std::vector<Retired> graveyard;
+  std::vector<void *> registered;   // host ranges page-locked by odr_host_register (released with the context)
   double *red;      // device reduction slots
   unsigned long long *counter;
   hipEvent_t ev0, ev1;
@@ -164,6 +176,9 @@ int odr_ctx_create(int device, uint64_t seed, odr_ctx **out) {
   HIPCHK(hipMalloc((void **)&c->counter, sizeof(unsigned long long) * 4));
   HIPCHK(hipEventCreate(&c->ev0));
   HIPCHK(hipEventCreate(&c->ev1));
+  HIPCHK(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&c->up_done, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->up_dep, hipEventDisableTiming));
   c->dirty = true;
   c->nsrc = 0;
   c->fuse_vadv = -1;
@@ -178,9 +193,19 @@ int odr_ctx_destroy(odr_ctx *c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->up_stream);
   for (int s = 0; s < MAXSRC; ++s)
-    for (int l = 0; l < MAXLEVELS; ++l)
+    for (int l = 0; l < MAXLEVELS; ++l) {
       for (void *b : c->block_bufs[s][l]) (void)hipFree(b);
+      if (c->staged[s][l].base) (void)hipFree(c->staged[s][l].base);
+    }
+  for (Retired &r : c->graveyard) { (void)hipFree(r.ptr); (void)hipEventDestroy(r.ev); }
+  for (void *q : c->registered) if (hipHostUnregister(q) != hipSuccess) (void)hipGetLastError();
+  if (c->prep[0]) (void)hipFree(c->prep[0]);
+  if (c->prep[1]) (void)hipFree(c->prep[1]);
+  (void)hipStreamDestroy(c->up_stream);
+  (void)hipEventDestroy(c->up_done);
+  (void)hipEventDestroy(c->up_dep);
   (void)hipFree(c->dw);
   (void)hipFree(c->red);
   (void)hipFree(c->counter);
@@ -494,57 +519,64 @@ static void sort_levels(DevSource &s) {
     }
 }
 
-static int block_upload(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, int nvars, const int32_t *var_ids,
-                        const void *const *data, bool on_device, const int32_t *var_nz, int ny, int nx,
-                        const double *xy8) {
+// ---- field block upload: a stream-ordered pipeline on the context's UPLOAD stream ----
+// copy (DMA when the source is pinned / registered or device memory) -> mask -> fill towards the seafloor ->
+// 10 NaN dilation sweeps -> transposition into node records, one variable after the other through two pooled
+// scratch buffers.  odr_block_upload_async only enqueues (it returns while the copy engine and the kernels
+// are still working, overlapping with the simulation on the compute stream); the staged block becomes the
+// content of its slot with odr_block_commit, where the compute stream waits for the upload's event.  The
+// block it replaces is freed (or recycled) once the compute stream has passed the commit.
+static void reap(odr_ctx *c, size_t want_bytes, float **reuse) {
+  for (size_t k = 0; k < c->graveyard.size();) {
+    Retired &r = c->graveyard[k];
+    if (hipEventQuery(r.ev) == hipSuccess) {
+      if (reuse && !*reuse && r.bytes == want_bytes) *reuse = (float *)r.ptr;
+      else (void)hipFree(r.ptr);
+      (void)hipEventDestroy(r.ev);
+      c->graveyard.erase(c->graveyard.begin() + (long)k);
+    } else ++k;
+  }
+}
+
+static int retire(odr_ctx *c, void *ptr, size_t bytes) {
+  Retired r;
+  r.ptr = ptr; r.bytes = bytes;
+  HIPCHK(hipEventCreateWithFlags(&r.ev, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(r.ev, c->stream));   // the compute stream may still read it up to here
+  c->graveyard.push_back(r);
+  return 0;
+}
+
+static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, int nvars, const int32_t *var_ids,
+                       const void *const *data, const int32_t *var_nz, int ny, int nx, const double *xy8) {
   REQUIRE(sid >= 0 && sid < c->nsrc && c->hw.src[sid].kind == SRC_GRID, "source %d is not a grid source", sid);
   REQUIRE(slot >= 0 && slot < MAXLEVELS, "slot must be in [0,%d)", MAXLEVELS);
   REQUIRE(nvars > 0 && var_ids && data && var_nz && xy8 && ny > 1 && nx > 1, "bad block arguments");
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  DevSource &s = c->hw.src[sid];
-  for (void *b : c->block_bufs[sid][slot]) HIPCHK(hipFree(b));
-  c->block_bufs[sid][slot].clear();
-  DevBlock &b = s.slot[slot];
+  const DevSource &s = c->hw.src[sid];
+  Staged &S = c->staged[sid][slot];
+  if (S.base) {  // an earlier staging of this slot that was never committed
+    HIPCHK(hipStreamSynchronize(c->up_stream));
+    HIPCHK(hipFree(S.base));
+    S.base = nullptr;
+  }
+  DevBlock &b = S.blk;
   memset(&b, 0, sizeof b);
   b.ny = ny; b.nx = nx; b.valid = 1;
   b.x0 = xy8[0]; b.xspan = xy8[1]; b.y0 = xy8[2]; b.yspan = xy8[3];
   b.xmin = xy8[4]; b.xrange = xy8[5]; b.ymin = xy8[6]; b.yrange = xy8[7];
   b.ixspan = 1.0 / b.xspan; b.iyspan = 1.0 / b.yspan; b.ixrange = 1.0 / b.xrange; b.iyrange = 1.0 / b.yrange;
   b.t = t_epoch;
-  size_t plane = (size_t)ny * nx;
-  std::vector<float *> prep((size_t)nvars, nullptr);
+  const size_t plane = (size_t)ny * nx;
+  size_t nmax = 0;
   for (int k = 0; k < nvars; ++k) {
     int v = var_ids[k], nzv = var_nz[k] > 1 ? var_nz[k] : 1;
     REQUIRE(v >= 0 && v < NVAR, "bad variable id %d", v);
     REQUIRE(nzv == 1 || nzv == s.nz, "variable %d has %d levels, source has %d", v, nzv, s.nz);
-    size_t n = plane * nzv;
-    float *buf, *tmp;
-    HIPCHK(hipMalloc((void **)&buf, sizeof(float) * n));
-    HIPCHK(hipMalloc((void **)&tmp, sizeof(float) * n));
-    (void)on_device;  // unified addressing: every data[k] may be a host or a device pointer
-    HIPCHK(hipMemcpyAsync(buf, data[k], sizeof(float) * n, hipMemcpyDefault, c->stream));
-    unsigned g = (unsigned)((n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(k_blk_mask, dim3(g), dim3(BLOCK), 0, c->stream, buf, n);
-    if (nzv > 1)
-      hipLaunchKernelGGL(k_blk_fill_seafloor, dim3((unsigned)((plane + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,
-                         c->stream, buf, nzv, plane);
-    if (v != VAR_LAND) {
-      // the reference dilates on demand, <=10 sweeps per interpolator call (interpolators.py:127-137);
-      // 10 sweeps up front give identical samples (DESIGN.md 4.3)
-      float *a = buf, *bb2 = tmp;
-      for (int it = 0; it < 10; ++it) {
-        hipLaunchKernelGGL(k_blk_dilate, dim3(g), dim3(BLOCK), 0, c->stream, a, bb2, nzv, ny, nx);
-        float *t2 = a; a = bb2; bb2 = t2;
-      }
-      // 10 swaps -> result is back in buf
-    }
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipFree(tmp));
-    prep[(size_t)k] = buf;
+    nmax = std::max(nmax, plane * (size_t)nzv);
   }
-  // final layout: one node record per grid point (odr_field.hip.h DevBlock): interleaved vector pairs
-  // first, then the other 3D variables, then the 2D ones; record length padded to 16 bytes
+  // record layout: interleaved vector pairs first, then the other 3D variables, then the 2D ones; the record
+  // length is padded to 16 bytes (odr_field.hip.h DevBlock)
   static const int pairs[3][2] = {{VAR_U, VAR_V}, {VAR_XWIND, VAR_YWIND}, {VAR_SX, VAR_SY}};
   std::vector<int> off((size_t)nvars, -1), es((size_t)nvars, 1), eo((size_t)nvars, 0);
   int rec = 0;
@@ -565,27 +597,98 @@ static int block_upload(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, i
       rec += nzv;
     }
   rec = (rec + 3) & ~3;
-  float *base;
-  HIPCHK(hipMalloc((void **)&base, sizeof(float) * plane * (size_t)rec + 64));
-  HIPCHK(hipMemsetAsync(base, 0, sizeof(float) * plane * (size_t)rec + 64, c->stream));
-  unsigned gp = (unsigned)((plane + BLOCK - 1) / BLOCK);
+  const size_t base_bytes = sizeof(float) * plane * (size_t)rec + 64;
+  float *base = nullptr;
+  reap(c, base_bytes, &base);   // recycle a retired block of the same size if the compute stream is done with it
+  if (!base) HIPCHK(hipMalloc((void **)&base, base_bytes));
+  if (c->prep_floats < nmax) {  // pooled scratch: one variable in flight + the dilation ping-pong buffer
+    HIPCHK(hipStreamSynchronize(c->up_stream));
+    if (c->prep[0]) HIPCHK(hipFree(c->prep[0]));
+    if (c->prep[1]) HIPCHK(hipFree(c->prep[1]));
+    c->prep[0] = c->prep[1] = nullptr;
+    HIPCHK(hipMalloc((void **)&c->prep[0], sizeof(float) * nmax));
+    HIPCHK(hipMalloc((void **)&c->prep[1], sizeof(float) * nmax));
+    c->prep_floats = nmax;
+  }
+  hipStream_t st = c->up_stream;
+  // device-resident sources (odr_sgrid_zslice results) may still be in the making on the compute stream: only
+  // then does the upload depend on it (host sources must NOT wait for the simulation's backlog -- that is the overlap)
+  bool dev_src = false;
+  for (int k = 0; k < nvars && !dev_src; ++k) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, data[k]) == hipSuccess) dev_src = at.type == hipMemoryTypeDevice;
+    else (void)hipGetLastError();   // plain pageable memory: not an error
+  }
+  if (dev_src) {
+    HIPCHK(hipEventRecord(c->up_dep, c->stream));
+    HIPCHK(hipStreamWaitEvent(st, c->up_dep, 0));
+  }
+  HIPCHK(hipMemsetAsync(base, 0, base_bytes, st));
+  const unsigned gp = (unsigned)((plane + BLOCK - 1) / BLOCK);
   for (int k = 0; k < nvars; ++k) {
-    int v = var_ids[k], nzv = var_nz[k] > 1 ? var_nz[k] : 1;
-    hipLaunchKernelGGL(k_blk_to_record, dim3(gp), dim3(BLOCK), 0, c->stream, prep[(size_t)k], base, nzv, plane, rec,
-                       off[(size_t)k], es[(size_t)k], eo[(size_t)k]);
+    const int v = var_ids[k], nzv = var_nz[k] > 1 ? var_nz[k] : 1;
+    const size_t n = plane * (size_t)nzv;
+    float *buf = c->prep[0], *tmp = c->prep[1];
+    // unified addressing: data[k] may be a host (pageable / pinned) or a device pointer
+    HIPCHK(hipMemcpyAsync(buf, data[k], sizeof(float) * n, hipMemcpyDefault, st));
+    const unsigned g = (unsigned)((n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_blk_mask, dim3(g), dim3(BLOCK), 0, st, buf, n);
+    if (nzv > 1) hipLaunchKernelGGL(k_blk_fill_seafloor, dim3(gp), dim3(BLOCK), 0, st, buf, nzv, plane);
+    if (v != VAR_LAND) {
+      // the reference dilates on demand, <=10 sweeps per interpolator call (interpolators.py:127-137);
+      // 10 sweeps up front give identical samples (DESIGN.md 4.3)
+      float *a = buf, *bb2 = tmp;
+      for (int it = 0; it < 10; ++it) {
+        hipLaunchKernelGGL(k_blk_dilate, dim3(g), dim3(BLOCK), 0, st, a, bb2, nzv, ny, nx);
+        float *t2 = a; a = bb2; bb2 = t2;
+      }
+      // 10 swaps -> result is back in buf
+    }
+    hipLaunchKernelGGL(k_blk_to_record, dim3(gp), dim3(BLOCK), 0, st, buf, base, nzv, plane, rec, off[(size_t)k],
+                       es[(size_t)k], eo[(size_t)k]);
     b.data[v] = base + off[(size_t)k] + eo[(size_t)k];
     b.es[v] = es[(size_t)k];
     b.var_nz[v] = nzv;
   }
+  HIPCHK(hipGetLastError());
   b.base = base;
   b.rec = rec;
   b.small = plane < (1u << 24) && (double)plane * rec * 4.0 < 4294967296.0 && rec * 4 < (1 << 24);
-  c->block_bufs[sid][slot].push_back(base);
-  HIPCHK(hipStreamSynchronize(c->stream));
-  for (float *q : prep) HIPCHK(hipFree(q));
+  S.base = base;
+  S.bytes = base_bytes;
+  HIPCHK(hipEventRecord(c->up_done, st));
+  return 0;
+}
+
+int odr_block_commit(odr_ctx *c, int32_t sid, int32_t slot) {
+  REQUIRE(sid >= 0 && sid < c->nsrc && slot >= 0 && slot < MAXLEVELS, "bad source/slot");
+  Staged &S = c->staged[sid][slot];
+  if (!S.base) return fail(ODR_ERR_STATE, "no staged block for source %d slot %d", sid, slot);
+  HIPCHK(hipSetDevice(c->device));
+  // the compute stream must not read the new records before the upload pipeline has written them
+  HIPCHK(hipStreamWaitEvent(c->stream, c->up_done, 0));
+  DevSource &s = c->hw.src[sid];
+  int rc;
+  for (size_t k = 0; k < c->block_bufs[sid][slot].size(); ++k)
+    if ((rc = retire(c, c->block_bufs[sid][slot][k], c->block_bytes[sid][slot]))) return rc;
+  c->block_bufs[sid][slot].clear();
+  s.slot[slot] = S.blk;
+  c->block_bufs[sid][slot].push_back(S.base);
+  c->block_bytes[sid][slot] = S.bytes;
+  S.base = nullptr;
   sort_levels(s);
   c->dirty = true;
   return 0;
+}
+
+static int block_upload(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, int nvars, const int32_t *var_ids,
+                        const void *const *data, bool on_device, const int32_t *var_nz, int ny, int nx,
+                        const double *xy8) {
+  (void)on_device;
+  int rc = stage_block(c, sid, slot, t_epoch, nvars, var_ids, data, var_nz, ny, nx, xy8);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->up_stream));   // synchronous entry points: the caller may reuse its arrays
+  return odr_block_commit(c, sid, slot);
 }
 
 int odr_block_upload(odr_ctx *c, int32_t sid, int32_t slot, double t, int nvars, const int32_t *var_ids,
@@ -596,12 +699,51 @@ int odr_block_upload_device(odr_ctx *c, int32_t sid, int32_t slot, double t, int
                             const void *const *dev_data, const int32_t *var_nz, int ny, int nx, const double *xy8) {
   return block_upload(c, sid, slot, t, nvars, var_ids, dev_data, true, var_nz, ny, nx, xy8);
 }
+// enqueue only; the arrays must stay valid (and should be pinned: odr_host_register) until odr_block_commit
+int odr_block_upload_async(odr_ctx *c, int32_t sid, int32_t slot, double t, int nvars, const int32_t *var_ids,
+                           const void *const *data, const int32_t *var_nz, int ny, int nx, const double *xy8) {
+  return stage_block(c, sid, slot, t, nvars, var_ids, data, var_nz, ny, nx, xy8);
+}
+// page-lock caller memory so that uploads from it are DMA transfers that overlap with the simulation
+int odr_host_register(odr_ctx *c, void *ptr, uint64_t bytes) {
+  REQUIRE(ptr && bytes > 0, "bad host range");
+  HIPCHK(hipSetDevice(c->device));
+  hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault);
+  if (e == hipErrorHostMemoryAlreadyRegistered) {  // pinned by another context / the caller: nothing to do, not ours to unpin
+    (void)hipGetLastError();
+    return 0;
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();   // do not leave a sticky error for the next launch check
+    return fail(ODR_ERR_HIP, "hipHostRegister: %s", hipGetErrorString(e));
+  }
+  c->registered.push_back(ptr);
+  return 0;
+}
+int odr_host_unregister(odr_ctx *c, void *ptr) {
+  REQUIRE(ptr, "NULL pointer");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->up_stream));
+  for (size_t k = 0; k < c->registered.size(); ++k)
+    if (c->registered[k] == ptr) {
+      c->registered.erase(c->registered.begin() + (long)k);
+      hipError_t e = hipHostUnregister(ptr);
+      if (e != hipSuccess) (void)hipGetLastError();
+      return 0;
+    }
+  return 0;   // not registered by this context
+}
 
 int odr_block_drop(odr_ctx *c, int32_t sid, int32_t slot) {
   REQUIRE(sid >= 0 && sid < c->nsrc && slot >= 0 && slot < MAXLEVELS, "bad source/slot");
   HIPCHK(hipStreamSynchronize(c->stream));
   for (void *b : c->block_bufs[sid][slot]) HIPCHK(hipFree(b));
   c->block_bufs[sid][slot].clear();
+  if (c->staged[sid][slot].base) {
+    HIPCHK(hipStreamSynchronize(c->up_stream));
+    HIPCHK(hipFree(c->staged[sid][slot].base));
+    c->staged[sid][slot].base = nullptr;
+  }
   memset(&c->hw.src[sid].slot[slot], 0, sizeof(DevBlock));
   sort_levels(c->hw.src[sid]);
   c->dirty = true;

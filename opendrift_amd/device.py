@@ -149,6 +149,38 @@ class Context:
         check(self.lib.odr_block_upload_device(self.h, sid, slot, float(t_epoch), len(names), pi, ptrs, pn,
                                                g['ny'], g['nx'], px))
 
+    def upload_block_async(self, sid, slot, t_epoch, arrays, var_nz=None):
+        """Enqueue the upload of one time level on the upload stream and return (the simulation continues); the
+        block becomes visible with commit_block().  arrays: {variable: float32 host array (pin it with pin() for a true
+        DMA transfer) or device pointer (int)}.  The arrays are kept referenced until the commit."""
+        g = self._grids[sid]
+        names = list(arrays)
+        ids, pi = _i([_vid(k) for k in names])
+        keep = {k: np.ascontiguousarray(np.ma.filled(v, np.nan) if isinstance(v, np.ma.MaskedArray) else v, dtype=np.float32)
+                for k, v in arrays.items() if not isinstance(v, (int, np.integer))}
+        nzs, pn = _i([(keep[k].shape[0] if keep[k].ndim == 3 else 1) if k in keep else var_nz[k] for k in names])
+        ptrs = (C.c_void_p * len(names))(*[C.c_void_p(keep[k].ctypes.data if k in keep else int(arrays[k])) for k in names])
+        xy8, px = _d(g['xy8'])
+        check(self.lib.odr_block_upload_async(self.h, sid, slot, float(t_epoch), len(names), pi, ptrs, pn, g['ny'], g['nx'], px))
+        self._staged_refs = getattr(self, '_staged_refs', {})
+        self._staged_refs[(sid, slot)] = keep
+
+    def commit_block(self, sid, slot):
+        check(self.lib.odr_block_commit(self.h, sid, slot))
+        getattr(self, '_staged_refs', {}).pop((sid, slot), None)
+
+    def pin(self, array):
+        """Page-lock a host array (hipHostRegister) so that uploads from it are asynchronous DMA transfers."""
+        a = np.asarray(array)
+        assert a.flags['C_CONTIGUOUS']
+        check(self.lib.odr_host_register(self.h, C.c_void_p(a.ctypes.data), a.nbytes))
+        self._pinned = getattr(self, '_pinned', [])
+        self._pinned.append(a)
+        return a
+
+    def unpin(self, array):
+        check(self.lib.odr_host_unregister(self.h, C.c_void_p(np.asarray(array).ctypes.data)))
+
     def set_time_coverage(self, sid, t_start, t_end, always_valid=False):
         check(self.lib.odr_source_time_coverage(self.h, sid, float(t_start), float(t_end), int(always_valid)))
 

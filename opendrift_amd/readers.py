@@ -213,11 +213,15 @@ class DeviceReaderBinding:
     (ReaderBlocks) are uploaded on demand.  Stands where StructuredReader keeps
     var_block_before/after (structured.py:121-123)."""
     NSLOTS = 4
+    PREFETCH = True   # stage the next time level on the upload stream while the current one is in use
 
     def __init__(self, ctx, reader, variables=None):
         self.ctx, self.reader = ctx, reader
         self.variables = [v for v in (variables or reader.variables)]
         self.slots = {}      # time index -> slot
+        self.staged = {}     # time index -> slot uploaded asynchronously, not yet committed
+        self.prefetch = self.PREFETCH
+        self._pinned = False
         kind = getattr(reader, 'device_kind', None)
         if kind == 'constant':
             self.sid = ctx.add_constant({v: reader._parameter_value_map[v] for v in self.variables})
@@ -249,53 +253,82 @@ class DeviceReaderBinding:
                 return
             lo_c, hi_c = max(lo, r.start_time), min(hi, r.end_time)
             need = list(range(r.nearest_time(lo_c)[0], r.nearest_time(hi_c)[1] + 1))
-        need = need[-self.NSLOTS:]
+        need = need[-(self.NSLOTS - 1):]
         for k in list(self.slots):
-            if k not in need and len(self.slots) + len([n for n in need if n not in self.slots]) > self.NSLOTS:
+            if k not in need and len(self.slots) + len(self.staged) + len([n for n in need if n not in self.slots]) >= self.NSLOTS:
                 self.ctx.drop_block(self.sid, self.slots.pop(k))
         for k in need:
             if k in self.slots:
                 continue
-            time = r.times[k] if r.times is not None else None
-            x = y = None
-            if extent is not None:
-                x, y = np.array(extent[0]), np.array(extent[1])
-            block = r.get_variables(self.variables, time, x, y, np.array([0.0]))
-            if broadcast is not None:
-                block = broadcast(block)
-            bx, by = np.asarray(block['x']), np.asarray(block['y'])
-            bz = block.get('z', None)
-            if self.sid is None:
-                proj = projection.parse_proj4(r.proj4)
-                zz = np.atleast_1d(bz) if bz is not None and np.size(bz) > 1 else None
-                lon_mode = 1
-                if proj['kind'] == 'latlong' and r.xmin is not None and r.xmin >= 0 and r.xmax > 180:
-                    lon_mode = 2
-                dom = (float(r.xmin), float(r.xmax), float(r.ymin), float(r.ymax), float(r.zmin), float(r.zmax))
-                self.sid = self.ctx.add_grid(bx, by, z=zz, proj=proj, lon_mode=lon_mode, domain=dom)
-                if r.start_time is not None:
-                    self.ctx.set_time_coverage(self.sid, _epoch(r.start_time), _epoch(r.end_time), r.always_valid)
-            else:
-                g = self.ctx._grids[self.sid]
-                if (len(by), len(bx)) != (g['ny'], g['nx']):
-                    raise ValueError('reader %s changed its block shape between time levels' % r.name)
-            free = [s for s in range(self.NSLOTS) if s not in self.slots.values()]
-            slot = free[0]
-            if getattr(r, 's_levels', False):
-                # ROMS-type reader: the block arrives on s-levels and is regridded to the z levels on the device
-                # (reader_ROMS_native.py:617-684); the float32 result never visits the host
-                if getattr(self, 'sgrid', None) is None:
-                    from .device import SigmaGrid
-                    self.sgrid = SigmaGrid(self.ctx, r.h, r.hc, r.Cs_r, Vtransform=r.Vtransform)
-                arrays, nzv = {}, {}
-                for i, v in enumerate([v for v in self.variables if v in block['s_level_variables']]):
-                    arrays[v] = self.sgrid.zslice(block[v], bz, slot=i)
-                    nzv[v] = len(bz)
+            if k in self.staged:     # prefetched on the upload stream while the previous steps ran
+                self.slots[k] = self.staged.pop(k)
+                self.ctx.commit_block(self.sid, self.slots[k])
+                continue
+            self._upload(k, extent, broadcast, asynchronous=False)
+        # prefetch the time level the run will need next (readers whose arrays live in host memory)
+        if self.prefetch and r.times is not None and broadcast is None and not getattr(r, 's_levels', False):
+            kn = (max(need) + 1) if t1 >= t0 else (min(need) - 1)
+            if 0 <= kn < len(r.times) and kn not in self.slots and kn not in self.staged and \
+                    len(self.slots) + len(self.staged) < self.NSLOTS:
+                self._upload(kn, extent, None, asynchronous=True)
+
+    def _upload(self, k, extent, broadcast, asynchronous):
+        """One reader time level -> one device block (synchronously, or staged on the upload stream)."""
+        r = self.reader
+        time = r.times[k] if r.times is not None else None
+        x = y = None
+        if extent is not None:
+            x, y = np.array(extent[0]), np.array(extent[1])
+        block = r.get_variables(self.variables, time, x, y, np.array([0.0]))
+        if broadcast is not None:
+            block = broadcast(block)
+        bx, by = np.asarray(block['x']), np.asarray(block['y'])
+        bz = block.get('z', None)
+        if self.sid is None:
+            proj = projection.parse_proj4(r.proj4)
+            zz = np.atleast_1d(bz) if bz is not None and np.size(bz) > 1 else None
+            lon_mode = 1
+            if proj['kind'] == 'latlong' and r.xmin is not None and r.xmin >= 0 and r.xmax > 180:
+                lon_mode = 2
+            dom = (float(r.xmin), float(r.xmax), float(r.ymin), float(r.ymax), float(r.zmin), float(r.zmax))
+            self.sid = self.ctx.add_grid(bx, by, z=zz, proj=proj, lon_mode=lon_mode, domain=dom)
+            if r.start_time is not None:
+                self.ctx.set_time_coverage(self.sid, _epoch(r.start_time), _epoch(r.end_time), r.always_valid)
+        else:
+            g = self.ctx._grids[self.sid]
+            if (len(by), len(bx)) != (g['ny'], g['nx']):
+                raise ValueError('reader %s changed its block shape between time levels' % r.name)
+        free = [s for s in range(self.NSLOTS) if s not in self.slots.values() and s not in self.staged.values()]
+        slot = free[0]
+        t_ep = _epoch(time) if time is not None else 0.0
+        if asynchronous:
+            if not self._pinned:     # page-lock the reader's in-memory arrays once: uploads become DMA transfers
+                self._pinned = True
                 for v in self.variables:
-                    if v not in arrays:
-                        arrays[v] = block[v]
-                self.ctx.upload_block_device(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays, nzv)
-            else:
-                arrays = {v: block[v] for v in self.variables}
-                self.ctx.upload_block(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays)
-            self.slots[k] = slot
+                    a = getattr(r, 'arrays', {}).get(v)
+                    if isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags['C_CONTIGUOUS']:
+                        try:
+                            self.ctx.pin(a)
+                        except Exception:
+                            pass
+            self.ctx.upload_block_async(self.sid, slot, t_ep, {v: block[v] for v in self.variables})
+            self.staged[k] = slot
+            return
+        if getattr(r, 's_levels', False):
+            # ROMS-type reader: the block arrives on s-levels and is regridded to the z levels on the device
+            # (reader_ROMS_native.py:617-684); the float32 result never visits the host
+            if getattr(self, 'sgrid', None) is None:
+                from .device import SigmaGrid
+                self.sgrid = SigmaGrid(self.ctx, r.h, r.hc, r.Cs_r, Vtransform=r.Vtransform)
+            arrays, nzv = {}, {}
+            for i, v in enumerate([v for v in self.variables if v in block['s_level_variables']]):
+                arrays[v] = self.sgrid.zslice(block[v], bz, slot=i)
+                nzv[v] = len(bz)
+            for v in self.variables:
+                if v not in arrays:
+                    arrays[v] = block[v]
+            self.ctx.upload_block_device(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays, nzv)
+        else:
+            arrays = {v: block[v] for v in self.variables}
+            self.ctx.upload_block(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays)
+        self.slots[k] = slot

@@ -1,0 +1,102 @@
+"""Asynchronous block upload (odr_block_upload_async + odr_block_commit on the upload stream) gives the same
+environment as the synchronous upload, the replaced block stays readable until the commit, and pinned host
+arrays can be uploaded while the simulation runs."""
+import numpy as np
+import pytest
+
+from opendrift_amd import synthetic as synth
+
+pytestmark = pytest.mark.gpu
+
+U, V, W = 'x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity'
+KZ, DEPTH, LAND = 'ocean_vertical_diffusivity', 'sea_floor_depth_below_sea_level', 'land_binary_mask'
+
+
+def _eq(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+def test_async_upload_equals_sync_and_overlaps(ctx):
+    g = synth.grid3d(nx=128, ny=96, nz=8, nt=3, seed=2)
+    names = [U, V, W, KZ, DEPTH, LAND]
+    sa = ctx.add_grid(g['x'], g['y'], z=g['z'])          # async
+    ss = ctx.add_grid(g['x'], g['y'], z=g['z'])          # sync
+    rng = np.random.default_rng(0)
+    n = 30000
+    lon, lat, z = rng.uniform(g['x'][2], g['x'][-3], n), rng.uniform(g['y'][2], g['y'][-3], n), -rng.uniform(0, 80, n)
+    P = ctx.particles(n)
+    P.append(lon, lat, z=z)
+    pinned = {k: ctx.pin(np.ascontiguousarray(g[k])) for k in names}     # page-locked once, uploaded level by level
+
+    def sample(sid, t):
+        for k in names:
+            ctx.bind(k, [sid], {LAND: np.nan, DEPTH: 10000.0}.get(k, 0.0))
+        return P.env_sample(names, t, download=True)
+
+    for slot in (0, 1):
+        ctx.upload_block(ss, slot, float(g['t'][slot]), {k: g[k][slot] for k in names})
+        ctx.upload_block_async(sa, slot, float(g['t'][slot]), {k: pinned[k][slot] for k in names})
+        ctx.commit_block(sa, slot)
+    a, b = sample(sa, 1000.0), sample(ss, 1000.0)
+    for k in names:
+        assert _eq(a[k], b[k]), k
+    # stage level 2 into slot 0 while kernels that read the old slot 0 are running; the old content stays in force
+    ctx.upload_block_async(sa, 0, float(g['t'][2]), {k: pinned[k][2] for k in names})
+    before = sample(sa, 1000.0)
+    for k in names:
+        assert _eq(before[k], b[k]), k                   # not committed yet: still levels 0 and 1
+    P.advect('runge-kutta4', 1000.0, 600.0)              # compute stream busy while the upload stream works
+    ctx.commit_block(sa, 0)
+    ctx.upload_block(ss, 0, float(g['t'][2]), {k: g[k][2] for k in names})
+    t = float(g['t'][1]) + 700.0
+    a, b = sample(sa, t), sample(ss, t)
+    for k in names:
+        assert _eq(a[k], b[k]), k
+    for k in names:
+        ctx.unpin(pinned[k])
+
+
+def test_commit_without_staging_is_an_error(ctx):
+    from opendrift_amd._abi import OdrError
+    g = synth.grid3d(nx=32, ny=24, nz=4, nt=1, seed=1)
+    sid = ctx.add_grid(g['x'], g['y'], z=g['z'])
+    with pytest.raises(OdrError):
+        ctx.commit_block(sid, 0)
+
+
+def test_model_run_with_prefetch_equals_run_without():
+    """run(): the next reader time level is staged on the upload stream while the steps of the current one execute
+    (DeviceReaderBinding prefetch); trajectories must not depend on it."""
+    from datetime import datetime, timedelta
+    from opendrift_amd import readers
+    from opendrift_amd.oceandrift import OceanDrift
+    g = synth.grid3d(nx=96, ny=80, nz=6, nt=6, seed=4)
+    T0 = datetime(2020, 1, 1)
+    times = [T0 + timedelta(seconds=float(t)) for t in g['t']]
+    names = [U, V, W, DEPTH, LAND]
+
+    def run(prefetch):
+        readers.DeviceReaderBinding.PREFETCH = prefetch
+        o = OceanDrift(loglevel=50, seed=1)
+        o.add_reader(readers.GridReader(g['x'], g['y'], times, {k: np.ascontiguousarray(g[k]) for k in names}, z=g['z']))
+        o.set_config('drift:advection_scheme', 'runge-kutta4')
+        o.set_config('general:coastline_action', 'previous')
+        r = np.random.default_rng(0)
+        n = 20000
+        o.seed_elements(lon=r.uniform(g['x'][5], g['x'][-6], n), lat=r.uniform(g['y'][5], g['y'][-6], n),
+                        z=-r.uniform(0, 30, n), time=T0)
+        nsteps = int((g['t'][-1] - g['t'][0]) // 600) - 1
+        o.run(time_step=600, steps=nsteps)
+        e = o.elements
+        k = np.argsort(e.ID)
+        staged = sum(len(b.staged) + len(b.slots) for b in o.readers.values())
+        assert all(b.prefetch == prefetch for b in o.readers.values())
+        return e.lon[k], e.lat[k], e.z[k], staged
+
+    try:
+        a, b = run(True), run(False)
+    finally:
+        readers.DeviceReaderBinding.PREFETCH = True
+    for p, q in zip(a[:3], b[:3]):
+        assert _eq(p, q)
+    assert a[3] >= 2
