@@ -17,6 +17,12 @@ namespace odr {
 #define ODR_BLOCK 256
 #endif
 constexpr int BLOCK = ODR_BLOCK;  // threads per workgroup (A/B builds may override)
+#ifndef ODR_POLAR_WAVES
+#define ODR_POLAR_WAVES 3   // measured on C4: 2 waves (183 VGPRs) 1.31 ms, 3 waves (168 VGPRs, 52 B scratch) 1.06 ms, 4 waves (128 VGPRs, 280 B scratch) 2.06 ms
+#endif
+// minimum waves per SIMD requested for the projected-reader instantiations (their stereographic forward /
+// rotation code otherwise takes ~185 VGPRs = 2 waves per SIMD)
+#define ODR_WAVES(PROJ) ((PROJ) == PROJ_LATLONG ? 1 : ODR_POLAR_WAVES)
 
 // XCD-aware block order.  Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2), so with
 // the natural order the eight L2s all stream the whole (spatially sorted) particle range and every field tile is
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_group(const DevWorld *__restrict_
 
 // fast version: the whole group comes from one gridded reader (odr_field.hip.h)
 template <int PROJ>
-__global__ __launch_bounds__(BLOCK) void k_env_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
+__global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_env_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
                                                     int record_prev) {
   long long i = pid();
   if (i >= p.n) return;
@@ -255,7 +261,7 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
 }
 
 template <int SCHEME, int PROJ, bool IS3D>
-__global__ __launch_bounds__(BLOCK) void k_advect_grid(const DevWorld *__restrict__ W, int sid, int geo_slot,
+__global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_advect_grid(const DevWorld *__restrict__ W, int sid, int geo_slot,
                                                        PView p, double dt, float factor, UVTime th,
                                                        UVTime tf) {
   long long i = pid();
@@ -283,7 +289,7 @@ struct StepDesc {
 };
 
 template <int SCHEME, int PROJ, bool IS3D>
-__global__ __launch_bounds__(BLOCK) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
+__global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
                                                      StepDesc S, double dt, float factor, UVTime th, UVTime tf,
                                                      unsigned long long *n_hit) {
   long long i = pid();
