@@ -104,10 +104,23 @@ __device__ __forceinline__ void move_f32(double &lon, double &lat, float u, floa
 // float64 velocities (advect_wind / stokes_drift / horizontal_diffusion callers)
 __device__ __forceinline__ void move_f64(double &lon, double &lat, double u, double v, int moving,
                                          double dt) {
-  double az = atan2(u, v) * (180.0 / kPi);
+  // azimuth = degrees(arctan2(u, v)) in float64 (no float32 rounding on this path): its sine and cosine are
+  // u/h and v/h to round-off -- no atan2, no degree reduction
+  const double h2 = fma(u, u, v * v);
+  double salp = 0.0, calp = 1.0;
+  if (h2 > 0 && h2 < 1.7e308) {
+    const double rh = fast_rsqrt(h2);
+    salp = u * rh;
+    calp = v * rh;
+  } else if (!(h2 == 0)) {  // NaN / infinite velocities: library semantics
+    double az = atan2(u, v) * (180.0 / kPi);
+    az = ang_normalize(az);
+    sincosd(ang_round(az), salp, calp);
+  }
   double vel = sqrt(__dadd_rn(__dmul_rn(u, u), __dmul_rn(v, v))) * (double)moving;
+  GeodOrigin o = geod_origin(lat, lon);
   double lo, la;
-  geod_direct(lat, lon, az, vel * dt, la, lo);
+  geod_direct_sc(o, salp, calp, vel * dt, la, lo);
   lon = lo;
   lat = la;
 }
