@@ -1,19 +1,22 @@
 #!/usr/bin/env python
 """bench.py -- particle-steps/s of the MI355X hot path on BASELINE.json's workloads.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4] [--particles P]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5] [--particles P]
 
 A "step" is one pass of the per-timestep hot path over all particles of this rank with the
 inputs already resident in HBM (field blocks uploaded, particle SoA on device):
-  c3 (default, "RK4, 3D interp"): Environment sample (u,v,w,depth,ssh,landmask) -> coastline
-      -> RK4 advect_ocean_current (3 more 3D field evaluations + 4 geodesics) -> vertical_mixing
-      (10 Visser sub-steps from the K profile) -> vertical_advection; 10 M particles, synthetic
-      ROMS-shaped 1024x1024x12 z-level block, 2 time levels interpolated.
+  c3 (default, "RK4, 3D interp"): spatial re-sort (every 16th step) -> ONE launch for Environment sample
+      (u,v,w,depth,ssh,landmask) + coastline 'previous' + previous state + RK4 advect_ocean_current (3 more 3D field
+      evaluations + 4 geodesics) -> vertical_mixing (10 Visser sub-steps from the K profile) + vertical_advection;
+      10 M particles, synthetic ROMS-shaped 1024x1024x12 z-level block, 2 time levels interpolated.
   c2: analytic double gyre, 1 M particles, RK4.
   c4: NorKyst-800-shaped 2602x902 polar-stereographic surface block (current, wind, Stokes,
-      landmask), RK4 + wind + Stokes + horizontal diffusion + stranding + compaction.
-One JSON line is printed by rank 0.  N>1: one process per GPU (torchrun), particles sharded,
-field blocks broadcast once from rank 0 over RCCL; weak scaling (per-GPU work fixed).
+      landmask), RK4 + wind + Stokes + horizontal diffusion + stranding + compaction, 6.25 M particles.
+  c5: Leeway ensemble members on the same grid (wind / current uncertainty, stranding), 10 M particles.
+One JSON line is printed by rank 0 (metric / roofline / cpu_baseline).  N>1: one process
+per GPU (torchrun), particles sharded, field blocks broadcast once from rank 0 over RCCL; weak scaling (per-GPU
+work fixed).  --block-every N [--block-async]: a new field time level arrives from host memory every N steps
+inside the timed region (PCIe-inclusive rate).
 """
 import argparse
 import json
@@ -245,7 +248,7 @@ def cpu_baseline(name, fields, n_cpu, rng):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=32)   # two re-sorts (every 16th step) fall in the timed region: steady-state mix
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default=os.environ.get('ODR_WORKLOAD', 'c3'), choices=['c2', 'c3', 'c4', 'c5'])
     ap.add_argument('--particles', type=int, default=0, help='particles per GPU (default: the config size)')
