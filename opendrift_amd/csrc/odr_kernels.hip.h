@@ -873,29 +873,50 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__
   rocrand_state_philox4x32_10 st;
   if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
   double2 u2 = make_double2(0.0, 0.0);
-  int zi_cur = -1;
-  double sig = 0, dKdt = 0;
+  // -dK/dz * dt_mix and sqrt(K |dt_mix| 2 / r) of one level (oceandrift.py:501-502,527-528)
+  auto level_terms = [&](int zl, double &dk_dt, double &sg) {
+    const double Kz = Kp[zl * BLOCK + tid];
+    double gK;  // np.gradient(Kprofiles, mixing_z, axis=0)[zl]
+    if (zl == 0) gK = div_cr(Kp[BLOCK + tid] - Kz, gd0, gi0);
+    else if (zl == nzp - 1) gK = div_cr(Kz - Kp[(nzp - 2) * BLOCK + tid], gd1, gi1);
+    else if (uniform_z) gK = div_cr(Kp[(zl + 1) * BLOCK + tid] - Kp[(zl - 1) * BLOCK + tid], gd2, gi2);
+    else
+      gK = __dadd_rn(__dadd_rn(__dmul_rn(gsh[zl], Kp[(zl - 1) * BLOCK + tid]), __dmul_rn(gsh[NL + zl], Kz)),
+                     __dmul_rn(gsh[2 * NL + zl], Kp[(zl + 1) * BLOCK + tid]));
+    double dK = -gK;
+    if (fabs(dK) < 1e-10) dK = 0;  // gradK[np.abs(gradK)<1e-10] = 0 (:502)
+    dk_dt = __dmul_rn(dK, dt_mix);
+    sg = sqrt(div_cr(__dmul_rn(__dmul_rn(Kz, fabs(dt_mix)), 2.0), r, ir));
+  };
+  // A particle rarely leaves the three levels around its starting one within a step: their terms are derived once
+  // (branch-free selection in the loop); anything else is derived on demand.  With a per-iteration "derive when the
+  // level changes" scheme the 64 lanes of a wave make that branch fire in practically every sub-step.
+  int lv0;
+  {
+    const double d0 = -z;
+    int zs = 0;
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) zs += ((k & 1) ? d0 >= zm[k] : d0 > zm[k]) ? 1 : 0;
+    lv0 = zs < 1 ? 1 : (zs > nzp - 2 ? nzp - 2 : zs);   // centre of the cached window [lv0-1, lv0+1]
+    if (nzp < 3) lv0 = 1;
+  }
+  double c_dk[3], c_sg[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int zl = lv0 - 1 + q;
+    c_dk[q] = 0; c_sg[q] = 0;
+    if (zl >= 0 && zl < nzp) level_terms(zl, c_dk[q], c_sg[q]);
+  }
   for (int it = 0; it < ntimes; ++it) {
     const bool surface = z == 0;
     const double d = -z;
     int zi = 0;
 #pragma unroll
     for (int k = 0; k < NL - 1; ++k) zi += ((k & 1) ? d >= zm[k] : d > zm[k]) ? 1 : 0;
-    if (zi != zi_cur) {
-      zi_cur = zi;
-      const double Kz = Kp[zi * BLOCK + tid];
-      double gK;  // np.gradient(Kprofiles, mixing_z, axis=0)[zi] (oceandrift.py:501)
-      if (zi == 0) gK = div_cr(Kp[BLOCK + tid] - Kz, gd0, gi0);
-      else if (zi == nzp - 1) gK = div_cr(Kz - Kp[(nzp - 2) * BLOCK + tid], gd1, gi1);
-      else if (uniform_z) gK = div_cr(Kp[(zi + 1) * BLOCK + tid] - Kp[(zi - 1) * BLOCK + tid], gd2, gi2);
-      else
-        gK = __dadd_rn(__dadd_rn(__dmul_rn(gsh[zi], Kp[(zi - 1) * BLOCK + tid]), __dmul_rn(gsh[NL + zi], Kz)),
-                       __dmul_rn(gsh[2 * NL + zi], Kp[(zi + 1) * BLOCK + tid]));
-      double dK = -gK;
-      if (fabs(dK) < 1e-10) dK = 0;  // gradK[np.abs(gradK)<1e-10] = 0 (:502)
-      dKdt = __dmul_rn(dK, dt_mix);
-      sig = sqrt(div_cr(__dmul_rn(__dmul_rn(Kz, fabs(dt_mix)), 2.0), r, ir));
-    }
+    const int q = zi - lv0 + 1;
+    double dKdt = q == 0 ? c_dk[0] : (q == 1 ? c_dk[1] : c_dk[2]);
+    double sig = q == 0 ? c_sg[0] : (q == 1 ? c_sg[1] : c_sg[2]);
+    if (q < 0 || q > 2) level_terms(zi, dKdt, sig);
     double u01;
     if (rng_mode == 1) u01 = huni[(size_t)it * p.n + i];
     else {  // one Philox4x32-10 block = two float64 uniforms
