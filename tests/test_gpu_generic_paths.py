@@ -125,3 +125,39 @@ def test_ordered_and_in_place_compaction_keep_the_same_elements(ctx):
         assert _eq(x, y)
     assert (res[1][0] == np.nonzero(~kill)[0]).all()
 
+
+def test_priority_list_of_two_grids_and_a_constant_matches_oracle(ctx):
+    """Environment.get_environment with a priority list: a small high-resolution reader first (with a NaN coast
+    and limited time coverage), a large coarse reader second, a constant reader third, then the fallback --
+    the group semantics of environment.py:597-791 on the device against the oracle, bit for bit; and RK4 across
+    the reader boundary."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(12)
+    gi = synth.grid3d(nx=64, ny=48, nz=6, nt=3, seed=1, lon0=3.0, lon1=4.0, lat0=60.5, lat1=61.0)
+    go = synth.grid3d(nx=40, ny=36, nz=6, nt=3, seed=2, lon0=1.0, lon1=7.0, lat0=59.0, lat1=63.0)
+    li = [(float(gi['t'][k]), {U: gi[U][k], V: gi[V][k]}) for k in range(2)]       # inner: only two time levels
+    lo = [(float(go['t'][k]), {U: go[U][k], V: go[V][k], W: go[W][k]}) for k in range(3)]
+    sc = Scenario([('grid', dict(x=gi['x'], y=gi['y'], z=gi['z'], levels=li, time_coverage=(float(gi['t'][0]), float(gi['t'][1])))),
+                   ('grid', dict(x=go['x'], y=go['y'], z=go['z'], levels=lo)),
+                   ('constant', {U: 0.11, V: -0.07, XW: 4.0})],
+                  fallbacks={U: 0.0, V: 0.0, W: 0.0, XW: 1.0, YW: 2.0})
+    sc.device(ctx)
+    n = 30000
+    lon, lat, z = rng.uniform(0.5, 7.5, n), rng.uniform(58.8, 63.2, n), -rng.uniform(0, 60, n)
+    P = ctx.particles(n)
+    P.append(lon, lat, z=z)
+    names = [U, V, W, XW, YW]
+    for t in (0.0, 1800.0, float(gi['t'][1]) + 600.0):      # the last one is outside the inner reader's coverage
+        w = sc.oracle_world()
+        got = P.env_sample(names, t, download=True)
+        ref = orc.get_environment(w, [orc.VAR[k] for k in names], lon, lat, z, t)
+        for k, r in zip(names, ref):
+            assert _eq(got[k], r), (k, t, int((~((got[k] == r) | (np.isnan(got[k]) & np.isnan(r)))).sum()))
+    w = sc.oracle_world()
+    lo_, la_ = lon.copy(), lat.copy()
+    ue, ve = orc.get_environment(w, [0, 1], lo_, la_, z, 900.0)
+    P.env_sample([U, V], 900.0)
+    P.advect('runge-kutta4', 900.0, 600.0)
+    orc.advect_ocean_current(w, 2, lo_, la_, z, np.ones(n, np.int32), np.ones(n, np.float32), ue, ve, 900.0, 600.0)
+    d = P.download()
+    assert np.abs(d['lon'] - lo_).max() < 1e-10 and np.abs(d['lat'] - la_).max() < 1e-10
