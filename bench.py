@@ -102,18 +102,14 @@ class Workload:
         for slot in range(3):
             arrays = {k: g[k][slot] for k in fields['names']} if rank == 0 else None
             shapes = {k: g[k][slot].shape for k in fields['names']}
-            if world > 1 or True:
-                # rank 0 owns the host Reader; the block travels to every GPU once per time level
-                import torch
-                if torch.cuda.is_available():
-                    tens = D.broadcast_block(arrays, shapes=shapes, src=0)
-                    torch.cuda.synchronize()
-                    ctx.upload_block_device(sid, slot, float(g['t'][slot]),
-                                            {k: t.data_ptr() for k, t in tens.items()},
-                                            {k: (t.shape[0] if t.dim() == 3 else 1) for k, t in tens.items()})
-                    del tens
-                    continue
-            ctx.upload_block(sid, slot, float(g['t'][slot]), {k: g[k][slot] for k in fields['names']})
+            # rank 0 owns the host Reader; the block travels to every GPU once per time level (RCCL broadcast), and
+            # goes from the received device tensors into the block without touching the other hosts' memory
+            tens = D.broadcast_block(arrays, shapes=shapes, src=0)
+            import torch
+            torch.cuda.synchronize()
+            ctx.upload_block_device(sid, slot, float(g['t'][slot]), {k: t.data_ptr() for k, t in tens.items()},
+                                    {k: (t.shape[0] if t.dim() == 3 else 1) for k, t in tens.items()})
+            del tens
         for k in fields['names']:
             ctx.bind(k, [sid], {LAND: np.nan, DEPTH: 10000.0}.get(k, 0.0))
         ctx.bind(SSH, [], 0.0)
@@ -204,13 +200,17 @@ def cpu_baseline(name, fields, n_cpu, rng):
         wb.set_fallback(orc.VAR[SSH], 0.0)
         if name == 'c4':
             wb.add_constant({orc.VAR[HD]: 10.0})
-        dt = 600.0 if name == 'c3' else 900.0
+        dt = 900.0 if name == 'c4' else 600.0
     w = wb.finish()
-    if name == 'c5':
-        raise SystemExit('cpu baseline for c5: run tests/test_oracle_golden.py::test_c5 (not timed in bench)')
     lon, lat, z = seed_particles(name, fields, n_cpu, rng)
     mv, cdf = np.ones(n_cpu, np.int32), np.ones(n_cpu, np.float32)
     wdf = np.full(n_cpu, 0.02, np.float32)
+    if name == 'c5':   # the same PIW-like LeewayObj coefficients as the device run
+        r5 = np.random.default_rng(7)
+        ori = (np.arange(n_cpu) % 2).astype(np.float32)
+        aux = [a.astype(np.float32) for a in (np.full(n_cpu, 0.96), np.where(ori == 0, 0.54, -0.54), np.zeros(n_cpu),
+                                              np.zeros(n_cpu), np.abs(r5.standard_normal(n_cpu)) * 12.0,
+                                              r5.standard_normal(n_cpu) * 9.4, np.full(n_cpu, 0.04), ori, np.zeros(n_cpu))]
 
     def step(k):
         t = (k * dt) % 6000.0
@@ -225,6 +225,15 @@ def cpu_baseline(name, fields, n_cpu, rng):
             uni = np.random.default_rng(k).uniform(size=(10, n_cpu))
             orc.vertical_mixing(z, mv, np.zeros(n_cpu, np.float32), dep, ssh, fields['z'], Kp, dt, 60.0, 0, uni)
             orc.vertical_advection(z, mv, ww, dt)
+        elif name == 'c5':
+            ids = [orc.VAR[n] for n in (XW, YW, U, V, LAND)]
+            xw, yw, u, v, land = orc.get_environment(w, ids, lon, lat, z, t)
+            r = np.random.default_rng(k)
+            u = (u.astype(np.float64) + r.normal(0, 0.1, n_cpu)).astype(np.float32)      # drift:current_uncertainty
+            v = (v.astype(np.float64) + r.normal(0, 0.1, n_cpu)).astype(np.float32)
+            xw = (xw.astype(np.float64) + r.normal(0, 2.0, n_cpu)).astype(np.float32)    # drift:wind_uncertainty
+            yw = (yw.astype(np.float64) + r.normal(0, 2.0, n_cpu)).astype(np.float32)
+            orc.leeway(lon, lat, mv, aux, xw, yw, u, v, dt, 0.4, r.uniform(size=n_cpu))
         else:
             ids = [orc.VAR[n] for n in (U, V, XW, YW, SX, SY, LAND, HD)]
             u, v, xw, yw, sx, sy, land, hd = orc.get_environment(w, ids, lon, lat, z, t)
@@ -283,7 +292,7 @@ def main():
         g = fields['g']
         if a.workload == 'c3':
             ix = np.searchsorted(g['x'], lon); iy = np.searchsorted(g['y'], lat)
-            o = np.lexsort((ix, iy)) if False else np.argsort((iy // 8) * 100000 + (ix // 8) * 64 + (iy % 8) * 8 + ix % 8, kind='stable')
+            o = np.argsort((iy // 8) * 100000 + (ix // 8) * 64 + (iy % 8) * 8 + ix % 8, kind='stable')
             lon, lat, z = lon[o], lat[o], z[o]
     lo, hi = D.shard_range(n * world, rank, world)     # global particle IDs of this shard
     P = ctx.particles(n)
@@ -356,7 +365,9 @@ def main():
             traffic = (pm['FETCH_SIZE_bytes'] + pm['WRITE_SIZE_bytes']) / 1e9
     if rank == 0:
         out = {
-            'metric': 'particle-steps/sec (RK4, 3D interp)', 'value': units / el_max, 'unit': 'particle-steps/s',
+            'metric': {'c3': 'particle-steps/sec (RK4, 3D interp)', 'c2': 'particle-steps/sec (RK4, analytic field)',
+                       'c4': 'particle-steps/sec (RK4, 2D interp + wind + Stokes + diffusion)',
+                       'c5': 'particle-steps/sec (Leeway, Euler)'}[a.workload], 'value': units / el_max, 'unit': 'particle-steps/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * el_max / a.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
             'data': 'synthetic',

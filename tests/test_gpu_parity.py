@@ -349,7 +349,6 @@ def test_coastline_and_compaction(ctx):
     # 'previous': back to the position of the last environment sample
     Q = ctx.particles(n)
     Q.append(lon, lat)
-    Q.env_sample([U], 0.0) if False else None
     Q.env_upload('land_binary_mask', land)
     Q.store_previous()
     Q.update_positions(np.full(n, 0.5), np.full(n, 0.5), 600.0)
