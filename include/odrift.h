@@ -193,7 +193,11 @@ int odr_stokes_drift(odr_ctx *ctx, odr_particles *p, double dt, int profile, int
 int odr_particles_set_property(odr_ctx *ctx, odr_particles *p, int slot, int64_t offset, int64_t count,
                                const float *host);
 int odr_particles_get_property(odr_ctx *ctx, odr_particles *p, int slot, float *host);
-/* Leeway.update (models/leeway.py:430-494, processes:capsizing off): leeway from wind, current,
+/* processes:capsizing (models/leeway.py:438-455): call before odr_leeway.  host_uniforms (ODR_RNG_HOST): one number
+ * per element, used by those that can be capsized */
+int odr_leeway_capsize(odr_ctx *ctx, odr_particles *p, double dt, double wind_threshold, double wind_threshold_sigma,
+                       int rng_mode, const double *host_uniforms, uint64_t step);
+/* Leeway.update (models/leeway.py:430-494, after the capsizing block): leeway from wind, current,
  * jibing; host_uniforms[i] = np.random.random draws in ODR_RNG_HOST mode */
 int odr_leeway(odr_ctx *ctx, odr_particles *p, double dt, double capsize_leeway_fraction, int rng_mode,
                const double *host_uniforms, uint64_t step);

@@ -1217,6 +1217,31 @@ __global__ __launch_bounds__(BLOCK) void k_leeway(PView p, double dt, float caps
   }
 }
 
+// processes:capsizing (models/leeway.py:438-455): before the leeway is formed, an element that can be capsized
+// (capsized == 0 in a forward run; == 1, i.e. un-capsizing, in a backward run) flips with probability
+// (0.5 + 0.5 tanh((windspeed - threshold) / sigma)) * |dt| / 3600, float32 like the reference's array expression
+constexpr unsigned long long RNG_OFF_CAPSIZE = 4864;
+__global__ __launch_bounds__(BLOCK) void k_capsize(PView p, double dt, float threshold, float sigma, int rng_mode,
+                                                   const double *__restrict__ huni, unsigned long long seed,
+                                                   unsigned long long step) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  const float from = dt >= 0 ? 0.0f : 1.0f;
+  const float cap = p.aux[AUX_CAPSIZED][i];
+  if (cap != from) return;
+  const float ws = speed_f32(p.env[VAR_XWIND][i], p.env[VAR_YWIND][i]);
+  const float th = (float)tanh((double)__fdiv_rn(__fsub_rn(ws, threshold), sigma));
+  const float prob = __fmul_rn(__fadd_rn(0.5f, __fmul_rn(0.5f, th)), (float)(fabs(dt) / 3600));
+  double u01;
+  if (rng_mode == 1) u01 = huni[i];
+  else {
+    rocrand_state_philox4x32_10 st;
+    rng_init(st, seed, p.id[i], step, RNG_OFF_CAPSIZE);
+    u01 = rocrand_uniform_double2(&st).x;
+  }
+  if (u01 < (double)prob) p.aux[AUX_CAPSIZED][i] = 1.0f - cap;
+}
+
 // ------------------------------------------------------------ spatial re-ordering
 // Memory order of the particle SoA is a device-side layout choice (particles are identified
 // by ID, the RNG is counter-based on ID): binning the particles by the grid cell of one

@@ -1183,6 +1183,26 @@ int odr_leeway(odr_ctx *c, odr_particles *p, double dt, double capsize_fraction,
   return 0;
 }
 
+// processes:capsizing of Leeway.update (models/leeway.py:438-455); call before odr_leeway
+int odr_leeway_capsize(odr_ctx *c, odr_particles *p, double dt, double wind_threshold, double wind_threshold_sigma,
+                       int rng_mode, const double *huni, uint64_t step) {
+  p->epoch++;
+  if (!p->aux[8]) return fail(ODR_ERR_STATE, "Leeway property slot 8 (capsized) has not been set");
+  if (!p->env[VAR_XWIND] || !p->env[VAR_YWIND]) return fail(ODR_ERR_STATE, "wind must be sampled before odr_leeway_capsize");
+  REQUIRE(wind_threshold_sigma > 0, "capsizing:wind_threshold_sigma must be positive");
+  if (p->n == 0) return 0;
+  double *du = nullptr, *dummy = nullptr;
+  if (rng_mode == ODR_RNG_HOST) {
+    REQUIRE(huni, "host uniforms required in ODR_RNG_HOST mode");
+    int rc = host_to_scratch(c, p, huni, nullptr, (size_t)p->n, &du, &dummy);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_capsize, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, (float)wind_threshold,
+                     (float)wind_threshold_sigma, rng_mode, du, c->seed, (unsigned long long)step);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static int reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind, bool wind_args_matter = true) {
   if (!p->external && c->red_owner == p && c->red_epoch == p->epoch &&
       (!wind_args_matter || (c->red_wdd == wdd && c->red_rel == relwind)))

@@ -363,6 +363,23 @@ class Particles:
         rank[np.argsort(ids, kind='stable')] = np.arange(n)
         return np.ascontiguousarray(a[..., rank])
 
+    def leeway_capsize(self, dt, wind_threshold=30.0, wind_threshold_sigma=5.0, step=0, uniforms=None):
+        """processes:capsizing (leeway.py:438-455).  uniforms (RNG_HOST parity mode) = np.random.rand(len(can_be_capsized))
+        in the reference's order (ascending ID of the elements that can be capsized)."""
+        if uniforms is not None:
+            n = len(self)
+            cap = self.get_property(8)
+            can = np.nonzero(cap == (0.0 if dt >= 0 else 1.0))[0]
+            order = can[np.argsort(self.ids()[can], kind='stable')]      # reference order of those elements
+            full = np.zeros(n)
+            full[order] = np.asarray(uniforms, dtype=np.float64)[:len(order)]
+            a, pa = _d(full, n)
+            check(self.lib.odr_leeway_capsize(self.ctx.h, self.h, float(dt), float(wind_threshold),
+                                              float(wind_threshold_sigma), _abi.RNG_HOST, pa, step))
+        else:
+            check(self.lib.odr_leeway_capsize(self.ctx.h, self.h, float(dt), float(wind_threshold),
+                                              float(wind_threshold_sigma), _abi.RNG_DEVICE, None, step))
+
     def leeway(self, dt, capsize_fraction=0.4, step=0, uniforms=None):
         if uniforms is not None:
             u, pu = _d(self._host_order(uniforms), len(self))

@@ -8,7 +8,7 @@ random jibing) -- the update is one HIP kernel (odr_leeway).
 The object-class table OBJECTPROP.DAT is a data file of the reference and is not shipped: pass the nine
 coefficients of the class as `leeway_coefficients=dict(DWSLOPE=..., DWOFFSET=..., DWSTD=..., CWRSLOPE=...,
 CWROFFSET=..., CWRSTD=..., CWLSLOPE=..., CWLOFFSET=..., CWLSTD=...)` or read them with
-`read_objectprop(path_to_OBJECTPROP.DAT)[object_type]`.  Capsizing (`processes:capsizing`) and the ASCII
+`read_objectprop(path_to_OBJECTPROP.DAT)[object_type]`.  Capsizing (`processes:capsizing`) runs on the device; the ASCII
 export are host bookkeeping outside the path.
 """
 import numpy as np
@@ -53,6 +53,10 @@ class Leeway(OpenDriftSimulation):
             'processes:capsizing': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_BASIC, 'description': ''},
             'capsizing:leeway_fraction': {'type': 'float', 'default': 0.4, 'min': 0, 'max': 1,
                                           'level': CONFIG_LEVEL_BASIC, 'description': ''},
+            'capsizing:wind_threshold': {'type': 'float', 'default': 30, 'min': 0, 'max': 50,
+                                         'level': CONFIG_LEVEL_BASIC, 'description': ''},          # leeway.py:262-281
+            'capsizing:wind_threshold_sigma': {'type': 'float', 'default': 5, 'min': 0, 'max': 20,
+                                               'level': CONFIG_LEVEL_BASIC, 'description': ''},
             'drift:stokes_drift': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
         })
         self._set_config_default('drift:max_speed', 5)
@@ -93,10 +97,16 @@ class Leeway(OpenDriftSimulation):
             self._sched[k] = v if n_before == 0 else np.concatenate([self._sched[k], v])
 
     def update(self):   # leeway.py:430-494
-        if self.get_config('processes:capsizing'):
-            raise NotImplementedError('capsizing is host bookkeeping outside the hot path')
         dt = self.time_step.total_seconds()
         frac = self.get_config('capsizing:leeway_fraction')
+        if self.get_config('processes:capsizing'):   # :438-455
+            thr, sig = self.get_config('capsizing:wind_threshold'), self.get_config('capsizing:wind_threshold_sigma')
+            if self.rng == 'numpy':
+                can = int((self.P.get_property(8) == (0.0 if dt >= 0 else 1.0)).sum())
+                if can > 0:
+                    self.P.leeway_capsize(dt, thr, sig, uniforms=np.random.rand(can))
+            else:
+                self.P.leeway_capsize(dt, thr, sig, step=self.steps_calculation)
         if self.rng == 'numpy':
             self.P.leeway(dt, frac, uniforms=np.random.random(self.num_elements_active()))
         else:

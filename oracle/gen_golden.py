@@ -177,9 +177,10 @@ def c4_stere():
                         wdf=0.03, **{('g_' + k): v for k, v in g.items()}, **res)
 
 
-def c5_leeway():
+def c5_leeway(capsizing=False):
     """C5-shaped: Leeway (object class 1, PIW-1) on the C4 stere grid with per-element wind / current
-    uncertainty; Euler by construction (leeway.py:472-476); jibing."""
+    uncertainty; Euler by construction (leeway.py:472-476); jibing.  capsizing=True: processes:capsizing with a
+    wind threshold inside the wind range of the block (leeway.py:438-455) -> c5b_leeway_capsizing.npz."""
     from opendrift.models.leeway import Leeway
     g = synth.grid_stere(nx=70, ny=50, nt=3, seed=5)
     times = [T0 + timedelta(seconds=float(t)) for t in g['t']]
@@ -192,6 +193,11 @@ def c5_leeway():
     o.set_config('drift:current_uncertainty', 0.1)
     o.set_config('general:coastline_action', 'stranding')
     o.set_config('seed:jibe_probability', 0.5)      # make jibing visible within a few steps
+    if capsizing:
+        o.set_config('processes:capsizing', True)
+        o.set_config('capsizing:wind_threshold', 8.0)
+        o.set_config('capsizing:wind_threshold_sigma', 2.0)
+        o.set_config('capsizing:leeway_fraction', 0.4)
     rng = np.random.default_rng(6)
     N = 300
     x = rng.uniform(g['x'][5], g['x'][int(0.8 * len(g['x']))], N)
@@ -212,11 +218,22 @@ def c5_leeway():
         for j, a in enumerate(nrm[k][:4]):
             normals[k, j, :len(a)] = a
         uniforms[k, :len(uni[k][0])] = uni[k][0]
-    np.savez_compressed(os.path.join(GOLD, 'c5_leeway_stere.npz'), dt=600.0, normals=normals, uniforms=uniforms,
+    extra = {}
+    if capsizing:   # np.random.rand(len(can_be_capsized)) per step, drawn before the jibing random()
+        cap = [[d[1] for d in step if d[0] == 'rand'] for step in draws]
+        cu = np.full((len(cap), N), np.nan)
+        for k in range(len(cap)):
+            if cap[k]:
+                cu[k, :len(cap[k][0])] = cap[k][0]
+        extra = dict(cap_uniforms=cu, wind_threshold=8.0, wind_threshold_sigma=2.0, capsized_final=np.array(o.elements.capsized),
+                     ID_final=np.array(o.elements.ID))
+    np.savez_compressed(os.path.join(GOLD, 'c5b_leeway_capsizing.npz' if capsizing else 'c5_leeway_stere.npz'), dt=600.0,
+                        normals=normals, uniforms=uniforms, **extra,
                         **{('p_' + k): v for k, v in props.items()}, **{('g_' + k): v for k, v in g.items()}, **res)
 
 
-SCEN = dict(c1=c1_constant, c2=c2_double_gyre, c3=c3_grid3d, c4=c4_stere, c5=c5_leeway)
+SCEN = dict(c1=c1_constant, c2=c2_double_gyre, c3=c3_grid3d, c4=c4_stere, c5=c5_leeway,
+            c5b=lambda: c5_leeway(capsizing=True))
 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)

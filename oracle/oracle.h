@@ -144,11 +144,12 @@ void orc_vertical_mixing(long n, double *z, const int *moving, const float *tv,
 void orc_vertical_advection(long n, double *z, const int *moving, const float *w,
                             double dt, int at_surface);
 
-/* Leeway.update (models/leeway.py:430-494), capsizing off; aux[9][n] = LeewayObj properties in the
+/* Leeway.update (models/leeway.py:430-494); capsizing when cap_uniforms != NULL; aux[9][n] = LeewayObj properties in the
  * slot order of include/odrift.h; uniforms = np.random.random(n) of the jibing draw */
 void orc_leeway(long n, double *lon, double *lat, const int *moving, float *const *aux,
                 const float *xwind, const float *ywind, const float *u, const float *v, double dt,
-                double capsize_fraction, const double *uniforms);
+                double capsize_fraction, const double *uniforms, const double *cap_uniforms,
+                double wind_threshold, double wind_threshold_sigma);
 
 /* interact_with_coastline 'stranding' / 'previous' (basemodel/__init__.py:670-746), precision None */
 void orc_coastline(long n, int action, const float *land, double *lon, double *lat,

@@ -352,10 +352,14 @@ def coastline(action, land, lon, lat, z, prev_lon, prev_lat, status, moving, str
                         C.c_int(seeded_on_land_code))
 
 
-def leeway(lon, lat, moving, aux, xwind, ywind, u, v, dt, capsize_fraction, uniforms):
-    """aux: list of 9 float32 arrays (mutated: crosswind_slope / orientation flip on jibing)."""
+def leeway(lon, lat, moving, aux, xwind, ywind, u, v, dt, capsize_fraction, uniforms, cap_uniforms=None,
+           wind_threshold=30.0, wind_threshold_sigma=5.0):
+    """aux: list of 9 float32 arrays (mutated: crosswind_slope / orientation flip on jibing, capsized).
+    cap_uniforms: np.random.rand(len(can_be_capsized)) of processes:capsizing, or None (capsizing off)."""
     n = lon.size
     ptrs = (C.POINTER(C.c_float) * 9)(*[_p(a, C.c_float) for a in aux])
+    cu = None if cap_uniforms is None else _d(np.concatenate([np.asarray(cap_uniforms, dtype=np.float64), [0.0]]))
     lib().orc_leeway(C.c_long(n), _p(lon, C.c_double), _p(lat, C.c_double), _p(_i(moving), C.c_int), ptrs,
                      _p(_f(xwind), C.c_float), _p(_f(ywind), C.c_float), _p(_f(u), C.c_float), _p(_f(v), C.c_float),
-                     C.c_double(dt), C.c_double(capsize_fraction), _p(_d(uniforms), C.c_double))
+                     C.c_double(dt), C.c_double(capsize_fraction), _p(_d(uniforms), C.c_double),
+                     None if cu is None else _p(cu, C.c_double), C.c_double(wind_threshold), C.c_double(wind_threshold_sigma))

@@ -15,14 +15,19 @@ import numpy as np
 
 
 class RecordingRandom:
-    """Context manager: records every np.random.random / normal / uniform draw in call order."""
+    """Context manager: records every np.random.random / normal / uniform / rand draw in call order."""
 
     def __init__(self):
         self.draws = []
 
     def __enter__(self):
-        self._orig = (np.random.random, np.random.normal, np.random.uniform)
+        self._orig = (np.random.random, np.random.normal, np.random.uniform, np.random.rand)
         rec = self
+
+        def rand(*shape):
+            r = rec._orig[3](*shape)
+            rec.draws.append(('rand', np.array(r, copy=True)))
+            return r
 
         def random(size=None):
             r = rec._orig[0](size)
@@ -39,11 +44,11 @@ class RecordingRandom:
             rec.draws.append(('uniform', np.array(r, copy=True), low, high))
             return r
 
-        np.random.random, np.random.normal, np.random.uniform = random, normal, uniform
+        np.random.random, np.random.normal, np.random.uniform, np.random.rand = random, normal, uniform, rand
         return self
 
     def __exit__(self, *a):
-        np.random.random, np.random.normal, np.random.uniform = self._orig
+        np.random.random, np.random.normal, np.random.uniform, np.random.rand = self._orig
 
 
 class RefStepper:

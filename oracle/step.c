@@ -704,13 +704,35 @@ void orc_coastline(long n, int action, const float *land, double *lon, double *l
 }
 
 /* ------------------------------------------------------------------ */
-/* Leeway.update, models/leeway.py:430-494 (processes:capsizing off)    */
+/* Leeway.update, models/leeway.py:430-494.  processes:capsizing (:438-455): cap_uniforms != NULL     */
+/* holds np.random.rand(len(can_be_capsized)) in element order; forward runs capsize (0 -> 1), backward */
+/* runs un-capsize (1 -> 0)                                                                            */
 /* ------------------------------------------------------------------ */
 void orc_leeway(long n, double *lon, double *lat, const int *moving, float *const *aux,
                 const float *xwind, const float *ywind, const float *u, const float *v, double dt,
-                double capsize_fraction, const double *uniforms) {
+                double capsize_fraction, const double *uniforms, const double *cap_uniforms,
+                double wind_threshold, double wind_threshold_sigma) {
   float *xl = (float *)malloc(sizeof(float) * (size_t)n), *yl = (float *)malloc(sizeof(float) * (size_t)n);
   long i;
+  if (cap_uniforms) {
+    const float from = dt >= 0 ? 0.0f : 1.0f;   /* simulation_direction() (basemodel/__init__.py:4524-4529) */
+    const double scale = fabs(dt) / 3600;        /* python floats */
+    long j = 0;
+    for (i = 0; i < n; ++i) {
+      if (aux[8][i] != from) continue;
+      {
+        float ws = speed_f32(xwind[i], ywind[i]);
+        volatile float a = ws - (float)wind_threshold;     /* float32 array with python scalars: float32 */
+        volatile float b = a / (float)wind_threshold_sigma;
+        volatile float th = (float)tanh((double)b);
+        volatile float c = 0.5f * th;
+        volatile float pr = 0.5f + c;
+        volatile float prob = pr * (float)scale;
+        if (cap_uniforms[j] < (double)prob) aux[8][i] = 1.0f - aux[8][i];
+        ++j;
+      }
+    }
+  }
   for (i = 0; i < n; ++i) {
     float ws = speed_f32(xwind[i], ywind[i]);
     float wd = (float)atan2((double)xwind[i], (double)ywind[i]);

@@ -101,10 +101,13 @@ class OracleBackend:
         self.env[vx] = (self.env[vx].astype(np.float64) + nx[:n]).astype(np.float32)
         self.env[vy] = (self.env[vy].astype(np.float64) + ny[:n]).astype(np.float32)
 
-    def leeway(self, dt, uniforms, frac=0.4):
+    def leeway(self, dt, uniforms, frac=0.4, cap_uniforms=None, thr=30.0, sig=5.0):
         n = len(self.lon)
+        cu = None
+        if cap_uniforms is not None:
+            cu = cap_uniforms[:int((self.aux[8] == (0.0 if dt >= 0 else 1.0)).sum())]
         orc.leeway(self.lon, self.lat, self.moving, self.aux, self.env[XW], self.env[YW], self.env[U], self.env[VV],
-                   dt, frac, uniforms[:n])
+                   dt, frac, uniforms[:n], cap_uniforms=cu, wind_threshold=thr, wind_threshold_sigma=sig)
 
     def vmix(self, t, dt, dt_mix, zlevels, uniforms, vadv=True):
         orc.vertical_mixing(self.z, self.moving, self.tv, self.env[DEPTH], self.env[SSH], zlevels, self.Kp, dt,
@@ -168,7 +171,9 @@ class DeviceBackend:
         n = len(self.P)
         self.P.env_add_noise(vx, vy, 1.0, normals=(nx[:n], ny[:n]))
 
-    def leeway(self, dt, uniforms, frac=0.4):
+    def leeway(self, dt, uniforms, frac=0.4, cap_uniforms=None, thr=30.0, sig=5.0):
+        if cap_uniforms is not None:
+            self.P.leeway_capsize(dt, thr, sig, uniforms=cap_uniforms)
         self.P.leeway(dt, frac, uniforms=uniforms[:len(self.P)])
 
     def vmix(self, t, dt, dt_mix, zlevels, uniforms, vadv=True):
@@ -240,7 +245,11 @@ def replay_c5(B, g, nsteps):
         B.increase_age(dt)
         B.compact()
         B.store_previous()
-        B.leeway(dt, g['uniforms'][k])
+        if 'cap_uniforms' in g:    # processes:capsizing golden (c5b)
+            B.leeway(dt, g['uniforms'][k], cap_uniforms=g['cap_uniforms'][k], thr=float(g['wind_threshold']),
+                     sig=float(g['wind_threshold_sigma']))
+        else:
+            B.leeway(dt, g['uniforms'][k])
         out.append(B.state(n))
     return out
 

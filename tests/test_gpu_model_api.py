@@ -216,6 +216,39 @@ def test_c5_leeway_model_run_numpy_rng():
     assert np.abs(lon - g['lon'][-1]).max() < 1e-7 and np.abs(lat - g['lat'][-1]).max() < 1e-7
 
 
+def test_c5b_leeway_capsizing_model_run_numpy_rng():
+    from opendrift_amd.leeway import Leeway
+    g = golden('c5b_leeway_capsizing.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'x_wind', 'y_wind', 'land_binary_mask']
+    o = Leeway(loglevel=50, seed=0, rng='numpy')
+    o.add_reader(_grid_reader(g, names, proj4=synth.NORKYST_PROJ4))
+    o.set_config('drift:wind_uncertainty', 2.0)
+    o.set_config('drift:current_uncertainty', 0.1)
+    o.set_config('processes:capsizing', True)
+    o.set_config('capsizing:wind_threshold', 8.0)
+    o.set_config('capsizing:wind_threshold_sigma', 2.0)
+    props = {k: g['p_' + k] for k in ('downwind_slope', 'crosswind_slope', 'downwind_offset', 'crosswind_offset',
+                                      'downwind_eps', 'crosswind_eps', 'orientation', 'capsized')}
+    o.seed_elements(lon=g['lon'][0], lat=g['lat'][0], time=T0, jibe_probability=0.5, **props)
+    # position of the reference's np.random stream after its seeding (see test_c5_leeway_model_run_numpy_rng)
+    n = g['lon'].shape[1]
+    o2 = Leeway(loglevel=50, seed=0, rng='numpy')
+    np.random.seed(0)
+    dwstd = float(g['p_downwind_eps'][0]) / np.random.randn(1)[0]
+    coeff = dict(DWSLOPE=float(g['p_downwind_slope'][0]), DWOFFSET=float(g['p_downwind_offset'][0]), DWSTD=dwstd,
+                 CWRSLOPE=float(g['p_crosswind_slope'][0]), CWROFFSET=float(g['p_crosswind_offset'][0]), CWRSTD=1.0,
+                 CWLSLOPE=float(g['p_crosswind_slope'][1]), CWLOFFSET=float(g['p_crosswind_offset'][1]), CWLSTD=1.0)
+    np.random.seed(0)
+    o2.seed_elements(lon=g['lon'][0], lat=g['lat'][0], time=T0, leeway_coefficients=coeff)
+    o.run(time_step=600, steps=8)
+    lon, lat, _ = _final(o, n)
+    assert np.abs(lon - g['lon'][-1]).max() < 1e-7 and np.abs(lat - g['lat'][-1]).max() < 1e-7
+    e = o.elements
+    ref = np.full(n, -1.0)
+    ref[g['ID_final']] = g['capsized_final']
+    assert (o.P.get_property(8) == ref[e.ID]).all()
+
+
 # ---- known answers of the reference's own tests (tests/models/test_run.py), no files needed ----
 def test_reference_kat_retirement():
     """tests/models/test_run.py:759-770"""

@@ -445,3 +445,18 @@ def test_c5_leeway_golden_device(ctx):
     cw = D.P.get_property(1)
     assert (np.sign(cw) != np.sign(g['p_crosswind_slope'][D.P.download()['ID']])).any()    # some elements jibed
     print('c5 device vs reference:', worst)
+
+
+def test_c5b_leeway_capsizing_golden_device(ctx):
+    """processes:capsizing on the device (k_capsize before k_leeway) vs the reference Leeway's own run."""
+    import replay
+    g = golden('c5b_leeway_capsizing.npz')
+    nst = g['lon'].shape[0] - 1
+    D = replay.DeviceBackend(replay.scenario_c5(g), ctx, g['lon'][0], g['lat'][0], g['z'][0])
+    dev = replay.replay_c5(D, g, nst)
+    worst = replay.compare(dev, g, tol_pos=1e-7)
+    ids, cap = D.P.download()['ID'], D.P.get_property(8)
+    ref = np.full(g['lon'].shape[1], -1.0)
+    ref[g['ID_final']] = g['capsized_final']
+    assert (cap == ref[ids]).all() and cap.sum() > 50        # the same elements capsized
+    print('c5b device vs reference:', worst)

@@ -153,3 +153,17 @@ def test_c5_leeway_golden_vs_oracle():
     B = replay.OracleBackend(replay.scenario_c5(g), g['lon'][0], g['lat'][0], g['z'][0])
     worst = replay.compare(replay.replay_c5(B, g, g['lon'].shape[0] - 1), g, tol_pos=1e-7)
     print('c5 oracle vs reference:', worst)
+
+
+def test_c5b_leeway_capsizing_golden_vs_oracle():
+    """processes:capsizing (leeway.py:438-455) against the reference Leeway's own run: positions and the final set of
+    capsized elements."""
+    g = golden('c5b_leeway_capsizing.npz')
+    B = replay.OracleBackend(replay.scenario_c5(g), g['lon'][0], g['lat'][0], g['z'][0])
+    worst = replay.compare(replay.replay_c5(B, g, g['lon'].shape[0] - 1), g, tol_pos=1e-7)
+    cap = np.zeros(g['lon'].shape[1])
+    cap[B.ID] = B.aux[8]
+    ref = np.zeros(g['lon'].shape[1])
+    ref[g['ID_final']] = g['capsized_final']
+    assert (cap[g['ID_final']] == ref[g['ID_final']]).all() and ref.sum() > 50
+    print('c5b oracle vs reference:', worst)
