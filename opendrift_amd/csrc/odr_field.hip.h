@@ -513,6 +513,74 @@ __device__ __forceinline__ void env_group(const DevWorld &W, const int (&vars)[N
 }
 
 
+// ------------------------------------------------------- analytic double gyre, fast path
+// reader_double_gyre (readers/reader_double_gyre.py:24-79) as the only source of the current: equatorial
+// stereographic projection on a sphere.  Same arithmetic as source_sample() to round-off, organised for the
+// vector pipe: sin(omega t) is wave-uniform (host), sin / cos of the small lon / lat by the reduced-range
+// kernels, sin / cos of pi f and pi y by sincospi, and the rotation of the vector to east / north
+// (rotate_vectors, variables.py:59-109) WITHOUT any transcendental call: for the 10 m line (x,y) -> (x,y+10)
+// the differences of the two inverse projections are, at the mid point, d(sin phi)/dy and d(tan lambda)/dy in
+// closed form (sin c and cos c of the inverse are rational in t = rho / 2k0), central differences being exact
+// to O((10 m / R)^3); the WGS84 Gauss mid-latitude azimuth is then a normalised 2-vector plus a first-order
+// rotation by the half meridian convergence.
+struct GyreTime { double sn; };  // sin(omega (t - t0)) of one evaluation time
+
+__device__ __forceinline__ void rotation_cs_equit(const DevProj &p, double x, double y, double &cs, double &sn) {
+#pragma clang fp contract(fast)
+  const GeodConst &g = c_geod;
+  const double inva = fast_rcp(p.a), ik = fast_rcp(p.akm1);
+  const double X = (x - p.x0) * inva, Y = (y + 5.0 - p.y0) * inva, h = 10.0 * inva;
+  const double t2 = (X * X + Y * Y) * ik * ik, D = 1 + t2, iD = fast_rcp(D);
+  const double S = 2 * Y * ik * iD;                                   // sin(phi_m)
+  const double S_Y = 2 * ik * iD * (1 - 2 * Y * Y * ik * ik * iD);    // d sin(phi) / dY
+  const double cphi = fast_sqrt(1 - S * S);
+  const double dphi = S_Y * h * fast_rcp(cphi);
+  const double P = 2 * X * ik, Q = 1 - t2;
+  const double dlam = P * 2 * Y * ik * ik * h * fast_rcp(P * P + Q * Q);
+  const double w2 = 1 - g.e2 * S * S, iw = fast_rsqrt(w2);
+  const double N = g.a * iw, M = g.a * (1 - g.e2) * iw * iw * iw;
+  const double east = dlam * N * cphi, north = dphi * M;
+  const double ir = fast_rsqrt(east * east + north * north);
+  const double sa = east * ir, ca = north * ir;                       // sin, cos of the mid-point azimuth
+  const double d = -0.5 * dlam * S, cd = 1 - 0.5 * d * d;             // az1 = az_mid + d
+  const double s1 = sa * cd + ca * d, c1 = ca * cd - sa * d;
+  cs = c1;    // rot_angle_rad = -az1
+  sn = -s1;
+}
+
+// (u, v) float32 environment of one particle from the double gyre source `s`
+__device__ __forceinline__ bool gyre_sample(const DevSource &s, double lon, double lat, double z, double snw,
+                                            float fbu, float fbv, float &uo, float &vo) {
+#pragma clang fp contract(fast)
+  if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
+  else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
+  const DevProj &p = s.proj;
+  double lam = wrap_pi(lon * kDeg - p.lon0), phi = lat * kDeg;
+  double sl, cl, sp, cp;
+  sincos_small(lam, sl, cl);
+  sincos_small(phi, sp, cp);
+  const double k = p.akm1 * fast_rcp(1 + cp * cl);
+  const double x = p.a * (k * cp * sl) + p.x0, y = p.a * (k * sp) + p.y0;
+  float fu = __builtin_nanf(""), fv = __builtin_nanf("");
+  const bool covered = x >= s.xmin && x <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin && z <= s.zmax;
+  if (covered) {
+    const double A = s.params[0], eps = s.params[1];
+    const double a = eps * snw, b = 1 - 2 * eps * snw;
+    const double f = a * x * x + b * x, dfdx = 2 * a * x + b;
+    double sf, cf, sy, cy;
+    sincospi(f, &sf, &cf);
+    sincospi(y, &sy, &cy);
+    double u = -kPi * A * sf * cy, v = kPi * A * cf * sy * dfdx;
+    double cs, sn;
+    rotation_cs_equit(p, x, y, cs, sn);
+    fu = (float)__dsub_rn(__dmul_rn(u, cs), __dmul_rn(v, sn));
+    fv = (float)__dadd_rn(__dmul_rn(u, sn), __dmul_rn(v, cs));
+  }
+  uo = isfinite(fu) ? fu : (isfinite(fbu) ? fbu : fu);
+  vo = isfinite(fv) ? fv : (isfinite(fbv) ? fbv : fv);
+  return covered;
+}
+
 // ------------------------------------------------------------------ fast (u,v) path
 // The common case of the RK sub-stages: x/y_sea_water_velocity come from ONE gridded reader
 // (plus the fallback constant).  The time bracket of each stage is the same for every

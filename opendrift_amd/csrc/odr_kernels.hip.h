@@ -356,6 +356,62 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevW
   }
 }
 
+// analytic double gyre as the only source of the current (odr_field.hip.h "analytic double gyre, fast path")
+__global__ __launch_bounds__(BLOCK) void k_env_gyre(const DevWorld *__restrict__ W, int sid, PView p, double snw,
+                                                    int with_land, int record_prev) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  const DevSource &s = W->src[sid];
+  const double lon = p.lon[i], lat = p.lat[i];
+  float u, v;
+  const bool covered = gyre_sample(s, lon, lat, p.z[i], snw, W->fallback[VAR_U], W->fallback[VAR_V], u, v);
+  p.env[VAR_U][i] = u;
+  p.env[VAR_V][i] = v;
+  // the reader reports land_binary_mask = 0 inside its domain (reader_double_gyre.py:78)
+  if (with_land) p.env[VAR_LAND][i] = covered ? 0.0f : W->fallback[VAR_LAND];
+  if (record_prev) { p.slon[i] = lon; p.slat[i] = lat; }
+}
+
+template <int SCHEME>
+__global__ __launch_bounds__(BLOCK) void k_advect_gyre(const DevWorld *__restrict__ W, int sid, PView p, double dt,
+                                                       float factor, double snw_half, double snw_full) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  const DevSource &s = W->src[sid];
+  const float fbu = W->fallback[VAR_U], fbv = W->fallback[VAR_V];
+  double lon = p.lon[i], lat = p.lat[i];
+  const double z = p.z[i];
+  const float u1 = p.env[VAR_U][i], v1 = p.env[VAR_V][i];
+  const float f = __fmul_rn(factor, p.cdf[i]);
+  float fu, fv;
+  GeodOrigin o = geod_origin(lat, lon);
+  if (SCHEME == 0) {
+    fu = __fmul_rn(f, u1);
+    fv = __fmul_rn(f, v1);
+  } else {
+    const float dtf = (float)dt;
+    double lon2, lat2;
+    float u2, v2;
+    stage_pos(o, u1, v1, dtf, lon2, lat2);
+    gyre_sample(s, lon2, lat2, z, snw_half, fbu, fbv, u2, v2);
+    if (SCHEME == 1) {
+      fu = __fmul_rn(f, u2);
+      fv = __fmul_rn(f, v2);
+    } else {
+      float u3, v3, u4, v4;
+      stage_pos(o, u2, v2, dtf, lon2, lat2);
+      gyre_sample(s, lon2, lat2, z, snw_half, fbu, fbv, u3, v3);
+      stage_pos(o, u3, v3, dtf, lon2, lat2);
+      gyre_sample(s, lon2, lat2, z, snw_full, fbu, fbv, u4, v4);
+      fu = __fmul_rn(rk4_mix(u1, u2, u3, u4), f);
+      fv = __fmul_rn(rk4_mix(v1, v2, v3, v4), f);
+    }
+  }
+  move_f32_from(o, lon, lat, fu, fv, p.moving[i], dt);
+  p.lon[i] = lon;
+  p.lat[i] = lat;
+}
+
 // update_positions with velocities supplied by the caller
 __global__ __launch_bounds__(BLOCK) void k_update_positions(PView p, const double *u, const double *v,
                                                             int is_f32, double dt) {

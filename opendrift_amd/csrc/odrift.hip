@@ -843,6 +843,31 @@ static bool launch_env_grid(odr_ctx *c, odr_particles *p, const int *grp, int ng
   return true;
 }
 
+// fast path of odr_env_sample: {x,y}_sea_water_velocity (and land_binary_mask) served by one double-gyre reader
+static bool gyre_source(const odr_ctx *c, int var, int &sid) {
+  const DevWorld &w = c->hw;
+  if (w.nlist[var] != 1) return false;
+  sid = w.list[var][0];
+  const DevSource &s = w.src[sid];
+  return s.kind == SRC_DOUBLE_GYRE && s.proj.kind == PROJ_STERE_EQUIT_SPHERE && s.proj.es == 0 && !s.mod360_x;
+}
+static bool launch_env_gyre(odr_ctx *c, odr_particles *p, const int *grp, int ng, double t, int rec) {
+  bool has_u = false, has_v = false, has_land = false;
+  for (int k = 0; k < ng; ++k) {
+    if (grp[k] == VAR_U) has_u = true;
+    else if (grp[k] == VAR_V) has_v = true;
+    else if (grp[k] == VAR_LAND) has_land = true;
+    else return false;
+  }
+  int sid;
+  if (!has_u || !has_v || !gyre_source(c, VAR_U, sid)) return false;
+  const DevSource &s = c->hw.src[sid];
+  if (!s.always_valid && (t < s.tmin || t > s.tmax)) return false;
+  const double snw = sin(s.params[2] * (t - s.params[3]));
+  hipLaunchKernelGGL(k_env_gyre, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, c->dw, sid, view(p), snw, has_land ? 1 : 0, rec);
+  return true;
+}
+
 // ----------------------------------------------------------------- environment
 template <int NV>
 static void launch_group(odr_ctx *c, odr_particles *p, const int *vars, double t, int rec) {
@@ -892,6 +917,7 @@ static int env_sample_impl(odr_ctx *c, odr_particles *p, int nvars, const int32_
         continue;
       }
       if (!getenv("ODR_NO_FAST_PATH") && launch_env_grid(c, p, grp, ng, t, rec)) { rec = 0; continue; }
+      if (!getenv("ODR_NO_FAST_PATH") && launch_env_gyre(c, p, grp, ng, t, rec)) { rec = 0; continue; }
       // the whole group goes through one launch: the reference decides "static variables only"
       // and the missing-data mask per reader call on the full group (structured.py:224-229,
       // environment.py:727-746)
@@ -1032,8 +1058,16 @@ int odr_advect(odr_ctx *c, odr_particles *p, int scheme, double t, double dt, do
   if (p->n == 0) return 0;
   dim3 g(nblk(p->n)), b(BLOCK);
   PView v = view(p);
-  int sid = -1;
+  int sid = -1, gsid = -1;
   if (scheme == 0) hipLaunchKernelGGL(k_advect<0>, g, b, 0, c->stream, c->dw, v, t, dt, (float)factor);
+  else if (!getenv("ODR_NO_FAST_PATH") && gyre_source(c, VAR_U, gsid) && c->hw.nlist[VAR_V] == 1 &&
+           c->hw.list[VAR_V][0] == gsid &&
+           (c->hw.src[gsid].always_valid || (fmin(t, t + dt) >= c->hw.src[gsid].tmin && fmax(t, t + dt) <= c->hw.src[gsid].tmax))) {
+    const DevSource &gs = c->hw.src[gsid];
+    const double sh = sin(gs.params[2] * (t + dt / 2 - gs.params[3])), sf = sin(gs.params[2] * (t + dt - gs.params[3]));
+    if (scheme == 1) hipLaunchKernelGGL(k_advect_gyre<1>, g, b, 0, c->stream, c->dw, gsid, v, dt, (float)factor, sh, sf);
+    else hipLaunchKernelGGL(k_advect_gyre<2>, g, b, 0, c->stream, c->dw, gsid, v, dt, (float)factor, sh, sf);
+  }
   else if (uv_fast_source(c, sid, t < t + dt ? t : t + dt, t < t + dt ? t + dt : t) && !getenv("ODR_NO_FAST_PATH")) {
     if (scheme == 1) launch_advect_grid<1>(c, p, sid, t, dt, factor);
     else launch_advect_grid<2>(c, p, sid, t, dt, factor);

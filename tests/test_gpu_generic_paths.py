@@ -161,3 +161,33 @@ def test_priority_list_of_two_grids_and_a_constant_matches_oracle(ctx):
     orc.advect_ocean_current(w, 2, lo_, la_, z, np.ones(n, np.int32), np.ones(n, np.float32), ue, ve, 900.0, 600.0)
     d = P.download()
     assert np.abs(d['lon'] - lo_).max() < 1e-10 and np.abs(d['lat'] - la_).max() < 1e-10
+
+
+def test_double_gyre_fast_path_against_generic(ctx):
+    """The analytic double-gyre fast path (trig-free vector rotation, reduced-range sin / cos) against the generic
+    source_sample() walk: environment within one float32 ulp (the formulas agree to float64 round-off, the cast may
+    flip in rare cases), RK4 positions to 1e-12 degrees."""
+    from opendrift_amd.projection import stere_equit_sphere_inverse
+    sid = ctx.add_double_gyre(A=0.1, epsilon=0.25, omega=0.628, t0=0.0)
+    ctx.bind(U, [sid], 0.0)
+    ctx.bind(V, [sid], 0.0)
+    ctx.bind(LAND, [sid], np.nan)
+    rng = np.random.default_rng(3)
+    n = 50000
+    lon, lat = stere_equit_sphere_inverse(rng.uniform(-0.05, 2.05, n), rng.uniform(-0.05, 1.05, n), 6.371e6)
+
+    def fn(P):
+        e = P.env_sample([U, V, LAND], 3.3, download=True)
+        P.env_sample([U, V], 3.3)
+        P.advect('runge-kutta4', 3.3, 0.1)
+        P.env_sample([U, V], 3.4)
+        P.advect('runge-kutta', 3.4, 0.1)
+        return e
+
+    (a, ea), (b, eb) = _both(ctx, lon, lat, np.zeros(n), fn)
+    assert _eq(ea[LAND], eb[LAND]) and np.isnan(ea[LAND]).any() and (ea[LAND] == 0).any()
+    for k in (U, V):
+        ulp = np.spacing(np.abs(eb[k]).astype(np.float32))
+        assert (np.abs(ea[k] - eb[k]) <= ulp).all(), k
+        assert (ea[k] != eb[k]).mean() < 0.01
+    assert np.abs(a['lon'] - b['lon']).max() < 1e-12 and np.abs(a['lat'] - b['lat']).max() < 1e-12
