@@ -843,6 +843,24 @@ static bool launch_env_grid(odr_ctx *c, odr_particles *p, const int *grp, int ng
   return true;
 }
 
+// fast path of odr_env_sample: a group served by one constant reader that covers the globe and all times
+// (reader_constant.py:60-82): every element gets the constant, cast to float32 -- a fill per variable
+static bool launch_env_constant(odr_ctx *c, odr_particles *p, const int *grp, int ng, double t) {
+  const DevWorld &w = c->hw;
+  if (w.nlist[grp[0]] != 1) return false;
+  const DevSource &s = w.src[w.list[grp[0]][0]];
+  if (s.kind != SRC_CONSTANT || s.proj.kind != PROJ_LATLONG || s.lon_mode != 1) return false;
+  if (!(s.xmin <= -180 && s.xmax >= 180 && s.ymin <= -90 && s.ymax >= 90 && s.zmin == -INFINITY && s.zmax == INFINITY))
+    return false;
+  if (!s.always_valid && (t < s.tmin || t > s.tmax)) return false;
+  for (int k = 0; k < ng; ++k) {
+    float f = (float)s.const_val[grp[k]];
+    if (!std::isfinite(f)) f = std::isfinite(w.fallback[grp[k]]) ? w.fallback[grp[k]] : f;
+    hipLaunchKernelGGL(k_fill_f32, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->env[grp[k]], p->n, f);
+  }
+  return true;
+}
+
 // fast path of odr_env_sample: {x,y}_sea_water_velocity (and land_binary_mask) served by one double-gyre reader
 static bool gyre_source(const odr_ctx *c, int var, int &sid) {
   const DevWorld &w = c->hw;
@@ -918,6 +936,7 @@ static int env_sample_impl(odr_ctx *c, odr_particles *p, int nvars, const int32_
       }
       if (!getenv("ODR_NO_FAST_PATH") && launch_env_grid(c, p, grp, ng, t, rec)) { rec = 0; continue; }
       if (!getenv("ODR_NO_FAST_PATH") && launch_env_gyre(c, p, grp, ng, t, rec)) { rec = 0; continue; }
+      if (!getenv("ODR_NO_FAST_PATH") && launch_env_constant(c, p, grp, ng, t)) continue;   // (positions recorded below)
       // the whole group goes through one launch: the reference decides "static variables only"
       // and the missing-data mask per reader call on the full group (structured.py:224-229,
       // environment.py:727-746)
