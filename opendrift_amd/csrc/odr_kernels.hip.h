@@ -1337,8 +1337,19 @@ __global__ __launch_bounds__(BLOCK) void k_gather_perm(const unsigned *__restric
   long long j = (long long)blockIdx.x * BLOCK + threadIdx.x;
   if (j >= n) return;
   unsigned src = perm[j];
-  for (int k = 0; k < A.n64; ++k) A.dst64[k][j] = A.src64[k][src];
-  for (int k = 0; k < A.n32; ++k) A.dst32[k][j] = A.src32[k][src];
+  // eight gathers in flight, then eight stores (a plain load-store loop pays one memory round trip per array)
+  double v64[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) if (k < A.n64) v64[k] = A.src64[k][src];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) if (k < A.n64) A.dst64[k][j] = v64[k];
+  for (int k0 = 0; k0 < A.n32; k0 += 8) {
+    int v32[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k0 + k < A.n32) v32[k] = A.src32[k0 + k][src];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k0 + k < A.n32) A.dst32[k0 + k][j] = v32[k];
+  }
 }
 
 // ---------------------------------------------------------------- block preparation
