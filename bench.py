@@ -6,7 +6,7 @@
 A "step" is one pass of the per-timestep hot path over all particles of this rank with the
 inputs already resident in HBM (field blocks uploaded, particle SoA on device):
   c3 (default, "RK4, 3D interp"): spatial re-sort (every 16th step) -> ONE launch for Environment sample
-      (u,v,w,depth,ssh,landmask) + coastline 'previous' + previous state + RK4 advect_ocean_current (3 more 3D field
+      (u,v,w,depth,ssh,landmask) + coastline 'previous' + seafloor + age + previous state + RK4 advect_ocean_current (3 more 3D field
       evaluations + 4 geodesics) -> vertical_mixing (10 Visser sub-steps from the K profile) + vertical_advection;
       10 M particles, synthetic ROMS-shaped 1024x1024x12 z-level block, 2 time levels interpolated.
   c2: analytic double gyre, 1 M particles, RK4.
@@ -40,7 +40,7 @@ HD = 'horizontal_diffusivity'
 BYTES = {
     'c2': dict(step=48, advect=56),
     # fused = k_step_grid: environment sample of the group + coastline + previous + RK4
-    'c3': dict(step=908, advect=3 * 128 + 56, fused=(128 + 64 + 32 + 8) + 100 + 3 * 128),
+    'c3': dict(step=908, advect=3 * 128 + 56, fused=(128 + 64 + 32 + 8) + 112 + 3 * 128),   # state: + age r/w, ssh
     'c4': dict(step=436, advect=3 * 64 + 56, fused=(3 * 64 + 8) + 92 + 3 * 64),
     'c5': dict(step=220, advect=88),
 }
@@ -138,10 +138,12 @@ class Workload:
         elif self.name == 'c3':
             if self.fused:
                 P.env_coast_advect(self.vars, t, 'runge-kutta4', self.dt, coastline='previous', store_previous=True,
-                                   count=False)
+                                   count=False, seafloor=True, age_dt=self.dt)
             else:
                 P.env_sample(self.vars, t)
                 P.coastline('previous')
+                P.seafloor()
+                P.increase_age(self.dt)
                 P.store_previous()
                 P.advect('runge-kutta4', t, self.dt)
             P.vmix(t, self.dt, self.dt_mix, step=k, fuse_vertical_advection=False)

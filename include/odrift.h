@@ -168,15 +168,23 @@ int odr_env_add_noise(odr_ctx *ctx, odr_particles *p, int32_t var_x, int32_t var
 int odr_advect(odr_ctx *ctx, odr_particles *p, int scheme, double t_epoch, double dt, double factor);
 /* One iteration of the run() loop up to and including the current advection
  * (basemodel/__init__.py:2136-2248): odr_env_sample(var_ids, t) -> odr_coastline(action, codes) ->
- * odr_store_previous (if store_previous) -> odr_advect(scheme, t, dt, factor), fused into ONE kernel
+ * [odr_seafloor -> odr_increase_age, if `extras` asks for them] -> odr_store_previous (if store_previous) ->
+ * odr_advect(scheme, t, dt, factor), fused into ONE kernel
  * when the group holding x/y_sea_water_velocity comes from one gridded reader (else the four calls are
  * made in that order).  Elements the coastline deactivates ('stranded', 'seeded_on_land') are
  * flagged and left where the coastline put them -- the reference removes them before update() --
  * so  fused call + odr_compact  is bit-identical to  sample, coastline, compact, store_previous,
  * advect. */
+typedef struct {              /* optional bookkeeping of the same loop body, between the coastline and update_previous_state */
+  int32_t seafloor_action;    /* 1: interact_with_seafloor 'lift_to_seafloor' (:748-783), else none */
+  int32_t retired_code;       /* status of elements older than max_age_seconds */
+  double age_dt;              /* increase_age_and_retire (:2342-2352): age_seconds += age_dt; 0: not part of this call */
+  double max_age_seconds;     /* 0: no retirement */
+} odr_step_extras;
 int odr_env_coast_advect(odr_ctx *ctx, odr_particles *p, int nvars, const int32_t *var_ids, double t_epoch,
                          int coastline_action, int stranded_code, int seeded_on_land_code,
-                         int store_previous, int scheme, double dt, double factor, int64_t *n_on_land);
+                         int store_previous, int scheme, double dt, double factor,
+                         const odr_step_extras *extras /* NULL: none */, int64_t *n_on_land);
 /* update_positions with caller-supplied velocities (models that compute them on the host) */
 int odr_update_positions(odr_ctx *ctx, odr_particles *p, const double *x_vel, const double *y_vel,
                          int velocities_are_float32, double dt);
@@ -268,7 +276,10 @@ typedef struct odr_history odr_history;
 int odr_history_create(odr_ctx *ctx, int64_t n_trajectories, int32_t n_times, int32_t nvars,
                        const int32_t *var_codes, odr_history **out);
 int odr_history_destroy(odr_ctx *ctx, odr_history *h);
-int odr_history_record(odr_ctx *ctx, odr_particles *p, odr_history *h, int32_t time_index, int only_deactivated);
+/* position_from_previous: lon / lat are taken from the state saved by update_previous_state (odr_store_previous,
+ * odr_env_coast_advect) -- the position before this step's advection -- so that the record may follow the fused launch */
+int odr_history_record(odr_ctx *ctx, odr_particles *p, odr_history *h, int32_t time_index, int only_deactivated,
+                       int position_from_previous);
 /* asynchronous: extract time slots [t0, t0+nt) of every variable into pinned host memory as
  * [trajectory][time] float32 (the reference's dims); _wait blocks; _host_ptr is valid until the next flush */
 int odr_history_flush(odr_ctx *ctx, odr_history *h, int32_t t0, int32_t nt);

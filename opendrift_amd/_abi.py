@@ -29,6 +29,11 @@ COAST = {'none': 0, 'stranding': 1, 'previous': 2}
 HIST = {'lon': 1000, 'lat': 1001, 'z': 1002, 'status': 1003, 'moving': 1004, 'age_seconds': 1005,
         'wind_drift_factor': 1006, 'current_drift_factor': 1007, 'terminal_velocity': 1008}
 HIST_PROPERTY0 = 2000
+
+
+class StepExtras(C.Structure):   # odr_step_extras
+    _fields_ = [('seafloor_action', C.c_int32), ('retired_code', C.c_int32), ('age_dt', C.c_double),
+                ('max_age_seconds', C.c_double)]
 ANALYTIC_DOUBLE_GYRE, ANALYTIC_OSCILLATING = 1, 2
 
 
@@ -78,7 +83,7 @@ _SIGNATURES = {
     'odr_env_add_noise': [_vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_int, _dp, _dp, C.c_uint64],
     'odr_advect': [_vp, _vp, C.c_int, C.c_double, C.c_double, C.c_double],
     'odr_env_coast_advect': [_vp, _vp, C.c_int, _ip, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                             C.c_double, C.c_double, _P(C.c_int64)],
+                             C.c_double, C.c_double, _vp, _P(C.c_int64)],
     'odr_update_positions': [_vp, _vp, _dp, _dp, C.c_int, C.c_double],
     'odr_advect_wind': [_vp, _vp, C.c_double, C.c_double, C.c_int, C.c_double],
     'odr_stokes_drift': [_vp, _vp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double],
@@ -109,7 +114,7 @@ _SIGNATURES = {
     'odr_sgrid_zslice': [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int32, _dp, C.c_int32, _P(_vp), _dp],
     'odr_history_create': [_vp, C.c_int64, C.c_int32, C.c_int32, _ip, _P(_vp)],
     'odr_history_destroy': [_vp, _vp],
-    'odr_history_record': [_vp, _vp, _vp, C.c_int32, C.c_int],
+    'odr_history_record': [_vp, _vp, _vp, C.c_int32, C.c_int, C.c_int],
     'odr_history_flush': [_vp, _vp, C.c_int32, C.c_int32],
     'odr_history_wait': [_vp, _vp],
     'odr_history_host_ptr': [_vp, _vp, C.c_int32, _P(_fp), _P(C.c_int32)],

@@ -298,7 +298,10 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_advect_grid(const De
 // and, if `land_slot` == 2, 2 = land_binary_mask.
 struct StepDesc {
   int coast_action, stranded_code, seeded_code, land_slot;  // land_slot: 2 or -1 (read p.env[LAND])
-  int store_previous, geo_slot_uv, pad0, pad1;
+  int store_previous, geo_slot_uv;
+  int seafloor, depth_slot;   // interact_with_seafloor 'lift_to_seafloor' (:748-783); depth_slot 2 | 3 | -1 (read p.env[DEPTH])
+  float age_dt, max_age;      // increase_age_and_retire (:2342-2352); age_dt == 0: not part of this call
+  int retired_code, pad;
 };
 
 template <int SCHEME, int PROJ, bool IS3D>
@@ -318,12 +321,12 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevW
     p.slon[i] = lon;
     p.slat[i] = lat;
     int moving = p.moving[i];
-    bool skip = false;  // deactivated by the coastline: the reference removes it before update()
+    int st = p.status[i];
+    double zz = z;
     if (S.coast_action) {  // k_coast
       const float land = S.land_slot == 2 ? out[2] : p.env[VAR_LAND][i];
       if (land == 1.0f) {
         hit = true;
-        int st = p.status[i];
         if (S.coast_action == 1) {
           if (z <= 0) {
             if (st == 0) p.status[i] = st = S.stranded_code;
@@ -337,13 +340,27 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevW
           lon = p.plon[i];
           lat = p.plat[i];
         }
-        skip = st != 0;
       }
     }
+    if (S.seafloor) {  // k_seafloor
+      const float dep = S.depth_slot == 2 ? out[2] : (S.depth_slot == 3 ? out[3] : p.env[VAR_DEPTH][i]);
+      const float floorz = -__fadd_rn(dep, p.env[VAR_SSH] ? p.env[VAR_SSH][i] : 0.f);
+      if (zz < (double)floorz) { zz = (double)floorz; p.z[i] = zz; }
+    }
+    if (S.age_dt != 0.0f) {  // k_age
+      const float a = __fadd_rn(p.age[i], S.age_dt);
+      p.age[i] = a;
+      if (S.max_age > 0 && a >= S.max_age) {
+        if (st == 0) p.status[i] = st = S.retired_code;
+        p.moving[i] = moving = 0;
+      }
+    }
+    // deactivated (now or earlier, not yet compacted): the reference removes it before update() -- it does not move
+    const bool skip = st != 0;
     if (S.store_previous) { p.plon[i] = lon; p.plat[i] = lat; }
     if (!skip) {
       const DevSource &s = W->src[G.sid];
-      advect_grid_body<SCHEME, PROJ, IS3D>(s, s.slot[S.geo_slot_uv], lon, lat, z, out[0], out[1],
+      advect_grid_body<SCHEME, PROJ, IS3D>(s, s.slot[S.geo_slot_uv], lon, lat, zz, out[0], out[1],
                                            __fmul_rn(factor, p.cdf[i]), moving, dt, th, tf, W->fallback[VAR_U],
                                            W->fallback[VAR_V]);
     }

@@ -1123,7 +1123,7 @@ static void launch_step_grid(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G
 
 int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t,
                          int coast_action, int stranded_code, int seeded_on_land_code, int store_previous,
-                         int scheme, double dt, double factor, int64_t *n_on_land) {
+                         int scheme, double dt, double factor, const odr_step_extras *extras, int64_t *n_on_land) {
   p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(nvars > 0 && nvars <= NVAR && var_ids, "bad variable list");
   REQUIRE(scheme >= 0 && scheme <= 2, "Drift scheme not recognised: %d", scheme);
@@ -1147,11 +1147,19 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
     return true;
   };
   bool land_in_group = has_land && same_list(VAR_LAND, VAR_U);
+  bool has_depth = false;
+  for (int k = 0; k < nvars; ++k) has_depth |= var_ids[k] == VAR_DEPTH;
+  const bool want_floor = extras && extras->seafloor_action == 1;
+  if (want_floor && !has_depth && !p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
+  const bool depth_in_group = want_floor && has_depth && same_list(VAR_DEPTH, VAR_U);
   grp[ng++] = VAR_U; grp[ng++] = VAR_V;
   if (land_in_group) grp[ng++] = VAR_LAND;
+  const int depth_slot = depth_in_group ? ng : -1;
+  if (depth_in_group) grp[ng++] = VAR_DEPTH;
   bool seen[NVAR] = {false};
   seen[VAR_U] = seen[VAR_V] = true;
   if (land_in_group) seen[VAR_LAND] = true;
+  if (depth_in_group) seen[VAR_DEPTH] = true;
   for (int k = 0; k < nvars; ++k) {
     int v = var_ids[k];
     if (seen[v]) continue;
@@ -1166,6 +1174,10 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   if (!fuse) {
     if ((rc = odr_env_sample(c, p, nvars, var_ids, t, nullptr))) return rc;
     if ((rc = odr_coastline(c, p, coast_action, stranded_code, seeded_on_land_code, n_on_land))) return rc;
+    if (want_floor && (rc = odr_seafloor(c, p, nullptr))) return rc;
+    if (extras && extras->age_dt != 0 &&
+        (rc = odr_increase_age(c, p, extras->age_dt, extras->max_age_seconds, extras->retired_code)))
+      return rc;
     if (store_previous && (rc = odr_store_previous(c, p))) return rc;
     return odr_advect(c, p, scheme, t, dt, factor);
   }
@@ -1176,6 +1188,12 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   S.coast_action = coast_action; S.stranded_code = stranded_code; S.seeded_code = seeded_on_land_code;
   S.land_slot = land_in_group ? 2 : -1;
   S.store_previous = store_previous;
+  S.seafloor = want_floor ? 1 : 0;
+  S.depth_slot = depth_slot;
+  S.age_dt = extras ? (float)extras->age_dt : 0.0f;
+  S.max_age = extras ? (float)extras->max_age_seconds : 0.0f;
+  S.retired_code = extras ? extras->retired_code : 0;
+  if (want_floor && (rc = ensure_env(c, p, VAR_SSH))) return rc;
   if (coast_action) HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
   if (scheme == 0) launch_step_grid<0>(c, p, G, S, t, dt, factor);
   else if (scheme == 1) launch_step_grid<1>(c, p, G, S, t, dt, factor);
@@ -1705,7 +1723,8 @@ int odr_history_destroy(odr_ctx *c, odr_history *h) {
   return 0;
 }
 
-int odr_history_record(odr_ctx *c, odr_particles *p, odr_history *h, int32_t time_index, int only_deactivated) {
+int odr_history_record(odr_ctx *c, odr_particles *p, odr_history *h, int32_t time_index, int only_deactivated,
+                       int position_from_previous) {
   REQUIRE(h && time_index >= 0 && time_index < h->ntimes, "time index %d outside the buffer (%d)", time_index, h ? h->ntimes : 0);
   if (p->n == 0) return 0;
   HistVars H;
@@ -1716,8 +1735,8 @@ int odr_history_record(odr_ctx *c, odr_particles *p, odr_history *h, int32_t tim
     const void *src = nullptr;
     int kind = HK_F32;
     if (cde >= 0 && cde < NVAR) src = p->env[cde];
-    else if (cde == ODR_HIST_LON) { src = p->d64[0]; kind = HK_F64; }
-    else if (cde == ODR_HIST_LAT) { src = p->d64[1]; kind = HK_F64; }
+    else if (cde == ODR_HIST_LON) { src = p->d64[position_from_previous ? 3 : 0]; kind = HK_F64; }
+    else if (cde == ODR_HIST_LAT) { src = p->d64[position_from_previous ? 4 : 1]; kind = HK_F64; }
     else if (cde == ODR_HIST_Z) { src = p->d64[2]; kind = HK_F64; }
     else if (cde == ODR_HIST_STATUS) { src = p->i32[1]; kind = HK_I32; }
     else if (cde == ODR_HIST_MOVING) { src = p->i32[2]; kind = HK_I32; }

@@ -308,18 +308,23 @@ class Particles:
         check(self.lib.odr_advect(self.ctx.h, self.h, s, float(t_epoch), float(dt), float(factor)))
 
     def env_coast_advect(self, variables, t_epoch, scheme, dt, coastline='none', stranded_code=1,
-                         seeded_on_land_code=0, store_previous=True, factor=1.0, count=True):
+                         seeded_on_land_code=0, store_previous=True, factor=1.0, count=True, seafloor=False,
+                         age_dt=0.0, max_age_seconds=0.0, retired_code=0):
         """env_sample -> coastline -> store_previous -> advect in one launch (odr_env_coast_advect).
-        count=False skips reading back the number of elements on land (no host synchronisation)."""
+        count=False skips reading back the number of elements on land (no host synchronisation).  seafloor=True and
+        age_dt != 0 add interact_with_seafloor ('lift_to_seafloor') and increase_age_and_retire, in the loop's order."""
         s = scheme if isinstance(scheme, int) else _abi.SCHEME.get(scheme, -1)
         if s < 0:
             raise ValueError('Drift scheme not recognised: ' + str(scheme))
         a = coastline if isinstance(coastline, int) else _abi.COAST[coastline]
         ids, pi = _i([_vid(v) for v in variables])
         n = C.c_int64()
+        ex = None
+        if seafloor or age_dt:
+            ex = C.byref(_abi.StepExtras(1 if seafloor else 0, int(retired_code), float(age_dt), float(max_age_seconds)))
         check(self.lib.odr_env_coast_advect(self.ctx.h, self.h, len(ids), pi, float(t_epoch), a, stranded_code,
                                             seeded_on_land_code, int(bool(store_previous)), s, float(dt),
-                                            float(factor), C.byref(n) if count else None))
+                                            float(factor), ex, C.byref(n) if count else None))
         return n.value if count else None
 
     def update_positions(self, x_vel, y_vel, dt):
@@ -482,8 +487,9 @@ class History:
         self.h = C.c_void_p()
         check(self.lib.odr_history_create(ctx.h, self.n_trajectories, self.n_times, len(codes), pa, C.byref(self.h)))
 
-    def record(self, particles, time_index, only_deactivated=False):
-        check(self.lib.odr_history_record(self.ctx.h, particles.h, self.h, int(time_index), int(bool(only_deactivated))))
+    def record(self, particles, time_index, only_deactivated=False, position_from_previous=False):
+        check(self.lib.odr_history_record(self.ctx.h, particles.h, self.h, int(time_index), int(bool(only_deactivated)),
+                                          int(bool(position_from_previous))))
 
     def flush(self, t0=0, nt=None):
         check(self.lib.odr_history_flush(self.ctx.h, self.h, int(t0), int(self.n_times - t0 if nt is None else nt)))

@@ -19,6 +19,8 @@ import logging
 from datetime import datetime, timedelta
 from types import SimpleNamespace
 
+import os
+
 import numpy as np
 
 from . import _abi
@@ -48,6 +50,7 @@ class OpenDriftSimulation(Configurable):
             np.random.seed(seed)             # basemodel/__init__.py:326
         self.status_categories = ['active']
         self.readers = {}                    # name -> DeviceReaderBinding (created by _finalize_environment)
+        self._advected = False
         self._readers_host = {}              # name -> (reader, variables) as given to add_reader
         self.priority_list = {}              # variable -> [reader names]
         self.required_variables = {k: dict(v) for k, v in type(self).required_variables.items()}
@@ -56,7 +59,7 @@ class OpenDriftSimulation(Configurable):
         self.steps_calculation = 0
         self.time = self.start_time = self.time_step = None
         self.newly_seeded = 0
-        self.sort_every = 8
+        self.sort_every = 16
         self._add_config({
             'general:use_auto_landmask': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_ADVANCED,
                                           'description': 'GSHHG landmask (not available on the device path)'},
@@ -220,14 +223,15 @@ class OpenDriftSimulation(Configurable):
         # LagrangianArray stores lon/lat/z as float32 at seeding (elements.py:71-88,156-158)
         new = dict(lon=np.float32(lon).astype(np.float64), lat=np.float32(lat).astype(np.float64),
                    z=(np.float32(z) * np.ones(number, np.float32)).astype(np.float64),
-                   time=np.array(time, dtype=object), **props)
+                   time=np.array(time, dtype=object),
+                   t_epoch=np.array(time, dtype='datetime64[us]').astype(np.int64) / 1e6, **props)   # vectorised schedule
         if self._sched is None:
             self._sched = new
         else:
             for k in new:
                 self._sched[k] = np.concatenate([self._sched[k], new[k]])
         self._sched['ID'] = np.arange(len(self._sched['lon']), dtype=np.int32)
-        st = min(self._sched['time'])
+        st = self._sched['time'][int(np.argmin(self._sched['t_epoch']))]
         self.start_time = st if self.start_time is None else min(self.start_time, st)
         if self.mode == 'Config':
             self.mode = 'Ready'
@@ -251,7 +255,11 @@ class OpenDriftSimulation(Configurable):
         return self.P.count()[1] if self.P is not None else 0
 
     def num_elements_scheduled(self):
-        return 0 if self._sched is None else int(self._released_mask().size - self._released_mask().sum())
+        if self._sched is None:
+            return 0
+        if getattr(self, '_n_unreleased', None) is not None:
+            return self._n_unreleased
+        return int(self._released_mask().size - self._released_mask().sum())
 
     def num_elements_total(self):
         return 0 if self._sched is None else len(self._sched['lon'])
@@ -278,12 +286,17 @@ class OpenDriftSimulation(Configurable):
     # ------------------------------------------------------------------ loop pieces
     def release_elements(self):   # :909-934
         s, rel = self._sched, self._released_mask()
+        if getattr(self, '_n_unreleased', None) is None:
+            self._n_unreleased = int(rel.size - rel.sum())
+            self._t_sched = s['t_epoch']
+        if self._n_unreleased == 0:      # nothing left to seed: no O(N) work per step
+            self.newly_seeded = 0
+            return
+        t0, t1 = _epoch(self.time), _epoch(self.time + self.time_step)
         if self.time_step.total_seconds() >= 0:
-            idx = np.array([(not rel[i]) and self.time <= s['time'][i] < self.time + self.time_step
-                            for i in range(len(rel))]) if not self._all_at_start else ~rel
+            idx = ~rel if self._all_at_start else (~rel & (self._t_sched >= t0) & (self._t_sched < t1))
         else:
-            idx = np.array([(not rel[i]) and self.time >= s['time'][i] > self.time + self.time_step
-                            for i in range(len(rel))])
+            idx = ~rel & (self._t_sched <= t0) & (self._t_sched > t1)
         n = int(idx.sum())
         self.newly_seeded = n
         if n == 0:
@@ -295,6 +308,7 @@ class OpenDriftSimulation(Configurable):
         for slot, name in enumerate(getattr(self, 'aux_properties', [])):   # model-specific float32 properties
             self.P.set_property(slot, s[name][idx], offset=n_before)
         rel[idx] = True
+        self._n_unreleased -= n
 
     def deactivate_outside(self):   # :2354-2382, validity domain of :2169-2179
         dom = [self.get_config('drift:deactivate_%s_of' % k) for k in ('west', 'east', 'south', 'north')]
@@ -365,6 +379,9 @@ class OpenDriftSimulation(Configurable):
 
     # ---- PhysicsMethods (physics_methods.py:611-848)
     def advect_ocean_current(self, factor=1):
+        if self._advected:       # already done by the fused launch of this step (run(), fused lane)
+            self._advected = False
+            return
         self.P.advect(self.get_config('drift:advection_scheme'), _epoch(self.time),
                       self.time_step.total_seconds(), factor)
 
@@ -413,7 +430,7 @@ class OpenDriftSimulation(Configurable):
         if not isinstance(time_step_output, timedelta):
             time_step_output = timedelta(seconds=time_step_output)
         if time_step.total_seconds() < 0:
-            self.start_time = max(self._sched['time'])
+            self.start_time = self._sched['time'][int(np.argmax(self._sched['t_epoch']))]
         if duration is not None:
             steps = int(round(duration.total_seconds() / abs(time_step.total_seconds())))
         elif end_time is not None:
@@ -427,7 +444,7 @@ class OpenDriftSimulation(Configurable):
                 if self.get_config(key) is val:
                     self.required_variables.pop(vn)
         self.time = self.start_time
-        self._all_at_start = all(t == self.start_time for t in self._sched['time'])
+        self._all_at_start = bool((self._sched['t_epoch'] == _epoch(self.start_time)).all())
         self._finalize_environment(self.start_time, self.start_time + steps * time_step)
         n_total = self.num_elements_total()
         self.P = self.ctx.particles(n_total)
@@ -440,11 +457,19 @@ class OpenDriftSimulation(Configurable):
         self._hist = _ResultBuffer(self.ctx, n_total, nout, min(nout, max(1, int(export_buffer_length))), hvars)
         times = []
         grid_sid = next((b.sid for b in self.readers.values() if b.is_grid() and b.sid is not None), None)
+        # fused lane: the stock loop body and the stock OceanDrift.update order (current advection first), no noise
+        # between sample and advection, no retirement between coastline and advection
+        B = OpenDriftSimulation
+        fused_lane = (not os.environ.get('ODR_RUN_UNFUSED') and getattr(type(self), 'update', None) is OceanDrift.update and
+                      all(getattr(type(self), m) is getattr(B, m) for m in (
+                          'advect_ocean_current', 'get_environment', 'interact_with_coastline', 'interact_with_seafloor',
+                          'deactivate_outside', 'deactivate_elements')) and
+                      not self.get_config('drift:current_uncertainty') and not self.get_config('drift:wind_uncertainty') and
+                      self.get_config('drift:max_age_seconds') is None and
+                      not self.get_config('general:coastline_approximation_precision') and
+                      'x_sea_water_velocity' in self.required_variables and 'y_sea_water_velocity' in self.required_variables)
         for i in range(steps):
             try:
-                if self.rng == 'device' and grid_sid is not None and self.sort_every and i % self.sort_every == 0 \
-                        and self.num_elements_active() > 65536:
-                    self.P.sort_by_cell(grid_sid)     # device layout maintenance, before release
                 self.release_elements()
                 if self.num_elements_active() == 0 and self.num_elements_scheduled() > 0:
                     self._state_to_buffer(i, out_every, times)   # (:2208)
@@ -453,20 +478,49 @@ class OpenDriftSimulation(Configurable):
                     continue
                 for b in self.readers.values():
                     b.ensure_levels(self.time, self.time + self.time_step)
-                self.get_environment()
-                self.deactivate_outside()
-                self.interact_with_coastline()
-                self.interact_with_seafloor()
-                self._state_to_buffer(i, out_every, times)
-                max_age = self.get_config('drift:max_age_seconds')
-                self.P.increase_age(self.time_step.total_seconds(), max_age or 0.0,
-                                    self._status_code('retired') if max_age else 0)
-                self.P.compact()
-                self.P.store_previous()
+                # device layout maintenance: re-sort by grid cell every sort_every steps and whenever a
+                # release added a sizeable share of new (unsorted) elements
+                n_act = self.num_elements_active()
+                if self.rng == 'device' and grid_sid is not None and self.sort_every and n_act > 65536 and \
+                        (i % self.sort_every == 0 or self.newly_seeded * 20 > n_act):
+                    self.P.sort_by_cell(grid_sid)
+                if fused_lane:
+                    # ONE launch for get_environment + coastline + seafloor + update_previous_state +
+                    # advect_ocean_current (odr_env_coast_advect).  deactivate_outside only reads positions and goes
+                    # first; the result buffer is written afterwards from the saved pre-advection position.
+                    self.deactivate_outside()
+                    names = list(self.required_variables)
+                    action = self.get_config('general:coastline_action')
+                    floor = ('sea_floor_depth_below_sea_level' in self.priority_list and
+                             self.get_config('general:seafloor_action', 'lift_to_seafloor') == 'lift_to_seafloor')
+                    self.P.env_coast_advect(
+                        names, _epoch(self.time), self.get_config('drift:advection_scheme'), self.time_step.total_seconds(),
+                        coastline=action if 'land_binary_mask' in names else 'none',
+                        stranded_code=self._status_code('stranded') if action == 'stranding' else 1,
+                        seeded_on_land_code=(self._status_code('seeded_on_land') if action == 'previous' and self.newly_seeded
+                                             else 0),
+                        store_previous=True, count=False, seafloor=floor)
+                    self._sampled = names
+                    self._state_to_buffer(i, out_every, times, from_previous=True)
+                    self.P.increase_age(self.time_step.total_seconds())
+                    self.P.compact()
+                    self._advected = True
+                else:
+                    self.get_environment()
+                    self.deactivate_outside()
+                    self.interact_with_coastline()
+                    self.interact_with_seafloor()
+                    self._state_to_buffer(i, out_every, times)
+                    max_age = self.get_config('drift:max_age_seconds')
+                    self.P.increase_age(self.time_step.total_seconds(), max_age or 0.0,
+                                        self._status_code('retired') if max_age else 0)
+                    self.P.compact()
+                    self.P.store_previous()
                 if self.num_elements_active() > 0:
                     self.update()
                 elif self.num_elements_scheduled() == 0:
                     raise ValueError('No more active or scheduled elements, quitting.')
+                self._advected = False
                 self.horizontal_diffusion()
                 self.time = self.time + self.time_step
                 self.steps_calculation += 1
@@ -495,16 +549,16 @@ class OpenDriftSimulation(Configurable):
         self._hist_aux = {name: ('property', list(getattr(self, 'aux_properties', [])).index(name)) for name in aux}
         return elem + aux + env
 
-    def _state_to_buffer(self, step, out_every, times, final=False):   # :2384-2403, on the device
+    def _state_to_buffer(self, step, out_every, times, final=False, from_previous=False):   # :2384-2403, on the device
         k = step // out_every
         if step % out_every == 0:            # output time: every element present
             if k < self._hist.ntimes:
                 if len(self.P) > 0:
-                    self._hist.record(self.P, k, False, self._hist_aux)
+                    self._hist.record(self.P, k, False, self._hist_aux, from_previous)
                 while len(times) <= k:       # result.time is a regular axis (:2088-2090)
                     times.append(self.start_time + len(times) * out_every * self.time_step)
         elif not final and k + 1 < self._hist.ntimes and len(self.P) > 0:
-            self._hist.record(self.P, k + 1, True, self._hist_aux)   # deactivated -> next output time (backfill)
+            self._hist.record(self.P, k + 1, True, self._hist_aux, from_previous)   # deactivated -> next output time (backfill)
 
 
 class _ResultBuffer:
@@ -519,11 +573,11 @@ class _ResultBuffer:
         if self.H is None:
             self.H = self.ctx.history(self.ntraj, self.nbuf, [aux.get(v, v) for v in self.variables])
 
-    def record(self, P, k, only_deactivated, aux):
+    def record(self, P, k, only_deactivated, aux, from_previous=False):
         self._open(aux)
         while k - self.base >= self.nbuf:
             self._flush(self.nbuf)
-        self.H.record(P, k - self.base, only_deactivated)
+        self.H.record(P, k - self.base, only_deactivated, position_from_previous=from_previous)
         self.used = max(self.used, k - self.base + 1)
 
     def _flush(self, nt):

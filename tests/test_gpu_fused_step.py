@@ -101,3 +101,45 @@ def test_missing_current_is_an_error(ctx):
     P.append(np.zeros(4), np.zeros(4))
     with pytest.raises(ValueError):
         P.env_coast_advect([XW, YW], 0.0, 'euler', 600.0)
+
+
+def test_fused_with_seafloor_and_age_equals_separate(ctx):
+    """The optional bookkeeping of the loop body inside the fused launch: interact_with_seafloor (lift_to_seafloor)
+    and increase_age_and_retire between the coastline and update_previous_state -- same bits as the separate calls
+    in the reference's order, retired / seeded-on-land elements do not move."""
+    g = synth.grid3d(nx=96, ny=80, nz=8, nt=3, seed=5)
+    names = [U, V, W, KZ, DEPTH, LAND]
+    arrays = {n: g[n] for n in names}
+    arrays[DEPTH] = (np.asarray(g[DEPTH]) * 0 + 25.0).astype(np.float32)      # shallow: many elements start below the floor
+    levels = [(float(g['t'][k]), {n: arrays[n][k] for n in names}) for k in range(3)]
+    Scenario([('grid', dict(x=g['x'], y=g['y'], z=g['z'], levels=levels))],
+             fallbacks={U: 0.0, V: 0.0, W: 0.0, KZ: 0.0, DEPTH: 10000.0, SSH: 0.0}).device(ctx)
+    rng = np.random.default_rng(9)
+    n = 40000
+    lon = rng.uniform(g['x'][2], g['x'][-3], n)
+    lat = rng.uniform(g['y'][2], g['y'][-3], n)
+    z = -rng.uniform(0, 60, n)
+    variables = [U, V, W, DEPTH, SSH, LAND]
+    P, Q = ctx.particles(n), ctx.particles(n)
+    for X in (P, Q):
+        X.append(lon, lat, z=z)
+        X.store_previous()
+    dt, max_age = 600.0, 1500.0
+    for k, t in enumerate([0.0, 600.0, 1200.0, 1800.0]):
+        P.env_sample(variables, t)
+        P.coastline('previous', seeded_on_land_code=5)
+        P.seafloor()
+        P.increase_age(dt, max_age, 7)
+        P.compact()
+        P.store_previous()
+        P.advect('runge-kutta4', t, dt)
+        Q.env_coast_advect(variables, t, 'runge-kutta4', dt, coastline='previous', seeded_on_land_code=5, store_previous=True,
+                           seafloor=True, age_dt=dt, max_age_seconds=max_age, retired_code=7)
+        Q.compact()
+        assert len(P) == len(Q), (k, len(P), len(Q))
+        _same(P.download(), Q.download(), 'step %d' % k)
+        da, db = P.download_deactivated(), Q.download_deactivated()
+        for q in ('lon', 'lat', 'z', 'status', 'ID'):
+            assert (da[q] == db[q]).all(), (k, 'deactivated', q)
+    assert len(P) == 0 or (P.download()['z'] >= -25.0 - 1e-9).all()
+    assert (Q.download_deactivated()['status'] == 7).any()

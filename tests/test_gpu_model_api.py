@@ -325,3 +325,41 @@ def test_reference_kat_previous():
         o.seed_elements(lon=3, lat=60, time=datetime(2024, 5, 17))
         o.run(steps=1)
         assert o.elements.lon[0] == pytest.approx(3.0645, .001)
+
+
+def test_run_fused_lane_equals_step_by_step_lane():
+    """run() uses ONE launch for sample + coastline + seafloor + previous state + current advection when the stock loop
+    body applies; ODR_RUN_UNFUSED keeps the call-by-call lane.  Same trajectories, same result buffer, same
+    deactivations -- with a validity domain, stranding, late releases and vertical mixing in play."""
+    import os
+    g = golden('c3_grid3d_rk4_vmix.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity',
+             'ocean_vertical_diffusivity', 'sea_floor_depth_below_sea_level', 'land_binary_mask']
+
+    def run(unfused, action):
+        if unfused:
+            os.environ['ODR_RUN_UNFUSED'] = '1'
+        try:
+            o = OceanDrift(loglevel=50, seed=5)
+            o.add_reader(_grid_reader(g, names, z=g['g_z']))
+            o.set_config('drift:advection_scheme', 'runge-kutta4')
+            o.set_config('drift:vertical_mixing', True)
+            o.set_config('general:coastline_action', action)
+            o.set_config('drift:deactivate_east_of', float(g['g_x'][-20]))
+            n = 30000
+            rng = np.random.default_rng(1)
+            lon, lat = rng.uniform(g['g_x'][2], g['g_x'][-3], n), rng.uniform(g['g_y'][2], g['g_y'][-3], n)
+            o.seed_elements(lon=lon[:20000], lat=lat[:20000], z=-rng.uniform(0, 40, 20000), time=T0)
+            o.seed_elements(lon=lon[20000:], lat=lat[20000:], z=-rng.uniform(0, 40, 10000), time=T0 + timedelta(seconds=1200))
+            res = o.run(time_step=600, steps=7, time_step_output=1200, export_variables=['z', 'x_sea_water_velocity'])
+            return _final(o, n), res, o.num_elements_deactivated(), list(o.status_categories)
+        finally:
+            os.environ.pop('ODR_RUN_UNFUSED', None)
+
+    for action in ('previous', 'stranding'):
+        (fa, ra, da, ca), (fb, rb, db, cb) = run(False, action), run(True, action)
+        assert da == db and da > 0 and ca == cb, (action, da, db, ca, cb)
+        for x, y in zip(fa, fb):
+            assert np.array_equal(x, y, equal_nan=True), action
+        for k in ('lon', 'lat', 'z', 'status', 'x_sea_water_velocity'):
+            assert np.array_equal(ra[k], rb[k], equal_nan=True), (action, k)
