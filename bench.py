@@ -282,11 +282,12 @@ def main():
         G.build()
     D.barrier()
     assert torch.cuda.is_available(), 'bench.py needs a GPU: the product path has no CPU fallback'
-    torch.cuda.set_device(local_rank)
+    dev = local_rank % torch.cuda.device_count()    # == local_rank on a node with one GPU per rank (the driver's launch)
+    torch.cuda.set_device(dev)
 
     n = a.particles or {'c2': 1_000_000, 'c3': 10_000_000, 'c4': 6_250_000, 'c5': 10_000_000}[a.workload]
     fields = make_fields(a.workload, a.small)
-    ctx = Context(device=local_rank, seed=0)
+    ctx = Context(device=dev, seed=0)
     wl = Workload(a.workload, ctx, fields, (rank, local_rank, world))
     rng = np.random.default_rng(1000 + rank)
     lon, lat, z = seed_particles(a.workload, fields, n, rng)

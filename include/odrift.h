@@ -56,7 +56,8 @@ enum {
 };
 
 /* ---- projections of a reader (pyproj.Proj(reader.proj4), basereader/__init__.py:119-137) ---- */
-enum { ODR_PROJ_LATLONG = 0, ODR_PROJ_STERE_EQUIT_SPHERE = 1, ODR_PROJ_STERE_POLAR = 2 };
+enum { ODR_PROJ_LATLONG = 0, ODR_PROJ_STERE_EQUIT_SPHERE = 1, ODR_PROJ_STERE_POLAR = 2,
+       ODR_PROJ_CURVILINEAR = 3 /* set by odr_source_grid_curvilinear, not through odr_proj_desc */ };
 typedef struct {
   int32_t kind;
   double a, es;                  /* semi-major axis, eccentricity squared */
@@ -117,6 +118,20 @@ int odr_source_analytic(odr_ctx *ctx, int kind, const double *params, int nparam
  * z = block z levels (NULL / nz<=1 for surface fields). */
 int odr_source_grid(odr_ctx *ctx, const odr_proj_desc *proj, const double *domain6,
                     int lon_mode, int mod360_x, int nz, const double *z, int32_t *source_id);
+/* StructuredReader WITHOUT a projection (basereader/structured.py:44-113; reader_ROMS_native.py and every reader that
+ * only has 2D lon/lat arrays): x/y are pixel indices, and lonlat2xy (structured.py:438-472) is scipy's
+ * LinearNDInterpolator over the Delaunay triangulation of the nodes.  lon/lat: [ny, nx] float64 node coordinates;
+ * domain = {0, nx-1, 0, ny-1, zmin, zmax}.  The same triangulation is built here from the structured mesh (cell
+ * diagonals + edge flips, csrc/odr_mesh.h), the device walks it per particle; positions outside the
+ * mesh outline are "not covered".  ODR_ERR_INVALID for folded / non-convex cells or non-finite nodes. */
+int odr_source_grid_curvilinear(odr_ctx *ctx, const double *lon, const double *lat, int ny, int nx,
+                                const double *domain6, int lon_mode, int nz, const double *z,
+                                int32_t *source_id);
+/* Variables.lonlat2xy of one source (variables.py:111-143, longitudes modulated as :259-280) for n host positions ->
+ * reader coordinates x, y (NaN outside a curvilinear mesh); synchronous.  Host-side callers (seeding, tests); the
+ * step kernels do the same transform in registers. */
+int odr_source_lonlat2xy(odr_ctx *ctx, int32_t source_id, int64_t n, const double *lon, const double *lat,
+                         double *x, double *y);
 /* One time level = one ReaderBlock (interpolation/structured.py:15-94).  data[k] is a host
  * float32 array [var_nz[k], ny, nx] (var_nz 1 => 2D).  xy8 = {x0, xspan, y0, yspan, xmin,
  * xrange, ymin, yrange} with the spans formed in the dtype of the reader's x/y arrays

@@ -67,6 +67,8 @@ _SIGNATURES = {
     'odr_source_constant': [_vp, C.c_int, _ip, _dp, _ip],
     'odr_source_analytic': [_vp, C.c_int, _dp, C.c_int, _ip],
     'odr_source_grid': [_vp, _P(ProjDesc), _dp, C.c_int, C.c_int, C.c_int, _dp, _ip],
+    'odr_source_grid_curvilinear': [_vp, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp, _ip],
+    'odr_source_lonlat2xy': [_vp, C.c_int32, C.c_int64, _dp, _dp, _dp, _dp],
     'odr_block_upload': [_vp, C.c_int32, C.c_int32, C.c_double, C.c_int, _ip, _P(_fp), _ip, C.c_int,
                          C.c_int, _dp],
     'odr_block_upload_device': [_vp, C.c_int32, C.c_int32, C.c_double, C.c_int, _ip, _P(_vp), _ip,

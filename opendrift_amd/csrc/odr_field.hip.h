@@ -18,12 +18,26 @@ enum { VAR_U = 0, VAR_V = 1, VAR_XWIND = 2, VAR_YWIND = 3, VAR_W = 4, VAR_KZ = 5
        VAR_SY = 7, VAR_LAND = 8, VAR_DEPTH = 9, VAR_SSH = 10, VAR_HDIFF = 11, VAR_HS = 12,
        VAR_TP = 13, VAR_MLD = 14 };
 enum { SRC_CONSTANT = 0, SRC_DOUBLE_GYRE = 1, SRC_OSCILLATING = 2, SRC_GRID = 3 };
-enum { PROJ_LATLONG = 0, PROJ_STERE_EQUIT_SPHERE = 1, PROJ_STERE_POLAR = 2 };
+enum { PROJ_LATLONG = 0, PROJ_STERE_EQUIT_SPHERE = 1, PROJ_STERE_POLAR = 2, PROJ_CURVILINEAR = 3 };
+// x/y vector pairs are rotated from the reader's CRS to lon/lat (variables.py:799-837); for a reader without a
+// projection (fakeproj) the rotation the reference computes is by the azimuth of due north, i.e. exactly zero
+#define ODR_PROJ_ROTATES(K) ((K) == PROJ_STERE_EQUIT_SPHERE || (K) == PROJ_STERE_POLAR)
+
+struct D2 { double x, y; };
 
 struct DevProj {
   int kind, south;
   double a, es, e, lon0, lat0, x0, y0, k0, akm1;
   double cchi[4];  // conformal -> geodetic latitude series (Snyder 3-5), used by rotation_angle
+  // PROJ_CURVILINEAR: a reader WITHOUT a projection (2D lon/lat node arrays, pixel indices as x/y;
+  // basereader/structured.py:44-113).  cv_nodes[j*cv_nx + i] = (lon, lat) of node (i, j); cv_tri_v / cv_tri_n = the
+  // Delaunay triangulation of the nodes (counter-clockwise vertices; neighbour across the edge opposite vertex k,
+  // -1 on the outline; csrc/odr_mesh.h); cv_bucket = a triangle near every bucket of a uniform lon/lat raster.
+  const D2 *cv_nodes;
+  const int *cv_tri_v, *cv_tri_n;
+  const int *cv_bucket;
+  int cv_nx, cv_maxit, cv_nbx, cv_nby;
+  double cv_bx0, cv_by0, cv_ibx, cv_iby;
 };
 
 struct DevBlock {
@@ -123,6 +137,41 @@ __device__ __forceinline__ double tsfn(double phi, double sinphi, double e) {
   return tan(0.5 * (kHalfPi - phi)) * exp(e * ath);
 }
 
+// StructuredReader.lonlat2xy of a reader without projection (structured.py:438-472): the reference evaluates
+// scipy's LinearNDInterpolator -- piecewise-linear interpolation of the pixel indices over the Delaunay
+// triangulation of the (lon, lat) nodes.  The triangulation is prepared once on the host from the structured
+// mesh (odr_mesh.h); here: visibility walk from the bucket raster's start triangle, then the barycentric
+// combination of the vertices' pixel indices.  Outside the mesh outline: NaN (not covered).
+__device__ __forceinline__ double cross2(double ax, double ay, double bx, double by) {
+  return __dsub_rn(__dmul_rn(ax, by), __dmul_rn(ay, bx));
+}
+__device__ __forceinline__ void curvi_locate(const DevProj &p, double lon, double lat, double &x, double &y) {
+  x = y = __builtin_nan("");
+  const double fx = (lon - p.cv_bx0) * p.cv_ibx, fy = (lat - p.cv_by0) * p.cv_iby;
+  if (!(fx >= 0 && fy >= 0 && fx < (double)p.cv_nbx && fy < (double)p.cv_nby)) return;
+  int t = p.cv_bucket[(int)fy * p.cv_nbx + (int)fx];
+  for (int it = 0; t >= 0 && it < p.cv_maxit; ++it) {
+    const int *v = p.cv_tri_v + 3 * (size_t)t;
+    const int v0 = v[0], v1 = v[1], v2 = v[2];
+    const D2 p0 = p.cv_nodes[v0], p1 = p.cv_nodes[v1], p2 = p.cv_nodes[v2];
+    const double e0 = cross2(p2.x - p1.x, p2.y - p1.y, lon - p1.x, lat - p1.y);  // edge opposite vertex 0
+    const double e1 = cross2(p0.x - p2.x, p0.y - p2.y, lon - p2.x, lat - p2.y);
+    const double e2 = cross2(p1.x - p0.x, p1.y - p0.y, lon - p0.x, lat - p0.y);
+    const double worst = fmin(e0, fmin(e1, e2));
+    if (!(worst < 0)) {   // inside (or on the border of) this triangle
+      const double det = cross2(p1.x - p0.x, p1.y - p0.y, p2.x - p0.x, p2.y - p0.y);
+      const double c0 = __ddiv_rn(e0, det), c1 = __ddiv_rn(e1, det);
+      const int nx = p.cv_nx;
+      const int j0 = v0 / nx, j1 = v1 / nx, j2 = v2 / nx;
+      const int i0 = v0 - j0 * nx, i1 = v1 - j1 * nx, i2 = v2 - j2 * nx;
+      x = (double)i2 + __dadd_rn(__dmul_rn(c0, (double)(i0 - i2)), __dmul_rn(c1, (double)(i1 - i2)));
+      y = (double)j2 + __dadd_rn(__dmul_rn(c0, (double)(j0 - j2)), __dmul_rn(c1, (double)(j1 - j2)));
+      return;
+    }
+    t = p.cv_tri_n[3 * (size_t)t + (worst == e0 ? 0 : worst == e1 ? 1 : 2)];
+  }
+}
+
 __device__ __forceinline__ void proj_fwd(const DevProj &p, double lon_deg, double lat_deg,
                                          double &x, double &y) {
 #pragma clang fp contract(fast)
@@ -145,6 +194,12 @@ __device__ __forceinline__ void proj_fwd(const DevProj &p, double lon_deg, doubl
   }
   x = p.a * X + p.x0;
   y = p.a * Y + p.y0;
+}
+
+// reader projection chosen at run time (kernels that serve any reader)
+__device__ __forceinline__ void proj_fwd_rt(const DevProj &p, double lon_deg, double lat_deg, double &x, double &y) {
+  if (p.kind == PROJ_CURVILINEAR) curvi_locate(p, lon_deg, lat_deg, x, y);
+  else proj_fwd(p, lon_deg, lat_deg, x, y);
 }
 
 __device__ __forceinline__ void proj_inv(const DevProj &p, double x, double y, double &lon_deg,
@@ -392,7 +447,7 @@ __device__ __forceinline__ bool source_sample(const DevSource &s, const int (&va
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
   double x, y;
-  proj_fwd(s.proj, lon, lat, x, y);
+  proj_fwd_rt(s.proj, lon, lat, x, y);
   double xchk = x;
   if (s.proj.kind == PROJ_LATLONG) {
     if (s.lon_mode == 1) xchk = np_mod(x + 180.0, 360.0) - 180.0;
@@ -459,7 +514,7 @@ __device__ __forceinline__ bool source_sample(const DevSource &s, const int (&va
     }
   }
   // rotate x/y vector pairs to the lon/lat CRS (variables.py:799-837)
-  if (s.proj.kind != PROJ_LATLONG) {
+  if (ODR_PROJ_ROTATES(s.proj.kind)) {
     bool need = false;
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -684,6 +739,7 @@ __device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBloc
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
   double x, y;
   if (PROJ == PROJ_LATLONG) { x = lon; y = lat; }
+  else if (PROJ == PROJ_CURVILINEAR) curvi_locate(s.proj, lon, lat, x, y);
   else proj_fwd(s.proj, lon, lat, x, y);
   double xchk = x;
   if (PROJ == PROJ_LATLONG) {
@@ -711,7 +767,7 @@ __device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBloc
         v = __dadd_rn(__dmul_rn(vb, 1 - tm.w), __dmul_rn(va, tm.w));
       }
     }
-    if (PROJ != PROJ_LATLONG) {
+    if (ODR_PROJ_ROTATES(PROJ)) {
       double sn, cs;
       rotation_cs(s.proj, x, y, cs, sn);
       double uu = u, vv = v;
@@ -791,6 +847,7 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
   double x, y;
   if (PROJ == PROJ_LATLONG) { x = lon; y = lat; }
+  else if (PROJ == PROJ_CURVILINEAR) curvi_locate(s.proj, lon, lat, x, y);
   else proj_fwd(s.proj, lon, lat, x, y);
   double xchk = x;
   if (PROJ == PROJ_LATLONG) {
@@ -848,7 +905,7 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
       }
       val[k] = vb;
     }
-    if (PROJ != PROJ_LATLONG) {
+    if (ODR_PROJ_ROTATES(PROJ)) {
       bool need = false;
 #pragma unroll
       for (int k = 0; k < MAXG; ++k) if (k < G.nv && G.partner[k] >= 0) need = true;

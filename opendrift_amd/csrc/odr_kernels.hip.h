@@ -727,7 +727,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
       double lon = p.slon[i], lat = p.slat[i], x, y;
       if (src->lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
       else if (src->lon_mode == 2) lon = np_mod(lon, 360.0);
-      proj_fwd(src->proj, lon, lat, x, y);
+      proj_fwd_rt(src->proj, lon, lat, x, y);
       cov = x >= src->xmin && x <= src->xmax && y >= src->ymin && y <= src->ymax;
       if (src->mod360_x) x = np_mod(x, 360.0);
       bracket(*src, t, ib, ia);
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__
     double lon = p.slon[i], lat = p.slat[i], x, y;
     if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
     else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
-    proj_fwd(s.proj, lon, lat, x, y);
+    proj_fwd_rt(s.proj, lon, lat, x, y);
     const bool cov = x >= s.xmin && x <= s.xmax && y >= s.ymin && y <= s.ymax;
     if (s.mod360_x) x = np_mod(x, 360.0);
     const DevBlock &bb = s.slot[D.geo_slot];
@@ -1186,6 +1186,22 @@ __global__ __launch_bounds__(BLOCK) void k_cmp_scatter(const int *status, long l
 
 // deactivate_outside (basemodel/__init__.py:2354-2382): elements beyond the user's validity domain
 // (drift:deactivate_west_of / east_of / south_of / north_of) get the status 'outside'
+// Variables.lonlat2xy of one reader for n positions (variables.py:111-143 after modulate_longitude :259-280;
+// StructuredReader.lonlat2xy structured.py:438-472 for readers without a projection)
+__global__ __launch_bounds__(BLOCK) void k_lonlat2xy(const DevWorld *W, int sid, long long n,
+                                                      const double *__restrict__ lon, const double *__restrict__ lat,
+                                                      double *__restrict__ xo, double *__restrict__ yo) {
+  const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const DevSource &s = W->src[sid];
+  double lo = lon[i], x, y;
+  if (s.lon_mode == 1) lo = np_mod(lo + 180.0, 360.0) - 180.0;
+  else if (s.lon_mode == 2) lo = np_mod(lo, 360.0);
+  proj_fwd_rt(s.proj, lo, lat[i], x, y);
+  xo[i] = x;
+  yo[i] = y;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_deactivate_outside(PView p, double W, double E, double S, double N,
                                                               int useW, int useE, int useS, int useN, int wrap360,
                                                               int code) {
@@ -1326,7 +1342,7 @@ __device__ __forceinline__ unsigned sort_key(const DevSource &s, const DevBlock 
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
   double x, y;
-  proj_fwd(s.proj, lon, lat, x, y);
+  proj_fwd_rt(s.proj, lon, lat, x, y);
   double xi = (x - b.x0) / b.xspan * (b.nx - 1), yi = (y - b.y0) / b.yspan * (b.ny - 1);
   if (!(xi >= 0 && xi <= b.nx - 1 && yi >= 0 && yi <= b.ny - 1)) return nbins - 1;
   int ix = (int)xi, iy = (int)yi;

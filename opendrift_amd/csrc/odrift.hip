@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/odrift.h"
+#include "odr_mesh.h"
 #include "odr_kernels.hip.h"
 
 using namespace odr;
@@ -54,6 +55,7 @@ struct odr_ctx {
   size_t prep_floats;
   Staged staged[MAXSRC][MAXLEVELS];
   std::vector<Retired> graveyard;
+  std::vector<void *> source_bufs;  // device arrays owned by sources (curvilinear node tables)
   std::vector<void *> registered;   // host ranges page-locked by odr_host_register (released with the context)
   double *red;      // device reduction slots
   unsigned long long *counter;
@@ -199,6 +201,7 @@ int odr_ctx_destroy(odr_ctx *c) {
       for (void *b : c->block_bufs[s][l]) (void)hipFree(b);
       if (c->staged[s][l].base) (void)hipFree(c->staged[s][l].base);
     }
+  for (void *q : c->source_bufs) (void)hipFree(q);
   for (Retired &r : c->graveyard) { (void)hipFree(r.ptr); (void)hipEventDestroy(r.ev); }
   for (void *q : c->registered) if (hipHostUnregister(q) != hipSuccess) (void)hipGetLastError();
   if (c->prep[0]) (void)hipFree(c->prep[0]);
@@ -507,6 +510,53 @@ int odr_source_grid(odr_ctx *c, const odr_proj_desc *proj, const double *dom, in
       s.zi_y[lo] = yl;
     }
   }
+  return 0;
+}
+
+// StructuredReader without a projection (structured.py:44-113): the Delaunay triangulation of the (lon, lat) nodes
+// is prepared on the host (odr_mesh.h: cell diagonals + Lawson flips) and kept in HBM for curvi_locate.
+int odr_source_grid_curvilinear(odr_ctx *c, const double *lon, const double *lat, int ny, int nx,
+                                const double *dom, int lon_mode, int nz, const double *z, int32_t *sid) {
+  REQUIRE(lon && lat && dom && sid, "bad arguments");
+  odr_mesh::Mesh m;
+  if (!odr_mesh::build(m, lon, lat, ny, nx)) return fail(ODR_ERR_INVALID, "curvilinear grid: %s", m.error.c_str());
+  int rc = odr_source_grid(c, nullptr, dom, lon_mode, 0, nz, z, sid);
+  if (rc) return rc;
+  void *dn = nullptr, *dv = nullptr, *dt = nullptr, *db = nullptr;
+  HIPCHK(hipMalloc(&dn, m.nodes.size() * sizeof(double)));
+  HIPCHK(hipMalloc(&dv, m.tri_v.size() * sizeof(int32_t)));
+  HIPCHK(hipMalloc(&dt, m.tri_n.size() * sizeof(int32_t)));
+  HIPCHK(hipMalloc(&db, m.bucket.size() * sizeof(int32_t)));
+  c->source_bufs.push_back(dn); c->source_bufs.push_back(dv); c->source_bufs.push_back(dt); c->source_bufs.push_back(db);
+  HIPCHK(hipMemcpy(dn, m.nodes.data(), m.nodes.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dv, m.tri_v.data(), m.tri_v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dt, m.tri_n.data(), m.tri_n.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(db, m.bucket.data(), m.bucket.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  DevProj &p = c->hw.src[*sid].proj;
+  p.kind = PROJ_CURVILINEAR;
+  p.cv_nodes = (const D2 *)dn; p.cv_tri_v = (const int *)dv; p.cv_tri_n = (const int *)dt; p.cv_bucket = (const int *)db;
+  p.cv_nx = nx; p.cv_maxit = 4 * (nx + ny) + 16; p.cv_nbx = m.nbx; p.cv_nby = m.nby;
+  p.cv_bx0 = m.bx0; p.cv_by0 = m.by0; p.cv_ibx = m.ibx; p.cv_iby = m.iby;
+  c->dirty = true;
+  return 0;
+}
+
+int odr_source_lonlat2xy(odr_ctx *c, int32_t sid, int64_t n, const double *lon, const double *lat, double *x, double *y) {
+  REQUIRE(sid >= 0 && sid < c->nsrc, "bad source id %d", sid);
+  REQUIRE(n >= 0 && (n == 0 || (lon && lat && x && y)), "bad arguments");
+  if (n == 0) return 0;
+  int rc = flush_world(c);
+  if (rc) return rc;
+  double *d = nullptr;
+  HIPCHK(hipMalloc((void **)&d, 4 * sizeof(double) * (size_t)n));
+  HIPCHK(hipMemcpyAsync(d, lon, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d + n, lat, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_lonlat2xy, dim3(nblk(n)), dim3(BLOCK), 0, c->stream, c->dw, sid, (long long)n, d, d + n, d + 2 * n, d + 3 * n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(x, d + 2 * n, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(y, d + 3 * n, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipFree(d));
   return 0;
 }
 
@@ -838,6 +888,7 @@ static bool launch_env_grid(odr_ctx *c, odr_particles *p, const int *grp, int ng
   switch (s.proj.kind) {
     case PROJ_LATLONG: hipLaunchKernelGGL(k_env_grid<PROJ_LATLONG>, g, b, 0, c->stream, c->dw, v, G, rec); break;
     case PROJ_STERE_POLAR: hipLaunchKernelGGL(k_env_grid<PROJ_STERE_POLAR>, g, b, 0, c->stream, c->dw, v, G, rec); break;
+    case PROJ_CURVILINEAR: hipLaunchKernelGGL(k_env_grid<PROJ_CURVILINEAR>, g, b, 0, c->stream, c->dw, v, G, rec); break;
     default: hipLaunchKernelGGL(k_env_grid<PROJ_STERE_EQUIT_SPHERE>, g, b, 0, c->stream, c->dw, v, G, rec); break;
   }
   return true;
@@ -1063,6 +1114,7 @@ static void launch_advect_grid(odr_ctx *c, odr_particles *p, int sid, double t, 
   switch (s.proj.kind) {
     case PROJ_LATLONG: if (is3d) ODR_LAUNCH(PROJ_LATLONG, true); else ODR_LAUNCH(PROJ_LATLONG, false); break;
     case PROJ_STERE_POLAR: if (is3d) ODR_LAUNCH(PROJ_STERE_POLAR, true); else ODR_LAUNCH(PROJ_STERE_POLAR, false); break;
+    case PROJ_CURVILINEAR: if (is3d) ODR_LAUNCH(PROJ_CURVILINEAR, true); else ODR_LAUNCH(PROJ_CURVILINEAR, false); break;
     default: if (is3d) ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, true); else ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, false); break;
   }
 #undef ODR_LAUNCH
@@ -1116,6 +1168,7 @@ static void launch_step_grid(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G
   switch (s.proj.kind) {
     case PROJ_LATLONG: if (is3d) ODR_LAUNCH(PROJ_LATLONG, true); else ODR_LAUNCH(PROJ_LATLONG, false); break;
     case PROJ_STERE_POLAR: if (is3d) ODR_LAUNCH(PROJ_STERE_POLAR, true); else ODR_LAUNCH(PROJ_STERE_POLAR, false); break;
+    case PROJ_CURVILINEAR: if (is3d) ODR_LAUNCH(PROJ_CURVILINEAR, true); else ODR_LAUNCH(PROJ_CURVILINEAR, false); break;
     default: if (is3d) ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, true); else ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, false); break;
   }
 #undef ODR_LAUNCH

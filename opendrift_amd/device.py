@@ -120,6 +120,35 @@ class Context:
         self._grids[sid.value] = dict(xy8=xy8, ny=len(y), nx=len(x), nz=max(nz, 1))
         return sid.value
 
+    def add_grid_curvilinear(self, lon2d, lat2d, z=None, lon_mode=None, domain=None):
+        """Reader without a projection (basereader/structured.py:44-113): 2D lon/lat node arrays, x/y = pixel indices."""
+        lon2d = np.ascontiguousarray(lon2d, dtype=np.float64)
+        lat2d = np.ascontiguousarray(lat2d, dtype=np.float64)
+        assert lon2d.ndim == 2 and lon2d.shape == lat2d.shape
+        ny, nx = lon2d.shape
+        if lon_mode is None:   # modulate_longitude, variables.py:259-280: from the corner longitudes
+            lon_mode = 1 if min(lon2d[0, 0], lon2d[0, -1], lon2d[-1, 0], lon2d[-1, -1]) < 0 else 2
+        if domain is None:
+            domain = (0.0, nx - 1.0, 0.0, ny - 1.0, -np.inf, np.inf)
+        dom, pd = _d(domain)
+        nz = 0 if z is None else int(np.size(z))
+        zz, pz = _d(np.atleast_1d(z)) if nz > 1 else (None, None)
+        sid = C.c_int32()
+        check(self.lib.odr_source_grid_curvilinear(self.h, lon2d.ctypes.data_as(_dp), lat2d.ctypes.data_as(_dp), ny, nx,
+                                                   pd, int(lon_mode), nz, pz, C.byref(sid)))
+        # x = arange(nx), y = arange(ny): the index maps of interpolators.py:32-33,110-111
+        xy8 = np.array([0.0, nx - 1.0, 0.0, ny - 1.0, 0.0, nx - 1.0, 0.0, ny - 1.0])
+        self._grids[sid.value] = dict(xy8=xy8, ny=ny, nx=nx, nz=max(nz, 1))
+        return sid.value
+
+    def lonlat2xy(self, sid, lon, lat):
+        """Variables.lonlat2xy of one source for host positions (variables.py:111-143)."""
+        lon, pl = _d(np.atleast_1d(lon))
+        lat, pa = _d(np.atleast_1d(lat))
+        x, y = np.empty(len(lon)), np.empty(len(lon))
+        check(self.lib.odr_source_lonlat2xy(self.h, sid, len(lon), pl, pa, x.ctypes.data_as(_dp), y.ctypes.data_as(_dp)))
+        return x, y
+
     def upload_block(self, sid, slot, t_epoch, arrays):
         """arrays: {variable: float32 [ny,nx] or [nz,ny,nx]} -- one ReaderBlock / time level."""
         g = self._grids[sid]

@@ -21,8 +21,8 @@ def init(backend=None):
     import torch.distributed as dist
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend is None:   # ODR_DIST_BACKEND=gloo: rehearsal of the N-rank flow on a box with fewer GPUs than ranks
+            backend = os.environ.get('ODR_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':

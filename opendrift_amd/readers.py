@@ -74,7 +74,57 @@ class ContinuousReader(BaseReader):
 
 
 class StructuredReader(BaseReader):
-    pass
+    """basereader/structured.py.  A reader that sets no projection (`proj4` None or 'fakeproj') but has 2D `lon` /
+    `lat` node arrays is 'unprojected' (structured.py:44-113): x/y are pixel indices, xy2lonlat is bilinear in the
+    node arrays (:421-436) and lonlat2xy is the Delaunay lookup (:438-472) -- which runs on the device
+    (odr_source_grid_curvilinear); on the host it is available once the reader is bound to a device context."""
+    projected = True
+
+    def __init__(self):
+        if self.proj4 is None or self.proj4 == 'fakeproj':
+            self.projected = False
+            self.lon = np.ascontiguousarray(self.lon, dtype=np.float64)
+            self.lat = np.ascontiguousarray(self.lat, dtype=np.float64)
+            self.proj4 = 'None'
+            self.xmin = self.ymin = 0.
+            self.delta_x = self.delta_y = 1.
+            self.xmax = self.lon.shape[1] - 1
+            self.ymax = self.lon.shape[0] - 1
+            self.numx, self.numy = self.xmax, self.ymax
+            self.x = np.arange(0, self.xmax + 1)
+            self.y = np.arange(0, self.ymax + 1)
+            self._device_lookup = None
+            proj4, self.proj4 = self.proj4, '+proj=latlong'
+            super().__init__()
+            self.proj4, self.proj = proj4, None
+        else:
+            super().__init__()
+
+    def xy2lonlat(self, x, y):
+        if self.projected:
+            return super().xy2lonlat(x, y)
+        x, y = np.array(x, dtype=np.float64, ndmin=1), np.array(y, dtype=np.float64, ndmin=1)
+        bad = (x < self.xmin) | (x > self.xmax) | (y < self.ymin) | ~np.isfinite(x) | ~np.isfinite(y)
+        xc, yc = np.where(bad, 0.0, x), np.clip(np.where(bad, 0.0, y), 0, self.ymax)   # mode='nearest' beyond ymax
+        i0 = np.minimum(xc.astype(np.int64), self.lon.shape[1] - 2)
+        j0 = np.minimum(yc.astype(np.int64), self.lon.shape[0] - 2)
+        tx, ty = xc - i0, yc - j0
+
+        def bil(a):
+            return ((1 - ty) * ((1 - tx) * a[j0, i0] + tx * a[j0, i0 + 1]) +
+                    ty * ((1 - tx) * a[j0 + 1, i0] + tx * a[j0 + 1, i0 + 1]))
+        lon, lat = bil(self.lon), bil(self.lat)
+        lon[bad] = np.nan
+        lat[bad] = np.nan
+        return lon, lat
+
+    def lonlat2xy(self, lon, lat):
+        if self.projected:
+            return super().lonlat2xy(lon, lat)
+        if self._device_lookup is None:
+            raise RuntimeError('reader %s has no projection: lonlat2xy is the device lookup, available once the '
+                               'reader is part of a simulation (add_reader + first step)' % self.name)
+        return self._device_lookup(lon, lat)
 
 
 class ConstantReader(ContinuousReader):
@@ -151,6 +201,31 @@ class GridReader(StructuredReader):
         self.x, self.y, self.z = np.asarray(x), np.asarray(y), (None if z is None else np.asarray(z, dtype=np.float64))
         self.xmin, self.xmax = float(self.x.min()), float(self.x.max())
         self.ymin, self.ymax = float(self.y.min()), float(self.y.max())
+        self.times = list(times)
+        self.start_time, self.end_time = self.times[0], self.times[-1]
+        self.time_step = (self.times[1] - self.times[0]) if len(self.times) > 1 else None
+        self.arrays = arrays
+        self.variables = list(arrays)
+        super().__init__()
+
+    def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
+        it = self.times.index(time)
+        out = {'x': self.x, 'y': self.y, 'time': time, 'z': self.z if self.z is not None else 0}
+        for v in requested_variables:
+            out[v] = self.arrays[v][it]
+        return out
+
+
+class CurvilinearGridReader(StructuredReader):
+    """In-memory StructuredReader on a curvilinear mesh given by 2D lon/lat node arrays and NO projection -- the
+    situation of reader_ROMS_native / reader_netCDF_CF_generic files that only carry lon(y,x), lat(y,x)
+    (structured.py:44-113).  arrays: {variable: [nt, ny, nx] or [nt, nz, ny, nx]}; vector components are taken as
+    east/north (the reference's rotation for such readers is by the azimuth of due north, i.e. none)."""
+
+    def __init__(self, lon, lat, times, arrays, z=None, name='curvilinear_grid_reader'):
+        self.proj4, self.name = None, name
+        self.lon, self.lat = lon, lat
+        self.z = None if z is None else np.asarray(z, dtype=np.float64)
         self.times = list(times)
         self.start_time, self.end_time = self.times[0], self.times[-1]
         self.time_step = (self.times[1] - self.times[0]) if len(self.times) > 1 else None
@@ -284,7 +359,18 @@ class DeviceReaderBinding:
             block = broadcast(block)
         bx, by = np.asarray(block['x']), np.asarray(block['y'])
         bz = block.get('z', None)
-        if self.sid is None:
+        if self.sid is None and not getattr(r, 'projected', True):
+            # reader without projection: the whole mesh is the device source (blocks must span it)
+            zz = np.atleast_1d(bz) if bz is not None and np.size(bz) > 1 else None
+            if (len(by), len(bx)) != r.lon.shape:
+                raise NotImplementedError('a reader without projection must hand out blocks of its whole mesh')
+            dom = (float(r.xmin), float(r.xmax), float(r.ymin), float(r.ymax), float(r.zmin), float(r.zmax))
+            self.sid = self.ctx.add_grid_curvilinear(r.lon, r.lat, z=zz, domain=dom)
+            sid, ctx = self.sid, self.ctx
+            r._device_lookup = lambda lon, lat: ctx.lonlat2xy(sid, lon, lat)
+            if r.start_time is not None:
+                self.ctx.set_time_coverage(self.sid, _epoch(r.start_time), _epoch(r.end_time), r.always_valid)
+        elif self.sid is None:
             proj = projection.parse_proj4(r.proj4)
             zz = np.atleast_1d(bz) if bz is not None and np.size(bz) > 1 else None
             lon_mode = 1

@@ -232,7 +232,65 @@ def c5_leeway(capsizing=False):
                         **{('p_' + k): v for k, v in props.items()}, **{('g_' + k): v for k, v in g.items()}, **res)
 
 
-SCEN = dict(c1=c1_constant, c2=c2_double_gyre, c3=c3_grid3d, c4=c4_stere, c5=c5_leeway,
+
+class CurvilinearReader(StructuredReader):
+    """StructuredReader WITHOUT a projection: 2D lon/lat node arrays, pixel coordinates as x/y (the
+    'fakeproj' branch, basereader/structured.py:44-113; reader_ROMS_native.py is the stock example)."""
+
+    def __init__(self, lon2d, lat2d, times, arrays, name='synthetic_curvilinear'):
+        self.proj4 = None
+        self.lon, self.lat = lon2d, lat2d
+        self.times = list(times)
+        self.start_time, self.end_time = times[0], times[-1]
+        self.time_step = times[1] - times[0] if len(times) > 1 else None
+        self.z = None
+        self.arrays = arrays
+        self.variables = list(arrays.keys())
+        self.name = name
+        super().__init__()
+
+    def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
+        it = self.times.index(time)
+        out = {'x': self.x, 'y': self.y, 'time': time, 'z': 0}
+        for v in requested_variables:
+            out[v] = np.array(self.arrays[v][it], copy=True)
+        return out
+
+
+def c6_curvilinear():
+    """Curvilinear lon/lat grid (the lon/lat image of a polar-stereographic mesh, i.e. what a ROMS-native /
+    NorKyst file holds as 2D lon,lat) read WITHOUT a projection: positions go through the Delaunay
+    LinearNDInterpolator lon,lat -> pixel lookup (structured.py:74-113,438-472); RK4 + stranding."""
+    from opendrift_amd.projection import stere_polar_inverse
+    g = synth.grid_stere(nx=60, ny=44, nt=3, seed=6, dx=4000.0)
+    X, Y = np.meshgrid(g['x'].astype(np.float64), g['y'].astype(np.float64))
+    lon2d, lat2d = stere_polar_inverse(X, Y, **synth.NORKYST_PROJ)
+    times = [T0 + timedelta(seconds=float(t)) for t in g['t']]
+    arrays = {k: g[k] for k in ('x_sea_water_velocity', 'y_sea_water_velocity', 'land_binary_mask')}
+    o = _base('runge-kutta4')
+    r = CurvilinearReader(lon2d, lat2d, times, arrays)
+    o.add_reader(r)
+    o.set_config('general:coastline_action', 'stranding')
+    o.set_config('general:coastline_approximation_precision', None)
+    o.set_config('drift:stokes_drift', False)
+    rng = np.random.default_rng(6)
+    N = 400
+    x = rng.uniform(4, 54, N)
+    y = rng.uniform(4, 39, N)
+    lon, lat = r.xy2lonlat(x.copy(), y.copy())
+    # the lookup on its own, at the seed positions and at a cloud that also leaves the mesh
+    qlon = np.concatenate([lon, rng.uniform(lon2d.min() - 0.2, lon2d.max() + 0.2, 600)])
+    qlat = np.concatenate([lat, rng.uniform(lat2d.min() - 0.1, lat2d.max() + 0.1, 600)])
+    qx, qy = r.lonlat2xy(qlon, qlat)
+    np.random.seed(0)
+    o.seed_elements(lon=lon, lat=lat, time=T0, wind_drift_factor=0.0)
+    res, _ = _run(o, 900, 8)
+    np.savez_compressed(os.path.join(GOLD, 'c6_curvilinear_rk4.npz'), dt=900.0, lon2d=lon2d, lat2d=lat2d,
+                        qlon=qlon, qlat=qlat, qx=qx, qy=qy,
+                        **{('g_' + k): g[k] for k in ('t',) + tuple(arrays)}, **res)
+
+
+SCEN = dict(c6=c6_curvilinear, c1=c1_constant, c2=c2_double_gyre, c3=c3_grid3d, c4=c4_stere, c5=c5_leeway,
             c5b=lambda: c5_leeway(capsizing=True))
 
 if __name__ == '__main__':

@@ -1,0 +1,119 @@
+"""GPU: readers WITHOUT a projection (2D lon/lat node arrays; basereader/structured.py:44-113,438-472).
+
+The lon,lat -> pixel lookup kernel (csrc/odr_field.hip.h::curvi_locate over the triangulation of csrc/odr_mesh.h)
+against (i) the reference's own StructuredReader.lonlat2xy output (tests/golden/c6_curvilinear_rk4.npz), (ii) the
+scipy construction the reference uses (oracle/curvilinear.py) on meshes that need edge flips, (iii) the host build
+of the same header; then a full OceanDrift run (RK4 + stranding) on such a reader against the reference's run.
+Tolerances: 1e-10 pixels for the lookup (two equivalent float64 2x2 solves), 1e-7 degrees for positions after 8
+steps (north-star tolerance: 1e-6 degrees)."""
+from datetime import datetime, timedelta
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from opendrift_amd import readers
+from opendrift_amd.device import Context
+from opendrift_amd.oceandrift import OceanDrift
+from oracle import curvilinear as cv
+from tests.mesh_host import HostMesh, meshes
+
+pytestmark = pytest.mark.gpu
+T0 = datetime(2020, 1, 1)
+TOL = 1e-10
+
+
+def test_lookup_equals_reference_output():
+    g = golden('c6_curvilinear_rk4.npz')
+    ctx = Context(seed=0)
+    sid = ctx.add_grid_curvilinear(g['lon2d'], g['lat2d'])
+    x, y = ctx.lonlat2xy(sid, g['qlon'], g['qlat'])
+    ins = cv.inside_outline(g['lon2d'], g['lat2d'], g['qlon'], g['qlat'])
+    assert np.array_equal(np.isfinite(x), ins) and np.array_equal(np.isfinite(y), ins)
+    assert not np.any(np.isfinite(x) & np.isnan(g['qx']))
+    assert np.abs(x - g['qx'])[ins].max() < TOL and np.abs(y - g['qy'])[ins].max() < TOL
+    hx, hy = HostMesh(g['lon2d'], g['lat2d']).locate(g['qlon'], g['qlat'])   # same algorithm on the host: same bits
+    assert np.array_equal(x[ins], hx[ins]) and np.array_equal(y[ins], hy[ins])
+
+
+@pytest.mark.parametrize('name', list(meshes()))
+def test_lookup_on_sheared_and_mirrored_meshes(name):
+    lon2d, lat2d, _ = meshes()[name]
+    ctx = Context(seed=0)
+    sid = ctx.add_grid_curvilinear(lon2d, lat2d)
+    rng = np.random.default_rng(11)
+    ql = rng.uniform(lon2d.min() - 0.05, lon2d.max() + 0.05, 20000)
+    qa = rng.uniform(lat2d.min() - 0.05, lat2d.max() + 0.05, 20000)
+    x, y = ctx.lonlat2xy(sid, ql, qa)
+    xr, yr = cv.lonlat2xy_reference(lon2d, lat2d, ql, qa)
+    ins = cv.inside_outline(lon2d, lat2d, ql, qa)
+    assert (np.isfinite(x) != ins).sum() <= 4     # only points within rounding distance of the outline
+    both = np.isfinite(x) & np.isfinite(xr)
+    assert both.sum() > 5000
+    assert np.abs(x - xr)[both].max() < TOL and np.abs(y - yr)[both].max() < TOL
+    assert not np.any(np.isfinite(x) & np.isnan(xr))
+    # pixel-index corners map to themselves
+    x, y = ctx.lonlat2xy(sid, lon2d[3:6, 4:9].ravel(), lat2d[3:6, 4:9].ravel())
+    jj, ii = np.mgrid[3:6, 4:9]
+    assert np.abs(x - ii.ravel()).max() < TOL and np.abs(y - jj.ravel()).max() < TOL
+
+
+def test_invalid_mesh_is_refused():
+    lon2d, lat2d, _ = meshes()['rectilinear']
+    bad = lon2d.copy()
+    bad[10, 10] += 0.2
+    with pytest.raises(ValueError, match='folded'):
+        Context(seed=0).add_grid_curvilinear(bad, lat2d)
+
+
+def _reader(g):
+    times = [T0 + timedelta(seconds=float(t)) for t in g['g_t']]
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'land_binary_mask']
+    return readers.CurvilinearGridReader(g['lon2d'], g['lat2d'], times, {k: g['g_' + k] for k in names})
+
+
+def _final(o, n):
+    lon, lat, st = np.full(n, np.nan), np.full(n, np.nan), np.zeros(n, np.int32)
+    for d in (o.elements, o.elements_deactivated):
+        lon[d.ID], lat[d.ID] = d.lon, d.lat
+    # removed elements only: run() ends with interact_with_coastline(final=True) (basemodel/__init__.py:2310), which
+    # may flag elements that the golden step driver (live state after k steps) has not looked at yet
+    st[o.elements_deactivated.ID] = o.elements_deactivated.status
+    return lon, lat, st
+
+
+def _run(g, steps, **env):
+    o = OceanDrift(loglevel=50, seed=0, rng='numpy')
+    r = _reader(g)
+    o.add_reader(r)
+    o.set_config('drift:advection_scheme', 'runge-kutta4')
+    o.set_config('general:coastline_action', 'stranding')
+    o.set_config('drift:stokes_drift', False)
+    np.random.seed(0)
+    o.seed_elements(lon=g['lon'][0], lat=g['lat'][0], time=T0, wind_drift_factor=0.0)
+    o.run(time_step=900, steps=steps)
+    return o, r
+
+
+def test_c6_model_run_on_reader_without_projection():
+    g = golden('c6_curvilinear_rk4.npz')
+    n = g['lon'].shape[1]
+    for k in (1, 8):
+        o, r = _run(g, k)
+        lon, lat, st = _final(o, n)
+        assert np.abs(lon - g['lon'][k]).max() < 1e-7 and np.abs(lat - g['lat'][k]).max() < 1e-7
+        assert np.array_equal(st != 0, g['status'][k] != 0)
+    assert (g['status'][8] != 0).sum() >= 3
+    # once bound, the reader's lonlat2xy is the device lookup (reader API, structured.py:438-472)
+    x, y = r.lonlat2xy(g['qlon'][:50], g['qlat'][:50])
+    assert np.abs(x - g['qx'][:50]).max() < TOL and np.abs(y - g['qy'][:50]).max() < TOL
+
+
+def test_c6_fused_lane_equals_step_by_step_lane(monkeypatch):
+    g = golden('c6_curvilinear_rk4.npz')
+    n = g['lon'].shape[1]
+    o1, _ = _run(g, 8)
+    monkeypatch.setenv('ODR_RUN_UNFUSED', '1')
+    o2, _ = _run(g, 8)
+    a, b = _final(o1, n), _final(o2, n)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
