@@ -117,3 +117,30 @@ def test_c6_fused_lane_equals_step_by_step_lane(monkeypatch):
     o2, _ = _run(g, 8)
     a, b = _final(o1, n), _final(o2, n)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_c3_fields_on_a_mesh_given_by_2d_lonlat():
+    """The C3 scenario (3D z-level block, RK4, vertical mixing with the reference's np.random draws, w, seafloor) with
+    the SAME rectilinear lon/lat grid handed over as 2D node arrays and no projection: the pixel indices from the
+    triangulation equal the latlong index map to rounding, so the run lands on the reference's golden trajectories
+    (IS3D / vertical-mixing kernels with the curvilinear lookup)."""
+    g = golden('c3_grid3d_rk4_vmix.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity',
+             'ocean_vertical_diffusivity', 'sea_floor_depth_below_sea_level', 'land_binary_mask']
+    lon2d, lat2d = np.meshgrid(g['g_x'].astype(np.float64), g['g_y'].astype(np.float64))
+    times = [T0 + timedelta(seconds=float(t)) for t in g['g_t']]
+    o = OceanDrift(loglevel=50, seed=0, rng='numpy')
+    o.add_reader(readers.CurvilinearGridReader(lon2d, lat2d, times, {k: g['g_' + k] for k in names}, z=g['g_z']))
+    o.set_config('drift:advection_scheme', 'runge-kutta4')
+    o.set_config('drift:vertical_mixing', True)
+    o.set_config('vertical_mixing:timestep', 60)
+    o.set_config('general:coastline_action', 'previous')
+    o.seed_elements(lon=g['lon'][0], lat=g['lat'][0], z=g['z'][0], time=T0)
+    o.run(time_step=600, steps=8)
+    n = g['lon'].shape[1]
+    lon, lat, z = np.full(n, np.nan), np.full(n, np.nan), np.full(n, np.nan)
+    for d in (o.elements, o.elements_deactivated):
+        lon[d.ID], lat[d.ID], z[d.ID] = d.lon, d.lat, d.z
+    assert np.abs(lon - g['lon'][-1]).max() < 1e-7 and np.abs(lat - g['lat'][-1]).max() < 1e-7
+    assert np.abs(z - g['z'][-1]).max() < 1e-5
+    assert o.num_elements_deactivated() == 4
