@@ -231,6 +231,15 @@ int odr_hdiffusion(odr_ctx *ctx, odr_particles *p, double dt, int rng_mode,
  * the positions of the last odr_env_sample; host_uniforms[i_sub*n + i] in ODR_RNG_HOST mode */
 int odr_vmix(odr_ctx *ctx, odr_particles *p, double t_epoch, double dt, double dt_mix,
              int mix_at_surface, int rng_mode, const double *host_uniforms, uint64_t step);
+/* OceanDrift.vertical_mixing with a wind-parameterised diffusivity profile (oceandrift.py:385-395,425-458;
+ * verticaldiffusivity_Large1994 / _Sundby1983, physics_methods.py:203-250): K from each element's wind speed and
+ * ocean_mixed_layer_thickness on 1 m levels down to max(MLD)+1.  This is also what the default 'environment' model
+ * does when no reader provides ocean_vertical_diffusivity (oceandrift.py:431-447).  Needs x_wind, y_wind,
+ * ocean_mixed_layer_thickness, sea_floor_depth_below_sea_level (sea_surface_height) in the environment. */
+enum { ODR_DIFFUSIVITY_LARGE1994 = 1, ODR_DIFFUSIVITY_SUNDBY1983 = 2 };
+int odr_vmix_wind_profile(odr_ctx *ctx, odr_particles *p, int model, double background_diffusivity, double dt,
+                          double dt_mix, int mix_at_surface, int rng_mode, const double *host_uniforms,
+                          uint64_t step);
 /* performance hint: apply vertical_advection (oceandrift.py:315-350) inside the next odr_vmix
  * kernel (OceanDrift.update() calls them back to back, oceandrift.py:201-208) */
 int odr_vmix_fuse_vertical_advection(odr_ctx *ctx, int at_surface);

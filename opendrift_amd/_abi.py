@@ -95,6 +95,7 @@ _SIGNATURES = {
     'odr_leeway': [_vp, _vp, C.c_double, C.c_double, C.c_int, _dp, C.c_uint64],
     'odr_hdiffusion': [_vp, _vp, C.c_double, C.c_int, _dp, _dp, C.c_uint64],
     'odr_vmix': [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _dp, C.c_uint64],
+    'odr_vmix_wind_profile': [_vp, _vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _dp, C.c_uint64],
     'odr_vmix_fuse_vertical_advection': [_vp, C.c_int],
     'odr_vertical_advection': [_vp, _vp, C.c_double, C.c_int],
     'odr_vertical_buoyancy': [_vp, _vp, C.c_double],
@@ -147,6 +148,9 @@ def load():
     lib.odr_version.argtypes = []
     _lib = lib
     return lib
+
+
+DIFFUSIVITY = {'windspeed_Large1994': 1, 'windspeed_Sundby1983': 2}
 
 
 def check(rc):

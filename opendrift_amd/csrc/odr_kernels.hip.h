@@ -444,7 +444,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_positions(PView p, const doubl
 // -------------------------------------------------------------------- reductions
 // red[] slots
 enum { R_NACT = 0, R_LONMIN, R_LONMAX, R_LATMIN, R_LATMAX, R_ZMIN, R_ZMAX, R_DMAX, R_STOKESMAX,
-       R_WSPEEDMAX, R_WDFMAX, R_NSURF, R_HSMAX, R_TPMAX, R_RELWSPEEDMAX, R_SPARE, R_N };
+       R_WSPEEDMAX, R_WDFMAX, R_NSURF, R_HSMAX, R_TPMAX, R_RELWSPEEDMAX, R_MLDMAX, R_N };
 
 __device__ __forceinline__ void atomic_max_d(double *addr, double v) {
   unsigned long long *a = (unsigned long long *)addr, old = *a, assumed;
@@ -489,6 +489,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(PView p, double wind_drift_dep
       v[R_STOKESMAX] = fmax(v[R_STOKESMAX], (double)__fadd_rn(p.env[VAR_SX][i], p.env[VAR_SY][i]));
     if (p.env[VAR_HS]) v[R_HSMAX] = fmax(v[R_HSMAX], (double)p.env[VAR_HS][i]);
     if (p.env[VAR_TP]) v[R_TPMAX] = fmax(v[R_TPMAX], (double)p.env[VAR_TP][i]);
+    if (p.env[VAR_MLD]) v[R_MLDMAX] = fmax(v[R_MLDMAX], (double)p.env[VAR_MLD][i]);
     if (p.env[VAR_XWIND] && p.env[VAR_YWIND]) {
       // advect_wind bookkeeping (physics_methods.py:738-775)
       bool surf = z >= -wdd;
@@ -796,7 +797,8 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
   double z = p.z[i];
   const int moving = p.moving[i];
   const float Zmin = __fmul_rn(-1.f, __fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH][i]));  // float32 (:408)
-  const double wstep = (double)__fmul_rn(p.tv[i], (float)dt_mix) * (double)moving;
+  // w*dt_mix*moving: dt_mix is a NumPy float64 scalar (np.sign, oceandrift.py:416) -> float64 product under NumPy 2
+  const double wstep = __dmul_rn(__dmul_rn((double)p.tv[i], dt_mix), (double)moving);
   rocrand_state_philox4x32_10 st;
   if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
   double2 u2 = make_double2(0.0, 0.0);
@@ -942,7 +944,8 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__
   double z = p.z[i];
   const int moving = p.moving[i];
   const float Zmin = __fmul_rn(-1.f, __fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH][i]));  // float32 (:408)
-  const double wstep = (double)__fmul_rn(p.tv[i], (float)dt_mix) * (double)moving;
+  // w*dt_mix*moving: dt_mix is a NumPy float64 scalar (np.sign, oceandrift.py:416) -> float64 product under NumPy 2
+  const double wstep = __dmul_rn(__dmul_rn((double)p.tv[i], dt_mix), (double)moving);
   rocrand_state_philox4x32_10 st;
   if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
   double2 u2 = make_double2(0.0, 0.0);
@@ -997,6 +1000,101 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__
       u01 = (it & 1) ? u2.y : u2.x;
     }
     double R = __dsub_rn(__dmul_rn(2.0, u01), 1.0);
+    z = __dsub_rn(z, __dmul_rn((double)moving, __dsub_rn(dKdt, __dmul_rn(R, sig))));
+    if (z >= 0) z = -z;
+    if (z < (double)Zmin && moving == 1) z = __dsub_rn((double)__fmul_rn(2.f, Zmin), z);
+    z = __dadd_rn(z, wstep);
+    if (!mix_at_surface && surface) z = 0.0;
+    if (z > 0) z = 0.0;
+    if (z < (double)Zmin) z = (double)Zmin;
+  }
+  if (vadv >= 0 && (vadv ? z <= 0 : z < 0)) {  // vertical_advection (oceandrift.py:315-350)
+    double zz = __dadd_rn(z, __dmul_rn(__dmul_rn((double)moving, (double)p.env[VAR_W][i]), dt));
+    z = zz < 0 ? zz : 0.0;
+  }
+  p.z[i] = z;
+}
+
+// ---- vertical mixing with a wind-parameterised diffusivity profile (oceandrift.py:385-395,425-458) ----
+// K at the 1 m level l (depth l metres) for one element: verticaldiffusivity_Large1994 / _Sundby1983
+// (physics_methods.py:203-250) with NumPy's dtypes: wind speed and mixed-layer depth are float32 environment
+// arrays, Python float constants multiply them in float32, depth / MLD and everything after are float64.
+enum { DIFF_LARGE1994 = 1, DIFF_SUNDBY1983 = 2 };
+template <int MODEL>
+__device__ __forceinline__ double k_windprofile(int l, float w, float mld, double bg) {
+  const double d = (double)l;
+  double K;
+  if (MODEL == DIFF_LARGE1994) {
+    const float ws = __fmul_rn(__fmul_rn(__fmul_rn(w, w), 1.25e-3f), 1.22f);  // windspeed*windspeed * cd * rhoa
+    const double sig = __ddiv_rn(d, (double)mld);
+    const double s2 = __dmul_rn(sig, sig);                                    // sigma**2 (NumPy: square)
+    // sigma**3 is libm pow(sigma, 3.0) in NumPy (< 1 ulp): the cube rounded once from the exact square
+    const double s2lo = fma(sig, sig, -s2);
+    const double ph = __dmul_rn(s2, sig);
+    const double s3 = ph + (fma(s2, sig, -ph) + s2lo * sig);
+    double G = __dadd_rn(__dadd_rn(sig, __dmul_rn(-2.0, s2)), s3);            // 1.*s + -2*s**2 + 1*s**3
+    if (G >= 1) G = 0.0;
+    const float m1 = __fmul_rn(__fmul_rn(mld, 0.2f), 0.4f);                   // MLD * stabilityfunction * 0.4
+    K = __dadd_rn(__dmul_rn(__dmul_rn((double)m1, G), (double)ws), __dmul_rn(sig, bg));
+  } else {
+    const float t = __fmul_rn(__fmul_rn(2.26e-4f, w), w);
+    K = __dadd_rn(76.1e-4, (double)t);
+    if (d > (double)__fsub_rn(mld, 1.0f)) K = __dmul_rn(__dadd_rn(K, bg), 0.5);  // transition
+  }
+  if (d >= (double)mld) K = bg;                                               // cutoff below the mixed layer
+  return K;
+}
+
+// Levels: mixing_z = -arange(0, MLD.max() + 2) (1 m spacing, oceandrift.py:430; MLD.max() from the reduction slot),
+// level index = round-half-even of the clamped depth (interp1d over arange is the identity), np.gradient with the
+// uniform spacing -1.  No profile gather, no LDS: K is a closed form of (level, wind speed, MLD) per element.
+template <int MODEL>
+__global__ __launch_bounds__(BLOCK) void k_vmix_wind(PView p, const double *__restrict__ red, double bg, double dt,
+                                                     double dt_mix_cfg, int mix_at_surface, int rng_mode,
+                                                     const double *__restrict__ huni, unsigned long long seed,
+                                                     unsigned long long step, int vadv) {
+  const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  const int nlev = (int)ceil((double)__fadd_rn((float)red[R_MLDMAX], 2.0f));
+  const float w = speed_f32(p.env[VAR_XWIND][i], p.env[VAR_YWIND][i]);        // wind_speed(), physics_methods.py:885
+  const float mld = p.env[VAR_MLD][i];
+  const double sgn = dt > 0 ? 1.0 : (dt < 0 ? -1.0 : 0.0);
+  const double dt_mix = dt_mix_cfg * sgn;
+  const int ntimes = abs((int)(dt / dt_mix));
+  const double r = 1.0 / 3, ir = 1.0 / r;
+  double z = p.z[i];
+  const int moving = p.moving[i];
+  const float Zmin = __fmul_rn(-1.f, __fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH][i]));
+  const double wstep = __dmul_rn(__dmul_rn((double)p.tv[i], dt_mix), (double)moving);
+  rocrand_state_philox4x32_10 st;
+  if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
+  double2 u2 = make_double2(0.0, 0.0);
+  int zc = -1;
+  double dKdt = 0, sig = 0;
+  for (int it = 0; it < ntimes; ++it) {
+    const bool surface = z == 0;
+    double idx = -z;
+    idx = idx < 0 ? 0.0 : (idx > (double)(nlev - 1) ? (double)(nlev - 1) : idx);
+    const int zi = (int)rint(idx);
+    if (zi != zc) {   // the level changes every few sub-steps at most
+      zc = zi;
+      const double Kz = k_windprofile<MODEL>(zi, w, mld, bg);
+      double g;
+      if (zi == 0) g = __ddiv_rn(__dsub_rn(k_windprofile<MODEL>(1, w, mld, bg), Kz), -1.0);
+      else if (zi == nlev - 1) g = __ddiv_rn(__dsub_rn(Kz, k_windprofile<MODEL>(zi - 1, w, mld, bg)), -1.0);
+      else g = __ddiv_rn(__dsub_rn(k_windprofile<MODEL>(zi + 1, w, mld, bg), k_windprofile<MODEL>(zi - 1, w, mld, bg)), -2.0);
+      double dK = -g;
+      if (fabs(dK) < 1e-10) dK = 0;
+      dKdt = __dmul_rn(dK, dt_mix);
+      sig = sqrt(div_cr(__dmul_rn(__dmul_rn(Kz, fabs(dt_mix)), 2.0), r, ir));
+    }
+    double u01;
+    if (rng_mode == 1) u01 = huni[(size_t)it * p.n + i];
+    else {
+      if ((it & 1) == 0) u2 = rocrand_uniform_double2(&st);
+      u01 = (it & 1) ? u2.y : u2.x;
+    }
+    const double R = __dsub_rn(__dmul_rn(2.0, u01), 1.0);
     z = __dsub_rn(z, __dmul_rn((double)moving, __dsub_rn(dKdt, __dmul_rn(R, sig))));
     if (z >= 0) z = -z;
     if (z < (double)Zmin && moving == 1) z = __dsub_rn((double)__fmul_rn(2.f, Zmin), z);

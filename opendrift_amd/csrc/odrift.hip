@@ -1481,6 +1481,47 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
   return 0;
 }
 
+// vertical_mixing with an analytical diffusivity model (oceandrift.py:385-395,448-458): also what the default
+// 'environment' model does when no reader provides ocean_vertical_diffusivity (:431-447 -> Large et al. 1994)
+int odr_vmix_wind_profile(odr_ctx *c, odr_particles *p, int model, double background_diffusivity, double dt,
+                          double dt_mix, int mix_at_surface, int rng_mode, const double *huni, uint64_t step) {
+  p->epoch++;
+  REQUIRE(model == ODR_DIFFUSIVITY_LARGE1994 || model == ODR_DIFFUSIVITY_SUNDBY1983, "Unknown diffusivity model: %d", model);
+  REQUIRE(dt_mix > 0 && dt != 0, "bad time steps");
+  if (!p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
+  int rc;
+  for (int v : {VAR_SSH, VAR_XWIND, VAR_YWIND, VAR_MLD})
+    if ((rc = ensure_env(c, p, v))) return rc;
+  if ((rc = flush_world(c))) return rc;
+  if (p->n == 0) return 0;
+  p->epoch++;  // the reduction must see this step's mixed-layer depths
+  if ((rc = reduce(c, p, 0.0, 0, false))) return rc;
+  double *du = nullptr;
+  if (rng_mode == ODR_RNG_HOST) {
+    REQUIRE(huni, "host uniforms required in ODR_RNG_HOST mode");
+    int ntimes = abs((int)(dt / (dt_mix * (dt > 0 ? 1 : -1))));
+    void *s;
+    size_t n = (size_t)ntimes * (size_t)p->n;
+    if ((rc = scratch(c, p, sizeof(double) * n, &s))) return rc;
+    du = (double *)s;
+    HIPCHK(hipMemcpyAsync(du, huni, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  int vadv = c->fuse_vadv;
+  c->fuse_vadv = -1;
+  if (vadv >= 0 && !p->env[VAR_W]) return fail(ODR_ERR_STATE, "upward_sea_water_velocity has not been sampled");
+  dim3 g(nblk(p->n)), b(BLOCK);
+  if (model == ODR_DIFFUSIVITY_LARGE1994)
+    hipLaunchKernelGGL(k_vmix_wind<DIFF_LARGE1994>, g, b, 0, c->stream, view(p), c->red, background_diffusivity, dt, dt_mix,
+                       mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv);
+  else
+    hipLaunchKernelGGL(k_vmix_wind<DIFF_SUNDBY1983>, g, b, 0, c->stream, view(p), c->red, background_diffusivity, dt, dt_mix,
+                       mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv);
+  HIPCHK(hipGetLastError());
+  p->epoch++;
+  return 0;
+}
+
 // odr_vmix followed by odr_vertical_advection in one kernel (same particle, same z): request
 // the fusion for the next odr_vmix call
 int odr_vmix_fuse_vertical_advection(odr_ctx *c, int at_surface) {

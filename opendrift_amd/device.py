@@ -440,6 +440,20 @@ class Particles:
             check(self.lib.odr_vmix(self.ctx.h, self.h, float(t_epoch), float(dt), float(dt_mix),
                                     int(mix_at_surface), _abi.RNG_DEVICE, None, step))
 
+    def vmix_analytic(self, model, background_diffusivity, dt, dt_mix, mix_at_surface=False, step=0, uniforms=None,
+                      fuse_vertical_advection=None):
+        """vertical_mixing with 'windspeed_Large1994' / 'windspeed_Sundby1983' profiles (oceandrift.py:385-395,448-458)."""
+        if model not in _abi.DIFFUSIVITY:
+            raise ValueError('Unknown diffusivity model: ' + str(model))      # oceandrift.py:395
+        if fuse_vertical_advection is not None:
+            check(self.lib.odr_vmix_fuse_vertical_advection(self.ctx.h, int(bool(fuse_vertical_advection))))
+        pu, mode = None, _abi.RNG_DEVICE
+        if uniforms is not None:
+            u, pu = _d(np.ascontiguousarray(self._host_order(uniforms)))
+            mode = _abi.RNG_HOST
+        check(self.lib.odr_vmix_wind_profile(self.ctx.h, self.h, _abi.DIFFUSIVITY[model], float(background_diffusivity),
+                                             float(dt), float(dt_mix), int(mix_at_surface), mode, pu, step))
+
     def vertical_advection(self, dt, at_surface=False):
         check(self.lib.odr_vertical_advection(self.ctx.h, self.h, float(dt), int(at_surface)))
 

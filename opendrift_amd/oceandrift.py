@@ -639,6 +639,8 @@ class OceanDrift(OpenDriftSimulation):
                                                  'enum': ['environment', 'stepfunction', 'windspeed_Sundby1983',
                                                           'windspeed_Large1994', 'constant'],
                                                  'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'vertical_mixing:background_diffusivity': {'type': 'float', 'min': 0, 'max': 1, 'default': 1.2e-5,
+                                                       'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
             'drift:wind_drift_depth': {'type': 'float', 'default': 0.1, 'min': 0, 'max': 10,
                                        'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
             'drift:stokes_drift': {'type': 'bool', 'default': True, 'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
@@ -653,11 +655,16 @@ class OceanDrift(OpenDriftSimulation):
         })
         self._set_config_default('drift:max_speed', 2)
 
-    def vertical_mixing(self):   # oceandrift.py:397-571, diffusivity model 'environment'
+    def vertical_mixing(self):   # oceandrift.py:397-571
         if self.get_config('drift:vertical_mixing') is False:
             return
-        if self.get_config('vertical_mixing:diffusivitymodel') not in ('environment', 'constant'):
-            raise NotImplementedError('wind-parameterised diffusivity profiles are not on the device path')
+        model = self.get_config('vertical_mixing:diffusivitymodel')
+        if model == 'environment' and not any(self.readers[n].sid is not None
+                                              for n in self.priority_list.get('ocean_vertical_diffusivity', [])):
+            # no reader / constant for ocean_vertical_diffusivity: the profile is the fallback everywhere and the
+            # reference switches to Large et al. (1994) (oceandrift.py:431-447).  (A reader that is listed but covers
+            # no element at all would do the same there; here its fallback-filled profile is used.)
+            model = 'windspeed_Large1994'
         dt, dt_mix = self.time_step.total_seconds(), self.get_config('vertical_mixing:timestep')
         fuse = None
         if self.get_config('drift:vertical_advection') and type(self).vertical_advection is OceanDrift.vertical_advection:
@@ -666,10 +673,13 @@ class OceanDrift(OpenDriftSimulation):
         kw = dict(mix_at_surface=self.get_config('drift:vertical_mixing_at_surface'), fuse_vertical_advection=fuse)
         if self.rng == 'numpy':
             n, nt = self.num_elements_active(), abs(int(dt / dt_mix))
-            uni = np.stack([np.random.random(n) for _ in range(nt)])
-            self.P.vmix(_epoch(self.time), dt, dt_mix, uniforms=uni, **kw)
+            kw['uniforms'] = np.stack([np.random.random(n) for _ in range(nt)])
         else:
-            self.P.vmix(_epoch(self.time), dt, dt_mix, step=self.steps_calculation, **kw)
+            kw['step'] = self.steps_calculation
+        if model in ('environment', 'constant'):
+            self.P.vmix(_epoch(self.time), dt, dt_mix, **kw)
+        else:   # get_diffusivity_profile (:385-395): raises ValueError('Unknown diffusivity model') like the reference
+            self.P.vmix_analytic(model, self.get_config('vertical_mixing:background_diffusivity'), dt, dt_mix, **kw)
 
     def vertical_buoyancy(self):   # :352-368
         self.P.vertical_buoyancy(self.time_step.total_seconds())

@@ -290,7 +290,69 @@ def c6_curvilinear():
                         **{('g_' + k): g[k] for k in ('t',) + tuple(arrays)}, **res)
 
 
-SCEN = dict(c6=c6_curvilinear, c1=c1_constant, c2=c2_double_gyre, c3=c3_grid3d, c4=c4_stere, c5=c5_leeway,
+
+def c7_diffusivity():
+    """Wind-parameterised diffusivity profiles in vertical_mixing (oceandrift.py:425-458, physics_methods.py:203-250):
+    (a) the default 'environment' model with NO reader for ocean_vertical_diffusivity -> Large et al. (1994),
+    (b) 'windspeed_Sundby1983' with a background diffusivity; wind, mixed layer depth and sea floor from a 2D lon/lat
+    reader (per-element wind speed and MLD, MLD.max() sets the 1 m mixing levels), Euler current, np.random draws
+    recorded.  Plus the two functions on the grid of the reference's test_vertical_diffusivity
+    (tests/models/test_physics.py:50-60) and on random float32 inputs."""
+    from opendrift.models.physics_methods import verticaldiffusivity_Large1994, verticaldiffusivity_Sundby1983
+    rng = np.random.default_rng(7)
+    nx, ny, nt = 40, 32, 3
+    x = np.linspace(2, 8, nx).astype(np.float32)
+    y = np.linspace(59, 63, ny).astype(np.float32)
+    X, Y = np.meshgrid(np.linspace(0, 1, nx), np.linspace(0, 1, ny))
+    t = np.arange(nt) * 3600.0
+    times = [T0 + timedelta(seconds=float(v)) for v in t]
+    g = dict(x=x, y=y, t=t)
+    g['x_wind'] = np.stack([(9 + 6 * np.sin(3 * X + k)) for k in range(nt)]).astype(np.float32)
+    g['y_wind'] = np.stack([(4 * np.cos(4 * Y - k)) for k in range(nt)]).astype(np.float32)
+    g['ocean_mixed_layer_thickness'] = np.stack([(30 + 22.5 * (1 + np.sin(2 * X + 3 * Y)))] * nt).astype(np.float32)
+    g['sea_floor_depth_below_sea_level'] = np.stack([(25 + 150 * X)] * nt).astype(np.float32)
+    g['x_sea_water_velocity'] = np.stack([0.2 * np.cos(3 * Y + k) for k in range(nt)]).astype(np.float32)
+    g['y_sea_water_velocity'] = np.stack([0.2 * np.sin(3 * X - k) for k in range(nt)]).astype(np.float32)
+    names = [k for k in g if k not in ('x', 'y', 't')]
+    N = 300
+    lon = rng.uniform(x[3], x[-4], N)
+    lat = rng.uniform(y[3], y[-4], N)
+    zz = -rng.uniform(0, 60, N)
+    zz[:40] = 0.0
+    tv = np.where(np.arange(N) % 3 == 0, 0.002, np.where(np.arange(N) % 3 == 1, -0.001, 0.0))
+    out = {}
+    for tag, model, bg in (('large', 'environment', 0.0), ('sundby', 'windspeed_Sundby1983', 2e-4)):
+        o = _base('euler')
+        o.add_reader(GridReader('+proj=latlong', x, y, times, {k: g[k] for k in names}))
+        o.set_config('environment:fallback:land_binary_mask', 0)
+        o.set_config('drift:vertical_mixing', True)
+        o.set_config('vertical_mixing:timestep', 60)
+        o.set_config('vertical_mixing:diffusivitymodel', model)
+        o.set_config('vertical_mixing:background_diffusivity', bg)
+        o.set_config('drift:stokes_drift', False)
+        np.random.seed(0)
+        o.seed_elements(lon=lon, lat=lat, z=zz, time=T0, terminal_velocity=tv, wind_drift_factor=0.0)
+        res, draws = _run(o, 900, 6, record_random=True)
+        uni = np.array([np.stack([d[1] for d in step if d[0] == 'random']) for step in draws])
+        out.update({tag + '_' + k: v for k, v in res.items()})
+        out[tag + '_uniforms'] = uni
+        out[tag + '_bg'] = bg
+    # the functions themselves
+    wind, depth = np.meshgrid(np.arange(0, 20, 5), np.arange(0, 80, 5))
+    out['kat_large'] = verticaldiffusivity_Large1994(wind, depth)
+    out['kat_sundby'] = verticaldiffusivity_Sundby1983(wind, depth)
+    w32 = rng.uniform(0, 25, 64).astype(np.float32)
+    mld32 = rng.uniform(8, 90, 64).astype(np.float32)
+    depths = np.abs(-np.arange(0, mld32.max() + 2))
+    W, D = np.meshgrid(w32, depths)
+    out['fn_wind'], out['fn_mld'], out['fn_depths'] = w32, mld32, depths
+    out['fn_large'] = verticaldiffusivity_Large1994(W, D, mld32, 1e-4)
+    out['fn_sundby'] = verticaldiffusivity_Sundby1983(W, D, mld32, 1e-4)
+    np.savez_compressed(os.path.join(GOLD, 'c7_wind_diffusivity.npz'), dt=900.0, dt_mix=60.0, tv=tv,
+                        **{('g_' + k): v for k, v in g.items()}, **out)
+
+
+SCEN = dict(c7=c7_diffusivity, c6=c6_curvilinear, c1=c1_constant, c2=c2_double_gyre, c3=c3_grid3d, c4=c4_stere, c5=c5_leeway,
             c5b=lambda: c5_leeway(capsizing=True))
 
 if __name__ == '__main__':

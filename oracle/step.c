@@ -654,7 +654,10 @@ void orc_vertical_mixing(long n, double *z, const int *moving, const float *tv,
       zz = zz - moving[i] * (dK * dt_mix - R * sqrt((Kz * fabs(dt_mix) * 2 / r)));
       if (zz >= 0) zz = -zz;                                      /* reflect from surface */
       if (zz < Zmin && moving[i] == 1) zz = 2 * Zmin - zz;        /* reflect from seafloor; 2*Zmin float32 */
-      w = (double)(float)(tv[i] * (float)dt_mix) * moving[i];     /* w*dt_mix float32, * int32 -> f64 */
+      /* w*dt_mix: dt_mix = timestep * np.sign(...) is a NumPy float64 SCALAR (oceandrift.py:416), so under NumPy 2
+       * (NEP 50; the golden vectors were written with NumPy 2.2) float32 array * float64 scalar is a float64 product
+       * (NumPy 1.x value-based casting would round it to float32: 2e-9 m per sub-step) */
+      w = (double)tv[i] * dt_mix * moving[i];
       zz = zz + w;
       if (!mix_at_surface && surface) zz = 0.;
       if (zz > 0) zz = 0;                                         /* surface_stick */

@@ -15,7 +15,7 @@ V = orc.VAR
 U, VV, W = 'x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity'
 KZ, DEPTH, SSH, LAND = ('ocean_vertical_diffusivity', 'sea_floor_depth_below_sea_level',
                         'sea_surface_height', 'land_binary_mask')
-XW, YW = 'x_wind', 'y_wind'
+XW, YW, MLD = 'x_wind', 'y_wind', 'ocean_mixed_layer_thickness'
 SX, SY = 'sea_surface_wave_stokes_drift_x_velocity', 'sea_surface_wave_stokes_drift_y_velocity'
 HS, HD = 'sea_surface_wave_significant_height', 'horizontal_diffusivity'
 LEEWAY_PROPS = ['downwind_slope', 'crosswind_slope', 'downwind_offset', 'crosswind_offset', 'downwind_eps',
@@ -115,6 +115,12 @@ class OracleBackend:
         if vadv:
             orc.vertical_advection(self.z, self.moving, self.env[W], dt)
 
+    def vmix_analytic(self, model, background, dt, dt_mix, uniforms):
+        from oracle import diffusivity
+        zlev, Kp = diffusivity.profiles(model, self.env[XW], self.env[YW], self.env[MLD], background)
+        orc.vertical_mixing(self.z, self.moving, self.tv, self.env[DEPTH], self.env[SSH], zlev,
+                            np.ascontiguousarray(Kp), dt, dt_mix, 0, uniforms)
+
     def state(self, n_total):
         lon, lat, z = np.full(n_total, np.nan), np.full(n_total, np.nan), np.full(n_total, np.nan)
         status = np.full(n_total, -1, np.int32)
@@ -178,6 +184,9 @@ class DeviceBackend:
 
     def vmix(self, t, dt, dt_mix, zlevels, uniforms, vadv=True):
         self.P.vmix(t, dt, dt_mix, uniforms=uniforms, fuse_vertical_advection=False if vadv else None)
+
+    def vmix_analytic(self, model, background, dt, dt_mix, uniforms):
+        self.P.vmix_analytic(model, background, dt, dt_mix, uniforms=uniforms)
 
     def state(self, n_total):
         a, d = self.P.download(), self.P.download_deactivated()
@@ -252,6 +261,33 @@ def replay_c5(B, g, nsteps):
             B.leeway(dt, g['uniforms'][k])
         out.append(B.state(n))
     return out
+
+
+def replay_c7(B, g, sub, model, background, nsteps, start=0):
+    """c7 golden: Euler current + vertical mixing with a wind-parameterised diffusivity profile.  `start`: first
+    step to replay (the back end then holds golden row `start`)."""
+    dt, dt_mix = float(g['dt']), float(g['dt_mix'])
+    n = sub['lon'].shape[1]
+    out = []
+    names = [U, VV, XW, YW, MLD, DEPTH, SSH, LAND]
+    for k in range(start, nsteps):
+        t = k * dt
+        B.sample(names, t)
+        B.seafloor()
+        B.increase_age(dt)
+        B.store_previous()
+        B.advect('euler', t, dt)
+        B.vmix_analytic(model, background, dt, dt_mix, sub['uniforms'][k])
+        out.append(B.state(n))
+    return out
+
+
+def scenario_c7(g):
+    from scenarios import Scenario
+    names = [U, VV, XW, YW, MLD, DEPTH]
+    levels = [(float(g['g_t'][k]), {nm: g['g_' + nm][k] for nm in names}) for k in range(len(g['g_t']))]
+    return Scenario([('grid', dict(x=g['g_x'], y=g['g_y'], levels=levels))],
+                    fallbacks={U: 0.0, VV: 0.0, XW: 0.0, YW: 0.0, MLD: 50.0, DEPTH: 10000.0, SSH: 0.0, LAND: 0.0})
 
 
 def scenario_c5(g):
