@@ -257,7 +257,20 @@ int odr_coastline(odr_ctx *ctx, odr_particles *p, int action, int stranded_code,
                   int64_t *n_on_land);
 /* increase_age_and_retire (basemodel/__init__.py:2342-2352); max_age_seconds <= 0: no retirement */
 int odr_increase_age(odr_ctx *ctx, odr_particles *p, double dt, double max_age_seconds, int retired_code);
-int odr_seafloor(odr_ctx *ctx, odr_particles *p, int64_t *n_below);
+int odr_seafloor(odr_ctx *ctx, odr_particles *p, int64_t *n_below);   /* 'lift_to_seafloor' */
+/* the other general:seafloor_action values (:768-783): DEACTIVATE flags the element with status_code ('seafloor') and
+ * puts it on the sea floor, PREVIOUS moves it back to the lon/lat of odr_store_previous (z unchanged) */
+enum { ODR_SEAFLOOR_LIFT = 1, ODR_SEAFLOOR_DEACTIVATE = 2, ODR_SEAFLOOR_PREVIOUS = 3 };
+int odr_seafloor_action(odr_ctx *ctx, odr_particles *p, int action, int32_t status_code, int64_t *n_below);
+/* The reference calls interact_with_seafloor() again INSIDE update(): from vertical_buoyancy (oceandrift.py:362-368)
+ * and from every sub-step of vertical_mixing (:555-559).  This sets what odr_vertical_buoyancy / odr_vmix* do with an
+ * element below the sea floor there (default ODR_SEAFLOOR_LIFT; 0 = 'none'). */
+int odr_set_seafloor_action(odr_ctx *ctx, int action, int32_t status_code);
+/* number of active-set elements currently flagged with status_code (not yet removed by odr_compact) */
+int odr_particles_count_status(odr_ctx *ctx, odr_particles *p, int32_t status_code, int64_t *n);
+/* status_categories grow in the order in which reasons FIRST OCCUR (deactivate_elements, :1778-1781): a caller hands
+ * out a provisional code for a reason not seen yet, counts it, and renumbers it once the category index is known */
+int odr_particles_remap_status(odr_ctx *ctx, odr_particles *p, int32_t from_code, int32_t to_code);
 /* deactivate elements flagged by the host (deactivate_elements, :1774-1795) */
 int odr_deactivate(odr_ctx *ctx, odr_particles *p, const uint8_t *mask_host, int32_t status_code);
 /* remove_deactivated_elements (:1797-1826) = LagrangianArray.move_elements (elements.py:197-228):

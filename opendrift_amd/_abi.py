@@ -104,6 +104,10 @@ _SIGNATURES = {
     'odr_increase_age': [_vp, _vp, C.c_double, C.c_double, C.c_int],
     'odr_source_time_coverage': [_vp, C.c_int32, C.c_double, C.c_double, C.c_int],
     'odr_seafloor': [_vp, _vp, _i64p],
+    'odr_seafloor_action': [_vp, _vp, C.c_int, C.c_int32, _i64p],
+    'odr_set_seafloor_action': [_vp, C.c_int, C.c_int32],
+    'odr_particles_count_status': [_vp, _vp, C.c_int32, _i64p],
+    'odr_particles_remap_status': [_vp, _vp, C.c_int32, C.c_int32],
     'odr_deactivate': [_vp, _vp, _P(C.c_uint8), C.c_int32],
     'odr_deactivate_outside': [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32],
     'odr_compact': [_vp, _vp, _i64p],

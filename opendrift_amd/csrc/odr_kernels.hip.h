@@ -701,7 +701,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
                                                 double dt, double dt_mix_cfg, int mix_at_surface,
                                                 int rng_mode, const double *__restrict__ huni,
                                                 unsigned long long seed, unsigned long long step,
-                                                int vadv /* -1 none, 0 below surface, 1 incl. surface */) {
+                                                int vadv /* -1 none, 0 below surface, 1 incl. surface */, int sfl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   const int tid = threadIdx.x;
@@ -795,10 +795,11 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
   const int ntimes = abs((int)(dt / dt_mix));
   const double r = 1.0 / 3, ir = 1.0 / r;
   double z = p.z[i];
-  const int moving = p.moving[i];
+  int moving = p.moving[i];
+  int sf_flags = 0;   // 1: deactivated on the sea floor, 2: moved back horizontally (general:seafloor_action)
   const float Zmin = __fmul_rn(-1.f, __fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH][i]));  // float32 (:408)
   // w*dt_mix*moving: dt_mix is a NumPy float64 scalar (np.sign, oceandrift.py:416) -> float64 product under NumPy 2
-  const double wstep = __dmul_rn(__dmul_rn((double)p.tv[i], dt_mix), (double)moving);
+  double wstep = __dmul_rn(__dmul_rn((double)p.tv[i], dt_mix), (double)moving);
   rocrand_state_philox4x32_10 st;
   if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
   double2 u2 = make_double2(0.0, 0.0);
@@ -847,8 +848,20 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
     z = __dadd_rn(z, wstep);                                                  // buoyancy
     if (!mix_at_surface && surface) z = 0.0;
     if (z > 0) z = 0.0;                                                       // surface_stick
-    if (z < (double)Zmin) z = (double)Zmin;                                   // lift_to_seafloor
+    if (z < (double)Zmin) {   // "let particles stick to bottom": interact_with_seafloor() inside the loop (oceandrift.py:555-559)
+      const int act = sfl & 255;
+      if (act == 3) sf_flags |= 2;                       // previous: lon/lat go back, z stays
+      else if (act) {
+        z = (double)Zmin;                                // lift_to_seafloor / deactivate
+        if (act == 2) { sf_flags |= 1; moving = 0; wstep = 0.0; }
+      }
+    }
   }
+  if (sf_flags & 1) {   // deactivate_elements(reason='seafloor') (basemodel/__init__.py:1774-1795)
+    if (p.status[i] == 0) p.status[i] = sfl >> 8;
+    p.moving[i] = 0;
+  }
+  if (sf_flags & 2) { p.lon[i] = p.plon[i]; p.lat[i] = p.plat[i]; }
   if (vadv >= 0 && (vadv ? z <= 0 : z < 0)) {  // vertical_advection (oceandrift.py:315-350)
     double zz = __dadd_rn(z, __dmul_rn(__dmul_rn((double)moving, (double)p.env[VAR_W][i]), dt));
     z = zz < 0 ? zz : 0.0;
@@ -874,7 +887,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__
                                                     double dt, double dt_mix_cfg, int mix_at_surface,
                                                     int rng_mode, const double *__restrict__ huni,
                                                     unsigned long long seed, unsigned long long step,
-                                                    int vadv) {
+                                                    int vadv, int sfl) {
   constexpr int NL = 4 * NQ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   long long i = pid();
@@ -942,10 +955,11 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__
   const int ntimes = abs((int)(dt / dt_mix));
   const double r = 1.0 / 3, ir = 1.0 / r;
   double z = p.z[i];
-  const int moving = p.moving[i];
+  int moving = p.moving[i];
+  int sf_flags = 0;   // 1: deactivated on the sea floor, 2: moved back horizontally (general:seafloor_action)
   const float Zmin = __fmul_rn(-1.f, __fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH][i]));  // float32 (:408)
   // w*dt_mix*moving: dt_mix is a NumPy float64 scalar (np.sign, oceandrift.py:416) -> float64 product under NumPy 2
-  const double wstep = __dmul_rn(__dmul_rn((double)p.tv[i], dt_mix), (double)moving);
+  double wstep = __dmul_rn(__dmul_rn((double)p.tv[i], dt_mix), (double)moving);
   rocrand_state_philox4x32_10 st;
   if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
   double2 u2 = make_double2(0.0, 0.0);
@@ -1006,8 +1020,20 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__
     z = __dadd_rn(z, wstep);
     if (!mix_at_surface && surface) z = 0.0;
     if (z > 0) z = 0.0;
-    if (z < (double)Zmin) z = (double)Zmin;
+    if (z < (double)Zmin) {   // "let particles stick to bottom": interact_with_seafloor() inside the loop (oceandrift.py:555-559)
+      const int act = sfl & 255;
+      if (act == 3) sf_flags |= 2;                       // previous: lon/lat go back, z stays
+      else if (act) {
+        z = (double)Zmin;                                // lift_to_seafloor / deactivate
+        if (act == 2) { sf_flags |= 1; moving = 0; wstep = 0.0; }
+      }
+    }
   }
+  if (sf_flags & 1) {   // deactivate_elements(reason='seafloor') (basemodel/__init__.py:1774-1795)
+    if (p.status[i] == 0) p.status[i] = sfl >> 8;
+    p.moving[i] = 0;
+  }
+  if (sf_flags & 2) { p.lon[i] = p.plon[i]; p.lat[i] = p.plat[i]; }
   if (vadv >= 0 && (vadv ? z <= 0 : z < 0)) {  // vertical_advection (oceandrift.py:315-350)
     double zz = __dadd_rn(z, __dmul_rn(__dmul_rn((double)moving, (double)p.env[VAR_W][i]), dt));
     z = zz < 0 ? zz : 0.0;
@@ -1052,7 +1078,7 @@ template <int MODEL>
 __global__ __launch_bounds__(BLOCK) void k_vmix_wind(PView p, const double *__restrict__ red, double bg, double dt,
                                                      double dt_mix_cfg, int mix_at_surface, int rng_mode,
                                                      const double *__restrict__ huni, unsigned long long seed,
-                                                     unsigned long long step, int vadv) {
+                                                     unsigned long long step, int vadv, int sfl) {
   const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= p.n) return;
   const int nlev = (int)ceil((double)__fadd_rn((float)red[R_MLDMAX], 2.0f));
@@ -1063,9 +1089,10 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_wind(PView p, const double *__re
   const int ntimes = abs((int)(dt / dt_mix));
   const double r = 1.0 / 3, ir = 1.0 / r;
   double z = p.z[i];
-  const int moving = p.moving[i];
+  int moving = p.moving[i];
+  int sf_flags = 0;   // 1: deactivated on the sea floor, 2: moved back horizontally (general:seafloor_action)
   const float Zmin = __fmul_rn(-1.f, __fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH][i]));
-  const double wstep = __dmul_rn(__dmul_rn((double)p.tv[i], dt_mix), (double)moving);
+  double wstep = __dmul_rn(__dmul_rn((double)p.tv[i], dt_mix), (double)moving);
   rocrand_state_philox4x32_10 st;
   if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
   double2 u2 = make_double2(0.0, 0.0);
@@ -1101,8 +1128,20 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_wind(PView p, const double *__re
     z = __dadd_rn(z, wstep);
     if (!mix_at_surface && surface) z = 0.0;
     if (z > 0) z = 0.0;
-    if (z < (double)Zmin) z = (double)Zmin;
+    if (z < (double)Zmin) {   // "let particles stick to bottom": interact_with_seafloor() inside the loop (oceandrift.py:555-559)
+      const int act = sfl & 255;
+      if (act == 3) sf_flags |= 2;                       // previous: lon/lat go back, z stays
+      else if (act) {
+        z = (double)Zmin;                                // lift_to_seafloor / deactivate
+        if (act == 2) { sf_flags |= 1; moving = 0; wstep = 0.0; }
+      }
+    }
   }
+  if (sf_flags & 1) {   // deactivate_elements(reason='seafloor') (basemodel/__init__.py:1774-1795)
+    if (p.status[i] == 0) p.status[i] = sfl >> 8;
+    p.moving[i] = 0;
+  }
+  if (sf_flags & 2) { p.lon[i] = p.plon[i]; p.lat[i] = p.plat[i]; }
   if (vadv >= 0 && (vadv ? z <= 0 : z < 0)) {  // vertical_advection (oceandrift.py:315-350)
     double zz = __dadd_rn(z, __dmul_rn(__dmul_rn((double)moving, (double)p.env[VAR_W][i]), dt));
     z = zz < 0 ? zz : 0.0;
@@ -1121,8 +1160,9 @@ __global__ __launch_bounds__(BLOCK) void k_vadvect(PView p, double dt, int at_su
   }
 }
 
-// vertical_buoyancy (oceandrift.py:352-368) with lift_to_seafloor
-__global__ __launch_bounds__(BLOCK) void k_vbuoy(PView p, double dt) {
+// vertical_buoyancy (oceandrift.py:352-368); elements below the sea floor "interact_with_seafloor" again, here
+// inside update(): sfl = action | status_code << 8 (0 none, 1 lift_to_seafloor, 2 deactivate, 3 previous)
+__global__ __launch_bounds__(BLOCK) void k_vbuoy(PView p, double dt, int sfl) {
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= p.n) return;
   double z = p.z[i];
@@ -1131,7 +1171,17 @@ __global__ __launch_bounds__(BLOCK) void k_vbuoy(PView p, double dt) {
     z = zz < 0 ? zz : 0.0;
   }
   float Zmin = __fmul_rn(-1.f, __fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH][i]));
-  if (z < (double)Zmin) z = (double)Zmin;
+  if (z < (double)Zmin) {
+    const int act = sfl & 255;
+    if (act == 3) { p.lon[i] = p.plon[i]; p.lat[i] = p.plat[i]; }
+    else if (act) {
+      z = (double)Zmin;
+      if (act == 2) {
+        if (p.status[i] == 0) p.status[i] = sfl >> 8;
+        p.moving[i] = 0;
+      }
+    }
+  }
   p.z[i] = z;
 }
 
@@ -1174,15 +1224,39 @@ __global__ __launch_bounds__(BLOCK) void k_age(PView p, float dt, float max_age,
   }
 }
 
-// interact_with_seafloor 'lift_to_seafloor' (:748-783)
-__global__ __launch_bounds__(BLOCK) void k_seafloor(PView p, unsigned long long *n_hit) {
+// interact_with_seafloor (basemodel/__init__.py:748-783): 1 lift_to_seafloor, 2 deactivate (reason 'seafloor', z set
+// to the sea floor), 3 previous (back to the stored lon/lat; z stays)
+__global__ __launch_bounds__(BLOCK) void k_seafloor(PView p, int action, int code, unsigned long long *n_hit) {
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   bool hit = false;
   if (i < p.n) {
     float floorz = -__fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH] ? p.env[VAR_SSH][i] : 0.f);
-    if (p.z[i] < (double)floorz) { p.z[i] = (double)floorz; hit = true; }
+    if (p.z[i] < (double)floorz) {
+      hit = true;
+      if (action == 3) {
+        p.lon[i] = p.plon[i];
+        p.lat[i] = p.plat[i];
+      } else {
+        if (action == 2) {
+          if (p.status[i] == 0) p.status[i] = code;
+          p.moving[i] = 0;
+        }
+        p.z[i] = (double)floorz;
+      }
+    }
   }
   unsigned long long b = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_hit, (unsigned long long)__popcll(b));
+}
+
+__global__ __launch_bounds__(BLOCK) void k_status_remap(PView p, int from, int to) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < p.n && p.status[i] == from) p.status[i] = to;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_count_status(PView p, int code, unsigned long long *n_hit) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  unsigned long long b = __ballot(i < p.n && p.status[i] == code);
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_hit, (unsigned long long)__popcll(b));
 }
 

@@ -62,6 +62,7 @@ struct odr_ctx {
   hipEvent_t ev0, ev1;
   int nsrc;
   int fuse_vadv;
+  int seafloor;     // general:seafloor_action for the in-update() sea floor checks: action | status_code << 8
   // reductions cached between the horizontal movers of one step (advect_wind -> stokes_drift -> horizontal
   // diffusion read the same maxima: environment, z and properties do not change in between)
   const odr_particles *red_owner;
@@ -184,6 +185,7 @@ int odr_ctx_create(int device, uint64_t seed, odr_ctx **out) {
   c->dirty = true;
   c->nsrc = 0;
   c->fuse_vadv = -1;
+  c->seafloor = ODR_SEAFLOOR_LIFT;
   GeodConst g;
   geod_consts(g);
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_geod), &g, sizeof(GeodConst)));
@@ -1460,9 +1462,9 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
   do {                                                                                                            \
     size_t l2 = sizeof(double) * ((size_t)(4 * NQ) * BLOCK + 3 * (size_t)(4 * NQ));                               \
     if (tl) hipLaunchKernelGGL((k_vmix_col<NQ, true>), g, b, l2, c->stream, c->dw, v, D, dt, dt_mix,              \
-                               mix_at_surface, rng_mode, du, c->seed, st, vadv);                                  \
+                               mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);                                  \
     else hipLaunchKernelGGL((k_vmix_col<NQ, false>), g, b, l2, c->stream, c->dw, v, D, dt, dt_mix,                \
-                            mix_at_surface, rng_mode, du, c->seed, st, vadv);                                     \
+                            mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);                                     \
   } while (0)
     // the smallest instantiated quad count >= nq; over-read stays inside the 64-byte array padding
     if (nq <= 1) VMIX_COL(1);
@@ -1474,9 +1476,9 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
     else if (nq <= 12) VMIX_COL(12);
     else VMIX_COL(16);
 #undef VMIX_COL
-  } else if (nzp <= 16) hipLaunchKernelGGL(k_vmix<16>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv);
-  else if (nzp <= 32) hipLaunchKernelGGL(k_vmix<32>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv);
-  else hipLaunchKernelGGL(k_vmix<1>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv);
+  } else if (nzp <= 16) hipLaunchKernelGGL(k_vmix<16>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
+  else if (nzp <= 32) hipLaunchKernelGGL(k_vmix<32>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
+  else hipLaunchKernelGGL(k_vmix<1>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1513,10 +1515,10 @@ int odr_vmix_wind_profile(odr_ctx *c, odr_particles *p, int model, double backgr
   dim3 g(nblk(p->n)), b(BLOCK);
   if (model == ODR_DIFFUSIVITY_LARGE1994)
     hipLaunchKernelGGL(k_vmix_wind<DIFF_LARGE1994>, g, b, 0, c->stream, view(p), c->red, background_diffusivity, dt, dt_mix,
-                       mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv);
+                       mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv, c->seafloor);
   else
     hipLaunchKernelGGL(k_vmix_wind<DIFF_SUNDBY1983>, g, b, 0, c->stream, view(p), c->red, background_diffusivity, dt, dt_mix,
-                       mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv);
+                       mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv, c->seafloor);
   HIPCHK(hipGetLastError());
   p->epoch++;
   return 0;
@@ -1544,7 +1546,7 @@ int odr_vertical_buoyancy(odr_ctx *c, odr_particles *p, double dt) {
   int rc = ensure_env(c, p, VAR_SSH);
   if (rc) return rc;
   if (p->n == 0) return 0;
-  hipLaunchKernelGGL(k_vbuoy, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt);
+  hipLaunchKernelGGL(k_vbuoy, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, c->seafloor);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1596,15 +1598,44 @@ int odr_coastline(odr_ctx *c, odr_particles *p, int action, int code, int seeded
   return read_counter(c, n_on_land);
 }
 
-int odr_seafloor(odr_ctx *c, odr_particles *p, int64_t *n_below) {
+int odr_seafloor_action(odr_ctx *c, odr_particles *p, int action, int32_t code, int64_t *n_below) {
   p->epoch++;  // invalidates the cached reductions (reduce())
+  REQUIRE(action >= ODR_SEAFLOOR_LIFT && action <= ODR_SEAFLOOR_PREVIOUS, "unknown seafloor action %d", action);
   if (n_below) *n_below = 0;
   if (p->n == 0) return 0;
   if (!p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
   HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
-  hipLaunchKernelGGL(k_seafloor, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), c->counter);
+  hipLaunchKernelGGL(k_seafloor, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), action, (int)code, c->counter);
   HIPCHK(hipGetLastError());
   return read_counter(c, n_below);
+}
+
+int odr_set_seafloor_action(odr_ctx *c, int action, int32_t code) {
+  REQUIRE(action >= 0 && action <= ODR_SEAFLOOR_PREVIOUS, "unknown seafloor action %d", action);
+  c->seafloor = action | ((int)code << 8);
+  return 0;
+}
+
+// elements of the active set carrying status_code (flagged, not yet removed by odr_compact)
+int odr_particles_count_status(odr_ctx *c, odr_particles *p, int32_t code, int64_t *n) {
+  REQUIRE(n, "n NULL");
+  *n = 0;
+  if (p->n == 0) return 0;
+  HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_count_status, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), (int)code, c->counter);
+  HIPCHK(hipGetLastError());
+  return read_counter(c, n);
+}
+
+int odr_particles_remap_status(odr_ctx *c, odr_particles *p, int32_t from, int32_t to) {
+  if (p->n == 0 || from == to) return 0;
+  hipLaunchKernelGGL(k_status_remap, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), (int)from, (int)to);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int odr_seafloor(odr_ctx *c, odr_particles *p, int64_t *n_below) {
+  return odr_seafloor_action(c, p, ODR_SEAFLOOR_LIFT, 0, n_below);
 }
 
 int odr_deactivate(odr_ctx *c, odr_particles *p, const uint8_t *mask, int32_t code) {

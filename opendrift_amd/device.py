@@ -210,6 +210,11 @@ class Context:
     def unpin(self, array):
         check(self.lib.odr_host_unregister(self.h, C.c_void_p(np.asarray(array).ctypes.data)))
 
+    def set_seafloor_action(self, action, status_code=0):
+        """general:seafloor_action for the sea floor checks inside update() (vertical_buoyancy, vertical_mixing)."""
+        a = {'none': 0, 'lift_to_seafloor': 1, 'deactivate': 2, 'previous': 3}[action]
+        check(self.lib.odr_set_seafloor_action(self.h, a, int(status_code)))
+
     def set_time_coverage(self, sid, t_start, t_end, always_valid=False):
         check(self.lib.odr_source_time_coverage(self.h, sid, float(t_start), float(t_end), int(always_valid)))
 
@@ -472,9 +477,19 @@ class Particles:
     def increase_age(self, dt, max_age_seconds=0.0, retired_code=0):
         check(self.lib.odr_increase_age(self.ctx.h, self.h, float(dt), float(max_age_seconds), retired_code))
 
-    def seafloor(self):
+    def count_status(self, status_code):
         n = C.c_int64()
-        check(self.lib.odr_seafloor(self.ctx.h, self.h, C.byref(n)))
+        check(self.lib.odr_particles_count_status(self.ctx.h, self.h, int(status_code), C.byref(n)))
+        return n.value
+
+    def remap_status(self, from_code, to_code):
+        check(self.lib.odr_particles_remap_status(self.ctx.h, self.h, int(from_code), int(to_code)))
+
+    def seafloor(self, action='lift_to_seafloor', status_code=0):
+        """interact_with_seafloor (basemodel/__init__.py:748-783): 'lift_to_seafloor' | 'deactivate' | 'previous'."""
+        n = C.c_int64()
+        a = {'lift_to_seafloor': 1, 'deactivate': 2, 'previous': 3}[action]
+        check(self.lib.odr_seafloor_action(self.ctx.h, self.h, a, int(status_code), C.byref(n)))
         return n.value
 
     def deactivate(self, mask, status_code):

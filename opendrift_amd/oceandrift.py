@@ -49,6 +49,7 @@ class OpenDriftSimulation(Configurable):
         if seed is not None:
             np.random.seed(seed)             # basemodel/__init__.py:326
         self.status_categories = ['active']
+        self._pending_status = []            # reasons handed to the device with a provisional status number
         self.readers = {}                    # name -> DeviceReaderBinding (created by _finalize_environment)
         self._advected = False
         self._readers_host = {}              # name -> (reader, variables) as given to add_reader
@@ -320,10 +321,30 @@ class OpenDriftSimulation(Configurable):
             self.status_categories.append(reason)
         self.P.deactivate(mask, self.status_categories.index(reason))
 
+    _PROVISIONAL = {'outside': 101, 'stranded': 102, 'seeded_on_land': 103, 'seafloor': 104, 'retired': 105}
+
     def _status_code(self, reason):
-        if reason not in self.status_categories:
-            self.status_categories.append(reason)
-        return self.status_categories.index(reason)
+        """Status number for a reason the device may assign.  The reference appends a category when a reason FIRST
+        OCCURS (deactivate_elements, basemodel/__init__.py:1778-1781), so a reason not seen yet gets a provisional
+        number; _resolve_status() turns it into the next category index once an element actually carries it."""
+        if reason in self.status_categories:
+            return self.status_categories.index(reason)
+        code = self._PROVISIONAL[reason]
+        if reason not in self._pending_status:
+            self._pending_status.append(reason)
+        return code
+
+    def _resolve_status(self):
+        """Register the pending reasons that occurred (in the order of the calls that could assign them) and renumber
+        their elements.  No device work when nothing is pending."""
+        pending, self._pending_status = self._pending_status, []
+        for reason in pending:
+            if reason in self.status_categories:
+                continue
+            code = self._PROVISIONAL[reason]
+            if self.P.count_status(code):
+                self.status_categories.append(reason)
+                self.P.remap_status(code, self.status_categories.index(reason))
 
     def interact_with_coastline(self, final=False):   # :670-746
         action = self.get_config('general:coastline_action')
@@ -342,8 +363,22 @@ class OpenDriftSimulation(Configurable):
     def interact_with_seafloor(self):   # :748-783, 'lift_to_seafloor'
         if 'sea_floor_depth_below_sea_level' not in self.priority_list or self.num_elements_active() == 0:
             return
-        if self.get_config('general:seafloor_action', 'lift_to_seafloor') == 'lift_to_seafloor':
-            self.P.seafloor()
+        action = self.get_config('general:seafloor_action', 'lift_to_seafloor')
+        if action == 'lift_to_seafloor' or action == 'previous':
+            self.P.seafloor(action)
+        elif action == 'deactivate':
+            self.P.seafloor(action, self._status_code('seafloor'))
+
+    def _with_seafloor_action(self, call):
+        """The reference calls interact_with_seafloor() again inside update() (vertical_buoyancy oceandrift.py:362-368,
+        every sub-step of vertical_mixing :555-559): the device call gets the configured action; the 'seafloor' status
+        category appears with the first element it deactivates (deactivate_elements, basemodel/__init__.py:1778)."""
+        action = self.get_config('general:seafloor_action', 'lift_to_seafloor')
+        if 'sea_floor_depth_below_sea_level' not in self.priority_list:
+            action = 'none'     # interact_with_seafloor returns before doing anything (:753-754)
+        self.ctx.set_seafloor_action(action, self._status_code('seafloor') if action == 'deactivate' else 0)
+        call()
+        self._resolve_status()
 
     def update_positions(self, x_vel, y_vel):   # :4631-4669
         self._require('Run')
@@ -466,6 +501,7 @@ class OpenDriftSimulation(Configurable):
                           'deactivate_outside', 'deactivate_elements')) and
                       not self.get_config('drift:current_uncertainty') and not self.get_config('drift:wind_uncertainty') and
                       self.get_config('drift:max_age_seconds') is None and
+                      self.get_config('general:seafloor_action', 'lift_to_seafloor') in ('lift_to_seafloor', 'none') and
                       not self.get_config('general:coastline_approximation_precision') and
                       'x_sea_water_velocity' in self.required_variables and 'y_sea_water_velocity' in self.required_variables)
         for i in range(steps):
@@ -501,6 +537,7 @@ class OpenDriftSimulation(Configurable):
                                              else 0),
                         store_previous=True, count=False, seafloor=floor)
                     self._sampled = names
+                    self._resolve_status()
                     self._state_to_buffer(i, out_every, times, from_previous=True)
                     self.P.increase_age(self.time_step.total_seconds())
                     self.P.compact()
@@ -510,10 +547,12 @@ class OpenDriftSimulation(Configurable):
                     self.deactivate_outside()
                     self.interact_with_coastline()
                     self.interact_with_seafloor()
+                    self._resolve_status()
                     self._state_to_buffer(i, out_every, times)
                     max_age = self.get_config('drift:max_age_seconds')
                     self.P.increase_age(self.time_step.total_seconds(), max_age or 0.0,
                                         self._status_code('retired') if max_age else 0)
+                    self._resolve_status()
                     self.P.compact()
                     self.P.store_previous()
                 if self.num_elements_active() > 0:
@@ -530,6 +569,7 @@ class OpenDriftSimulation(Configurable):
                 logger.warning('The simulation stopped before requested end time was reached: %s', e)
                 break
         self.interact_with_coastline(final=True)
+        self._resolve_status()
         self._state_to_buffer(self.steps_calculation, out_every, times, final=True)
         self.mode = 'Result'
         self.result = dict(time=times, **self._hist.finish(len(times)))
@@ -677,12 +717,13 @@ class OceanDrift(OpenDriftSimulation):
         else:
             kw['step'] = self.steps_calculation
         if model in ('environment', 'constant'):
-            self.P.vmix(_epoch(self.time), dt, dt_mix, **kw)
+            self._with_seafloor_action(lambda: self.P.vmix(_epoch(self.time), dt, dt_mix, **kw))
         else:   # get_diffusivity_profile (:385-395): raises ValueError('Unknown diffusivity model') like the reference
-            self.P.vmix_analytic(model, self.get_config('vertical_mixing:background_diffusivity'), dt, dt_mix, **kw)
+            bg = self.get_config('vertical_mixing:background_diffusivity')
+            self._with_seafloor_action(lambda: self.P.vmix_analytic(model, bg, dt, dt_mix, **kw))
 
     def vertical_buoyancy(self):   # :352-368
-        self.P.vertical_buoyancy(self.time_step.total_seconds())
+        self._with_seafloor_action(lambda: self.P.vertical_buoyancy(self.time_step.total_seconds()))
 
     def vertical_advection(self):   # :315-350
         if self.get_config('drift:vertical_advection') is False or getattr(self, '_vadv_fused', False):

@@ -352,7 +352,69 @@ def c7_diffusivity():
                         **{('g_' + k): v for k, v in g.items()}, **out)
 
 
-SCEN = dict(c7=c7_diffusivity, c6=c6_curvilinear, c1=c1_constant, c2=c2_double_gyre, c3=c3_grid3d, c4=c4_stere, c5=c5_leeway,
+
+def c8_seafloor():
+    """general:seafloor_action 'deactivate' and 'previous' (basemodel/__init__.py:748-783): elements at depth carried
+    by an Euler current towards shoaling water (2D lon/lat reader with the sea floor depth), no mixing."""
+    nx, ny, nt = 40, 32, 3
+    x = np.linspace(2, 8, nx).astype(np.float32)
+    y = np.linspace(59, 63, ny).astype(np.float32)
+    X, Y = np.meshgrid(np.linspace(0, 1, nx), np.linspace(0, 1, ny))
+    t = np.arange(nt) * 3600.0
+    times = [T0 + timedelta(seconds=float(v)) for v in t]
+    g = dict(x=x, y=y, t=t)
+    g['sea_floor_depth_below_sea_level'] = np.stack([(20 + 300 * X + 40 * np.sin(3 * Y))] * nt).astype(np.float32)
+    g['x_sea_water_velocity'] = np.stack([-1.2 - 0.3 * np.cos(3 * Y + k) for k in range(nt)]).astype(np.float32)
+    g['y_sea_water_velocity'] = np.stack([0.3 * np.sin(3 * X - k) for k in range(nt)]).astype(np.float32)
+    names = [k for k in g if k not in ('x', 'y', 't')]
+    rng = np.random.default_rng(8)
+    N = 200
+    lon = rng.uniform(x[8], x[-6], N)
+    lat = rng.uniform(y[3], y[-4], N)
+    zz = -rng.uniform(5, 250, N)
+    out = {}
+    for action in ('deactivate', 'previous'):
+        o = _base('euler')
+        o.add_reader(GridReader('+proj=latlong', x, y, times, {k: g[k] for k in names}))
+        o.set_config('environment:fallback:land_binary_mask', 0)
+        o.set_config('general:seafloor_action', action)
+        o.set_config('drift:vertical_mixing', False)
+        o.set_config('drift:vertical_advection', False)
+        o.set_config('drift:stokes_drift', False)
+        np.random.seed(0)
+        o.seed_elements(lon=lon, lat=lat, z=zz, time=T0, wind_drift_factor=0.0)
+        res, _ = _run(o, 900, 8)
+        out.update({action + '_' + k: v for k, v in res.items()})
+        out[action + '_categories'] = np.array(o.status_categories)
+    # 'deactivate' reached INSIDE the vertical-mixing loop (oceandrift.py:555-559): sinking elements, Sundby profile
+    tv = np.where(np.arange(N) % 2 == 0, -0.02, -0.004)
+    o = _base('euler')
+    o.add_reader(GridReader('+proj=latlong', x, y, times, {k: g[k] for k in names}))
+    o.add_reader(reader_constant.Reader({'x_wind': 9.0, 'y_wind': -3.0}))
+    o.set_config('environment:fallback:land_binary_mask', 0)
+    o.set_config('general:seafloor_action', 'deactivate')
+    o.set_config('drift:vertical_mixing', True)
+    o.set_config('vertical_mixing:timestep', 60)
+    o.set_config('vertical_mixing:diffusivitymodel', 'windspeed_Sundby1983')
+    o.set_config('drift:vertical_advection', False)
+    o.set_config('drift:stokes_drift', False)
+    np.random.seed(0)
+    o.seed_elements(lon=lon, lat=lat, z=zz * 0.5, time=T0, wind_drift_factor=0.0, terminal_velocity=tv)
+    res, draws = _run(o, 900, 6, record_random=True)
+    out.update({'deactmix_' + k: v for k, v in res.items()})
+    out['deactmix_categories'] = np.array(o.status_categories)
+    out['deactmix_tv'] = tv
+    mx = max(len(d[1]) for step in draws for d in step if d[0] == 'random')
+    uni = np.full((len(draws), 15, mx), np.nan)
+    for k, step in enumerate(draws):
+        for j, d in enumerate([d for d in step if d[0] == 'random']):
+            uni[k, j, :len(d[1])] = d[1]
+    out['deactmix_uniforms'] = uni
+    np.savez_compressed(os.path.join(GOLD, 'c8_seafloor_actions.npz'), dt=900.0,
+                        **{('g_' + k): v for k, v in g.items()}, **out)
+
+
+SCEN = dict(c8=c8_seafloor, c7=c7_diffusivity, c6=c6_curvilinear, c1=c1_constant, c2=c2_double_gyre, c3=c3_grid3d, c4=c4_stere, c5=c5_leeway,
             c5b=lambda: c5_leeway(capsizing=True))
 
 if __name__ == '__main__':

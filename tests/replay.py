@@ -53,9 +53,15 @@ class OracleBackend:
     def increase_age(self, dt):
         self.age = (self.age + np.float32(dt)).astype(np.float32)
 
-    def seafloor(self):
+    def seafloor(self, action='lift_to_seafloor', code=1):   # basemodel/__init__.py:748-783
         floor = -(self.env[DEPTH] + self.env.get(SSH, np.float32(0)))
         below = self.z < floor
+        if action == 'previous':
+            self.lon[below], self.lat[below] = self.plon[below], self.plat[below]
+            return
+        if action == 'deactivate':
+            self.status[below & (self.status == 0)] = code
+            self.moving[below] = 0
         self.z[below] = floor[below]
 
     def compact(self):
@@ -115,6 +121,13 @@ class OracleBackend:
         if vadv:
             orc.vertical_advection(self.z, self.moving, self.env[W], dt)
 
+    def vbuoy(self, dt, action='lift_to_seafloor', code=1):   # vertical_buoyancy, oceandrift.py:352-368
+        oc = self.z < 0
+        self.z[oc] = np.minimum(0, self.z[oc] + self.tv[oc] * dt)
+        Zmin = -1. * (self.env[DEPTH] + self.env[SSH])
+        if (self.z < Zmin).any() and action != 'none':
+            self.seafloor(action, code)      # interact_with_seafloor() again, inside update()
+
     def vmix_analytic(self, model, background, dt, dt_mix, uniforms):
         from oracle import diffusivity
         zlev, Kp = diffusivity.profiles(model, self.env[XW], self.env[YW], self.env[MLD], background)
@@ -147,8 +160,8 @@ class DeviceBackend:
     def increase_age(self, dt):
         self.P.increase_age(dt)
 
-    def seafloor(self):
-        self.P.seafloor()
+    def seafloor(self, action='lift_to_seafloor', code=1):
+        self.P.seafloor(action, code)
 
     def compact(self):
         self.P.compact()
@@ -184,6 +197,11 @@ class DeviceBackend:
 
     def vmix(self, t, dt, dt_mix, zlevels, uniforms, vadv=True):
         self.P.vmix(t, dt, dt_mix, uniforms=uniforms, fuse_vertical_advection=False if vadv else None)
+
+    def vbuoy(self, dt, action='lift_to_seafloor', code=1):
+        self.ctx.set_seafloor_action(action, code)
+        self.P.vertical_buoyancy(dt)
+        self.ctx.set_seafloor_action('lift_to_seafloor')
 
     def vmix_analytic(self, model, background, dt, dt_mix, uniforms):
         self.P.vmix_analytic(model, background, dt, dt_mix, uniforms=uniforms)
@@ -280,6 +298,33 @@ def replay_c7(B, g, sub, model, background, nsteps, start=0):
         B.vmix_analytic(model, background, dt, dt_mix, sub['uniforms'][k])
         out.append(B.state(n))
     return out
+
+
+def replay_c8(B, g, sub, action, nsteps):
+    """c8 golden: Euler current into shoaling water, general:seafloor_action 'deactivate' / 'previous'."""
+    dt = float(g['dt'])
+    n = sub['lon'].shape[1]
+    out = []
+    names = [U, VV, DEPTH, SSH, LAND]
+    for k in range(nsteps):
+        t = k * dt
+        B.sample(names, t)
+        B.seafloor(action, code=1)
+        B.increase_age(dt)
+        B.compact()
+        B.store_previous()
+        B.advect('euler', t, dt)
+        B.vbuoy(dt, action, code=1)      # OceanDrift.update without mixing: vertical_buoyancy checks the sea floor again
+        out.append(B.state(n))
+    return out
+
+
+def scenario_c8(g):
+    from scenarios import Scenario
+    names = [U, VV, DEPTH]
+    levels = [(float(g['g_t'][k]), {nm: g['g_' + nm][k] for nm in names}) for k in range(len(g['g_t']))]
+    return Scenario([('grid', dict(x=g['g_x'], y=g['g_y'], levels=levels))],
+                    fallbacks={U: 0.0, VV: 0.0, DEPTH: 10000.0, SSH: 0.0, LAND: 0.0})
 
 
 def scenario_c7(g):

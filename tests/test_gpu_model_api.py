@@ -363,3 +363,57 @@ def test_run_fused_lane_equals_step_by_step_lane():
             assert np.array_equal(x, y, equal_nan=True), action
         for k in ('lon', 'lat', 'z', 'status', 'x_sea_water_velocity'):
             assert np.array_equal(ra[k], rb[k], equal_nan=True), (action, k)
+
+
+@pytest.mark.parametrize('action', ['deactivate', 'previous'])
+def test_c8_seafloor_action_model_run(action):
+    """general:seafloor_action through run() (the step-by-step lane: the fused kernel only lifts) vs the reference."""
+    g = golden('c8_seafloor_actions.npz')
+    names = ['sea_floor_depth_below_sea_level', 'x_sea_water_velocity', 'y_sea_water_velocity']
+    o = OceanDrift(loglevel=50, seed=0)
+    o.add_reader(_grid_reader(g, names))
+    o.set_config('environment:fallback:land_binary_mask', 0)
+    o.set_config('drift:advection_scheme', 'euler')
+    o.set_config('general:seafloor_action', action)
+    o.set_config('drift:vertical_mixing', False)
+    o.set_config('drift:vertical_advection', False)
+    o.set_config('drift:stokes_drift', False)
+    o.seed_elements(lon=g[action + '_lon'][0], lat=g[action + '_lat'][0], z=g[action + '_z'][0], time=T0,
+                    wind_drift_factor=0.0)
+    o.run(time_step=900, steps=8)
+    lon, lat, z = _final(o, g[action + '_lon'].shape[1])
+    assert np.abs(lon - g[action + '_lon'][8]).max() < 1e-7 and np.abs(lat - g[action + '_lat'][8]).max() < 1e-7
+    assert np.abs(z - g[action + '_z'][8]).max() < 2e-5
+    assert o.status_categories == list(g[action + '_categories'])
+    assert o.num_elements_deactivated() == int((g[action + '_status'][8] != 0).sum())
+
+
+def test_c8_deactivate_inside_the_mixing_loop_model_run():
+    """general:seafloor_action = 'deactivate' reached inside vertical_mixing's sub-steps (oceandrift.py:555-559;
+    odr_set_seafloor_action): sinking elements, Sundby profile, the reference's np.random draws."""
+    g = golden('c8_seafloor_actions.npz')
+    names = ['sea_floor_depth_below_sea_level', 'x_sea_water_velocity', 'y_sea_water_velocity']
+    o = OceanDrift(loglevel=50, seed=0, rng='numpy')
+    o.add_reader(_grid_reader(g, names))
+    o.add_reader(readers.ConstantReader({'x_wind': 9.0, 'y_wind': -3.0}))
+    o.set_config('environment:fallback:land_binary_mask', 0)
+    o.set_config('drift:advection_scheme', 'euler')
+    o.set_config('general:seafloor_action', 'deactivate')
+    o.set_config('drift:vertical_mixing', True)
+    o.set_config('vertical_mixing:timestep', 60)
+    o.set_config('vertical_mixing:diffusivitymodel', 'windspeed_Sundby1983')
+    o.set_config('drift:vertical_advection', False)
+    o.set_config('drift:stokes_drift', False)
+    np.random.seed(0)
+    o.seed_elements(lon=g['deactmix_lon'][0], lat=g['deactmix_lat'][0], z=g['deactmix_z'][0], time=T0,
+                    wind_drift_factor=0.0, terminal_velocity=g['deactmix_tv'])
+    o.run(time_step=900, steps=6)
+    n = g['deactmix_lon'].shape[1]
+    lon, lat, z = _final(o, n)
+    flagged = np.zeros(n, bool)
+    flagged[o.elements_deactivated.ID] = True
+    flagged[o.elements.ID[o.elements.status != 0]] = True
+    assert np.array_equal(flagged, g['deactmix_status'][6] != 0) and flagged.sum() == 29
+    assert o.status_categories == ['active', 'seafloor']
+    assert np.abs(lon - g['deactmix_lon'][6]).max() < 1e-7 and np.abs(lat - g['deactmix_lat'][6]).max() < 1e-7
+    assert np.abs(z - g['deactmix_z'][6]).max() < 2e-5

@@ -460,3 +460,17 @@ def test_c5b_leeway_capsizing_golden_device(ctx):
     ref[g['ID_final']] = g['capsized_final']
     assert (cap == ref[ids]).all() and cap.sum() > 50        # the same elements capsized
     print('c5b device vs reference:', worst)
+
+
+@pytest.mark.parametrize('action', ['deactivate', 'previous'])
+def test_c8_seafloor_actions_device(ctx, action):
+    """general:seafloor_action 'deactivate' / 'previous' (odr_seafloor_action): device vs the reference's runs and
+    bit for bit vs the oracle."""
+    import replay
+    g = golden('c8_seafloor_actions.npz')
+    sub = {k: g[action + '_' + k] for k in ('lon', 'lat', 'z', 'status')}
+    D = replay.DeviceBackend(replay.scenario_c8(g), ctx, sub['lon'][0], sub['lat'][0], sub['z'][0], wdf=0.0)
+    dev = replay.replay_c8(D, g, sub, action, 8)
+    replay.compare(dev, sub, tol_pos=1e-7, tol_z=2e-5)      # z: first-step float32 depth, DESIGN.md 2.1
+    O = replay.OracleBackend(replay.scenario_c8(g), sub['lon'][0], sub['lat'][0], sub['z'][0], wdf=0.0)
+    _states_close(dev, replay.replay_c8(O, g, sub, action, 8), 1e-10, 1e-12)

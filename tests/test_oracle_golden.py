@@ -167,3 +167,17 @@ def test_c5b_leeway_capsizing_golden_vs_oracle():
     ref[g['ID_final']] = g['capsized_final']
     assert (cap[g['ID_final']] == ref[g['ID_final']]).all() and ref.sum() > 50
     print('c5b oracle vs reference:', worst)
+
+
+@pytest.mark.parametrize('action', ['deactivate', 'previous'])
+def test_c8_seafloor_actions_vs_oracle(action):
+    """general:seafloor_action 'deactivate' / 'previous' (basemodel/__init__.py:748-783) against the reference's runs."""
+    g = golden('c8_seafloor_actions.npz')
+    sub = {k: g[action + '_' + k] for k in ('lon', 'lat', 'z', 'status')}
+    B = replay.OracleBackend(replay.scenario_c8(g), sub['lon'][0], sub['lat'][0], sub['z'][0], wdf=0.0)
+    # z: elements put on the sea floor during the FIRST step carry the reference's first-step float32 index arithmetic
+    # in their depth (DESIGN.md 2.1, deviation 2): one float32 ulp of a ~250 m depth = 1.5e-5 m
+    worst = replay.compare(replay.replay_c8(B, g, sub, action, 8), sub, tol_pos=1e-7, tol_z=2e-5)
+    if action == 'deactivate':
+        assert list(g['deactivate_categories']) == ['active', 'seafloor'] and (sub['status'][8] != 0).sum() == 37
+    print('c8', action, worst)
