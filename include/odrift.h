@@ -195,6 +195,10 @@ typedef struct {              /* optional bookkeeping of the same loop body, bet
   int32_t retired_code;       /* status of elements older than max_age_seconds */
   double age_dt;              /* increase_age_and_retire (:2342-2352): age_seconds += age_dt; 0: not part of this call */
   double max_age_seconds;     /* 0: no retirement */
+  int32_t missing_code;       /* report_missing_variables (:2501-2515), first in the loop's order: elements with a NaN in
+                               * any sampled variable (no reader covers them and there is no fallback) get this status;
+                               * 0: not part of this call */
+  int32_t pad;
 } odr_step_extras;
 int odr_env_coast_advect(odr_ctx *ctx, odr_particles *p, int nvars, const int32_t *var_ids, double t_epoch,
                          int coastline_action, int stranded_code, int seeded_on_land_code,
@@ -255,6 +259,11 @@ int odr_store_previous(odr_ctx *ctx, odr_particles *p);
 int odr_coastline(odr_ctx *ctx, odr_particles *p, int action, int stranded_code,
                   int seeded_on_land_code /* 'previous': deactivate age==0 elements on land, 0 = off */,
                   int64_t *n_on_land);
+/* report_missing_variables (basemodel/__init__.py:2501-2515) on the result of the last odr_env_sample: elements for
+ * which any of var_ids is NaN in the environment (Environment.get_environment's `missing`, environment.py:903-908)
+ * are deactivated with status_code ('missing_data') */
+int odr_deactivate_missing(odr_ctx *ctx, odr_particles *p, int nvars, const int32_t *var_ids,
+                           int32_t status_code, int64_t *n_missing);
 /* increase_age_and_retire (basemodel/__init__.py:2342-2352); max_age_seconds <= 0: no retirement */
 int odr_increase_age(odr_ctx *ctx, odr_particles *p, double dt, double max_age_seconds, int retired_code);
 int odr_seafloor(odr_ctx *ctx, odr_particles *p, int64_t *n_below);   /* 'lift_to_seafloor' */

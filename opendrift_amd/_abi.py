@@ -33,7 +33,7 @@ HIST_PROPERTY0 = 2000
 
 class StepExtras(C.Structure):   # odr_step_extras
     _fields_ = [('seafloor_action', C.c_int32), ('retired_code', C.c_int32), ('age_dt', C.c_double),
-                ('max_age_seconds', C.c_double)]
+                ('max_age_seconds', C.c_double), ('missing_code', C.c_int32), ('pad', C.c_int32)]
 ANALYTIC_DOUBLE_GYRE, ANALYTIC_OSCILLATING = 1, 2
 
 
@@ -106,6 +106,7 @@ _SIGNATURES = {
     'odr_seafloor': [_vp, _vp, _i64p],
     'odr_seafloor_action': [_vp, _vp, C.c_int, C.c_int32, _i64p],
     'odr_set_seafloor_action': [_vp, C.c_int, C.c_int32],
+    'odr_deactivate_missing': [_vp, _vp, C.c_int, _ip, C.c_int32, _i64p],
     'odr_particles_count_status': [_vp, _vp, C.c_int32, _i64p],
     'odr_particles_remap_status': [_vp, _vp, C.c_int32, C.c_int32],
     'odr_deactivate': [_vp, _vp, _P(C.c_uint8), C.c_int32],

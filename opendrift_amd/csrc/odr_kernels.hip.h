@@ -301,7 +301,9 @@ struct StepDesc {
   int store_previous, geo_slot_uv;
   int seafloor, depth_slot;   // interact_with_seafloor 'lift_to_seafloor' (:748-783); depth_slot 2 | 3 | -1 (read p.env[DEPTH])
   float age_dt, max_age;      // increase_age_and_retire (:2342-2352); age_dt == 0: not part of this call
-  int retired_code, pad;
+  int retired_code, missing_code;   // report_missing_variables: NaN in a sampled variable whose fallback is None
+  int nmiss_grp, nmiss_rest;
+  int miss_grp[4], miss_rest[4];    // group slots / variable ids (sampled by the preceding launch) to test for NaN
 };
 
 template <int SCHEME, int PROJ, bool IS3D>
@@ -323,6 +325,18 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevW
     int moving = p.moving[i];
     int st = p.status[i];
     double zz = z;
+    if (S.missing_code) {  // k_deactivate_missing
+      bool miss = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k < S.nmiss_grp) miss |= out[S.miss_grp[k]] != out[S.miss_grp[k]];
+        if (k < S.nmiss_rest) { const float e = p.env[S.miss_rest[k]][i]; miss |= e != e; }
+      }
+      if (miss) {
+        if (st == 0) p.status[i] = st = S.missing_code;
+        p.moving[i] = moving = 0;
+      }
+    }
     if (S.coast_action) {  // k_coast
       const float land = S.land_slot == 2 ? out[2] : p.env[VAR_LAND][i];
       if (land == 1.0f) {
@@ -1246,6 +1260,22 @@ __global__ __launch_bounds__(BLOCK) void k_seafloor(PView p, int action, int cod
     }
   }
   unsigned long long b = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_hit, (unsigned long long)__popcll(b));
+}
+
+struct VarList { int n; int var[NVAR]; };
+// report_missing_variables (basemodel/__init__.py:2501-2515)
+__global__ __launch_bounds__(BLOCK) void k_deactivate_missing(PView p, VarList L, int code, unsigned long long *n_hit) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  bool miss = false;
+  if (i < p.n) {
+    for (int k = 0; k < L.n; ++k) { const float e = p.env[L.var[k]][i]; miss |= e != e; }
+    if (miss) {
+      if (p.status[i] == 0) p.status[i] = code;
+      p.moving[i] = 0;
+    }
+  }
+  unsigned long long b = __ballot(miss);
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_hit, (unsigned long long)__popcll(b));
 }
 

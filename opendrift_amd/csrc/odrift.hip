@@ -1221,13 +1221,21 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
     seen[v] = true;
     if (same_list(v, VAR_U)) grp[ng++] = v; else rest[nrest++] = v;
   }
+  // report_missing_variables inside the fused kernel: the variables that can still be NaN (no fallback)
+  int miss_grp[NVAR], nmg = 0, miss_rest[NVAR], nmr = 0;
+  if (extras && extras->missing_code) {
+    for (int k = 0; k < ng; ++k) if (std::isnan(c->hw.fallback[grp[k]])) miss_grp[nmg++] = k;
+    for (int k = 0; k < nrest; ++k) if (std::isnan(c->hw.fallback[rest[k]])) miss_rest[nmr++] = rest[k];
+  }
   EnvGroupDesc G;
   int sid = -1;
-  bool fuse = p->n > 0 && !getenv("ODR_NO_FAST_PATH") && same_list(VAR_V, VAR_U) && ng <= MAXG &&
+  bool fuse = p->n > 0 && !getenv("ODR_NO_FAST_PATH") && same_list(VAR_V, VAR_U) && ng <= MAXG && nmg <= 4 && nmr <= 4 &&
               uv_fast_source(c, sid, t < t + dt ? t : t + dt, t < t + dt ? t + dt : t) &&
               build_env_group(c, grp, ng, t, G) && G.sid == sid;
   if (!fuse) {
     if ((rc = odr_env_sample(c, p, nvars, var_ids, t, nullptr))) return rc;
+    if (extras && extras->missing_code && (rc = odr_deactivate_missing(c, p, nvars, var_ids, extras->missing_code, nullptr)))
+      return rc;
     if ((rc = odr_coastline(c, p, coast_action, stranded_code, seeded_on_land_code, n_on_land))) return rc;
     if (want_floor && (rc = odr_seafloor(c, p, nullptr))) return rc;
     if (extras && extras->age_dt != 0 &&
@@ -1248,6 +1256,10 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   S.age_dt = extras ? (float)extras->age_dt : 0.0f;
   S.max_age = extras ? (float)extras->max_age_seconds : 0.0f;
   S.retired_code = extras ? extras->retired_code : 0;
+  S.missing_code = extras ? extras->missing_code : 0;
+  S.nmiss_grp = nmg; S.nmiss_rest = nmr;
+  for (int k = 0; k < nmg && k < 4; ++k) S.miss_grp[k] = miss_grp[k];
+  for (int k = 0; k < nmr && k < 4; ++k) S.miss_rest[k] = miss_rest[k];
   if (want_floor && (rc = ensure_env(c, p, VAR_SSH))) return rc;
   if (coast_action) HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
   if (scheme == 0) launch_step_grid<0>(c, p, G, S, t, dt, factor);
@@ -1576,6 +1588,24 @@ int odr_source_time_coverage(odr_ctx *c, int32_t sid, double t_start, double t_e
   c->hw.src[sid].always_valid = always_valid;
   c->dirty = true;
   return 0;
+}
+
+int odr_deactivate_missing(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, int32_t code, int64_t *n_missing) {
+  p->epoch++;
+  REQUIRE(nvars >= 0 && nvars <= NVAR && (nvars == 0 || var_ids), "bad variable list");
+  if (n_missing) *n_missing = 0;
+  VarList L;
+  L.n = 0;
+  for (int k = 0; k < nvars; ++k) {
+    REQUIRE(var_ids[k] >= 0 && var_ids[k] < NVAR, "bad variable id %d", var_ids[k]);
+    // only a variable without fallback can still be NaN after get_environment (environment.py:781-790)
+    if (p->env[var_ids[k]] && std::isnan(c->hw.fallback[var_ids[k]])) L.var[L.n++] = var_ids[k];
+  }
+  if (p->n == 0 || L.n == 0) return 0;
+  HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_deactivate_missing, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), L, (int)code, c->counter);
+  HIPCHK(hipGetLastError());
+  return read_counter(c, n_missing);
 }
 
 int odr_increase_age(odr_ctx *c, odr_particles *p, double dt, double max_age_seconds, int retired_code) {

@@ -343,7 +343,7 @@ class Particles:
 
     def env_coast_advect(self, variables, t_epoch, scheme, dt, coastline='none', stranded_code=1,
                          seeded_on_land_code=0, store_previous=True, factor=1.0, count=True, seafloor=False,
-                         age_dt=0.0, max_age_seconds=0.0, retired_code=0):
+                         age_dt=0.0, max_age_seconds=0.0, retired_code=0, missing_code=0):
         """env_sample -> coastline -> store_previous -> advect in one launch (odr_env_coast_advect).
         count=False skips reading back the number of elements on land (no host synchronisation).  seafloor=True and
         age_dt != 0 add interact_with_seafloor ('lift_to_seafloor') and increase_age_and_retire, in the loop's order."""
@@ -354,8 +354,9 @@ class Particles:
         ids, pi = _i([_vid(v) for v in variables])
         n = C.c_int64()
         ex = None
-        if seafloor or age_dt:
-            ex = C.byref(_abi.StepExtras(1 if seafloor else 0, int(retired_code), float(age_dt), float(max_age_seconds)))
+        if seafloor or age_dt or missing_code:
+            ex = C.byref(_abi.StepExtras(1 if seafloor else 0, int(retired_code), float(age_dt), float(max_age_seconds),
+                                         int(missing_code), 0))
         check(self.lib.odr_env_coast_advect(self.ctx.h, self.h, len(ids), pi, float(t_epoch), a, stranded_code,
                                             seeded_on_land_code, int(bool(store_previous)), s, float(dt),
                                             float(factor), ex, C.byref(n) if count else None))
@@ -476,6 +477,13 @@ class Particles:
 
     def increase_age(self, dt, max_age_seconds=0.0, retired_code=0):
         check(self.lib.odr_increase_age(self.ctx.h, self.h, float(dt), float(max_age_seconds), retired_code))
+
+    def deactivate_missing(self, variables, status_code):
+        """report_missing_variables (basemodel/__init__.py:2501-2515) on the last environment sample."""
+        ids, pi = _i([_vid(v) for v in variables])
+        n = C.c_int64()
+        check(self.lib.odr_deactivate_missing(self.ctx.h, self.h, len(ids), pi, int(status_code), C.byref(n)))
+        return n.value
 
     def count_status(self, status_code):
         n = C.c_int64()

@@ -311,6 +311,15 @@ class OpenDriftSimulation(Configurable):
         rel[idx] = True
         self._n_unreleased -= n
 
+    def _can_be_missing(self, names):
+        """Variables that can still be NaN after get_environment: those without a fallback (environment.py:781-790)."""
+        return [v for v in names if self.get_config('environment:fallback:%s' % v) is None]
+
+    def report_missing_variables(self):   # :2501-2515 on Environment.get_environment's `missing` (environment.py:903-908)
+        names = self._can_be_missing(self._sampled)
+        if names and self.num_elements_active() > 0:
+            self.P.deactivate_missing(names, self._status_code('missing_data'))
+
     def deactivate_outside(self):   # :2354-2382, validity domain of :2169-2179
         dom = [self.get_config('drift:deactivate_%s_of' % k) for k in ('west', 'east', 'south', 'north')]
         if dom != [None, None, None, None]:
@@ -321,7 +330,7 @@ class OpenDriftSimulation(Configurable):
             self.status_categories.append(reason)
         self.P.deactivate(mask, self.status_categories.index(reason))
 
-    _PROVISIONAL = {'outside': 101, 'stranded': 102, 'seeded_on_land': 103, 'seafloor': 104, 'retired': 105}
+    _PROVISIONAL = {'missing_data': 100, 'outside': 101, 'stranded': 102, 'seeded_on_land': 103, 'seafloor': 104, 'retired': 105}
 
     def _status_code(self, reason):
         """Status number for a reason the device may assign.  The reference appends a category when a reason FIRST
@@ -535,7 +544,8 @@ class OpenDriftSimulation(Configurable):
                         stranded_code=self._status_code('stranded') if action == 'stranding' else 1,
                         seeded_on_land_code=(self._status_code('seeded_on_land') if action == 'previous' and self.newly_seeded
                                              else 0),
-                        store_previous=True, count=False, seafloor=floor)
+                        store_previous=True, count=False, seafloor=floor,
+                        missing_code=self._status_code('missing_data') if self._can_be_missing(names) else 0)
                     self._sampled = names
                     self._resolve_status()
                     self._state_to_buffer(i, out_every, times, from_previous=True)
@@ -544,6 +554,7 @@ class OpenDriftSimulation(Configurable):
                     self._advected = True
                 else:
                     self.get_environment()
+                    self.report_missing_variables()
                     self.deactivate_outside()
                     self.interact_with_coastline()
                     self.interact_with_seafloor()

@@ -46,6 +46,13 @@ class OracleBackend:
             self.Kp = orc.get_profile(w, V[profile], self.lon, self.lat, t, nzp)
         self._w = w
 
+    def report_missing(self, names, code):   # basemodel/__init__.py:2501-2515, environment.py:903-908
+        missing = np.zeros(len(self.lon), bool)
+        for k in names:
+            missing |= np.isnan(self.env[k])
+        self.status[missing & (self.status == 0)] = code
+        self.moving[missing] = 0
+
     def coast(self, action, code=1, seeded_code=0):
         orc.coastline({'stranding': 1, 'previous': 2}[action], self.env[LAND], self.lon, self.lat, self.z,
                       self.plon, self.plat, self.status, self.moving, code, self.age, seeded_code)
@@ -154,6 +161,9 @@ class DeviceBackend:
     def sample(self, names, t, profile=None, nzp=0):
         self.P.env_sample(names, t)
 
+    def report_missing(self, names, code):
+        self.P.deactivate_missing(names, code)
+
     def coast(self, action, code=1, seeded_code=0):
         self.P.coastline(action, stranded_code=code, seeded_on_land_code=seeded_code)
 
@@ -244,6 +254,7 @@ def replay_c4(B, g, nsteps):
     for k in range(nsteps):
         t = k * dt
         B.sample(names, t)
+        B.report_missing(names, 2)           # land_binary_mask has no fallback: NaN outside the reader's coverage
         B.coast('stranding', code=1)         # status_categories: ['active', 'stranded', 'missing_data']
         B.increase_age(dt)
         B.compact()

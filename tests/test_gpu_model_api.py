@@ -417,3 +417,27 @@ def test_c8_deactivate_inside_the_mixing_loop_model_run():
     assert o.status_categories == ['active', 'seafloor']
     assert np.abs(lon - g['deactmix_lon'][6]).max() < 1e-7 and np.abs(lat - g['deactmix_lat'][6]).max() < 1e-7
     assert np.abs(z - g['deactmix_z'][6]).max() < 2e-5
+
+
+def test_c4_run_until_reader_time_coverage_ends():
+    """10th step of the C4 golden: the model time has left the reader's time coverage, land_binary_mask (no fallback)
+    is NaN for every element and the reference deactivates them all as 'missing_data'
+    (report_missing_variables, basemodel/__init__.py:2501-2515); the run ends there."""
+    g = golden('c4_stere_rk4_hdiff_strand.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'x_wind', 'y_wind',
+             'sea_surface_wave_stokes_drift_x_velocity', 'sea_surface_wave_stokes_drift_y_velocity', 'land_binary_mask']
+    o = OceanDrift(loglevel=50, seed=0, rng='numpy')
+    o.add_reader(_grid_reader(g, names, proj4=synth.NORKYST_PROJ4))
+    o.set_config('drift:advection_scheme', 'runge-kutta4')
+    o.set_config('environment:constant:horizontal_diffusivity', 10)
+    o.set_config('general:coastline_action', 'stranding')
+    o.seed_elements(lon=g['lon'][0], lat=g['lat'][0], time=T0, wind_drift_factor=float(g['wdf']))
+    o.run(time_step=900, steps=12)
+    n = g['lon'].shape[1]
+    lon, lat, _ = _final(o, n)
+    assert o.num_elements_active() == 0 and o.num_elements_deactivated() == n
+    assert o.status_categories == ['active', 'stranded', 'missing_data']
+    st = np.zeros(n, np.int32)
+    st[o.elements_deactivated.ID] = o.elements_deactivated.status
+    assert np.array_equal(st, g['status'][10])
+    assert np.abs(lon - g['lon'][10]).max() < 1e-7 and np.abs(lat - g['lat'][10]).max() < 1e-7

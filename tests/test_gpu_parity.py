@@ -425,10 +425,10 @@ def test_c4_golden_device(ctx):
     import replay
     g = golden('c4_stere_rk4_hdiff_strand.npz')
     D = replay.DeviceBackend(replay.scenario_c4(g), ctx, g['lon'][0], g['lat'][0], g['z'][0], wdf=float(g['wdf']))
-    dev = replay.replay_c4(D, g, 9)
+    dev = replay.replay_c4(D, g, 10)    # the 10th step: everything 'missing_data' (reader time coverage ended)
     worst = replay.compare(dev, g, tol_pos=1e-7)
     O = replay.OracleBackend(replay.scenario_c4(g), g['lon'][0], g['lat'][0], g['z'][0], wdf=float(g['wdf']))
-    _states_close(dev, replay.replay_c4(O, g, 9), 2e-9, 1e-12)
+    _states_close(dev, replay.replay_c4(O, g, 10), 2e-9, 1e-12)
     print('c4 device vs reference:', worst)
 
 

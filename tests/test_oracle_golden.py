@@ -141,10 +141,11 @@ def test_c3_golden_vs_oracle():
 def test_c4_golden_vs_oracle():
     g = golden('c4_stere_rk4_hdiff_strand.npz')
     B = replay.OracleBackend(replay.scenario_c4(g), g['lon'][0], g['lat'][0], g['z'][0], wdf=float(g['wdf']))
-    # 9 of the 10 stored steps: in the last one the model time has left the reader's time coverage and
-    # the reference deactivates everything as 'missing_data' (host bookkeeping, not on the device path);
-    # step 8 still exercises the uncovered RK sub-stage times (fallback velocity)
-    worst = replay.compare(replay.replay_c4(B, g, 9), g, tol_pos=1e-7)
+    # step 8 exercises the uncovered RK sub-stage times (fallback velocity); in the last step the model time has left
+    # the reader's time coverage: land_binary_mask (no fallback) is NaN and the reference deactivates every element
+    # as 'missing_data' (report_missing_variables, basemodel/__init__.py:2501-2515)
+    worst = replay.compare(replay.replay_c4(B, g, 10), g, tol_pos=1e-7)
+    assert (g['status'][10] != 0).all()
     print('c4 oracle vs reference:', worst)
 
 
