@@ -52,7 +52,9 @@ enum {
   ODR_VAR_SIGNIFICANT_WAVE_HEIGHT = 12,
   ODR_VAR_WAVE_PERIOD = 13,
   ODR_VAR_MIXED_LAYER_THICKNESS = 14,
-  ODR_NVAR = 16
+  ODR_VAR_SEA_WATER_TEMPERATURE = 15, /* OpenOil.required_variables (models/openoil/openoil.py:271-278) */
+  ODR_VAR_SEA_WATER_SALINITY = 16,
+  ODR_NVAR = 18
 };
 
 /* ---- projections of a reader (pyproj.Proj(reader.proj4), basereader/__init__.py:119-137) ---- */

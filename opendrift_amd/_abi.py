@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ODR_LIB') or os.path.join(HERE, 'libodrift_hip.so')   # ODR_LIB: A/B builds (tools/ab_bench.sh)
 
-NVAR = 16
+NVAR = 18
 VARIABLES = {
     'x_sea_water_velocity': 0, 'y_sea_water_velocity': 1, 'x_wind': 2, 'y_wind': 3,
     'upward_sea_water_velocity': 4, 'ocean_vertical_diffusivity': 5,
@@ -18,6 +18,7 @@ VARIABLES = {
     'horizontal_diffusivity': 11, 'sea_surface_wave_significant_height': 12,
     'sea_surface_wave_period_at_variance_spectral_density_maximum': 13,
     'ocean_mixed_layer_thickness': 14,
+    'sea_water_temperature': 15, 'sea_water_salinity': 16,     # OpenOil.required_variables (openoil.py:271-278)
 }
 VARIABLE_NAMES = {v: k for k, v in VARIABLES.items()}
 PROJ_LATLONG, PROJ_STERE_EQUIT_SPHERE, PROJ_STERE_POLAR = 0, 1, 2

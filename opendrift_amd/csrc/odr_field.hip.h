@@ -8,7 +8,7 @@
 
 namespace odr {
 
-constexpr int NVAR = 16;
+constexpr int NVAR = 18;
 constexpr int MAXLEVELS = 4;
 constexpr int MAXSRC = 8;
 constexpr int MAXNZ = 64;
@@ -16,7 +16,7 @@ constexpr int MAXLIST = 4;
 
 enum { VAR_U = 0, VAR_V = 1, VAR_XWIND = 2, VAR_YWIND = 3, VAR_W = 4, VAR_KZ = 5, VAR_SX = 6,
        VAR_SY = 7, VAR_LAND = 8, VAR_DEPTH = 9, VAR_SSH = 10, VAR_HDIFF = 11, VAR_HS = 12,
-       VAR_TP = 13, VAR_MLD = 14 };
+       VAR_TP = 13, VAR_MLD = 14, VAR_TEMP = 15, VAR_SALT = 16 };
 enum { SRC_CONSTANT = 0, SRC_DOUBLE_GYRE = 1, SRC_OSCILLATING = 2, SRC_GRID = 3 };
 enum { PROJ_LATLONG = 0, PROJ_STERE_EQUIT_SPHERE = 1, PROJ_STERE_POLAR = 2, PROJ_CURVILINEAR = 3 };
 // x/y vector pairs are rotated from the reader's CRS to lon/lat (variables.py:799-837); for a reader without a

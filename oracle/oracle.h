@@ -30,7 +30,9 @@ enum {
   ORC_VAR_HS = 12,    /* sea_surface_wave_significant_height */
   ORC_VAR_TP = 13,    /* sea_surface_wave_period_at_variance_spectral_density_maximum */
   ORC_VAR_MLD = 14,   /* ocean_mixed_layer_thickness */
-  ORC_NVAR = 16
+  ORC_VAR_TEMP = 15,  /* sea_water_temperature (OpenOil.required_variables, openoil.py:271-278) */
+  ORC_VAR_SALT = 16,  /* sea_water_salinity */
+  ORC_NVAR = 18
 };
 
 /* ---- projections (proj.c) ---- */

@@ -12,7 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, '_build', 'liboracle.so')
 
-NVAR = 16
+NVAR = 18
 MAXLEVELS = 4
 VAR = dict(x_sea_water_velocity=0, y_sea_water_velocity=1, x_wind=2, y_wind=3,
            upward_sea_water_velocity=4, ocean_vertical_diffusivity=5,
@@ -21,7 +21,7 @@ VAR = dict(x_sea_water_velocity=0, y_sea_water_velocity=1, x_wind=2, y_wind=3,
            sea_floor_depth_below_sea_level=9, sea_surface_height=10,
            horizontal_diffusivity=11, sea_surface_wave_significant_height=12,
            sea_surface_wave_period_at_variance_spectral_density_maximum=13,
-           ocean_mixed_layer_thickness=14)
+           ocean_mixed_layer_thickness=14, sea_water_temperature=15, sea_water_salinity=16)
 PROJ_LATLONG, PROJ_STERE_EQUIT_SPHERE, PROJ_STERE_POLAR = 0, 1, 2
 SRC_CONSTANT, SRC_DOUBLE_GYRE, SRC_OSCILLATING, SRC_GRID = 0, 1, 2, 3
 

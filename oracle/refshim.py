@@ -183,7 +183,9 @@ _MOCKED = ['xarray', 'copernicusmarine', 'cartopy', 'cartopy.crs', 'cartopy.feat
            'cartopy.io', 'cartopy.io.shapereader', 'cartopy.mpl', 'cartopy.mpl.geoaxes', 'cmocean',
            'roaring_landmask', 'geojson', 'coloredlogs', 'shapely', 'shapely.geometry', 'shapely.ops',
            'shapely.vectorized', 'netCDF4', 'dotenv', 'geopandas', 'nc_time_axis', 'trajan', 'cftime',
-           'cfgrib', 'pykdtree', 'pykdtree.kdtree', 'utm', 'adios_db', 'requests', 'earthaccess',
+           'cfgrib', 'pykdtree', 'pykdtree.kdtree', 'utm', 'adios_db', 'adios_db.models', 'adios_db.models.oil',
+           'adios_db.models.oil.oil', 'adios_db.computation', 'adios_db.computation.physical_properties',
+           'adios_db.computation.gnome_oil', 'adios_db.computation.estimations', 'requests', 'earthaccess',
            'pyarrow', 'zarr', 'dask', 'h5netcdf']
 
 

@@ -18,6 +18,8 @@ KZ, DEPTH, SSH, LAND = ('ocean_vertical_diffusivity', 'sea_floor_depth_below_sea
 XW, YW, MLD = 'x_wind', 'y_wind', 'ocean_mixed_layer_thickness'
 SX, SY = 'sea_surface_wave_stokes_drift_x_velocity', 'sea_surface_wave_stokes_drift_y_velocity'
 HS, HD = 'sea_surface_wave_significant_height', 'horizontal_diffusivity'
+TEMP, SALT = 'sea_water_temperature', 'sea_water_salinity'
+OIL_PROPS = ['diameter', 'density', 'viscosity', 'oil_film_thickness', 'diameter_if_entrained']   # property slots
 LEEWAY_PROPS = ['downwind_slope', 'crosswind_slope', 'downwind_offset', 'crosswind_offset', 'downwind_eps',
                 'crosswind_eps', 'jibe_probability', 'orientation', 'capsized']
 
@@ -141,6 +143,38 @@ class OracleBackend:
         orc.vertical_mixing(self.z, self.moving, self.tv, self.env[DEPTH], self.env[SSH], zlev,
                             np.ascontiguousarray(Kp), dt, dt_mix, 0, uniforms)
 
+    def set_oil(self, diameter, density, viscosity, film):
+        n = len(self.lon)
+        self.oil = dict(diameter=np.asarray(diameter, np.float32) * np.ones(n, np.float32),
+                        density=np.asarray(density, np.float64) * np.ones(n),        # float64 after oil_weathering_noaa
+                        viscosity=np.asarray(viscosity, np.float64) * np.ones(n),
+                        film=np.asarray(film, np.float32) * np.ones(n, np.float32))
+
+    def vmix_oil(self, model, background, dt, dt_mix, interfacial_tension, distribution, uniforms):
+        """OpenOil: oil_weathering_noaa's Kelvin conversion (openoil.py:722-724), prepare_vertical_mixing and the
+        mixing loop with the oil physics (oracle/oil.py); no wave height / period from readers (from the wind)."""
+        from oracle import diffusivity, oil
+        o, e = self.oil, self.env
+        T = e[TEMP].copy()
+        T[T < 100] += 273.15
+        hs = oil.significant_wave_height(e[XW], e[YW])
+        wbf = oil.wave_breaking_fraction(e[XW], e[YW])
+        self.probability = oil.entrainment_probability(o['density'], o['viscosity'], interfacial_tension, hs, wbf, dt_mix)
+        if distribution == 'Johansen et al. (2015)':
+            self.dV_50 = oil.droplet_median_johansen2015(o['density'], o['viscosity'], o['film'], hs, interfacial_tension)
+        else:
+            self.dV_50 = oil.droplet_median_li2017(o['density'], o['viscosity'], hs, interfacial_tension)
+        self.diameter_if_entrained = oil.droplet_diameters(self.dV_50, uniforms['diameter'])
+        self.mean_zb = np.mean(1.5 * hs)
+        zlev, Kp = diffusivity.profiles(model, e[XW], e[YW], e[MLD], background)
+        self.w = oil.vertical_mixing_oil(self.z, self.moving, o['diameter'], o['density'], T, e[SALT], e[DEPTH], e[SSH],
+                                         zlev, Kp, dt, dt_mix, self.probability, self.diameter_if_entrained,
+                                         self.mean_zb, uniforms['mix'], uniforms['entrain'], uniforms['intrusion'])
+
+    def oil_state(self):
+        return dict(diameter=self.oil['diameter'].copy(), diameter_if_entrained=self.diameter_if_entrained.copy(),
+                    terminal_velocity=self.w.copy())
+
     def state(self, n_total):
         lon, lat, z = np.full(n_total, np.nan), np.full(n_total, np.nan), np.full(n_total, np.nan)
         status = np.full(n_total, -1, np.int32)
@@ -215,6 +249,18 @@ class DeviceBackend:
 
     def vmix_analytic(self, model, background, dt, dt_mix, uniforms):
         self.P.vmix_analytic(model, background, dt, dt_mix, uniforms=uniforms)
+
+    def set_oil(self, diameter, density, viscosity, film):
+        n = len(self.P)
+        for slot, v in enumerate((diameter, density, viscosity, film)):
+            self.P.set_property(slot, np.asarray(v, np.float32) * np.ones(n, np.float32))
+
+    def vmix_oil(self, model, background, dt, dt_mix, interfacial_tension, distribution, uniforms):
+        self.P.vmix_oil(model, background, dt, dt_mix, interfacial_tension, distribution, uniforms=uniforms)
+
+    def oil_state(self):
+        return dict(diameter=self.P.get_property(0), diameter_if_entrained=self.P.get_property(4),
+                    terminal_velocity=self.P.download()['terminal_velocity'])
 
     def state(self, n_total):
         a, d = self.P.download(), self.P.download_deactivated()
@@ -309,6 +355,37 @@ def replay_c7(B, g, sub, model, background, nsteps, start=0):
         B.vmix_analytic(model, background, dt, dt_mix, sub['uniforms'][k])
         out.append(B.state(n))
     return out
+
+
+def replay_c9(B, g, tag, nsteps, distribution, start=0):
+    """c9 golden: the reference's OpenOil with a constant-property oil: per step oil_weathering (Kelvin), vertical
+    mixing with terminal velocities / slick / wave entrainment, then advect_oil (Euler current; no windage, no Stokes
+    drift) -- OpenOil.update, openoil.py:1218-1239.  Returns [(lon, lat, z, status, oil_state)] per step."""
+    dt, dt_mix = float(g['dt']), float(g['dt_mix'])
+    n = g[tag + '_lon'].shape[1]
+    out = []
+    names = [U, VV, XW, YW, MLD, DEPTH, SSH, LAND, TEMP, SALT]
+    for k in range(start, nsteps):
+        t = k * dt
+        B.sample(names, t)
+        B.seafloor()
+        B.increase_age(dt)
+        B.store_previous()
+        uni = dict(mix=g[tag + '_u_mix'][k], entrain=g[tag + '_u_entrain'][k],
+                   intrusion=np.nan_to_num(g[tag + '_u_intrusion'][k], nan=0.5), diameter=g[tag + '_u_diameter'][k])
+        B.vmix_oil('windspeed_Large1994', float(g['background_diffusivity']), dt, dt_mix, float(g['interfacial_tension']), distribution, uni)
+        B.advect('euler', t, dt)
+        out.append(B.state(n) + (B.oil_state(),))
+    return out
+
+
+def scenario_c9(g):
+    from scenarios import Scenario
+    names = [U, VV, XW, YW, MLD, DEPTH, TEMP, SALT]
+    levels = [(float(g['g_t'][k]), {nm: g['g_' + nm][k] for nm in names}) for k in range(len(g['g_t']))]
+    return Scenario([('grid', dict(x=g['g_x'], y=g['g_y'], levels=levels))],
+                    fallbacks={U: 0.0, VV: 0.0, XW: 0.0, YW: 0.0, MLD: 50.0, DEPTH: 10000.0, SSH: 0.0, LAND: 0.0,
+                               TEMP: 10.0, SALT: 34.0})
 
 
 def replay_c8(B, g, sub, action, nsteps):
