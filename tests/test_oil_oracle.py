@@ -40,10 +40,10 @@ def test_c9_oracle_replays_the_references_openoil(tag, dist, start):
 @pytest.mark.parametrize('tag,dist', CASES)
 def test_c9_probability_and_mean_intrusion_depth(tag, dist):
     g = golden('c9_openoil_mixing.npz')
-    B = _backend(g, tag)
-    out = replay.replay_c9(B, g, tag, 1, dist)
-    assert np.allclose(B.probability, g[tag + '_probability'][1], rtol=1e-14, atol=0)
-    m = g[tag + '_mean_zb'][0]
+    B = _backend(g, tag, 1)           # from the reference's second state (float64 positions)
+    out = replay.replay_c9(B, g, tag, 2, dist, start=1)
+    assert np.allclose(B.probability, g[tag + '_probability'][2], rtol=1e-14, atol=0)
+    m = g[tag + '_mean_zb'][1]
     assert float(B.mean_zb) == m[np.isfinite(m)][0]
     assert len(out) == 1
 
