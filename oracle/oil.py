@@ -51,8 +51,12 @@ def significant_wave_height(x_wind, y_wind, hs=None):
     return 0.0246 * np.power(wind_speed(x_wind, y_wind), 2)
 
 
-def wave_period(x_wind, y_wind, tp=None):
-    """physics_methods.py:918-943 without a period from readers: 2 pi / omega (float64)."""
+def wave_period(x_wind, y_wind, tp=None, in_environment=True):
+    """physics_methods.py:918-943 without a period from readers: 2 pi / omega.  OpenOil has the wave period among
+    its required variables, so calculate_missing_environment_variables (:876-883, called right after
+    get_environment) has already stored that float64 result in the float32 environment recarray and every later
+    call of the step reads the float32 value back (in_environment=True); a model without the variable
+    (OceanDrift) computes the float64 value at every call."""
     if tp is not None and tp.max() > 0:
         T = tp.copy()
     else:
@@ -60,6 +64,8 @@ def wave_period(x_wind, y_wind, tp=None):
         omega = 5 * np.ones(ws.shape)
         omega[ws > 0] = 0.877 * 9.81 / (1.17 * ws[ws > 0])
         T = (2 * np.pi) / omega
+        if in_environment:
+            T = T.astype(np.float32)
     if T.min() == 0:
         T[T == 0] = np.mean(T[T > 0])
     return T
