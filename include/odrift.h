@@ -101,6 +101,9 @@ int odr_particles_download_deactivated(odr_ctx *ctx, odr_particles *p, double *l
 int odr_particles_upload(odr_ctx *ctx, odr_particles *p, const double *lon, const double *lat,
                          const double *z, const int32_t *moving, const float *wind_drift_factor,
                          const float *current_drift_factor, const float *terminal_velocity);
+/* float32 element properties of the active set: "wind_drift_factor", "current_drift_factor", "terminal_velocity",
+ * "age_seconds" (LagrangianArray variables, elements/elements.py:71-88) */
+int odr_particles_download_f32(odr_ctx *ctx, odr_particles *p, const char *name, float *host);
 /* raw device pointers (for torch.distributed / zero-copy consumers): name in
  * {"lon","lat","z","id","status","moving","env:<var_id>"} */
 int odr_particles_device_ptr(odr_ctx *ctx, odr_particles *p, const char *name, void **dptr);
@@ -246,6 +249,27 @@ enum { ODR_DIFFUSIVITY_LARGE1994 = 1, ODR_DIFFUSIVITY_SUNDBY1983 = 2 };
 int odr_vmix_wind_profile(odr_ctx *ctx, odr_particles *p, int model, double background_diffusivity, double dt,
                           double dt_mix, int mix_at_surface, int rng_mode, const double *host_uniforms,
                           uint64_t step);
+/* OpenOil (models/openoil/openoil.py): the oil physics INSIDE the vertical-mixing loop.  Element properties live in
+ * the property slots of odr_particles_set_property: */
+enum { ODR_OIL_DIAMETER = 0, ODR_OIL_DENSITY = 1, ODR_OIL_VISCOSITY = 2, ODR_OIL_FILM_THICKNESS = 3,
+       ODR_OIL_DIAMETER_IF_ENTRAINED = 4 /* written by odr_oil_prepare_mixing */ };
+enum { ODR_DROPLETS_JOHANSEN2015 = 1, ODR_DROPLETS_LI2017 = 2 };   /* wave_entrainment:droplet_size_distribution */
+/* OpenOil.prepare_vertical_mixing (openoil.py:1017-1031): entrainment probability after Li et al. 2017
+ * (physics_methods.py:115-137) and one droplet diameter per element drawn from the Johansen et al. 2015 / Li et al.
+ * 2017 spectrum (:1072-1172: 1e6-point log-normal around the MEAN median diameter of all elements, np.random.choice).
+ * It also arms the next odr_vmix / odr_vmix_wind_profile call on `p`: that call then runs the loop as OpenOil does --
+ * update_terminal_velocity in every sub-step (:922-998; elements.terminal_velocity is overwritten), surface_stick
+ * (:1056-1061), surface_wave_mixing (:1033-1054; entrained elements take their new diameter unless
+ * keep_droplet_diameter).  hs_mode / tp_mode as in odr_stokes_drift, plus tp_mode 3 = period from the wind as stored
+ * in the float32 environment (physics_methods.py:876-883).  temperature_to_kelvin: oil_weathering_noaa's in-place
+ * conversion (:722-724) has happened.  sea_water_density: PhysicsMethods.sea_water_density() (T=10, S=35).
+ * ODR_RNG_HOST: host_u_diameter[n] (the uniforms behind np.random.choice), host_u_entrain[i_sub*n + i] (np.random.uniform(0,1)),
+ * host_u_intrusion[i_sub*n + i] (unit draws of np.random.uniform(0, mean(1.5 Hs)) placed at the element they belong to). */
+int odr_oil_prepare_mixing(odr_ctx *ctx, odr_particles *p, double dt, double dt_mix, double interfacial_tension,
+                           double sea_water_density, int droplet_distribution, int keep_droplet_diameter, int hs_mode,
+                           int tp_mode, int temperature_to_kelvin, int rng_mode, const double *host_u_diameter,
+                           const double *host_u_entrain, const double *host_u_intrusion, uint64_t step);
+int odr_oil_mixing_stats(odr_ctx *ctx, double *mean_zb, double *dv50);
 /* performance hint: apply vertical_advection (oceandrift.py:315-350) inside the next odr_vmix
  * kernel (OceanDrift.update() calls them back to back, oceandrift.py:201-208) */
 int odr_vmix_fuse_vertical_advection(odr_ctx *ctx, int at_surface);

@@ -65,6 +65,7 @@ _SIGNATURES = {
     'odr_particles_download_deactivated': [_vp, _vp, _dp, _dp, _dp, _ip, _ip],
     'odr_particles_upload': [_vp, _vp, _dp, _dp, _dp, _ip, _fp, _fp, _fp],
     'odr_particles_device_ptr': [_vp, _vp, C.c_char_p, _P(_vp)],
+    'odr_particles_download_f32': [_vp, _vp, C.c_char_p, _fp],
     'odr_source_constant': [_vp, C.c_int, _ip, _dp, _ip],
     'odr_source_analytic': [_vp, C.c_int, _dp, C.c_int, _ip],
     'odr_source_grid': [_vp, _P(ProjDesc), _dp, C.c_int, C.c_int, C.c_int, _dp, _ip],
@@ -98,6 +99,9 @@ _SIGNATURES = {
     'odr_vmix': [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _dp, C.c_uint64],
     'odr_vmix_wind_profile': [_vp, _vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _dp, C.c_uint64],
     'odr_vmix_fuse_vertical_advection': [_vp, C.c_int],
+    'odr_oil_prepare_mixing': [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_int, _dp, _dp, _dp, C.c_uint64],
+    'odr_oil_mixing_stats': [_vp, _dp, _dp],
     'odr_vertical_advection': [_vp, _vp, C.c_double, C.c_int],
     'odr_vertical_buoyancy': [_vp, _vp, C.c_double],
     'odr_store_previous': [_vp, _vp],
@@ -157,6 +161,8 @@ def load():
 
 
 DIFFUSIVITY = {'windspeed_Large1994': 1, 'windspeed_Sundby1983': 2}
+DROPLETS = {'Johansen et al. (2015)': 1, 'Li et al. (2017)': 2}
+OIL_PROPERTIES = ['diameter', 'density', 'viscosity', 'oil_film_thickness', 'diameter_if_entrained']
 
 
 def check(rc):

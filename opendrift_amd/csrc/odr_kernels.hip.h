@@ -602,16 +602,19 @@ __global__ __launch_bounds__(BLOCK) void k_stokes(PView p, double dt, int profil
   float sx = p.env[VAR_SX][i], sy = p.env[VAR_SY][i];
   float speed = speed_f32(sx, sy);
   float ws = 0.f;
-  if (hs_mode == 1 || tp_mode == 1) ws = speed_f32(p.env[VAR_XWIND][i], p.env[VAR_YWIND][i]);
+  if (hs_mode == 1 || tp_mode == 1 || tp_mode == 3) ws = speed_f32(p.env[VAR_XWIND][i], p.env[VAR_YWIND][i]);
   TVal H, T;
   if (hs_mode == 0) H = tv_(p.env[VAR_HS][i], 1);
   else if (hs_mode == 1) H = tv_(__fmul_rn((float)0.0246, __fmul_rn(ws, ws)), 1);
   else H = tv_(1, 0);
   if (tp_mode == 0) T = tv_(p.env[VAR_TP][i], 1);
-  else if (tp_mode == 1) {
+  else if (tp_mode == 1 || tp_mode == 3) {
     double omega = 5;
     if (ws > 0) omega = __fdiv_rn((float)(0.877 * 9.81), __fmul_rn((float)1.17, ws));
     T = tv_(__ddiv_rn(2 * kPi, omega), 2);
+    // a model that has the wave period among its variables (OpenOil) reads it back from the float32 environment
+    // (calculate_missing_environment_variables, physics_methods.py:876-883)
+    if (tp_mode == 3) T = tv_((float)T.v, 1);
   } else T = tv_(8, 0);
   TVal mwf = tdiv(tv_(2. * kPi, 0), T);
   TVal transport = tdiv(tmul(mwf, tmul(H, H)), tv_(16, 0));
@@ -693,6 +696,10 @@ __global__ __launch_bounds__(BLOCK) void k_env_noise(PView p, int vx, int vy, do
   p.env[vy][i] = (float)__dadd_rn((double)p.env[vy][i], ny);
 }
 
+}  // namespace odr
+#include "odr_oil.hip.h"
+namespace odr {
+
 // ---------------------------------------------------------------- vertical mixing
 // OceanDrift.vertical_mixing (oceandrift.py:397-571), diffusivity model 'environment'.
 // The diffusivity profile of each particle (all block levels at the position of the last
@@ -710,12 +717,13 @@ __device__ __forceinline__ void kcolumn(const float *__restrict__ col, int nz, f
   for (; k < nz; ++k) out[k] = col[k];
 }
 
-template <int NZMAX>
+template <int NZMAX, bool OIL = false>
 __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, PView p, double t,
                                                 double dt, double dt_mix_cfg, int mix_at_surface,
                                                 int rng_mode, const double *__restrict__ huni,
                                                 unsigned long long seed, unsigned long long step,
-                                                int vadv /* -1 none, 0 below surface, 1 incl. surface */, int sfl) {
+                                                int vadv /* -1 none, 0 below surface, 1 incl. surface */, int sfl,
+                                                OilArgs oa = OilArgs()) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   const int tid = threadIdx.x;
@@ -817,10 +825,14 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
   rocrand_state_philox4x32_10 st;
   if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
   double2 u2 = make_double2(0.0, 0.0);
+  OilLane oil;
+  if (OIL) oil.init(p, i, oa);
   int zi_cur = -1;
   double sig = 0, dKdt = 0;
   for (int it = 0; it < ntimes; ++it) {
     const bool surface = z == 0;
+    if (OIL)   // update_terminal_velocity at the top of every sub-step (oceandrift.py:509), w*dt_mix*moving (:548)
+      wstep = __dmul_rn(__dmul_rn(oil.terminal_velocity(), dt_mix), (double)moving);
     const double d = -z;
     int zi = 0;
 #pragma unroll
@@ -862,6 +874,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
     z = __dadd_rn(z, wstep);                                                  // buoyancy
     if (!mix_at_surface && surface) z = 0.0;
     if (z > 0) z = 0.0;                                                       // surface_stick
+    if (OIL && z >= 0) z = oil.surface_wave_mixing(z, p, i, it, oa, seed, step);   // OpenOil.surface_wave_mixing (:553-554)
     if (z < (double)Zmin) {   // "let particles stick to bottom": interact_with_seafloor() inside the loop (oceandrift.py:555-559)
       const int act = sfl & 255;
       if (act == 3) sf_flags |= 2;                       // previous: lon/lat go back, z stays
@@ -879,6 +892,10 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
   if (vadv >= 0 && (vadv ? z <= 0 : z < 0)) {  // vertical_advection (oceandrift.py:315-350)
     double zz = __dadd_rn(z, __dmul_rn(__dmul_rn((double)moving, (double)p.env[VAR_W][i]), dt));
     z = zz < 0 ? zz : 0.0;
+  }
+  if (OIL) {   // elements.terminal_velocity = W of the last sub-step; entrained elements carry their new droplet size
+    p.tv[i] = (float)oil.W;
+    p.aux[OIL_DIAMETER][i] = oil.d;
   }
   p.z[i] = z;
 }
@@ -1088,11 +1105,11 @@ __device__ __forceinline__ double k_windprofile(int l, float w, float mld, doubl
 // Levels: mixing_z = -arange(0, MLD.max() + 2) (1 m spacing, oceandrift.py:430; MLD.max() from the reduction slot),
 // level index = round-half-even of the clamped depth (interp1d over arange is the identity), np.gradient with the
 // uniform spacing -1.  No profile gather, no LDS: K is a closed form of (level, wind speed, MLD) per element.
-template <int MODEL>
+template <int MODEL, bool OIL = false>
 __global__ __launch_bounds__(BLOCK) void k_vmix_wind(PView p, const double *__restrict__ red, double bg, double dt,
                                                      double dt_mix_cfg, int mix_at_surface, int rng_mode,
                                                      const double *__restrict__ huni, unsigned long long seed,
-                                                     unsigned long long step, int vadv, int sfl) {
+                                                     unsigned long long step, int vadv, int sfl, OilArgs oa = OilArgs()) {
   const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= p.n) return;
   const int nlev = (int)ceil((double)__fadd_rn((float)red[R_MLDMAX], 2.0f));
@@ -1110,10 +1127,14 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_wind(PView p, const double *__re
   rocrand_state_philox4x32_10 st;
   if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
   double2 u2 = make_double2(0.0, 0.0);
+  OilLane oil;
+  if (OIL) oil.init(p, i, oa);
   int zc = -1;
   double dKdt = 0, sig = 0;
   for (int it = 0; it < ntimes; ++it) {
     const bool surface = z == 0;
+    if (OIL)   // update_terminal_velocity at the top of every sub-step (oceandrift.py:509), w*dt_mix*moving (:548)
+      wstep = __dmul_rn(__dmul_rn(oil.terminal_velocity(), dt_mix), (double)moving);
     double idx = -z;
     idx = idx < 0 ? 0.0 : (idx > (double)(nlev - 1) ? (double)(nlev - 1) : idx);
     const int zi = (int)rint(idx);
@@ -1142,6 +1163,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_wind(PView p, const double *__re
     z = __dadd_rn(z, wstep);
     if (!mix_at_surface && surface) z = 0.0;
     if (z > 0) z = 0.0;
+    if (OIL && z >= 0) z = oil.surface_wave_mixing(z, p, i, it, oa, seed, step);   // OpenOil.surface_wave_mixing (:553-554)
     if (z < (double)Zmin) {   // "let particles stick to bottom": interact_with_seafloor() inside the loop (oceandrift.py:555-559)
       const int act = sfl & 255;
       if (act == 3) sf_flags |= 2;                       // previous: lon/lat go back, z stays
@@ -1159,6 +1181,10 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_wind(PView p, const double *__re
   if (vadv >= 0 && (vadv ? z <= 0 : z < 0)) {  // vertical_advection (oceandrift.py:315-350)
     double zz = __dadd_rn(z, __dmul_rn(__dmul_rn((double)moving, (double)p.env[VAR_W][i]), dt));
     z = zz < 0 ? zz : 0.0;
+  }
+  if (OIL) {   // elements.terminal_velocity = W of the last sub-step; entrained elements carry their new droplet size
+    p.tv[i] = (float)oil.W;
+    p.aux[OIL_DIAMETER][i] = oil.d;
   }
   p.z[i] = z;
 }

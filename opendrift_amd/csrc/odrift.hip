@@ -58,6 +58,11 @@ struct odr_ctx {
   std::vector<void *> source_bufs;  // device arrays owned by sources (curvilinear node tables)
   std::vector<void *> registered;   // host ranges page-locked by odr_host_register (released with the context)
   double *red;      // device reduction slots
+  // OpenOil mixing-loop physics (odr_oil_prepare_mixing): armed for the next odr_vmix* call on `oil_owner`
+  const odr_particles *oil_owner;
+  OilArgs oil;
+  double *oil_stat, *oil_cdf, *oil_chunk, *oil_part, *oil_u;
+  size_t oil_part_n, oil_u_n;
   unsigned long long *counter;
   hipEvent_t ev0, ev1;
   int nsrc;
@@ -213,6 +218,7 @@ int odr_ctx_destroy(odr_ctx *c) {
   (void)hipEventDestroy(c->up_dep);
   (void)hipFree(c->dw);
   (void)hipFree(c->red);
+  for (double *q : {c->oil_stat, c->oil_cdf, c->oil_chunk, c->oil_part, c->oil_u}) if (q) (void)hipFree(q);
   (void)hipFree(c->counter);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
@@ -388,6 +394,19 @@ int odr_particles_device_ptr(odr_ctx *c, odr_particles *p, const char *name, voi
     return 0;
   }
   return fail(ODR_ERR_INVALID, "unknown array '%s'", name);
+}
+
+// float32 element properties of the active set (LagrangianArray variables, elements/elements.py:71-88)
+int odr_particles_download_f32(odr_ctx *c, odr_particles *p, const char *name, float *host) {
+  REQUIRE(name && host, "name/host NULL");
+  static const char *nf[4] = {"wind_drift_factor", "current_drift_factor", "terminal_velocity", "age_seconds"};
+  for (int k = 0; k < 4; ++k)
+    if (!strcmp(name, nf[k])) {
+      if (p->n) HIPCHK(hipMemcpyAsync(host, p->f32[k], sizeof(float) * (size_t)p->n, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      return 0;
+    }
+  return fail(ODR_ERR_INVALID, "unknown property '%s'", name);
 }
 
 // --------------------------------------------------------------------- sources
@@ -1381,10 +1400,10 @@ int odr_advect_wind(odr_ctx *c, odr_particles *p, double dt, double wdd, int rel
 }
 
 int odr_stokes_drift(odr_ctx *c, odr_particles *p, double dt, int profile, int hs_mode, int tp_mode, double factor) {
-  REQUIRE(profile >= 0 && profile <= 2 && hs_mode >= 0 && hs_mode <= 2 && tp_mode >= 0 && tp_mode <= 2, "bad stokes options");
+  REQUIRE(profile >= 0 && profile <= 2 && hs_mode >= 0 && hs_mode <= 2 && tp_mode >= 0 && tp_mode <= 3, "bad stokes options");
   if (!p->env[VAR_SX] || !p->env[VAR_SY]) return fail(ODR_ERR_STATE, "Stokes drift has not been sampled");
   if ((hs_mode == 0 && !p->env[VAR_HS]) || (tp_mode == 0 && !p->env[VAR_TP])) return fail(ODR_ERR_STATE, "Hs/Tp not sampled");
-  if ((hs_mode == 1 || tp_mode == 1) && (!p->env[VAR_XWIND] || !p->env[VAR_YWIND])) return fail(ODR_ERR_STATE, "wind not sampled");
+  if ((hs_mode == 1 || tp_mode == 1 || tp_mode == 3) && (!p->env[VAR_XWIND] || !p->env[VAR_YWIND])) return fail(ODR_ERR_STATE, "wind not sampled");
   if (p->n == 0) return 0;
   int rc = reduce(c, p, 0.0, 0, false);
   if (rc) return rc;
@@ -1445,7 +1464,9 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
   int ksid = -1;
   for (int k = 0; k < c->hw.nlist[VAR_KZ]; ++k)
     if (c->hw.src[c->hw.list[VAR_KZ][k]].kind == SRC_GRID) { ksid = c->hw.list[VAR_KZ][k]; break; }
-  bool fast = ksid >= 0 && nzp > 1 && !getenv("ODR_NO_FAST_PATH");
+  const bool oil = c->oil_owner == p;   // OpenOil: terminal velocities, slick and wave entrainment inside the loop
+  c->oil_owner = nullptr;
+  bool fast = ksid >= 0 && nzp > 1 && !oil && !getenv("ODR_NO_FAST_PATH");
   VMixDesc D;
   memset(&D, 0, sizeof D);
   if (fast) {
@@ -1488,6 +1509,10 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
     else if (nq <= 12) VMIX_COL(12);
     else VMIX_COL(16);
 #undef VMIX_COL
+  } else if (oil) {
+    if (nzp <= 16) hipLaunchKernelGGL((k_vmix<16, true>), g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor, c->oil);
+    else if (nzp <= 32) hipLaunchKernelGGL((k_vmix<32, true>), g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor, c->oil);
+    else hipLaunchKernelGGL((k_vmix<1, true>), g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor, c->oil);
   } else if (nzp <= 16) hipLaunchKernelGGL(k_vmix<16>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
   else if (nzp <= 32) hipLaunchKernelGGL(k_vmix<32>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
   else hipLaunchKernelGGL(k_vmix<1>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
@@ -1525,7 +1550,15 @@ int odr_vmix_wind_profile(odr_ctx *c, odr_particles *p, int model, double backgr
   c->fuse_vadv = -1;
   if (vadv >= 0 && !p->env[VAR_W]) return fail(ODR_ERR_STATE, "upward_sea_water_velocity has not been sampled");
   dim3 g(nblk(p->n)), b(BLOCK);
-  if (model == ODR_DIFFUSIVITY_LARGE1994)
+  const bool oil = c->oil_owner == p;
+  c->oil_owner = nullptr;
+  if (oil && model == ODR_DIFFUSIVITY_LARGE1994)
+    hipLaunchKernelGGL((k_vmix_wind<DIFF_LARGE1994, true>), g, b, 0, c->stream, view(p), c->red, background_diffusivity, dt, dt_mix,
+                       mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv, c->seafloor, c->oil);
+  else if (oil)
+    hipLaunchKernelGGL((k_vmix_wind<DIFF_SUNDBY1983, true>), g, b, 0, c->stream, view(p), c->red, background_diffusivity, dt, dt_mix,
+                       mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv, c->seafloor, c->oil);
+  else if (model == ODR_DIFFUSIVITY_LARGE1994)
     hipLaunchKernelGGL(k_vmix_wind<DIFF_LARGE1994>, g, b, 0, c->stream, view(p), c->red, background_diffusivity, dt, dt_mix,
                        mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv, c->seafloor);
   else
@@ -1533,6 +1566,90 @@ int odr_vmix_wind_profile(odr_ctx *c, odr_particles *p, int model, double backgr
                        mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv, c->seafloor);
   HIPCHK(hipGetLastError());
   p->epoch++;
+  return 0;
+}
+
+// OpenOil.prepare_vertical_mixing (models/openoil/openoil.py:1017-1031) on the device, and the switch that makes the
+// next odr_vmix / odr_vmix_wind_profile call on these particles run OpenOil's version of the loop: terminal velocity
+// of the droplets in every sub-step (:922-998), slick formation (:1056-1061), wave entrainment (:1033-1054).
+int odr_oil_prepare_mixing(odr_ctx *c, odr_particles *p, double dt, double dt_mix, double interfacial_tension,
+                           double sea_water_density, int droplet_distribution, int keep_droplet_diameter, int hs_mode,
+                           int tp_mode, int temperature_to_kelvin, int rng_mode, const double *host_u_diameter,
+                           const double *host_u_entrain, const double *host_u_intrusion, uint64_t step) {
+  c->oil_owner = nullptr;
+  REQUIRE(dt_mix > 0 && dt != 0, "bad time steps");
+  REQUIRE(droplet_distribution == ODR_DROPLETS_JOHANSEN2015 || droplet_distribution == ODR_DROPLETS_LI2017,
+          "no wave entrainment droplet size distribution specified");      // openoil.py:1070
+  REQUIRE(interfacial_tension > 0 && sea_water_density > 0, "bad oil / water constants");
+  REQUIRE(hs_mode >= 0 && hs_mode <= 2 && tp_mode >= 0 && tp_mode <= 3, "bad wave options");
+  for (int k : {OIL_DIAMETER, OIL_DENSITY, OIL_VISCOSITY, OIL_FILM})
+    if (!p->aux[k]) return fail(ODR_ERR_STATE, "oil property slot %d has not been set", k);
+  for (int v : {VAR_XWIND, VAR_YWIND, VAR_TEMP, VAR_SALT})
+    if (!p->env[v]) return fail(ODR_ERR_STATE, "wind, sea_water_temperature and sea_water_salinity must have been sampled");
+  if ((hs_mode == 0 && !p->env[VAR_HS]) || (tp_mode == 0 && !p->env[VAR_TP])) return fail(ODR_ERR_STATE, "Hs/Tp not sampled");
+  if (!p->aux[OIL_DIAMETER_IF_ENTRAINED]) {
+    HIPCHK(hipMalloc((void **)&p->aux[OIL_DIAMETER_IF_ENTRAINED], sizeof(float) * (size_t)p->cap));
+    HIPCHK(hipMemsetAsync(p->aux[OIL_DIAMETER_IF_ENTRAINED], 0, sizeof(float) * (size_t)p->cap, c->stream));
+  }
+  if (!c->oil_stat) {
+    HIPCHK(hipMalloc((void **)&c->oil_stat, sizeof(double) * OIL_STAT_N));
+    HIPCHK(hipMalloc((void **)&c->oil_cdf, sizeof(double) * OIL_NSPEC));
+    HIPCHK(hipMalloc((void **)&c->oil_chunk, sizeof(double) * OIL_SPEC_BLOCKS));
+  }
+  if (p->n == 0) return 0;
+  const int ntimes = abs((int)(dt / (dt_mix * (dt > 0 ? 1 : -1))));
+  const unsigned nb = nblk(p->n);
+  if (c->oil_part_n < 2 * (size_t)nb) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->oil_part) HIPCHK(hipFree(c->oil_part));
+    HIPCHK(hipMalloc((void **)&c->oil_part, sizeof(double) * 2 * (size_t)nb));
+    c->oil_part_n = 2 * (size_t)nb;
+  }
+  OilArgs &a = c->oil;
+  memset(&a, 0, sizeof a);
+  a.keep_diameter = keep_droplet_diameter ? 1 : 0;
+  a.hs_mode = hs_mode; a.tp_mode = tp_mode; a.to_kelvin = temperature_to_kelvin ? 1 : 0;
+  a.droplets = droplet_distribution; a.rng_mode = rng_mode;
+  a.sigma_ow = interfacial_tension; a.rho_w = sea_water_density; a.dt_mix_cfg = dt_mix;
+  a.stat = c->oil_stat;
+  const double *du_d = nullptr;
+  if (rng_mode == ODR_RNG_HOST) {
+    REQUIRE(host_u_diameter && host_u_entrain && host_u_intrusion, "host uniforms required in ODR_RNG_HOST mode");
+    const size_t per = (size_t)ntimes * (size_t)p->n, need = 2 * per + (size_t)p->n;
+    if (c->oil_u_n < need) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (c->oil_u) HIPCHK(hipFree(c->oil_u));
+      HIPCHK(hipMalloc((void **)&c->oil_u, sizeof(double) * need));
+      c->oil_u_n = need;
+    }
+    HIPCHK(hipMemcpyAsync(c->oil_u, host_u_entrain, sizeof(double) * per, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->oil_u + per, host_u_intrusion, sizeof(double) * per, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->oil_u + 2 * per, host_u_diameter, sizeof(double) * (size_t)p->n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // the host arrays are pageable and may change right after
+    a.u_ent = c->oil_u; a.u_int = c->oil_u + per; du_d = c->oil_u + 2 * per;
+  }
+  const PView v = view(p);
+  const dim3 g(nb), b(BLOCK);
+  hipLaunchKernelGGL(k_oil_stats, g, b, 0, c->stream, v, a, c->oil_part);
+  hipLaunchKernelGGL(k_oil_stats_final, dim3(1), b, 0, c->stream, c->oil_part, (int)nb, (long long)p->n, c->oil_stat);
+  hipLaunchKernelGGL(k_oil_spectrum_sums, dim3(OIL_SPEC_BLOCKS), b, 0, c->stream, c->oil_stat, c->oil_chunk);
+  hipLaunchKernelGGL(k_oil_spectrum_offsets, dim3(1), dim3(64), 0, c->stream, c->oil_chunk, c->oil_stat);
+  hipLaunchKernelGGL(k_oil_spectrum_scan, dim3(OIL_SPEC_BLOCKS), b, 0, c->stream, c->oil_stat, c->oil_chunk, c->oil_cdf);
+  hipLaunchKernelGGL(k_oil_choice, g, b, 0, c->stream, v, c->oil_cdf, c->oil_stat, rng_mode, du_d, c->seed,
+                     (unsigned long long)step);
+  HIPCHK(hipGetLastError());
+  c->oil_owner = p;
+  return 0;
+}
+
+// mean intrusion depth scale np.mean(1.5 Hs) and the spectrum median dV_50 of the last odr_oil_prepare_mixing
+int odr_oil_mixing_stats(odr_ctx *c, double *mean_zb, double *dv50) {
+  if (!c->oil_stat) return fail(ODR_ERR_STATE, "odr_oil_prepare_mixing has not run");
+  double h[OIL_STAT_N];
+  HIPCHK(hipMemcpyAsync(h, c->oil_stat, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (mean_zb) *mean_zb = h[OIL_STAT_MEAN_ZB];
+  if (dv50) *dv50 = h[OIL_STAT_DV50];
   return 0;
 }
 

@@ -57,6 +57,17 @@ def proj_desc(proj):
                          proj.get('lat_ts', 90.0), proj.get('k0', 1.0), proj.get('x0', 0.0), proj.get('y0', 0.0))
 
 
+def sea_water_density_default():
+    """PhysicsMethods.sea_water_density() with its default arguments T=10., S=35. (physics_methods.py:574-608): the
+    UNESCO 1983 one-atmosphere equation of state, a float64 constant of the oil formulae."""
+    T, S = 10., 35.
+    R1 = ((((6.536332E-09 * T - 1.120083E-06) * T + 1.001685E-04) * T - 9.095290E-03) * T + 6.793952E-02) * T - 28.263737
+    R2 = (((5.3875E-09 * T - 8.2467E-07) * T + 7.6438E-05) * T - 4.0899E-03) * T + 8.24493E-01
+    R3 = (-1.6546E-06 * T + 1.0227E-04) * T - 5.72466E-03
+    SIG = R1 + (4.8314E-04 * S + R3 * np.sqrt(S) + R2) * S
+    return float(SIG + 28.106331 + 1000.)
+
+
 class Context:
     def __init__(self, device=0, seed=0):
         self.lib = _abi.load()
@@ -291,6 +302,12 @@ class Particles:
             out['moving'].ctypes.data_as(_ip)))
         return out
 
+    def download_f32(self, name):
+        """wind_drift_factor / current_drift_factor / terminal_velocity / age_seconds of the active elements"""
+        out = np.empty(len(self), np.float32)
+        check(self.lib.odr_particles_download_f32(self.ctx.h, self.h, name.encode(), out.ctypes.data_as(_fp)))
+        return out
+
     def download_deactivated(self):
         n = self.count()[1]
         out = dict(lon=np.empty(n), lat=np.empty(n), z=np.empty(n), ID=np.empty(n, np.int32),
@@ -459,6 +476,44 @@ class Particles:
             mode = _abi.RNG_HOST
         check(self.lib.odr_vmix_wind_profile(self.ctx.h, self.h, _abi.DIFFUSIVITY[model], float(background_diffusivity),
                                              float(dt), float(dt_mix), int(mix_at_surface), mode, pu, step))
+
+    def oil_prepare_mixing(self, dt, dt_mix, interfacial_tension, distribution, sea_water_density, keep_droplet_diameter=False,
+                           hs_mode=1, tp_mode=3, temperature_to_kelvin=True, step=0, uniforms=None):
+        """OpenOil.prepare_vertical_mixing on the device (openoil.py:1017-1031); the next vmix / vmix_analytic call runs
+        OpenOil's version of the mixing loop.  uniforms (np.random parity): dict(diameter [n], entrain [nt, n],
+        intrusion [nt, n])."""
+        if distribution not in _abi.DROPLETS:
+            raise ValueError('no wave entrainment droplet size distribution specified')      # openoil.py:1070
+        pd = pe = pi = None
+        mode = _abi.RNG_DEVICE
+        if uniforms is not None:
+            d, pd = _d(np.ascontiguousarray(self._host_order(uniforms['diameter'])))
+            e, pe = _d(np.ascontiguousarray(self._host_order(uniforms['entrain'])))
+            i, pi = _d(np.ascontiguousarray(self._host_order(uniforms['intrusion'])))
+            mode = _abi.RNG_HOST
+        check(self.lib.odr_oil_prepare_mixing(self.ctx.h, self.h, float(dt), float(dt_mix), float(interfacial_tension),
+                                              float(sea_water_density), _abi.DROPLETS[distribution],
+                                              int(bool(keep_droplet_diameter)), int(hs_mode), int(tp_mode),
+                                              int(bool(temperature_to_kelvin)), mode, pd, pe, pi, step))
+
+    def oil_mixing_stats(self):
+        a, b = C.c_double(), C.c_double()
+        check(self.lib.odr_oil_mixing_stats(self.ctx.h, C.byref(a), C.byref(b)))
+        return dict(mean_zb=a.value, dV_50=b.value)
+
+    def vmix_oil(self, model, background_diffusivity, dt, dt_mix, interfacial_tension, distribution, sea_water_density=None,
+                 t_epoch=0.0, uniforms=None, step=0, mix_at_surface=False, **kw):
+        """prepare_vertical_mixing + vertical_mixing as OpenOil.update runs them (openoil.py:1228-1231).  model: a wind
+        parameterisation of the diffusivity or 'environment' (profiles from a reader)."""
+        if sea_water_density is None:
+            sea_water_density = sea_water_density_default()
+        self.oil_prepare_mixing(dt, dt_mix, interfacial_tension, distribution, sea_water_density, step=step,
+                                uniforms=uniforms, **kw)
+        mix = None if uniforms is None else uniforms['mix']
+        if model in ('environment', 'constant'):
+            self.vmix(t_epoch, dt, dt_mix, mix_at_surface=mix_at_surface, step=step, uniforms=mix)
+        else:
+            self.vmix_analytic(model, background_diffusivity, dt, dt_mix, mix_at_surface=mix_at_surface, step=step, uniforms=mix)
 
     def vertical_advection(self, dt, at_surface=False):
         check(self.lib.odr_vertical_advection(self.ctx.h, self.h, float(dt), int(at_surface)))

@@ -1,20 +1,64 @@
-"""OpenOil on the device path: the ADVECTION of oil elements.
+"""OpenOil on the device path (the oil physics inside the mixing loop).
 
-Mirrors the ordering and defaults of opendrift/models/openoil/openoil.py: `update()` =
-(weathering) -> vertical mixing -> vertical advection -> `advect_oil()` (:1218-1239), the reverse of
-OceanDrift.update; `advect_oil()` = advect_ocean_current(1-k_ice) + advect_wind(1-k_ice) +
-stokes_drift(factor_stokes) (:1179-1216) with no sea ice; config defaults of :493-499.  Oil
-weathering (evaporation, emulsification, dispersion, droplet spectra, the ADIOS oil database) is
-chemistry outside the hot path: `oil_weathering()` is a host hook that does nothing here, and the
-surface slick / wave-entrainment terms inside the mixing loop (`surface_wave_mixing`, :1033-1054)
-are not applied.
+Mirrors opendrift/models/openoil/openoil.py for what lies on the advection path:
+
+  required_variables (:221-296), element properties on the path (Oil: diameter, density, viscosity,
+  oil_film_thickness, :105-208), config defaults (:493-499), seed_elements' droplet sizes for elements seeded below
+  the surface and `keep_droplet_diameter` (:1629-1700);
+  update() = (weathering) -> update_terminal_velocity + vertical_mixing -> vertical advection -> advect_oil()
+  (:1218-1239), the reverse of OceanDrift.update;
+  advect_oil() = advect_ocean_current + advect_wind + stokes_drift (:1179-1216, no sea ice: k_ice = 0);
+  the mixing loop as OpenOil runs it (oceandrift.py:505-565 with the OpenOil hooks): droplet terminal velocities
+  (Tkalich et al. 2002, :922-998) in every sub-step, slick formation (:1056-1061), wave entrainment
+  (Li et al. 2017 rate, Johansen et al. 2015 / Li et al. 2017 droplet spectra, :1000-1054, :1072-1172) --
+  all of it on the device (odr_oil_prepare_mixing + the oil variants of the mixing kernels).
+
+Outside the path and not here: the ADIOS oil database and the NOAA weathering chemistry (evaporation,
+emulsification, dispersion, biodegradation).  What the database contributes to THIS path is three numbers per oil --
+density, kinematic viscosity, oil-water interfacial tension -- which `set_oiltype` / `seed_elements(oil_type=...)`
+take as a dict ({'density': kg/m3, 'viscosity': m2/s, 'oil_water_interfacial_tension': N/m}; the reference accepts
+a json dict for `oil_type` too, :1708-1710).  `oil_weathering()` keeps only what the reference's
+oil_weathering_noaa does with all processes off: the sea water temperature is in Kelvin afterwards (:722-724).
+
+np.random parity (rng='numpy'): the reference draws the intrusion depths of the entrained elements compacted
+(np.random.uniform(0, mean(zb), entrained.sum()), :1048-1049); which elements are entrained is decided on the
+device, so this mirror draws one number per element and sub-step instead -- same distributions, a different
+consumption of the stream.  Exact parity with recorded draws is tested through Particles.vmix_oil
+(tests/test_gpu_oil.py, golden c9).
 """
-from .config import CONFIG_LEVEL_BASIC
-from .oceandrift import OceanDrift
+import numpy as np
+
+from . import _abi
+from .config import CONFIG_LEVEL_ADVANCED, CONFIG_LEVEL_BASIC
+from .device import sea_water_density_default
+from .oceandrift import OceanDrift, _epoch
+
+_DEFAULT_OIL = {'density': 880.0, 'viscosity': 0.005, 'oil_water_interfacial_tension': 0.03}   # Oil defaults (:117-130)
 
 
 class OpenOil(OceanDrift):
     element_properties = dict(OceanDrift.element_properties, wind_drift_factor=0.03)   # openoil.py:133-140
+    # slot order of odr_particles_set_property (include/odrift.h ODR_OIL_*)
+    aux_properties = list(_abi.OIL_PROPERTIES)
+    required_variables = {   # openoil.py:221-296 (sea ice and the second-moment wave period are not device variables)
+        'x_sea_water_velocity': {'fallback': None},
+        'y_sea_water_velocity': {'fallback': None},
+        'x_wind': {'fallback': None},
+        'y_wind': {'fallback': None},
+        'sea_surface_height': {'fallback': 0},
+        'upward_sea_water_velocity': {'fallback': 0, 'skip_if': ['drift:vertical_advection', 'is', False]},
+        'sea_surface_wave_significant_height': {'fallback': 0},
+        'sea_surface_wave_stokes_drift_x_velocity': {'fallback': 0, 'skip_if': ['drift:stokes_drift', 'is', False]},
+        'sea_surface_wave_stokes_drift_y_velocity': {'fallback': 0, 'skip_if': ['drift:stokes_drift', 'is', False]},
+        'sea_surface_wave_period_at_variance_spectral_density_maximum': {'fallback': 0},
+        'sea_water_temperature': {'fallback': 10},
+        'sea_water_salinity': {'fallback': 34},
+        'sea_floor_depth_below_sea_level': {'fallback': 10000},
+        'horizontal_diffusivity': {'fallback': 0},
+        'ocean_vertical_diffusivity': {'fallback': 0.02, 'skip_if': ['drift:vertical_mixing', 'is', False], 'profiles': True},
+        'land_binary_mask': {'fallback': None},
+        'ocean_mixed_layer_thickness': {'fallback': 50, 'skip_if': ['drift:vertical_mixing', 'is', False]},
+    }
 
     def __init__(self, *args, **kwargs):
         kwargs.pop('weathering_model', None)
@@ -23,6 +67,21 @@ class OpenOil(OceanDrift):
             'processes:evaporation': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_BASIC, 'description': ''},
             'processes:emulsification': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_BASIC, 'description': ''},
             'processes:dispersion': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_BASIC, 'description': ''},
+            'wave_entrainment:droplet_size_distribution': {
+                'type': 'enum', 'enum': ['Johansen et al. (2015)', 'Li et al. (2017)'],
+                'default': 'Johansen et al. (2015)', 'level': CONFIG_LEVEL_ADVANCED, 'description': ''},     # :457-467
+            'wave_entrainment:entrainment_rate': {'type': 'enum', 'enum': ['Li et al. (2017)'], 'default': 'Li et al. (2017)',
+                                                  'level': CONFIG_LEVEL_ADVANCED, 'description': ''},        # :468-478
+            'seed:droplet_size_distribution': {'type': 'enum', 'enum': ['uniform', 'normal', 'lognormal'],
+                                               'default': 'uniform', 'level': CONFIG_LEVEL_BASIC, 'description': ''},
+            'seed:droplet_diameter_mu': {'type': 'float', 'default': 0.001, 'min': 1e-8, 'max': 1,
+                                         'level': CONFIG_LEVEL_BASIC, 'description': ''},
+            'seed:droplet_diameter_sigma': {'type': 'float', 'default': 0.0005, 'min': 1e-8, 'max': 1,
+                                            'level': CONFIG_LEVEL_BASIC, 'description': ''},
+            'seed:droplet_diameter_min_subsea': {'type': 'float', 'default': 0.0005, 'min': 1e-8, 'max': 1,
+                                                 'level': CONFIG_LEVEL_BASIC, 'description': ''},
+            'seed:droplet_diameter_max_subsea': {'type': 'float', 'default': 0.005, 'min': 1e-8, 'max': 1,
+                                                 'level': CONFIG_LEVEL_BASIC, 'description': ''},
         })
         self._set_config_default('drift:vertical_advection', False)
         self._set_config_default('drift:vertical_advection_at_surface', False)
@@ -31,14 +90,123 @@ class OpenOil(OceanDrift):
         self._set_config_default('drift:current_uncertainty', 0.05)
         self._set_config_default('drift:wind_uncertainty', 0.5)
         self._set_config_default('drift:max_speed', 1.3)
+        self.oiltype = None
+        self.keep_droplet_diameter = False
+        self._temperature_in_kelvin = False
 
     def set_config(self, key, value):
         if key.startswith('processes:') and value is True:
-            raise NotImplementedError('oil weathering is outside the advection hot path (DESIGN.md section 8)')
+            raise NotImplementedError('oil weathering is outside the advection hot path (DESIGN.md section 9)')
         super().set_config(key, value)
 
-    def oil_weathering(self):
-        pass
+    # ---- oil properties: the three numbers the ADIOS database contributes to this path
+    def set_oiltype(self, oiltype):
+        if not isinstance(oiltype, dict):
+            raise ValueError('The ADIOS oil database is not part of the device path: pass the oil as a dict with '
+                             'density [kg/m3], viscosity [m2/s] and oil_water_interfacial_tension [N/m]')
+        unknown = set(oiltype) - set(_DEFAULT_OIL) - {'name'}
+        if unknown:
+            raise ValueError('Unknown oil properties: %s' % sorted(unknown))
+        self.oiltype = dict(_DEFAULT_OIL, **{k: v for k, v in oiltype.items() if k != 'name'})
+        self.oil_name = oiltype.get('name', 'user-defined oil')
+        self.oil_water_interfacial_tension = float(self.oiltype['oil_water_interfacial_tension'])
+
+    def seed_elements(self, lon, lat, time=None, oil_type=None, diameter=None, oil_film_thickness=0.001, **kwargs):
+        """openoil.py:1629-1759.  z < 0 without `diameter`: droplet sizes from seed:droplet_size_distribution, drawn
+        with np.random like the reference (and before the positions, as there)."""
+        if 'oiltype' in kwargs:
+            raise ValueError('Seed argument *oiltype* is deprecated, use *oil_type* instead')      # :1701-1702
+        kwargs.pop('m3_per_hour', None)     # oil mass is weathering bookkeeping, not on the path
+        if oil_type is not None:
+            self.set_oiltype(oil_type)
+        elif self.oiltype is None:
+            self.set_oiltype(dict(_DEFAULT_OIL))
+        lon_a = np.atleast_1d(lon).ravel()
+        number = kwargs.get('number')
+        if number is None:
+            number = len(lon_a) if len(lon_a) > 1 else self.get_config('seed:number')
+        self.keep_droplet_diameter = diameter is not None                       # :1638-1645
+        z = kwargs.get('z')
+        if z is None:
+            z = self.get_config('seed:z')
+        zz = np.atleast_1d(z) * np.ones(number) if np.size(z) in (1, number) else np.atleast_1d(z)
+        if np.sum(zz < 0) > 0 and diameter is None:                             # :1659-1700
+            dsd = self.get_config('seed:droplet_size_distribution')
+            if dsd == 'uniform':
+                diameter = np.random.uniform(self.get_config('seed:droplet_diameter_min_subsea'),
+                                             self.get_config('seed:droplet_diameter_max_subsea'), number)
+            elif dsd == 'normal':
+                diameter = np.random.normal(self.get_config('seed:droplet_diameter_mu'),
+                                            self.get_config('seed:droplet_diameter_sigma'), number)
+            else:
+                mu, sigma2 = self.get_config('seed:droplet_diameter_mu'), self.get_config('seed:droplet_diameter_sigma')**2
+                s2 = np.log(sigma2 / mu**2 + 1)
+                diameter = np.random.lognormal(np.log(mu) - s2 / 2, s2**0.5, number)
+        n_before = 0 if self._sched is None else len(self._sched['lon'])
+        super().seed_elements(lon, lat, time, **kwargs)
+        n_new = len(self._sched['lon']) - n_before
+        if diameter is not None and np.size(diameter) not in (1, n_new):
+            raise ValueError('diameter has length %s, but %s elements were seeded' % (np.size(diameter), n_new))
+        props = dict(diameter=0.0 if diameter is None else diameter, density=self.oiltype['density'],
+                     viscosity=self.oiltype['viscosity'], oil_film_thickness=oil_film_thickness, diameter_if_entrained=0.0)
+        for k, v in props.items():
+            v = np.asarray(v, dtype=np.float32) * np.ones(n_new, np.float32)
+            self._sched[k] = v if n_before == 0 else np.concatenate([self._sched[k], v])
+
+    # ---- PhysicsMethods pieces that OpenOil evaluates differently from OceanDrift
+    def _wave_modes(self):
+        """Provenance of wave height and period (physics_methods.py:893-943): from readers when any value is > 0,
+        else from the wind; the wind-derived period has passed through the float32 environment
+        (calculate_missing_environment_variables, :876-883) because OpenOil requires the variable."""
+        r = self.P.reduce_scalars(self.get_config('drift:wind_drift_depth', 0.1))
+        return r, (0 if r['hs_max'] > 0 else 1), (0 if r['tp_max'] > 0 else 3)
+
+    def stokes_drift(self, factor=1):
+        if self.get_config('drift:stokes_drift') is False:
+            return
+        profile = {'monochromatic': 0, 'exponential': 1, 'Phillips': 2}.get(self.get_config('drift:stokes_drift_profile', 'Phillips'))
+        if profile is None:
+            raise NotImplementedError('windsea_swell Stokes profile is not on the device path')
+        r, hs_mode, tp_mode = self._wave_modes()
+        if r['stokes_sum_max'] == 0:
+            return
+        self.P.stokes_drift(self.time_step.total_seconds(), profile, hs_mode, tp_mode, factor)
+
+    def oil_weathering(self):   # :673-680, :717-724 with every process off
+        self._temperature_in_kelvin = self.time_step.days >= 0
+
+    def update_terminal_velocity(self, Tprofiles=None, Sprofiles=None, z_index=None):
+        pass    # evaluated inside the mixing kernel in every sub-step (and before the first one, like :1229)
+
+    def vertical_mixing(self):   # oceandrift.py:397-571 with OpenOil's prepare_vertical_mixing / surface hooks
+        if self.get_config('drift:vertical_mixing') is False:
+            return
+        model = self.get_config('vertical_mixing:diffusivitymodel')
+        if model == 'environment' and not any(self.readers[n].sid is not None
+                                              for n in self.priority_list.get('ocean_vertical_diffusivity', [])):
+            model = 'windspeed_Large1994'       # oceandrift.py:431-447
+        if model not in ('environment', 'constant') and model not in _abi.DIFFUSIVITY:
+            raise ValueError('Unknown diffusivity model: ' + str(model))
+        dt, dt_mix = self.time_step.total_seconds(), self.get_config('vertical_mixing:timestep')
+        _, hs_mode, tp_mode = self._wave_modes()
+        kw = dict(keep_droplet_diameter=self.keep_droplet_diameter, hs_mode=hs_mode, tp_mode=tp_mode,
+                  temperature_to_kelvin=self._temperature_in_kelvin)
+        if self.rng == 'numpy':
+            n, nt = self.num_elements_active(), abs(int(dt / dt_mix))
+            uni = dict(diameter=np.random.random(n), mix=np.empty((nt, n)), entrain=np.empty((nt, n)),
+                       intrusion=np.empty((nt, n)))
+            for it in range(nt):
+                uni['mix'][it] = np.random.random(n)
+                uni['entrain'][it] = np.random.uniform(0, 1, n)
+                uni['intrusion'][it] = np.random.uniform(0, 1, n)
+            kw['uniforms'] = uni
+        else:
+            kw['step'] = self.steps_calculation
+        self._with_seafloor_action(lambda: self.P.vmix_oil(
+            model, self.get_config('vertical_mixing:background_diffusivity'), dt, dt_mix,
+            self.oil_water_interfacial_tension, self.get_config('wave_entrainment:droplet_size_distribution'),
+            sea_water_density=sea_water_density_default(), t_epoch=_epoch(self.time),
+            mix_at_surface=self.get_config('drift:vertical_mixing_at_surface'), **kw))
 
     def advect_oil(self):   # openoil.py:1179-1216, no sea ice: k_ice = 0, factor_stokes = 1
         self.advect_ocean_current(factor=1)

@@ -260,7 +260,7 @@ class DeviceBackend:
 
     def oil_state(self):
         return dict(diameter=self.P.get_property(0), diameter_if_entrained=self.P.get_property(4),
-                    terminal_velocity=self.P.download()['terminal_velocity'])
+                    terminal_velocity=self.P.download_f32('terminal_velocity'))
 
     def state(self, n_total):
         a, d = self.P.download(), self.P.download_deactivated()
