@@ -22,7 +22,8 @@ namespace odr {
 
 enum { OIL_DIAMETER = 0, OIL_DENSITY = 1, OIL_VISCOSITY = 2, OIL_FILM = 3, OIL_DIAMETER_IF_ENTRAINED = 4 };  // property slots
 enum { OIL_STAT_MEAN_ZB = 0, OIL_STAT_DV50 = 1, OIL_STAT_CDF_TOTAL = 2, OIL_STAT_N = 4 };
-constexpr unsigned long long RNG_OFF_OIL_ENTRAIN = 5120, RNG_OFF_OIL_DIAMETER = 8000;   // Philox offsets within a step
+constexpr unsigned long long RNG_OFF_OIL_ENTRAIN = 5120, RNG_OFF_OIL_DIAMETER = 8000;   // Philox offsets within a step (32-bit units)
+constexpr int OIL_MAX_SUBSTEPS_DEVICE_RNG = (8000 - 5120) / 4;
 constexpr int OIL_NSPEC = 1000000;              // np.linspace(1e-6, 3e-3, 1000000) (openoil.py:1081,1131)
 constexpr int OIL_SPEC_PER_THREAD = 16;
 constexpr int OIL_SPEC_CHUNK = BLOCK * OIL_SPEC_PER_THREAD;
@@ -149,7 +150,7 @@ struct OilLane {
       ui = a.u_int[(size_t)it * p.n + i];
     } else {
       rocrand_state_philox4x32_10 st;
-      rng_init(st, seed, p.id[i], step, RNG_OFF_OIL_ENTRAIN + (unsigned long long)it);
+      rng_init(st, seed, p.id[i], step, RNG_OFF_OIL_ENTRAIN + 4ull * (unsigned long long)it);   // one Philox block (4 x 32 bit) per sub-step
       const double2 u = rocrand_uniform_double2(&st);
       ue = u.x; ui = u.y;
     }
@@ -161,7 +162,43 @@ struct OilLane {
   }
 };
 
+// median droplet diameter (volume distribution) of one element for the two spectra
+__device__ __forceinline__ double oil_dv50_element(const PView &p, long long i, const OilArgs &a, float H) {
+  const double g = 9.81;
+  const double rho = (double)p.aux[OIL_DENSITY][i], visc = (double)p.aux[OIL_VISCOSITY][i];
+  if (a.droplets == 1) {   // Johansen et al. (2015), eqs. 7a, 7b (:1136-1154)
+    const float film = p.aux[OIL_FILM][i];
+    const double rf = __dmul_rn(rho, (double)film);
+    const double re = __ddiv_rn(__dmul_rn(rf, (double)sqrtf(__fmul_rn(OF(g), H))), __dmul_rn(visc, rho));
+    const double we = __ddiv_rn(__dmul_rn(__dmul_rn(rf, g), (double)H), a.sigma_ow);
+    const double A = 2.251, B = 2.251 * 0.027;
+    const double dN = __dadd_rn(__dmul_rn((double)__fmul_rn(OF(A), film), pow(we, -0.6)),
+                                __dmul_rn((double)__fmul_rn(OF(B), film), pow(re, -0.6)));
+    const double Sd = 2.302585092994046 * 0.4;   // np.log(10) * 0.4
+    return exp(__dadd_rn(log(dN), __dmul_rn(3.0, __dmul_rn(Sd, Sd))));
+  }
+  // Li et al. (2017) (:1083-1097)
+  const double delta_rho = __dsub_rn(a.rho_w, rho);
+  const double d_o = __dmul_rn(4.0, sqrt(__ddiv_rn(a.sigma_ow, __dmul_rn(delta_rho, g))));
+  const double we = __ddiv_rn(__dmul_rn(__dmul_rn(__dmul_rn(a.rho_w, g), (double)H), d_o), a.sigma_ow);
+  const double oh = __dmul_rn(__dmul_rn(visc, rho), pow(__dmul_rn(__dmul_rn(rho, a.sigma_ow), d_o), -0.5));
+  return __dmul_rn(__dmul_rn(__dmul_rn(d_o, 1.791), pow(__dadd_rn(1.0, __dmul_rn(10.0, oh)), 0.460)), pow(we, -0.518));
+}
+
+__device__ __forceinline__ double oil_diameter_of(int k) {   // np.linspace: start + k*step, last point = stop
+  const double step = (3e-3 - 1e-6) / (double)(OIL_NSPEC - 1);
+  return k == OIL_NSPEC - 1 ? 3e-3 : __dadd_rn(__dmul_rn((double)k, step), 1e-6);
+}
+__device__ __forceinline__ double oil_spectrum_at(int k, double log_dv50) {
+  const double Sd = 2.302585092994046 * 0.4;
+  const double d = oil_diameter_of(k);
+  const double q = __dsub_rn(log(d), log_dv50);
+  return __ddiv_rn(exp(__ddiv_rn(-__dmul_rn(q, q), __dmul_rn(2.0, __dmul_rn(Sd, Sd)))),
+                   __dmul_rn(__dmul_rn(d, Sd), sqrt(2 * kPi)));
+}
+
 // ---------------------------------------------------------------- prepare_vertical_mixing
+#ifndef ODR_OIL_HOST   // tests/oil_host.cpp compiles the per-element arithmetic above for the CPU
 // Per-element median droplet diameter dV_50 of the spectrum (its MEAN over the elements parameterises the one
 // spectrum all elements draw from, :1099-1101 / :1156-1158) and zb = 1.5 Hs (:1047): block sums -> part[2][nblocks],
 // summed in a fixed order by k_oil_stats_final (deterministic, unlike floating-point atomics).
@@ -170,28 +207,9 @@ __global__ __launch_bounds__(BLOCK) void k_oil_stats(PView p, OilArgs a, double 
   const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   double dv = 0, zb = 0;
   if (i < p.n) {
-    const double g = 9.81;
-    const double rho = (double)p.aux[OIL_DENSITY][i], visc = (double)p.aux[OIL_VISCOSITY][i];
-    const float ws = speed_f32(p.env[VAR_XWIND][i], p.env[VAR_YWIND][i]);
-    const float H = oil_hs(p, i, a.hs_mode, ws);
+    const float H = oil_hs(p, i, a.hs_mode, speed_f32(p.env[VAR_XWIND][i], p.env[VAR_YWIND][i]));
     zb = (double)__fmul_rn(1.5f, H);
-    if (a.droplets == 1) {   // Johansen et al. (2015), eqs. 7a, 7b (:1136-1154)
-      const float film = p.aux[OIL_FILM][i];
-      const double rf = __dmul_rn(rho, (double)film);
-      const double re = __ddiv_rn(__dmul_rn(rf, (double)sqrtf(__fmul_rn(OF(g), H))), __dmul_rn(visc, rho));
-      const double we = __ddiv_rn(__dmul_rn(__dmul_rn(rf, g), (double)H), a.sigma_ow);
-      const double A = 2.251, B = 2.251 * 0.027;
-      const double dN = __dadd_rn(__dmul_rn((double)__fmul_rn(OF(A), film), pow(we, -0.6)),
-                                  __dmul_rn((double)__fmul_rn(OF(B), film), pow(re, -0.6)));
-      const double Sd = 2.302585092994046 * 0.4;   // np.log(10) * 0.4
-      dv = exp(__dadd_rn(log(dN), __dmul_rn(3.0, __dmul_rn(Sd, Sd))));
-    } else {                 // Li et al. (2017) (:1083-1097)
-      const double delta_rho = __dsub_rn(a.rho_w, rho);
-      const double d_o = __dmul_rn(4.0, sqrt(__ddiv_rn(a.sigma_ow, __dmul_rn(delta_rho, g))));
-      const double we = __ddiv_rn(__dmul_rn(__dmul_rn(__dmul_rn(a.rho_w, g), (double)H), d_o), a.sigma_ow);
-      const double oh = __dmul_rn(__dmul_rn(visc, rho), pow(__dmul_rn(__dmul_rn(rho, a.sigma_ow), d_o), -0.5));
-      dv = __dmul_rn(__dmul_rn(__dmul_rn(d_o, 1.791), pow(__dadd_rn(1.0, __dmul_rn(10.0, oh)), 0.460)), pow(we, -0.518));
-    }
+    dv = oil_dv50_element(p, i, a, H);
   }
   for (int o = 32; o > 0; o >>= 1) { dv += __shfl_down(dv, o); zb += __shfl_down(zb, o); }
   const int w = threadIdx.x >> 6;
@@ -227,18 +245,6 @@ __global__ __launch_bounds__(BLOCK) void k_oil_stats_final(const double *__restr
 // cdf = p.cumsum(); cdf /= cdf[-1]; idx = cdf.searchsorted(uniform, side='right')).  Three deterministic passes:
 // chunk sums, scan of the 245 chunk sums, chunk-local scan + offset.  The normalisation by the total is applied
 // by the reader (k_oil_choice), so that no fourth pass is needed.
-__device__ __forceinline__ double oil_diameter_of(int k) {   // np.linspace: start + k*step, last point = stop
-  const double step = (3e-3 - 1e-6) / (double)(OIL_NSPEC - 1);
-  return k == OIL_NSPEC - 1 ? 3e-3 : __dadd_rn(__dmul_rn((double)k, step), 1e-6);
-}
-__device__ __forceinline__ double oil_spectrum_at(int k, double log_dv50) {
-  const double Sd = 2.302585092994046 * 0.4;
-  const double d = oil_diameter_of(k);
-  const double q = __dsub_rn(log(d), log_dv50);
-  return __ddiv_rn(exp(__ddiv_rn(-__dmul_rn(q, q), __dmul_rn(2.0, __dmul_rn(Sd, Sd)))),
-                   __dmul_rn(__dmul_rn(d, Sd), sqrt(2 * kPi)));
-}
-
 __global__ __launch_bounds__(BLOCK) void k_oil_spectrum_sums(const double *__restrict__ stat, double *__restrict__ chunk) {
   __shared__ double sh[BLOCK];
   const double ldv = log(stat[OIL_STAT_DV50]);
@@ -309,5 +315,6 @@ __global__ __launch_bounds__(BLOCK) void k_oil_choice(PView p, const double *__r
   p.aux[OIL_DIAMETER_IF_ENTRAINED][i] = (float)oil_diameter_of(lo);
 }
 
+#endif  // ODR_OIL_HOST
 #undef OF
 }  // namespace odr

@@ -1598,6 +1598,7 @@ int odr_oil_prepare_mixing(odr_ctx *c, odr_particles *p, double dt, double dt_mi
   }
   if (p->n == 0) return 0;
   const int ntimes = abs((int)(dt / (dt_mix * (dt > 0 ? 1 : -1))));
+  REQUIRE(rng_mode == ODR_RNG_HOST || ntimes <= OIL_MAX_SUBSTEPS_DEVICE_RNG, "more than %d mixing sub-steps per step", OIL_MAX_SUBSTEPS_DEVICE_RNG);
   const unsigned nb = nblk(p->n);
   if (c->oil_part_n < 2 * (size_t)nb) {
     HIPCHK(hipStreamSynchronize(c->stream));
