@@ -62,6 +62,7 @@ struct odr_ctx {
   const odr_particles *oil_owner;
   OilArgs oil;
   double *oil_stat, *oil_cdf, *oil_chunk, *oil_part, *oil_u;
+  int *oil_guide;
   size_t oil_part_n, oil_u_n;
   unsigned long long *counter;
   hipEvent_t ev0, ev1;
@@ -219,6 +220,7 @@ int odr_ctx_destroy(odr_ctx *c) {
   (void)hipFree(c->dw);
   (void)hipFree(c->red);
   for (double *q : {c->oil_stat, c->oil_cdf, c->oil_chunk, c->oil_part, c->oil_u}) if (q) (void)hipFree(q);
+  if (c->oil_guide) (void)hipFree(c->oil_guide);
   (void)hipFree(c->counter);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
@@ -1595,6 +1597,7 @@ int odr_oil_prepare_mixing(odr_ctx *c, odr_particles *p, double dt, double dt_mi
     HIPCHK(hipMalloc((void **)&c->oil_stat, sizeof(double) * OIL_STAT_N));
     HIPCHK(hipMalloc((void **)&c->oil_cdf, sizeof(double) * OIL_NSPEC));
     HIPCHK(hipMalloc((void **)&c->oil_chunk, sizeof(double) * OIL_SPEC_BLOCKS));
+    HIPCHK(hipMalloc((void **)&c->oil_guide, sizeof(int) * (OIL_GUIDE + 1)));
   }
   if (p->n == 0) return 0;
   const int ntimes = abs((int)(dt / (dt_mix * (dt > 0 ? 1 : -1))));
@@ -1636,7 +1639,8 @@ int odr_oil_prepare_mixing(odr_ctx *c, odr_particles *p, double dt, double dt_mi
   hipLaunchKernelGGL(k_oil_spectrum_sums, dim3(OIL_SPEC_BLOCKS), b, 0, c->stream, c->oil_stat, c->oil_chunk);
   hipLaunchKernelGGL(k_oil_spectrum_offsets, dim3(1), dim3(64), 0, c->stream, c->oil_chunk, c->oil_stat);
   hipLaunchKernelGGL(k_oil_spectrum_scan, dim3(OIL_SPEC_BLOCKS), b, 0, c->stream, c->oil_stat, c->oil_chunk, c->oil_cdf);
-  hipLaunchKernelGGL(k_oil_choice, g, b, 0, c->stream, v, c->oil_cdf, c->oil_stat, rng_mode, du_d, c->seed,
+  hipLaunchKernelGGL(k_oil_guide, dim3((OIL_GUIDE + 1 + BLOCK - 1) / BLOCK), b, 0, c->stream, c->oil_cdf, c->oil_guide);
+  hipLaunchKernelGGL(k_oil_choice, g, b, 0, c->stream, v, c->oil_cdf, c->oil_guide, rng_mode, du_d, c->seed,
                      (unsigned long long)step);
   HIPCHK(hipGetLastError());
   c->oil_owner = p;

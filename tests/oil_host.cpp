@@ -100,12 +100,18 @@ void oilh_choice(double dv50, long long n, const double *u, double *diameter, lo
     run += csum;
   }
   const double total = cdf[OIL_NSPEC - 1];
-  for (long long i = 0; i < n; ++i) {
+  static int guide[OIL_GUIDE + 1];                       // k_oil_guide
+  for (int j = 0; j <= OIL_GUIDE; ++j) guide[j] = oil_search_right(cdf, total, (double)j / (double)OIL_GUIDE, 0, OIL_NSPEC);
+  for (long long i = 0; i < n; ++i) {                    // k_oil_choice
     int lo = 0, hi = OIL_NSPEC;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (__ddiv_rn(cdf[mid], total) <= u[i]) lo = mid + 1; else hi = mid;
+    if (u[i] >= 0.0 && u[i] < 1.0) {
+      const int j = (int)(u[i] * (double)OIL_GUIDE);
+      lo = guide[j];
+      hi = guide[j + 1];
     }
+    lo = oil_search_right(cdf, total, u[i], lo, hi);
+    const int plain = oil_search_right(cdf, total, u[i], 0, OIL_NSPEC);
+    if (plain != lo) lo = -1000000;                      // the bracketed search must equal the plain one
     if (lo > OIL_NSPEC - 1) lo = OIL_NSPEC - 1;
     index[i] = lo;
     diameter[i] = (double)(float)oil_diameter_of(lo);
