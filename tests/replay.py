@@ -59,6 +59,26 @@ class OracleBackend:
         orc.coastline({'stranding': 1, 'previous': 2}[action], self.env[LAND], self.lon, self.lat, self.z,
                       self.plon, self.plat, self.status, self.moving, code, self.age, seeded_code)
 
+    def sample_landmask(self, mask):
+        """land_binary_mask from the raster landmask reader (exact at the element positions)"""
+        self.env[LAND] = mask.land_binary_mask(self.lon, self.lat)
+
+    def coast_crossing(self, action, precision, mask, code=1):
+        """interact_with_coastline with general:coastline_approximation_precision (basemodel/__init__.py:694-746)"""
+        from oracle import landmask
+        land = self.env[LAND] == 1
+        on = np.where(land)[0]
+        if len(on) == 0:
+            return
+        if action == 'stranding':
+            hit = land & (self.z <= 0)
+            self.status[hit & (self.status == 0)] = code
+            self.moving[hit] = 0
+        lc, la = landmask.coastline_crossing(mask, self.plon[on], self.plat[on], self.lon[on], self.lat[on], precision,
+                                             land_side=(action == 'stranding'))
+        self.lon[on], self.lat[on] = lc, la
+        self.env[LAND][on] = 0
+
     def increase_age(self, dt):
         self.age = (self.age + np.float32(dt)).astype(np.float32)
 
@@ -200,6 +220,12 @@ class DeviceBackend:
 
     def coast(self, action, code=1, seeded_code=0):
         self.P.coastline(action, stranded_code=code, seeded_on_land_code=seeded_code)
+
+    def sample_landmask(self, mask):
+        pass      # the raster is a source of the device context (scenario_c10): sampled with the other variables
+
+    def coast_crossing(self, action, precision, mask, code=1):
+        self.P.coastline_crossing(action, precision, self.landmask_sid, stranded_code=code)
 
     def increase_age(self, dt):
         self.P.increase_age(dt)
@@ -386,6 +412,36 @@ def scenario_c9(g):
     return Scenario([('grid', dict(x=g['g_x'], y=g['g_y'], levels=levels))],
                     fallbacks={U: 0.0, VV: 0.0, XW: 0.0, YW: 0.0, MLD: 50.0, DEPTH: 10000.0, SSH: 0.0, LAND: 0.0,
                                TEMP: 10.0, SALT: 34.0})
+
+
+def replay_c10(B, g, action, nsteps, mask):
+    """c10 golden: constant current towards a raster coast, general:coastline_approximation_precision set."""
+    dt, prec = float(g['dt']), float(g['precision'])
+    n = g[action + '_lon'].shape[1]
+    out = []
+    for k in range(nsteps):
+        t = k * dt
+        B.sample([U, VV, LAND], t)
+        B.sample_landmask(mask)
+        B.coast_crossing(action, prec, mask)
+        B.increase_age(dt)
+        B.compact()
+        B.store_previous()
+        B.advect('euler', t, dt)
+        out.append(B.state(n))
+    return out
+
+
+def scenario_c10(g, device_raster=None):
+    """constant current; the landmask raster is a device source (device_raster = RasterMask) or is sampled by the
+    oracle back end in NumPy (fallback 0 here)"""
+    from scenarios import Scenario
+    src = [('constant', {U: float(g['u']), VV: float(g['v'])})]
+    if device_raster is not None:
+        m = device_raster
+        src.append(('landmask', dict(lon0=m.lon0, lat0=m.lat0, dlon=m.dlon, dlat=m.dlat, cells=m.cells)))
+        return Scenario(src)
+    return Scenario(src, fallbacks={LAND: 0.0})
 
 
 def replay_c8(B, g, sub, action, nsteps):

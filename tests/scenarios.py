@@ -57,6 +57,10 @@ class Scenario:
             elif kind == 'double_gyre':
                 sid = ctx.add_double_gyre(**a)
                 names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'land_binary_mask']
+            elif kind == 'landmask':
+                sid = ctx.add_landmask(a['lon0'], a['lat0'], a['dlon'], a['dlat'], a['cells'])
+                names = ['land_binary_mask']
+                ctx.landmask_sid = sid
             elif kind == 'oscillating':
                 sid = ctx.add_oscillating(a['variable'], a['amplitude'], a['period_s'], a['t0'])
                 names = [a['variable']]
