@@ -118,6 +118,12 @@ int odr_source_constant(odr_ctx *ctx, int nvars, const int32_t *var_ids, const d
  * reader_oscillating.py:49-59 params {var_id, amplitude, period_seconds, t0_epoch} */
 int odr_source_analytic(odr_ctx *ctx, int kind, const double *params, int nparams,
                         int32_t *source_id);
+/* reader_global_landmask.Reader (readers/reader_global_landmask.py:201-255) as a device source: a lon/lat raster,
+ * cells[iy * nx + ix] != 0 is land, cell (ix, iy) covers lon0 + [ix, ix+1) dlon x lat0 + [iy, iy+1) dlat; ocean outside.
+ * Exact at the element position (ContinuousReader), longitudes modulated to [-180, 180).  The GSHHG data the
+ * reference ships through roaring_landmask is not part of this repository: any raster can be handed over. */
+int odr_source_landmask(odr_ctx *ctx, int32_t nx, int32_t ny, double lon0, double lat0, double dlon, double dlat,
+                        const uint8_t *cells, int32_t *source_id);
 /* StructuredReader on a regular grid in its own projection (basereader/structured.py).
  * domain = {xmin,xmax,ymin,ymax,zmin,zmax}; lon_mode 1: [-180,180), 2: [0,360) (variables.py:259-280);
  * z = block z levels (NULL / nz<=1 for surface fields). */
@@ -285,6 +291,12 @@ int odr_store_previous(odr_ctx *ctx, odr_particles *p);
 int odr_coastline(odr_ctx *ctx, odr_particles *p, int action, int stranded_code,
                   int seeded_on_land_code /* 'previous': deactivate age==0 elements on land, 0 = off */,
                   int64_t *n_on_land);
+/* interact_with_coastline with general:coastline_approximation_precision (basemodel/__init__.py:694-746): elements on
+ * land are moved to the coastline found by coastline_crossing (:81-134) between their previous (odr_store_previous)
+ * and current position -- first sample on land ('stranding') or last sample in water ('previous') of the reference's
+ * sampling pattern with step `precision_deg`, evaluated on the landmask raster `landmask_source`. */
+int odr_coastline_crossing(odr_ctx *ctx, odr_particles *p, int action, int stranded_code, int seeded_on_land_code,
+                           double precision_deg, int32_t landmask_source, int64_t *n_on_land);
 /* report_missing_variables (basemodel/__init__.py:2501-2515) on the result of the last odr_env_sample: elements for
  * which any of var_ids is NaN in the environment (Environment.get_environment's `missing`, environment.py:903-908)
  * are deactivated with status_code ('missing_data') */

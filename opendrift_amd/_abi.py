@@ -70,6 +70,7 @@ _SIGNATURES = {
     'odr_source_analytic': [_vp, C.c_int, _dp, C.c_int, _ip],
     'odr_source_grid': [_vp, _P(ProjDesc), _dp, C.c_int, C.c_int, C.c_int, _dp, _ip],
     'odr_source_grid_curvilinear': [_vp, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp, _ip],
+    'odr_source_landmask': [_vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, _P(C.c_uint8), _ip],
     'odr_source_lonlat2xy': [_vp, C.c_int32, C.c_int64, _dp, _dp, _dp, _dp],
     'odr_block_upload': [_vp, C.c_int32, C.c_int32, C.c_double, C.c_int, _ip, _P(_fp), _ip, C.c_int,
                          C.c_int, _dp],
@@ -106,6 +107,7 @@ _SIGNATURES = {
     'odr_vertical_buoyancy': [_vp, _vp, C.c_double],
     'odr_store_previous': [_vp, _vp],
     'odr_coastline': [_vp, _vp, C.c_int, C.c_int, C.c_int, _i64p],
+    'odr_coastline_crossing': [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int32, _i64p],
     'odr_increase_age': [_vp, _vp, C.c_double, C.c_double, C.c_int],
     'odr_source_time_coverage': [_vp, C.c_int32, C.c_double, C.c_double, C.c_int],
     'odr_seafloor': [_vp, _vp, _i64p],

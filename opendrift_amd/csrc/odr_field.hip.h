@@ -17,7 +17,7 @@ constexpr int MAXLIST = 4;
 enum { VAR_U = 0, VAR_V = 1, VAR_XWIND = 2, VAR_YWIND = 3, VAR_W = 4, VAR_KZ = 5, VAR_SX = 6,
        VAR_SY = 7, VAR_LAND = 8, VAR_DEPTH = 9, VAR_SSH = 10, VAR_HDIFF = 11, VAR_HS = 12,
        VAR_TP = 13, VAR_MLD = 14, VAR_TEMP = 15, VAR_SALT = 16 };
-enum { SRC_CONSTANT = 0, SRC_DOUBLE_GYRE = 1, SRC_OSCILLATING = 2, SRC_GRID = 3 };
+enum { SRC_CONSTANT = 0, SRC_DOUBLE_GYRE = 1, SRC_OSCILLATING = 2, SRC_GRID = 3, SRC_LANDMASK = 4 };
 enum { PROJ_LATLONG = 0, PROJ_STERE_EQUIT_SPHERE = 1, PROJ_STERE_POLAR = 2, PROJ_CURVILINEAR = 3 };
 // x/y vector pairs are rotated from the reader's CRS to lon/lat (variables.py:799-837); for a reader without a
 // projection (fakeproj) the rotation the reference computes is by the azimuth of due north, i.e. exactly zero
@@ -438,6 +438,20 @@ __device__ __forceinline__ void bracket(const DevSource &s, double t, int &ib, i
   ia = (b + 1 < s.nlevels && s.slot[ib].t != t) ? s.level_slot[b + 1] : -1;
 }
 
+// Landmask raster (the device image of reader_global_landmask.Reader, readers/reader_global_landmask.py:201-255: a
+// ContinuousReader, exact at the element position): bit (iy * nx + ix) of the packed raster, cell
+// ix = floor((lon - lon0) / dlon), iy = floor((lat - lat0) / dlat); ocean outside the raster.
+// params = {lon0, lat0, dlon, dlat}; slot[0].data[VAR_LAND] = the packed words; slot[0].nx / ny = raster size.
+__device__ __forceinline__ bool landmask_contains(const DevSource &s, double lon, double lat) {
+  const double fx = floor(__ddiv_rn(__dsub_rn(lon, s.params[0]), s.params[2]));
+  const double fy = floor(__ddiv_rn(__dsub_rn(lat, s.params[1]), s.params[3]));
+  const int nx = s.slot[0].nx, ny = s.slot[0].ny;
+  if (!(fx >= 0 && fx < (double)nx && fy >= 0 && fy < (double)ny)) return false;
+  const size_t bit = (size_t)fy * (size_t)nx + (size_t)fx;
+  const unsigned *w = (const unsigned *)s.slot[0].data[VAR_LAND];
+  return (w[bit >> 5] >> (bit & 31)) & 1u;
+}
+
 // One reader.get_variables_interpolated (variables.py:860-920) for one particle and the
 // NV variables of a group.  Returns false when the reader does not cover the position.
 template <int NV>
@@ -464,6 +478,10 @@ __device__ __forceinline__ bool source_sample(const DevSource &s, const int (&va
     double value = s.params[1] * sin(phase);
 #pragma unroll
     for (int v = 0; v < NV; ++v) val[v] = value;
+  } else if (s.kind == SRC_LANDMASK) {
+    const double land = landmask_contains(s, x, y) ? 1.0 : 0.0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) val[v] = vars[v] == VAR_LAND ? land : __builtin_nan("");
   } else if (s.kind == SRC_DOUBLE_GYRE) {
     // reader_double_gyre.get_variables (reader_double_gyre.py:55-79)
     double A = s.params[0], eps = s.params[1], om = s.params[2], tt = t - s.params[3];

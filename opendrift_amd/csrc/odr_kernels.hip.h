@@ -1251,6 +1251,74 @@ __global__ __launch_bounds__(BLOCK) void k_coast(PView p, int action, int code, 
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_hit, (unsigned long long)__popcll(b));
 }
 
+// interact_with_coastline with general:coastline_approximation_precision (basemodel/__init__.py:694-746) and
+// coastline_crossing (:81-134): every element on land is moved to the first land sample ('stranding', land_side) or
+// the last water sample before it ('previous') of the reference's search pattern between its previous and its
+// current position -- np.meshgrid(np.linspace(lon1, lon2, xs), np.linspace(lat1, lat2, ys)) raveled, i.e. the
+// RECTANGLE spanned by the two positions scanned row by row (x fastest), xs = floor(|dlon| / step) samples (1 when
+// |dlon| <= step: only lon1), likewise ys; the first sample on land wins.  In the reference this is a Python loop over
+// the stranded elements with one landmask call each; here one thread per element walks its own rectangle against the
+// bit-packed raster (`mask`, the landmask source -- the reference uses its global landmask here, whatever reader
+// provided land_binary_mask).
+__global__ __launch_bounds__(BLOCK) void k_coast_crossing(const DevWorld *__restrict__ W, int mask_sid, PView p, int action,
+                                                          int code, int seeded_code, double step_deg,
+                                                          unsigned long long *n_hit) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  bool hit = false;
+  if (i < p.n && p.env[VAR_LAND][i] == 1.0f) {
+    hit = true;
+    const DevSource &mask = W->src[mask_sid];
+    if (action == 1) {
+      if (p.z[i] <= 0) {  // deactivate_elements(reason='stranded') (:1774-1795)
+        if (p.status[i] == 0) p.status[i] = code;
+        p.moving[i] = 0;
+      }
+    } else if (seeded_code > 0 && p.age[i] == 0.0f) {  // reason='seeded_on_land' (:715-719)
+      if (p.status[i] == 0) p.status[i] = seeded_code;
+      p.moving[i] = 0;
+    }
+    const bool land_side = action == 1;
+    const double lon1 = p.plon[i], lat1 = p.plat[i];
+    double lon2 = p.lon[i];
+    const double lat2 = p.lat[i];
+    double lon_c = land_side ? lon2 : lon1, lat_c = land_side ? lat2 : lat1;
+    double xd = fabs(__dsub_rn(lon2, lon1));
+    const double yd = fabs(__dsub_rn(lat2, lat1));
+    if (!(xd == 0 && yd == 0)) {
+      if (xd > 180 && lon1 < 0) {   // crossing the dateline
+        lon2 = __dsub_rn(lon2, 360.0);
+        xd = fabs(__dsub_rn(lon2, lon1));
+      }
+      const long long xs = xd > step_deg ? (long long)floor(__ddiv_rn(xd, step_deg)) : 1;
+      const long long ys = yd > step_deg ? (long long)floor(__ddiv_rn(yd, step_deg)) : 1;
+      // np.linspace(a, b, n): k * ((b - a) / (n - 1)) + a, the last sample is b itself, n == 1 gives [a]
+      const double sx = xs > 1 ? __ddiv_rn(__dsub_rn(lon2, lon1), (double)(xs - 1)) : 0.0;
+      const double sy = ys > 1 ? __ddiv_rn(__dsub_rn(lat2, lat1), (double)(ys - 1)) : 0.0;
+      double px = 0, py = 0;   // the sample before the current one in raveled order
+      bool found = false, first = true;
+      for (long long iy = 0; iy < ys && !found; ++iy) {
+        const double yy = (ys > 1 && iy == ys - 1) ? lat2 : __dadd_rn(__dmul_rn((double)iy, sy), lat1);
+        for (long long ix = 0; ix < xs; ++ix) {
+          const double xx = (xs > 1 && ix == xs - 1) ? lon2 : __dadd_rn(__dmul_rn((double)ix, sx), lon1);
+          if (landmask_contains(mask, xx, yy)) {
+            // land_side False: index = max(0, index - 1) -- the very first sample stays itself
+            if (land_side || first) { lon_c = xx; lat_c = yy; }
+            else { lon_c = px; lat_c = py; }
+            found = true;
+            break;
+          }
+          px = xx; py = yy; first = false;
+        }
+      }
+    }
+    p.lon[i] = lon_c;
+    p.lat[i] = lat_c;
+    p.env[VAR_LAND][i] = 0.0f;   // self.environment.land_binary_mask[on_land] = 0 (:729, :746)
+  }
+  unsigned long long b = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_hit, (unsigned long long)__popcll(b));
+}
+
 // increase_age_and_retire (basemodel/__init__.py:2342-2352): age_seconds += dt (float32);
 // elements older than drift:max_age_seconds are deactivated with reason 'retired'
 __global__ __launch_bounds__(BLOCK) void k_age(PView p, float dt, float max_age, int retired_code) {

@@ -494,6 +494,28 @@ int odr_source_analytic(odr_ctx *c, int kind, const double *params, int nparams,
   return 0;
 }
 
+// Landmask raster source (device image of reader_global_landmask.Reader): cells[iy * nx + ix] != 0 is land
+int odr_source_landmask(odr_ctx *c, int32_t nx, int32_t ny, double lon0, double lat0, double dlon, double dlat,
+                        const uint8_t *cells, int32_t *sid) {
+  REQUIRE(cells && sid && nx > 0 && ny > 0 && dlon > 0 && dlat > 0, "bad raster");
+  int rc = new_source(c, SRC_LANDMASK, sid);
+  if (rc) return rc;
+  DevSource &s = c->hw.src[*sid];
+  const size_t nbits = (size_t)nx * (size_t)ny, nwords = (nbits + 31) / 32;
+  std::vector<unsigned> words(nwords, 0u);
+  for (size_t k = 0; k < nbits; ++k)
+    if (cells[k]) words[k >> 5] |= 1u << (k & 31);
+  unsigned *d = nullptr;
+  HIPCHK(hipMalloc((void **)&d, sizeof(unsigned) * nwords));
+  c->source_bufs.push_back(d);
+  HIPCHK(hipMemcpy(d, words.data(), sizeof(unsigned) * nwords, hipMemcpyHostToDevice));
+  s.params[0] = lon0; s.params[1] = lat0; s.params[2] = dlon; s.params[3] = dlat;
+  s.slot[0].nx = nx; s.slot[0].ny = ny;
+  s.slot[0].data[VAR_LAND] = (const float *)d;
+  s.always_valid = 1;
+  return 0;
+}
+
 int odr_source_grid(odr_ctx *c, const odr_proj_desc *proj, const double *dom, int lon_mode, int mod360_x,
                     int nz, const double *z, int32_t *sid) {
   REQUIRE(dom && sid, "bad arguments");
@@ -1746,6 +1768,25 @@ int odr_coastline(odr_ctx *c, odr_particles *p, int action, int code, int seeded
   if (!p->env[VAR_LAND]) return fail(ODR_ERR_STATE, "land_binary_mask has not been sampled");
   HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
   hipLaunchKernelGGL(k_coast, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), action, code, seeded_on_land_code, c->counter);
+  HIPCHK(hipGetLastError());
+  return read_counter(c, n_on_land);
+}
+
+int odr_coastline_crossing(odr_ctx *c, odr_particles *p, int action, int code, int seeded_on_land_code,
+                           double precision_deg, int32_t landmask_source, int64_t *n_on_land) {
+  p->epoch++;  // invalidates the cached reductions (reduce())
+  REQUIRE(action == ODR_COAST_STRANDING || action == ODR_COAST_PREVIOUS, "bad coastline action");
+  REQUIRE(precision_deg > 0, "coastline_approximation_precision must be positive");
+  REQUIRE(landmask_source >= 0 && landmask_source < c->nsrc && c->hw.src[landmask_source].kind == SRC_LANDMASK,
+          "source %d is not a landmask raster", landmask_source);
+  if (n_on_land) *n_on_land = 0;
+  if (p->n == 0) return 0;
+  if (!p->env[VAR_LAND]) return fail(ODR_ERR_STATE, "land_binary_mask has not been sampled");
+  int rc = flush_world(c);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_coast_crossing, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, c->dw, (int)landmask_source, view(p),
+                     action, code, seeded_on_land_code, precision_deg, c->counter);
   HIPCHK(hipGetLastError());
   return read_counter(c, n_on_land);
 }

@@ -101,6 +101,15 @@ class Context:
         check(self.lib.odr_source_constant(self.h, len(ids), pi, pv, C.byref(sid)))
         return sid.value
 
+    def add_landmask(self, lon0, lat0, dlon, dlat, cells):
+        """Landmask raster source (reader_global_landmask.Reader on the device): cells[iy, ix] != 0 is land."""
+        cells = np.ascontiguousarray(np.asarray(cells) != 0, dtype=np.uint8)
+        ny, nx = cells.shape
+        sid = C.c_int32()
+        check(self.lib.odr_source_landmask(self.h, nx, ny, float(lon0), float(lat0), float(dlon), float(dlat),
+                                           cells.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(sid)))
+        return sid.value
+
     def add_double_gyre(self, A=0.25, epsilon=0.1, omega=0.628, t0=0.0):
         prm, pp = _d([A, epsilon, omega, t0])
         sid = C.c_int32()
@@ -528,6 +537,14 @@ class Particles:
         a = action if isinstance(action, int) else _abi.COAST[action]
         n = C.c_int64()
         check(self.lib.odr_coastline(self.ctx.h, self.h, a, stranded_code, seeded_on_land_code, C.byref(n)))
+        return n.value
+
+    def coastline_crossing(self, action, precision, landmask_source, stranded_code=1, seeded_on_land_code=0):
+        """interact_with_coastline with general:coastline_approximation_precision (basemodel/__init__.py:694-746)."""
+        a = action if isinstance(action, int) else _abi.COAST[action]
+        n = C.c_int64()
+        check(self.lib.odr_coastline_crossing(self.ctx.h, self.h, a, stranded_code, seeded_on_land_code, float(precision),
+                                              int(landmask_source), C.byref(n)))
         return n.value
 
     def increase_age(self, dt, max_age_seconds=0.0, retired_code=0):

@@ -156,9 +156,18 @@ class OpenDriftSimulation(Configurable):
                 self.priority_list.setdefault(v, []).insert(0, 'constant_reader_config')
         for name, (r, vs) in self._readers_host.items():
             self.readers[name] = DeviceReaderBinding(self.ctx, r, variables=vs)
+        landmasks = [n for n, (r, _) in self._readers_host.items() if getattr(r, 'device_kind', None) == 'landmask']
+        self._landmask_sid = self.readers[landmasks[0]].sid if landmasks else None
         if self.get_config('general:use_auto_landmask'):
-            raise NotImplementedError('general:use_auto_landmask needs the GSHHG dataset; add a reader or a '
-                                      'constant/fallback for land_binary_mask (out of scope, DESIGN.md 8)')
+            # environment.py:190-211: with the auto landmask, land_binary_mask comes from the global landmask reader
+            # only.  The GSHHG dataset is not part of this repository: the raster is whatever
+            # readers.LandmaskRasterReader was added; without one there is nothing to look up.
+            if not landmasks and self.get_config('environment:constant:land_binary_mask') is None:
+                raise NotImplementedError('general:use_auto_landmask needs a landmask raster (the GSHHG dataset is not '
+                                          'shipped): add readers.LandmaskRasterReader, another reader or a constant / '
+                                          'fallback for land_binary_mask (DESIGN.md 8e)')
+            if landmasks:
+                self.priority_list['land_binary_mask'] = [landmasks[0]]
         for b in self.readers.values():
             b.ensure_levels(t0, t1)
         for v in self.required_variables:
@@ -359,10 +368,18 @@ class OpenDriftSimulation(Configurable):
         action = self.get_config('general:coastline_action')
         if action == 'none' or 'land_binary_mask' not in self._sampled or self.num_elements_active() == 0:
             return
-        if self.get_config('general:coastline_approximation_precision'):
-            raise NotImplementedError('coastline_approximation_precision needs the GSHHG landmask (out of scope)')
         if final:
             self.P.env_sample(['land_binary_mask'], _epoch(self.time))
+        precision = self.get_config('general:coastline_approximation_precision')
+        if precision:   # :726-746: coastline_crossing between the previous and the current position
+            if getattr(self, '_landmask_sid', None) is None:
+                raise NotImplementedError('coastline_approximation_precision searches the global landmask: add '
+                                          'readers.LandmaskRasterReader (the GSHHG dataset is not shipped, DESIGN.md 8e)')
+            self.P.coastline_crossing(action, precision, self._landmask_sid,
+                                      stranded_code=self._status_code('stranded') if action == 'stranding' else 1,
+                                      seeded_on_land_code=self._status_code('seeded_on_land')
+                                      if action == 'previous' and self.newly_seeded else 0)
+            return
         if action == 'stranding':
             self.P.coastline('stranding', stranded_code=self._status_code('stranded'))
         else:

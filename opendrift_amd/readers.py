@@ -35,7 +35,7 @@ class BaseReader:
     always_valid = False
     z = None
     variables = []
-    device_kind = None   # 'constant' | 'double_gyre' | 'oscillating' | None (gridded)
+    device_kind = None   # 'constant' | 'double_gyre' | 'oscillating' | 'landmask' | None (gridded)
 
     def __init__(self):
         self.proj = projection.Proj(self.proj4)
@@ -147,6 +147,39 @@ class ConstantReader(ContinuousReader):
         for v in requested_variables:
             out[v] = self._parameter_value_map[v] * np.ones(np.shape(x))
         return out
+
+
+class LandmaskRasterReader(ContinuousReader):
+    """reader_global_landmask.Reader (readers/reader_global_landmask.py:201-255) over a lon/lat raster handed in by the
+    caller: land_binary_mask exactly at the element positions.  The reference's class wraps the GSHHG dataset through
+    roaring_landmask, which is not part of this repository; its contains_many(x, y) is what `cells` replaces:
+    cells[iy, ix] != 0 is land, cell (ix, iy) covers lon0 + [ix, ix+1) dlon x lat0 + [iy, iy+1) dlat, ocean outside.
+    It is also the landmask `coastline_crossing` searches when general:coastline_approximation_precision is set."""
+    device_kind = 'landmask'
+    name = 'global_landmask'
+    variables = ['land_binary_mask']
+
+    def __init__(self, lon0, lat0, dlon, dlat, cells):
+        self.lon0, self.lat0, self.dlon, self.dlat = float(lon0), float(lat0), float(dlon), float(dlat)
+        self.cells = np.ascontiguousarray(np.asarray(cells) != 0, dtype=np.uint8)
+        self.proj4 = '+proj=latlong'
+        self.xmin, self.xmax, self.ymin, self.ymax = -180, 180, -90, 90
+        self.always_valid = True
+        super().__init__()
+
+    def contains_many(self, x, y):
+        x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        ix = np.floor((x - self.lon0) / self.dlon).astype(np.int64)
+        iy = np.floor((y - self.lat0) / self.dlat).astype(np.int64)
+        ny, nx = self.cells.shape
+        ok = (ix >= 0) & (ix < nx) & (iy >= 0) & (iy < ny)
+        out = np.zeros(x.shape, bool)
+        out[ok] = self.cells[iy[ok], ix[ok]] != 0
+        return out
+
+    def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
+        x = np.mod(np.asarray(x, dtype=np.float64) + 180, 360) - 180      # modulate_longitude
+        return {'time': time, 'x': x, 'y': y, 'z': z, 'land_binary_mask': self.contains_many(x, y)}
 
 
 class DoubleGyreReader(ContinuousReader):
@@ -304,6 +337,8 @@ class DeviceReaderBinding:
             self.sid = ctx.add_double_gyre(A=reader.A, epsilon=reader.epsilon, omega=reader.omega,
                                            t0=_epoch(reader.initial_time))
             self.variables = ['x_sea_water_velocity', 'y_sea_water_velocity', 'land_binary_mask']
+        elif kind == 'landmask':
+            self.sid = ctx.add_landmask(reader.lon0, reader.lat0, reader.dlon, reader.dlat, reader.cells)
         elif kind == 'oscillating':
             self.sid = ctx.add_oscillating(reader.variables[0], reader.amplitude, reader.period_seconds,
                                            _epoch(reader.zero_time))

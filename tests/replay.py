@@ -225,7 +225,7 @@ class DeviceBackend:
         pass      # the raster is a source of the device context (scenario_c10): sampled with the other variables
 
     def coast_crossing(self, action, precision, mask, code=1):
-        self.P.coastline_crossing(action, precision, self.landmask_sid, stranded_code=code)
+        self.P.coastline_crossing(action, precision, self.ctx.landmask_sid, stranded_code=code)
 
     def increase_age(self, dt):
         self.P.increase_age(dt)
