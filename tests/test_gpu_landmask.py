@@ -103,8 +103,23 @@ def test_c10_model_run_with_auto_landmask(action):
     lon, lat, status = np.full(n, np.nan), np.full(n, np.nan), np.full(n, -1)
     for d in (o.elements, o.elements_deactivated):
         lon[d.ID], lat[d.ID], status[d.ID] = d.lon, d.lat, d.status
-    assert (status == g[action + '_status'][14]).all()
-    assert np.abs(lon - g[action + '_lon'][14]).max() < 1e-6 and np.abs(lat - g[action + '_lat'][14]).max() < 1e-6
+    # run() ends with interact_with_coastline(final=True) (basemodel/__init__.py:2310), which the step-by-step golden
+    # does not contain: the expectation is the oracle replay of the golden (checked against it in
+    # test_c10_device_vs_oracle_and_reference) followed by that one call
+    O = replay.OracleBackend(replay.scenario_c10(g), g[action + '_lon'][0], g[action + '_lat'][0], g[action + '_z'][0], wdf=0.0)
+    replay.replay_c10(O, g, action, 14, m)
+    before = O.state(n)
+    O.sample_landmask(m)
+    moved_ids = O.ID[O.env[LAND] == 1]
+    O.coast_crossing(action, float(g['precision']), m)
+    lon_e, lat_e, _, st_e = O.state(n)
+    assert len(moved_ids) > 3 and (np.abs(before[0] - lon_e)[moved_ids] > 0).any()
+    assert (status == st_e).all()
+    # a final position that differs by 1e-9 deg can put the crossing on the neighbouring 0.001 deg sample
+    tol = np.full(n, 1e-6)
+    tol[moved_ids] = 2e-3
+    assert (np.abs(lon - lon_e) < tol).all() and (np.abs(lat - lat_e) < tol).all()
+    assert (np.abs(lon - lon_e)[moved_ids] < 1e-6).mean() > 0.5
 
 
 def test_precision_without_a_landmask_raster_raises():
