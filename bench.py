@@ -84,7 +84,7 @@ def seed_particles(workload, fields, n, rng):
 class Workload:
     """Device-side step of one workload (the product path: opendrift_amd -> libodrift_hip.so)."""
 
-    def __init__(self, name, ctx, fields, dist_info):
+    def __init__(self, name, ctx, fields, dist_info, via_torch=True):
         from opendrift_amd import distributed as D
         self.name, self.ctx, self.fields = name, ctx, fields
         self.sort_every = int(os.environ.get('ODR_SORT_EVERY', 16))
@@ -100,6 +100,10 @@ class Workload:
         sid = ctx.add_grid(g['x'], g['y'], z=fields['z'], proj=fields['proj'])
         self.sid = sid
         for slot in range(3):
+            if not via_torch:   # single process, no torch in it (tests/test_gpu_full_size.py): host arrays straight in
+                assert world == 1
+                ctx.upload_block(sid, slot, float(g['t'][slot]), {k: g[k][slot] for k in fields['names']})
+                continue
             arrays = {k: g[k][slot] for k in fields['names']} if rank == 0 else None
             shapes = {k: g[k][slot].shape for k in fields['names']}
             # rank 0 owns the host Reader; the block travels to every GPU once per time level (RCCL broadcast), and
