@@ -414,7 +414,55 @@ def c8_seafloor():
                         **{('g_' + k): v for k, v in g.items()}, **out)
 
 
-SCEN = dict(c8=c8_seafloor, c7=c7_diffusivity, c6=c6_curvilinear, c1=c1_constant, c2=c2_double_gyre, c3=c3_grid3d, c4=c4_stere, c5=c5_leeway,
+def c11_mixing_profiles():
+    """The reference's own known-answer test of an isolated mixing time step (tests/models/test_run.py:359-410,
+    test_vertical_mixing_profiles): hand-made diffusivity profiles on z = 0, -2, ..., -28, six cases (no mixing,
+    sinking, mixing, mixing + rising, mixing + sinking, mixed layer), 100 elements from z = -10, 2 h in 120
+    sub-steps, mixing at the surface allowed.  The body of the test is executed verbatim on the reference's
+    OceanDrift; stored: the np.random draws and the final depths (the test's own assertions -- min / max / mean
+    to one decimal -- are checked here too)."""
+    cases = [{'vt': 0, 'K': 0, 'K_below': .01, 'T': 60, 'zmin': -10, 'zmax': -10, 'zmean': -10},
+             {'vt': -.005, 'K': 0, 'K_below': .01, 'T': 60, 'zmin': -74.79, 'zmax': -21.6, 'zmean': -49.97},
+             {'vt': 0, 'K': .01, 'K_below': .01, 'T': 60, 'zmin': -42.76, 'zmax': -0.02, 'zmean': -14.38},
+             {'vt': .005, 'K': .01, 'K_below': .01, 'T': 60, 'zmin': -7.85, 'zmax': -0.01, 'zmean': -2.1},
+             {'vt': -0.005, 'K': .01, 'K_below': .01, 'T': 60, 'zmin': -78.76, 'zmax': -19.74, 'zmean': -48.0},
+             {'vt': 0, 'K': .02, 'K_below': .001, 'T': 60, 'zmin': -21.3, 'zmax': -0.1, 'zmean': -9.55}]
+    N = 100
+    z = np.arange(0, -30, -2)
+    time = T0
+    out = dict(z_levels=z, cases=np.array([[c['vt'], c['K'], c['K_below'], c['T'], c['zmin'], c['zmax'], c['zmean']] for c in cases]))
+    for ic, case in enumerate(cases):
+        diffusivity = np.ones(z.shape) * case['K']
+        diffusivity[z < -15] = case['K_below']
+        o = OceanDrift(loglevel=50)
+        o.set_config('drift:vertical_mixing', True)
+        o.set_config('drift:vertical_mixing_at_surface', True)
+        o.set_config('drift:vertical_advection_at_surface', True)
+        o.set_config('vertical_mixing:diffusivitymodel', 'environment')
+        o.set_config('vertical_mixing:timestep', case['T'])
+        o.set_config('environment:fallback:land_binary_mask', 0)
+        o.seed_elements(lon=4, lat=60, z=-10, time=time, number=N, terminal_velocity=case['vt'])
+        o.time = time
+        o.time_step = timedelta(hours=2)
+        o.release_elements()
+        o.environment = np.array([(100, 0) for _ in range(N)],
+                                 dtype=[('sea_floor_depth_below_sea_level', np.float32),
+                                        ('sea_surface_height', np.float32)]).view(np.recarray)
+        o.environment.ocean_mixed_layer_thickness = np.ones(N) * 50
+        o.environment_profiles = {'z': z, 'ocean_vertical_diffusivity': np.tile(diffusivity, (N, 1)).T}
+        o.env.finalize()
+        with RecordingRandom() as rr:
+            o.vertical_mixing()
+        zz = np.array(o.elements.z, dtype=np.float64)
+        assert abs(zz.min() - case['zmin']) < 0.05 and abs(zz.max() - case['zmax']) < 0.05 and abs(zz.mean() - case['zmean']) < 0.05, \
+            (ic, zz.min(), zz.max(), zz.mean())
+        out['z_final_%d' % ic] = zz
+        out['uniforms_%d' % ic] = np.stack([d[1] for d in rr.draws if d[0] == 'random'])
+        out['K_%d' % ic] = diffusivity
+    np.savez_compressed(os.path.join(GOLD, 'c11_mixing_profiles.npz'), **out)
+
+
+SCEN = dict(c11=c11_mixing_profiles, c8=c8_seafloor, c7=c7_diffusivity, c6=c6_curvilinear, c1=c1_constant, c2=c2_double_gyre, c3=c3_grid3d, c4=c4_stere, c5=c5_leeway,
             c5b=lambda: c5_leeway(capsizing=True))
 
 if __name__ == '__main__':

@@ -182,3 +182,20 @@ def test_c8_seafloor_actions_vs_oracle(action):
     if action == 'deactivate':
         assert list(g['deactivate_categories']) == ['active', 'seafloor'] and (sub['status'][8] != 0).sum() == 37
     print('c8', action, worst)
+
+
+@pytest.mark.parametrize('case', range(6))
+def test_c11_reference_known_answers_of_an_isolated_mixing_step(case):
+    """tests/models/test_run.py:359-410 (test_vertical_mixing_profiles) executed on the reference itself
+    (oracle/gen_golden.py:c11): the oracle reproduces the final depths, and with them the test's published
+    min / max / mean."""
+    g = golden('c11_mixing_profiles.npz')
+    vt, K, Kb, T, zmin, zmax, zmean = g['cases'][case]
+    n = 100
+    z = np.full(n, -10.0)
+    zl = g['z_levels'].astype(np.float64)
+    Kp = np.ascontiguousarray(np.tile(g['K_%d' % case], (n, 1)).T)
+    orc.vertical_mixing(z, np.ones(n, np.int32), np.full(n, vt, np.float32), np.full(n, 100, np.float32),
+                        np.zeros(n, np.float32), zl, Kp, 7200.0, float(T), 1, g['uniforms_%d' % case])
+    assert np.abs(z - g['z_final_%d' % case]).max() < 1e-9
+    assert abs(z.min() - zmin) < 0.05 and abs(z.max() - zmax) < 0.05 and abs(z.mean() - zmean) < 0.05
