@@ -54,6 +54,7 @@ class OpenDriftSimulation(Configurable):
         self._advected = False
         self._readers_host = {}              # name -> (reader, variables) as given to add_reader
         self.priority_list = {}              # variable -> [reader names]
+        self.discarded_readers = {}          # name -> reason (Environment.discarded_readers, environment.py:376-389)
         self.required_variables = {k: dict(v) for k, v in type(self).required_variables.items()}
         self._sched = None                   # scheduled elements (host arrays, seeding order = ID)
         self.P = None
@@ -168,11 +169,36 @@ class OpenDriftSimulation(Configurable):
                                           'fallback for land_binary_mask (DESIGN.md 8e)')
             if landmasks:
                 self.priority_list['land_binary_mask'] = [landmasks[0]]
-        for b in self.readers.values():
-            b.ensure_levels(t0, t1)
+        self._ensure_reader_levels(t0, t1)
+        self._bind_variables()
+
+    def _bind_variables(self):
         for v in self.required_variables:
-            ids = [self.readers[n].sid for n in self.priority_list.get(v, []) if self.readers[n].sid is not None]
+            ids = [self.readers[n].sid for n in self.priority_list.get(v, [])
+                   if n in self.readers and self.readers[n].sid is not None]
             self.ctx.bind(v, ids[:4], self.get_config('environment:fallback:%s' % v))
+
+    def _ensure_reader_levels(self, t0, t1):
+        """Make the time levels of every reader resident.  A reader whose get_variables raises is counted and, after
+        more than readers:max_number_of_fails failures, discarded (Environment.get_environment, environment.py:640-668,
+        discard_reader :376-389; tests/readers/test_readers.py:15-26): its variables fall to the next reader of the
+        priority list or to the fallback value."""
+        for name, b in list(self.readers.items()):
+            try:
+                b.ensure_levels(t0, t1)
+            except Exception as e:   # the reference catches every exception of a reader call
+                r = b.reader
+                r.number_of_fails = getattr(r, 'number_of_fails', 0) + 1
+                max_fails = self.get_config('readers:max_number_of_fails')
+                logger.warning('Reader %s failed (%s), number of fails: %d', name, e, r.number_of_fails)
+                if r.number_of_fails > max_fails:
+                    self.discarded_readers[name] = 'failed more than allowed number of times (%d)' % max_fails
+                    del self.readers[name]
+                    for v, lst in self.priority_list.items():
+                        if name in lst:
+                            lst.remove(name)
+                    if b.sid is not None:      # it had delivered blocks before: take it out of the device lists
+                        self._bind_variables()
 
     # ------------------------------------------------------------------ seeding (:1033-1330)
     def seed_elements(self, lon, lat, time, radius=0, number=None, number_per_point=None,
@@ -538,8 +564,7 @@ class OpenDriftSimulation(Configurable):
                     self.steps_calculation += 1
                     self.time = self.time + self.time_step
                     continue
-                for b in self.readers.values():
-                    b.ensure_levels(self.time, self.time + self.time_step)
+                self._ensure_reader_levels(self.time, self.time + self.time_step)
                 # device layout maintenance: re-sort by grid cell every sort_every steps and whenever a
                 # release added a sizeable share of new (unsorted) elements
                 n_act = self.num_elements_active()

@@ -182,6 +182,21 @@ class LandmaskRasterReader(ContinuousReader):
         return {'time': time, 'x': x, 'y': y, 'z': z, 'land_binary_mask': self.contains_many(x, y)}
 
 
+class FailingReader(ContinuousReader):
+    """reader_failing.Reader (readers/reader_failing.py:20-43): raises in every call, for testing the quarantine of
+    readers after readers:max_number_of_fails failures."""
+
+    def __init__(self):
+        self.variables = ['x_wind', 'y_wind']
+        self.proj4 = '+proj=latlong'
+        self.xmin, self.xmax, self.ymin, self.ymax = -180, 180, -90, 90
+        self.name = 'failing_reader'
+        super().__init__()
+
+    def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
+        raise ValueError('Failing reader, for testing only.')
+
+
 class DoubleGyreReader(ContinuousReader):
     """reader_double_gyre.Reader (readers/reader_double_gyre.py:24-79)."""
     device_kind = 'double_gyre'

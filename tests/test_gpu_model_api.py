@@ -441,3 +441,21 @@ def test_c4_run_until_reader_time_coverage_ends():
     st[o.elements_deactivated.ID] = o.elements_deactivated.status
     assert np.array_equal(st, g['status'][10])
     assert np.abs(lon - g['lon'][10]).max() < 1e-7 and np.abs(lat - g['lat'][10]).max() < 1e-7
+
+
+def test_failing_reader_is_discarded_after_the_allowed_number_of_fails():
+    """tests/readers/test_readers.py:15-26 (test_failing_reader): a reader that raises in every call is quarantined
+    after more than readers:max_number_of_fails failures and the run completes on the fallback values."""
+    from opendrift_amd import readers
+    o = OceanDrift(loglevel=50, seed=0)
+    r = readers.FailingReader()
+    assert len(o.discarded_readers) == 0
+    o.set_config('readers:max_number_of_fails', 1)
+    o.set_config('environment:fallback:land_binary_mask', 0)
+    o.add_reader(r)
+    o.seed_elements(lon=4, lat=60, time=T0)
+    o.run(time_step=3600, steps=5)
+    assert len(o.discarded_readers) == 1 and 'failing_reader' in o.discarded_readers
+    assert o.steps_calculation == 5
+    assert r.number_of_fails == 2
+    assert o.num_elements_active() == 1
