@@ -769,7 +769,11 @@ class OceanDrift(OpenDriftSimulation):
             kw['uniforms'] = np.stack([np.random.random(n) for _ in range(nt)])
         else:
             kw['step'] = self.steps_calculation
-        if model in ('environment', 'constant'):
+        if model == 'constant':     # oceandrift.py:448-452: the fallback value at every level, whatever the readers say
+            self.ctx.bind('ocean_vertical_diffusivity', [], self.get_config('environment:fallback:ocean_vertical_diffusivity'))
+            self._with_seafloor_action(lambda: self.P.vmix(_epoch(self.time), dt, dt_mix, **kw))
+            self._bind_variables()
+        elif model == 'environment':
             self._with_seafloor_action(lambda: self.P.vmix(_epoch(self.time), dt, dt_mix, **kw))
         else:   # get_diffusivity_profile (:385-395): raises ValueError('Unknown diffusivity model') like the reference
             bg = self.get_config('vertical_mixing:background_diffusivity')

@@ -165,11 +165,14 @@ def vertical_mixing_oil(z, moving, diameter, density, T_kelvin, S, depth, ssh, m
     gradK = -np.gradient(Kprofiles, mixing_z, axis=0)
     gradK[np.abs(gradK) < 1e-10] = 0
     nz = mixing_z.shape[0]
+    from scipy.interpolate import interp1d
+    z_index = (lambda d: np.zeros(len(d))) if nz == 1 else \
+        interp1d(-mixing_z, range(nz), bounds_error=False, fill_value=(0, nz - 1))
     w = None
     for it in range(ntimes):
         surface = z == 0
         w = terminal_velocity(diameter, density, T_kelvin, S)
-        zi = np.round(np.clip(-z, 0, nz - 1)).astype(np.uint16)     # interp1d over 1 m levels is the identity
+        zi = np.round(z_index(-z)).astype(np.uint16)                # oceandrift.py:485-488,513
         Kz = Kprofiles[zi, cols]
         dKdz = gradK[zi, cols]
         R = 2 * u_mix[it] - 1

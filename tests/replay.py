@@ -170,7 +170,7 @@ class OracleBackend:
                         viscosity=np.asarray(viscosity, np.float64) * np.ones(n),
                         film=np.asarray(film, np.float32) * np.ones(n, np.float32))
 
-    def vmix_oil(self, model, background, dt, dt_mix, interfacial_tension, distribution, uniforms):
+    def vmix_oil(self, model, background, dt, dt_mix, interfacial_tension, distribution, uniforms, t=0.0, zlevels=None):
         """OpenOil: oil_weathering_noaa's Kelvin conversion (openoil.py:722-724), prepare_vertical_mixing and the
         mixing loop with the oil physics (oracle/oil.py); no wave height / period from readers (from the wind)."""
         from oracle import diffusivity, oil
@@ -186,7 +186,10 @@ class OracleBackend:
             self.dV_50 = oil.droplet_median_li2017(o['density'], o['viscosity'], hs, interfacial_tension)
         self.diameter_if_entrained = oil.droplet_diameters(self.dV_50, uniforms['diameter'])
         self.mean_zb = np.mean(1.5 * hs)
-        zlev, Kp = diffusivity.profiles(model, e[XW], e[YW], e[MLD], background)
+        if model == 'environment':      # profiles from a reader (B.sample(..., profile=KZ, nzp=...))
+            zlev, Kp = np.asarray(zlevels, dtype=np.float64), np.ascontiguousarray(self.Kp)
+        else:
+            zlev, Kp = diffusivity.profiles(model, e[XW], e[YW], e[MLD], background)
         self.w = oil.vertical_mixing_oil(self.z, self.moving, o['diameter'], o['density'], T, e[SALT], e[DEPTH], e[SSH],
                                          zlev, Kp, dt, dt_mix, self.probability, self.diameter_if_entrained,
                                          self.mean_zb, uniforms['mix'], uniforms['entrain'], uniforms['intrusion'])
@@ -281,8 +284,8 @@ class DeviceBackend:
         for slot, v in enumerate((diameter, density, viscosity, film)):
             self.P.set_property(slot, np.asarray(v, np.float32) * np.ones(n, np.float32))
 
-    def vmix_oil(self, model, background, dt, dt_mix, interfacial_tension, distribution, uniforms):
-        self.P.vmix_oil(model, background, dt, dt_mix, interfacial_tension, distribution, uniforms=uniforms)
+    def vmix_oil(self, model, background, dt, dt_mix, interfacial_tension, distribution, uniforms, t=0.0, zlevels=None):
+        self.P.vmix_oil(model, background, dt, dt_mix, interfacial_tension, distribution, uniforms=uniforms, t_epoch=t)
 
     def oil_state(self):
         return dict(diameter=self.P.get_property(0), diameter_if_entrained=self.P.get_property(4),

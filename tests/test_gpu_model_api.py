@@ -459,3 +459,33 @@ def test_failing_reader_is_discarded_after_the_allowed_number_of_fails():
     assert o.steps_calculation == 5
     assert r.number_of_fails == 2
     assert o.num_elements_active() == 1
+
+
+def test_constant_diffusivity_model_ignores_the_readers():
+    """vertical_mixing:diffusivitymodel 'constant' (oceandrift.py:448-452): the fallback diffusivity at every level,
+    whether or not a reader provides ocean_vertical_diffusivity -- the run with a diffusivity reader equals the run
+    without one, and differs from the 'environment' run that uses the reader."""
+    KZ = 'ocean_vertical_diffusivity'
+    zl = np.arange(0, -30, -2).astype(np.float64)
+    arr = np.ascontiguousarray(np.broadcast_to((0.03 * np.exp(zl / 10))[None, :, None, None], (2, len(zl), 2, 2))).astype(np.float32)
+
+    def run(model, with_reader):
+        o = OceanDrift(loglevel=50, seed=0, rng='numpy')
+        if with_reader:
+            o.add_reader(readers.GridReader(np.array([3.0, 5.0]), np.array([59.0, 61.0]), [T0, T0 + timedelta(days=1)],
+                                            {KZ: arr}, z=zl))
+        o.set_config('drift:vertical_mixing', True)
+        o.set_config('vertical_mixing:diffusivitymodel', model)
+        o.set_config('environment:fallback:ocean_vertical_diffusivity', 0.005)
+        o.set_config('environment:fallback:land_binary_mask', 0)
+        o.set_config('environment:fallback:sea_floor_depth_below_sea_level', 100)
+        o.seed_elements(lon=4, lat=60, z=-10, time=T0, number=200)
+        np.random.seed(1)
+        o.run(time_step=3600, steps=2)
+        z = np.empty(200)
+        z[o.elements.ID] = o.elements.z
+        return z
+
+    a, b, c = run('constant', True), run('constant', False), run('environment', True)
+    assert np.array_equal(a, b)
+    assert np.abs(a - c).max() > 0.5 and a.std() > 1.0

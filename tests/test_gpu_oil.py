@@ -67,6 +67,51 @@ def test_c9_spectrum_median_and_intrusion_scale(tag, dist):
     assert abs(st['mean_zb'] / float(O.mean_zb) - 1) < 1.3e-7          # one float32 ulp
 
 
+def test_oil_mixing_with_diffusivity_profiles_from_a_reader():
+    """The oil variant of the profile kernel (k_vmix<NZ, OIL>): diffusivity from a gridded reader with uneven z levels
+    (vertical_mixing:diffusivitymodel 'environment', oceandrift.py:433-438) instead of the wind parameterisation;
+    device against the oracle over four steps with handed-over uniforms."""
+    from scenarios import Scenario
+    g = golden('c9_openoil_mixing.npz')
+    names = [replay.U, replay.VV, replay.XW, replay.YW, replay.MLD, replay.DEPTH, replay.TEMP, replay.SALT]
+    levels = [(float(g['g_t'][k]), {nm: g['g_' + nm][k] for nm in names}) for k in range(len(g['g_t']))]
+    zl = np.array([0.0, -2.0, -5.0, -10.0, -20.0, -35.0, -60.0, -100.0])
+    ny, nx = g['g_x_wind'].shape[1:]
+    X, Y = np.meshgrid(np.linspace(0, 1, nx), np.linspace(0, 1, ny))
+    K = np.stack([(0.002 + 0.02 * np.exp(zl[:, None, None] / 25.0) * (1 + 0.5 * np.sin(3 * X + k) * np.cos(2 * Y))) for k in range(3)])
+    klev = [(float(g['g_t'][k]), {replay.KZ: K[k].astype(np.float32)}) for k in range(3)]
+    sc = Scenario([('grid', dict(x=g['g_x'], y=g['g_y'], levels=levels)),
+                   ('grid', dict(x=g['g_x'], y=g['g_y'], z=zl, levels=klev))],
+                  fallbacks={replay.U: 0.0, replay.VV: 0.0, replay.XW: 0.0, replay.YW: 0.0, replay.MLD: 50.0, replay.DEPTH: 10000.0,
+                             replay.SSH: 0.0, replay.LAND: 0.0, replay.TEMP: 10.0, replay.SALT: 34.0, replay.KZ: 0.02})
+    rng = np.random.default_rng(5)
+    n, nt = 2000, 10
+    lon = rng.uniform(g['g_x'][3], g['g_x'][-4], n)
+    lat = rng.uniform(g['g_y'][3], g['g_y'][-4], n)
+    z0 = np.where(np.arange(n) % 2 == 0, 0.0, -rng.uniform(0.5, 60, n))
+    d0 = np.where(z0 < 0, rng.uniform(2e-5, 2e-3, n), 0.0).astype(np.float32)
+    film = rng.uniform(5e-4, 1.5e-3, n).astype(np.float32)
+    D = replay.DeviceBackend(sc, Context(seed=0), lon, lat, z0, wdf=0.0)
+    O = replay.OracleBackend(sc, lon, lat, z0, wdf=0.0)
+    for B in (D, O):
+        B.set_oil(d0, 900.0, float(np.float32(0.005)), film)
+    samp = [replay.U, replay.VV, replay.XW, replay.YW, replay.MLD, replay.DEPTH, replay.SSH, replay.LAND, replay.TEMP, replay.SALT]
+    for k in range(4):
+        t = k * 600.0
+        uni = dict(mix=rng.uniform(size=(nt, n)), entrain=rng.uniform(size=(nt, n)), intrusion=rng.uniform(size=(nt, n)),
+                   diameter=rng.uniform(size=n))
+        for B in (D, O):
+            B.sample(samp, t, profile=replay.KZ, nzp=len(zl))
+            B.vmix_oil('environment', 0.0, 600.0, 60.0, 0.03, 'Li et al. (2017)', uni, t=t, zlevels=zl)
+            B.advect('euler', t, 600.0)
+        (lo1, la1, z1, s1), (lo2, la2, z2, s2) = D.state(n), O.state(n)
+        o1, o2 = D.oil_state(), O.oil_state()
+        assert np.abs(lo1 - lo2).max() < 1e-10 and np.abs(z1 - z2).max() < 1e-6, (k, np.abs(z1 - z2).max())
+        assert ((z1 == 0) == (z2 == 0)).all()
+        assert np.abs(o1['diameter'].astype(np.float64) - o2['diameter']).max() <= CELL
+    assert (z1 < -30).sum() > 20 and ((d0 == 0) & (o1['diameter'] > 0)).sum() > 50
+
+
 def test_device_rng_entrainment_statistics():
     """Device Philox mode: the entrained share of a slick after one sub-step equals the Li et al. (2017) probability,
     the intrusion depths are uniform on [0, mean(1.5 Hs)], the droplets follow the log-normal spectrum."""
