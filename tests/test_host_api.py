@@ -114,7 +114,7 @@ def test_openoil_host_interface():
 def test_landmask_raster_reader_surface():
     r = readers.LandmaskRasterReader(3.0, 59.0, 0.5, 0.25, np.array([[0, 1, 0], [1, 1, 0]]))
     assert r.variables == ['land_binary_mask'] and r.name == 'global_landmask' and r.device_kind == 'landmask'
-    out = r.get_variables(['land_binary_mask'], None, np.array([3.6, 3.6 + 360, 2.9, 4.49, 4.51]), np.array([59.1, 59.3, 59.1, 59.3, 59.3]))
+    out = r.get_variables(['land_binary_mask'], None, np.array([3.6, 3.6 + 360, 2.9, 3.2, 4.51]), np.array([59.1, 59.3, 59.1, 59.3, 59.3]))
     assert out['land_binary_mask'].tolist() == [True, True, False, True, False]
     f = readers.FailingReader()
     with pytest.raises(ValueError):
