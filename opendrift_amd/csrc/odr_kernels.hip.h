@@ -1738,7 +1738,7 @@ __global__ __launch_bounds__(BLOCK) void k_blk_dilate(const float *__restrict__ 
 // step, which the reference removes only afterwards); between output steps only deactivated
 // elements are written, into the slot of the next output time (:2390-2397, method='backfill').
 enum { HK_F64 = 0, HK_I32 = 1, HK_F32 = 2 };
-constexpr int HIST_MAXV = 28;
+constexpr int HIST_MAXV = 40;   // OpenOil with every default variable exports 30 (9 element properties + 4 oil properties + 17 environment variables)
 struct HistVars {
   int nvars, stride;
   const void *src[HIST_MAXV];

@@ -2079,7 +2079,10 @@ int odr_history_record(odr_ctx *c, odr_particles *p, odr_history *h, int32_t tim
     case 4: HIST_REC(4); break;
     case 5: HIST_REC(5); break;
     case 6: HIST_REC(6); break;
-    default: HIST_REC(7); break;
+    case 7: HIST_REC(7); break;
+    case 8: HIST_REC(8); break;
+    case 9: HIST_REC(9); break;
+    default: HIST_REC(10); break;
   }
 #undef HIST_REC
   HIPCHK(hipGetLastError());

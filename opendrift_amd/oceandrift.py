@@ -634,7 +634,7 @@ class OpenDriftSimulation(Configurable):
         variable, or `export_variables` + ['lon', 'lat', 'status']."""
         elem = ['lon', 'lat', 'z', 'status', 'moving', 'age_seconds', 'wind_drift_factor', 'current_drift_factor',
                 'terminal_velocity']
-        aux = list(getattr(self, 'aux_properties', []))
+        aux = [a for a in getattr(self, 'aux_properties', []) if a not in getattr(self, 'internal_properties', ())]
         env = list(self.required_variables)
         if export_variables is not None:
             keep = set(export_variables) | {'lon', 'lat', 'status'}

@@ -40,6 +40,7 @@ class OpenOil(OceanDrift):
     element_properties = dict(OceanDrift.element_properties, wind_drift_factor=0.03)   # openoil.py:133-140
     # slot order of odr_particles_set_property (include/odrift.h ODR_OIL_*)
     aux_properties = list(_abi.OIL_PROPERTIES)
+    internal_properties = ('diameter_if_entrained',)   # device scratch of prepare_vertical_mixing, not an Oil element variable
     required_variables = {   # openoil.py:221-296 (sea ice and the second-moment wave period are not device variables)
         'x_sea_water_velocity': {'fallback': None},
         'y_sea_water_velocity': {'fallback': None},
