@@ -5,7 +5,7 @@
 //   seawater_dynamic_viscosity_sharqawy         models/physics_methods.py:159-178      oil_water_viscosity_f32
 //   OpenOil.prepare_vertical_mixing             models/openoil/openoil.py:1017-1031    OilLane::init (probability), k_oil_*
 //   oil_wave_entrainment_rate_li2017            models/physics_methods.py:115-137      oil_entrainment_probability
-//   get_wave_breaking_droplet_diameter_*        models/openoil/openoil.py:1072-1172    k_oil_median_*, k_oil_spectrum_*, k_oil_choice
+//   get_wave_breaking_droplet_diameter_*        models/openoil/openoil.py:1072-1172    oil_dv50_element, k_oil_stats*, k_oil_spectrum_*, k_oil_guide, k_oil_choice
 //   surface_stick / surface_wave_mixing         models/openoil/openoil.py:1033-1061    OilLane::surface_wave_mixing
 //
 // Everything is evaluated with the operand dtypes NumPy 2 gives the reference: the environment (wind, wave height,
