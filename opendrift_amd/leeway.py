@@ -20,13 +20,15 @@ RIGHT, LEFT = 0, 1
 
 
 def read_objectprop(path):
-    """Parse an OBJECTPROP.DAT (layout of leeway.py:190-222): {object_type (1-based): coefficients}."""
+    """Parse an OBJECTPROP.DAT (leeway.py:186-219): three lines per object class -- key (and number), description,
+    the nine coefficients -- up to the first blank line.  Returns {object_type (1-based): coefficients}."""
     lines = open(path).readlines()
-    n = int(lines[0])
     out = {}
-    for i in range(n):
-        arr = [float(x) for x in lines[i * 3 + 3].split()]
-        out[i + 1] = dict(OBJKEY=lines[i * 3 + 1].strip(), Description=lines[i * 3 + 2].strip(),
+    for i in range(len(lines) // 3 + 1):
+        if 3 * i >= len(lines) or not lines[i * 3].strip():
+            break
+        arr = [float(x) for x in lines[i * 3 + 2].split()]
+        out[i + 1] = dict(OBJKEY=lines[i * 3].split()[0].strip(), Description=lines[i * 3 + 1].strip(),
                           DWSLOPE=arr[0], DWOFFSET=arr[1], DWSTD=arr[2], CWRSLOPE=arr[3], CWROFFSET=arr[4],
                           CWRSTD=arr[5], CWLSLOPE=arr[6], CWLOFFSET=arr[7], CWLSTD=arr[8])
     return out
@@ -85,7 +87,8 @@ class Leeway(OpenDriftSimulation):
             crosswind_eps = np.where(orientation == RIGHT, rcw * c['CWRSTD'], rcw * c['CWLSTD'])
             props = dict(downwind_slope=downwind_slope, crosswind_slope=crosswind_slope,
                          downwind_offset=downwind_offset, crosswind_offset=crosswind_offset, downwind_eps=epsdw,
-                         crosswind_eps=crosswind_eps, orientation=orientation, capsized=np.zeros(number))
+                         crosswind_eps=crosswind_eps, orientation=orientation,
+                         capsized=np.asarray(explicit.get('capsized', 0), dtype=np.float64) * np.ones(number))   # :373-374
         else:
             defaults = dict(downwind_slope=1, crosswind_slope=1, downwind_offset=0, crosswind_offset=0, downwind_eps=0,
                             crosswind_eps=0, orientation=1, capsized=0)     # LeewayObj defaults (:50-131)

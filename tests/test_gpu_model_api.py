@@ -489,3 +489,29 @@ def test_constant_diffusivity_model_ignores_the_readers():
     a, b, c = run('constant', True), run('constant', False), run('environment', True)
     assert np.array_equal(a, b)
     assert np.abs(a - c).max() > 0.5 and a.std() > 1.0
+
+
+# OBJECTPROP.DAT, object class 1 (PIW-1, "Person-in-water (PIW), unknown state (mean values)": the default
+# seed:object_type of the reference's Leeway, leeway.py:228-232)
+PIW1 = dict(DWSLOPE=0.96, DWOFFSET=0.0, DWSTD=12.0, CWRSLOPE=0.54, CWROFFSET=0.0, CWRSTD=9.4, CWLSLOPE=-0.54, CWLOFFSET=0.0,
+            CWLSTD=9.4)
+
+
+@pytest.mark.parametrize('dt,capsized0,expected', [(900, 0, 18), (-900, 0, 0), (-900, 1, 82)])
+def test_reference_capsize_counts(dt, capsized0, expected):
+    """tests/models/test_leeway.py:92-130 (test_capsize): 25 m/s wind, threshold 30 m/s, sigma 3, six hours in 15-minute
+    steps with the reference's np.random stream (seed 0): 18 of 100 elements capsize in the forward run, none in a
+    backward run of upright elements, and 82 of 100 capsized elements remain capsized in a backward run."""
+    from opendrift_amd.leeway import Leeway
+    o = Leeway(loglevel=50, seed=0, rng='numpy')
+    for k, v in {'x_sea_water_velocity': 0, 'y_sea_water_velocity': 0, 'x_wind': 25, 'y_wind': 0, 'land_binary_mask': 0}.items():
+        o.set_config('environment:constant:%s' % k, v)
+    o.set_config('processes:capsizing', True)
+    o.set_config('capsizing:wind_threshold', 30)
+    o.set_config('capsizing:wind_threshold_sigma', 3)
+    o.set_config('capsizing:leeway_fraction', .4)
+    np.random.seed(0)                    # the reference's constructor seeds the stream right before its seeding
+    o.seed_elements(lon=0, lat=60, time=T0, number=100, leeway_coefficients=PIW1, capsized=capsized0)
+    o.run(time_step=dt, time_step_output=900, duration=timedelta(hours=6))
+    cap = o.P.get_property(8)
+    assert cap.max() <= 1 and cap.min() >= 0 and cap.sum() == expected, cap.sum()

@@ -121,3 +121,18 @@ def test_landmask_raster_reader_surface():
         f.get_variables(['x_wind'])
     o = OceanDrift(loglevel=50)
     assert o.discarded_readers == {}
+
+
+def test_read_objectprop_layout(tmp_path):
+    """OBJECTPROP.DAT as the reference reads it (leeway.py:186-219): key line, description line, nine numbers; the
+    first blank line ends the table."""
+    from opendrift_amd.leeway import read_objectprop
+    f = tmp_path / 'OBJECTPROP.DAT'
+    f.write_text(' PIW-1                        1\n Person-in-water (PIW), unknown state (mean values)\n'
+                 '       0.96     0.00     12.00      0.54      0.00      9.40     -0.54      0.00      9.40\n'
+                 ' PIW-2                        2\n >PIW, vertical PFD type III conscious\n'
+                 '       0.48     0.00      8.30      0.15      0.00      6.70     -0.15      0.00      6.70\n'
+                 '\n ignored\n')
+    t = read_objectprop(str(f))
+    assert list(t) == [1, 2] and t[1]['OBJKEY'] == 'PIW-1' and t[2]['Description'] == '>PIW, vertical PFD type III conscious'
+    assert (t[1]['DWSLOPE'], t[1]['DWSTD'], t[1]['CWLSLOPE'], t[2]['CWRSTD']) == (0.96, 12.0, -0.54, 6.7)
