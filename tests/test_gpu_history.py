@@ -86,5 +86,5 @@ def test_history_errors(ctx):
     with pytest.raises(OdrError):
         H.array('lon')                       # nothing flushed yet
     with pytest.raises(ValueError):
-        ctx.history(8, 2, ['lon'] * 40)
+        ctx.history(8, 2, ['lon'] * 41)      # more than the 40 variables of a record
     H.close()
