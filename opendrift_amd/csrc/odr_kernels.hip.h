@@ -1296,9 +1296,14 @@ __global__ __launch_bounds__(BLOCK) void k_coast_crossing(const DevWorld *__rest
       const double sy = ys > 1 ? __ddiv_rn(__dsub_rn(lat2, lat1), (double)(ys - 1)) : 0.0;
       double px = 0, py = 0;   // the sample before the current one in raveled order
       bool found = false, first = true;
+      // The reference evaluates all xs * ys samples at once (and runs out of memory when an element jumps across the
+      // dateline eastwards: |dlon| ~ 360 is only repaired for lon1 < 0); one thread must not spin on such a rectangle
+      // for seconds: after 4 M samples without land the search ends like a search that found none.
+      long long budget = 4000000;
       for (long long iy = 0; iy < ys && !found; ++iy) {
         const double yy = (ys > 1 && iy == ys - 1) ? lat2 : __dadd_rn(__dmul_rn((double)iy, sy), lat1);
         for (long long ix = 0; ix < xs; ++ix) {
+          if (--budget < 0) { found = true; break; }
           const double xx = (xs > 1 && ix == xs - 1) ? lon2 : __dadd_rn(__dmul_rn((double)ix, sx), lon1);
           if (landmask_contains(mask, xx, yy)) {
             // land_side False: index = max(0, index - 1) -- the very first sample stays itself
