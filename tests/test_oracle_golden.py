@@ -199,3 +199,20 @@ def test_c11_reference_known_answers_of_an_isolated_mixing_step(case):
                         np.zeros(n, np.float32), zl, Kp, 7200.0, float(T), 1, g['uniforms_%d' % case])
     assert np.abs(z - g['z_final_%d' % case]).max() < 1e-9
     assert abs(z.min() - zmin) < 0.05 and abs(z.max() - zmax) < 0.05 and abs(z.mean() - zmean) < 0.05
+
+
+def test_reference_known_answers_of_the_vertical_interpolator():
+    """tests/readers/test_interpolation.py:261-283 (test_interpolation_vertical, Linear1DInterpolator): [0.5, 2, 2.857]
+    between the levels 0, 1, 3, 10 and [0, 2.2, 3] with clamping outside the levels 1, 3, 5, 10 -- reproduced by the
+    oracle's world sampling of a 3D variable that equals its level number.  (The horizontal known answer of that file,
+    :199-214, belongs to the optional nearest-neighbour 'ndimage' interpolator, which is not on the path.)"""
+    for zgrid, z, want in (([0, -1, -3, -10], [-.5, -3, -9], [0.5, 2, 2.85714286]),
+                           ([-1, -3, -5, -10], [-.5, -6, -12], [0.0, 2.2, 3])):
+        wb = orc.WorldBuilder()
+        lev = np.ascontiguousarray(np.broadcast_to(np.arange(4, dtype=np.float32)[:, None, None], (4, 2, 2)))
+        wb.add_grid(orc.make_proj(), np.array([3.0, 5.0]), np.array([59.0, 61.0]), [(0.0, {orc.VAR['x_sea_water_velocity']: lev})],
+                    z=np.array(zgrid, dtype=np.float64))
+        w = wb.finish()
+        n = len(z)
+        (u,) = orc.get_environment(w, [orc.VAR['x_sea_water_velocity']], np.full(n, 4.0), np.full(n, 60.0), np.array(z, dtype=np.float64), 0.0)
+        assert np.allclose(u, want, atol=1e-6), (u, want)
