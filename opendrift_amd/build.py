@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'odrift.hip')
 DEPS = [SRC] + [os.path.join(HERE, 'csrc', f) for f in
-                ('odr_kernels.hip.h', 'odr_field.hip.h', 'odr_geodesic.hip.h', 'odr_mesh.h')] + \
+                ('odr_kernels.hip.h', 'odr_field.hip.h', 'odr_geodesic.hip.h', 'odr_oil.hip.h', 'odr_mesh.h')] + \
     [os.path.join(os.path.dirname(HERE), 'include', 'odrift.h')]
 LIB = os.path.join(HERE, 'libodrift_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
