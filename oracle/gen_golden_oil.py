@@ -217,6 +217,56 @@ def c9_openoil(distribution='Johansen et al. (2015)', tag='johansen'):
     return g, out, dict(film=np.asarray(o.elements.oil_film_thickness, dtype=np.float32))
 
 
+def c12_kelvin():
+    """Environment.get_environment's unit check (environment.py:829-838): sea_water_temperature above 100 is taken as
+    Kelvin and converted to Celsius per element.  A reader whose temperature field is in Kelvin in the western half
+    of the domain and in Celsius in the eastern half; the float32 environment right after the reference's
+    get_environment is stored."""
+    rng = np.random.default_rng(12)
+    nx, ny, nt = 40, 32, 2
+    x = np.linspace(2, 8, nx).astype(np.float32)
+    y = np.linspace(59, 63, ny).astype(np.float32)
+    X, Y = np.meshgrid(np.linspace(0, 1, nx), np.linspace(0, 1, ny))
+    times = [gg.T0 + timedelta(seconds=3600.0 * k) for k in range(nt)]
+    T = np.stack([(4 + 9 * Y + 0.5 * k + np.where(X < 0.5, 273.15, 0.0)) for k in range(nt)]).astype(np.float32)
+    g = dict(x=x, y=y, t=np.arange(nt) * 3600.0, sea_water_temperature=T,
+             x_sea_water_velocity=np.zeros_like(T), y_sea_water_velocity=np.zeros_like(T),
+             x_wind=np.zeros_like(T), y_wind=np.zeros_like(T))
+    oo.adios.get_oil_names = lambda location=None: ['STUB OIL']
+    oo.Density = lambda oil: _Const(OIL_DENSITY)
+    oo.KinematicViscosity = lambda oil: _Const(OIL_VISCOSITY)
+    o = oo.OpenOil(loglevel=50)
+    o.oiltype = _StubOil()
+    o.oil_name = 'STUB OIL'
+    o.store_oil_seed_metadata = lambda **kw: None
+    o.add_reader(gg.GridReader('+proj=latlong', x, y, times, {k: v for k, v in g.items() if k not in ('x', 'y', 't')}))
+    o.set_config('general:use_auto_landmask', False)
+    o.set_config('environment:fallback:land_binary_mask', 0)
+    for p in ('evaporation', 'emulsification', 'dispersion', 'biodegradation'):
+        o.set_config('processes:' + p, False)
+    o.set_config('drift:vertical_mixing', False)
+    o.set_config('drift:stokes_drift', False)
+    o.set_config('drift:current_uncertainty', 0)
+    o.set_config('drift:wind_uncertainty', 0)
+    N = 200
+    lon, lat = rng.uniform(x[2], x[-3], N), rng.uniform(y[2], y[-3], N)
+    o.seed_elements(lon=lon, lat=lat, z=0.0, time=gg.T0, wind_drift_factor=0.0)
+    st = RefStepper(o, 1800.0, 2)
+    seen = []
+    orig = o.calculate_missing_environment_variables
+
+    def hook():
+        seen.append(np.array(o.environment.sea_water_temperature, copy=True))
+        orig()
+    o.calculate_missing_environment_variables = hook
+    st.step()
+    st.step()
+    sch_lon, sch_lat = np.array(lon, dtype=np.float32).astype(np.float64), np.array(lat, dtype=np.float32).astype(np.float64)
+    assert seen[0].dtype == np.float32 and (seen[0] < 100).all() and (T[0][:, :nx // 2] > 100).all()
+    np.savez_compressed(os.path.join(gg.GOLD, 'c12_kelvin_environment.npz'), g_x=x, g_y=y, g_t=g['t'], g_T=T,
+                        lon=sch_lon, lat=sch_lat, T_env_step0=seen[0], T_env_step1=seen[1], dt=1800.0)
+
+
 def main():
     out = {}
     for dist, tag in (('Johansen et al. (2015)', 'johansen'), ('Li et al. (2017)', 'li')):
@@ -228,4 +278,7 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    if 'c12' in sys.argv[1:]:
+        c12_kelvin()
+    else:
+        main()

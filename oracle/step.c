@@ -349,6 +349,13 @@ void orc_get_environment(const orc_world *w, int nv, const int *vars, long n,
   for (v = 0; v < nv; ++v) /* fallback for masked, :782-791 */
     if (isfinite(w->fallback[vars[v]]))
       for (i = 0; i < n; ++i) if (!isfinite(out[v][i])) out[v][i] = w->fallback[vars[v]];
+  /* "Some extra checks of units" (:829-838): temperatures above 100 are Kelvin and become Celsius.  env is a MASKED
+   * float32 recarray at that point: numpy.ma wraps the Python float into a 0-d float64 array, which is not a weak
+   * scalar, so the difference is formed in float64 and rounded to float32 by the assignment (golden c12) */
+  for (v = 0; v < nv; ++v)
+    if (vars[v] == ORC_VAR_TEMP)
+      for (i = 0; i < n; ++i)
+        if (out[v][i] > 100.f) out[v][i] = (float)((double)out[v][i] - 273.15);
 }
 
 /* Profiles of one variable from the first GRID source of its priority list:

@@ -216,3 +216,21 @@ def test_reference_known_answers_of_the_vertical_interpolator():
         n = len(z)
         (u,) = orc.get_environment(w, [orc.VAR['x_sea_water_velocity']], np.full(n, 4.0), np.full(n, 60.0), np.array(z, dtype=np.float64), 0.0)
         assert np.allclose(u, want, atol=1e-6), (u, want)
+
+
+def test_c12_kelvin_temperatures_become_celsius_like_the_reference():
+    """Environment.get_environment's unit check (environment.py:829-838) on a reader that is in Kelvin over half of its
+    domain: golden c12 holds the reference's float32 environment right after get_environment (step 0: float32
+    positions of the seeding; step 1: no current, same positions in float64)."""
+    g = golden('c12_kelvin_environment.npz')
+    wb = orc.WorldBuilder()
+    levels = [(float(g['g_t'][k]), {orc.VAR['sea_water_temperature']: g['g_T'][k]}) for k in range(len(g['g_t']))]
+    wb.add_grid(orc.make_proj(), g['g_x'], g['g_y'], levels)
+    w = wb.finish()
+    n = len(g['lon'])
+    for k, key in enumerate(('T_env_step0', 'T_env_step1')):
+        (T,) = orc.get_environment(w, [orc.VAR['sea_water_temperature']], g['lon'], g['lat'], np.zeros(n), k * float(g['dt']))
+        assert T.dtype == np.float32 and (T < 100).all()
+        tol = 2e-3 if k == 0 else 0.0          # first step: float32 coordinates in the reference, times the 273 K jump across one cell
+        assert np.abs(T - g[key]).max() <= tol, (k, np.abs(T - g[key]).max())
+    assert (g['g_T'][0] > 100).any() and (g['g_T'][0] < 100).any()
