@@ -1,27 +1,53 @@
-"""Builds libodrift_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+"""Builds libodrift_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+
+The library is three translation units (csrc/odrift.hip, odr_step.hip, odr_mix.hip) compiled in parallel and
+linked into one shared object; objects are rebuilt only when a source they include changed."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, 'csrc', 'odrift.hip')
-DEPS = [SRC] + [os.path.join(HERE, 'csrc', f) for f in
-                ('odr_kernels.hip.h', 'odr_field.hip.h', 'odr_geodesic.hip.h', 'odr_oil.hip.h', 'odr_mesh.h')] + \
+CSRC = os.path.join(HERE, 'csrc')
+UNITS = ['odrift.hip', 'odr_step.hip', 'odr_mix.hip']
+HEADERS = [os.path.join(CSRC, f) for f in ('odr_host.h', 'odr_kernels.hip.h', 'odr_field.hip.h', 'odr_geodesic.hip.h',
+                                           'odr_oil.hip.h', 'odr_mesh.h')] + \
     [os.path.join(os.path.dirname(HERE), 'include', 'odrift.h')]
 LIB = os.path.join(HERE, 'libodrift_hip.so')
+OBJDIR = os.path.join(HERE, 'build')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
+         '-I' + os.path.join(os.path.dirname(HERE), 'include')]
 
 
-def build(force=False, verbose=False):
-    if (not force and os.path.exists(LIB)
-            and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)):
-        return LIB
-    cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
-           '-I' + os.path.join(os.path.dirname(HERE), 'include'), '-o', LIB, SRC]
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
-    return LIB
+def _stale(target, deps):
+    return not os.path.exists(target) or any(os.path.getmtime(target) < os.path.getmtime(d) for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir=OBJDIR):
+    """extra_flags / lib / objdir: A/B builds of the same sources (tools/ab_build.sh)."""
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for u in UNITS:
+        src = os.path.join(CSRC, u)
+        obj = os.path.join(objdir, u.replace('.hip', '.o'))
+        if force or _stale(obj, [src] + HEADERS):
+            jobs.append([HIPCC] + FLAGS + list(extra_flags) + ['-c', src, '-o', obj])
+    if jobs:
+        def run(cmd):
+            if verbose:
+                print(' '.join(cmd))
+            subprocess.check_call(cmd)
+        with ThreadPoolExecutor(len(jobs)) as ex:
+            list(ex.map(run, jobs))
+    objs = [os.path.join(objdir, u.replace('.hip', '.o')) for u in UNITS]
+    if jobs or _stale(lib, objs):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return lib
 
 
 if __name__ == '__main__':
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -30,7 +30,36 @@ struct GeodConst {
   double A3x[6];
   double C3x[15];
 };
-__constant__ GeodConst c_geod;
+constexpr GeodConst geod_wgs84() {
+  GeodConst g{};
+  // WGS84 (pyproj.Geod(ellps='WGS84')); A3/C3 coefficient polynomials in n, Karney (2013) eqs. 24-25
+  g.a = 6378137.0;
+  g.f = 1 / 298.257223563;
+  g.f1 = 1 - g.f;
+  g.e2 = g.f * (2 - g.f);
+  g.ep2 = g.e2 / (g.f1 * g.f1);
+  g.n = g.f / (2 - g.f);
+  g.b = g.a * g.f1;
+  g.ib = 1.0 / g.b;
+  const double n = g.n;
+  g.A3x[0] = -3.0 / 128;
+  g.A3x[1] = (-2 * n - 3) / 64;
+  g.A3x[2] = ((-n - 3) * n - 1) / 16;
+  g.A3x[3] = ((3 * n - 1) * n - 2) / 8;
+  g.A3x[4] = (n - 1) / 2;
+  g.A3x[5] = 1;
+  double *c = g.C3x;
+  c[0] = 3.0 / 128;              c[1] = (2 * n + 5) / 128;        c[2] = ((-n + 3) * n + 3) / 64;
+  c[3] = ((-n + 0) * n + 1) / 8; c[4] = (-n + 1) / 4;
+  c[5] = 5.0 / 256;              c[6] = (n + 3) / 128;            c[7] = ((-3 * n - 2) * n + 3) / 64;
+  c[8] = ((n - 3) * n + 2) / 32;
+  c[9] = 7.0 / 512;              c[10] = (-10 * n + 9) / 384;     c[11] = ((5 * n - 9) * n + 5) / 192;
+  c[12] = 7.0 / 512;             c[13] = (-14 * n + 7) / 512;
+  c[14] = 21.0 / 2560;
+  return g;
+}
+// one copy per translation unit (no relocatable device code), initialised at compile time
+static __constant__ GeodConst c_geod = geod_wgs84();
 
 static constexpr double kDeg = 3.14159265358979323846264338327950288 / 180.0;
 static constexpr double kDegLo = 2.9486522708701687e-19;  // pi/180 - kDeg
@@ -169,7 +198,7 @@ __device__ __forceinline__ double atan_ratio(double y, double x) {
 // on [0, 1] (max relative error 1.6e-17), octant reconstruction.  The coefficients live in constant memory and
 // reach the FMAs as scalar operands: the library routine spends 46 of its 102 vector instructions on
 // materialising 64-bit literals.
-__constant__ double c_atanq[20] = {
+static __constant__ double c_atanq[20] = {
     -0.33333333333333330252, 0.19999999999997532204, -0.14285714285384131545, 0.11111111093490828096,
     -0.090909085908919342252, 0.07692298971033216917, -0.066665646992891042112, 0.058815068777936560666,
     -0.05257973334284110807, 0.047377495795277789723, -0.042603566326016521328, 0.037494868125352471116,

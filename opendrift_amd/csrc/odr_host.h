@@ -1,0 +1,167 @@
+// Host-side internals shared by the translation units of libodrift_hip.so (odrift.hip: context, particle sets, field
+// blocks, environment sample, bookkeeping; odr_step.hip: current advection and the fused step; odr_mix.hip: vertical
+// mixing and the OpenOil mixing physics).  The library is built from several TUs so that hipcc compiles them in
+// parallel; no device code is shared across TUs (every kernel is defined where it is launched).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/odrift.h"
+#include "odr_kernels.hip.h"
+
+using namespace odr;
+
+int odr_i_fail(int code, const char *fmt, ...);   // records the message for odr_last_error(), returns code
+#define fail odr_i_fail
+#define HIPCHK(x)                                                                          \
+  do {                                                                                     \
+    hipError_t e_ = (x);                                                                   \
+    if (e_ != hipSuccess) return fail(ODR_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_));   \
+  } while (0)
+#define REQUIRE(c, ...) do { if (!(c)) return fail(ODR_ERR_INVALID, __VA_ARGS__); } while (0)
+
+struct Staged { DevBlock blk; float *base; size_t bytes; };       // uploaded, not yet committed
+struct Retired { void *ptr; size_t bytes; hipEvent_t ev; };       // replaced block, freed once the compute stream passed
+
+struct odr_ctx {
+  int device;
+  unsigned long long seed;
+  hipStream_t stream, own_stream;
+  DevWorld hw;      // host image
+  DevWorld *dw;     // device image
+  bool dirty;
+  std::vector<void *> block_bufs[MAXSRC][MAXLEVELS];  // owned device arrays per slot
+  size_t block_bytes[MAXSRC][MAXLEVELS];
+  // upload pipeline (stage_block / odr_block_commit)
+  hipStream_t up_stream;
+  hipEvent_t up_done, up_dep;
+  float *prep[2];
+  size_t prep_floats;
+  Staged staged[MAXSRC][MAXLEVELS];
+  std::vector<Retired> graveyard;
+  std::vector<void *> source_bufs;  // device arrays owned by sources (curvilinear node tables)
+  std::vector<void *> registered;   // host ranges page-locked by odr_host_register (released with the context)
+  double *red;      // device reduction slots
+  // OpenOil mixing-loop physics (odr_oil_prepare_mixing): armed for the next odr_vmix* call on `oil_owner`
+  const odr_particles *oil_owner;
+  OilArgs oil;
+  double *oil_stat, *oil_cdf, *oil_chunk, *oil_part, *oil_u;
+  int *oil_guide;
+  size_t oil_part_n, oil_u_n;
+  unsigned long long *counter;
+  hipEvent_t ev0, ev1;
+  int nsrc;
+  int fuse_vadv;
+  int seafloor;     // general:seafloor_action for the in-update() sea floor checks: action | status_code << 8
+  // reductions cached between the horizontal movers of one step (advect_wind -> stokes_drift -> horizontal
+  // diffusion read the same maxima: environment, z and properties do not change in between)
+  const odr_particles *red_owner;
+  unsigned long long red_epoch;
+  double red_wdd;
+  int red_rel;
+};
+
+struct odr_particles {
+  long long cap, n, ndead, dead_cap;
+  double *d64[7];       // lon lat z plon plat slon slat
+  double *alt64[7];
+  int *i32[3];          // id status moving
+  int *alti32[3];
+  float *f32[4];        // wdf cdf tv age_seconds
+  float *altf32[4];
+  float *env[NVAR];
+  float *altenv[NVAR];
+  float *aux[9];
+  float *altaux[9];
+  double *dead64[3];    // lon lat z of the deactivated store
+  int *deadi32[2];      // id status
+  unsigned *bcount;
+  void *scratch;
+  size_t scratch_bytes;
+  unsigned long long epoch;  // bumped by every call that changes z, the environment, properties or the element set
+  bool external;
+};
+
+static inline unsigned nblk(long long n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+static inline PView view(const odr_particles *p) {
+  PView v;
+  v.n = p->n;
+  v.lon = p->d64[0]; v.lat = p->d64[1]; v.z = p->d64[2]; v.plon = p->d64[3]; v.plat = p->d64[4];
+  v.slon = p->d64[5]; v.slat = p->d64[6];
+  v.id = p->i32[0]; v.status = p->i32[1]; v.moving = p->i32[2];
+  v.wdf = p->f32[0]; v.cdf = p->f32[1]; v.tv = p->f32[2]; v.age = p->f32[3];
+  for (int k = 0; k < NVAR; ++k) v.env[k] = p->env[k];
+  for (int k = 0; k < 9; ++k) v.aux[k] = p->aux[k];
+  return v;
+}
+
+static inline int flush_world(odr_ctx *c) {
+  if (c->dirty) {
+    HIPCHK(hipMemcpyAsync(c->dw, &c->hw, sizeof(DevWorld), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // hw is pageable and may change right after
+    c->dirty = false;
+  }
+  return 0;
+}
+
+static inline int ensure_env(odr_ctx *c, odr_particles *p, int var) {
+  if (!p->env[var]) {
+    HIPCHK(hipMalloc((void **)&p->env[var], sizeof(float) * (size_t)p->cap));
+    HIPCHK(hipMemsetAsync(p->env[var], 0, sizeof(float) * (size_t)p->cap, c->stream));
+  }
+  return 0;
+}
+
+static inline int scratch(odr_ctx *c, odr_particles *p, size_t bytes, void **out) {
+  if (p->scratch_bytes < bytes) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (p->scratch) HIPCHK(hipFree(p->scratch));
+    HIPCHK(hipMalloc(&p->scratch, bytes));
+    p->scratch_bytes = bytes;
+  }
+  *out = p->scratch;
+  return 0;
+}
+
+// host copy of nearest_time (variables.py:402-443) on the resident levels of one source
+static inline void host_bracket(const DevSource &s, double t, int &ib, int &ia) {
+  int b = 0;
+  for (int k = 0; k < s.nlevels; ++k) if (s.slot[s.level_slot[k]].t <= t) b = k;
+  ib = s.level_slot[b];
+  ia = (b + 1 < s.nlevels && s.slot[ib].t != t) ? s.level_slot[b + 1] : -1;
+}
+
+static inline UVTime uv_time(const DevSource &s, double t) {
+  int ib, ia;
+  host_bracket(s, t, ib, ia);
+  UVTime tm;
+  tm.b = s.slot[ib].data[VAR_U];
+  tm.a = (ia >= 0 && !s.always_valid) ? s.slot[ia].data[VAR_U] : nullptr;
+  tm.w = ia >= 0 ? (t - s.slot[ib].t) / (s.slot[ia].t - s.slot[ib].t) : 0.0;
+  return tm;
+}
+
+
+// defined in odrift.hip
+bool odr_i_build_env_group(const odr_ctx *c, const int *grp, int ng, double t, EnvGroupDesc &G);
+bool odr_i_uv_fast_source(const odr_ctx *c, int &sid, double t_lo, double t_hi);
+bool odr_i_gyre_source(const odr_ctx *c, int var, int &sid);
+int odr_i_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t, float *const *out_host,
+                     bool record_positions);
+int odr_i_reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind, bool wind_args_matter = true);
+int odr_i_read_counter(odr_ctx *c, int64_t *out);
+#define build_env_group odr_i_build_env_group
+#define uv_fast_source odr_i_uv_fast_source
+#define gyre_source odr_i_gyre_source
+#define env_sample_impl odr_i_env_sample
+#define reduce odr_i_reduce
+#define read_counter odr_i_read_counter

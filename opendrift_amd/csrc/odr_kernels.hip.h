@@ -135,6 +135,7 @@ __device__ __forceinline__ void stage_pos(const GeodOrigin &o, float u, float v,
   geod_direct_sc(o, salp, calp, (double)dist, lat2, lon2);
 }
 
+#ifdef ODR_TU_MISC
 // ------------------------------------------------------------------ environment
 // Environment.get_environment for one variable group of NV variables
 template <int NV>
@@ -183,6 +184,8 @@ __global__ __launch_bounds__(BLOCK) void k_record_prev(PView p, int which) {
   else { p.plon[i] = p.lon[i]; p.plat[i] = p.lat[i]; }
 }
 
+#endif  // ODR_TU_MISC
+#ifdef ODR_TU_STEP
 // --------------------------------------------------------------------- advection
 // PhysicsMethods.advect_ocean_current (physics_methods.py:611-691) with every RK
 // sub-stage -- geodesic to the stage position, reader front door, block gathers,
@@ -387,6 +390,8 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevW
   }
 }
 
+#endif  // ODR_TU_STEP
+#ifdef ODR_TU_MISC
 // analytic double gyre as the only source of the current (odr_field.hip.h "analytic double gyre, fast path")
 __global__ __launch_bounds__(BLOCK) void k_env_gyre(const DevWorld *__restrict__ W, int sid, PView p, double snw,
                                                     int with_land, int record_prev) {
@@ -403,6 +408,8 @@ __global__ __launch_bounds__(BLOCK) void k_env_gyre(const DevWorld *__restrict__
   if (record_prev) { p.slon[i] = lon; p.slat[i] = lat; }
 }
 
+#endif  // ODR_TU_MISC
+#ifdef ODR_TU_STEP
 template <int SCHEME>
 __global__ __launch_bounds__(BLOCK) void k_advect_gyre(const DevWorld *__restrict__ W, int sid, PView p, double dt,
                                                        float factor, double snw_half, double snw_full) {
@@ -443,6 +450,8 @@ __global__ __launch_bounds__(BLOCK) void k_advect_gyre(const DevWorld *__restric
   p.lat[i] = lat;
 }
 
+#endif  // ODR_TU_STEP
+#ifdef ODR_TU_MISC
 // update_positions with velocities supplied by the caller
 __global__ __launch_bounds__(BLOCK) void k_update_positions(PView p, const double *u, const double *v,
                                                             int is_f32, double dt) {
@@ -455,6 +464,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_positions(PView p, const doubl
   p.lat[i] = lat;
 }
 
+#endif  // ODR_TU_MISC
 // -------------------------------------------------------------------- reductions
 // red[] slots
 enum { R_NACT = 0, R_LONMIN, R_LONMAX, R_LATMIN, R_LATMAX, R_ZMIN, R_ZMAX, R_DMAX, R_STOKESMAX,
@@ -480,6 +490,7 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+#ifdef ODR_TU_MISC
 // min is stored as max of the negated value; red must be pre-filled with -inf (sums with 0).
 // Grid-stride over a bounded grid, wave shuffle + LDS block reduction, ONE atomic per slot per
 // workgroup (the first version issued one per wave: 8 ms of atomic contention for 6 M particles).
@@ -548,6 +559,8 @@ __global__ void k_red_init(double *red) {
   if (k < R_N) red[k] = (k == R_NACT || k == R_NSURF) ? 0.0 : -__builtin_inf();
 }
 
+#endif  // ODR_TU_MISC
+#ifdef ODR_TU_MISC
 // ------------------------------------------------------------------- wind / Stokes
 // advect_wind (physics_methods.py:712-791).  red[] carries the global early-out tests.
 __global__ __launch_bounds__(BLOCK) void k_advect_wind(PView p, double dt, double wind_drift_depth,
@@ -638,6 +651,7 @@ __global__ __launch_bounds__(BLOCK) void k_stokes(PView p, double dt, int profil
   p.lat[i] = lat;
 }
 
+#endif  // ODR_TU_MISC
 // --------------------------------------------------------------- random numbers
 // Philox4x32-10 (rocRAND device API), counter = (particle ID, step, stream): results do
 // not depend on how particles are sharded over GPUs or ordered in memory.
@@ -649,6 +663,7 @@ __device__ __forceinline__ void rng_init(rocrand_state_philox4x32_10 &st, unsign
   rocrand_init(seed, (unsigned long long)(unsigned)id, step * RNG_STEP_STRIDE + off, &st);
 }
 
+#ifdef ODR_TU_MISC
 // horizontal_diffusion (basemodel/__init__.py:1746-1772)
 __global__ __launch_bounds__(BLOCK) void k_hdiff(PView p, double dt, int rng_mode,
                                                  const double *__restrict__ hnx,
@@ -696,10 +711,12 @@ __global__ __launch_bounds__(BLOCK) void k_env_noise(PView p, int vx, int vy, do
   p.env[vy][i] = (float)__dadd_rn((double)p.env[vy][i], ny);
 }
 
+#endif  // ODR_TU_MISC
 }  // namespace odr
 #include "odr_oil.hip.h"
 namespace odr {
 
+#ifdef ODR_TU_MIX
 // ---------------------------------------------------------------- vertical mixing
 // OceanDrift.vertical_mixing (oceandrift.py:397-571), diffusivity model 'environment'.
 // The diffusivity profile of each particle (all block levels at the position of the last
@@ -1189,6 +1206,8 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_wind(PView p, const double *__re
   p.z[i] = z;
 }
 
+#endif  // ODR_TU_MIX
+#ifdef ODR_TU_MISC
 // vertical_advection (oceandrift.py:315-350)
 __global__ __launch_bounds__(BLOCK) void k_vadvect(PView p, double dt, int at_surface) {
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -1897,4 +1916,5 @@ __global__ __launch_bounds__(BLOCK) void k_blk_to_record(const float *__restrict
   }
 }
 
+#endif  // ODR_TU_MISC
 }  // namespace odr

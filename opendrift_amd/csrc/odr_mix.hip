@@ -1,0 +1,232 @@
+// libodrift_hip.so, translation unit 3: vertical mixing (reader profiles / wind-parameterised profiles) and the
+// OpenOil physics inside the mixing loop.  See odrift.hip for the rest.
+#define ODR_TU_MIX 1
+#include "odr_host.h"
+
+int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, int mix_at_surface, int rng_mode,
+             const double *huni, uint64_t step) {
+  p->epoch++;  // invalidates the cached reductions (reduce())
+  REQUIRE(dt_mix > 0 && dt != 0, "bad time steps");
+  if (!p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
+  int rc = ensure_env(c, p, VAR_SSH);
+  if (rc) return rc;
+  if ((rc = flush_world(c))) return rc;
+  if (p->n == 0) return 0;
+  int nzp = 1;
+  for (int k = 0; k < c->hw.nlist[VAR_KZ]; ++k) {
+    const DevSource &s = c->hw.src[c->hw.list[VAR_KZ][k]];
+    if (s.kind == SRC_GRID) { nzp = s.nz > 1 ? s.nz : 1; break; }
+  }
+  double *du = nullptr;
+  if (rng_mode == ODR_RNG_HOST) {
+    REQUIRE(huni, "host uniforms required in ODR_RNG_HOST mode");
+    int ntimes = abs((int)(dt / (dt_mix * (dt > 0 ? 1 : -1))));
+    void *s;
+    size_t n = (size_t)ntimes * (size_t)p->n;
+    if ((rc = scratch(c, p, sizeof(double) * n, &s))) return rc;
+    du = (double *)s;
+    HIPCHK(hipMemcpyAsync(du, huni, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  size_t lds = sizeof(double) * ((size_t)nzp * BLOCK + 3 * (size_t)nzp);
+  dim3 g(nblk(p->n)), b(BLOCK);
+  PView v = view(p);
+  unsigned long long st = (unsigned long long)step;
+  int vadv = c->fuse_vadv;
+  c->fuse_vadv = -1;
+  if (vadv >= 0 && !p->env[VAR_W]) return fail(ODR_ERR_STATE, "upward_sea_water_velocity has not been sampled");
+  // fast column kernel: K from one gridded reader, plain z-innermost array on every resident level
+  int ksid = -1;
+  for (int k = 0; k < c->hw.nlist[VAR_KZ]; ++k)
+    if (c->hw.src[c->hw.list[VAR_KZ][k]].kind == SRC_GRID) { ksid = c->hw.list[VAR_KZ][k]; break; }
+  const bool oil = c->oil_owner == p;   // OpenOil: terminal velocities, slick and wave entrainment inside the loop
+  c->oil_owner = nullptr;
+  bool fast = ksid >= 0 && nzp > 1 && !oil && !getenv("ODR_NO_FAST_PATH");
+  VMixDesc D;
+  memset(&D, 0, sizeof D);
+  if (fast) {
+    const DevSource &s = c->hw.src[ksid];
+    fast = s.nlevels >= 1;
+    for (int k = 0; k < s.nlevels && fast; ++k) {
+      const DevBlock &bk = s.slot[s.level_slot[k]], &g0 = s.slot[s.level_slot[0]];
+      if (!bk.data[VAR_KZ] || bk.es[VAR_KZ] != 1 || bk.var_nz[VAR_KZ] != nzp || bk.rec != g0.rec || bk.ny != g0.ny || bk.nx != g0.nx ||
+          bk.x0 != g0.x0 || bk.xspan != g0.xspan || bk.y0 != g0.y0 || bk.yspan != g0.yspan)
+        fast = false;
+    }
+    if (fast) {
+      int ib, ia;
+      host_bracket(s, t, ib, ia);
+      D.sid = ksid; D.nzp = nzp; D.geo_slot = ib;
+      D.kb = s.slot[ib].data[VAR_KZ];
+      D.ka = ia >= 0 ? s.slot[ia].data[VAR_KZ] : nullptr;
+      D.wgt = ia >= 0 ? (t - s.slot[ib].t) / (s.slot[ia].t - s.slot[ib].t) : 0.0;
+      D.Kfb = c->hw.fallback[VAR_KZ];
+    }
+  }
+  if (fast) {
+    const int nq = (nzp + 3) / 4;
+    const bool tl = D.ka != nullptr;
+#define VMIX_COL(NQ)                                                                                              \
+  do {                                                                                                            \
+    size_t l2 = sizeof(double) * ((size_t)(4 * NQ) * BLOCK + 3 * (size_t)(4 * NQ));                               \
+    if (tl) hipLaunchKernelGGL((k_vmix_col<NQ, true>), g, b, l2, c->stream, c->dw, v, D, dt, dt_mix,              \
+                               mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);                                  \
+    else hipLaunchKernelGGL((k_vmix_col<NQ, false>), g, b, l2, c->stream, c->dw, v, D, dt, dt_mix,                \
+                            mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);                                     \
+  } while (0)
+    // the smallest instantiated quad count >= nq; over-read stays inside the 64-byte array padding
+    if (nq <= 1) VMIX_COL(1);
+    else if (nq == 2) VMIX_COL(2);
+    else if (nq == 3) VMIX_COL(3);
+    else if (nq == 4) VMIX_COL(4);
+    else if (nq <= 6) VMIX_COL(6);
+    else if (nq <= 8) VMIX_COL(8);
+    else if (nq <= 12) VMIX_COL(12);
+    else VMIX_COL(16);
+#undef VMIX_COL
+  } else if (oil) {
+    if (nzp <= 16) hipLaunchKernelGGL((k_vmix<16, true>), g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor, c->oil);
+    else if (nzp <= 32) hipLaunchKernelGGL((k_vmix<32, true>), g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor, c->oil);
+    else hipLaunchKernelGGL((k_vmix<1, true>), g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor, c->oil);
+  } else if (nzp <= 16) hipLaunchKernelGGL(k_vmix<16>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
+  else if (nzp <= 32) hipLaunchKernelGGL(k_vmix<32>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
+  else hipLaunchKernelGGL(k_vmix<1>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// vertical_mixing with an analytical diffusivity model (oceandrift.py:385-395,448-458): also what the default
+// 'environment' model does when no reader provides ocean_vertical_diffusivity (:431-447 -> Large et al. 1994)
+int odr_vmix_wind_profile(odr_ctx *c, odr_particles *p, int model, double background_diffusivity, double dt,
+                          double dt_mix, int mix_at_surface, int rng_mode, const double *huni, uint64_t step) {
+  p->epoch++;
+  REQUIRE(model == ODR_DIFFUSIVITY_LARGE1994 || model == ODR_DIFFUSIVITY_SUNDBY1983, "Unknown diffusivity model: %d", model);
+  REQUIRE(dt_mix > 0 && dt != 0, "bad time steps");
+  if (!p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
+  int rc;
+  for (int v : {VAR_SSH, VAR_XWIND, VAR_YWIND, VAR_MLD})
+    if ((rc = ensure_env(c, p, v))) return rc;
+  if ((rc = flush_world(c))) return rc;
+  if (p->n == 0) return 0;
+  p->epoch++;  // the reduction must see this step's mixed-layer depths
+  if ((rc = reduce(c, p, 0.0, 0, false))) return rc;
+  double *du = nullptr;
+  if (rng_mode == ODR_RNG_HOST) {
+    REQUIRE(huni, "host uniforms required in ODR_RNG_HOST mode");
+    int ntimes = abs((int)(dt / (dt_mix * (dt > 0 ? 1 : -1))));
+    void *s;
+    size_t n = (size_t)ntimes * (size_t)p->n;
+    if ((rc = scratch(c, p, sizeof(double) * n, &s))) return rc;
+    du = (double *)s;
+    HIPCHK(hipMemcpyAsync(du, huni, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  int vadv = c->fuse_vadv;
+  c->fuse_vadv = -1;
+  if (vadv >= 0 && !p->env[VAR_W]) return fail(ODR_ERR_STATE, "upward_sea_water_velocity has not been sampled");
+  dim3 g(nblk(p->n)), b(BLOCK);
+  const bool oil = c->oil_owner == p;
+  c->oil_owner = nullptr;
+  if (oil && model == ODR_DIFFUSIVITY_LARGE1994)
+    hipLaunchKernelGGL((k_vmix_wind<DIFF_LARGE1994, true>), g, b, 0, c->stream, view(p), c->red, background_diffusivity, dt, dt_mix,
+                       mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv, c->seafloor, c->oil);
+  else if (oil)
+    hipLaunchKernelGGL((k_vmix_wind<DIFF_SUNDBY1983, true>), g, b, 0, c->stream, view(p), c->red, background_diffusivity, dt, dt_mix,
+                       mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv, c->seafloor, c->oil);
+  else if (model == ODR_DIFFUSIVITY_LARGE1994)
+    hipLaunchKernelGGL(k_vmix_wind<DIFF_LARGE1994>, g, b, 0, c->stream, view(p), c->red, background_diffusivity, dt, dt_mix,
+                       mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv, c->seafloor);
+  else
+    hipLaunchKernelGGL(k_vmix_wind<DIFF_SUNDBY1983>, g, b, 0, c->stream, view(p), c->red, background_diffusivity, dt, dt_mix,
+                       mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv, c->seafloor);
+  HIPCHK(hipGetLastError());
+  p->epoch++;
+  return 0;
+}
+
+// OpenOil.prepare_vertical_mixing (models/openoil/openoil.py:1017-1031) on the device, and the switch that makes the
+// next odr_vmix / odr_vmix_wind_profile call on these particles run OpenOil's version of the loop: terminal velocity
+// of the droplets in every sub-step (:922-998), slick formation (:1056-1061), wave entrainment (:1033-1054).
+int odr_oil_prepare_mixing(odr_ctx *c, odr_particles *p, double dt, double dt_mix, double interfacial_tension,
+                           double sea_water_density, int droplet_distribution, int keep_droplet_diameter, int hs_mode,
+                           int tp_mode, int temperature_to_kelvin, int rng_mode, const double *host_u_diameter,
+                           const double *host_u_entrain, const double *host_u_intrusion, uint64_t step) {
+  c->oil_owner = nullptr;
+  REQUIRE(dt_mix > 0 && dt != 0, "bad time steps");
+  REQUIRE(droplet_distribution == ODR_DROPLETS_JOHANSEN2015 || droplet_distribution == ODR_DROPLETS_LI2017,
+          "no wave entrainment droplet size distribution specified");      // openoil.py:1070
+  REQUIRE(interfacial_tension > 0 && sea_water_density > 0, "bad oil / water constants");
+  REQUIRE(hs_mode >= 0 && hs_mode <= 2 && tp_mode >= 0 && tp_mode <= 3, "bad wave options");
+  for (int k : {OIL_DIAMETER, OIL_DENSITY, OIL_VISCOSITY, OIL_FILM})
+    if (!p->aux[k]) return fail(ODR_ERR_STATE, "oil property slot %d has not been set", k);
+  for (int v : {VAR_XWIND, VAR_YWIND, VAR_TEMP, VAR_SALT})
+    if (!p->env[v]) return fail(ODR_ERR_STATE, "wind, sea_water_temperature and sea_water_salinity must have been sampled");
+  if ((hs_mode == 0 && !p->env[VAR_HS]) || (tp_mode == 0 && !p->env[VAR_TP])) return fail(ODR_ERR_STATE, "Hs/Tp not sampled");
+  if (!p->aux[OIL_DIAMETER_IF_ENTRAINED]) {
+    HIPCHK(hipMalloc((void **)&p->aux[OIL_DIAMETER_IF_ENTRAINED], sizeof(float) * (size_t)p->cap));
+    HIPCHK(hipMemsetAsync(p->aux[OIL_DIAMETER_IF_ENTRAINED], 0, sizeof(float) * (size_t)p->cap, c->stream));
+  }
+  if (!c->oil_stat) {
+    HIPCHK(hipMalloc((void **)&c->oil_stat, sizeof(double) * OIL_STAT_N));
+    HIPCHK(hipMalloc((void **)&c->oil_cdf, sizeof(double) * OIL_NSPEC));
+    HIPCHK(hipMalloc((void **)&c->oil_chunk, sizeof(double) * OIL_SPEC_BLOCKS));
+    HIPCHK(hipMalloc((void **)&c->oil_guide, sizeof(int) * (OIL_GUIDE + 1)));
+  }
+  if (p->n == 0) return 0;
+  const int ntimes = abs((int)(dt / (dt_mix * (dt > 0 ? 1 : -1))));
+  REQUIRE(rng_mode == ODR_RNG_HOST || ntimes <= OIL_MAX_SUBSTEPS_DEVICE_RNG, "more than %d mixing sub-steps per step", OIL_MAX_SUBSTEPS_DEVICE_RNG);
+  const unsigned nb = nblk(p->n);
+  if (c->oil_part_n < 2 * (size_t)nb) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->oil_part) HIPCHK(hipFree(c->oil_part));
+    HIPCHK(hipMalloc((void **)&c->oil_part, sizeof(double) * 2 * (size_t)nb));
+    c->oil_part_n = 2 * (size_t)nb;
+  }
+  OilArgs &a = c->oil;
+  memset(&a, 0, sizeof a);
+  a.keep_diameter = keep_droplet_diameter ? 1 : 0;
+  a.hs_mode = hs_mode; a.tp_mode = tp_mode; a.to_kelvin = temperature_to_kelvin ? 1 : 0;
+  a.droplets = droplet_distribution; a.rng_mode = rng_mode;
+  a.sigma_ow = interfacial_tension; a.rho_w = sea_water_density; a.dt_mix_cfg = dt_mix;
+  a.stat = c->oil_stat;
+  const double *du_d = nullptr;
+  if (rng_mode == ODR_RNG_HOST) {
+    REQUIRE(host_u_diameter && host_u_entrain && host_u_intrusion, "host uniforms required in ODR_RNG_HOST mode");
+    const size_t per = (size_t)ntimes * (size_t)p->n, need = 2 * per + (size_t)p->n;
+    if (c->oil_u_n < need) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (c->oil_u) HIPCHK(hipFree(c->oil_u));
+      HIPCHK(hipMalloc((void **)&c->oil_u, sizeof(double) * need));
+      c->oil_u_n = need;
+    }
+    HIPCHK(hipMemcpyAsync(c->oil_u, host_u_entrain, sizeof(double) * per, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->oil_u + per, host_u_intrusion, sizeof(double) * per, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->oil_u + 2 * per, host_u_diameter, sizeof(double) * (size_t)p->n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // the host arrays are pageable and may change right after
+    a.u_ent = c->oil_u; a.u_int = c->oil_u + per; du_d = c->oil_u + 2 * per;
+  }
+  const PView v = view(p);
+  const dim3 g(nb), b(BLOCK);
+  hipLaunchKernelGGL(k_oil_stats, g, b, 0, c->stream, v, a, c->oil_part);
+  hipLaunchKernelGGL(k_oil_stats_final, dim3(1), b, 0, c->stream, c->oil_part, (int)nb, (long long)p->n, c->oil_stat);
+  hipLaunchKernelGGL(k_oil_spectrum_sums, dim3(OIL_SPEC_BLOCKS), b, 0, c->stream, c->oil_stat, c->oil_chunk);
+  hipLaunchKernelGGL(k_oil_spectrum_offsets, dim3(1), dim3(64), 0, c->stream, c->oil_chunk, c->oil_stat);
+  hipLaunchKernelGGL(k_oil_spectrum_scan, dim3(OIL_SPEC_BLOCKS), b, 0, c->stream, c->oil_stat, c->oil_chunk, c->oil_cdf);
+  hipLaunchKernelGGL(k_oil_guide, dim3((OIL_GUIDE + 1 + BLOCK - 1) / BLOCK), b, 0, c->stream, c->oil_cdf, c->oil_guide);
+  hipLaunchKernelGGL(k_oil_choice, g, b, 0, c->stream, v, c->oil_cdf, c->oil_guide, rng_mode, du_d, c->seed,
+                     (unsigned long long)step);
+  HIPCHK(hipGetLastError());
+  c->oil_owner = p;
+  return 0;
+}
+
+// mean intrusion depth scale np.mean(1.5 Hs) and the spectrum median dV_50 of the last odr_oil_prepare_mixing
+int odr_oil_mixing_stats(odr_ctx *c, double *mean_zb, double *dv50) {
+  if (!c->oil_stat) return fail(ODR_ERR_STATE, "odr_oil_prepare_mixing has not run");
+  double h[OIL_STAT_N];
+  HIPCHK(hipMemcpyAsync(h, c->oil_stat, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (mean_zb) *mean_zb = h[OIL_STAT_MEAN_ZB];
+  if (dv50) *dv50 = h[OIL_STAT_DV50];
+  return 0;
+}

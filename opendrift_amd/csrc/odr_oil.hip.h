@@ -207,6 +207,7 @@ __device__ __forceinline__ int oil_search_right(const double *__restrict__ cdf, 
   return lo;
 }
 
+#ifdef ODR_TU_MIX
 // ---------------------------------------------------------------- prepare_vertical_mixing
 #ifndef ODR_OIL_HOST   // tests/oil_host.cpp compiles the per-element arithmetic above for the CPU
 // Per-element median droplet diameter dV_50 of the spectrum (its MEAN over the elements parameterises the one
@@ -337,4 +338,5 @@ __global__ __launch_bounds__(BLOCK) void k_oil_choice(PView p, const double *__r
 
 #endif  // ODR_OIL_HOST
 #undef OF
+#endif  // ODR_TU_MIX
 }  // namespace odr

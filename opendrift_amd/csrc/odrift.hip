@@ -2,25 +2,14 @@
 // One context = one HIP stream + the device image of the Environment (field sources,
 // priority lists) ; one particle set = SoA arrays in HBM.  Everything is launched on the
 // context stream; only calls that hand data back to the host synchronise.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
-
-#include "../../include/odrift.h"
+// Translation unit 1 of 3 (odr_step.hip, odr_mix.hip): context, particle sets, field blocks, environment sample,
+// Euler movers, bookkeeping, compaction / sort, result buffer, sigma grids.
+#define ODR_TU_MISC 1
+#include "odr_host.h"
 #include "odr_mesh.h"
-#include "odr_kernels.hip.h"
-
-using namespace odr;
 
 static thread_local std::string g_err;
-static int fail(int code, const char *fmt, ...) {
+int odr_i_fail(int code, const char *fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -29,146 +18,9 @@ static int fail(int code, const char *fmt, ...) {
   g_err = buf;
   return code;
 }
-#define HIPCHK(x)                                                                          \
-  do {                                                                                     \
-    hipError_t e_ = (x);                                                                   \
-    if (e_ != hipSuccess) return fail(ODR_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_));   \
-  } while (0)
-#define REQUIRE(c, ...) do { if (!(c)) return fail(ODR_ERR_INVALID, __VA_ARGS__); } while (0)
-
-struct Staged { DevBlock blk; float *base; size_t bytes; };       // uploaded, not yet committed
-struct Retired { void *ptr; size_t bytes; hipEvent_t ev; };       // replaced block, freed once the compute stream passed
-
-struct odr_ctx {
-  int device;
-  unsigned long long seed;
-  hipStream_t stream, own_stream;
-  DevWorld hw;      // host image
-  DevWorld *dw;     // device image
-  bool dirty;
-  std::vector<void *> block_bufs[MAXSRC][MAXLEVELS];  // owned device arrays per slot
-  size_t block_bytes[MAXSRC][MAXLEVELS];
-  // upload pipeline (stage_block / odr_block_commit)
-  hipStream_t up_stream;
-  hipEvent_t up_done, up_dep;
-  float *prep[2];
-  size_t prep_floats;
-  Staged staged[MAXSRC][MAXLEVELS];
-  std::vector<Retired> graveyard;
-  std::vector<void *> source_bufs;  // device arrays owned by sources (curvilinear node tables)
-  std::vector<void *> registered;   // host ranges page-locked by odr_host_register (released with the context)
-  double *red;      // device reduction slots
-  // OpenOil mixing-loop physics (odr_oil_prepare_mixing): armed for the next odr_vmix* call on `oil_owner`
-  const odr_particles *oil_owner;
-  OilArgs oil;
-  double *oil_stat, *oil_cdf, *oil_chunk, *oil_part, *oil_u;
-  int *oil_guide;
-  size_t oil_part_n, oil_u_n;
-  unsigned long long *counter;
-  hipEvent_t ev0, ev1;
-  int nsrc;
-  int fuse_vadv;
-  int seafloor;     // general:seafloor_action for the in-update() sea floor checks: action | status_code << 8
-  // reductions cached between the horizontal movers of one step (advect_wind -> stokes_drift -> horizontal
-  // diffusion read the same maxima: environment, z and properties do not change in between)
-  const odr_particles *red_owner;
-  unsigned long long red_epoch;
-  double red_wdd;
-  int red_rel;
-};
-
-struct odr_particles {
-  long long cap, n, ndead, dead_cap;
-  double *d64[7];       // lon lat z plon plat slon slat
-  double *alt64[7];
-  int *i32[3];          // id status moving
-  int *alti32[3];
-  float *f32[4];        // wdf cdf tv age_seconds
-  float *altf32[4];
-  float *env[NVAR];
-  float *altenv[NVAR];
-  float *aux[9];
-  float *altaux[9];
-  double *dead64[3];    // lon lat z of the deactivated store
-  int *deadi32[2];      // id status
-  unsigned *bcount;
-  void *scratch;
-  size_t scratch_bytes;
-  unsigned long long epoch;  // bumped by every call that changes z, the environment, properties or the element set
-  bool external;
-};
-
-static inline unsigned nblk(long long n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
-
-static PView view(const odr_particles *p) {
-  PView v;
-  v.n = p->n;
-  v.lon = p->d64[0]; v.lat = p->d64[1]; v.z = p->d64[2]; v.plon = p->d64[3]; v.plat = p->d64[4];
-  v.slon = p->d64[5]; v.slat = p->d64[6];
-  v.id = p->i32[0]; v.status = p->i32[1]; v.moving = p->i32[2];
-  v.wdf = p->f32[0]; v.cdf = p->f32[1]; v.tv = p->f32[2]; v.age = p->f32[3];
-  for (int k = 0; k < NVAR; ++k) v.env[k] = p->env[k];
-  for (int k = 0; k < 9; ++k) v.aux[k] = p->aux[k];
-  return v;
-}
-
-static int flush_world(odr_ctx *c) {
-  if (c->dirty) {
-    HIPCHK(hipMemcpyAsync(c->dw, &c->hw, sizeof(DevWorld), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));  // hw is pageable and may change right after
-    c->dirty = false;
-  }
-  return 0;
-}
-
-static int ensure_env(odr_ctx *c, odr_particles *p, int var) {
-  if (!p->env[var]) {
-    HIPCHK(hipMalloc((void **)&p->env[var], sizeof(float) * (size_t)p->cap));
-    HIPCHK(hipMemsetAsync(p->env[var], 0, sizeof(float) * (size_t)p->cap, c->stream));
-  }
-  return 0;
-}
-
-static int scratch(odr_ctx *c, odr_particles *p, size_t bytes, void **out) {
-  if (p->scratch_bytes < bytes) {
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (p->scratch) HIPCHK(hipFree(p->scratch));
-    HIPCHK(hipMalloc(&p->scratch, bytes));
-    p->scratch_bytes = bytes;
-  }
-  *out = p->scratch;
-  return 0;
-}
 
 const char *odr_last_error(void) { return g_err.c_str(); }
 const char *odr_version(void) { return "odrift-hip 0.1 (gfx950)"; }
-
-static void geod_consts(GeodConst &g) {
-  // WGS84 (pyproj.Geod(ellps='WGS84')); A3/C3 coefficient polynomials in n, Karney (2013) eqs. 24-25
-  g.a = 6378137.0;
-  g.f = 1 / 298.257223563;
-  g.f1 = 1 - g.f;
-  g.e2 = g.f * (2 - g.f);
-  g.ep2 = g.e2 / (g.f1 * g.f1);
-  g.n = g.f / (2 - g.f);
-  g.b = g.a * g.f1;
-  g.ib = 1.0 / g.b;
-  const double n = g.n;
-  g.A3x[0] = -3.0 / 128;
-  g.A3x[1] = (-2 * n - 3) / 64;
-  g.A3x[2] = ((-n - 3) * n - 1) / 16;
-  g.A3x[3] = ((3 * n - 1) * n - 2) / 8;
-  g.A3x[4] = (n - 1) / 2;
-  g.A3x[5] = 1;
-  double *c = g.C3x;
-  c[0] = 3.0 / 128;              c[1] = (2 * n + 5) / 128;        c[2] = ((-n + 3) * n + 3) / 64;
-  c[3] = ((-n + 0) * n + 1) / 8; c[4] = (-n + 1) / 4;
-  c[5] = 5.0 / 256;              c[6] = (n + 3) / 128;            c[7] = ((-3 * n - 2) * n + 3) / 64;
-  c[8] = ((n - 3) * n + 2) / 32;
-  c[9] = 7.0 / 512;              c[10] = (-10 * n + 9) / 384;     c[11] = ((5 * n - 9) * n + 5) / 192;
-  c[12] = 7.0 / 512;             c[13] = (-14 * n + 7) / 512;
-  c[14] = 21.0 / 2560;
-}
 
 int odr_ctx_create(int device, uint64_t seed, odr_ctx **out) {
   REQUIRE(out, "out is NULL");
@@ -192,9 +44,6 @@ int odr_ctx_create(int device, uint64_t seed, odr_ctx **out) {
   c->nsrc = 0;
   c->fuse_vadv = -1;
   c->seafloor = ODR_SEAFLOOR_LIFT;
-  GeodConst g;
-  geod_consts(g);
-  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_geod), &g, sizeof(GeodConst)));
   *out = c;
   return 0;
 }
@@ -858,10 +707,8 @@ int odr_env_bind(odr_ctx *c, int32_t var, int ns, const int32_t *sids, float fal
   return 0;
 }
 
-static void host_bracket(const DevSource &s, double t, int &ib, int &ia);
-
 // fast path of odr_env_sample: a group served by one gridded reader with a uniform grid
-static bool build_env_group(const odr_ctx *c, const int *grp, int ng, double t, EnvGroupDesc &G) {
+bool odr_i_build_env_group(const odr_ctx *c, const int *grp, int ng, double t, EnvGroupDesc &G) {
   const DevWorld &w = c->hw;
   if (ng > MAXG || w.nlist[grp[0]] != 1) return false;
   int sid = w.list[grp[0]][0];
@@ -958,7 +805,7 @@ static bool launch_env_constant(odr_ctx *c, odr_particles *p, const int *grp, in
 }
 
 // fast path of odr_env_sample: {x,y}_sea_water_velocity (and land_binary_mask) served by one double-gyre reader
-static bool gyre_source(const odr_ctx *c, int var, int &sid) {
+bool odr_i_gyre_source(const odr_ctx *c, int var, int &sid) {
   const DevWorld &w = c->hw;
   if (w.nlist[var] != 1) return false;
   sid = w.list[var][0];
@@ -990,16 +837,13 @@ static void launch_group(odr_ctx *c, odr_particles *p, const int *vars, double t
   hipLaunchKernelGGL(k_env_group<NV>, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, c->dw, view(p), gv, t, rec);
 }
 
-static int env_sample_impl(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t,
-                           float *const *out_host, bool record_positions);
-
 int odr_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t, float *const *out_host) {
   return env_sample_impl(c, p, nvars, var_ids, t, out_host, true);
 }
 
 // record_positions: remember the sample position (slon/slat) for the profiles of odr_vmix
-static int env_sample_impl(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t,
-                           float *const *out_host, bool record_positions) {
+int odr_i_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t,
+                     float *const *out_host, bool record_positions) {
   p->epoch++;
   REQUIRE(nvars > 0 && nvars <= NVAR && var_ids, "bad variable list");
   HIPCHK(hipSetDevice(c->device));
@@ -1109,16 +953,8 @@ int odr_env_add_noise(odr_ctx *c, odr_particles *p, int32_t vx, int32_t vy, doub
   return 0;
 }
 
-// -------------------------------------------------------------------- advection
-// host copy of nearest_time (variables.py:402-443) on the resident levels of one source
-static void host_bracket(const DevSource &s, double t, int &ib, int &ia) {
-  int b = 0;
-  for (int k = 0; k < s.nlevels; ++k) if (s.slot[s.level_slot[k]].t <= t) b = k;
-  ib = s.level_slot[b];
-  ia = (b + 1 < s.nlevels && s.slot[ib].t != t) ? s.level_slot[b + 1] : -1;
-}
-
-static bool uv_fast_source(const odr_ctx *c, int &sid, double t_lo, double t_hi) {
+// odr_advect, odr_env_coast_advect: odr_step.hip
+bool odr_i_uv_fast_source(const odr_ctx *c, int &sid, double t_lo, double t_hi) {
   const DevWorld &w = c->hw;
   if (w.nlist[VAR_U] != 1 || w.nlist[VAR_V] != 1 || w.list[VAR_U][0] != w.list[VAR_V][0]) return false;
   sid = w.list[VAR_U][0];
@@ -1136,181 +972,6 @@ static bool uv_fast_source(const odr_ctx *c, int &sid, double t_lo, double t_hi)
   return true;
 }
 
-static UVTime uv_time(const DevSource &s, double t) {
-  int ib, ia;
-  host_bracket(s, t, ib, ia);
-  UVTime tm;
-  tm.b = s.slot[ib].data[VAR_U];
-  tm.a = (ia >= 0 && !s.always_valid) ? s.slot[ia].data[VAR_U] : nullptr;
-  tm.w = ia >= 0 ? (t - s.slot[ib].t) / (s.slot[ia].t - s.slot[ib].t) : 0.0;
-  return tm;
-}
-
-template <int SCHEME>
-static void launch_advect_grid(odr_ctx *c, odr_particles *p, int sid, double t, double dt, double factor) {
-  const DevSource &s = c->hw.src[sid];
-  UVTime th = uv_time(s, t + dt / 2), tf = uv_time(s, t + dt);
-  int geo = s.level_slot[0];
-  bool is3d = s.slot[geo].var_nz[VAR_U] > 1;
-  dim3 g(nblk(p->n)), b(BLOCK);
-  PView v = view(p);
-  float f = (float)factor;
-#define ODR_LAUNCH(PROJ, D3) hipLaunchKernelGGL((k_advect_grid<SCHEME, PROJ, D3>), g, b, 0, c->stream, c->dw, sid, geo, v, dt, f, th, tf)
-  switch (s.proj.kind) {
-    case PROJ_LATLONG: if (is3d) ODR_LAUNCH(PROJ_LATLONG, true); else ODR_LAUNCH(PROJ_LATLONG, false); break;
-    case PROJ_STERE_POLAR: if (is3d) ODR_LAUNCH(PROJ_STERE_POLAR, true); else ODR_LAUNCH(PROJ_STERE_POLAR, false); break;
-    case PROJ_CURVILINEAR: if (is3d) ODR_LAUNCH(PROJ_CURVILINEAR, true); else ODR_LAUNCH(PROJ_CURVILINEAR, false); break;
-    default: if (is3d) ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, true); else ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, false); break;
-  }
-#undef ODR_LAUNCH
-}
-
-int odr_advect(odr_ctx *c, odr_particles *p, int scheme, double t, double dt, double factor) {
-  REQUIRE(scheme >= 0 && scheme <= 2, "Drift scheme not recognised: %d", scheme);
-  if (!p->env[VAR_U] || !p->env[VAR_V]) return fail(ODR_ERR_STATE, "odr_env_sample of the current must precede odr_advect");
-  HIPCHK(hipSetDevice(c->device));
-  int rc = flush_world(c);
-  if (rc) return rc;
-  if (p->n == 0) return 0;
-  dim3 g(nblk(p->n)), b(BLOCK);
-  PView v = view(p);
-  int sid = -1, gsid = -1;
-  if (scheme == 0) hipLaunchKernelGGL(k_advect<0>, g, b, 0, c->stream, c->dw, v, t, dt, (float)factor);
-  else if (!getenv("ODR_NO_FAST_PATH") && gyre_source(c, VAR_U, gsid) && c->hw.nlist[VAR_V] == 1 &&
-           c->hw.list[VAR_V][0] == gsid &&
-           (c->hw.src[gsid].always_valid || (fmin(t, t + dt) >= c->hw.src[gsid].tmin && fmax(t, t + dt) <= c->hw.src[gsid].tmax))) {
-    const DevSource &gs = c->hw.src[gsid];
-    const double sh = sin(gs.params[2] * (t + dt / 2 - gs.params[3])), sf = sin(gs.params[2] * (t + dt - gs.params[3]));
-    if (scheme == 1) hipLaunchKernelGGL(k_advect_gyre<1>, g, b, 0, c->stream, c->dw, gsid, v, dt, (float)factor, sh, sf);
-    else hipLaunchKernelGGL(k_advect_gyre<2>, g, b, 0, c->stream, c->dw, gsid, v, dt, (float)factor, sh, sf);
-  }
-  else if (uv_fast_source(c, sid, t < t + dt ? t : t + dt, t < t + dt ? t + dt : t) && !getenv("ODR_NO_FAST_PATH")) {
-    if (scheme == 1) launch_advect_grid<1>(c, p, sid, t, dt, factor);
-    else launch_advect_grid<2>(c, p, sid, t, dt, factor);
-  } else if (scheme == 1) hipLaunchKernelGGL(k_advect<1>, g, b, 0, c->stream, c->dw, v, t, dt, (float)factor);
-  else hipLaunchKernelGGL(k_advect<2>, g, b, 0, c->stream, c->dw, v, t, dt, (float)factor);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
-static int read_counter(odr_ctx *c, int64_t *out);
-
-// get_environment -> interact_with_coastline -> update_previous_state -> advect_ocean_current in
-// one launch (k_step_grid) when the current comes from one gridded reader; otherwise exactly the
-// four separate entry points, in that order.  Results are bit-identical either way
-// (tests/test_gpu_parity.py::test_fused_step_equals_separate_calls).
-template <int SCHEME>
-static void launch_step_grid(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, StepDesc S, double t, double dt,
-                             double factor) {
-  const DevSource &s = c->hw.src[G.sid];
-  UVTime th = uv_time(s, t + dt / 2), tf = uv_time(s, t + dt);
-  S.geo_slot_uv = s.level_slot[0];
-  bool is3d = s.slot[S.geo_slot_uv].var_nz[VAR_U] > 1;
-  dim3 g(nblk(p->n)), b(BLOCK);
-  PView v = view(p);
-  float f = (float)factor;
-#define ODR_LAUNCH(PROJ, D3) hipLaunchKernelGGL((k_step_grid<SCHEME, PROJ, D3>), g, b, 0, c->stream, c->dw, v, G, S, dt, f, th, tf, c->counter)
-  switch (s.proj.kind) {
-    case PROJ_LATLONG: if (is3d) ODR_LAUNCH(PROJ_LATLONG, true); else ODR_LAUNCH(PROJ_LATLONG, false); break;
-    case PROJ_STERE_POLAR: if (is3d) ODR_LAUNCH(PROJ_STERE_POLAR, true); else ODR_LAUNCH(PROJ_STERE_POLAR, false); break;
-    case PROJ_CURVILINEAR: if (is3d) ODR_LAUNCH(PROJ_CURVILINEAR, true); else ODR_LAUNCH(PROJ_CURVILINEAR, false); break;
-    default: if (is3d) ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, true); else ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, false); break;
-  }
-#undef ODR_LAUNCH
-}
-
-int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t,
-                         int coast_action, int stranded_code, int seeded_on_land_code, int store_previous,
-                         int scheme, double dt, double factor, const odr_step_extras *extras, int64_t *n_on_land) {
-  p->epoch++;  // invalidates the cached reductions (reduce())
-  REQUIRE(nvars > 0 && nvars <= NVAR && var_ids, "bad variable list");
-  REQUIRE(scheme >= 0 && scheme <= 2, "Drift scheme not recognised: %d", scheme);
-  REQUIRE(coast_action >= 0 && coast_action <= 2, "bad coastline action");
-  HIPCHK(hipSetDevice(c->device));
-  if (n_on_land) *n_on_land = 0;
-  int rc;
-  bool has_u = false, has_v = false, has_land = false;
-  for (int k = 0; k < nvars; ++k) {
-    REQUIRE(var_ids[k] >= 0 && var_ids[k] < NVAR, "bad variable id %d", var_ids[k]);
-    has_u |= var_ids[k] == VAR_U; has_v |= var_ids[k] == VAR_V; has_land |= var_ids[k] == VAR_LAND;
-  }
-  REQUIRE(has_u && has_v, "the variable list must hold x/y_sea_water_velocity");
-  if (coast_action && !has_land && !p->env[VAR_LAND]) return fail(ODR_ERR_STATE, "land_binary_mask has not been sampled");
-  if ((rc = flush_world(c))) return rc;
-  // the group of the current: variables of the list that share its priority list
-  int grp[NVAR], ng = 0, rest[NVAR], nrest = 0;
-  auto same_list = [&](int a, int b) {
-    if (c->hw.nlist[a] != c->hw.nlist[b]) return false;
-    for (int k = 0; k < c->hw.nlist[a]; ++k) if (c->hw.list[a][k] != c->hw.list[b][k]) return false;
-    return true;
-  };
-  bool land_in_group = has_land && same_list(VAR_LAND, VAR_U);
-  bool has_depth = false;
-  for (int k = 0; k < nvars; ++k) has_depth |= var_ids[k] == VAR_DEPTH;
-  const bool want_floor = extras && extras->seafloor_action == 1;
-  if (want_floor && !has_depth && !p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
-  const bool depth_in_group = want_floor && has_depth && same_list(VAR_DEPTH, VAR_U);
-  grp[ng++] = VAR_U; grp[ng++] = VAR_V;
-  if (land_in_group) grp[ng++] = VAR_LAND;
-  const int depth_slot = depth_in_group ? ng : -1;
-  if (depth_in_group) grp[ng++] = VAR_DEPTH;
-  bool seen[NVAR] = {false};
-  seen[VAR_U] = seen[VAR_V] = true;
-  if (land_in_group) seen[VAR_LAND] = true;
-  if (depth_in_group) seen[VAR_DEPTH] = true;
-  for (int k = 0; k < nvars; ++k) {
-    int v = var_ids[k];
-    if (seen[v]) continue;
-    seen[v] = true;
-    if (same_list(v, VAR_U)) grp[ng++] = v; else rest[nrest++] = v;
-  }
-  // report_missing_variables inside the fused kernel: the variables that can still be NaN (no fallback)
-  int miss_grp[NVAR], nmg = 0, miss_rest[NVAR], nmr = 0;
-  if (extras && extras->missing_code) {
-    for (int k = 0; k < ng; ++k) if (std::isnan(c->hw.fallback[grp[k]])) miss_grp[nmg++] = k;
-    for (int k = 0; k < nrest; ++k) if (std::isnan(c->hw.fallback[rest[k]])) miss_rest[nmr++] = rest[k];
-  }
-  EnvGroupDesc G;
-  int sid = -1;
-  bool fuse = p->n > 0 && !getenv("ODR_NO_FAST_PATH") && same_list(VAR_V, VAR_U) && ng <= MAXG && nmg <= 4 && nmr <= 4 &&
-              uv_fast_source(c, sid, t < t + dt ? t : t + dt, t < t + dt ? t + dt : t) &&
-              build_env_group(c, grp, ng, t, G) && G.sid == sid;
-  if (!fuse) {
-    if ((rc = odr_env_sample(c, p, nvars, var_ids, t, nullptr))) return rc;
-    if (extras && extras->missing_code && (rc = odr_deactivate_missing(c, p, nvars, var_ids, extras->missing_code, nullptr)))
-      return rc;
-    if ((rc = odr_coastline(c, p, coast_action, stranded_code, seeded_on_land_code, n_on_land))) return rc;
-    if (want_floor && (rc = odr_seafloor(c, p, nullptr))) return rc;
-    if (extras && extras->age_dt != 0 &&
-        (rc = odr_increase_age(c, p, extras->age_dt, extras->max_age_seconds, extras->retired_code)))
-      return rc;
-    if (store_previous && (rc = odr_store_previous(c, p))) return rc;
-    return odr_advect(c, p, scheme, t, dt, factor);
-  }
-  for (int k = 0; k < ng; ++k) if ((rc = ensure_env(c, p, grp[k]))) return rc;
-  if (nrest && (rc = env_sample_impl(c, p, nrest, rest, t, nullptr, false))) return rc;  // k_step_grid records the positions
-  StepDesc S;
-  memset(&S, 0, sizeof S);
-  S.coast_action = coast_action; S.stranded_code = stranded_code; S.seeded_code = seeded_on_land_code;
-  S.land_slot = land_in_group ? 2 : -1;
-  S.store_previous = store_previous;
-  S.seafloor = want_floor ? 1 : 0;
-  S.depth_slot = depth_slot;
-  S.age_dt = extras ? (float)extras->age_dt : 0.0f;
-  S.max_age = extras ? (float)extras->max_age_seconds : 0.0f;
-  S.retired_code = extras ? extras->retired_code : 0;
-  S.missing_code = extras ? extras->missing_code : 0;
-  S.nmiss_grp = nmg; S.nmiss_rest = nmr;
-  for (int k = 0; k < nmg && k < 4; ++k) S.miss_grp[k] = miss_grp[k];
-  for (int k = 0; k < nmr && k < 4; ++k) S.miss_rest[k] = miss_rest[k];
-  if (want_floor && (rc = ensure_env(c, p, VAR_SSH))) return rc;
-  if (coast_action) HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
-  if (scheme == 0) launch_step_grid<0>(c, p, G, S, t, dt, factor);
-  else if (scheme == 1) launch_step_grid<1>(c, p, G, S, t, dt, factor);
-  else launch_step_grid<2>(c, p, G, S, t, dt, factor);
-  HIPCHK(hipGetLastError());
-  return coast_action ? read_counter(c, n_on_land) : 0;
-}
 
 int odr_update_positions(odr_ctx *c, odr_particles *p, const double *u, const double *v, int is_f32, double dt) {
   REQUIRE(u && v, "velocities required");
@@ -1384,7 +1045,7 @@ int odr_leeway_capsize(odr_ctx *c, odr_particles *p, double dt, double wind_thre
   return 0;
 }
 
-static int reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind, bool wind_args_matter = true) {
+int odr_i_reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind, bool wind_args_matter) {
   if (!p->external && c->red_owner == p && c->red_epoch == p->epoch &&
       (!wind_args_matter || (c->red_wdd == wdd && c->red_rel == relwind)))
     return 0;
@@ -1452,234 +1113,6 @@ int odr_hdiffusion(odr_ctx *c, odr_particles *p, double dt, int rng_mode, const 
   return 0;
 }
 
-int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, int mix_at_surface, int rng_mode,
-             const double *huni, uint64_t step) {
-  p->epoch++;  // invalidates the cached reductions (reduce())
-  REQUIRE(dt_mix > 0 && dt != 0, "bad time steps");
-  if (!p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
-  int rc = ensure_env(c, p, VAR_SSH);
-  if (rc) return rc;
-  if ((rc = flush_world(c))) return rc;
-  if (p->n == 0) return 0;
-  int nzp = 1;
-  for (int k = 0; k < c->hw.nlist[VAR_KZ]; ++k) {
-    const DevSource &s = c->hw.src[c->hw.list[VAR_KZ][k]];
-    if (s.kind == SRC_GRID) { nzp = s.nz > 1 ? s.nz : 1; break; }
-  }
-  double *du = nullptr;
-  if (rng_mode == ODR_RNG_HOST) {
-    REQUIRE(huni, "host uniforms required in ODR_RNG_HOST mode");
-    int ntimes = abs((int)(dt / (dt_mix * (dt > 0 ? 1 : -1))));
-    void *s;
-    size_t n = (size_t)ntimes * (size_t)p->n;
-    if ((rc = scratch(c, p, sizeof(double) * n, &s))) return rc;
-    du = (double *)s;
-    HIPCHK(hipMemcpyAsync(du, huni, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-  }
-  size_t lds = sizeof(double) * ((size_t)nzp * BLOCK + 3 * (size_t)nzp);
-  dim3 g(nblk(p->n)), b(BLOCK);
-  PView v = view(p);
-  unsigned long long st = (unsigned long long)step;
-  int vadv = c->fuse_vadv;
-  c->fuse_vadv = -1;
-  if (vadv >= 0 && !p->env[VAR_W]) return fail(ODR_ERR_STATE, "upward_sea_water_velocity has not been sampled");
-  // fast column kernel: K from one gridded reader, plain z-innermost array on every resident level
-  int ksid = -1;
-  for (int k = 0; k < c->hw.nlist[VAR_KZ]; ++k)
-    if (c->hw.src[c->hw.list[VAR_KZ][k]].kind == SRC_GRID) { ksid = c->hw.list[VAR_KZ][k]; break; }
-  const bool oil = c->oil_owner == p;   // OpenOil: terminal velocities, slick and wave entrainment inside the loop
-  c->oil_owner = nullptr;
-  bool fast = ksid >= 0 && nzp > 1 && !oil && !getenv("ODR_NO_FAST_PATH");
-  VMixDesc D;
-  memset(&D, 0, sizeof D);
-  if (fast) {
-    const DevSource &s = c->hw.src[ksid];
-    fast = s.nlevels >= 1;
-    for (int k = 0; k < s.nlevels && fast; ++k) {
-      const DevBlock &bk = s.slot[s.level_slot[k]], &g0 = s.slot[s.level_slot[0]];
-      if (!bk.data[VAR_KZ] || bk.es[VAR_KZ] != 1 || bk.var_nz[VAR_KZ] != nzp || bk.rec != g0.rec || bk.ny != g0.ny || bk.nx != g0.nx ||
-          bk.x0 != g0.x0 || bk.xspan != g0.xspan || bk.y0 != g0.y0 || bk.yspan != g0.yspan)
-        fast = false;
-    }
-    if (fast) {
-      int ib, ia;
-      host_bracket(s, t, ib, ia);
-      D.sid = ksid; D.nzp = nzp; D.geo_slot = ib;
-      D.kb = s.slot[ib].data[VAR_KZ];
-      D.ka = ia >= 0 ? s.slot[ia].data[VAR_KZ] : nullptr;
-      D.wgt = ia >= 0 ? (t - s.slot[ib].t) / (s.slot[ia].t - s.slot[ib].t) : 0.0;
-      D.Kfb = c->hw.fallback[VAR_KZ];
-    }
-  }
-  if (fast) {
-    const int nq = (nzp + 3) / 4;
-    const bool tl = D.ka != nullptr;
-#define VMIX_COL(NQ)                                                                                              \
-  do {                                                                                                            \
-    size_t l2 = sizeof(double) * ((size_t)(4 * NQ) * BLOCK + 3 * (size_t)(4 * NQ));                               \
-    if (tl) hipLaunchKernelGGL((k_vmix_col<NQ, true>), g, b, l2, c->stream, c->dw, v, D, dt, dt_mix,              \
-                               mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);                                  \
-    else hipLaunchKernelGGL((k_vmix_col<NQ, false>), g, b, l2, c->stream, c->dw, v, D, dt, dt_mix,                \
-                            mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);                                     \
-  } while (0)
-    // the smallest instantiated quad count >= nq; over-read stays inside the 64-byte array padding
-    if (nq <= 1) VMIX_COL(1);
-    else if (nq == 2) VMIX_COL(2);
-    else if (nq == 3) VMIX_COL(3);
-    else if (nq == 4) VMIX_COL(4);
-    else if (nq <= 6) VMIX_COL(6);
-    else if (nq <= 8) VMIX_COL(8);
-    else if (nq <= 12) VMIX_COL(12);
-    else VMIX_COL(16);
-#undef VMIX_COL
-  } else if (oil) {
-    if (nzp <= 16) hipLaunchKernelGGL((k_vmix<16, true>), g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor, c->oil);
-    else if (nzp <= 32) hipLaunchKernelGGL((k_vmix<32, true>), g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor, c->oil);
-    else hipLaunchKernelGGL((k_vmix<1, true>), g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor, c->oil);
-  } else if (nzp <= 16) hipLaunchKernelGGL(k_vmix<16>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
-  else if (nzp <= 32) hipLaunchKernelGGL(k_vmix<32>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
-  else hipLaunchKernelGGL(k_vmix<1>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
-// vertical_mixing with an analytical diffusivity model (oceandrift.py:385-395,448-458): also what the default
-// 'environment' model does when no reader provides ocean_vertical_diffusivity (:431-447 -> Large et al. 1994)
-int odr_vmix_wind_profile(odr_ctx *c, odr_particles *p, int model, double background_diffusivity, double dt,
-                          double dt_mix, int mix_at_surface, int rng_mode, const double *huni, uint64_t step) {
-  p->epoch++;
-  REQUIRE(model == ODR_DIFFUSIVITY_LARGE1994 || model == ODR_DIFFUSIVITY_SUNDBY1983, "Unknown diffusivity model: %d", model);
-  REQUIRE(dt_mix > 0 && dt != 0, "bad time steps");
-  if (!p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
-  int rc;
-  for (int v : {VAR_SSH, VAR_XWIND, VAR_YWIND, VAR_MLD})
-    if ((rc = ensure_env(c, p, v))) return rc;
-  if ((rc = flush_world(c))) return rc;
-  if (p->n == 0) return 0;
-  p->epoch++;  // the reduction must see this step's mixed-layer depths
-  if ((rc = reduce(c, p, 0.0, 0, false))) return rc;
-  double *du = nullptr;
-  if (rng_mode == ODR_RNG_HOST) {
-    REQUIRE(huni, "host uniforms required in ODR_RNG_HOST mode");
-    int ntimes = abs((int)(dt / (dt_mix * (dt > 0 ? 1 : -1))));
-    void *s;
-    size_t n = (size_t)ntimes * (size_t)p->n;
-    if ((rc = scratch(c, p, sizeof(double) * n, &s))) return rc;
-    du = (double *)s;
-    HIPCHK(hipMemcpyAsync(du, huni, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-  }
-  int vadv = c->fuse_vadv;
-  c->fuse_vadv = -1;
-  if (vadv >= 0 && !p->env[VAR_W]) return fail(ODR_ERR_STATE, "upward_sea_water_velocity has not been sampled");
-  dim3 g(nblk(p->n)), b(BLOCK);
-  const bool oil = c->oil_owner == p;
-  c->oil_owner = nullptr;
-  if (oil && model == ODR_DIFFUSIVITY_LARGE1994)
-    hipLaunchKernelGGL((k_vmix_wind<DIFF_LARGE1994, true>), g, b, 0, c->stream, view(p), c->red, background_diffusivity, dt, dt_mix,
-                       mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv, c->seafloor, c->oil);
-  else if (oil)
-    hipLaunchKernelGGL((k_vmix_wind<DIFF_SUNDBY1983, true>), g, b, 0, c->stream, view(p), c->red, background_diffusivity, dt, dt_mix,
-                       mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv, c->seafloor, c->oil);
-  else if (model == ODR_DIFFUSIVITY_LARGE1994)
-    hipLaunchKernelGGL(k_vmix_wind<DIFF_LARGE1994>, g, b, 0, c->stream, view(p), c->red, background_diffusivity, dt, dt_mix,
-                       mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv, c->seafloor);
-  else
-    hipLaunchKernelGGL(k_vmix_wind<DIFF_SUNDBY1983>, g, b, 0, c->stream, view(p), c->red, background_diffusivity, dt, dt_mix,
-                       mix_at_surface, rng_mode, du, c->seed, (unsigned long long)step, vadv, c->seafloor);
-  HIPCHK(hipGetLastError());
-  p->epoch++;
-  return 0;
-}
-
-// OpenOil.prepare_vertical_mixing (models/openoil/openoil.py:1017-1031) on the device, and the switch that makes the
-// next odr_vmix / odr_vmix_wind_profile call on these particles run OpenOil's version of the loop: terminal velocity
-// of the droplets in every sub-step (:922-998), slick formation (:1056-1061), wave entrainment (:1033-1054).
-int odr_oil_prepare_mixing(odr_ctx *c, odr_particles *p, double dt, double dt_mix, double interfacial_tension,
-                           double sea_water_density, int droplet_distribution, int keep_droplet_diameter, int hs_mode,
-                           int tp_mode, int temperature_to_kelvin, int rng_mode, const double *host_u_diameter,
-                           const double *host_u_entrain, const double *host_u_intrusion, uint64_t step) {
-  c->oil_owner = nullptr;
-  REQUIRE(dt_mix > 0 && dt != 0, "bad time steps");
-  REQUIRE(droplet_distribution == ODR_DROPLETS_JOHANSEN2015 || droplet_distribution == ODR_DROPLETS_LI2017,
-          "no wave entrainment droplet size distribution specified");      // openoil.py:1070
-  REQUIRE(interfacial_tension > 0 && sea_water_density > 0, "bad oil / water constants");
-  REQUIRE(hs_mode >= 0 && hs_mode <= 2 && tp_mode >= 0 && tp_mode <= 3, "bad wave options");
-  for (int k : {OIL_DIAMETER, OIL_DENSITY, OIL_VISCOSITY, OIL_FILM})
-    if (!p->aux[k]) return fail(ODR_ERR_STATE, "oil property slot %d has not been set", k);
-  for (int v : {VAR_XWIND, VAR_YWIND, VAR_TEMP, VAR_SALT})
-    if (!p->env[v]) return fail(ODR_ERR_STATE, "wind, sea_water_temperature and sea_water_salinity must have been sampled");
-  if ((hs_mode == 0 && !p->env[VAR_HS]) || (tp_mode == 0 && !p->env[VAR_TP])) return fail(ODR_ERR_STATE, "Hs/Tp not sampled");
-  if (!p->aux[OIL_DIAMETER_IF_ENTRAINED]) {
-    HIPCHK(hipMalloc((void **)&p->aux[OIL_DIAMETER_IF_ENTRAINED], sizeof(float) * (size_t)p->cap));
-    HIPCHK(hipMemsetAsync(p->aux[OIL_DIAMETER_IF_ENTRAINED], 0, sizeof(float) * (size_t)p->cap, c->stream));
-  }
-  if (!c->oil_stat) {
-    HIPCHK(hipMalloc((void **)&c->oil_stat, sizeof(double) * OIL_STAT_N));
-    HIPCHK(hipMalloc((void **)&c->oil_cdf, sizeof(double) * OIL_NSPEC));
-    HIPCHK(hipMalloc((void **)&c->oil_chunk, sizeof(double) * OIL_SPEC_BLOCKS));
-    HIPCHK(hipMalloc((void **)&c->oil_guide, sizeof(int) * (OIL_GUIDE + 1)));
-  }
-  if (p->n == 0) return 0;
-  const int ntimes = abs((int)(dt / (dt_mix * (dt > 0 ? 1 : -1))));
-  REQUIRE(rng_mode == ODR_RNG_HOST || ntimes <= OIL_MAX_SUBSTEPS_DEVICE_RNG, "more than %d mixing sub-steps per step", OIL_MAX_SUBSTEPS_DEVICE_RNG);
-  const unsigned nb = nblk(p->n);
-  if (c->oil_part_n < 2 * (size_t)nb) {
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->oil_part) HIPCHK(hipFree(c->oil_part));
-    HIPCHK(hipMalloc((void **)&c->oil_part, sizeof(double) * 2 * (size_t)nb));
-    c->oil_part_n = 2 * (size_t)nb;
-  }
-  OilArgs &a = c->oil;
-  memset(&a, 0, sizeof a);
-  a.keep_diameter = keep_droplet_diameter ? 1 : 0;
-  a.hs_mode = hs_mode; a.tp_mode = tp_mode; a.to_kelvin = temperature_to_kelvin ? 1 : 0;
-  a.droplets = droplet_distribution; a.rng_mode = rng_mode;
-  a.sigma_ow = interfacial_tension; a.rho_w = sea_water_density; a.dt_mix_cfg = dt_mix;
-  a.stat = c->oil_stat;
-  const double *du_d = nullptr;
-  if (rng_mode == ODR_RNG_HOST) {
-    REQUIRE(host_u_diameter && host_u_entrain && host_u_intrusion, "host uniforms required in ODR_RNG_HOST mode");
-    const size_t per = (size_t)ntimes * (size_t)p->n, need = 2 * per + (size_t)p->n;
-    if (c->oil_u_n < need) {
-      HIPCHK(hipStreamSynchronize(c->stream));
-      if (c->oil_u) HIPCHK(hipFree(c->oil_u));
-      HIPCHK(hipMalloc((void **)&c->oil_u, sizeof(double) * need));
-      c->oil_u_n = need;
-    }
-    HIPCHK(hipMemcpyAsync(c->oil_u, host_u_entrain, sizeof(double) * per, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->oil_u + per, host_u_intrusion, sizeof(double) * per, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->oil_u + 2 * per, host_u_diameter, sizeof(double) * (size_t)p->n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));   // the host arrays are pageable and may change right after
-    a.u_ent = c->oil_u; a.u_int = c->oil_u + per; du_d = c->oil_u + 2 * per;
-  }
-  const PView v = view(p);
-  const dim3 g(nb), b(BLOCK);
-  hipLaunchKernelGGL(k_oil_stats, g, b, 0, c->stream, v, a, c->oil_part);
-  hipLaunchKernelGGL(k_oil_stats_final, dim3(1), b, 0, c->stream, c->oil_part, (int)nb, (long long)p->n, c->oil_stat);
-  hipLaunchKernelGGL(k_oil_spectrum_sums, dim3(OIL_SPEC_BLOCKS), b, 0, c->stream, c->oil_stat, c->oil_chunk);
-  hipLaunchKernelGGL(k_oil_spectrum_offsets, dim3(1), dim3(64), 0, c->stream, c->oil_chunk, c->oil_stat);
-  hipLaunchKernelGGL(k_oil_spectrum_scan, dim3(OIL_SPEC_BLOCKS), b, 0, c->stream, c->oil_stat, c->oil_chunk, c->oil_cdf);
-  hipLaunchKernelGGL(k_oil_guide, dim3((OIL_GUIDE + 1 + BLOCK - 1) / BLOCK), b, 0, c->stream, c->oil_cdf, c->oil_guide);
-  hipLaunchKernelGGL(k_oil_choice, g, b, 0, c->stream, v, c->oil_cdf, c->oil_guide, rng_mode, du_d, c->seed,
-                     (unsigned long long)step);
-  HIPCHK(hipGetLastError());
-  c->oil_owner = p;
-  return 0;
-}
-
-// mean intrusion depth scale np.mean(1.5 Hs) and the spectrum median dV_50 of the last odr_oil_prepare_mixing
-int odr_oil_mixing_stats(odr_ctx *c, double *mean_zb, double *dv50) {
-  if (!c->oil_stat) return fail(ODR_ERR_STATE, "odr_oil_prepare_mixing has not run");
-  double h[OIL_STAT_N];
-  HIPCHK(hipMemcpyAsync(h, c->oil_stat, sizeof h, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  if (mean_zb) *mean_zb = h[OIL_STAT_MEAN_ZB];
-  if (dv50) *dv50 = h[OIL_STAT_DV50];
-  return 0;
-}
-
 // odr_vmix followed by odr_vertical_advection in one kernel (same particle, same z): request
 // the fusion for the next odr_vmix call
 int odr_vmix_fuse_vertical_advection(odr_ctx *c, int at_surface) {
@@ -1707,7 +1140,7 @@ int odr_vertical_buoyancy(odr_ctx *c, odr_particles *p, double dt) {
   return 0;
 }
 
-static int read_counter(odr_ctx *c, int64_t *out) {
+int odr_i_read_counter(odr_ctx *c, int64_t *out) {
   if (out) {
     unsigned long long v;
     HIPCHK(hipMemcpyAsync(&v, c->counter, sizeof v, hipMemcpyDeviceToHost, c->stream));

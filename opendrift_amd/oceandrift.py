@@ -183,9 +183,15 @@ class OpenDriftSimulation(Configurable):
         more than readers:max_number_of_fails failures, discarded (Environment.get_environment, environment.py:640-668,
         discard_reader :376-389; tests/readers/test_readers.py:15-26): its variables fall to the next reader of the
         priority list or to the fallback value."""
+        rebind = False
         for name, b in list(self.readers.items()):
             try:
+                sid_before = b.sid
                 b.ensure_levels(t0, t1)
+                # a gridded reader gets its device source with its first block: a reader whose time coverage starts
+                # inside the run enters the priority lists when the run reaches it (the reference uses any reader
+                # that covers the current time, environment.py:597-668)
+                rebind |= sid_before is None and b.sid is not None
             except Exception as e:   # the reference catches every exception of a reader call
                 r = b.reader
                 r.number_of_fails = getattr(r, 'number_of_fails', 0) + 1
@@ -198,7 +204,9 @@ class OpenDriftSimulation(Configurable):
                         if name in lst:
                             lst.remove(name)
                     if b.sid is not None:      # it had delivered blocks before: take it out of the device lists
-                        self._bind_variables()
+                        rebind = True
+        if rebind:
+            self._bind_variables()
 
     # ------------------------------------------------------------------ seeding (:1033-1330)
     def seed_elements(self, lon, lat, time, radius=0, number=None, number_per_point=None,
@@ -361,6 +369,8 @@ class OpenDriftSimulation(Configurable):
             self.P.deactivate_outside(*dom, status_code=self._status_code('outside'))
 
     def deactivate_elements(self, mask, reason='deactivated'):   # :1774-1795
+        if not np.any(mask):     # "if sum(indices) == 0: return" -- no status category for an empty mask
+            return
         if reason not in self.status_categories:
             self.status_categories.append(reason)
         self.P.deactivate(mask, self.status_categories.index(reason))
@@ -504,8 +514,8 @@ class OpenDriftSimulation(Configurable):
             raise ValueError('Please seed elements before starting a run.')
         if outfile is not None:
             raise NotImplementedError('netCDF export is host-side I/O outside the hot path')
-        if sum(x is not None for x in (steps, duration, end_time)) != 1:
-            raise ValueError('Exactly one of the keywords steps, duration and end_time must be provided')
+        if sum(x is not None for x in (steps, duration, end_time)) > 1:
+            raise ValueError('Only one of "steps", "duration" and "end_time" may be provided simultaneously')
         if time_step is None:
             time_step = timedelta(minutes=self.get_config('general:time_step_minutes'))
         if not isinstance(time_step, timedelta):
@@ -514,16 +524,40 @@ class OpenDriftSimulation(Configurable):
         if time_step_output is None:
             m = self.get_config('general:time_step_output_minutes')
             time_step_output = time_step if m is None else timedelta(minutes=m)
-        if not isinstance(time_step_output, timedelta):
-            time_step_output = timedelta(seconds=time_step_output)
+        else:
+            if not isinstance(time_step_output, timedelta):
+                time_step_output = timedelta(seconds=time_step_output)
+            if time_step_output.days >= 0 and time_step.days < 0:
+                time_step_output = -time_step_output
+        ratio = time_step_output.total_seconds() / time_step.total_seconds()
+        if ratio < 1:
+            raise ValueError('Output time step must be equal or larger than calculation time step.')
+        if not float(ratio).is_integer():
+            raise ValueError('Ratio of calculation and output time steps must be an integer - given ratio is %s' % ratio)
         if time_step.total_seconds() < 0:
             self.start_time = self._sched['time'][int(np.argmax(self._sched['t_epoch']))]
-        if duration is not None:
-            steps = int(round(duration.total_seconds() / abs(time_step.total_seconds())))
-        elif end_time is not None:
-            steps = int(round(abs((end_time - self.start_time).total_seconds() / time_step.total_seconds())))
+        # simulation duration (:1960-2010): steps | duration | end_time | the end of the first reader; extended to a
+        # multiple of the output time step
+        if duration is None and end_time is None:
+            if steps is not None:
+                duration = steps * time_step
+            else:
+                ends = [r.end_time for r, _ in self._readers_host.values() if getattr(r, 'end_time', None) is not None]
+                if not ends:
+                    raise ValueError('Exactly one of the keywords steps, duration and end_time must be provided')
+                end_time = min(ends)
+        if duration is None:
+            duration = end_time - self.start_time
+        if time_step.days < 0 and duration.days >= 0:
+            duration = -duration
+        if np.sign(duration.total_seconds()) * np.sign(time_step.total_seconds()) < 0:
+            raise ValueError('Time step must be negative if duration is negative.')
+        ratio_duration_output = duration / time_step_output
+        if not float(ratio_duration_output).is_integer():
+            duration = np.ceil(ratio_duration_output) * time_step_output
+        steps = int(round(duration.total_seconds() / time_step.total_seconds()))
         self.expected_steps_calculation = steps
-        out_every = max(1, int(round(abs(time_step_output.total_seconds() / time_step.total_seconds()))))
+        out_every = max(1, int(round(ratio)))
         # skip_if conditionals of required_variables (:1899-1906)
         for vn, var in list(self.required_variables.items()):
             if 'skip_if' in var:
@@ -532,7 +566,7 @@ class OpenDriftSimulation(Configurable):
                     self.required_variables.pop(vn)
         self.time = self.start_time
         self._all_at_start = bool((self._sched['t_epoch'] == _epoch(self.start_time)).all())
-        self._finalize_environment(self.start_time, self.start_time + steps * time_step)
+        self._finalize_environment(self.start_time, self.start_time + time_step)
         n_total = self.num_elements_total()
         self.P = self.ctx.particles(n_total)
         self.mode = 'Run'

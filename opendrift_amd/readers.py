@@ -370,18 +370,28 @@ class DeviceReaderBinding:
         r = self.reader
         if not self.is_grid():
             return
-        lo, hi = (t0, t1) if t0 <= t1 else (t1, t0)
         if r.times is None:
             need = [0]
         else:
-            if not (r.covers_time(lo) or r.covers_time(hi)):
+            # The step samples the reader at t0 (main loop), t0 + dt/2 and t0 + dt (Runge-Kutta stages,
+            # physics_methods.py:638-670): the two levels bracketing EACH of these times must be resident -- not the
+            # whole range in between (a model time step may span many reader levels), and never a truncated range
+            # (a dropped 'before' level would make the device extrapolate in time).
+            times = [t for t in (t0, t0 + (t1 - t0) / 2, t1) if r.covers_time(t)]
+            if not times:
                 return
-            lo_c, hi_c = max(lo, r.start_time), min(hi, r.end_time)
-            need = list(range(r.nearest_time(lo_c)[0], r.nearest_time(hi_c)[1] + 1))
-        need = need[-(self.NSLOTS - 1):]
-        for k in list(self.slots):
-            if k not in need and len(self.slots) + len(self.staged) + len([n for n in need if n not in self.slots]) >= self.NSLOTS:
-                self.ctx.drop_block(self.sid, self.slots.pop(k))
+            need = sorted({k for t in times for k in r.nearest_time(t)})
+            if len(need) > self.NSLOTS:
+                raise ValueError('reader %s: one model time step needs %d time levels resident, at most %d fit'
+                                 % (r.name, len(need), self.NSLOTS))
+        # make room: first the resident levels the step does not need, then prefetched levels it does not need
+        missing = [k for k in need if k not in self.slots and k not in self.staged]
+        for pool in (self.slots, self.staged):
+            for k in list(pool):
+                if len(self.slots) + len(self.staged) + len(missing) <= self.NSLOTS:
+                    break
+                if k not in need:
+                    self.ctx.drop_block(self.sid, pool.pop(k))
         for k in need:
             if k in self.slots:
                 continue
