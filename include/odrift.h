@@ -186,9 +186,21 @@ int odr_env_sample(odr_ctx *ctx, odr_particles *p, int nvars, const int32_t *var
                    double t_epoch, float *const *out_host);
 int odr_env_download(odr_ctx *ctx, odr_particles *p, int32_t var_id, float *out_host);
 int odr_env_upload(odr_ctx *ctx, odr_particles *p, int32_t var_id, const float *host);
-/* drift:current_uncertainty / wind_uncertainty (environment.py:869-891): env[x]+=N(0,std), env[y]+=N(0,std) */
-int odr_env_add_noise(odr_ctx *ctx, odr_particles *p, int32_t var_x, int32_t var_y, double std,
+/* drift:current_uncertainty / wind_uncertainty (environment.py:869-879,887-891): env[x] += N(0,std), env[y] += N(0,std)
+ * (ODR_NOISE_NORMAL); drift:current_uncertainty_uniform (:880-886): env[x] += U(-std,std), env[y] += U(-std,std)
+ * (ODR_NOISE_UNIFORM).  ODR_RNG_HOST: host_nx / host_ny = the np.random draws (already scaled by std). */
+enum { ODR_NOISE_NORMAL = 0, ODR_NOISE_UNIFORM = 1 };
+int odr_env_add_noise(odr_ctx *ctx, odr_particles *p, int32_t var_x, int32_t var_y, double std, int distribution,
                       int rng_mode, const double *host_nx, const double *host_ny, uint64_t step);
+/* The same uncertainties INSIDE advect_ocean_current: the reference adds them in every get_environment call whose
+ * variables hold the current, i.e. also in the one (RK2) / three (RK4) stage calls (physics_methods.py:638-670 ->
+ * environment.py:869-886).  Arms the NEXT odr_advect / odr_env_coast_advect on `p` (call it right before).
+ * ODR_RNG_DEVICE: one Philox stream per (ID, step, call, distribution).  ODR_RNG_HOST: host_stage = the draws of the
+ * stage calls in np.random order, [nstage][ncomp][n] with ncomp = 2 (normal x, y | uniform x, y) or 4 (normal x, y,
+ * uniform x, y), n = active elements; host_main = [ncomp][n] draws of the main-loop sample for odr_env_coast_advect
+ * with odr_step_extras.main_noise (NULL otherwise). */
+int odr_advect_set_noise(odr_ctx *ctx, odr_particles *p, double std_normal, double std_uniform, int rng_mode,
+                         const double *host_main, const double *host_stage, int nstage, uint64_t step);
 /* PhysicsMethods.advect_ocean_current (physics_methods.py:611-691) + update_positions
  * (basemodel/__init__.py:4631-4657), all sub-stages fused in one kernel. */
 int odr_advect(odr_ctx *ctx, odr_particles *p, int scheme, double t_epoch, double dt, double factor);
@@ -209,7 +221,8 @@ typedef struct {              /* optional bookkeeping of the same loop body, bet
   int32_t missing_code;       /* report_missing_variables (:2501-2515), first in the loop's order: elements with a NaN in
                                * any sampled variable (no reader covers them and there is no fallback) get this status;
                                * 0: not part of this call */
-  int32_t pad;
+  int32_t main_noise;        /* 1: add the armed current uncertainty (odr_advect_set_noise) to the sampled current
+                              * right after the sample, like get_environment does (environment.py:869-886) */
 } odr_step_extras;
 int odr_env_coast_advect(odr_ctx *ctx, odr_particles *p, int nvars, const int32_t *var_ids, double t_epoch,
                          int coastline_action, int stranded_code, int seeded_on_land_code,

@@ -34,7 +34,7 @@ HIST_PROPERTY0 = 2000
 
 class StepExtras(C.Structure):   # odr_step_extras
     _fields_ = [('seafloor_action', C.c_int32), ('retired_code', C.c_int32), ('age_dt', C.c_double),
-                ('max_age_seconds', C.c_double), ('missing_code', C.c_int32), ('pad', C.c_int32)]
+                ('max_age_seconds', C.c_double), ('missing_code', C.c_int32), ('main_noise', C.c_int32)]
 ANALYTIC_DOUBLE_GYRE, ANALYTIC_OSCILLATING = 1, 2
 
 
@@ -85,7 +85,8 @@ _SIGNATURES = {
     'odr_env_sample': [_vp, _vp, C.c_int, _ip, C.c_double, _P(_fp)],
     'odr_env_download': [_vp, _vp, C.c_int32, _fp],
     'odr_env_upload': [_vp, _vp, C.c_int32, _fp],
-    'odr_env_add_noise': [_vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_int, _dp, _dp, C.c_uint64],
+    'odr_env_add_noise': [_vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_int, C.c_int, _dp, _dp, C.c_uint64],
+    'odr_advect_set_noise': [_vp, _vp, C.c_double, C.c_double, C.c_int, _dp, _dp, C.c_int, C.c_uint64],
     'odr_advect': [_vp, _vp, C.c_int, C.c_double, C.c_double, C.c_double],
     'odr_env_coast_advect': [_vp, _vp, C.c_int, _ip, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_double, C.c_double, _vp, _P(C.c_int64)],
@@ -162,6 +163,7 @@ def load():
     return lib
 
 
+NOISE_NORMAL, NOISE_UNIFORM = 0, 1
 DIFFUSIVITY = {'windspeed_Large1994': 1, 'windspeed_Sundby1983': 2}
 DROPLETS = {'Johansen et al. (2015)': 1, 'Li et al. (2017)': 2}
 OIL_PROPERTIES = ['diameter', 'density', 'viscosity', 'oil_film_thickness', 'diameter_if_entrained']

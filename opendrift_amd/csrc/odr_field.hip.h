@@ -558,6 +558,13 @@ __device__ __forceinline__ bool source_sample(const DevSource &s, const int (&va
   return true;
 }
 
+// "Some extra checks of units" at the end of get_environment (environment.py:829-838): a sea_water_temperature above
+// 100 is taken as Kelvin.  env is a masked float32 recarray there: the difference is formed in float64 and stored
+// as float32 (golden c12).
+__device__ __forceinline__ float kelvin_to_celsius(float T) {
+  return T > 100.f ? (float)__dsub_rn((double)T, 273.15) : T;
+}
+
 // Environment.get_environment for one particle and one variable group (variables that
 // share a priority list): walk the readers until every variable is finite
 // (environment.py:597-762), then the fallback (:782-791).  out = float32 environment.
@@ -581,8 +588,10 @@ __device__ __forceinline__ void env_group(const DevWorld &W, const int (&vars)[N
     if (!bad) break;
   }
 #pragma unroll
-  for (int v = 0; v < NV; ++v)
+  for (int v = 0; v < NV; ++v) {
     if (!isfinite(out[v]) && isfinite(W.fallback[vars[v]])) out[v] = W.fallback[vars[v]];
+    if (vars[v] == VAR_TEMP) out[v] = kelvin_to_celsius(out[v]);
+  }
 }
 
 
@@ -944,7 +953,8 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
   for (int k = 0; k < MAXG; ++k) {
     if (k >= G.nv) break;
     float f = covered ? (float)val[k] : __builtin_nanf("");
-    out[k] = isfinite(f) ? f : (isfinite(G.fallback[k]) ? G.fallback[k] : f);
+    f = isfinite(f) ? f : (isfinite(G.fallback[k]) ? G.fallback[k] : f);
+    out[k] = G.var[k] == VAR_TEMP ? kelvin_to_celsius(f) : f;
   }
 }
 

@@ -50,6 +50,11 @@ struct odr_ctx {
   std::vector<void *> source_bufs;  // device arrays owned by sources (curvilinear node tables)
   std::vector<void *> registered;   // host ranges page-locked by odr_host_register (released with the context)
   double *red;      // device reduction slots
+  // current uncertainty of the next odr_advect / odr_env_coast_advect on `noise_owner` (odr_advect_set_noise)
+  const odr_particles *noise_owner;
+  StageNoise noise;
+  double *noise_buf;
+  size_t noise_buf_n;
   // OpenOil mixing-loop physics (odr_oil_prepare_mixing): armed for the next odr_vmix* call on `oil_owner`
   const odr_particles *oil_owner;
   OilArgs oil;
@@ -159,6 +164,9 @@ int odr_i_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var
                      bool record_positions);
 int odr_i_reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind, bool wind_args_matter = true);
 int odr_i_read_counter(odr_ctx *c, int64_t *out);
+// k_env_noise with DEVICE arrays of draws (ODR_RNG_HOST) or none (ODR_RNG_DEVICE)
+int odr_i_env_noise(odr_ctx *c, odr_particles *p, int vx, int vy, double std, int distribution, int rng_mode,
+                    const double *dev_nx, const double *dev_ny, unsigned long long step);
 #define build_env_group odr_i_build_env_group
 #define uv_fast_source odr_i_uv_fast_source
 #define gyre_source odr_i_gyre_source

@@ -135,6 +135,57 @@ __device__ __forceinline__ void stage_pos(const GeodOrigin &o, float u, float v,
   geod_direct_sc(o, salp, calp, (double)dist, lat2, lon2);
 }
 
+// --------------------------------------------------------------- random numbers
+// Philox4x32-10 (rocRAND device API), counter = (particle ID, step, stream): results do
+// not depend on how particles are sharded over GPUs or ordered in memory.
+constexpr unsigned long long RNG_STEP_STRIDE = 8192;
+constexpr unsigned long long RNG_OFF_VMIX = 0, RNG_OFF_HDIFF = 4096, RNG_OFF_NOISE = 4352;
+
+__device__ __forceinline__ void rng_init(rocrand_state_philox4x32_10 &st, unsigned long long seed,
+                                         int id, unsigned long long step, unsigned long long off) {
+  rocrand_init(seed, (unsigned long long)(unsigned)id, step * RNG_STEP_STRIDE + off, &st);
+}
+
+// drift:current_uncertainty / drift:current_uncertainty_uniform of ONE Environment.get_environment call
+// (environment.py:869-886).  The reference adds them in every call whose variables hold the current: the main-loop
+// sample (call 0) and the one / three Runge-Kutta stage calls of advect_ocean_current (calls 1..3,
+// physics_methods.py:638-670).  env[var] += draws is a float32 array += float64 array: float32(float64(u) + draw), first
+// the normal pair, then the uniform pair.  ODR_RNG_HOST: the caller's np.random draws in the reference's call order
+// (main: [ncomp][n], stage: [nstage][ncomp][n]); ODR_RNG_DEVICE: one Philox stream per (ID, step, call, distribution).
+constexpr unsigned long long RNG_OFF_NOISE_UNIFORM = 64, RNG_OFF_NOISE_STAGE = 128;
+struct StageNoise {
+  int on, rng_mode, ncomp, pad;
+  double std_n, std_u;
+  const double *main, *stage;
+  unsigned long long seed, step;
+};
+__device__ __forceinline__ void add_f32_f64(float &u, float &v, double nx, double ny) {
+  u = (float)__dadd_rn((double)u, nx);
+  v = (float)__dadd_rn((double)v, ny);
+}
+__device__ __forceinline__ void add_current_noise(const StageNoise &N, int call, long long i, long long n, int id,
+                                                  float &u, float &v) {
+  if (N.rng_mode == 1) {
+    const double *a = call == 0 ? N.main : N.stage + (size_t)(call - 1) * (size_t)N.ncomp * (size_t)n;
+    int c = 0;
+    if (N.std_n > 0) { add_f32_f64(u, v, a[i], a[(size_t)n + i]); c = 2; }
+    if (N.std_u > 0) add_f32_f64(u, v, a[(size_t)c * (size_t)n + i], a[(size_t)(c + 1) * (size_t)n + i]);
+  } else {
+    const unsigned long long off = RNG_OFF_NOISE + (call == 0 ? 4ull * (unsigned)VAR_U : RNG_OFF_NOISE_STAGE + 8ull * (unsigned)call);
+    rocrand_state_philox4x32_10 st;
+    if (N.std_n > 0) {
+      rng_init(st, N.seed, id, N.step, off);
+      const double2 g = rocrand_normal_double2(&st);
+      add_f32_f64(u, v, g.x * N.std_n, g.y * N.std_n);
+    }
+    if (N.std_u > 0) {   // np.random.uniform(-std, std): low + (high - low) * u01
+      rng_init(st, N.seed, id, N.step, off + (call == 0 ? RNG_OFF_NOISE_UNIFORM : 4ull));
+      const double2 q = rocrand_uniform_double2(&st);
+      add_f32_f64(u, v, fma(2.0 * N.std_u, q.x, -N.std_u), fma(2.0 * N.std_u, q.y, -N.std_u));
+    }
+  }
+}
+
 #ifdef ODR_TU_MISC
 // ------------------------------------------------------------------ environment
 // Environment.get_environment for one variable group of NV variables
@@ -201,9 +252,9 @@ __device__ __forceinline__ float rk4_mix(float k1, float k2, float k3, float k4)
 }
 
 // generic version: any mix of readers behind the (u,v) priority list
-template <int SCHEME>
+template <int SCHEME, bool NOISE>
 __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W, PView p, double t,
-                                                  double dt, float factor) {
+                                                  double dt, float factor, StageNoise N) {
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= p.n) return;
   const int uv[2] = {VAR_U, VAR_V};
@@ -222,6 +273,8 @@ __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W
     float k2[2];
     stage_pos(o, u1, v1, dtf, lon2, lat2);
     env_group<2>(*W, uv, lon2, lat2, z, t + dt / 2, k2);
+    const int id = NOISE ? p.id[i] : 0;
+    if (NOISE) add_current_noise(N, 1, i, p.n, id, k2[0], k2[1]);
     if (SCHEME == 1) {
       fu = __fmul_rn(f, k2[0]);
       fv = __fmul_rn(f, k2[1]);
@@ -229,8 +282,10 @@ __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W
       float k3[2], k4[2];
       stage_pos(o, k2[0], k2[1], dtf, lon2, lat2);
       env_group<2>(*W, uv, lon2, lat2, z, t + dt / 2, k3);
+      if (NOISE) add_current_noise(N, 2, i, p.n, id, k3[0], k3[1]);
       stage_pos(o, k3[0], k3[1], dtf, lon2, lat2);  // dt*.5 again: reference quirk (:662)
       env_group<2>(*W, uv, lon2, lat2, z, t + dt, k4);
+      if (NOISE) add_current_noise(N, 3, i, p.n, id, k4[0], k4[1]);
       fu = __fmul_rn(rk4_mix(u1, k2[0], k3[0], k4[0]), f);
       fv = __fmul_rn(rk4_mix(v1, k2[1], k3[1], k4[1]), f);
     }
@@ -242,10 +297,11 @@ __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W
 
 // fast version: (u,v) from one gridded reader, interleaved z-innermost blocks, host-resolved
 // time brackets (odr_field.hip.h "fast (u,v) path")
-template <int SCHEME, int PROJ, bool IS3D>
+template <int SCHEME, int PROJ, bool IS3D, bool NOISE>
 __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBlock &geo, double &lon, double &lat,
                                                  double z, float u1, float v1, float f, int moving, double dt,
-                                                 const UVTime &th, const UVTime &tf, float fbu, float fbv) {
+                                                 const UVTime &th, const UVTime &tf, float fbu, float fbv,
+                                                 const StageNoise &N, long long i, long long n, int id) {
   float fu, fv;
   GeodOrigin o = geod_origin(lat, lon);
   if (SCHEME == 0) {
@@ -260,6 +316,7 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
     float u2, v2;
     stage_pos(o, u1, v1, dtf, lon2, lat2);
     uv_sample_fast<PROJ, IS3D>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u2, v2);
+    if (NOISE) add_current_noise(N, 1, i, n, id, u2, v2);
     if (SCHEME == 1) {
       fu = __fmul_rn(f, u2);
       fv = __fmul_rn(f, v2);
@@ -267,8 +324,10 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
       float u3, v3, u4, v4;
       stage_pos(o, u2, v2, dtf, lon2, lat2);
       uv_sample_fast<PROJ, IS3D>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u3, v3);
+      if (NOISE) add_current_noise(N, 2, i, n, id, u3, v3);
       stage_pos(o, u3, v3, dtf, lon2, lat2);
       uv_sample_fast<PROJ, IS3D>(s, geo, tf, lon2, lat2, z, zb, fbu, fbv, u4, v4);
+      if (NOISE) add_current_noise(N, 3, i, n, id, u4, v4);
       fu = __fmul_rn(rk4_mix(u1, u2, u3, u4), f);
       fv = __fmul_rn(rk4_mix(v1, v2, v3, v4), f);
     }
@@ -276,18 +335,18 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
   move_f32_from(o, lon, lat, fu, fv, moving, dt);
 }
 
-template <int SCHEME, int PROJ, bool IS3D>
+template <int SCHEME, int PROJ, bool IS3D, bool NOISE>
 __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_advect_grid(const DevWorld *__restrict__ W, int sid, int geo_slot,
                                                        PView p, double dt, float factor, UVTime th,
-                                                       UVTime tf) {
+                                                       UVTime tf, StageNoise N) {
   long long i = pid();
   if (i >= p.n) return;
   const DevSource &s = W->src[sid];
   const DevBlock &geo = s.slot[geo_slot];
   double lon = p.lon[i], lat = p.lat[i];
-  advect_grid_body<SCHEME, PROJ, IS3D>(s, geo, lon, lat, p.z[i], p.env[VAR_U][i], p.env[VAR_V][i],
-                                       __fmul_rn(factor, p.cdf[i]), p.moving[i], dt, th, tf, W->fallback[VAR_U],
-                                       W->fallback[VAR_V]);
+  advect_grid_body<SCHEME, PROJ, IS3D, NOISE>(s, geo, lon, lat, p.z[i], p.env[VAR_U][i], p.env[VAR_V][i],
+                                              __fmul_rn(factor, p.cdf[i]), p.moving[i], dt, th, tf, W->fallback[VAR_U],
+                                              W->fallback[VAR_V], N, i, p.n, NOISE ? p.id[i] : 0);
   p.lon[i] = lon;
   p.lat[i] = lat;
 }
@@ -307,12 +366,13 @@ struct StepDesc {
   int retired_code, missing_code;   // report_missing_variables: NaN in a sampled variable whose fallback is None
   int nmiss_grp, nmiss_rest;
   int miss_grp[4], miss_rest[4];    // group slots / variable ids (sampled by the preceding launch) to test for NaN
+  int main_noise, pad;              // uncertainty of the main-loop sample of the current (StageNoise call 0)
 };
 
-template <int SCHEME, int PROJ, bool IS3D>
+template <int SCHEME, int PROJ, bool IS3D, bool NOISE>
 __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
                                                      StepDesc S, double dt, float factor, UVTime th, UVTime tf,
-                                                     unsigned long long *n_hit) {
+                                                     unsigned long long *n_hit, StageNoise N) {
   long long i = pid();
   bool hit = false;
   if (i < p.n) {
@@ -320,6 +380,8 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevW
     const double z = p.z[i];
     float out[MAXG];
     env_group_fast<PROJ>(*W, G, lon, lat, z, out);
+    const int id = NOISE ? p.id[i] : 0;
+    if (NOISE && S.main_noise) add_current_noise(N, 0, i, p.n, id, out[0], out[1]);
 #pragma unroll
     for (int k = 0; k < MAXG; ++k)
       if (k < G.nv) p.env[G.var[k]][i] = out[k];
@@ -356,6 +418,7 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevW
           }
           lon = p.plon[i];
           lat = p.plat[i];
+          p.env[VAR_LAND][i] = 0.0f;   // self.environment.land_binary_mask[on_land] = 0 (:746)
         }
       }
     }
@@ -377,9 +440,9 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevW
     if (S.store_previous) { p.plon[i] = lon; p.plat[i] = lat; }
     if (!skip) {
       const DevSource &s = W->src[G.sid];
-      advect_grid_body<SCHEME, PROJ, IS3D>(s, s.slot[S.geo_slot_uv], lon, lat, zz, out[0], out[1],
-                                           __fmul_rn(factor, p.cdf[i]), moving, dt, th, tf, W->fallback[VAR_U],
-                                           W->fallback[VAR_V]);
+      advect_grid_body<SCHEME, PROJ, IS3D, NOISE>(s, s.slot[S.geo_slot_uv], lon, lat, zz, out[0], out[1],
+                                                  __fmul_rn(factor, p.cdf[i]), moving, dt, th, tf, W->fallback[VAR_U],
+                                                  W->fallback[VAR_V], N, i, p.n, id);
     }
     p.lon[i] = lon;
     p.lat[i] = lat;
@@ -410,9 +473,9 @@ __global__ __launch_bounds__(BLOCK) void k_env_gyre(const DevWorld *__restrict__
 
 #endif  // ODR_TU_MISC
 #ifdef ODR_TU_STEP
-template <int SCHEME>
+template <int SCHEME, bool NOISE>
 __global__ __launch_bounds__(BLOCK) void k_advect_gyre(const DevWorld *__restrict__ W, int sid, PView p, double dt,
-                                                       float factor, double snw_half, double snw_full) {
+                                                       float factor, double snw_half, double snw_full, StageNoise N) {
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= p.n) return;
   const DevSource &s = W->src[sid];
@@ -432,6 +495,8 @@ __global__ __launch_bounds__(BLOCK) void k_advect_gyre(const DevWorld *__restric
     float u2, v2;
     stage_pos(o, u1, v1, dtf, lon2, lat2);
     gyre_sample(s, lon2, lat2, z, snw_half, fbu, fbv, u2, v2);
+    const int id = NOISE ? p.id[i] : 0;
+    if (NOISE) add_current_noise(N, 1, i, p.n, id, u2, v2);
     if (SCHEME == 1) {
       fu = __fmul_rn(f, u2);
       fv = __fmul_rn(f, v2);
@@ -439,8 +504,10 @@ __global__ __launch_bounds__(BLOCK) void k_advect_gyre(const DevWorld *__restric
       float u3, v3, u4, v4;
       stage_pos(o, u2, v2, dtf, lon2, lat2);
       gyre_sample(s, lon2, lat2, z, snw_half, fbu, fbv, u3, v3);
+      if (NOISE) add_current_noise(N, 2, i, p.n, id, u3, v3);
       stage_pos(o, u3, v3, dtf, lon2, lat2);
       gyre_sample(s, lon2, lat2, z, snw_full, fbu, fbv, u4, v4);
+      if (NOISE) add_current_noise(N, 3, i, p.n, id, u4, v4);
       fu = __fmul_rn(rk4_mix(u1, u2, u3, u4), f);
       fv = __fmul_rn(rk4_mix(v1, v2, v3, v4), f);
     }
@@ -652,17 +719,6 @@ __global__ __launch_bounds__(BLOCK) void k_stokes(PView p, double dt, int profil
 }
 
 #endif  // ODR_TU_MISC
-// --------------------------------------------------------------- random numbers
-// Philox4x32-10 (rocRAND device API), counter = (particle ID, step, stream): results do
-// not depend on how particles are sharded over GPUs or ordered in memory.
-constexpr unsigned long long RNG_STEP_STRIDE = 8192;
-constexpr unsigned long long RNG_OFF_VMIX = 0, RNG_OFF_HDIFF = 4096, RNG_OFF_NOISE = 4352;
-
-__device__ __forceinline__ void rng_init(rocrand_state_philox4x32_10 &st, unsigned long long seed,
-                                         int id, unsigned long long step, unsigned long long off) {
-  rocrand_init(seed, (unsigned long long)(unsigned)id, step * RNG_STEP_STRIDE + off, &st);
-}
-
 #ifdef ODR_TU_MISC
 // horizontal_diffusion (basemodel/__init__.py:1746-1772)
 __global__ __launch_bounds__(BLOCK) void k_hdiff(PView p, double dt, int rng_mode,
@@ -692,19 +748,24 @@ __global__ __launch_bounds__(BLOCK) void k_hdiff(PView p, double dt, int rng_mod
 }
 
 // drift:current_uncertainty / wind_uncertainty (environment.py:869-891)
-__global__ __launch_bounds__(BLOCK) void k_env_noise(PView p, int vx, int vy, double std, int rng_mode,
+__global__ __launch_bounds__(BLOCK) void k_env_noise(PView p, int vx, int vy, double std, int dist, int rng_mode,
                                                      const double *__restrict__ hnx,
                                                      const double *__restrict__ hny,
                                                      unsigned long long seed, unsigned long long step) {
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= p.n) return;
   double nx, ny;
-  if (rng_mode == 1) { nx = hnx[i]; ny = hny[i]; }  // np.random.normal(0, std, N) already scaled
-  else {
+  if (rng_mode == 1) { nx = hnx[i]; ny = hny[i]; }  // np.random.normal(0, std, N) / uniform(-std, std, N): already scaled
+  else if (dist == 0) {
     rocrand_state_philox4x32_10 st;
     rng_init(st, seed, p.id[i], step, RNG_OFF_NOISE + 4ull * (unsigned)vx);
     double2 g = rocrand_normal_double2(&st);
     nx = g.x * std; ny = g.y * std;
+  } else {   // drift:current_uncertainty_uniform (environment.py:880-886)
+    rocrand_state_philox4x32_10 st;
+    rng_init(st, seed, p.id[i], step, RNG_OFF_NOISE + RNG_OFF_NOISE_UNIFORM + 4ull * (unsigned)vx);
+    const double2 q = rocrand_uniform_double2(&st);
+    nx = fma(2.0 * std, q.x, -std); ny = fma(2.0 * std, q.y, -std);
   }
   // float32 array += float64 array: computed in float64, cast back to float32
   p.env[vx][i] = (float)__dadd_rn((double)p.env[vx][i], nx);
@@ -1264,6 +1325,7 @@ __global__ __launch_bounds__(BLOCK) void k_coast(PView p, int action, int code, 
       }
       p.lon[i] = p.plon[i];
       p.lat[i] = p.plat[i];
+      p.env[VAR_LAND][i] = 0.0f;   // self.environment.land_binary_mask[on_land] = 0 (:746)
     }
   }
   unsigned long long b = __ballot(hit);

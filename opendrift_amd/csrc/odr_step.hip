@@ -1,83 +1,87 @@
 // libodrift_hip.so, translation unit 2: advect_ocean_current (Euler / RK2 / RK4) and the fused step
 // (get_environment + coastline + previous state + advection in one launch).  See odrift.hip for the rest.
 #define ODR_TU_STEP 1
-#include "odr_host.h"
+#include "odr_step_launch.h"
 
-template <int SCHEME>
-static void launch_advect_grid(odr_ctx *c, odr_particles *p, int sid, double t, double dt, double factor) {
-  const DevSource &s = c->hw.src[sid];
-  UVTime th = uv_time(s, t + dt / 2), tf = uv_time(s, t + dt);
-  int geo = s.level_slot[0];
-  bool is3d = s.slot[geo].var_nz[VAR_U] > 1;
-  dim3 g(nblk(p->n)), b(BLOCK);
-  PView v = view(p);
-  float f = (float)factor;
-#define ODR_LAUNCH(PROJ, D3) hipLaunchKernelGGL((k_advect_grid<SCHEME, PROJ, D3>), g, b, 0, c->stream, c->dw, sid, geo, v, dt, f, th, tf)
-  switch (s.proj.kind) {
-    case PROJ_LATLONG: if (is3d) ODR_LAUNCH(PROJ_LATLONG, true); else ODR_LAUNCH(PROJ_LATLONG, false); break;
-    case PROJ_STERE_POLAR: if (is3d) ODR_LAUNCH(PROJ_STERE_POLAR, true); else ODR_LAUNCH(PROJ_STERE_POLAR, false); break;
-    case PROJ_CURVILINEAR: if (is3d) ODR_LAUNCH(PROJ_CURVILINEAR, true); else ODR_LAUNCH(PROJ_CURVILINEAR, false); break;
-    default: if (is3d) ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, true); else ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, false); break;
+// drift:current_uncertainty / drift:current_uncertainty_uniform are part of every get_environment call that holds the
+// current (environment.py:869-886) -- also of the Runge-Kutta stage calls inside advect_ocean_current
+// (physics_methods.py:638-670).  odr_advect_set_noise arms them for the NEXT odr_advect / odr_env_coast_advect on `p`
+// (call it right before: host arrays are indexed by the element order of that moment).
+int odr_advect_set_noise(odr_ctx *c, odr_particles *p, double std_normal, double std_uniform, int rng_mode,
+                         const double *host_main, const double *host_stage, int nstage, uint64_t step) {
+  c->noise_owner = nullptr;
+  REQUIRE(std_normal >= 0 && std_uniform >= 0, "uncertainties must not be negative");
+  REQUIRE(rng_mode == ODR_RNG_DEVICE || rng_mode == ODR_RNG_HOST, "bad rng mode");
+  if (!(std_normal > 0) && !(std_uniform > 0)) return 0;
+  StageNoise &N = c->noise;
+  memset(&N, 0, sizeof N);
+  N.on = 1; N.rng_mode = rng_mode; N.std_n = std_normal; N.std_u = std_uniform;
+  N.ncomp = 2 * ((std_normal > 0) + (std_uniform > 0));
+  N.seed = c->seed; N.step = (unsigned long long)step;
+  if (rng_mode == ODR_RNG_HOST && p->n > 0) {
+    REQUIRE(nstage >= 0 && nstage <= 3 && (nstage == 0 || host_stage), "host draws of the stage calls required in ODR_RNG_HOST mode");
+    const size_t per = (size_t)N.ncomp * (size_t)p->n, need = per * (size_t)(nstage + (host_main ? 1 : 0));
+    if (c->noise_buf_n < need) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (c->noise_buf) HIPCHK(hipFree(c->noise_buf));
+      HIPCHK(hipMalloc((void **)&c->noise_buf, sizeof(double) * need));
+      c->noise_buf_n = need;
+    }
+    double *d = c->noise_buf;
+    if (host_main) {
+      HIPCHK(hipMemcpyAsync(d, host_main, sizeof(double) * per, hipMemcpyHostToDevice, c->stream));
+      N.main = d;
+      d += per;
+    }
+    if (nstage) {
+      HIPCHK(hipMemcpyAsync(d, host_stage, sizeof(double) * per * (size_t)nstage, hipMemcpyHostToDevice, c->stream));
+      N.stage = d;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));   // the host arrays are pageable and may change right after
   }
-#undef ODR_LAUNCH
+  c->noise_owner = p;
+  return 0;
 }
 
-int odr_advect(odr_ctx *c, odr_particles *p, int scheme, double t, double dt, double factor) {
+// the armed uncertainty of `p`, disarmed
+static StageNoise take_noise(odr_ctx *c, const odr_particles *p) {
+  StageNoise N;
+  memset(&N, 0, sizeof N);
+  if (c->noise_owner == p) N = c->noise;
+  c->noise_owner = nullptr;
+  return N;
+}
+
+static int advect_impl(odr_ctx *c, odr_particles *p, int scheme, double t, double dt, double factor, const StageNoise &N) {
   REQUIRE(scheme >= 0 && scheme <= 2, "Drift scheme not recognised: %d", scheme);
   if (!p->env[VAR_U] || !p->env[VAR_V]) return fail(ODR_ERR_STATE, "odr_env_sample of the current must precede odr_advect");
   HIPCHK(hipSetDevice(c->device));
   int rc = flush_world(c);
   if (rc) return rc;
   if (p->n == 0) return 0;
-  dim3 g(nblk(p->n)), b(BLOCK);
-  PView v = view(p);
-  int sid = -1, gsid = -1;
-  if (scheme == 0) hipLaunchKernelGGL(k_advect<0>, g, b, 0, c->stream, c->dw, v, t, dt, (float)factor);
-  else if (!getenv("ODR_NO_FAST_PATH") && gyre_source(c, VAR_U, gsid) && c->hw.nlist[VAR_V] == 1 &&
-           c->hw.list[VAR_V][0] == gsid &&
-           (c->hw.src[gsid].always_valid || (fmin(t, t + dt) >= c->hw.src[gsid].tmin && fmax(t, t + dt) <= c->hw.src[gsid].tmax))) {
-    const DevSource &gs = c->hw.src[gsid];
-    const double sh = sin(gs.params[2] * (t + dt / 2 - gs.params[3])), sf = sin(gs.params[2] * (t + dt - gs.params[3]));
-    if (scheme == 1) hipLaunchKernelGGL(k_advect_gyre<1>, g, b, 0, c->stream, c->dw, gsid, v, dt, (float)factor, sh, sf);
-    else hipLaunchKernelGGL(k_advect_gyre<2>, g, b, 0, c->stream, c->dw, gsid, v, dt, (float)factor, sh, sf);
-  }
-  else if (uv_fast_source(c, sid, t < t + dt ? t : t + dt, t < t + dt ? t + dt : t) && !getenv("ODR_NO_FAST_PATH")) {
-    if (scheme == 1) launch_advect_grid<1>(c, p, sid, t, dt, factor);
-    else launch_advect_grid<2>(c, p, sid, t, dt, factor);
-  } else if (scheme == 1) hipLaunchKernelGGL(k_advect<1>, g, b, 0, c->stream, c->dw, v, t, dt, (float)factor);
-  else hipLaunchKernelGGL(k_advect<2>, g, b, 0, c->stream, c->dw, v, t, dt, (float)factor);
+  if (N.on && scheme > 0) {
+    if (N.rng_mode == ODR_RNG_HOST && !N.stage) return fail(ODR_ERR_INVALID, "no host draws for the Runge-Kutta stage calls");
+    odr_i_advect_noise(c, p, scheme, t, dt, factor, N);
+  } else advect_dispatch<false>(c, p, scheme, t, dt, factor, N);
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+int odr_advect(odr_ctx *c, odr_particles *p, int scheme, double t, double dt, double factor) {
+  const StageNoise N = take_noise(c, p);
+  return advect_impl(c, p, scheme, t, dt, factor, N);
 }
 
 // get_environment -> interact_with_coastline -> update_previous_state -> advect_ocean_current in
 // one launch (k_step_grid) when the current comes from one gridded reader; otherwise exactly the
 // four separate entry points, in that order.  Results are bit-identical either way
 // (tests/test_gpu_parity.py::test_fused_step_equals_separate_calls).
-template <int SCHEME>
-static void launch_step_grid(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, StepDesc S, double t, double dt,
-                             double factor) {
-  const DevSource &s = c->hw.src[G.sid];
-  UVTime th = uv_time(s, t + dt / 2), tf = uv_time(s, t + dt);
-  S.geo_slot_uv = s.level_slot[0];
-  bool is3d = s.slot[S.geo_slot_uv].var_nz[VAR_U] > 1;
-  dim3 g(nblk(p->n)), b(BLOCK);
-  PView v = view(p);
-  float f = (float)factor;
-#define ODR_LAUNCH(PROJ, D3) hipLaunchKernelGGL((k_step_grid<SCHEME, PROJ, D3>), g, b, 0, c->stream, c->dw, v, G, S, dt, f, th, tf, c->counter)
-  switch (s.proj.kind) {
-    case PROJ_LATLONG: if (is3d) ODR_LAUNCH(PROJ_LATLONG, true); else ODR_LAUNCH(PROJ_LATLONG, false); break;
-    case PROJ_STERE_POLAR: if (is3d) ODR_LAUNCH(PROJ_STERE_POLAR, true); else ODR_LAUNCH(PROJ_STERE_POLAR, false); break;
-    case PROJ_CURVILINEAR: if (is3d) ODR_LAUNCH(PROJ_CURVILINEAR, true); else ODR_LAUNCH(PROJ_CURVILINEAR, false); break;
-    default: if (is3d) ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, true); else ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, false); break;
-  }
-#undef ODR_LAUNCH
-}
-
 int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t,
                          int coast_action, int stranded_code, int seeded_on_land_code, int store_previous,
                          int scheme, double dt, double factor, const odr_step_extras *extras, int64_t *n_on_land) {
   p->epoch++;  // invalidates the cached reductions (reduce())
+  const StageNoise N = take_noise(c, p);
+  const bool main_noise = N.on && extras && extras->main_noise;
   REQUIRE(nvars > 0 && nvars <= NVAR && var_ids, "bad variable list");
   REQUIRE(scheme >= 0 && scheme <= 2, "Drift scheme not recognised: %d", scheme);
   REQUIRE(coast_action >= 0 && coast_action <= 2, "bad coastline action");
@@ -130,8 +134,17 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   bool fuse = p->n > 0 && !getenv("ODR_NO_FAST_PATH") && same_list(VAR_V, VAR_U) && ng <= MAXG && nmg <= 4 && nmr <= 4 &&
               uv_fast_source(c, sid, t < t + dt ? t : t + dt, t < t + dt ? t + dt : t) &&
               build_env_group(c, grp, ng, t, G) && G.sid == sid;
+  if (main_noise && N.rng_mode == ODR_RNG_HOST && !N.main) return fail(ODR_ERR_INVALID, "no host draws for the main sample");
   if (!fuse) {
     if ((rc = odr_env_sample(c, p, nvars, var_ids, t, nullptr))) return rc;
+    if (main_noise) {   // environment.py:869-886 of the main-loop call: normal pair, then uniform pair
+      const size_t n = (size_t)p->n;
+      if (N.std_n > 0 && (rc = odr_i_env_noise(c, p, VAR_U, VAR_V, N.std_n, ODR_NOISE_NORMAL, N.rng_mode, N.main, N.main ? N.main + n : nullptr, N.step)))
+        return rc;
+      const double *um = N.main ? N.main + (N.std_n > 0 ? 2 * n : 0) : nullptr;
+      if (N.std_u > 0 && (rc = odr_i_env_noise(c, p, VAR_U, VAR_V, N.std_u, ODR_NOISE_UNIFORM, N.rng_mode, um, um ? um + n : nullptr, N.step)))
+        return rc;
+    }
     if (extras && extras->missing_code && (rc = odr_deactivate_missing(c, p, nvars, var_ids, extras->missing_code, nullptr)))
       return rc;
     if ((rc = odr_coastline(c, p, coast_action, stranded_code, seeded_on_land_code, n_on_land))) return rc;
@@ -140,7 +153,7 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
         (rc = odr_increase_age(c, p, extras->age_dt, extras->max_age_seconds, extras->retired_code)))
       return rc;
     if (store_previous && (rc = odr_store_previous(c, p))) return rc;
-    return odr_advect(c, p, scheme, t, dt, factor);
+    return advect_impl(c, p, scheme, t, dt, factor, N);
   }
   for (int k = 0; k < ng; ++k) if ((rc = ensure_env(c, p, grp[k]))) return rc;
   if (nrest && (rc = env_sample_impl(c, p, nrest, rest, t, nullptr, false))) return rc;  // k_step_grid records the positions
@@ -160,9 +173,11 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   for (int k = 0; k < nmr && k < 4; ++k) S.miss_rest[k] = miss_rest[k];
   if (want_floor && (rc = ensure_env(c, p, VAR_SSH))) return rc;
   if (coast_action) HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
-  if (scheme == 0) launch_step_grid<0>(c, p, G, S, t, dt, factor);
-  else if (scheme == 1) launch_step_grid<1>(c, p, G, S, t, dt, factor);
-  else launch_step_grid<2>(c, p, G, S, t, dt, factor);
+  S.main_noise = main_noise ? 1 : 0;
+  if (N.on && (scheme > 0 || main_noise)) {
+    if (scheme > 0 && N.rng_mode == ODR_RNG_HOST && !N.stage) return fail(ODR_ERR_INVALID, "no host draws for the Runge-Kutta stage calls");
+    odr_i_step_noise(c, p, G, S, scheme, t, dt, factor, N);
+  } else step_dispatch<false>(c, p, G, S, scheme, t, dt, factor, N);
   HIPCHK(hipGetLastError());
   return coast_action ? read_counter(c, n_on_land) : 0;
 }

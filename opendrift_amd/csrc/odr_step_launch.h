@@ -1,0 +1,83 @@
+// Launchers of the current-advection kernels, templated on NOISE (drift:current_uncertainty inside the Runge-Kutta
+// stage calls).  Included by odr_step.hip (NOISE = false) and odr_step_noise.hip (NOISE = true): the two sets of
+// instantiations are separate translation units so that they compile in parallel.
+#pragma once
+#include "odr_host.h"
+
+template <int SCHEME, bool NOISE>
+static void launch_advect_grid(odr_ctx *c, odr_particles *p, int sid, double t, double dt, double factor, const StageNoise &N) {
+  const DevSource &s = c->hw.src[sid];
+  UVTime th = uv_time(s, t + dt / 2), tf = uv_time(s, t + dt);
+  int geo = s.level_slot[0];
+  bool is3d = s.slot[geo].var_nz[VAR_U] > 1;
+  dim3 g(nblk(p->n)), b(BLOCK);
+  PView v = view(p);
+  float f = (float)factor;
+#define ODR_LAUNCH(PROJ, D3) hipLaunchKernelGGL((k_advect_grid<SCHEME, PROJ, D3, NOISE>), g, b, 0, c->stream, c->dw, sid, geo, v, dt, f, th, tf, N)
+  switch (s.proj.kind) {
+    case PROJ_LATLONG: if (is3d) ODR_LAUNCH(PROJ_LATLONG, true); else ODR_LAUNCH(PROJ_LATLONG, false); break;
+    case PROJ_STERE_POLAR: if (is3d) ODR_LAUNCH(PROJ_STERE_POLAR, true); else ODR_LAUNCH(PROJ_STERE_POLAR, false); break;
+    case PROJ_CURVILINEAR: if (is3d) ODR_LAUNCH(PROJ_CURVILINEAR, true); else ODR_LAUNCH(PROJ_CURVILINEAR, false); break;
+    default: if (is3d) ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, true); else ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, false); break;
+  }
+#undef ODR_LAUNCH
+}
+
+// the kernel choice of odr_advect: Euler | analytic double gyre | one gridded reader | any reader mix
+template <bool NOISE>
+static void advect_dispatch(odr_ctx *c, odr_particles *p, int scheme, double t, double dt, double factor, const StageNoise &N) {
+  dim3 g(nblk(p->n)), b(BLOCK);
+  PView v = view(p);
+  int sid = -1, gsid = -1;
+  if (scheme == 0) hipLaunchKernelGGL((k_advect<0, false>), g, b, 0, c->stream, c->dw, v, t, dt, (float)factor, N);
+  else if (!getenv("ODR_NO_FAST_PATH") && gyre_source(c, VAR_U, gsid) && c->hw.nlist[VAR_V] == 1 &&
+           c->hw.list[VAR_V][0] == gsid &&
+           (c->hw.src[gsid].always_valid || (fmin(t, t + dt) >= c->hw.src[gsid].tmin && fmax(t, t + dt) <= c->hw.src[gsid].tmax))) {
+    const DevSource &gs = c->hw.src[gsid];
+    const double sh = sin(gs.params[2] * (t + dt / 2 - gs.params[3])), sf = sin(gs.params[2] * (t + dt - gs.params[3]));
+    if (scheme == 1) hipLaunchKernelGGL((k_advect_gyre<1, NOISE>), g, b, 0, c->stream, c->dw, gsid, v, dt, (float)factor, sh, sf, N);
+    else hipLaunchKernelGGL((k_advect_gyre<2, NOISE>), g, b, 0, c->stream, c->dw, gsid, v, dt, (float)factor, sh, sf, N);
+  }
+  else if (uv_fast_source(c, sid, t < t + dt ? t : t + dt, t < t + dt ? t + dt : t) && !getenv("ODR_NO_FAST_PATH")) {
+    if (scheme == 1) launch_advect_grid<1, NOISE>(c, p, sid, t, dt, factor, N);
+    else launch_advect_grid<2, NOISE>(c, p, sid, t, dt, factor, N);
+  } else if (scheme == 1) hipLaunchKernelGGL((k_advect<1, NOISE>), g, b, 0, c->stream, c->dw, v, t, dt, (float)factor, N);
+  else hipLaunchKernelGGL((k_advect<2, NOISE>), g, b, 0, c->stream, c->dw, v, t, dt, (float)factor, N);
+}
+
+// get_environment -> interact_with_coastline -> update_previous_state -> advect_ocean_current in
+// one launch (k_step_grid) when the current comes from one gridded reader; otherwise exactly the
+// four separate entry points, in that order.  Results are bit-identical either way
+// (tests/test_gpu_parity.py::test_fused_step_equals_separate_calls).
+template <int SCHEME, bool NOISE>
+static void launch_step_grid(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, StepDesc S, double t, double dt,
+                             double factor, const StageNoise &N) {
+  const DevSource &s = c->hw.src[G.sid];
+  UVTime th = uv_time(s, t + dt / 2), tf = uv_time(s, t + dt);
+  S.geo_slot_uv = s.level_slot[0];
+  bool is3d = s.slot[S.geo_slot_uv].var_nz[VAR_U] > 1;
+  dim3 g(nblk(p->n)), b(BLOCK);
+  PView v = view(p);
+  float f = (float)factor;
+#define ODR_LAUNCH(PROJ, D3) hipLaunchKernelGGL((k_step_grid<SCHEME, PROJ, D3, NOISE>), g, b, 0, c->stream, c->dw, v, G, S, dt, f, th, tf, c->counter, N)
+  switch (s.proj.kind) {
+    case PROJ_LATLONG: if (is3d) ODR_LAUNCH(PROJ_LATLONG, true); else ODR_LAUNCH(PROJ_LATLONG, false); break;
+    case PROJ_STERE_POLAR: if (is3d) ODR_LAUNCH(PROJ_STERE_POLAR, true); else ODR_LAUNCH(PROJ_STERE_POLAR, false); break;
+    case PROJ_CURVILINEAR: if (is3d) ODR_LAUNCH(PROJ_CURVILINEAR, true); else ODR_LAUNCH(PROJ_CURVILINEAR, false); break;
+    default: if (is3d) ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, true); else ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, false); break;
+  }
+#undef ODR_LAUNCH
+}
+
+template <bool NOISE>
+static void step_dispatch(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, const StepDesc &S, int scheme, double t, double dt,
+                          double factor, const StageNoise &N) {
+  if (scheme == 0) launch_step_grid<0, NOISE>(c, p, G, S, t, dt, factor, N);
+  else if (scheme == 1) launch_step_grid<1, NOISE>(c, p, G, S, t, dt, factor, N);
+  else launch_step_grid<2, NOISE>(c, p, G, S, t, dt, factor, N);
+}
+
+// defined in odr_step_noise.hip
+void odr_i_advect_noise(odr_ctx *c, odr_particles *p, int scheme, double t, double dt, double factor, const StageNoise &N);
+void odr_i_step_noise(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, const StepDesc &S, int scheme, double t, double dt,
+                      double factor, const StageNoise &N);

@@ -70,6 +70,7 @@ int odr_ctx_destroy(odr_ctx *c) {
   (void)hipFree(c->red);
   for (double *q : {c->oil_stat, c->oil_cdf, c->oil_chunk, c->oil_part, c->oil_u}) if (q) (void)hipFree(q);
   if (c->oil_guide) (void)hipFree(c->oil_guide);
+  if (c->noise_buf) (void)hipFree(c->noise_buf);
   (void)hipFree(c->counter);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
@@ -118,6 +119,7 @@ int odr_particles_create(odr_ctx *c, int64_t capacity, odr_particles **out) {
 
 int odr_particles_destroy(odr_ctx *c, odr_particles *p) {
   if (c->red_owner == p) c->red_owner = nullptr;
+  if (c->noise_owner == p) c->noise_owner = nullptr;
   if (!p) return 0;
   (void)hipStreamSynchronize(c->stream);
   auto fr = [](void *q) { if (q) (void)hipFree(q); };
@@ -799,6 +801,7 @@ static bool launch_env_constant(odr_ctx *c, odr_particles *p, const int *grp, in
   for (int k = 0; k < ng; ++k) {
     float f = (float)s.const_val[grp[k]];
     if (!std::isfinite(f)) f = std::isfinite(w.fallback[grp[k]]) ? w.fallback[grp[k]] : f;
+    if (grp[k] == VAR_TEMP && f > 100.f) f = (float)((double)f - 273.15);   // Kelvin -> Celsius (environment.py:829-838)
     hipLaunchKernelGGL(k_fill_f32, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->env[grp[k]], p->n, f);
   }
   return true;
@@ -869,9 +872,11 @@ int odr_i_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var
         if (same) { grp[ng++] = vb; done[vb] = true; }
       }
       if (c->hw.nlist[va] == 0) {  // no reader: fallback only
-        for (int k = 0; k < ng; ++k)
-          hipLaunchKernelGGL(k_fill_f32, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->env[grp[k]], p->n,
-                             c->hw.fallback[grp[k]]);
+        for (int k = 0; k < ng; ++k) {
+          float f = c->hw.fallback[grp[k]];
+          if (grp[k] == VAR_TEMP && f > 100.f) f = (float)((double)f - 273.15);   // Kelvin -> Celsius (environment.py:829-838)
+          hipLaunchKernelGGL(k_fill_f32, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->env[grp[k]], p->n, f);
+        }
         continue;
       }
       if (!getenv("ODR_NO_FAST_PATH") && launch_env_grid(c, p, grp, ng, t, rec)) { rec = 0; continue; }
@@ -935,22 +940,28 @@ static int host_to_scratch(odr_ctx *c, odr_particles *p, const double *a, const 
   return 0;
 }
 
-int odr_env_add_noise(odr_ctx *c, odr_particles *p, int32_t vx, int32_t vy, double std, int rng_mode,
-                      const double *hnx, const double *hny, uint64_t step) {
+int odr_i_env_noise(odr_ctx *c, odr_particles *p, int vx, int vy, double std, int distribution, int rng_mode,
+                    const double *dev_nx, const double *dev_ny, unsigned long long step) {
   p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(vx >= 0 && vx < NVAR && vy >= 0 && vy < NVAR, "bad variable ids");
+  REQUIRE(distribution == ODR_NOISE_NORMAL || distribution == ODR_NOISE_UNIFORM, "unknown noise distribution %d", distribution);
   if (!p->env[vx] || !p->env[vy]) return fail(ODR_ERR_STATE, "variables not sampled");
   if (p->n == 0) return 0;
+  hipLaunchKernelGGL(k_env_noise, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), vx, vy, std, distribution, rng_mode,
+                     dev_nx, dev_ny, c->seed, step);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int odr_env_add_noise(odr_ctx *c, odr_particles *p, int32_t vx, int32_t vy, double std, int distribution, int rng_mode,
+                      const double *hnx, const double *hny, uint64_t step) {
   double *da = nullptr, *db = nullptr;
-  if (rng_mode == ODR_RNG_HOST) {
-    REQUIRE(hnx && hny, "host normals required in ODR_RNG_HOST mode");
+  if (rng_mode == ODR_RNG_HOST && p->n > 0) {
+    REQUIRE(hnx && hny, "host draws required in ODR_RNG_HOST mode");
     int rc = host_to_scratch(c, p, hnx, hny, (size_t)p->n, &da, &db);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_env_noise, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), vx, vy, std, rng_mode, da, db,
-                     c->seed, (unsigned long long)step);
-  HIPCHK(hipGetLastError());
-  return 0;
+  return odr_i_env_noise(c, p, vx, vy, std, distribution, rng_mode, da, db, (unsigned long long)step);
 }
 
 // odr_advect, odr_env_coast_advect: odr_step.hip

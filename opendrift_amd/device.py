@@ -351,15 +351,37 @@ class Particles:
         a, p = _f(values, len(self))
         check(self.lib.odr_env_upload(self.ctx.h, self.h, _vid(variable), p))
 
-    def env_add_noise(self, var_x, var_y, std, step=0, normals=None):
+    def env_add_noise(self, var_x, var_y, std, step=0, normals=None, uniform=False):
+        """drift:current_uncertainty / wind_uncertainty (normal) or drift:current_uncertainty_uniform (uniform=True) on
+        the last sample (environment.py:869-891).  normals: the caller's np.random draws (x, y), already scaled."""
         n = len(self)
+        dist = _abi.NOISE_UNIFORM if uniform else _abi.NOISE_NORMAL
         if normals is not None:
             (ax, px), (ay, py) = _d(self._host_order(normals[0]), n), _d(self._host_order(normals[1]), n)
-            check(self.lib.odr_env_add_noise(self.ctx.h, self.h, _vid(var_x), _vid(var_y), float(std),
+            check(self.lib.odr_env_add_noise(self.ctx.h, self.h, _vid(var_x), _vid(var_y), float(std), dist,
                                              _abi.RNG_HOST, px, py, step))
         else:
-            check(self.lib.odr_env_add_noise(self.ctx.h, self.h, _vid(var_x), _vid(var_y), float(std),
+            check(self.lib.odr_env_add_noise(self.ctx.h, self.h, _vid(var_x), _vid(var_y), float(std), dist,
                                              _abi.RNG_DEVICE, None, None, step))
+
+    def set_advect_noise(self, std_normal=0.0, std_uniform=0.0, step=0, stage_draws=None, main_draws=None):
+        """drift:current_uncertainty(_uniform) inside the next advect() / env_coast_advect() (odr_advect_set_noise): the
+        reference adds them in the Runge-Kutta stage get_environment calls too (physics_methods.py:638-670).
+        stage_draws [nstage][ncomp][n] / main_draws [ncomp][n]: np.random draws in the reference's order (parity mode);
+        None: Philox on the device."""
+        if stage_draws is None and main_draws is None:
+            check(self.lib.odr_advect_set_noise(self.ctx.h, self.h, float(std_normal), float(std_uniform), _abi.RNG_DEVICE,
+                                                None, None, 0, step))
+            return
+        ps = pm = None
+        nstage = 0
+        if stage_draws is not None:
+            sd, ps = _d(np.ascontiguousarray(self._host_order(np.asarray(stage_draws, dtype=np.float64))))
+            nstage = sd.shape[0]
+        if main_draws is not None:
+            md, pm = _d(np.ascontiguousarray(self._host_order(np.asarray(main_draws, dtype=np.float64))))
+        check(self.lib.odr_advect_set_noise(self.ctx.h, self.h, float(std_normal), float(std_uniform), _abi.RNG_HOST,
+                                            pm, ps, nstage, step))
 
     def advect(self, scheme, t_epoch, dt, factor=1.0):
         s = scheme if isinstance(scheme, int) else _abi.SCHEME.get(scheme, -1)
@@ -369,7 +391,7 @@ class Particles:
 
     def env_coast_advect(self, variables, t_epoch, scheme, dt, coastline='none', stranded_code=1,
                          seeded_on_land_code=0, store_previous=True, factor=1.0, count=True, seafloor=False,
-                         age_dt=0.0, max_age_seconds=0.0, retired_code=0, missing_code=0):
+                         age_dt=0.0, max_age_seconds=0.0, retired_code=0, missing_code=0, main_noise=False):
         """env_sample -> coastline -> store_previous -> advect in one launch (odr_env_coast_advect).
         count=False skips reading back the number of elements on land (no host synchronisation).  seafloor=True and
         age_dt != 0 add interact_with_seafloor ('lift_to_seafloor') and increase_age_and_retire, in the loop's order."""
@@ -380,9 +402,9 @@ class Particles:
         ids, pi = _i([_vid(v) for v in variables])
         n = C.c_int64()
         ex = None
-        if seafloor or age_dt or missing_code:
+        if seafloor or age_dt or missing_code or main_noise:
             ex = C.byref(_abi.StepExtras(1 if seafloor else 0, int(retired_code), float(age_dt), float(max_age_seconds),
-                                         int(missing_code), 0))
+                                         int(missing_code), 1 if main_noise else 0))
         check(self.lib.odr_env_coast_advect(self.ctx.h, self.h, len(ids), pi, float(t_epoch), a, stranded_code,
                                             seeded_on_land_code, int(bool(store_previous)), s, float(dt),
                                             float(factor), ex, C.byref(n) if count else None))

@@ -89,6 +89,8 @@ class OpenDriftSimulation(Configurable):
                                        'default': 'euler', 'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
             'drift:current_uncertainty': {'type': 'float', 'default': 0, 'min': 0, 'max': 5,
                                           'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'drift:current_uncertainty_uniform': {'type': 'float', 'default': 0, 'min': 0, 'max': 5,
+                                                  'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
             'drift:wind_uncertainty': {'type': 'float', 'default': 0, 'min': 0, 'max': 5,
                                        'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
             'drift:relative_wind': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
@@ -464,23 +466,53 @@ class OpenDriftSimulation(Configurable):
         names = list(self.required_variables)
         self.P.env_sample(names, t)
         self._sampled = names
+        self._add_uncertainty(names, current=True)
+
+    def _add_uncertainty(self, names, current):
+        """environment.py:869-891, in the reference's order of draws: current normal (x, y), current uniform (x, y), wind
+        normal (x, y).  current=False: the current's share has been added inside the fused launch."""
         n = self.num_elements_active()
-        for (vx, vy, key) in (('x_sea_water_velocity', 'y_sea_water_velocity', 'drift:current_uncertainty'),
-                              ('x_wind', 'y_wind', 'drift:wind_uncertainty')):
+        for (vx, vy, key, uniform) in (
+                ('x_sea_water_velocity', 'y_sea_water_velocity', 'drift:current_uncertainty', False),
+                ('x_sea_water_velocity', 'y_sea_water_velocity', 'drift:current_uncertainty_uniform', True),
+                ('x_wind', 'y_wind', 'drift:wind_uncertainty', False)):
             std = self.get_config(key)
-            if std and std > 0 and vx in names and vy in names:
-                if self.rng == 'numpy':
-                    self.P.env_add_noise(vx, vy, std, normals=(np.random.normal(0, std, n), np.random.normal(0, std, n)))
-                else:
-                    self.P.env_add_noise(vx, vy, std, step=self.steps_calculation)
+            if not (std and std > 0 and vx in names and vy in names) or (vx == 'x_sea_water_velocity' and not current):
+                continue
+            if self.rng == 'numpy':
+                draw = (lambda: np.random.uniform(-std, std, n)) if uniform else (lambda: np.random.normal(0, std, n))
+                self.P.env_add_noise(vx, vy, std, normals=(draw(), draw()), uniform=uniform)
+            else:
+                self.P.env_add_noise(vx, vy, std, step=self.steps_calculation, uniform=uniform)
+
+    def _current_uncertainty(self):
+        return (self.get_config('drift:current_uncertainty') or 0.0, self.get_config('drift:current_uncertainty_uniform') or 0.0)
 
     # ---- PhysicsMethods (physics_methods.py:611-848)
     def advect_ocean_current(self, factor=1):
         if self._advected:       # already done by the fused launch of this step (run(), fused lane)
             self._advected = False
             return
-        self.P.advect(self.get_config('drift:advection_scheme'), _epoch(self.time),
-                      self.time_step.total_seconds(), factor)
+        scheme = self.get_config('drift:advection_scheme')
+        std, ustd = self._current_uncertainty()
+        nstage = {'runge-kutta': 1, 'runge-kutta4': 3}.get(scheme, 0)
+        if nstage and (std > 0 or ustd > 0):
+            # every Runge-Kutta stage is a get_environment call of the current: it carries the uncertainty too
+            # (environment.py:869-886 inside physics_methods.py:638-670)
+            if self.rng == 'numpy':
+                n = self.num_elements_active()
+                draws = []
+                for _ in range(nstage):
+                    call = []
+                    if std > 0:
+                        call += [np.random.normal(0, std, n), np.random.normal(0, std, n)]
+                    if ustd > 0:
+                        call += [np.random.uniform(-ustd, ustd, n), np.random.uniform(-ustd, ustd, n)]
+                    draws.append(call)
+                self.P.set_advect_noise(std, ustd, stage_draws=np.array(draws))
+            else:
+                self.P.set_advect_noise(std, ustd, step=self.steps_calculation)
+        self.P.advect(scheme, _epoch(self.time), self.time_step.total_seconds(), factor)
 
     def advect_wind(self, factor=1):
         self.P.advect_wind(self.time_step.total_seconds(), self.get_config('drift:wind_drift_depth', 0.1),
@@ -578,14 +610,16 @@ class OpenDriftSimulation(Configurable):
         self._hist = _ResultBuffer(self.ctx, n_total, nout, min(nout, max(1, int(export_buffer_length))), hvars)
         times = []
         grid_sid = next((b.sid for b in self.readers.values() if b.is_grid() and b.sid is not None), None)
-        # fused lane: the stock loop body and the stock OceanDrift.update order (current advection first), no noise
-        # between sample and advection, no retirement between coastline and advection
+        # fused lane: the stock loop body and the stock OceanDrift.update order (current advection first), no
+        # retirement between coastline and advection.  Uncertainties: with the device RNG (streams keyed by element
+        # ID) they are added inside the launch; np.random draws are sized by the elements present at each call, which
+        # the fused launch cannot honour -> call-by-call lane
         B = OpenDriftSimulation
         fused_lane = (not os.environ.get('ODR_RUN_UNFUSED') and getattr(type(self), 'update', None) is OceanDrift.update and
                       all(getattr(type(self), m) is getattr(B, m) for m in (
                           'advect_ocean_current', 'get_environment', 'interact_with_coastline', 'interact_with_seafloor',
                           'deactivate_outside', 'deactivate_elements')) and
-                      not self.get_config('drift:current_uncertainty') and not self.get_config('drift:wind_uncertainty') and
+                      (self.rng == 'device' or not (any(self._current_uncertainty()) or self.get_config('drift:wind_uncertainty'))) and
                       self.get_config('drift:max_age_seconds') is None and
                       self.get_config('general:seafloor_action', 'lift_to_seafloor') in ('lift_to_seafloor', 'none') and
                       not self.get_config('general:coastline_approximation_precision') and
@@ -614,6 +648,10 @@ class OpenDriftSimulation(Configurable):
                     action = self.get_config('general:coastline_action')
                     floor = ('sea_floor_depth_below_sea_level' in self.priority_list and
                              self.get_config('general:seafloor_action', 'lift_to_seafloor') == 'lift_to_seafloor')
+                    std, ustd = self._current_uncertainty()
+                    noisy = std > 0 or ustd > 0
+                    if noisy:
+                        self.P.set_advect_noise(std, ustd, step=self.steps_calculation)
                     self.P.env_coast_advect(
                         names, _epoch(self.time), self.get_config('drift:advection_scheme'), self.time_step.total_seconds(),
                         coastline=action if 'land_binary_mask' in names else 'none',
@@ -621,8 +659,10 @@ class OpenDriftSimulation(Configurable):
                         seeded_on_land_code=(self._status_code('seeded_on_land') if action == 'previous' and self.newly_seeded
                                              else 0),
                         store_previous=True, count=False, seafloor=floor,
-                        missing_code=self._status_code('missing_data') if self._can_be_missing(names) else 0)
+                        missing_code=self._status_code('missing_data') if self._can_be_missing(names) else 0,
+                        main_noise=noisy)
                     self._sampled = names
+                    self._add_uncertainty(names, current=False)     # the wind's share
                     self._resolve_status()
                     self._state_to_buffer(i, out_every, times, from_previous=True)
                     self.P.increase_age(self.time_step.total_seconds())

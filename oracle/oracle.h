@@ -117,6 +117,13 @@ void orc_advect_ocean_current(const orc_world *w, int scheme, long n, double *lo
                               double *lat, const double *z, const int *moving,
                               const float *cdf, const float *u_env,
                               const float *v_env, double t, double dt, double factor);
+/* the same with the uncertainty draws of the Runge-Kutta stage calls (environment.py:869-886 inside
+ * physics_methods.py:638-670): stage_noise = [nstage][ncomp][n], ncomp = 2 (normal x, y) or 4 (+ uniform x, y) */
+void orc_advect_ocean_current_noise(const orc_world *w, int scheme, long n, double *lon,
+                                    double *lat, const double *z, const int *moving,
+                                    const float *cdf, const float *u_env,
+                                    const float *v_env, double t, double dt, double factor,
+                                    int ncomp, const double *stage_noise);
 
 /* advect_wind (physics_methods.py:712-791) */
 void orc_advect_wind(long n, double *lon, double *lat, const double *z,
@@ -154,7 +161,7 @@ void orc_leeway(long n, double *lon, double *lat, const int *moving, float *cons
                 double wind_threshold, double wind_threshold_sigma);
 
 /* interact_with_coastline 'stranding' / 'previous' (basemodel/__init__.py:670-746), precision None */
-void orc_coastline(long n, int action, const float *land, double *lon, double *lat,
+void orc_coastline(long n, int action, float *land, double *lon, double *lat,
                    const double *z, const double *prev_lon, const double *prev_lat,
                    int *status, int *moving, int stranded_code, const float *age_seconds,
                    int seeded_on_land_code);

@@ -293,13 +293,21 @@ def update_positions(lon, lat, u, v, moving, dt):
                                        C.c_double(dt))
 
 
-def advect_ocean_current(world, scheme, lon, lat, z, moving, cdf, u_env, v_env, t, dt, factor=1.0):
+def advect_ocean_current(world, scheme, lon, lat, z, moving, cdf, u_env, v_env, t, dt, factor=1.0, stage_noise=None):
+    """stage_noise: [nstage][ncomp][n] float64 -- the np.random draws of the Runge-Kutta stage get_environment calls
+    (drift:current_uncertainty normal x, y; then drift:current_uncertainty_uniform x, y), or None"""
     n = lon.size
     z, moving, cdf = _d(np.broadcast_to(z, lon.shape)), _i(moving), _f(np.broadcast_to(cdf, lon.shape))
-    lib().orc_advect_ocean_current(C.byref(world), C.c_int(scheme), C.c_long(n), _p(lon, C.c_double),
-                                   _p(lat, C.c_double), _p(z, C.c_double), _p(moving, C.c_int),
-                                   _p(cdf, C.c_float), _p(_f(u_env), C.c_float), _p(_f(v_env), C.c_float),
-                                   C.c_double(t), C.c_double(dt), C.c_double(factor))
+    ncomp, sn = 0, None
+    if stage_noise is not None and scheme > 0:
+        sn = _d(np.asarray(stage_noise)[..., :n])
+        assert sn.ndim == 3 and sn.shape[0] == (1 if scheme == 1 else 3) and sn.shape[1] in (2, 4), sn.shape
+        ncomp = sn.shape[1]
+    lib().orc_advect_ocean_current_noise(C.byref(world), C.c_int(scheme), C.c_long(n), _p(lon, C.c_double),
+                                         _p(lat, C.c_double), _p(z, C.c_double), _p(moving, C.c_int),
+                                         _p(cdf, C.c_float), _p(_f(u_env), C.c_float), _p(_f(v_env), C.c_float),
+                                         C.c_double(t), C.c_double(dt), C.c_double(factor), C.c_int(ncomp),
+                                         _p(sn, C.c_double) if sn is not None else None)
 
 
 def advect_wind(lon, lat, z, moving, wdf, xwind, ywind, u_env, v_env, wind_drift_depth, relative_wind,

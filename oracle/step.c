@@ -420,11 +420,35 @@ static void stage_positions(long n, const double *lon, const double *lat,
   }
 }
 
+/* drift:current_uncertainty / drift:current_uncertainty_uniform (environment.py:869-886) are part of EVERY
+ * get_environment call whose variables hold the current -- also of the Runge-Kutta stage calls
+ * (physics_methods.py:638-670): env[var] += draw, a float32 array += float64 array, i.e. float32(float64(u) + draw),
+ * first the normal pair (x, y), then the uniform pair.  noise = [ncomp][n] draws of one call in np.random order. */
+static void add_uncertainty(long n, float *u, float *v, int ncomp, const double *noise) {
+  long i;
+  int c;
+  for (c = 0; c + 1 < ncomp; c += 2)
+    for (i = 0; i < n; ++i) {
+      u[i] = (float)((double)u[i] + noise[(size_t)c * (size_t)n + (size_t)i]);
+      v[i] = (float)((double)v[i] + noise[(size_t)(c + 1) * (size_t)n + (size_t)i]);
+    }
+}
+
 void orc_advect_ocean_current(const orc_world *w, int scheme, long n, double *lon,
                               double *lat, const double *z, const int *moving,
                               const float *cdf, const float *u_env,
                               const float *v_env, double t, double dt, double factor) {
+  orc_advect_ocean_current_noise(w, scheme, n, lon, lat, z, moving, cdf, u_env, v_env, t, dt, factor, 0, NULL);
+}
+
+/* stage_noise: [nstage][ncomp][n] (nstage = 1 for RK2, 3 for RK4; ncomp = 2 or 4), or NULL */
+void orc_advect_ocean_current_noise(const orc_world *w, int scheme, long n, double *lon,
+                                    double *lat, const double *z, const int *moving,
+                                    const float *cdf, const float *u_env,
+                                    const float *v_env, double t, double dt, double factor,
+                                    int ncomp, const double *stage_noise) {
   static const int uv[2] = {ORC_VAR_U, ORC_VAR_V};
+  const size_t per = (size_t)ncomp * (size_t)n;
   float *fu = (float *)malloc(sizeof(float) * (size_t)n);
   float *fv = (float *)malloc(sizeof(float) * (size_t)n);
   long i;
@@ -442,6 +466,7 @@ void orc_advect_ocean_current(const orc_world *w, int scheme, long n, double *lo
     o2[0] = u2; o2[1] = v2;
     stage_positions(n, lon, lat, u_env, v_env, dt * .5, lon2, lat2);
     orc_get_environment(w, 2, uv, n, lon2, lat2, z, t + dt / 2, o2);
+    if (stage_noise) add_uncertainty(n, u2, v2, ncomp, stage_noise);
     if (scheme == 1) {
       for (i = 0; i < n; ++i) {
         float f = (float)factor * cdf[i];
@@ -455,8 +480,10 @@ void orc_advect_ocean_current(const orc_world *w, int scheme, long n, double *lo
       o3[0] = u3; o3[1] = v3; o4[0] = u4; o4[1] = v4;
       stage_positions(n, lon, lat, u2, v2, dt * .5, lon2, lat2);
       orc_get_environment(w, 2, uv, n, lon2, lat2, z, t + dt / 2, o3);
+      if (stage_noise) add_uncertainty(n, u3, v3, ncomp, stage_noise + per);
       stage_positions(n, lon, lat, u3, v3, dt * .5, lon2, lat2); /* dt*.5 again: reference quirk :662 */
       orc_get_environment(w, 2, uv, n, lon2, lat2, z, t + dt, o4);
+      if (stage_noise) add_uncertainty(n, u4, v4, ncomp, stage_noise + 2 * per);
       for (i = 0; i < n; ++i) { /* (x_vel + 2*x_vel2 + 2*x_vel3 + x_vel4)/6.0 in float32 (:674-675) */
         volatile float a2 = 2 * u2[i], a3 = 2 * u3[i], b2 = 2 * v2[i], b3 = 2 * v3[i];
         volatile float su = u_env[i] + a2, sv = v_env[i] + b2;
@@ -690,7 +717,7 @@ void orc_vertical_advection(long n, double *z, const int *moving, const float *w
 
 /* interact_with_coastline, basemodel/__init__.py:670-746 (precision None);
  * action 1 = stranding, 2 = previous */
-void orc_coastline(long n, int action, const float *land, double *lon, double *lat,
+void orc_coastline(long n, int action, float *land, double *lon, double *lat,
                    const double *z, const double *prev_lon, const double *prev_lat,
                    int *status, int *moving, int stranded_code, const float *age_seconds,
                    int seeded_on_land_code) {
@@ -709,6 +736,7 @@ void orc_coastline(long n, int action, const float *land, double *lon, double *l
       }
       lon[i] = prev_lon[i]; /* on_land includes the elements just deactivated (:720-730) */
       lat[i] = prev_lat[i];
+      land[i] = 0; /* self.environment.land_binary_mask[on_land] = 0 (:746) */
     }
   }
 }

@@ -110,10 +110,14 @@ class OracleBackend:
     def store_previous(self):
         self.plon, self.plat = self.lon.copy(), self.lat.copy()
 
-    def advect(self, scheme, t, dt):
+    def advect(self, scheme, t, dt, stage_noise=None, stds=None):
+        """stage_noise [nstage][ncomp][n]: np.random draws of the Runge-Kutta stage calls (current uncertainty)"""
         w = self.sc.oracle_world()
         orc.advect_ocean_current(w, {'euler': 0, 'runge-kutta': 1, 'runge-kutta4': 2}[scheme], self.lon, self.lat,
-                                 self.z, self.moving, self.cdf, self.env[U], self.env[VV], t, dt)
+                                 self.z, self.moving, self.cdf, self.env[U], self.env[VV], t, dt, stage_noise=stage_noise)
+
+    def vadvect(self, dt):
+        orc.vertical_advection(self.z, self.moving, self.env[W], dt)
 
     def wind(self, dt, wdd=0.1, relative=False):
         orc.advect_wind(self.lon, self.lat, self.z, self.moving, self.wdf, self.env[XW], self.env[YW],
@@ -131,7 +135,7 @@ class OracleBackend:
     def set_leeway(self, props):
         self.aux = [np.array(props[k], dtype=np.float32) for k in LEEWAY_PROPS]
 
-    def noise(self, vx, vy, nx, ny):   # environment.py:869-891: float32 += float64
+    def noise(self, vx, vy, nx, ny, uniform=False):   # environment.py:869-891: float32 += float64
         n = len(self.lon)
         self.env[vx] = (self.env[vx].astype(np.float64) + nx[:n]).astype(np.float32)
         self.env[vy] = (self.env[vy].astype(np.float64) + ny[:n]).astype(np.float32)
@@ -242,8 +246,13 @@ class DeviceBackend:
     def store_previous(self):
         self.P.store_previous()
 
-    def advect(self, scheme, t, dt):
+    def advect(self, scheme, t, dt, stage_noise=None, stds=None):
+        if stage_noise is not None:
+            self.P.set_advect_noise(stds[0], stds[1], stage_draws=np.asarray(stage_noise)[..., :len(self.P)])
         self.P.advect(scheme, t, dt)
+
+    def vadvect(self, dt):
+        self.P.vertical_advection(dt)
 
     def wind(self, dt, wdd=0.1, relative=False):
         self.P.advect_wind(dt, wind_drift_depth=wdd, relative_wind=relative)
@@ -259,9 +268,9 @@ class DeviceBackend:
         for slot, k in enumerate(LEEWAY_PROPS):
             self.P.set_property(slot, np.asarray(props[k], dtype=np.float32))
 
-    def noise(self, vx, vy, nx, ny):
+    def noise(self, vx, vy, nx, ny, uniform=False):
         n = len(self.P)
-        self.P.env_add_noise(vx, vy, 1.0, normals=(nx[:n], ny[:n]))
+        self.P.env_add_noise(vx, vy, 1.0, normals=(nx[:n], ny[:n]), uniform=uniform)
 
     def leeway(self, dt, uniforms, frac=0.4, cap_uniforms=None, thr=30.0, sig=5.0):
         if cap_uniforms is not None:
@@ -364,6 +373,73 @@ def replay_c5(B, g, nsteps):
         else:
             B.leeway(dt, g['uniforms'][k])
         out.append(B.state(n))
+    return out
+
+
+def replay_c13(B, g, tag, nsteps):
+    """c13 golden: OceanDrift, 3-D lon/lat grid + constant wind, 'runge-kutta' (tag 'rk2') / 'runge-kutta4' ('rk4') with
+    drift:current_uncertainty (+ _uniform for rk4) and drift:wind_uncertainty: noise in the main sample AND in every
+    Runge-Kutta stage call (environment.py:869-891, physics_methods.py:638-670)."""
+    dt = float(g['dt'])
+    n = g[tag + '_lon'].shape[1]
+    scheme = {'rk2': 'runge-kutta', 'rk4': 'runge-kutta4'}[tag]
+    main, stage = g[tag + '_main_noise'], g[tag + '_stage_noise']
+    ncomp = stage.shape[2]
+    stds = (float(g['current_uncertainty']), float(g['current_uncertainty_uniform']) if ncomp == 4 else 0.0)
+    out = []
+    names = [U, VV, W, XW, YW, DEPTH, SSH, LAND]
+    for k in range(nsteps):
+        t = k * dt
+        B.sample(names, t)
+        B.noise(U, VV, main[k][0], main[k][1])
+        if ncomp == 4:
+            B.noise(U, VV, main[k][2], main[k][3], uniform=True)
+        B.noise(XW, YW, main[k][ncomp], main[k][ncomp + 1])
+        B.coast('previous', seeded_code=1)   # status_categories: ['active', 'seeded_on_land']
+        B.seafloor()
+        B.increase_age(dt)
+        B.compact()
+        B.store_previous()
+        B.advect(scheme, t, dt, stage_noise=stage[k], stds=stds)
+        B.wind(dt, wdd=0.1)
+        B.vbuoy(dt)
+        B.vadvect(dt)
+        out.append(B.state(n))
+    return out
+
+
+def scenario_c13(g):
+    from scenarios import Scenario
+    names = [U, VV, W, DEPTH, LAND]
+    levels = [(float(g['g_t'][k]), {nm: g['g_' + nm][k] for nm in names}) for k in range(len(g['g_t']))]
+    return Scenario([('grid', dict(x=g['g_x'], y=g['g_y'], z=g['g_z'], levels=levels)),
+                     ('constant', {XW: float(g['wind'][0]), YW: float(g['wind'][1])})],
+                    fallbacks={U: 0.0, VV: 0.0, W: 0.0, XW: 0.0, YW: 0.0, DEPTH: 10000.0, SSH: 0.0})
+
+
+def replay_c14(B, g, nsteps, start=0):
+    """c14 golden: the reference's OpenOil at its DEFAULT uncertainties (current 0.05, wind 0.5; openoil.py:497-498) with
+    'runge-kutta4': OpenOil.update = oil_weathering (Kelvin) -> vertical mixing with the oil physics -> advect_oil =
+    RK4 current (noise in the three stage calls) + windage."""
+    dt, dt_mix = float(g['dt']), float(g['dt_mix'])
+    n = g['lon'].shape[1]
+    out = []
+    names = [U, VV, XW, YW, MLD, DEPTH, SSH, LAND, TEMP, SALT]
+    for k in range(start, nsteps):
+        t = k * dt
+        B.sample(names, t)
+        B.noise(U, VV, g['main_noise'][k][0], g['main_noise'][k][1])
+        B.noise(XW, YW, g['main_noise'][k][2], g['main_noise'][k][3])
+        B.seafloor()
+        B.increase_age(dt)
+        B.store_previous()
+        uni = dict(mix=g['u_mix'][k], entrain=g['u_entrain'][k], intrusion=np.nan_to_num(g['u_intrusion'][k], nan=0.5),
+                   diameter=g['u_diameter'][k])
+        B.vmix_oil('windspeed_Large1994', float(g['background_diffusivity']), dt, dt_mix, float(g['interfacial_tension']),
+                   'Johansen et al. (2015)', uni)
+        B.advect('runge-kutta4', t, dt, stage_noise=g['stage_noise'][k], stds=(0.05, 0.0))
+        B.wind(dt, wdd=0.1)
+        out.append(B.state(n) + (B.oil_state(),))
     return out
 
 

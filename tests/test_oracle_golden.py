@@ -234,3 +234,35 @@ def test_c12_kelvin_temperatures_become_celsius_like_the_reference():
         tol = 2e-3 if k == 0 else 0.0          # first step: float32 coordinates in the reference, times the 273 K jump across one cell
         assert np.abs(T - g[key]).max() <= tol, (k, np.abs(T - g[key]).max())
     assert (g['g_T'][0] > 100).any() and (g['g_T'][0] < 100).any()
+
+
+@pytest.mark.parametrize('tag', ['rk2', 'rk4'])
+def test_c13_uncertainty_in_the_runge_kutta_stage_calls_vs_oracle(tag):
+    """drift:current_uncertainty (+ _uniform) and drift:wind_uncertainty as the reference applies them: in the main
+    get_environment call AND in every Runge-Kutta stage call (environment.py:869-891 inside physics_methods.py:638-670);
+    golden c13 = the reference's own OceanDrift runs with every np.random draw recorded."""
+    g = golden('c13_noise_rk.npz')
+    sub = {k: g[tag + '_' + k] for k in ('lon', 'lat', 'z', 'status')}
+    B = replay.OracleBackend(replay.scenario_c13(g), sub['lon'][0], sub['lat'][0], sub['z'][0], wdf=0.02)
+    worst = replay.compare(replay.replay_c13(B, g, tag, sub['lon'].shape[0] - 1), sub, tol_pos=1e-7, tol_z=1e-5)
+    assert list(g[tag + '_categories']) == ['active', 'seeded_on_land']
+    print('c13', tag, 'oracle vs reference:', worst)
+    # the stage noise matters: without it the run leaves the golden by far more than the tolerance
+    B0 = replay.OracleBackend(replay.scenario_c13(g), sub['lon'][0], sub['lat'][0], sub['z'][0], wdf=0.02)
+    g0 = dict(g)
+    g0[tag + '_stage_noise'] = np.zeros_like(g[tag + '_stage_noise'])
+    st = replay.replay_c13(B0, g0, tag, 2)
+    assert np.nanmax(np.abs(st[1][0] - sub['lon'][2])) > 1e-5
+
+
+def test_c14_openoil_defaults_vs_oracle():
+    """The reference's own OpenOil at its default uncertainties with 'runge-kutta4' (golden c14)."""
+    g = golden('c14_openoil_defaults.npz')
+    for start, tol_pos, tol_z in ((0, 1e-6, 1e-4), (1, 1e-7, 1e-6)):    # from seeding: first-step float32 positions (DESIGN.md 2.1)
+        B = replay.OracleBackend(replay.scenario_c9(g), g['lon'][start], g['lat'][start], g['z'][start], wdf=g['wdf'])
+        B.set_oil(g['diameter'][start].astype(np.float32), float(g['oil_density']), float(g['oil_viscosity']), g['film'])
+        states = replay.replay_c14(B, g, 6, start=start)
+        for k, (lon, lat, z, status, oil) in enumerate(states, start):
+            assert np.abs(lon - g['lon'][k + 1]).max() < tol_pos and np.abs(lat - g['lat'][k + 1]).max() < tol_pos, \
+                (k, np.abs(lon - g['lon'][k + 1]).max(), np.abs(lat - g['lat'][k + 1]).max())
+            assert np.abs(z - g['z'][k + 1]).max() < tol_z, (k, np.abs(z - g['z'][k + 1]).max())
