@@ -89,6 +89,7 @@ class Workload:
         self.name, self.ctx, self.fields = name, ctx, fields
         self.sort_every = int(os.environ.get('ODR_SORT_EVERY', 16))
         self.fused = not os.environ.get('ODR_UNFUSED')   # one launch for sample+coastline+previous+advect
+        self.scheme = os.environ.get('ODR_BENCH_SCHEME', 'runge-kutta4')   # what-if runs only: the metric is quoted on RK4
         rank, local_rank, world = dist_info
         if name == 'c2':
             sid = ctx.add_double_gyre(A=0.1, epsilon=0.25, omega=0.628, t0=0.0)
@@ -141,7 +142,7 @@ class Workload:
             P.advect('runge-kutta4', t, self.dt)
         elif self.name == 'c3':
             if self.fused:
-                P.env_coast_advect(self.vars, t, 'runge-kutta4', self.dt, coastline='previous', store_previous=True,
+                P.env_coast_advect(self.vars, t, self.scheme, self.dt, coastline='previous', store_previous=True,
                                    count=False, seafloor=True, age_dt=self.dt)
             else:
                 P.env_sample(self.vars, t)

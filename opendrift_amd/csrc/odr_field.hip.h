@@ -727,21 +727,80 @@ __device__ __forceinline__ T ld_off(const float *__restrict__ base, unsigned byt
 #endif
 }
 
-// (u,v) of an interleaved pair at one time level; `uv` = address of the pair in node record 0
-template <bool IS3D>
-__device__ __forceinline__ void uv_level(const float *__restrict__ uv, int nz, const Foot &ft,
-                                         const ZBracket &zb, double &u, double &v, bool &f32class) {
+// ------------------------------------------------------------------ LDS field tile
+// The (u,v) node records around the particles of one workgroup, staged in LDS for the Runge-Kutta stage samples
+// (k_step_grid<..., TILE>): after the spatial sort the 256 particles of a workgroup sit in ~27 neighbouring grid cells,
+// and a stage position is less than a cell away from the particle, so the node rectangle spanned by the workgroup
+// (+1 node margin) serves all three stage evaluations of all its particles.  The three dependent gather rounds of
+// RK4 -- each an L2 / HBM round trip behind the other waves' gathers -- become LDS reads; the rectangle itself is
+// fetched once, coalesced along the node records.  Layout: tile[(node * 2 + time) * nz + k] = (u, v) of level k,
+// node = (iy - y0) * w + (ix - x0), time 0 = the 'before' block, 1 = 'after'.  Footprints that leave the rectangle
+// (stragglers after in-place compaction, workgroups that straddle two sort tiles) take the global path.
+struct __attribute__((aligned(8))) F2a { float x, y; };
+struct TileView {
+  const F2a *t;        // LDS
+  int x0, y0, w, h;    // node rectangle [x0, x0 + w) x [y0, y0 + h)
+  int nz;              // levels per node and time (1: 2-D field)
+};
+struct GlobalUV {       // the same access pattern on the blocks in HBM
+  const float *b, *a;
+  unsigned o[4], kb;
+  __device__ __forceinline__ F4 q4(int time, int c) const { return ld_off<F4>(time ? a : b, o[c] + kb); }
+  __device__ __forceinline__ F2 q2(int time, int c) const { return ld_off<F2>(time ? a : b, o[c]); }
+};
+struct TileUV {
+  const F2a *t;
+  unsigned l[4];       // (node * 2) * nz + iz0 per corner
+  unsigned nz;
+  __device__ __forceinline__ F4 q4(int time, int c) const {
+    const F2a *q = t + l[c] + (time ? nz : 0u);
+    const F2a lo = q[0], hi = q[1];
+    F4 r; r.x = lo.x; r.y = lo.y; r.z = hi.x; r.w = hi.y;
+    return r;
+  }
+  __device__ __forceinline__ F2 q2(int time, int c) const {
+    const F2a v = t[l[c] + (time ? nz : 0u)];
+    F2 r; r.x = v.x; r.y = v.y;
+    return r;
+  }
+};
+
+// one float32 layer value from multiplied-out weights (w00 = wy0 wx0, ...): the same sum as bil4 evaluated with three
+// fused multiply-adds -- a float64 round-off apart, which reaches the float32 rounding in ~1e-8 of the values
+__device__ __forceinline__ float bilw(float v00, float v01, float v10, float v11, double w00, double w01, double w10,
+                                      double w11) {
+  return (float)fma((double)v11, w11, fma((double)v10, w10, fma((double)v01, w01, (double)v00 * w00)));
+}
+struct FootW { double w00, w01, w10, w11; };
+__device__ __forceinline__ FootW foot_weights(const Foot &ft) {
+  FootW w;
+  w.w00 = ft.wy0 * ft.wx0; w.w01 = ft.wy0 * ft.tx; w.w10 = ft.ty * ft.wx0; w.w11 = ft.ty * ft.tx;
+  return w;
+}
+
+// (u,v) of an interleaved pair at one time level through a loader LD (GlobalUV / TileUV).
+// FASTW: layer values from the multiplied-out weights `fw` (Runge-Kutta stage samples) instead of scipy's
+// (v*wy)*wx order (the stored environment)
+template <bool IS3D, bool FASTW, class LD>
+__device__ __forceinline__ void uv_level_ld(const LD &ld, int time, int nz, const Foot &ft, const ZBracket &zb, double &u,
+                                            double &v, bool &f32class, const FootW &fw) {
   const double ty = ft.ty, tx = ft.tx, wy0 = ft.wy0, wx0 = ft.wx0;
   if (IS3D) {
-    const unsigned kb = (unsigned)zb.iz0 * 8u;
-    const F4 q00 = ld_off<F4>(uv, ft.o00 + kb), q01 = ld_off<F4>(uv, ft.o01 + kb);
-    const F4 q10 = ld_off<F4>(uv, ft.o10 + kb), q11 = ld_off<F4>(uv, ft.o11 + kb);
+    const F4 q00 = ld.q4(time, 0), q01 = ld.q4(time, 1), q10 = ld.q4(time, 2), q11 = ld.q4(time, 3);
     // level "above" (ia) and "below" (ib): (x,y) = level iz0, (z,w) = level iz0+1
     float ua, va, ub, vb;
-    ub = bil4(q00.z, q01.z, q10.z, q11.z, wy0, ty, wx0, tx);
-    vb = bil4(q00.w, q01.w, q10.w, q11.w, wy0, ty, wx0, tx);
+    if (FASTW) {
+      ub = bilw(q00.z, q01.z, q10.z, q11.z, fw.w00, fw.w01, fw.w10, fw.w11);
+      vb = bilw(q00.w, q01.w, q10.w, q11.w, fw.w00, fw.w01, fw.w10, fw.w11);
+    } else {
+      ub = bil4(q00.z, q01.z, q10.z, q11.z, wy0, ty, wx0, tx);
+      vb = bil4(q00.w, q01.w, q10.w, q11.w, wy0, ty, wx0, tx);
+    }
     if (zb.same && nz > 1) { ua = ub; va = vb; }
-    else {
+    else if (FASTW) {
+      ua = bilw(q00.x, q01.x, q10.x, q11.x, fw.w00, fw.w01, fw.w10, fw.w11);
+      va = bilw(q00.y, q01.y, q10.y, q11.y, fw.w00, fw.w01, fw.w10, fw.w11);
+    } else {
       ua = bil4(q00.x, q01.x, q10.x, q11.x, wy0, ty, wx0, tx);
       va = bil4(q00.y, q01.y, q10.y, q11.y, wy0, ty, wx0, tx);
     }
@@ -749,19 +808,39 @@ __device__ __forceinline__ void uv_level(const float *__restrict__ uv, int nz, c
     v = __dadd_rn(__dmul_rn((double)va, zb.wa), __dmul_rn((double)vb, 1 - zb.wa));
     f32class = false;
   } else {
-    const F2 q00 = ld_off<F2>(uv, ft.o00), q01 = ld_off<F2>(uv, ft.o01);
-    const F2 q10 = ld_off<F2>(uv, ft.o10), q11 = ld_off<F2>(uv, ft.o11);
-    u = bil4(q00.x, q01.x, q10.x, q11.x, wy0, ty, wx0, tx);
-    v = bil4(q00.y, q01.y, q10.y, q11.y, wy0, ty, wx0, tx);
+    const F2 q00 = ld.q2(time, 0), q01 = ld.q2(time, 1), q10 = ld.q2(time, 2), q11 = ld.q2(time, 3);
+    if (FASTW) {
+      u = bilw(q00.x, q01.x, q10.x, q11.x, fw.w00, fw.w01, fw.w10, fw.w11);
+      v = bilw(q00.y, q01.y, q10.y, q11.y, fw.w00, fw.w01, fw.w10, fw.w11);
+    } else {
+      u = bil4(q00.x, q01.x, q10.x, q11.x, wy0, ty, wx0, tx);
+      v = bil4(q00.y, q01.y, q10.y, q11.y, wy0, ty, wx0, tx);
+    }
     f32class = true;
   }
 }
+template <bool IS3D, bool FASTW = false>
+__device__ __forceinline__ void uv_level(const float *__restrict__ uv, int nz, const Foot &ft,
+                                         const ZBracket &zb, double &u, double &v, bool &f32class,
+                                         const FootW &fw = FootW()) {
+  GlobalUV g;
+  g.b = uv; g.a = uv;
+  g.o[0] = ft.o00; g.o[1] = ft.o01; g.o[2] = ft.o10; g.o[3] = ft.o11;
+  g.kb = IS3D ? (unsigned)zb.iz0 * 8u : 0u;
+  uv_level_ld<IS3D, FASTW>(g, 0, nz, ft, zb, u, v, f32class, fw);
+}
 
-// (u,v) float32 environment of one particle from the single grid source `s`
-template <int PROJ, bool IS3D>
+// (u,v) float32 environment of one particle from the single grid source `s` at a Runge-Kutta STAGE position: the
+// reference's layer-by-layer arithmetic (every (time, z) layer interpolated horizontally and rounded to float32, then
+// z and time interpolation) with the horizontal weights multiplied out once for all layers.
+// -DODR_FAST_STAGE_SAMPLE (measured, not the default): all 2 x 2 x 2 x 2 corner values combined in float64 and rounded
+// to float32 once -- the intermediate float32 roundings of the reference are skipped, 60 instructions fewer per sample,
+// but the stage value is then 1-2 float32 ulp off in most samples (1.5e-9 deg per step in tests/test_gpu_parity.py).
+template <int PROJ, bool IS3D, bool TILE = false>
 __device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBlock &geo, const UVTime &tm,
                                                double lon, double lat, double z, const ZBracket &zb,
-                                               float fbu, float fbv, float &uo, float &vo) {
+                                               float fbu, float fbv, float &uo, float &vo,
+                                               const TileView &T = TileView(), bool tile_ok = false) {
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
   double x, y;
@@ -778,22 +857,98 @@ __device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBloc
     if (s.mod360_x) x = np_mod(x, 360.0);
     double xi = __dmul_rn(div_cr(x - geo.x0, geo.xspan, geo.ixspan), (double)(geo.nx - 1));
     double yi = __dmul_rn(div_cr(y - geo.y0, geo.yspan, geo.iyspan), (double)(geo.ny - 1));
-    double ub, vb;
+    double u, v;
+#ifndef ODR_FAST_STAGE_SAMPLE
     bool f32c;
-    const Foot ft = footprint(yi, xi, geo.ny, geo.nx, (unsigned)geo.rec * 4u);
-    uv_level<IS3D>(tm.b, s.nz, ft, zb, ub, vb, f32c);
-    double u = ub, v = vb;
-    if (tm.a) {
-      double ua, va;
-      uv_level<IS3D>(tm.a, s.nz, ft, zb, ua, va, f32c);
-      if (f32c) {
-        u = __fadd_rn(__fmul_rn((float)ub, (float)(1 - tm.w)), __fmul_rn((float)ua, (float)tm.w));
-        v = __fadd_rn(__fmul_rn((float)vb, (float)(1 - tm.w)), __fmul_rn((float)va, (float)tm.w));
-      } else {
-        u = __dadd_rn(__dmul_rn(ub, 1 - tm.w), __dmul_rn(ua, tm.w));
-        v = __dadd_rn(__dmul_rn(vb, 1 - tm.w), __dmul_rn(va, tm.w));
+    bool from_tile = false;
+    if (TILE && tile_ok) {   // both corners of both axes inside the staged rectangle?
+      const Axis ay = axis_fp(yi, geo.ny), ax = axis_fp(xi, geo.nx);
+      const int lx0 = ax.i0 - T.x0, lx1 = ax.i1 - T.x0, ly0 = ay.i0 - T.y0, ly1 = ay.i1 - T.y0;
+      if (lx0 >= 0 && lx1 < T.w && ly0 >= 0 && ly1 < T.h) {
+        from_tile = true;
+        Foot ft;
+        ft.ty = ay.t; ft.tx = ax.t; ft.wy0 = 1 - ay.t; ft.wx0 = 1 - ax.t;
+        ft.o00 = ft.o01 = ft.o10 = ft.o11 = 0;
+        const FootW fw = foot_weights(ft);
+        TileUV L;
+        L.t = T.t; L.nz = (unsigned)T.nz;
+        const unsigned k0 = IS3D ? (unsigned)zb.iz0 : 0u, nz2 = 2u * (unsigned)T.nz;
+        L.l[0] = (unsigned)(ly0 * T.w + lx0) * nz2 + k0; L.l[1] = (unsigned)(ly0 * T.w + lx1) * nz2 + k0;
+        L.l[2] = (unsigned)(ly1 * T.w + lx0) * nz2 + k0; L.l[3] = (unsigned)(ly1 * T.w + lx1) * nz2 + k0;
+        double ub, vb;
+        uv_level_ld<IS3D, true>(L, 0, s.nz, ft, zb, ub, vb, f32c, fw);
+        u = ub; v = vb;
+        if (tm.a) {
+          double ua, va;
+          uv_level_ld<IS3D, true>(L, 1, s.nz, ft, zb, ua, va, f32c, fw);
+          if (f32c) {
+            u = __fadd_rn(__fmul_rn((float)ub, (float)(1 - tm.w)), __fmul_rn((float)ua, (float)tm.w));
+            v = __fadd_rn(__fmul_rn((float)vb, (float)(1 - tm.w)), __fmul_rn((float)va, (float)tm.w));
+          } else {
+            u = __dadd_rn(__dmul_rn(ub, 1 - tm.w), __dmul_rn(ua, tm.w));
+            v = __dadd_rn(__dmul_rn(vb, 1 - tm.w), __dmul_rn(va, tm.w));
+          }
+        }
       }
     }
+    if (!from_tile) {
+      const Foot ft = footprint(yi, xi, geo.ny, geo.nx, (unsigned)geo.rec * 4u);
+      double ub, vb;
+      const FootW fw = foot_weights(ft);
+      uv_level<IS3D, true>(tm.b, s.nz, ft, zb, ub, vb, f32c, fw);
+      u = ub; v = vb;
+      if (tm.a) {
+        double ua, va;
+        uv_level<IS3D, true>(tm.a, s.nz, ft, zb, ua, va, f32c, fw);
+        if (f32c) {
+          u = __fadd_rn(__fmul_rn((float)ub, (float)(1 - tm.w)), __fmul_rn((float)ua, (float)tm.w));
+          v = __fadd_rn(__fmul_rn((float)vb, (float)(1 - tm.w)), __fmul_rn((float)va, (float)tm.w));
+        } else {
+          u = __dadd_rn(__dmul_rn(ub, 1 - tm.w), __dmul_rn(ua, tm.w));
+          v = __dadd_rn(__dmul_rn(vb, 1 - tm.w), __dmul_rn(va, tm.w));
+        }
+      }
+    }
+#else
+    {
+#pragma clang fp contract(fast)
+      const Foot ft = footprint(yi, xi, geo.ny, geo.nx, (unsigned)geo.rec * 4u);
+      const double w00 = ft.wy0 * ft.wx0, w01 = ft.wy0 * ft.tx, w10 = ft.ty * ft.wx0, w11 = ft.ty * ft.tx;
+      if (IS3D) {
+        // levels (iz0, iz0 + 1) = ("above", "below"); clamped at the deepest level both are iz0 + 1
+        const bool same = zb.same && s.nz > 1;
+        const double za = same ? 0.0 : zb.wa, zbw = same ? 1.0 : 1 - zb.wa;
+        const double a00 = w00 * za, a01 = w01 * za, a10 = w10 * za, a11 = w11 * za;
+        const double b00 = w00 * zbw, b01 = w01 * zbw, b10 = w10 * zbw, b11 = w11 * zbw;
+        const unsigned kb = (unsigned)zb.iz0 * 8u;
+        const F4 q00 = ld_off<F4>(tm.b, ft.o00 + kb), q01 = ld_off<F4>(tm.b, ft.o01 + kb);
+        const F4 q10 = ld_off<F4>(tm.b, ft.o10 + kb), q11 = ld_off<F4>(tm.b, ft.o11 + kb);
+        u = fma(q11.z, b11, fma(q10.z, b10, fma(q01.z, b01, fma(q00.z, b00, fma(q11.x, a11, fma(q10.x, a10, fma(q01.x, a01, q00.x * a00)))))));
+        v = fma(q11.w, b11, fma(q10.w, b10, fma(q01.w, b01, fma(q00.w, b00, fma(q11.y, a11, fma(q10.y, a10, fma(q01.y, a01, q00.y * a00)))))));
+        if (tm.a) {
+          const F4 r00 = ld_off<F4>(tm.a, ft.o00 + kb), r01 = ld_off<F4>(tm.a, ft.o01 + kb);
+          const F4 r10 = ld_off<F4>(tm.a, ft.o10 + kb), r11 = ld_off<F4>(tm.a, ft.o11 + kb);
+          const double ua = fma(r11.z, b11, fma(r10.z, b10, fma(r01.z, b01, fma(r00.z, b00, fma(r11.x, a11, fma(r10.x, a10, fma(r01.x, a01, r00.x * a00)))))));
+          const double va = fma(r11.w, b11, fma(r10.w, b10, fma(r01.w, b01, fma(r00.w, b00, fma(r11.y, a11, fma(r10.y, a10, fma(r01.y, a01, r00.y * a00)))))));
+          u = fma(ua - u, tm.w, u);
+          v = fma(va - v, tm.w, v);
+        }
+      } else {
+        const F2 q00 = ld_off<F2>(tm.b, ft.o00), q01 = ld_off<F2>(tm.b, ft.o01);
+        const F2 q10 = ld_off<F2>(tm.b, ft.o10), q11 = ld_off<F2>(tm.b, ft.o11);
+        u = fma(q11.x, w11, fma(q10.x, w10, fma(q01.x, w01, q00.x * w00)));
+        v = fma(q11.y, w11, fma(q10.y, w10, fma(q01.y, w01, q00.y * w00)));
+        if (tm.a) {
+          const F2 r00 = ld_off<F2>(tm.a, ft.o00), r01 = ld_off<F2>(tm.a, ft.o01);
+          const F2 r10 = ld_off<F2>(tm.a, ft.o10), r11 = ld_off<F2>(tm.a, ft.o11);
+          const double ua = fma(r11.x, w11, fma(r10.x, w10, fma(r01.x, w01, r00.x * w00)));
+          const double va = fma(r11.y, w11, fma(r10.y, w10, fma(r01.y, w01, r00.y * w00)));
+          u = fma(ua - u, tm.w, u);
+          v = fma(va - v, tm.w, v);
+        }
+      }
+    }
+#endif
     if (ODR_PROJ_ROTATES(PROJ)) {
       double sn, cs;
       rotation_cs(s.proj, x, y, cs, sn);

@@ -367,6 +367,91 @@ __device__ __forceinline__ void geod_direct_sc(const GeodOrigin &o, double salp1
     lat2 = atan2d(sbet2, den);
 }
 
+// ---------------------------------------------------------------- short steps: Legendre series
+// A particle-step moves an element by metres to a few kilometres, 1e-6 ... 1e-3 of the earth radius.  For such
+// steps the direct problem is the Taylor series of the geodesic equations on the ellipsoid about the start point
+//   dphi/ds = cos(alpha) V^3 / c,  dlam/ds = sin(alpha) V / (c cos phi),  dalpha/ds = sin(alpha) tan(phi) V / c
+// (V^2 = 1 + eta^2, eta^2 = e'^2 cos^2 phi, c = a / sqrt(1 - e^2) -- Legendre's series, e.g. Rapp, Geometric
+// Geodesy I, sec. 6.3; the coefficients below were re-derived symbolically to 4th order, tools/derive_geodesic_series.py):
+//   dphi / V^2   = u + a20 u^2 + a02 v^2 + a30 u^3 + a12 u v^2 + a40 u^4 + a22 u^2 v^2 + a04 v^4
+//   dlam cos phi = v (1 + b11 u + b21 u^2 + b31 u^3 + (b03 + b13 u) v^2)
+// with u = s cos(alpha) / N, v = s sin(alpha) / N (N = a / sqrt(1 - e^2 sin^2 phi)), t = tan phi:
+//   a20 = -3/2 eta^2 t, a02 = -t/2, a30 = eta^2 (5 eta^2 t^2 - eta^2 + t^2 - 1) / 2, a12 = (9 eta^2 t^2 - eta^2 - 3 t^2 - 1) / 6,
+//   a40 = -eta^2 t (35 eta^4 t^2 - 19 eta^4 + 15 eta^2 t^2 - 23 eta^2 - 4) / 8,
+//   a22 = -t (45 eta^4 t^2 - 17 eta^4 - 9 eta^2 t^2 - 13 eta^2 + 6 t^2 + 4) / 12, a04 = -t a12 / 4,
+//   b11 = t, b21 = (eta^2 + 3 t^2 + 1) / 3, b03 = -t^2 / 3, b31 = t (-eta^4 + eta^2 + 3 t^2 + 2) / 3, b13 = -t b21.
+// The coefficients depend on the start latitude only: they are formed once per particle and step and serve all
+// Runge-Kutta stage positions and the final move (~30 instructions each instead of ~275 for the full solution).
+// Truncation: O(q^5), q = (s / N) max(1, |t|); measured against the full solution (tests/test_gpu_parity.py,
+// tools/derive_geodesic_series.py --check): < 3e-12 deg for q <= kGeodLocalQ, i.e. steps up to 16 km at low
+// latitudes, 9 km at 60 deg and 2.8 km at 80 deg.  Longer steps and start points within 1 deg of a pole take the full solution (geod_direct_sc).
+static constexpr double kGeodLocalQ = 2.5e-3;
+struct GeodLocal {
+  double lat1, lon1n;        // start point (longitude normalised)
+  double iN, qs;             // 1 / N; max(1, |t|) (validity scale), infinity within 1 deg of a pole
+  double kphi, klam;         // V^2 * 180/pi;  180/pi / cos(phi)
+  double t, a20, a30, a12, a40, a22, b21, b31;
+};
+
+__device__ __forceinline__ GeodLocal geod_local_origin(double lat1, double lon1) {
+#pragma clang fp contract(fast)
+  const GeodConst &g = c_geod;
+  GeodLocal L;
+  if (fabs(lat1) > 90) lat1 = __builtin_nan("");
+  L.lat1 = lat1;
+  L.lon1n = ang_normalize(lon1);
+  double sphi, cphi;
+  sincosd(ang_round(lat1), sphi, cphi);
+  const double ic = fast_rcp(fmax(kTiny, cphi));
+  const double t = sphi * ic, t2 = t * t;
+  const double h = g.ep2 * cphi * cphi, h2 = h * h;
+  L.iN = fast_sqrt(1 - g.e2 * sphi * sphi) * (1.0 / g.a);
+  L.qs = fabs(lat1) < 89.0 ? fmax(1.0, fabs(t)) : __builtin_inf();
+  L.kphi = (1 + h) * kRad2Deg;
+  L.klam = ic * kRad2Deg;
+  L.t = t;
+  L.a20 = -1.5 * h * t;
+  L.a30 = 0.5 * h * (t2 * (5 * h + 1) - h - 1);
+  L.a12 = (t2 * (9 * h - 3) - h - 1) * (1.0 / 6);
+  L.a40 = -0.125 * h * t * (t2 * (35 * h2 + 15 * h) - 19 * h2 - 23 * h - 4);
+  L.a22 = (-1.0 / 12) * t * (t2 * (45 * h2 - 9 * h + 6) - 17 * h2 - 13 * h + 4);
+  L.b21 = (h + 3 * t2 + 1) * (1.0 / 3);
+  L.b31 = (1.0 / 3) * t * (h - h2 + 3 * t2 + 2);
+  return L;
+}
+
+// the full solution for the steps the series does not cover (rare: kept out of line)
+__device__ __attribute__((noinline)) void geod_local_far(double lat1, double lon1n, double x, double y, double &lat2,
+                                                         double &lon2) {
+  const GeodOrigin o = geod_origin(lat1, lon1n);
+  const double s = sqrt(x * x + y * y);
+  double salp = 0.0, calp = 1.0;
+  if (s > 0) { salp = x / s; calp = y / s; }
+  geod_direct_sc(o, salp, calp, s, lat2, lon2);
+}
+
+// end point of the geodesic that starts at the origin of L with azimuth atan2(x, y) and length hypot(x, y):
+// x = east, y = north component of the step in metres
+__device__ __forceinline__ void geod_local_move(const GeodLocal &L, double x, double y, double &lat2, double &lon2) {
+#pragma clang fp contract(fast)
+  const double u = y * L.iN, v = x * L.iN;
+  const double u2 = u * u, v2 = v * v;
+  if (!((u2 + v2) * (L.qs * L.qs) <= kGeodLocalQ * kGeodLocalQ)) {   // also NaN steps
+    if (u2 + v2 == u2 + v2 && L.lat1 == L.lat1) { geod_local_far(L.lat1, L.lon1n, x, y, lat2, lon2); return; }
+    lat2 = lon2 = __builtin_nan("");
+    return;
+  }
+  const double t = L.t;
+  const double a02 = -0.5 * t, a04 = -0.25 * t * L.a12, b03 = (-1.0 / 3) * t * t, b13 = -t * L.b21;
+  const double pu = fma(fma(L.a40, u, L.a30), u, L.a20);                       // a20 + a30 u + a40 u^2
+  const double pv = fma(a04, v2, fma(fma(L.a22, u, L.a12), u, a02));           // a02 + a12 u + a22 u^2 + a04 v^2
+  const double p = fma(pv, v2, fma(pu, u2, u));
+  const double lu = fma(fma(fma(L.b31, u, L.b21), u, t), u, 1.0);              // 1 + b11 u + b21 u^2 + b31 u^3
+  const double l = v * fma(fma(b13, u, b03), v2, lu);
+  lat2 = fma(L.kphi, p, L.lat1);
+  lon2 = ang_normalize(fma(L.klam, l, L.lon1n));
+}
+
 // azimuth in degrees (float64 callers: advect_wind, stokes_drift, horizontal diffusion)
 __device__ __forceinline__ void geod_direct_from(const GeodOrigin &o, double azi1, double s12,
                                                   double &lat2, double &lon2) {

@@ -22,7 +22,10 @@ constexpr int BLOCK = ODR_BLOCK;  // threads per workgroup (A/B builds may overr
 #endif
 // minimum waves per SIMD requested for the projected-reader instantiations (their stereographic forward /
 // rotation code otherwise takes ~185 VGPRs = 2 waves per SIMD)
-#define ODR_WAVES(PROJ) ((PROJ) == PROJ_LATLONG ? 1 : ODR_POLAR_WAVES)
+#ifndef ODR_LATLONG_WAVES
+#define ODR_LATLONG_WAVES 1
+#endif
+#define ODR_WAVES(PROJ) ((PROJ) == PROJ_LATLONG ? ODR_LATLONG_WAVES : ODR_POLAR_WAVES)
 
 // XCD-aware block order.  Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2), so with
 // the natural order the eight L2s all stream the whole (spatially sorted) particle range and every field tile is
@@ -88,17 +91,36 @@ __device__ __forceinline__ void azimuth_sincos_f32(float xv, float yv, double &s
   calp = fma(-st, delta, ct * c2);
 }
 
+// Start point of the (up to five) geodesics of one particle-step and one step along it.  Default: Legendre series
+// about the start point (odr_geodesic.hip.h), the full Karney solution only for steps it does not cover.
+// -DODR_FULL_GEODESIC: every step through the full solution (A/B measurements, strict build).
+#ifdef ODR_FULL_GEODESIC
+typedef GeodOrigin GeodStart;
+__device__ __forceinline__ GeodStart geod_start(double lat, double lon) { return geod_origin(lat, lon); }
+__device__ __forceinline__ void geod_step(const GeodStart &o, double salp, double calp, double s12, double &lat2,
+                                          double &lon2) {
+  geod_direct_sc(o, salp, calp, s12, lat2, lon2);
+}
+#else
+typedef GeodLocal GeodStart;
+__device__ __forceinline__ GeodStart geod_start(double lat, double lon) { return geod_local_origin(lat, lon); }
+__device__ __forceinline__ void geod_step(const GeodStart &o, double salp, double calp, double s12, double &lat2,
+                                          double &lon2) {
+  geod_local_move(o, s12 * salp, s12 * calp, lat2, lon2);
+}
+#endif
+
 // update_positions (basemodel/__init__.py:4631-4657), float32 velocities
-__device__ __forceinline__ void move_f32_from(const GeodOrigin &o, double &lon, double &lat, float u,
+__device__ __forceinline__ void move_f32_from(const GeodStart &o, double &lon, double &lat, float u,
                                               float v, int moving, double dt) {
   double salp, calp;
   azimuth_sincos_f32(u, v, salp, calp);
   double vel = (double)speed_f32(u, v) * (double)moving;  // f32 * int32 array -> float64
-  geod_direct_sc(o, salp, calp, vel * dt, lat, lon);
+  geod_step(o, salp, calp, vel * dt, lat, lon);
 }
 __device__ __forceinline__ void move_f32(double &lon, double &lat, float u, float v, int moving,
                                          double dt) {
-  GeodOrigin o = geod_origin(lat, lon);
+  GeodStart o = geod_start(lat, lon);
   move_f32_from(o, lon, lat, u, v, moving, dt);
 }
 // float64 velocities (advect_wind / stokes_drift / horizontal_diffusion callers)
@@ -118,21 +140,31 @@ __device__ __forceinline__ void move_f64(double &lon, double &lat, double u, dou
     sincosd(ang_round(az), salp, calp);
   }
   double vel = sqrt(__dadd_rn(__dmul_rn(u, u), __dmul_rn(v, v))) * (double)moving;
-  GeodOrigin o = geod_origin(lat, lon);
+  GeodStart o = geod_start(lat, lon);
   double lo, la;
-  geod_direct_sc(o, salp, calp, vel * dt, la, lo);
+  geod_step(o, salp, calp, vel * dt, la, lo);
   lon = lo;
   lat = la;
 }
 
-// RK sub-stage position: geod.fwd(lon, lat, az, speed*dt*.5) with dist in float32
-// (physics_methods.py:629-635); the origin is shared by all stages of a particle
-__device__ __forceinline__ void stage_pos(const GeodOrigin &o, float u, float v, float dtf,
+// RK sub-stage position: geod.fwd(lon, lat, az, speed*dt*.5) with az and dist in float32 (physics_methods.py:629-635);
+// the start point is shared by all stages of a particle.
+// -DODR_DIRECT_STAGE_STEP (measured, not the default): the stage step taken directly along (u, v) dt/2 without the
+// float32 azimuth / distance emulation -- no arctan2, no square root.  A stage position only matters through the
+// velocity sampled there and the two roundings move it by < 1e-4 m, but on strongly sheared fields the sampled
+// float32 velocity then differs in the last bit often enough to show: up to 9e-10 deg per step against the oracle in
+// tests/test_gpu_parity.py, for 0.025 ms of the 1.7 ms C3 step (profiles/r02_ab_variants.txt).
+__device__ __forceinline__ void stage_pos(const GeodStart &o, float u, float v, float dtf,
                                           double &lon2, double &lat2) {
+#if defined(ODR_FULL_GEODESIC) || !defined(ODR_DIRECT_STAGE_STEP)
   double salp, calp;
   azimuth_sincos_f32(u, v, salp, calp);
   float dist = __fmul_rn(__fmul_rn(speed_f32(u, v), dtf), 0.5f);
-  geod_direct_sc(o, salp, calp, (double)dist, lat2, lon2);
+  geod_step(o, salp, calp, (double)dist, lat2, lon2);
+#else
+  const double hd = 0.5 * (double)dtf;
+  geod_local_move(o, (double)u * hd, (double)v * hd, lat2, lon2);
+#endif
 }
 
 // --------------------------------------------------------------- random numbers
@@ -263,7 +295,7 @@ __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W
   float f = __fmul_rn(factor, p.cdf[i]);  // factor*cdf, float32
   int moving = p.moving[i];
   float fu, fv;
-  GeodOrigin o = geod_origin(lat, lon);
+  GeodStart o = geod_start(lat, lon);
   if (SCHEME == 0) {
     fu = __fmul_rn(f, u1);
     fv = __fmul_rn(f, v1);
@@ -297,13 +329,14 @@ __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W
 
 // fast version: (u,v) from one gridded reader, interleaved z-innermost blocks, host-resolved
 // time brackets (odr_field.hip.h "fast (u,v) path")
-template <int SCHEME, int PROJ, bool IS3D, bool NOISE>
+template <int SCHEME, int PROJ, bool IS3D, bool NOISE, bool TILE = false>
 __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBlock &geo, double &lon, double &lat,
                                                  double z, float u1, float v1, float f, int moving, double dt,
                                                  const UVTime &th, const UVTime &tf, float fbu, float fbv,
-                                                 const StageNoise &N, long long i, long long n, int id) {
+                                                 const StageNoise &N, long long i, long long n, int id,
+                                                 const TileView &T = TileView(), bool tile_h = false, bool tile_f = false) {
   float fu, fv;
-  GeodOrigin o = geod_origin(lat, lon);
+  GeodStart o = geod_start(lat, lon);
   if (SCHEME == 0) {
     fu = __fmul_rn(f, u1);
     fv = __fmul_rn(f, v1);
@@ -315,7 +348,7 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
     double lon2, lat2;
     float u2, v2;
     stage_pos(o, u1, v1, dtf, lon2, lat2);
-    uv_sample_fast<PROJ, IS3D>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u2, v2);
+    uv_sample_fast<PROJ, IS3D, TILE>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u2, v2, T, tile_h);
     if (NOISE) add_current_noise(N, 1, i, n, id, u2, v2);
     if (SCHEME == 1) {
       fu = __fmul_rn(f, u2);
@@ -323,10 +356,10 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
     } else {
       float u3, v3, u4, v4;
       stage_pos(o, u2, v2, dtf, lon2, lat2);
-      uv_sample_fast<PROJ, IS3D>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u3, v3);
+      uv_sample_fast<PROJ, IS3D, TILE>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u3, v3, T, tile_h);
       if (NOISE) add_current_noise(N, 2, i, n, id, u3, v3);
       stage_pos(o, u3, v3, dtf, lon2, lat2);
-      uv_sample_fast<PROJ, IS3D>(s, geo, tf, lon2, lat2, z, zb, fbu, fbv, u4, v4);
+      uv_sample_fast<PROJ, IS3D, TILE>(s, geo, tf, lon2, lat2, z, zb, fbu, fbv, u4, v4, T, tile_f);
       if (NOISE) add_current_noise(N, 3, i, n, id, u4, v4);
       fu = __fmul_rn(rk4_mix(u1, u2, u3, u4), f);
       fv = __fmul_rn(rk4_mix(v1, v2, v3, v4), f);
@@ -369,12 +402,101 @@ struct StepDesc {
   int main_noise, pad;              // uncertainty of the main-loop sample of the current (StageNoise call 0)
 };
 
-template <int SCHEME, int PROJ, bool IS3D, bool NOISE>
+// TILE: the (u,v) node records around the workgroup's particles are staged in LDS for the stage samples (odr_field.hip.h
+// "LDS field tile"); tile_nodes = capacity of the dynamic LDS allocation in nodes.
+template <int SCHEME, int PROJ, bool IS3D, bool NOISE, bool TILE = false>
 __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
                                                      StepDesc S, double dt, float factor, UVTime th, UVTime tf,
-                                                     unsigned long long *n_hit, StageNoise N) {
+                                                     unsigned long long *n_hit, StageNoise N, int tile_nodes = 0) {
   long long i = pid();
   bool hit = false;
+  TileView T;
+  T.t = nullptr; T.x0 = T.y0 = T.w = T.h = 0; T.nz = 1;
+  bool tile_h = false, tile_f = false;
+  if (TILE) {
+    extern __shared__ __attribute__((aligned(16))) char tile_mem[];
+    __shared__ int s_red[2][BLOCK / 64][4];
+    __shared__ int s_anchor[2];
+    const DevSource &s = W->src[G.sid];
+    const DevBlock &geo = s.slot[S.geo_slot_uv];
+    const int tid = threadIdx.x, wv = tid >> 6;
+    // cell of this particle's position in the block's index space (the main-loop sample position)
+    int cx = 0x7fffffff, cy = 0x7fffffff;
+    if (i < p.n) {
+      double lon = p.lon[i], lat = p.lat[i], x, y;
+      if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
+      else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
+      if (PROJ == PROJ_LATLONG) { x = lon; y = lat; }
+      else if (PROJ == PROJ_CURVILINEAR) curvi_locate(s.proj, lon, lat, x, y);
+      else proj_fwd(s.proj, lon, lat, x, y);
+      if (s.mod360_x) x = np_mod(x, 360.0);
+      const double fx = floor((x - geo.x0) * geo.ixspan * (double)(geo.nx - 1));
+      const double fy = floor((y - geo.y0) * geo.iyspan * (double)(geo.ny - 1));
+      if (fx >= 0 && fx <= (double)(geo.nx - 1) && fy >= 0 && fy <= (double)(geo.ny - 1)) { cx = (int)fx; cy = (int)fy; }
+    }
+    const bool have = cx != 0x7fffffff;
+    auto block_minmax = [&](int slot, bool use, int &mnx, int &mxx, int &mny, int &mxy) {
+      int a = use ? cx : 0x7fffffff, b = use ? cx : -0x7fffffff, c = use ? cy : 0x7fffffff, d = use ? cy : -0x7fffffff;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        a = min(a, __shfl_xor(a, o, 64)); b = max(b, __shfl_xor(b, o, 64));
+        c = min(c, __shfl_xor(c, o, 64)); d = max(d, __shfl_xor(d, o, 64));
+      }
+      if ((tid & 63) == 0) { s_red[slot][wv][0] = a; s_red[slot][wv][1] = b; s_red[slot][wv][2] = c; s_red[slot][wv][3] = d; }
+      if (slot == 0 && tid == BLOCK / 2) { s_anchor[0] = cx; s_anchor[1] = cy; }
+      __syncthreads();
+      mnx = s_red[slot][0][0]; mxx = s_red[slot][0][1]; mny = s_red[slot][0][2]; mxy = s_red[slot][0][3];
+#pragma unroll
+      for (int k = 1; k < BLOCK / 64; ++k) {
+        mnx = min(mnx, s_red[slot][k][0]); mxx = max(mxx, s_red[slot][k][1]);
+        mny = min(mny, s_red[slot][k][2]); mxy = max(mxy, s_red[slot][k][3]);
+      }
+    };
+    int mnx, mxx, mny, mxy;
+    block_minmax(0, have, mnx, mxx, mny, mxy);
+    // nodes needed: one cell of margin around the cells (a stage position is < 1 cell from the particle) plus the
+    // upper corner of the footprint: [mnx - 1, mxx + 2] x [mny - 1, mxy + 2]
+    bool any = mxx >= mnx;
+    if (any && (long long)(mxx - mnx + 4) * (long long)(mxy - mny + 4) > (long long)tile_nodes) {
+      // the workgroup straddles two sort tiles or holds stragglers: keep the cluster around its middle particle
+      const int ax = s_anchor[0], ay = s_anchor[1];
+      const bool nearby = have && ax != 0x7fffffff && abs(cx - ax) <= 5 && abs(cy - ay) <= 3;
+      block_minmax(1, nearby, mnx, mxx, mny, mxy);
+      any = mxx >= mnx && (long long)(mxx - mnx + 4) * (long long)(mxy - mny + 4) <= (long long)tile_nodes;
+    }
+    if (any) {
+      const int x0 = max(mnx - 1, 0), x1 = min(mxx + 2, geo.nx - 1), y0 = max(mny - 1, 0), y1 = min(mxy + 2, geo.ny - 1);
+      T.t = (const F2a *)tile_mem;
+      T.x0 = x0; T.y0 = y0; T.w = x1 - x0 + 1; T.h = y1 - y0 + 1;
+      T.nz = IS3D ? s.nz : 1;
+      // the tile holds the time bracket of the half-step stages; the full-step stage uses it when its bracket is the same
+      tile_h = true;
+      tile_f = tf.b == th.b && (tf.a == th.a || tf.a == nullptr);
+      // cooperative load, coalesced along the node records: `lpn` lanes per node (the next power of two >= the
+      // 2 nz (u,v) pairs of a node), BLOCK / lpn nodes per sweep; the node's (column, row) advances without divisions
+      const int per = 2 * T.nz, nodes = T.w * T.h;
+      int lpn = 2;
+      while (lpn < per) lpn <<= 1;
+      const int nps = BLOCK / lpn, r = tid & (lpn - 1);
+      int node = tid / lpn;                       // lpn is a power of two: a shift
+      int ny_ = node / T.w, nx_ = node - ny_ * T.w;   // once per thread
+      const int tm = r >= T.nz ? 1 : 0, k = r - tm * T.nz;
+      const float *src = tm ? (th.a ? th.a : th.b) : th.b;
+      const unsigned rec_bytes = (unsigned)geo.rec * 4u;
+      F2a *dst = (F2a *)tile_mem;
+      for (; node < nodes; node += nps) {
+        if (r < per) {
+          const unsigned off = __umul24(__umul24((unsigned)(y0 + ny_), (unsigned)geo.nx) + (unsigned)(x0 + nx_), rec_bytes) + 8u * (unsigned)k;
+          const F2 v = ld_off<F2>(src, off);
+          F2a w; w.x = v.x; w.y = v.y;
+          dst[node * per + r] = w;
+        }
+        nx_ += nps;
+        while (nx_ >= T.w) { nx_ -= T.w; ++ny_; }
+      }
+    }
+    __syncthreads();
+  }
   if (i < p.n) {
     double lon = p.lon[i], lat = p.lat[i];
     const double z = p.z[i];
@@ -382,11 +504,13 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevW
     env_group_fast<PROJ>(*W, G, lon, lat, z, out);
     const int id = NOISE ? p.id[i] : 0;
     if (NOISE && S.main_noise) add_current_noise(N, 0, i, p.n, id, out[0], out[1]);
+#ifndef ODR_ABLATE_STORES   // what-if build (tools/ab_bench.sh)
 #pragma unroll
     for (int k = 0; k < MAXG; ++k)
       if (k < G.nv) p.env[G.var[k]][i] = out[k];
     p.slon[i] = lon;
     p.slat[i] = lat;
+#endif
     int moving = p.moving[i];
     int st = p.status[i];
     double zz = z;
@@ -437,12 +561,14 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevW
     }
     // deactivated (now or earlier, not yet compacted): the reference removes it before update() -- it does not move
     const bool skip = st != 0;
+#ifndef ODR_ABLATE_STORES
     if (S.store_previous) { p.plon[i] = lon; p.plat[i] = lat; }
+#endif
     if (!skip) {
       const DevSource &s = W->src[G.sid];
-      advect_grid_body<SCHEME, PROJ, IS3D, NOISE>(s, s.slot[S.geo_slot_uv], lon, lat, zz, out[0], out[1],
-                                                  __fmul_rn(factor, p.cdf[i]), moving, dt, th, tf, W->fallback[VAR_U],
-                                                  W->fallback[VAR_V], N, i, p.n, id);
+      advect_grid_body<SCHEME, PROJ, IS3D, NOISE, TILE>(s, s.slot[S.geo_slot_uv], lon, lat, zz, out[0], out[1],
+                                                        __fmul_rn(factor, p.cdf[i]), moving, dt, th, tf, W->fallback[VAR_U],
+                                                        W->fallback[VAR_V], N, i, p.n, id, T, tile_h, tile_f);
     }
     p.lon[i] = lon;
     p.lat[i] = lat;
@@ -485,7 +611,7 @@ __global__ __launch_bounds__(BLOCK) void k_advect_gyre(const DevWorld *__restric
   const float u1 = p.env[VAR_U][i], v1 = p.env[VAR_V][i];
   const float f = __fmul_rn(factor, p.cdf[i]);
   float fu, fv;
-  GeodOrigin o = geod_origin(lat, lon);
+  GeodStart o = geod_start(lat, lon);
   if (SCHEME == 0) {
     fu = __fmul_rn(f, u1);
     fv = __fmul_rn(f, v1);
@@ -786,6 +912,16 @@ namespace odr {
 // free for per-thread dynamic level indices) together with -dK/dz per level, and the whole
 // ntimes_mix random walk runs out of registers + LDS.  vertical_advection (:315-350) is fused
 // at the end when `vadv` >= 0 (same particle, same z).
+// Uniform number of mixing sub-step `it` (ODR_RNG_DEVICE): one Philox4x32-10 block serves FOUR sub-steps -- each 32-bit
+// word is one uniform (x + 1/2) 2^-32 in (0, 1), symmetric about 1/2; the random-walk displacement R = 2u - 1 is
+// resolved to 5e-10 of its range.  (Two 53-bit uniforms per block cost one block per two sub-steps: 45 instead of 25
+// instructions per sub-step.)
+__device__ __forceinline__ double mix_uniform(rocrand_state_philox4x32_10 &st, uint4 &q, int it) {
+  if ((it & 3) == 0) q = rocrand4(&st);
+  const unsigned k = (unsigned)it & 3u;
+  const unsigned x = k == 0 ? q.x : (k == 1 ? q.y : (k == 2 ? q.z : q.w));
+  return ((double)x + 0.5) * 2.3283064365386963e-10;
+}
 __device__ __forceinline__ void kcolumn(const float *__restrict__ col, int nz, float *out /*[MAXNZ]*/) {
   int k = 0;
   for (; k + 4 <= nz; k += 4) {
@@ -902,7 +1038,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
   double wstep = __dmul_rn(__dmul_rn((double)p.tv[i], dt_mix), (double)moving);
   rocrand_state_philox4x32_10 st;
   if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
-  double2 u2 = make_double2(0.0, 0.0);
+  uint4 u4 = make_uint4(0u, 0u, 0u, 0u);
   OilLane oil;
   if (OIL) oil.init(p, i, oa);
   int zi_cur = -1;
@@ -940,10 +1076,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
     }
     double u01;
     if (rng_mode == 1) u01 = huni[(size_t)it * p.n + i];
-    else {  // one Philox4x32-10 block = two float64 uniforms
-      if ((it & 1) == 0) u2 = rocrand_uniform_double2(&st);
-      u01 = (it & 1) ? u2.y : u2.x;
-    }
+    else u01 = mix_uniform(st, u4, it);
     double R = __dsub_rn(__dmul_rn(2.0, u01), 1.0);
     // z - moving*(dKdz*dt_mix - R*sqrt(Kz*|dt_mix|*2/r)) (:527-528)
     z = __dsub_rn(z, __dmul_rn((double)moving, __dsub_rn(dKdt, __dmul_rn(R, sig))));
@@ -1029,23 +1162,27 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__
     const size_t o00 = cov ? ((size_t)ay.i0 * nx + ax.i0) * rec : 0, o01 = cov ? ((size_t)ay.i0 * nx + ax.i1) * rec : 0;
     const size_t o10 = cov ? ((size_t)ay.i1 * nx + ax.i0) * rec : 0, o11 = cov ? ((size_t)ay.i1 * nx + ax.i1) * rec : 0;
     const float *kb = D.kb, *ka = TL ? D.ka : D.kb;
+    // horizontal weights multiplied out once for the whole column (float64; the layer value is rounded to float32 like
+    // the ReaderBlock's: same bits as (v*wy)*wx summed, but for a float64 round-off that reaches the float32 rounding
+    // in ~1e-8 of the values)
+    const double w00 = wy0 * wx0, w01 = wy0 * tx, w10 = ty * wx0, w11 = ty * tx;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const F4 b00 = *(const F4 *)(kb + o00 + 4 * q), b01 = *(const F4 *)(kb + o01 + 4 * q);
       const F4 b10 = *(const F4 *)(kb + o10 + 4 * q), b11 = *(const F4 *)(kb + o11 + 4 * q);
       double v[4];
-      v[0] = (double)bil4(b00.x, b01.x, b10.x, b11.x, wy0, ty, wx0, tx);
-      v[1] = (double)bil4(b00.y, b01.y, b10.y, b11.y, wy0, ty, wx0, tx);
-      v[2] = (double)bil4(b00.z, b01.z, b10.z, b11.z, wy0, ty, wx0, tx);
-      v[3] = (double)bil4(b00.w, b01.w, b10.w, b11.w, wy0, ty, wx0, tx);
+      v[0] = (double)bilw(b00.x, b01.x, b10.x, b11.x, w00, w01, w10, w11);
+      v[1] = (double)bilw(b00.y, b01.y, b10.y, b11.y, w00, w01, w10, w11);
+      v[2] = (double)bilw(b00.z, b01.z, b10.z, b11.z, w00, w01, w10, w11);
+      v[3] = (double)bilw(b00.w, b01.w, b10.w, b11.w, w00, w01, w10, w11);
       if (TL) {
         const F4 a00 = *(const F4 *)(ka + o00 + 4 * q), a01 = *(const F4 *)(ka + o01 + 4 * q);
         const F4 a10 = *(const F4 *)(ka + o10 + 4 * q), a11 = *(const F4 *)(ka + o11 + 4 * q);
         double w[4];
-        w[0] = (double)bil4(a00.x, a01.x, a10.x, a11.x, wy0, ty, wx0, tx);
-        w[1] = (double)bil4(a00.y, a01.y, a10.y, a11.y, wy0, ty, wx0, tx);
-        w[2] = (double)bil4(a00.z, a01.z, a10.z, a11.z, wy0, ty, wx0, tx);
-        w[3] = (double)bil4(a00.w, a01.w, a10.w, a11.w, wy0, ty, wx0, tx);
+        w[0] = (double)bilw(a00.x, a01.x, a10.x, a11.x, w00, w01, w10, w11);
+        w[1] = (double)bilw(a00.y, a01.y, a10.y, a11.y, w00, w01, w10, w11);
+        w[2] = (double)bilw(a00.z, a01.z, a10.z, a11.z, w00, w01, w10, w11);
+        w[3] = (double)bilw(a00.w, a01.w, a10.w, a11.w, w00, w01, w10, w11);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = __dadd_rn(__dmul_rn(v[j], 1 - wgt), __dmul_rn(w[j], wgt));
       }
@@ -1071,7 +1208,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__
   double wstep = __dmul_rn(__dmul_rn((double)p.tv[i], dt_mix), (double)moving);
   rocrand_state_philox4x32_10 st;
   if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
-  double2 u2 = make_double2(0.0, 0.0);
+  uint4 u4 = make_uint4(0u, 0u, 0u, 0u);
   // -dK/dz * dt_mix and sqrt(K |dt_mix| 2 / r) of one level (oceandrift.py:501-502,527-528)
   auto level_terms = [&](int zl, double &dk_dt, double &sg) {
     const double Kz = Kp[zl * BLOCK + tid];
@@ -1118,10 +1255,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__
     if (q < 0 || q > 2) level_terms(zi, dKdt, sig);
     double u01;
     if (rng_mode == 1) u01 = huni[(size_t)it * p.n + i];
-    else {  // one Philox4x32-10 block = two float64 uniforms
-      if ((it & 1) == 0) u2 = rocrand_uniform_double2(&st);
-      u01 = (it & 1) ? u2.y : u2.x;
-    }
+    else u01 = mix_uniform(st, u4, it);
     double R = __dsub_rn(__dmul_rn(2.0, u01), 1.0);
     z = __dsub_rn(z, __dmul_rn((double)moving, __dsub_rn(dKdt, __dmul_rn(R, sig))));
     if (z >= 0) z = -z;
@@ -1204,7 +1338,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_wind(PView p, const double *__re
   double wstep = __dmul_rn(__dmul_rn((double)p.tv[i], dt_mix), (double)moving);
   rocrand_state_philox4x32_10 st;
   if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
-  double2 u2 = make_double2(0.0, 0.0);
+  uint4 u4 = make_uint4(0u, 0u, 0u, 0u);
   OilLane oil;
   if (OIL) oil.init(p, i, oa);
   int zc = -1;
@@ -1230,10 +1364,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_wind(PView p, const double *__re
     }
     double u01;
     if (rng_mode == 1) u01 = huni[(size_t)it * p.n + i];
-    else {
-      if ((it & 1) == 0) u2 = rocrand_uniform_double2(&st);
-      u01 = (it & 1) ? u2.y : u2.x;
-    }
+    else u01 = mix_uniform(st, u4, it);
     const double R = __dsub_rn(__dmul_rn(2.0, u01), 1.0);
     z = __dsub_rn(z, __dmul_rn((double)moving, __dsub_rn(dKdt, __dmul_rn(R, sig))));
     if (z >= 0) z = -z;

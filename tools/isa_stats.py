@@ -17,7 +17,7 @@ def main():
         out = os.path.join(td, 'k.s')
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off',
                                '-S', '--cuda-device-only', '-I', os.path.join(ROOT, 'include'),
-                               os.path.join(ROOT, 'opendrift_amd/csrc/odrift.hip'), '-o', out])
+                               os.path.join(ROOT, 'opendrift_amd/csrc', os.environ.get('ODR_TU', 'odr_step.hip')), '-o', out] + os.environ.get('ODR_FLAGS', '').split())
         txt = open(out).read()
     cur, stats, meta = None, collections.OrderedDict(), {}
     for line in txt.splitlines():
