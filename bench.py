@@ -142,8 +142,12 @@ class Workload:
             P.advect('runge-kutta4', t, self.dt)
         elif self.name == 'c3':
             if self.fused:
+                # one call for the loop body up to and including OceanDrift.update(): sample, coastline, sea floor, age,
+                # previous state, RK4 advect_ocean_current, vertical_mixing, vertical_advection
                 P.env_coast_advect(self.vars, t, self.scheme, self.dt, coastline='previous', store_previous=True,
-                                   count=False, seafloor=True, age_dt=self.dt)
+                                   count=False, seafloor=True, age_dt=self.dt,
+                                   vmix=dict(dt_mix=self.dt_mix, step=k, vertical_advection=False))
+                return
             else:
                 P.env_sample(self.vars, t)
                 P.coastline('previous')

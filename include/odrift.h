@@ -223,6 +223,17 @@ typedef struct {              /* optional bookkeeping of the same loop body, bet
                                * 0: not part of this call */
   int32_t main_noise;        /* 1: add the armed current uncertainty (odr_advect_set_noise) to the sampled current
                               * right after the sample, like get_environment does (environment.py:869-886) */
+  /* OceanDrift.vertical_mixing (+ vertical_advection) of the same step as part of this call: what
+   * odr_vmix_fuse_vertical_advection + odr_vmix(t_epoch, dt, vmix_dt_mix, vmix_at_surface, ODR_RNG_DEVICE, NULL,
+   * vmix_step) would do after it (vertical mixing reads the environment of the step start and changes z only, so it
+   * commutes with the horizontal movers).  When the diffusivity comes from the gridded reader of the current the
+   * mixing runs inside the same launch (k_step_grid<..., MIXQ>), otherwise the two calls are made in sequence. */
+  int32_t vmix;              /* 0: not part of this call */
+  int32_t vmix_at_surface;   /* drift:vertical_mixing_at_surface */
+  int32_t vmix_vadv;         /* vertical advection after the mixing: -1 none, 0 below the surface, 1 including it */
+  int32_t pad;
+  double vmix_dt_mix;        /* vertical_mixing:timestep */
+  uint64_t vmix_step;        /* Philox offset (the model step number) */
 } odr_step_extras;
 int odr_env_coast_advect(odr_ctx *ctx, odr_particles *p, int nvars, const int32_t *var_ids, double t_epoch,
                          int coastline_action, int stranded_code, int seeded_on_land_code,

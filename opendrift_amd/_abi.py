@@ -34,7 +34,9 @@ HIST_PROPERTY0 = 2000
 
 class StepExtras(C.Structure):   # odr_step_extras
     _fields_ = [('seafloor_action', C.c_int32), ('retired_code', C.c_int32), ('age_dt', C.c_double),
-                ('max_age_seconds', C.c_double), ('missing_code', C.c_int32), ('main_noise', C.c_int32)]
+                ('max_age_seconds', C.c_double), ('missing_code', C.c_int32), ('main_noise', C.c_int32),
+                ('vmix', C.c_int32), ('vmix_at_surface', C.c_int32), ('vmix_vadv', C.c_int32), ('pad', C.c_int32),
+                ('vmix_dt_mix', C.c_double), ('vmix_step', C.c_uint64)]
 ANALYTIC_DOUBLE_GYRE, ANALYTIC_OSCILLATING = 1, 2
 
 

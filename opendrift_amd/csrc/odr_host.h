@@ -156,6 +156,34 @@ static inline UVTime uv_time(const DevSource &s, double t) {
 }
 
 
+// The fast column path of vertical mixing (k_vmix_col, and the mixing fused into k_step_grid): K from one gridded
+// reader with a plain z-innermost array on every resident level of the same geometry.  Fills D for time t.
+static inline bool build_vmix_desc(const odr_ctx *c, double t, VMixDesc &D) {
+  memset(&D, 0, sizeof D);
+  int ksid = -1, nzp = 1;
+  for (int k = 0; k < c->hw.nlist[VAR_KZ]; ++k)
+    if (c->hw.src[c->hw.list[VAR_KZ][k]].kind == SRC_GRID) { ksid = c->hw.list[VAR_KZ][k]; break; }
+  if (ksid < 0) return false;
+  const DevSource &s = c->hw.src[ksid];
+  nzp = s.nz > 1 ? s.nz : 1;
+  if (nzp <= 1 || s.nlevels < 1) return false;
+  const DevBlock &g0 = s.slot[s.level_slot[0]];
+  for (int k = 0; k < s.nlevels; ++k) {
+    const DevBlock &bk = s.slot[s.level_slot[k]];
+    if (!bk.data[VAR_KZ] || bk.es[VAR_KZ] != 1 || bk.var_nz[VAR_KZ] != nzp || bk.rec != g0.rec || bk.ny != g0.ny || bk.nx != g0.nx ||
+        bk.x0 != g0.x0 || bk.xspan != g0.xspan || bk.y0 != g0.y0 || bk.yspan != g0.yspan)
+      return false;
+  }
+  int ib, ia;
+  host_bracket(s, t, ib, ia);
+  D.sid = ksid; D.nzp = nzp; D.geo_slot = ib;
+  D.kb = s.slot[ib].data[VAR_KZ];
+  D.ka = ia >= 0 ? s.slot[ia].data[VAR_KZ] : nullptr;
+  D.wgt = ia >= 0 ? (t - s.slot[ib].t) / (s.slot[ia].t - s.slot[ib].t) : 0.0;
+  D.Kfb = c->hw.fallback[VAR_KZ];
+  return true;
+}
+
 // defined in odrift.hip
 bool odr_i_build_env_group(const odr_ctx *c, const int *grp, int ng, double t, EnvGroupDesc &G);
 bool odr_i_uv_fast_source(const odr_ctx *c, int &sid, double t_lo, double t_hi);

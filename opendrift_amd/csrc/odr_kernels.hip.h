@@ -26,6 +26,9 @@ constexpr int BLOCK = ODR_BLOCK;  // threads per workgroup (A/B builds may overr
 #define ODR_LATLONG_WAVES 1
 #endif
 #define ODR_WAVES(PROJ) ((PROJ) == PROJ_LATLONG ? ODR_LATLONG_WAVES : ODR_POLAR_WAVES)
+#ifndef ODR_MIX_WAVES
+#define ODR_MIX_WAVES 1   // the step kernel with the mixing inside: 129 VGPRs (3 waves per SIMD); held at 128 (= 4) it is slower still
+#endif
 
 // XCD-aware block order.  Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2), so with
 // the natural order the eight L2s all stream the whole (spatially sorted) particle range and every field tile is
@@ -218,6 +221,178 @@ __device__ __forceinline__ void add_current_noise(const StageNoise &N, int call,
   }
 }
 
+// ---- vertical mixing on a K column in LDS: device functions shared by k_vmix_col (odr_mix.hip) and the fused
+// step + mixing kernel k_step_grid<..., MIXQ> (odr_step_mix.hip)
+// Uniform number of mixing sub-step `it` (ODR_RNG_DEVICE): one Philox4x32-10 block serves FOUR sub-steps -- each 32-bit
+// word is one uniform (x + 1/2) 2^-32 in (0, 1), symmetric about 1/2; the random-walk displacement R = 2u - 1 is
+// resolved to 5e-10 of its range.  (Two 53-bit uniforms per block cost one block per two sub-steps: 45 instead of 25
+// instructions per sub-step.)
+__device__ __forceinline__ double mix_uniform(rocrand_state_philox4x32_10 &st, uint4 &q, int it) {
+  if ((it & 3) == 0) q = rocrand4(&st);
+  const unsigned k = (unsigned)it & 3u;
+  const unsigned x = k == 0 ? q.x : (k == 1 ? q.y : (k == 2 ? q.z : q.w));
+  return ((double)x + 0.5) * 2.3283064365386963e-10;
+}
+// Fast version for the common case -- the diffusivity comes from one gridded reader with a
+// plain (not interleaved) z-innermost K array.  The host resolves source, time bracket and
+// weight (VMixDesc); NQ = number of 4-level quads per column is a compile-time constant, so the
+// 8 column gathers are straight-line 16-byte loads that are all in flight together (the generic
+// kernel's run-time loops serialise them: one memory round trip per load), the level
+// boundaries live in scalar registers and the np.gradient divisors are host constants.
+struct VMixDesc {
+  int sid, nzp, geo_slot, pad;
+  const float *kb, *ka;  // K arrays of the bracketing time levels (ka == nullptr: on a time level)
+  double wgt;            // weight_after (structured.py:353-354)
+  float Kfb, pad2;
+};
+
+// K column of one particle at (lon, lat) -> Kp[level][tid] (LDS), time-interpolated like the ReaderBlock's profiles
+template <int NQ, bool TL>
+__device__ __forceinline__ void vmix_col_fill(const DevSource &s, const VMixDesc &D, double lon, double lat, double *Kp,
+                                              int tid) {
+  const double Kfb = (double)D.Kfb;
+  double x, y;
+  if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
+  else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
+  proj_fwd_rt(s.proj, lon, lat, x, y);
+  const bool cov = x >= s.xmin && x <= s.xmax && y >= s.ymin && y <= s.ymax;
+  if (s.mod360_x) x = np_mod(x, 360.0);
+  const DevBlock &bb = s.slot[D.geo_slot];
+  const double xi = __dmul_rn(div_cr(x - bb.x0, bb.xspan, bb.ixspan), (double)(bb.nx - 1));
+  const double yi = __dmul_rn(div_cr(y - bb.y0, bb.yspan, bb.iyspan), (double)(bb.ny - 1));
+  const int ny = bb.ny, nx = bb.nx;
+  const Axis ay = axis_fp(yi, ny), ax = axis_fp(xi, nx);
+  const double ty = ay.t, tx = ax.t, wy0 = 1 - ty, wx0 = 1 - tx, wgt = D.wgt;
+  // uncovered particles gather node (0,0) and discard it: keeps the loads unconditional
+  const size_t rec = (size_t)bb.rec;
+  const size_t o00 = cov ? ((size_t)ay.i0 * nx + ax.i0) * rec : 0, o01 = cov ? ((size_t)ay.i0 * nx + ax.i1) * rec : 0;
+  const size_t o10 = cov ? ((size_t)ay.i1 * nx + ax.i0) * rec : 0, o11 = cov ? ((size_t)ay.i1 * nx + ax.i1) * rec : 0;
+  const float *kb = D.kb, *ka = TL ? D.ka : D.kb;
+  // horizontal weights multiplied out once for the whole column (float64; the layer value is rounded to float32 like
+  // the ReaderBlock's: same bits as (v*wy)*wx summed, but for a float64 round-off that reaches the float32 rounding
+  // in ~1e-8 of the values)
+  const double w00 = wy0 * wx0, w01 = wy0 * tx, w10 = ty * wx0, w11 = ty * tx;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const F4 b00 = *(const F4 *)(kb + o00 + 4 * q), b01 = *(const F4 *)(kb + o01 + 4 * q);
+    const F4 b10 = *(const F4 *)(kb + o10 + 4 * q), b11 = *(const F4 *)(kb + o11 + 4 * q);
+    double v[4];
+    v[0] = (double)bilw(b00.x, b01.x, b10.x, b11.x, w00, w01, w10, w11);
+    v[1] = (double)bilw(b00.y, b01.y, b10.y, b11.y, w00, w01, w10, w11);
+    v[2] = (double)bilw(b00.z, b01.z, b10.z, b11.z, w00, w01, w10, w11);
+    v[3] = (double)bilw(b00.w, b01.w, b10.w, b11.w, w00, w01, w10, w11);
+    if (TL) {
+      const F4 a00 = *(const F4 *)(ka + o00 + 4 * q), a01 = *(const F4 *)(ka + o01 + 4 * q);
+      const F4 a10 = *(const F4 *)(ka + o10 + 4 * q), a11 = *(const F4 *)(ka + o11 + 4 * q);
+      double w[4];
+      w[0] = (double)bilw(a00.x, a01.x, a10.x, a11.x, w00, w01, w10, w11);
+      w[1] = (double)bilw(a00.y, a01.y, a10.y, a11.y, w00, w01, w10, w11);
+      w[2] = (double)bilw(a00.z, a01.z, a10.z, a11.z, w00, w01, w10, w11);
+      w[3] = (double)bilw(a00.w, a01.w, a10.w, a11.w, w00, w01, w10, w11);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = __dadd_rn(__dmul_rn(v[j], 1 - wgt), __dmul_rn(w[j], wgt));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Kp[(4 * q + j) * BLOCK + tid] = (cov && isfinite(v[j])) ? v[j] : Kfb;
+  }
+}
+
+// The ntimes_mix random-walk sub-steps of one particle on its K column in LDS (oceandrift.py:505-565).  Returns the
+// new z; sf_flags: 1 deactivated on the sea floor, 2 moved back horizontally (general:seafloor_action).
+struct VMixArgs {
+  double dt, dt_mix_cfg;
+  int mix_at_surface, rng_mode, sfl, pad;
+  const double *huni;
+  unsigned long long seed, step;
+};
+template <int NQ>
+__device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, const double *Kp, const double *gsh, int tid,
+                                                const VMixArgs &A, long long i, long long n, int id, double z, int &moving,
+                                                float Zmin, float tv, int &sf_flags) {
+  constexpr int NL = 4 * NQ;
+  const double dt = A.dt;
+  const int mix_at_surface = A.mix_at_surface, rng_mode = A.rng_mode, sfl = A.sfl;
+  // level boundaries (see k_vmix) in scalar registers; levels past the profile never match
+  double zm[NL - 1];
+#pragma unroll
+  for (int k = 0; k < NL - 1; ++k) zm[k] = k < nzp - 1 ? s.zmid[k] : __builtin_inf();
+  const bool uniform_z = s.vg_uniform != 0;
+  const double gd0 = s.vg_d[0], gi0 = s.vg_id[0], gd1 = s.vg_d[1], gi1 = s.vg_id[1], gd2 = s.vg_d[2], gi2 = s.vg_id[2];
+  const double sgn = dt > 0 ? 1.0 : (dt < 0 ? -1.0 : 0.0);
+  const double dt_mix = A.dt_mix_cfg * sgn;
+  const int ntimes = abs((int)(dt / dt_mix));
+  const double r = 1.0 / 3, ir = 1.0 / r;
+  // w*dt_mix*moving: dt_mix is a NumPy float64 scalar (np.sign, oceandrift.py:416) -> float64 product under NumPy 2
+  double wstep = __dmul_rn(__dmul_rn((double)tv, dt_mix), (double)moving);
+  rocrand_state_philox4x32_10 st;
+  if (rng_mode == 0) rng_init(st, A.seed, id, A.step, RNG_OFF_VMIX);
+  uint4 u4 = make_uint4(0u, 0u, 0u, 0u);
+  // -dK/dz * dt_mix and sqrt(K |dt_mix| 2 / r) of one level (oceandrift.py:501-502,527-528)
+  auto level_terms = [&](int zl, double &dk_dt, double &sg) {
+    const double Kz = Kp[zl * BLOCK + tid];
+    double gK;  // np.gradient(Kprofiles, mixing_z, axis=0)[zl]
+    if (zl == 0) gK = div_cr(Kp[BLOCK + tid] - Kz, gd0, gi0);
+    else if (zl == nzp - 1) gK = div_cr(Kz - Kp[(nzp - 2) * BLOCK + tid], gd1, gi1);
+    else if (uniform_z) gK = div_cr(Kp[(zl + 1) * BLOCK + tid] - Kp[(zl - 1) * BLOCK + tid], gd2, gi2);
+    else
+      gK = __dadd_rn(__dadd_rn(__dmul_rn(gsh[zl], Kp[(zl - 1) * BLOCK + tid]), __dmul_rn(gsh[NL + zl], Kz)),
+                     __dmul_rn(gsh[2 * NL + zl], Kp[(zl + 1) * BLOCK + tid]));
+    double dK = -gK;
+    if (fabs(dK) < 1e-10) dK = 0;  // gradK[np.abs(gradK)<1e-10] = 0 (:502)
+    dk_dt = __dmul_rn(dK, dt_mix);
+    sg = sqrt(div_cr(__dmul_rn(__dmul_rn(Kz, fabs(dt_mix)), 2.0), r, ir));
+  };
+  // A particle rarely leaves the three levels around its starting one within a step: their terms are derived once
+  // (branch-free selection in the loop); anything else is derived on demand.  With a per-iteration "derive when the
+  // level changes" scheme the 64 lanes of a wave make that branch fire in practically every sub-step.
+  int lv0;
+  {
+    const double d0 = -z;
+    int zs = 0;
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) zs += ((k & 1) ? d0 >= zm[k] : d0 > zm[k]) ? 1 : 0;
+    lv0 = zs < 1 ? 1 : (zs > nzp - 2 ? nzp - 2 : zs);   // centre of the cached window [lv0-1, lv0+1]
+    if (nzp < 3) lv0 = 1;
+  }
+  double c_dk[3], c_sg[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int zl = lv0 - 1 + q;
+    c_dk[q] = 0; c_sg[q] = 0;
+    if (zl >= 0 && zl < nzp) level_terms(zl, c_dk[q], c_sg[q]);
+  }
+  for (int it = 0; it < ntimes; ++it) {
+    const bool surface = z == 0;
+    const double d = -z;
+    int zi = 0;
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) zi += ((k & 1) ? d >= zm[k] : d > zm[k]) ? 1 : 0;
+    const int q = zi - lv0 + 1;
+    double dKdt = q == 0 ? c_dk[0] : (q == 1 ? c_dk[1] : c_dk[2]);
+    double sig = q == 0 ? c_sg[0] : (q == 1 ? c_sg[1] : c_sg[2]);
+    if (q < 0 || q > 2) level_terms(zi, dKdt, sig);
+    double u01;
+    if (rng_mode == 1) u01 = A.huni[(size_t)it * n + i];
+    else u01 = mix_uniform(st, u4, it);
+    double R = __dsub_rn(__dmul_rn(2.0, u01), 1.0);
+    z = __dsub_rn(z, __dmul_rn((double)moving, __dsub_rn(dKdt, __dmul_rn(R, sig))));
+    if (z >= 0) z = -z;
+    if (z < (double)Zmin && moving == 1) z = __dsub_rn((double)__fmul_rn(2.f, Zmin), z);
+    z = __dadd_rn(z, wstep);
+    if (!mix_at_surface && surface) z = 0.0;
+    if (z > 0) z = 0.0;
+    if (z < (double)Zmin) {   // "let particles stick to bottom": interact_with_seafloor() inside the loop (oceandrift.py:555-559)
+      const int act = sfl & 255;
+      if (act == 3) sf_flags |= 2;                       // previous: lon/lat go back, z stays
+      else if (act) {
+        z = (double)Zmin;                                // lift_to_seafloor / deactivate
+        if (act == 2) { sf_flags |= 1; moving = 0; wstep = 0.0; }
+      }
+    }
+  }
+  return z;
+}
+
 #ifdef ODR_TU_MISC
 // ------------------------------------------------------------------ environment
 // Environment.get_environment for one variable group of NV variables
@@ -404,12 +579,36 @@ struct StepDesc {
 
 // TILE: the (u,v) node records around the workgroup's particles are staged in LDS for the stage samples (odr_field.hip.h
 // "LDS field tile"); tile_nodes = capacity of the dynamic LDS allocation in nodes.
-template <int SCHEME, int PROJ, bool IS3D, bool NOISE, bool TILE = false>
-__global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
+// MIXQ > 0: OceanDrift.vertical_mixing (+ vertical_advection) of the same step runs in this launch as well (the body of
+// k_vmix_col<MIXQ, MIXTL>): the K column is gathered at the sample position while the particle is in registers, the
+// random walk follows the horizontal move; z, moving, depth, ssh and the sample position are not written and read
+// again, one launch and one pass over the particle state less.  Same arithmetic, same bits as the two launches.
+struct StepMix {
+  VMixDesc D;
+  VMixArgs A;
+  int vadv, w_slot;   // vertical advection: -1 none | 0 below the surface | 1 including it; slot of W in the group or -1
+};
+template <int SCHEME, int PROJ, bool IS3D, bool NOISE, bool TILE = false, int MIXQ = 0, bool MIXTL = false>
+__global__ __launch_bounds__(BLOCK, (MIXQ > 0 && ODR_WAVES(PROJ) < ODR_MIX_WAVES) ? ODR_MIX_WAVES : ODR_WAVES(PROJ)) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
                                                      StepDesc S, double dt, float factor, UVTime th, UVTime tf,
-                                                     unsigned long long *n_hit, StageNoise N, int tile_nodes = 0) {
+                                                     unsigned long long *n_hit, StageNoise N, int tile_nodes = 0,
+                                                     StepMix M = StepMix()) {
+  static_assert(!(TILE && MIXQ > 0), "the LDS tile and the fused mixing both use the dynamic LDS allocation");
   long long i = pid();
   bool hit = false;
+  double *Kp = nullptr, *gsh = nullptr;
+  if (MIXQ > 0) {
+    extern __shared__ __attribute__((aligned(16))) char mix_mem[];
+    constexpr int NL = 4 * (MIXQ > 0 ? MIXQ : 1);
+    Kp = (double *)mix_mem;                  // [NL][BLOCK]
+    gsh = Kp + (size_t)NL * BLOCK;           // [3][NL]
+    const DevSource &sk = W->src[M.D.sid];
+    if ((int)threadIdx.x < M.D.nzp) {
+      const int t_ = threadIdx.x;
+      gsh[t_] = sk.vg_a[t_]; gsh[NL + t_] = sk.vg_b[t_]; gsh[2 * NL + t_] = sk.vg_c[t_];
+    }
+    __syncthreads();
+  }
   TileView T;
   T.t = nullptr; T.x0 = T.y0 = T.w = T.h = 0; T.nz = 1;
   bool tile_h = false, tile_f = false;
@@ -502,14 +701,17 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevW
     const double z = p.z[i];
     float out[MAXG];
     env_group_fast<PROJ>(*W, G, lon, lat, z, out);
-    const int id = NOISE ? p.id[i] : 0;
+    const int id = (NOISE || MIXQ > 0) ? p.id[i] : 0;
+    if (MIXQ > 0) vmix_col_fill<(MIXQ > 0 ? MIXQ : 1), MIXTL>(W->src[M.D.sid], M.D, lon, lat, Kp, threadIdx.x);
     if (NOISE && S.main_noise) add_current_noise(N, 0, i, p.n, id, out[0], out[1]);
 #ifndef ODR_ABLATE_STORES   // what-if build (tools/ab_bench.sh)
 #pragma unroll
     for (int k = 0; k < MAXG; ++k)
       if (k < G.nv) p.env[G.var[k]][i] = out[k];
-    p.slon[i] = lon;
-    p.slat[i] = lat;
+    if (MIXQ == 0) {   // the sample position is what odr_vmix gathers its profiles at: not needed when the mixing is in here
+      p.slon[i] = lon;
+      p.slat[i] = lat;
+    }
 #endif
     int moving = p.moving[i];
     int st = p.status[i];
@@ -549,7 +751,7 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevW
     if (S.seafloor) {  // k_seafloor
       const float dep = S.depth_slot == 2 ? out[2] : (S.depth_slot == 3 ? out[3] : p.env[VAR_DEPTH][i]);
       const float floorz = -__fadd_rn(dep, p.env[VAR_SSH] ? p.env[VAR_SSH][i] : 0.f);
-      if (zz < (double)floorz) { zz = (double)floorz; p.z[i] = zz; }
+      if (zz < (double)floorz) { zz = (double)floorz; if (MIXQ == 0) p.z[i] = zz; }
     }
     if (S.age_dt != 0.0f) {  // k_age
       const float a = __fadd_rn(p.age[i], S.age_dt);
@@ -569,6 +771,27 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_grid(const DevW
       advect_grid_body<SCHEME, PROJ, IS3D, NOISE, TILE>(s, s.slot[S.geo_slot_uv], lon, lat, zz, out[0], out[1],
                                                         __fmul_rn(factor, p.cdf[i]), moving, dt, th, tf, W->fallback[VAR_U],
                                                         W->fallback[VAR_V], N, i, p.n, id, T, tile_h, tile_f);
+    }
+    if (MIXQ > 0) {   // vertical_mixing + vertical_advection (oceandrift.py:397-571, :315-350) after the horizontal move
+      double zn = zz;
+      if (!skip) {
+        const float dep = S.depth_slot == 2 ? out[2] : (S.depth_slot == 3 ? out[3] : p.env[VAR_DEPTH][i]);
+        const float Zmin = __fmul_rn(-1.f, __fadd_rn(dep, p.env[VAR_SSH][i]));  // float32 (:408)
+        int sf_flags = 0;
+        zn = vmix_col_walk<(MIXQ > 0 ? MIXQ : 1)>(W->src[M.D.sid], M.D.nzp, Kp, gsh, threadIdx.x, M.A, i, p.n, id, zz, moving, Zmin,
+                                                  p.tv[i], sf_flags);
+        if (sf_flags & 1) {   // deactivate_elements(reason='seafloor')
+          if (st == 0) p.status[i] = M.A.sfl >> 8;
+          p.moving[i] = 0;
+        }
+        if (sf_flags & 2) { lon = p.plon[i]; lat = p.plat[i]; }
+        if (M.vadv >= 0 && (M.vadv ? zn <= 0 : zn < 0)) {
+          const float wv = M.w_slot >= 0 ? out[M.w_slot] : p.env[VAR_W][i];
+          const double zq = __dadd_rn(zn, __dmul_rn(__dmul_rn((double)moving, (double)wv), dt));
+          zn = zq < 0 ? zq : 0.0;
+        }
+      }
+      p.z[i] = zn;
     }
     p.lon[i] = lon;
     p.lat[i] = lat;
@@ -912,16 +1135,6 @@ namespace odr {
 // free for per-thread dynamic level indices) together with -dK/dz per level, and the whole
 // ntimes_mix random walk runs out of registers + LDS.  vertical_advection (:315-350) is fused
 // at the end when `vadv` >= 0 (same particle, same z).
-// Uniform number of mixing sub-step `it` (ODR_RNG_DEVICE): one Philox4x32-10 block serves FOUR sub-steps -- each 32-bit
-// word is one uniform (x + 1/2) 2^-32 in (0, 1), symmetric about 1/2; the random-walk displacement R = 2u - 1 is
-// resolved to 5e-10 of its range.  (Two 53-bit uniforms per block cost one block per two sub-steps: 45 instead of 25
-// instructions per sub-step.)
-__device__ __forceinline__ double mix_uniform(rocrand_state_philox4x32_10 &st, uint4 &q, int it) {
-  if ((it & 3) == 0) q = rocrand4(&st);
-  const unsigned k = (unsigned)it & 3u;
-  const unsigned x = k == 0 ? q.x : (k == 1 ? q.y : (k == 2 ? q.z : q.w));
-  return ((double)x + 0.5) * 2.3283064365386963e-10;
-}
 __device__ __forceinline__ void kcolumn(const float *__restrict__ col, int nz, float *out /*[MAXNZ]*/) {
   int k = 0;
   for (; k + 4 <= nz; k += 4) {
@@ -1111,19 +1324,6 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
   p.z[i] = z;
 }
 
-// Fast version for the common case -- the diffusivity comes from one gridded reader with a
-// plain (not interleaved) z-innermost K array.  The host resolves source, time bracket and
-// weight (VMixDesc); NQ = number of 4-level quads per column is a compile-time constant, so the
-// 8 column gathers are straight-line 16-byte loads that are all in flight together (the generic
-// kernel's run-time loops serialise them: one memory round trip per load), the level
-// boundaries live in scalar registers and the np.gradient divisors are host constants.
-struct VMixDesc {
-  int sid, nzp, geo_slot, pad;
-  const float *kb, *ka;  // K arrays of the bracketing time levels (ka == nullptr: on a time level)
-  double wgt;            // weight_after (structured.py:353-354)
-  float Kfb, pad2;
-};
-
 template <int NQ, bool TL>
 __global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__ W, PView p, VMixDesc D,
                                                     double dt, double dt_mix_cfg, int mix_at_surface,
@@ -1143,135 +1343,15 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__
   }
   __syncthreads();
   if (i >= p.n) return;  // no barrier below: every thread touches only its own LDS column
-  const double Kfb = (double)D.Kfb;
-  {
-    double lon = p.slon[i], lat = p.slat[i], x, y;
-    if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
-    else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
-    proj_fwd_rt(s.proj, lon, lat, x, y);
-    const bool cov = x >= s.xmin && x <= s.xmax && y >= s.ymin && y <= s.ymax;
-    if (s.mod360_x) x = np_mod(x, 360.0);
-    const DevBlock &bb = s.slot[D.geo_slot];
-    const double xi = __dmul_rn(div_cr(x - bb.x0, bb.xspan, bb.ixspan), (double)(bb.nx - 1));
-    const double yi = __dmul_rn(div_cr(y - bb.y0, bb.yspan, bb.iyspan), (double)(bb.ny - 1));
-    const int ny = bb.ny, nx = bb.nx;
-    const Axis ay = axis_fp(yi, ny), ax = axis_fp(xi, nx);
-    const double ty = ay.t, tx = ax.t, wy0 = 1 - ty, wx0 = 1 - tx, wgt = D.wgt;
-    // uncovered particles gather node (0,0) and discard it: keeps the loads unconditional
-    const size_t rec = (size_t)bb.rec;
-    const size_t o00 = cov ? ((size_t)ay.i0 * nx + ax.i0) * rec : 0, o01 = cov ? ((size_t)ay.i0 * nx + ax.i1) * rec : 0;
-    const size_t o10 = cov ? ((size_t)ay.i1 * nx + ax.i0) * rec : 0, o11 = cov ? ((size_t)ay.i1 * nx + ax.i1) * rec : 0;
-    const float *kb = D.kb, *ka = TL ? D.ka : D.kb;
-    // horizontal weights multiplied out once for the whole column (float64; the layer value is rounded to float32 like
-    // the ReaderBlock's: same bits as (v*wy)*wx summed, but for a float64 round-off that reaches the float32 rounding
-    // in ~1e-8 of the values)
-    const double w00 = wy0 * wx0, w01 = wy0 * tx, w10 = ty * wx0, w11 = ty * tx;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const F4 b00 = *(const F4 *)(kb + o00 + 4 * q), b01 = *(const F4 *)(kb + o01 + 4 * q);
-      const F4 b10 = *(const F4 *)(kb + o10 + 4 * q), b11 = *(const F4 *)(kb + o11 + 4 * q);
-      double v[4];
-      v[0] = (double)bilw(b00.x, b01.x, b10.x, b11.x, w00, w01, w10, w11);
-      v[1] = (double)bilw(b00.y, b01.y, b10.y, b11.y, w00, w01, w10, w11);
-      v[2] = (double)bilw(b00.z, b01.z, b10.z, b11.z, w00, w01, w10, w11);
-      v[3] = (double)bilw(b00.w, b01.w, b10.w, b11.w, w00, w01, w10, w11);
-      if (TL) {
-        const F4 a00 = *(const F4 *)(ka + o00 + 4 * q), a01 = *(const F4 *)(ka + o01 + 4 * q);
-        const F4 a10 = *(const F4 *)(ka + o10 + 4 * q), a11 = *(const F4 *)(ka + o11 + 4 * q);
-        double w[4];
-        w[0] = (double)bilw(a00.x, a01.x, a10.x, a11.x, w00, w01, w10, w11);
-        w[1] = (double)bilw(a00.y, a01.y, a10.y, a11.y, w00, w01, w10, w11);
-        w[2] = (double)bilw(a00.z, a01.z, a10.z, a11.z, w00, w01, w10, w11);
-        w[3] = (double)bilw(a00.w, a01.w, a10.w, a11.w, w00, w01, w10, w11);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = __dadd_rn(__dmul_rn(v[j], 1 - wgt), __dmul_rn(w[j], wgt));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) Kp[(4 * q + j) * BLOCK + tid] = (cov && isfinite(v[j])) ? v[j] : Kfb;
-    }
-  }
-  // level boundaries (see k_vmix) in scalar registers; levels past the profile never match
-  double zm[NL - 1];
-#pragma unroll
-  for (int k = 0; k < NL - 1; ++k) zm[k] = k < nzp - 1 ? s.zmid[k] : __builtin_inf();
-  const bool uniform_z = s.vg_uniform != 0;
-  const double gd0 = s.vg_d[0], gi0 = s.vg_id[0], gd1 = s.vg_d[1], gi1 = s.vg_id[1], gd2 = s.vg_d[2], gi2 = s.vg_id[2];
-  const double sgn = dt > 0 ? 1.0 : (dt < 0 ? -1.0 : 0.0);
-  const double dt_mix = dt_mix_cfg * sgn;
-  const int ntimes = abs((int)(dt / dt_mix));
-  const double r = 1.0 / 3, ir = 1.0 / r;
-  double z = p.z[i];
+  vmix_col_fill<NQ, TL>(s, D, p.slon[i], p.slat[i], Kp, tid);
+  VMixArgs A;
+  A.dt = dt; A.dt_mix_cfg = dt_mix_cfg; A.mix_at_surface = mix_at_surface; A.rng_mode = rng_mode; A.sfl = sfl; A.pad = 0;
+  A.huni = huni; A.seed = seed; A.step = step;
   int moving = p.moving[i];
-  int sf_flags = 0;   // 1: deactivated on the sea floor, 2: moved back horizontally (general:seafloor_action)
+  int sf_flags = 0;
   const float Zmin = __fmul_rn(-1.f, __fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH][i]));  // float32 (:408)
-  // w*dt_mix*moving: dt_mix is a NumPy float64 scalar (np.sign, oceandrift.py:416) -> float64 product under NumPy 2
-  double wstep = __dmul_rn(__dmul_rn((double)p.tv[i], dt_mix), (double)moving);
-  rocrand_state_philox4x32_10 st;
-  if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
-  uint4 u4 = make_uint4(0u, 0u, 0u, 0u);
-  // -dK/dz * dt_mix and sqrt(K |dt_mix| 2 / r) of one level (oceandrift.py:501-502,527-528)
-  auto level_terms = [&](int zl, double &dk_dt, double &sg) {
-    const double Kz = Kp[zl * BLOCK + tid];
-    double gK;  // np.gradient(Kprofiles, mixing_z, axis=0)[zl]
-    if (zl == 0) gK = div_cr(Kp[BLOCK + tid] - Kz, gd0, gi0);
-    else if (zl == nzp - 1) gK = div_cr(Kz - Kp[(nzp - 2) * BLOCK + tid], gd1, gi1);
-    else if (uniform_z) gK = div_cr(Kp[(zl + 1) * BLOCK + tid] - Kp[(zl - 1) * BLOCK + tid], gd2, gi2);
-    else
-      gK = __dadd_rn(__dadd_rn(__dmul_rn(gsh[zl], Kp[(zl - 1) * BLOCK + tid]), __dmul_rn(gsh[NL + zl], Kz)),
-                     __dmul_rn(gsh[2 * NL + zl], Kp[(zl + 1) * BLOCK + tid]));
-    double dK = -gK;
-    if (fabs(dK) < 1e-10) dK = 0;  // gradK[np.abs(gradK)<1e-10] = 0 (:502)
-    dk_dt = __dmul_rn(dK, dt_mix);
-    sg = sqrt(div_cr(__dmul_rn(__dmul_rn(Kz, fabs(dt_mix)), 2.0), r, ir));
-  };
-  // A particle rarely leaves the three levels around its starting one within a step: their terms are derived once
-  // (branch-free selection in the loop); anything else is derived on demand.  With a per-iteration "derive when the
-  // level changes" scheme the 64 lanes of a wave make that branch fire in practically every sub-step.
-  int lv0;
-  {
-    const double d0 = -z;
-    int zs = 0;
-#pragma unroll
-    for (int k = 0; k < NL - 1; ++k) zs += ((k & 1) ? d0 >= zm[k] : d0 > zm[k]) ? 1 : 0;
-    lv0 = zs < 1 ? 1 : (zs > nzp - 2 ? nzp - 2 : zs);   // centre of the cached window [lv0-1, lv0+1]
-    if (nzp < 3) lv0 = 1;
-  }
-  double c_dk[3], c_sg[3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int zl = lv0 - 1 + q;
-    c_dk[q] = 0; c_sg[q] = 0;
-    if (zl >= 0 && zl < nzp) level_terms(zl, c_dk[q], c_sg[q]);
-  }
-  for (int it = 0; it < ntimes; ++it) {
-    const bool surface = z == 0;
-    const double d = -z;
-    int zi = 0;
-#pragma unroll
-    for (int k = 0; k < NL - 1; ++k) zi += ((k & 1) ? d >= zm[k] : d > zm[k]) ? 1 : 0;
-    const int q = zi - lv0 + 1;
-    double dKdt = q == 0 ? c_dk[0] : (q == 1 ? c_dk[1] : c_dk[2]);
-    double sig = q == 0 ? c_sg[0] : (q == 1 ? c_sg[1] : c_sg[2]);
-    if (q < 0 || q > 2) level_terms(zi, dKdt, sig);
-    double u01;
-    if (rng_mode == 1) u01 = huni[(size_t)it * p.n + i];
-    else u01 = mix_uniform(st, u4, it);
-    double R = __dsub_rn(__dmul_rn(2.0, u01), 1.0);
-    z = __dsub_rn(z, __dmul_rn((double)moving, __dsub_rn(dKdt, __dmul_rn(R, sig))));
-    if (z >= 0) z = -z;
-    if (z < (double)Zmin && moving == 1) z = __dsub_rn((double)__fmul_rn(2.f, Zmin), z);
-    z = __dadd_rn(z, wstep);
-    if (!mix_at_surface && surface) z = 0.0;
-    if (z > 0) z = 0.0;
-    if (z < (double)Zmin) {   // "let particles stick to bottom": interact_with_seafloor() inside the loop (oceandrift.py:555-559)
-      const int act = sfl & 255;
-      if (act == 3) sf_flags |= 2;                       // previous: lon/lat go back, z stays
-      else if (act) {
-        z = (double)Zmin;                                // lift_to_seafloor / deactivate
-        if (act == 2) { sf_flags |= 1; moving = 0; wstep = 0.0; }
-      }
-    }
-  }
+  double z = vmix_col_walk<NQ>(s, nzp, Kp, gsh, tid, A, i, p.n, rng_mode == 0 ? p.id[i] : 0, p.z[i], moving, Zmin,
+                               p.tv[i], sf_flags);
   if (sf_flags & 1) {   // deactivate_elements(reason='seafloor') (basemodel/__init__.py:1774-1795)
     if (p.status[i] == 0) p.status[i] = sfl >> 8;
     p.moving[i] = 0;

@@ -36,33 +36,10 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
   c->fuse_vadv = -1;
   if (vadv >= 0 && !p->env[VAR_W]) return fail(ODR_ERR_STATE, "upward_sea_water_velocity has not been sampled");
   // fast column kernel: K from one gridded reader, plain z-innermost array on every resident level
-  int ksid = -1;
-  for (int k = 0; k < c->hw.nlist[VAR_KZ]; ++k)
-    if (c->hw.src[c->hw.list[VAR_KZ][k]].kind == SRC_GRID) { ksid = c->hw.list[VAR_KZ][k]; break; }
   const bool oil = c->oil_owner == p;   // OpenOil: terminal velocities, slick and wave entrainment inside the loop
   c->oil_owner = nullptr;
-  bool fast = ksid >= 0 && nzp > 1 && !oil && !getenv("ODR_NO_FAST_PATH");
   VMixDesc D;
-  memset(&D, 0, sizeof D);
-  if (fast) {
-    const DevSource &s = c->hw.src[ksid];
-    fast = s.nlevels >= 1;
-    for (int k = 0; k < s.nlevels && fast; ++k) {
-      const DevBlock &bk = s.slot[s.level_slot[k]], &g0 = s.slot[s.level_slot[0]];
-      if (!bk.data[VAR_KZ] || bk.es[VAR_KZ] != 1 || bk.var_nz[VAR_KZ] != nzp || bk.rec != g0.rec || bk.ny != g0.ny || bk.nx != g0.nx ||
-          bk.x0 != g0.x0 || bk.xspan != g0.xspan || bk.y0 != g0.y0 || bk.yspan != g0.yspan)
-        fast = false;
-    }
-    if (fast) {
-      int ib, ia;
-      host_bracket(s, t, ib, ia);
-      D.sid = ksid; D.nzp = nzp; D.geo_slot = ib;
-      D.kb = s.slot[ib].data[VAR_KZ];
-      D.ka = ia >= 0 ? s.slot[ia].data[VAR_KZ] : nullptr;
-      D.wgt = ia >= 0 ? (t - s.slot[ib].t) / (s.slot[ia].t - s.slot[ib].t) : 0.0;
-      D.Kfb = c->hw.fallback[VAR_KZ];
-    }
-  }
+  const bool fast = !oil && !getenv("ODR_NO_FAST_PATH") && build_vmix_desc(c, t, D);
   if (fast) {
     const int nq = (nzp + 3) / 4;
     const bool tl = D.ka != nullptr;

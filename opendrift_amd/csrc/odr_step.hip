@@ -76,6 +76,16 @@ int odr_advect(odr_ctx *c, odr_particles *p, int scheme, double t, double dt, do
 // one launch (k_step_grid) when the current comes from one gridded reader; otherwise exactly the
 // four separate entry points, in that order.  Results are bit-identical either way
 // (tests/test_gpu_parity.py::test_fused_step_equals_separate_calls).
+// extras->vmix when the mixing cannot run inside the step launch: the two calls in sequence
+static int mix_after(odr_ctx *c, odr_particles *p, double t, double dt, const odr_step_extras *ex) {
+  c->fuse_vadv = ex->vmix_vadv;
+  return odr_vmix(c, p, t, dt, ex->vmix_dt_mix, ex->vmix_at_surface, ODR_RNG_DEVICE, nullptr, ex->vmix_step);
+}
+static bool s_is_latlong_3d(const odr_ctx *c, int sid) {
+  const DevSource &s = c->hw.src[sid];
+  return s.proj.kind == PROJ_LATLONG && s.nz > 1 && s.slot[s.level_slot[0]].var_nz[VAR_U] > 1;
+}
+
 int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t,
                          int coast_action, int stranded_code, int seeded_on_land_code, int store_previous,
                          int scheme, double dt, double factor, const odr_step_extras *extras, int64_t *n_on_land) {
@@ -107,8 +117,10 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   bool has_depth = false;
   for (int k = 0; k < nvars; ++k) has_depth |= var_ids[k] == VAR_DEPTH;
   const bool want_floor = extras && extras->seafloor_action == 1;
+  const bool want_mix = extras && extras->vmix;
+  if (want_mix) REQUIRE(extras->vmix_dt_mix > 0 && dt != 0, "bad mixing time step");
   if (want_floor && !has_depth && !p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
-  const bool depth_in_group = want_floor && has_depth && same_list(VAR_DEPTH, VAR_U);
+  const bool depth_in_group = (want_floor || want_mix) && has_depth && same_list(VAR_DEPTH, VAR_U);
   grp[ng++] = VAR_U; grp[ng++] = VAR_V;
   if (land_in_group) grp[ng++] = VAR_LAND;
   const int depth_slot = depth_in_group ? ng : -1;
@@ -153,7 +165,8 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
         (rc = odr_increase_age(c, p, extras->age_dt, extras->max_age_seconds, extras->retired_code)))
       return rc;
     if (store_previous && (rc = odr_store_previous(c, p))) return rc;
-    return advect_impl(c, p, scheme, t, dt, factor, N);
+    if ((rc = advect_impl(c, p, scheme, t, dt, factor, N))) return rc;
+    return want_mix ? mix_after(c, p, t, dt, extras) : 0;
   }
   for (int k = 0; k < ng; ++k) if ((rc = ensure_env(c, p, grp[k]))) return rc;
   if (nrest && (rc = env_sample_impl(c, p, nrest, rest, t, nullptr, false))) return rc;  // k_step_grid records the positions
@@ -174,10 +187,36 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   if (want_floor && (rc = ensure_env(c, p, VAR_SSH))) return rc;
   if (coast_action) HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
   S.main_noise = main_noise ? 1 : 0;
+  // vertical mixing inside the launch: K from the reader of the current (lon/lat, 3-D, <= 16 levels), device RNG
+  StepMix M;
+  memset(&M, 0, sizeof M);
+  bool mix_fused = false;
+  // Measured on C3 (profiles/r02_ab_variants.txt): the merged kernel needs 129 VGPRs (3 waves per SIMD instead of 4) and is
+  // SLOWER than the two launches (1.88 vs 1.75 ms per step; held at 128 VGPRs: 2.48 ms) -- both kernels are bound by
+  // instruction issue, there is no idle time for the merger to fill.  It stays behind ODR_FUSED_MIX=1 with its
+  // bit-identity test (tests/test_gpu_fused_step.py); by default extras->vmix makes the two launches back to back.
+  if (want_mix && !N.on && getenv("ODR_FUSED_MIX") && !getenv("ODR_NO_FUSED_MIX") && s_is_latlong_3d(c, G.sid) && c->oil_owner != p &&
+      build_vmix_desc(c, t, M.D) && M.D.sid == G.sid && M.D.nzp <= 16) {
+    if ((rc = ensure_env(c, p, VAR_SSH))) return rc;
+    M.A.dt = dt; M.A.dt_mix_cfg = extras->vmix_dt_mix; M.A.mix_at_surface = extras->vmix_at_surface;
+    M.A.rng_mode = ODR_RNG_DEVICE; M.A.sfl = c->seafloor; M.A.huni = nullptr; M.A.seed = c->seed;
+    M.A.step = (unsigned long long)extras->vmix_step;
+    M.vadv = extras->vmix_vadv;
+    M.w_slot = -1;
+    for (int k = 0; k < G.nv; ++k) if (G.var[k] == VAR_W) M.w_slot = k;
+    if (M.vadv >= 0 && M.w_slot < 0 && !p->env[VAR_W]) return fail(ODR_ERR_STATE, "upward_sea_water_velocity has not been sampled");
+    mix_fused = true;
+  }
+  if (mix_fused) {
+    odr_i_step_mix(c, p, G, S, scheme, t, dt, factor, M);
+    HIPCHK(hipGetLastError());
+    return coast_action ? read_counter(c, n_on_land) : 0;
+  }
   if (N.on && (scheme > 0 || main_noise)) {
     if (scheme > 0 && N.rng_mode == ODR_RNG_HOST && !N.stage) return fail(ODR_ERR_INVALID, "no host draws for the Runge-Kutta stage calls");
     odr_i_step_noise(c, p, G, S, scheme, t, dt, factor, N);
   } else step_dispatch<false>(c, p, G, S, scheme, t, dt, factor, N);
   HIPCHK(hipGetLastError());
-  return coast_action ? read_counter(c, n_on_land) : 0;
+  if ((rc = coast_action ? read_counter(c, n_on_land) : 0)) return rc;
+  return want_mix ? mix_after(c, p, t, dt, extras) : 0;
 }

@@ -95,6 +95,9 @@ static void step_dispatch(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, c
   else launch_step_grid<2, NOISE>(c, p, G, S, t, dt, factor, N);
 }
 
+// defined in odr_step_mix.hip: the step with OceanDrift.vertical_mixing inside the launch
+void odr_i_step_mix(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, const StepDesc &S, int scheme, double t, double dt,
+                    double factor, const StepMix &M);
 // defined in odr_step_noise.hip
 void odr_i_advect_noise(odr_ctx *c, odr_particles *p, int scheme, double t, double dt, double factor, const StageNoise &N);
 void odr_i_step_noise(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, const StepDesc &S, int scheme, double t, double dt,

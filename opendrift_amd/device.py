@@ -391,7 +391,7 @@ class Particles:
 
     def env_coast_advect(self, variables, t_epoch, scheme, dt, coastline='none', stranded_code=1,
                          seeded_on_land_code=0, store_previous=True, factor=1.0, count=True, seafloor=False,
-                         age_dt=0.0, max_age_seconds=0.0, retired_code=0, missing_code=0, main_noise=False):
+                         age_dt=0.0, max_age_seconds=0.0, retired_code=0, missing_code=0, main_noise=False, vmix=None):
         """env_sample -> coastline -> store_previous -> advect in one launch (odr_env_coast_advect).
         count=False skips reading back the number of elements on land (no host synchronisation).  seafloor=True and
         age_dt != 0 add interact_with_seafloor ('lift_to_seafloor') and increase_age_and_retire, in the loop's order."""
@@ -402,9 +402,15 @@ class Particles:
         ids, pi = _i([_vid(v) for v in variables])
         n = C.c_int64()
         ex = None
-        if seafloor or age_dt or missing_code or main_noise:
+        if seafloor or age_dt or missing_code or main_noise or vmix:
+            # vmix = dict(dt_mix=, step=, mix_at_surface=False, vertical_advection=None | False (below the surface) | True):
+            # OceanDrift.vertical_mixing (+ vertical_advection) of the same step inside the call (device RNG)
+            m = vmix or {}
+            va = m.get('vertical_advection')
             ex = C.byref(_abi.StepExtras(1 if seafloor else 0, int(retired_code), float(age_dt), float(max_age_seconds),
-                                         int(missing_code), 1 if main_noise else 0))
+                                         int(missing_code), 1 if main_noise else 0, 1 if vmix else 0,
+                                         int(bool(m.get('mix_at_surface', False))), -1 if va is None else int(bool(va)), 0,
+                                         float(m.get('dt_mix', 0.0)), int(m.get('step', 0))))
         check(self.lib.odr_env_coast_advect(self.ctx.h, self.h, len(ids), pi, float(t_epoch), a, stranded_code,
                                             seeded_on_land_code, int(bool(store_previous)), s, float(dt),
                                             float(factor), ex, C.byref(n) if count else None))

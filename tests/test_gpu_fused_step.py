@@ -191,3 +191,49 @@ def test_lds_tile_gives_the_same_bits_as_global_gathers(monkeypatch, layout, sch
         P.close()
         ctx.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize('scheme', ['euler', 'runge-kutta4'])
+@pytest.mark.parametrize('vadv', [None, False, True])
+def test_mixing_inside_the_step_launch_gives_the_same_bits_as_two_calls(monkeypatch, scheme, vadv):
+    """odr_step_extras.vmix: OceanDrift.vertical_mixing (+ vertical_advection) inside k_step_grid<..., MIXQ> -- K column
+    gathered at the sample position while the particle is in registers -- against odr_env_coast_advect followed by
+    odr_vmix (device RNG keyed by element ID and step): bit-identical lon / lat / z / status, also with the sea floor
+    in reach, a coastline and a reader time level crossed between the stages."""
+    g = synth.grid3d(nx=96, ny=80, nz=8, nt=3, seed=5)
+    g[DEPTH][:] = np.minimum(g[DEPTH], 60.0 + 100.0 * np.linspace(0, 1, 96)[None, None, :]).astype(np.float32)
+    names = [U, V, W, KZ, DEPTH, LAND]
+    rng = np.random.default_rng(12)
+    n = 30000
+    lon = rng.uniform(g['x'][3], g['x'][-4], n)
+    lat = rng.uniform(g['y'][3], g['y'][-4], n)
+    z = -rng.uniform(0, 70, n)
+    z[:2000] = 0.0
+    res = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.setenv('ODR_FUSED_MIX', '1')
+            monkeypatch.delenv('ODR_NO_FUSED_MIX', raising=False)
+        else:
+            monkeypatch.setenv('ODR_NO_FUSED_MIX', '1')
+        ctx = Context(seed=4)
+        sid = ctx.add_grid(g['x'], g['y'], z=g['z'])
+        for k in range(3):
+            ctx.upload_block(sid, k, float(g['t'][k]), {nm: g[nm][k] for nm in names})
+        for nm in names:
+            ctx.bind(nm, [sid], {LAND: np.nan, DEPTH: 10000.0}.get(nm, 0.0))
+        ctx.bind(SSH, [], 0.0)
+        P = ctx.particles(n)
+        P.append(lon, lat, z=z, terminal_velocity=np.where(np.arange(n) % 3 == 0, -0.004, 0.001).astype(np.float32))
+        P.sort_by_cell(sid)
+        for k, t in enumerate((0.0, 900.0, 3300.0, 3600.0)):
+            P.env_coast_advect([U, V, W, DEPTH, SSH, LAND], t, scheme, 600.0, coastline='previous', count=False, seafloor=True,
+                               age_dt=600.0, vmix=dict(dt_mix=60.0, step=k, vertical_advection=vadv))
+        d = P.download()
+        o = np.argsort(d['ID'])
+        res.append(tuple(d[q][o] for q in ('lon', 'lat', 'z', 'status', 'moving')))
+        P.close()
+        ctx.close()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+    assert np.abs(res[0][2] - np.sort(z)[::1][0] * 0).max() > 1.0 and (res[0][2] <= 0).all()
