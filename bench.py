@@ -142,12 +142,8 @@ class Workload:
             P.advect('runge-kutta4', t, self.dt)
         elif self.name == 'c3':
             if self.fused:
-                # one call for the loop body up to and including OceanDrift.update(): sample, coastline, sea floor, age,
-                # previous state, RK4 advect_ocean_current, vertical_mixing, vertical_advection
                 P.env_coast_advect(self.vars, t, self.scheme, self.dt, coastline='previous', store_previous=True,
-                                   count=False, seafloor=True, age_dt=self.dt,
-                                   vmix=dict(dt_mix=self.dt_mix, step=k, vertical_advection=False))
-                return
+                                   count=False, seafloor=True, age_dt=self.dt)
             else:
                 P.env_sample(self.vars, t)
                 P.coastline('previous')
@@ -177,16 +173,23 @@ class Workload:
             P.stokes_drift(self.dt, profile=2, hs_mode=1, tp_mode=1)
             P.hdiffusion(self.dt, step=k)
 
-    def advect_only(self, P, k):
-        """The dominant kernel alone (timed with HIP events for the roofline object)."""
+    def dominant_kernel(self, P, k):
+        """The dominant launch of the step on its own, with exactly the arguments step() uses (timed with HIP events)."""
+        t = self.time_of(k)
         if self.name == 'c5':
             P.leeway(self.dt, 0.4, step=k)
-        elif self.fused and self.name in ('c3', 'c4'):
-            P.env_coast_advect([v for v in self.vars if v not in (SSH, HD)], self.time_of(k), 'runge-kutta4', self.dt,
-                               coastline='previous' if self.name == 'c3' else 'stranding',
-                               store_previous=self.name == 'c3', count=False)
+        elif self.name == 'c3' and self.fused:
+            P.env_coast_advect(self.vars, t, self.scheme, self.dt, coastline='previous', store_previous=True,
+                               count=False, seafloor=True, age_dt=self.dt)
+        elif self.name == 'c4' and self.fused:
+            P.env_coast_advect(self.vars, t, 'runge-kutta4', self.dt, coastline='stranding', stranded_code=1,
+                               store_previous=False, count=False)
         else:
-            P.advect('runge-kutta4', self.time_of(k), self.dt)
+            P.advect('runge-kutta4', t, self.dt)
+
+    def second_kernel(self, P, k):
+        """C3: the vertical-mixing launch on its own."""
+        P.vmix(self.time_of(k), self.dt, self.dt_mix, step=k, fuse_vertical_advection=False)
 
 
 def cpu_baseline(name, fields, n_cpu, rng):
@@ -205,7 +208,8 @@ def cpu_baseline(name, fields, n_cpu, rng):
                       % (n_cpu, nsteps, el))
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     host_cores = cores
-    cores = min(cores, int(os.environ.get('ODR_CPU_THREADS', 16)))   # every simulation holds its own copy of the field blocks
+    # every simulation holds its own copy of the field blocks (C3: 0.9 GB): all host cores up to 64 simulations
+    cores = min(cores, int(os.environ.get('ODR_CPU_THREADS', 64)))
     if cores > 1 and not os.environ.get('ODR_CPU_ONE_CORE'):
         steppers = [step1] + [_cpu_stepper(name, fields, n_cpu, np.random.default_rng(100 + k)) for k in range(cores - 1)]
         counts, deadline = [0] * cores, [0.0]
@@ -226,6 +230,7 @@ def cpu_baseline(name, fields, n_cpu, rng):
             x.join()
         el = time.perf_counter() - t0
         out['all_cores'] = dict(value=n_cpu * sum(counts) / el, cores=cores, host_cores=host_cores,
+                                note='%d of the %d host cores' % (cores, host_cores),
                                 sample='%d independent simulations x %d particles, %d steps in total, %.1f s'
                                        % (cores, n_cpu, sum(counts), el))
     return out
@@ -301,15 +306,56 @@ def _cpu_stepper(name, fields, n_cpu, rng):
     return step
 
 
+def model_api_leg(fields, n, steps, device):
+    """The drop-in surface on the same inputs: OceanDrift.run() (opendrift_amd/oceandrift.py) with a GridReader holding
+    the C3 fields; steady-state ms per step of the main loop (first step -- seeding, first uploads, first sort --
+    excluded), lon / lat / status as the only export variables, one output at the end."""
+    from datetime import datetime, timedelta
+    from opendrift_amd import readers
+    from opendrift_amd.oceandrift import OceanDrift
+    g = fields['g']
+    t0 = datetime(2020, 1, 1)
+    times = [t0 + timedelta(seconds=float(t)) for t in g['t']]
+    nlev = len(g['t'])
+    hours = int(np.ceil(steps * 600.0 / 3600.0)) + 2
+
+    class CyclingReader(readers.GridReader):   # hourly levels for the whole run: the three synthetic levels in turn
+        def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
+            it = self.times.index(time) % nlev
+            out = {'x': self.x, 'y': self.y, 'time': time, 'z': self.z}
+            for v in requested_variables:
+                out[v] = self.arrays[v][it]
+            return out
+    times = [t0 + timedelta(hours=k) for k in range(hours)]
+    o = OceanDrift(loglevel=50, seed=0, device=device)
+    o.add_reader(CyclingReader(g['x'], g['y'], times, {k: g[k] for k in fields['names']}, z=fields['z']))
+    o.set_config('drift:advection_scheme', 'runge-kutta4')
+    o.set_config('drift:vertical_mixing', True)
+    o.set_config('vertical_mixing:timestep', 60)
+    o.set_config('drift:vertical_advection', True)
+    o.set_config('general:coastline_action', 'previous')
+    o.set_config('drift:stokes_drift', False)
+    rng = np.random.default_rng(1000)
+    lon, lat, z = seed_particles('c3', fields, n, rng)
+    o.seed_elements(lon=lon, lat=lat, z=z, time=t0, wind_drift_factor=0.0)
+    o.run(time_step=600, steps=steps, time_step_output=600 * steps, export_variables=['z'])
+    tm = o.timing
+    return dict(ms_per_step=tm['steady_ms_per_step'], value=n * 1e3 / tm['steady_ms_per_step'], unit='particle-steps/s',
+                steps=tm['steps'], what='OceanDrift.run(): the full loop body per step (release, all 14 required variables '
+                'sampled, deactivation checks, result buffer, age, compaction, update(): RK4 + wind + vertical mixing + '
+                'vertical advection, horizontal diffusion early-out)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=32)   # two re-sorts (every 16th step) fall in the timed region: steady-state mix
+    ap.add_argument('--steps', type=int, default=400)   # >= 0.6 s timed region; 25 re-sorts (every 16th step) fall inside it
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default=os.environ.get('ODR_WORKLOAD', 'c3'), choices=['c2', 'c3', 'c4', 'c5'])
     ap.add_argument('--particles', type=int, default=0, help='particles per GPU (default: the config size)')
     ap.add_argument('--small', action='store_true', help='small field block (debug)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the model_api and pcie_inclusive legs')
     ap.add_argument('--host-sort', action='store_true', help='experiment: seed particles already sorted by grid cell')
     ap.add_argument('--cpu-particles', type=int, default=200000)
     ap.add_argument('--block-every', type=int, default=0,
@@ -353,12 +399,32 @@ def main():
                                     np.full(n, 0.04), ori, np.zeros(n)]):
             P.set_property(slot, val.astype(np.float32))
 
-    pinned = None
-    if a.block_every and a.block_async and a.workload != 'c2':
-        pinned = {kk: ctx.pin(np.ascontiguousarray(fields['g'][kk])) for kk in fields['names']}
-    for k in range(a.warmup):
-        wl.step(P, k)
-    if a.block_every and a.workload != 'c2':   # untimed: scratch pools and recyclable blocks of the upload pipeline exist
+    def timed_loop(steps, first, block_every=0, block_async=False, pinned=None):
+        """`steps` steps between barrier + synchronize on both sides; returns (seconds, particle-steps of this rank)"""
+        ctx.sync()
+        torch.cuda.synchronize()
+        D.barrier()
+        n0 = len(P)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            if block_every and a.workload != 'c2':   # a new reader time level arrives every block_every steps
+                g = fields['g']
+                j = k // block_every
+                if block_async:     # staged one period ahead on the upload stream from pinned arrays, committed when due
+                    if k % block_every == 0:
+                        if j > 0:
+                            ctx.commit_block(wl.sid, (j - 1) % 3)
+                        ctx.upload_block_async(wl.sid, j % 3, float(g['t'][j % 3]), {kk: pinned[kk][j % 3] for kk in fields['names']})
+                elif k % block_every == 0:
+                    ctx.upload_block(wl.sid, j % 3, float(g['t'][j % 3]), {kk: g[kk][j % 3] for kk in fields['names']})
+            wl.step(P, first + k)
+        ctx.sync()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        D.barrier()
+        return el, 0.5 * (n0 + len(P)) * steps
+
+    def warm_uploads(pinned):   # untimed: scratch pools and recyclable blocks of the upload pipeline exist
         g = fields['g']
         for rep in range(2):
             for slot in range(3):
@@ -366,52 +432,66 @@ def main():
                 ctx.upload_block_async(wl.sid, slot, float(g['t'][slot]), arrs)
                 ctx.commit_block(wl.sid, slot)
                 wl.step(P, a.warmup)
-    ctx.sync()
-    torch.cuda.synchronize()
-    D.barrier()
-    n0 = len(P)
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        if a.block_every and a.workload != 'c2':   # a new reader time level arrives every block_every steps
-            g = fields['g']
-            j = k // a.block_every
-            if a.block_async:     # staged one period ahead on the upload stream from pinned arrays, committed when due
-                if k % a.block_every == 0:
-                    if j > 0:
-                        ctx.commit_block(wl.sid, (j - 1) % 3)
-                    ctx.upload_block_async(wl.sid, j % 3, float(g['t'][j % 3]), {kk: pinned[kk][j % 3] for kk in fields['names']})
-            elif k % a.block_every == 0:
-                ctx.upload_block(wl.sid, j % 3, float(g['t'][j % 3]), {kk: g[kk][j % 3] for kk in fields['names']})
-        wl.step(P, a.warmup + k)
-    ctx.sync()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    D.barrier()
-    n1 = len(P)
-    el_max = float(D.allreduce_scalars([el], 'max')[0])
-    units = float(D.allreduce_scalars([0.5 * (n0 + n1) * a.steps], 'sum')[0])
 
-    # dominant kernel (fused RK4 advection) timed with HIP events on the context stream
-    reps = 10
-    P.env_sample([U, V], wl.time_of(0))
-    wl.advect_only(P, 0)
+    pinned = None
+    if a.block_every and a.block_async and a.workload != 'c2':
+        pinned = {kk: ctx.pin(np.ascontiguousarray(fields['g'][kk])) for kk in fields['names']}
+    for k in range(a.warmup):
+        wl.step(P, k)
+    if a.block_every and a.workload != 'c2':
+        warm_uploads(pinned)
+    el, units_rank = timed_loop(a.steps, a.warmup, a.block_every, a.block_async, pinned)
+    el_max = float(D.allreduce_scalars([el], 'max')[0])
+    units = float(D.allreduce_scalars([units_rank], 'sum')[0])
+
+    # the two kernels of the step on their own, HIP events on the context stream, exactly the step's launches
+    reps = 20
+    kfused = wl.fused and a.workload in ('c3', 'c4')
+    if a.workload != 'c2' and wl.sort_every:
+        P.sort_by_cell(wl.sid)      # the layout right after a re-sort, as in 1 of every 16 steps (the kernels drift apart by < 3 % in between)
+    if not kfused:
+        P.env_sample([U, V], wl.time_of(0))
+    wl.dominant_kernel(P, 0)
     ctx.sync()
     ctx.timer_begin()
     for k in range(reps):
-        wl.advect_only(P, k)
+        wl.dominant_kernel(P, k)
     k_ms = ctx.timer_end() / reps
+    k2_ms = None
+    if a.workload == 'c3':
+        wl.second_kernel(P, 0)
+        ctx.sync()
+        ctx.timer_begin()
+        for k in range(reps):
+            wl.second_kernel(P, k)
+        k2_ms = ctx.timer_end() / reps
     nact = len(P)
-    kfused = wl.fused and a.workload in ('c3', 'c4')
     kbytes = BYTES[a.workload]['fused' if kfused else 'advect']
     ach = kbytes * nact / (k_ms * 1e-3)
 
-    traffic = None
-    pj = os.path.join(ROOT, 'profiles', 'r01_%s_pmc.json' % a.workload)
-    if os.path.exists(pj):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/)
-        pm = json.load(open(pj))
+    # counters of the same command from the committed rocprofv3 passes (profiles/r02_<workload>_pmc.json): PMC counters
+    # cannot be collected from inside this process
+    pmc, pmc_file = None, os.path.join('profiles', 'r02_%s_pmc.json' % a.workload)
+    if os.path.exists(os.path.join(ROOT, pmc_file)):
+        pm = json.load(open(os.path.join(ROOT, pmc_file)))
         if pm.get('particles') == n:
-            traffic = (pm['FETCH_SIZE_bytes'] + pm['WRITE_SIZE_bytes']) / 1e9
+            pmc = pm
+    extras = {}
+    if rank == 0 and world == 1 and not a.no_extras and a.workload == 'c3' and not a.block_every and not a.small:
+        # (i) PCIe-inclusive: a new reader time level (hourly fields, 10-minute steps) arrives from pinned host memory
+        # every 6 steps on the upload stream inside the timed region
+        pinned = {kk: ctx.pin(np.ascontiguousarray(fields['g'][kk])) for kk in fields['names']}
+        warm_uploads(pinned)
+        nst = min(a.steps, 120)
+        el_p, up = timed_loop(nst, a.warmup, 6, True, pinned)
+        extras['pcie_inclusive'] = dict(ms_per_step=1e3 * el_p / nst, value=up / el_p, unit='particle-steps/s', steps=nst,
+                                        what='one 210 MB time level uploaded every 6 steps (odr_block_upload_async from '
+                                             'page-locked arrays, committed one period later) inside the timed region')
+        for kk in fields['names']:
+            ctx.unpin(pinned[kk])
+        pinned = None
     if rank == 0:
+        traffic = None if pmc is None else (pmc['FETCH_SIZE_bytes_x2'] + pmc['WRITE_SIZE_bytes']) / 1e9
         out = {
             'metric': {'c3': 'particle-steps/sec (RK4, 3D interp)', 'c2': 'particle-steps/sec (RK4, analytic field)',
                        'c4': 'particle-steps/sec (RK4, 2D interp + wind + Stokes + diffusion)',
@@ -427,18 +507,53 @@ def main():
                                     'c5': 'C5: Leeway ensemble members (2 x 5 M per GPU) on the NorKyst-800-shaped grid, '
                                           'wind/current uncertainty, stranding'}[a.workload],
                        'particles_per_gpu': n, 'particles_total': n * world, 'time_step_s': wl.dt,
+                       'block_every': a.block_every, 'inputs': 'resident in HBM' if not a.block_every else 'uploaded in the timed region',
                        'parallelism': 'particle-sharded x%d, field block broadcast once per time level' % world},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_leeway' if a.workload == 'c5' else ('k_step_grid<RK4>' if kfused else 'k_advect<RK4>'), 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9,
+            # the algorithmic figure of SURVEY.md 8(d): 4 B per field corner touched + state once in / once out
+            'roofline': {'bound': 'hbm', 'kernel': 'k_leeway' if a.workload == 'c5' else ('k_step_grid<RK4>' if kfused else 'k_advect<RK4>'),
+                         'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9,
                          'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': traffic, 'traffic_unit': 'GB per launch (PMC)',
+                         'traffic_source': None if pmc is None else pmc_file,
                          'algorithmic_gb_per_launch': kbytes * nact / 1e9,
                          'kernel_ms': k_ms, 'algorithmic_bytes_per_particle': kbytes,
+                         'note': 'algorithmic bytes count cache-served corners: not a physical bandwidth (see roofline_hbm_counters, roofline_issue)',
                          'step_bytes_per_particle': BYTES[a.workload]['step'],
                          'step_frac': BYTES[a.workload]['step'] * (units / el_max) / world / HBM_PEAK},
         }
+        if k2_ms is not None:
+            out['roofline']['second_kernel'] = {'kernel': 'k_vmix_col', 'kernel_ms': k2_ms}
+        if pmc is not None:
+            # what the HBM counters saw (FETCH_SIZE x2 per MI355X_MICROARCH.md, + WRITE_SIZE) against the 8 TB/s peak, and
+            # the instruction-issue bound: one VALU wave-instruction per 4 cycles per SIMD, 1024 SIMDs at 2.4 GHz
+            hb = (pmc['FETCH_SIZE_bytes_x2'] + pmc['WRITE_SIZE_bytes']) / (k_ms * 1e-3)
+            out['roofline_hbm_counters'] = {'bound': 'hbm', 'kernel': out['roofline']['kernel'], 'achieved': hb / 1e9,
+                                            'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': hb / HBM_PEAK,
+                                            'traffic': traffic, 'source': pmc_file}
+            issue = pmc['SQ_INSTS_VALU'] * 4.0 / (1024 * 2.4e9)
+            out['roofline_issue'] = {'bound': 'valu_issue', 'kernel': out['roofline']['kernel'],
+                                     'valu_wave_instructions_per_launch': pmc['SQ_INSTS_VALU'],
+                                     'issue_ms_at_peak': issue * 1e3, 'kernel_ms': k_ms, 'frac': issue * 1e3 / k_ms,
+                                     'peak': '1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction', 'source': pmc_file}
+        out.update(extras)
+        if world == 1 and not a.no_extras and a.workload == 'c3' and not a.small and not a.block_every:
+            P.close()
+            P = None
+            out['model_api'] = model_api_leg(fields, n, 48, dev)
+            out['model_api']['vs_bare_sequence'] = out['model_api']['ms_per_step'] / out['ms_per_step']
         if not a.no_cpu and world == 1:
             out['cpu_baseline'] = cpu_baseline(a.workload, fields, a.cpu_particles, np.random.default_rng(5))
+            ref = os.path.join(ROOT, 'profiles', 'r02_cpu_reference_numpy.json')
+            if a.workload == 'c3' and os.path.exists(ref):   # the reference's own NumPy path, timed where /root/reference exists
+                rj = json.load(open(ref))
+                best = max(rj['runs'], key=lambda r: r['particle_steps_per_s'])
+                out['cpu_baseline']['reference_numpy'] = dict(
+                    value=best['particle_steps_per_s'], unit='particle-steps/s', cores=1, kind='reference',
+                    sample='%d particles x %d steps, median' % (best['particles'], best['steps_timed']),
+                    measured_on='%s (%s, %d cores) -- not this host; /root/reference is not on the GPU box'
+                                % (rj['measured_on'], rj['host_cpu'], rj['host_cores']), source='profiles/r02_cpu_reference_numpy.json')
         print(json.dumps(out), flush=True)
-    P.close()
+    if P is not None:
+        P.close()
     ctx.close()
     if world > 1:
         import torch.distributed as dist

@@ -351,6 +351,14 @@ int odr_deactivate(odr_ctx *ctx, odr_particles *p, const uint8_t *mask_host, int
 int odr_deactivate_outside(odr_ctx *ctx, odr_particles *p, double west, double east, double south, double north,
                            int32_t status_code);
 int odr_compact(odr_ctx *ctx, odr_particles *p, int64_t *n_active);
+/* odr_compact in two halves, for a loop that needs the deactivation state on the host once per step:
+ * odr_scan_status counts the elements that stay and reports which PROVISIONAL status numbers are present (bit k of
+ * *status_flags: some element carries status 100 + k -- a deactivation reason without a status category yet, which the
+ * caller registers and renumbers with odr_particles_remap_status, basemodel/__init__.py:1778-1781) in ONE host read;
+ * odr_compact_apply then removes the deactivated elements without another read.  No call that deactivates, adds or
+ * re-orders elements may run in between (ODR_ERR_STATE otherwise). */
+int odr_scan_status(odr_ctx *ctx, odr_particles *p, int64_t *n_kept, uint64_t *status_flags);
+int odr_compact_apply(odr_ctx *ctx, odr_particles *p, int64_t *n_active);
 /* Device-side layout operation with no reference counterpart: re-order the particle arrays by
  * the grid cell of gridded source `source_id` so that the lanes of a wavefront gather
  * neighbouring grid nodes.  Particles keep their ID; results per ID are unchanged (the device

@@ -122,6 +122,8 @@ _SIGNATURES = {
     'odr_deactivate': [_vp, _vp, _P(C.c_uint8), C.c_int32],
     'odr_deactivate_outside': [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32],
     'odr_compact': [_vp, _vp, _i64p],
+    'odr_scan_status': [_vp, _vp, _i64p, _P(C.c_uint64)],
+    'odr_compact_apply': [_vp, _vp, _i64p],
     'odr_sort_particles': [_vp, _vp, C.c_int32],
     'odr_reduce_scalars': [_vp, _vp, C.c_double, _dp],
     'odr_timer_begin': [_vp],

@@ -92,6 +92,16 @@ struct odr_particles {
   void *scratch;
   size_t scratch_bytes;
   unsigned long long epoch;  // bumped by every call that changes z, the environment, properties or the element set
+  // odr_scan_status -> odr_compact_apply: the count of the scan stays valid while no call that can deactivate elements,
+  // add elements or re-order them has run (those bump status_epoch)
+  unsigned long long status_epoch, scan_epoch;
+  long long scan_kept;
+  // environment variables that hold ONE value for every element (no reader: the fallback; a global constant reader):
+  // env[v][0 .. env_cn[v]) == env_cval[v] while env_cok[v].  A repeated sample writes only new elements; movers whose
+  // global early-out is decided by such a value (wind, Stokes drift, horizontal diffusivity identically 0) return at once.
+  float env_cval[NVAR];
+  long long env_cn[NVAR];
+  bool env_cok[NVAR];
   bool external;
 };
 
@@ -118,6 +128,10 @@ static inline int flush_world(odr_ctx *c) {
   return 0;
 }
 
+// env[v] is the constant `val` for every element (see odr_particles::env_cok)
+static inline bool env_is_const(const odr_particles *p, int v, float val) {
+  return p->env[v] && p->env_cok[v] && p->env_cn[v] >= p->n && p->env_cval[v] == val;
+}
 static inline int ensure_env(odr_ctx *c, odr_particles *p, int var) {
   if (!p->env[var]) {
     HIPCHK(hipMalloc((void **)&p->env[var], sizeof(float) * (size_t)p->cap));

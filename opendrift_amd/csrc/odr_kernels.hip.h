@@ -1692,14 +1692,25 @@ __global__ __launch_bounds__(BLOCK) void k_deactivate(PView p, const unsigned ch
 // remove_deactivated_elements = LagrangianArray.move_elements (elements.py:197-228):
 // order-preserving partition.  Pass 1 counts actives per 256-block, pass 2 scans the
 // block counts (single workgroup), pass 3 scatters every property.
-__global__ __launch_bounds__(BLOCK) void k_cmp_count(const int *status, long long n, unsigned *bcount) {
+// flags (may be NULL): bit k is set when an element carries the provisional status number 100 + k (a deactivation reason
+// that has no status category yet, opendrift_amd/oceandrift.py:_status_code) -- read back with the count in one transfer
+__global__ __launch_bounds__(BLOCK) void k_cmp_count(const int *status, long long n, unsigned *bcount,
+                                                     unsigned long long *flags, unsigned long long *total = nullptr) {
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-  bool keep = i < n && status[i] == 0;
+  const int st = i < n ? status[i] : 0;
+  bool keep = i < n && st == 0;
+  if (flags && __ballot(st >= 100 && st < 164)) {   // rare: only while a reason waits for its first occurrence
+    if (st >= 100 && st < 164) atomicOr(flags, 1ull << (st - 100));
+  }
   unsigned long long b = __ballot(keep);
   __shared__ unsigned wc[BLOCK / 64];
   if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = (unsigned)__popcll(b);
   __syncthreads();
-  if (threadIdx.x == 0) bcount[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+  if (threadIdx.x == 0) {
+    const unsigned cnt = wc[0] + wc[1] + wc[2] + wc[3];
+    bcount[blockIdx.x] = cnt;
+    if (total && cnt) atomicAdd(total, (unsigned long long)cnt);   // the number of elements that stay
+  }
 }
 
 __global__ __launch_bounds__(1024) void k_cmp_scan(unsigned *bcount, long long nblocks,

@@ -5,6 +5,7 @@
 
 int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, int mix_at_surface, int rng_mode,
              const double *huni, uint64_t step) {
+  p->status_epoch++;
   p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(dt_mix > 0 && dt != 0, "bad time steps");
   if (!p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
@@ -76,6 +77,7 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
 // 'environment' model does when no reader provides ocean_vertical_diffusivity (:431-447 -> Large et al. 1994)
 int odr_vmix_wind_profile(odr_ctx *c, odr_particles *p, int model, double background_diffusivity, double dt,
                           double dt_mix, int mix_at_surface, int rng_mode, const double *huni, uint64_t step) {
+  p->status_epoch++;
   p->epoch++;
   REQUIRE(model == ODR_DIFFUSIVITY_LARGE1994 || model == ODR_DIFFUSIVITY_SUNDBY1983, "Unknown diffusivity model: %d", model);
   REQUIRE(dt_mix > 0 && dt != 0, "bad time steps");

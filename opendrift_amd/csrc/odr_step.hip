@@ -89,6 +89,7 @@ static bool s_is_latlong_3d(const odr_ctx *c, int sid) {
 int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t,
                          int coast_action, int stranded_code, int seeded_on_land_code, int store_previous,
                          int scheme, double dt, double factor, const odr_step_extras *extras, int64_t *n_on_land) {
+  p->status_epoch++;
   p->epoch++;  // invalidates the cached reductions (reduce())
   const StageNoise N = take_noise(c, p);
   const bool main_noise = N.on && extras && extras->main_noise;
@@ -168,7 +169,8 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
     if ((rc = advect_impl(c, p, scheme, t, dt, factor, N))) return rc;
     return want_mix ? mix_after(c, p, t, dt, extras) : 0;
   }
-  for (int k = 0; k < ng; ++k) if ((rc = ensure_env(c, p, grp[k]))) return rc;
+  for (int k = 0; k < ng; ++k) { if ((rc = ensure_env(c, p, grp[k]))) return rc; p->env_cok[grp[k]] = false; }
+  if (coast_action == 2) p->env_cok[VAR_LAND] = false;   // elements on land get land_binary_mask = 0
   if (nrest && (rc = env_sample_impl(c, p, nrest, rest, t, nullptr, false))) return rc;  // k_step_grid records the positions
   StepDesc S;
   memset(&S, 0, sizeof S);

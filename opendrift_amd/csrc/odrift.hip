@@ -109,6 +109,7 @@ int odr_particles_create(odr_ctx *c, int64_t capacity, odr_particles **out) {
   memset(p, 0, sizeof(*p));
   p->cap = capacity;
   p->dead_cap = capacity;
+  p->scan_kept = -1;
   for (int k = 0; k < 7; ++k) HIPCHK(hipMalloc((void **)&p->d64[k], sizeof(double) * (size_t)capacity));
   for (int k = 0; k < 3; ++k) HIPCHK(hipMalloc((void **)&p->i32[k], sizeof(int) * (size_t)capacity));
   for (int k = 0; k < 4; ++k) HIPCHK(hipMalloc((void **)&p->f32[k], sizeof(float) * (size_t)capacity));
@@ -150,6 +151,7 @@ static int put(odr_ctx *c, T *dst, const T *src, long long n, T dflt) {
 int odr_particles_append(odr_ctx *c, odr_particles *p, int64_t n, const double *lon, const double *lat,
                          const double *z, const int32_t *id, const int32_t *moving, const float *wdf,
                          const float *cdf, const float *tv) {
+  p->status_epoch++;
   p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(n >= 0 && lon && lat, "lon/lat required");
   if (p->n + n > p->cap) return fail(ODR_ERR_CAPACITY, "capacity %lld exceeded (%lld + %lld)", p->cap, p->n, (long long)n);
@@ -218,6 +220,7 @@ int odr_particles_download_deactivated(odr_ctx *c, odr_particles *p, double *lon
 
 int odr_particles_upload(odr_ctx *c, odr_particles *p, const double *lon, const double *lat, const double *z,
                          const int32_t *moving, const float *wdf, const float *cdf, const float *tv) {
+  p->status_epoch++;
   p->epoch++;  // invalidates the cached reductions (reduce())
   size_t n = (size_t)p->n;
   if (lon) HIPCHK(hipMemcpyAsync(p->d64[0], lon, 8 * n, hipMemcpyHostToDevice, c->stream));
@@ -243,6 +246,7 @@ int odr_particles_device_ptr(odr_ctx *c, odr_particles *p, const char *name, voi
     REQUIRE(v >= 0 && v < NVAR, "bad variable id");
     int rc = ensure_env(c, p, v);
     if (rc) return rc;
+    p->env_cok[v] = false;
     *dptr = p->env[v];
     return 0;
   }
@@ -684,8 +688,10 @@ int odr_host_unregister(odr_ctx *c, void *ptr) {
 
 int odr_block_drop(odr_ctx *c, int32_t sid, int32_t slot) {
   REQUIRE(sid >= 0 && sid < c->nsrc && slot >= 0 && slot < MAXLEVELS, "bad source/slot");
-  HIPCHK(hipStreamSynchronize(c->stream));
-  for (void *b : c->block_bufs[sid][slot]) HIPCHK(hipFree(b));
+  // no host synchronisation: the block is freed (or recycled by the next upload of the same size) once the compute
+  // stream has passed this point
+  int rc;
+  for (void *b : c->block_bufs[sid][slot]) if ((rc = retire(c, b, c->block_bytes[sid][slot]))) return rc;
   c->block_bufs[sid][slot].clear();
   if (c->staged[sid][slot].base) {
     HIPCHK(hipStreamSynchronize(c->up_stream));
@@ -788,6 +794,15 @@ static bool launch_env_grid(odr_ctx *c, odr_particles *p, const int *grp, int ng
   return true;
 }
 
+// every element gets the same value: write only the elements that do not hold it yet (a steady run: none)
+static void fill_const(odr_ctx *c, odr_particles *p, int v, float f) {
+  const bool same = p->env_cok[v] && memcmp(&p->env_cval[v], &f, sizeof f) == 0;
+  const long long from = same ? std::min(p->env_cn[v], p->n) : 0;
+  if (from < p->n)
+    hipLaunchKernelGGL(k_fill_f32, dim3(nblk(p->n - from)), dim3(BLOCK), 0, c->stream, p->env[v] + from, p->n - from, f);
+  p->env_cok[v] = true; p->env_cval[v] = f; p->env_cn[v] = p->n;
+}
+
 // fast path of odr_env_sample: a group served by one constant reader that covers the globe and all times
 // (reader_constant.py:60-82): every element gets the constant, cast to float32 -- a fill per variable
 static bool launch_env_constant(odr_ctx *c, odr_particles *p, const int *grp, int ng, double t) {
@@ -802,7 +817,7 @@ static bool launch_env_constant(odr_ctx *c, odr_particles *p, const int *grp, in
     float f = (float)s.const_val[grp[k]];
     if (!std::isfinite(f)) f = std::isfinite(w.fallback[grp[k]]) ? w.fallback[grp[k]] : f;
     if (grp[k] == VAR_TEMP && f > 100.f) f = (float)((double)f - 273.15);   // Kelvin -> Celsius (environment.py:829-838)
-    hipLaunchKernelGGL(k_fill_f32, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->env[grp[k]], p->n, f);
+    fill_const(c, p, grp[k], f);
   }
   return true;
 }
@@ -875,13 +890,14 @@ int odr_i_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var
         for (int k = 0; k < ng; ++k) {
           float f = c->hw.fallback[grp[k]];
           if (grp[k] == VAR_TEMP && f > 100.f) f = (float)((double)f - 273.15);   // Kelvin -> Celsius (environment.py:829-838)
-          hipLaunchKernelGGL(k_fill_f32, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->env[grp[k]], p->n, f);
+          fill_const(c, p, grp[k], f);
         }
         continue;
       }
+      if (!getenv("ODR_NO_FAST_PATH") && launch_env_constant(c, p, grp, ng, t)) continue;   // (positions recorded below)
+      for (int k = 0; k < ng; ++k) p->env_cok[grp[k]] = false;   // written per element by the kernels below
       if (!getenv("ODR_NO_FAST_PATH") && launch_env_grid(c, p, grp, ng, t, rec)) { rec = 0; continue; }
       if (!getenv("ODR_NO_FAST_PATH") && launch_env_gyre(c, p, grp, ng, t, rec)) { rec = 0; continue; }
-      if (!getenv("ODR_NO_FAST_PATH") && launch_env_constant(c, p, grp, ng, t)) continue;   // (positions recorded below)
       // the whole group goes through one launch: the reference decides "static variables only"
       // and the missing-data mask per reader call on the full group (structured.py:224-229,
       // environment.py:727-746)
@@ -921,6 +937,7 @@ int odr_env_download(odr_ctx *c, odr_particles *p, int32_t var, float *out) {
 int odr_env_upload(odr_ctx *c, odr_particles *p, int32_t var, const float *host) {
   p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(var >= 0 && var < NVAR && host, "bad arguments");
+  p->env_cok[var] = false;
   int rc = ensure_env(c, p, var);
   if (rc) return rc;
   if (p->n > 0) HIPCHK(hipMemcpyAsync(p->env[var], host, sizeof(float) * (size_t)p->n, hipMemcpyHostToDevice, c->stream));
@@ -946,6 +963,7 @@ int odr_i_env_noise(odr_ctx *c, odr_particles *p, int vx, int vy, double std, in
   REQUIRE(vx >= 0 && vx < NVAR && vy >= 0 && vy < NVAR, "bad variable ids");
   REQUIRE(distribution == ODR_NOISE_NORMAL || distribution == ODR_NOISE_UNIFORM, "unknown noise distribution %d", distribution);
   if (!p->env[vx] || !p->env[vy]) return fail(ODR_ERR_STATE, "variables not sampled");
+  p->env_cok[vx] = p->env_cok[vy] = false;
   if (p->n == 0) return 0;
   hipLaunchKernelGGL(k_env_noise, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), vx, vy, std, distribution, rng_mode,
                      dev_nx, dev_ny, c->seed, step);
@@ -1020,6 +1038,7 @@ int odr_particles_get_property(odr_ctx *c, odr_particles *p, int slot, float *ho
 // Leeway.update (models/leeway.py:430-494, capsizing off)
 int odr_leeway(odr_ctx *c, odr_particles *p, double dt, double capsize_fraction, int rng_mode, const double *huni,
                uint64_t step) {
+  p->status_epoch++;
   for (int k = 0; k < 9; ++k) if (!p->aux[k]) return fail(ODR_ERR_STATE, "Leeway property slot %d has not been set", k);
   if (!p->env[VAR_XWIND] || !p->env[VAR_YWIND] || !p->env[VAR_U] || !p->env[VAR_V])
     return fail(ODR_ERR_STATE, "wind and current must be sampled before odr_leeway");
@@ -1039,6 +1058,7 @@ int odr_leeway(odr_ctx *c, odr_particles *p, double dt, double capsize_fraction,
 // processes:capsizing of Leeway.update (models/leeway.py:438-455); call before odr_leeway
 int odr_leeway_capsize(odr_ctx *c, odr_particles *p, double dt, double wind_threshold, double wind_threshold_sigma,
                        int rng_mode, const double *huni, uint64_t step) {
+  p->status_epoch++;
   p->epoch++;
   if (!p->aux[8]) return fail(ODR_ERR_STATE, "Leeway property slot 8 (capsized) has not been set");
   if (!p->env[VAR_XWIND] || !p->env[VAR_YWIND]) return fail(ODR_ERR_STATE, "wind must be sampled before odr_leeway_capsize");
@@ -1088,6 +1108,8 @@ int odr_advect_wind(odr_ctx *c, odr_particles *p, double dt, double wdd, int rel
   if (!p->env[VAR_XWIND] || !p->env[VAR_YWIND]) return fail(ODR_ERR_STATE, "wind has not been sampled");
   if (relwind && (!p->env[VAR_U] || !p->env[VAR_V])) return fail(ODR_ERR_STATE, "current has not been sampled");
   if (p->n == 0) return 0;
+  // wind identically 0 (no reader, fallback 0): wind_speed.max() == 0 -> "No wind for wind-sheared ocean drift" (:775-780)
+  if (!relwind && env_is_const(p, VAR_XWIND, 0.0f) && env_is_const(p, VAR_YWIND, 0.0f)) return 0;
   int rc = reduce(c, p, wdd, relwind);
   if (rc) return rc;
   hipLaunchKernelGGL(k_advect_wind, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, wdd, relwind, factor, c->red);
@@ -1101,6 +1123,7 @@ int odr_stokes_drift(odr_ctx *c, odr_particles *p, double dt, int profile, int h
   if ((hs_mode == 0 && !p->env[VAR_HS]) || (tp_mode == 0 && !p->env[VAR_TP])) return fail(ODR_ERR_STATE, "Hs/Tp not sampled");
   if ((hs_mode == 1 || tp_mode == 1 || tp_mode == 3) && (!p->env[VAR_XWIND] || !p->env[VAR_YWIND])) return fail(ODR_ERR_STATE, "wind not sampled");
   if (p->n == 0) return 0;
+  if (env_is_const(p, VAR_SX, 0.0f) && env_is_const(p, VAR_SY, 0.0f)) return 0;   // "No Stokes drift velocity available" (:799-804)
   int rc = reduce(c, p, 0.0, 0, false);
   if (rc) return rc;
   hipLaunchKernelGGL(k_stokes, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, profile, hs_mode, tp_mode, factor, c->red);
@@ -1111,6 +1134,7 @@ int odr_stokes_drift(odr_ctx *c, odr_particles *p, double dt, int profile, int h
 int odr_hdiffusion(odr_ctx *c, odr_particles *p, double dt, int rng_mode, const double *hnx, const double *hny, uint64_t step) {
   if (!p->env[VAR_HDIFF]) return fail(ODR_ERR_STATE, "horizontal_diffusivity has not been sampled");
   if (p->n == 0) return 0;
+  if (env_is_const(p, VAR_HDIFF, 0.0f)) return 0;   // "Horizontal diffusivity is 0, no random walk." (:1754)
   double *da = nullptr, *db = nullptr;
   int rc;
   if (rng_mode == ODR_RNG_HOST) {
@@ -1141,6 +1165,7 @@ int odr_vertical_advection(odr_ctx *c, odr_particles *p, double dt, int at_surfa
 }
 
 int odr_vertical_buoyancy(odr_ctx *c, odr_particles *p, double dt) {
+  p->status_epoch++;
   p->epoch++;  // invalidates the cached reductions (reduce())
   if (!p->env[VAR_DEPTH]) return fail(ODR_ERR_STATE, "sea_floor_depth_below_sea_level has not been sampled");
   int rc = ensure_env(c, p, VAR_SSH);
@@ -1179,6 +1204,7 @@ int odr_source_time_coverage(odr_ctx *c, int32_t sid, double t_start, double t_e
 }
 
 int odr_deactivate_missing(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, int32_t code, int64_t *n_missing) {
+  p->status_epoch++;
   p->epoch++;
   REQUIRE(nvars >= 0 && nvars <= NVAR && (nvars == 0 || var_ids), "bad variable list");
   if (n_missing) *n_missing = 0;
@@ -1197,6 +1223,7 @@ int odr_deactivate_missing(odr_ctx *c, odr_particles *p, int nvars, const int32_
 }
 
 int odr_increase_age(odr_ctx *c, odr_particles *p, double dt, double max_age_seconds, int retired_code) {
+  if (max_age_seconds > 0) p->status_epoch++;   // only retirement deactivates
   p->epoch++;  // invalidates the cached reductions (reduce())
   if (p->n == 0) return 0;
   hipLaunchKernelGGL(k_age, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), (float)dt, (float)max_age_seconds, retired_code);
@@ -1205,11 +1232,13 @@ int odr_increase_age(odr_ctx *c, odr_particles *p, double dt, double max_age_sec
 }
 
 int odr_coastline(odr_ctx *c, odr_particles *p, int action, int code, int seeded_on_land_code, int64_t *n_on_land) {
+  p->status_epoch++;
   p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(action >= 0 && action <= 2, "bad coastline action");
   if (n_on_land) *n_on_land = 0;
   if (action == 0 || p->n == 0) return 0;
   if (!p->env[VAR_LAND]) return fail(ODR_ERR_STATE, "land_binary_mask has not been sampled");
+  if (action == 2) p->env_cok[VAR_LAND] = false;   // elements on land get land_binary_mask = 0
   HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
   hipLaunchKernelGGL(k_coast, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), action, code, seeded_on_land_code, c->counter);
   HIPCHK(hipGetLastError());
@@ -1218,6 +1247,7 @@ int odr_coastline(odr_ctx *c, odr_particles *p, int action, int code, int seeded
 
 int odr_coastline_crossing(odr_ctx *c, odr_particles *p, int action, int code, int seeded_on_land_code,
                            double precision_deg, int32_t landmask_source, int64_t *n_on_land) {
+  p->status_epoch++;
   p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(action == ODR_COAST_STRANDING || action == ODR_COAST_PREVIOUS, "bad coastline action");
   REQUIRE(precision_deg > 0, "coastline_approximation_precision must be positive");
@@ -1228,6 +1258,7 @@ int odr_coastline_crossing(odr_ctx *c, odr_particles *p, int action, int code, i
   if (!p->env[VAR_LAND]) return fail(ODR_ERR_STATE, "land_binary_mask has not been sampled");
   int rc = flush_world(c);
   if (rc) return rc;
+  p->env_cok[VAR_LAND] = false;
   HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
   hipLaunchKernelGGL(k_coast_crossing, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, c->dw, (int)landmask_source, view(p),
                      action, code, seeded_on_land_code, precision_deg, c->counter);
@@ -1236,6 +1267,7 @@ int odr_coastline_crossing(odr_ctx *c, odr_particles *p, int action, int code, i
 }
 
 int odr_seafloor_action(odr_ctx *c, odr_particles *p, int action, int32_t code, int64_t *n_below) {
+  p->status_epoch++;
   p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(action >= ODR_SEAFLOOR_LIFT && action <= ODR_SEAFLOOR_PREVIOUS, "unknown seafloor action %d", action);
   if (n_below) *n_below = 0;
@@ -1276,6 +1308,7 @@ int odr_seafloor(odr_ctx *c, odr_particles *p, int64_t *n_below) {
 }
 
 int odr_deactivate(odr_ctx *c, odr_particles *p, const uint8_t *mask, int32_t code) {
+  p->status_epoch++;
   p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(mask, "mask NULL");
   if (p->n == 0) return 0;
@@ -1292,6 +1325,7 @@ int odr_deactivate(odr_ctx *c, odr_particles *p, const uint8_t *mask, int32_t co
 // deactivate_outside (basemodel/__init__.py:2354-2382); NaN bound = not set
 int odr_deactivate_outside(odr_ctx *c, odr_particles *p, double west, double east, double south, double north,
                            int32_t code) {
+  p->status_epoch++;
   p->epoch++;
   if (p->n == 0) return 0;
   const int uW = west == west, uE = east == east, uS = south == south, uN = north == north;
@@ -1342,27 +1376,51 @@ static void swap_sets(odr_particles *p) {
   for (int k = 0; k < 9; ++k) if (p->aux[k]) std::swap(p->aux[k], p->altaux[k]);
 }
 
-int odr_compact(odr_ctx *c, odr_particles *p, int64_t *n_active) {
+// First half of odr_compact: how many elements stay, and which provisional status numbers (100 + k -> bit k of *flags)
+// are present -- one kernel pair, ONE host read for both (the run() loop needs both every step).
+int odr_scan_status(odr_ctx *c, odr_particles *p, int64_t *n_kept, uint64_t *flags) {
+  HIPCHK(hipSetDevice(c->device));
+  if (n_kept) *n_kept = p->n;
+  if (flags) *flags = 0;
+  if (p->n == 0) return 0;
+  unsigned nb = nblk(p->n);
+  HIPCHK(hipMemsetAsync(c->counter + 1, 0, 2 * sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_cmp_count, dim3(nb), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount, c->counter + 2, c->counter + 1);
+  unsigned long long out[2];
+  HIPCHK(hipMemcpyAsync(out, c->counter + 1, sizeof out, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (n_kept) *n_kept = (int64_t)out[0];
+  if (flags) *flags = out[1];
+  p->scan_kept = (long long)out[0];
+  p->scan_epoch = p->status_epoch;
+  return 0;
+}
+
+// Second half: remove the deactivated elements using the counts of the last odr_scan_status (no host read).  Valid as
+// long as no element changed between active and deactivated since the scan (renumbering statuses is fine).
+int odr_compact_apply(odr_ctx *c, odr_particles *p, int64_t *n_active) {
   p->epoch++;  // invalidates the cached reductions (reduce())
   HIPCHK(hipSetDevice(c->device));
   if (p->n == 0) { if (n_active) *n_active = 0; return 0; }
+  if (p->scan_epoch != p->status_epoch || p->scan_kept < 0)
+    return fail(ODR_ERR_STATE, "odr_compact_apply: elements were deactivated since the last odr_scan_status");
+  const long long kept = p->scan_kept;
+  p->scan_kept = -1;
   unsigned nb = nblk(p->n);
-  hipLaunchKernelGGL(k_cmp_count, dim3(nb), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount);
-  hipLaunchKernelGGL(k_cmp_scan, dim3(1), dim3(1024), 0, c->stream, p->bcount, (long long)nb, c->counter + 1);
-  unsigned long long kept;
-  HIPCHK(hipMemcpyAsync(&kept, c->counter + 1, sizeof kept, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  if ((long long)kept == p->n) { if (n_active) *n_active = p->n; return 0; }  // "No elements to deactivate"
+  if (kept == p->n) { if (n_active) *n_active = p->n; return 0; }  // "No elements to deactivate"
   int rc = ensure_alt(p);  // (allocates the deactivated store)
   if (rc) return rc;
+  // exclusive scan of the per-block counts of the last odr_scan_status (only now that something is to be removed)
+  hipLaunchKernelGGL(k_cmp_scan, dim3(1), dim3(1024), 0, c->stream, p->bcount, (long long)nb, c->counter + 3);
   CmpArrays A;
   all_arrays(p, A);
-  long long removed = p->n - (long long)kept;
+  long long removed = p->n - kept;
   if (getenv("ODR_ORDERED_COMPACT")) {  // order-preserving variant: rewrites every array
     hipLaunchKernelGGL(k_cmp_scatter, dim3(nb), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount, A, p->ndead);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     swap_sets(p);
+    for (int v = 0; v < NVAR; ++v) p->env_cn[v] = std::min(p->env_cn[v], kept);
   } else {
     void *sc;
     if ((rc = scratch(c, p, sizeof(unsigned) * 2 * (size_t)removed, &sc))) return rc;
@@ -1374,9 +1432,15 @@ int odr_compact(odr_ctx *c, odr_particles *p, int64_t *n_active) {
     HIPCHK(hipGetLastError());
   }
   p->ndead += removed;
-  p->n = (long long)kept;
+  p->n = kept;
   if (n_active) *n_active = p->n;
   return 0;
+}
+
+int odr_compact(odr_ctx *c, odr_particles *p, int64_t *n_active) {
+  int rc = odr_scan_status(c, p, nullptr, nullptr);
+  if (rc) return rc;
+  return odr_compact_apply(c, p, n_active);
 }
 
 // Re-order the particle arrays by the grid cell of one gridded reader (see k_sort_hist).
@@ -1412,8 +1476,9 @@ int odr_sort_particles(odr_ctx *c, odr_particles *p, int32_t sid) {
   all_arrays(p, A);
   hipLaunchKernelGGL(k_gather_perm, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, perm, p->n, A);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(c->stream));
-  swap_sets(p);
+  swap_sets(p);     // host pointers only: everything after this call is ordered behind the gather on the stream
+  for (int v = 0; v < NVAR; ++v) p->env_cn[v] = std::min(p->env_cn[v], p->n);
+  p->status_epoch++;
   return 0;
 }
 

@@ -618,6 +618,21 @@ class Particles:
             self._permuted = True
         return n.value
 
+    def scan_status(self):
+        """(elements that stay, provisional status numbers present as a bit mask: bit k <-> status 100 + k) in one host
+        read (odr_scan_status); follow with compact_apply()."""
+        n, f = C.c_int64(), C.c_uint64()
+        check(self.lib.odr_scan_status(self.ctx.h, self.h, C.byref(n), C.byref(f)))
+        return n.value, f.value
+
+    def compact_apply(self):
+        n0 = len(self)
+        n = C.c_int64()
+        check(self.lib.odr_compact_apply(self.ctx.h, self.h, C.byref(n)))
+        if n.value != n0:
+            self._permuted = True
+        return n.value
+
     def sort_by_cell(self, source_id):
         """Re-order the SoA by grid cell of a gridded source (layout only; IDs are preserved)."""
         check(self.lib.odr_sort_particles(self.ctx.h, self.h, int(source_id)))

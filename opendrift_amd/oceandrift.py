@@ -16,6 +16,7 @@ Out of scope (host-side features of the reference that are not on the path): plo
 export, the GSHHG global landmask (`general:use_auto_landmask`), lazy readers.
 """
 import logging
+import time
 from datetime import datetime, timedelta
 from types import SimpleNamespace
 
@@ -244,8 +245,7 @@ class OpenDriftSimulation(Configurable):
                 time = [time[0] + i * td for i in range(number)]
             else:
                 raise ValueError('Time array has length %s, must be 1, 2 or %s' % (len(time), number))
-        if len(time) == 1:
-            time = time * number
+        single_time = len(time) == 1
         if radius.max() > 0:   # :1151-1170
             if radius_type == 'gaussian':
                 x = np.random.randn(number) * radius
@@ -269,8 +269,9 @@ class OpenDriftSimulation(Configurable):
         # LagrangianArray stores lon/lat/z as float32 at seeding (elements.py:71-88,156-158)
         new = dict(lon=np.float32(lon).astype(np.float64), lat=np.float32(lat).astype(np.float64),
                    z=(np.float32(z) * np.ones(number, np.float32)).astype(np.float64),
-                   time=np.array(time, dtype=object),
-                   t_epoch=np.array(time, dtype='datetime64[us]').astype(np.int64) / 1e6, **props)   # vectorised schedule
+                   time=np.full(number, time[0], dtype=object) if single_time else np.array(time, dtype=object),
+                   t_epoch=(np.full(number, _epoch(time[0])) if single_time else
+                            np.array(time, dtype='datetime64[us]').astype(np.int64) / 1e6), **props)   # vectorised schedule
         if self._sched is None:
             self._sched = new
         else:
@@ -390,15 +391,19 @@ class OpenDriftSimulation(Configurable):
             self._pending_status.append(reason)
         return code
 
-    def _resolve_status(self):
+    def _resolve_status(self, flags=None):
         """Register the pending reasons that occurred (in the order of the calls that could assign them) and renumber
-        their elements.  No device work when nothing is pending."""
+        their elements.  `flags`: the provisional status numbers present (Particles.scan_status); without it one scan is
+        made -- one host read however many reasons are pending, none when nothing is pending."""
         pending, self._pending_status = self._pending_status, []
+        pending = [r for r in pending if r not in self.status_categories]
+        if not pending:
+            return
+        if flags is None:
+            flags = self.P.scan_status()[1] if len(self.P) else 0
         for reason in pending:
-            if reason in self.status_categories:
-                continue
             code = self._PROVISIONAL[reason]
-            if self.P.count_status(code):
+            if flags >> (code - 100) & 1:
                 self.status_categories.append(reason)
                 self.P.remap_status(code, self.status_categories.index(reason))
 
@@ -518,12 +523,20 @@ class OpenDriftSimulation(Configurable):
         self.P.advect_wind(self.time_step.total_seconds(), self.get_config('drift:wind_drift_depth', 0.1),
                            self.get_config('drift:relative_wind'), factor)
 
+    def _identically_zero(self, v):
+        """No reader delivers `v` and its fallback is 0: the variable is 0 for every element without looking."""
+        live = [n for n in self.priority_list.get(v, []) if n in self.readers and self.readers[n].sid is not None]
+        return not live and v in self.required_variables and self.get_config('environment:fallback:%s' % v) == 0
+
     def stokes_drift(self, factor=1):
         if self.get_config('drift:stokes_drift') is False:
             return
         profile = {'monochromatic': 0, 'exponential': 1, 'Phillips': 2}.get(self.get_config('drift:stokes_drift_profile', 'Phillips'))
         if profile is None:
             raise NotImplementedError('windsea_swell Stokes profile is not on the device path')
+        if self._identically_zero('sea_surface_wave_stokes_drift_x_velocity') and \
+                self._identically_zero('sea_surface_wave_stokes_drift_y_velocity'):
+            return      # "No Stokes drift velocity available" (physics_methods.py:799-804) without a device round trip
         r = self.P.reduce_scalars(self.get_config('drift:wind_drift_depth', 0.1))
         if r['stokes_sum_max'] == 0:
             return
@@ -624,8 +637,16 @@ class OpenDriftSimulation(Configurable):
                       self.get_config('general:seafloor_action', 'lift_to_seafloor') in ('lift_to_seafloor', 'none') and
                       not self.get_config('general:coastline_approximation_precision') and
                       'x_sea_water_velocity' in self.required_variables and 'y_sea_water_velocity' in self.required_variables)
+        self.ctx.sync()
+        t_loop = [time.perf_counter(), None]      # main-loop wall time (the reference keeps 'main loop' timers, basemodel :2174)
+        # increase_age_and_retire comes after state_to_buffer in the loop: inside the fused launch only when the result
+        # buffer does not hold age_seconds (it would see the age one step ahead)
+        age_in_launch = 'age_seconds' not in self._hist.variables
         for i in range(steps):
             try:
+                if i == 1:
+                    self.ctx.sync()
+                    t_loop[1] = time.perf_counter()   # after the first step: seeding, first uploads and sort are behind
                 self.release_elements()
                 if self.num_elements_active() == 0 and self.num_elements_scheduled() > 0:
                     self._state_to_buffer(i, out_every, times)   # (:2208)
@@ -660,13 +681,16 @@ class OpenDriftSimulation(Configurable):
                                              else 0),
                         store_previous=True, count=False, seafloor=floor,
                         missing_code=self._status_code('missing_data') if self._can_be_missing(names) else 0,
-                        main_noise=noisy)
+                        main_noise=noisy, age_dt=self.time_step.total_seconds() if age_in_launch else 0.0)
                     self._sampled = names
                     self._add_uncertainty(names, current=False)     # the wind's share
-                    self._resolve_status()
+                    # ONE host read per step: how many elements stay + which new deactivation reasons occurred
+                    kept, flags = self.P.scan_status()
+                    self._resolve_status(flags)
                     self._state_to_buffer(i, out_every, times, from_previous=True)
-                    self.P.increase_age(self.time_step.total_seconds())
-                    self.P.compact()
+                    if not age_in_launch:
+                        self.P.increase_age(self.time_step.total_seconds())
+                    self.P.compact_apply()
                     self._advected = True
                 else:
                     self.get_environment()
@@ -695,6 +719,10 @@ class OpenDriftSimulation(Configurable):
                     raise
                 logger.warning('The simulation stopped before requested end time was reached: %s', e)
                 break
+        self.ctx.sync()
+        t_end = time.perf_counter()
+        self.timing = {'main_loop_s': t_end - t_loop[0], 'steps': self.steps_calculation,
+                       'steady_ms_per_step': (1e3 * (t_end - t_loop[1]) / max(1, self.steps_calculation - 1)) if t_loop[1] else None}
         self.interact_with_coastline(final=True)
         self._resolve_status()
         self._state_to_buffer(self.steps_calculation, out_every, times, final=True)

@@ -403,9 +403,14 @@ class DeviceReaderBinding:
         # prefetch the time level the run will need next (readers whose arrays live in host memory)
         if self.prefetch and r.times is not None and broadcast is None and not getattr(r, 's_levels', False):
             kn = (max(need) + 1) if t1 >= t0 else (min(need) - 1)
-            if 0 <= kn < len(r.times) and kn not in self.slots and kn not in self.staged and \
-                    len(self.slots) + len(self.staged) < self.NSLOTS:
-                self._upload(kn, extent, None, asynchronous=True)
+            if 0 <= kn < len(r.times) and kn not in self.slots and kn not in self.staged:
+                if len(self.slots) + len(self.staged) >= self.NSLOTS:     # room for the prefetch: the stalest level goes
+                    stale = [k for k in self.slots if k not in need]
+                    if stale:
+                        k_old = min(stale) if t1 >= t0 else max(stale)
+                        self.ctx.drop_block(self.sid, self.slots.pop(k_old))
+                if len(self.slots) + len(self.staged) < self.NSLOTS:
+                    self._upload(kn, extent, None, asynchronous=True)
 
     def _upload(self, k, extent, broadcast, asynchronous):
         """One reader time level -> one device block (synchronously, or staged on the upload stream)."""
