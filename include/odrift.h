@@ -300,6 +300,13 @@ int odr_oil_prepare_mixing(odr_ctx *ctx, odr_particles *p, double dt, double dt_
                            int tp_mode, int temperature_to_kelvin, int rng_mode, const double *host_u_diameter,
                            const double *host_u_entrain, const double *host_u_intrusion, uint64_t step);
 int odr_oil_mixing_stats(odr_ctx *ctx, double *mean_zb, double *dv50);
+/* Sharded run (one process per GPU): OpenOil takes two means over ALL elements -- np.mean(dV_50) of the droplet spectrum
+ * (openoil.py:1099-1101,1156-1158) and np.mean(1.5 Hs) (:1047).  odr_oil_local_sums returns this rank's sums (the
+ * float32 1.5 Hs summed in float64), the caller adds sums and element counts over the ranks and installs the means;
+ * the next odr_oil_prepare_mixing uses them instead of reducing over its own elements. */
+int odr_oil_local_sums(odr_ctx *ctx, odr_particles *p, double interfacial_tension, double sea_water_density,
+                       int droplet_distribution, int hs_mode, double *sum_dv50, double *sum_zb);
+int odr_oil_set_mixing_stats(odr_ctx *ctx, double mean_zb, double dv50);
 /* performance hint: apply vertical_advection (oceandrift.py:315-350) inside the next odr_vmix
  * kernel (OceanDrift.update() calls them back to back, oceandrift.py:201-208) */
 int odr_vmix_fuse_vertical_advection(odr_ctx *ctx, int at_surface);
@@ -369,6 +376,14 @@ int odr_sort_particles(odr_ctx *ctx, odr_particles *p, int32_t source_id);
  * out16 = {n_active, lon_min, lon_max, lat_min, lat_max, z_min, z_max, D_max, stokes_sum_max,
  *          wind_speed_max, wdf_surface_max, n_surface, hs_max, tp_max, 0, 0} */
 int odr_reduce_scalars(odr_ctx *ctx, odr_particles *p, double wind_drift_depth, double *out16);
+/* The same reductions for a run sharded over several GPUs (one process per GPU): odr_reduce_local returns the RAW slots
+ * of this particle set (0 and 11 are counts, every other slot a maximum; minima negated), the caller combines them over
+ * the ranks (sum / max: an all-reduce of 16 doubles) and installs the result; until odr_reduce_unpin the movers
+ * (odr_advect_wind, odr_stokes_drift, odr_hdiffusion, odr_vmix_wind_profile) use the installed values -- their global
+ * early-outs and MLD.max() are then those of the reference's single process, independent of the number of ranks. */
+int odr_reduce_local(odr_ctx *ctx, odr_particles *p, double wind_drift_depth, int relative_wind, double *out16);
+int odr_reduce_install(odr_ctx *ctx, odr_particles *p, const double *in16);
+int odr_reduce_unpin(odr_ctx *ctx);
 
 /* kernel timing hook for bench.py: HIP events recorded on the context stream around the
  * launches issued between begin and end; returns milliseconds */
@@ -391,6 +406,9 @@ enum {
 typedef struct odr_history odr_history;
 int odr_history_create(odr_ctx *ctx, int64_t n_trajectories, int32_t n_times, int32_t nvars,
                        const int32_t *var_codes, odr_history **out);
+/* trajectory row 0 of the buffer = element `id_base` (default 0): one rank of a particle-sharded run records its own
+ * contiguous ID range */
+int odr_history_set_id_base(odr_ctx *ctx, odr_history *h, int64_t id_base);
 int odr_history_destroy(odr_ctx *ctx, odr_history *h);
 /* position_from_previous: lon / lat are taken from the state saved by update_previous_state (odr_store_previous,
  * odr_env_coast_advect) -- the position before this step's advection -- so that the record may follow the fused launch */

@@ -106,6 +106,8 @@ _SIGNATURES = {
     'odr_oil_prepare_mixing': [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_int, _dp, _dp, _dp, C.c_uint64],
     'odr_oil_mixing_stats': [_vp, _dp, _dp],
+    'odr_oil_local_sums': [_vp, _vp, C.c_double, C.c_double, C.c_int, C.c_int, _dp, _dp],
+    'odr_oil_set_mixing_stats': [_vp, C.c_double, C.c_double],
     'odr_vertical_advection': [_vp, _vp, C.c_double, C.c_int],
     'odr_vertical_buoyancy': [_vp, _vp, C.c_double],
     'odr_store_previous': [_vp, _vp],
@@ -126,6 +128,9 @@ _SIGNATURES = {
     'odr_compact_apply': [_vp, _vp, _i64p],
     'odr_sort_particles': [_vp, _vp, C.c_int32],
     'odr_reduce_scalars': [_vp, _vp, C.c_double, _dp],
+    'odr_reduce_local': [_vp, _vp, C.c_double, C.c_int, _dp],
+    'odr_reduce_install': [_vp, _vp, _dp],
+    'odr_reduce_unpin': [_vp],
     'odr_timer_begin': [_vp],
     'odr_timer_end': [_vp, _fp],
     'odr_sgrid_create': [_vp, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.c_double, _dp, _dp, C.c_int32, _P(_vp)],
@@ -134,6 +139,7 @@ _SIGNATURES = {
     'odr_sgrid_zslice': [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int32, _dp, C.c_int32, _P(_vp), _dp],
     'odr_history_create': [_vp, C.c_int64, C.c_int32, C.c_int32, _ip, _P(_vp)],
     'odr_history_destroy': [_vp, _vp],
+    'odr_history_set_id_base': [_vp, _vp, C.c_int64],
     'odr_history_record': [_vp, _vp, _vp, C.c_int32, C.c_int, C.c_int],
     'odr_history_flush': [_vp, _vp, C.c_int32, C.c_int32],
     'odr_history_wait': [_vp, _vp],

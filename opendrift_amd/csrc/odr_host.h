@@ -60,6 +60,8 @@ struct odr_ctx {
   OilArgs oil;
   double *oil_stat, *oil_cdf, *oil_chunk, *oil_part, *oil_u;
   int *oil_guide;
+  int oil_override;            // odr_oil_set_mixing_stats: means combined over the ranks of a sharded run
+  double oil_stat_host[2];
   size_t oil_part_n, oil_u_n;
   unsigned long long *counter;
   hipEvent_t ev0, ev1;
@@ -72,6 +74,7 @@ struct odr_ctx {
   unsigned long long red_epoch;
   double red_wdd;
   int red_rel;
+  int red_pinned;   // odr_reduce_install: red[] holds values combined over the ranks of a sharded run
 };
 
 struct odr_particles {

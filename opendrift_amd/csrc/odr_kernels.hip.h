@@ -2057,11 +2057,11 @@ template <int NQ>  // record length in 16-byte quads: the record is assembled in
 __global__ __launch_bounds__(BLOCK) void k_hist_record(long long n, const int *__restrict__ id,
                                                        const int *__restrict__ status, HistVars H,
                                                        float *__restrict__ slab, long long ntraj,
-                                                       int only_deactivated) {
+                                                       int only_deactivated, long long id_base) {
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   if (only_deactivated && status[i] == 0) return;
-  const long long tr = id[i];
+  const long long tr = (long long)id[i] - id_base;   // trajectory row of this buffer (a shard of a sharded run starts at id_base)
   if (tr < 0 || tr >= ntraj) return;
   float rec[4 * NQ];
 #pragma unroll

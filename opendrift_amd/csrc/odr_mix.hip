@@ -186,8 +186,17 @@ int odr_oil_prepare_mixing(odr_ctx *c, odr_particles *p, double dt, double dt_mi
   }
   const PView v = view(p);
   const dim3 g(nb), b(BLOCK);
-  hipLaunchKernelGGL(k_oil_stats, g, b, 0, c->stream, v, a, c->oil_part);
-  hipLaunchKernelGGL(k_oil_stats_final, dim3(1), b, 0, c->stream, c->oil_part, (int)nb, (long long)p->n, c->oil_stat);
+  if (c->oil_override) {   // odr_oil_set_mixing_stats: the means over the elements of ALL ranks of a sharded run
+    c->oil_override = 0;
+    double h[OIL_STAT_N] = {0};
+    h[OIL_STAT_MEAN_ZB] = c->oil_stat_host[0];
+    h[OIL_STAT_DV50] = c->oil_stat_host[1];
+    HIPCHK(hipMemcpyAsync(c->oil_stat, h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  } else {
+    hipLaunchKernelGGL(k_oil_stats, g, b, 0, c->stream, v, a, c->oil_part);
+    hipLaunchKernelGGL(k_oil_stats_final, dim3(1), b, 0, c->stream, c->oil_part, (int)nb, (long long)p->n, c->oil_stat);
+  }
   hipLaunchKernelGGL(k_oil_spectrum_sums, dim3(OIL_SPEC_BLOCKS), b, 0, c->stream, c->oil_stat, c->oil_chunk);
   hipLaunchKernelGGL(k_oil_spectrum_offsets, dim3(1), dim3(64), 0, c->stream, c->oil_chunk, c->oil_stat);
   hipLaunchKernelGGL(k_oil_spectrum_scan, dim3(OIL_SPEC_BLOCKS), b, 0, c->stream, c->oil_stat, c->oil_chunk, c->oil_cdf);
@@ -196,6 +205,44 @@ int odr_oil_prepare_mixing(odr_ctx *c, odr_particles *p, double dt, double dt_mi
                      (unsigned long long)step);
   HIPCHK(hipGetLastError());
   c->oil_owner = p;
+  return 0;
+}
+
+// Sharded run: the two means OpenOil takes over ALL elements -- np.mean(dV_50) that parameterises the droplet spectrum
+// (openoil.py:1099-1101,1156-1158) and np.mean(1.5 Hs), the intrusion depth scale (:1047) -- as sums over this rank's
+// elements; the caller adds them over the ranks and installs the means with odr_oil_set_mixing_stats before
+// odr_oil_prepare_mixing, which then skips its own reduction.
+int odr_oil_local_sums(odr_ctx *c, odr_particles *p, double interfacial_tension, double sea_water_density,
+                       int droplet_distribution, int hs_mode, double *sum_dv50, double *sum_zb) {
+  REQUIRE(sum_dv50 && sum_zb, "NULL output");
+  *sum_dv50 = *sum_zb = 0;
+  REQUIRE(droplet_distribution == ODR_DROPLETS_JOHANSEN2015 || droplet_distribution == ODR_DROPLETS_LI2017,
+          "no wave entrainment droplet size distribution specified");
+  if (p->n == 0) return 0;
+  for (int k : {OIL_DENSITY, OIL_VISCOSITY, OIL_FILM})
+    if (!p->aux[k]) return fail(ODR_ERR_STATE, "oil property slot %d has not been set", k);
+  if (!p->env[VAR_XWIND] || !p->env[VAR_YWIND] || (hs_mode == 0 && !p->env[VAR_HS])) return fail(ODR_ERR_STATE, "wind / Hs not sampled");
+  const unsigned nb = nblk(p->n);
+  double *part = nullptr, *stat = nullptr;
+  HIPCHK(hipMalloc((void **)&part, sizeof(double) * (2 * (size_t)nb + OIL_STAT_N)));
+  stat = part + 2 * (size_t)nb;
+  OilArgs a;
+  memset(&a, 0, sizeof a);
+  a.hs_mode = hs_mode; a.droplets = droplet_distribution; a.sigma_ow = interfacial_tension; a.rho_w = sea_water_density;
+  hipLaunchKernelGGL(k_oil_stats, dim3(nb), dim3(BLOCK), 0, c->stream, view(p), a, part);
+  hipLaunchKernelGGL(k_oil_stats_final, dim3(1), dim3(BLOCK), 0, c->stream, part, (int)nb, 1LL, stat);   // n = 1: the sums
+  double h[OIL_STAT_N];
+  HIPCHK(hipMemcpyAsync(h, stat, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipFree(part));
+  *sum_dv50 = h[OIL_STAT_DV50];
+  *sum_zb = h[OIL_STAT_MEAN_ZB];
+  return 0;
+}
+int odr_oil_set_mixing_stats(odr_ctx *c, double mean_zb, double dv50) {
+  c->oil_stat_host[0] = (double)(float)mean_zb;   // np.mean of a float32 array is float32
+  c->oil_stat_host[1] = dv50;
+  c->oil_override = 1;
   return 0;
 }
 

@@ -1077,6 +1077,7 @@ int odr_leeway_capsize(odr_ctx *c, odr_particles *p, double dt, double wind_thre
 }
 
 int odr_i_reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind, bool wind_args_matter) {
+  if (c->red_pinned && c->red_owner == p) return 0;   // installed by the caller (odr_reduce_install): the all-rank values
   if (!p->external && c->red_owner == p && c->red_epoch == p->epoch &&
       (!wind_args_matter || (c->red_wdd == wdd && c->red_rel == relwind)))
     return 0;
@@ -1101,6 +1102,37 @@ int odr_reduce_scalars(odr_ctx *c, odr_particles *p, double wdd, double *out16) 
   out16[R_LONMIN] = -r[R_LONMIN];
   out16[R_LATMIN] = -r[R_LATMIN];
   out16[R_ZMIN] = -r[R_ZMIN];
+  return 0;
+}
+
+// The global reductions of the movers (cdf / wdf extremes, wind speed maximum, Stokes maximum, D.max(), MLD.max():
+// physics_methods.py:741,771-775,799-804, basemodel/__init__.py:1754, oceandrift.py:430) over the elements of THIS
+// particle set, raw: slots 0 and 11 are counts, every other slot is a maximum (minima are stored negated).  A run sharded
+// over several GPUs combines them over the ranks (sum / max) and hands the result back with odr_reduce_install: the
+// movers that follow then see what the reference's single process would have seen, whatever the number of ranks.
+int odr_reduce_local(odr_ctx *c, odr_particles *p, double wdd, int relwind, double *out16) {
+  REQUIRE(out16, "out16 NULL");
+  c->red_pinned = 0;
+  c->red_owner = nullptr;
+  int rc = reduce(c, p, wdd, relwind);
+  if (rc) return rc;
+  double r[R_N];
+  HIPCHK(hipMemcpyAsync(r, c->red, sizeof r, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 16; ++k) out16[k] = k < R_N ? r[k] : 0;
+  return 0;
+}
+int odr_reduce_install(odr_ctx *c, odr_particles *p, const double *in16) {
+  REQUIRE(in16, "in16 NULL");
+  HIPCHK(hipMemcpyAsync(c->red, in16, sizeof(double) * R_N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));   // in16 is pageable
+  c->red_owner = p; c->red_epoch = p->epoch;
+  c->red_pinned = 1;      // until odr_reduce_unpin: the calls in between do not reduce again
+  return 0;
+}
+int odr_reduce_unpin(odr_ctx *c) {
+  c->red_pinned = 0;
+  c->red_owner = nullptr;
   return 0;
 }
 
@@ -1500,6 +1532,7 @@ struct odr_history {
   hipStream_t copy_stream;
   hipEvent_t recorded, flushed;
   double *red;           // 2 doubles
+  long long id_base;     // element ID of trajectory row 0 (odr_history_set_id_base)
 };
 
 static int hist_fill_nan(odr_ctx *c, odr_history *h, hipStream_t st) {
@@ -1531,6 +1564,12 @@ int odr_history_create(odr_ctx *c, int64_t n_trajectories, int32_t n_times, int3
   int rc = hist_fill_nan(c, h, c->stream);
   if (rc) return rc;
   *out = h;
+  return 0;
+}
+
+// the buffer holds the trajectories [id_base, id_base + n_trajectories): the shard of one rank of a sharded run
+int odr_history_set_id_base(odr_ctx *, odr_history *h, int64_t id_base) {
+  h->id_base = id_base;
   return 0;
 }
 
@@ -1580,7 +1619,7 @@ int odr_history_record(odr_ctx *c, odr_particles *p, odr_history *h, int32_t tim
   HIPCHK(hipStreamWaitEvent(c->stream, h->flushed, 0));
   float *slab = h->buf + (size_t)time_index * (size_t)h->ntraj * (size_t)h->stride;
 #define HIST_REC(NQ) hipLaunchKernelGGL(k_hist_record<NQ>, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->n, p->i32[0], p->i32[1], \
-                                        H, slab, h->ntraj, only_deactivated)
+                                        H, slab, h->ntraj, only_deactivated, h->id_base)
   switch (h->stride / 4) {
     case 1: HIST_REC(1); break;
     case 2: HIST_REC(2); break;

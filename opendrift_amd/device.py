@@ -246,8 +246,8 @@ class Context:
         check(self.lib.odr_env_bind(self.h, _vid(variable), len(source_ids), pi,
                                     np.nan if fallback is None else float(fallback)))
 
-    def history(self, n_trajectories, n_times, variables):
-        return History(self, n_trajectories, n_times, variables)
+    def history(self, n_trajectories, n_times, variables, id_base=0):
+        return History(self, n_trajectories, n_times, variables, id_base=id_base)
 
     def particles(self, capacity):
         return Particles(self, capacity)
@@ -533,6 +533,16 @@ class Particles:
                                               int(bool(keep_droplet_diameter)), int(hs_mode), int(tp_mode),
                                               int(bool(temperature_to_kelvin)), mode, pd, pe, pi, step))
 
+    def oil_global_stats(self, allreduce_sum, interfacial_tension, distribution, sea_water_density, hs_mode=1):
+        """Sharded run: np.mean(dV_50) and np.mean(1.5 Hs) over the elements of ALL ranks, installed for the next
+        oil_prepare_mixing (odr_oil_local_sums / odr_oil_set_mixing_stats)."""
+        a, b = C.c_double(), C.c_double()
+        check(self.lib.odr_oil_local_sums(self.ctx.h, self.h, float(interfacial_tension), float(sea_water_density),
+                                          _abi.DROPLETS[distribution], int(hs_mode), C.byref(a), C.byref(b)))
+        g = allreduce_sum([a.value, b.value, float(len(self))])
+        if g[2] > 0:
+            check(self.lib.odr_oil_set_mixing_stats(self.ctx.h, g[1] / g[2], g[0] / g[2]))
+
     def oil_mixing_stats(self):
         a, b = C.c_double(), C.c_double()
         check(self.lib.odr_oil_mixing_stats(self.ctx.h, C.byref(a), C.byref(b)))
@@ -638,6 +648,27 @@ class Particles:
         check(self.lib.odr_sort_particles(self.ctx.h, self.h, int(source_id)))
         self._permuted = True
 
+    def reduce_global(self, combine, wind_drift_depth=0.1, relative_wind=False):
+        """Sharded run: this set's raw reductions -> combine(raw16) over the ranks (counts summed, maxima maximised) ->
+        installed for the movers that follow, until reduce_unpin()."""
+        raw = np.empty(16)
+        check(self.lib.odr_reduce_local(self.ctx.h, self.h, float(wind_drift_depth), int(relative_wind), raw.ctypes.data_as(_dp)))
+        g = np.ascontiguousarray(combine(raw), dtype=np.float64)
+        check(self.lib.odr_reduce_install(self.ctx.h, self.h, g.ctypes.data_as(_dp)))
+        return g
+
+    @staticmethod
+    def reduction_dict(raw):
+        keys = ['n_active', 'lon_min', 'lon_max', 'lat_min', 'lat_max', 'z_min', 'z_max', 'D_max',
+                'stokes_sum_max', 'wind_speed_max', 'wdf_surface_max', 'n_surface', 'hs_max', 'tp_max']
+        d = dict(zip(keys, raw))
+        for k in ('lon_min', 'lat_min', 'z_min'):
+            d[k] = -d[k]
+        return d
+
+    def reduce_unpin(self):
+        check(self.lib.odr_reduce_unpin(self.ctx.h))
+
     def reduce_scalars(self, wind_drift_depth=0.1):
         out = np.empty(16)
         check(self.lib.odr_reduce_scalars(self.ctx.h, self.h, float(wind_drift_depth), out.ctypes.data_as(_dp)))
@@ -652,9 +683,10 @@ class History:
     ('property', slot).  record() scatters the current state at (ID, time index); flush() copies time slots to
     pinned host memory asynchronously; array(var) returns the [trajectory, time] float32 view of the last flush."""
 
-    def __init__(self, ctx, n_trajectories, n_times, variables):
+    def __init__(self, ctx, n_trajectories, n_times, variables, id_base=0):
         self.ctx, self.lib = ctx, ctx.lib
         self.variables = list(variables)
+        self._id_base = int(id_base)
         self.n_trajectories, self.n_times = int(n_trajectories), int(n_times)
         codes = []
         for v in self.variables:
@@ -667,6 +699,8 @@ class History:
         a, pa = _i(codes)
         self.h = C.c_void_p()
         check(self.lib.odr_history_create(ctx.h, self.n_trajectories, self.n_times, len(codes), pa, C.byref(self.h)))
+        if self._id_base:
+            check(self.lib.odr_history_set_id_base(ctx.h, self.h, self._id_base))
 
     def record(self, particles, time_index, only_deactivated=False, position_from_previous=False):
         check(self.lib.odr_history_record(self.ctx.h, particles.h, self.h, int(time_index), int(bool(only_deactivated)),

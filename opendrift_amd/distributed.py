@@ -87,3 +87,39 @@ def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
+
+
+COUNT_SLOTS = (0, 11)      # odr_reduce_local: n_active, n_surface are sums; every other slot is a maximum
+
+
+def combine_reductions(raw16):
+    """The 16 raw reduction slots of every rank -> what one process holding all elements would have computed."""
+    raw = np.asarray(raw16, dtype=np.float64)
+    rank, local_rank, world = env_world()
+    if world == 1:
+        return raw
+    mx = allreduce_scalars(raw, 'max')
+    sm = allreduce_scalars([raw[k] for k in COUNT_SLOTS], 'sum')
+    out = mx.copy()
+    for j, k in enumerate(COUNT_SLOTS):
+        out[k] = sm[j]
+    return out
+
+
+def broadcast_reader_block(block_or_none, variables, src=0):
+    """One reader time level from the rank that runs the host Reader to every rank: the coordinate metadata as a Python
+    object, the arrays as tensors (RCCL broadcast into device memory under nccl).  Returns (meta, {variable: tensor})."""
+    import torch.distributed as dist
+    rank, local_rank, world = env_world()
+    meta = [None]
+    arrays = None
+    if rank == src:
+        b = block_or_none
+        meta = [{k: (np.asarray(b[k]) if k in ('x', 'y', 'z') and b.get(k) is not None else b.get(k))
+                 for k in ('x', 'y', 'z', 'time', 's_level_variables') if k in b}]
+        arrays = {v: np.ascontiguousarray(np.ma.filled(b[v], np.nan) if isinstance(b[v], np.ma.MaskedArray) else b[v],
+                                          dtype=np.float32) for v in variables}
+    if world > 1:
+        dist.broadcast_object_list(meta, src=src)
+    tens = broadcast_block(arrays, src=src)
+    return meta[0], tens

@@ -45,6 +45,19 @@ class OpenDriftSimulation(Configurable):
         if loglevel is not None:
             logger.setLevel(loglevel)
         self.mode = 'Config'
+        # one process per GPU (torchrun: RANK / LOCAL_RANK / WORLD_SIZE): every rank runs the same script, seeds the same
+        # schedule (same np.random seed) and owns a contiguous range of element IDs; rank 0's readers are the ones that
+        # read, their blocks are broadcast; the global reductions of the movers are combined over the ranks
+        from . import distributed as D
+        self._rank, local_rank, self._world = D.env_world()
+        if self._world > 1:
+            D.init()
+            if device == 0:
+                import torch
+                device = local_rank % max(1, torch.cuda.device_count())
+            if rng != 'device':
+                raise ValueError("a sharded run (WORLD_SIZE > 1) needs rng='device': np.random draws are sized by the "
+                                 "elements of one process")
         self._ctx, self._device, self._seed = None, device, seed or 0   # the device context is created on first use
         self.rng = rng                       # 'device' (Philox by ID) | 'numpy' (np.random in reference call order)
         if seed is not None:
@@ -62,6 +75,7 @@ class OpenDriftSimulation(Configurable):
         self.steps_calculation = 0
         self.time = self.start_time = self.time_step = None
         self.newly_seeded = 0
+        self._newly_any, self._g_active = False, 0
         self.sort_every = 16
         self._add_config({
             'general:use_auto_landmask': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_ADVANCED,
@@ -363,7 +377,7 @@ class OpenDriftSimulation(Configurable):
 
     def report_missing_variables(self):   # :2501-2515 on Environment.get_environment's `missing` (environment.py:903-908)
         names = self._can_be_missing(self._sampled)
-        if names and self.num_elements_active() > 0:
+        if names and (self._world > 1 or self.num_elements_active() > 0):   # sharded: same calls on every rank
             self.P.deactivate_missing(names, self._status_code('missing_data'))
 
     def deactivate_outside(self):   # :2354-2382, validity domain of :2169-2179
@@ -391,16 +405,45 @@ class OpenDriftSimulation(Configurable):
             self._pending_status.append(reason)
         return code
 
+    # ---- sharded run: what the control flow and the status categories depend on is combined over the ranks, so that
+    # every rank takes the same branches, makes the same collectives and numbers the deactivation reasons alike
+    def _global_counts(self):
+        """(active, scheduled) over all ranks; also whether ANY rank released elements in this step (the reference's
+        `newly_seeded_IDs is not None`, which arms the 'seeded_on_land' check) -- one all-reduce."""
+        na, ns = self.num_elements_active(), self.num_elements_scheduled()
+        self._newly_any = self.newly_seeded > 0
+        self._g_active = na
+        if self._world == 1:
+            return na, ns
+        from . import distributed as D
+        g = D.allreduce_scalars([na, ns, self.newly_seeded], 'sum')
+        self._newly_any = g[2] > 0
+        self._g_active = int(g[0])
+        return int(g[0]), int(g[1])
+
+    def _global_scan(self, kept, flags):
+        if self._world == 1:
+            return kept, flags
+        from . import distributed as D
+        bits = [float(flags >> k & 1) for k in range(8)]
+        g = D.allreduce_scalars(bits, 'max')
+        return kept, sum(1 << k for k in range(8) if g[k] > 0)
+
+    def _combine(self):
+        """combine(raw16) for Particles.reduce_global: identity in a one-process run"""
+        from . import distributed as D
+        return D.combine_reductions
+
     def _resolve_status(self, flags=None):
         """Register the pending reasons that occurred (in the order of the calls that could assign them) and renumber
         their elements.  `flags`: the provisional status numbers present (Particles.scan_status); without it one scan is
         made -- one host read however many reasons are pending, none when nothing is pending."""
         pending, self._pending_status = self._pending_status, []
         pending = [r for r in pending if r not in self.status_categories]
-        if not pending:
+        if not pending and (self._world == 1 or flags is not None):
             return
         if flags is None:
-            flags = self.P.scan_status()[1] if len(self.P) else 0
+            flags = self._global_scan(0, self.P.scan_status()[1] if len(self.P) else 0)[1]
         for reason in pending:
             code = self._PROVISIONAL[reason]
             if flags >> (code - 100) & 1:
@@ -409,7 +452,8 @@ class OpenDriftSimulation(Configurable):
 
     def interact_with_coastline(self, final=False):   # :670-746
         action = self.get_config('general:coastline_action')
-        if action == 'none' or 'land_binary_mask' not in self._sampled or self.num_elements_active() == 0:
+        if action == 'none' or 'land_binary_mask' not in self._sampled or \
+                (self._world == 1 and self.num_elements_active() == 0):
             return
         if final:
             self.P.env_sample(['land_binary_mask'], _epoch(self.time))
@@ -421,16 +465,17 @@ class OpenDriftSimulation(Configurable):
             self.P.coastline_crossing(action, precision, self._landmask_sid,
                                       stranded_code=self._status_code('stranded') if action == 'stranding' else 1,
                                       seeded_on_land_code=self._status_code('seeded_on_land')
-                                      if action == 'previous' and self.newly_seeded else 0)
+                                      if action == 'previous' and self._newly_any else 0)
             return
         if action == 'stranding':
             self.P.coastline('stranding', stranded_code=self._status_code('stranded'))
         else:
             self.P.coastline('previous', seeded_on_land_code=self._status_code('seeded_on_land')
-                             if self.newly_seeded else 0)
+                             if self._newly_any else 0)
 
     def interact_with_seafloor(self):   # :748-783, 'lift_to_seafloor'
-        if 'sea_floor_depth_below_sea_level' not in self.priority_list or self.num_elements_active() == 0:
+        if 'sea_floor_depth_below_sea_level' not in self.priority_list or \
+                (self._world == 1 and self.num_elements_active() == 0):
             return
         action = self.get_config('general:seafloor_action', 'lift_to_seafloor')
         if action == 'lift_to_seafloor' or action == 'previous':
@@ -454,7 +499,8 @@ class OpenDriftSimulation(Configurable):
         self.P.update_positions(x_vel, y_vel, self.time_step.total_seconds())
 
     def horizontal_diffusion(self):   # :1746-1772
-        if 'horizontal_diffusivity' not in self.required_variables or self.num_elements_active() == 0:
+        if 'horizontal_diffusivity' not in self.required_variables or \
+                (self._g_active if self._world > 1 else self.num_elements_active()) == 0:
             return
         dt = self.time_step.total_seconds()
         if self.rng == 'numpy':
@@ -463,7 +509,7 @@ class OpenDriftSimulation(Configurable):
             n = self.num_elements_active()
             self.P.hdiffusion(dt, normals=(np.random.normal(scale=1, size=n), np.random.normal(scale=1, size=n)))
         else:
-            self.P.hdiffusion(dt, step=self.steps_calculation)
+            self._with_global_reduction(lambda: self.P.hdiffusion(dt, step=self.steps_calculation))
 
     def get_environment(self):
         """Environment.get_environment for all required variables (:2238-2246) + uncertainty (:869-891)."""
@@ -519,7 +565,30 @@ class OpenDriftSimulation(Configurable):
                 self.P.set_advect_noise(std, ustd, step=self.steps_calculation)
         self.P.advect(scheme, _epoch(self.time), self.time_step.total_seconds(), factor)
 
+    def _reduce_scalars(self, wdd=0.1):
+        """The movers' global scalars on the host; sharded run: over the elements of all ranks, and installed on the
+        device for the mover that follows (release with P.reduce_unpin())."""
+        if self._world == 1:
+            return self.P.reduce_scalars(wdd)
+        return self.P.reduction_dict(self.P.reduce_global(self._combine(), wdd, False))
+
+    def _with_global_reduction(self, call, wdd=0.1, relwind=False):
+        """Sharded run: the movers' global early-outs and maxima over the elements of ALL ranks (odr_reduce_local /
+        _install); one process: the device reduces on its own."""
+        if self._world == 1:
+            return call()
+        self.P.reduce_global(self._combine(), wdd, relwind)
+        try:
+            return call()
+        finally:
+            self.P.reduce_unpin()
+
     def advect_wind(self, factor=1):
+        if self._world > 1:
+            return self._with_global_reduction(lambda: self.P.advect_wind(
+                self.time_step.total_seconds(), self.get_config('drift:wind_drift_depth', 0.1),
+                self.get_config('drift:relative_wind'), factor), self.get_config('drift:wind_drift_depth', 0.1),
+                self.get_config('drift:relative_wind'))
         self.P.advect_wind(self.time_step.total_seconds(), self.get_config('drift:wind_drift_depth', 0.1),
                            self.get_config('drift:relative_wind'), factor)
 
@@ -537,13 +606,17 @@ class OpenDriftSimulation(Configurable):
         if self._identically_zero('sea_surface_wave_stokes_drift_x_velocity') and \
                 self._identically_zero('sea_surface_wave_stokes_drift_y_velocity'):
             return      # "No Stokes drift velocity available" (physics_methods.py:799-804) without a device round trip
-        r = self.P.reduce_scalars(self.get_config('drift:wind_drift_depth', 0.1))
-        if r['stokes_sum_max'] == 0:
-            return
-        # provenance of Hs / Tp (physics_methods.py:893-943, :809-814)
-        hs_mode = 0 if r['hs_max'] > 0 else (1 if r['wind_speed_max'] > 0 else 2)
-        tp_mode = 1 if r['wind_speed_max'] >= 0 else 2   # Tp is not an OceanDrift variable: from wind (omega=5 when calm)
-        self.P.stokes_drift(self.time_step.total_seconds(), profile, hs_mode, tp_mode, factor)
+        r = self._reduce_scalars(self.get_config('drift:wind_drift_depth', 0.1))
+        try:
+            if r['stokes_sum_max'] == 0:
+                return
+            # provenance of Hs / Tp (physics_methods.py:893-943, :809-814)
+            hs_mode = 0 if r['hs_max'] > 0 else (1 if r['wind_speed_max'] > 0 else 2)
+            tp_mode = 1 if r['wind_speed_max'] >= 0 else 2   # Tp is not an OceanDrift variable: from wind (omega=5 when calm)
+            self.P.stokes_drift(self.time_step.total_seconds(), profile, hs_mode, tp_mode, factor)
+        finally:
+            if self._world > 1:
+                self.P.reduce_unpin()
 
     def prepare_run(self):
         pass
@@ -613,14 +686,24 @@ class OpenDriftSimulation(Configurable):
         self._all_at_start = bool((self._sched['t_epoch'] == _epoch(self.start_time)).all())
         self._finalize_environment(self.start_time, self.start_time + time_step)
         n_total = self.num_elements_total()
-        self.P = self.ctx.particles(n_total)
+        lo_id, hi_id = 0, n_total
+        if self._world > 1:     # this rank's contiguous range of element IDs; the others are never released here
+            from . import distributed as D
+            lo_id, hi_id = D.shard_range(n_total, self._rank, self._world)
+            rel = self._released_mask()
+            rel[:lo_id] = True
+            rel[hi_id:] = True
+            self._all_at_start = False if n_total == 0 else self._all_at_start
+        self._shard = (lo_id, hi_id)
+        self.P = self.ctx.particles(max(1, hi_id - lo_id))
         self.mode = 'Run'
         self.prepare_run()
         nout = steps // out_every + 1
         # float32 result buffer on the device (basemodel/__init__.py:2084-2105): element properties and
         # environment variables, [trajectory, time], NaN where an element does not exist
         hvars = self._history_variables(export_variables)
-        self._hist = _ResultBuffer(self.ctx, n_total, nout, min(nout, max(1, int(export_buffer_length))), hvars)
+        self._hist = _ResultBuffer(self.ctx, max(1, hi_id - lo_id), nout, min(nout, max(1, int(export_buffer_length))), hvars,
+                                   id_base=lo_id)
         times = []
         grid_sid = next((b.sid for b in self.readers.values() if b.is_grid() and b.sid is not None), None)
         # fused lane: the stock loop body and the stock OceanDrift.update order (current advection first), no
@@ -648,7 +731,8 @@ class OpenDriftSimulation(Configurable):
                     self.ctx.sync()
                     t_loop[1] = time.perf_counter()   # after the first step: seeding, first uploads and sort are behind
                 self.release_elements()
-                if self.num_elements_active() == 0 and self.num_elements_scheduled() > 0:
+                g_active, g_sched = self._global_counts()
+                if g_active == 0 and g_sched > 0:
                     self._state_to_buffer(i, out_every, times)   # (:2208)
                     self.steps_calculation += 1
                     self.time = self.time + self.time_step
@@ -677,7 +761,7 @@ class OpenDriftSimulation(Configurable):
                         names, _epoch(self.time), self.get_config('drift:advection_scheme'), self.time_step.total_seconds(),
                         coastline=action if 'land_binary_mask' in names else 'none',
                         stranded_code=self._status_code('stranded') if action == 'stranding' else 1,
-                        seeded_on_land_code=(self._status_code('seeded_on_land') if action == 'previous' and self.newly_seeded
+                        seeded_on_land_code=(self._status_code('seeded_on_land') if action == 'previous' and self._newly_any
                                              else 0),
                         store_previous=True, count=False, seafloor=floor,
                         missing_code=self._status_code('missing_data') if self._can_be_missing(names) else 0,
@@ -686,6 +770,7 @@ class OpenDriftSimulation(Configurable):
                     self._add_uncertainty(names, current=False)     # the wind's share
                     # ONE host read per step: how many elements stay + which new deactivation reasons occurred
                     kept, flags = self.P.scan_status()
+                    kept, flags = self._global_scan(kept, flags)
                     self._resolve_status(flags)
                     self._state_to_buffer(i, out_every, times, from_previous=True)
                     if not age_in_launch:
@@ -706,9 +791,15 @@ class OpenDriftSimulation(Configurable):
                     self._resolve_status()
                     self.P.compact()
                     self.P.store_previous()
-                if self.num_elements_active() > 0:
+                if self._world > 1:
+                    newly = self._newly_any
+                    g_active = self._global_counts()[0]
+                    self._newly_any = newly
+                else:
+                    g_active = self._g_active = self.num_elements_active()
+                if g_active > 0:
                     self.update()
-                elif self.num_elements_scheduled() == 0:
+                elif g_sched == 0:
                     raise ValueError('No more active or scheduled elements, quitting.')
                 self._advected = False
                 self.horizontal_diffusion()
@@ -760,13 +851,14 @@ class _ResultBuffer:
     """export_buffer_length output times on the device (device.History); when full it is flushed to host
     chunks asynchronously and reset (:2489-2499)."""
 
-    def __init__(self, ctx, ntraj, ntimes, nbuf, variables):
+    def __init__(self, ctx, ntraj, ntimes, nbuf, variables, id_base=0):
         self.ctx, self.ntraj, self.ntimes, self.nbuf, self.variables = ctx, ntraj, ntimes, nbuf, list(variables)
+        self.id_base = id_base
         self.base, self.used, self.chunks, self.H, self.minmax = 0, 0, [], None, {}
 
     def _open(self, aux):
         if self.H is None:
-            self.H = self.ctx.history(self.ntraj, self.nbuf, [aux.get(v, v) for v in self.variables])
+            self.H = self.ctx.history(self.ntraj, self.nbuf, [aux.get(v, v) for v in self.variables], id_base=self.id_base)
 
     def record(self, P, k, only_deactivated, aux, from_previous=False):
         self._open(aux)
@@ -878,8 +970,8 @@ class OceanDrift(OpenDriftSimulation):
         elif model == 'environment':
             self._with_seafloor_action(lambda: self.P.vmix(_epoch(self.time), dt, dt_mix, **kw))
         else:   # get_diffusivity_profile (:385-395): raises ValueError('Unknown diffusivity model') like the reference
-            bg = self.get_config('vertical_mixing:background_diffusivity')
-            self._with_seafloor_action(lambda: self.P.vmix_analytic(model, bg, dt, dt_mix, **kw))
+            bg = self.get_config('vertical_mixing:background_diffusivity')   # MLD.max() over all elements (oceandrift.py:430)
+            self._with_global_reduction(lambda: self._with_seafloor_action(lambda: self.P.vmix_analytic(model, bg, dt, dt_mix, **kw)))
 
     def vertical_buoyancy(self):   # :352-368
         self._with_seafloor_action(lambda: self.P.vertical_buoyancy(self.time_step.total_seconds()))

@@ -159,7 +159,9 @@ class OpenOil(OceanDrift):
         """Provenance of wave height and period (physics_methods.py:893-943): from readers when any value is > 0,
         else from the wind; the wind-derived period has passed through the float32 environment
         (calculate_missing_environment_variables, :876-883) because OpenOil requires the variable."""
-        r = self.P.reduce_scalars(self.get_config('drift:wind_drift_depth', 0.1))
+        r = self._reduce_scalars(self.get_config('drift:wind_drift_depth', 0.1))
+        if self._world > 1:
+            self.P.reduce_unpin()
         return r, (0 if r['hs_max'] > 0 else 1), (0 if r['tp_max'] > 0 else 3)
 
     def stokes_drift(self, factor=1):
@@ -171,7 +173,7 @@ class OpenOil(OceanDrift):
         r, hs_mode, tp_mode = self._wave_modes()
         if r['stokes_sum_max'] == 0:
             return
-        self.P.stokes_drift(self.time_step.total_seconds(), profile, hs_mode, tp_mode, factor)
+        self._with_global_reduction(lambda: self.P.stokes_drift(self.time_step.total_seconds(), profile, hs_mode, tp_mode, factor))
 
     def oil_weathering(self):   # :673-680, :717-724 with every process off
         self._temperature_in_kelvin = self.time_step.days >= 0
@@ -203,11 +205,18 @@ class OpenOil(OceanDrift):
             kw['uniforms'] = uni
         else:
             kw['step'] = self.steps_calculation
-        self._with_seafloor_action(lambda: self.P.vmix_oil(
+        if self._world > 1:   # OpenOil's means over ALL elements: np.mean(dV_50), np.mean(1.5 Hs) (openoil.py:1099-1101,1047)
+            from . import distributed as D
+            self.P.oil_global_stats(lambda v: D.allreduce_scalars(v, 'sum'), self.oil_water_interfacial_tension,
+                                    self.get_config('wave_entrainment:droplet_size_distribution'),
+                                    sea_water_density_default(), hs_mode=hs_mode)
+        mix = lambda: self._with_seafloor_action(lambda: self.P.vmix_oil(
             model, self.get_config('vertical_mixing:background_diffusivity'), dt, dt_mix,
             self.oil_water_interfacial_tension, self.get_config('wave_entrainment:droplet_size_distribution'),
             sea_water_density=sea_water_density_default(), t_epoch=_epoch(self.time),
             mix_at_surface=self.get_config('drift:vertical_mixing_at_surface'), **kw))
+        # a wind-parameterised diffusivity needs MLD.max() over all elements (oceandrift.py:430)
+        self._with_global_reduction(mix)
 
     def advect_oil(self):   # openoil.py:1179-1216, no sea ice: k_ice = 0, factor_stokes = 1
         self.advect_ocean_current(factor=1)

@@ -331,6 +331,11 @@ class SigmaGridReader(StructuredReader):
         return out
 
 
+def _dev(a):
+    """a block array as Context.upload_block_device wants it: the device pointer of a CUDA tensor, else the host array"""
+    return int(a.data_ptr()) if hasattr(a, 'is_cuda') and a.is_cuda else a
+
+
 class DeviceReaderBinding:
     """Device image of one reader: constant/analytic source, or a grid source whose time levels
     (ReaderBlocks) are uploaded on demand.  Stands where StructuredReader keeps
@@ -345,6 +350,10 @@ class DeviceReaderBinding:
         self.staged = {}     # time index -> slot uploaded asynchronously, not yet committed
         self.prefetch = self.PREFETCH
         self._pinned = False
+        from .distributed import env_world
+        self.rank, _, self.world = env_world()
+        if self.world > 1:
+            self.prefetch = False      # the broadcast of a level is a collective: made when the level is due
         kind = getattr(reader, 'device_kind', None)
         if kind == 'constant':
             self.sid = ctx.add_constant({v: reader._parameter_value_map[v] for v in self.variables})
@@ -419,7 +428,19 @@ class DeviceReaderBinding:
         x = y = None
         if extent is not None:
             x, y = np.array(extent[0]), np.array(extent[1])
-        block = r.get_variables(self.variables, time, x, y, np.array([0.0]))
+        if self.world > 1:
+            # sharded run (one process per GPU): the rank that owns the host Reader reads the level, every rank receives
+            # it -- over RCCL / xGMI straight into device memory (opendrift_amd/distributed.py)
+            from . import distributed as D
+            block = r.get_variables(self.variables, time, x, y, np.array([0.0])) if self.rank == 0 else None
+            meta, tens = D.broadcast_reader_block(block, self.variables, src=0)
+            block = dict(meta)
+            for v, t in tens.items():
+                block[v] = t if t.is_cuda else t.numpy()
+            self._tensors = tens      # keep the device tensors alive until the block is built
+            asynchronous = False
+        else:
+            block = r.get_variables(self.variables, time, x, y, np.array([0.0]))
         if broadcast is not None:
             block = broadcast(block)
         bx, by = np.asarray(block['x']), np.asarray(block['y'])
@@ -473,12 +494,18 @@ class DeviceReaderBinding:
                 self.sgrid = SigmaGrid(self.ctx, r.h, r.hc, r.Cs_r, Vtransform=r.Vtransform)
             arrays, nzv = {}, {}
             for i, v in enumerate([v for v in self.variables if v in block['s_level_variables']]):
-                arrays[v] = self.sgrid.zslice(block[v], bz, slot=i)
+                arrays[v] = self.sgrid.zslice(_dev(block[v]), bz, slot=i)
                 nzv[v] = len(bz)
             for v in self.variables:
                 if v not in arrays:
-                    arrays[v] = block[v]
+                    arrays[v] = _dev(block[v])
+                    nzv.setdefault(v, block[v].shape[0] if len(block[v].shape) == 3 else 1)
             self.ctx.upload_block_device(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays, nzv)
+        elif self.world > 1:
+            arrays = {v: _dev(block[v]) for v in self.variables}
+            nzv = {v: (block[v].shape[0] if len(block[v].shape) == 3 else 1) for v in self.variables}
+            self.ctx.upload_block_device(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays, nzv)
+            self._tensors = None
         else:
             arrays = {v: block[v] for v in self.variables}
             self.ctx.upload_block(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays)

@@ -1,0 +1,80 @@
+"""Worker of tests/test_gpu_distributed.py: one rank of a (possibly) sharded model run.  Every rank runs this same script
+-- as a user script would under torchrun -- and writes the final state of ITS elements to <out>.rank<r>.npz.
+
+    RANK=r LOCAL_RANK=r WORLD_SIZE=w MASTER_ADDR=127.0.0.1 MASTER_PORT=p ODR_DIST_BACKEND=gloo python tests/dist_worker.py <scenario> <out>
+"""
+import os
+import sys
+from datetime import datetime, timedelta
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from opendrift_amd import readers  # noqa: E402
+from opendrift_amd.oceandrift import OceanDrift  # noqa: E402
+from opendrift_amd.openoil import OpenOil  # noqa: E402
+
+T0 = datetime(2020, 1, 1)
+
+
+def grid_reader(g, names):
+    times = [T0 + timedelta(seconds=float(t)) for t in g['g_t']]
+    return readers.GridReader(g['g_x'], g['g_y'], times, {k: g['g_' + k] for k in names})
+
+
+def main():
+    scenario, out = sys.argv[1], sys.argv[2]
+    gold = os.path.join(ROOT, 'tests', 'golden')
+    if scenario == 'oceandrift':
+        # wind-parameterised mixing (MLD.max() over all elements), windage (wind speed / wdf maxima), uncertainty,
+        # stranding and a validity domain (status categories in order of first occurrence)
+        g = np.load(os.path.join(gold, 'c7_wind_diffusivity.npz'))
+        names = ['x_wind', 'y_wind', 'ocean_mixed_layer_thickness', 'sea_floor_depth_below_sea_level',
+                 'x_sea_water_velocity', 'y_sea_water_velocity']
+        o = OceanDrift(loglevel=50, seed=0)
+        o.add_reader(grid_reader(g, names))
+        o.set_config('environment:fallback:land_binary_mask', 0)
+        o.set_config('drift:advection_scheme', 'runge-kutta4')
+        o.set_config('drift:vertical_mixing', True)
+        o.set_config('vertical_mixing:timestep', 60)
+        o.set_config('drift:current_uncertainty', 0.05)
+        o.set_config('drift:wind_uncertainty', 1.0)
+        o.set_config('drift:deactivate_east_of', 6.6)
+        o.set_config('environment:fallback:horizontal_diffusivity', 5.0)
+        n = 4000
+        rng = np.random.default_rng(3)
+        lon = rng.uniform(g['g_x'][3], g['g_x'][-4], n)
+        lat = rng.uniform(g['g_y'][3], g['g_y'][-4], n)
+        z = -rng.uniform(0, 40, n)
+        z[: n // 4] = 0.0
+        o.seed_elements(lon=lon, lat=lat, z=z, time=[T0, T0 + timedelta(seconds=1800)], wind_drift_factor=0.03)
+        o.run(time_step=600, steps=9)
+    else:
+        # OpenOil: np.mean(dV_50) and np.mean(1.5 Hs) over all elements, wave entrainment, default uncertainties
+        g = np.load(os.path.join(gold, 'c9_openoil_mixing.npz'))
+        names = ['x_wind', 'y_wind', 'ocean_mixed_layer_thickness', 'sea_floor_depth_below_sea_level',
+                 'x_sea_water_velocity', 'y_sea_water_velocity', 'sea_water_temperature', 'sea_water_salinity']
+        o = OpenOil(loglevel=50, seed=0)
+        o.add_reader(grid_reader(g, names))
+        o.set_config('environment:fallback:land_binary_mask', 0)
+        o.set_config('drift:advection_scheme', 'runge-kutta4')
+        o.set_config('vertical_mixing:timestep', 60)
+        n = 4000
+        rng = np.random.default_rng(4)
+        lon = rng.uniform(g['g_x'][3], g['g_x'][-4], n)
+        lat = rng.uniform(g['g_y'][3], g['g_y'][-4], n)
+        o.seed_elements(lon=lon, lat=lat, z=0.0, time=T0, oil_type={'density': 900.0, 'viscosity': 0.005})
+        o.run(time_step=600, steps=6)
+    a, d = o.elements, o.elements_deactivated
+    np.savez(out + '.rank%d.npz' % o._rank, ID=np.concatenate([a.ID, d.ID]), lon=np.concatenate([a.lon, d.lon]),
+             lat=np.concatenate([a.lat, d.lat]), z=np.concatenate([a.z, d.z]), status=np.concatenate([a.status, d.status]),
+             categories=np.array(o.status_categories), shard=np.array(o._shard))
+    if o._world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -65,3 +65,45 @@ def test_shard_range_properties():
             assert all(edges[k][1] == edges[k + 1][0] for k in range(w - 1))
             sizes = [b - a for a, b in edges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _combine_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from opendrift_amd import distributed as D
+    D.init(backend='gloo')
+    # raw reduction slots of one rank (odr_reduce_local): counts in slots 0 and 11, maxima elsewhere (minima negated)
+    raw = np.full(16, -np.inf)
+    raw[0], raw[11] = 100.0 + rank, 7.0 * (rank + 1)
+    raw[1], raw[2] = -(4.0 + rank), 9.0 - rank           # lon_min (negated), lon_max
+    raw[7] = 0.0 if rank == 0 else 12.5                  # D.max(): only the other rank has diffusivity
+    got = D.combine_reductions(raw)
+    # a reader block read by rank 0 only
+    blk = dict(x=np.arange(5, dtype=np.float32), y=np.arange(4, dtype=np.float32), z=None, time=None,
+               u=np.arange(20, dtype=np.float32).reshape(4, 5)) if rank == 0 else None
+    meta, tens = D.broadcast_reader_block(blk, ['u'])
+    q.put((rank, got.tolist(), meta['x'].tolist(), tens['u'].numpy().tolist()))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_reduction_combine_and_reader_block_broadcast_gloo_world2():
+    """What makes a sharded run independent of the number of ranks: counts summed, maxima maximised (the early-outs of
+    advect_wind / stokes_drift / horizontal_diffusion and MLD.max() see all elements); the reader block of the rank
+    that reads arrives on every rank with its coordinate metadata."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_combine_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, got, x, u in res:
+        assert got[0] == 201.0 and got[11] == 21.0 and got[1] == -4.0 and got[2] == 9.0 and got[7] == 12.5
+        assert got[3] == -np.inf
+        assert x == [0, 1, 2, 3, 4] and u[3][4] == 19.0
