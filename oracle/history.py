@@ -9,8 +9,10 @@ Follows opendrift/models/basemodel/__init__.py:
     time (`method='backfill'`); the assignment casts float64 / int32 properties to float32;
   * min / max        :2409-2414 -- var.min(skipna=True), var.max(skipna=True);
   * new buffer       :2493-2499 -- all variables reset to NaN.
-Parity note: the reference's own state_to_buffer needs xarray (not installed here), so this
-restatement is NOT pinned by running the reference: "parity unpinned" for this row.
+Pinned by reference execution: oracle/gen_golden_history.py runs the reference's OWN state_to_buffer on a functional
+stand-in for the xarray calls it makes (oracle/xarray_standin.py) and stores every full buffer
+(tests/golden/c15_state_to_buffer.npz); tests/test_history_oracle.py replays the recorded states through this
+restatement and obtains the same float32 arrays, NaN pattern included.
 """
 import numpy as np
 

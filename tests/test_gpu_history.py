@@ -88,3 +88,62 @@ def test_history_errors(ctx):
     with pytest.raises(ValueError):
         ctx.history(8, 2, ['lon'] * 41)      # more than the 40 variables of a record
     H.close()
+
+
+def test_c15_device_buffer_equals_the_references_own_state_to_buffer(ctx):
+    """Golden c15: the reference's OWN state_to_buffer, executed (oracle/gen_golden_history.py).  The recorded element
+    states are put on the device call by call -- releases appended, the deactivated elements of the previous call removed
+    by the in-place compaction (which permutes the survivors) -- and odr_history_record / flush / minmax / reset must
+    deliver the reference's float32 [trajectory, time] buffers bit for bit, and its minval / maxval attributes."""
+    from conftest import golden
+    from test_history_oracle import _replay_slots
+    g = golden('c15_state_to_buffer.npz')
+    variables = [str(v) for v in g['variables']]
+    n, nbuf, dt = int(g['n']), int(g['export_buffer_length']), float(g['dt'])
+    P = ctx.particles(n)
+    H = ctx.history(n, nbuf, variables)
+    bufs, mm = [], {}
+
+    def put_state(i):
+        ID = g['call%d_ID' % i]
+        have = P.ids() if len(P) else np.zeros(0, np.int32)
+        new = ~np.isin(ID, have)
+        if new.any():
+            P.append(g['call%d_lon' % i][new], g['call%d_lat' % i][new], z=g['call%d_z' % i][new], id=ID[new].astype(np.int32))
+        dev = P.ids()
+        assert sorted(dev.tolist()) == sorted(ID.tolist())          # compaction removed exactly what the reference removed
+        pos = {int(k): j for j, k in enumerate(ID)}
+        o = np.array([pos[int(k)] for k in dev])                    # reference order -> device order
+        P.upload(lon=g['call%d_lon' % i][o], lat=g['call%d_lat' % i][o], z=g['call%d_z' % i][o])
+        for v in variables:
+            if v not in ('lon', 'lat', 'z', 'status', 'age_seconds'):
+                P.env_upload(v, g['call%d_%s' % (i, v)][o].astype(np.float32))
+        st = g['call%d_status' % i][o]
+        assert np.allclose(P.download_f32('age_seconds'), g['call%d_age_seconds' % i][o])
+        for code in np.unique(st[st != 0]):
+            P.deactivate(st == code, int(code))
+
+    def record(i, slot, only_deactivated):
+        put_state(i)
+        H.record(P, slot, only_deactivated)
+        P.increase_age(dt)
+        P.compact()
+
+    def flush():
+        for v in variables:
+            lo, hi = H.minmax(v)
+            old = mm.get(v)
+            mm[v] = (lo, hi) if old is None else (np.fmin(old[0], lo), np.fmax(old[1], hi))
+        H.flush()
+        H.wait()
+        bufs.append({v: H.array(v).copy() for v in variables})
+        H.reset()
+    _replay_slots(g, record, flush)
+    assert len(bufs) == int(g['n_buffers'])
+    for j, b in enumerate(bufs):
+        for v in variables:
+            assert _same(b[v], g['buf%d_%s' % (j, v)]), (j, v)
+    for v in variables:
+        if v != 'status':
+            assert np.float32(mm[v][0]) == g['minval_' + v] and np.float32(mm[v][1]) == g['maxval_' + v], v
+    H.close()
