@@ -677,6 +677,28 @@ class Particles:
         return dict(zip(keys, out))
 
 
+def _touching(fn):
+    """A call that changes the device state: what a model wrote into its `o.elements` view goes to the device first
+    (oceandrift.ElementsView.flush), and views taken before the call become stale."""
+    def wrapper(self, *a, **kw):
+        v = self.__dict__.get('_view')
+        if v is not None:
+            self._view = None
+            v.flush()
+        self._touch = self.__dict__.get('_touch', 0) + 1
+        return fn(self, *a, **kw)
+    wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
+    return wrapper
+
+
+for _name in ('append', 'upload', 'env_sample', 'env_upload', 'env_add_noise', 'advect', 'env_coast_advect',
+              'update_positions', 'advect_wind', 'stokes_drift', 'set_property', 'leeway_capsize', 'leeway', 'hdiffusion',
+              'vmix', 'vmix_analytic', 'vmix_oil', 'vertical_advection', 'vertical_buoyancy', 'coastline', 'coastline_crossing',
+              'increase_age', 'deactivate_missing', 'remap_status', 'seafloor', 'deactivate', 'deactivate_outside', 'compact',
+              'compact_apply', 'sort_by_cell'):
+    setattr(Particles, _name, _touching(getattr(Particles, _name)))
+
+
 class History:
     """Device-resident float32 result buffer (state_to_buffer, basemodel/__init__.py:2084-2105,2384-2499):
     `variables` = element property names ('lon', 'lat', 'z', 'status', ...), environment variable names, or

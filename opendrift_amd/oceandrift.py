@@ -174,6 +174,7 @@ class OpenDriftSimulation(Configurable):
                 self.priority_list.setdefault(v, []).insert(0, 'constant_reader_config')
         for name, (r, vs) in self._readers_host.items():
             self.readers[name] = DeviceReaderBinding(self.ctx, r, variables=vs)
+            self.readers[name].set_extent(getattr(self, 'simulation_extent', None))
         landmasks = [n for n, (r, _) in self._readers_host.items() if getattr(r, 'device_kind', None) == 'landmask']
         self._landmask_sid = self.readers[landmasks[0]].sid if landmasks else None
         if self.get_config('general:use_auto_landmask'):
@@ -192,7 +193,7 @@ class OpenDriftSimulation(Configurable):
     def _bind_variables(self):
         for v in self.required_variables:
             ids = [self.readers[n].sid for n in self.priority_list.get(v, [])
-                   if n in self.readers and self.readers[n].sid is not None]
+                   if n in self.readers and self.readers[n].sid is not None and not getattr(self.readers[n], 'host_eval', False)]
             self.ctx.bind(v, ids[:4], self.get_config('environment:fallback:%s' % v))
 
     def _ensure_reader_levels(self, t0, t1):
@@ -210,20 +211,25 @@ class OpenDriftSimulation(Configurable):
                 # that covers the current time, environment.py:597-668)
                 rebind |= sid_before is None and b.sid is not None
             except Exception as e:   # the reference catches every exception of a reader call
-                r = b.reader
-                r.number_of_fails = getattr(r, 'number_of_fails', 0) + 1
-                max_fails = self.get_config('readers:max_number_of_fails')
-                logger.warning('Reader %s failed (%s), number of fails: %d', name, e, r.number_of_fails)
-                if r.number_of_fails > max_fails:
-                    self.discarded_readers[name] = 'failed more than allowed number of times (%d)' % max_fails
-                    del self.readers[name]
-                    for v, lst in self.priority_list.items():
-                        if name in lst:
-                            lst.remove(name)
-                    if b.sid is not None:      # it had delivered blocks before: take it out of the device lists
-                        rebind = True
+                rebind |= self._reader_failed(name, b, e)
         if rebind:
             self._bind_variables()
+
+    def _reader_failed(self, name, b, e):
+        """Count the failure; after more than readers:max_number_of_fails the reader is discarded (discard_reader,
+        environment.py:376-389).  Returns True when device priority lists must be rebuilt."""
+        r = b.reader
+        r.number_of_fails = getattr(r, 'number_of_fails', 0) + 1
+        max_fails = self.get_config('readers:max_number_of_fails')
+        logger.warning('Reader %s failed (%s), number of fails: %d', name, e, r.number_of_fails)
+        if r.number_of_fails > max_fails:
+            self.discarded_readers[name] = 'failed more than allowed number of times (%d)' % max_fails
+            del self.readers[name]
+            for v, lst in self.priority_list.items():
+                if name in lst:
+                    lst.remove(name)
+            return b.sid is not None      # it had delivered blocks before: take it out of the device lists
+        return False
 
     # ------------------------------------------------------------------ seeding (:1033-1330)
     def seed_elements(self, lon, lat, time, radius=0, number=None, number_per_point=None,
@@ -332,9 +338,20 @@ class OpenDriftSimulation(Configurable):
 
     @property
     def elements(self):
-        """Live float64 state of the active elements (device order), like o.elements in the reference."""
-        d = self.P.download()
-        return SimpleNamespace(**d)
+        """The active elements as the reference's `o.elements` presents them: NumPy arrays in ascending-ID order (the
+        reference's release order), WRITABLE -- `self.elements.z = ...`, `self.elements.lon[mask] += ...` inside a model's
+        update() or any other hook reach the device when the hook returns (run() calls _flush_elements()), or at once
+        with o.elements.flush().  The arrays are a snapshot of the device state at the time of access."""
+        v = getattr(self, '_elements_view', None)
+        if v is None or v.stale():
+            v = self._elements_view = ElementsView(self)
+        return v
+
+    def _flush_elements(self):
+        v = getattr(self, '_elements_view', None)
+        if v is not None:
+            v.flush()
+        self._elements_view = None
 
     @property
     def elements_deactivated(self):
@@ -517,7 +534,36 @@ class OpenDriftSimulation(Configurable):
         names = list(self.required_variables)
         self.P.env_sample(names, t)
         self._sampled = names
+        self._sample_host_readers(names)
         self._add_uncertainty(names, current=True)
+
+    def _host_bindings(self):
+        return [(n, b) for n, b in self.readers.items() if getattr(b, 'host_eval', False)]
+
+    def _sample_host_readers(self, names):
+        """Readers evaluated on the host (user-defined ContinuousReaders): where such a reader comes BEFORE the device
+        sources of a variable its finite values replace what the device sampled (the priority-list walk of
+        environment.py:597-762 with the host reader in first place); elsewhere in the list it only fills what is
+        still missing."""
+        hb = self._host_bindings()
+        if not hb or self.num_elements_active() == 0:
+            return
+        d = self.P.download()
+        for name, b in hb:
+            vs = [v for v in b.variables if v in names and name in self.priority_list.get(v, [])]
+            if not vs:
+                continue
+            try:
+                vals = b.evaluate_on_host(vs, self.time, d['lon'], d['lat'], d['z'])
+            except Exception as e:      # the reference catches every exception of a reader call (environment.py:640-668)
+                self._reader_failed(name, b, e)
+                continue
+            for v in vs:
+                first = self.priority_list[v][0] == name
+                cur = self.P.env_download(v)
+                take = np.isfinite(vals[v]) & (first | ~np.isfinite(cur))
+                if take.any():
+                    self.P.env_upload(v, np.where(take, vals[v], cur).astype(np.float32))
 
     def _add_uncertainty(self, names, current):
         """environment.py:869-891, in the reference's order of draws: current normal (x, y), current uniform (x, y), wind
@@ -683,6 +729,15 @@ class OpenDriftSimulation(Configurable):
                 if self.get_config(key) is val:
                     self.required_variables.pop(vn)
         self.time = self.start_time
+        # the lon / lat box the elements can reach (:2017-2035): readers are prepared for it
+        max_distance = self.get_config('drift:max_speed') * steps * abs(time_step.total_seconds())
+        dlat = max_distance / 111000.
+        dlon = dlat / np.cos(np.radians(np.mean(self._sched['lat'])))
+        ext = np.array([max(-360, self._sched['lon'].min() - dlon), max(-89, self._sched['lat'].min() - dlat),
+                        min(360, self._sched['lon'].max() + dlon), min(89, self._sched['lat'].max() + dlat)])
+        if ext[2] == 360 and ext[0] < 0:
+            ext[0] = 0
+        self.simulation_extent = ext
         self._all_at_start = bool((self._sched['t_epoch'] == _epoch(self.start_time)).all())
         self._finalize_environment(self.start_time, self.start_time + time_step)
         n_total = self.num_elements_total()
@@ -698,6 +753,7 @@ class OpenDriftSimulation(Configurable):
         self.P = self.ctx.particles(max(1, hi_id - lo_id))
         self.mode = 'Run'
         self.prepare_run()
+        self._flush_elements()
         nout = steps // out_every + 1
         # float32 result buffer on the device (basemodel/__init__.py:2084-2105): element properties and
         # environment variables, [trajectory, time], NaN where an element does not exist
@@ -719,7 +775,12 @@ class OpenDriftSimulation(Configurable):
                       self.get_config('drift:max_age_seconds') is None and
                       self.get_config('general:seafloor_action', 'lift_to_seafloor') in ('lift_to_seafloor', 'none') and
                       not self.get_config('general:coastline_approximation_precision') and
-                      'x_sea_water_velocity' in self.required_variables and 'y_sea_water_velocity' in self.required_variables)
+                      'x_sea_water_velocity' in self.required_variables and 'y_sea_water_velocity' in self.required_variables and
+                      not self._host_bindings())
+        if self._host_bindings() and self.get_config('drift:advection_scheme') != 'euler' and any(
+                'x_sea_water_velocity' in b.variables for _, b in self._host_bindings()):
+            raise NotImplementedError('Runge-Kutta stages sample the current inside the kernel: a host-evaluated '
+                                      'ContinuousReader can deliver it for the euler scheme only')
         self.ctx.sync()
         t_loop = [time.perf_counter(), None]      # main-loop wall time (the reference keeps 'main loop' timers, basemodel :2174)
         # increase_age_and_retire comes after state_to_buffer in the loop: inside the fused launch only when the result
@@ -799,6 +860,7 @@ class OpenDriftSimulation(Configurable):
                     g_active = self._g_active = self.num_elements_active()
                 if g_active > 0:
                     self.update()
+                    self._flush_elements()      # what a model's update() wrote into self.elements goes to the device
                 elif g_sched == 0:
                     raise ValueError('No more active or scheduled elements, quitting.')
                 self._advected = False
@@ -845,6 +907,69 @@ class OpenDriftSimulation(Configurable):
                     times.append(self.start_time + len(times) * out_every * self.time_step)
         elif not final and k + 1 < self._hist.ntimes and len(self.P) > 0:
             self._hist.record(self.P, k + 1, True, self._hist_aux, from_previous)   # deactivated -> next output time (backfill)
+
+
+class ElementsView:
+    """`o.elements` (LagrangianArray, elements/elements.py:22-254) over the device arrays: see OpenDriftSimulation.elements."""
+    _F64 = ('lon', 'lat', 'z')
+    _F32 = ('wind_drift_factor', 'current_drift_factor', 'terminal_velocity')
+    _RO = ('ID', 'status', 'age_seconds')
+
+    def __init__(self, model):
+        object.__setattr__(self, '_m', model)
+        P = model.P
+        d = P.download()
+        order = np.argsort(d['ID'], kind='stable')             # device order -> ascending ID
+        cur = {k: d[k][order] for k in ('lon', 'lat', 'z', 'ID', 'status', 'moving')}
+        for k in self._F32 + ('age_seconds',):
+            cur[k] = P.download_f32(k)[order]
+        for slot, name in enumerate(getattr(model, 'aux_properties', [])):
+            cur[name] = P.get_property(slot)[order]
+        object.__setattr__(self, '_order', order)
+        object.__setattr__(self, '_cur', cur)
+        object.__setattr__(self, '_orig', {k: v.copy() for k, v in cur.items()})
+        object.__setattr__(self, '_epoch', (len(P), model.steps_calculation, getattr(P, '_touch', 0)))
+        P._view = self      # the next call that changes the device state flushes this view first (device._touching)
+
+    def stale(self):
+        P = self._m.P
+        return (len(P), self._m.steps_calculation, getattr(P, '_touch', 0)) != self._epoch
+
+    def __len__(self):
+        return len(self._cur['ID'])
+
+    def __getattr__(self, k):
+        try:
+            return self._cur[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        if k not in self._cur:
+            raise AttributeError('%s is not an element property' % k)
+        if k in self._RO:
+            raise AttributeError('%s is maintained by the model (use deactivate_elements for status)' % k)
+        n = len(self)
+        self._cur[k] = np.broadcast_to(np.asarray(v, dtype=self._orig[k].dtype), (n,)).copy()
+
+    def flush(self):
+        """Upload every property that differs from what was downloaded (assignment or in-place change)."""
+        P, cur, orig = self._m.P, self._cur, self._orig
+        if P.__dict__.get('_view') is self:
+            P._view = None
+        if len(P) != len(self):
+            return      # the element set changed underneath: nothing sensible to write
+        inv = np.empty(len(self), np.int64)
+        inv[self._order] = np.arange(len(self))                # ascending ID -> device order
+        changed = [k for k in cur if k not in self._RO and not np.array_equal(cur[k], orig[k], equal_nan=True)]
+        core = {k: np.ascontiguousarray(cur[k][inv]) for k in changed if k in self._F64 + self._F32 + ('moving',)}
+        if core:
+            P.upload(**core)
+        for slot, name in enumerate(getattr(self._m, 'aux_properties', [])):
+            if name in changed:
+                P.set_property(slot, np.ascontiguousarray(cur[name][inv]))
+        for k in changed:
+            orig[k] = cur[k].copy()
 
 
 class _ResultBuffer:

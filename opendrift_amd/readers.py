@@ -256,11 +256,25 @@ class GridReader(StructuredReader):
         self.variables = list(arrays)
         super().__init__()
 
+    buffer = 2      # pixels around the requested positions (StructuredReader.set_buffer_size, structured.py:125-147)
+
     def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
+        """The block covering the requested positions x, y plus `buffer` pixels (as reader_netCDF_CF_generic /
+        reader_ROMS_native cut it, reader_netCDF_CF_generic.py:404-470); without positions the whole domain."""
         it = self.times.index(time)
-        out = {'x': self.x, 'y': self.y, 'time': time, 'z': self.z if self.z is not None else 0}
+        jy, ix = slice(None), slice(None)
+        if x is not None and y is not None and np.size(x) > 0 and self.x.ndim == 1 and len(self.x) > 1:
+            def window(c, q):
+                asc = c[-1] > c[0]
+                ca = c if asc else c[::-1]
+                lo = int(np.clip(np.searchsorted(ca, np.nanmin(q), side='right') - 1 - self.buffer, 0, len(c) - 1))
+                hi = int(np.clip(np.searchsorted(ca, np.nanmax(q), side='left') + self.buffer, 0, len(c) - 1))
+                return slice(lo, hi + 1) if asc else slice(len(c) - 1 - hi, len(c) - lo)
+            ix, jy = window(np.asarray(self.x, dtype=np.float64), np.asarray(x, dtype=np.float64)), \
+                window(np.asarray(self.y, dtype=np.float64), np.asarray(y, dtype=np.float64))
+        out = {'x': self.x[ix], 'y': self.y[jy], 'time': time, 'z': self.z if self.z is not None else 0}
         for v in requested_variables:
-            out[v] = self.arrays[v][it]
+            out[v] = self.arrays[v][it][..., jy, ix]
         return out
 
 
@@ -355,6 +369,9 @@ class DeviceReaderBinding:
         if self.world > 1:
             self.prefetch = False      # the broadcast of a level is a collective: made when the level is due
         kind = getattr(reader, 'device_kind', None)
+        # a ContinuousReader the device has no closed form for (a user's analytic or point-wise reader,
+        # basereader/continuous.py:20-46): evaluated on the host at the element positions, values uploaded
+        self.host_eval = kind is None and isinstance(reader, ContinuousReader)
         if kind == 'constant':
             self.sid = ctx.add_constant({v: reader._parameter_value_map[v] for v in self.variables})
         elif kind == 'double_gyre':
@@ -372,11 +389,60 @@ class DeviceReaderBinding:
             ctx.set_time_coverage(self.sid, _epoch(reader.start_time), _epoch(reader.end_time), reader.always_valid)
 
     def is_grid(self):
-        return getattr(self.reader, 'device_kind', None) is None
+        return getattr(self.reader, 'device_kind', None) is None and not self.host_eval
+
+    def evaluate_on_host(self, variables, time, lon, lat, z):
+        """ContinuousReader._get_variables_interpolated_ (continuous.py:31-46): the reader's values exactly at the element
+        positions; NaN where it does not cover (position or time)."""
+        r = self.reader
+        n = len(lon)
+        out = {v: np.full(n, np.nan, np.float32) for v in variables}
+        if not r.covers_time(time):
+            return out
+        x, y = r.lonlat2xy(lon, lat)
+        x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        ok = np.ones(n, bool)
+        if r.xmin is not None:
+            ok &= (x >= r.xmin) & (x <= r.xmax) & (y >= r.ymin) & (y <= r.ymax)
+        ok &= (z >= r.zmin) & (z <= r.zmax)
+        if ok.any():
+            res = r.get_variables(list(variables), time, x[ok], y[ok], z[ok])
+            for v in variables:
+                out[v][ok] = np.asarray(np.ma.filled(res[v], np.nan), dtype=np.float32) * np.ones(int(ok.sum()), np.float32)
+        return out
+
+    def set_extent(self, lonlat_box):
+        """Reader.prepare(extent, ...) (basereader/__init__.py, called from Environment.finalize :139-211): the lon / lat
+        box the simulation can reach.  Blocks are then requested for that box only (+ the reader's buffer) instead of
+        the reader's whole domain -- what makes a basin-scale model with many levels fit: every resident time level is
+        cut to the same window.  Readers whose window would be most of their domain, readers without projection
+        (whole-mesh lookup) and s-level readers keep whole-domain blocks."""
+        r = self.reader
+        self.extent = None
+        if not self.is_grid() or not getattr(r, 'projected', True) or getattr(r, 's_levels', False) or lonlat_box is None:
+            return
+        if not (hasattr(r, 'x') and np.ndim(r.x) == 1 and len(r.x) > 8 and len(r.y) > 8):
+            return
+        lo0, la0, lo1, la1 = [float(v) for v in lonlat_box]
+        t = np.linspace(0, 1, 33)
+        lon = np.concatenate([lo0 + (lo1 - lo0) * t, lo0 + (lo1 - lo0) * t, np.full(33, lo0), np.full(33, lo1)])
+        lat = np.concatenate([np.full(33, la0), np.full(33, la1), la0 + (la1 - la0) * t, la0 + (la1 - la0) * t])
+        x, y = r.lonlat2xy(lon, lat)
+        x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        if not (np.isfinite(x).all() and np.isfinite(y).all()):
+            return
+        xs, ys = np.asarray(r.x, dtype=np.float64), np.asarray(r.y, dtype=np.float64)
+        fx = (min(x.max(), xs.max()) - max(x.min(), xs.min())) / (xs.max() - xs.min())
+        fy = (min(y.max(), ys.max()) - max(y.min(), ys.min())) / (ys.max() - ys.min())
+        if fx <= 0 or fy <= 0 or fx * fy > 0.6:
+            return        # no overlap (nothing to cut) or most of the domain anyway
+        self.extent = (np.array([x.min(), x.max()]), np.array([y.min(), y.max()]))
 
     def ensure_levels(self, t0, t1, extent=None, broadcast=None):
         """Make the time levels bracketing [t0, t1] resident (datetime arguments)."""
         r = self.reader
+        if extent is None:
+            extent = getattr(self, 'extent', None)
         if not self.is_grid():
             return
         if r.times is None:
@@ -463,6 +529,9 @@ class DeviceReaderBinding:
             if proj['kind'] == 'latlong' and r.xmin is not None and r.xmin >= 0 and r.xmax > 180:
                 lon_mode = 2
             dom = (float(r.xmin), float(r.xmax), float(r.ymin), float(r.ymax), float(r.zmin), float(r.zmax))
+            if extent is not None:     # blocks cut to the simulation extent: the source covers what the blocks cover
+                dom = (max(dom[0], float(np.min(bx))), min(dom[1], float(np.max(bx))), max(dom[2], float(np.min(by))),
+                       min(dom[3], float(np.max(by))), dom[4], dom[5])
             self.sid = self.ctx.add_grid(bx, by, z=zz, proj=proj, lon_mode=lon_mode, domain=dom)
             if r.start_time is not None:
                 self.ctx.set_time_coverage(self.sid, _epoch(r.start_time), _epoch(r.end_time), r.always_valid)

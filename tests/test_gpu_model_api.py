@@ -515,3 +515,103 @@ def test_reference_capsize_counts(dt, capsized0, expected):
     o.run(time_step=dt, time_step_output=900, duration=timedelta(hours=6))
     cap = o.P.get_property(8)
     assert cap.max() <= 1 and cap.min() >= 0 and cap.sum() == expected, cap.sum()
+
+
+def test_elements_view_is_id_ordered_and_writable_from_a_model_hook():
+    """B1: `o.elements` is what the reference hands to model code -- arrays in release (ascending ID) order that a
+    subclass's update() may assign or change in place (`self.elements.z = ...`, models/oceandrift.py:315-368 do exactly
+    that); here the writes reach the device before the next device call and when the hook returns."""
+    class Sinker(OceanDrift):
+        def update(self):
+            e = self.elements
+            assert (np.diff(e.ID) > 0).all()
+            e.z = e.z - 1.0                               # assignment
+            e.lon[e.ID % 2 == 0] += 0.001                 # in place, on the array the view handed out
+            self.advect_ocean_current()                   # a device call: must see the writes above
+            e2 = self.elements                            # a fresh view after the device moved the elements
+            assert np.allclose(e2.z, e.z) and not np.array_equal(e2.lon, e.lon)
+            e2.terminal_velocity = np.where(e2.ID < 5, 0.25, 0.0)
+
+    o = Sinker(loglevel=50, seed=0)
+    o.add_reader(readers.ConstantReader({'x_sea_water_velocity': 0.5, 'y_sea_water_velocity': 0.0}))
+    o.set_config('environment:constant:land_binary_mask', 0)
+    n = 5000
+    lon0 = np.linspace(4.0, 5.0, n)
+    o.seed_elements(lon=lon0, lat=np.full(n, 60.0), z=-10.0, time=T0)
+    o.run(time_step=600, steps=3)
+    o.P.compact()
+    o.P.sort_by_cell                                      # (no grid here; the view must cope with any device order)
+    e = o.elements
+    assert (np.diff(e.ID) > 0).all() and len(e) == n
+    assert np.allclose(e.z, -13.0)
+    # 3 steps x (0.001 deg for even IDs + 300 m eastward)
+    dlon = e.lon - np.float32(lon0).astype(np.float64)
+    east = 3 * 300.0 / (111319.5 * np.cos(np.radians(60.0)))
+    assert np.allclose(dlon[1::2], east, rtol=5e-3) and np.allclose(dlon[0::2] - dlon[1::2], 0.003, atol=1e-6)   # (spherical estimate of the eastward step)
+    assert np.array_equal(e.terminal_velocity, np.where(e.ID < 5, np.float32(0.25), np.float32(0.0)))
+    with pytest.raises(AttributeError):
+        e.status = 1
+
+
+def test_user_defined_continuous_reader_is_evaluated_on_the_host():
+    """B2: a ContinuousReader the device has no closed form for (basereader/continuous.py:20-46) -- its get_variables is
+    called with the element positions, the values are uploaded; euler advection then follows them."""
+    class Shear(readers.ContinuousReader):
+        name = 'shear'
+        variables = ['x_sea_water_velocity', 'y_sea_water_velocity']
+        xmin, xmax, ymin, ymax = -180, 180, -90, 90
+
+        def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
+            return {'x_sea_water_velocity': 0.4 * (np.asarray(y) - 60.0), 'y_sea_water_velocity': np.zeros(np.shape(x)),
+                    'time': time, 'x': x, 'y': y, 'z': z}
+
+    o = OceanDrift(loglevel=50, seed=0)
+    o.add_reader(Shear())
+    o.set_config('environment:constant:land_binary_mask', 0)
+    n = 1000
+    lat0 = np.linspace(60.0, 61.0, n)
+    o.seed_elements(lon=np.full(n, 4.0), lat=lat0, time=T0)
+    o.run(time_step=600, steps=4)
+    e = o.elements
+    u = 0.4 * (np.float32(lat0).astype(np.float64) - 60.0)
+    want = 4.0 + 4 * 600.0 * u / (111319.5 * np.cos(np.radians(e.lat)))
+    assert np.allclose(e.lon - 4.0, want - 4.0, rtol=5e-3, atol=1e-9) and (e.lon[-1] - 4.0) > 0.01    # (spherical estimate)
+    assert np.allclose(o.environment.x_sea_water_velocity[np.argsort(o.P.ids())], u.astype(np.float32), atol=1e-6)
+    o2 = OceanDrift(loglevel=50, seed=0)
+    o2.add_reader(Shear())
+    o2.set_config('environment:constant:land_binary_mask', 0)
+    o2.set_config('drift:advection_scheme', 'runge-kutta4')
+    o2.seed_elements(lon=4.0, lat=60.5, time=T0)
+    with pytest.raises(NotImplementedError):
+        o2.run(time_step=600, steps=1)
+
+
+def test_blocks_are_cut_to_the_simulation_extent():
+    """basereader/structured.py:275-318 + Environment.finalize: a reader is asked for the part of its domain the
+    simulation can reach (+ its buffer), not for whole-domain blocks -- same trajectories, a fraction of the block."""
+    g = golden('c3_grid3d_rk4_vmix.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity',
+             'ocean_vertical_diffusivity', 'sea_floor_depth_below_sea_level', 'land_binary_mask']
+    sel = (g['lon'][0] < g['g_x'][16]) & (g['lat'][0] < g['g_y'][14])          # elements in one corner of the domain
+    assert sel.sum() > 20
+    res, shapes = [], []
+    for cut in (True, False):
+        o = OceanDrift(loglevel=50, seed=0)
+        r = _grid_reader(g, names, z=g['g_z'])
+        if not cut:
+            r.get_variables = lambda req, time=None, x=None, y=None, z=None, _f=r.get_variables: _f(req, time, None, None, z)
+        o.add_reader(r)
+        o.set_config('drift:advection_scheme', 'runge-kutta4')
+        o.set_config('drift:max_speed', 1.0)
+        o.set_config('general:coastline_action', 'previous')
+        o.seed_elements(lon=g['lon'][0][sel], lat=g['lat'][0][sel], z=g['z'][0][sel], time=T0)
+        o.run(time_step=600, steps=6)
+        e = o.elements
+        res.append((e.lon.copy(), e.lat.copy(), e.z.copy()))
+        b = next(iter(o.readers.values()))
+        shapes.append((o.ctx._grids[b.sid]['ny'], o.ctx._grids[b.sid]['nx']))
+    assert shapes[0][0] * shapes[0][1] < 0.5 * shapes[1][0] * shapes[1][1], shapes
+    # the cut block has its own origin and span: fractional indices differ by float64 round-off, a float32 sample flips
+    # its last bit now and then (as in the reference, whose blocks are cut the same way)
+    assert np.abs(res[0][0] - res[1][0]).max() < 1e-7 and np.abs(res[0][1] - res[1][1]).max() < 1e-7
+    assert np.abs(res[0][2] - res[1][2]).max() < 1e-5
