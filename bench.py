@@ -136,7 +136,7 @@ class Workload:
     def step(self, P, k):
         t = self.time_of(k)
         if self.sort_every and self.name != 'c2' and k % self.sort_every == 0:
-            P.sort_by_cell(self.sid)   # device layout maintenance, part of the timed step
+            P.sort_by_cell(self.sid, keep_environment=False)   # device layout maintenance, part of the timed step
         if self.name == 'c2':
             P.env_sample([U, V], t)
             P.advect('runge-kutta4', t, self.dt)

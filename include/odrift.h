@@ -372,6 +372,9 @@ int odr_compact_apply(odr_ctx *ctx, odr_particles *p, int64_t *n_active);
  * RNG is counter-based on ID).  Do not use together with ODR_RNG_HOST arrays, which are
  * indexed by position. */
 int odr_sort_particles(odr_ctx *ctx, odr_particles *p, int32_t source_id);
+/* keep_environment = 0: the sampled environment and the sample position are not carried along (the next odr_env_sample /
+ * odr_env_coast_advect rewrites them for every element): a re-sort at the top of a step moves half the bytes */
+int odr_sort_particles_ex(odr_ctx *ctx, odr_particles *p, int32_t source_id, int keep_environment);
 /* counts and min/max used for the per-step log line and early-outs (:2212-2233):
  * out16 = {n_active, lon_min, lon_max, lat_min, lat_max, z_min, z_max, D_max, stokes_sum_max,
  *          wind_speed_max, wdf_surface_max, n_surface, hs_max, tp_max, 0, 0} */

@@ -1383,28 +1383,32 @@ static int ensure_alt(odr_particles *p) {
   return 0;
 }
 
-static void all_arrays(odr_particles *p, CmpArrays &A) {
+// with_env = false: without the environment and the sample position (slon / slat), which the next environment sample
+// rewrites for every element -- a re-sort at the top of a step moves 68 instead of ~130 bytes per particle
+static void all_arrays(odr_particles *p, CmpArrays &A, bool with_env = true) {
   memset(&A, 0, sizeof A);
-  for (int k = 0; k < 7; ++k) {
+  const int n64 = with_env ? 7 : 5;
+  for (int k = 0; k < n64; ++k) {
     A.src64[k] = p->d64[k]; A.dst64[k] = p->alt64[k];
     A.dead64[k] = k < 3 ? p->dead64[k] : nullptr;
   }
-  A.n64 = 7;
+  A.n64 = n64;
   int m = 0;
   for (int k = 0; k < 3; ++k, ++m) { A.src32[m] = p->i32[k]; A.dst32[m] = p->alti32[k]; A.dead32[m] = k < 2 ? p->deadi32[k] : nullptr; }
   for (int k = 0; k < 4; ++k, ++m) { A.src32[m] = (const int *)p->f32[k]; A.dst32[m] = (int *)p->altf32[k]; }
-  for (int k = 0; k < NVAR; ++k)
-    if (p->env[k]) { A.src32[m] = (const int *)p->env[k]; A.dst32[m] = (int *)p->altenv[k]; ++m; }
+  if (with_env)
+    for (int k = 0; k < NVAR; ++k)
+      if (p->env[k]) { A.src32[m] = (const int *)p->env[k]; A.dst32[m] = (int *)p->altenv[k]; ++m; }
   for (int k = 0; k < 9; ++k)
     if (p->aux[k]) { A.src32[m] = (const int *)p->aux[k]; A.dst32[m] = (int *)p->altaux[k]; ++m; }
   A.n32 = m;
 }
 
-static void swap_sets(odr_particles *p) {
-  for (int k = 0; k < 7; ++k) std::swap(p->d64[k], p->alt64[k]);
+static void swap_sets(odr_particles *p, bool with_env = true) {
+  for (int k = 0; k < (with_env ? 7 : 5); ++k) std::swap(p->d64[k], p->alt64[k]);
   for (int k = 0; k < 3; ++k) std::swap(p->i32[k], p->alti32[k]);
   for (int k = 0; k < 4; ++k) std::swap(p->f32[k], p->altf32[k]);
-  for (int k = 0; k < NVAR; ++k) if (p->env[k]) std::swap(p->env[k], p->altenv[k]);
+  if (with_env) for (int k = 0; k < NVAR; ++k) if (p->env[k]) std::swap(p->env[k], p->altenv[k]);
   for (int k = 0; k < 9; ++k) if (p->aux[k]) std::swap(p->aux[k], p->altaux[k]);
 }
 
@@ -1476,7 +1480,13 @@ int odr_compact(odr_ctx *c, odr_particles *p, int64_t *n_active) {
 }
 
 // Re-order the particle arrays by the grid cell of one gridded reader (see k_sort_hist).
-int odr_sort_particles(odr_ctx *c, odr_particles *p, int32_t sid) {
+int odr_sort_particles(odr_ctx *c, odr_particles *p, int32_t sid) { return odr_sort_particles_ex(c, p, sid, 1); }
+
+// keep_environment = 0: the sampled environment and the sample position are NOT carried along (they are left in the old
+// order, i.e. meaningless): for a re-sort at the top of a step, whose environment sample rewrites them anyway.
+// Environment variables that hold one value for every element stay valid.
+int odr_sort_particles_ex(odr_ctx *c, odr_particles *p, int32_t sid, int keep_environment) {
+  const bool with_env = keep_environment != 0;
   REQUIRE(sid >= 0 && sid < c->nsrc && c->hw.src[sid].kind == SRC_GRID && c->hw.src[sid].nlevels > 0,
           "source %d is not a gridded source with a resident block", sid);
   HIPCHK(hipSetDevice(c->device));
@@ -1505,11 +1515,14 @@ int odr_sort_particles(odr_ctx *c, odr_particles *p, int32_t sid) {
   }
   hipLaunchKernelGGL(k_sort_perm, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, keys, p->n, hist, perm);
   CmpArrays A;
-  all_arrays(p, A);
+  all_arrays(p, A, with_env);
   hipLaunchKernelGGL(k_gather_perm, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, perm, p->n, A);
   HIPCHK(hipGetLastError());
-  swap_sets(p);     // host pointers only: everything after this call is ordered behind the gather on the stream
-  for (int v = 0; v < NVAR; ++v) p->env_cn[v] = std::min(p->env_cn[v], p->n);
+  swap_sets(p, with_env);     // host pointers only: everything after this call is ordered behind the gather on the stream
+  for (int v = 0; v < NVAR; ++v) {
+    if (with_env) p->env_cn[v] = std::min(p->env_cn[v], p->n);
+    else if (!(p->env_cok[v] && p->env_cn[v] >= p->n)) p->env_cok[v] = false;   // not carried: only a constant survives
+  }
   p->status_epoch++;
   return 0;
 }

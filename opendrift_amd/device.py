@@ -643,9 +643,10 @@ class Particles:
             self._permuted = True
         return n.value
 
-    def sort_by_cell(self, source_id):
-        """Re-order the SoA by grid cell of a gridded source (layout only; IDs are preserved)."""
-        check(self.lib.odr_sort_particles(self.ctx.h, self.h, int(source_id)))
+    def sort_by_cell(self, source_id, keep_environment=True):
+        """Re-order the SoA by grid cell of a gridded source (layout only; IDs are preserved).  keep_environment=False:
+        the sampled environment is not carried along (a re-sort right before the next sample)."""
+        check(self.lib.odr_sort_particles_ex(self.ctx.h, self.h, int(source_id), int(bool(keep_environment))))
         self._permuted = True
 
     def reduce_global(self, combine, wind_drift_depth=0.1, relative_wind=False):

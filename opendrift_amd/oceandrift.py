@@ -804,7 +804,7 @@ class OpenDriftSimulation(Configurable):
                 n_act = self.num_elements_active()
                 if self.rng == 'device' and grid_sid is not None and self.sort_every and n_act > 65536 and \
                         (i % self.sort_every == 0 or self.newly_seeded * 20 > n_act):
-                    self.P.sort_by_cell(grid_sid)
+                    self.P.sort_by_cell(grid_sid, keep_environment=False)   # the step's sample follows
                 if fused_lane:
                     # ONE launch for get_environment + coastline + seafloor + update_previous_state +
                     # advect_ocean_current (odr_env_coast_advect).  deactivate_outside only reads positions and goes
