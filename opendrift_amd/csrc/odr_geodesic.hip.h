@@ -421,13 +421,17 @@ __device__ __forceinline__ GeodLocal geod_local_origin(double lat1, double lon1)
 }
 
 // the full solution for the steps the series does not cover (rare: kept out of line)
-__device__ __attribute__((noinline)) void geod_local_far(double lat1, double lon1n, double x, double y, double &lat2,
-                                                         double &lon2) {
+// (the result comes back by value, in registers: reference outputs of an out-of-line call pin the callers' lon / lat
+// to scratch memory for the whole kernel)
+struct GeodLL { double lat, lon; };
+__device__ __attribute__((noinline)) GeodLL geod_local_far(double lat1, double lon1n, double x, double y) {
   const GeodOrigin o = geod_origin(lat1, lon1n);
   const double s = sqrt(x * x + y * y);
   double salp = 0.0, calp = 1.0;
   if (s > 0) { salp = x / s; calp = y / s; }
-  geod_direct_sc(o, salp, calp, s, lat2, lon2);
+  GeodLL r;
+  geod_direct_sc(o, salp, calp, s, r.lat, r.lon);
+  return r;
 }
 
 // end point of the geodesic that starts at the origin of L with azimuth atan2(x, y) and length hypot(x, y):
@@ -437,7 +441,7 @@ __device__ __forceinline__ void geod_local_move(const GeodLocal &L, double x, do
   const double u = y * L.iN, v = x * L.iN;
   const double u2 = u * u, v2 = v * v;
   if (!((u2 + v2) * (L.qs * L.qs) <= kGeodLocalQ * kGeodLocalQ)) {   // also NaN steps
-    if (u2 + v2 == u2 + v2 && L.lat1 == L.lat1) { geod_local_far(L.lat1, L.lon1n, x, y, lat2, lon2); return; }
+    if (u2 + v2 == u2 + v2 && L.lat1 == L.lat1) { const GeodLL r = geod_local_far(L.lat1, L.lon1n, x, y); lat2 = r.lat; lon2 = r.lon; return; }
     lat2 = lon2 = __builtin_nan("");
     return;
   }

@@ -18,8 +18,15 @@ namespace odr {
 #endif
 constexpr int BLOCK = ODR_BLOCK;  // threads per workgroup (A/B builds may override)
 #ifndef ODR_POLAR_WAVES
-#define ODR_POLAR_WAVES 3   // measured on C4: 2 waves (183 VGPRs) 1.31 ms, 3 waves (168 VGPRs, 52 B scratch) 1.06 ms, 4 waves (128 VGPRs, 280 B scratch) 2.06 ms
+#define ODR_POLAR_WAVES 3   // the environment-only kernel of a projected reader (latency-bound gathers: occupancy first)
 #endif
+#ifndef ODR_POLAR_STEP_WAVES
+// the advection kernels of a projected reader.  C4, round 1: 2 waves 1.31 ms, 3 waves (168 VGPRs, 52 B scratch) 1.06 ms,
+// 4 waves (280 B scratch) 2.06 ms; round 2 (stage noise, series geodesic: 128-160 B scratch at 3 waves): 3 waves 1.045 ms,
+// 2 waves (no scratch) 0.998 ms  (profiles/r02_ab_variants.txt)
+#define ODR_POLAR_STEP_WAVES 2
+#endif
+#define ODR_STEP_WAVES(PROJ) ((PROJ) == PROJ_LATLONG ? ODR_LATLONG_WAVES : ODR_POLAR_STEP_WAVES)
 // minimum waves per SIMD requested for the projected-reader instantiations (their stereographic forward /
 // rotation code otherwise takes ~185 VGPRs = 2 waves per SIMD)
 #ifndef ODR_LATLONG_WAVES
@@ -544,7 +551,7 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
 }
 
 template <int SCHEME, int PROJ, bool IS3D, bool NOISE>
-__global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_advect_grid(const DevWorld *__restrict__ W, int sid, int geo_slot,
+__global__ __launch_bounds__(BLOCK, ODR_STEP_WAVES(PROJ)) void k_advect_grid(const DevWorld *__restrict__ W, int sid, int geo_slot,
                                                        PView p, double dt, float factor, UVTime th,
                                                        UVTime tf, StageNoise N) {
   long long i = pid();
@@ -588,8 +595,21 @@ struct StepMix {
   VMixArgs A;
   int vadv, w_slot;   // vertical advection: -1 none | 0 below the surface | 1 including it; slot of W in the group or -1
 };
+// out[j] with a run-time j, as a chain of selects: a dynamically indexed register array lives in scratch memory
+// (k_step_grid<RK4>: 80 B per lane, 0.5 GB of HBM writes per launch at 10 M particles)
+__device__ __forceinline__ float pick_slot(const float (&a)[MAXG], int j) {
+  float r = a[0];
+#pragma unroll
+  for (int k = 1; k < MAXG; ++k) {
+    float v = a[k];
+    asm volatile("" : "+v"(v));   // opaque: keeps the optimiser from folding the selects back into one indexed load
+    r = j == k ? v : r;
+  }
+  return r;
+}
+
 template <int SCHEME, int PROJ, bool IS3D, bool NOISE, bool TILE = false, int MIXQ = 0, bool MIXTL = false>
-__global__ __launch_bounds__(BLOCK, (MIXQ > 0 && ODR_WAVES(PROJ) < ODR_MIX_WAVES) ? ODR_MIX_WAVES : ODR_WAVES(PROJ)) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
+__global__ __launch_bounds__(BLOCK, (MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_WAVES) ? ODR_MIX_WAVES : ODR_STEP_WAVES(PROJ)) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
                                                      StepDesc S, double dt, float factor, UVTime th, UVTime tf,
                                                      unsigned long long *n_hit, StageNoise N, int tile_nodes = 0,
                                                      StepMix M = StepMix()) {
@@ -720,7 +740,7 @@ __global__ __launch_bounds__(BLOCK, (MIXQ > 0 && ODR_WAVES(PROJ) < ODR_MIX_WAVES
       bool miss = false;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (k < S.nmiss_grp) miss |= out[S.miss_grp[k]] != out[S.miss_grp[k]];
+        if (k < S.nmiss_grp) { const float e = pick_slot(out, S.miss_grp[k]); miss |= e != e; }
         if (k < S.nmiss_rest) { const float e = p.env[S.miss_rest[k]][i]; miss |= e != e; }
       }
       if (miss) {
@@ -786,7 +806,7 @@ __global__ __launch_bounds__(BLOCK, (MIXQ > 0 && ODR_WAVES(PROJ) < ODR_MIX_WAVES
         }
         if (sf_flags & 2) { lon = p.plon[i]; lat = p.plat[i]; }
         if (M.vadv >= 0 && (M.vadv ? zn <= 0 : zn < 0)) {
-          const float wv = M.w_slot >= 0 ? out[M.w_slot] : p.env[VAR_W][i];
+          const float wv = M.w_slot >= 0 ? pick_slot(out, M.w_slot) : p.env[VAR_W][i];
           const double zq = __dadd_rn(zn, __dmul_rn(__dmul_rn((double)moving, (double)wv), dt));
           zn = zq < 0 ? zq : 0.0;
         }
