@@ -141,9 +141,10 @@ class Workload:
             P.env_sample([U, V], t)
             P.advect('runge-kutta4', t, self.dt)
         elif self.name == 'c3':
-            if self.fused:
+            if self.fused:   # one call, as OceanDrift.run() makes it: the step launch, then the mixing launch
                 P.env_coast_advect(self.vars, t, self.scheme, self.dt, coastline='previous', store_previous=True,
-                                   count=False, seafloor=True, age_dt=self.dt)
+                                   count=False, seafloor=True, age_dt=self.dt,
+                                   vmix=dict(dt_mix=self.dt_mix, step=k, vertical_advection=False))
             else:
                 P.env_sample(self.vars, t)
                 P.coastline('previous')
@@ -151,7 +152,7 @@ class Workload:
                 P.increase_age(self.dt)
                 P.store_previous()
                 P.advect('runge-kutta4', t, self.dt)
-            P.vmix(t, self.dt, self.dt_mix, step=k, fuse_vertical_advection=False)
+                P.vmix(t, self.dt, self.dt_mix, step=k, fuse_vertical_advection=False)
         elif self.name == 'c5':   # Leeway ensemble members: Euler by construction (leeway.py:472-476)
             P.env_sample(self.vars, t)
             P.env_add_noise(U, V, 0.1, step=k)        # drift:current_uncertainty

@@ -31,6 +31,7 @@ int odr_i_fail(int code, const char *fmt, ...);   // records the message for odr
 struct Staged { DevBlock blk; float *base; size_t bytes; };       // uploaded, not yet committed
 struct Retired { void *ptr; size_t bytes; hipEvent_t ev; };       // replaced block, freed once the compute stream passed
 
+constexpr int ODR_MAX_LANES = 8;
 struct odr_ctx {
   int device;
   unsigned long long seed;
@@ -75,10 +76,15 @@ struct odr_ctx {
   double red_wdd;
   int red_rel;
   int red_pinned;   // odr_reduce_install: red[] holds values combined over the ranks of a sharded run
+  // lanes of the fused step (odr_step.hip, step_in_lanes): contiguous particle ranges on streams of their own
+  hipStream_t lane_stream[ODR_MAX_LANES];
+  hipEvent_t lane_step[ODR_MAX_LANES], lane_done[ODR_MAX_LANES], lane_fork;
+  int lanes_ready;
 };
 
 struct odr_particles {
   long long cap, n, ndead, dead_cap;
+  long long win;        // first element of the window that view() exposes (0 except inside step_in_lanes)
   double *d64[7];       // lon lat z plon plat slon slat
   double *alt64[7];
   int *i32[3];          // id status moving
@@ -113,12 +119,13 @@ static inline unsigned nblk(long long n) { return (unsigned)((n + BLOCK - 1) / B
 static inline PView view(const odr_particles *p) {
   PView v;
   v.n = p->n;
-  v.lon = p->d64[0]; v.lat = p->d64[1]; v.z = p->d64[2]; v.plon = p->d64[3]; v.plat = p->d64[4];
-  v.slon = p->d64[5]; v.slat = p->d64[6];
-  v.id = p->i32[0]; v.status = p->i32[1]; v.moving = p->i32[2];
-  v.wdf = p->f32[0]; v.cdf = p->f32[1]; v.tv = p->f32[2]; v.age = p->f32[3];
-  for (int k = 0; k < NVAR; ++k) v.env[k] = p->env[k];
-  for (int k = 0; k < 9; ++k) v.aux[k] = p->aux[k];
+  const long long w = p->win;
+  v.lon = p->d64[0] + w; v.lat = p->d64[1] + w; v.z = p->d64[2] + w; v.plon = p->d64[3] + w; v.plat = p->d64[4] + w;
+  v.slon = p->d64[5] + w; v.slat = p->d64[6] + w;
+  v.id = p->i32[0] + w; v.status = p->i32[1] + w; v.moving = p->i32[2] + w;
+  v.wdf = p->f32[0] + w; v.cdf = p->f32[1] + w; v.tv = p->f32[2] + w; v.age = p->f32[3] + w;
+  for (int k = 0; k < NVAR; ++k) v.env[k] = p->env[k] ? p->env[k] + w : nullptr;
+  for (int k = 0; k < 9; ++k) v.aux[k] = p->aux[k] ? p->aux[k] + w : nullptr;
   return v;
 }
 

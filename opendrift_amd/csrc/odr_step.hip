@@ -86,6 +86,58 @@ static bool s_is_latlong_3d(const odr_ctx *c, int sid) {
   return s.proj.kind == PROJ_LATLONG && s.nz > 1 && s.slot[s.level_slot[0]].var_nz[VAR_U] > 1;
 }
 
+// ---- lanes: the step kernel (gathers: bound by memory latency, VALU about half busy) and the mixing kernel (bound by
+// VALU issue) of DIFFERENT particles have nothing to wait for in each other.  The particle range is cut into `lanes`
+// contiguous windows, each on a stream of its own: step(l) -> mix(l) in order on lane l, and step(l + 1) starts when
+// step(l) has drained, so that mix(l) and step(l + 1) are resident together and fill each other's idle issue slots.
+// Results are those of the single launch (kernels are per-particle; the RNG is keyed by element ID).
+static int lane_count(odr_ctx *c, const odr_particles *p, bool want_mix, bool noise_on) {
+  if (!want_mix || noise_on || c->oil_owner == p) return 1;
+  const char *e = getenv("ODR_LANES");
+  int lanes = e ? atoi(e) : 1;
+  if (lanes > ODR_MAX_LANES) lanes = ODR_MAX_LANES;
+  const char *m = getenv("ODR_LANES_MIN_N");
+  const long long min_n = m ? atoll(m) : 2000000;
+  if (p->n < min_n || p->n / (lanes > 0 ? lanes : 1) < 4 * BLOCK) return 1;
+  return lanes;
+}
+
+static int step_in_lanes(odr_ctx *c, odr_particles *p, int lanes, const EnvGroupDesc &G, const StepDesc &S, int scheme,
+                         double t, double dt, double factor, const StageNoise &N, const odr_step_extras *ex) {
+  if (!c->lanes_ready) {
+    for (int l = 0; l < ODR_MAX_LANES; ++l) {
+      HIPCHK(hipStreamCreateWithFlags(&c->lane_stream[l], hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&c->lane_step[l], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&c->lane_done[l], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
+    c->lanes_ready = 1;
+  }
+  const long long n = p->n;
+  const hipStream_t main_stream = c->stream;
+  long long per = (n / lanes + BLOCK - 1) / BLOCK * BLOCK;
+  HIPCHK(hipEventRecord(c->lane_fork, main_stream));
+  int rc = 0, used = 0;
+  for (int l = 0; l < lanes && !rc; ++l) {
+    const long long first = (long long)l * per, count = l == lanes - 1 ? n - first : std::min(per, n - first);
+    if (count <= 0) break;
+    hipStream_t s = c->lane_stream[l];
+    HIPCHK(hipStreamWaitEvent(s, c->lane_fork, 0));
+    if (l > 0) HIPCHK(hipStreamWaitEvent(s, c->lane_step[l - 1], 0));
+    p->win = first; p->n = count; c->stream = s;
+    step_dispatch<false>(c, p, G, S, scheme, t, dt, factor, N);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventRecord(c->lane_step[l], s);
+    if (e == hipSuccess) rc = mix_after(c, p, t, dt, ex);
+    if (e == hipSuccess && !rc) e = hipEventRecord(c->lane_done[l], s);
+    p->win = 0; p->n = n; c->stream = main_stream;
+    if (e != hipSuccess) return fail(ODR_ERR_HIP, "lane launch: %s", hipGetErrorString(e));
+    used = l + 1;
+  }
+  for (int l = 0; l < used; ++l) HIPCHK(hipStreamWaitEvent(main_stream, c->lane_done[l], 0));
+  return rc;
+}
+
 int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t,
                          int coast_action, int stranded_code, int seeded_on_land_code, int store_previous,
                          int scheme, double dt, double factor, const odr_step_extras *extras, int64_t *n_on_land) {
@@ -212,6 +264,12 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   if (mix_fused) {
     odr_i_step_mix(c, p, G, S, scheme, t, dt, factor, M);
     HIPCHK(hipGetLastError());
+    return coast_action ? read_counter(c, n_on_land) : 0;
+  }
+  const int lanes = lane_count(c, p, want_mix, N.on);
+  if (lanes > 1) {
+    if ((rc = ensure_env(c, p, VAR_SSH))) return rc;
+    if ((rc = step_in_lanes(c, p, lanes, G, S, scheme, t, dt, factor, N, extras))) return rc;
     return coast_action ? read_counter(c, n_on_land) : 0;
   }
   if (N.on && (scheme > 0 || main_noise)) {

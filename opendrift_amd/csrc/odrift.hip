@@ -72,6 +72,14 @@ int odr_ctx_destroy(odr_ctx *c) {
   if (c->oil_guide) (void)hipFree(c->oil_guide);
   if (c->noise_buf) (void)hipFree(c->noise_buf);
   (void)hipFree(c->counter);
+  if (c->lanes_ready) {
+    for (int l = 0; l < ODR_MAX_LANES; ++l) {
+      (void)hipStreamDestroy(c->lane_stream[l]);
+      (void)hipEventDestroy(c->lane_step[l]);
+      (void)hipEventDestroy(c->lane_done[l]);
+    }
+    (void)hipEventDestroy(c->lane_fork);
+  }
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->own_stream);

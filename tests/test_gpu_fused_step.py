@@ -237,3 +237,46 @@ def test_mixing_inside_the_step_launch_gives_the_same_bits_as_two_calls(monkeypa
     for a, b in zip(*res):
         assert np.array_equal(a, b)
     assert np.abs(res[0][2] - np.sort(z)[::1][0] * 0).max() > 1.0 and (res[0][2] <= 0).all()
+
+
+@pytest.mark.parametrize('lanes', [2, 5])
+def test_step_in_lanes_gives_the_same_bits_as_one_launch(monkeypatch, lanes):
+    """ODR_LANES: the step + mixing of contiguous particle windows on streams of their own (step_in_lanes, odr_step.hip),
+    so that the mixing kernel of one window and the step kernel of the next are resident together.  Per-particle kernels,
+    RNG keyed by element ID: bit-identical lon / lat / z / status / environment to the single launch, also with a last
+    window that is not a multiple of the workgroup size."""
+    g = synth.grid3d(nx=96, ny=80, nz=8, nt=3, seed=5)
+    g[DEPTH][:] = np.minimum(g[DEPTH], 60.0 + 100.0 * np.linspace(0, 1, 96)[None, None, :]).astype(np.float32)
+    names = [U, V, W, KZ, DEPTH, LAND]
+    rng = np.random.default_rng(13)
+    n = 30011
+    lon = rng.uniform(g['x'][3], g['x'][-4], n)
+    lat = rng.uniform(g['y'][3], g['y'][-4], n)
+    z = -rng.uniform(0, 70, n)
+    monkeypatch.setenv('ODR_LANES_MIN_N', '0')
+    res = []
+    for nl in (lanes, 1):
+        monkeypatch.setenv('ODR_LANES', str(nl))
+        ctx = Context(seed=4)
+        sid = ctx.add_grid(g['x'], g['y'], z=g['z'])
+        for k in range(3):
+            ctx.upload_block(sid, k, float(g['t'][k]), {nm: g[nm][k] for nm in names})
+        for nm in names:
+            ctx.bind(nm, [sid], {LAND: np.nan, DEPTH: 10000.0}.get(nm, 0.0))
+        ctx.bind(SSH, [], 0.0)
+        P = ctx.particles(n)
+        P.append(lon, lat, z=z, terminal_velocity=np.where(np.arange(n) % 3 == 0, -0.004, 0.001).astype(np.float32))
+        P.sort_by_cell(sid)
+        for k, t in enumerate((0.0, 900.0, 3300.0, 3600.0)):
+            P.env_coast_advect([U, V, W, DEPTH, SSH, LAND], t, 'runge-kutta4', 600.0, coastline='previous', count=False,
+                               seafloor=True, age_dt=600.0, vmix=dict(dt_mix=60.0, step=k, vertical_advection=True))
+            if k == 1:
+                P.sort_by_cell(sid, keep_environment=False)
+        d = P.download()
+        o = np.argsort(d['ID'])
+        res.append(tuple(d[q][o] for q in ('lon', 'lat', 'z', 'status', 'moving')) + (P.download_f32('age_seconds')[o],) +
+                   tuple(P.env_download(q)[o] for q in (U, W, DEPTH)))
+        P.close()
+        ctx.close()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b, equal_nan=True)

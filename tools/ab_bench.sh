@@ -5,8 +5,6 @@
 W=${1:-c3}; R=${2:-3}
 for i in $(seq $R); do
   for v in A B; do
-    ODR_LIB=$PWD/tools/_lib$v.so python bench.py --workload $W --no-cpu 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('$v', d['config']['workload'][:3], 'ms/step %.4f'%d['ms_per_step'], 'kernel_ms %.4f'%d['roofline']['kernel_ms'])"
+    ODR_LIB=$PWD/tools/_lib$v.so python bench.py --workload $W --no-cpu 2>/dev/null | tail -1 | python tools/bl.py $v
   done
 done
