@@ -596,9 +596,22 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
       // the reference dilates on demand, <=10 sweeps per interpolator call (interpolators.py:127-137);
       // 10 sweeps up front give identical samples.  (An LDS-tiled single-pass version of the
       // ten sweeps was measured slower than these ten bandwidth-bound launches -- 0.67 vs 0.41 ms -- and dropped.)
+      // Sweeps after the first only look at the cells that are still NaN in their ping-pong target (= the state two
+      // sweeps back; k_blk_dilate_row): one read of the target where the field has no NaN, instead of read + write.
       float *a = buf, *bb2 = tmp;
+      const unsigned rows = (unsigned)nzv * (unsigned)ny;
+      const bool by_row = !getenv("ODR_PLAIN_DILATE") && (size_t)nzv * (size_t)ny < (1ull << 31);
       for (int it = 0; it < 10; ++it) {
-        hipLaunchKernelGGL(k_blk_dilate, dim3(g), dim3(BLOCK), 0, st, a, bb2, nzv, ny, nx);
+#define DILATE_ROW(W)                                                                                                   \
+  do {                                                                                                                  \
+    if (it == 0) hipLaunchKernelGGL((k_blk_dilate_row<W, true>), dim3(rows), dim3(BLOCK), 0, st, a, bb2, ny, nx);        \
+    else hipLaunchKernelGGL((k_blk_dilate_row<W, false>), dim3(rows), dim3(BLOCK), 0, st, a, bb2, ny, nx);               \
+  } while (0)
+        if (!by_row) hipLaunchKernelGGL(k_blk_dilate, dim3(g), dim3(BLOCK), 0, st, a, bb2, nzv, ny, nx);
+        else if (nx % 4 == 0) DILATE_ROW(4);
+        else if (nx % 2 == 0) DILATE_ROW(2);
+        else DILATE_ROW(1);
+#undef DILATE_ROW
         float *t2 = a; a = bb2; bb2 = t2;
       }
       // 10 swaps -> result is back in buf
@@ -1429,7 +1442,7 @@ int odr_scan_status(odr_ctx *c, odr_particles *p, int64_t *n_kept, uint64_t *fla
   if (p->n == 0) return 0;
   unsigned nb = nblk(p->n);
   HIPCHK(hipMemsetAsync(c->counter + 1, 0, 2 * sizeof(unsigned long long), c->stream));
-  hipLaunchKernelGGL(k_cmp_count, dim3(nb), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount, c->counter + 2, c->counter + 1);
+  hipLaunchKernelGGL(k_cmp_count, dim3(std::min(nb, 2048u)), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount, c->counter + 2, c->counter + 1);
   unsigned long long out[2];
   HIPCHK(hipMemcpyAsync(out, c->counter + 1, sizeof out, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));

@@ -100,3 +100,45 @@ def test_model_run_with_prefetch_equals_run_without():
     for p, q in zip(a[:3], b[:3]):
         assert _eq(p, q)
     assert a[3] >= 2
+
+
+@pytest.mark.parametrize('nx', [33, 34, 36])
+def test_row_dilation_sweeps_equal_the_plain_ones(ctx, monkeypatch, nx):
+    """The ten grey_dilation sweeps of a new block (expand_numpy_array, interpolators.py:9-20): the row kernels that only
+    look at the cells still NaN in their ping-pong target (k_blk_dilate_row, 4 / 2 / 1 cells per thread by the parity
+    of nx) against the plain sweeps (ODR_PLAIN_DILATE): the same samples bit for bit, on fields with NaN blobs wider
+    than ten cells (so that NaN survives), NaN on the block edges and NaN-free variables."""
+    ny, nz = 29, 5
+    rng = np.random.default_rng(nx)
+    x, y, z = np.linspace(3.0, 5.0, nx), np.linspace(59.0, 61.0, ny), -np.linspace(0, 40, nz)
+    Y, X = np.meshgrid(np.arange(ny), np.arange(nx), indexing='ij')
+    blob = ((X - 8) ** 2 + (Y - 9) ** 2 < 36) | ((X - nx + 3) ** 2 + (Y - 20) ** 2 < 150) | (rng.uniform(size=(ny, nx)) < 0.08)
+    blob[0, :5] = True
+    blob[-1, -4:] = True
+    fields = {}
+    for k, nm in enumerate((U, V, KZ)):
+        f = rng.normal(size=(nz, ny, nx)).astype(np.float32)
+        if nm != KZ:
+            f[:, blob] = np.nan
+            f[3:, (X + Y) % 7 == 0] = np.nan          # deeper layers: more NaN (fill towards the sea floor first)
+        fields[nm] = f
+    fields[DEPTH] = np.where(blob, np.nan, 100.0).astype(np.float32)
+    names = [U, V, KZ, DEPTH]
+    n = 40000
+    lon, lat, zz = rng.uniform(x[0], x[-1], n), rng.uniform(y[0], y[-1], n), -rng.uniform(0, 40, n)
+    P = ctx.particles(n)
+    P.append(lon, lat, z=zz)
+    res = []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv('ODR_PLAIN_DILATE', '1')
+        else:
+            monkeypatch.delenv('ODR_PLAIN_DILATE', raising=False)
+        sid = ctx.add_grid(x, y, z=z)
+        ctx.upload_block(sid, 0, 0.0, fields)
+        for nm in names:
+            ctx.bind(nm, [sid], np.nan)
+        res.append(P.env_sample(names, 0.0, download=True))
+    for nm in names:
+        assert _eq(res[0][nm], res[1][nm]), nm
+    assert np.isnan(res[0][U]).any() and np.isfinite(res[0][U]).sum() > n // 2
