@@ -40,7 +40,7 @@ for line in raw.splitlines():
                 vals[(k, m.group(2))] = float(m.group(4))
                 break
 calib = vals.get(('sort_hist', 'FETCH_SIZE'), float('nan')) * 1024 / (16.0 * N)
-# second calibration: k_gather_perm reads the permutation (4 B) and every byte it writes exactly once
+# k_gather_perm reads the permutation (4 B) and every byte it writes exactly once -- in permuted order: over-fetch, not a calibration
 calib_g = vals.get(('gather', 'FETCH_SIZE'), float('nan')) / (vals.get(('gather', 'WRITE_SIZE'), float('nan')) + 4.0 * N / 1024)
 hdr = '''PMC counters of the C3 bench (per dispatch, summed over dimensions; avg over the dispatches of that kernel), MI355X,
 10 M particles:  rocprofv3 --kernel-trace --pmc <set> -- python bench.py --workload c3 --steps 6 --warmup 2 --no-cpu --no-extras
@@ -50,7 +50,8 @@ SQ_ACTIVE_INST_MISC SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_IFETCH}.
 FETCH_SIZE / WRITE_SIZE are in KiB per dispatch; the SQ cycle counters are in quad-cycles summed over waves.
 FETCH_SIZE calibration in this code's access pattern: k_sort_hist streams lon and lat (16 B per particle, 8-byte lanes) =
 160 MB; FETCH_SIZE x 1024 / 160 MB = %.3f  (1.0 = exact, 0.5 = the guide's halved count; its histogram atomics add a little).
-k_gather_perm reads the permutation (4 B per particle) plus every byte it writes, once: FETCH_SIZE / (WRITE_SIZE + 4 B x N) = %.3f.
+k_gather_perm reads the permutation (4 B per particle) plus every byte it writes, once, but in permuted order: raw FETCH_SIZE /
+(WRITE_SIZE + 4 B x N) = %.3f -- whole lines fetched for 4- and 8-byte elements (the first sort starts from random order).
 WRITE_SIZE calibration: k_step_grid<RK4> stores 68 B per particle (= 680 MB); WRITE_SIZE x 1024 / 680 MB = %.3f.
 ''' % (calib, calib_g, vals.get(('step_rk4', 'WRITE_SIZE'), float('nan')) * 1024 / (68.0 * N))
 open(os.path.join(dst, '%s_c3_pmc.txt' % R), 'w').write(hdr + raw)
@@ -58,7 +59,7 @@ fs = vals[('step_rk4', 'FETCH_SIZE')] * 1024
 out = {
     'kernel': 'k_step_grid<2,0,true> (RK4, lon/lat, 3D)', 'workload': 'c3', 'particles': N,
     'FETCH_SIZE_bytes_raw': fs, 'FETCH_SIZE_bytes_x2': 2 * fs,
-    'FETCH_SIZE_calibration_8B_stream': calib, 'FETCH_SIZE_calibration_gather': calib_g,
+    'FETCH_SIZE_calibration_8B_stream': calib, 'gather_perm_fetch_over_useful_raw': calib_g,
     'WRITE_SIZE_bytes': vals[('step_rk4', 'WRITE_SIZE')] * 1024,
     'SQ_WAVES': vals[('step_rk4', 'SQ_WAVES')], 'SQ_INSTS_VALU': vals[('step_rk4', 'SQ_INSTS_VALU')],
     'SQ_INSTS_SALU': vals[('step_rk4', 'SQ_INSTS_SALU')], 'SQ_INSTS_VMEM_RD': vals.get(('step_rk4', 'SQ_INSTS_VMEM_RD')),
