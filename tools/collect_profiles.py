@@ -52,8 +52,9 @@ FETCH_SIZE calibration in this code's access pattern: k_sort_hist streams lon an
 160 MB; FETCH_SIZE x 1024 / 160 MB = %.3f  (1.0 = exact, 0.5 = the guide's halved count; its histogram atomics add a little).
 k_gather_perm reads the permutation (4 B per particle) plus every byte it writes, once, but in permuted order: raw FETCH_SIZE /
 (WRITE_SIZE + 4 B x N) = %.3f -- whole lines fetched for 4- and 8-byte elements (the first sort starts from random order).
-WRITE_SIZE calibration: k_step_grid<RK4> stores 68 B per particle (= 680 MB); WRITE_SIZE x 1024 / 680 MB = %.3f.
-''' % (calib, calib_g, vals.get(('step_rk4', 'WRITE_SIZE'), float('nan')) * 1024 / (68.0 * N))
+WRITE_SIZE calibration: k_step_grid<RK4> stores 72 B per particle (5 float32 environment values, sample position, previous
+position, lon, lat, age = 720 MB; z only where the sea floor lifts an element); WRITE_SIZE x 1024 / 720 MB = %.3f.
+''' % (calib, calib_g, vals.get(('step_rk4', 'WRITE_SIZE'), float('nan')) * 1024 / (72.0 * N))
 open(os.path.join(dst, '%s_c3_pmc.txt' % R), 'w').write(hdr + raw)
 fs = vals[('step_rk4', 'FETCH_SIZE')] * 1024
 out = {
