@@ -723,7 +723,17 @@ __device__ __forceinline__ T ld_off(const float *__restrict__ base, unsigned byt
   for (unsigned k = 0; k < sizeof(T) / 4; ++k) f[k] = (float)(byte_off & 1023u) * 1e-4f + (float)k;
   return t;
 #else
+#ifdef ODR_FLAT_GATHERS
   return *(const T *)((const char *)base + byte_off);
+#else
+  // buffer addressing: descriptor of the wave-uniform base in scalar registers + the 32-bit offset as it is -- no
+  // 64-bit address arithmetic per gather (the flat form costs one v_lshl_add_u64 per load: 503 in k_step_grid<RK4>)
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8 || sizeof(T) == 16, "gather width");
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0xffffffff, 0x00020000);
+  if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+  else if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
+  else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+#endif
 #endif
 }
 
