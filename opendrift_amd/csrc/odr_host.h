@@ -194,7 +194,7 @@ static inline bool build_vmix_desc(const odr_ctx *c, double t, VMixDesc &D) {
   const DevBlock &g0 = s.slot[s.level_slot[0]];
   for (int k = 0; k < s.nlevels; ++k) {
     const DevBlock &bk = s.slot[s.level_slot[k]];
-    if (!bk.data[VAR_KZ] || bk.es[VAR_KZ] != 1 || bk.var_nz[VAR_KZ] != nzp || bk.rec != g0.rec || bk.ny != g0.ny || bk.nx != g0.nx ||
+    if (!bk.small || !bk.data[VAR_KZ] || bk.es[VAR_KZ] != 1 || bk.var_nz[VAR_KZ] != nzp || bk.rec != g0.rec || bk.ny != g0.ny || bk.nx != g0.nx ||
         bk.x0 != g0.x0 || bk.xspan != g0.xspan || bk.y0 != g0.y0 || bk.yspan != g0.yspan)
       return false;
   }

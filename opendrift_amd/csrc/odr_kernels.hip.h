@@ -271,9 +271,11 @@ __device__ __forceinline__ void vmix_col_fill(const DevSource &s, const VMixDesc
   const Axis ay = axis_fp(yi, ny), ax = axis_fp(xi, nx);
   const double ty = ay.t, tx = ax.t, wy0 = 1 - ty, wx0 = 1 - tx, wgt = D.wgt;
   // uncovered particles gather node (0,0) and discard it: keeps the loads unconditional
-  const size_t rec = (size_t)bb.rec;
-  const size_t o00 = cov ? ((size_t)ay.i0 * nx + ax.i0) * rec : 0, o01 = cov ? ((size_t)ay.i0 * nx + ax.i1) * rec : 0;
-  const size_t o10 = cov ? ((size_t)ay.i1 * nx + ax.i0) * rec : 0, o11 = cov ? ((size_t)ay.i1 * nx + ax.i1) * rec : 0;
+  // byte offsets of the four node records (blocks of the fast path are `small`: < 2^24 nodes, < 4 GiB; 24-bit multiplies)
+  const unsigned recb = (unsigned)bb.rec * 4u;
+  const unsigned r0 = __umul24((unsigned)ay.i0, (unsigned)nx), r1 = __umul24((unsigned)ay.i1, (unsigned)nx);
+  const unsigned o00 = cov ? __umul24(r0 + (unsigned)ax.i0, recb) : 0u, o01 = cov ? __umul24(r0 + (unsigned)ax.i1, recb) : 0u;
+  const unsigned o10 = cov ? __umul24(r1 + (unsigned)ax.i0, recb) : 0u, o11 = cov ? __umul24(r1 + (unsigned)ax.i1, recb) : 0u;
   const float *kb = D.kb, *ka = TL ? D.ka : D.kb;
   // horizontal weights multiplied out once for the whole column (float64; the layer value is rounded to float32 like
   // the ReaderBlock's: same bits as (v*wy)*wx summed, but for a float64 round-off that reaches the float32 rounding
@@ -281,16 +283,16 @@ __device__ __forceinline__ void vmix_col_fill(const DevSource &s, const VMixDesc
   const double w00 = wy0 * wx0, w01 = wy0 * tx, w10 = ty * wx0, w11 = ty * tx;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const F4 b00 = *(const F4 *)(kb + o00 + 4 * q), b01 = *(const F4 *)(kb + o01 + 4 * q);
-    const F4 b10 = *(const F4 *)(kb + o10 + 4 * q), b11 = *(const F4 *)(kb + o11 + 4 * q);
+    const F4 b00 = ld_off<F4>(kb, o00 + 16u * q), b01 = ld_off<F4>(kb, o01 + 16u * q);
+    const F4 b10 = ld_off<F4>(kb, o10 + 16u * q), b11 = ld_off<F4>(kb, o11 + 16u * q);
     double v[4];
     v[0] = (double)bilw(b00.x, b01.x, b10.x, b11.x, w00, w01, w10, w11);
     v[1] = (double)bilw(b00.y, b01.y, b10.y, b11.y, w00, w01, w10, w11);
     v[2] = (double)bilw(b00.z, b01.z, b10.z, b11.z, w00, w01, w10, w11);
     v[3] = (double)bilw(b00.w, b01.w, b10.w, b11.w, w00, w01, w10, w11);
     if (TL) {
-      const F4 a00 = *(const F4 *)(ka + o00 + 4 * q), a01 = *(const F4 *)(ka + o01 + 4 * q);
-      const F4 a10 = *(const F4 *)(ka + o10 + 4 * q), a11 = *(const F4 *)(ka + o11 + 4 * q);
+      const F4 a00 = ld_off<F4>(ka, o00 + 16u * q), a01 = ld_off<F4>(ka, o01 + 16u * q);
+      const F4 a10 = ld_off<F4>(ka, o10 + 16u * q), a11 = ld_off<F4>(ka, o11 + 16u * q);
       double w[4];
       w[0] = (double)bilw(a00.x, a01.x, a10.x, a11.x, w00, w01, w10, w11);
       w[1] = (double)bilw(a00.y, a01.y, a10.y, a11.y, w00, w01, w10, w11);
