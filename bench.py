@@ -452,20 +452,21 @@ def main():
         P.sort_by_cell(wl.sid)      # the layout right after a re-sort, as in 1 of every 16 steps (the kernels drift apart by < 3 % in between)
     if not kfused:
         P.env_sample([U, V], wl.time_of(0))
-    wl.dominant_kernel(P, 0)
-    ctx.sync()
-    ctx.timer_begin()
-    for k in range(reps):
-        wl.dominant_kernel(P, k)
-    k_ms = ctx.timer_end() / reps
+    # every launch between its own pair of events (one pair around all 20 launches also times the host whenever it
+    # falls behind the device: seen as 2.5 instead of 0.84 ms at --steps 200 while rocprofv3 reported 0.84 ms)
+    def launch_ms(fn):
+        fn(P, 0)
+        ctx.sync()
+        out = []
+        for k in range(reps):
+            ctx.timer_begin()
+            fn(P, k)
+            out.append(ctx.timer_end())
+        return float(np.mean(out)), float(np.median(out))
+    k_ms, k_ms_median = launch_ms(wl.dominant_kernel)
     k2_ms = None
     if a.workload == 'c3':
-        wl.second_kernel(P, 0)
-        ctx.sync()
-        ctx.timer_begin()
-        for k in range(reps):
-            wl.second_kernel(P, k)
-        k2_ms = ctx.timer_end() / reps
+        k2_ms, _ = launch_ms(wl.second_kernel)
     nact = len(P)
     kbytes = BYTES[a.workload]['fused' if kfused else 'advect']
     ach = kbytes * nact / (k_ms * 1e-3)
@@ -516,7 +517,7 @@ def main():
                          'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': traffic, 'traffic_unit': 'GB per launch (PMC)',
                          'traffic_source': None if pmc is None else pmc_file,
                          'algorithmic_gb_per_launch': kbytes * nact / 1e9,
-                         'kernel_ms': k_ms, 'algorithmic_bytes_per_particle': kbytes,
+                         'kernel_ms': k_ms, 'kernel_ms_median': k_ms_median, 'algorithmic_bytes_per_particle': kbytes,
                          'note': 'algorithmic bytes count cache-served corners: not a physical bandwidth (see roofline_hbm_counters, roofline_issue)',
                          'step_bytes_per_particle': BYTES[a.workload]['step'],
                          'step_frac': BYTES[a.workload]['step'] * (units / el_max) / world / HBM_PEAK},

@@ -46,6 +46,7 @@ struct odr_ctx {
   hipEvent_t up_done, up_dep;
   float *prep[2];
   size_t prep_floats;
+  int *dilate_flags;   // [NVAR][16]: "sweep k gave a cell a value" (k_blk_dilate_row stops at the fixed point)
   Staged staged[MAXSRC][MAXLEVELS];
   std::vector<Retired> graveyard;
   std::vector<void *> source_bufs;  // device arrays owned by sources (curvilinear node tables)

@@ -2074,8 +2074,13 @@ __global__ __launch_bounds__(BLOCK) void k_blk_dilate(const float *__restrict__ 
 // that is finite there never changes again, so only the cells that are NaN in `dst` are looked at (their value: the
 // source cell if it has become finite, its dilation otherwise) and a vector is written only when a cell actually got a
 // value.  For a field with few NaN cells a sweep is one read of the target (no neighbour reads, no writes).
+// `changed[0]` (written by the previous sweep when it gave any cell a value) = 0: the field has reached its fixed point,
+// both ping-pong buffers hold it, this and every later sweep is a no-op.  `changed[1]` is this sweep's own flag.
 template <int W, bool FIRST>
-__global__ __launch_bounds__(BLOCK) void k_blk_dilate_row(const float *__restrict__ src, float *__restrict__ dst, int ny, int nx) {
+__global__ __launch_bounds__(BLOCK) void k_blk_dilate_row(const float *__restrict__ src, float *__restrict__ dst, int ny, int nx,
+                                                          int *__restrict__ changed) {
+  if (!FIRST && changed[0] == 0) return;
+  bool any = false;
   const unsigned row = blockIdx.x;                 // layer * ny + y
   const int y = (int)(row % (unsigned)ny);
   const size_t r0 = (size_t)row * (size_t)nx;
@@ -2118,7 +2123,13 @@ __global__ __launch_bounds__(BLOCK) void k_blk_dilate_row(const float *__restric
       wr |= isfinite(v);
     }
     if (wr) *(Vec *)(dst + r0 + x0) = o;
+    any |= FIRST ? false : wr;
+    if (FIRST) {
+#pragma unroll
+      for (int q = 0; q < W; ++q) any |= !isfinite(c.v[q]) && isfinite(o.v[q]);
+    }
   }
+  if (any) changed[1] = 1;
 }
 
 // ------------------------------------------------------------------ output history

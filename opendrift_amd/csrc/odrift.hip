@@ -35,6 +35,7 @@ int odr_ctx_create(int device, uint64_t seed, odr_ctx **out) {
   HIPCHK(hipMalloc((void **)&c->dw, sizeof(DevWorld)));
   HIPCHK(hipMalloc((void **)&c->red, sizeof(double) * R_N));
   HIPCHK(hipMalloc((void **)&c->counter, sizeof(unsigned long long) * 4));
+  HIPCHK(hipMalloc((void **)&c->dilate_flags, sizeof(int) * 16 * NVAR));
   HIPCHK(hipEventCreate(&c->ev0));
   HIPCHK(hipEventCreate(&c->ev1));
   HIPCHK(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
@@ -72,6 +73,7 @@ int odr_ctx_destroy(odr_ctx *c) {
   if (c->oil_guide) (void)hipFree(c->oil_guide);
   if (c->noise_buf) (void)hipFree(c->noise_buf);
   (void)hipFree(c->counter);
+  (void)hipFree(c->dilate_flags);
   if (c->lanes_ready) {
     for (int l = 0; l < ODR_MAX_LANES; ++l) {
       (void)hipStreamDestroy(c->lane_stream[l]);
@@ -601,11 +603,14 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
       float *a = buf, *bb2 = tmp;
       const unsigned rows = (unsigned)nzv * (unsigned)ny;
       const bool by_row = !getenv("ODR_PLAIN_DILATE") && (size_t)nzv * (size_t)ny < (1ull << 31);
+      // flags[it + 1] = sweep `it` gave some cell a value; a sweep that sees 0 from its predecessor returns at once
+      int *flags = c->dilate_flags + 16 * k;
+      if (by_row) HIPCHK(hipMemsetAsync(flags, 0, 16 * sizeof(int), st));
       for (int it = 0; it < 10; ++it) {
 #define DILATE_ROW(W)                                                                                                   \
   do {                                                                                                                  \
-    if (it == 0) hipLaunchKernelGGL((k_blk_dilate_row<W, true>), dim3(rows), dim3(BLOCK), 0, st, a, bb2, ny, nx);        \
-    else hipLaunchKernelGGL((k_blk_dilate_row<W, false>), dim3(rows), dim3(BLOCK), 0, st, a, bb2, ny, nx);               \
+    if (it == 0) hipLaunchKernelGGL((k_blk_dilate_row<W, true>), dim3(rows), dim3(BLOCK), 0, st, a, bb2, ny, nx, flags); \
+    else hipLaunchKernelGGL((k_blk_dilate_row<W, false>), dim3(rows), dim3(BLOCK), 0, st, a, bb2, ny, nx, flags + it);    \
   } while (0)
         if (!by_row) hipLaunchKernelGGL(k_blk_dilate, dim3(g), dim3(BLOCK), 0, st, a, bb2, nzv, ny, nx);
         else if (nx % 4 == 0) DILATE_ROW(4);

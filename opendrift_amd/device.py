@@ -292,7 +292,25 @@ class Particles:
         n = lon.size
         a = [_d(lon, n), _d(lat, n), _d(z, n), _i(id, n), _i(moving, n), _f(wind_drift_factor, n),
              _f(current_drift_factor, n), _f(terminal_velocity, n)]
+        if id is None:                       # the device numbers them (active + deactivated so far) + 0 .. n-1
+            act, dead = self.count()
+            ids = act + dead + np.arange(n, dtype=np.int64)
+        else:
+            ids = np.atleast_1d(np.asarray(id, dtype=np.int64))
         check(self.lib.odr_particles_append(self.ctx.h, self.h, n, *[p for _, p in a]))
+        # release sequence of every ID: the reference keeps its arrays in release order (move_elements appends the
+        # scheduled elements as they are released, elements.py:197-228), which differs from ID order when the seed times
+        # are not monotonic in ID; host-drawn random numbers (rng='numpy') arrive in that order (_host_order)
+        seq = getattr(self, '_release_seq', None)
+        top = int(ids.max()) + 1 if n else 0
+        if seq is None or seq.size < top:
+            new = np.full(max(top, 2 * (seq.size if seq is not None else 0), 1024), -1, np.int64)
+            if seq is not None:
+                new[:seq.size] = seq
+            seq = self._release_seq = new
+        k0 = getattr(self, '_release_count', 0)
+        seq[ids] = k0 + np.arange(n)
+        self._release_count = k0 + n
 
     def upload(self, lon=None, lat=None, z=None, moving=None, wind_drift_factor=None,
                current_drift_factor=None, terminal_velocity=None):
@@ -444,17 +462,24 @@ class Particles:
         check(self.lib.odr_particles_download(self.ctx.h, self.h, None, None, None, out.ctypes.data_as(_ip), None, None))
         return out
 
+    def _ref_key(self, ids):
+        """Sort key that puts elements in the reference's array order: the release sequence (ID where unknown)."""
+        seq = getattr(self, '_release_seq', None)
+        if seq is not None and ids.size and ids.max() < seq.size and (seq[ids] >= 0).all():
+            return seq[ids]
+        return ids
+
     def _host_order(self, arr):
         """Host-drawn random numbers (RNG_HOST parity mode) arrive in the reference's element order,
-        i.e. ascending ID of the active elements; in-place compaction and spatial sorting permute the
+        i.e. release order of the active elements (= ascending ID unless the seed times are not monotonic in ID); in-place compaction and spatial sorting permute the
         device arrays, so the numbers are gathered into device order first."""
         n = len(self)
         a = np.asarray(arr)[..., :n]
         if not getattr(self, '_permuted', False):
             return a
-        ids = self.ids()
+        key = self._ref_key(self.ids())
         rank = np.empty(n, np.int64)
-        rank[np.argsort(ids, kind='stable')] = np.arange(n)
+        rank[np.argsort(key, kind='stable')] = np.arange(n)
         return np.ascontiguousarray(a[..., rank])
 
     def leeway_capsize(self, dt, wind_threshold=30.0, wind_threshold_sigma=5.0, step=0, uniforms=None):
@@ -464,7 +489,7 @@ class Particles:
             n = len(self)
             cap = self.get_property(8)
             can = np.nonzero(cap == (0.0 if dt >= 0 else 1.0))[0]
-            order = can[np.argsort(self.ids()[can], kind='stable')]      # reference order of those elements
+            order = can[np.argsort(self._ref_key(self.ids()[can]), kind='stable')]      # reference order of those elements
             full = np.zeros(n)
             full[order] = np.asarray(uniforms, dtype=np.float64)[:len(order)]
             a, pa = _d(full, n)

@@ -278,8 +278,29 @@ class OpenDriftSimulation(Configurable):
                 raise ValueError('radius_type must be gaussian or uniform')
             lon, lat = self._geod_fwd(lon, lat, az, dist)
         z = kwargs.pop('z', None)
+        if z is None and 'seed:seafloor' in self._config and self.get_config('seed:seafloor') is True:
+            z = 'seafloor'                     # "Seafloor is selected, neglecting z" (:1169-1173)
         if z is None:
             z = self.get_config('seed:z') if 'seed:z' in self._config else 0.0
+        zoff = np.nan                          # finite: metres above the sea floor, depth looked up when the run starts
+        if isinstance(z, str):                 # 'seafloor' / 'seafloor+M' (:1174-1210)
+            if z[0:8] != 'seafloor':
+                raise ValueError('z must be a number, "seafloor" or "seafloor+<metres>": ' + z)
+            above = float(z[9:]) if len(z) > 8 and z[8] == '+' else 0.0
+            cfg = lambda k: self.get_config(k) if k in self._config else None
+            depth_c = cfg('environment:constant:sea_floor_depth_below_sea_level')
+            depth_f = cfg('environment:fallback:sea_floor_depth_below_sea_level')
+            if depth_c is not None:
+                z = -np.float32(depth_c) + above
+            elif 'sea_floor_depth_below_sea_level' in self.priority_list:
+                # the reference samples its readers here; the readers of this model live on the device once the run is
+                # set up, so the lookup (same sampling kernels, at the seeded positions) happens at the start of run()
+                z, zoff = np.nan, above
+            elif depth_f is not None:
+                z = -np.float32(depth_f) + above
+            else:
+                raise ValueError('A reader providing the variable sea_floor_depth_below_sea_level must be '
+                                 'added before seeding elements at seafloor.')
         props = {}
         for prop in self.element_properties:
             val = kwargs.pop(prop, None)
@@ -289,6 +310,7 @@ class OpenDriftSimulation(Configurable):
         # LagrangianArray stores lon/lat/z as float32 at seeding (elements.py:71-88,156-158)
         new = dict(lon=np.float32(lon).astype(np.float64), lat=np.float32(lat).astype(np.float64),
                    z=(np.float32(z) * np.ones(number, np.float32)).astype(np.float64),
+                   z_above_seafloor=np.full(number, zoff),
                    time=np.full(number, time[0], dtype=object) if single_time else np.array(time, dtype=object),
                    t_epoch=(np.full(number, _epoch(time[0])) if single_time else
                             np.array(time, dtype='datetime64[us]').astype(np.int64) / 1e6), **props)   # vectorised schedule
@@ -360,6 +382,25 @@ class OpenDriftSimulation(Configurable):
     @property
     def environment(self):
         return SimpleNamespace(**{v: self.P.env_download(v) for v in self._sampled})
+
+    def _resolve_seafloor_seeds(self, lo_id, hi_id):
+        """seed_elements(z='seafloor[+M]') with the depth from a reader (:1185-1210): sea_floor_depth_below_sea_level sampled
+        at the seeded positions by the device's own sampling path, z = -float32(depth) + M, stored as float32."""
+        s = self._sched
+        off = s.get('z_above_seafloor')
+        if off is None:
+            return
+        idx = np.nonzero(np.isfinite(off[lo_id:hi_id]) & np.isnan(s['z'][lo_id:hi_id]))[0] + lo_id
+        if idx.size == 0:
+            return
+        Q = self.ctx.particles(idx.size)
+        try:
+            Q.append(s['lon'][idx], s['lat'][idx], z=np.zeros(idx.size))
+            depth = Q.env_sample(['sea_floor_depth_below_sea_level'], _epoch(self.start_time), download=True)[
+                'sea_floor_depth_below_sea_level']
+        finally:
+            Q.close()
+        s['z'][idx] = np.float32(-depth.astype(np.float32) + off[idx]).astype(np.float64)
 
     # ------------------------------------------------------------------ loop pieces
     def release_elements(self):   # :909-934
@@ -750,6 +791,7 @@ class OpenDriftSimulation(Configurable):
             rel[hi_id:] = True
             self._all_at_start = False if n_total == 0 else self._all_at_start
         self._shard = (lo_id, hi_id)
+        self._resolve_seafloor_seeds(lo_id, hi_id)
         self.P = self.ctx.particles(max(1, hi_id - lo_id))
         self.mode = 'Run'
         self.prepare_run()
@@ -776,7 +818,11 @@ class OpenDriftSimulation(Configurable):
                       self.get_config('general:seafloor_action', 'lift_to_seafloor') in ('lift_to_seafloor', 'none') and
                       not self.get_config('general:coastline_approximation_precision') and
                       'x_sea_water_velocity' in self.required_variables and 'y_sea_water_velocity' in self.required_variables and
-                      not self._host_bindings())
+                      not self._host_bindings() and
+                      # report_missing_variables comes BEFORE deactivate_outside in the loop (:2251-2253) but sits inside the
+                      # launch: an element both outside the domain and without data must end as 'missing_data'
+                      not (any(self.get_config('drift:deactivate_%s_of' % k) is not None for k in ('west', 'east', 'south', 'north'))
+                           and self._can_be_missing(list(self.required_variables))))
         if self._host_bindings() and self.get_config('drift:advection_scheme') != 'euler' and any(
                 'x_sea_water_velocity' in b.variables for _, b in self._host_bindings()):
             raise NotImplementedError('Runge-Kutta stages sample the current inside the kernel: a host-evaluated '
@@ -1064,6 +1110,8 @@ class OceanDrift(OpenDriftSimulation):
                                         'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
             'seed:z': {'type': 'float', 'default': 0, 'min': -10000, 'max': 0, 'level': CONFIG_LEVEL_ESSENTIAL,
                        'description': ''},
+            'seed:seafloor': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_ESSENTIAL,
+                              'description': 'Elements are seeded at seafloor, and seeding depth (z) is neglected.'},
         })
         self._set_config_default('drift:max_speed', 2)
 

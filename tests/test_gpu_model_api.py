@@ -615,3 +615,38 @@ def test_blocks_are_cut_to_the_simulation_extent():
     # its last bit now and then (as in the reference, whose blocks are cut the same way)
     assert np.abs(res[0][0] - res[1][0]).max() < 1e-7 and np.abs(res[0][1] - res[1][1]).max() < 1e-7
     assert np.abs(res[0][2] - res[1][2]).max() < 1e-5
+
+
+def test_seed_at_and_above_the_seafloor():
+    """seed_elements(z='seafloor' / 'seafloor+M') (basemodel/__init__.py:1168-1210, tests/models/test_run.py:618-661):
+    the depth comes from the reader at the seeded positions (here: the oracle's get_environment on the same block),
+    z = -float32(depth) + M; from the config constant when there is one; ValueError without any source."""
+    import oracle.oracle as orc
+    from scenarios import Scenario
+    g = golden('c3_grid3d_rk4_vmix.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'sea_floor_depth_below_sea_level', 'land_binary_mask']
+    lon, lat = g['lon'][0][:40], g['lat'][0][:40]
+    DEP = 'sea_floor_depth_below_sea_level'
+    sc = Scenario([('grid', dict(x=g['g_x'], y=g['g_y'], z=g['g_z'],
+                                 levels=[(float(t), {DEP: g['g_' + DEP][k]}) for k, t in enumerate(g['g_t'])]))],
+                  fallbacks={DEP: 10000.0}, priority={DEP: [0]})
+    depth = orc.get_environment(sc.oracle_world(), [orc.VAR[DEP]], lon.astype(np.float32).astype(np.float64),
+                                lat.astype(np.float32).astype(np.float64), np.zeros(40), float(g['g_t'][0]))[0]
+    for zspec, above in (('seafloor', 0.0), ('seafloor+7.5', 7.5)):
+        o = OceanDrift(loglevel=50, seed=0)
+        o.add_reader(_grid_reader(g, names, z=g['g_z']))
+        o.seed_elements(lon=lon, lat=lat, z=zspec, time=T0)
+        o.run(time_step=600, steps=1)
+        want = np.float32(-depth.astype(np.float32) + above)
+        # (the model's block is the window around the elements: its own origin and span, a float32 sample may flip its last bit)
+        assert np.abs(o.result['z'][:, 0] - want).max() < 1e-4, (zspec, np.abs(o.result['z'][:, 0] - want).max())
+    o = OceanDrift(loglevel=50, seed=0)
+    o.set_config('environment:constant:sea_floor_depth_below_sea_level', 120.0)
+    o.add_reader(_grid_reader(g, names[:2] + names[3:], z=g['g_z']))
+    o.seed_elements(lon=lon, lat=lat, z='seafloor+20', time=T0)
+    o.run(time_step=600, steps=1)
+    assert np.all(o.result['z'][:, 0] == np.float32(-100.0))
+    o = OceanDrift(loglevel=50, seed=0)
+    o.set_config('environment:fallback:sea_floor_depth_below_sea_level', None)
+    with pytest.raises(ValueError, match='must be added before seeding elements at seafloor'):
+        o.seed_elements(lon=4.0, lat=60.0, z='seafloor', time=T0)

@@ -168,3 +168,23 @@ def test_c12_kelvin_reader_gives_celsius_environment_on_the_device():
     P2.append(np.full(4, 5.0), np.full(4, 60.0))
     got = P2.env_sample([T], 0.0, download=True)[T]
     assert (got == np.float32(np.float64(np.float32(283.15)) - 273.15)).all()
+
+
+def test_host_drawn_numbers_follow_the_release_order_not_the_id_order(ctx):
+    """rng='numpy' parity mode: np.random arrays arrive in the reference's element order, which is the RELEASE order
+    (move_elements appends what is released, elements.py:197-228) -- not ascending ID when seed times are not monotonic
+    in ID.  After a compaction has permuted the device arrays, Particles._host_order must hand element `ID` the number
+    at its release rank."""
+    P = ctx.particles(16)
+    P.append(np.full(3, 4.0), np.full(3, 60.0), id=np.array([5, 6, 7], np.int32))        # released first
+    P.append(np.full(5, 4.0), np.full(5, 60.0), id=np.array([0, 1, 2, 3, 4], np.int32))  # released later
+    mask = np.zeros(8, bool)
+    mask[1] = True                                  # device slot 1 = ID 6
+    P.deactivate(mask, 1)
+    P.compact()                                     # in-place compaction: the tail fills the hole -> permuted
+    ids = P.ids()
+    assert sorted(ids) == [0, 1, 2, 3, 4, 5, 7]
+    draws = np.arange(7, dtype=np.float64) * 10.0   # reference order of the survivors: 5, 7, 0, 1, 2, 3, 4
+    want = {5: 0.0, 7: 10.0, 0: 20.0, 1: 30.0, 2: 40.0, 3: 50.0, 4: 60.0}
+    got = P._host_order(draws)
+    assert [want[int(i)] for i in ids] == list(got)
