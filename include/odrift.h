@@ -54,7 +54,17 @@ enum {
   ODR_VAR_MIXED_LAYER_THICKNESS = 14,
   ODR_VAR_SEA_WATER_TEMPERATURE = 15, /* OpenOil.required_variables (models/openoil/openoil.py:271-278) */
   ODR_VAR_SEA_WATER_SALINITY = 16,
-  ODR_NVAR = 18
+  ODR_VAR_SEA_ICE_AREA_FRACTION = 17, /* OpenOil.advect_oil in ice (models/openoil/openoil.py:1179-1216) */
+  ODR_VAR_SEA_ICE_X_VELOCITY = 18,    /* a vector pair: rotated from the reader's projection (basereader/consts.py:27-36) */
+  ODR_VAR_SEA_ICE_Y_VELOCITY = 19,
+  /* the windsea_swell Stokes profile (models/physics_methods.py:418-456, 831-841) */
+  ODR_VAR_SWELL_WAVE_TO_DIRECTION = 20,
+  ODR_VAR_SWELL_WAVE_PEAK_PERIOD = 21,
+  ODR_VAR_SWELL_WAVE_SIGNIFICANT_HEIGHT = 22,
+  ODR_VAR_WIND_WAVE_TO_DIRECTION = 23,
+  ODR_VAR_WIND_WAVE_MEAN_PERIOD = 24,
+  ODR_VAR_WIND_WAVE_SIGNIFICANT_HEIGHT = 25,
+  ODR_NVAR = 26
 };
 
 /* ---- projections of a reader (pyproj.Proj(reader.proj4), basereader/__init__.py:119-137) ---- */
@@ -242,6 +252,17 @@ int odr_env_coast_advect(odr_ctx *ctx, odr_particles *p, int nvars, const int32_
 /* update_positions with caller-supplied velocities (models that compute them on the host) */
 int odr_update_positions(odr_ctx *ctx, odr_particles *p, const double *x_vel, const double *y_vel,
                          int velocities_are_float32, double dt);
+
+/* Per-element factors of the movers that follow, as OpenOil.advect_oil derives them from the float32
+ * sea_ice_area_fraction A of the sampled environment (models/openoil/openoil.py:1182-1216): ICE_CURRENT = 1 - k_ice with
+ * k_ice = clip((A - 0.3) / 0.5, 0, 1) for odr_advect and odr_advect_wind, ICE_STOKES = (0.7 - A) / 0.7 (0 above 0.7) for
+ * odr_stokes_drift, ICE_DRIFT = k_ice for odr_advect_sea_ice.  With a kind other than SCALAR the scalar `factor`
+ * argument of those calls is not used.  Stays in force until set again. */
+enum { ODR_FACTOR_SCALAR = 0, ODR_FACTOR_ICE_CURRENT = 1, ODR_FACTOR_ICE_STOKES = 2, ODR_FACTOR_ICE_DRIFT = 3 };
+int odr_set_element_factor(odr_ctx *ctx, odr_particles *p, int kind);
+/* advect_with_sea_ice (models/physics_methods.py:693-710): update_positions(factor * sea_ice_x/y_velocity) with the
+ * sampled ice velocity; without it the rule of thumb current + 1.5 % of the wind; nothing when neither is there. */
+int odr_advect_sea_ice(odr_ctx *ctx, odr_particles *p, double dt, double factor);
 /* advect_wind (physics_methods.py:712-791) */
 int odr_advect_wind(odr_ctx *ctx, odr_particles *p, double dt, double wind_drift_depth,
                     int relative_wind, double factor);

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ODR_LIB') or os.path.join(HERE, 'libodrift_hip.so')   # ODR_LIB: A/B builds (tools/ab_bench.sh)
 
-NVAR = 18
+NVAR = 26
 VARIABLES = {
     'x_sea_water_velocity': 0, 'y_sea_water_velocity': 1, 'x_wind': 2, 'y_wind': 3,
     'upward_sea_water_velocity': 4, 'ocean_vertical_diffusivity': 5,
@@ -19,6 +19,12 @@ VARIABLES = {
     'sea_surface_wave_period_at_variance_spectral_density_maximum': 13,
     'ocean_mixed_layer_thickness': 14,
     'sea_water_temperature': 15, 'sea_water_salinity': 16,     # OpenOil.required_variables (openoil.py:271-278)
+    'sea_ice_area_fraction': 17, 'sea_ice_x_velocity': 18, 'sea_ice_y_velocity': 19,      # advect_oil in ice (openoil.py:1179-1216)
+    # the windsea_swell Stokes profile (physics_methods.py:418-456)
+    'sea_surface_swell_wave_to_direction': 20,
+    'sea_surface_swell_wave_peak_period_from_variance_spectral_density': 21,
+    'sea_surface_swell_wave_significant_height': 22, 'sea_surface_wind_wave_to_direction': 23,
+    'sea_surface_wind_wave_mean_period': 24, 'sea_surface_wind_wave_significant_height': 25,
 }
 VARIABLE_NAMES = {v: k for k, v in VARIABLES.items()}
 PROJ_LATLONG, PROJ_STERE_EQUIT_SPHERE, PROJ_STERE_POLAR = 0, 1, 2
@@ -93,6 +99,8 @@ _SIGNATURES = {
     'odr_env_coast_advect': [_vp, _vp, C.c_int, _ip, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_double, C.c_double, _vp, _P(C.c_int64)],
     'odr_update_positions': [_vp, _vp, _dp, _dp, C.c_int, C.c_double],
+    'odr_set_element_factor': [_vp, _vp, C.c_int],
+    'odr_advect_sea_ice': [_vp, _vp, C.c_double, C.c_double],
     'odr_advect_wind': [_vp, _vp, C.c_double, C.c_double, C.c_int, C.c_double],
     'odr_stokes_drift': [_vp, _vp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double],
     'odr_particles_set_property': [_vp, _vp, C.c_int, C.c_int64, C.c_int64, _fp],

@@ -8,7 +8,7 @@
 
 namespace odr {
 
-constexpr int NVAR = 18;
+constexpr int NVAR = 26;
 constexpr int MAXLEVELS = 4;
 constexpr int MAXSRC = 8;
 constexpr int MAXNZ = 64;
@@ -16,7 +16,10 @@ constexpr int MAXLIST = 4;
 
 enum { VAR_U = 0, VAR_V = 1, VAR_XWIND = 2, VAR_YWIND = 3, VAR_W = 4, VAR_KZ = 5, VAR_SX = 6,
        VAR_SY = 7, VAR_LAND = 8, VAR_DEPTH = 9, VAR_SSH = 10, VAR_HDIFF = 11, VAR_HS = 12,
-       VAR_TP = 13, VAR_MLD = 14, VAR_TEMP = 15, VAR_SALT = 16 };
+       VAR_TP = 13, VAR_MLD = 14, VAR_TEMP = 15, VAR_SALT = 16,
+       // OpenOil.advect_oil in ice (openoil.py:1179-1216); the windsea_swell Stokes profile (physics_methods.py:418-456)
+       VAR_ICE_A = 17, VAR_ICE_U = 18, VAR_ICE_V = 19, VAR_SWELL_DIR = 20, VAR_SWELL_TP = 21, VAR_SWELL_HS = 22,
+       VAR_WW_DIR = 23, VAR_WW_TM = 24, VAR_WW_HS = 25 };
 enum { SRC_CONSTANT = 0, SRC_DOUBLE_GYRE = 1, SRC_OSCILLATING = 2, SRC_GRID = 3, SRC_LANDMASK = 4 };
 enum { PROJ_LATLONG = 0, PROJ_STERE_EQUIT_SPHERE = 1, PROJ_STERE_POLAR = 2, PROJ_CURVILINEAR = 3 };
 // x/y vector pairs are rotated from the reader's CRS to lon/lat (variables.py:799-837); for a reader without a
@@ -536,14 +539,14 @@ __device__ __forceinline__ bool source_sample(const DevSource &s, const int (&va
     bool need = false;
 #pragma unroll
     for (int v = 0; v < NV; ++v)
-      if (vars[v] == VAR_U || vars[v] == VAR_XWIND || vars[v] == VAR_SX) need = true;
+      if (vars[v] == VAR_U || vars[v] == VAR_XWIND || vars[v] == VAR_SX || vars[v] == VAR_ICE_U) need = true;
     if (need) {
       double sn, cs;
       rotation_cs(s.proj, x, y, cs, sn);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         int partner = vars[v] == VAR_U ? VAR_V : vars[v] == VAR_XWIND ? VAR_YWIND
-                                              : vars[v] == VAR_SX ? VAR_SY : -1;
+                                              : vars[v] == VAR_SX ? VAR_SY : vars[v] == VAR_ICE_U ? VAR_ICE_V : -1;
         if (partner < 0) continue;
 #pragma unroll
         for (int u = 0; u < NV; ++u) {

@@ -86,6 +86,7 @@ struct odr_ctx {
 struct odr_particles {
   long long cap, n, ndead, dead_cap;
   long long win;        // first element of the window that view() exposes (0 except inside step_in_lanes)
+  int ice_kind;         // odr_set_element_factor
   double *d64[7];       // lon lat z plon plat slon slat
   double *alt64[7];
   int *i32[3];          // id status moving
@@ -127,6 +128,7 @@ static inline PView view(const odr_particles *p) {
   v.wdf = p->f32[0] + w; v.cdf = p->f32[1] + w; v.tv = p->f32[2] + w; v.age = p->f32[3] + w;
   for (int k = 0; k < NVAR; ++k) v.env[k] = p->env[k] ? p->env[k] + w : nullptr;
   for (int k = 0; k < 9; ++k) v.aux[k] = p->aux[k] ? p->aux[k] + w : nullptr;
+  v.ice = p->ice_kind; v.pad = 0;
   return v;
 }
 

@@ -59,7 +59,28 @@ struct PView {  // device pointers of the active set
   float *wdf, *cdf, *tv, *age;
   float *aux[9];  // model-specific float32 element properties (Leeway: LeewayObj, leeway.py:50-131)
   float *env[NVAR];
+  int ice;        // odr_set_element_factor: 0 scalar factors; 1 (1 - k_ice), 2 factor_stokes, 3 k_ice per element
+  int pad;
 };
+
+// OpenOil.advect_oil in sea ice (openoil.py:1182-1201; Nordam et al. 2019, Arneborg 2017), float32 like NumPy on the
+// float32 environment array: k_ice = (A - 0.3) / (0.8 - 0.3), 0 below 30 %, 1 above 80 %;
+// factor_stokes = (0.7 - A) / 0.7, 0 above 70 %
+__device__ __forceinline__ float ice_k(float A) {
+  float k = __fdiv_rn(__fsub_rn(A, 0.3f), 0.5f);
+  if (A < 0.3f) k = 0.f;
+  if (A > 0.8f) k = 1.f;
+  return k;
+}
+__device__ __forceinline__ float ice_stokes_factor(float A) {
+  float f = __fdiv_rn(__fsub_rn(0.7f, A), 0.7f);
+  if (A > 0.7f) f = 0.f;
+  return f;
+}
+// factor of advect_ocean_current / advect_wind for element i: the caller's scalar, or 1 - k_ice (float32)
+__device__ __forceinline__ float current_factor(const PView &p, long long i, float factor) {
+  return p.ice == 1 ? __fsub_rn(1.0f, ice_k(p.env[VAR_ICE_A][i])) : factor;
+}
 
 // ------------------------------------------------------------ float32 rounding points
 // np.degrees(np.arctan2(x_vel, y_vel)) in float32 (physics_methods.py:629,
@@ -476,7 +497,7 @@ __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W
   const int uv[2] = {VAR_U, VAR_V};
   double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
   float u1 = p.env[VAR_U][i], v1 = p.env[VAR_V][i];
-  float f = __fmul_rn(factor, p.cdf[i]);  // factor*cdf, float32
+  float f = __fmul_rn(current_factor(p, i, factor), p.cdf[i]);  // factor*cdf, float32
   int moving = p.moving[i];
   float fu, fv;
   GeodStart o = geod_start(lat, lon);
@@ -562,7 +583,7 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_WAVES(PROJ)) void k_advect_grid(con
   const DevBlock &geo = s.slot[geo_slot];
   double lon = p.lon[i], lat = p.lat[i];
   advect_grid_body<SCHEME, PROJ, IS3D, NOISE>(s, geo, lon, lat, p.z[i], p.env[VAR_U][i], p.env[VAR_V][i],
-                                              __fmul_rn(factor, p.cdf[i]), p.moving[i], dt, th, tf, W->fallback[VAR_U],
+                                              __fmul_rn(current_factor(p, i, factor), p.cdf[i]), p.moving[i], dt, th, tf, W->fallback[VAR_U],
                                               W->fallback[VAR_V], N, i, p.n, NOISE ? p.id[i] : 0);
   p.lon[i] = lon;
   p.lat[i] = lat;
@@ -791,7 +812,7 @@ __global__ __launch_bounds__(BLOCK, (MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_
     if (!skip) {
       const DevSource &s = W->src[G.sid];
       advect_grid_body<SCHEME, PROJ, IS3D, NOISE, TILE>(s, s.slot[S.geo_slot_uv], lon, lat, zz, out[0], out[1],
-                                                        __fmul_rn(factor, p.cdf[i]), moving, dt, th, tf, W->fallback[VAR_U],
+                                                        __fmul_rn(current_factor(p, i, factor), p.cdf[i]), moving, dt, th, tf, W->fallback[VAR_U],
                                                         W->fallback[VAR_V], N, i, p.n, id, T, tile_h, tile_f);
     }
     if (MIXQ > 0) {   // vertical_mixing + vertical_advection (oceandrift.py:397-571, :315-350) after the horizontal move
@@ -854,7 +875,7 @@ __global__ __launch_bounds__(BLOCK) void k_advect_gyre(const DevWorld *__restric
   double lon = p.lon[i], lat = p.lat[i];
   const double z = p.z[i];
   const float u1 = p.env[VAR_U][i], v1 = p.env[VAR_V][i];
-  const float f = __fmul_rn(factor, p.cdf[i]);
+  const float f = __fmul_rn(current_factor(p, i, factor), p.cdf[i]);
   float fu, fv;
   GeodStart o = geod_start(lat, lon);
   if (SCHEME == 0) {
@@ -1021,6 +1042,7 @@ __global__ __launch_bounds__(BLOCK) void k_advect_wind(PView p, double dt, doubl
     xw = __fsub_rn(xw, p.env[VAR_U][i]);
     yw = __fsub_rn(yw, p.env[VAR_V][i]);
   }
+  if (p.ice == 1) factor = (double)__fsub_rn(1.0f, ice_k(p.env[VAR_ICE_A][i]));   // x_wind*wdf*factor: float64 * float32 array
   double xu = __dmul_rn(__dmul_rn((double)xw, wdf), factor);
   double xv = __dmul_rn(__dmul_rn((double)yw, wdf), factor);
   move_f64(lon, lat, xu, xv, p.moving[i], dt);
@@ -1082,9 +1104,28 @@ __global__ __launch_bounds__(BLOCK) void k_stokes(PView p, double dt, int profil
     unit = __dsub_rn(exp(__dmul_rn(k2, z)),
                      __dmul_rn(sqrt(__dmul_rn(c2, az)), erfc(sqrt(__dmul_rn(k2, az)))));
   }
+  if (p.ice == 2) factor = (double)ice_stokes_factor(p.env[VAR_ICE_A][i]);   // stokes_u*factor: float64 * float32 array
   double su = speed == 0 ? 0.0 : __dmul_rn(__dmul_rn((double)sx, unit), factor);
   double sv = speed == 0 ? 0.0 : __dmul_rn(__dmul_rn((double)sy, unit), factor);
   move_f64(lon, lat, su, sv, p.moving[i], dt);
+  p.lon[i] = lon;
+  p.lat[i] = lat;
+}
+
+// advect_with_sea_ice (physics_methods.py:693-710): update_positions(factor*ice_u, factor*ice_v), float32 products;
+// without sea_ice_x/y_velocity the rule of thumb current + 1.5 % of the wind (Nordam et al. 2019)
+__global__ __launch_bounds__(BLOCK) void k_advect_ice(PView p, double dt, float factor, int have_ice_velocity) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  const float f = p.ice == 3 ? ice_k(p.env[VAR_ICE_A][i]) : factor;
+  float iu, iv;
+  if (have_ice_velocity) { iu = p.env[VAR_ICE_U][i]; iv = p.env[VAR_ICE_V][i]; }
+  else {   // x_sea_water_velocity + 0.015*x_wind: float32
+    iu = __fadd_rn(p.env[VAR_U][i], __fmul_rn(0.015f, p.env[VAR_XWIND][i]));
+    iv = __fadd_rn(p.env[VAR_V][i], __fmul_rn(0.015f, p.env[VAR_YWIND][i]));
+  }
+  double lon = p.lon[i], lat = p.lat[i];
+  move_f32(lon, lat, __fmul_rn(f, iu), __fmul_rn(f, iv), p.moving[i], dt);
   p.lon[i] = lon;
   p.lat[i] = lat;
 }

@@ -537,10 +537,10 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
   }
   // record layout: interleaved vector pairs first, then the other 3D variables, then the 2D ones; the record
   // length is padded to 16 bytes (odr_field.hip.h DevBlock)
-  static const int pairs[3][2] = {{VAR_U, VAR_V}, {VAR_XWIND, VAR_YWIND}, {VAR_SX, VAR_SY}};
+  static const int pairs[4][2] = {{VAR_U, VAR_V}, {VAR_XWIND, VAR_YWIND}, {VAR_SX, VAR_SY}, {VAR_ICE_U, VAR_ICE_V}};
   std::vector<int> off((size_t)nvars, -1), es((size_t)nvars, 1), eo((size_t)nvars, 0);
   int rec = 0;
-  for (int pr = 0; pr < 3; ++pr) {
+  for (int pr = 0; pr < 4; ++pr) {
     int ka = -1, kb = -1;
     for (int k = 0; k < nvars; ++k) { if (var_ids[k] == pairs[pr][0]) ka = k; if (var_ids[k] == pairs[pr][1]) kb = k; }
     if (ka < 0 || kb < 0) continue;
@@ -760,7 +760,7 @@ bool odr_i_build_env_group(const odr_ctx *c, const int *grp, int ng, double t, E
   host_bracket(s, t, ib, ia);
   memset(&G, 0, sizeof G);
   // order: the caller's, except that the y-component of a vector pair follows its x-component
-  static const int pairs[3][2] = {{VAR_U, VAR_V}, {VAR_XWIND, VAR_YWIND}, {VAR_SX, VAR_SY}};
+  static const int pairs[4][2] = {{VAR_U, VAR_V}, {VAR_XWIND, VAR_YWIND}, {VAR_SX, VAR_SY}, {VAR_ICE_U, VAR_ICE_V}};
   auto in_group = [&](int v) { for (int k = 0; k < ng; ++k) if (grp[k] == v) return true; return false; };
   auto pair_y = [&](int v) { for (auto &pr : pairs) if (pr[0] == v) return pr[1]; return -1; };
   auto pair_x = [&](int v) { for (auto &pr : pairs) if (pr[1] == v) return pr[0]; return -1; };
@@ -922,6 +922,42 @@ int odr_i_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var
       }
       if (!getenv("ODR_NO_FAST_PATH") && launch_env_constant(c, p, grp, ng, t)) continue;   // (positions recorded below)
       for (int k = 0; k < ng; ++k) p->env_cok[grp[k]] = false;   // written per element by the kernels below
+      if (ng > MAXG && c->hw.nlist[va] == 1) {
+        // more variables from ONE reader than a launch carries (OpenOil with sea ice: 10): consecutive launches of up to
+        // MAXG variables, vector pairs kept together.  With a single reader in the list there is no next reader whose
+        // turn would depend on the whole group's missing-data mask, so the split does not change any value.
+        static const int pairs[4][2] = {{VAR_U, VAR_V}, {VAR_XWIND, VAR_YWIND}, {VAR_SX, VAR_SY}, {VAR_ICE_U, VAR_ICE_V}};
+        int ord[NVAR], no = 0;
+        bool placed[NVAR] = {false};
+        for (auto &pr : pairs) {
+          bool hx = false, hy = false;
+          for (int k = 0; k < ng; ++k) { hx |= grp[k] == pr[0]; hy |= grp[k] == pr[1]; }
+          if (hx && hy) { ord[no++] = pr[0]; ord[no++] = pr[1]; placed[pr[0]] = placed[pr[1]] = true; }
+        }
+        for (int k = 0; k < ng; ++k) if (!placed[grp[k]]) ord[no++] = grp[k];
+        int at = 0, rcg = 0;
+        while (at < no && !rcg) {
+          const int m = std::min(MAXG, no - at);   // MAXG is even and the pairs come first, two by two: no pair is cut
+          int sub[MAXG];
+          for (int k = 0; k < m; ++k) sub[k] = ord[at + k];
+          bool ok = !getenv("ODR_NO_FAST_PATH") && launch_env_grid(c, p, sub, m, t, rec);
+          if (!ok) {
+            switch (m) {
+              case 1: launch_group<1>(c, p, sub, t, rec); break;
+              case 2: launch_group<2>(c, p, sub, t, rec); break;
+              case 3: launch_group<3>(c, p, sub, t, rec); break;
+              case 4: launch_group<4>(c, p, sub, t, rec); break;
+              case 5: launch_group<5>(c, p, sub, t, rec); break;
+              case 6: launch_group<6>(c, p, sub, t, rec); break;
+              case 7: launch_group<7>(c, p, sub, t, rec); break;
+              default: launch_group<8>(c, p, sub, t, rec); break;
+            }
+          }
+          rec = 0;
+          at += m;
+        }
+        continue;
+      }
       if (!getenv("ODR_NO_FAST_PATH") && launch_env_grid(c, p, grp, ng, t, rec)) { rec = 0; continue; }
       if (!getenv("ODR_NO_FAST_PATH") && launch_env_gyre(c, p, grp, ng, t, rec)) { rec = 0; continue; }
       // the whole group goes through one launch: the reference decides "static variables only"
@@ -1035,6 +1071,31 @@ int odr_update_positions(odr_ctx *c, odr_particles *p, const double *u, const do
   int rc = host_to_scratch(c, p, u, v, (size_t)p->n, &da, &db);
   if (rc) return rc;
   hipLaunchKernelGGL(k_update_positions, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), da, db, is_f32, dt);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Per-element factors of the following movers, derived from the sampled sea_ice_area_fraction (OpenOil.advect_oil,
+// openoil.py:1179-1216).  Stays in force until set again.
+int odr_set_element_factor(odr_ctx *c, odr_particles *p, int kind) {
+  (void)c;
+  REQUIRE(kind >= ODR_FACTOR_SCALAR && kind <= ODR_FACTOR_ICE_DRIFT, "bad element factor kind %d", kind);
+  if (kind != ODR_FACTOR_SCALAR && !p->env[VAR_ICE_A]) return fail(ODR_ERR_STATE, "sea_ice_area_fraction has not been sampled");
+  p->ice_kind = kind;
+  return 0;
+}
+
+// advect_with_sea_ice (physics_methods.py:693-710)
+int odr_advect_sea_ice(odr_ctx *c, odr_particles *p, double dt, double factor) {
+  p->epoch++;
+  if (p->n == 0) return 0;
+  const int have = p->env[VAR_ICE_U] && p->env[VAR_ICE_V];
+  if (!have) {
+    if (!p->env[VAR_U] || !p->env[VAR_V]) return 0;   // "No sea ice velocity available"
+    if (!p->env[VAR_XWIND] || !p->env[VAR_YWIND]) return fail(ODR_ERR_STATE, "wind has not been sampled");
+  }
+  if (p->ice_kind == ODR_FACTOR_ICE_DRIFT && !p->env[VAR_ICE_A]) return fail(ODR_ERR_STATE, "sea_ice_area_fraction has not been sampled");
+  hipLaunchKernelGGL(k_advect_ice, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, (float)factor, have);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -444,6 +444,17 @@ class Particles:
         check(self.lib.odr_advect_wind(self.ctx.h, self.h, float(dt), float(wind_drift_depth),
                                        int(relative_wind), float(factor)))
 
+    ELEMENT_FACTORS = {None: 0, 'scalar': 0, 'ice_current': 1, 'ice_stokes': 2, 'ice_drift': 3}
+
+    def set_element_factor(self, kind):
+        """Per-element factors of the following movers from the sampled sea_ice_area_fraction (OpenOil.advect_oil,
+        openoil.py:1179-1216): 'ice_current' (advect, advect_wind), 'ice_stokes' (stokes_drift), 'ice_drift'
+        (advect_sea_ice); None: the scalar `factor` arguments again."""
+        check(self.lib.odr_set_element_factor(self.ctx.h, self.h, self.ELEMENT_FACTORS[kind]))
+
+    def advect_sea_ice(self, dt, factor=1.0):
+        check(self.lib.odr_advect_sea_ice(self.ctx.h, self.h, float(dt), float(factor)))
+
     def stokes_drift(self, dt, profile=2, hs_mode=0, tp_mode=0, factor=1.0):
         check(self.lib.odr_stokes_drift(self.ctx.h, self.h, float(dt), profile, hs_mode, tp_mode, float(factor)))
 
@@ -718,7 +729,7 @@ def _touching(fn):
 
 
 for _name in ('append', 'upload', 'env_sample', 'env_upload', 'env_add_noise', 'advect', 'env_coast_advect',
-              'update_positions', 'advect_wind', 'stokes_drift', 'set_property', 'leeway_capsize', 'leeway', 'hdiffusion',
+              'update_positions', 'advect_wind', 'stokes_drift', 'advect_sea_ice', 'set_property', 'leeway_capsize', 'leeway', 'hdiffusion',
               'vmix', 'vmix_analytic', 'vmix_oil', 'vertical_advection', 'vertical_buoyancy', 'coastline', 'coastline_crossing',
               'increase_age', 'deactivate_missing', 'remap_status', 'seafloor', 'deactivate', 'deactivate_outside', 'compact',
               'compact_apply', 'sort_by_cell'):

@@ -41,7 +41,7 @@ class OpenOil(OceanDrift):
     # slot order of odr_particles_set_property (include/odrift.h ODR_OIL_*)
     aux_properties = list(_abi.OIL_PROPERTIES)
     internal_properties = ('diameter_if_entrained',)   # device scratch of prepare_vertical_mixing, not an Oil element variable
-    required_variables = {   # openoil.py:221-296 (sea ice and the second-moment wave period are not device variables)
+    required_variables = {   # openoil.py:221-296 (the second-moment wave period is not a device variable)
         'x_sea_water_velocity': {'fallback': None},
         'y_sea_water_velocity': {'fallback': None},
         'x_wind': {'fallback': None},
@@ -52,6 +52,9 @@ class OpenOil(OceanDrift):
         'sea_surface_wave_stokes_drift_x_velocity': {'fallback': 0, 'skip_if': ['drift:stokes_drift', 'is', False]},
         'sea_surface_wave_stokes_drift_y_velocity': {'fallback': 0, 'skip_if': ['drift:stokes_drift', 'is', False]},
         'sea_surface_wave_period_at_variance_spectral_density_maximum': {'fallback': 0},
+        'sea_ice_area_fraction': {'fallback': 0},        # advect_oil in ice (openoil.py:263-275, 1179-1216)
+        'sea_ice_x_velocity': {'fallback': 0},
+        'sea_ice_y_velocity': {'fallback': 0},
         'sea_water_temperature': {'fallback': 10},
         'sea_water_salinity': {'fallback': 34},
         'sea_floor_depth_below_sea_level': {'fallback': 10000},
@@ -218,10 +221,29 @@ class OpenOil(OceanDrift):
         # a wind-parameterised diffusivity needs MLD.max() over all elements (oceandrift.py:430)
         self._with_global_reduction(mix)
 
-    def advect_oil(self):   # openoil.py:1179-1216, no sea ice: k_ice = 0, factor_stokes = 1
-        self.advect_ocean_current(factor=1)
-        self.advect_wind(factor=1)
-        self.stokes_drift(1)
+    def advect_oil(self):   # openoil.py:1179-1216
+        if self._identically_zero('sea_ice_area_fraction'):
+            # no reader delivers the ice concentration: k_ice = 0 and factor_stokes = 1 for every element, and
+            # advect_with_sea_ice(factor=0) is a zero-length move (position unchanged)
+            self.advect_ocean_current(factor=1)
+            self.advect_wind(factor=1)
+            self.stokes_drift(1)
+            return
+        # Nordam et al. (2019) / Arneborg (2017): per-element factors from the sampled float32 concentration, derived
+        # inside the kernels (odr_set_element_factor)
+        try:
+            self.P.set_element_factor('ice_current')      # 1 - k_ice
+            self.advect_ocean_current(factor=1)
+            self.advect_wind(factor=1)
+            self.P.set_element_factor('ice_stokes')       # (0.7 - A) / 0.7, 0 above 70 %
+            self.stokes_drift(1)
+            self.P.set_element_factor('ice_drift')        # k_ice
+            self.advect_with_sea_ice()
+        finally:
+            self.P.set_element_factor(None)
+
+    def advect_with_sea_ice(self, factor=1):   # physics_methods.py:693-710
+        self.P.advect_sea_ice(self.time_step.total_seconds(), factor)
 
     def update(self):       # openoil.py:1218-1239
         self.oil_weathering()

@@ -32,7 +32,16 @@ enum {
   ORC_VAR_MLD = 14,   /* ocean_mixed_layer_thickness */
   ORC_VAR_TEMP = 15,  /* sea_water_temperature (OpenOil.required_variables, openoil.py:271-278) */
   ORC_VAR_SALT = 16,  /* sea_water_salinity */
-  ORC_NVAR = 18
+  ORC_VAR_ICE_A = 17, /* sea_ice_area_fraction (OpenOil.advect_oil, openoil.py:1179-1216) */
+  ORC_VAR_ICE_U = 18, /* sea_ice_x_velocity */
+  ORC_VAR_ICE_V = 19, /* sea_ice_y_velocity */
+  ORC_VAR_SWELL_DIR = 20, /* sea_surface_swell_wave_to_direction (windsea_swell Stokes profile, physics_methods.py:418-456) */
+  ORC_VAR_SWELL_TP = 21,  /* sea_surface_swell_wave_peak_period_from_variance_spectral_density */
+  ORC_VAR_SWELL_HS = 22,  /* sea_surface_swell_wave_significant_height */
+  ORC_VAR_WW_DIR = 23,    /* sea_surface_wind_wave_to_direction */
+  ORC_VAR_WW_TM = 24,     /* sea_surface_wind_wave_mean_period */
+  ORC_VAR_WW_HS = 25,     /* sea_surface_wind_wave_significant_height */
+  ORC_NVAR = 26
 };
 
 /* ---- projections (proj.c) ---- */
@@ -131,12 +140,23 @@ void orc_advect_wind(long n, double *lon, double *lat, const double *z,
                      const float *ywind, const float *u_env, const float *v_env,
                      double wind_drift_depth, int relative_wind, double factor, double dt);
 
+void orc_advect_wind_ef(long n, double *lon, double *lat, const double *z,
+                        const int *moving, const float *wdf, const float *xwind,
+                        const float *ywind, const float *u_env, const float *v_env,
+                        double wind_drift_depth, int relative_wind, double factor, const float *efac, double dt);
+
 /* stokes_drift (physics_methods.py:793-848) with profile 0 monochromatic, 1 exponential, 2 Phillips */
 void orc_stokes_drift(long n, double *lon, double *lat, const double *z,
                       const int *moving, const float *sx, const float *sy,
                       const float *hs, const float *tp, const float *xwind,
                       const float *ywind, int hs_mode, int tp_mode, int profile,
                       double factor, double dt);
+
+void orc_stokes_drift_ef(long n, double *lon, double *lat, const double *z,
+                         const int *moving, const float *sx, const float *sy,
+                         const float *hs, const float *tp, const float *xwind,
+                         const float *ywind, int hs_mode, int tp_mode, int profile,
+                         double factor, const float *efac, double dt);
 
 /* horizontal_diffusion (basemodel/__init__.py:1746-1772), normals drawn by the caller */
 void orc_horizontal_diffusion(long n, double *lon, double *lat, const int *moving,

@@ -12,7 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, '_build', 'liboracle.so')
 
-NVAR = 18
+NVAR = 26
 MAXLEVELS = 4
 VAR = dict(x_sea_water_velocity=0, y_sea_water_velocity=1, x_wind=2, y_wind=3,
            upward_sea_water_velocity=4, ocean_vertical_diffusivity=5,
@@ -21,7 +21,12 @@ VAR = dict(x_sea_water_velocity=0, y_sea_water_velocity=1, x_wind=2, y_wind=3,
            sea_floor_depth_below_sea_level=9, sea_surface_height=10,
            horizontal_diffusivity=11, sea_surface_wave_significant_height=12,
            sea_surface_wave_period_at_variance_spectral_density_maximum=13,
-           ocean_mixed_layer_thickness=14, sea_water_temperature=15, sea_water_salinity=16)
+           ocean_mixed_layer_thickness=14, sea_water_temperature=15, sea_water_salinity=16,
+           sea_ice_area_fraction=17, sea_ice_x_velocity=18, sea_ice_y_velocity=19,
+           sea_surface_swell_wave_to_direction=20,
+           sea_surface_swell_wave_peak_period_from_variance_spectral_density=21,
+           sea_surface_swell_wave_significant_height=22, sea_surface_wind_wave_to_direction=23,
+           sea_surface_wind_wave_mean_period=24, sea_surface_wind_wave_significant_height=25)
 PROJ_LATLONG, PROJ_STERE_EQUIT_SPHERE, PROJ_STERE_POLAR = 0, 1, 2
 SRC_CONSTANT, SRC_DOUBLE_GYRE, SRC_OSCILLATING, SRC_GRID = 0, 1, 2, 3
 
@@ -298,6 +303,8 @@ def advect_ocean_current(world, scheme, lon, lat, z, moving, cdf, u_env, v_env, 
     (drift:current_uncertainty normal x, y; then drift:current_uncertainty_uniform x, y), or None"""
     n = lon.size
     z, moving, cdf = _d(np.broadcast_to(z, lon.shape)), _i(moving), _f(np.broadcast_to(cdf, lon.shape))
+    if np.ndim(factor):      # per-element float32 factor: factor*cdf is float32 * float32 (physics_methods.py:622)
+        cdf, factor = _f(np.asarray(factor, dtype=np.float32) * cdf), 1.0
     ncomp, sn = 0, None
     if stage_noise is not None and scheme > 0:
         sn = _d(np.asarray(stage_noise)[..., :n])
@@ -310,23 +317,41 @@ def advect_ocean_current(world, scheme, lon, lat, z, moving, cdf, u_env, v_env, 
                                          _p(sn, C.c_double) if sn is not None else None)
 
 
+def ice_factors(A):
+    """OpenOil.advect_oil (openoil.py:1182-1201) on the float32 sea_ice_area_fraction: (k_ice, factor_stokes), float32
+    like NumPy computes them (float32 array with python scalars)."""
+    A = np.asarray(A, dtype=np.float32)
+    k_ice = (A - 0.3) / (0.8 - 0.3)
+    k_ice[A < 0.3] = 0
+    k_ice[A > 0.8] = 1
+    factor_stokes = (0.7 - A) / 0.7
+    factor_stokes[A > 0.7] = 0
+    assert k_ice.dtype == np.float32 and factor_stokes.dtype == np.float32
+    return k_ice, factor_stokes
+
+
 def advect_wind(lon, lat, z, moving, wdf, xwind, ywind, u_env, v_env, wind_drift_depth, relative_wind,
                 factor, dt):
+    """factor: python scalar, or a float32 array (per element)"""
     n = lon.size
-    lib().orc_advect_wind(C.c_long(n), _p(lon, C.c_double), _p(lat, C.c_double), _p(_d(z), C.c_double),
-                          _p(_i(moving), C.c_int), _p(_f(wdf), C.c_float), _p(_f(xwind), C.c_float),
-                          _p(_f(ywind), C.c_float), _p(_f(u_env), C.c_float), _p(_f(v_env), C.c_float),
-                          C.c_double(wind_drift_depth), C.c_int(relative_wind), C.c_double(factor),
-                          C.c_double(dt))
+    ef = _f(factor) if np.ndim(factor) else None
+    lib().orc_advect_wind_ef(C.c_long(n), _p(lon, C.c_double), _p(lat, C.c_double), _p(_d(z), C.c_double),
+                             _p(_i(moving), C.c_int), _p(_f(wdf), C.c_float), _p(_f(xwind), C.c_float),
+                             _p(_f(ywind), C.c_float), _p(_f(u_env), C.c_float), _p(_f(v_env), C.c_float),
+                             C.c_double(wind_drift_depth), C.c_int(relative_wind),
+                             C.c_double(1.0 if ef is not None else factor), _p(ef, C.c_float) if ef is not None else None,
+                             C.c_double(dt))
 
 
 def stokes_drift(lon, lat, z, moving, sx, sy, hs, tp, xwind, ywind, hs_mode, tp_mode, profile, factor, dt):
     n = lon.size
-    lib().orc_stokes_drift(C.c_long(n), _p(lon, C.c_double), _p(lat, C.c_double), _p(_d(z), C.c_double),
-                           _p(_i(moving), C.c_int), _p(_f(sx), C.c_float), _p(_f(sy), C.c_float),
-                           _p(_f(hs), C.c_float), _p(_f(tp), C.c_float), _p(_f(xwind), C.c_float),
-                           _p(_f(ywind), C.c_float), C.c_int(hs_mode), C.c_int(tp_mode), C.c_int(profile),
-                           C.c_double(factor), C.c_double(dt))
+    ef = _f(factor) if np.ndim(factor) else None
+    lib().orc_stokes_drift_ef(C.c_long(n), _p(lon, C.c_double), _p(lat, C.c_double), _p(_d(z), C.c_double),
+                              _p(_i(moving), C.c_int), _p(_f(sx), C.c_float), _p(_f(sy), C.c_float),
+                              _p(_f(hs), C.c_float), _p(_f(tp), C.c_float), _p(_f(xwind), C.c_float),
+                              _p(_f(ywind), C.c_float), C.c_int(hs_mode), C.c_int(tp_mode), C.c_int(profile),
+                              C.c_double(1.0 if ef is not None else factor),
+                              _p(ef, C.c_float) if ef is not None else None, C.c_double(dt))
 
 
 def horizontal_diffusion(lon, lat, moving, D, nx, ny, dt):

@@ -273,12 +273,13 @@ static void source_call(const orc_source *s, int nv, const int *vars, long m,
     }
     /* rotate vector pairs to lon/lat CRS (variables.py:799-837) */
     if (s->proj.kind != ORC_PROJ_LATLONG) {
-      static const int pairs[3][2] = {{ORC_VAR_XWIND, ORC_VAR_YWIND},
+      static const int pairs[4][2] = {{ORC_VAR_XWIND, ORC_VAR_YWIND},        /* vector_pairs_xy, basereader/consts.py:27-36 */
+                                      {ORC_VAR_ICE_U, ORC_VAR_ICE_V},
                                       {ORC_VAR_U, ORC_VAR_V},
                                       {ORC_VAR_STOKES_X, ORC_VAR_STOKES_Y}};
       int p;
       double *rot = NULL;
-      for (p = 0; p < 3; ++p) {
+      for (p = 0; p < 4; ++p) {
         int iu = -1, iv = -1;
         for (v = 0; v < nv; ++v) { if (vars[v] == pairs[p][0]) iu = v; if (vars[v] == pairs[p][1]) iv = v; }
         if (iu < 0 || iv < 0) continue;
@@ -509,6 +510,16 @@ void orc_advect_wind(long n, double *lon, double *lat, const double *z,
                      const int *moving, const float *wdf_in, const float *xwind,
                      const float *ywind, const float *u_env, const float *v_env,
                      double wind_drift_depth, int relative_wind, double factor, double dt) {
+  orc_advect_wind_ef(n, lon, lat, z, moving, wdf_in, xwind, ywind, u_env, v_env, wind_drift_depth, relative_wind,
+                     factor, NULL, dt);
+}
+
+/* the same with a per-element float32 factor (OpenOil.advect_oil in ice: factor = 1 - k_ice, openoil.py:1210);
+ * efac == NULL: the scalar factor */
+void orc_advect_wind_ef(long n, double *lon, double *lat, const double *z,
+                        const int *moving, const float *wdf_in, const float *xwind,
+                        const float *ywind, const float *u_env, const float *v_env,
+                        double wind_drift_depth, int relative_wind, double factor, const float *efac, double dt) {
   double *xu = (double *)malloc(sizeof(double) * (size_t)n);
   double *xv = (double *)malloc(sizeof(double) * (size_t)n);
   double wdd = fabs(wind_drift_depth), wmax = 0, smax = 0;
@@ -530,8 +541,8 @@ void orc_advect_wind(long n, double *lon, double *lat, const double *z,
       if (wdf > wmax) wmax = wdf;
       if (sp > smax) smax = sp;
     }
-    xu[i] = (double)xw * wdf * factor;
-    xv[i] = (double)yw * wdf * factor;
+    xu[i] = (double)xw * wdf * (efac ? (double)efac[i] : factor);   /* x_wind*wdf*factor (:791): f64 * f32 array */
+    xv[i] = (double)yw * wdf * (efac ? (double)efac[i] : factor);
   }
   /* early returns (:741-747, :775-780) */
   if (any && wmax != 0 && smax != 0) orc_update_positions_f64(n, lon, lat, xu, xv, moving, dt);
@@ -564,6 +575,17 @@ void orc_stokes_drift(long n, double *lon, double *lat, const double *z,
                       const float *hs_in, const float *tp_in, const float *xwind,
                       const float *ywind, int hs_mode, int tp_mode, int profile,
                       double factor, double dt) {
+  orc_stokes_drift_ef(n, lon, lat, z, moving, sx, sy, hs_in, tp_in, xwind, ywind, hs_mode, tp_mode, profile, factor, NULL, dt);
+}
+
+/* the same with a per-element float32 factor (OpenOil.advect_oil in ice: factor_stokes, openoil.py:1200-1213) and
+ * tp_mode 3 = parameterised from the wind, then read back from the float32 environment (a model that has the wave
+ * period among its variables: calculate_missing_environment_variables, physics_methods.py:876-883) */
+void orc_stokes_drift_ef(long n, double *lon, double *lat, const double *z,
+                         const int *moving, const float *sx, const float *sy,
+                         const float *hs_in, const float *tp_in, const float *xwind,
+                         const float *ywind, int hs_mode, int tp_mode, int profile,
+                         double factor, const float *efac, double dt) {
   double *su = (double *)malloc(sizeof(double) * (size_t)n);
   double *sv = (double *)malloc(sizeof(double) * (size_t)n);
   float mx = -INFINITY;
@@ -572,17 +594,18 @@ void orc_stokes_drift(long n, double *lon, double *lat, const double *z,
   if (n == 0 || mx == 0) { free(su); free(sv); return; } /* "No Stokes drift velocity available" */
   for (i = 0; i < n; ++i) {
     float speed = speed_f32(sx[i], sy[i]); /* float32 */
-    float ws = (hs_mode == 1 || tp_mode == 1) ? speed_f32(xwind[i], ywind[i]) : 0.f;
+    float ws = (hs_mode == 1 || tp_mode == 1 || tp_mode == 3) ? speed_f32(xwind[i], ywind[i]) : 0.f;
     tval H, T, mwf, pw, transport, num, km;
     double unit, az;
     if (hs_mode == 0) H = tv_(hs_in[i], K_F32);
     else if (hs_mode == 1) { volatile float w2 = ws * ws; volatile float h = (float)0.0246 * w2; H = tv_(h, K_F32); }
     else H = tv_(1, K_WEAK);
     if (tp_mode == 0) T = tv_(tp_in[i], K_F32);
-    else if (tp_mode == 1) {
+    else if (tp_mode == 1 || tp_mode == 3) {
       double omega = 5;
       if (ws > 0) { volatile float d = (float)1.17 * ws; volatile float o = (float)(0.877 * 9.81) / d; omega = o; }
       T = tv_((2 * PI) / omega, K_F64);
+      if (tp_mode == 3) { volatile float tf = (float)T.v; T = tv_(tf, K_F32); }
     } else T = tv_(8, K_WEAK);
     mwf = tdiv(tv_(2. * PI, K_WEAK), T);               /* stokes_transport_monochromatic :332-334 */
     pw = tmul(H, H);                                   /* np.power(H, 2) */
@@ -599,8 +622,8 @@ void orc_stokes_drift(long n, double *lon, double *lat, const double *z,
       double k2 = tmul(tv_(2, K_WEAK), km).v, c2 = tmul(tv_(2 * PI, K_WEAK), km).v;
       unit = exp(k2 * z[i]) - 1 * sqrt(c2 * az) * erfc(sqrt(k2 * az));
     }
-    su[i] = speed == 0 ? 0 : (double)sx[i] * unit * factor;
-    sv[i] = speed == 0 ? 0 : (double)sy[i] * unit * factor;
+    su[i] = speed == 0 ? 0 : (double)sx[i] * unit * (efac ? (double)efac[i] : factor);
+    sv[i] = speed == 0 ? 0 : (double)sy[i] * unit * (efac ? (double)efac[i] : factor);
   }
   orc_update_positions_f64(n, lon, lat, su, sv, moving, dt);
   free(su); free(sv);

@@ -19,6 +19,7 @@ XW, YW, MLD = 'x_wind', 'y_wind', 'ocean_mixed_layer_thickness'
 SX, SY = 'sea_surface_wave_stokes_drift_x_velocity', 'sea_surface_wave_stokes_drift_y_velocity'
 HS, HD = 'sea_surface_wave_significant_height', 'horizontal_diffusivity'
 TEMP, SALT = 'sea_water_temperature', 'sea_water_salinity'
+ICE_A, ICE_U, ICE_V = 'sea_ice_area_fraction', 'sea_ice_x_velocity', 'sea_ice_y_velocity'
 OIL_PROPS = ['diameter', 'density', 'viscosity', 'oil_film_thickness', 'diameter_if_entrained']   # property slots
 LEEWAY_PROPS = ['downwind_slope', 'crosswind_slope', 'downwind_offset', 'crosswind_offset', 'downwind_eps',
                 'crosswind_eps', 'jibe_probability', 'orientation', 'capsized']
@@ -110,23 +111,32 @@ class OracleBackend:
     def store_previous(self):
         self.plon, self.plat = self.lon.copy(), self.lat.copy()
 
-    def advect(self, scheme, t, dt, stage_noise=None, stds=None):
-        """stage_noise [nstage][ncomp][n]: np.random draws of the Runge-Kutta stage calls (current uncertainty)"""
+    def advect(self, scheme, t, dt, stage_noise=None, stds=None, ice=False):
+        """stage_noise [nstage][ncomp][n]: np.random draws of the Runge-Kutta stage calls (current uncertainty);
+        ice: factor = 1 - k_ice per element (OpenOil.advect_oil, openoil.py:1207)"""
         w = self.sc.oracle_world()
+        factor = 1 - orc.ice_factors(self.env[ICE_A])[0] if ice else 1.0
         orc.advect_ocean_current(w, {'euler': 0, 'runge-kutta': 1, 'runge-kutta4': 2}[scheme], self.lon, self.lat,
-                                 self.z, self.moving, self.cdf, self.env[U], self.env[VV], t, dt, stage_noise=stage_noise)
+                                 self.z, self.moving, self.cdf, self.env[U], self.env[VV], t, dt, factor=factor,
+                                 stage_noise=stage_noise)
 
     def vadvect(self, dt):
         orc.vertical_advection(self.z, self.moving, self.env[W], dt)
 
-    def wind(self, dt, wdd=0.1, relative=False):
+    def wind(self, dt, wdd=0.1, relative=False, ice=False):
+        factor = 1 - orc.ice_factors(self.env[ICE_A])[0] if ice else 1.0
         orc.advect_wind(self.lon, self.lat, self.z, self.moving, self.wdf, self.env[XW], self.env[YW],
-                        self.env[U], self.env[VV], wdd, int(relative), 1.0, dt)
+                        self.env[U], self.env[VV], wdd, int(relative), factor, dt)
 
-    def stokes(self, dt, profile=2, hs_mode=1, tp_mode=1):
+    def stokes(self, dt, profile=2, hs_mode=1, tp_mode=1, ice=False):
         z = np.zeros_like(self.env[SX])
+        factor = orc.ice_factors(self.env[ICE_A])[1] if ice else 1.0
         orc.stokes_drift(self.lon, self.lat, self.z, self.moving, self.env[SX], self.env[SY],
-                         self.env.get(HS, z), z, self.env[XW], self.env[YW], hs_mode, tp_mode, profile, 1.0, dt)
+                         self.env.get(HS, z), z, self.env[XW], self.env[YW], hs_mode, tp_mode, profile, factor, dt)
+
+    def ice_drift(self, dt):   # advect_with_sea_ice(factor=k_ice), physics_methods.py:693-697: float32 products
+        k = orc.ice_factors(self.env[ICE_A])[0]
+        orc.update_positions(self.lon, self.lat, k * self.env[ICE_U], k * self.env[ICE_V], self.moving, dt)
 
     def hdiff(self, dt, normals):
         n = len(self.lon)
@@ -246,19 +256,30 @@ class DeviceBackend:
     def store_previous(self):
         self.P.store_previous()
 
-    def advect(self, scheme, t, dt, stage_noise=None, stds=None):
+    def advect(self, scheme, t, dt, stage_noise=None, stds=None, ice=False):
         if stage_noise is not None:
             self.P.set_advect_noise(stds[0], stds[1], stage_draws=np.asarray(stage_noise)[..., :len(self.P)])
+        self.P.set_element_factor('ice_current' if ice else None)
         self.P.advect(scheme, t, dt)
+        self.P.set_element_factor(None)
 
     def vadvect(self, dt):
         self.P.vertical_advection(dt)
 
-    def wind(self, dt, wdd=0.1, relative=False):
+    def wind(self, dt, wdd=0.1, relative=False, ice=False):
+        self.P.set_element_factor('ice_current' if ice else None)
         self.P.advect_wind(dt, wind_drift_depth=wdd, relative_wind=relative)
+        self.P.set_element_factor(None)
 
-    def stokes(self, dt, profile=2, hs_mode=1, tp_mode=1):
+    def stokes(self, dt, profile=2, hs_mode=1, tp_mode=1, ice=False):
+        self.P.set_element_factor('ice_stokes' if ice else None)
         self.P.stokes_drift(dt, profile=profile, hs_mode=hs_mode, tp_mode=tp_mode)
+        self.P.set_element_factor(None)
+
+    def ice_drift(self, dt):
+        self.P.set_element_factor('ice_drift')
+        self.P.advect_sea_ice(dt)
+        self.P.set_element_factor(None)
 
     def hdiff(self, dt, normals):
         n = len(self.P)
@@ -441,6 +462,35 @@ def replay_c14(B, g, nsteps, start=0):
         B.wind(dt, wdd=0.1)
         out.append(B.state(n) + (B.oil_state(),))
     return out
+
+
+def replay_c16(B, g, nsteps):
+    """c16 golden: the reference's OpenOil in sea ice (openoil.py:1179-1216): RK4 current and windage scaled by 1 - k_ice,
+    Stokes drift by (0.7 - A) / 0.7, drift with the ice velocity scaled by k_ice; no mixing, no uncertainties."""
+    dt = float(g['dt'])
+    n = g['lon'].shape[1]
+    out = []
+    names = [U, VV, XW, YW, SX, SY, LAND, ICE_A, ICE_U, ICE_V]
+    for k in range(nsteps):
+        t = k * dt
+        B.sample(names, t)
+        B.increase_age(dt)
+        B.store_previous()
+        B.advect('runge-kutta4', t, dt, ice=True)
+        B.wind(dt, wdd=float(g['wind_drift_depth']), ice=True)
+        B.stokes(dt, profile=2, hs_mode=1, tp_mode=3, ice=True)
+        B.ice_drift(dt)
+        out.append(B.state(n))
+    return out
+
+
+def scenario_c16(g):
+    from scenarios import Scenario
+    from opendrift_amd import synthetic as synth
+    names = [U, VV, XW, YW, SX, SY, LAND, ICE_A, ICE_U, ICE_V]
+    levels = [(float(t), {k: g['g_' + k][i] for k in names}) for i, t in enumerate(g['g_t'])]
+    return Scenario([('grid', dict(x=g['g_x'], y=g['g_y'], levels=levels, proj=synth.NORKYST_PROJ))],
+                    fallbacks={k: 0.0 for k in names + [HS]})
 
 
 def replay_c7(B, g, sub, model, background, nsteps, start=0):

@@ -272,3 +272,52 @@ def test_reference_sanity_constant_scheme_entrainment_only():
     assert -4.2 < z.min() < -3.2, z.min()
     assert (z < 0).mean() > 0.2        # measured: 0.27
     o.P.close()
+
+
+def test_c16_sea_ice_factors_device_vs_oracle_and_reference():
+    """OpenOil.advect_oil in sea ice (openoil.py:1179-1216) through the C ABI: odr_set_element_factor + the movers +
+    odr_advect_sea_ice against the CPU oracle (1e-10 deg per step) and the reference's own run (golden c16)."""
+    import replay
+    from opendrift_amd.device import Context
+    g = golden('c16_openoil_sea_ice.npz')
+    ns = g['lon'].shape[0] - 1
+    dev = replay.replay_c16(replay.DeviceBackend(replay.scenario_c16(g), Context(seed=0), g['lon'][0], g['lat'][0],
+                                                 g['z'][0], wdf=g['wdf']), g, ns)
+    orc = replay.replay_c16(replay.OracleBackend(replay.scenario_c16(g), g['lon'][0], g['lat'][0], g['z'][0], wdf=g['wdf']), g, ns)
+    for k, ((lo1, la1, z1, s1), (lo2, la2, z2, s2)) in enumerate(zip(dev, orc)):
+        assert np.abs(lo1 - lo2).max() < 1e-10 * (k + 1) and np.abs(la1 - la2).max() < 1e-10 * (k + 1), \
+            (k, np.abs(lo1 - lo2).max(), np.abs(la1 - la2).max())
+        assert np.abs(lo1 - g['lon'][k + 1]).max() < 1e-7 and np.abs(la1 - g['lat'][k + 1]).max() < 1e-7
+
+
+def test_c16_openoil_run_in_sea_ice_reproduces_the_reference():
+    """The same through OpenOil.run(): sea_ice_area_fraction / sea_ice_x/y_velocity are OpenOil variables (fallback 0);
+    with a reader that delivers them advect_oil uses the per-element factors, without one it is the plain sequence."""
+    from opendrift_amd.openoil import OpenOil
+    from opendrift_amd import synthetic as synth
+    g = golden('c16_openoil_sea_ice.npz')
+    n = g['lon'].shape[1]
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'x_wind', 'y_wind', 'sea_surface_wave_stokes_drift_x_velocity',
+             'sea_surface_wave_stokes_drift_y_velocity', 'land_binary_mask', 'sea_ice_area_fraction', 'sea_ice_x_velocity',
+             'sea_ice_y_velocity']
+    times = [T0 + timedelta(seconds=float(t)) for t in g['g_t']]
+    res = []
+    for with_ice in (True, False):
+        o = OpenOil(loglevel=50, seed=0)
+        use = names if with_ice else names[:7]
+        o.add_reader(readers.GridReader(g['g_x'], g['g_y'], times, {k: g['g_' + k] for k in use}, proj4=synth.NORKYST_PROJ4))
+        o.set_config('drift:advection_scheme', 'runge-kutta4')
+        o.set_config('drift:vertical_mixing', False)
+        o.set_config('drift:current_uncertainty', 0)
+        o.set_config('drift:wind_uncertainty', 0)
+        o.set_config('drift:stokes_drift', True)
+        o.seed_elements(lon=g['lon'][0], lat=g['lat'][0], z=g['z'][0], time=T0,
+                        oil_type={'density': 900.0, 'viscosity': 0.005, 'oil_water_interfacial_tension': 0.03})
+        o.run(time_step=float(g['dt']), steps=6)
+        e = o.elements
+        lon, lat = np.full(n, np.nan), np.full(n, np.nan)
+        lon[e.ID], lat[e.ID] = e.lon, e.lat
+        res.append((lon, lat))
+        o.P.close()
+    assert np.abs(res[0][0] - g['lon'][6]).max() < 1e-7 and np.abs(res[0][1] - g['lat'][6]).max() < 1e-7
+    assert np.abs(res[1][0] - g['lon'][6]).max() > 1e-4       # the ice matters

@@ -266,3 +266,26 @@ def test_c14_openoil_defaults_vs_oracle():
             assert np.abs(lon - g['lon'][k + 1]).max() < tol_pos and np.abs(lat - g['lat'][k + 1]).max() < tol_pos, \
                 (k, np.abs(lon - g['lon'][k + 1]).max(), np.abs(lat - g['lat'][k + 1]).max())
             assert np.abs(z - g['z'][k + 1]).max() < tol_z, (k, np.abs(z - g['z'][k + 1]).max())
+
+
+def test_c16_openoil_in_sea_ice_vs_oracle():
+    """OpenOil.advect_oil with the Nordam / Arneborg ice factors per element (openoil.py:1179-1216): golden c16 = the
+    reference's own OpenOil on a polar-stereographic reader with an ice edge across the domain (half of the elements in
+    pack ice, a third in the transition zone), RK4, windage, Phillips Stokes profile, ice drift."""
+    g = golden('c16_openoil_sea_ice.npz')
+    B = replay.OracleBackend(replay.scenario_c16(g), g['lon'][0], g['lat'][0], g['z'][0], wdf=g['wdf'])
+    states = replay.replay_c16(B, g, g['lon'].shape[0] - 1)
+    worst = 0.0
+    for k, (lon, lat, z, status) in enumerate(states):
+        d = max(np.abs(lon - g['lon'][k + 1]).max(), np.abs(lat - g['lat'][k + 1]).max())
+        worst = max(worst, d)
+        assert d < 1e-7, (k, d)
+    print('c16 oracle vs reference:', worst)
+    # the ice matters: the same run without the factors leaves the golden by orders of magnitude more
+    B0 = replay.OracleBackend(replay.scenario_c16(g), g['lon'][0], g['lat'][0], g['z'][0], wdf=g['wdf'])
+    dt = float(g['dt'])
+    B0.sample([replay.U, replay.VV, replay.XW, replay.YW, replay.SX, replay.SY], 0.0)
+    B0.advect('runge-kutta4', 0.0, dt)
+    B0.wind(dt, wdd=float(g['wind_drift_depth']))
+    B0.stokes(dt, profile=2, hs_mode=1, tp_mode=3)
+    assert np.abs(B0.lon - g['lon'][1]).max() > 1e-4
