@@ -183,6 +183,14 @@ int odr_block_drop(odr_ctx *ctx, int32_t source_id, int32_t slot);
  * interval the reader is skipped and the next reader / the fallback applies */
 int odr_source_time_coverage(odr_ctx *ctx, int32_t source_id, double t_start_epoch, double t_end_epoch,
                              int always_valid);
+/* Ensemble data: the reader hands `var` out as a LIST of `members` arrays (readers/basereader/structured.py:125-147);
+ * ReaderBlock.interpolate gives element number j of a call the member j % members
+ * (readers/interpolation/structured.py:119-135).  Declare it before the blocks are uploaded; the block arrays of `var`
+ * then hold the members one after the other along the layer axis ([members x nz][ny][nx], var_nz = members x nz).
+ * Element number = rank among the present elements in ascending ID (the reference's array order for seed times that are
+ * monotonic in ID; elements outside the reader's coverage are counted, unlike in the reference).  Sampled by the generic
+ * kernels; ocean_vertical_diffusivity profiles cannot be ensemble data. */
+int odr_source_set_members(odr_ctx *ctx, int32_t source_id, int32_t var, int32_t members);
 /* priority list + fallback of one variable (environment.py:592-595,782-791); NaN = no fallback */
 int odr_env_bind(odr_ctx *ctx, int32_t var_id, int nsources, const int32_t *source_ids,
                  float fallback);

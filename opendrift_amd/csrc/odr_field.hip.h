@@ -82,6 +82,10 @@ struct DevSource {
   int vg_uniform, vg_pad;
   double zmid[MAXNZ];  // mid-depths -(z[k] + z[k+1])/2 formed as d[k] + 0.5*(d[k+1]-d[k]), d = -z (k_vmix level search)
   int level_slot[MAXLEVELS];  // slots sorted by time
+  // > 1: the reader hands the variable out as a LIST of ensemble members (readers/interpolation/structured.py:119-135);
+  // the block holds them one after the other along the layer axis (var_nz = members x levels); element number j of a
+  // call takes member j % members (odr_source_set_members; sampled by the generic kernels only)
+  int members[NVAR];
   DevBlock slot[MAXLEVELS];
 };
 
@@ -407,10 +411,15 @@ __device__ __forceinline__ void zinterp(const DevSource &s, double z, int &ia, i
 
 // value of one variable from one block; f32class = the reference hands back float32 (2D layer)
 __device__ __forceinline__ double block_value(const DevBlock &b, const DevSource &s, int var,
-                                              double x, double y, double z, bool &f32class) {
+                                              double x, double y, double z, bool &f32class, int rank = 0) {
   const float *d = b.data[var];
-  const int nzv = b.var_nz[var], es = b.es[var];
+  int nzv = b.var_nz[var];
+  const int es = b.es[var];
   const size_t ns = (size_t)b.rec;
+  if (s.members[var] > 1) {   // ensemble data: this element's member, `nzv` levels of it
+    nzv /= s.members[var];
+    d += (size_t)(rank % s.members[var]) * (size_t)nzv * (size_t)es;
+  }
   if (var == VAR_LAND) {
     f32class = true;
     int xi = nearest_index(x, b.xmin, b.xrange, b.ixrange, b.nx);
@@ -459,7 +468,7 @@ __device__ __forceinline__ bool landmask_contains(const DevSource &s, double lon
 // NV variables of a group.  Returns false when the reader does not cover the position.
 template <int NV>
 __device__ __forceinline__ bool source_sample(const DevSource &s, const int (&vars)[NV], double lon,
-                                              double lat, double z, double t, double (&val)[NV]) {
+                                              double lat, double z, double t, double (&val)[NV], int rank = 0) {
   if (!s.always_valid && (t < s.tmin || t > s.tmax)) return false;  // OutsideTemporalCoverageError
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
@@ -515,7 +524,7 @@ __device__ __forceinline__ bool source_sample(const DevSource &s, const int (&va
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         bool f32c;
-        val[v] = block_value(bb, s, vars[v], x, y, z, f32c);
+        val[v] = block_value(bb, s, vars[v], x, y, z, f32c, rank);
       }
     } else {
       const DevBlock &ba = s.slot[ia];
@@ -523,8 +532,8 @@ __device__ __forceinline__ bool source_sample(const DevSource &s, const int (&va
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         bool fb, fa;
-        double vb = block_value(bb, s, vars[v], x, y, z, fb);
-        double va = block_value(ba, s, vars[v], x, y, z, fa);
+        double vb = block_value(bb, s, vars[v], x, y, z, fb, rank);
+        double va = block_value(ba, s, vars[v], x, y, z, fa, rank);
         if (fb && fa) {  // float32 arrays * python floats stay float32 (:362-364)
           float pq = __fadd_rn(__fmul_rn((float)vb, (float)(1 - w)), __fmul_rn((float)va, (float)w));
           val[v] = pq;
@@ -573,14 +582,14 @@ __device__ __forceinline__ float kelvin_to_celsius(float T) {
 // (environment.py:597-762), then the fallback (:782-791).  out = float32 environment.
 template <int NV>
 __device__ __forceinline__ void env_group(const DevWorld &W, const int (&vars)[NV], double lon,
-                                          double lat, double z, double t, float (&out)[NV]) {
+                                          double lat, double z, double t, float (&out)[NV], int rank = 0) {
 #pragma unroll
   for (int v = 0; v < NV; ++v) out[v] = W.fallback[vars[v]];
   int nl = W.nlist[vars[0]];
   for (int k = 0; k < nl; ++k) {
     const DevSource &s = W.src[W.list[vars[0]][k]];
     double val[NV];
-    bool covered = source_sample<NV>(s, vars, lon, lat, z, t, val);
+    bool covered = source_sample<NV>(s, vars, lon, lat, z, t, val, rank);
     bool bad = !covered;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {

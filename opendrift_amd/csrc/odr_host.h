@@ -87,6 +87,11 @@ struct odr_particles {
   long long cap, n, ndead, dead_cap;
   long long win;        // first element of the window that view() exposes (0 except inside step_in_lanes)
   int ice_kind;         // odr_set_element_factor
+  // ranks of the present elements in ascending ID (ensemble members, odr_i_ensure_ranks)
+  int *rank;
+  unsigned *rank_words, *rank_before, *rank_bsum;
+  long long rank_words_n, id_max;
+  int rank_on;
   double *d64[7];       // lon lat z plon plat slon slat
   double *alt64[7];
   int *i32[3];          // id status moving
@@ -129,6 +134,7 @@ static inline PView view(const odr_particles *p) {
   for (int k = 0; k < NVAR; ++k) v.env[k] = p->env[k] ? p->env[k] + w : nullptr;
   for (int k = 0; k < 9; ++k) v.aux[k] = p->aux[k] ? p->aux[k] + w : nullptr;
   v.ice = p->ice_kind; v.pad = 0;
+  v.rank = p->rank_on && p->rank ? p->rank + w : nullptr;
   return v;
 }
 
@@ -197,7 +203,7 @@ static inline bool build_vmix_desc(const odr_ctx *c, double t, VMixDesc &D) {
   const DevBlock &g0 = s.slot[s.level_slot[0]];
   for (int k = 0; k < s.nlevels; ++k) {
     const DevBlock &bk = s.slot[s.level_slot[k]];
-    if (!bk.small || !bk.data[VAR_KZ] || bk.es[VAR_KZ] != 1 || bk.var_nz[VAR_KZ] != nzp || bk.rec != g0.rec || bk.ny != g0.ny || bk.nx != g0.nx ||
+    if (s.members[VAR_KZ] > 1 || !bk.small || !bk.data[VAR_KZ] || bk.es[VAR_KZ] != 1 || bk.var_nz[VAR_KZ] != nzp || bk.rec != g0.rec || bk.ny != g0.ny || bk.nx != g0.nx ||
         bk.x0 != g0.x0 || bk.xspan != g0.xspan || bk.y0 != g0.y0 || bk.yspan != g0.yspan)
       return false;
   }
@@ -210,6 +216,16 @@ static inline bool build_vmix_desc(const odr_ctx *c, double t, VMixDesc &D) {
   D.Kfb = c->hw.fallback[VAR_KZ];
   return true;
 }
+
+static inline bool source_has_members(const DevSource &s) {
+  for (int v = 0; v < NVAR; ++v) if (s.members[v] > 1) return true;
+  return false;
+}
+static inline bool any_members(const odr_ctx *c) {
+  for (int k = 0; k < c->nsrc; ++k) if (c->hw.src[k].kind == SRC_GRID && source_has_members(c->hw.src[k])) return true;
+  return false;
+}
+int odr_i_ensure_ranks(odr_ctx *c, odr_particles *p);
 
 // defined in odrift.hip
 bool odr_i_build_env_group(const odr_ctx *c, const int *grp, int ng, double t, EnvGroupDesc &G);

@@ -61,6 +61,7 @@ struct PView {  // device pointers of the active set
   float *env[NVAR];
   int ice;        // odr_set_element_factor: 0 scalar factors; 1 (1 - k_ice), 2 factor_stokes, 3 k_ice per element
   int pad;
+  const int *rank;  // position among the present elements in ascending ID (ensemble member = rank % members), or null
 };
 
 // OpenOil.advect_oil in sea ice (openoil.py:1182-1201; Nordam et al. 2019, Arneborg 2017), float32 like NumPy on the
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_group(const DevWorld *__restrict_
   for (int k = 0; k < NV; ++k) vars[k] = gv.v[k];
   double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
   float out[NV];
-  env_group<NV>(*W, vars, lon, lat, z, t, out);
+  env_group<NV>(*W, vars, lon, lat, z, t, out, p.rank ? p.rank[i] : 0);
 #pragma unroll
   for (int k = 0; k < NV; ++k) p.env[vars[k]][i] = out[k];
   if (record_prev) { p.slon[i] = lon; p.slat[i] = lat; }
@@ -499,6 +500,7 @@ __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W
   float u1 = p.env[VAR_U][i], v1 = p.env[VAR_V][i];
   float f = __fmul_rn(current_factor(p, i, factor), p.cdf[i]);  // factor*cdf, float32
   int moving = p.moving[i];
+  const int rk = p.rank ? p.rank[i] : 0;
   float fu, fv;
   GeodStart o = geod_start(lat, lon);
   if (SCHEME == 0) {
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W
     double lon2, lat2;
     float k2[2];
     stage_pos(o, u1, v1, dtf, lon2, lat2);
-    env_group<2>(*W, uv, lon2, lat2, z, t + dt / 2, k2);
+    env_group<2>(*W, uv, lon2, lat2, z, t + dt / 2, k2, rk);
     const int id = NOISE ? p.id[i] : 0;
     if (NOISE) add_current_noise(N, 1, i, p.n, id, k2[0], k2[1]);
     if (SCHEME == 1) {
@@ -518,10 +520,10 @@ __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W
     } else {
       float k3[2], k4[2];
       stage_pos(o, k2[0], k2[1], dtf, lon2, lat2);
-      env_group<2>(*W, uv, lon2, lat2, z, t + dt / 2, k3);
+      env_group<2>(*W, uv, lon2, lat2, z, t + dt / 2, k3, rk);
       if (NOISE) add_current_noise(N, 2, i, p.n, id, k3[0], k3[1]);
       stage_pos(o, k3[0], k3[1], dtf, lon2, lat2);  // dt*.5 again: reference quirk (:662)
-      env_group<2>(*W, uv, lon2, lat2, z, t + dt, k4);
+      env_group<2>(*W, uv, lon2, lat2, z, t + dt, k4, rk);
       if (NOISE) add_current_noise(N, 3, i, p.n, id, k4[0], k4[1]);
       fu = __fmul_rn(rk4_mix(u1, k2[0], k3[0], k4[0]), f);
       fv = __fmul_rn(rk4_mix(v1, k2[1], k3[1], k4[1]), f);
@@ -1757,6 +1759,26 @@ __global__ __launch_bounds__(BLOCK) void k_deactivate(PView p, const unsigned ch
 // block counts (single workgroup), pass 3 scatters every property.
 // flags (may be NULL): bit k is set when an element carries the provisional status number 100 + k (a deactivation reason
 // that has no status category yet, opendrift_amd/oceandrift.py:_status_code) -- read back with the count in one transfer
+// ---- rank of every present element in ascending ID (what the reference's arrays are ordered by): a bitmap of the IDs,
+// popcounts per word, their exclusive scan, then rank = words before + bits before
+// (elements already deactivated in this step are not counted: the reference has removed them from its arrays by the time
+// the next call is made, remove_deactivated_elements comes before update())
+__global__ __launch_bounds__(BLOCK) void k_rank_mark(const int *id, const int *status, long long n, unsigned *words) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n && status[i] == 0) atomicOr(&words[(unsigned)id[i] >> 5], 1u << ((unsigned)id[i] & 31u));
+}
+__global__ __launch_bounds__(BLOCK) void k_rank_count(const unsigned *words, long long nw, unsigned *cnt) {
+  long long w = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (w < nw) cnt[w] = (unsigned)__popc(words[w]);
+}
+__global__ __launch_bounds__(BLOCK) void k_rank_assign(const int *id, long long n, const unsigned *words, const unsigned *before,
+                                                       int *rank) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const unsigned v = (unsigned)id[i], w = v >> 5, bit = v & 31u;
+  rank[i] = (int)(before[w] + (unsigned)__popc(words[w] & ((1u << bit) - 1u)));
+}
+
 // Grid-stride over the 256-element chunks: the per-chunk counts feed the scan; the grand total is ONE atomic per
 // workgroup (one per chunk = 39 063 serialised atomics on one address for 10 M elements cost 0.47 ms).
 __global__ __launch_bounds__(BLOCK) void k_cmp_count(const int *status, long long n, unsigned *bcount,

@@ -59,6 +59,7 @@ static int advect_impl(odr_ctx *c, odr_particles *p, int scheme, double t, doubl
   int rc = flush_world(c);
   if (rc) return rc;
   if (p->n == 0) return 0;
+  if (scheme > 0 && (rc = odr_i_ensure_ranks(c, p))) return rc;   // stage calls on ensemble data: the present elements' ranks
   if (N.on && scheme > 0) {
     if (N.rng_mode == ODR_RNG_HOST && !N.stage) return fail(ODR_ERR_INVALID, "no host draws for the Runge-Kutta stage calls");
     odr_i_advect_noise(c, p, scheme, t, dt, factor, N);

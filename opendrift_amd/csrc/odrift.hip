@@ -142,6 +142,7 @@ int odr_particles_destroy(odr_ctx *c, odr_particles *p) {
   for (int k = 0; k < 9; ++k) { fr(p->aux[k]); fr(p->altaux[k]); }
   fr(p->bcount);
   fr(p->scratch);
+  fr(p->rank); fr(p->rank_words); fr(p->rank_before); fr(p->rank_bsum);
   delete p;
   return 0;
 }
@@ -175,9 +176,15 @@ int odr_particles_append(odr_ctx *c, odr_particles *p, int64_t n, const double *
   if ((rc = put<double>(c, p->d64[4] + o, lat, n, 0.0))) return rc;
   if ((rc = put<double>(c, p->d64[5] + o, lon, n, 0.0))) return rc;
   if ((rc = put<double>(c, p->d64[6] + o, lat, n, 0.0))) return rc;
-  if (id) { if ((rc = put<int>(c, p->i32[0] + o, id, n, 0))) return rc; }
-  else {
+  if (id) {
+    for (long long k = 0; k < n; ++k) {
+      REQUIRE(id[k] >= 0, "element IDs must not be negative");
+      p->id_max = std::max(p->id_max, (long long)id[k]);
+    }
+    if ((rc = put<int>(c, p->i32[0] + o, id, n, 0))) return rc;
+  } else {
     std::vector<int> ids((size_t)n);
+    p->id_max = std::max(p->id_max, o + p->ndead + n - 1);
     for (long long k = 0; k < n; ++k) ids[(size_t)k] = (int)(o + p->ndead + k);
     HIPCHK(hipMemcpyAsync(p->i32[0] + o, ids.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -532,7 +539,9 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
   for (int k = 0; k < nvars; ++k) {
     int v = var_ids[k], nzv = var_nz[k] > 1 ? var_nz[k] : 1;
     REQUIRE(v >= 0 && v < NVAR, "bad variable id %d", v);
-    REQUIRE(nzv == 1 || nzv == s.nz, "variable %d has %d levels, source has %d", v, nzv, s.nz);
+    const int mem = s.members[v] > 1 ? s.members[v] : 1;
+    REQUIRE(nzv == mem || nzv == mem * s.nz, "variable %d has %d layers, source has %d levels x %d members", v, nzv, s.nz, mem);
+    REQUIRE(mem == 1 || v != VAR_KZ, "ensemble members of ocean_vertical_diffusivity profiles are not supported");
     nmax = std::max(nmax, plane * (size_t)nzv);
   }
   // record layout: interleaved vector pairs first, then the other 3D variables, then the 2D ones; the record
@@ -593,7 +602,8 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
     HIPCHK(hipMemcpyAsync(buf, data[k], sizeof(float) * n, hipMemcpyDefault, st));
     const unsigned g = (unsigned)((n + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(k_blk_mask, dim3(g), dim3(BLOCK), 0, st, buf, n);
-    if (nzv > 1) hipLaunchKernelGGL(k_blk_fill_seafloor, dim3(gp), dim3(BLOCK), 0, st, buf, nzv, plane);
+    // ("Ensemble data currently not extrapolated towards seafloor", readers/interpolation/structured.py:58-60)
+    if (nzv > 1 && s.members[v] <= 1) hipLaunchKernelGGL(k_blk_fill_seafloor, dim3(gp), dim3(BLOCK), 0, st, buf, nzv, plane);
     if (v != VAR_LAND) {
       // the reference dilates on demand, <=10 sweeps per interpolator call (interpolators.py:127-137);
       // 10 sweeps up front give identical samples.  (An LDS-tiled single-pass version of the
@@ -749,6 +759,7 @@ bool odr_i_build_env_group(const odr_ctx *c, const int *grp, int ng, double t, E
   const DevSource &s = w.src[sid];
   if (s.kind != SRC_GRID || s.nlevels < 1) return false;
   if (!s.always_valid && (t < s.tmin || t > s.tmax)) return false;
+  for (int k = 0; k < ng; ++k) if (s.members[grp[k]] > 1) return false;   // ensemble data: generic kernels
   const DevBlock &g0 = s.slot[s.level_slot[0]];
   for (int k = 0; k < s.nlevels; ++k) {
     const DevBlock &b = s.slot[s.level_slot[k]];
@@ -897,6 +908,7 @@ int odr_i_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var
     if ((rc = ensure_env(c, p, var_ids[k]))) return rc;
   }
   if ((rc = flush_world(c))) return rc;
+  if ((rc = odr_i_ensure_ranks(c, p))) return rc;   // ensemble data only
   if (p->n > 0) {
     // variable groups = variables sharing the same priority list (get_reader_groups, environment.py:339-374)
     bool done[NVAR] = {false};
@@ -1051,6 +1063,7 @@ bool odr_i_uv_fast_source(const odr_ctx *c, int &sid, double t_lo, double t_hi) 
   sid = w.list[VAR_U][0];
   const DevSource &s = w.src[sid];
   if (s.kind != SRC_GRID || s.nlevels < 1) return false;
+  if (s.members[VAR_U] > 1 || s.members[VAR_V] > 1) return false;         // ensemble data: generic kernels
   if (!s.always_valid && (t_lo < s.tmin || t_hi > s.tmax)) return false;  // generic path handles uncovered times
   const DevBlock &g0 = s.slot[s.level_slot[0]];
   for (int k = 0; k < s.nlevels; ++k) {
@@ -1072,6 +1085,46 @@ int odr_update_positions(odr_ctx *c, odr_particles *p, const double *u, const do
   if (rc) return rc;
   hipLaunchKernelGGL(k_update_positions, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), da, db, is_f32, dt);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// A reader that hands `var` out as a list of `members` arrays (ensemble data, readers/interpolation/structured.py:119-135).
+// Declared before the blocks are uploaded; their arrays then hold the members one after the other along the layer axis.
+int odr_source_set_members(odr_ctx *c, int32_t sid, int32_t var, int32_t members) {
+  REQUIRE(sid >= 0 && sid < c->nsrc && c->hw.src[sid].kind == SRC_GRID, "source %d is not a grid source", sid);
+  REQUIRE(var >= 0 && var < NVAR && members >= 1 && members <= 1024, "bad ensemble declaration");
+  c->hw.src[sid].members[var] = members > 1 ? members : 0;
+  c->dirty = true;
+  return 0;
+}
+
+// rank of every present element in ascending ID = its position in the reference's arrays (release order, for seed
+// times that are monotonic in ID); PView::rank.  Only computed when some reader delivers ensemble data.
+int odr_i_ensure_ranks(odr_ctx *c, odr_particles *p) {
+  p->rank_on = 0;
+  if (!any_members(c) || p->n == 0) return 0;
+  const long long nw = p->id_max / 32 + 1;
+  if (!p->rank) HIPCHK(hipMalloc((void **)&p->rank, sizeof(int) * (size_t)p->cap));
+  if (p->rank_words_n < nw) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (p->rank_words) { HIPCHK(hipFree(p->rank_words)); HIPCHK(hipFree(p->rank_before)); HIPCHK(hipFree(p->rank_bsum)); }
+    const long long cap = nw * 2;
+    HIPCHK(hipMalloc((void **)&p->rank_words, sizeof(unsigned) * (size_t)cap));
+    HIPCHK(hipMalloc((void **)&p->rank_before, sizeof(unsigned) * (size_t)cap));
+    HIPCHK(hipMalloc((void **)&p->rank_bsum, sizeof(unsigned) * (size_t)((cap + 1023) / 1024 + 1)));
+    p->rank_words_n = cap;
+  }
+  HIPCHK(hipMemsetAsync(p->rank_words, 0, sizeof(unsigned) * (size_t)nw, c->stream));
+  hipLaunchKernelGGL(k_rank_mark, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->i32[0], p->i32[1], p->n, p->rank_words);
+  hipLaunchKernelGGL(k_rank_count, dim3(nblk(nw)), dim3(BLOCK), 0, c->stream, p->rank_words, nw, p->rank_before);
+  const unsigned nsb = (unsigned)((nw + 1023) / 1024);
+  hipLaunchKernelGGL(k_scan_local, dim3(nsb), dim3(1024), 0, c->stream, p->rank_before, nw, p->rank_bsum);
+  hipLaunchKernelGGL(k_cmp_scan, dim3(1), dim3(1024), 0, c->stream, p->rank_bsum, (long long)nsb, c->counter + 3);
+  hipLaunchKernelGGL(k_scan_add, dim3(nsb), dim3(1024), 0, c->stream, p->rank_before, nw, p->rank_bsum);
+  hipLaunchKernelGGL(k_rank_assign, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->i32[0], p->n, p->rank_words, p->rank_before,
+                     p->rank);
+  HIPCHK(hipGetLastError());
+  p->rank_on = 1;
   return 0;
 }
 

@@ -169,9 +169,26 @@ class Context:
         check(self.lib.odr_source_lonlat2xy(self.h, sid, len(lon), pl, pa, x.ctypes.data_as(_dp), y.ctypes.data_as(_dp)))
         return x, y
 
+    def _ensemble_arrays(self, sid, arrays):
+        """A variable given as a LIST of member arrays (ensemble data, basereader/structured.py:125-147): declared on the
+        source (odr_source_set_members) and stacked along the layer axis, [members x nz, ny, nx]."""
+        out = {}
+        for k, v in arrays.items():
+            if isinstance(v, (list, tuple)):
+                m = np.stack([np.ma.filled(a, np.nan) if isinstance(a, np.ma.MaskedArray) else np.asarray(a) for a in v]).astype(np.float32)
+                known = self._grids[sid].setdefault('members', {})
+                if known.get(k) != len(v):
+                    check(self.lib.odr_source_set_members(self.h, sid, _vid(k), len(v)))
+                    known[k] = len(v)
+                v = np.ascontiguousarray(m.reshape((-1,) + m.shape[-2:]))
+            out[k] = v
+        return out
+
     def upload_block(self, sid, slot, t_epoch, arrays):
-        """arrays: {variable: float32 [ny,nx] or [nz,ny,nx]} -- one ReaderBlock / time level."""
+        """arrays: {variable: float32 [ny,nx] or [nz,ny,nx], or a list of such arrays (ensemble members)} -- one
+        ReaderBlock / time level."""
         g = self._grids[sid]
+        arrays = self._ensemble_arrays(sid, arrays)
         names = list(arrays)
         ids, pi = _i([_vid(k) for k in names])
         keep = [np.ascontiguousarray(np.ma.filled(arrays[k], np.nan) if isinstance(arrays[k], np.ma.MaskedArray)
@@ -188,6 +205,7 @@ class Context:
         """dev_ptrs: {variable: device pointer (int) of a float32 array already in HBM, or a host NumPy array};
         var_nz: levels per variable (needed for the device pointers)."""
         g = self._grids[sid]
+        dev_ptrs = self._ensemble_arrays(sid, dev_ptrs)
         names = list(dev_ptrs)
         ids, pi = _i([_vid(k) for k in names])
         keep = {k: np.ascontiguousarray(np.ma.filled(v, np.nan) if isinstance(v, np.ma.MaskedArray) else v, dtype=np.float32)
@@ -203,6 +221,7 @@ class Context:
         block becomes visible with commit_block().  arrays: {variable: float32 host array (pin it with pin() for a true
         DMA transfer) or device pointer (int)}.  The arrays are kept referenced until the commit."""
         g = self._grids[sid]
+        arrays = self._ensemble_arrays(sid, arrays)
         names = list(arrays)
         ids, pi = _i([_vid(k) for k in names])
         keep = {k: np.ascontiguousarray(np.ma.filled(v, np.nan) if isinstance(v, np.ma.MaskedArray) else v, dtype=np.float32)

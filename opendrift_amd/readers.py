@@ -242,7 +242,7 @@ class OscillatingReader(ContinuousReader):
 class GridReader(StructuredReader):
     """In-memory StructuredReader with time levels and optional z levels (the shape of
     reader_constant_2d.py:20-49 / reader_netCDF_CF_generic / reader_ROMS_native output blocks).
-    arrays: {variable: [nt, ny, nx] or [nt, nz, ny, nx]}."""
+    arrays: {variable: [nt, ny, nx] or [nt, nz, ny, nx], or a list of such arrays = ensemble members}."""
 
     def __init__(self, x, y, times, arrays, z=None, proj4='+proj=latlong', name='grid_reader'):
         self.proj4, self.name = proj4, name
@@ -274,7 +274,11 @@ class GridReader(StructuredReader):
                 window(np.asarray(self.y, dtype=np.float64), np.asarray(y, dtype=np.float64))
         out = {'x': self.x[ix], 'y': self.y[jy], 'time': time, 'z': self.z if self.z is not None else 0}
         for v in requested_variables:
-            out[v] = self.arrays[v][it][..., jy, ix]
+            a = self.arrays[v]
+            if isinstance(a, (list, tuple)):      # ensemble data: a list of member arrays (structured.py:125-147)
+                out[v] = [m[it][..., jy, ix] for m in a]
+            else:
+                out[v] = a[it][..., jy, ix]
         return out
 
 
@@ -499,6 +503,8 @@ class DeviceReaderBinding:
             # it -- over RCCL / xGMI straight into device memory (opendrift_amd/distributed.py)
             from . import distributed as D
             block = r.get_variables(self.variables, time, x, y, np.array([0.0])) if self.rank == 0 else None
+            if block is not None and any(isinstance(block[v], (list, tuple)) for v in self.variables):
+                raise NotImplementedError('ensemble data (lists of member arrays) in a sharded run')
             meta, tens = D.broadcast_reader_block(block, self.variables, src=0)
             block = dict(meta)
             for v, t in tens.items():

@@ -66,6 +66,8 @@ typedef struct {
   double t;        /* epoch seconds of this time level */
   float *data[ORC_NVAR];       /* NULL if absent; mutated by the in-place NaN dilation */
   int var_nz[ORC_NVAR];        /* 1 => [ny,nx], nz => [nz,ny,nx] */
+  int members[ORC_NVAR];       /* > 1: the reader hands the variable out as a LIST of ensemble members; data holds them
+                                * one after the other, each [var_nz][ny][nx] (readers/interpolation/structured.py:119-135) */
 } orc_block;
 
 /* expand_numpy_array (interpolators.py:9-20): one 3x3 grey dilation of the NaN cells. */

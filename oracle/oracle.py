@@ -52,7 +52,7 @@ class Block(C.Structure):
                 ('x0', C.c_double), ('xspan', C.c_double), ('y0', C.c_double), ('yspan', C.c_double),
                 ('xmin', C.c_double), ('xrange', C.c_double), ('ymin', C.c_double), ('yrange', C.c_double),
                 ('z', C.POINTER(C.c_double)), ('t', C.c_double),
-                ('data', C.POINTER(C.c_float) * NVAR), ('var_nz', C.c_int * NVAR)]
+                ('data', C.POINTER(C.c_float) * NVAR), ('var_nz', C.c_int * NVAR), ('members', C.c_int * NVAR)]
 
 
 class Source(C.Structure):
@@ -237,10 +237,16 @@ class WorldBuilder:
             if zz is not None:
                 b.z = _p(zz, C.c_double)
             for v, arr in arrays.items():
-                arr = np.array(arr, dtype=np.float32, order='C', copy=True)
+                if isinstance(arr, (list, tuple)):      # ensemble members (structured.py:125-147): one after the other
+                    b.members[v] = len(arr)
+                    b.var_nz[v] = arr[0].shape[0] if np.ndim(arr[0]) == 3 else 1
+                    arr = np.stack([np.asarray(a, dtype=np.float32) for a in arr])
+                    arr = np.array(arr.reshape((-1,) + arr.shape[-2:]), dtype=np.float32, order='C', copy=True)
+                else:
+                    arr = np.array(arr, dtype=np.float32, order='C', copy=True)
+                    b.var_nz[v] = arr.shape[0] if arr.ndim == 3 else 1
                 self.keep.append(arr)
                 b.data[v] = _p(arr, C.c_float)
-                b.var_nz[v] = arr.shape[0] if arr.ndim == 3 else 1
         return idx
 
     def set_fallback(self, var, value):

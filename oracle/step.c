@@ -128,7 +128,33 @@ static int nearest_index(double v, double vmin, double vrange, int n) {
  * (interpolation/structured.py:107-163).  out64 receives the value in the dtype
  * class the reference produces: is_f32 = 1 => float32-valued (2D layers),
  * 0 => float64 (3D + z interpolation). */
+static void block_interp_one(orc_block *b, int var, long n, const double *x,
+                             const double *y, const double *z, double *out64,
+                             int *is_f32);
+
+/* ReaderBlock.interpolate for one variable.  Ensemble data (a list of member arrays): every member is interpolated for
+ * ALL n positions of the call -- the NaN dilation of a member can therefore be triggered by a position that does not use
+ * it -- and position j takes member j % M (readers/interpolation/structured.py:119-135). */
 static void block_interp_var(orc_block *b, int var, long n, const double *x,
+                             const double *y, const double *z, double *out64,
+                             int *is_f32) {
+  int M = b->members[var], m;
+  if (M <= 1) { block_interp_one(b, var, n, x, y, z, out64, is_f32); return; }
+  {
+    float *base = b->data[var];
+    long per = (long)(b->var_nz[var] > 1 ? b->var_nz[var] : 1) * b->ny * b->nx, j;
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)n);
+    for (m = 0; m < M; ++m) {
+      b->data[var] = base + (long)m * per;
+      block_interp_one(b, var, n, x, y, z, tmp, is_f32);
+      for (j = m; j < n; j += M) out64[j] = tmp[j];
+    }
+    b->data[var] = base;
+    free(tmp);
+  }
+}
+
+static void block_interp_one(orc_block *b, int var, long n, const double *x,
                              const double *y, const double *z, double *out64,
                              int *is_f32) {
   long i;

@@ -493,6 +493,35 @@ def scenario_c16(g):
                     fallbacks={k: 0.0 for k in names + [HS]})
 
 
+def replay_c17(B, g, tag, nsteps):
+    """c17 golden: a reader whose current comes as a list of ensemble members -- element j of a call takes member j % M
+    (readers/interpolation/structured.py:119-135); RK4 (the stage calls map the same way), stranding (the ranks shift)."""
+    dt = float(g['dt'])
+    n = g[tag + '_lon'].shape[1]
+    out = []
+    names = [U, VV, LAND]
+    for k in range(nsteps):
+        t = k * dt
+        B.sample(names, t)
+        B.coast('stranding', code=1)
+        B.increase_age(dt)
+        B.compact()
+        B.store_previous()
+        B.advect('runge-kutta4', t, dt)
+        out.append(B.state(n))
+    return out
+
+
+def scenario_c17(g, tag):
+    from scenarios import Scenario
+    M = int(g['members'])
+    q = lambda k: g['%s_g_%s' % (tag, k)]
+    levels = [(float(t), {U: [q('u%d' % m)[i] for m in range(M)], VV: [q('v%d' % m)[i] for m in range(M)],
+                          LAND: q('land_binary_mask')[i]}) for i, t in enumerate(q('t'))]
+    z = g[tag + '_g_z'] if (tag + '_g_z') in g else None
+    return Scenario([('grid', dict(x=q('x'), y=q('y'), z=z, levels=levels))], fallbacks={U: 0.0, VV: 0.0})
+
+
 def replay_c7(B, g, sub, model, background, nsteps, start=0):
     """c7 golden: Euler current + vertical mixing with a wind-parameterised diffusivity profile.  `start`: first
     step to replay (the back end then holds golden row `start`)."""

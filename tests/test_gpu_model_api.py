@@ -650,3 +650,48 @@ def test_seed_at_and_above_the_seafloor():
     o.set_config('environment:fallback:sea_floor_depth_below_sea_level', None)
     with pytest.raises(ValueError, match='must be added before seeding elements at seafloor'):
         o.seed_elements(lon=4.0, lat=60.0, z='seafloor', time=T0)
+
+
+@pytest.mark.parametrize('tag', ['2d', '3d'])
+def test_c17_ensemble_reader_device_and_model_run(tag):
+    """Ensemble data (a reader that hands a variable out as a list of member arrays; element j of a call takes member
+    j % M, readers/interpolation/structured.py:119-135): the device kernels against the oracle and the reference's own
+    run (golden c17, RK4 + stranding so that the ranks shift), then the same through OceanDrift.run()."""
+    import replay
+    from opendrift_amd.device import Context
+    g = golden('c17_ensemble_reader.npz')
+    sub = {k: g['%s_%s' % (tag, k)] for k in ('lon', 'lat', 'z', 'status')}
+    ns = sub['lon'].shape[0] - 1
+    dev = replay.replay_c17(replay.DeviceBackend(replay.scenario_c17(g, tag), Context(seed=0), sub['lon'][0], sub['lat'][0],
+                                                 sub['z'][0], wdf=0.0), g, tag, ns)
+    orc = replay.replay_c17(replay.OracleBackend(replay.scenario_c17(g, tag), sub['lon'][0], sub['lat'][0], sub['z'][0],
+                                                 wdf=0.0), g, tag, ns)
+    for k, ((lo1, la1, z1, s1), (lo2, la2, z2, s2)) in enumerate(zip(dev, orc)):
+        assert np.array_equal(s1, s2)
+        assert np.nanmax(np.abs(lo1 - lo2)) < 1e-10 * (k + 1) and np.nanmax(np.abs(la1 - la2)) < 1e-10 * (k + 1)
+    replay.compare(dev, sub, tol_pos=1e-7, tol_z=1e-5)
+    # the model API
+    M = int(g['members'])
+    q = lambda k: g['%s_g_%s' % (tag, k)]
+    times = [T0 + timedelta(seconds=float(t)) for t in q('t')]
+    arrays = {'x_sea_water_velocity': [q('u%d' % m) for m in range(M)], 'y_sea_water_velocity': [q('v%d' % m) for m in range(M)],
+              'land_binary_mask': q('land_binary_mask')}
+    o = OceanDrift(loglevel=50, seed=0)
+    r = readers.GridReader(q('x'), q('y'), times, arrays, z=g[tag + '_g_z'] if tag == '3d' else None)
+    # whole-domain blocks, as the golden's reader hands them out: the reference's nearest-neighbour index of the land mask
+    # (interpolators.py:32-37, scaled by len(grid)) is not invariant under cutting the block, and one element that strands
+    # a step later shifts every later element's member
+    r.get_variables = lambda req, time=None, x=None, y=None, z=None, _f=r.get_variables: _f(req, time, None, None, z)
+    o.add_reader(r)
+    o.set_config('drift:advection_scheme', 'runge-kutta4')
+    o.set_config('general:coastline_action', 'stranding')
+    o.set_config('general:coastline_approximation_precision', None)
+    o.set_config('drift:stokes_drift', False)
+    o.set_config('drift:vertical_mixing', False)
+    o.seed_elements(lon=sub['lon'][0], lat=sub['lat'][0], z=sub['z'][0], time=T0, wind_drift_factor=0.0)
+    o.run(time_step=float(g['dt']), steps=ns)
+    n = sub['lon'].shape[1]
+    lon, lat = _final(o, n)[:2]
+    act = sub['status'][-1] == 0
+    assert act.sum() == o.num_elements_active() and (~act).sum() > 10
+    assert np.abs(lon - sub['lon'][-1]).max() < 1e-7 and np.abs(lat - sub['lat'][-1]).max() < 1e-7

@@ -289,3 +289,15 @@ def test_c16_openoil_in_sea_ice_vs_oracle():
     B0.wind(dt, wdd=float(g['wind_drift_depth']))
     B0.stokes(dt, profile=2, hs_mode=1, tp_mode=3)
     assert np.abs(B0.lon - g['lon'][1]).max() > 1e-4
+
+
+@pytest.mark.parametrize('tag', ['2d', '3d'])
+def test_c17_ensemble_members_of_a_reader_vs_oracle(tag):
+    """ReaderBlock ensembles (readers/interpolation/structured.py:119-135): golden c17 = the reference's own OceanDrift on
+    a reader that hands the current out as a list of three member arrays, RK4 + stranding."""
+    g = golden('c17_ensemble_reader.npz')
+    sub = {k: g['%s_%s' % (tag, k)] for k in ('lon', 'lat', 'z', 'status')}
+    B = replay.OracleBackend(replay.scenario_c17(g, tag), sub['lon'][0], sub['lat'][0], sub['z'][0], wdf=0.0)
+    worst = replay.compare(replay.replay_c17(B, g, tag, sub['lon'].shape[0] - 1), sub, tol_pos=1e-7, tol_z=1e-5)
+    print('c17', tag, 'oracle vs reference:', worst)
+    assert (sub['status'][-1] > 0).sum() > 10
