@@ -47,6 +47,8 @@ struct odr_ctx {
   float *prep[2];
   size_t prep_floats;
   int *dilate_flags;   // [NVAR][16]: "sweep k gave a cell a value" (k_blk_dilate_row stops at the fixed point)
+  // page-locked bounce buffers for copies from / to caller memory: [0] compute stream, [1] upload stream (odr_i_h2d)
+  void *bounce[2];
   Staged staged[MAXSRC][MAXLEVELS];
   std::vector<Retired> graveyard;
   std::vector<void *> source_bufs;  // device arrays owned by sources (curvilinear node tables)
@@ -216,6 +218,45 @@ static inline bool build_vmix_desc(const odr_ctx *c, double t, VMixDesc &D) {
   D.Kfb = c->hw.fallback[VAR_KZ];
   return true;
 }
+
+// ---- copies between CALLER memory and the device go through a page-locked bounce buffer of the context, chunk by chunk.
+// Handing pageable caller memory to hipMemcpyAsync lets the runtime pin the caller's pages on the fly for transfers above
+// ~1 MB and read them later; with NumPy arrays that live in the malloc heap this produced a sporadic
+// "Memory access fault by GPU ... on address <heap address>" (a 1.6 MB array at an address an earlier, freed array had
+// been pinned at), aborting the process.  The bounce buffer is the only host memory the GPU ever touches on these paths.
+// Synchronous by construction (one buffer): every call site synchronised right after the copy anyway.
+constexpr size_t ODR_BOUNCE_BYTES = 8u << 20;
+static inline int odr_i_bounce(odr_ctx *c, int which, void **buf) {
+  if (!c->bounce[which]) HIPCHK(hipHostMalloc(&c->bounce[which], ODR_BOUNCE_BYTES, hipHostMallocDefault));
+  *buf = c->bounce[which];
+  return 0;
+}
+static inline int odr_i_h2d(odr_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t st, int which = 0) {
+  void *b;
+  int rc = odr_i_bounce(c, which, &b);
+  if (rc) return rc;
+  for (size_t o = 0; o < bytes; o += ODR_BOUNCE_BYTES) {
+    const size_t m = std::min(ODR_BOUNCE_BYTES, bytes - o);
+    memcpy(b, (const char *)src + o, m);
+    HIPCHK(hipMemcpyAsync((char *)dst + o, b, m, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  return 0;
+}
+static inline int odr_i_d2h(odr_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t st, int which = 0) {
+  void *b;
+  int rc = odr_i_bounce(c, which, &b);
+  if (rc) return rc;
+  for (size_t o = 0; o < bytes; o += ODR_BOUNCE_BYTES) {
+    const size_t m = std::min(ODR_BOUNCE_BYTES, bytes - o);
+    HIPCHK(hipMemcpyAsync(b, (const char *)src + o, m, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy((char *)dst + o, b, m);
+  }
+  return 0;
+}
+#define H2D(dst, src, bytes) do { int rc_ = odr_i_h2d(c, (dst), (src), (bytes), c->stream); if (rc_) return rc_; } while (0)
+#define D2H(dst, src, bytes) do { int rc_ = odr_i_d2h(c, (dst), (src), (bytes), c->stream); if (rc_) return rc_; } while (0)
 
 static inline bool source_has_members(const DevSource &s) {
   for (int v = 0; v < NVAR; ++v) if (s.members[v] > 1) return true;

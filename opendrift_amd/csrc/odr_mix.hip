@@ -26,7 +26,7 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
     size_t n = (size_t)ntimes * (size_t)p->n;
     if ((rc = scratch(c, p, sizeof(double) * n, &s))) return rc;
     du = (double *)s;
-    HIPCHK(hipMemcpyAsync(du, huni, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    H2D(du, huni, sizeof(double) * n);
     HIPCHK(hipStreamSynchronize(c->stream));
   }
   size_t lds = sizeof(double) * ((size_t)nzp * BLOCK + 3 * (size_t)nzp);
@@ -97,7 +97,7 @@ int odr_vmix_wind_profile(odr_ctx *c, odr_particles *p, int model, double backgr
     size_t n = (size_t)ntimes * (size_t)p->n;
     if ((rc = scratch(c, p, sizeof(double) * n, &s))) return rc;
     du = (double *)s;
-    HIPCHK(hipMemcpyAsync(du, huni, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    H2D(du, huni, sizeof(double) * n);
     HIPCHK(hipStreamSynchronize(c->stream));
   }
   int vadv = c->fuse_vadv;
@@ -178,9 +178,9 @@ int odr_oil_prepare_mixing(odr_ctx *c, odr_particles *p, double dt, double dt_mi
       HIPCHK(hipMalloc((void **)&c->oil_u, sizeof(double) * need));
       c->oil_u_n = need;
     }
-    HIPCHK(hipMemcpyAsync(c->oil_u, host_u_entrain, sizeof(double) * per, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->oil_u + per, host_u_intrusion, sizeof(double) * per, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->oil_u + 2 * per, host_u_diameter, sizeof(double) * (size_t)p->n, hipMemcpyHostToDevice, c->stream));
+    H2D(c->oil_u, host_u_entrain, sizeof(double) * per);
+    H2D(c->oil_u + per, host_u_intrusion, sizeof(double) * per);
+    H2D(c->oil_u + 2 * per, host_u_diameter, sizeof(double) * (size_t)p->n);
     HIPCHK(hipStreamSynchronize(c->stream));   // the host arrays are pageable and may change right after
     a.u_ent = c->oil_u; a.u_int = c->oil_u + per; du_d = c->oil_u + 2 * per;
   }
@@ -191,7 +191,7 @@ int odr_oil_prepare_mixing(odr_ctx *c, odr_particles *p, double dt, double dt_mi
     double h[OIL_STAT_N] = {0};
     h[OIL_STAT_MEAN_ZB] = c->oil_stat_host[0];
     h[OIL_STAT_DV50] = c->oil_stat_host[1];
-    HIPCHK(hipMemcpyAsync(c->oil_stat, h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    H2D(c->oil_stat, h, sizeof h);
     HIPCHK(hipStreamSynchronize(c->stream));
   } else {
     hipLaunchKernelGGL(k_oil_stats, g, b, 0, c->stream, v, a, c->oil_part);
@@ -232,7 +232,7 @@ int odr_oil_local_sums(odr_ctx *c, odr_particles *p, double interfacial_tension,
   hipLaunchKernelGGL(k_oil_stats, dim3(nb), dim3(BLOCK), 0, c->stream, view(p), a, part);
   hipLaunchKernelGGL(k_oil_stats_final, dim3(1), dim3(BLOCK), 0, c->stream, part, (int)nb, 1LL, stat);   // n = 1: the sums
   double h[OIL_STAT_N];
-  HIPCHK(hipMemcpyAsync(h, stat, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  D2H(h, stat, sizeof h);
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipFree(part));
   *sum_dv50 = h[OIL_STAT_DV50];
@@ -250,7 +250,7 @@ int odr_oil_set_mixing_stats(odr_ctx *c, double mean_zb, double dv50) {
 int odr_oil_mixing_stats(odr_ctx *c, double *mean_zb, double *dv50) {
   if (!c->oil_stat) return fail(ODR_ERR_STATE, "odr_oil_prepare_mixing has not run");
   double h[OIL_STAT_N];
-  HIPCHK(hipMemcpyAsync(h, c->oil_stat, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  D2H(h, c->oil_stat, sizeof h);
   HIPCHK(hipStreamSynchronize(c->stream));
   if (mean_zb) *mean_zb = h[OIL_STAT_MEAN_ZB];
   if (dv50) *dv50 = h[OIL_STAT_DV50];

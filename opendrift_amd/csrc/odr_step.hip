@@ -29,12 +29,12 @@ int odr_advect_set_noise(odr_ctx *c, odr_particles *p, double std_normal, double
     }
     double *d = c->noise_buf;
     if (host_main) {
-      HIPCHK(hipMemcpyAsync(d, host_main, sizeof(double) * per, hipMemcpyHostToDevice, c->stream));
+      H2D(d, host_main, sizeof(double) * per);
       N.main = d;
       d += per;
     }
     if (nstage) {
-      HIPCHK(hipMemcpyAsync(d, host_stage, sizeof(double) * per * (size_t)nstage, hipMemcpyHostToDevice, c->stream));
+      H2D(d, host_stage, sizeof(double) * per * (size_t)nstage);
       N.stage = d;
     }
     HIPCHK(hipStreamSynchronize(c->stream));   // the host arrays are pageable and may change right after

@@ -74,6 +74,7 @@ int odr_ctx_destroy(odr_ctx *c) {
   if (c->noise_buf) (void)hipFree(c->noise_buf);
   (void)hipFree(c->counter);
   (void)hipFree(c->dilate_flags);
+  for (int k = 0; k < 2; ++k) if (c->bounce[k]) (void)hipHostFree(c->bounce[k]);
   if (c->lanes_ready) {
     for (int l = 0; l < ODR_MAX_LANES; ++l) {
       (void)hipStreamDestroy(c->lane_stream[l]);
@@ -150,10 +151,10 @@ int odr_particles_destroy(odr_ctx *c, odr_particles *p) {
 template <class T>
 static int put(odr_ctx *c, T *dst, const T *src, long long n, T dflt) {
   if (src) {
-    HIPCHK(hipMemcpyAsync(dst, src, sizeof(T) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    H2D(dst, src, sizeof(T) * (size_t)n);
   } else {
     std::vector<T> tmp((size_t)n, dflt);
-    HIPCHK(hipMemcpyAsync(dst, tmp.data(), sizeof(T) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    H2D(dst, tmp.data(), sizeof(T) * (size_t)n);
     HIPCHK(hipStreamSynchronize(c->stream));
   }
   return 0;
@@ -186,7 +187,7 @@ int odr_particles_append(odr_ctx *c, odr_particles *p, int64_t n, const double *
     std::vector<int> ids((size_t)n);
     p->id_max = std::max(p->id_max, o + p->ndead + n - 1);
     for (long long k = 0; k < n; ++k) ids[(size_t)k] = (int)(o + p->ndead + k);
-    HIPCHK(hipMemcpyAsync(p->i32[0] + o, ids.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    H2D(p->i32[0] + o, ids.data(), sizeof(int) * (size_t)n);
     HIPCHK(hipStreamSynchronize(c->stream));
   }
   if ((rc = put<int>(c, p->i32[1] + o, nullptr, n, 0))) return rc;
@@ -208,7 +209,7 @@ int odr_particles_count(odr_ctx *, odr_particles *p, int64_t *na, int64_t *nd) {
 
 template <class T>
 static int get(odr_ctx *c, T *dst, const T *src, long long n) {
-  if (dst && n > 0) HIPCHK(hipMemcpyAsync(dst, src, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  if (dst && n > 0) D2H(dst, src, sizeof(T) * (size_t)n);
   return 0;
 }
 
@@ -240,13 +241,13 @@ int odr_particles_upload(odr_ctx *c, odr_particles *p, const double *lon, const 
   p->status_epoch++;
   p->epoch++;  // invalidates the cached reductions (reduce())
   size_t n = (size_t)p->n;
-  if (lon) HIPCHK(hipMemcpyAsync(p->d64[0], lon, 8 * n, hipMemcpyHostToDevice, c->stream));
-  if (lat) HIPCHK(hipMemcpyAsync(p->d64[1], lat, 8 * n, hipMemcpyHostToDevice, c->stream));
-  if (z) HIPCHK(hipMemcpyAsync(p->d64[2], z, 8 * n, hipMemcpyHostToDevice, c->stream));
-  if (moving) HIPCHK(hipMemcpyAsync(p->i32[2], moving, 4 * n, hipMemcpyHostToDevice, c->stream));
-  if (wdf) HIPCHK(hipMemcpyAsync(p->f32[0], wdf, 4 * n, hipMemcpyHostToDevice, c->stream));
-  if (cdf) HIPCHK(hipMemcpyAsync(p->f32[1], cdf, 4 * n, hipMemcpyHostToDevice, c->stream));
-  if (tv) HIPCHK(hipMemcpyAsync(p->f32[2], tv, 4 * n, hipMemcpyHostToDevice, c->stream));
+  if (lon) H2D(p->d64[0], lon, 8 * n);
+  if (lat) H2D(p->d64[1], lat, 8 * n);
+  if (z) H2D(p->d64[2], z, 8 * n);
+  if (moving) H2D(p->i32[2], moving, 4 * n);
+  if (wdf) H2D(p->f32[0], wdf, 4 * n);
+  if (cdf) H2D(p->f32[1], cdf, 4 * n);
+  if (tv) H2D(p->f32[2], tv, 4 * n);
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -276,7 +277,7 @@ int odr_particles_download_f32(odr_ctx *c, odr_particles *p, const char *name, f
   static const char *nf[4] = {"wind_drift_factor", "current_drift_factor", "terminal_velocity", "age_seconds"};
   for (int k = 0; k < 4; ++k)
     if (!strcmp(name, nf[k])) {
-      if (p->n) HIPCHK(hipMemcpyAsync(host, p->f32[k], sizeof(float) * (size_t)p->n, hipMemcpyDeviceToHost, c->stream));
+      if (p->n) D2H(host, p->f32[k], sizeof(float) * (size_t)p->n);
       HIPCHK(hipStreamSynchronize(c->stream));
       return 0;
     }
@@ -380,7 +381,7 @@ int odr_source_landmask(odr_ctx *c, int32_t nx, int32_t ny, double lon0, double 
   unsigned *d = nullptr;
   HIPCHK(hipMalloc((void **)&d, sizeof(unsigned) * nwords));
   c->source_bufs.push_back(d);
-  HIPCHK(hipMemcpy(d, words.data(), sizeof(unsigned) * nwords, hipMemcpyHostToDevice));
+  H2D(d, words.data(), sizeof(unsigned) * nwords);
   s.params[0] = lon0; s.params[1] = lat0; s.params[2] = dlon; s.params[3] = dlat;
   s.slot[0].nx = nx; s.slot[0].ny = ny;
   s.slot[0].data[VAR_LAND] = (const float *)d;
@@ -445,10 +446,10 @@ int odr_source_grid_curvilinear(odr_ctx *c, const double *lon, const double *lat
   HIPCHK(hipMalloc(&dt, m.tri_n.size() * sizeof(int32_t)));
   HIPCHK(hipMalloc(&db, m.bucket.size() * sizeof(int32_t)));
   c->source_bufs.push_back(dn); c->source_bufs.push_back(dv); c->source_bufs.push_back(dt); c->source_bufs.push_back(db);
-  HIPCHK(hipMemcpy(dn, m.nodes.data(), m.nodes.size() * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dv, m.tri_v.data(), m.tri_v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dt, m.tri_n.data(), m.tri_n.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(db, m.bucket.data(), m.bucket.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  H2D(dn, m.nodes.data(), m.nodes.size() * sizeof(double));
+  H2D(dv, m.tri_v.data(), m.tri_v.size() * sizeof(int32_t));
+  H2D(dt, m.tri_n.data(), m.tri_n.size() * sizeof(int32_t));
+  H2D(db, m.bucket.data(), m.bucket.size() * sizeof(int32_t));
   DevProj &p = c->hw.src[*sid].proj;
   p.kind = PROJ_CURVILINEAR;
   p.cv_nodes = (const D2 *)dn; p.cv_tri_v = (const int *)dv; p.cv_tri_n = (const int *)dt; p.cv_bucket = (const int *)db;
@@ -466,12 +467,12 @@ int odr_source_lonlat2xy(odr_ctx *c, int32_t sid, int64_t n, const double *lon, 
   if (rc) return rc;
   double *d = nullptr;
   HIPCHK(hipMalloc((void **)&d, 4 * sizeof(double) * (size_t)n));
-  HIPCHK(hipMemcpyAsync(d, lon, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(d + n, lat, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  H2D(d, lon, 8 * (size_t)n);
+  H2D(d + n, lat, 8 * (size_t)n);
   hipLaunchKernelGGL(k_lonlat2xy, dim3(nblk(n)), dim3(BLOCK), 0, c->stream, c->dw, sid, (long long)n, d, d + n, d + 2 * n, d + 3 * n);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(x, d + 2 * n, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(y, d + 3 * n, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  D2H(x, d + 2 * n, 8 * (size_t)n);
+  D2H(y, d + 3 * n, 8 * (size_t)n);
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipFree(d));
   return 0;
@@ -598,8 +599,17 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
     const int v = var_ids[k], nzv = var_nz[k] > 1 ? var_nz[k] : 1;
     const size_t n = plane * (size_t)nzv;
     float *buf = c->prep[0], *tmp = c->prep[1];
-    // unified addressing: data[k] may be a host (pageable / pinned) or a device pointer
-    HIPCHK(hipMemcpyAsync(buf, data[k], sizeof(float) * n, hipMemcpyDefault, st));
+    // data[k]: device memory, page-locked host memory (odr_host_register / hipHostMalloc: a true asynchronous DMA), or
+    // pageable host memory -- the latter through the upload stream's bounce buffer (see odr_i_h2d), which makes this
+    // variable's copy synchronous for the host
+    {
+      hipPointerAttribute_t at;
+      bool pageable = false;
+      if (hipPointerGetAttributes(&at, data[k]) != hipSuccess) { (void)hipGetLastError(); pageable = true; }
+      else pageable = at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeHost && at.type != hipMemoryTypeManaged;
+      if (pageable) { int rcb = odr_i_h2d(c, buf, data[k], sizeof(float) * n, st, 1); if (rcb) return rcb; }
+      else HIPCHK(hipMemcpyAsync(buf, data[k], sizeof(float) * n, hipMemcpyDefault, st));
+    }
     const unsigned g = (unsigned)((n + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(k_blk_mask, dim3(g), dim3(BLOCK), 0, st, buf, n);
     // ("Ensemble data currently not extrapolated towards seafloor", readers/interpolation/structured.py:58-60)
@@ -653,6 +663,11 @@ int odr_block_commit(odr_ctx *c, int32_t sid, int32_t slot) {
   Staged &S = c->staged[sid][slot];
   if (!S.base) return fail(ODR_ERR_STATE, "no staged block for source %d slot %d", sid, slot);
   HIPCHK(hipSetDevice(c->device));
+  // The caller may release (or overwrite) the host arrays of the staged level after this call: wait until the upload
+  // pipeline has consumed them.  (A copy from pageable memory is pinned on the fly and read by the copy engine LATER:
+  // arrays freed at commit time while it was still in flight showed up as a sporadic "Memory access fault by GPU" in
+  // whatever ran next.)  Normally the upload finished a reader period ago and this returns at once.
+  HIPCHK(hipEventSynchronize(c->up_done));
   // the compute stream must not read the new records before the upload pipeline has written them
   HIPCHK(hipStreamWaitEvent(c->stream, c->up_done, 0));
   DevSource &s = c->hw.src[sid];
@@ -994,7 +1009,7 @@ int odr_i_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var
   if (out_host) {
     for (int k = 0; k < nvars; ++k)
       if (out_host[k] && p->n > 0)
-        HIPCHK(hipMemcpyAsync(out_host[k], p->env[var_ids[k]], sizeof(float) * (size_t)p->n, hipMemcpyDeviceToHost, c->stream));
+        D2H(out_host[k], p->env[var_ids[k]], sizeof(float) * (size_t)p->n);
     HIPCHK(hipStreamSynchronize(c->stream));
   }
   return 0;
@@ -1003,7 +1018,7 @@ int odr_i_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var
 int odr_env_download(odr_ctx *c, odr_particles *p, int32_t var, float *out) {
   REQUIRE(var >= 0 && var < NVAR && out, "bad arguments");
   if (!p->env[var]) return fail(ODR_ERR_STATE, "variable %d has not been sampled", var);
-  if (p->n > 0) HIPCHK(hipMemcpyAsync(out, p->env[var], sizeof(float) * (size_t)p->n, hipMemcpyDeviceToHost, c->stream));
+  if (p->n > 0) D2H(out, p->env[var], sizeof(float) * (size_t)p->n);
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1014,7 +1029,7 @@ int odr_env_upload(odr_ctx *c, odr_particles *p, int32_t var, const float *host)
   p->env_cok[var] = false;
   int rc = ensure_env(c, p, var);
   if (rc) return rc;
-  if (p->n > 0) HIPCHK(hipMemcpyAsync(p->env[var], host, sizeof(float) * (size_t)p->n, hipMemcpyHostToDevice, c->stream));
+  if (p->n > 0) H2D(p->env[var], host, sizeof(float) * (size_t)p->n);
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1025,8 +1040,8 @@ static int host_to_scratch(odr_ctx *c, odr_particles *p, const double *a, const 
   if (rc) return rc;
   *da = (double *)s;
   *db = *da + n;
-  HIPCHK(hipMemcpyAsync(*da, a, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-  if (b) HIPCHK(hipMemcpyAsync(*db, b, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  H2D(*da, a, sizeof(double) * n);
+  if (b) H2D(*db, b, sizeof(double) * n);
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1163,14 +1178,14 @@ int odr_particles_set_property(odr_ctx *c, odr_particles *p, int slot, int64_t o
     HIPCHK(hipMalloc((void **)&p->aux[slot], sizeof(float) * (size_t)p->cap));
     HIPCHK(hipMemsetAsync(p->aux[slot], 0, sizeof(float) * (size_t)p->cap, c->stream));
   }
-  if (count) HIPCHK(hipMemcpyAsync(p->aux[slot] + offset, host, sizeof(float) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+  if (count) H2D(p->aux[slot] + offset, host, sizeof(float) * (size_t)count);
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 int odr_particles_get_property(odr_ctx *c, odr_particles *p, int slot, float *host) {
   REQUIRE(slot >= 0 && slot < 9 && host, "bad property slot");
   if (!p->aux[slot]) return fail(ODR_ERR_STATE, "property slot %d has not been set", slot);
-  if (p->n) HIPCHK(hipMemcpyAsync(host, p->aux[slot], sizeof(float) * (size_t)p->n, hipMemcpyDeviceToHost, c->stream));
+  if (p->n) D2H(host, p->aux[slot], sizeof(float) * (size_t)p->n);
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1236,7 +1251,7 @@ int odr_reduce_scalars(odr_ctx *c, odr_particles *p, double wdd, double *out16) 
   int rc = reduce(c, p, wdd, 0);
   if (rc) return rc;
   double r[R_N];
-  HIPCHK(hipMemcpyAsync(r, c->red, sizeof r, hipMemcpyDeviceToHost, c->stream));
+  D2H(r, c->red, sizeof r);
   HIPCHK(hipStreamSynchronize(c->stream));
   for (int k = 0; k < 16; ++k) out16[k] = k < R_N ? r[k] : 0;
   out16[R_LONMIN] = -r[R_LONMIN];
@@ -1257,14 +1272,14 @@ int odr_reduce_local(odr_ctx *c, odr_particles *p, double wdd, int relwind, doub
   int rc = reduce(c, p, wdd, relwind);
   if (rc) return rc;
   double r[R_N];
-  HIPCHK(hipMemcpyAsync(r, c->red, sizeof r, hipMemcpyDeviceToHost, c->stream));
+  D2H(r, c->red, sizeof r);
   HIPCHK(hipStreamSynchronize(c->stream));
   for (int k = 0; k < 16; ++k) out16[k] = k < R_N ? r[k] : 0;
   return 0;
 }
 int odr_reduce_install(odr_ctx *c, odr_particles *p, const double *in16) {
   REQUIRE(in16, "in16 NULL");
-  HIPCHK(hipMemcpyAsync(c->red, in16, sizeof(double) * R_N, hipMemcpyHostToDevice, c->stream));
+  H2D(c->red, in16, sizeof(double) * R_N);
   HIPCHK(hipStreamSynchronize(c->stream));   // in16 is pageable
   c->red_owner = p; c->red_epoch = p->epoch;
   c->red_pinned = 1;      // until odr_reduce_unpin: the calls in between do not reduce again
@@ -1351,7 +1366,7 @@ int odr_vertical_buoyancy(odr_ctx *c, odr_particles *p, double dt) {
 int odr_i_read_counter(odr_ctx *c, int64_t *out) {
   if (out) {
     unsigned long long v;
-    HIPCHK(hipMemcpyAsync(&v, c->counter, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    D2H(&v, c->counter, sizeof v);
     HIPCHK(hipStreamSynchronize(c->stream));
     *out = (int64_t)v;
   }
@@ -1487,7 +1502,7 @@ int odr_deactivate(odr_ctx *c, odr_particles *p, const uint8_t *mask, int32_t co
   void *s;
   int rc = scratch(c, p, (size_t)p->n, &s);
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(s, mask, (size_t)p->n, hipMemcpyHostToDevice, c->stream));
+  H2D(s, mask, (size_t)p->n);
   HIPCHK(hipStreamSynchronize(c->stream));
   hipLaunchKernelGGL(k_deactivate, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), (const unsigned char *)s, code);
   HIPCHK(hipGetLastError());
@@ -1563,7 +1578,7 @@ int odr_scan_status(odr_ctx *c, odr_particles *p, int64_t *n_kept, uint64_t *fla
   HIPCHK(hipMemsetAsync(c->counter + 1, 0, 2 * sizeof(unsigned long long), c->stream));
   hipLaunchKernelGGL(k_cmp_count, dim3(std::min(nb, 2048u)), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount, c->counter + 2, c->counter + 1);
   unsigned long long out[2];
-  HIPCHK(hipMemcpyAsync(out, c->counter + 1, sizeof out, hipMemcpyDeviceToHost, c->stream));
+  D2H(out, c->counter + 1, sizeof out);
   HIPCHK(hipStreamSynchronize(c->stream));
   if (n_kept) *n_kept = (int64_t)out[0];
   if (flags) *flags = out[1];
@@ -1854,11 +1869,11 @@ int odr_history_reset(odr_ctx *c, odr_history *h) {
 int odr_history_minmax(odr_ctx *c, odr_history *h, int32_t var_index, double *minval, double *maxval) {
   REQUIRE(h && var_index >= 0 && var_index < h->nvars && minval && maxval, "bad arguments");
   double init[2] = {-INFINITY, -INFINITY}, r[2];
-  HIPCHK(hipMemcpyAsync(h->red, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+  H2D(h->red, init, sizeof init);
   long long nrec = (long long)h->ntimes * h->ntraj;
   hipLaunchKernelGGL(k_hist_minmax, dim3(2048), dim3(BLOCK), 0, c->stream, h->buf, nrec, h->stride, var_index, h->red);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(r, h->red, sizeof r, hipMemcpyDeviceToHost, c->stream));
+  D2H(r, h->red, sizeof r);
   HIPCHK(hipStreamSynchronize(c->stream));
   *minval = r[0] == -INFINITY ? NAN : -r[0];
   *maxval = r[1] == -INFINITY ? NAN : r[1];
@@ -1900,18 +1915,18 @@ int odr_sgrid_create(odr_ctx *c, int32_t ny, int32_t nx, int32_t N, const double
   HIPCHK(hipMalloc((void **)&dS, sizeof(double) * (size_t)N));
   HIPCHK(hipMalloc((void **)&flag, sizeof(int)));
   HIPCHK(hipMalloc((void **)&g->zr, sizeof(double) * (size_t)M * (size_t)N));
-  HIPCHK(hipMemcpyAsync(dH, H, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(dC, Cs, sizeof(double) * (size_t)N, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(dS, s.data(), sizeof(double) * (size_t)N, hipMemcpyHostToDevice, c->stream));
+  H2D(dH, H, sizeof(double) * (size_t)M);
+  H2D(dC, Cs, sizeof(double) * (size_t)N);
+  H2D(dS, s.data(), sizeof(double) * (size_t)N);
   HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
   if (zeta) {
     HIPCHK(hipMalloc((void **)&dz, sizeof(double) * (size_t)M));
-    HIPCHK(hipMemcpyAsync(dz, zeta, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, c->stream));
+    H2D(dz, zeta, sizeof(double) * (size_t)M);
   }
   hipLaunchKernelGGL(k_roms_zrho, dim3(nblk(M)), dim3(BLOCK), 0, c->stream, dH, dz, Hc, dC, dS, N, M, vtransform, g->zr);
   hipLaunchKernelGGL(k_roms_zrho_positive, dim3(nblk(M * N)), dim3(BLOCK), 0, c->stream, g->zr, M * N, flag, 0);
   int hflag = 0;
-  HIPCHK(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  D2H(&hflag, flag, sizeof(int));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (hflag) hipLaunchKernelGGL(k_roms_zrho_positive, dim3(nblk(M * N)), dim3(BLOCK), 0, c->stream, g->zr, M * N, flag, 1);
   HIPCHK(hipGetLastError());
@@ -1937,7 +1952,7 @@ int odr_sgrid_destroy(odr_ctx *c, odr_sgrid *g) {
 
 int odr_sgrid_download_zrho(odr_ctx *c, odr_sgrid *g, double *out) {
   REQUIRE(g && out, "bad arguments");
-  HIPCHK(hipMemcpyAsync(out, g->zr, sizeof(double) * (size_t)g->N * g->ny * g->nx, hipMemcpyDeviceToHost, c->stream));
+  D2H(out, g->zr, sizeof(double) * (size_t)g->N * g->ny * g->nx);
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1959,7 +1974,7 @@ int odr_sgrid_zslice(odr_ctx *c, odr_sgrid *g, const void *field, int is_f64, in
       HIPCHK(hipMalloc(&g->fbuf, fbytes));
       g->fbuf_bytes = fbytes;
     }
-    HIPCHK(hipMemcpyAsync(g->fbuf, field, fbytes, hipMemcpyHostToDevice, c->stream));
+    H2D(g->fbuf, field, fbytes);
     dF = g->fbuf;
   }
   if (g->kmax_cap < kmax) {
@@ -1968,7 +1983,7 @@ int odr_sgrid_zslice(odr_ctx *c, odr_sgrid *g, const void *field, int is_f64, in
     HIPCHK(hipMalloc((void **)&g->Z, sizeof(double) * (size_t)kmax));
     g->kmax_cap = kmax;
   }
-  HIPCHK(hipMemcpyAsync(g->Z, Z, sizeof(double) * (size_t)kmax, hipMemcpyHostToDevice, c->stream));
+  H2D(g->Z, Z, sizeof(double) * (size_t)kmax);
   const size_t oel = (size_t)M * (size_t)kmax;
   if (g->out_elems[out_slot] < oel) {
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1996,7 +2011,7 @@ int odr_sgrid_zslice(odr_ctx *c, odr_sgrid *g, const void *field, int is_f64, in
   }
   HIPCHK(hipGetLastError());
   if (out_host64) {
-    HIPCHK(hipMemcpyAsync(out_host64, g->out64, sizeof(double) * oel, hipMemcpyDeviceToHost, c->stream));
+    D2H(out_host64, g->out64, sizeof(double) * oel);
     HIPCHK(hipStreamSynchronize(c->stream));
   }
   if (out_dev32) *out_dev32 = g->out32[out_slot];

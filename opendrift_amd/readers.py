@@ -491,6 +491,26 @@ class DeviceReaderBinding:
                 if len(self.slots) + len(self.staged) < self.NSLOTS:
                     self._upload(kn, extent, None, asynchronous=True)
 
+    def _page_locked(self, v, arr):
+        if isinstance(arr, (list, tuple)):       # ensemble members: stacked by the context
+            return arr
+        a = np.asarray(arr) if not isinstance(arr, np.ma.MaskedArray) else arr
+        if isinstance(a, np.ndarray) and not isinstance(a, np.ma.MaskedArray) and a.dtype == np.float32 and \
+                a.flags['C_CONTIGUOUS'] and any(lo <= a.ctypes.data and a.ctypes.data + a.nbytes <= hi
+                                                for lo, hi in getattr(self, '_pinned_ranges', [])):
+            return a
+        stage = self.__dict__.setdefault('_stage', {})
+        st = stage.get((self._ring, v))
+        if st is None or st.shape != a.shape:
+            st = np.empty(a.shape, np.float32)
+            try:
+                self.ctx.pin(st)
+            except Exception:
+                pass
+            stage[(self._ring, v)] = st
+        np.copyto(st, np.ma.filled(a, np.nan) if isinstance(a, np.ma.MaskedArray) else a, casting='unsafe')
+        return st
+
     def _upload(self, k, extent, broadcast, asynchronous):
         """One reader time level -> one device block (synchronously, or staged on the upload stream)."""
         r = self.reader
@@ -551,14 +571,21 @@ class DeviceReaderBinding:
         if asynchronous:
             if not self._pinned:     # page-lock the reader's in-memory arrays once: uploads become DMA transfers
                 self._pinned = True
+                self._pinned_ranges = []
                 for v in self.variables:
                     a = getattr(r, 'arrays', {}).get(v)
                     if isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags['C_CONTIGUOUS']:
                         try:
                             self.ctx.pin(a)
+                            self._pinned_ranges.append((a.ctypes.data, a.ctypes.data + a.nbytes))
                         except Exception:
                             pass
-            self.ctx.upload_block_async(self.sid, slot, t_ep, {v: block[v] for v in self.variables})
+            # what is not a contiguous float32 piece of page-locked memory (a window cut out of the reader's arrays, a
+            # masked or float64 array, ensemble lists) is copied into page-locked staging arrays of this binding, two
+            # sets in turn: the upload then is an asynchronous DMA transfer for these as well (pageable memory would go
+            # through the library's bounce buffer, synchronously)
+            self._ring = 1 - getattr(self, '_ring', 1)
+            self.ctx.upload_block_async(self.sid, slot, t_ep, {v: self._page_locked(v, block[v]) for v in self.variables})
             self.staged[k] = slot
             return
         if getattr(r, 's_levels', False):
