@@ -595,7 +595,7 @@ class OpenDriftSimulation(Configurable):
             if not vs:
                 continue
             try:
-                vals = b.evaluate_on_host(vs, self.time, d['lon'], d['lat'], d['z'])
+                vals = b.evaluate_on_host(vs, self.time, d['lon'], d['lat'], d['z'], element_ID=d['ID'])
             except Exception as e:      # the reference catches every exception of a reader call (environment.py:640-668)
                 self._reader_failed(name, b, e)
                 continue

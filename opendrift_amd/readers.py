@@ -133,9 +133,16 @@ class ConstantReader(ContinuousReader):
 
     def __init__(self, parameter_value_map=None, **kwargs):
         m = dict(parameter_value_map or kwargs)
+        self._element_ID = None
         if 'element_ID' in m:
-            raise NotImplementedError('per-element constants are not on the device path')
-        self._parameter_value_map = {k: float(np.atleast_1d(v)[0]) for k, v in m.items()}
+            # values per element (reader_constant.py:42-58,70-80): the listed IDs get their values, every other element
+            # NaN -> next reader / fallback.  Evaluated on the host at every sample (no closed form for the device).
+            self.device_kind = None
+            self._element_ID = True              # set to the IDs of the call by the model (environment.py:621-623)
+            self._ids = np.atleast_1d(np.asarray(m.pop('element_ID'))).astype(np.int64)
+            self._parameter_value_map = {k: np.atleast_1d(np.asarray(v, dtype=np.float64)) for k, v in m.items()}
+        else:
+            self._parameter_value_map = {k: float(np.atleast_1d(v)[0]) for k, v in m.items()}
         self.variables = list(self._parameter_value_map)
         self.proj4 = '+proj=latlong'
         self.xmin, self.xmax, self.ymin, self.ymax = -180, 180, -90, 90
@@ -145,7 +152,17 @@ class ConstantReader(ContinuousReader):
     def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
         out = {'time': time, 'x': x, 'y': y, 'z': z}
         for v in requested_variables:
-            out[v] = self._parameter_value_map[v] * np.ones(np.shape(x))
+            value = self._parameter_value_map[v]
+            if self._element_ID is None:
+                out[v] = value * np.ones(np.shape(x))
+                continue
+            ids = np.atleast_1d(self._element_ID)              # the IDs of this call's elements
+            a = np.full(np.shape(x), np.nan)
+            pos = {int(i): k for k, i in enumerate(self._ids)}
+            hit = np.array([int(i) in pos for i in ids], dtype=bool)
+            if hit.any():
+                a[hit] = value[0] if len(value) == 1 else value[[pos[int(i)] for i in ids[hit]]]
+            out[v] = a
         return out
 
 
@@ -395,9 +412,10 @@ class DeviceReaderBinding:
     def is_grid(self):
         return getattr(self.reader, 'device_kind', None) is None and not self.host_eval
 
-    def evaluate_on_host(self, variables, time, lon, lat, z):
+    def evaluate_on_host(self, variables, time, lon, lat, z, element_ID=None):
         """ContinuousReader._get_variables_interpolated_ (continuous.py:31-46): the reader's values exactly at the element
-        positions; NaN where it does not cover (position or time)."""
+        positions; NaN where it does not cover (position or time).  A reader that maps values to element IDs
+        (`_element_ID`, environment.py:621-623) is told the IDs of the positions it receives."""
         r = self.reader
         n = len(lon)
         out = {v: np.full(n, np.nan, np.float32) for v in variables}
@@ -410,6 +428,8 @@ class DeviceReaderBinding:
             ok &= (x >= r.xmin) & (x <= r.xmax) & (y >= r.ymin) & (y <= r.ymax)
         ok &= (z >= r.zmin) & (z <= r.zmax)
         if ok.any():
+            if getattr(r, '_element_ID', None) is not None and element_ID is not None:
+                r._element_ID = np.asarray(element_ID)[ok]
             res = r.get_variables(list(variables), time, x[ok], y[ok], z[ok])
             for v in variables:
                 out[v][ok] = np.asarray(np.ma.filled(res[v], np.nan), dtype=np.float32) * np.ones(int(ok.sum()), np.float32)

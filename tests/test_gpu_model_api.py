@@ -695,3 +695,26 @@ def test_c17_ensemble_reader_device_and_model_run(tag):
     act = sub['status'][-1] == 0
     assert act.sum() == o.num_elements_active() and (~act).sum() > 10
     assert np.abs(lon - sub['lon'][-1]).max() < 1e-7 and np.abs(lat - sub['lat'][-1]).max() < 1e-7
+
+
+def test_constant_reader_with_values_per_element_id():
+    """reader_constant with an 'element_ID' entry (reader_constant.py:42-80, environment.py:621-623): the listed IDs get
+    their own values, the other elements fall through to the next reader / the fallback.  Euler drift over 3 steps with
+    an eastward current per element: displacement proportional to the element's value."""
+    n = 12
+    ids = np.array([1, 4, 7, 10])
+    u = np.array([0.1, 0.2, 0.4, 0.8])
+    o = OceanDrift(loglevel=50, seed=0)
+    o.add_reader(readers.ConstantReader({'x_sea_water_velocity': u, 'y_sea_water_velocity': np.zeros(4), 'element_ID': ids}))
+    o.set_config('environment:fallback:x_sea_water_velocity', -0.05)
+    o.set_config('environment:fallback:y_sea_water_velocity', 0)
+    o.set_config('environment:fallback:land_binary_mask', 0)
+    o.set_config('drift:stokes_drift', False)
+    o.seed_elements(lon=np.full(n, 4.0), lat=np.full(n, 60.0), time=T0, wind_drift_factor=0.0)
+    o.run(time_step=600, steps=3)
+    e = o.elements
+    dx = (e.lon - 4.0) * 111319.49 * np.cos(np.radians(60.0))       # metres east, roughly
+    want = np.full(n, -0.05)
+    want[ids] = u
+    assert np.allclose(dx / 1800.0, want, rtol=5e-3), dx / 1800.0
+    assert np.allclose(o.environment.x_sea_water_velocity, want.astype(np.float32))
