@@ -66,6 +66,10 @@ def broadcast_block(arrays, shapes=None, src=0, device=None):
         if world > 1:
             dist.broadcast(t, src=src)
         out[k] = t
+    if device.type == 'cuda':
+        # the collective runs on RCCL's stream, the block is consumed on the library's upload stream: the tensors must
+        # be complete before their pointers are handed over (odr_block_upload_device)
+        torch.cuda.synchronize(device)
     return out
 
 

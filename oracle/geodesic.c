@@ -7,7 +7,7 @@
  *   opendrift/models/basemodel/__init__.py:4643-4657 and
  *   opendrift/models/physics_methods.py:632-666.
  * pyproj/PROJ are NOT vendored in the reference tree; parity of this file is
- * pinned in tests/test_oracle_geodesic.py against (i) an independent mpmath
+ * pinned in tests/test_oracle_golden.py (test_geodesic_*) against (i) an independent mpmath
  * 40-digit integration of the geodesic ODE on the ellipsoid, (ii) the
  * reference's own coarse known answers (tests/models/test_models.py:61-64,
  * tests/models/test_environment.py:30-51).
