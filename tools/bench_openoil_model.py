@@ -51,13 +51,22 @@ def main():
     o.seed_elements(lon=lon, lat=lat, z=0.0, time=t0, oil_type={'density': 900.0, 'viscosity': 0.005,
                                                                 'oil_water_interfacial_tension': 0.03})
     t_start = time.perf_counter()
+    if os.environ.get('ODR_PROFILE'):
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
     o.run(time_step=900, steps=a.steps, time_step_output=900 * a.steps, export_variables=['lon', 'lat', 'z', 'status'])
     o.ctx.sync()
     el = time.perf_counter() - t_start
+    if os.environ.get('ODR_PROFILE'):
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats('cumulative').print_stats(32)
     e = o.elements
     print(json.dumps({
         'metric': 'particle-steps/s through OpenOil.run() (model API, whole loop body)', 'particles': n, 'steps': a.steps,
         'vertical_mixing_with_oil_physics': not a.no_mixing, 'ms_per_step_including_setup': 1e3 * el / a.steps,
+        'timing': {k: v for k, v in getattr(o, 'timing', {}).items()},
         'value': n * a.steps / el, 'unit': 'particle-steps/s', 'active_at_end': int(o.num_elements_active()),
         'stranded': int(o.num_elements_deactivated()), 'share_at_surface': float((e.z == 0).mean()),
         'z_min': float(e.z.min()) if len(e.z) else None, 'status_categories': list(getattr(o, 'status_categories', []))}))
