@@ -479,7 +479,8 @@ def main():
         if pm.get('particles') == n:
             pmc = pm
     extras = {}
-    if rank == 0 and world == 1 and not a.no_extras and a.workload == 'c3' and not a.block_every and not a.small:
+    if rank == 0 and world == 1 and not a.no_extras and a.workload == 'c3' and not a.block_every and not a.small and \
+            not os.environ.get('ODR_BENCH_SKIP_PCIE'):
         # (i) PCIe-inclusive: a new reader time level (hourly fields, 10-minute steps) arrives from pinned host memory
         # every 6 steps on the upload stream inside the timed region
         pinned = {kk: ctx.pin(np.ascontiguousarray(fields['g'][kk])) for kk in fields['names']}
@@ -540,6 +541,7 @@ def main():
         if world == 1 and not a.no_extras and a.workload == 'c3' and not a.small and not a.block_every:
             P.close()
             P = None
+            ctx.close()       # the model builds its own context
             out['model_api'] = model_api_leg(fields, n, 48, dev)
             out['model_api']['vs_bare_sequence'] = out['model_api']['ms_per_step'] / out['ms_per_step']
         if not a.no_cpu and world == 1:
