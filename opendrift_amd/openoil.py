@@ -131,9 +131,13 @@ class OpenOil(OceanDrift):
             number = len(lon_a) if len(lon_a) > 1 else self.get_config('seed:number')
         self.keep_droplet_diameter = diameter is not None                       # :1638-1645
         z = kwargs.get('z')
-        if z is None:
-            z = self.get_config('seed:z')
-        zz = np.atleast_1d(z) * np.ones(number) if np.size(z) in (1, number) else np.atleast_1d(z)
+        if z is None:                                                           # :1646-1650
+            z = 'seafloor' if ('seed:seafloor' in self._config and self.get_config('seed:seafloor') is True) else \
+                self.get_config('seed:z')
+        if isinstance(z, str) and z[0:8] == 'seafloor':
+            zz = -np.ones(number)      # "z = -np.ones(number)" (:1655-1657): at the sea floor every element is a droplet
+        else:
+            zz = np.atleast_1d(z) * np.ones(number) if np.size(z) in (1, number) else np.atleast_1d(z)
         if np.sum(zz < 0) > 0 and diameter is None:                             # :1659-1700
             dsd = self.get_config('seed:droplet_size_distribution')
             if dsd == 'uniform':

@@ -321,3 +321,34 @@ def test_c16_openoil_run_in_sea_ice_reproduces_the_reference():
         o.P.close()
     assert np.abs(res[0][0] - g['lon'][6]).max() < 1e-7 and np.abs(res[0][1] - g['lat'][6]).max() < 1e-7
     assert np.abs(res[1][0] - g['lon'][6]).max() > 1e-4       # the ice matters
+
+
+def test_openoil_seeded_above_the_seafloor_gets_droplets_and_rises():
+    """tests/models/test_run.py:638-661 (test_seed_above_seafloor) in spirit: OpenOil.seed_elements(z='seafloor+M') treats
+    every element as a subsea droplet (openoil.py:1651-1660: diameters drawn), z starts M metres above the reader's sea
+    floor and the droplets rise."""
+    from opendrift_amd.openoil import OpenOil
+    from opendrift_amd import synthetic as synth
+    g = synth.grid3d(nx=64, ny=48, nz=8, nt=3, seed=1, coast=False)
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'sea_floor_depth_below_sea_level']
+    times = [T0 + timedelta(seconds=float(t)) for t in g['t']]
+    o = OpenOil(loglevel=50, seed=0)
+    o.add_reader(readers.GridReader(g['x'], g['y'], times, {k: g[k] for k in names}, z=g['z']))
+    o.set_config('environment:fallback:land_binary_mask', 0)
+    o.set_config('environment:fallback:x_wind', 0)
+    o.set_config('environment:fallback:y_wind', 0)
+    o.set_config('seed:droplet_diameter_min_subsea', 0.001)
+    o.set_config('seed:droplet_diameter_max_subsea', 0.001)
+    o.set_config('vertical_mixing:timestep', 5)
+    lon0, lat0 = float(np.mean(g['x'])), float(np.mean(g['y']))
+    np.random.seed(0)
+    o.seed_elements(lon=lon0, lat=lat0, z='seafloor+5', number=50, time=T0,
+                    oil_type={'density': 900.0, 'viscosity': 0.005, 'oil_water_interfacial_tension': 0.03})
+    assert np.all(o._sched['diameter'] == np.float32(0.001))
+    o.run(time_step=300, steps=3, time_step_output=300)
+    z0, z3 = o.result['z'][:, 0], o.result['z'][:, -1]
+    depth = o.result['sea_floor_depth_below_sea_level'][:, 0] if 'sea_floor_depth_below_sea_level' in o.result else None
+    assert np.all(z0 < -10) and np.all(z3 > z0 + 1.0)          # started deep, rose
+    if depth is not None:
+        assert np.allclose(z0, -depth + 5, atol=1e-3)
+    o.P.close()
