@@ -734,6 +734,7 @@ class OpenDriftSimulation(Configurable):
                 time_step_output = timedelta(seconds=time_step_output)
             if time_step_output.days >= 0 and time_step.days < 0:
                 time_step_output = -time_step_output
+        self.time_step_output = time_step_output      # (basemodel/__init__.py:1939-1958)
         ratio = time_step_output.total_seconds() / time_step.total_seconds()
         if ratio < 1:
             raise ValueError('Output time step must be equal or larger than calculation time step.')

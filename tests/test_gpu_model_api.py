@@ -718,3 +718,40 @@ def test_constant_reader_with_values_per_element_id():
     want[ids] = u
     assert np.allclose(dx / 1800.0, want, rtol=5e-3), dx / 1800.0
     assert np.allclose(o.environment.x_sea_water_velocity, want.astype(np.float32))
+
+
+def test_reference_kat_time_step_config():
+    """tests/models/test_run.py::test_time_step_config: time_step / time_step_output from arguments, from config, defaults."""
+    def model(**cfg):
+        o = OceanDrift(loglevel=50)
+        o.set_config('environment:fallback:land_binary_mask', 0)
+        for k, v in cfg.items():
+            o.set_config(k, v)
+        o.seed_elements(lon=4, lat=60, time=datetime.now())
+        return o
+    o = model()
+    o.run(steps=2)
+    assert o.time_step.total_seconds() == 3600 and o.time_step_output.total_seconds() == 3600
+    o = model()
+    o.run(steps=2, time_step=1800)
+    assert o.time_step.total_seconds() == 1800
+    o = model()
+    o.run(steps=2, time_step=1800, time_step_output=3600)
+    assert o.time_step.total_seconds() == 1800 and o.time_step_output.total_seconds() == 3600
+    o = model(**{'general:time_step_minutes': 15})
+    o.run(steps=2)
+    assert o.time_step.total_seconds() == 900 and o.time_step_output.total_seconds() == 900
+    o = model(**{'general:time_step_minutes': 15, 'general:time_step_output_minutes': 120})
+    o.run(steps=2)
+    assert o.time_step.total_seconds() == 900 and o.time_step_output.total_seconds() == 7200
+
+
+def test_reference_kat_seed_seafloor_config():
+    """tests/models/test_seed.py::test_seed_seafloor: seed:seafloor overrides z to the sea floor of the (constant) reader."""
+    o = OceanDrift(loglevel=50)
+    o.add_reader(readers.ConstantReader({'sea_floor_depth_below_sea_level': 200}))
+    o.set_config('environment:fallback:land_binary_mask', 0)
+    o.set_config('seed:seafloor', True)
+    o.seed_elements(lon=4, lat=60, time=T0)
+    o.run(steps=1, time_step=600)
+    assert abs(float(o.result['z'][0, 0]) + 200) < 1e-4
