@@ -755,3 +755,14 @@ def test_reference_kat_seed_seafloor_config():
     o.seed_elements(lon=4, lat=60, time=T0)
     o.run(steps=1, time_step=600)
     assert abs(float(o.result['z'][0, 0]) + 200) < 1e-4
+
+
+def test_reference_kat_skip_env_variable():
+    """tests/models/test_environment.py::test_skip_env_variable: the skip_if rule of required_variables (:1899-1906)."""
+    for mixing in (True, False):
+        o = OceanDrift(loglevel=50)
+        o.set_config('drift:vertical_mixing', mixing)
+        o.set_config('environment:constant:land_binary_mask', 0)
+        o.seed_elements(lon=3, lat=60, time=datetime.now())
+        o.run(steps=1)
+        assert ('ocean_vertical_diffusivity' in o.required_variables) is mixing
