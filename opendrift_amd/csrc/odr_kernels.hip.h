@@ -554,8 +554,16 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
     float dtf = (float)dt;
     double lon2, lat2;
     float u2, v2;
+    // projected readers: sines / cosines of the particle's own position once, the stage positions relative to it
+    ProjStart ps;
+    if (ODR_PROJ_ROTATES(PROJ) && s.proj.kind == PROJ_STERE_POLAR && s.proj.es != 0) {
+      double lw = lon;
+      if (s.lon_mode == 1) lw = np_mod(lw + 180.0, 360.0) - 180.0;
+      else if (s.lon_mode == 2) lw = np_mod(lw, 360.0);
+      ps = proj_start(s.proj, lw, lat);
+    }
     stage_pos(o, u1, v1, dtf, lon2, lat2);
-    uv_sample_fast<PROJ, IS3D, TILE>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u2, v2, T, tile_h);
+    uv_sample_fast<PROJ, IS3D, TILE>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u2, v2, T, tile_h, ps);
     if (NOISE) add_current_noise(N, 1, i, n, id, u2, v2);
     if (SCHEME == 1) {
       fu = __fmul_rn(f, u2);
@@ -563,10 +571,10 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
     } else {
       float u3, v3, u4, v4;
       stage_pos(o, u2, v2, dtf, lon2, lat2);
-      uv_sample_fast<PROJ, IS3D, TILE>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u3, v3, T, tile_h);
+      uv_sample_fast<PROJ, IS3D, TILE>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u3, v3, T, tile_h, ps);
       if (NOISE) add_current_noise(N, 2, i, n, id, u3, v3);
       stage_pos(o, u3, v3, dtf, lon2, lat2);
-      uv_sample_fast<PROJ, IS3D, TILE>(s, geo, tf, lon2, lat2, z, zb, fbu, fbv, u4, v4, T, tile_f);
+      uv_sample_fast<PROJ, IS3D, TILE>(s, geo, tf, lon2, lat2, z, zb, fbu, fbv, u4, v4, T, tile_f, ps);
       if (NOISE) add_current_noise(N, 3, i, n, id, u4, v4);
       fu = __fmul_rn(rk4_mix(u1, u2, u3, u4), f);
       fv = __fmul_rn(rk4_mix(v1, v2, v3, v4), f);
