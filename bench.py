@@ -541,7 +541,8 @@ def main():
         if world == 1 and not a.no_extras and a.workload == 'c3' and not a.small and not a.block_every:
             P.close()
             P = None
-            ctx.close()       # the model builds its own context
+            if not os.environ.get('ODR_BENCH_KEEP_CTX'):
+                ctx.close()   # the model builds its own context (two live contexts in one process cost 30 %)
             out['model_api'] = model_api_leg(fields, n, 48, dev)
             out['model_api']['vs_bare_sequence'] = out['model_api']['ms_per_step'] / out['ms_per_step']
         if not a.no_cpu and world == 1:

@@ -170,6 +170,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise OdrError('libodrift_hip.so is missing: run `python -c "import __graft_entry__ as g; '
                        'g.build()"` (hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+    # The HIP runtime maps a process's streams onto 4 hardware queues by default.  A context uses three streams (compute,
+    # block upload, result-buffer flush); with a second context, or PyTorch's and RCCL's streams, in the same process the
+    # compute and the upload stream end up sharing a queue and the uploads no longer overlap with the simulation (measured:
+    # OceanDrift.run() 2.4 instead of 1.8 ms per step, profiles/r02_ab_variants.txt section 15).  Read by the runtime when
+    # it initialises, so it only has an effect if no HIP call has been made yet; an explicit setting is left alone.
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     lib = C.CDLL(LIB_PATH)
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)
