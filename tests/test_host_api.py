@@ -136,3 +136,33 @@ def test_read_objectprop_layout(tmp_path):
     t = read_objectprop(str(f))
     assert list(t) == [1, 2] and t[1]['OBJKEY'] == 'PIW-1' and t[2]['Description'] == '>PIW, vertical PFD type III conscious'
     assert (t[1]['DWSLOPE'], t[1]['DWSTD'], t[1]['CWLSLOPE'], t[2]['CWRSTD']) == (0.96, 12.0, -0.54, 6.7)
+
+
+def test_constant_reader_values_per_element_id_on_the_host():
+    """reader_constant with 'element_ID' (reader_constant.py:42-80): the listed IDs get their values -- one value for all of
+    them or one each --, everything else NaN (the next reader's turn)."""
+    import numpy as np
+    from opendrift_amd import readers
+    r = readers.ConstantReader({'x_wind': np.array([1.0, 2.0, 3.0]), 'y_wind': 5.0, 'element_ID': [4, 9, 2]})
+    assert getattr(r, 'device_kind', 'constant') is None          # evaluated on the host at the element positions
+    r._element_ID = np.array([0, 2, 4, 7, 9])
+    out = r.get_variables(['x_wind', 'y_wind'], None, np.zeros(5), np.zeros(5), np.zeros(5))
+    assert np.array_equal(out['x_wind'], [np.nan, 3.0, 1.0, np.nan, 2.0], equal_nan=True)
+    assert np.array_equal(out['y_wind'], [np.nan, 5.0, 5.0, np.nan, 5.0], equal_nan=True)
+    plain = readers.ConstantReader({'x_wind': 3.0})
+    assert plain.device_kind == 'constant' and np.all(plain.get_variables(['x_wind'], None, np.zeros(3))['x_wind'] == 3.0)
+
+
+def test_grid_reader_hands_out_ensemble_members_as_a_list():
+    """basereader/structured.py:125-147: a variable may be a list of member arrays; the window cut applies to every member."""
+    import numpy as np
+    from datetime import datetime, timedelta
+    from opendrift_amd import readers
+    x, y = np.linspace(0, 9, 10), np.linspace(50, 57, 8)
+    t = [datetime(2020, 1, 1) + timedelta(hours=k) for k in range(2)]
+    members = [np.full((2, 8, 10), float(m), np.float32) + np.arange(10, dtype=np.float32) for m in range(3)]
+    r = readers.GridReader(x, y, t, {'x_sea_water_velocity': members, 'land_binary_mask': np.zeros((2, 8, 10), np.float32)})
+    b = r.get_variables(['x_sea_water_velocity', 'land_binary_mask'], t[1], np.array([4.2, 4.6]), np.array([53.1, 53.2]))
+    assert isinstance(b['x_sea_water_velocity'], list) and len(b['x_sea_water_velocity']) == 3
+    assert all(m.shape == b['land_binary_mask'].shape == (len(b['y']), len(b['x'])) for m in b['x_sea_water_velocity'])
+    assert len(b['x']) < 10 and b['x_sea_water_velocity'][2][0, 0] == 2.0 + b['x'][0]
