@@ -479,6 +479,11 @@ def main():
         if pm.get('particles') == n:
             pmc = pm
     extras = {}
+    if rank == 0 and world == 1 and not a.no_extras and a.workload == 'c3' and not a.small and not a.block_every:
+        # (0) the drop-in surface: OceanDrift.run() on the same inputs, in a context of its own (first of the extra legs: it
+        # came out 20 % slower when it ran after the upload leg below; the bare sequence's context and particles stay open)
+        extras['model_api'] = model_api_leg(fields, n, 48, dev)
+        extras['model_api']['vs_bare_sequence'] = extras['model_api']['ms_per_step'] / (1e3 * el_max / a.steps)
     if rank == 0 and world == 1 and not a.no_extras and a.workload == 'c3' and not a.block_every and not a.small and \
             not os.environ.get('ODR_BENCH_SKIP_PCIE'):
         # (i) PCIe-inclusive: a new reader time level (hourly fields, 10-minute steps) arrives from pinned host memory
@@ -538,13 +543,6 @@ def main():
                                      'issue_ms_at_peak': issue * 1e3, 'kernel_ms': k_ms, 'frac': issue * 1e3 / k_ms,
                                      'peak': '1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction', 'source': pmc_file}
         out.update(extras)
-        if world == 1 and not a.no_extras and a.workload == 'c3' and not a.small and not a.block_every:
-            P.close()
-            P = None
-            if not os.environ.get('ODR_BENCH_KEEP_CTX'):
-                ctx.close()   # the model builds its own context (two live contexts in one process cost 30 %)
-            out['model_api'] = model_api_leg(fields, n, 48, dev)
-            out['model_api']['vs_bare_sequence'] = out['model_api']['ms_per_step'] / out['ms_per_step']
         if not a.no_cpu and world == 1:
             out['cpu_baseline'] = cpu_baseline(a.workload, fields, a.cpu_particles, np.random.default_rng(5))
             ref = os.path.join(ROOT, 'profiles', 'r02_cpu_reference_numpy.json')
