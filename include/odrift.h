@@ -274,8 +274,10 @@ int odr_advect_sea_ice(odr_ctx *ctx, odr_particles *p, double dt, double factor)
 /* advect_wind (physics_methods.py:712-791) */
 int odr_advect_wind(odr_ctx *ctx, odr_particles *p, double dt, double wind_drift_depth,
                     int relative_wind, double factor);
-/* stokes_drift (physics_methods.py:793-848); profile 0 monochromatic, 1 exponential, 2 Phillips;
- * hs_mode/tp_mode 0 environment, 1 from wind, 2 scalar default */
+/* stokes_drift (physics_methods.py:793-848); profile 0 monochromatic, 1 exponential, 2 Phillips, 3 windsea_swell
+ * (stokes_drift_profile_windsea_swell :418-456: needs the six ODR_VAR_SWELL_* / ODR_VAR_WIND_WAVE_* variables sampled,
+ * hs_mode / tp_mode not used); hs_mode/tp_mode 0 environment, 1 from wind, 2 scalar default, tp_mode 3 from wind and
+ * read back as float32 */
 int odr_stokes_drift(odr_ctx *ctx, odr_particles *p, double dt, int profile, int hs_mode,
                      int tp_mode, double factor);
 /* model-specific float32 element properties (slots 0..8); for LeewayObj (models/leeway.py:50-131):

@@ -1074,31 +1074,10 @@ __device__ __forceinline__ TVal tdiv(TVal a, TVal b) {
   return r;
 }
 
-// stokes_drift (physics_methods.py:793-848) with the Breivik profiles (:336-416)
-__global__ __launch_bounds__(BLOCK) void k_stokes(PView p, double dt, int profile, int hs_mode,
-                                                  int tp_mode, double factor,
-                                                  const double *__restrict__ red) {
-  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= p.n) return;
-  if (red[R_STOKESMAX] == 0) return;  // "No Stokes drift velocity available" (:799-804)
-  double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
-  float sx = p.env[VAR_SX][i], sy = p.env[VAR_SY][i];
-  float speed = speed_f32(sx, sy);
-  float ws = 0.f;
-  if (hs_mode == 1 || tp_mode == 1 || tp_mode == 3) ws = speed_f32(p.env[VAR_XWIND][i], p.env[VAR_YWIND][i]);
-  TVal H, T;
-  if (hs_mode == 0) H = tv_(p.env[VAR_HS][i], 1);
-  else if (hs_mode == 1) H = tv_(__fmul_rn((float)0.0246, __fmul_rn(ws, ws)), 1);
-  else H = tv_(1, 0);
-  if (tp_mode == 0) T = tv_(p.env[VAR_TP][i], 1);
-  else if (tp_mode == 1 || tp_mode == 3) {
-    double omega = 5;
-    if (ws > 0) omega = __fdiv_rn((float)(0.877 * 9.81), __fmul_rn((float)1.17, ws));
-    T = tv_(__ddiv_rn(2 * kPi, omega), 2);
-    // a model that has the wave period among its variables (OpenOil) reads it back from the float32 environment
-    // (calculate_missing_environment_variables, physics_methods.py:876-883)
-    if (tp_mode == 3) T = tv_((float)T.v, 1);
-  } else T = tv_(8, 0);
+// one profile function of physics_methods.py:336-416 for one element: float32 surface components, wave height and period
+// with their NumPy dtype classes, depth -> (stokes_u, stokes_v) in float64
+__device__ __forceinline__ void stokes_profile(int profile, float sx, float sy, TVal H, TVal T, double z, double &su, double &sv) {
+  const float speed = speed_f32(sx, sy);
   TVal mwf = tdiv(tv_(2. * kPi, 0), T);
   TVal transport = tdiv(tmul(mwf, tmul(H, H)), tv_(16, 0));
   TVal num = tv_(speed, 1);
@@ -1114,9 +1093,64 @@ __global__ __launch_bounds__(BLOCK) void k_stokes(PView p, double dt, int profil
     unit = __dsub_rn(exp(__dmul_rn(k2, z)),
                      __dmul_rn(sqrt(__dmul_rn(c2, az)), erfc(sqrt(__dmul_rn(k2, az)))));
   }
+  su = speed == 0 ? 0.0 : __dmul_rn((double)sx, unit);
+  sv = speed == 0 ? 0.0 : __dmul_rn((double)sy, unit);
+}
+
+// stokes_drift (physics_methods.py:793-848) with the Breivik profiles (:336-416); profile 3 = 'windsea_swell'
+// (stokes_drift_profile_windsea_swell :418-456, Breivik & Christensen 2020): the surface drift split into a swell part along
+// the swell direction (monochromatic profile, swell height / period) and the wind-sea rest (Phillips profile, wind-sea
+// height / period); unit vectors and split in float32 like NumPy on the float32 environment, profiles in float64
+__global__ __launch_bounds__(BLOCK) void k_stokes(PView p, double dt, int profile, int hs_mode,
+                                                  int tp_mode, double factor,
+                                                  const double *__restrict__ red) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  if (red[R_STOKESMAX] == 0) return;  // "No Stokes drift velocity available" (:799-804)
+  double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
+  float sx = p.env[VAR_SX][i], sy = p.env[VAR_SY][i];
+  double su, sv;
+  if (profile == 3) {
+    const float rws = __fmul_rn(p.env[VAR_WW_DIR][i], (float)(kPi / 180.)), rsw = __fmul_rn(p.env[VAR_SWELL_DIR][i], (float)(kPi / 180.));
+    // np.cos / np.sin of a float32 array: float32 results.  Rounded from the float64 functions (= correctly rounded float32
+    // in all but ~1e-9 of the cases) so that device and CPU oracle hold the same unit vectors; NumPy's own float32 loops
+    // differ from that by one ulp in 17 % of the values (tests/test_oracle_golden.py, c18)
+    double sd, cd;
+    sincos((double)rws, &sd, &cd);
+    const float ws_n = (float)cd, ws_e = (float)sd;
+    sincos((double)rsw, &sd, &cd);
+    const float sw_n = (float)cd, sw_e = (float)sd;
+    const float numr = __fsub_rn(__fmul_rn(sx, ws_n), __fmul_rn(sy, ws_e));
+    const float den = __fsub_rn(__fmul_rn(sw_e, ws_n), __fmul_rn(sw_n, ws_e));
+    const float sp = __fdiv_rn(numr, den);
+    const float swu = __fmul_rn(sp, sw_e), swv = __fmul_rn(sp, sw_n);
+    const float wu = __fsub_rn(sx, swu), wv = __fsub_rn(sy, swv);
+    double u1, v1, u2, v2;
+    stokes_profile(0, swu, swv, tv_(p.env[VAR_SWELL_HS][i], 1), tv_(p.env[VAR_SWELL_TP][i], 1), z, u1, v1);
+    stokes_profile(2, wu, wv, tv_(p.env[VAR_WW_HS][i], 1), tv_(p.env[VAR_WW_TM][i], 1), z, u2, v2);
+    su = __dadd_rn(u1, u2);
+    sv = __dadd_rn(v1, v2);
+  } else {
+    float ws = 0.f;
+    if (hs_mode == 1 || tp_mode == 1 || tp_mode == 3) ws = speed_f32(p.env[VAR_XWIND][i], p.env[VAR_YWIND][i]);
+    TVal H, T;
+    if (hs_mode == 0) H = tv_(p.env[VAR_HS][i], 1);
+    else if (hs_mode == 1) H = tv_(__fmul_rn((float)0.0246, __fmul_rn(ws, ws)), 1);
+    else H = tv_(1, 0);
+    if (tp_mode == 0) T = tv_(p.env[VAR_TP][i], 1);
+    else if (tp_mode == 1 || tp_mode == 3) {
+      double omega = 5;
+      if (ws > 0) omega = __fdiv_rn((float)(0.877 * 9.81), __fmul_rn((float)1.17, ws));
+      T = tv_(__ddiv_rn(2 * kPi, omega), 2);
+      // a model that has the wave period among its variables (OpenOil) reads it back from the float32 environment
+      // (calculate_missing_environment_variables, physics_methods.py:876-883)
+      if (tp_mode == 3) T = tv_((float)T.v, 1);
+    } else T = tv_(8, 0);
+    stokes_profile(profile, sx, sy, H, T, z, su, sv);
+  }
   if (p.ice == 2) factor = (double)ice_stokes_factor(p.env[VAR_ICE_A][i]);   // stokes_u*factor: float64 * float32 array
-  double su = speed == 0 ? 0.0 : __dmul_rn(__dmul_rn((double)sx, unit), factor);
-  double sv = speed == 0 ? 0.0 : __dmul_rn(__dmul_rn((double)sy, unit), factor);
+  su = __dmul_rn(su, factor);
+  sv = __dmul_rn(sv, factor);
   move_f64(lon, lat, su, sv, p.moving[i], dt);
   p.lon[i] = lon;
   p.lat[i] = lat;

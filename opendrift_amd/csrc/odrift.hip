@@ -1305,10 +1305,15 @@ int odr_advect_wind(odr_ctx *c, odr_particles *p, double dt, double wdd, int rel
 }
 
 int odr_stokes_drift(odr_ctx *c, odr_particles *p, double dt, int profile, int hs_mode, int tp_mode, double factor) {
-  REQUIRE(profile >= 0 && profile <= 2 && hs_mode >= 0 && hs_mode <= 2 && tp_mode >= 0 && tp_mode <= 3, "bad stokes options");
+  REQUIRE(profile >= 0 && profile <= 3 && hs_mode >= 0 && hs_mode <= 2 && tp_mode >= 0 && tp_mode <= 3, "bad stokes options");
   if (!p->env[VAR_SX] || !p->env[VAR_SY]) return fail(ODR_ERR_STATE, "Stokes drift has not been sampled");
-  if ((hs_mode == 0 && !p->env[VAR_HS]) || (tp_mode == 0 && !p->env[VAR_TP])) return fail(ODR_ERR_STATE, "Hs/Tp not sampled");
-  if ((hs_mode == 1 || tp_mode == 1 || tp_mode == 3) && (!p->env[VAR_XWIND] || !p->env[VAR_YWIND])) return fail(ODR_ERR_STATE, "wind not sampled");
+  if (profile == 3) {   // windsea_swell: its own six variables instead of Hs / Tp / wind
+    for (int v : {VAR_SWELL_DIR, VAR_SWELL_TP, VAR_SWELL_HS, VAR_WW_DIR, VAR_WW_TM, VAR_WW_HS})
+      if (!p->env[v]) return fail(ODR_ERR_STATE, "the windsea_swell profile needs the swell / wind-sea direction, period and height (variable %d not sampled)", v);
+  } else {
+    if ((hs_mode == 0 && !p->env[VAR_HS]) || (tp_mode == 0 && !p->env[VAR_TP])) return fail(ODR_ERR_STATE, "Hs/Tp not sampled");
+    if ((hs_mode == 1 || tp_mode == 1 || tp_mode == 3) && (!p->env[VAR_XWIND] || !p->env[VAR_YWIND])) return fail(ODR_ERR_STATE, "wind not sampled");
+  }
   if (p->n == 0) return 0;
   if (env_is_const(p, VAR_SX, 0.0f) && env_is_const(p, VAR_SY, 0.0f)) return 0;   // "No Stokes drift velocity available" (:799-804)
   int rc = reduce(c, p, 0.0, 0, false);

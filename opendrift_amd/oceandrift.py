@@ -687,9 +687,8 @@ class OpenDriftSimulation(Configurable):
     def stokes_drift(self, factor=1):
         if self.get_config('drift:stokes_drift') is False:
             return
-        profile = {'monochromatic': 0, 'exponential': 1, 'Phillips': 2}.get(self.get_config('drift:stokes_drift_profile', 'Phillips'))
-        if profile is None:
-            raise NotImplementedError('windsea_swell Stokes profile is not on the device path')
+        profile = {'monochromatic': 0, 'exponential': 1, 'Phillips': 2, 'windsea_swell': 3}[
+            self.get_config('drift:stokes_drift_profile', 'Phillips')]
         if self._identically_zero('sea_surface_wave_stokes_drift_x_velocity') and \
                 self._identically_zero('sea_surface_wave_stokes_drift_y_velocity'):
             return      # "No Stokes drift velocity available" (physics_methods.py:799-804) without a device round trip
@@ -768,7 +767,8 @@ class OpenDriftSimulation(Configurable):
         for vn, var in list(self.required_variables.items()):
             if 'skip_if' in var:
                 key, op, val = var['skip_if']
-                if self.get_config(key) is val:
+                cur = self.get_config(key)
+                if {'is': cur is val, '==': cur == val, '!=': cur != val}[op]:
                     self.required_variables.pop(vn)
         self.time = self.start_time
         # the lon / lat box the elements can reach (:2017-2035): readers are prepared for it
@@ -1081,6 +1081,16 @@ class OceanDrift(OpenDriftSimulation):
         'ocean_mixed_layer_thickness': {'fallback': 50, 'skip_if': ['drift:vertical_mixing', 'is', False]},
         'sea_floor_depth_below_sea_level': {'fallback': 10000},
         'land_binary_mask': {'fallback': None},
+        # the inputs of drift:stokes_drift_profile = 'windsea_swell' (physics_methods.py:831-841).  The reference's stock
+        # models do not list them (a run with that profile ends with an AttributeError there); here they are sampled
+        # when -- and only when -- the profile is selected.
+        'sea_surface_swell_wave_to_direction': {'fallback': 0, 'skip_if': ['drift:stokes_drift_profile', '!=', 'windsea_swell']},
+        'sea_surface_swell_wave_peak_period_from_variance_spectral_density': {
+            'fallback': 0, 'skip_if': ['drift:stokes_drift_profile', '!=', 'windsea_swell']},
+        'sea_surface_swell_wave_significant_height': {'fallback': 0, 'skip_if': ['drift:stokes_drift_profile', '!=', 'windsea_swell']},
+        'sea_surface_wind_wave_to_direction': {'fallback': 0, 'skip_if': ['drift:stokes_drift_profile', '!=', 'windsea_swell']},
+        'sea_surface_wind_wave_mean_period': {'fallback': 0, 'skip_if': ['drift:stokes_drift_profile', '!=', 'windsea_swell']},
+        'sea_surface_wind_wave_significant_height': {'fallback': 0, 'skip_if': ['drift:stokes_drift_profile', '!=', 'windsea_swell']},
     }
 
     def __init__(self, *args, **kwargs):

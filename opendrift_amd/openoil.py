@@ -174,9 +174,12 @@ class OpenOil(OceanDrift):
     def stokes_drift(self, factor=1):
         if self.get_config('drift:stokes_drift') is False:
             return
-        profile = {'monochromatic': 0, 'exponential': 1, 'Phillips': 2}.get(self.get_config('drift:stokes_drift_profile', 'Phillips'))
-        if profile is None:
-            raise NotImplementedError('windsea_swell Stokes profile is not on the device path')
+        profile = {'monochromatic': 0, 'exponential': 1, 'Phillips': 2, 'windsea_swell': 3}[
+            self.get_config('drift:stokes_drift_profile', 'Phillips')]
+        if profile == 3 and 'sea_surface_swell_wave_to_direction' not in self.required_variables:
+            # OpenOil does not list the swell / wind-sea variables (the reference stops with an AttributeError here)
+            raise AttributeError("'Environment' has no 'sea_surface_swell_wave_to_direction': add the six windsea_swell "
+                                 "variables to required_variables in a subclass")
         r, hs_mode, tp_mode = self._wave_modes()
         if r['stokes_sum_max'] == 0:
             return

@@ -160,6 +160,16 @@ void orc_stokes_drift_ef(long n, double *lon, double *lat, const double *z,
                          const float *ywind, int hs_mode, int tp_mode, int profile,
                          double factor, const float *efac, double dt);
 
+/* stokes_drift_profile_windsea_swell (physics_methods.py:418-456): (stokes_u, stokes_v) at depth z */
+void orc_stokes_windsea_swell(long n, const double *z, const float *sx, const float *sy,
+                              const float *swell_dir, const float *swell_tp, const float *swell_hs,
+                              const float *ww_dir, const float *ww_tm, const float *ww_hs,
+                              double *out_u, double *out_v);
+void orc_stokes_drift_windsea_swell(long n, double *lon, double *lat, const double *z, const int *moving,
+                                    const float *sx, const float *sy, const float *swell_dir, const float *swell_tp,
+                                    const float *swell_hs, const float *ww_dir, const float *ww_tm, const float *ww_hs,
+                                    double factor, double dt);
+
 /* horizontal_diffusion (basemodel/__init__.py:1746-1772), normals drawn by the caller */
 void orc_horizontal_diffusion(long n, double *lon, double *lat, const int *moving,
                               const float *D, const double *nx, const double *ny, double dt);

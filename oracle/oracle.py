@@ -360,6 +360,23 @@ def stokes_drift(lon, lat, z, moving, sx, sy, hs, tp, xwind, ywind, hs_mode, tp_
                               _p(ef, C.c_float) if ef is not None else None, C.c_double(dt))
 
 
+def stokes_windsea_swell(z, sx, sy, swell_dir, swell_tp, swell_hs, ww_dir, ww_tm, ww_hs):
+    """stokes_drift_profile_windsea_swell (physics_methods.py:418-456): (stokes_u, stokes_v), float64"""
+    n = np.size(sx)
+    u, v = np.empty(n), np.empty(n)
+    lib().orc_stokes_windsea_swell(C.c_long(n), _p(_d(z), C.c_double), *[_p(_f(a), C.c_float) for a in (
+        sx, sy, swell_dir, swell_tp, swell_hs, ww_dir, ww_tm, ww_hs)], _p(u, C.c_double), _p(v, C.c_double))
+    return u, v
+
+
+def stokes_drift_windsea_swell(lon, lat, z, moving, sx, sy, swell_dir, swell_tp, swell_hs, ww_dir, ww_tm, ww_hs, factor, dt):
+    n = lon.size
+    lib().orc_stokes_drift_windsea_swell(C.c_long(n), _p(lon, C.c_double), _p(lat, C.c_double), _p(_d(z), C.c_double),
+                                         _p(_i(moving), C.c_int), *[_p(_f(a), C.c_float) for a in (
+                                             sx, sy, swell_dir, swell_tp, swell_hs, ww_dir, ww_tm, ww_hs)],
+                                         C.c_double(factor), C.c_double(dt))
+
+
 def horizontal_diffusion(lon, lat, moving, D, nx, ny, dt):
     n = lon.size
     lib().orc_horizontal_diffusion(C.c_long(n), _p(lon, C.c_double), _p(lat, C.c_double),

@@ -607,6 +607,73 @@ void orc_stokes_drift(long n, double *lon, double *lat, const double *z,
 /* the same with a per-element float32 factor (OpenOil.advect_oil in ice: factor_stokes, openoil.py:1200-1213) and
  * tp_mode 3 = parameterised from the wind, then read back from the float32 environment (a model that has the wave
  * period among its variables: calculate_missing_environment_variables, physics_methods.py:876-883) */
+/* one profile function of physics_methods.py:336-416 for one element: surface components (float32), wave height and
+ * period with their NumPy dtype classes, depth -> (stokes_u, stokes_v) float64 */
+static void stokes_profile(int profile, float sxs, float sys, tval H, tval T, double zz, double *su, double *sv) {
+  float speed = speed_f32(sxs, sys); /* float32 */
+  tval mwf, pw, transport, num, km;
+  double unit, az = fabs(zz);
+  mwf = tdiv(tv_(2. * PI, K_WEAK), T);               /* stokes_transport_monochromatic :332-334 */
+  pw = tmul(H, H);                                   /* np.power(H, 2) */
+  transport = tdiv(tmul(mwf, pw), tv_(16, K_WEAK));
+  num = tv_(speed, K_F32);
+  if (profile == 2) num = tmul(num, tv_(1 - 2 * 1.0 / 3, K_WEAK)); /* (1-2*beta/3) */
+  km = tdiv(num, tmul(tv_(2, K_WEAK), transport));
+  if (profile == 0) unit = exp(tmul(tv_(2, K_WEAK), km).v * zz);
+  else if (profile == 1) {
+    tval ke = tdiv(km, tv_(3, K_WEAK));
+    unit = exp(tmul(tv_(2.0, K_WEAK), ke).v * zz) / (1.0 - tmul(tv_(8.0, K_WEAK), ke).v * zz);
+  } else {
+    double k2 = tmul(tv_(2, K_WEAK), km).v, c2 = tmul(tv_(2 * PI, K_WEAK), km).v;
+    unit = exp(k2 * zz) - 1 * sqrt(c2 * az) * erfc(sqrt(k2 * az));
+  }
+  *su = speed == 0 ? 0 : (double)sxs * unit;
+  *sv = speed == 0 ? 0 : (double)sys * unit;
+}
+
+/* stokes_drift_profile_windsea_swell (physics_methods.py:418-456; Breivik & Christensen 2020): the surface Stokes drift
+ * split into a swell part along the swell direction (monochromatic profile with the swell height / period) and a
+ * wind-sea part (the rest; Phillips profile with the wind-sea height / period).  All inputs float32 environment arrays:
+ * the unit vectors and the split are float32 arithmetic, the profiles float64. */
+void orc_stokes_windsea_swell(long n, const double *z, const float *sx, const float *sy,
+                              const float *swell_dir, const float *swell_tp, const float *swell_hs,
+                              const float *ww_dir, const float *ww_tm, const float *ww_hs,
+                              double *out_u, double *out_v) {
+  long i;
+  for (i = 0; i < n; ++i) {
+    volatile float rws = ww_dir[i] * (float)(PI / 180.), rsw = swell_dir[i] * (float)(PI / 180.);   /* np.radians, float32 */
+    /* float32 cos / sin as the rounded float64 functions (correctly rounded float32 but for ~1e-9 of the arguments) */
+    float ws_n = (float)cos((double)rws), ws_e = (float)sin((double)rws), sw_n = (float)cos((double)rsw), sw_e = (float)sin((double)rsw);
+    volatile float a1 = sx[i] * ws_n, a2 = sy[i] * ws_e, numr = a1 - a2;
+    volatile float d1 = sw_e * ws_n, d2 = sw_n * ws_e, den = d1 - d2;
+    volatile float sp = numr / den;
+    volatile float swu = sp * sw_e, swv = sp * sw_n;
+    volatile float wu = sx[i] - swu, wv = sy[i] - swv;
+    double u1, v1, u2, v2;
+    stokes_profile(0, swu, swv, tv_(swell_hs[i], K_F32), tv_(swell_tp[i], K_F32), z[i], &u1, &v1);
+    stokes_profile(2, wu, wv, tv_(ww_hs[i], K_F32), tv_(ww_tm[i], K_F32), z[i], &u2, &v2);
+    out_u[i] = u1 + u2;
+    out_v[i] = v1 + v2;
+  }
+}
+
+/* stokes_drift with drift:stokes_drift_profile = 'windsea_swell' (physics_methods.py:793-848) */
+void orc_stokes_drift_windsea_swell(long n, double *lon, double *lat, const double *z, const int *moving,
+                                    const float *sx, const float *sy, const float *swell_dir, const float *swell_tp,
+                                    const float *swell_hs, const float *ww_dir, const float *ww_tm, const float *ww_hs,
+                                    double factor, double dt) {
+  double *su = (double *)malloc(sizeof(double) * (size_t)n);
+  double *sv = (double *)malloc(sizeof(double) * (size_t)n);
+  float mx = -INFINITY;
+  long i;
+  for (i = 0; i < n; ++i) { volatile float s = sx[i] + sy[i]; if (s > mx) mx = s; }
+  if (n == 0 || mx == 0) { free(su); free(sv); return; } /* "No Stokes drift velocity available" */
+  orc_stokes_windsea_swell(n, z, sx, sy, swell_dir, swell_tp, swell_hs, ww_dir, ww_tm, ww_hs, su, sv);
+  for (i = 0; i < n; ++i) { su[i] *= factor; sv[i] *= factor; }
+  orc_update_positions_f64(n, lon, lat, su, sv, moving, dt);
+  free(su); free(sv);
+}
+
 void orc_stokes_drift_ef(long n, double *lon, double *lat, const double *z,
                          const int *moving, const float *sx, const float *sy,
                          const float *hs_in, const float *tp_in, const float *xwind,
@@ -619,10 +686,9 @@ void orc_stokes_drift_ef(long n, double *lon, double *lat, const double *z,
   for (i = 0; i < n; ++i) { volatile float s = sx[i] + sy[i]; if (s > mx) mx = s; }
   if (n == 0 || mx == 0) { free(su); free(sv); return; } /* "No Stokes drift velocity available" */
   for (i = 0; i < n; ++i) {
-    float speed = speed_f32(sx[i], sy[i]); /* float32 */
     float ws = (hs_mode == 1 || tp_mode == 1 || tp_mode == 3) ? speed_f32(xwind[i], ywind[i]) : 0.f;
-    tval H, T, mwf, pw, transport, num, km;
-    double unit, az;
+    tval H, T;
+    double u, v, f = efac ? (double)efac[i] : factor;
     if (hs_mode == 0) H = tv_(hs_in[i], K_F32);
     else if (hs_mode == 1) { volatile float w2 = ws * ws; volatile float h = (float)0.0246 * w2; H = tv_(h, K_F32); }
     else H = tv_(1, K_WEAK);
@@ -633,23 +699,9 @@ void orc_stokes_drift_ef(long n, double *lon, double *lat, const double *z,
       T = tv_((2 * PI) / omega, K_F64);
       if (tp_mode == 3) { volatile float tf = (float)T.v; T = tv_(tf, K_F32); }
     } else T = tv_(8, K_WEAK);
-    mwf = tdiv(tv_(2. * PI, K_WEAK), T);               /* stokes_transport_monochromatic :332-334 */
-    pw = tmul(H, H);                                   /* np.power(H, 2) */
-    transport = tdiv(tmul(mwf, pw), tv_(16, K_WEAK));
-    num = tv_(speed, K_F32);
-    if (profile == 2) num = tmul(num, tv_(1 - 2 * 1.0 / 3, K_WEAK)); /* (1-2*beta/3) */
-    km = tdiv(num, tmul(tv_(2, K_WEAK), transport));
-    az = fabs(z[i]);
-    if (profile == 0) unit = exp(tmul(tv_(2, K_WEAK), km).v * z[i]);
-    else if (profile == 1) {
-      tval ke = tdiv(km, tv_(3, K_WEAK));
-      unit = exp(tmul(tv_(2.0, K_WEAK), ke).v * z[i]) / (1.0 - tmul(tv_(8.0, K_WEAK), ke).v * z[i]);
-    } else {
-      double k2 = tmul(tv_(2, K_WEAK), km).v, c2 = tmul(tv_(2 * PI, K_WEAK), km).v;
-      unit = exp(k2 * z[i]) - 1 * sqrt(c2 * az) * erfc(sqrt(k2 * az));
-    }
-    su[i] = speed == 0 ? 0 : (double)sx[i] * unit * (efac ? (double)efac[i] : factor);
-    sv[i] = speed == 0 ? 0 : (double)sy[i] * unit * (efac ? (double)efac[i] : factor);
+    stokes_profile(profile, sx[i], sy[i], H, T, z[i], &u, &v);
+    su[i] = u * f;      /* stokes_u*factor (:843) */
+    sv[i] = v * f;
   }
   orc_update_positions_f64(n, lon, lat, su, sv, moving, dt);
   free(su); free(sv);

@@ -766,3 +766,27 @@ def test_reference_kat_skip_env_variable():
         o.seed_elements(lon=3, lat=60, time=datetime.now())
         o.run(steps=1)
         assert ('ocean_vertical_diffusivity' in o.required_variables) is mixing
+
+
+def test_windsea_swell_profile_through_the_model():
+    """drift:stokes_drift_profile = 'windsea_swell': the six swell / wind-sea variables are sampled when the profile is
+    selected (the reference's stock models do not list them and stop with an AttributeError); a swell-only sea state
+    (no wind sea: the whole surface drift is swell) gives the monochromatic profile with the swell's height and period."""
+    env = {'sea_surface_wave_stokes_drift_x_velocity': 0.0, 'sea_surface_wave_stokes_drift_y_velocity': 0.1,
+           'sea_surface_swell_wave_to_direction': 0.0, 'sea_surface_swell_wave_peak_period_from_variance_spectral_density': 10.0,
+           'sea_surface_swell_wave_significant_height': 2.0, 'sea_surface_wind_wave_to_direction': 90.0,
+           'sea_surface_wind_wave_mean_period': 4.0, 'sea_surface_wind_wave_significant_height': 0.5}
+    res = {}
+    for profile, extra in (('windsea_swell', {}), ('monochromatic', {'sea_surface_wave_significant_height': 2.0})):
+        o = OceanDrift(loglevel=50, seed=0)
+        o.add_reader(readers.ConstantReader({**env, **extra, 'x_sea_water_velocity': 0.0, 'y_sea_water_velocity': 0.0}))
+        o.set_config('environment:fallback:land_binary_mask', 0)
+        o.set_config('drift:stokes_drift', True)
+        o.set_config('drift:stokes_drift_profile', profile)
+        o.seed_elements(lon=np.full(5, 4.0), lat=np.full(5, 60.0), z=-np.arange(5.0), time=T0, wind_drift_factor=0.0)
+        o.run(time_step=600, steps=3)
+        assert ('sea_surface_swell_wave_to_direction' in o.required_variables) == (profile == 'windsea_swell')
+        res[profile] = o.elements.lat.copy()
+    d = (res['windsea_swell'] - 60.0) * 111200.0            # metres north
+    assert d[0] > 150 and np.all(np.diff(d) < 0)            # 0.1 m/s * 1800 s at the surface, decaying with depth
+    assert np.all(np.abs(res['windsea_swell'] - 60.0) > 0)

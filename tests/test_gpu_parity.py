@@ -546,3 +546,34 @@ def test_c11_known_answers_through_the_model_api(case):
     z[o.elements.ID] = o.elements.z
     assert abs(z.min() - zmin) < 0.05 and abs(z.max() - zmax) < 0.05 and abs(z.mean() - zmean) < 0.05
     assert np.abs(z - g['z_final_%d' % case]).max() < 1e-6
+
+
+def test_windsea_swell_stokes_profile_device_vs_oracle(ctx):
+    """odr_stokes_drift with profile 3 = drift:stokes_drift_profile 'windsea_swell' (physics_methods.py:418-456, 831-841):
+    swell part (monochromatic profile) + wind-sea part (Phillips profile) from six float32 environment variables, against
+    the CPU oracle (itself pinned by the reference's own function, golden c18).  Tolerance 1e-9 deg: device and libm
+    cosf / sinf may differ by an ulp, amplified where the two directions are nearly parallel."""
+    from conftest import golden
+    g = golden('c18_windsea_swell_profile.npz')
+    n = len(g['sx'])
+    rng = np.random.default_rng(3)
+    lon, lat = rng.uniform(3, 6, n), rng.uniform(58, 62, n)
+    names = {'sea_surface_wave_stokes_drift_x_velocity': g['sx'], 'sea_surface_wave_stokes_drift_y_velocity': g['sy'],
+             'sea_surface_swell_wave_to_direction': g['swell_dir'],
+             'sea_surface_swell_wave_peak_period_from_variance_spectral_density': g['swell_tp'],
+             'sea_surface_swell_wave_significant_height': g['swell_hs'], 'sea_surface_wind_wave_to_direction': g['ww_dir'],
+             'sea_surface_wind_wave_mean_period': g['ww_tm'], 'sea_surface_wind_wave_significant_height': g['ww_hs']}
+    P = ctx.particles(n)
+    P.append(lon, lat, z=g['z'])
+    for k, v in names.items():
+        P.env_upload(k, v.astype(np.float32))
+    P.stokes_drift(900.0, profile=3)
+    got = P.download()
+    lo, la = lon.copy(), lat.copy()
+    orc.stokes_drift_windsea_swell(lo, la, g['z'], np.ones(n, np.int32), g['sx'], g['sy'], g['swell_dir'], g['swell_tp'],
+                                   g['swell_hs'], g['ww_dir'], g['ww_tm'], g['ww_hs'], 1.0, 900.0)
+    o = np.argsort(got['ID'])
+    cond = np.abs(np.sin(np.radians(g['swell_dir'].astype(float) - g['ww_dir'].astype(float))))
+    d = np.maximum(np.abs(got['lon'][o] - lo), np.abs(got['lat'][o] - la))
+    assert d.max() < 1e-9 and d[cond > 0.5].max() < 1e-10 and np.median(d) < 1e-13
+    assert np.abs(lo - lon).max() > 1e-4          # it moved

@@ -301,3 +301,18 @@ def test_c17_ensemble_members_of_a_reader_vs_oracle(tag):
     worst = replay.compare(replay.replay_c17(B, g, tag, sub['lon'].shape[0] - 1), sub, tol_pos=1e-7, tol_z=1e-5)
     print('c17', tag, 'oracle vs reference:', worst)
     assert (sub['status'][-1] > 0).sum() > 10
+
+
+def test_c18_windsea_swell_stokes_profile_vs_reference_function():
+    """stokes_drift_profile_windsea_swell (physics_methods.py:418-456) evaluated by the reference itself on float32
+    environment-like arrays (golden c18).  Agreement is exact to float64 round-off wherever NumPy's float32 cos / sin
+    (SIMD, not correctly rounded: 17 % of the values differ from libm's by one ulp) and libm agree; a one-ulp difference of
+    a unit vector is amplified where swell and wind sea run nearly parallel (the split divides by the sine of their angle)."""
+    g = golden('c18_windsea_swell_profile.npz')
+    u, v = orc.stokes_windsea_swell(g['z'], g['sx'], g['sy'], g['swell_dir'], g['swell_tp'], g['swell_hs'], g['ww_dir'],
+                                    g['ww_tm'], g['ww_hs'])
+    err = np.hypot(u - g['stokes_u'], v - g['stokes_v'])
+    assert np.isfinite(err).all() and err.max() < 1e-6 and np.median(err) < 1e-15
+    assert (u[:20] == 0).all() and (v[:20] == 0).all()              # zero surface drift stays zero
+    cond = np.abs(np.sin(np.radians(g['swell_dir'].astype(float) - g['ww_dir'].astype(float))))
+    assert err[cond > 0.5].max() < 5e-8
