@@ -347,6 +347,61 @@ def model_api_leg(fields, n, steps, device):
                 'vertical advection, horizontal diffusion early-out)')
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` on its own (no RANK / WORLD_SIZE in the environment) starts its N ranks itself: this
+    process becomes the launcher of `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same
+    arguments>` (one process per GPU, rendezvous on 127.0.0.1, a free port), rank 0 prints the one JSON line.  Under the
+    driver's own torchrun launch WORLD_SIZE is set and nothing is spawned."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # the host driver only supports dmabuf IPC (RCCL over xGMI)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def plumbing_only(a):
+    """--plumbing-only: the N-rank machinery of this script WITHOUT the device path -- rendezvous, the ID shards, one field
+    block broadcast from rank 0, the barrier-bracketed loop, max / sum over the ranks, rank 0's single line.  What a box
+    without N GPUs can check (tests/test_bench_spawn.py, gloo); `value` is null: it measures nothing."""
+    from opendrift_amd import distributed as D
+    rank, local_rank, world = D.init(backend=os.environ.get('ODR_DIST_BACKEND') or None)
+    n = a.particles or 1000
+    fields = make_fields(a.workload, True)
+    lo, hi = D.shard_range(n * world, rank, world)
+    ok = hi - lo == n
+    if fields is not None:
+        g = fields['g']
+        names = fields['names']
+        arrays = {k: g[k][0] for k in names} if rank == 0 else None
+        tens = D.broadcast_block(arrays, shapes={k: g[k][0].shape for k in names}, src=0)
+        ok = ok and all(np.array_equal(tens[k].cpu().numpy(), g[k][0], equal_nan=True) for k in names)
+    D.barrier()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        pass
+    el = time.perf_counter() - t0
+    D.barrier()
+    el_max = float(D.allreduce_scalars([el], 'max')[0])
+    units = float(D.allreduce_scalars([float(n * a.steps)], 'sum')[0])
+    all_ok = float(D.allreduce_scalars([1.0 if ok else 0.0], 'min')[0]) == 1.0
+    if rank == 0:
+        print(json.dumps({'metric': 'particle-steps/sec (plumbing only: nothing measured)', 'value': None, 'unit': 'particle-steps/s',
+                          'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': None, 'higher_is_better': True,
+                          'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'plumbing_only': True,
+                          'shards_ok': all_ok, 'units_all_ranks': units, 'loop_s_max_over_ranks': el_max,
+                          'config': {'workload': a.workload, 'particles_per_gpu': n, 'particles_total': n * world}}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return 0 if all_ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -363,7 +418,17 @@ def main():
                     help='re-upload one field time level from host memory every N steps inside the timed region '
                          '(PCIe-inclusive rate, DESIGN.md section 5; 0 = inputs resident, the headline)')
     ap.add_argument('--block-async', action='store_true', help='with --block-every: odr_block_upload_async from pinned arrays')
+    ap.add_argument('--plumbing-only', action='store_true',
+                    help='rendezvous, shards, block broadcast and the reductions of the N-rank run without the device path '
+                         '(no GPU needed; value is null)')
     a = ap.parse_args()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(a))      # this process is the launcher; its ranks re-enter main() with RANK / WORLD_SIZE set
+    if int(os.environ.get('WORLD_SIZE', 1)) != a.gpus:
+        print('bench.py: --gpus %d but WORLD_SIZE=%s: the launcher decides, running %s rank(s)'
+              % (a.gpus, os.environ.get('WORLD_SIZE', '1'), os.environ.get('WORLD_SIZE', '1')), file=sys.stderr)
+    if a.plumbing_only:
+        sys.exit(plumbing_only(a))
 
     import torch
     from opendrift_amd import distributed as D
