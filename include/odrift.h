@@ -219,6 +219,16 @@ int odr_env_add_noise(odr_ctx *ctx, odr_particles *p, int32_t var_x, int32_t var
  * with odr_step_extras.main_noise (NULL otherwise). */
 int odr_advect_set_noise(odr_ctx *ctx, odr_particles *p, double std_normal, double std_uniform, int rng_mode,
                          const double *host_main, const double *host_stage, int nstage, uint64_t step);
+/* Arithmetic of the Runge-Kutta STAGE evaluations inside odr_advect / odr_env_coast_advect (physics_methods.py:629-670: the
+ * sub-stage position geod.fwd(lon, lat, azimuth, speed*dt*.5) and the get_environment call of the current there).
+ *   ODR_STAGE_EXACT (default): every float32 rounding point of the reference inside a stage is reproduced (float32
+ *     azimuth / distance, each (time, z) layer of the ReaderBlock rounded to float32): <= 1e-10 deg per step vs the oracle.
+ *   ODR_STAGE_FAST: stage step taken directly along (u, v) dt/2, the stage value of a gridded reader as one float32
+ *     weighted sum of its 16 corner values: <= 2e-9 deg per step vs the oracle (the stage value is a few float32 ulp off).
+ * The main-loop sample (o.environment), the RK combination and the final update_positions are identical in both modes;
+ * Euler is unaffected.  Applies to every particle set of the context from the next call on. */
+enum { ODR_STAGE_EXACT = 0, ODR_STAGE_FAST = 1 };
+int odr_ctx_set_stage_math(odr_ctx *ctx, int mode);
 /* PhysicsMethods.advect_ocean_current (physics_methods.py:611-691) + update_positions
  * (basemodel/__init__.py:4631-4657), all sub-stages fused in one kernel. */
 int odr_advect(odr_ctx *ctx, odr_particles *p, int scheme, double t_epoch, double dt, double factor);

@@ -30,6 +30,7 @@ VARIABLE_NAMES = {v: k for k, v in VARIABLES.items()}
 PROJ_LATLONG, PROJ_STERE_EQUIT_SPHERE, PROJ_STERE_POLAR = 0, 1, 2
 SCHEME = {'euler': 0, 'runge-kutta': 1, 'runge-kutta4': 2}
 RNG_DEVICE, RNG_HOST = 0, 1
+STAGE_MATH = {'exact': 0, 'fast': 1}     # odr_ctx_set_stage_math
 COAST = {'none': 0, 'stranding': 1, 'previous': 2}
 # odr_history variable codes of the element properties (include/odrift.h ODR_HIST_*); environment
 # variables use their ODR_VAR_* id
@@ -95,6 +96,7 @@ _SIGNATURES = {
     'odr_env_upload': [_vp, _vp, C.c_int32, _fp],
     'odr_env_add_noise': [_vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_int, C.c_int, _dp, _dp, C.c_uint64],
     'odr_advect_set_noise': [_vp, _vp, C.c_double, C.c_double, C.c_int, _dp, _dp, C.c_int, C.c_uint64],
+    'odr_ctx_set_stage_math': [_vp, C.c_int],
     'odr_advect': [_vp, _vp, C.c_int, C.c_double, C.c_double, C.c_double],
     'odr_env_coast_advect': [_vp, _vp, C.c_int, _ip, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_double, C.c_double, _vp, _P(C.c_int64)],

@@ -8,9 +8,26 @@
 
 namespace odr {
 
+// -DODR_PHASE_TIMING (developer build, tools/vbuild.sh): per-phase shader cycles of k_step_grid, summed over waves
+// (s_memtime stamps where the phase's results are consumed; dumped by odr_i_phase_dump at context destruction)
+#ifdef ODR_PHASE_TIMING
+__device__ unsigned long long g_phase[32];
+#define ODR_PT_DECL unsigned long long pt_[24] = {0}
+#define ODR_PT(k) do { if (pt_) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pt_[k] = __builtin_readcyclecounter(); } } while (0)
+#define ODR_PT_USE(x) asm volatile("" :: "v"(x))
+#define ODR_PT_ARG , pt_
+#define ODR_PT_PARAM , unsigned long long *pt_ = nullptr
+#else
+#define ODR_PT_DECL
+#define ODR_PT(k)
+#define ODR_PT_USE(x)
+#define ODR_PT_ARG
+#define ODR_PT_PARAM
+#endif
+
 constexpr int NVAR = 26;
-constexpr int MAXLEVELS = 4;
-constexpr int MAXSRC = 8;
+constexpr int MAXLEVELS = 6;   // resident time levels per reader: t0, t0 + dt/2 and t0 + dt may each sit between two different levels
+constexpr int MAXSRC = 16;
 constexpr int MAXNZ = 64;
 constexpr int MAXLIST = 4;
 
@@ -432,17 +449,29 @@ __device__ __forceinline__ int nearest_index(double v, double vmin, double vrang
 // The interval is found by counting the (wave-uniform) levels below z; its node, slope and index
 // value come from the per-source tables the host filled with the same IEEE operations interp1d
 // performs -- no per-particle divide and no dependent table walk.
-__device__ __forceinline__ void zinterp(const DevSource &s, double z, int &ia, int &ib, double &wa) {
+// ZT: the three interp1d tables of the source come from the workgroup's LDS copy `zt` ([0] zi_x, [MAXNZ] zi_slope,
+// [2 MAXNZ] zi_y; zt_stage()) instead of the source in global memory -- the index is per lane, so the global form is a
+// vector-memory round trip in front of the gathers that need the bracket.  The level count reads the (wave-uniform) levels
+// four per scalar load; zasc is padded with +inf beyond nz (round 3: a scalar load + wait per level and the table gather
+// were 3 500 cycles of a wave's life in k_step_grid).
+template <bool ZT = false>
+__device__ __forceinline__ void zinterp(const DevSource &s, double z, int &ia, int &ib, double &wa, const double *zt = nullptr) {
   const int nz = s.nz;
   const double zmin = s.zasc[0], zmax = s.zasc[nz - 1];  // zgrid.min()/max(): monotone grids only
   z = z < zmin ? zmin : z;
   z = z > zmax ? zmax : z;
   int hi = 0;
-  for (int k = 0; k < nz; ++k) hi += s.zasc[k] < z ? 1 : 0;
+  for (int k = 0; k < nz; k += 4) {
+    const double a0 = s.zasc[k], a1 = s.zasc[k + 1], a2 = s.zasc[k + 2], a3 = s.zasc[k + 3];   // MAXNZ is a multiple of 4
+    hi += (a0 < z ? 1 : 0) + (a1 < z ? 1 : 0) + (a2 < z ? 1 : 0) + (a3 < z ? 1 : 0);
+  }
   hi = hi < 1 ? 1 : hi;
   hi = hi > nz - 1 ? nz - 1 : hi;
   const int lo = hi - 1;
-  double zi = __dadd_rn(__dmul_rn(s.zi_slope[lo], z - s.zi_x[lo]), s.zi_y[lo]);
+  double tx, ts, tyv;
+  if constexpr (ZT) { tx = zt[lo]; ts = zt[MAXNZ + lo]; tyv = zt[2 * MAXNZ + lo]; }
+  else { tx = s.zi_x[lo]; ts = s.zi_slope[lo]; tyv = s.zi_y[lo]; }
+  double zi = __dadd_rn(__dmul_rn(ts, z - tx), tyv);
   ia = (int)(signed char)(long long)floor(zi);
   ia = ia < 0 ? 0 : ia;
   ib = ia + 1 < nz - 1 ? ia + 1 : nz - 1;
@@ -731,10 +760,17 @@ struct UVTime {
 struct __attribute__((aligned(4))) F4 { float x, y, z, w; };
 
 struct ZBracket { int iz0, same; double wa; };  // levels (ia, ib): ia = iz0 + (same?1:0) ...
-__device__ __forceinline__ ZBracket zbracket(const DevSource &s, double z) {
+// the workgroup's copy of the interp1d tables of source `s` (call from every thread, before any divergence)
+__device__ __forceinline__ void zt_stage(const DevSource &s, double *zt) {
+  const int t = threadIdx.x;
+  if (t < s.nz) { zt[t] = s.zi_x[t]; zt[MAXNZ + t] = s.zi_slope[t]; zt[2 * MAXNZ + t] = s.zi_y[t]; }
+  __syncthreads();
+}
+template <bool ZT = false>
+__device__ __forceinline__ ZBracket zbracket(const DevSource &s, double z, const double *zt = nullptr) {
   ZBracket zb;
   int ia, ib;
-  zinterp(s, z, ia, ib, zb.wa);
+  zinterp<ZT>(s, z, ia, ib, zb.wa, zt);
   zb.same = ia == ib;                       // clamped at the deepest level
   zb.iz0 = zb.same ? (ia > 0 ? ia - 1 : 0) : ia;
   return zb;
@@ -781,6 +817,9 @@ __device__ __forceinline__ T ld_off(const float *__restrict__ base, unsigned byt
   // buffer addressing: descriptor of the wave-uniform base in scalar registers + the 32-bit offset as it is -- no
   // 64-bit address arithmetic per gather (the flat form costs one v_lshl_add_u64 per load: 503 in k_step_grid<RK4>)
   static_assert(sizeof(T) == 4 || sizeof(T) == 8 || sizeof(T) == 16, "gather width");
+#ifdef ODR_ABLATE_UNIFORM_GATHER   // what-if build: every lane reads lane 0's address (one L1 access per gather instead of up to 64; wrong values)
+  byte_off = (unsigned)__builtin_amdgcn_readfirstlane((int)byte_off);
+#endif
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0xffffffff, 0x00020000);
   if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
   else if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
@@ -1030,6 +1069,94 @@ __device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBloc
 }
 
 
+// ODR_STAGE_FAST (odr_ctx_set_stage_math): the (u,v) of a Runge-Kutta STAGE position as ONE weighted sum of the
+// 4 corners x 2 z levels x 2 time levels in float32 -- the reference's result is a float32 as well (the environment is cast to
+// float32, environment.py:543), reached through float32 roundings of every (time, z) layer; here the 16 corner values per
+// component go through packed float32 FMAs (u and v of a node are neighbours in the record: one v_pk_fma_f32 serves
+// both), i.e. 16 instructions instead of 32 conversions + 72 float64 operations.  The value differs from the reference's
+// stage value by a few float32 ulp (like the stage value of ODR_FAST_STAGE_SAMPLE in round 2): <= 2e-9 deg per step in
+// the position.  Front door (longitude convention, projection, coverage, fractional indices) as in uv_sample_fast.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int PROJ, bool IS3D>
+__device__ __forceinline__ void uv_sample_stage_f32(const DevSource &s, const DevBlock &geo, const UVTime &tm,
+                                                    double lon, double lat, double z, const ZBracket &zb,
+                                                    float fbu, float fbv, float &uo, float &vo, const ProjStart &ps) {
+  if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
+  else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
+  double x, y;
+  if (PROJ == PROJ_LATLONG) { x = lon; y = lat; }
+  else if (PROJ == PROJ_CURVILINEAR) curvi_locate(s.proj, lon, lat, x, y);
+  else if (ps.ok) proj_fwd_near(s.proj, ps, lon, lat, x, y);
+  else proj_fwd(s.proj, lon, lat, x, y);
+  double xchk = x;
+  if (PROJ == PROJ_LATLONG) {
+    if (s.lon_mode == 1) xchk = np_mod(x + 180.0, 360.0) - 180.0;
+    else if (s.lon_mode == 2) xchk = np_mod(x, 360.0);
+  }
+  float fu = __builtin_nanf(""), fv = __builtin_nanf("");
+  if (xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin && z <= s.zmax) {
+#pragma clang fp contract(fast)
+    if (s.mod360_x) x = np_mod(x, 360.0);
+    const double xi = (x - geo.x0) * geo.ixspan * (double)(geo.nx - 1);
+    const double yi = (y - geo.y0) * geo.iyspan * (double)(geo.ny - 1);
+    const Foot ft = footprint(yi, xi, geo.ny, geo.nx, (unsigned)geo.rec * 4u);
+    const float tx = (float)ft.tx, ty = (float)ft.ty, sx = 1.f - tx, sy = 1.f - ty;
+    const float w00 = sy * sx, w01 = sy * tx, w10 = ty * sx, w11 = ty * tx;
+    const float wt = tm.a ? (float)tm.w : 0.f;
+    f32x2 r;
+    if (IS3D) {
+      // levels (iz0, iz0 + 1) = ("above", "below"); clamped at the deepest level both are iz0 + 1
+      const bool same = zb.same && s.nz > 1;
+      const float za = same ? 0.f : (float)zb.wa, zw = 1.f - za;
+      const unsigned kb = (unsigned)zb.iz0 * 8u;
+      auto level = [&](const float *base) {
+        const F4 q00 = ld_off<F4>(base, ft.o00 + kb), q01 = ld_off<F4>(base, ft.o01 + kb);
+        const F4 q10 = ld_off<F4>(base, ft.o10 + kb), q11 = ld_off<F4>(base, ft.o11 + kb);
+        f32x2 lo = (f32x2){q00.x, q00.y} * w00, hi = (f32x2){q00.z, q00.w} * w00;
+        lo = __builtin_elementwise_fma((f32x2){q01.x, q01.y}, (f32x2){w01, w01}, lo);
+        hi = __builtin_elementwise_fma((f32x2){q01.z, q01.w}, (f32x2){w01, w01}, hi);
+        lo = __builtin_elementwise_fma((f32x2){q10.x, q10.y}, (f32x2){w10, w10}, lo);
+        hi = __builtin_elementwise_fma((f32x2){q10.z, q10.w}, (f32x2){w10, w10}, hi);
+        lo = __builtin_elementwise_fma((f32x2){q11.x, q11.y}, (f32x2){w11, w11}, lo);
+        hi = __builtin_elementwise_fma((f32x2){q11.z, q11.w}, (f32x2){w11, w11}, hi);
+        return __builtin_elementwise_fma(hi, (f32x2){zw, zw}, lo * za);
+      };
+      r = level(tm.b);
+      if (tm.a) { const f32x2 ra = level(tm.a); r = __builtin_elementwise_fma(ra - r, (f32x2){wt, wt}, r); }
+    } else {
+      auto level = [&](const float *base) {
+        const F2 q00 = ld_off<F2>(base, ft.o00), q01 = ld_off<F2>(base, ft.o01);
+        const F2 q10 = ld_off<F2>(base, ft.o10), q11 = ld_off<F2>(base, ft.o11);
+        f32x2 a = (f32x2){q00.x, q00.y} * w00;
+        a = __builtin_elementwise_fma((f32x2){q01.x, q01.y}, (f32x2){w01, w01}, a);
+        a = __builtin_elementwise_fma((f32x2){q10.x, q10.y}, (f32x2){w10, w10}, a);
+        return __builtin_elementwise_fma((f32x2){q11.x, q11.y}, (f32x2){w11, w11}, a);
+      };
+      r = level(tm.b);
+      if (tm.a) { const f32x2 ra = level(tm.a); r = __builtin_elementwise_fma(ra - r, (f32x2){wt, wt}, r); }
+    }
+    fu = r.x; fv = r.y;
+    if (ODR_PROJ_ROTATES(PROJ)) {
+      double sn, cs;
+      rotation_cs(s.proj, x, y, cs, sn);
+      const float c = (float)cs, n = (float)sn, uu = fu, vv = fv;
+      fu = uu * c - vv * n;
+      fv = uu * n + vv * c;
+    }
+  }
+  uo = isfinite(fu) ? fu : (isfinite(fbu) ? fbu : fu);
+  vo = isfinite(fv) ? fv : (isfinite(fbv) ? fbv : fv);
+}
+
+// the stage sample of the chosen stage math (SM: 0 = ODR_STAGE_EXACT, 1 = ODR_STAGE_FAST)
+template <int PROJ, bool IS3D, bool TILE, int SM>
+__device__ __forceinline__ void uv_stage(const DevSource &s, const DevBlock &geo, const UVTime &tm, double lon, double lat,
+                                         double z, const ZBracket &zb, float fbu, float fbv, float &uo, float &vo,
+                                         const TileView &T, bool tile_ok, const ProjStart &ps) {
+  if constexpr (SM == 1) uv_sample_stage_f32<PROJ, IS3D>(s, geo, tm, lon, lat, z, zb, fbu, fbv, uo, vo, ps);
+  else uv_sample_fast<PROJ, IS3D, TILE>(s, geo, tm, lon, lat, z, zb, fbu, fbv, uo, vo, T, tile_ok, ps);
+}
+
 // ---------------------------------------------------------- fast environment group
 // Main-loop Environment.get_environment for a variable group served by ONE gridded reader:
 // projection, coverage, fractional indices, the 2x2 footprint, the vertical bracket and the
@@ -1050,7 +1177,19 @@ struct EnvGroupDesc {
   int kind[MAXG];        // 0 scalar; 1 x-component of an interleaved pair whose y-component is slot k+1; 2 that y-component
   float fallback[MAXG];
   int has_land, pad;
+  int mode[MAXG];        // ENV_* below: how the slot is gathered and combined (host: odr_i_build_env_group)
+  // burst sampler (env_burst): group index of the variable in each physical slot A, B, C, D, L (-1: empty); burst = 0: the
+  // group does not fit the slots and takes the serial sampler; rotates: some slot holds a vector pair to rotate
+  int bs[5], burst, rotates, pad2;
+  // per physical slot (static indices in the kernel: one batched scalar load instead of dependent ones): byte offset of the
+  // variable in the node record, ENV_* mode, 1 = vector pair to rotate; temp_mask: bit k = group variable k is sea_water_temperature
+  int ps_off[5], ps_mode[5], ps_rot[5], temp_mask;
+  float *out_ptr[MAXG];  // where group variable k of the launch's particle set is stored (env_bind_out: p.env[var[k]]): a static
+                         // index in the kernels instead of two dependent scalar loads per stored variable
 };
+// gather / arithmetic class of a group slot.  S = scalar, P = interleaved vector pair (the slot and the one after it);
+// 2 / 3 = 2-D / z-interpolated; S3I = one component of an interleaved 3-D pair on its own
+enum { ENV_S2 = 0, ENV_S3 = 1, ENV_S3I = 2, ENV_P2 = 3, ENV_P3 = 4, ENV_LAND = 5, ENV_SKIP = 6 };
 
 // one scalar variable at one time level -> value in the reference's dtype class; d = address of
 // the variable in node record 0
@@ -1086,9 +1225,153 @@ __device__ __forceinline__ double var_level(const float *__restrict__ d, int var
   return __dadd_rn(__dmul_rn((double)va, zb.wa), __dmul_rn((double)vb, 1 - zb.wa));
 }
 
+// ---- burst sampler (round 3).  Phase timing of k_step_grid showed the main-loop sample as 45 % of a wave's life: the
+// serial sampler below gathers one variable and time level after the other (a memory round trip each, behind uniform
+// branches the compiler cannot move loads across).  Here the host assigns the group's variables to five PHYSICAL
+// slots of fixed register width -- A: up to 16 bytes per corner (a 3-D vector pair, or anything narrower), B and C: up to
+// 8 bytes (a 3-D scalar or a 2-D pair), D: 4 bytes (a 2-D scalar), L: the land mask's nearest node -- and ALL their
+// gathers, both time levels, leave in one burst; the arithmetic follows, slot by slot, with the rounding points of the
+// serial sampler (same bits: tests/test_gpu_parity.py, test_gpu_generic_paths.py).  Groups that do not fit the slots
+// (more variables, pairs that are not interleaved) take the serial sampler.
+__device__ __forceinline__ void put_slot(float *out /*[MAXG]*/, int k, float v) {
+#pragma unroll
+  for (int j = 0; j < MAXG; ++j) out[j] = j == k ? v : out[j];
+}
+template <int WIDTH, class Get>
+__device__ __forceinline__ void burst_math(int m, Get get, const Foot &ft, const ZBracket &zb, int snz, bool tl, double w,
+                                           double &v0, double &v1) {
+  const double ty = ft.ty, tx = ft.tx, wy0 = ft.wy0, wx0 = ft.wx0;
+  auto lerp32 = [&](double b, double a) { return (double)__fadd_rn(__fmul_rn((float)b, (float)(1 - w)), __fmul_rn((float)a, (float)w)); };
+  auto lerp64 = [&](double b, double a) { return __dadd_rn(__dmul_rn(b, 1 - w), __dmul_rn(a, w)); };
+  auto b4 = [&](int t, int c) { return bil4(get(t, 0, c), get(t, 1, c), get(t, 2, c), get(t, 3, c), wy0, ty, wx0, tx); };
+  const bool same = zb.same && snz > 1;
+  auto z2 = [&](float a, float b) { return __dadd_rn(__dmul_rn((double)a, zb.wa), __dmul_rn((double)b, 1 - zb.wa)); };
+  v0 = v1 = 0;
+  if (m == ENV_S2) {
+    const float b = b4(0, 0);
+    v0 = tl ? lerp32(b, b4(1, 0)) : (double)b;
+    return;
+  }
+  if constexpr (WIDTH >= 2) {
+    if (m == ENV_P2) {
+      const float ub = b4(0, 0), vb = b4(0, 1);
+      if (tl) { v0 = lerp32(ub, b4(1, 0)); v1 = lerp32(vb, b4(1, 1)); }
+      else { v0 = ub; v1 = vb; }
+      return;
+    }
+    if (m == ENV_S3) {
+      const float lb = b4(0, 1), la = same ? lb : b4(0, 0);
+      v0 = z2(la, lb);
+      if (tl) { const float mb = b4(1, 1), ma = same ? mb : b4(1, 0); v0 = lerp64(v0, z2(ma, mb)); }
+      return;
+    }
+  }
+  if constexpr (WIDTH >= 4) {
+    if (m == ENV_S3I) {
+      const float lb = b4(0, 2), la = same ? lb : b4(0, 0);
+      v0 = z2(la, lb);
+      if (tl) { const float mb = b4(1, 2), ma = same ? mb : b4(1, 0); v0 = lerp64(v0, z2(ma, mb)); }
+      return;
+    }
+    if (m == ENV_P3) {
+      const float ub = b4(0, 2), vb = b4(0, 3);
+      const float ua = same ? ub : b4(0, 0), va = same ? vb : b4(0, 1);
+      v0 = z2(ua, ub); v1 = z2(va, vb);
+      if (tl) {
+        const float pb = b4(1, 2), qb = b4(1, 3);
+        const float pa = same ? pb : b4(1, 0), qa = same ? qb : b4(1, 1);
+        v0 = lerp64(v0, z2(pa, pb)); v1 = lerp64(v1, z2(qa, qb));
+      }
+    }
+  }
+}
 template <int PROJ>
+__device__ __forceinline__ void env_burst(const DevSource &s, const EnvGroupDesc &G, const Foot &ft, const ZBracket &zb,
+                                          unsigned near_off, bool tl, double x, double y, float *out /*[MAXG]*/ ODR_PT_PARAM) {
+  const float *bb = G.bb, *ba = tl ? G.ba : G.bb;
+  const unsigned o[4] = {ft.o00, ft.o01, ft.o10, ft.o11};
+  const unsigned iz0 = (unsigned)zb.iz0;
+  const int kA = G.bs[0], kB = G.bs[1], kC = G.bs[2], kD = G.bs[3], kL = G.bs[4];
+  const int mA = G.ps_mode[0], mB = G.ps_mode[1], mC = G.ps_mode[2];
+  double cs = 1, sn = 0;
+  if (ODR_PROJ_ROTATES(PROJ) && G.rotates) rotation_cs(s.proj, x, y, cs, sn);
+  const int temp_mask = G.temp_mask;
+  auto finish = [&](int k, double v) {      // masked_invalid(...).astype('float32'), fallback, Kelvin -> Celsius
+    float f = (float)v;
+    if (!isfinite(f)) { const float fb = G.fallback[k]; f = isfinite(fb) ? fb : f; }   // rare: the scalar load stays in here
+    put_slot(out, k, (temp_mask >> k & 1) ? kelvin_to_celsius(f) : f);
+  };
+  auto emit = [&](int k, int m, int rot, double v0, double v1) {
+    if (m == ENV_P2 || m == ENV_P3) {
+      if (ODR_PROJ_ROTATES(PROJ) && rot) {
+        const double uu = v0, vv = v1;
+        v0 = __dsub_rn(__dmul_rn(uu, cs), __dmul_rn(vv, sn));
+        v1 = __dadd_rn(__dmul_rn(uu, sn), __dmul_rn(vv, cs));
+      }
+      finish(k, v0); finish(k + 1, v1);
+    } else finish(k, v0);
+  };
+  const double w = G.w;
+  // The gathers of a slot are the SAME instructions whatever the slot holds -- always 16 (A), 8 (B, C), 4 (D) bytes per
+  // corner, only the byte offset depends on the mode: a load whose destination registers differ between uniform branches
+  // ends in a copy at the join, i.e. in a wait right behind it, and the burst would be gone.  A narrower variable in a
+  // wider slot over-reads into its neighbours in the node record (blocks end with 64 spare bytes); empty slots read offset 0.
+  // ---- burst 1: slot A and the land mask (34 registers in flight), then their arithmetic
+  {
+    const unsigned dA = (unsigned)G.ps_off[0] + ((mA == ENV_P3 || mA == ENV_S3I) ? iz0 * 8u : mA == ENV_S3 ? iz0 * 4u : 0u);
+    const unsigned dL = kL >= 0 ? near_off + (unsigned)G.ps_off[4] : 0u;
+    F4 Ab[4], Aa[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { Ab[c] = ld_off<F4>(bb, o[c] + dA); Aa[c] = ld_off<F4>(ba, o[c] + dA); }
+    const float Lb = ld_off<float>(bb, dL), La = ld_off<float>(ba, dL);
+    if (kA >= 0) {
+      double v0, v1;
+      burst_math<4>(mA, [&](int t, int c, int q) { const F4 &r = t ? Aa[c] : Ab[c]; return q == 0 ? r.x : q == 1 ? r.y : q == 2 ? r.z : r.w; },
+                    ft, zb, s.nz, tl, w, v0, v1);
+      emit(kA, mA, G.ps_rot[0], v0, v1);
+    }
+    if (kL >= 0)
+      finish(kL, tl ? (double)__fadd_rn(__fmul_rn(Lb, (float)(1 - w)), __fmul_rn(La, (float)w)) : (double)Lb);
+  }
+  ODR_PT_USE(out[0]); ODR_PT_USE(out[1]); ODR_PT_USE(out[2]); ODR_PT(15);
+  // ---- burst 2: slots B, C, D (40 registers), then their arithmetic
+  if (kB >= 0 || kC >= 0 || kD >= 0) {
+    const unsigned dB = (unsigned)G.ps_off[1] + (mB == ENV_S3 ? iz0 * 4u : 0u);
+    const unsigned dC = (unsigned)G.ps_off[2] + (mC == ENV_S3 ? iz0 * 4u : 0u);
+    const unsigned dD = (unsigned)G.ps_off[3];
+    F2 Bb[4], Ba[4], Cb[4], Ca[4];
+    float Db[4], Da[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { Bb[c] = ld_off<F2>(bb, o[c] + dB); Ba[c] = ld_off<F2>(ba, o[c] + dB); }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { Cb[c] = ld_off<F2>(bb, o[c] + dC); Ca[c] = ld_off<F2>(ba, o[c] + dC); }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { Db[c] = ld_off<float>(bb, o[c] + dD); Da[c] = ld_off<float>(ba, o[c] + dD); }
+    if (kB >= 0) {
+      double v0, v1;
+      burst_math<2>(mB, [&](int t, int c, int q) { const F2 &r = t ? Ba[c] : Bb[c]; return q == 0 ? r.x : r.y; }, ft, zb, s.nz, tl, w, v0, v1);
+      emit(kB, mB, G.ps_rot[1], v0, v1);
+    }
+    if (kC >= 0) {
+      double v0, v1;
+      burst_math<2>(mC, [&](int t, int c, int q) { const F2 &r = t ? Ca[c] : Cb[c]; return q == 0 ? r.x : r.y; }, ft, zb, s.nz, tl, w, v0, v1);
+      emit(kC, mC, G.ps_rot[2], v0, v1);
+    }
+    if (kD >= 0) {
+      double v0, v1;
+      burst_math<1>(ENV_S2, [&](int t, int c, int q) { return t ? Da[c] : Db[c]; }, ft, zb, s.nz, tl, w, v0, v1);
+      emit(kD, ENV_S2, 0, v0, v1);
+    }
+  }
+  ODR_PT_USE(out[3]); ODR_PT_USE(out[4]); ODR_PT(16);
+}
+
+// BURST_ONLY: the caller guarantees G.burst (the fused step kernel: groups that do not fit the slots take the separate launches)
+template <int PROJ, bool BURST_ONLY, bool ZT>
 __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroupDesc &G, double lon,
-                                               double lat, double z, float *out /*[MAXG]*/) {
+                                               double lat, double z, float *out /*[MAXG]*/, const double *zt,
+                                               ZBracket &zb_out ODR_PT_PARAM) {
+  ODR_PT(10);
   const DevSource &s = W.src[G.sid];
   const DevBlock &geo = s.slot[G.geo_slot];
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
@@ -1104,13 +1387,30 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
   }
   const bool covered = xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin && z <= s.zmax;
   double val[MAXG];
+  const bool burst = BURST_ONLY || G.burst;
+  if (burst) {
+#pragma unroll
+    for (int k = 0; k < MAXG; ++k) out[k] = 0.f;
+    if (!covered) {     // NaN -> fallback (rare: the scalar loads of the fallbacks stay in here)
+#pragma unroll
+      for (int k = 0; k < MAXG; ++k) {
+        if (k >= G.nv) break;
+        const float fb = G.fallback[k];
+        out[k] = !isfinite(fb) ? __builtin_nanf("") : ((G.temp_mask >> k & 1) ? kelvin_to_celsius(fb) : fb);
+      }
+    }
+  }
+  ODR_PT_USE(covered); ODR_PT(11);
   if (covered) {
     if (s.mod360_x) x = np_mod(x, 360.0);
     const double xi = __dmul_rn(div_cr(x - geo.x0, geo.xspan, geo.ixspan), (double)(geo.nx - 1));
     const double yi = __dmul_rn(div_cr(y - geo.y0, geo.yspan, geo.iyspan), (double)(geo.ny - 1));
+    ODR_PT_USE(xi); ODR_PT_USE(yi); ODR_PT(12);
     ZBracket zb;
     zb.iz0 = 0; zb.same = 0; zb.wa = 1;
-    if (s.nz > 1) zb = zbracket(s, z);
+    if (s.nz > 1) zb = zbracket<ZT>(s, z, zt);
+    zb_out = zb;
+    ODR_PT_USE(zb.iz0); ODR_PT_USE(zb.wa); ODR_PT(13);
     // shared by all variables and both time levels: bilinear footprint, nearest node (land mask)
     const unsigned rec_bytes = (unsigned)geo.rec * 4u;
     const Foot ft = footprint(yi, xi, geo.ny, geo.nx, rec_bytes);
@@ -1120,6 +1420,9 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
                               (unsigned)nearest_index(x, geo.xmin, geo.xrange, geo.ixrange, geo.nx),
                           rec_bytes);
     const bool tl = G.ba != nullptr && !G.all_static;
+    ODR_PT_USE(ft.o00); ODR_PT_USE(ft.o11); ODR_PT_USE(near_off); ODR_PT(14);
+    if (burst) env_burst<PROJ>(s, G, ft, zb, near_off, tl, x, y, out ODR_PT_ARG);
+    else if constexpr (!BURST_ONLY) {
 #pragma unroll
     for (int k = 0; k < MAXG; ++k) {
       if (k >= G.nv) break;
@@ -1169,7 +1472,9 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
         }
       }
     }
+    }
   }
+  if (burst) return;
 #pragma unroll
   for (int k = 0; k < MAXG; ++k) {
     if (k >= G.nv) break;
@@ -1177,6 +1482,13 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
     f = isfinite(f) ? f : (isfinite(G.fallback[k]) ? G.fallback[k] : f);
     out[k] = G.var[k] == VAR_TEMP ? kelvin_to_celsius(f) : f;
   }
+}
+
+// for the kernels that need neither LDS tables nor the bracket
+template <int PROJ>
+__device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroupDesc &G, double lon, double lat, double z, float *out) {
+  ZBracket zb;
+  env_group_fast<PROJ, false, false>(W, G, lon, lat, z, out, nullptr, zb);
 }
 
 }  // namespace odr

@@ -70,6 +70,7 @@ struct odr_ctx {
   unsigned long long *counter;
   hipEvent_t ev0, ev1;
   int nsrc;
+  int stage_math;   // odr_ctx_set_stage_math: ODR_STAGE_EXACT | ODR_STAGE_FAST (Runge-Kutta stage evaluations)
   int fuse_vadv;
   int seafloor;     // general:seafloor_action for the in-update() sea floor checks: action | status_code << 8
   // reductions cached between the horizontal movers of one step (advect_wind -> stokes_drift -> horizontal
@@ -138,6 +139,13 @@ static inline PView view(const odr_particles *p) {
   v.ice = p->ice_kind; v.pad = 0;
   v.rank = p->rank_on && p->rank ? p->rank + w : nullptr;
   return v;
+}
+
+// the store targets of a variable group for the particle set behind `v` (EnvGroupDesc::out_ptr)
+static inline EnvGroupDesc env_bind_out(const EnvGroupDesc &G0, const PView &v) {
+  EnvGroupDesc G = G0;
+  for (int k = 0; k < MAXG; ++k) G.out_ptr[k] = k < G.nv ? v.env[G.var[k]] : nullptr;
+  return G;
 }
 
 static inline int flush_world(odr_ctx *c) {
@@ -270,6 +278,7 @@ int odr_i_ensure_ranks(odr_ctx *c, odr_particles *p);
 
 // defined in odrift.hip
 bool odr_i_build_env_group(const odr_ctx *c, const int *grp, int ng, double t, EnvGroupDesc &G);
+void odr_i_phase_dump();   // odr_step.hip
 bool odr_i_uv_fast_source(const odr_ctx *c, int &sid, double t_lo, double t_hi);
 bool odr_i_gyre_source(const odr_ctx *c, int var, int &sid);
 int odr_i_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t, float *const *out_host,

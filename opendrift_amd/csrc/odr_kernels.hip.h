@@ -181,22 +181,38 @@ __device__ __forceinline__ void move_f64(double &lon, double &lat, double u, dou
 
 // RK sub-stage position: geod.fwd(lon, lat, az, speed*dt*.5) with az and dist in float32 (physics_methods.py:629-635);
 // the start point is shared by all stages of a particle.
-// -DODR_DIRECT_STAGE_STEP (measured, not the default): the stage step taken directly along (u, v) dt/2 without the
-// float32 azimuth / distance emulation -- no arctan2, no square root.  A stage position only matters through the
-// velocity sampled there and the two roundings move it by < 1e-4 m, but on strongly sheared fields the sampled
-// float32 velocity then differs in the last bit often enough to show: up to 9e-10 deg per step against the oracle in
-// tests/test_gpu_parity.py, for 0.025 ms of the 1.7 ms C3 step (profiles/r02_ab_variants.txt).
+// Stage math (odr_ctx_set_stage_math):
+//   ODR_STAGE_EXACT (SM = 0): the reference's float32 rounding points inside a stage are reproduced -- azimuth = float32
+//     arctan2 in degrees, distance = float32 speed * dt * .5 -- trajectories stay within 1e-10 deg per step of the oracle.
+//   ODR_STAGE_FAST  (SM = 1): the stage step taken directly along (u, v) dt/2 -- no arctan2, no square root.  A stage
+//     position only matters through the velocity sampled there; the two skipped roundings move it by < 1e-4 m, the sampled
+//     float32 velocity then differs in its last bits now and then: <= 2e-9 deg per step against the oracle, 500 times inside
+//     the 1e-6 deg of the task and below the 1e-8 deg the oracle itself differs from the reference by.
+//     The main-loop sample, the RK combination and the final move keep every rounding point in both modes.
+template <int SM>
 __device__ __forceinline__ void stage_pos(const GeodStart &o, float u, float v, float dtf,
                                           double &lon2, double &lat2) {
-#if defined(ODR_FULL_GEODESIC) || !defined(ODR_DIRECT_STAGE_STEP)
-  double salp, calp;
-  azimuth_sincos_f32(u, v, salp, calp);
-  float dist = __fmul_rn(__fmul_rn(speed_f32(u, v), dtf), 0.5f);
-  geod_step(o, salp, calp, (double)dist, lat2, lon2);
+#if defined(ODR_FULL_GEODESIC)
+  constexpr bool direct = false;
 #else
-  const double hd = 0.5 * (double)dtf;
-  geod_local_move(o, (double)u * hd, (double)v * hd, lat2, lon2);
+  constexpr bool direct = SM == 1;
 #endif
+  if constexpr (!direct) {
+    double salp, calp;
+    azimuth_sincos_f32(u, v, salp, calp);
+    float dist = __fmul_rn(__fmul_rn(speed_f32(u, v), dtf), 0.5f);
+    geod_step(o, salp, calp, (double)dist, lat2, lon2);
+  } else {
+#ifndef ODR_FULL_GEODESIC
+    const double hd = 0.5 * (double)dtf;
+    geod_local_move(o, (double)u * hd, (double)v * hd, lat2, lon2);
+#endif
+  }
+}
+// the same with the mode as a (wave-uniform) run-time value: kernels that serve any reader mix
+__device__ __forceinline__ void stage_pos_rt(int sm, const GeodStart &o, float u, float v, float dtf, double &lon2, double &lat2) {
+  if (sm == 1) stage_pos<1>(o, u, v, dtf, lon2, lat2);
+  else stage_pos<0>(o, u, v, dtf, lon2, lat2);
 }
 
 // --------------------------------------------------------------- random numbers
@@ -218,7 +234,8 @@ __device__ __forceinline__ void rng_init(rocrand_state_philox4x32_10 &st, unsign
 // (main: [ncomp][n], stage: [nstage][ncomp][n]); ODR_RNG_DEVICE: one Philox stream per (ID, step, call, distribution).
 constexpr unsigned long long RNG_OFF_NOISE_UNIFORM = 64, RNG_OFF_NOISE_STAGE = 128;
 struct StageNoise {
-  int on, rng_mode, ncomp, pad;
+  int on, rng_mode, ncomp;
+  int sm;   // stage math of the launch (ODR_STAGE_EXACT / ODR_STAGE_FAST): read by the kernels that take it at run time
   double std_n, std_u;
   const double *main, *stage;
   unsigned long long seed, step;
@@ -457,7 +474,7 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_env_grid(const DevWo
   env_group_fast<PROJ>(*W, G, lon, lat, z, out);
 #pragma unroll
   for (int k = 0; k < MAXG; ++k)
-    if (k < G.nv) p.env[G.var[k]][i] = out[k];
+    if (k < G.nv) G.out_ptr[k][i] = out[k];
   if (record_prev) { p.slon[i] = lon; p.slat[i] = lat; }
 }
 
@@ -510,7 +527,7 @@ __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W
     float dtf = (float)dt;
     double lon2, lat2;
     float k2[2];
-    stage_pos(o, u1, v1, dtf, lon2, lat2);
+    stage_pos_rt(N.sm, o, u1, v1, dtf, lon2, lat2);
     env_group<2>(*W, uv, lon2, lat2, z, t + dt / 2, k2, rk);
     const int id = NOISE ? p.id[i] : 0;
     if (NOISE) add_current_noise(N, 1, i, p.n, id, k2[0], k2[1]);
@@ -519,10 +536,10 @@ __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W
       fv = __fmul_rn(f, k2[1]);
     } else {
       float k3[2], k4[2];
-      stage_pos(o, k2[0], k2[1], dtf, lon2, lat2);
+      stage_pos_rt(N.sm, o, k2[0], k2[1], dtf, lon2, lat2);
       env_group<2>(*W, uv, lon2, lat2, z, t + dt / 2, k3, rk);
       if (NOISE) add_current_noise(N, 2, i, p.n, id, k3[0], k3[1]);
-      stage_pos(o, k3[0], k3[1], dtf, lon2, lat2);  // dt*.5 again: reference quirk (:662)
+      stage_pos_rt(N.sm, o, k3[0], k3[1], dtf, lon2, lat2);  // dt*.5 again: reference quirk (:662)
       env_group<2>(*W, uv, lon2, lat2, z, t + dt, k4, rk);
       if (NOISE) add_current_noise(N, 3, i, p.n, id, k4[0], k4[1]);
       fu = __fmul_rn(rk4_mix(u1, k2[0], k3[0], k4[0]), f);
@@ -536,12 +553,13 @@ __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W
 
 // fast version: (u,v) from one gridded reader, interleaved z-innermost blocks, host-resolved
 // time brackets (odr_field.hip.h "fast (u,v) path")
-template <int SCHEME, int PROJ, bool IS3D, bool NOISE, bool TILE = false>
+template <int SCHEME, int PROJ, bool IS3D, bool NOISE, bool TILE = false, int SM = 0>
 __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBlock &geo, double &lon, double &lat,
                                                  double z, float u1, float v1, float f, int moving, double dt,
                                                  const UVTime &th, const UVTime &tf, float fbu, float fbv,
                                                  const StageNoise &N, long long i, long long n, int id,
-                                                 const TileView &T = TileView(), bool tile_h = false, bool tile_f = false) {
+                                                 const TileView &T = TileView(), bool tile_h = false, bool tile_f = false,
+                                                 ZBracket zb_pre = ZBracket(), bool have_pre = false ODR_PT_PARAM) {
   float fu, fv;
   GeodStart o = geod_start(lat, lon);
   if (SCHEME == 0) {
@@ -550,7 +568,8 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
   } else {
     ZBracket zb;
     zb.iz0 = 0; zb.same = 0; zb.wa = 1;
-    if (IS3D) zb = zbracket(s, z);
+    // the bracket of the main-loop sample serves the stages as well (same z unless the sea floor lifted the element)
+    if (IS3D) { if (have_pre) zb = zb_pre; else zb = zbracket(s, z); }
     float dtf = (float)dt;
     double lon2, lat2;
     float u2, v2;
@@ -562,20 +581,24 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
       else if (s.lon_mode == 2) lw = np_mod(lw, 360.0);
       ps = proj_start(s.proj, lw, lat);
     }
-    stage_pos(o, u1, v1, dtf, lon2, lat2);
-    uv_sample_fast<PROJ, IS3D, TILE>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u2, v2, T, tile_h, ps);
+    stage_pos<SM>(o, u1, v1, dtf, lon2, lat2);
+    ODR_PT_USE(lon2); ODR_PT_USE(lat2); ODR_PT(4);
+    uv_stage<PROJ, IS3D, TILE, SM>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u2, v2, T, tile_h, ps);
     if (NOISE) add_current_noise(N, 1, i, n, id, u2, v2);
+    ODR_PT_USE(u2); ODR_PT_USE(v2); ODR_PT(5);
     if (SCHEME == 1) {
       fu = __fmul_rn(f, u2);
       fv = __fmul_rn(f, v2);
     } else {
       float u3, v3, u4, v4;
-      stage_pos(o, u2, v2, dtf, lon2, lat2);
-      uv_sample_fast<PROJ, IS3D, TILE>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u3, v3, T, tile_h, ps);
+      stage_pos<SM>(o, u2, v2, dtf, lon2, lat2);
+      uv_stage<PROJ, IS3D, TILE, SM>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u3, v3, T, tile_h, ps);
       if (NOISE) add_current_noise(N, 2, i, n, id, u3, v3);
-      stage_pos(o, u3, v3, dtf, lon2, lat2);
-      uv_sample_fast<PROJ, IS3D, TILE>(s, geo, tf, lon2, lat2, z, zb, fbu, fbv, u4, v4, T, tile_f, ps);
+      ODR_PT_USE(u3); ODR_PT_USE(v3); ODR_PT(6);
+      stage_pos<SM>(o, u3, v3, dtf, lon2, lat2);
+      uv_stage<PROJ, IS3D, TILE, SM>(s, geo, tf, lon2, lat2, z, zb, fbu, fbv, u4, v4, T, tile_f, ps);
       if (NOISE) add_current_noise(N, 3, i, n, id, u4, v4);
+      ODR_PT_USE(u4); ODR_PT_USE(v4); ODR_PT(7);
       fu = __fmul_rn(rk4_mix(u1, u2, u3, u4), f);
       fv = __fmul_rn(rk4_mix(v1, v2, v3, v4), f);
     }
@@ -583,7 +606,7 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
   move_f32_from(o, lon, lat, fu, fv, moving, dt);
 }
 
-template <int SCHEME, int PROJ, bool IS3D, bool NOISE>
+template <int SCHEME, int PROJ, bool IS3D, bool NOISE, int SM = 0>
 __global__ __launch_bounds__(BLOCK, ODR_STEP_WAVES(PROJ)) void k_advect_grid(const DevWorld *__restrict__ W, int sid, int geo_slot,
                                                        PView p, double dt, float factor, UVTime th,
                                                        UVTime tf, StageNoise N) {
@@ -592,7 +615,7 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_WAVES(PROJ)) void k_advect_grid(con
   const DevSource &s = W->src[sid];
   const DevBlock &geo = s.slot[geo_slot];
   double lon = p.lon[i], lat = p.lat[i];
-  advect_grid_body<SCHEME, PROJ, IS3D, NOISE>(s, geo, lon, lat, p.z[i], p.env[VAR_U][i], p.env[VAR_V][i],
+  advect_grid_body<SCHEME, PROJ, IS3D, NOISE, false, SM>(s, geo, lon, lat, p.z[i], p.env[VAR_U][i], p.env[VAR_V][i],
                                               __fmul_rn(current_factor(p, i, factor), p.cdf[i]), p.moving[i], dt, th, tf, W->fallback[VAR_U],
                                               W->fallback[VAR_V], N, i, p.n, NOISE ? p.id[i] : 0);
   p.lon[i] = lon;
@@ -614,7 +637,8 @@ struct StepDesc {
   int retired_code, missing_code;   // report_missing_variables: NaN in a sampled variable whose fallback is None
   int nmiss_grp, nmiss_rest;
   int miss_grp[4], miss_rest[4];    // group slots / variable ids (sampled by the preceding launch) to test for NaN
-  int main_noise, pad;              // uncertainty of the main-loop sample of the current (StageNoise call 0)
+  int main_noise;                   // uncertainty of the main-loop sample of the current (StageNoise call 0)
+  int ssh_slot;                     // group slot of sea_surface_height, or -1: sampled by the preceding launch (p.env[SSH])
 };
 
 // TILE: the (u,v) node records around the workgroup's particles are staged in LDS for the stage samples (odr_field.hip.h
@@ -641,14 +665,20 @@ __device__ __forceinline__ float pick_slot(const float (&a)[MAXG], int j) {
   return r;
 }
 
-template <int SCHEME, int PROJ, bool IS3D, bool NOISE, bool TILE = false, int MIXQ = 0, bool MIXTL = false>
+template <int SCHEME, int PROJ, bool IS3D, bool NOISE, bool TILE = false, int MIXQ = 0, bool MIXTL = false, int SM = 0>
 __global__ __launch_bounds__(BLOCK, (MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_WAVES) ? ODR_MIX_WAVES : ODR_STEP_WAVES(PROJ)) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
                                                      StepDesc S, double dt, float factor, UVTime th, UVTime tf,
                                                      unsigned long long *n_hit, StageNoise N, int tile_nodes = 0,
                                                      StepMix M = StepMix()) {
   static_assert(!(TILE && MIXQ > 0), "the LDS tile and the fused mixing both use the dynamic LDS allocation");
+  static_assert(!(SM != 0 && (TILE || MIXQ > 0)), "the fast stage math exists for the plain step kernel only");
   long long i = pid();
   bool hit = false;
+  ODR_PT_DECL;
+  ODR_PT(0);
+  __shared__ double s_zt[IS3D ? 3 * MAXNZ : 1];   // interp1d tables of the reader's z grid (zinterp)
+  const double *zt = nullptr;
+  if (IS3D) { zt_stage(W->src[G.sid], s_zt); zt = s_zt; }
   double *Kp = nullptr, *gsh = nullptr;
   if (MIXQ > 0) {
     extern __shared__ __attribute__((aligned(16))) char mix_mem[];
@@ -752,22 +782,30 @@ __global__ __launch_bounds__(BLOCK, (MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_
   if (i < p.n) {
     double lon = p.lon[i], lat = p.lat[i];
     const double z = p.z[i];
+    // everything the bookkeeping below reads of this particle, requested together with the position: each of these
+    // loads after the environment stores is a memory round trip of its own (float stores may alias float loads)
+    int moving = p.moving[i];
+    int st = p.status[i];
+    const float age0 = p.age[i], cdf0 = p.cdf[i];
+    const float ssh0 = (S.seafloor || MIXQ > 0) && p.env[VAR_SSH] ? p.env[VAR_SSH][i] : 0.f;
+    ODR_PT_USE(lon); ODR_PT_USE(lat); ODR_PT_USE(z); ODR_PT(1);
     float out[MAXG];
-    env_group_fast<PROJ>(*W, G, lon, lat, z, out);
+    ZBracket zb_env;
+    zb_env.iz0 = 0; zb_env.same = 0; zb_env.wa = 1;
+    env_group_fast<PROJ, true, IS3D>(*W, G, lon, lat, z, out, zt, zb_env ODR_PT_ARG);
+    ODR_PT_USE(out[0]); ODR_PT_USE(out[1]); ODR_PT_USE(out[2]); ODR_PT_USE(out[3]); ODR_PT_USE(out[4]); ODR_PT(2);
     const int id = (NOISE || MIXQ > 0) ? p.id[i] : 0;
     if (MIXQ > 0) vmix_col_fill<(MIXQ > 0 ? MIXQ : 1), MIXTL>(W->src[M.D.sid], M.D, lon, lat, Kp, threadIdx.x);
     if (NOISE && S.main_noise) add_current_noise(N, 0, i, p.n, id, out[0], out[1]);
 #ifndef ODR_ABLATE_STORES   // what-if build (tools/ab_bench.sh)
 #pragma unroll
     for (int k = 0; k < MAXG; ++k)
-      if (k < G.nv) p.env[G.var[k]][i] = out[k];
+      if (k < G.nv) G.out_ptr[k][i] = out[k];
     if (MIXQ == 0) {   // the sample position is what odr_vmix gathers its profiles at: not needed when the mixing is in here
       p.slon[i] = lon;
       p.slat[i] = lat;
     }
 #endif
-    int moving = p.moving[i];
-    int st = p.status[i];
     double zz = z;
     if (S.missing_code) {  // k_deactivate_missing
       bool miss = false;
@@ -791,7 +829,7 @@ __global__ __launch_bounds__(BLOCK, (MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_
             p.moving[i] = moving = 0;
           }
         } else {
-          if (S.seeded_code > 0 && p.age[i] == 0.0f) {
+          if (S.seeded_code > 0 && age0 == 0.0f) {
             if (st == 0) p.status[i] = st = S.seeded_code;
             p.moving[i] = moving = 0;
           }
@@ -803,11 +841,11 @@ __global__ __launch_bounds__(BLOCK, (MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_
     }
     if (S.seafloor) {  // k_seafloor
       const float dep = S.depth_slot == 2 ? out[2] : (S.depth_slot == 3 ? out[3] : p.env[VAR_DEPTH][i]);
-      const float floorz = -__fadd_rn(dep, p.env[VAR_SSH] ? p.env[VAR_SSH][i] : 0.f);
+      const float floorz = -__fadd_rn(dep, S.ssh_slot >= 0 ? pick_slot(out, S.ssh_slot) : ssh0);
       if (zz < (double)floorz) { zz = (double)floorz; if (MIXQ == 0) p.z[i] = zz; }
     }
     if (S.age_dt != 0.0f) {  // k_age
-      const float a = __fadd_rn(p.age[i], S.age_dt);
+      const float a = __fadd_rn(age0, S.age_dt);
       p.age[i] = a;
       if (S.max_age > 0 && a >= S.max_age) {
         if (st == 0) p.status[i] = st = S.retired_code;
@@ -819,17 +857,19 @@ __global__ __launch_bounds__(BLOCK, (MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_
 #ifndef ODR_ABLATE_STORES
     if (S.store_previous) { p.plon[i] = lon; p.plat[i] = lat; }
 #endif
+    ODR_PT(3);
     if (!skip) {
       const DevSource &s = W->src[G.sid];
-      advect_grid_body<SCHEME, PROJ, IS3D, NOISE, TILE>(s, s.slot[S.geo_slot_uv], lon, lat, zz, out[0], out[1],
-                                                        __fmul_rn(current_factor(p, i, factor), p.cdf[i]), moving, dt, th, tf, W->fallback[VAR_U],
-                                                        W->fallback[VAR_V], N, i, p.n, id, T, tile_h, tile_f);
+      advect_grid_body<SCHEME, PROJ, IS3D, NOISE, TILE, SM>(s, s.slot[S.geo_slot_uv], lon, lat, zz, out[0], out[1],
+                                                        __fmul_rn(current_factor(p, i, factor), cdf0), moving, dt, th, tf, W->fallback[VAR_U],
+                                                        W->fallback[VAR_V], N, i, p.n, id, T, tile_h, tile_f, zb_env, IS3D && zz == z ODR_PT_ARG);
     }
+    ODR_PT_USE(lon); ODR_PT_USE(lat); ODR_PT(8);
     if (MIXQ > 0) {   // vertical_mixing + vertical_advection (oceandrift.py:397-571, :315-350) after the horizontal move
       double zn = zz;
       if (!skip) {
         const float dep = S.depth_slot == 2 ? out[2] : (S.depth_slot == 3 ? out[3] : p.env[VAR_DEPTH][i]);
-        const float Zmin = __fmul_rn(-1.f, __fadd_rn(dep, p.env[VAR_SSH][i]));  // float32 (:408)
+        const float Zmin = __fmul_rn(-1.f, __fadd_rn(dep, S.ssh_slot >= 0 ? pick_slot(out, S.ssh_slot) : ssh0));  // float32 (:408)
         int sf_flags = 0;
         zn = vmix_col_walk<(MIXQ > 0 ? MIXQ : 1)>(W->src[M.D.sid], M.D.nzp, Kp, gsh, threadIdx.x, M.A, i, p.n, id, zz, moving, Zmin,
                                                   p.tv[i], sf_flags);
@@ -848,6 +888,14 @@ __global__ __launch_bounds__(BLOCK, (MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_
     }
     p.lon[i] = lon;
     p.lat[i] = lat;
+#ifdef ODR_PHASE_TIMING
+    pt_[9] = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0 && (blockIdx.x & 127) == 5) {   // a sample of the waves: the atomics must not load the memory system
+      for (int k = 0; k < 9; ++k) atomicAdd(&g_phase[k], pt_[k + 1] > pt_[k] && pt_[k] ? pt_[k + 1] - pt_[k] : 0ull);
+      for (int k = 10; k < 17; ++k) atomicAdd(&g_phase[k], pt_[k + 1] > pt_[k] && pt_[k] ? pt_[k + 1] - pt_[k] : 0ull);
+      atomicAdd(&g_phase[31], 1ull);
+    }
+#endif
   }
   if (S.coast_action) {
     unsigned long long b = __ballot(hit);
@@ -895,7 +943,7 @@ __global__ __launch_bounds__(BLOCK) void k_advect_gyre(const DevWorld *__restric
     const float dtf = (float)dt;
     double lon2, lat2;
     float u2, v2;
-    stage_pos(o, u1, v1, dtf, lon2, lat2);
+    stage_pos_rt(N.sm, o, u1, v1, dtf, lon2, lat2);
     gyre_sample(s, lon2, lat2, z, snw_half, fbu, fbv, u2, v2);
     const int id = NOISE ? p.id[i] : 0;
     if (NOISE) add_current_noise(N, 1, i, p.n, id, u2, v2);
@@ -904,10 +952,10 @@ __global__ __launch_bounds__(BLOCK) void k_advect_gyre(const DevWorld *__restric
       fv = __fmul_rn(f, v2);
     } else {
       float u3, v3, u4, v4;
-      stage_pos(o, u2, v2, dtf, lon2, lat2);
+      stage_pos_rt(N.sm, o, u2, v2, dtf, lon2, lat2);
       gyre_sample(s, lon2, lat2, z, snw_half, fbu, fbv, u3, v3);
       if (NOISE) add_current_noise(N, 2, i, p.n, id, u3, v3);
-      stage_pos(o, u3, v3, dtf, lon2, lat2);
+      stage_pos_rt(N.sm, o, u3, v3, dtf, lon2, lat2);
       gyre_sample(s, lon2, lat2, z, snw_full, fbu, fbv, u4, v4);
       if (NOISE) add_current_noise(N, 3, i, p.n, id, u4, v4);
       fu = __fmul_rn(rk4_mix(u1, u2, u3, u4), f);

@@ -43,12 +43,39 @@ int odr_advect_set_noise(odr_ctx *c, odr_particles *p, double std_normal, double
   return 0;
 }
 
+#ifdef ODR_PHASE_TIMING
+// developer build: per-phase cycles of k_step_grid (this translation unit's instantiations), averaged per wave
+void odr_i_phase_dump() {
+  unsigned long long h[32];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h) != hipSuccess || !h[31]) return;
+  h[15] = h[31];
+  static const char *nm[9] = {"entry->state loaded", "env sample (gathers+math)", "stores+bookkeeping", "geod origin+stage1 pos",
+                              "stage1 sample", "stage2 pos+sample", "stage3 pos+sample", "rk4 mix+final move", "final stores issue"};
+  double tot = 0;
+  for (int k = 0; k < 9; ++k) tot += (double)h[k] / (double)h[15];
+  fprintf(stderr, "k_step_grid phases (cycles per wave, %llu waves, total %.0f):\n", h[15], tot);
+  for (int k = 0; k < 9; ++k) fprintf(stderr, "  %-28s %9.0f  %5.1f %%\n", nm[k], (double)h[k] / (double)h[15], 100.0 * (double)h[k] / (double)h[15] / tot);
+  static const char *sub[6] = {"env: front door + coverage", "env: xi, yi", "env: zbracket", "env: footprint + nearest", "env: burst 1 (A, land)", "env: burst 2 (B, C, D)"};
+  for (int k = 0; k < 6; ++k) fprintf(stderr, "      %-28s %9.0f\n", sub[k], (double)h[10 + k] / (double)h[15]);
+}
+#else
+void odr_i_phase_dump() {}
+#endif
+
+int odr_ctx_set_stage_math(odr_ctx *c, int mode) {
+  REQUIRE(c, "null context");
+  REQUIRE(mode == ODR_STAGE_EXACT || mode == ODR_STAGE_FAST, "stage math must be ODR_STAGE_EXACT (0) or ODR_STAGE_FAST (1)");
+  c->stage_math = mode;
+  return 0;
+}
+
 // the armed uncertainty of `p`, disarmed
 static StageNoise take_noise(odr_ctx *c, const odr_particles *p) {
   StageNoise N;
   memset(&N, 0, sizeof N);
   if (c->noise_owner == p) N = c->noise;
   c->noise_owner = nullptr;
+  N.sm = c->stage_math;
   return N;
 }
 
@@ -62,8 +89,9 @@ static int advect_impl(odr_ctx *c, odr_particles *p, int scheme, double t, doubl
   if (scheme > 0 && (rc = odr_i_ensure_ranks(c, p))) return rc;   // stage calls on ensemble data: the present elements' ranks
   if (N.on && scheme > 0) {
     if (N.rng_mode == ODR_RNG_HOST && !N.stage) return fail(ODR_ERR_INVALID, "no host draws for the Runge-Kutta stage calls");
-    odr_i_advect_noise(c, p, scheme, t, dt, factor, N);
-  } else advect_dispatch<false>(c, p, scheme, t, dt, factor, N);
+    if (!(N.sm == ODR_STAGE_FAST && odr_i_advect_fast_noise(c, p, scheme, t, dt, factor, N))) odr_i_advect_noise(c, p, scheme, t, dt, factor, N);
+  } else if (!(N.sm == ODR_STAGE_FAST && scheme > 0 && odr_i_advect_fast(c, p, scheme, t, dt, factor, N)))
+    advect_dispatch<false>(c, p, scheme, t, dt, factor, N);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -199,7 +227,7 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   int sid = -1;
   bool fuse = p->n > 0 && !getenv("ODR_NO_FAST_PATH") && same_list(VAR_V, VAR_U) && ng <= MAXG && nmg <= 4 && nmr <= 4 &&
               uv_fast_source(c, sid, t < t + dt ? t : t + dt, t < t + dt ? t + dt : t) &&
-              build_env_group(c, grp, ng, t, G) && G.sid == sid;
+              build_env_group(c, grp, ng, t, G) && G.sid == sid && G.burst;   // k_step_grid carries the burst sampler only
   if (main_noise && N.rng_mode == ODR_RNG_HOST && !N.main) return fail(ODR_ERR_INVALID, "no host draws for the main sample");
   if (!fuse) {
     if ((rc = odr_env_sample(c, p, nvars, var_ids, t, nullptr))) return rc;
@@ -242,6 +270,8 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   if (want_floor && (rc = ensure_env(c, p, VAR_SSH))) return rc;
   if (coast_action) HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
   S.main_noise = main_noise ? 1 : 0;
+  S.ssh_slot = -1;
+  for (int k = 0; k < G.nv; ++k) if (G.var[k] == VAR_SSH) S.ssh_slot = k;
   // vertical mixing inside the launch: K from the reader of the current (lon/lat, 3-D, <= 16 levels), device RNG
   StepMix M;
   memset(&M, 0, sizeof M);
@@ -275,8 +305,10 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   }
   if (N.on && (scheme > 0 || main_noise)) {
     if (scheme > 0 && N.rng_mode == ODR_RNG_HOST && !N.stage) return fail(ODR_ERR_INVALID, "no host draws for the Runge-Kutta stage calls");
-    odr_i_step_noise(c, p, G, S, scheme, t, dt, factor, N);
-  } else step_dispatch<false>(c, p, G, S, scheme, t, dt, factor, N);
+    if (N.sm == ODR_STAGE_FAST && scheme > 0) odr_i_step_fast_noise(c, p, G, S, scheme, t, dt, factor, N);
+    else odr_i_step_noise(c, p, G, S, scheme, t, dt, factor, N);
+  } else if (N.sm == ODR_STAGE_FAST && scheme > 0) odr_i_step_fast(c, p, G, S, scheme, t, dt, factor, N);
+  else step_dispatch<false>(c, p, G, S, scheme, t, dt, factor, N);
   HIPCHK(hipGetLastError());
   if ((rc = coast_action ? read_counter(c, n_on_land) : 0)) return rc;
   return want_mix ? mix_after(c, p, t, dt, extras) : 0;

@@ -4,8 +4,9 @@
 #include "odr_step_launch.h"
 
 template <int SCHEME, int NQ, bool TL>
-static void launch_mix(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, StepDesc S, double t, double dt, double factor,
+static void launch_mix(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G0, StepDesc S, double t, double dt, double factor,
                        const StepMix &M) {
+  const EnvGroupDesc G = env_bind_out(G0, view(p));
   const DevSource &s = c->hw.src[G.sid];
   UVTime th = uv_time(s, t + dt / 2), tf = uv_time(s, t + dt);
   S.geo_slot_uv = s.level_slot[0];

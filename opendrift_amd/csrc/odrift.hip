@@ -54,6 +54,7 @@ int odr_ctx_destroy(odr_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->up_stream);
+  odr_i_phase_dump();   // -DODR_PHASE_TIMING builds only
   for (int s = 0; s < MAXSRC; ++s)
     for (int l = 0; l < MAXLEVELS; ++l) {
       for (void *b : c->block_bufs[s][l]) (void)hipFree(b);
@@ -421,6 +422,7 @@ int odr_source_grid(odr_ctx *c, const odr_proj_desc *proj, const double *dom, in
     const bool asc = z[1] > z[0];
     const int n = s.nz;
     for (int k = 0; k < n; ++k) s.zasc[k] = asc ? z[k] : z[n - 1 - k];
+    for (int k = n; k < MAXNZ; ++k) s.zasc[k] = INFINITY;   // zinterp counts the levels below z four at a time: the padding never counts
     for (int lo = 0; lo + 1 < n; ++lo) {
       double yl = asc ? lo : n - 1 - lo, yh = asc ? lo + 1 : n - 2 - lo;
       s.zi_x[lo] = s.zasc[lo];
@@ -827,6 +829,49 @@ bool odr_i_build_env_group(const odr_ctx *c, const int *grp, int ng, double t, E
       }
     }
   }
+  for (int k = 0; k < MAXG; ++k) G.mode[k] = ENV_SKIP;
+  for (int k = 0; k < ng; ++k) {      // gather / arithmetic class of each slot (env_slot_load / env_slot_math)
+    if (G.kind[k] == 2) G.mode[k] = ENV_SKIP;
+    else if (G.kind[k] == 1) G.mode[k] = G.nz[k] > 1 ? ENV_P3 : ENV_P2;
+    else if (G.var[k] == VAR_LAND) G.mode[k] = ENV_LAND;
+    else if (G.nz[k] <= 1) G.mode[k] = ENV_S2;
+    else G.mode[k] = G.es[k] == 1 ? ENV_S3 : ENV_S3I;
+  }
+  {   // burst sampler: the group's variables in the physical slots A (<= 16 B per corner), B, C (<= 8 B), D (4 B), L (land)
+    for (int q = 0; q < 5; ++q) G.bs[q] = -1;
+    G.burst = getenv("ODR_ENV_SERIAL") ? 0 : 1;
+    G.rotates = 0;
+    auto width = [&](int m) { return (m == ENV_P3 || m == ENV_S3I) ? 4 : (m == ENV_S3 || m == ENV_P2) ? 2 : 1; };
+    for (int pass = 4; pass >= 1 && G.burst; pass >>= 1)        // widest first
+      for (int k = 0; k < ng && G.burst; ++k) {
+        const int m = G.mode[k];
+        if (m == ENV_SKIP || m == ENV_LAND || width(m) != pass) continue;
+        if (G.partner[k] >= 0 && G.kind[k] != 1) { G.burst = 0; break; }   // a vector pair that is not interleaved: serial sampler
+        int q = -1;
+        if (G.bs[0] < 0) q = 0;
+        else if (pass <= 2 && G.bs[1] < 0) q = 1;
+        else if (pass <= 2 && G.bs[2] < 0) q = 2;
+        else if (pass == 1 && G.bs[3] < 0) q = 3;
+        if (q < 0) { G.burst = 0; break; }
+        G.bs[q] = k;
+        if (G.partner[k] >= 0) G.rotates = 1;
+      }
+    for (int k = 0; k < ng && G.burst; ++k) {
+      if (G.mode[k] == ENV_LAND) G.bs[4] = k;
+      if (G.kind[k] == 0 && G.partner[k] < 0) {   // the y-component of a pair that is not interleaved sits alone: serial sampler
+        for (int j = 0; j < ng; ++j) if (G.partner[j] == k && G.kind[j] != 1) G.burst = 0;
+      }
+    }
+    // a width-1 variable may have landed in slot B / C (8-byte slots hold it as ENV_S2): fine; slot D only takes ENV_S2
+    G.temp_mask = 0;
+    for (int k = 0; k < ng; ++k) if (G.var[k] == VAR_TEMP) G.temp_mask |= 1 << k;
+    for (int q = 0; q < 5; ++q) {
+      const int k = G.bs[q];
+      G.ps_off[q] = k >= 0 ? G.off[k] * 4 : 0;
+      G.ps_mode[q] = k >= 0 ? G.mode[k] : ENV_SKIP;
+      G.ps_rot[q] = k >= 0 && G.partner[k] >= 0 ? 1 : 0;
+    }
+  }
   G.w = ia >= 0 ? (t - s.slot[ib].t) / (s.slot[ia].t - s.slot[ib].t) : 0.0;
   return true;
 }
@@ -837,6 +882,7 @@ static bool launch_env_grid(odr_ctx *c, odr_particles *p, const int *grp, int ng
   const DevSource &s = c->hw.src[G.sid];
   dim3 g(nblk(p->n)), b(BLOCK);
   PView v = view(p);
+  G = env_bind_out(G, v);
   switch (s.proj.kind) {
     case PROJ_LATLONG: hipLaunchKernelGGL(k_env_grid<PROJ_LATLONG>, g, b, 0, c->stream, c->dw, v, G, rec); break;
     case PROJ_STERE_POLAR: hipLaunchKernelGGL(k_env_grid<PROJ_STERE_POLAR>, g, b, 0, c->stream, c->dw, v, G, rec); break;

@@ -5,6 +5,7 @@
 libodrift_hip.so; this file only marshals arrays.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -75,6 +76,9 @@ class Context:
         check(self.lib.odr_ctx_create(device, seed, C.byref(self.h)))
         self.device = device
         self._grids = {}
+        self.stage_math = 'exact'
+        if os.environ.get('ODR_STAGE_MATH'):     # what-if runs of whole test / bench sessions: 'exact' | 'fast'
+            self.set_stage_math(os.environ['ODR_STAGE_MATH'])
 
     def close(self):
         if self.h:
@@ -248,6 +252,11 @@ class Context:
 
     def unpin(self, array):
         check(self.lib.odr_host_unregister(self.h, C.c_void_p(np.asarray(array).ctypes.data)))
+
+    def set_stage_math(self, mode):
+        """'exact' | 'fast': arithmetic of the Runge-Kutta stage evaluations (odr_ctx_set_stage_math, include/odrift.h)"""
+        check(self.lib.odr_ctx_set_stage_math(self.h, _abi.STAGE_MATH[mode]))
+        self.stage_math = mode
 
     def set_seafloor_action(self, action, status_code=0):
         """general:seafloor_action for the sea floor checks inside update() (vertical_buoyancy, vertical_mixing)."""
@@ -751,8 +760,29 @@ for _name in ('append', 'upload', 'env_sample', 'env_upload', 'env_add_noise', '
               'update_positions', 'advect_wind', 'stokes_drift', 'advect_sea_ice', 'set_property', 'leeway_capsize', 'leeway', 'hdiffusion',
               'vmix', 'vmix_analytic', 'vmix_oil', 'vertical_advection', 'vertical_buoyancy', 'coastline', 'coastline_crossing',
               'increase_age', 'deactivate_missing', 'remap_status', 'seafloor', 'deactivate', 'deactivate_outside', 'compact',
-              'compact_apply', 'sort_by_cell'):
+              'compact_apply', 'sort_by_cell', 'store_previous', 'oil_prepare_mixing'):
     setattr(Particles, _name, _touching(getattr(Particles, _name)))
+
+
+def _reading(fn):
+    """A call that only READS the device state (downloads, reductions, scans): pending writes of the `o.elements` view
+    reach the device first -- `self.elements.z = ...` inside update() must be seen by the reductions of stokes_drift and
+    by the stored previous positions -- but the view stays valid (nothing changed underneath it)."""
+    def wrapper(self, *a, **kw):
+        v = self.__dict__.get('_view')
+        if v is not None and not getattr(v, '_flushing', False):
+            touch = self.__dict__.get('_touch', 0)
+            v.flush()                    # uploads what differs (a _touching call) ...
+            self._touch = touch          # ... which does not make the view stale: it holds what it just wrote
+            self._view = v
+        return fn(self, *a, **kw)
+    wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
+    return wrapper
+
+
+for _name in ('download', 'download_f32', 'env_download', 'get_property', 'reduce_scalars', 'reduce_global', 'oil_global_stats',
+              'scan_status', 'count_status'):
+    setattr(Particles, _name, _reading(getattr(Particles, _name)))
 
 
 class History:

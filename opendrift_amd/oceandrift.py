@@ -27,7 +27,7 @@ import numpy as np
 from . import _abi
 from .config import Configurable, CONFIG_LEVEL_BASIC, CONFIG_LEVEL_ADVANCED, CONFIG_LEVEL_ESSENTIAL
 from .device import Context
-from .readers import BaseReader, ConstantReader, DeviceReaderBinding, _epoch
+from .readers import BaseReader, ConstantReader, DeviceReaderBinding, ReaderLevelsError, _epoch
 
 logger = logging.getLogger('opendrift_amd')
 
@@ -202,14 +202,21 @@ class OpenDriftSimulation(Configurable):
         discard_reader :376-389; tests/readers/test_readers.py:15-26): its variables fall to the next reader of the
         priority list or to the fallback value."""
         rebind = False
+        # the instants a step samples a reader at: every reader at t0 (the main-loop get_environment); the readers that
+        # hold the current also at the Runge-Kutta stage times (physics_methods.py:638-670)
+        scheme = self.get_config('drift:advection_scheme') if 'drift:advection_scheme' in self._config else 'euler'
+        stage_times = {'runge-kutta': [t0, t0 + (t1 - t0) / 2], 'runge-kutta4': [t0, t0 + (t1 - t0) / 2, t1]}.get(scheme, [t0])
         for name, b in list(self.readers.items()):
             try:
                 sid_before = b.sid
-                b.ensure_levels(t0, t1)
+                holds_current = 'x_sea_water_velocity' in b.variables or 'y_sea_water_velocity' in b.variables
+                b.ensure_levels(t0, t1, times=stage_times if holds_current else [t0])
                 # a gridded reader gets its device source with its first block: a reader whose time coverage starts
                 # inside the run enters the priority lists when the run reaches it (the reference uses any reader
                 # that covers the current time, environment.py:597-668)
                 rebind |= sid_before is None and b.sid is not None
+            except ReaderLevelsError:
+                raise
             except Exception as e:   # the reference catches every exception of a reader call
                 rebind |= self._reader_failed(name, b, e)
         if rebind:
@@ -1006,6 +1013,13 @@ class ElementsView:
             P._view = None
         if len(P) != len(self):
             return      # the element set changed underneath: nothing sensible to write
+        object.__setattr__(self, '_flushing', True)     # the uploads below read nothing back through this view
+        try:
+            self._flush_changed(P, cur, orig)
+        finally:
+            object.__setattr__(self, '_flushing', False)
+
+    def _flush_changed(self, P, cur, orig):
         inv = np.empty(len(self), np.int64)
         inv[self._order] = np.arange(len(self))                # ascending ID -> device order
         changed = [k for k in cur if k not in self._RO and not np.array_equal(cur[k], orig[k], equal_nan=True)]

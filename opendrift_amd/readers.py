@@ -371,11 +371,16 @@ def _dev(a):
     return int(a.data_ptr()) if hasattr(a, 'is_cuda') and a.is_cuda else a
 
 
+class ReaderLevelsError(RuntimeError):
+    """The time levels one step needs do not fit the device slots: a configuration error of the run, NOT a reader
+    failure (the model's reader-failure handling must not swallow it and fall back to constants silently)."""
+
+
 class DeviceReaderBinding:
     """Device image of one reader: constant/analytic source, or a grid source whose time levels
     (ReaderBlocks) are uploaded on demand.  Stands where StructuredReader keeps
     var_block_before/after (structured.py:121-123)."""
-    NSLOTS = 4
+    NSLOTS = 6        # = MAXLEVELS of the device source: t0, t0 + dt/2 and t0 + dt may each sit between two different levels
     PREFETCH = True   # stage the next time level on the upload stream while the current one is in use
 
     def __init__(self, ctx, reader, variables=None):
@@ -462,8 +467,10 @@ class DeviceReaderBinding:
             return        # no overlap (nothing to cut) or most of the domain anyway
         self.extent = (np.array([x.min(), x.max()]), np.array([y.min(), y.max()]))
 
-    def ensure_levels(self, t0, t1, extent=None, broadcast=None):
-        """Make the time levels bracketing [t0, t1] resident (datetime arguments)."""
+    def ensure_levels(self, t0, t1, extent=None, broadcast=None, times=None):
+        """Make the time levels the step from t0 to t1 samples resident (datetime arguments).  `times`: the instants the
+        step samples THIS reader at (default: t0, the middle and t1 -- a Runge-Kutta-4 step of a reader that holds the
+        current; the model passes [t0] for Euler and for readers the stages do not sample)."""
         r = self.reader
         if extent is None:
             extent = getattr(self, 'extent', None)
@@ -476,13 +483,15 @@ class DeviceReaderBinding:
             # physics_methods.py:638-670): the two levels bracketing EACH of these times must be resident -- not the
             # whole range in between (a model time step may span many reader levels), and never a truncated range
             # (a dropped 'before' level would make the device extrapolate in time).
-            times = [t for t in (t0, t0 + (t1 - t0) / 2, t1) if r.covers_time(t)]
+            if times is None:
+                times = (t0, t0 + (t1 - t0) / 2, t1)
+            times = [t for t in times if r.covers_time(t)]
             if not times:
                 return
             need = sorted({k for t in times for k in r.nearest_time(t)})
-            if len(need) > self.NSLOTS:
-                raise ValueError('reader %s: one model time step needs %d time levels resident, at most %d fit'
-                                 % (r.name, len(need), self.NSLOTS))
+            if len(need) > self.NSLOTS:     # cannot happen with NSLOTS = 6 (three instants, two levels each)
+                raise ReaderLevelsError('reader %s: one model time step needs %d time levels resident, at most %d fit'
+                                        % (r.name, len(need), self.NSLOTS))
         # make room: first the resident levels the step does not need, then prefetched levels it does not need
         missing = [k for k in need if k not in self.slots and k not in self.staged]
         for pool in (self.slots, self.staged):

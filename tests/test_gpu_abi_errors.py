@@ -42,9 +42,9 @@ def test_bad_source_arguments(ctx):
         ctx.upload_block(g, 0, 0.0, {U: np.zeros((4, 6, 8), np.float32)})
     with pytest.raises(ValueError):
         ctx.upload_block(g, 7, 0.0, {U: np.zeros((3, 6, 8), np.float32)})   # slot out of range
-    for k in range(8 - 2):
+    for k in range(16 - 2):
         ctx.add_constant({U: 0.0})
-    with pytest.raises(OdrError):                       # at most 8 sources
+    with pytest.raises(OdrError):                       # at most 16 sources (MAXSRC)
         ctx.add_constant({U: 0.0})
 
 
