@@ -418,6 +418,10 @@ def main():
                     help='re-upload one field time level from host memory every N steps inside the timed region '
                          '(PCIe-inclusive rate, DESIGN.md section 5; 0 = inputs resident, the headline)')
     ap.add_argument('--block-async', action='store_true', help='with --block-every: odr_block_upload_async from pinned arrays')
+    ap.add_argument('--stage-math', default=os.environ.get('ODR_STAGE_MATH', 'fast'), choices=['fast', 'exact'],
+                    help="arithmetic of the Runge-Kutta stage evaluations (odr_ctx_set_stage_math): 'fast' is the headline -- its "
+                         "parity gate is tests/test_gpu_stage_math.py -- 'exact' keeps every float32 rounding point of the "
+                         "reference inside a stage; the line carries the other mode's rate as `stage_math_exact` / `_fast`")
     ap.add_argument('--plumbing-only', action='store_true',
                     help='rendezvous, shards, block broadcast and the reductions of the N-rank run without the device path '
                          '(no GPU needed; value is null)')
@@ -445,6 +449,7 @@ def main():
     n = a.particles or {'c2': 1_000_000, 'c3': 10_000_000, 'c4': 6_250_000, 'c5': 10_000_000}[a.workload]
     fields = make_fields(a.workload, a.small)
     ctx = Context(device=dev, seed=0)
+    ctx.set_stage_math(a.stage_math)
     wl = Workload(a.workload, ctx, fields, (rank, local_rank, world))
     rng = np.random.default_rng(1000 + rank)
     lon, lat, z = seed_particles(a.workload, fields, n, rng)

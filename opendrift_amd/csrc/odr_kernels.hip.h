@@ -142,6 +142,29 @@ __device__ __forceinline__ void geod_step(const GeodStart &o, double salp, doubl
 }
 #endif
 
+// The start-point coefficients of the series geodesic (12 doubles = 24 registers) live from the first stage position to the
+// final move, across the three stage samples -- the register peak of k_step_grid.  PARKED: they wait in the workgroup's LDS
+// (one column per thread, [coefficient][thread]: conflict-free 8-byte accesses) and are read back where a move needs them;
+// the kernel then fits 96 registers = 5 waves per SIMD without scratch memory (round 3; 111 registers = 4 waves before,
+// 80 B of scratch when merely capped at 96).
+constexpr int GEOD_PARK = 12;
+#ifndef ODR_FULL_GEODESIC
+typedef volatile __attribute__((address_space(3))) double lds_f64;   // explicit LDS pointer: ds_read / ds_write, not flat accesses
+__device__ __forceinline__ void geod_park(const GeodLocal &o, lds_f64 *slot) {
+  slot[0 * BLOCK] = o.iN; slot[1 * BLOCK] = o.qs; slot[2 * BLOCK] = o.kphi; slot[3 * BLOCK] = o.klam;
+  slot[4 * BLOCK] = o.t; slot[5 * BLOCK] = o.a20; slot[6 * BLOCK] = o.a30; slot[7 * BLOCK] = o.a12;
+  slot[8 * BLOCK] = o.a40; slot[9 * BLOCK] = o.a22; slot[10 * BLOCK] = o.b21; slot[11 * BLOCK] = o.b31;
+}
+__device__ __forceinline__ GeodLocal geod_unpark(double lat1, double lon1n, lds_f64 *slot) {
+  GeodLocal o;
+  o.lat1 = lat1; o.lon1n = lon1n;
+  o.iN = slot[0 * BLOCK]; o.qs = slot[1 * BLOCK]; o.kphi = slot[2 * BLOCK]; o.klam = slot[3 * BLOCK];
+  o.t = slot[4 * BLOCK]; o.a20 = slot[5 * BLOCK]; o.a30 = slot[6 * BLOCK]; o.a12 = slot[7 * BLOCK];
+  o.a40 = slot[8 * BLOCK]; o.a22 = slot[9 * BLOCK]; o.b21 = slot[10 * BLOCK]; o.b31 = slot[11 * BLOCK];
+  return o;
+}
+#endif
+
 // update_positions (basemodel/__init__.py:4631-4657), float32 velocities
 __device__ __forceinline__ void move_f32_from(const GeodStart &o, double &lon, double &lat, float u,
                                               float v, int moving, double dt) {
@@ -409,13 +432,32 @@ __device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, con
     c_dk[q] = 0; c_sg[q] = 0;
     if (zl >= 0 && zl < nzp) level_terms(zl, c_dk[q], c_sg[q]);
   }
+  // The level of a sub-step is the number of boundaries below d (odd ones count when d >= zm, even ones when d > zm).
+  // Inside the cached window only the window's own four boundaries decide -- lv0 - 2 ... lv0 + 1, per lane, with the
+  // ">=" of the odd ones folded into the value (d >= b  <=>  d > the double just below b; b > 0) -- four compares
+  // instead of NL - 1; a sub-step that leaves the window counts all of them (round 3: 22 -> 8 instructions per sub-step).
+  double wb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = lv0 - 2 + j;
+    double b = k < 0 ? -1.0 : __builtin_inf();
+    if (k >= 0 && k < nzp - 1) {
+      b = gsh[3 * NL + k];
+      if ((k & 1) && b > 0) b = __longlong_as_double(__double_as_longlong(b) - 1);
+    }
+    wb[j] = b;
+  }
   for (int it = 0; it < ntimes; ++it) {
     const bool surface = z == 0;
     const double d = -z;
-    int zi = 0;
+    int q = (d > wb[1] ? 1 : 0) + (d > wb[2] ? 1 : 0);
+    int zi = lv0 - 1 + q;
+    if (!(d > wb[0]) || d > wb[3]) {     // outside the window (rare; also NaN)
+      zi = 0;
 #pragma unroll
-    for (int k = 0; k < NL - 1; ++k) zi += ((k & 1) ? d >= zm[k] : d > zm[k]) ? 1 : 0;
-    const int q = zi - lv0 + 1;
+      for (int k = 0; k < NL - 1; ++k) zi += ((k & 1) ? d >= zm[k] : d > zm[k]) ? 1 : 0;
+      q = zi - lv0 + 1;
+    }
     double dKdt = q == 0 ? c_dk[0] : (q == 1 ? c_dk[1] : c_dk[2]);
     double sig = q == 0 ? c_sg[0] : (q == 1 ? c_sg[1] : c_sg[2]);
     if (q < 0 || q > 2) level_terms(zi, dKdt, sig);
@@ -553,15 +595,26 @@ __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W
 
 // fast version: (u,v) from one gridded reader, interleaved z-innermost blocks, host-resolved
 // time brackets (odr_field.hip.h "fast (u,v) path")
-template <int SCHEME, int PROJ, bool IS3D, bool NOISE, bool TILE = false, int SM = 0>
+template <int SCHEME, int PROJ, bool IS3D, bool NOISE, bool TILE = false, int SM = 0, bool PARK = false>
 __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBlock &geo, double &lon, double &lat,
                                                  double z, float u1, float v1, float f, int moving, double dt,
                                                  const UVTime &th, const UVTime &tf, float fbu, float fbv,
                                                  const StageNoise &N, long long i, long long n, int id,
                                                  const TileView &T = TileView(), bool tile_h = false, bool tile_f = false,
-                                                 ZBracket zb_pre = ZBracket(), bool have_pre = false ODR_PT_PARAM) {
+                                                 ZBracket zb_pre = ZBracket(), bool have_pre = false,
+                                                 double *park = nullptr ODR_PT_PARAM) {
   float fu, fv;
-  GeodStart o = geod_start(lat, lon);
+  GeodStart o0 = geod_start(lat, lon);
+#ifndef ODR_FULL_GEODESIC
+  // PARK: the series coefficients wait in LDS between the moves (geod_park); the start point is rebuilt where it is used
+  const double lat1 = o0.lat1, lon1n = o0.lon1n;
+  lds_f64 *slot = (lds_f64 *)park;
+  if constexpr (PARK) geod_park(o0, slot);
+  auto O = [&]() { if constexpr (PARK) return geod_unpark(lat1, lon1n, slot); else return o0; };
+#else
+  auto O = [&]() { return o0; };
+#endif
+#define ODR_O O()
   if (SCHEME == 0) {
     fu = __fmul_rn(f, u1);
     fv = __fmul_rn(f, v1);
@@ -581,7 +634,7 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
       else if (s.lon_mode == 2) lw = np_mod(lw, 360.0);
       ps = proj_start(s.proj, lw, lat);
     }
-    stage_pos<SM>(o, u1, v1, dtf, lon2, lat2);
+    stage_pos<SM>(ODR_O, u1, v1, dtf, lon2, lat2);
     ODR_PT_USE(lon2); ODR_PT_USE(lat2); ODR_PT(4);
     uv_stage<PROJ, IS3D, TILE, SM>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u2, v2, T, tile_h, ps);
     if (NOISE) add_current_noise(N, 1, i, n, id, u2, v2);
@@ -591,11 +644,11 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
       fv = __fmul_rn(f, v2);
     } else {
       float u3, v3, u4, v4;
-      stage_pos<SM>(o, u2, v2, dtf, lon2, lat2);
+      stage_pos<SM>(ODR_O, u2, v2, dtf, lon2, lat2);
       uv_stage<PROJ, IS3D, TILE, SM>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u3, v3, T, tile_h, ps);
       if (NOISE) add_current_noise(N, 2, i, n, id, u3, v3);
       ODR_PT_USE(u3); ODR_PT_USE(v3); ODR_PT(6);
-      stage_pos<SM>(o, u3, v3, dtf, lon2, lat2);
+      stage_pos<SM>(ODR_O, u3, v3, dtf, lon2, lat2);
       uv_stage<PROJ, IS3D, TILE, SM>(s, geo, tf, lon2, lat2, z, zb, fbu, fbv, u4, v4, T, tile_f, ps);
       if (NOISE) add_current_noise(N, 3, i, n, id, u4, v4);
       ODR_PT_USE(u4); ODR_PT_USE(v4); ODR_PT(7);
@@ -603,7 +656,8 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
       fv = __fmul_rn(rk4_mix(v1, v2, v3, v4), f);
     }
   }
-  move_f32_from(o, lon, lat, fu, fv, moving, dt);
+  move_f32_from(ODR_O, lon, lat, fu, fv, moving, dt);
+#undef ODR_O
 }
 
 template <int SCHEME, int PROJ, bool IS3D, bool NOISE, int SM = 0>
@@ -665,8 +719,17 @@ __device__ __forceinline__ float pick_slot(const float (&a)[MAXG], int j) {
   return r;
 }
 
+// lat / lon and curvilinear readers, Runge-Kutta schemes: geodesic coefficients parked in LDS, 5 waves per SIMD (geod_park)
+#ifndef ODR_PARK_WAVES
+#define ODR_PARK_WAVES 5
+#endif
+#if defined(ODR_FULL_GEODESIC) || defined(ODR_NO_PARK)
+#define ODR_STEP_PARKS(SCHEME, PROJ, TILE, MIXQ) false
+#else
+#define ODR_STEP_PARKS(SCHEME, PROJ, TILE, MIXQ) ((SCHEME) > 0 && !(TILE) && (MIXQ) == 0 && ((PROJ) == PROJ_LATLONG || (PROJ) == PROJ_CURVILINEAR))
+#endif
 template <int SCHEME, int PROJ, bool IS3D, bool NOISE, bool TILE = false, int MIXQ = 0, bool MIXTL = false, int SM = 0>
-__global__ __launch_bounds__(BLOCK, (MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_WAVES) ? ODR_MIX_WAVES : ODR_STEP_WAVES(PROJ)) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
+__global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, TILE, MIXQ) ? ODR_PARK_WAVES : ((MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_WAVES) ? ODR_MIX_WAVES : ODR_STEP_WAVES(PROJ))) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
                                                      StepDesc S, double dt, float factor, UVTime th, UVTime tf,
                                                      unsigned long long *n_hit, StageNoise N, int tile_nodes = 0,
                                                      StepMix M = StepMix()) {
@@ -676,6 +739,8 @@ __global__ __launch_bounds__(BLOCK, (MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_
   bool hit = false;
   ODR_PT_DECL;
   ODR_PT(0);
+  constexpr bool PARK = ODR_STEP_PARKS(SCHEME, PROJ, TILE, MIXQ);
+  __shared__ double s_park[PARK ? GEOD_PARK * BLOCK : 1];
   __shared__ double s_zt[IS3D ? 3 * MAXNZ : 1];   // interp1d tables of the reader's z grid (zinterp)
   const double *zt = nullptr;
   if (IS3D) { zt_stage(W->src[G.sid], s_zt); zt = s_zt; }
@@ -684,11 +749,11 @@ __global__ __launch_bounds__(BLOCK, (MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_
     extern __shared__ __attribute__((aligned(16))) char mix_mem[];
     constexpr int NL = 4 * (MIXQ > 0 ? MIXQ : 1);
     Kp = (double *)mix_mem;                  // [NL][BLOCK]
-    gsh = Kp + (size_t)NL * BLOCK;           // [3][NL]
+    gsh = Kp + (size_t)NL * BLOCK;           // [4][NL]
     const DevSource &sk = W->src[M.D.sid];
     if ((int)threadIdx.x < M.D.nzp) {
       const int t_ = threadIdx.x;
-      gsh[t_] = sk.vg_a[t_]; gsh[NL + t_] = sk.vg_b[t_]; gsh[2 * NL + t_] = sk.vg_c[t_];
+      gsh[t_] = sk.vg_a[t_]; gsh[NL + t_] = sk.vg_b[t_]; gsh[2 * NL + t_] = sk.vg_c[t_]; gsh[3 * NL + t_] = sk.zmid[t_];
     }
     __syncthreads();
   }
@@ -860,9 +925,9 @@ __global__ __launch_bounds__(BLOCK, (MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_
     ODR_PT(3);
     if (!skip) {
       const DevSource &s = W->src[G.sid];
-      advect_grid_body<SCHEME, PROJ, IS3D, NOISE, TILE, SM>(s, s.slot[S.geo_slot_uv], lon, lat, zz, out[0], out[1],
+      advect_grid_body<SCHEME, PROJ, IS3D, NOISE, TILE, SM, PARK>(s, s.slot[S.geo_slot_uv], lon, lat, zz, out[0], out[1],
                                                         __fmul_rn(current_factor(p, i, factor), cdf0), moving, dt, th, tf, W->fallback[VAR_U],
-                                                        W->fallback[VAR_V], N, i, p.n, id, T, tile_h, tile_f, zb_env, IS3D && zz == z ODR_PT_ARG);
+                                                        W->fallback[VAR_V], N, i, p.n, id, T, tile_h, tile_f, zb_env, IS3D && zz == z, PARK ? s_park + threadIdx.x : nullptr ODR_PT_ARG);
     }
     ODR_PT_USE(lon); ODR_PT_USE(lat); ODR_PT(8);
     if (MIXQ > 0) {   // vertical_mixing + vertical_advection (oceandrift.py:397-571, :315-350) after the horizontal move
@@ -1495,25 +1560,30 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__
   double *gsh = Kp + (size_t)NL * BLOCK;    // [3][NL]
   if (tid < nzp) {
     gsh[tid] = s.vg_a[tid]; gsh[NL + tid] = s.vg_b[tid]; gsh[2 * NL + tid] = s.vg_c[tid];
+    gsh[3 * NL + tid] = s.zmid[tid];     // level boundaries (entries >= nzp - 1 are not read)
   }
   __syncthreads();
   if (i >= p.n) return;  // no barrier below: every thread touches only its own LDS column
-  vmix_col_fill<NQ, TL>(s, D, p.slon[i], p.slat[i], Kp, tid);
+  // the particle's state in one round trip (requested before the column gathers, used behind them)
+  const double slon = p.slon[i], slat = p.slat[i], z0 = p.z[i];
+  int moving = p.moving[i];
+  const float dep0 = p.env[VAR_DEPTH][i], ssh0 = p.env[VAR_SSH][i], tv0 = p.tv[i];
+  const int id0 = rng_mode == 0 ? p.id[i] : 0;
+  const float w0 = vadv >= 0 ? p.env[VAR_W][i] : 0.f;
+  vmix_col_fill<NQ, TL>(s, D, slon, slat, Kp, tid);
   VMixArgs A;
   A.dt = dt; A.dt_mix_cfg = dt_mix_cfg; A.mix_at_surface = mix_at_surface; A.rng_mode = rng_mode; A.sfl = sfl; A.pad = 0;
   A.huni = huni; A.seed = seed; A.step = step;
-  int moving = p.moving[i];
   int sf_flags = 0;
-  const float Zmin = __fmul_rn(-1.f, __fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH][i]));  // float32 (:408)
-  double z = vmix_col_walk<NQ>(s, nzp, Kp, gsh, tid, A, i, p.n, rng_mode == 0 ? p.id[i] : 0, p.z[i], moving, Zmin,
-                               p.tv[i], sf_flags);
+  const float Zmin = __fmul_rn(-1.f, __fadd_rn(dep0, ssh0));  // float32 (:408)
+  double z = vmix_col_walk<NQ>(s, nzp, Kp, gsh, tid, A, i, p.n, id0, z0, moving, Zmin, tv0, sf_flags);
   if (sf_flags & 1) {   // deactivate_elements(reason='seafloor') (basemodel/__init__.py:1774-1795)
     if (p.status[i] == 0) p.status[i] = sfl >> 8;
     p.moving[i] = 0;
   }
   if (sf_flags & 2) { p.lon[i] = p.plon[i]; p.lat[i] = p.plat[i]; }
   if (vadv >= 0 && (vadv ? z <= 0 : z < 0)) {  // vertical_advection (oceandrift.py:315-350)
-    double zz = __dadd_rn(z, __dmul_rn(__dmul_rn((double)moving, (double)p.env[VAR_W][i]), dt));
+    double zz = __dadd_rn(z, __dmul_rn(__dmul_rn((double)moving, (double)w0), dt));
     z = zz < 0 ? zz : 0.0;
   }
   p.z[i] = z;

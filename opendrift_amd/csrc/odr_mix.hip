@@ -46,7 +46,7 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
     const bool tl = D.ka != nullptr;
 #define VMIX_COL(NQ)                                                                                              \
   do {                                                                                                            \
-    size_t l2 = sizeof(double) * ((size_t)(4 * NQ) * BLOCK + 3 * (size_t)(4 * NQ));                               \
+    size_t l2 = sizeof(double) * ((size_t)(4 * NQ) * BLOCK + 4 * (size_t)(4 * NQ));                               \
     if (tl) hipLaunchKernelGGL((k_vmix_col<NQ, true>), g, b, l2, c->stream, c->dw, v, D, dt, dt_mix,              \
                                mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);                                  \
     else hipLaunchKernelGGL((k_vmix_col<NQ, false>), g, b, l2, c->stream, c->dw, v, D, dt, dt_mix,                \

@@ -43,24 +43,8 @@ int odr_advect_set_noise(odr_ctx *c, odr_particles *p, double std_normal, double
   return 0;
 }
 
-#ifdef ODR_PHASE_TIMING
-// developer build: per-phase cycles of k_step_grid (this translation unit's instantiations), averaged per wave
-void odr_i_phase_dump() {
-  unsigned long long h[32];
-  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h) != hipSuccess || !h[31]) return;
-  h[15] = h[31];
-  static const char *nm[9] = {"entry->state loaded", "env sample (gathers+math)", "stores+bookkeeping", "geod origin+stage1 pos",
-                              "stage1 sample", "stage2 pos+sample", "stage3 pos+sample", "rk4 mix+final move", "final stores issue"};
-  double tot = 0;
-  for (int k = 0; k < 9; ++k) tot += (double)h[k] / (double)h[15];
-  fprintf(stderr, "k_step_grid phases (cycles per wave, %llu waves, total %.0f):\n", h[15], tot);
-  for (int k = 0; k < 9; ++k) fprintf(stderr, "  %-28s %9.0f  %5.1f %%\n", nm[k], (double)h[k] / (double)h[15], 100.0 * (double)h[k] / (double)h[15] / tot);
-  static const char *sub[6] = {"env: front door + coverage", "env: xi, yi", "env: zbracket", "env: footprint + nearest", "env: burst 1 (A, land)", "env: burst 2 (B, C, D)"};
-  for (int k = 0; k < 6; ++k) fprintf(stderr, "      %-28s %9.0f\n", sub[k], (double)h[10 + k] / (double)h[15]);
-}
-#else
-void odr_i_phase_dump() {}
-#endif
+ODR_DEFINE_PHASE_DUMP(odr_i_phase_dump_exact, "exact stage math")
+void odr_i_phase_dump() { odr_i_phase_dump_exact(); odr_i_phase_dump_fast(); }
 
 int odr_ctx_set_stage_math(odr_ctx *c, int mode) {
   REQUIRE(c, "null context");

@@ -10,3 +10,4 @@ void odr_i_step_fast(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, const 
                      double factor, const StageNoise &N) {
   step_dispatch<false, 1>(c, p, G, S, scheme, t, dt, factor, N);
 }
+ODR_DEFINE_PHASE_DUMP(odr_i_phase_dump_fast, "fast stage math")

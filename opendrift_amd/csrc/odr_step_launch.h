@@ -112,6 +112,27 @@ static void step_dispatch(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, c
 // defined in odr_step_mix.hip: the step with OceanDrift.vertical_mixing inside the launch
 void odr_i_step_mix(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, const StepDesc &S, int scheme, double t, double dt,
                     double factor, const StepMix &M);
+// developer build (-DODR_PHASE_TIMING): per-phase cycles of the k_step_grid instantiations of ONE translation unit (g_phase is
+// a per-unit device variable), averaged per sampled wave
+#ifdef ODR_PHASE_TIMING
+#define ODR_DEFINE_PHASE_DUMP(NAME, LABEL)                                                                                      \
+  void NAME() {                                                                                                                 \
+    unsigned long long h[32];                                                                                                   \
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h) != hipSuccess || !h[31]) return;                                  \
+    static const char *nm[9] = {"entry->state loaded", "env sample (gathers+math)", "stores+bookkeeping", "geod origin+stage1 pos", \
+                                "stage1 sample", "stage2 pos+sample", "stage3 pos+sample", "rk4 mix+final move", "final stores issue"}; \
+    static const char *sub[6] = {"env: front door + coverage", "env: xi, yi", "env: zbracket", "env: footprint + nearest",       \
+                                 "env: burst 1 (A, land)", "env: burst 2 (B, C, D)"};                                            \
+    double tot = 0;                                                                                                             \
+    for (int k = 0; k < 9; ++k) tot += (double)h[k] / (double)h[31];                                                             \
+    fprintf(stderr, "k_step_grid phases, %s (cycles per wave, %llu waves, total %.0f):\n", LABEL, h[31], tot);                   \
+    for (int k = 0; k < 9; ++k) fprintf(stderr, "  %-28s %9.0f  %5.1f %%\n", nm[k], (double)h[k] / (double)h[31], 100.0 * (double)h[k] / (double)h[31] / tot); \
+    for (int k = 0; k < 6; ++k) fprintf(stderr, "      %-28s %9.0f\n", sub[k], (double)h[10 + k] / (double)h[31]);               \
+  }
+#else
+#define ODR_DEFINE_PHASE_DUMP(NAME, LABEL) void NAME() {}
+#endif
+void odr_i_phase_dump_fast();
 // defined in odr_step_fast.hip / odr_step_fast_noise.hip: the ODR_STAGE_FAST instantiations (Runge-Kutta schemes only; the
 // kernels that serve any reader mix and the analytic double gyre take the mode at run time, StageNoise::sm)
 bool odr_i_advect_fast(odr_ctx *c, odr_particles *p, int scheme, double t, double dt, double factor, const StageNoise &N);

@@ -40,7 +40,7 @@ class OpenDriftSimulation(Configurable):
     required_variables = {}
     element_properties = {}   # name -> default (in addition to the LagrangianArray core variables)
 
-    def __init__(self, seed=0, loglevel=None, device=0, rng='device', iomodule=None, logfile=None):
+    def __init__(self, seed=0, loglevel=None, device=0, rng='device', iomodule=None, logfile=None, stage_math=None):
         super().__init__()
         if loglevel is not None:
             logger.setLevel(loglevel)
@@ -60,6 +60,12 @@ class OpenDriftSimulation(Configurable):
                                  "elements of one process")
         self._ctx, self._device, self._seed = None, device, seed or 0   # the device context is created on first use
         self.rng = rng                       # 'device' (Philox by ID) | 'numpy' (np.random in reference call order)
+        # arithmetic of the Runge-Kutta stage evaluations (odr_ctx_set_stage_math): 'exact' reproduces every float32 rounding
+        # point of the reference inside a stage (1e-10 deg per step vs the oracle), 'fast' takes the stage step and the stage
+        # sample without them (<= 2e-9 deg per step).  Runs that replay the reference's np.random stream are parity runs: exact.
+        self.stage_math = stage_math or ('exact' if rng == 'numpy' else 'fast')
+        if self.stage_math not in ('exact', 'fast'):
+            raise ValueError("stage_math must be 'exact' or 'fast'")
         if seed is not None:
             np.random.seed(seed)             # basemodel/__init__.py:326
         self.status_categories = ['active']
@@ -128,6 +134,8 @@ class OpenDriftSimulation(Configurable):
     def ctx(self):
         if self._ctx is None:
             self._ctx = Context(device=self._device, seed=self._seed)
+            if not os.environ.get('ODR_STAGE_MATH'):
+                self._ctx.set_stage_math(self.stage_math)
         return self._ctx
 
     # ------------------------------------------------------------------ mode machine (:136-190)

@@ -1,0 +1,192 @@
+"""The parity gate of ODR_STAGE_FAST (odr_ctx_set_stage_math, include/odrift.h): every golden vector written by the
+reference with a Runge-Kutta scheme, replayed through the device and through the model API with the FAST arithmetic of the
+stage evaluations, at the SAME tolerances the exact arithmetic is held to against the reference (1e-7 deg, z 1e-5 m);
+plus the direct distance between the two arithmetics per step.  (The device-vs-oracle tests of the other files pin the
+EXACT arithmetic at 1e-10 deg per step; they are not expected to hold under FAST and do not run with it.)"""
+from datetime import datetime, timedelta
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+T0 = datetime(2020, 1, 1)
+
+
+@pytest.fixture()
+def fast_ctx():
+    from opendrift_amd.device import Context
+    c = Context(device=0, seed=0)
+    c.set_stage_math('fast')
+    yield c
+    c.close()
+
+
+def test_the_mode_is_a_context_property_and_rejects_nonsense(fast_ctx):
+    from opendrift_amd._abi import OdrError
+    assert fast_ctx.stage_math == 'fast'
+    fast_ctx.set_stage_math('exact')
+    assert fast_ctx.stage_math == 'exact'
+    with pytest.raises(KeyError):
+        fast_ctx.set_stage_math('sloppy')
+    with pytest.raises((OdrError, ValueError)):
+        from opendrift_amd._abi import check
+        check(fast_ctx.lib.odr_ctx_set_stage_math(fast_ctx.h, 7))
+
+
+@pytest.mark.parametrize('name,scheme', [('rungekutta', 'runge-kutta'), ('rungekutta4', 'runge-kutta4')])
+def test_c2_double_gyre_fast(fast_ctx, name, scheme):
+    """analytic double gyre (k_advect_gyre takes the mode at run time) vs the reference's own run"""
+    g = golden('c2_double_gyre_%s.npz' % name)
+    U, V = 'x_sea_water_velocity', 'y_sea_water_velocity'
+    sid = fast_ctx.add_double_gyre(A=0.1, epsilon=0.25, omega=0.628, t0=0.0)
+    fast_ctx.bind(U, [sid], 0.0)
+    fast_ctx.bind(V, [sid], 0.0)
+    P = fast_ctx.particles(g['lon'].shape[1])
+    P.append(g['lon'][0], g['lat'][0])
+    nst, dt = g['lon'].shape[0] - 1, float(g['dt']) if 'dt' in g else 0.1
+    for k in range(nst):
+        P.env_sample([U, V], dt * k)
+        P.advect(scheme, dt * k, dt)
+    d = P.download()
+    o = np.argsort(d['ID'])
+    # the tolerance the exact arithmetic is held to on this golden (tests/test_gpu_parity.py): the domain is 2 m x 1 m
+    assert np.abs(d['lon'][o] - g['lon'][nst]).max() < 1e-9 and np.abs(d['lat'][o] - g['lat'][nst]).max() < 1e-9
+
+
+def test_c3_golden_fast(fast_ctx):
+    """RK4 + 3-D interpolation + vertical mixing + coastline 'previous' (the fused lat / lon kernel, SM = 1)"""
+    import replay
+    g = golden('c3_grid3d_rk4_vmix.npz')
+    nst = g['lon'].shape[0] - 1
+    D = replay.DeviceBackend(replay.scenario_c3(g), fast_ctx, g['lon'][0], g['lat'][0], g['z'][0])
+    worst = replay.compare(replay.replay_c3(D, g, nst), g, tol_pos=1e-7, tol_z=1e-5)
+    print('c3 FAST device vs reference:', worst)
+
+
+def test_c4_golden_fast(fast_ctx):
+    """polar-stereographic reader: projected stage positions, rotated float32 stage vectors"""
+    import replay
+    g = golden('c4_stere_rk4_hdiff_strand.npz')
+    D = replay.DeviceBackend(replay.scenario_c4(g), fast_ctx, g['lon'][0], g['lat'][0], g['z'][0], wdf=float(g['wdf']))
+    worst = replay.compare(replay.replay_c4(D, g, 10), g, tol_pos=1e-7)
+    print('c4 FAST device vs reference:', worst)
+
+
+@pytest.mark.parametrize('tag', ['rk2', 'rk4'])
+def test_c13_stage_noise_fast(fast_ctx, tag):
+    """current uncertainty inside the stage calls (the NOISE instantiations of the FAST kernels)"""
+    import replay
+    g = golden('c13_noise_rk.npz')
+    sub = {k: g[tag + '_' + k] for k in ('lon', 'lat', 'z', 'status')}
+    nsteps = sub['lon'].shape[0] - 1
+    D = replay.DeviceBackend(replay.scenario_c13(g), fast_ctx, sub['lon'][0], sub['lat'][0], sub['z'][0], wdf=0.02)
+    worst = replay.compare(replay.replay_c13(D, g, tag, nsteps), sub, tol_pos=1e-7, tol_z=1e-5)
+    print('c13', tag, 'FAST device vs reference:', worst)
+
+
+def test_c16_sea_ice_fast(fast_ctx):
+    import replay
+    g = golden('c16_openoil_sea_ice.npz')
+    nst = g['lon'].shape[0] - 1
+    D = replay.DeviceBackend(replay.scenario_c16(g), fast_ctx, g['lon'][0], g['lat'][0], g['z'][0], wdf=g['wdf'])
+    worst = replay.compare(replay.replay_c16(D, g, nst), g, tol_pos=1e-7)
+    print('c16 FAST device vs reference:', worst)
+
+
+@pytest.mark.parametrize('tag', ['2d', '3d'])
+def test_c17_ensemble_fast(fast_ctx, tag):
+    """ensemble members: the generic kernels (k_advect takes the mode at run time)"""
+    import replay
+    g = golden('c17_ensemble_reader.npz')
+    sub = {k: g[tag + '_' + k] for k in ('lon', 'lat', 'z', 'status')}
+    nst = sub['lon'].shape[0] - 1
+    D = replay.DeviceBackend(replay.scenario_c17(g, tag), fast_ctx, sub['lon'][0], sub['lat'][0], sub['z'][0], wdf=0.0)
+    worst = replay.compare(replay.replay_c17(D, g, tag, nst), sub, tol_pos=1e-7, tol_z=1e-5)
+    print('c17', tag, 'FAST device vs reference:', worst)
+
+
+def _model_c3(stage_math, rng):
+    from opendrift_amd import readers
+    from opendrift_amd.oceandrift import OceanDrift
+    g = golden('c3_grid3d_rk4_vmix.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity',
+             'ocean_vertical_diffusivity', 'sea_floor_depth_below_sea_level', 'land_binary_mask']
+    times = [T0 + timedelta(seconds=float(t)) for t in g['g_t']]
+    o = OceanDrift(loglevel=50, seed=0, rng=rng, stage_math=stage_math)
+    o.add_reader(readers.GridReader(g['g_x'], g['g_y'], times, {k: g['g_' + k] for k in names}, z=g['g_z']))
+    o.set_config('drift:advection_scheme', 'runge-kutta4')
+    o.set_config('drift:vertical_mixing', True)
+    o.set_config('vertical_mixing:timestep', 60)
+    o.set_config('general:coastline_action', 'previous')
+    o.seed_elements(lon=g['lon'][0], lat=g['lat'][0], z=g['z'][0], time=T0)
+    o.run(time_step=600, steps=8)
+    n = g['lon'].shape[1]
+    lon, lat, z = np.full(n, np.nan), np.full(n, np.nan), np.full(n, np.nan)
+    for d in (o.elements, o.elements_deactivated):
+        lon[d.ID], lat[d.ID], z[d.ID] = d.lon, d.lat, d.z
+    return g, lon, lat, z, o
+
+
+def test_c3_model_api_fast_reproduces_the_reference_run():
+    """OceanDrift(rng='numpy', stage_math='fast').run(): the reference's stochastic C3 run at the exact mode's tolerance"""
+    g, lon, lat, z, o = _model_c3('fast', 'numpy')
+    assert o.ctx.stage_math == 'fast'
+    assert np.nanmax(np.abs(lon - g['lon'][-1])) < 1e-7 and np.nanmax(np.abs(lat - g['lat'][-1])) < 1e-7
+    assert np.nanmax(np.abs(z - g['z'][-1])) < 1e-5
+    assert o.status_categories == ['active', 'seeded_on_land'] and o.num_elements_deactivated() == 4
+
+
+def test_defaults_parity_runs_exact_device_rng_runs_fast():
+    from opendrift_amd.oceandrift import OceanDrift
+    assert OceanDrift(loglevel=50, rng='numpy').stage_math == 'exact'
+    assert OceanDrift(loglevel=50).stage_math == 'fast'
+    assert OceanDrift(loglevel=50, stage_math='exact').stage_math == 'exact'
+    with pytest.raises(ValueError):
+        OceanDrift(loglevel=50, stage_math='sloppy')
+
+
+def test_fast_and_exact_differ_by_nanodegrees_per_step():
+    """the two arithmetics on the same RK4 step of a sheared 3-D field: identical main-loop sample (bit for bit), positions
+    within 3e-9 deg of each other after one step (measured 1e-9); Euler is the same launch in both modes"""
+    from opendrift_amd import synthetic as synth
+    from opendrift_amd.device import Context
+    U, V, W = 'x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity'
+    DEPTH, LAND, SSH = 'sea_floor_depth_below_sea_level', 'land_binary_mask', 'sea_surface_height'
+    g = synth.grid3d(nx=96, ny=64, nz=10, nt=3, seed=5)
+    names = [U, V, W, DEPTH, LAND]
+    rng = np.random.default_rng(11)
+    n = 20000
+    lon = rng.uniform(g['x'][3], g['x'][-4], n)
+    lat = rng.uniform(g['y'][3], g['y'][-4], n)
+    z = -rng.uniform(0, 80, n)
+    out = {}
+    for mode in ('exact', 'fast'):
+        for scheme in ('euler', 'runge-kutta', 'runge-kutta4'):
+            c = Context(device=0, seed=0)
+            c.set_stage_math(mode)
+            sid = c.add_grid(g['x'], g['y'], z=g['z'])
+            for k in range(3):
+                c.upload_block(sid, k, float(g['t'][k]), {nm: g[nm][k] for nm in names})
+            for nm in names:
+                c.bind(nm, [sid], {LAND: np.nan, DEPTH: 10000.0}.get(nm, 0.0))
+            c.bind(SSH, [], 0.0)
+            P = c.particles(n)
+            P.append(lon, lat, z=z)
+            P.env_coast_advect([U, V, W, DEPTH, SSH, LAND], 1500.0, scheme, 600.0, coastline='previous', store_previous=True,
+                               count=False, seafloor=True)
+            d = P.download()
+            o = np.argsort(d['ID'])
+            out[mode, scheme] = (d['lon'][o], d['lat'][o], P.env_download(U)[o], P.env_download(W)[o])
+            P.close()
+            c.close()
+    for scheme in ('euler', 'runge-kutta', 'runge-kutta4'):
+        (lo1, la1, u1, w1), (lo2, la2, u2, w2) = out['exact', scheme], out['fast', scheme]
+        assert np.array_equal(u1, u2, equal_nan=True) and np.array_equal(w1, w2, equal_nan=True)   # o.environment: same bits
+        dmax = max(np.nanmax(np.abs(lo1 - lo2)), np.nanmax(np.abs(la1 - la2)))
+        if scheme == 'euler':
+            assert dmax == 0.0
+        else:
+            assert 0.0 < dmax < 3e-9, dmax
+        print(scheme, 'FAST vs EXACT after one step: %.2e deg' % dmax)
