@@ -1086,6 +1086,9 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(PView p, double wind_drift_dep
   v[R_NSURF] = 0;
   const double wdd = fabs(wind_drift_depth);
   for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < p.n; i += (long long)gridDim.x * BLOCK) {
+    // elements deactivated in this step and not yet compacted do not count: the reference has removed them by the time
+    // its movers reduce (a sharded run reduces once per step, before the compaction: odr_reduce_local)
+    if (p.status[i] != 0) continue;
     double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
     v[R_NACT] += 1;
     v[R_LONMIN] = fmax(v[R_LONMIN], -lon); v[R_LONMAX] = fmax(v[R_LONMAX], lon);

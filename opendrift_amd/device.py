@@ -722,6 +722,17 @@ class Particles:
         check(self.lib.odr_reduce_install(self.ctx.h, self.h, g.ctypes.data_as(_dp)))
         return g
 
+    def reduce_local(self, wind_drift_depth=0.1, relative_wind=False):
+        """The 16 raw reduction slots of THIS rank's active elements (status 0; odr_reduce_local): slots 0 and 11 are
+        counts, the others maxima (minima negated).  Combined over the ranks by the caller, then reduce_install()."""
+        raw = np.empty(16)
+        check(self.lib.odr_reduce_local(self.ctx.h, self.h, float(wind_drift_depth), int(relative_wind), raw.ctypes.data_as(_dp)))
+        return raw
+
+    def reduce_install(self, combined16):
+        g = np.ascontiguousarray(combined16, dtype=np.float64)
+        check(self.lib.odr_reduce_install(self.ctx.h, self.h, g.ctypes.data_as(_dp)))
+
     @staticmethod
     def reduction_dict(raw):
         keys = ['n_active', 'lon_min', 'lon_max', 'lat_min', 'lat_max', 'z_min', 'z_max', 'D_max',
@@ -780,7 +791,7 @@ def _reading(fn):
     return wrapper
 
 
-for _name in ('download', 'download_f32', 'env_download', 'get_property', 'reduce_scalars', 'reduce_global', 'oil_global_stats',
+for _name in ('download', 'download_f32', 'env_download', 'get_property', 'reduce_scalars', 'reduce_global', 'reduce_local', 'oil_global_stats',
               'scan_status', 'count_status'):
     setattr(Particles, _name, _reading(getattr(Particles, _name)))
 

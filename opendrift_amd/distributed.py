@@ -10,6 +10,9 @@ import os
 import numpy as np
 
 
+COUNT_SLOTS = (0, 11)      # odr_reduce_local: n_active, n_surface are sums; every other slot is a maximum
+
+
 def env_world():
     return (int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)),
             int(os.environ.get('WORLD_SIZE', 1)))
@@ -87,13 +90,41 @@ def allreduce_scalars(values, op='sum'):
     return t.cpu().numpy()
 
 
+def allgather_vector(values):
+    """ONE collective for everything a step needs from the other ranks: every rank's float64 vector, as rows of a
+    [world, n] array (the caller sums / maximises the columns itself -- counts and maxima travel together)."""
+    import torch
+    import torch.distributed as dist
+    rank, local_rank, world = env_world()
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    if world == 1 or not dist.is_initialized():
+        return v[None, :]
+    dev = torch.device('cuda', local_rank) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.from_numpy(v).to(dev)
+    if dist.get_backend() == 'nccl':
+        out = torch.empty((world, v.size), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(out, t)
+        return out.cpu().numpy()
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    return torch.stack(parts).numpy()
+
+
+def combine_rows(rows):
+    """Rows of raw reduction slots (one per rank) -> the all-rank reductions: COUNT_SLOTS summed, the others maximised."""
+    rows = np.asarray(rows, dtype=np.float64)
+    out = rows.max(axis=0)
+    for k in COUNT_SLOTS:
+        out[k] = rows[:, k].sum()
+    return out
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
 
 
-COUNT_SLOTS = (0, 11)      # odr_reduce_local: n_active, n_surface are sums; every other slot is a maximum
 
 
 def combine_reductions(raw16):
@@ -110,20 +141,87 @@ def combine_reductions(raw16):
     return out
 
 
-def broadcast_reader_block(block_or_none, variables, src=0):
-    """One reader time level from the rank that runs the host Reader to every rank: the coordinate metadata as a Python
-    object, the arrays as tensors (RCCL broadcast into device memory under nccl).  Returns (meta, {variable: tensor})."""
+class RemoteReaderError(RuntimeError):
+    """The reader of the rank that reads failed: raised on EVERY rank, so that all of them count the failure alike."""
+
+
+def broadcast_reader_block(block_or_none, variables, src=0, error=None, shapes=None, async_op=False):
+    """One reader time level from the rank that runs the host Reader to every rank:
+      * a one-number header (1 = the level follows, 0 = the reader failed: EVERY rank raises RemoteReaderError -- nobody is
+        left waiting in a collective, and all ranks count the failure alike);
+      * `shapes` None (first level of a reader): the coordinate metadata and the array shapes as a Python object; later
+        levels pass the shapes they know and skip this (the metadata of a reader does not change);
+      * the arrays as tensors (RCCL broadcast into device memory under nccl).
+    async_op: the array broadcasts are only STARTED -- the prefetch of the next level while the current one is in use; all
+    ranks step in lockstep, so the order of the collectives is the same everywhere.  Returns (meta or None, {variable:
+    tensor}, [work handles]); finish_broadcast(works) before the tensors are used."""
     import torch.distributed as dist
     rank, local_rank, world = env_world()
-    meta = [None]
-    arrays = None
-    if rank == src:
+    meta, arrays = None, None
+    if rank == src and error is None:
         b = block_or_none
-        meta = [{k: (np.asarray(b[k]) if k in ('x', 'y', 'z') and b.get(k) is not None else b.get(k))
-                 for k in ('x', 'y', 'z', 'time', 's_level_variables') if k in b}]
         arrays = {v: np.ascontiguousarray(np.ma.filled(b[v], np.nan) if isinstance(b[v], np.ma.MaskedArray) else b[v],
                                           dtype=np.float32) for v in variables}
+        if shapes is None:
+            meta = {k: (np.asarray(b[k]) if k in ('x', 'y', 'z') and b.get(k) is not None else b.get(k))
+                    for k in ('x', 'y', 'z', 'time', 's_level_variables') if k in b}
+            meta['__shapes__'] = {v: tuple(a.shape) for v, a in arrays.items()}
     if world > 1:
-        dist.broadcast_object_list(meta, src=src)
-    tens = broadcast_block(arrays, src=src)
-    return meta[0], tens
+        ok = allreduce_scalars([0.0 if (rank == src and error is not None) else 1.0], 'min')[0]
+        if ok < 1:
+            raise RemoteReaderError('the reader failed on rank %d%s' % (src, (': %r' % (error,)) if error is not None else ''))
+        if shapes is None:
+            box = [meta]
+            dist.broadcast_object_list(box, src=src)
+            meta = box[0]
+    elif error is not None:
+        raise error
+    if shapes is None:
+        shapes = meta.pop('__shapes__')
+    tens, works = start_broadcast_block(arrays, shapes, src)
+    if not async_op:
+        finish_broadcast(works)
+        works = []
+    return meta, tens, works
+
+
+def _device():
+    import torch
+    import torch.distributed as dist
+    rank, local_rank, world = env_world()
+    return torch.device('cuda', local_rank) if (world > 1 and dist.get_backend() == 'nccl') or \
+        (world == 1 and torch.cuda.is_available()) else torch.device('cpu')
+
+
+def start_broadcast_block(arrays, shapes, src=0):
+    """Start the broadcasts of one block whose shapes every rank knows; returns ({variable: tensor}, [work handles])."""
+    import torch
+    import torch.distributed as dist
+    rank, local_rank, world = env_world()
+    dev = _device()
+    tens, works = {}, []
+    for k, shp in shapes.items():
+        if rank == src:
+            a = torch.from_numpy(np.ascontiguousarray(arrays[k], dtype=np.float32))
+            t = a.pin_memory().to(dev, non_blocking=True) if dev.type == 'cuda' else a
+        else:
+            t = torch.empty(tuple(shp), dtype=torch.float32, device=dev)
+        if world > 1:
+            works.append(dist.broadcast(t, src=src, async_op=True))
+        tens[k] = t
+    return tens, works
+
+
+def finish_broadcast(works):
+    import torch
+    for w in works:
+        w.wait()
+    dev = _device()
+    if dev.type == 'cuda':
+        torch.cuda.synchronize(dev)    # the tensors are consumed on the library's upload stream, not on torch's
+
+
+def broadcast_block_known(arrays, shapes, src=0):
+    tens, works = start_broadcast_block(arrays, shapes, src)
+    finish_broadcast(works)
+    return tens

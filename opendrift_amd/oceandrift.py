@@ -366,6 +366,8 @@ class OpenDriftSimulation(Configurable):
         return int(self._released_mask().size - self._released_mask().sum())
 
     def num_elements_total(self):
+        if getattr(self, '_n_global', None) is not None:
+            return self._n_global       # a sharded run keeps its own ID range of the schedule only
         return 0 if self._sched is None else len(self._sched['lon'])
 
     def _released_mask(self):
@@ -479,26 +481,70 @@ class OpenDriftSimulation(Configurable):
         return code
 
     # ---- sharded run: what the control flow and the status categories depend on is combined over the ranks, so that
-    # every rank takes the same branches, makes the same collectives and numbers the deactivation reasons alike
-    def _global_counts(self):
+    # every rank takes the same branches, makes the same collectives and numbers the deactivation reasons alike.
+    # ONE collective per step (_step_summary, after the fused launch); the counts at the top of a step need none: every
+    # rank knows the release schedule of ALL elements (run() keeps its per-step histogram before it cuts the schedule down
+    # to its own ID range), and the number of active elements is what the previous step's collective left plus the releases.
+    def _global_counts(self, step=None):
         """(active, scheduled) over all ranks; also whether ANY rank released elements in this step (the reference's
-        `newly_seeded_IDs is not None`, which arms the 'seeded_on_land' check) -- one all-reduce."""
+        `newly_seeded_IDs is not None`, which arms the 'seeded_on_land' check)."""
         na, ns = self.num_elements_active(), self.num_elements_scheduled()
         self._newly_any = self.newly_seeded > 0
         self._g_active = na
         if self._world == 1:
             return na, ns
+        if step is not None and getattr(self, '_g_release', None) is not None and step < len(self._g_release):
+            rel = int(self._g_release[step])
+            self._newly_any = rel > 0
+            self._g_active = self._g_active_carry + rel
+            self._g_active_carry = self._g_active
+            return self._g_active, int(self._n_global - self._g_release_cum[step + 1])
         from . import distributed as D
+        self._timing_collectives += 1
         g = D.allreduce_scalars([na, ns, self.newly_seeded], 'sum')
         self._newly_any = g[2] > 0
-        self._g_active = int(g[0])
+        self._g_active = self._g_active_carry = int(g[0])
         return int(g[0]), int(g[1])
+
+    def _step_summary(self, kept, flags, want_reductions):
+        """The ONE collective of a sharded step: this rank's kept count, provisional status flags and (when a mover of this
+        step needs them) its 16 raw reduction slots, all-gathered; returns the all-rank (kept, flags) and installs the
+        all-rank reductions for the movers that follow (released by _step_release at the end of the step)."""
+        if self._world == 1:
+            return kept, flags
+        from . import distributed as D
+        wdd, rel = self.get_config('drift:wind_drift_depth', 0.1), bool(self.get_config('drift:relative_wind'))
+        raw = self.P.reduce_local(wdd, rel) if want_reductions else np.zeros(16)
+        t0 = time.perf_counter()
+        rows = D.allgather_vector(np.concatenate([[float(kept)], [float(flags >> k & 1) for k in range(8)], raw]))
+        self._timing_collective_s += time.perf_counter() - t0
+        self._timing_collectives += 1
+        g_kept = int(round(rows[:, 0].sum()))
+        g_flags = sum(1 << k for k in range(8) if rows[:, 1 + k].max() > 0)
+        if want_reductions:
+            self._step_red = D.combine_rows(rows[:, 9:])
+            self.P.reduce_install(self._step_red)
+        self._g_active = self._g_active_carry = g_kept
+        return g_kept, g_flags
+
+    def _step_release(self):
+        if getattr(self, '_step_red', None) is not None:
+            self._step_red = None
+            self.P.reduce_unpin()
+
+    def _needs_reductions(self):
+        """Does a mover of this step consult global maxima / counts (advect_wind, stokes_drift, horizontal_diffusion, the
+        wind-parameterised mixing)?"""
+        rv = self.required_variables
+        return ('x_wind' in rv or 'sea_surface_wave_stokes_drift_x_velocity' in rv or 'horizontal_diffusivity' in rv or
+                'ocean_mixed_layer_thickness' in rv)
 
     def _global_scan(self, kept, flags):
         if self._world == 1:
             return kept, flags
         from . import distributed as D
         bits = [float(flags >> k & 1) for k in range(8)]
+        self._timing_collectives = getattr(self, '_timing_collectives', 0) + 1
         g = D.allreduce_scalars(bits, 'max')
         return kept, sum(1 << k for k in range(8) if g[k] > 0)
 
@@ -513,7 +559,7 @@ class OpenDriftSimulation(Configurable):
         made -- one host read however many reasons are pending, none when nothing is pending."""
         pending, self._pending_status = self._pending_status, []
         pending = [r for r in pending if r not in self.status_categories]
-        if not pending and (self._world == 1 or flags is not None):
+        if not pending:      # (the pending list is the same on every rank: it follows from the configuration alone)
             return
         if flags is None:
             flags = self._global_scan(0, self.P.scan_status()[1] if len(self.P) else 0)[1]
@@ -672,13 +718,17 @@ class OpenDriftSimulation(Configurable):
         device for the mover that follows (release with P.reduce_unpin())."""
         if self._world == 1:
             return self.P.reduce_scalars(wdd)
+        if getattr(self, '_step_red', None) is not None:      # this step's collective already holds them
+            return self.P.reduction_dict(self._step_red)
+        self._timing_collectives += 2
         return self.P.reduction_dict(self.P.reduce_global(self._combine(), wdd, False))
 
     def _with_global_reduction(self, call, wdd=0.1, relwind=False):
         """Sharded run: the movers' global early-outs and maxima over the elements of ALL ranks (odr_reduce_local /
         _install); one process: the device reduces on its own."""
-        if self._world == 1:
-            return call()
+        if self._world == 1 or getattr(self, '_step_red', None) is not None:
+            return call()          # one process: the device reduces on its own; sharded: installed by this step's collective
+        self._timing_collectives += 2
         self.P.reduce_global(self._combine(), wdd, relwind)
         try:
             return call()
@@ -716,7 +766,7 @@ class OpenDriftSimulation(Configurable):
             tp_mode = 1 if r['wind_speed_max'] >= 0 else 2   # Tp is not an OceanDrift variable: from wind (omega=5 when calm)
             self.P.stokes_drift(self.time_step.total_seconds(), profile, hs_mode, tp_mode, factor)
         finally:
-            if self._world > 1:
+            if self._world > 1 and getattr(self, '_step_red', None) is None:
                 self.P.reduce_unpin()
 
     def prepare_run(self):
@@ -799,15 +849,31 @@ class OpenDriftSimulation(Configurable):
         self._finalize_environment(self.start_time, self.start_time + time_step)
         n_total = self.num_elements_total()
         lo_id, hi_id = 0, n_total
+        self._n_global = n_total
+        self._g_release = self._g_release_cum = None
+        self._g_active_carry = 0
+        self._timing_collectives, self._timing_collective_s, self._step_red = 0, 0.0, None
         if self._world > 1:     # this rank's contiguous range of element IDs; the others are never released here
             from . import distributed as D
             lo_id, hi_id = D.shard_range(n_total, self._rank, self._world)
-            rel = self._released_mask()
-            rel[:lo_id] = True
-            rel[hi_id:] = True
+            # the release schedule of ALL elements as a histogram over the steps (what _global_counts needs), then the
+            # schedule itself cut down to this rank's range: the per-step host work is O(N / ranks) from here on
+            te, dts = self._sched['t_epoch'], time_step.total_seconds()
+            t_start = _epoch(self.start_time)
+            if self._all_at_start:
+                k = np.zeros(n_total, np.int64)
+            else:
+                k = np.floor((te - t_start) / dts + 1e-9).astype(np.int64) if dts > 0 else np.floor((t_start - te) / -dts + 1e-9).astype(np.int64)
+            ok = (k >= 0) & (k < steps)
+            self._g_release = np.bincount(k[ok], minlength=steps)
+            self._g_release_cum = np.concatenate([[0], np.cumsum(self._g_release)])
+            self._sched = {kk: v[lo_id:hi_id] for kk, v in self._sched.items()}
+            for attr in ('_released', '_n_unreleased', '_t_sched'):
+                if hasattr(self, attr):
+                    delattr(self, attr)
             self._all_at_start = False if n_total == 0 else self._all_at_start
         self._shard = (lo_id, hi_id)
-        self._resolve_seafloor_seeds(lo_id, hi_id)
+        self._resolve_seafloor_seeds(0, hi_id - lo_id)
         self.P = self.ctx.particles(max(1, hi_id - lo_id))
         self.mode = 'Run'
         self.prepare_run()
@@ -854,7 +920,7 @@ class OpenDriftSimulation(Configurable):
                     self.ctx.sync()
                     t_loop[1] = time.perf_counter()   # after the first step: seeding, first uploads and sort are behind
                 self.release_elements()
-                g_active, g_sched = self._global_counts()
+                g_active, g_sched = self._global_counts(i)
                 if g_active == 0 and g_sched > 0:
                     self._state_to_buffer(i, out_every, times)   # (:2208)
                     self.steps_calculation += 1
@@ -867,6 +933,7 @@ class OpenDriftSimulation(Configurable):
                 if self.rng == 'device' and grid_sid is not None and self.sort_every and n_act > 65536 and \
                         (i % self.sort_every == 0 or self.newly_seeded * 20 > n_act):
                     self.P.sort_by_cell(grid_sid, keep_environment=False)   # the step's sample follows
+                one_collective = False
                 if fused_lane:
                     # ONE launch for get_environment + coastline + seafloor + update_previous_state +
                     # advect_ocean_current (odr_env_coast_advect).  deactivate_outside only reads positions and goes
@@ -893,7 +960,7 @@ class OpenDriftSimulation(Configurable):
                     self._add_uncertainty(names, current=False)     # the wind's share
                     # ONE host read per step: how many elements stay + which new deactivation reasons occurred
                     kept, flags = self.P.scan_status()
-                    kept, flags = self._global_scan(kept, flags)
+                    kept, flags = self._step_summary(kept, flags, self._needs_reductions())   # the step's ONE collective
                     self._resolve_status(flags)
                     self._state_to_buffer(i, out_every, times, from_previous=True)
                     if not age_in_launch:
@@ -906,15 +973,26 @@ class OpenDriftSimulation(Configurable):
                     self.deactivate_outside()
                     self.interact_with_coastline()
                     self.interact_with_seafloor()
-                    self._resolve_status()
-                    self._state_to_buffer(i, out_every, times)
                     max_age = self.get_config('drift:max_age_seconds')
+                    one_collective = self._world > 1 and not max_age
+                    if one_collective:      # sharded: the step's ONE collective, as in the fused lane
+                        kept, flags = self.P.scan_status()
+                        kept, flags = self._step_summary(kept, flags, self._needs_reductions())
+                        self._resolve_status(flags)
+                    else:
+                        self._resolve_status()
+                    self._state_to_buffer(i, out_every, times)
                     self.P.increase_age(self.time_step.total_seconds(), max_age or 0.0,
                                         self._status_code('retired') if max_age else 0)
-                    self._resolve_status()
-                    self.P.compact()
+                    if one_collective:
+                        self.P.compact_apply()
+                    else:
+                        self._resolve_status()
+                        self.P.compact()
                     self.P.store_previous()
-                if self._world > 1:
+                if self._world > 1 and (fused_lane or one_collective):
+                    g_active = self._g_active           # from this step's collective
+                elif self._world > 1:
                     newly = self._newly_any
                     g_active = self._global_counts()[0]
                     self._newly_any = newly
@@ -927,6 +1005,7 @@ class OpenDriftSimulation(Configurable):
                     raise ValueError('No more active or scheduled elements, quitting.')
                 self._advected = False
                 self.horizontal_diffusion()
+                self._step_release()
                 self.time = self.time + self.time_step
                 self.steps_calculation += 1
             except Exception as e:
@@ -937,6 +1016,8 @@ class OpenDriftSimulation(Configurable):
         self.ctx.sync()
         t_end = time.perf_counter()
         self.timing = {'main_loop_s': t_end - t_loop[0], 'steps': self.steps_calculation,
+                       'collectives': self._timing_collectives, 'collective_s': self._timing_collective_s,
+                       'reader_level_stall_s': sum(getattr(b, 'stall_s', 0.0) for b in self.readers.values()),
                        'steady_ms_per_step': (1e3 * (t_end - t_loop[1]) / max(1, self.steps_calculation - 1)) if t_loop[1] else None}
         self.interact_with_coastline(final=True)
         self._resolve_status()

@@ -217,6 +217,7 @@ class OpenOil(OceanDrift):
             kw['step'] = self.steps_calculation
         if self._world > 1:   # OpenOil's means over ALL elements: np.mean(dV_50), np.mean(1.5 Hs) (openoil.py:1099-1101,1047)
             from . import distributed as D
+            self._timing_collectives = getattr(self, '_timing_collectives', 0) + 1
             self.P.oil_global_stats(lambda v: D.allreduce_scalars(v, 'sum'), self.oil_water_interfacial_tension,
                                     self.get_config('wave_entrainment:droplet_size_distribution'),
                                     sea_water_density_default(), hs_mode=hs_mode)

@@ -392,8 +392,8 @@ class DeviceReaderBinding:
         self._pinned = False
         from .distributed import env_world
         self.rank, _, self.world = env_world()
-        if self.world > 1:
-            self.prefetch = False      # the broadcast of a level is a collective: made when the level is due
+        self.stall_s = 0.0             # host time spent waiting for a level that was due (run().timing reports the sum)
+        self._dist_pre = {}            # sharded run: time index -> (tensors, works) of a level whose broadcast is under way
         kind = getattr(reader, 'device_kind', None)
         # a ContinuousReader the device has no closed form for (a user's analytic or point-wise reader,
         # basereader/continuous.py:20-46): evaluated on the host at the element positions, values uploaded
@@ -509,7 +509,15 @@ class DeviceReaderBinding:
                 continue
             self._upload(k, extent, broadcast, asynchronous=False)
         # prefetch the time level the run will need next (readers whose arrays live in host memory)
-        if self.prefetch and r.times is not None and broadcast is None and not getattr(r, 's_levels', False):
+        if self.prefetch and self.world > 1 and r.times is not None and broadcast is None and self.sid is not None and \
+                getattr(self, '_dist_shapes', None) is not None:
+            kn = (max(need) + 1) if t1 >= t0 else (min(need) - 1)
+            if 0 <= kn < len(r.times) and kn not in self.slots and kn not in self._dist_pre and len(self._dist_pre) == 0:
+                try:
+                    self._prefetch_dist(kn, extent)
+                except Exception:        # a failing read shows up -- on every rank alike -- when the level is due
+                    self._dist_pre.pop(kn, None)
+        elif self.prefetch and r.times is not None and broadcast is None and not getattr(r, 's_levels', False):
             kn = (max(need) + 1) if t1 >= t0 else (min(need) - 1)
             if 0 <= kn < len(r.times) and kn not in self.slots and kn not in self.staged:
                 if len(self.slots) + len(self.staged) >= self.NSLOTS:     # room for the prefetch: the stalest level goes
@@ -519,6 +527,36 @@ class DeviceReaderBinding:
                         self.ctx.drop_block(self.sid, self.slots.pop(k_old))
                 if len(self.slots) + len(self.staged) < self.NSLOTS:
                     self._upload(kn, extent, None, asynchronous=True)
+
+    def _read_and_broadcast(self, k, x, y, async_op):
+        """Sharded run: rank 0 reads time level k, every rank receives it.  A reader failure on rank 0 reaches every rank as
+        RemoteReaderError (the header of broadcast_reader_block): no rank is left waiting in a collective, and all of them
+        count the failure alike."""
+        from . import distributed as D
+        r = self.reader
+        time = r.times[k] if r.times is not None else None
+        block, err = None, None
+        if self.rank == 0:
+            try:
+                block = r.get_variables(self.variables, time, x, y, np.array([0.0]))
+                if any(isinstance(block[v], (list, tuple)) for v in self.variables):
+                    raise NotImplementedError('ensemble data (lists of member arrays) in a sharded run')
+            except Exception as e:      # noqa: BLE001 -- every reader exception is a reader failure (environment.py:640-668)
+                err = e
+        shapes = getattr(self, '_dist_shapes', None)
+        meta, tens, works = D.broadcast_reader_block(block, self.variables, src=0, error=err, shapes=shapes, async_op=async_op)
+        if shapes is None:
+            self._dist_shapes = {v: tuple(t.shape) for v, t in tens.items()}
+        return meta, tens, works
+
+    def _prefetch_dist(self, kn, extent):
+        """Start the broadcast of the level the run needs next while the current one is in use (every rank makes this call
+        at the same step: the collectives stay in the same order everywhere)."""
+        x = y = None
+        if extent is not None:
+            x, y = np.array(extent[0]), np.array(extent[1])
+        meta, tens, works = self._read_and_broadcast(kn, x, y, async_op=True)
+        self._dist_pre[kn] = (tens, works)
 
     def _page_locked(self, v, arr):
         if isinstance(arr, (list, tuple)):       # ensemble members: stacked by the context
@@ -549,13 +587,22 @@ class DeviceReaderBinding:
             x, y = np.array(extent[0]), np.array(extent[1])
         if self.world > 1:
             # sharded run (one process per GPU): the rank that owns the host Reader reads the level, every rank receives
-            # it -- over RCCL / xGMI straight into device memory (opendrift_amd/distributed.py)
+            # it -- over RCCL / xGMI straight into device memory (opendrift_amd/distributed.py).  A level whose broadcast
+            # was started one period ahead (_prefetch_dist) only has to be waited for.
             from . import distributed as D
-            block = r.get_variables(self.variables, time, x, y, np.array([0.0])) if self.rank == 0 else None
-            if block is not None and any(isinstance(block[v], (list, tuple)) for v in self.variables):
-                raise NotImplementedError('ensemble data (lists of member arrays) in a sharded run')
-            meta, tens = D.broadcast_reader_block(block, self.variables, src=0)
-            block = dict(meta)
+            import time as _time
+            t_wait = _time.perf_counter()
+            if k in self._dist_pre:
+                tens, works = self._dist_pre.pop(k)
+                D.finish_broadcast(works)
+                meta = None
+            else:
+                meta, tens, _ = self._read_and_broadcast(k, x, y, async_op=False)
+            self.stall_s += _time.perf_counter() - t_wait
+            if meta is not None:
+                self._dist_meta = meta
+            block = dict(self._dist_meta)
+            block['time'] = time
             for v, t in tens.items():
                 block[v] = t if t.is_cuda else t.numpy()
             self._tensors = tens      # keep the device tensors alive until the block is built

@@ -69,7 +69,10 @@ def main():
     a, d = o.elements, o.elements_deactivated
     np.savez(out + '.rank%d.npz' % o._rank, ID=np.concatenate([a.ID, d.ID]), lon=np.concatenate([a.lon, d.lon]),
              lat=np.concatenate([a.lat, d.lat]), z=np.concatenate([a.z, d.z]), status=np.concatenate([a.status, d.status]),
-             categories=np.array(o.status_categories), shard=np.array(o._shard))
+             categories=np.array(o.status_categories), shard=np.array(o._shard),
+             timing=np.array([o.timing['steps'], o.timing['collectives'], o.timing['collective_s'], o.timing['reader_level_stall_s']]),
+             n_sched_local=np.array(len(o._sched['lon'])), n_total=np.array(o.num_elements_total()),
+             prefetched=np.array(sum(int(getattr(b, '_dist_shapes', None) is not None) for b in o.readers.values())))
     if o._world > 1:
         import torch.distributed as dist
         dist.barrier()

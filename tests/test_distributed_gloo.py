@@ -83,7 +83,8 @@ def _combine_worker(rank, world, port, q):
     # a reader block read by rank 0 only
     blk = dict(x=np.arange(5, dtype=np.float32), y=np.arange(4, dtype=np.float32), z=None, time=None,
                u=np.arange(20, dtype=np.float32).reshape(4, 5)) if rank == 0 else None
-    meta, tens = D.broadcast_reader_block(blk, ['u'])
+    meta, tens, works = D.broadcast_reader_block(blk, ['u'])
+    assert works == []
     q.put((rank, got.tolist(), meta['x'].tolist(), tens['u'].numpy().tolist()))
     import torch.distributed as dist
     dist.destroy_process_group()

@@ -43,6 +43,7 @@ def _run(scenario, world, out):
     res = {k: np.concatenate([q[k] for q in parts])[order] for k in ('ID', 'lon', 'lat', 'z', 'status')}
     cats = [list(q['categories']) for q in parts]
     assert all(c == cats[0] for c in cats), cats       # every rank numbers the deactivation reasons alike
+    res['_parts'] = parts
     return res, cats[0], [tuple(q['shard']) for q in parts]
 
 
@@ -62,6 +63,14 @@ def test_two_ranks_equal_one_rank(tmp_path, scenario):
         assert np.abs(one['z'] - two['z']).max() < 2e-6 and np.array_equal(one['z'] == 0, two['z'] == 0)
     else:
         assert np.array_equal(one['z'], two['z']), np.abs(one['z'] - two['z']).max()
+    # the sharded run's communication: ONE collective per step (the all-gathered step summary: kept count, new status
+    # reasons, the movers' reductions) -- plus OpenOil's two global means and the per-level reader headers; every rank
+    # holds only its own ID range of the schedule
+    for q in two['_parts']:
+        steps, ncoll = int(q['timing'][0]), int(q['timing'][1])
+        per_step = 2 if scenario == 'openoil' else 1
+        assert ncoll <= per_step * steps + 4, (steps, ncoll)
+        assert int(q['n_sched_local']) == int(q['shard'][1] - q['shard'][0]) and int(q['n_total']) == len(one['ID'])
     if scenario == 'oceandrift':
         assert 'outside' in cats1 and (one['status'] != 0).sum() > 10
     assert (one['z'] < -1).sum() > 100
