@@ -182,7 +182,7 @@ class OpenDriftSimulation(Configurable):
                 self.priority_list.setdefault(v, []).insert(0, 'constant_reader_config')
         for name, (r, vs) in self._readers_host.items():
             self.readers[name] = DeviceReaderBinding(self.ctx, r, variables=vs)
-            self.readers[name].set_extent(getattr(self, 'simulation_extent', None))
+            self.readers[name].set_extent(getattr(self, '_block_extent', getattr(self, 'simulation_extent', None)))
         landmasks = [n for n, (r, _) in self._readers_host.items() if getattr(r, 'device_kind', None) == 'landmask']
         self._landmask_sid = self.readers[landmasks[0]].sid if landmasks else None
         if self.get_config('general:use_auto_landmask'):
@@ -209,7 +209,7 @@ class OpenDriftSimulation(Configurable):
         more than readers:max_number_of_fails failures, discarded (Environment.get_environment, environment.py:640-668,
         discard_reader :376-389; tests/readers/test_readers.py:15-26): its variables fall to the next reader of the
         priority list or to the fallback value."""
-        rebind = False
+        rebind = self._check_reader_windows()
         # the instants a step samples a reader at: every reader at t0 (the main-loop get_environment); the readers that
         # hold the current also at the Runge-Kutta stage times (physics_methods.py:638-670)
         scheme = self.get_config('drift:advection_scheme') if 'drift:advection_scheme' in self._config else 'euler'
@@ -229,6 +229,39 @@ class OpenDriftSimulation(Configurable):
                 rebind |= self._reader_failed(name, b, e)
         if rebind:
             self._bind_variables()
+
+    WINDOW_CHECK_EVERY = 16     # steps between two looks at the elements' lon / lat box (one reduction + host read each)
+
+    def _check_reader_windows(self):
+        """Blocks are cut to the box the elements can reach at drift:max_speed (set_extent) -- plus what they could cover
+        until the next check.  Elements that are faster than that (OpenOil with strong wind, Stokes drift and current) would
+        leave the window and silently take fallback values; the reference's blocks follow the elements instead.  Every
+        WINDOW_CHECK_EVERY steps the elements' box is compared with the windows; a reader whose window they approach gets a
+        new one around where they are now (its device source is rebuilt: returns True when variables must be rebound)."""
+        cut = [b for b in self.readers.values() if getattr(b, 'extent', None) is not None]
+        if not cut or self.P is None or self.time_step is None or self.steps_calculation % self.WINDOW_CHECK_EVERY != 0 or \
+                self.steps_calculation == 0 or (self._g_active if self._world > 1 else self.num_elements_active()) == 0:
+            return False
+        r = self._reduce_scalars() if self._world == 1 else self.P.reduction_dict(
+            __import__('opendrift_amd.distributed', fromlist=['x']).combine_reductions(self.P.reduce_local()))
+        if self._world > 1:
+            self._timing_collectives += 2
+        reach = self.get_config('drift:max_speed') * self.WINDOW_CHECK_EVERY * abs(self.time_step.total_seconds())
+        glat = reach / 111000.
+        glon = glat / max(0.05, np.cos(np.radians(0.5 * (r['lat_min'] + r['lat_max']))))
+        rebind = False
+        for b in cut:
+            if b.outside_window(r['lon_min'], r['lon_max'], r['lat_min'], r['lat_max'], glon, glat):
+                left = max(0, self.expected_steps_calculation - self.steps_calculation) + self.WINDOW_CHECK_EVERY
+                d = self.get_config('drift:max_speed') * left * abs(self.time_step.total_seconds()) / 111000.
+                dl = d / max(0.05, np.cos(np.radians(0.5 * (r['lat_min'] + r['lat_max']))))
+                box = np.array([max(-360, r['lon_min'] - dl), max(-89, r['lat_min'] - d), min(360, r['lon_max'] + dl),
+                                min(89, r['lat_max'] + d)])
+                logger.warning('elements approach the edge of the block window of reader %s (faster than drift:max_speed = %s '
+                               'm/s?): new window %s', b.reader.name, self.get_config('drift:max_speed'), box)
+                b.recut(box)
+                rebind = True
+        return rebind
 
     def _reader_failed(self, name, b, e):
         """Count the failure; after more than readers:max_number_of_fails the reader is discarded (discard_reader,
@@ -845,6 +878,11 @@ class OpenDriftSimulation(Configurable):
         if ext[2] == 360 and ext[0] < 0:
             ext[0] = 0
         self.simulation_extent = ext
+        # the window the reader blocks are cut to (DeviceReaderBinding.set_extent): what can be covered between two looks
+        # at the elements' box on top of it (_check_reader_windows)
+        mlat = self.get_config('drift:max_speed') * self.WINDOW_CHECK_EVERY * abs(time_step.total_seconds()) / 111000.
+        mlon = mlat / np.cos(np.radians(np.mean(self._sched['lat'])))
+        self._block_extent = np.array([max(-360, ext[0] - mlon), max(-89, ext[1] - mlat), min(360, ext[2] + mlon), min(89, ext[3] + mlat)])
         self._all_at_start = bool((self._sched['t_epoch'] == _epoch(self.start_time)).all())
         self._finalize_environment(self.start_time, self.start_time + time_step)
         n_total = self.num_elements_total()

@@ -448,11 +448,13 @@ class DeviceReaderBinding:
         (whole-mesh lookup) and s-level readers keep whole-domain blocks."""
         r = self.reader
         self.extent = None
+        self.extent_lonlat = None
         if not self.is_grid() or not getattr(r, 'projected', True) or getattr(r, 's_levels', False) or lonlat_box is None:
             return
         if not (hasattr(r, 'x') and np.ndim(r.x) == 1 and len(r.x) > 8 and len(r.y) > 8):
             return
         lo0, la0, lo1, la1 = [float(v) for v in lonlat_box]
+        self.extent_lonlat = (lo0, la0, lo1, la1)
         t = np.linspace(0, 1, 33)
         lon = np.concatenate([lo0 + (lo1 - lo0) * t, lo0 + (lo1 - lo0) * t, np.full(33, lo0), np.full(33, lo1)])
         lat = np.concatenate([np.full(33, la0), np.full(33, la1), la0 + (la1 - la0) * t, la0 + (la1 - la0) * t])
@@ -466,6 +468,35 @@ class DeviceReaderBinding:
         if fx <= 0 or fy <= 0 or fx * fy > 0.6:
             return        # no overlap (nothing to cut) or most of the domain anyway
         self.extent = (np.array([x.min(), x.max()]), np.array([y.min(), y.max()]))
+
+    def outside_window(self, lon_min, lon_max, lat_min, lat_max, guard_lon, guard_lat):
+        """Do the elements (their lon / lat box) come within `guard` of the window the blocks were cut to?  (The reference's
+        Reader.prepare() does not shrink a reader's coverage: its blocks follow the elements.  Here every resident level is
+        cut to ONE window for the run -- set_extent() -- so elements that outrun drift:max_speed would fall off it and
+        silently take the fallback values; the model checks with this and re-cuts the window, recut().)"""
+        if getattr(self, 'extent', None) is None or self.extent_lonlat is None:
+            return False
+        lo0, la0, lo1, la1 = self.extent_lonlat
+        r = self.reader
+        # the window may be bounded by the reader's own domain: nothing to gain beyond it
+        xs, ys = np.asarray(r.x, dtype=np.float64), np.asarray(r.y, dtype=np.float64)
+        x, y = r.lonlat2xy(np.array([lon_min - guard_lon, lon_max + guard_lon, lon_min - guard_lon, lon_max + guard_lon]),
+                           np.array([lat_min - guard_lat, lat_min - guard_lat, lat_max + guard_lat, lat_max + guard_lat]))
+        x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        ex, ey = self.extent
+        return bool((x.min() < max(ex[0], xs.min())) or (x.max() > min(ex[1], xs.max())) or
+                    (y.min() < max(ey[0], ys.min())) or (y.max() > min(ey[1], ys.max())))
+
+    def recut(self, lonlat_box):
+        """A new window for the blocks: every resident level is dropped and the device source of the reader is rebuilt with
+        the next upload (the model rebinds its variables: the reader's source id changes)."""
+        for pool in (self.slots, self.staged):
+            for k in list(pool):
+                self.ctx.drop_block(self.sid, pool.pop(k))
+        self._dist_pre = {}
+        self._dist_shapes = None
+        self.sid = None
+        self.set_extent(lonlat_box)
 
     def ensure_levels(self, t0, t1, extent=None, broadcast=None, times=None):
         """Make the time levels the step from t0 to t1 samples resident (datetime arguments).  `times`: the instants the

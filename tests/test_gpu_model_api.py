@@ -617,6 +617,42 @@ def test_blocks_are_cut_to_the_simulation_extent():
     assert np.abs(res[0][2] - res[1][2]).max() < 1e-5
 
 
+def test_block_window_follows_elements_that_outrun_max_speed(monkeypatch):
+    """The reference's blocks follow the elements; here every level is cut to one window for the run (set_extent).  With
+    drift:max_speed far below the real speeds the elements reach the window's edge: the model notices (a look at the
+    elements' box every WINDOW_CHECK_EVERY steps) and re-cuts the window -- same trajectories as with whole-domain blocks,
+    nobody falls back to the fallback values silently."""
+    g = golden('c3_grid3d_rk4_vmix.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity',
+             'ocean_vertical_diffusivity', 'sea_floor_depth_below_sea_level', 'land_binary_mask']
+    sel = (g['lon'][0] < g['g_x'][16]) & (g['lat'][0] < g['g_y'][14])
+    monkeypatch.setattr(OceanDrift, 'WINDOW_CHECK_EVERY', 2)
+    res, recuts = [], []
+    for cut in (True, False):
+        o = OceanDrift(loglevel=50, seed=0)
+        r = _grid_reader(g, names, z=g['g_z'])
+        if not cut:
+            r.get_variables = lambda req, time=None, x=None, y=None, z=None, _f=r.get_variables: _f(req, time, None, None, z)
+        o.add_reader(r)
+        o.set_config('drift:advection_scheme', 'runge-kutta4')
+        o.set_config('drift:max_speed', 0.01)          # the field moves the elements 10-50 times faster
+        o.set_config('general:coastline_action', 'previous')
+        o.seed_elements(lon=g['lon'][0][sel], lat=g['lat'][0][sel], z=g['z'][0][sel], time=T0)
+        b0 = None
+        calls = []
+        orig = readers.DeviceReaderBinding.recut
+        monkeypatch.setattr(readers.DeviceReaderBinding, 'recut', lambda self, box, _o=orig: (calls.append(1), _o(self, box))[1])
+        o.run(time_step=600, steps=6)
+        monkeypatch.setattr(readers.DeviceReaderBinding, 'recut', orig)
+        e = o.elements
+        res.append((e.lon.copy(), e.lat.copy(), e.z.copy(), e.ID.copy()))
+        recuts.append(len(calls))
+    assert recuts[0] >= 1, recuts       # (the second run's reader ignores the window it is asked for: whole-domain blocks)
+    assert np.array_equal(res[0][3], res[1][3])
+    assert np.abs(res[0][0] - res[1][0]).max() < 1e-7 and np.abs(res[0][1] - res[1][1]).max() < 1e-7
+    assert np.abs(res[0][2] - res[1][2]).max() < 1e-5
+
+
 def test_seed_at_and_above_the_seafloor():
     """seed_elements(z='seafloor' / 'seafloor+M') (basemodel/__init__.py:1168-1210, tests/models/test_run.py:618-661):
     the depth comes from the reader at the seeded positions (here: the oracle's get_environment on the same block),
