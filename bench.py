@@ -42,7 +42,7 @@ BYTES = {
     # fused = k_step_grid: environment sample of the group + coastline + previous + RK4
     'c3': dict(step=908, advect=3 * 128 + 56, fused=(128 + 64 + 32 + 8) + 112 + 3 * 128),   # state: + age r/w, ssh
     'c4': dict(step=436, advect=3 * 64 + 56, fused=(3 * 64 + 8) + 92 + 3 * 64),
-    'c5': dict(step=220, advect=88),
+    'c5': dict(step=220, advect=88, fused=220 - 8),   # fused = k_step_leeway: the whole step but the compaction's status scan
 }
 HBM_PEAK = 8.0e12
 
@@ -154,12 +154,17 @@ class Workload:
                 P.advect('runge-kutta4', t, self.dt)
                 P.vmix(t, self.dt, self.dt_mix, step=k, fuse_vertical_advection=False)
         elif self.name == 'c5':   # Leeway ensemble members: Euler by construction (leeway.py:472-476)
-            P.env_sample(self.vars, t)
-            P.env_add_noise(U, V, 0.1, step=k)        # drift:current_uncertainty
-            P.env_add_noise(XW, YW, 2.0, step=k)      # drift:wind_uncertainty
-            P.coastline('stranding', stranded_code=1)
-            P.compact()
-            P.leeway(self.dt, 0.4, step=k)
+            if self.fused:   # ONE launch: sample + drift:current_uncertainty + drift:wind_uncertainty + coastline + Leeway.update
+                P.env_coast_leeway(self.vars, t, self.dt, 0.4, coastline='stranding', stranded_code=1,
+                                   current_uncertainty=0.1, wind_uncertainty=2.0, step=k)
+                P.compact()
+            else:
+                P.env_sample(self.vars, t)
+                P.env_add_noise(U, V, 0.1, step=k)        # drift:current_uncertainty
+                P.env_add_noise(XW, YW, 2.0, step=k)      # drift:wind_uncertainty
+                P.coastline('stranding', stranded_code=1)
+                P.compact()
+                P.leeway(self.dt, 0.4, step=k)
         else:
             if self.fused:
                 P.env_coast_advect(self.vars, t, 'runge-kutta4', self.dt, coastline='stranding', stranded_code=1,
@@ -177,7 +182,10 @@ class Workload:
     def dominant_kernel(self, P, k):
         """The dominant launch of the step on its own, with exactly the arguments step() uses (timed with HIP events)."""
         t = self.time_of(k)
-        if self.name == 'c5':
+        if self.name == 'c5' and self.fused:
+            P.env_coast_leeway(self.vars, t, self.dt, 0.4, coastline='stranding', stranded_code=1, current_uncertainty=0.1,
+                               wind_uncertainty=2.0, step=k)
+        elif self.name == 'c5':
             P.leeway(self.dt, 0.4, step=k)
         elif self.name == 'c3' and self.fused:
             P.env_coast_advect(self.vars, t, self.scheme, self.dt, coastline='previous', store_previous=True,
@@ -517,7 +525,7 @@ def main():
 
     # the two kernels of the step on their own, HIP events on the context stream, exactly the step's launches
     reps = 20
-    kfused = wl.fused and a.workload in ('c3', 'c4')
+    kfused = wl.fused and a.workload in ('c3', 'c4', 'c5')
     if a.workload != 'c2' and wl.sort_every:
         P.sort_by_cell(wl.sid)      # the layout right after a re-sort, as in 1 of every 16 steps (the kernels drift apart by < 3 % in between)
     if not kfused:
@@ -588,7 +596,7 @@ def main():
                        'block_every': a.block_every, 'inputs': 'resident in HBM' if not a.block_every else 'uploaded in the timed region',
                        'parallelism': 'particle-sharded x%d, field block broadcast once per time level' % world},
             # the algorithmic figure of SURVEY.md 8(d): 4 B per field corner touched + state once in / once out
-            'roofline': {'bound': 'hbm', 'kernel': 'k_leeway' if a.workload == 'c5' else ('k_step_grid<RK4>' if kfused else 'k_advect<RK4>'),
+            'roofline': {'bound': 'hbm', 'kernel': ('k_step_leeway' if wl.fused else 'k_leeway') if a.workload == 'c5' else ('k_step_grid<RK4>' if kfused else 'k_advect<RK4>'),
                          'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9,
                          'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': traffic, 'traffic_unit': 'GB per launch (PMC)',
                          'traffic_source': None if pmc is None else pmc_file,

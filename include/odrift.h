@@ -296,6 +296,18 @@ int odr_stokes_drift(odr_ctx *ctx, odr_particles *p, double dt, int profile, int
 int odr_particles_set_property(odr_ctx *ctx, odr_particles *p, int slot, int64_t offset, int64_t count,
                                const float *host);
 int odr_particles_get_property(odr_ctx *ctx, odr_particles *p, int slot, float *host);
+/* The Leeway loop body between two compactions in ONE launch: Environment.get_environment of `var_ids` at t_epoch
+ * (environment.py:499-923; the list must hold x/y_wind and x/y_sea_water_velocity) + drift:current_uncertainty /
+ * drift:wind_uncertainty (:869-891; device RNG, 0 = none) + interact_with_coastline (basemodel/__init__.py:670-746) +
+ * update_previous_state + Leeway.update (models/leeway.py:430-494, capsizing not included).  Elements the coastline
+ * deactivates are flagged and not moved: call + odr_compact is bit-identical to odr_env_sample, odr_env_add_noise x 2,
+ * odr_coastline, odr_compact, odr_leeway.  Returns ODR_SPLIT_LANE (1, not an error) when wind, current and land mask do not
+ * come from one gridded reader: sampling, noise, coastline and previous state are then done, the caller compacts and calls
+ * odr_leeway itself. */
+enum { ODR_SPLIT_LANE = 1 };
+int odr_env_coast_leeway(odr_ctx *ctx, odr_particles *p, int nvars, const int32_t *var_ids, double t_epoch, int coast_action,
+                         int stranded_code, int seeded_on_land_code, int store_previous, double dt, double capsize_fraction,
+                         double std_current, double std_wind, uint64_t step, int64_t *n_on_land);
 /* processes:capsizing (models/leeway.py:438-455): call before odr_leeway.  host_uniforms (ODR_RNG_HOST): one number
  * per element, used by those that can be capsized */
 int odr_leeway_capsize(odr_ctx *ctx, odr_particles *p, double dt, double wind_threshold, double wind_threshold_sigma,

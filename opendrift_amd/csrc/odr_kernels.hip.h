@@ -483,6 +483,19 @@ __device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, con
   return z;
 }
 
+// out[j] with a run-time j, as a chain of selects: a dynamically indexed register array lives in scratch memory
+// (k_step_grid<RK4>: 80 B per lane, 0.5 GB of HBM writes per launch at 10 M particles)
+__device__ __forceinline__ float pick_slot(const float (&a)[MAXG], int j) {
+  float r = a[0];
+#pragma unroll
+  for (int k = 1; k < MAXG; ++k) {
+    float v = a[k];
+    asm volatile("" : "+v"(v));   // opaque: keeps the optimiser from folding the selects back into one indexed load
+    r = j == k ? v : r;
+  }
+  return r;
+}
+
 #ifdef ODR_TU_MISC
 // ------------------------------------------------------------------ environment
 // Environment.get_environment for one variable group of NV variables
@@ -706,19 +719,6 @@ struct StepMix {
   VMixArgs A;
   int vadv, w_slot;   // vertical advection: -1 none | 0 below the surface | 1 including it; slot of W in the group or -1
 };
-// out[j] with a run-time j, as a chain of selects: a dynamically indexed register array lives in scratch memory
-// (k_step_grid<RK4>: 80 B per lane, 0.5 GB of HBM writes per launch at 10 M particles)
-__device__ __forceinline__ float pick_slot(const float (&a)[MAXG], int j) {
-  float r = a[0];
-#pragma unroll
-  for (int k = 1; k < MAXG; ++k) {
-    float v = a[k];
-    asm volatile("" : "+v"(v));   // opaque: keeps the optimiser from folding the selects back into one indexed load
-    r = j == k ? v : r;
-  }
-  return r;
-}
-
 // lat / lon and curvilinear readers, Runge-Kutta schemes: geodesic coefficients parked in LDS, 5 waves per SIMD (geod_park)
 #ifndef ODR_PARK_WAVES
 #define ODR_PARK_WAVES 5
@@ -2126,12 +2126,10 @@ enum { AUX_DW_SLOPE = 0, AUX_CW_SLOPE, AUX_DW_OFFSET, AUX_CW_OFFSET, AUX_DW_EPS,
        AUX_ORIENTATION, AUX_CAPSIZED };
 constexpr unsigned long long RNG_OFF_JIBE = 4608;
 
-__global__ __launch_bounds__(BLOCK) void k_leeway(PView p, double dt, float capsize_fraction, int rng_mode,
-                                                  const double *__restrict__ huni, unsigned long long seed,
-                                                  unsigned long long step) {
-  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= p.n) return;
-  float xw = p.env[VAR_XWIND][i], yw = p.env[VAR_YWIND][i];
+// one element of Leeway.update: leeway + current moves of (lon, lat), jibing; xw, yw, u, v = its sampled environment
+__device__ __forceinline__ void leeway_body(const PView &p, long long i, double &lon, double &lat, int moving, float xw, float yw,
+                                            float u, float v, double dt, float capsize_fraction, int rng_mode,
+                                            const double *__restrict__ huni, unsigned long long seed, unsigned long long step) {
   float windspeed = speed_f32(xw, yw);
   float winddir = (float)atan2((double)xw, (double)yw);          // np.arctan2 on float32
   float dwe = p.aux[AUX_DW_EPS][i], cwe = p.aux[AUX_CW_EPS][i];
@@ -2145,12 +2143,8 @@ __global__ __launch_bounds__(BLOCK) void k_leeway(PView p, double dt, float caps
   float yl = __fadd_rn(__fmul_rn(dw, costh), __fmul_rn(cw, sinth));
   float xl = __fadd_rn(__fmul_rn(-dw, sinth), __fmul_rn(cw, costh));
   if (p.aux[AUX_CAPSIZED][i] == 1.0f) { xl = __fmul_rn(xl, capsize_fraction); yl = __fmul_rn(yl, capsize_fraction); }
-  double lon = p.lon[i], lat = p.lat[i];
-  int moving = p.moving[i];
   move_f32(lon, lat, -xl, yl, moving, dt);                        // :472
-  move_f32(lon, lat, p.env[VAR_U][i], p.env[VAR_V][i], moving, dt);  // :475-476
-  p.lon[i] = lon;
-  p.lat[i] = lat;
+  move_f32(lon, lat, u, v, moving, dt);                           // :475-476
   // jibing (:478-487): rate = -log(1-p)/3600, probability per step 1-exp(-rate*|dt|), float32
   float jp = p.aux[AUX_JIBE_P][i];
   float rate = __fdiv_rn(-(float)log((double)__fsub_rn(1.0f, jp)), 3600.0f);
@@ -2165,6 +2159,102 @@ __global__ __launch_bounds__(BLOCK) void k_leeway(PView p, double dt, float caps
   if ((double)pstep > u01) {
     p.aux[AUX_CW_SLOPE][i] = -cws;
     p.aux[AUX_ORIENTATION][i] = 1.0f - p.aux[AUX_ORIENTATION][i];
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_leeway(PView p, double dt, float capsize_fraction, int rng_mode,
+                                                  const double *__restrict__ huni, unsigned long long seed,
+                                                  unsigned long long step) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  double lon = p.lon[i], lat = p.lat[i];
+  leeway_body(p, i, lon, lat, p.moving[i], p.env[VAR_XWIND][i], p.env[VAR_YWIND][i], p.env[VAR_U][i], p.env[VAR_V][i], dt,
+              capsize_fraction, rng_mode, huni, seed, step);
+  p.lon[i] = lon;
+  p.lat[i] = lat;
+}
+
+// The Leeway loop body between two compactions in ONE launch (round 3; C5 was five launches, each streaming the particle
+// state again): get_environment of the group that holds wind and current from one gridded reader (burst sampler) ->
+// drift:current_uncertainty / drift:wind_uncertainty (device RNG: the Philox streams of k_env_noise) -> interact_with_coastline
+// -> Leeway.update.  Elements the coastline deactivates are flagged and left where they are (the reference removes them
+// before update()): fused call + compact is bit-identical to sample, noise, noise, coastline, compact, leeway
+// (tests/test_gpu_fused_step.py).  The group is ordered (x_wind, y_wind, current x, current y[, land, ...]) by the host.
+struct LeewayStep {
+  int coast_action, stranded_code, seeded_code, land_slot;   // land_slot: group slot of land_binary_mask or -1 (p.env[LAND])
+  int wind_slot, uv_slot, store_previous, pad;
+  double std_current, std_wind;
+  float capsize_fraction, pad2;
+  unsigned long long seed, step;
+};
+template <int PROJ>
+__global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_leeway(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
+                                                                        LeewayStep S, double dt, unsigned long long *n_hit) {
+  long long i = pid();
+  bool hit = false;
+  if (i < p.n) {
+    double lon = p.lon[i], lat = p.lat[i];
+    const double z = p.z[i];
+    int moving = p.moving[i];
+    int st = p.status[i];
+    const float age0 = p.age[i];
+    const int id = p.id[i];
+    float out[MAXG];
+    ZBracket zb;
+    env_group_fast<PROJ, true, false>(*W, G, lon, lat, z, out, nullptr, zb);
+    float xw = pick_slot(out, S.wind_slot), yw = pick_slot(out, S.wind_slot + 1);
+    float u = pick_slot(out, S.uv_slot), v = pick_slot(out, S.uv_slot + 1);
+    // environment.py:869-891: env[x] += N(0, std) (float32 array += float64 draws), first the current, then the wind
+    if (S.std_current > 0) {
+      rocrand_state_philox4x32_10 rs;
+      rng_init(rs, S.seed, id, S.step, RNG_OFF_NOISE + 4ull * (unsigned)VAR_U);
+      const double2 g = rocrand_normal_double2(&rs);
+      add_f32_f64(u, v, g.x * S.std_current, g.y * S.std_current);
+    }
+    if (S.std_wind > 0) {
+      rocrand_state_philox4x32_10 rs;
+      rng_init(rs, S.seed, id, S.step, RNG_OFF_NOISE + 4ull * (unsigned)VAR_XWIND);
+      const double2 g = rocrand_normal_double2(&rs);
+      add_f32_f64(xw, yw, g.x * S.std_wind, g.y * S.std_wind);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXG; ++k) {
+      if (k >= G.nv) break;
+      float val = out[k];
+      if (k == S.wind_slot) val = xw; else if (k == S.wind_slot + 1) val = yw;
+      else if (k == S.uv_slot) val = u; else if (k == S.uv_slot + 1) val = v;
+      G.out_ptr[k][i] = val;
+    }
+    p.slon[i] = lon;
+    p.slat[i] = lat;
+    if (S.coast_action) {  // k_coast
+      const float land = S.land_slot >= 0 ? pick_slot(out, S.land_slot) : p.env[VAR_LAND][i];
+      if (land == 1.0f) {
+        hit = true;
+        if (S.coast_action == 1) {
+          if (z <= 0) {
+            if (st == 0) p.status[i] = st = S.stranded_code;
+            p.moving[i] = moving = 0;
+          }
+        } else {
+          if (S.seeded_code > 0 && age0 == 0.0f) {
+            if (st == 0) p.status[i] = st = S.seeded_code;
+            p.moving[i] = moving = 0;
+          }
+          lon = p.plon[i];
+          lat = p.plat[i];
+          p.env[VAR_LAND][i] = 0.0f;
+        }
+      }
+    }
+    if (S.store_previous) { p.plon[i] = lon; p.plat[i] = lat; }
+    if (st == 0) leeway_body(p, i, lon, lat, moving, xw, yw, u, v, dt, S.capsize_fraction, 0, nullptr, S.seed, S.step);
+    p.lon[i] = lon;
+    p.lat[i] = lat;
+  }
+  if (S.coast_action) {
+    unsigned long long b = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_hit, (unsigned long long)__popcll(b));
   }
 }
 

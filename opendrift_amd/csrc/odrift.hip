@@ -1256,6 +1256,87 @@ int odr_leeway(odr_ctx *c, odr_particles *p, double dt, double capsize_fraction,
   return 0;
 }
 
+// The Leeway loop body between two compactions in one launch (k_step_leeway): Environment.get_environment of `var_ids` at t
+// (environment.py:499-923) + drift:current_uncertainty / drift:wind_uncertainty (:869-891, device RNG) +
+// interact_with_coastline (basemodel/__init__.py:670-746) + update_previous_state + Leeway.update (models/leeway.py:430-494,
+// without capsizing).  Falls back to the separate entry points -- same results -- when wind, current (and landmask) do not
+// come from ONE gridded reader that fits the burst sampler.
+int odr_env_coast_leeway(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t, int coast_action,
+                         int stranded_code, int seeded_on_land_code, int store_previous, double dt, double capsize_fraction,
+                         double std_current, double std_wind, uint64_t step, int64_t *n_on_land) {
+  p->status_epoch++;
+  p->epoch++;
+  REQUIRE(nvars > 0 && nvars <= NVAR && var_ids, "bad variable list");
+  REQUIRE(coast_action >= 0 && coast_action <= 2, "bad coastline action");
+  REQUIRE(std_current >= 0 && std_wind >= 0, "uncertainties must not be negative");
+  for (int k = 0; k < 9; ++k) if (!p->aux[k]) return fail(ODR_ERR_STATE, "Leeway property slot %d has not been set", k);
+  HIPCHK(hipSetDevice(c->device));
+  if (n_on_land) *n_on_land = 0;
+  bool has[NVAR] = {false};
+  for (int k = 0; k < nvars; ++k) { REQUIRE(var_ids[k] >= 0 && var_ids[k] < NVAR, "bad variable id %d", var_ids[k]); has[var_ids[k]] = true; }
+  REQUIRE(has[VAR_XWIND] && has[VAR_YWIND] && has[VAR_U] && has[VAR_V], "the variable list must hold wind and current");
+  if (coast_action && !has[VAR_LAND] && !p->env[VAR_LAND]) return fail(ODR_ERR_STATE, "land_binary_mask has not been sampled");
+  int rc;
+  if ((rc = flush_world(c))) return rc;
+  auto same_list = [&](int a, int b) {
+    if (c->hw.nlist[a] != c->hw.nlist[b]) return false;
+    for (int k = 0; k < c->hw.nlist[a]; ++k) if (c->hw.list[a][k] != c->hw.list[b][k]) return false;
+    return true;
+  };
+  // the group: wind pair, current pair, then every other variable of the list that shares their reader list
+  int grp[NVAR], ng = 0, rest[NVAR], nrest = 0;
+  grp[ng++] = VAR_XWIND; grp[ng++] = VAR_YWIND; grp[ng++] = VAR_U; grp[ng++] = VAR_V;
+  bool seen[NVAR] = {false};
+  seen[VAR_XWIND] = seen[VAR_YWIND] = seen[VAR_U] = seen[VAR_V] = true;
+  for (int k = 0; k < nvars; ++k) {
+    const int v = var_ids[k];
+    if (seen[v]) continue;
+    seen[v] = true;
+    if (same_list(v, VAR_U)) grp[ng++] = v; else rest[nrest++] = v;
+  }
+  EnvGroupDesc G;
+  const bool fuse = p->n > 0 && !getenv("ODR_NO_FAST_PATH") && same_list(VAR_XWIND, VAR_U) && same_list(VAR_YWIND, VAR_U) &&
+                    same_list(VAR_V, VAR_U) && ng <= MAXG && build_env_group(c, grp, ng, t, G) && G.burst;
+  if (!fuse) {
+    if ((rc = odr_env_sample(c, p, nvars, var_ids, t, nullptr))) return rc;
+    if (std_current > 0 && (rc = odr_i_env_noise(c, p, VAR_U, VAR_V, std_current, ODR_NOISE_NORMAL, ODR_RNG_DEVICE, nullptr, nullptr, step))) return rc;
+    if (std_wind > 0 && (rc = odr_i_env_noise(c, p, VAR_XWIND, VAR_YWIND, std_wind, ODR_NOISE_NORMAL, ODR_RNG_DEVICE, nullptr, nullptr, step))) return rc;
+    if ((rc = odr_coastline(c, p, coast_action, stranded_code, seeded_on_land_code, n_on_land))) return rc;
+    if (store_previous && (rc = odr_store_previous(c, p))) return rc;
+    // (the caller compacts before odr_leeway in this lane: elements on land must not move)
+    return ODR_SPLIT_LANE;
+  }
+  for (int k = 0; k < ng; ++k) { if ((rc = ensure_env(c, p, grp[k]))) return rc; p->env_cok[grp[k]] = false; }
+  if (coast_action == 2) p->env_cok[VAR_LAND] = false;
+  if (nrest && (rc = env_sample_impl(c, p, nrest, rest, t, nullptr, false))) return rc;
+  LeewayStep S;
+  memset(&S, 0, sizeof S);
+  S.coast_action = coast_action; S.stranded_code = stranded_code; S.seeded_code = seeded_on_land_code;
+  S.land_slot = -1; S.wind_slot = -1; S.uv_slot = -1;
+  for (int k = 0; k < G.nv; ++k) {
+    if (G.var[k] == VAR_LAND) S.land_slot = k;
+    if (G.var[k] == VAR_XWIND) S.wind_slot = k;
+    if (G.var[k] == VAR_U) S.uv_slot = k;
+  }
+  S.store_previous = store_previous;
+  S.std_current = std_current; S.std_wind = std_wind;
+  S.capsize_fraction = (float)capsize_fraction;
+  S.seed = c->seed; S.step = (unsigned long long)step;
+  if (coast_action) HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
+  const DevSource &s = c->hw.src[G.sid];
+  dim3 g(nblk(p->n)), b(BLOCK);
+  PView v = view(p);
+  G = env_bind_out(G, v);
+  switch (s.proj.kind) {
+    case PROJ_LATLONG: hipLaunchKernelGGL(k_step_leeway<PROJ_LATLONG>, g, b, 0, c->stream, c->dw, v, G, S, dt, c->counter); break;
+    case PROJ_STERE_POLAR: hipLaunchKernelGGL(k_step_leeway<PROJ_STERE_POLAR>, g, b, 0, c->stream, c->dw, v, G, S, dt, c->counter); break;
+    case PROJ_CURVILINEAR: hipLaunchKernelGGL(k_step_leeway<PROJ_CURVILINEAR>, g, b, 0, c->stream, c->dw, v, G, S, dt, c->counter); break;
+    default: hipLaunchKernelGGL(k_step_leeway<PROJ_STERE_EQUIT_SPHERE>, g, b, 0, c->stream, c->dw, v, G, S, dt, c->counter); break;
+  }
+  HIPCHK(hipGetLastError());
+  return coast_action ? read_counter(c, n_on_land) : 0;
+}
+
 // processes:capsizing of Leeway.update (models/leeway.py:438-455); call before odr_leeway
 int odr_leeway_capsize(odr_ctx *c, odr_particles *p, double dt, double wind_threshold, double wind_threshold_sigma,
                        int rng_mode, const double *huni, uint64_t step) {

@@ -545,6 +545,25 @@ class Particles:
         else:
             check(self.lib.odr_leeway(self.ctx.h, self.h, float(dt), float(capsize_fraction), _abi.RNG_DEVICE, None, step))
 
+    def env_coast_leeway(self, variables, t_epoch, dt, capsize_fraction=0.4, coastline='stranding', stranded_code=1,
+                         seeded_on_land_code=0, store_previous=False, current_uncertainty=0.0, wind_uncertainty=0.0, step=0):
+        """The Leeway loop body between two compactions in one launch (odr_env_coast_leeway): sample, uncertainties (device
+        RNG), coastline, previous state, Leeway.update.  When wind / current / landmask do not come from one gridded reader the
+        library has sampled, perturbed and applied the coastline only: compaction and Leeway.update follow here, so that
+        env_coast_leeway() + compact() is the same sequence either way.  Returns the number of elements on land."""
+        ids, pi = _i([_vid(v) for v in variables])
+        nhit = C.c_int64()
+        rc = self.lib.odr_env_coast_leeway(self.ctx.h, self.h, len(variables), pi, float(t_epoch), _abi.COAST[coastline],
+                                           int(stranded_code), int(seeded_on_land_code), int(bool(store_previous)), float(dt),
+                                           float(capsize_fraction), float(current_uncertainty), float(wind_uncertainty), int(step),
+                                           C.byref(nhit))
+        if rc == 1:          # ODR_SPLIT_LANE
+            self.compact()
+            self.leeway(dt, capsize_fraction, step=step)
+        else:
+            check(rc)
+        return nhit.value
+
     def hdiffusion(self, dt, step=0, normals=None):
         n = len(self)
         if normals is not None:
@@ -771,7 +790,7 @@ for _name in ('append', 'upload', 'env_sample', 'env_upload', 'env_add_noise', '
               'update_positions', 'advect_wind', 'stokes_drift', 'advect_sea_ice', 'set_property', 'leeway_capsize', 'leeway', 'hdiffusion',
               'vmix', 'vmix_analytic', 'vmix_oil', 'vertical_advection', 'vertical_buoyancy', 'coastline', 'coastline_crossing',
               'increase_age', 'deactivate_missing', 'remap_status', 'seafloor', 'deactivate', 'deactivate_outside', 'compact',
-              'compact_apply', 'sort_by_cell', 'store_previous', 'oil_prepare_mixing'):
+              'compact_apply', 'sort_by_cell', 'store_previous', 'oil_prepare_mixing', 'env_coast_leeway'):
     setattr(Particles, _name, _touching(getattr(Particles, _name)))
 
 

@@ -280,3 +280,74 @@ def test_step_in_lanes_gives_the_same_bits_as_one_launch(monkeypatch, lanes):
         ctx.close()
     for a, b in zip(*res):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def _leeway_props(P, n, seed):
+    r = np.random.default_rng(seed)
+    ori = (np.arange(n) % 2).astype(np.float32)
+    for slot, val in enumerate([np.full(n, 0.96), np.where(ori == 0, 0.54, -0.54), np.zeros(n), np.zeros(n),
+                                np.abs(r.standard_normal(n)) * 12.0, r.standard_normal(n) * 9.4, np.full(n, 0.04), ori,
+                                (r.uniform(size=n) < 0.2).astype(np.float64)]):
+        P.set_property(slot, val.astype(np.float32))
+
+
+@pytest.mark.parametrize('layout', ['stere', 'latlon', 'constant_wind'])
+def test_leeway_step_in_one_launch_equals_the_separate_calls(ctx, layout):
+    """odr_env_coast_leeway (k_step_leeway: sample + current / wind uncertainty + coastline + Leeway.update in one launch)
+    == env_sample, env_add_noise x 2, coastline, compact, leeway, bit for bit: positions, status, the sampled (perturbed)
+    environment, the jibed crosswind slopes -- on a polar-stereographic reader (C5), on a lat / lon reader, and through the
+    split lane when the wind comes from another reader than the current."""
+    rng = np.random.default_rng(21)
+    n = 5000
+    if layout == 'stere':
+        g = synth.grid_stere(nx=120, ny=90, nt=3, seed=3)
+        names = [U, V, XW, YW, LAND]
+        levels = [(float(g['t'][k]), {nm: g[nm][k] for nm in names}) for k in range(3)]
+        sc = Scenario([('grid', dict(x=g['x'], y=g['y'], levels=levels, proj=synth.NORKYST_PROJ))], fallbacks={U: 0.0, V: 0.0, XW: 0.0, YW: 0.0})
+        sc.device(ctx)
+        from opendrift_amd.projection import stere_polar_inverse
+        x = rng.uniform(g['x'][4], g['x'][-5], n)
+        y = rng.uniform(g['y'][4], g['y'][-5], n)
+        lon, lat = stere_polar_inverse(x, y, **synth.NORKYST_PROJ)
+    else:
+        g = synth.grid3d(nx=96, ny=80, nz=1, nt=3, seed=5) if False else synth.grid_stere(nx=96, ny=80, nt=3, seed=4)
+        # a lat / lon grid with the stere generator's fields: same arrays, geographic axes
+        gx, gy = np.linspace(3.0, 9.0, 96), np.linspace(59.0, 63.0, 80)
+        names = [U, V, LAND] if layout == 'constant_wind' else [U, V, XW, YW, LAND]
+        levels = [(float(g['t'][k]), {nm: g[nm][k] for nm in names}) for k in range(3)]
+        srcs = [('grid', dict(x=gx, y=gy, levels=levels))]
+        if layout == 'constant_wind':
+            srcs.append(('constant', {XW: 7.0, YW: -3.0}))
+        sc = Scenario(srcs, fallbacks={U: 0.0, V: 0.0, XW: 0.0, YW: 0.0})
+        sc.device(ctx)
+        lon, lat = rng.uniform(gx[3], gx[-4], n), rng.uniform(gy[3], gy[-4], n)
+    variables = [XW, YW, U, V, LAND]
+    P, Q = ctx.particles(n), ctx.particles(n)
+    for X in (P, Q):
+        X.append(lon, lat)
+        _leeway_props(X, n, 9)
+    dt = 600.0
+    hits = 0
+    for k in range(5):
+        t = 300.0 + 600.0 * k
+        P.env_sample(variables, t)
+        P.env_add_noise(U, V, 0.1, step=k)
+        P.env_add_noise(XW, YW, 2.0, step=k)
+        n1 = P.coastline('stranding', stranded_code=1)
+        P.compact()
+        P.leeway(dt, 0.4, step=k)
+        n2 = Q.env_coast_leeway(variables, t, dt, 0.4, coastline='stranding', stranded_code=1, current_uncertainty=0.1,
+                                wind_uncertainty=2.0, step=k)
+        Q.compact()
+        hits += n1
+        assert n1 == n2 and len(P) == len(Q), (k, n1, n2, len(P), len(Q))
+        _same(P.download(), Q.download(), 'step %d' % k)
+        for v in variables:
+            a, b = P.env_download(v), Q.env_download(v)
+            assert ((a == b) | (np.isnan(a) & np.isnan(b))).all(), (k, v)
+        for slot in (1, 7):     # crosswind slope and orientation: the jibes
+            assert np.array_equal(P.get_property(slot), Q.get_property(slot)), (k, slot)
+        da, db = P.download_deactivated(), Q.download_deactivated()
+        for q in ('lon', 'lat', 'status', 'ID'):
+            assert (da[q] == db[q]).all(), (k, 'deactivated', q)
+    assert hits > 0 or layout != 'stere'        # the stere scenario has a coast
