@@ -549,12 +549,28 @@ def main():
     kbytes = BYTES[a.workload]['fused' if kfused else 'advect']
     ach = kbytes * nact / (k_ms * 1e-3)
 
-    # counters of the same command from the committed rocprofv3 passes (profiles/r02_<workload>_pmc.json): PMC counters
-    # cannot be collected from inside this process
-    pmc, pmc_file = None, os.path.join('profiles', 'r02_%s_pmc.json' % a.workload)
+    # the other arithmetic of the stage evaluations on the same particles (a quarter of the steps, same bracketing): the
+    # headline is `a.stage_math`; both modes have a parity gate (tests/test_gpu_parity.py ... / tests/test_gpu_stage_math.py)
+    other_mode, other = ('exact' if a.stage_math == 'fast' else 'fast'), None
+    if a.workload != 'c5' and not a.block_every and not os.environ.get('ODR_BENCH_ONE_MODE'):
+        ctx.set_stage_math(other_mode)
+        nst_o = max(8, a.steps // 4)
+        for k in range(2):
+            wl.step(P, a.warmup + a.steps + k)
+        el_o, units_o = timed_loop(nst_o, a.warmup + a.steps + 2)
+        el_o = float(D.allreduce_scalars([el_o], 'max')[0])
+        units_o = float(D.allreduce_scalars([units_o], 'sum')[0])
+        ko_ms, _ = launch_ms(wl.dominant_kernel)
+        other = dict(value=units_o / el_o, unit='particle-steps/s', ms_per_step=1e3 * el_o / nst_o, steps=nst_o, kernel_ms=ko_ms)
+        ctx.set_stage_math(a.stage_math)
+
+    # counters of the same command from the committed rocprofv3 passes (profiles/r03_<workload>_pmc.json, written by
+    # tools/gpu_profile_r03.sh + tools/collect_profiles_r03.py from this tree): PMC counters cannot be collected from inside
+    # this process.  Used only when they belong to this size and stage math.
+    pmc, pmc_file = None, os.path.join('profiles', 'r03_%s_pmc.json' % a.workload)
     if os.path.exists(os.path.join(ROOT, pmc_file)):
         pm = json.load(open(os.path.join(ROOT, pmc_file)))
-        if pm.get('particles') == n:
+        if pm.get('particles') == n and pm.get('stage_math', a.stage_math) == a.stage_math:
             pmc = pm
     extras = {}
     if rank == 0 and world == 1 and not a.no_extras and a.workload == 'c3' and not a.small and not a.block_every:
@@ -592,34 +608,58 @@ def main():
                                           'Stokes + horizontal diffusion + stranding',
                                     'c5': 'C5: Leeway ensemble members (2 x 5 M per GPU) on the NorKyst-800-shaped grid, '
                                           'wind/current uncertainty, stranding'}[a.workload],
-                       'particles_per_gpu': n, 'particles_total': n * world, 'time_step_s': wl.dt,
+                       'particles_per_gpu': n, 'particles_total': n * world, 'time_step_s': wl.dt, 'stage_math': a.stage_math,
                        'block_every': a.block_every, 'inputs': 'resident in HBM' if not a.block_every else 'uploaded in the timed region',
                        'parallelism': 'particle-sharded x%d, field block broadcast once per time level' % world},
-            # the algorithmic figure of SURVEY.md 8(d): 4 B per field corner touched + state once in / once out
-            'roofline': {'bound': 'hbm', 'kernel': ('k_step_leeway' if wl.fused else 'k_leeway') if a.workload == 'c5' else ('k_step_grid<RK4>' if kfused else 'k_advect<RK4>'),
-                         'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9,
-                         'unit': 'GB/s', 'frac': ach / HBM_PEAK, 'traffic': traffic, 'traffic_unit': 'GB per launch (PMC)',
-                         'traffic_source': None if pmc is None else pmc_file,
-                         'algorithmic_gb_per_launch': kbytes * nact / 1e9,
-                         'kernel_ms': k_ms, 'kernel_ms_median': k_ms_median, 'algorithmic_bytes_per_particle': kbytes,
-                         'note': 'algorithmic bytes count cache-served corners: not a physical bandwidth (see roofline_hbm_counters, roofline_issue)',
-                         'step_bytes_per_particle': BYTES[a.workload]['step'],
-                         'step_frac': BYTES[a.workload]['step'] * (units / el_max) / world / HBM_PEAK},
         }
-        if k2_ms is not None:
-            out['roofline']['second_kernel'] = {'kernel': 'k_vmix_col', 'kernel_ms': k2_ms}
+        kname = ('k_step_leeway' if wl.fused else 'k_leeway') if a.workload == 'c5' else ('k_step_grid<RK4>' if kfused else 'k_advect<RK4>')
+        # (1) SURVEY.md 8(d): algorithmic bytes (4 B per field corner touched + state once in / once out) over the launch time.
+        # Counts cache-served corners: a throughput figure in the survey's unit, NOT a physical bandwidth (it can exceed 1).
+        algorithmic = {'bound': 'hbm', 'kernel': kname, 'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                       'frac': ach / HBM_PEAK, 'algorithmic_gb_per_launch': kbytes * nact / 1e9,
+                       'algorithmic_bytes_per_particle': kbytes, 'step_bytes_per_particle': BYTES[a.workload]['step'],
+                       'step_frac': BYTES[a.workload]['step'] * (units / el_max) / world / HBM_PEAK,
+                       'note': 'SURVEY 8(d) accounting: counts corners served by L1 / L2 / Infinity Cache; not a physical bandwidth'}
+        out['roofline_algorithmic'] = algorithmic
         if pmc is not None:
-            # what the HBM counters saw (FETCH_SIZE x2 per MI355X_MICROARCH.md, + WRITE_SIZE) against the 8 TB/s peak, and
-            # the instruction-issue bound: one VALU wave-instruction per 4 cycles per SIMD, 1024 SIMDs at 2.4 GHz
-            hb = (pmc['FETCH_SIZE_bytes_x2'] + pmc['WRITE_SIZE_bytes']) / (k_ms * 1e-3)
-            out['roofline_hbm_counters'] = {'bound': 'hbm', 'kernel': out['roofline']['kernel'], 'achieved': hb / 1e9,
-                                            'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': hb / HBM_PEAK,
-                                            'traffic': traffic, 'source': pmc_file}
-            issue = pmc['SQ_INSTS_VALU'] * 4.0 / (1024 * 2.4e9)
-            out['roofline_issue'] = {'bound': 'valu_issue', 'kernel': out['roofline']['kernel'],
-                                     'valu_wave_instructions_per_launch': pmc['SQ_INSTS_VALU'],
-                                     'issue_ms_at_peak': issue * 1e3, 'kernel_ms': k_ms, 'frac': issue * 1e3 / k_ms,
-                                     'peak': '1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction', 'source': pmc_file}
+            # (2) the ceilings of the dominant kernel from its counters, each as the time the launch would take if that unit
+            # alone were the limit, over the measured launch time.  Peaks: HBM 8 TB/s; the L1 (TCP) takes one lane-access per
+            # cycle per CU: 256 CUs x 2.4 GHz; VALU issue per SIMD (1024 SIMDs x 2.4 GHz) priced per instruction class as
+            # measured by tools/rate_bench.hip (profiles/r03_rate_bench_raw.txt): float64 arithmetic / conversions 4 cycles,
+            # transcendental float64 16, every other wave64 instruction 2.
+            hbm_bytes = pmc['FETCH_SIZE_bytes_x2'] + pmc['WRITE_SIZE_bytes']
+            t_hbm = hbm_bytes / HBM_PEAK
+            t_l1 = (pmc.get('TCP_TOTAL_CACHE_ACCESSES') or 0) / (256 * 2.4e9)
+            t_valu = pmc['valu_cycles_per_simd_slot'] / (1024 * 2.4e9)
+            ceil = {'hbm': t_hbm, 'l1_lane_access': t_l1, 'valu_issue': t_valu}
+            bound = max(ceil, key=ceil.get)
+            ks = k_ms * 1e-3
+            out['roofline'] = {
+                'bound': bound, 'kernel': kname, 'kernel_ms': k_ms, 'kernel_ms_median': k_ms_median,
+                'achieved': {'hbm': hbm_bytes / ks / 1e9, 'l1_lane_access': (pmc.get('TCP_TOTAL_CACHE_ACCESSES') or 0) / ks / 1e9,
+                             'valu_issue': pmc['valu_cycles_per_simd_slot'] / ks / 1e9}[bound],
+                'peak': {'hbm': HBM_PEAK / 1e9, 'l1_lane_access': 256 * 2.4, 'valu_issue': 1024 * 2.4}[bound],
+                'unit': {'hbm': 'GB/s', 'l1_lane_access': 'G lane-accesses/s', 'valu_issue': 'G SIMD-cycles/s'}[bound],
+                'frac': ceil[bound] / ks,
+                'traffic': hbm_bytes / 1e9, 'traffic_unit': 'GB of HBM traffic per launch (FETCH_SIZE x2 + WRITE_SIZE)',
+                'fractions': {k: v / ks for k, v in ceil.items()},
+                'source': pmc_file + ' (counters of the same command and tree; this line times the launch itself)',
+                'note': 'the binding ceiling of the dominant kernel; the SURVEY 8(d) figure is roofline_algorithmic'}
+            if 'second' in pmc and k2_ms is not None:
+                q = pmc['second']
+                c2 = {'hbm': (q['FETCH_SIZE_bytes_x2'] + q['WRITE_SIZE_bytes']) / HBM_PEAK,
+                      'l1_lane_access': (q.get('TCP_TOTAL_CACHE_ACCESSES') or 0) / (256 * 2.4e9),
+                      'valu_issue': q['valu_cycles_per_simd_slot'] / (1024 * 2.4e9)}
+                b2 = max(c2, key=c2.get)
+                out['roofline']['second_kernel'] = {'kernel': 'k_vmix_col', 'kernel_ms': k2_ms, 'bound': b2,
+                                                    'frac': c2[b2] / (k2_ms * 1e-3), 'fractions': {k: v / (k2_ms * 1e-3) for k, v in c2.items()}}
+        else:
+            out['roofline'] = dict(algorithmic, kernel_ms=k_ms, kernel_ms_median=k_ms_median, traffic=None,
+                                   note='no counter file for this size / stage math: the SURVEY 8(d) algorithmic figure only')
+            if k2_ms is not None:
+                out['roofline']['second_kernel'] = {'kernel': 'k_vmix_col', 'kernel_ms': k2_ms}
+        if other is not None:
+            out['stage_math_' + other_mode] = other
         out.update(extras)
         if not a.no_cpu and world == 1:
             out['cpu_baseline'] = cpu_baseline(a.workload, fields, a.cpu_particles, np.random.default_rng(5))

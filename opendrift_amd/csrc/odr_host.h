@@ -47,6 +47,8 @@ struct odr_ctx {
   float *prep[2];
   size_t prep_floats;
   int *dilate_flags;   // [NVAR][16]: "sweep k gave a cell a value" (k_blk_dilate_row stops at the fixed point)
+  int *tile_flags = nullptr;   // [layer][44x44-cell tile]: the tile still holds a NaN after mask + sea-floor fill (k_blk_mask_fill)
+  size_t tile_flags_n = 0;
   // page-locked bounce buffers for copies from / to caller memory: [0] compute stream, [1] upload stream (odr_i_h2d)
   void *bounce[2];
   Staged staged[MAXSRC][MAXLEVELS];

@@ -2448,6 +2448,122 @@ __global__ __launch_bounds__(BLOCK) void k_blk_dilate_row(const float *__restric
   if (any) changed[1] = 1;
 }
 
+// ---- block preparation in three passes (round 3; the ten row sweeps above read a variable ~10 times: 2.4 ms per C3 time
+// level).  (1) k_blk_mask_fill: mask + fill_NaN_towards_seafloor in place, one thread per water column, and a flag per
+// (layer, 44x44-cell tile) whose interior still holds a NaN.  (2) k_blk_dilate_tile: only flagged tiles -- the tile and a
+// 10-cell halo (what ten 3x3 sweeps can reach) on chip, the ten sweeps there (stopping at the fixed point), interior written
+// to `dst`; cells outside the grid are NaN there, which the dilation ignores like the plain kernel's bounds checks.
+// A halo cell's value is exact only for as many sweeps as its distance to the region's border -- exactly what the interior
+// needs.  (3) k_blk_to_record(src, fix): a cell that is NaN in src takes fix's value.  Same bits as the plain sweeps
+// (tests/test_gpu_async_upload.py).
+constexpr int DIL_T = 44, DIL_H = 10, DIL_R = DIL_T + 2 * DIL_H;   // interior, halo, LDS region edge (64)
+struct BlkPrep {   // the variables of one time level, staged side by side ([nz][ny][nx] each)
+  int nvars, ny, nx, rec, tiles_x, ntiles, pad0, pad1;
+  float *src[NVAR], *fix[NVAR];            // staged array; dilated values of its NaN cells (k_blk_dilate_tile)
+  int nz[NVAR], cum[NVAR + 1];             // layers; layers of the variables before it (flag rows, flat layer index)
+  int off[NVAR], es[NVAR], eo[NVAR];       // record layout (DevBlock)
+  unsigned char fill[NVAR], dil[NVAR];     // fill towards the sea floor; dilate (everything but the land mask)
+};
+__global__ __launch_bounds__(BLOCK) void k_blk_mask_fill(BlkPrep Q, int *__restrict__ tile_flags) {
+  const int x = blockIdx.x * BLOCK + threadIdx.x, y = blockIdx.y, kv = blockIdx.z;
+  if (x >= Q.nx) return;
+  float *a = Q.src[kv];
+  const int nz = Q.nz[kv];
+  const bool fill = Q.fill[kv];
+  int *flags = Q.dil[kv] ? tile_flags + (size_t)Q.cum[kv] * Q.ntiles : nullptr;
+  const size_t plane = (size_t)Q.ny * Q.nx, i = (size_t)y * Q.nx + x;
+  const int tile = (y / DIL_T) * Q.tiles_x + x / DIL_T;
+  float prev = 0;
+  for (int k0 = 0; k0 < nz; k0 += 4) {     // four layers in flight: the stores below would otherwise fence every load
+    float v4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v4[j] = k0 + j < nz ? a[(k0 + j) * plane + i] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + j;
+      if (k >= nz) break;
+      const float v0 = v4[j];
+      float v = v0;
+      bool wr = false;
+      if (!isfinite(v) || v < -1e9f || v > 1e9f) { v = __builtin_nanf(""); wr = !isnan(v0); }
+      if (fill && k > 0 && isnan(v) && !isnan(prev)) { v = prev; wr = true; }
+      if (wr) a[k * plane + i] = v;
+      if (flags && isnan(v)) flags[k * Q.ntiles + tile] = 1;
+      prev = v;
+    }
+  }
+}
+// The 64x64 region lives in REGISTERS: lane = column, each of the 4 waves holds 16 rows of its column (NaN kept as -inf so
+// that "largest finite neighbour" is a plain compare chain in the plain kernel's scan order -- row-major, first maximum
+// wins).  Left / right neighbours come over DPP wave shifts, the rows above / below a wave's strip through a small LDS
+// exchange, one barrier per sweep.  (First version, two 16 KB LDS planes and 9 LDS reads per cell: 256 us per C3
+// variable -- the ~3 flagged tiles per CU could not hide the LDS latency -- against ~20 us for this one.)
+__device__ __forceinline__ float dpp_from_left(float v, float absent) {    // lane i <- lane i-1; lane 0 <- absent
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(absent), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_right(float v, float absent) {   // lane i <- lane i+1; lane 63 <- absent
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(absent), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+__global__ __launch_bounds__(BLOCK) void k_blk_dilate_tile(BlkPrep Q, const int *__restrict__ tile_flags) {
+  const int tile = blockIdx.x, flat = blockIdx.y, ny = Q.ny, nx = Q.nx, tiles_x = Q.tiles_x;
+  if (!tile_flags[(size_t)flat * Q.ntiles + tile]) return;   // (never set for the land mask)
+  int kv = 0;
+  while (kv + 1 < Q.nvars && flat >= Q.cum[kv + 1]) ++kv;
+  const int layer = flat - Q.cum[kv];
+  const float *__restrict__ src = Q.src[kv];
+  float *__restrict__ dst = Q.fix[kv];
+  constexpr int ROWS = DIL_R / (BLOCK / 64);   // 16 rows per wave
+  __shared__ float edge[2][2][BLOCK / 64][64];   // [sweep parity][top / bottom row of the strip][wave][column]
+  const int ty0 = (tile / tiles_x) * DIL_T - DIL_H, tx0 = (tile % tiles_x) * DIL_T - DIL_H;
+  const float *s = src + (size_t)layer * ny * nx;
+  const int c = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float NINF = -__builtin_inff();
+  float w[ROWS];
+  const int x = tx0 + c;
+#pragma unroll
+  for (int j = 0; j < ROWS; ++j) {
+    const int y = ty0 + ROWS * wv + j;
+    float v = (y >= 0 && y < ny && x >= 0 && x < nx) ? s[(size_t)y * nx + x] : NINF;
+    w[j] = isnan(v) ? NINF : v;
+  }
+  auto row3 = [&](float m) {   // first maximum of (left, centre, right)
+    const float l = dpp_from_left(m, NINF), r = dpp_from_right(m, NINF);
+    float b = l;
+    if (m > b) b = m;
+    if (r > b) b = r;
+    return b;
+  };
+  for (int it = 0; it < 10; ++it) {
+    const int par = it & 1;
+    edge[par][0][wv][c] = w[0];
+    edge[par][1][wv][c] = w[ROWS - 1];
+    __syncthreads();
+    const float above = wv > 0 ? edge[par][1][wv - 1][c] : NINF, below = wv < BLOCK / 64 - 1 ? edge[par][0][wv + 1][c] : NINF;
+    float h[ROWS + 2];
+    h[0] = row3(above);
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) h[j + 1] = row3(w[j]);
+    h[ROWS + 1] = row3(below);
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+      float b = h[j];
+      if (h[j + 1] > b) b = h[j + 1];
+      if (h[j + 2] > b) b = h[j + 2];
+      if (w[j] == NINF && b > NINF) { w[j] = b; any = true; }
+    }
+    if (!__syncthreads_or(any)) break;   // fixed point
+  }
+  if (c >= DIL_H && c < DIL_H + DIL_T && x < nx) {
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+      const int r = ROWS * wv + j, y = ty0 + r;
+      if (r >= DIL_H && r < DIL_H + DIL_T && y < ny)
+        dst[(size_t)layer * ny * nx + (size_t)y * nx + x] = w[j] == NINF ? __builtin_nanf("") : w[j];
+    }
+  }
+}
+
 // ------------------------------------------------------------------ output history
 // state_to_buffer (basemodel/__init__.py:2384-2403) on the device: the float32 result buffer
 // (:2084-2105: every exported variable is a float32 [trajectory, time] array initialised with NaN)
@@ -2595,19 +2711,81 @@ __global__ __launch_bounds__(BLOCK) void k_roms_zslice(const TF *__restrict__ F,
 // dst[node * rec + off + k * es + eo] (es = 2, eo = 0/1 for the two components of a vector pair).
 // src is the reader's [nz][ny][nx] array.
 __global__ __launch_bounds__(BLOCK) void k_blk_to_record(const float *__restrict__ src, float *__restrict__ dst,
-                                                        int nz, size_t plane, int rec, int off, int es, int eo) {
+                                                        int nz, size_t plane, int rec, int off, int es, int eo,
+                                                        const float *__restrict__ fix = nullptr) {
   // 64 nodes per workgroup through LDS: reads are coalesced along the nodes of one level, writes run along the
   // levels of one node (the record's contiguous direction) instead of 64 lanes hitting 64 different records
   __shared__ float t[64][MAXNZ + 1];
   const size_t n0 = (size_t)blockIdx.x * 64;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int k = w; k < nz; k += BLOCK / 64)
-    if (n0 + lane < plane) t[lane][k] = src[(size_t)k * plane + n0 + lane];
+    if (n0 + lane < plane) {
+      float v = src[(size_t)k * plane + n0 + lane];
+      if (fix && isnan(v)) v = fix[(size_t)k * plane + n0 + lane];   // dilated value of a cell that had none (k_blk_dilate_tile)
+      t[lane][k] = v;
+    }
   __syncthreads();
   const int total = 64 * nz;
   for (int q = threadIdx.x; q < total; q += BLOCK) {
     const int node = q / nz, k = q - node * nz;
     if (n0 + node < plane) dst[(n0 + node) * rec + off + k * es + eo] = t[node][k];
+  }
+}
+
+// The record writer of the three-pass preparation: 64 nodes per workgroup, the COMPLETE records of those nodes assembled
+// in LDS (every layer of every variable read along the nodes: 256-byte coalesced reads; NaN cells take the dilated value)
+// and written as one contiguous run of 64 x rec floats -- instead of one strided pass over the block per variable.
+// Records longer than REC_CH floats go in chunks.  Padding floats are written as 0.
+constexpr int REC_CH = 128;
+__global__ __launch_bounds__(BLOCK) void k_blk_records(BlkPrep Q, float *__restrict__ dst, size_t plane) {
+  extern __shared__ float t[];   // [64][cs], cs = min(rec, REC_CH) | 1: lane-strided writes and row reads without bank conflicts
+  // record position -> plane of that (variable, layer) in the staging area, and the plane of its dilated values (or null):
+  // looked up per read instead of walking the descriptor (chains of dependent scalar loads: 0.36 ms per C3 level)
+  __shared__ const float *tab_src[REC_CH], *tab_fix[REC_CH];
+  const size_t n0 = (size_t)blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, rec = Q.rec;
+  const int cs = (rec < REC_CH ? rec : REC_CH) | 1;
+  const bool live = n0 + lane < plane;
+  const int total = Q.cum[Q.nvars];
+  constexpr int NW = BLOCK / 64, UN = 8;
+  for (int r0 = 0; r0 < rec; r0 += REC_CH) {
+    const int cw = rec - r0 < REC_CH ? rec - r0 : REC_CH;
+    if (r0) __syncthreads();
+    for (int pp = threadIdx.x; pp < cw; pp += BLOCK) { tab_src[pp] = nullptr; tab_fix[pp] = nullptr; }
+    for (int node = w; node < 64; node += NW)
+      for (int pp = lane; pp < cw; pp += 64) t[node * cs + pp] = 0.f;
+    __syncthreads();
+    for (int f = threadIdx.x; f < total; f += BLOCK) {
+      int kv = 0;
+      while (f >= Q.cum[kv + 1]) ++kv;
+      const int k = f - Q.cum[kv], pr = Q.off[kv] + k * Q.es[kv] + Q.eo[kv] - r0;
+      if (pr >= 0 && pr < cw) {
+        tab_src[pr] = Q.src[kv] + (size_t)k * plane;
+        tab_fix[pr] = Q.dil[kv] ? Q.fix[kv] + (size_t)k * plane : nullptr;
+      }
+    }
+    __syncthreads();
+    for (int p0 = w; p0 < cw; p0 += NW * UN) {   // UN independent plane reads in flight per lane
+      float v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int pr = p0 + NW * u;
+        const float *sp = pr < cw ? tab_src[pr] : nullptr;
+        v[u] = sp && live ? sp[n0 + lane] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int pr = p0 + NW * u;
+        if (pr >= cw) break;
+        float x = v[u];
+        if (isnan(x) && tab_fix[pr]) x = tab_fix[pr][n0 + lane];   // dilated value of a cell that had none
+        t[lane * cs + pr] = x;
+      }
+    }
+    __syncthreads();
+    for (int node = w; node < 64; node += NW)
+      if (n0 + node < plane)
+        for (int pp = lane; pp < cw; pp += 64) dst[(n0 + node) * rec + r0 + pp] = t[node * cs + pp];
   }
 }
 

@@ -75,6 +75,7 @@ int odr_ctx_destroy(odr_ctx *c) {
   if (c->noise_buf) (void)hipFree(c->noise_buf);
   (void)hipFree(c->counter);
   (void)hipFree(c->dilate_flags);
+  if (c->tile_flags) (void)hipFree(c->tile_flags);
   for (int k = 0; k < 2; ++k) if (c->bounce[k]) (void)hipHostFree(c->bounce[k]);
   if (c->lanes_ready) {
     for (int l = 0; l < ODR_MAX_LANES; ++l) {
@@ -538,7 +539,7 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
   b.ixspan = 1.0 / b.xspan; b.iyspan = 1.0 / b.yspan; b.ixrange = 1.0 / b.xrange; b.iyrange = 1.0 / b.yrange;
   b.t = t_epoch;
   const size_t plane = (size_t)ny * nx;
-  size_t nmax = 0;
+  size_t nmax = 0, ntot = 0, nlayers = 0;
   for (int k = 0; k < nvars; ++k) {
     int v = var_ids[k], nzv = var_nz[k] > 1 ? var_nz[k] : 1;
     REQUIRE(v >= 0 && v < NVAR, "bad variable id %d", v);
@@ -546,7 +547,10 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
     REQUIRE(nzv == mem || nzv == mem * s.nz, "variable %d has %d layers, source has %d levels x %d members", v, nzv, s.nz, mem);
     REQUIRE(mem == 1 || v != VAR_KZ, "ensemble members of ocean_vertical_diffusivity profiles are not supported");
     nmax = std::max(nmax, plane * (size_t)nzv);
+    ntot += plane * (size_t)nzv;
+    nlayers += (size_t)nzv;
   }
+  nmax = std::max(nmax, ntot);   // the whole level is staged at once (prep_all below)
   // record layout: interleaved vector pairs first, then the other 3D variables, then the 2D ones; the record
   // length is padded to 16 bytes (odr_field.hip.h DevBlock)
   static const int pairs[4][2] = {{VAR_U, VAR_V}, {VAR_XWIND, VAR_YWIND}, {VAR_SX, VAR_SY}, {VAR_ICE_U, VAR_ICE_V}};
@@ -595,9 +599,60 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
     HIPCHK(hipEventRecord(c->up_dep, c->stream));
     HIPCHK(hipStreamWaitEvent(st, c->up_dep, 0));
   }
+  // Preparation of the whole level in three launches (k_blk_mask_fill / k_blk_dilate_tile / k_blk_records): every variable
+  // staged side by side in the scratch pool, mask + sea-floor fill with a NaN flag per (layer, tile), the ten dilation
+  // sweeps on flagged tiles only, one record writer that assembles complete node records.  ODR_ROW_DILATE /
+  // ODR_PLAIN_DILATE: the per-variable whole-array sweeps of rounds 1-2 (the cross-check of tests/test_gpu_async_upload.py).
+  const bool prep_all = !getenv("ODR_PLAIN_DILATE") && !getenv("ODR_ROW_DILATE") && ny < 65536 && nlayers < 65536 && nvars <= NVAR;
+  if (prep_all) {
+    BlkPrep Q;
+    memset(&Q, 0, sizeof Q);
+    Q.nvars = nvars; Q.ny = ny; Q.nx = nx; Q.rec = rec;
+    Q.tiles_x = (nx + DIL_T - 1) / DIL_T;
+    Q.ntiles = Q.tiles_x * ((ny + DIL_T - 1) / DIL_T);
+    const size_t nflags = nlayers * (size_t)Q.ntiles;
+    if (c->tile_flags_n < nflags) {
+      HIPCHK(hipStreamSynchronize(st));
+      if (c->tile_flags) HIPCHK(hipFree(c->tile_flags));
+      c->tile_flags = nullptr;
+      HIPCHK(hipMalloc((void **)&c->tile_flags, sizeof(int) * nflags));
+      c->tile_flags_n = nflags;
+    }
+    HIPCHK(hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflags, st));
+    HIPCHK(hipMemsetAsync((char *)base + base_bytes - 64, 0, 64, st));   // the spare bytes wide slot loads may touch
+    size_t at_f = 0;
+    int cum = 0, ndil = 0;
+    for (int k = 0; k < nvars; ++k) {
+      const int v = var_ids[k], nzv = var_nz[k] > 1 ? var_nz[k] : 1;
+      const size_t n = plane * (size_t)nzv;
+      float *buf = c->prep[0] + at_f;
+      hipPointerAttribute_t at;
+      bool pageable = false;
+      if (hipPointerGetAttributes(&at, data[k]) != hipSuccess) { (void)hipGetLastError(); pageable = true; }
+      else pageable = at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeHost && at.type != hipMemoryTypeManaged;
+      if (pageable) { int rcb = odr_i_h2d(c, buf, data[k], sizeof(float) * n, st, 1); if (rcb) return rcb; }
+      else HIPCHK(hipMemcpyAsync(buf, data[k], sizeof(float) * n, hipMemcpyDefault, st));
+      Q.src[k] = buf; Q.fix[k] = c->prep[1] + at_f;
+      Q.nz[k] = nzv; Q.cum[k] = cum; Q.off[k] = off[(size_t)k]; Q.es[k] = es[(size_t)k]; Q.eo[k] = eo[(size_t)k];
+      Q.fill[k] = nzv > 1 && s.members[v] <= 1;     // ("Ensemble data currently not extrapolated towards seafloor", structured.py:58-60)
+      Q.dil[k] = v != VAR_LAND;
+      ndil += Q.dil[k];
+      at_f += n; cum += nzv;
+      b.data[v] = base + off[(size_t)k] + eo[(size_t)k];
+      b.es[v] = es[(size_t)k];
+      b.var_nz[v] = nzv;
+    }
+    Q.cum[nvars] = cum;
+    hipLaunchKernelGGL(k_blk_mask_fill, dim3((unsigned)((nx + BLOCK - 1) / BLOCK), (unsigned)ny, (unsigned)nvars), dim3(BLOCK), 0, st,
+                       Q, c->tile_flags);
+    if (ndil) hipLaunchKernelGGL(k_blk_dilate_tile, dim3((unsigned)Q.ntiles, (unsigned)cum), dim3(BLOCK), 0, st, Q,
+                                 (const int *)c->tile_flags);
+    hipLaunchKernelGGL(k_blk_records, dim3((unsigned)((plane + 63) / 64)), dim3(BLOCK), sizeof(float) * 64 * (size_t)((rec < REC_CH ? rec : REC_CH) | 1), st,
+                       Q, base, plane);
+  } else
   HIPCHK(hipMemsetAsync(base, 0, base_bytes, st));
   const unsigned gp = (unsigned)((plane + BLOCK - 1) / BLOCK);
-  for (int k = 0; k < nvars; ++k) {
+  for (int k = 0; k < nvars && !prep_all; ++k) {
     const int v = var_ids[k], nzv = var_nz[k] > 1 ? var_nz[k] : 1;
     const size_t n = plane * (size_t)nzv;
     float *buf = c->prep[0], *tmp = c->prep[1];
@@ -645,7 +700,7 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
     }
     const float *fin = buf;
     hipLaunchKernelGGL(k_blk_to_record, dim3((unsigned)((plane + 63) / 64)), dim3(BLOCK), 0, st, fin, base, nzv, plane, rec,
-                       off[(size_t)k], es[(size_t)k], eo[(size_t)k]);
+                       off[(size_t)k], es[(size_t)k], eo[(size_t)k], (const float *)nullptr);
     b.data[v] = base + off[(size_t)k] + eo[(size_t)k];
     b.es[v] = es[(size_t)k];
     b.var_nz[v] = nzv;

@@ -142,3 +142,49 @@ def test_row_dilation_sweeps_equal_the_plain_ones(ctx, monkeypatch, nx):
     for nm in names:
         assert _eq(res[0][nm], res[1][nm]), nm
     assert np.isnan(res[0][U]).any() and np.isfinite(res[0][U]).sum() > n // 2
+
+
+@pytest.mark.parametrize('nx,ny,old', [(150, 101, 'ODR_PLAIN_DILATE'), (89, 133, 'ODR_ROW_DILATE'), (44, 45, 'ODR_PLAIN_DILATE')])
+def test_tiled_block_preparation_equals_the_sweeps(ctx, monkeypatch, nx, ny, old):
+    """mask + sea-floor fill + ten grey_dilation sweeps of a new block (ReaderBlock.__init__, expand_numpy_array):
+    k_blk_mask_fill + k_blk_dilate_tile (44x44-cell tiles with a 10-cell halo in LDS, flagged tiles only) + the merging
+    record writer against the whole-variable sweeps of rounds 1-2 -- the same samples bit for bit on grids of several
+    tiles with NaN regions deeper than ten cells, NaN across tile seams and on the block edges, values beyond 1e9, inf,
+    a layer that is NaN everywhere, a NaN-free variable, a 2-D variable and the (undilated) land mask."""
+    nz = 4
+    rng = np.random.default_rng(nx)
+    x, y, z = np.linspace(3.0, 5.0, nx), np.linspace(59.0, 61.0, ny), -np.linspace(0, 30, nz)
+    Y, X = np.meshgrid(np.arange(ny), np.arange(nx), indexing='ij')
+    blob = ((X - 44) ** 2 + (Y - 44) ** 2 < 300) | ((X - nx + 3) ** 2 + (Y - 20) ** 2 < 150) | (rng.uniform(size=(ny, nx)) < 0.05) \
+        | ((X > 80) & (X < 97) & (Y > 30))
+    blob[0, :5] = True
+    blob[-1, -4:] = True
+    blob[:, 43:45] |= (Y[:, 43:45] % 3 == 0)           # a dotted line along a tile seam
+    fields = {}
+    for k, nm in enumerate((U, V, KZ)):
+        f = rng.normal(size=(nz, ny, nx)).astype(np.float32)
+        if nm != KZ:
+            f[:, blob] = np.nan
+            f[2:, (X + Y) % 7 == 0] = np.nan
+            f[1, (X * Y) % 11 == 0] = 3e9 if nm == U else np.inf
+        fields[nm] = f
+    fields[V][0] = np.nan                                # a whole layer without a value (sea-floor fill leaves layer 0 alone)
+    fields[DEPTH] = np.where(blob, np.nan, 100.0 + X).astype(np.float32)
+    fields[LAND] = blob.astype(np.float32)
+    names = [U, V, KZ, DEPTH, LAND]
+    n = 60000
+    lon, lat, zz = rng.uniform(x[0], x[-1], n), rng.uniform(y[0], y[-1], n), -rng.uniform(0, 30, n)
+    P = ctx.particles(n)
+    P.append(lon, lat, z=zz)
+    res = []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv(old, '1')
+        sid = ctx.add_grid(x, y, z=z)
+        ctx.upload_block(sid, 0, 0.0, {k: v.copy() for k, v in fields.items()})
+        for nm in names:
+            ctx.bind(nm, [sid], np.nan)
+        res.append(P.env_sample(names, 0.0, download=True))
+    for nm in names:
+        assert _eq(res[0][nm], res[1][nm]), nm
+    assert np.isnan(res[0][U]).any() and np.isfinite(res[0][U]).sum() > n // 2
