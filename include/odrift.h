@@ -69,11 +69,14 @@ enum {
 
 /* ---- projections of a reader (pyproj.Proj(reader.proj4), basereader/__init__.py:119-137) ---- */
 enum { ODR_PROJ_LATLONG = 0, ODR_PROJ_STERE_EQUIT_SPHERE = 1, ODR_PROJ_STERE_POLAR = 2,
-       ODR_PROJ_CURVILINEAR = 3 /* set by odr_source_grid_curvilinear, not through odr_proj_desc */ };
+       ODR_PROJ_CURVILINEAR = 3 /* set by odr_source_grid_curvilinear, not through odr_proj_desc */,
+       ODR_PROJ_MERC = 4 /* +proj=merc (+lat_ts or +k_0), sphere or ellipsoid: Snyder ch. 7 */,
+       ODR_PROJ_LCC = 5 /* +proj=lcc +lat_1 [+lat_2] +lat_0 +lon_0, sphere or ellipsoid: Snyder ch. 15 */ };
 typedef struct {
   int32_t kind;
   double a, es;                  /* semi-major axis, eccentricity squared */
   double lat0_deg, lon0_deg, lat_ts_deg, k0, x0, y0;
+  double lat1_deg, lat2_deg;     /* standard parallels (ODR_PROJ_LCC; lat2 = lat1 for the tangent cone) */
 } odr_proj_desc;
 
 enum { ODR_SCHEME_EULER = 0, ODR_SCHEME_RK2 = 1, ODR_SCHEME_RK4 = 2 };

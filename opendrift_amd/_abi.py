@@ -28,6 +28,7 @@ VARIABLES = {
 }
 VARIABLE_NAMES = {v: k for k, v in VARIABLES.items()}
 PROJ_LATLONG, PROJ_STERE_EQUIT_SPHERE, PROJ_STERE_POLAR = 0, 1, 2
+PROJ_MERC, PROJ_LCC = 4, 5
 SCHEME = {'euler': 0, 'runge-kutta': 1, 'runge-kutta4': 2}
 RNG_DEVICE, RNG_HOST = 0, 1
 STAGE_MATH = {'exact': 0, 'fast': 1}     # odr_ctx_set_stage_math
@@ -50,7 +51,7 @@ ANALYTIC_DOUBLE_GYRE, ANALYTIC_OSCILLATING = 1, 2
 class ProjDesc(C.Structure):
     _fields_ = [('kind', C.c_int32), ('a', C.c_double), ('es', C.c_double), ('lat0_deg', C.c_double),
                 ('lon0_deg', C.c_double), ('lat_ts_deg', C.c_double), ('k0', C.c_double),
-                ('x0', C.c_double), ('y0', C.c_double)]
+                ('x0', C.c_double), ('y0', C.c_double), ('lat1_deg', C.c_double), ('lat2_deg', C.c_double)]
 
 
 class OdrError(RuntimeError):

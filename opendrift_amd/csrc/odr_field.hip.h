@@ -38,10 +38,12 @@ enum { VAR_U = 0, VAR_V = 1, VAR_XWIND = 2, VAR_YWIND = 3, VAR_W = 4, VAR_KZ = 5
        VAR_ICE_A = 17, VAR_ICE_U = 18, VAR_ICE_V = 19, VAR_SWELL_DIR = 20, VAR_SWELL_TP = 21, VAR_SWELL_HS = 22,
        VAR_WW_DIR = 23, VAR_WW_TM = 24, VAR_WW_HS = 25 };
 enum { SRC_CONSTANT = 0, SRC_DOUBLE_GYRE = 1, SRC_OSCILLATING = 2, SRC_GRID = 3, SRC_LANDMASK = 4 };
-enum { PROJ_LATLONG = 0, PROJ_STERE_EQUIT_SPHERE = 1, PROJ_STERE_POLAR = 2, PROJ_CURVILINEAR = 3 };
+enum { PROJ_LATLONG = 0, PROJ_STERE_EQUIT_SPHERE = 1, PROJ_STERE_POLAR = 2, PROJ_CURVILINEAR = 3, PROJ_MERC = 4, PROJ_LCC = 5 };
+// (kernels templated on the projection: anything but latlong / polar stere / curvilinear takes the PROJ_STERE_EQUIT_SPHERE
+// instantiation, whose proj_fwd / proj_inv / rotation_angle switch on DevProj::kind at run time)
 // x/y vector pairs are rotated from the reader's CRS to lon/lat (variables.py:799-837); for a reader without a
 // projection (fakeproj) the rotation the reference computes is by the azimuth of due north, i.e. exactly zero
-#define ODR_PROJ_ROTATES(K) ((K) == PROJ_STERE_EQUIT_SPHERE || (K) == PROJ_STERE_POLAR)
+#define ODR_PROJ_ROTATES(K) ((K) == PROJ_STERE_EQUIT_SPHERE || (K) == PROJ_STERE_POLAR || (K) == PROJ_MERC || (K) == PROJ_LCC)
 
 struct D2 { double x, y; };
 
@@ -49,6 +51,7 @@ struct DevProj {
   int kind, south;
   double a, es, e, lon0, lat0, x0, y0, k0, akm1;
   double cchi[4];  // conformal -> geodetic latitude series (Snyder 3-5), used by rotation_angle
+  double cn, cc, crho0;  // PROJ_LCC: cone constant n, F = m1 / (n t1^n), rho0 / a (Snyder 15-1..15-8); PROJ_MERC: k0 in k0
   // PROJ_CURVILINEAR: a reader WITHOUT a projection (2D lon/lat node arrays, pixel indices as x/y;
   // basereader/structured.py:44-113).  cv_nodes[j*cv_nx + i] = (lon, lat) of node (i, j); cv_tri_v / cv_tri_n = the
   // Delaunay triangulation of the nodes (counter-clockwise vertices; neighbour across the edge opposite vertex k,
@@ -202,6 +205,18 @@ __device__ __forceinline__ void proj_fwd(const DevProj &p, double lon_deg, doubl
   if (p.kind == PROJ_LATLONG) { x = lon_deg; y = lat_deg; return; }
   double lam = wrap_pi(lon_deg * kDeg - p.lon0), phi = lat_deg * kDeg;
   double sinlam, coslam, sinphi, cosphi, X, Y;
+  if (p.kind == PROJ_MERC) {        // Snyder 7-6 / 7-7 (sphere: e = 0)
+    x = p.a * (p.k0 * lam) + p.x0;
+    y = p.a * (-p.k0 * log(tsfn(phi, sin(phi), p.e))) + p.y0;
+    return;
+  }
+  if (p.kind == PROJ_LCC) {         // Snyder 15-7, 14-4, 14-1, 14-2
+    const double rho = fabs(fabs(phi) - kHalfPi) < 1e-10 ? 0.0 : p.cc * pow(tsfn(phi, sin(phi), p.e), p.cn);
+    sincos(p.cn * lam, &sinlam, &coslam);
+    x = p.a * (p.k0 * (rho * sinlam)) + p.x0;
+    y = p.a * (p.k0 * (p.crho0 - rho * coslam)) + p.y0;
+    return;
+  }
   sincos(lam, &sinlam, &coslam);
   sincos(phi, &sinphi, &cosphi);
   if (p.kind == PROJ_STERE_EQUIT_SPHERE) {
@@ -272,6 +287,29 @@ __device__ __forceinline__ void proj_inv(const DevProj &p, double x, double y, d
   if (p.kind == PROJ_LATLONG) { lon_deg = x; lat_deg = y; return; }
   double X = (x - p.x0) / p.a, Y = (y - p.y0) / p.a;
   double rh = hypot(X, Y), lam = 0, phi = 0;
+  if (p.kind == PROJ_MERC || p.kind == PROJ_LCC) {
+    double ts;
+    if (p.kind == PROJ_MERC) { ts = exp(-Y / p.k0); lam = X / p.k0; }       // Snyder 7-10, 7-12
+    else {                                                                   // Snyder 14-10, 14-11, 15-11, 14-9
+      double xx = X / p.k0, yy = p.crho0 - Y / p.k0, rho = hypot(xx, yy);
+      if (p.cn < 0) { rho = -rho; xx = -xx; yy = -yy; }
+      ts = rho != 0 ? pow(rho / p.cc, 1 / p.cn) : 0.0;
+      lam = rho != 0 ? atan2(xx, yy) / p.cn : 0.0;
+      if (rho == 0) { lon_deg = wrap_pi(p.lon0) / kDeg; lat_deg = p.cn > 0 ? 90.0 : -90.0; return; }
+    }
+    double phi_l = kHalfPi - 2 * atan(ts), halfe = 0.5 * p.e;                // Snyder 7-9 to convergence
+    phi = phi_l;
+#pragma unroll 1
+    for (int i = 0; i < 10 && p.e != 0; ++i) {
+      double es = p.e * sin(phi_l);
+      phi = kHalfPi - 2 * atan(ts * pow((1 - es) / (1 + es), halfe));
+      if (fabs(phi - phi_l) < 1e-15) break;
+      phi_l = phi;
+    }
+    lon_deg = wrap_pi(lam + p.lon0) / kDeg;
+    lat_deg = phi / kDeg;
+    return;
+  }
   if (p.kind == PROJ_STERE_EQUIT_SPHERE) {
     double c = 2 * atan(rh / p.akm1), sinc, cosc;
     sincos(c, &sinc, &cosc);

@@ -308,6 +308,22 @@ static void proj_init(DevProj &p, const odr_proj_desc *d) {
     p.cchi[2] = 7 * e6 / 120 + 81 * e8 / 1120;
     p.cchi[3] = 4279 * e8 / 161280;
   }
+  if (d->kind == PROJ_MERC || d->kind == PROJ_LCC) {
+    // PROJ's merc / lcc set-up: k0 from +lat_ts (merc); cone constant, F and rho0 from the standard parallels (lcc)
+    auto msfn = [&](double phi) { double sp = sin(phi); return cos(phi) / sqrt(1 - d->es * sp * sp); };
+    auto ts = [&](double phi) { double es = p.e * sin(phi); return tan(0.5 * (kHalfPi - phi)) / pow((1 - es) / (1 + es), 0.5 * p.e); };
+    if (d->kind == PROJ_MERC) {
+      if (d->lat_ts_deg != 0) p.k0 = msfn(fabs(d->lat_ts_deg) * kDeg);
+    } else {
+      const double phi1 = d->lat1_deg * kDeg, phi2 = d->lat2_deg * kDeg;
+      double n = sin(phi1);
+      const double m1 = msfn(phi1), t1 = ts(phi1);
+      if (fabs(phi1 - phi2) >= 1e-10) n = log(m1 / msfn(phi2)) / log(t1 / ts(phi2));
+      p.cn = n;
+      p.cc = m1 * pow(t1, -n) / n;
+      p.crho0 = fabs(fabs(p.lat0) - kHalfPi) < 1e-10 ? 0.0 : p.cc * pow(ts(p.lat0), n);
+    }
+  }
   if (d->kind == PROJ_STERE_POLAR) {  // Snyder 21-33/21-34 scale constant
     double phits = fabs(d->lat_ts_deg) * kDeg, e = p.e;
     if (d->es == 0) {

@@ -44,10 +44,11 @@ def _i(a, n=None):
 
 
 def proj_desc(proj):
-    """dict(kind='latlong'|'stere_equit_sphere'|'stere_polar', a, rf|es, lat0, lon0, lat_ts, k0, x0, y0)"""
+    """dict(kind='latlong'|'stere_equit_sphere'|'stere_polar'|'merc'|'lcc', a, rf|es, lat0, lon0, lat_ts, k0, x0, y0, lat1, lat2)"""
     if proj is None or proj.get('kind', 'latlong') == 'latlong':
         return None
-    kind = {'stere_equit_sphere': _abi.PROJ_STERE_EQUIT_SPHERE, 'stere_polar': _abi.PROJ_STERE_POLAR}[proj['kind']]
+    kind = {'stere_equit_sphere': _abi.PROJ_STERE_EQUIT_SPHERE, 'stere_polar': _abi.PROJ_STERE_POLAR,
+            'merc': _abi.PROJ_MERC, 'lcc': _abi.PROJ_LCC}[proj['kind']]
     if 'es' in proj:
         es = proj['es']
     else:
@@ -55,7 +56,8 @@ def proj_desc(proj):
         f = 0.0 if not rf else 1.0 / rf
         es = f * (2 - f)
     return _abi.ProjDesc(kind, proj.get('a', 6378137.0), es, proj.get('lat0', 0.0), proj.get('lon0', 0.0),
-                         proj.get('lat_ts', 90.0), proj.get('k0', 1.0), proj.get('x0', 0.0), proj.get('y0', 0.0))
+                         proj.get('lat_ts', 90.0), proj.get('k0', 1.0), proj.get('x0', 0.0), proj.get('y0', 0.0),
+                         proj.get('lat1', 0.0), proj.get('lat2', proj.get('lat1', 0.0)))
 
 
 def sea_water_density_default():

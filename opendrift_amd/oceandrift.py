@@ -675,30 +675,82 @@ class OpenDriftSimulation(Configurable):
     def _host_bindings(self):
         return [(n, b) for n, b in self.readers.items() if getattr(b, 'host_eval', False)]
 
-    def _sample_host_readers(self, names):
+    def _sample_host_readers(self, names, P=None, time=None):
         """Readers evaluated on the host (user-defined ContinuousReaders): where such a reader comes BEFORE the device
         sources of a variable its finite values replace what the device sampled (the priority-list walk of
         environment.py:597-762 with the host reader in first place); elsewhere in the list it only fills what is
-        still missing."""
+        still missing.  P / time: the particle set and time of the sample (default: the elements, now)."""
         hb = self._host_bindings()
-        if not hb or self.num_elements_active() == 0:
+        P = self.P if P is None else P
+        time = self.time if time is None else time
+        if not hb or len(P) == 0:
             return
-        d = self.P.download()
+        d = P.download()
         for name, b in hb:
             vs = [v for v in b.variables if v in names and name in self.priority_list.get(v, [])]
             if not vs:
                 continue
             try:
-                vals = b.evaluate_on_host(vs, self.time, d['lon'], d['lat'], d['z'], element_ID=d['ID'])
+                vals = b.evaluate_on_host(vs, time, d['lon'], d['lat'], d['z'], element_ID=d['ID'])
             except Exception as e:      # the reference catches every exception of a reader call (environment.py:640-668)
                 self._reader_failed(name, b, e)
                 continue
             for v in vs:
                 first = self.priority_list[v][0] == name
-                cur = self.P.env_download(v)
+                cur = P.env_download(v)
                 take = np.isfinite(vals[v]) & (first | ~np.isfinite(cur))
                 if take.any():
-                    self.P.env_upload(v, np.where(take, vals[v], cur).astype(np.float32))
+                    P.env_upload(v, np.where(take, vals[v], cur).astype(np.float32))
+
+    def _advect_stage_split(self, scheme, factor):
+        """advect_ocean_current under a Runge-Kutta scheme when a host-evaluated reader is among the sources of the
+        current (physics_methods.py:623-680): the stages cannot run inside one kernel -- every stage is a
+        get_environment call that has to reach the user's reader -- so the step is split at the stage boundaries.  Per
+        stage: the stage positions on the device (geod.fwd along the float32 stage velocity over dt/2: odr_update_positions
+        on a scratch particle set holding the elements' positions and IDs), the device sources sampled there
+        (odr_env_sample at the stage time), the host readers evaluated at the same positions and merged by priority, the
+        stage's uncertainty draws; then the float32 RK combination and update_positions of the elements."""
+        U, V = 'x_sea_water_velocity', 'y_sea_water_velocity'
+        P, dt = self.P, self.time_step.total_seconds()
+        n = len(P)
+        if n == 0:
+            return
+        d = P.download()
+        u1, v1 = P.env_download(U), P.env_download(V)
+        fac = factor * P.download_f32('current_drift_factor')          # factor*cdf: float32 (physics_methods.py:622)
+        std, ustd = self._current_uncertainty()
+        S = self.ctx.particles(n)
+        try:
+            S.append(d['lon'], d['lat'], z=d['z'], id=d['ID'])
+
+            def stage(k, u, v, t):
+                if k:
+                    S.upload(lon=d['lon'], lat=d['lat'])
+                S.update_positions(u, v, 0.5 * dt)       # geod.fwd(lon, lat, az, speed*dt*.5), all float32 up to the distance
+                S.env_sample([U, V], _epoch(t))
+                self._sample_host_readers([U, V], P=S, time=t)
+                for sd, uniform in ((std, False), (ustd, True)):          # environment.py:869-886, per get_environment call
+                    if not sd:
+                        continue
+                    if self.rng == 'numpy':
+                        draw = (lambda: np.random.uniform(-sd, sd, n)) if uniform else (lambda: np.random.normal(0, sd, n))
+                        S.env_add_noise(U, V, sd, normals=(draw(), draw()), uniform=uniform)
+                    else:
+                        S.env_add_noise(U, V, sd, step=self.steps_calculation + ((k + 1) << 24), uniform=uniform)
+                return S.env_download(U), S.env_download(V)
+
+            half = self.time + self.time_step / 2
+            u2, v2 = stage(0, u1, v1, half)
+            if scheme == 'runge-kutta4':
+                u3, v3 = stage(1, u2, v2, half)
+                u4, v4 = stage(2, u3, v3, self.time + self.time_step)    # (half the distance, the full step later: :662-668)
+                ue = (u1 + 2 * u2 + 2 * u3 + u4) / 6.0
+                ve = (v1 + 2 * v2 + 2 * v3 + v4) / 6.0
+                P.update_positions(ue * fac, ve * fac, dt)
+            else:
+                P.update_positions(fac * u2, fac * v2, dt)
+        finally:
+            S.close()
 
     def _add_uncertainty(self, names, current):
         """environment.py:869-891, in the reference's order of draws: current normal (x, y), current uniform (x, y), wind
@@ -728,6 +780,9 @@ class OpenDriftSimulation(Configurable):
         scheme = self.get_config('drift:advection_scheme')
         std, ustd = self._current_uncertainty()
         nstage = {'runge-kutta': 1, 'runge-kutta4': 3}.get(scheme, 0)
+        if nstage and any('x_sea_water_velocity' in b.variables or 'y_sea_water_velocity' in b.variables
+                          for _, b in self._host_bindings()):
+            return self._advect_stage_split(scheme, factor)
         if nstage and (std > 0 or ustd > 0):
             # every Runge-Kutta stage is a get_environment call of the current: it carries the uncertainty too
             # (environment.py:869-886 inside physics_methods.py:638-670)
@@ -943,10 +998,6 @@ class OpenDriftSimulation(Configurable):
                       # launch: an element both outside the domain and without data must end as 'missing_data'
                       not (any(self.get_config('drift:deactivate_%s_of' % k) is not None for k in ('west', 'east', 'south', 'north'))
                            and self._can_be_missing(list(self.required_variables))))
-        if self._host_bindings() and self.get_config('drift:advection_scheme') != 'euler' and any(
-                'x_sea_water_velocity' in b.variables for _, b in self._host_bindings()):
-            raise NotImplementedError('Runge-Kutta stages sample the current inside the kernel: a host-evaluated '
-                                      'ContinuousReader can deliver it for the euler scheme only')
         self.ctx.sync()
         t_loop = [time.perf_counter(), None]      # main-loop wall time (the reference keeps 'main loop' timers, basemodel :2174)
         # increase_age_and_retire comes after state_to_buffer in the loop: inside the fused launch only when the result

@@ -45,11 +45,15 @@ enum {
 };
 
 /* ---- projections (proj.c) ---- */
-enum { ORC_PROJ_LATLONG = 0, ORC_PROJ_STERE_EQUIT_SPHERE = 1, ORC_PROJ_STERE_POLAR = 2 };
+enum { ORC_PROJ_LATLONG = 0, ORC_PROJ_STERE_EQUIT_SPHERE = 1, ORC_PROJ_STERE_POLAR = 2, ORC_PROJ_MERC = 4, ORC_PROJ_LCC = 5 };
 typedef struct {
   int kind, south;
   double a, es, e, lon0, lat0, x0, y0, k0, akm1;
+  double n, c, rho0;   /* ORC_PROJ_LCC: cone constant, F, rho0 / a (orc_proj_init_conic) */
 } orc_proj;
+/* merc (lat1/lat2 unused; k0 from lat_ts when that is not 0) and lcc (standard parallels lat1, lat2 = lat1 for a tangent cone) */
+void orc_proj_init_conic(orc_proj *p, int kind, double a, double es, double lat0_deg, double lon0_deg, double lat_ts_deg,
+                         double k0, double x0, double y0, double lat1_deg, double lat2_deg);
 void orc_proj_init(orc_proj *p, int kind, double a, double es, double lat0_deg,
                    double lon0_deg, double lat_ts_deg, double k0, double x0, double y0);
 void orc_proj_fwd(const orc_proj *p, double lon_deg, double lat_deg, double *x, double *y);

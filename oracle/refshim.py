@@ -53,7 +53,7 @@ class _CRS:
 
 class Proj:
     """Subset of pyproj.Proj: +proj=latlong/longlat, +proj=stere (equatorial sphere,
-    polar sphere/ellipsoid).  Arithmetic = oracle/proj.c."""
+    polar sphere/ellipsoid), +proj=merc, +proj=lcc.  Arithmetic = oracle/proj.c."""
 
     def __init__(self, projparams=None, **kwargs):
         from oracle import oracle as orc
@@ -103,6 +103,15 @@ class Proj:
             self.crs = _CRS(False, self.srs)
             self._orc = orc.make_proj(kind, a=a, es=es, lat0=lat0, lon0=lon0, lat_ts=lat_ts, k0=k0,
                                       x0=x0, y0=y0)
+        elif name in ('merc', 'lcc'):
+            lat1 = float(p.get('lat_1', 0.0))
+            lat2 = float(p['lat_2']) if 'lat_2' in p else lat1
+            lat0 = float(p['lat_0']) if 'lat_0' in p else (lat1 if name == 'lcc' and 'lat_2' not in p else 0.0)
+            self.crs = _CRS(False, self.srs)
+            self._orc = orc.make_proj(orc.PROJ_MERC if name == 'merc' else orc.PROJ_LCC, a=a, es=es, lat0=lat0,
+                                      lon0=float(p.get('lon_0', 0)), lat_ts=float(p.get('lat_ts', 0.0)),
+                                      k0=float(p.get('k_0', p.get('k', 1.0))), x0=float(p.get('x_0', 0)),
+                                      y0=float(p.get('y_0', 0)), lat1=lat1, lat2=lat2)
         else:
             raise NotImplementedError('pyproj shim: +proj=%s' % name)
 

@@ -316,3 +316,32 @@ def test_c18_windsea_swell_stokes_profile_vs_reference_function():
     assert (u[:20] == 0).all() and (v[:20] == 0).all()              # zero surface drift stays zero
     cond = np.abs(np.sin(np.radians(g['swell_dir'].astype(float) - g['ww_dir'].astype(float))))
     assert err[cond > 0.5].max() < 5e-8
+
+
+def test_mercator_and_lambert_reproduce_snyders_numerical_examples():
+    """oracle/proj.c (and the host-side NumPy projections of opendrift_amd/projection.py) against the worked examples of
+    Snyder, Map Projections -- A Working Manual (USGS PP 1395): Mercator pp. 266-267 (sphere, Clarke 1866 ellipsoid),
+    Lambert conformal conic pp. 295-297 (sphere, Clarke 1866), forward and inverse.  PROJ itself is not in this image: these
+    are the known answers the two projections are pinned on."""
+    from oracle import oracle as orc
+    from opendrift_amd.projection import Proj
+    es = 0.00676866                      # Clarke 1866 (Snyder's examples), a = 6378206.4 m
+    rf = 1 / (1 - np.sqrt(1 - es))
+    cases = [
+        (orc.make_proj(orc.PROJ_LCC, a=6378206.4, es=es, lat0=23, lon0=-96, lat1=33, lat2=45),
+         '+proj=lcc +lat_1=33 +lat_2=45 +lat_0=23 +lon_0=-96 +a=6378206.4 +rf=%.12f' % rf, 1894410.9, 1564649.5, 0.06),
+        (orc.make_proj(orc.PROJ_MERC, a=6378206.4, es=es, lon0=-180, lat_ts=0.0),
+         '+proj=merc +lon_0=-180 +a=6378206.4 +rf=%.12f' % rf, 11688673.7, 4139145.6, 0.06),
+        (orc.make_proj(orc.PROJ_LCC, a=1.0, es=0.0, lat0=23, lon0=-96, lat1=33, lat2=45),
+         '+proj=lcc +lat_1=33 +lat_2=45 +lat_0=23 +lon_0=-96 +R=1', 0.2966785, 0.2462112, 6e-8),
+        (orc.make_proj(orc.PROJ_MERC, a=1.0, es=0.0, lon0=-180, lat_ts=0.0), '+proj=merc +lon_0=-180 +R=1', 1.8325957, 0.6528366, 6e-8),
+    ]
+    for op, proj4, x_want, y_want, tol in cases:
+        x, y = orc.proj_fwd(op, -75.0, 35.0)
+        assert abs(x[0] - x_want) < tol and abs(y[0] - y_want) < tol, (proj4, x, y)
+        lon, lat = orc.proj_inv(op, x, y)
+        assert abs(lon[0] + 75.0) < 1e-12 and abs(lat[0] - 35.0) < 1e-12
+        hx, hy = Proj(proj4)(-75.0, 35.0)
+        assert abs(hx - x[0]) < 1e-6 * max(1.0, abs(x_want) * 1e-6) and abs(hy - y[0]) < 1e-6 * max(1.0, abs(y_want) * 1e-6)
+        hl, hp = Proj(proj4)(hx, hy, inverse=True)
+        assert abs(hl + 75.0) < 1e-10 and abs(hp - 35.0) < 1e-10
