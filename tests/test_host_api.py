@@ -64,8 +64,10 @@ def test_reader_surface():
     assert gr.covers_time(times[2]) and not gr.covers_time(times[2] + timedelta(seconds=1))
     p = projection.parse_proj4(synthetic.NORKYST_PROJ4)
     assert p['kind'] == 'stere_polar' and p['lat_ts'] == 60 and p['lon0'] == 70 and abs(p['rf'] - 298.257223563) < 1e-9
+    q = projection.parse_proj4('+proj=lcc +lat_1=49.5 +lon_0=10 +R=6371000')     # tangent cone: lat_0 = lat_2 = lat_1
+    assert q['kind'] == 'lcc' and q['lat1'] == q['lat2'] == q['lat0'] == 49.5 and q['rf'] == 0.0
     with pytest.raises(NotImplementedError):
-        projection.parse_proj4('+proj=lcc +lat_1=49.5')
+        projection.parse_proj4('+proj=ob_tran +o_proj=longlat +o_lat_p=22 +lon_0=-40')
 
 
 def test_openoil_host_interface():
