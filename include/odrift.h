@@ -194,6 +194,11 @@ int odr_source_time_coverage(odr_ctx *ctx, int32_t source_id, double t_start_epo
  * monotonic in ID; elements outside the reader's coverage are counted, unlike in the reference).  Sampled by the generic
  * kernels; ocean_vertical_diffusivity profiles cannot be ensemble data. */
 int odr_source_set_members(odr_ctx *ctx, int32_t source_id, int32_t var, int32_t members);
+/* Ensemble data hands element number j OF THE CALL member j % M (readers/interpolation/structured.py:119-135): j is the rank
+ * of the element among the present ones in ascending ID.  A particle set that holds only a contiguous ID range of a larger
+ * simulation (one rank of a sharded run) adds the number of present elements with smaller IDs held elsewhere; the host
+ * knows it from the step's collective.  Default 0. */
+int odr_particles_set_rank_offset(odr_ctx *ctx, odr_particles *p, int64_t offset);
 /* priority list + fallback of one variable (environment.py:592-595,782-791); NaN = no fallback */
 int odr_env_bind(odr_ctx *ctx, int32_t var_id, int nsources, const int32_t *source_ids,
                  float fallback);

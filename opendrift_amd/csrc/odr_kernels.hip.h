@@ -1935,11 +1935,11 @@ __global__ __launch_bounds__(BLOCK) void k_rank_count(const unsigned *words, lon
   if (w < nw) cnt[w] = (unsigned)__popc(words[w]);
 }
 __global__ __launch_bounds__(BLOCK) void k_rank_assign(const int *id, long long n, const unsigned *words, const unsigned *before,
-                                                       int *rank) {
+                                                       int *rank, int offset) {
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const unsigned v = (unsigned)id[i], w = v >> 5, bit = v & 31u;
-  rank[i] = (int)(before[w] + (unsigned)__popc(words[w] & ((1u << bit) - 1u)));
+  rank[i] = offset + (int)(before[w] + (unsigned)__popc(words[w] & ((1u << bit) - 1u)));
 }
 
 // Grid-stride over the 256-element chunks: the per-chunk counts feed the scan; the grand total is ONE atomic per

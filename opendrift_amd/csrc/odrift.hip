@@ -1254,9 +1254,16 @@ int odr_i_ensure_ranks(odr_ctx *c, odr_particles *p) {
   hipLaunchKernelGGL(k_cmp_scan, dim3(1), dim3(1024), 0, c->stream, p->rank_bsum, (long long)nsb, c->counter + 3);
   hipLaunchKernelGGL(k_scan_add, dim3(nsb), dim3(1024), 0, c->stream, p->rank_before, nw, p->rank_bsum);
   hipLaunchKernelGGL(k_rank_assign, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->i32[0], p->n, p->rank_words, p->rank_before,
-                     p->rank);
+                     p->rank, (int)p->rank_offset);
   HIPCHK(hipGetLastError());
   p->rank_on = 1;
+  return 0;
+}
+
+int odr_particles_set_rank_offset(odr_ctx *c, odr_particles *p, int64_t offset) {
+  (void)c;
+  REQUIRE(p && offset >= 0 && offset < (1ll << 30), "bad rank offset");
+  p->rank_offset = offset;
   return 0;
 }
 

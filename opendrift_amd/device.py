@@ -190,6 +190,14 @@ class Context:
             out[k] = v
         return out
 
+    def declare_members(self, sid, variable, members):
+        """The variable of this source arrives as `members` ensemble members stacked along the layer axis (what
+        _ensemble_arrays does for a list of member arrays; a sharded run receives the stack itself)."""
+        known = self._grids[sid].setdefault('members', {})
+        if known.get(variable) != members:
+            check(self.lib.odr_source_set_members(self.h, sid, _vid(variable), int(members)))
+            known[variable] = members
+
     def upload_block(self, sid, slot, t_epoch, arrays):
         """arrays: {variable: float32 [ny,nx] or [nz,ny,nx], or a list of such arrays (ensemble members)} -- one
         ReaderBlock / time level."""
@@ -463,6 +471,11 @@ class Particles:
                                             seeded_on_land_code, int(bool(store_previous)), s, float(dt),
                                             float(factor), ex, C.byref(n) if count else None))
         return n.value if count else None
+
+    def set_rank_offset(self, offset):
+        """Present elements with smaller IDs held by other particle sets (the lower ranks of a sharded run): added to the
+        rank among the present elements that selects the ensemble member (odr_particles_set_rank_offset)."""
+        check(self.lib.odr_particles_set_rank_offset(self.ctx.h, self.h, int(offset)))
 
     def update_positions(self, x_vel, y_vel, dt):
         n = len(self)

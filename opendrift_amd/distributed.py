@@ -160,12 +160,20 @@ def broadcast_reader_block(block_or_none, variables, src=0, error=None, shapes=N
     meta, arrays = None, None
     if rank == src and error is None:
         b = block_or_none
-        arrays = {v: np.ascontiguousarray(np.ma.filled(b[v], np.nan) if isinstance(b[v], np.ma.MaskedArray) else b[v],
-                                          dtype=np.float32) for v in variables}
+        def one(a):
+            return np.ascontiguousarray(np.ma.filled(a, np.nan) if isinstance(a, np.ma.MaskedArray) else a, dtype=np.float32)
+        arrays, members = {}, {}
+        for v in variables:
+            if isinstance(b[v], (list, tuple)):     # ensemble members: stacked along the layer axis, [members x nz, ny, nx]
+                m = np.stack([one(a) for a in b[v]])
+                arrays[v], members[v] = np.ascontiguousarray(m.reshape((-1,) + m.shape[-2:])), len(b[v])
+            else:
+                arrays[v] = one(b[v])
         if shapes is None:
             meta = {k: (np.asarray(b[k]) if k in ('x', 'y', 'z') and b.get(k) is not None else b.get(k))
                     for k in ('x', 'y', 'z', 'time', 's_level_variables') if k in b}
             meta['__shapes__'] = {v: tuple(a.shape) for v, a in arrays.items()}
+            meta['__members__'] = members
     if world > 1:
         ok = allreduce_scalars([0.0 if (rank == src and error is not None) else 1.0], 'min')[0]
         if ok < 1:

@@ -531,6 +531,11 @@ class OpenDriftSimulation(Configurable):
             self._newly_any = rel > 0
             self._g_active = self._g_active_carry + rel
             self._g_active_carry = self._g_active
+            # present elements on the lower ranks (all their IDs are smaller): what the last collective left + their releases
+            # of this step -- the offset of this rank's elements in the all-rank array whose positions select the ensemble
+            # member (readers/interpolation/structured.py:119-135)
+            self._below_active += int(self._g_release_below[step])
+            self.P.set_rank_offset(self._below_active)
             return self._g_active, int(self._n_global - self._g_release_cum[step + 1])
         from . import distributed as D
         self._timing_collectives += 1
@@ -558,6 +563,7 @@ class OpenDriftSimulation(Configurable):
             self._step_red = D.combine_rows(rows[:, 9:])
             self.P.reduce_install(self._step_red)
         self._g_active = self._g_active_carry = g_kept
+        self._below_active = int(round(rows[:self._rank, 0].sum()))
         return g_kept, g_flags
 
     def _step_release(self):
@@ -944,7 +950,7 @@ class OpenDriftSimulation(Configurable):
         lo_id, hi_id = 0, n_total
         self._n_global = n_total
         self._g_release = self._g_release_cum = None
-        self._g_active_carry = 0
+        self._g_active_carry = self._below_active = 0
         self._timing_collectives, self._timing_collective_s, self._step_red = 0, 0.0, None
         if self._world > 1:     # this rank's contiguous range of element IDs; the others are never released here
             from . import distributed as D
@@ -960,6 +966,7 @@ class OpenDriftSimulation(Configurable):
             ok = (k >= 0) & (k < steps)
             self._g_release = np.bincount(k[ok], minlength=steps)
             self._g_release_cum = np.concatenate([[0], np.cumsum(self._g_release)])
+            self._g_release_below = np.bincount(k[:lo_id][ok[:lo_id]], minlength=steps)
             self._sched = {kk: v[lo_id:hi_id] for kk, v in self._sched.items()}
             for attr in ('_released', '_n_unreleased', '_t_sched'):
                 if hasattr(self, attr):
@@ -1023,7 +1030,12 @@ class OpenDriftSimulation(Configurable):
                         (i % self.sort_every == 0 or self.newly_seeded * 20 > n_act):
                     self.P.sort_by_cell(grid_sid, keep_environment=False)   # the step's sample follows
                 one_collective = False
-                if fused_lane:
+                # ensemble data in a sharded run: the stage calls of advect_ocean_current take the member by the rank among
+                # the elements that are STILL active after this step's coastline / seafloor deactivations on ALL ranks --
+                # known only from the step's collective, which the call-by-call lane makes between the two
+                ens_sharded = self._world > 1 and any(
+                    b.sid is not None and self.ctx._grids.get(b.sid, {}).get('members') for b in self.readers.values())
+                if fused_lane and not ens_sharded:
                     # ONE launch for get_environment + coastline + seafloor + update_previous_state +
                     # advect_ocean_current (odr_env_coast_advect).  deactivate_outside only reads positions and goes
                     # first; the result buffer is written afterwards from the saved pre-advection position.
@@ -1067,6 +1079,7 @@ class OpenDriftSimulation(Configurable):
                     if one_collective:      # sharded: the step's ONE collective, as in the fused lane
                         kept, flags = self.P.scan_status()
                         kept, flags = self._step_summary(kept, flags, self._needs_reductions())
+                        self.P.set_rank_offset(self._below_active)     # (ensemble members of the stage calls, see above)
                         self._resolve_status(flags)
                     else:
                         self._resolve_status()
@@ -1079,7 +1092,7 @@ class OpenDriftSimulation(Configurable):
                         self._resolve_status()
                         self.P.compact()
                     self.P.store_previous()
-                if self._world > 1 and (fused_lane or one_collective):
+                if self._world > 1 and ((fused_lane and not ens_sharded) or one_collective):
                     g_active = self._g_active           # from this step's collective
                 elif self._world > 1:
                     newly = self._newly_any

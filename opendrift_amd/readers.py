@@ -570,8 +570,6 @@ class DeviceReaderBinding:
         if self.rank == 0:
             try:
                 block = r.get_variables(self.variables, time, x, y, np.array([0.0]))
-                if any(isinstance(block[v], (list, tuple)) for v in self.variables):
-                    raise NotImplementedError('ensemble data (lists of member arrays) in a sharded run')
             except Exception as e:      # noqa: BLE001 -- every reader exception is a reader failure (environment.py:640-668)
                 err = e
         shapes = getattr(self, '_dist_shapes', None)
@@ -631,6 +629,7 @@ class DeviceReaderBinding:
                 meta, tens, _ = self._read_and_broadcast(k, x, y, async_op=False)
             self.stall_s += _time.perf_counter() - t_wait
             if meta is not None:
+                self._dist_members = meta.pop('__members__', {})   # ensemble variables arrive as [members x nz, ny, nx] stacks
                 self._dist_meta = meta
             block = dict(self._dist_meta)
             block['time'] = time
@@ -711,6 +710,8 @@ class DeviceReaderBinding:
                     nzv.setdefault(v, block[v].shape[0] if len(block[v].shape) == 3 else 1)
             self.ctx.upload_block_device(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays, nzv)
         elif self.world > 1:
+            for v, m in getattr(self, '_dist_members', {}).items():
+                self.ctx.declare_members(self.sid, v, m)
             arrays = {v: _dev(block[v]) for v in self.variables}
             nzv = {v: (block[v].shape[0] if len(block[v].shape) == 3 else 1) for v in self.variables}
             self.ctx.upload_block_device(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays, nzv)

@@ -50,6 +50,22 @@ def main():
         z[: n // 4] = 0.0
         o.seed_elements(lon=lon, lat=lat, z=z, time=[T0, T0 + timedelta(seconds=1800)], wind_drift_factor=0.03)
         o.run(time_step=600, steps=9)
+    elif scenario == 'ensemble':
+        # a reader whose current comes as a LIST of member arrays: element j of the all-rank array of present elements
+        # takes member j % 3 (readers/interpolation/structured.py:119-135); stranding and two release times shift the ranks
+        g = np.load(os.path.join(gold, 'c17_ensemble_reader.npz'))
+        times = [T0 + timedelta(seconds=float(t)) for t in g['2d_g_t']]
+        arrays = {'x_sea_water_velocity': [g['2d_g_u%d' % m] for m in range(3)], 'y_sea_water_velocity': [g['2d_g_v%d' % m] for m in range(3)],
+                  'land_binary_mask': g['2d_g_land_binary_mask']}
+        o = OceanDrift(loglevel=50, seed=0)
+        o.add_reader(readers.GridReader(g['2d_g_x'], g['2d_g_y'], times, arrays))
+        o.set_config('drift:advection_scheme', 'runge-kutta4')
+        o.set_config('general:coastline_action', 'stranding')
+        n = 3000
+        rng = np.random.default_rng(5)
+        o.seed_elements(lon=rng.uniform(4.4, 5.34, n), lat=rng.uniform(59.3, 60.7, n), time=[T0, T0 + timedelta(seconds=2700)],
+                        wind_drift_factor=0.0)
+        o.run(time_step=900, steps=8)
     else:
         # OpenOil: np.mean(dV_50) and np.mean(1.5 Hs) over all elements, wave entrainment, default uncertainties
         g = np.load(os.path.join(gold, 'c9_openoil_mixing.npz'))
