@@ -76,11 +76,14 @@ class Leeway(OpenDriftSimulation):
             orientation = np.r_[:number] % 2          # odd numbered particles are left-drifting (:318-320)
             ones = np.ones(number)
             downwind_slope, downwind_offset = ones * c['DWSLOPE'], ones * c['DWOFFSET']
-            epsdw = np.zeros(number)
-            for i in range(number):                   # avoid negative downwind slopes (:331-339)
-                epsdw[i] = np.random.randn(1)[0] * c['DWSTD']
-                while downwind_slope[i] + epsdw[i] / 20.0 < 0.0:
-                    epsdw[i] = np.random.randn(1)[0] * c['DWSTD']
+            # avoid negative downwind slopes (:331-339): the reference draws randn(1) element by element and draws again
+            # while slope + eps / 20 < 0.  The slope is the same for every element, so the elements take, in order, the
+            # draws of the stream that pass -- whole batches of the legacy generator (randn(n) continues the stream exactly
+            # like n calls of randn(1)), the shortfall drawn again, never past the last draw the loop would have made
+            epsdw = np.empty(0)
+            while len(epsdw) < number:
+                e = np.random.randn(number - len(epsdw)) * c['DWSTD']
+                epsdw = np.concatenate([epsdw, e[~(c['DWSLOPE'] + e / 20.0 < 0.0)]])
             rcw = np.random.randn(number)
             crosswind_slope = np.where(orientation == RIGHT, c['CWRSLOPE'], c['CWLSLOPE'])
             crosswind_offset = np.where(orientation == RIGHT, c['CWROFFSET'], c['CWLOFFSET'])

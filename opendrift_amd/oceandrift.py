@@ -145,6 +145,13 @@ class OpenDriftSimulation(Configurable):
 
     def set_config(self, key, value):
         self._require('Config')
+        if key == 'vertical_mixing:TSprofiles':
+            # (oceandrift.py:146,461-477).  Not implemented, on purpose: in the reference the temperature profiles reach
+            # update_terminal_velocity in Celsius and have 273.15 subtracted again -- there is no sound
+            # behaviour to be identical to.  False (the default) is accepted, True fails loudly.
+            if value:
+                raise NotImplementedError('vertical_mixing:TSprofiles is not implemented (DESIGN.md section 7)')
+            return
         super().set_config(key, value)
 
     # ------------------------------------------------------------------ readers (:613-632)

@@ -168,3 +168,30 @@ def test_grid_reader_hands_out_ensemble_members_as_a_list():
     assert isinstance(b['x_sea_water_velocity'], list) and len(b['x_sea_water_velocity']) == 3
     assert all(m.shape == b['land_binary_mask'].shape == (len(b['y']), len(b['x'])) for m in b['x_sea_water_velocity'])
     assert len(b['x']) < 10 and b['x_sea_water_velocity'][2][0, 0] == 2.0 + b['x'][0]
+
+
+def test_tsprofiles_is_refused_loudly_and_leeway_seeding_keeps_the_random_stream():
+    """vertical_mixing:TSprofiles = True is not implemented and says so; Leeway.seed_elements draws the
+    downwind perturbations in batches that consume np.random exactly like the reference's element-by-element loop with
+    rejection (leeway.py:331-339): same values, same generator state afterwards."""
+    from opendrift_amd.oceandrift import OceanDrift
+    from opendrift_amd.leeway import Leeway
+    o = OceanDrift(loglevel=50)
+    o.set_config('vertical_mixing:TSprofiles', False)
+    with pytest.raises(NotImplementedError):
+        o.set_config('vertical_mixing:TSprofiles', True)
+    c = dict(DWSLOPE=0.05, DWOFFSET=1.0, DWSTD=12.0, CWRSLOPE=0.5, CWROFFSET=1.0, CWRSTD=5.0, CWLSLOPE=-0.5, CWLOFFSET=-1.0, CWLSTD=5.0)
+    n = 4001
+    np.random.seed(7)
+    want = np.zeros(n)
+    for i in range(n):
+        want[i] = np.random.randn(1)[0] * c['DWSTD']
+        while c['DWSLOPE'] + want[i] / 20.0 < 0.0:
+            want[i] = np.random.randn(1)[0] * c['DWSTD']
+    rcw, tail = np.random.randn(n), np.random.randn(2)
+    lw = Leeway(loglevel=50)
+    np.random.seed(7)
+    lw.seed_elements(lon=np.full(n, 4.0), lat=np.full(n, 60.0), time=datetime(2020, 1, 1), leeway_coefficients=c)
+    assert np.array_equal(lw._sched['downwind_eps'], want.astype(np.float32))
+    assert (want != np.random.RandomState(7).randn(n) * c['DWSTD']).any()          # some draws were rejected
+    assert np.array_equal(np.random.randn(2), tail)
