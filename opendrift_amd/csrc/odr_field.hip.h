@@ -199,12 +199,25 @@ __device__ __forceinline__ void curvi_locate(const DevProj &p, double lon, doubl
   }
 }
 
+// ELLPOLAR: the caller knows the projection to be the polar stereographic one on an ellipsoid (the kernels instantiated
+// for PROJ_STERE_POLAR: the host sends spherical polar readers to the generic instantiation) -- no code, and no registers,
+// for the other kinds (k_step_grid<RK4, polar> held 39 700 VALU instructions / 215 VGPRs with them)
+template <bool ELLPOLAR = false>
 __device__ __forceinline__ void proj_fwd(const DevProj &p, double lon_deg, double lat_deg,
                                          double &x, double &y) {
 #pragma clang fp contract(fast)
-  if (p.kind == PROJ_LATLONG) { x = lon_deg; y = lat_deg; return; }
+  if (!ELLPOLAR && p.kind == PROJ_LATLONG) { x = lon_deg; y = lat_deg; return; }
   double lam = wrap_pi(lon_deg * kDeg - p.lon0), phi = lat_deg * kDeg;
   double sinlam, coslam, sinphi, cosphi, X, Y;
+  if (ELLPOLAR) {
+    sincos(lam, &sinlam, &coslam);
+    sinphi = sin(phi);
+    if (p.south) { phi = -phi; coslam = -coslam; sinphi = -sinphi; }
+    const double rho = fabs(phi - kHalfPi) < 1e-15 ? 0.0 : p.akm1 * tsfn(phi, sinphi, p.e);
+    x = p.a * (rho * sinlam) + p.x0;
+    y = p.a * (-rho * coslam) + p.y0;
+    return;
+  }
   if (p.kind == PROJ_MERC) {        // Snyder 7-6 / 7-7 (sphere: e = 0)
     x = p.a * (p.k0 * lam) + p.x0;
     y = p.a * (-p.k0 * log(tsfn(phi, sin(phi), p.e))) + p.y0;
@@ -250,12 +263,13 @@ __device__ __forceinline__ ProjStart proj_start(const DevProj &p, double lon_deg
   sincos(o.phi, &o.sp, &o.cp);
   return o;
 }
+template <bool ELLPOLAR = false>
 __device__ __forceinline__ void proj_fwd_near(const DevProj &p, const ProjStart &o, double lon_deg, double lat_deg,
                                               double &x, double &y) {
 #pragma clang fp contract(fast)
   const double lam = wrap_pi(lon_deg * kDeg - p.lon0), phi0 = lat_deg * kDeg;
   const double dl = lam - o.lam, dp = phi0 - o.phi;
-  if (!(o.ok && fabs(dl) < 8e-3 && fabs(dp) < 8e-3)) { proj_fwd(p, lon_deg, lat_deg, x, y); return; }
+  if (!(o.ok && fabs(dl) < 8e-3 && fabs(dp) < 8e-3)) { proj_fwd<ELLPOLAR>(p, lon_deg, lat_deg, x, y); return; }
   const double l2 = dl * dl, p2 = dp * dp;
   const double sdl = dl * (1 - l2 * (1.0 / 6) * (1 - l2 * (1.0 / 20) * (1 - l2 * (1.0 / 42))));
   const double cdl = 1 - l2 * 0.5 * (1 - l2 * (1.0 / 12) * (1 - l2 * (1.0 / 30) * (1 - l2 * (1.0 / 56))));
@@ -403,9 +417,10 @@ __device__ __forceinline__ double rotation_angle(const DevProj &p, double x, dou
 // both atans have arguments ~1e-6 (10 m over the earth radius -> Gregory series), sin/cos of chi_m are
 // rational in t_m, sin/cos of the multiples by recurrence, and the geodetic mid latitude is
 // chi_m + delta with |delta| < 3.4e-3 (angle-addition with a short Taylor series).
+template <bool ELLPOLAR = false>
 __device__ __forceinline__ void rotation_cs(const DevProj &p, double x, double y, double &cs, double &sn) {
 #pragma clang fp contract(fast)
-  if (!(p.kind == PROJ_STERE_POLAR && p.es != 0)) {
+  if (!ELLPOLAR && !(p.kind == PROJ_STERE_POLAR && p.es != 0)) {
     double rot = rotation_angle(p, x, y);
     sincos(rot, &sn, &cs);
     return;
@@ -987,9 +1002,9 @@ __device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBloc
   if (PROJ == PROJ_LATLONG) { x = lon; y = lat; }
   else if (PROJ == PROJ_CURVILINEAR) curvi_locate(s.proj, lon, lat, x, y);
 #ifndef ODR_FULL_STAGE_PROJECTION
-  else if (ps.ok) proj_fwd_near(s.proj, ps, lon, lat, x, y);   // (by value: a pointer would pin the struct to scratch memory)
+  else if (ps.ok) proj_fwd_near<PROJ == PROJ_STERE_POLAR>(s.proj, ps, lon, lat, x, y);   // (by value: a pointer would pin the struct to scratch memory)
 #endif
-  else proj_fwd(s.proj, lon, lat, x, y);
+  else proj_fwd<PROJ == PROJ_STERE_POLAR>(s.proj, lon, lat, x, y);
   double xchk = x;
   if (PROJ == PROJ_LATLONG) {
     if (s.lon_mode == 1) xchk = np_mod(x + 180.0, 360.0) - 180.0;
@@ -1094,7 +1109,7 @@ __device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBloc
 #endif
     if (ODR_PROJ_ROTATES(PROJ)) {
       double sn, cs;
-      rotation_cs(s.proj, x, y, cs, sn);
+      rotation_cs<PROJ == PROJ_STERE_POLAR>(s.proj, x, y, cs, sn);
       double uu = u, vv = v;
       u = __dsub_rn(__dmul_rn(uu, cs), __dmul_rn(vv, sn));
       v = __dadd_rn(__dmul_rn(uu, sn), __dmul_rn(vv, cs));
@@ -1124,8 +1139,8 @@ __device__ __forceinline__ void uv_sample_stage_f32(const DevSource &s, const De
   double x, y;
   if (PROJ == PROJ_LATLONG) { x = lon; y = lat; }
   else if (PROJ == PROJ_CURVILINEAR) curvi_locate(s.proj, lon, lat, x, y);
-  else if (ps.ok) proj_fwd_near(s.proj, ps, lon, lat, x, y);
-  else proj_fwd(s.proj, lon, lat, x, y);
+  else if (ps.ok) proj_fwd_near<PROJ == PROJ_STERE_POLAR>(s.proj, ps, lon, lat, x, y);
+  else proj_fwd<PROJ == PROJ_STERE_POLAR>(s.proj, lon, lat, x, y);
   double xchk = x;
   if (PROJ == PROJ_LATLONG) {
     if (s.lon_mode == 1) xchk = np_mod(x + 180.0, 360.0) - 180.0;
@@ -1176,7 +1191,7 @@ __device__ __forceinline__ void uv_sample_stage_f32(const DevSource &s, const De
     fu = r.x; fv = r.y;
     if (ODR_PROJ_ROTATES(PROJ)) {
       double sn, cs;
-      rotation_cs(s.proj, x, y, cs, sn);
+      rotation_cs<PROJ == PROJ_STERE_POLAR>(s.proj, x, y, cs, sn);
       const float c = (float)cs, n = (float)sn, uu = fu, vv = fv;
       fu = uu * c - vv * n;
       fv = uu * n + vv * c;
@@ -1332,7 +1347,7 @@ __device__ __forceinline__ void env_burst(const DevSource &s, const EnvGroupDesc
   const int kA = G.bs[0], kB = G.bs[1], kC = G.bs[2], kD = G.bs[3], kL = G.bs[4];
   const int mA = G.ps_mode[0], mB = G.ps_mode[1], mC = G.ps_mode[2];
   double cs = 1, sn = 0;
-  if (ODR_PROJ_ROTATES(PROJ) && G.rotates) rotation_cs(s.proj, x, y, cs, sn);
+  if (ODR_PROJ_ROTATES(PROJ) && G.rotates) rotation_cs<PROJ == PROJ_STERE_POLAR>(s.proj, x, y, cs, sn);
   const int temp_mask = G.temp_mask;
   auto finish = [&](int k, double v) {      // masked_invalid(...).astype('float32'), fallback, Kelvin -> Celsius
     float f = (float)v;
@@ -1420,7 +1435,7 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
   double x, y;
   if (PROJ == PROJ_LATLONG) { x = lon; y = lat; }
   else if (PROJ == PROJ_CURVILINEAR) curvi_locate(s.proj, lon, lat, x, y);
-  else proj_fwd(s.proj, lon, lat, x, y);
+  else proj_fwd<PROJ == PROJ_STERE_POLAR>(s.proj, lon, lat, x, y);
   double xchk = x;
   if (PROJ == PROJ_LATLONG) {
     if (s.lon_mode == 1) xchk = np_mod(x + 180.0, 360.0) - 180.0;
@@ -1503,7 +1518,7 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
       for (int k = 0; k < MAXG; ++k) if (k < G.nv && G.partner[k] >= 0) need = true;
       if (need) {
         double sn, cs;
-        rotation_cs(s.proj, x, y, cs, sn);
+        rotation_cs<PROJ == PROJ_STERE_POLAR>(s.proj, x, y, cs, sn);
 #pragma unroll
         for (int k = 0; k + 1 < MAXG; ++k) {  // the host places the y-component right after its x-component
           if (k >= G.nv || G.partner[k] < 0) continue;

@@ -277,6 +277,13 @@ static inline bool any_members(const odr_ctx *c) {
   for (int k = 0; k < c->nsrc; ++k) if (c->hw.src[k].kind == SRC_GRID && source_has_members(c->hw.src[k])) return true;
   return false;
 }
+// which instantiation of the kernels templated on the projection serves a reader: the PROJ_STERE_POLAR one assumes an
+// ellipsoid (proj_fwd<true>, rotation_cs<true>: closed forms only); a spherical polar reader, Mercator, Lambert ... take the
+// PROJ_STERE_EQUIT_SPHERE instantiation, whose projection functions switch on DevProj::kind at run time
+static inline int odr_proj_template(const odr::DevProj &p) {
+  if (p.kind == odr::PROJ_STERE_POLAR) return p.es != 0 ? odr::PROJ_STERE_POLAR : odr::PROJ_STERE_EQUIT_SPHERE;
+  return p.kind;
+}
 int odr_i_ensure_ranks(odr_ctx *c, odr_particles *p);
 
 // defined in odrift.hip

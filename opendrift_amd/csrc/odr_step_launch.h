@@ -14,7 +14,7 @@ static void launch_advect_grid(odr_ctx *c, odr_particles *p, int sid, double t, 
   PView v = view(p);
   float f = (float)factor;
 #define ODR_LAUNCH(PROJ, D3) hipLaunchKernelGGL((k_advect_grid<SCHEME, PROJ, D3, NOISE, SM>), g, b, 0, c->stream, c->dw, sid, geo, v, dt, f, th, tf, N)
-  switch (s.proj.kind) {
+  switch (odr_proj_template(s.proj)) {
     case PROJ_LATLONG: if (is3d) ODR_LAUNCH(PROJ_LATLONG, true); else ODR_LAUNCH(PROJ_LATLONG, false); break;
     case PROJ_STERE_POLAR: if (is3d) ODR_LAUNCH(PROJ_STERE_POLAR, true); else ODR_LAUNCH(PROJ_STERE_POLAR, false); break;
     case PROJ_CURVILINEAR: if (is3d) ODR_LAUNCH(PROJ_CURVILINEAR, true); else ODR_LAUNCH(PROJ_CURVILINEAR, false); break;
@@ -80,7 +80,7 @@ static void launch_step_grid(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G
   const int tile_nodes = 160;
   const size_t tile_bytes = (size_t)tile_nodes * 2 * (size_t)nzu * 8;
   const char *tile_min = getenv("ODR_LDS_TILE_MIN_N");     // tests lower the threshold to exercise the tile on small sets
-  const bool tile = SM == 0 && SCHEME > 0 && (s.proj.kind == PROJ_LATLONG || s.proj.kind == PROJ_STERE_POLAR) && tile_bytes <= 40 * 1024 && nzu <= 32 &&
+  const bool tile = SM == 0 && SCHEME > 0 && (s.proj.kind == PROJ_LATLONG || odr_proj_template(s.proj) == PROJ_STERE_POLAR) && tile_bytes <= 40 * 1024 && nzu <= 32 &&
                     p->n >= (tile_min ? atoll(tile_min) : 65536) && getenv("ODR_LDS_TILE") && !getenv("ODR_NO_LDS_TILE");
   // what-if runs: ODR_OCC_LDS=<bytes> of (unused) dynamic LDS per workgroup caps the workgroups per CU (160 KiB / bytes)
   static const size_t occ_lds = getenv("ODR_OCC_LDS") ? (size_t)atoll(getenv("ODR_OCC_LDS")) : 0;
@@ -91,7 +91,7 @@ static void launch_step_grid(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G
     else { if (is3d) ODR_LAUNCH_TILE(PROJ_STERE_POLAR, true); else ODR_LAUNCH_TILE(PROJ_STERE_POLAR, false); }
     return;
   }
-  switch (s.proj.kind) {
+  switch (odr_proj_template(s.proj)) {
     case PROJ_LATLONG: if (is3d) ODR_LAUNCH(PROJ_LATLONG, true); else ODR_LAUNCH(PROJ_LATLONG, false); break;
     case PROJ_STERE_POLAR: if (is3d) ODR_LAUNCH(PROJ_STERE_POLAR, true); else ODR_LAUNCH(PROJ_STERE_POLAR, false); break;
     case PROJ_CURVILINEAR: if (is3d) ODR_LAUNCH(PROJ_CURVILINEAR, true); else ODR_LAUNCH(PROJ_CURVILINEAR, false); break;

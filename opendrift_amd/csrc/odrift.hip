@@ -954,7 +954,7 @@ static bool launch_env_grid(odr_ctx *c, odr_particles *p, const int *grp, int ng
   dim3 g(nblk(p->n)), b(BLOCK);
   PView v = view(p);
   G = env_bind_out(G, v);
-  switch (s.proj.kind) {
+  switch (odr_proj_template(s.proj)) {
     case PROJ_LATLONG: hipLaunchKernelGGL(k_env_grid<PROJ_LATLONG>, g, b, 0, c->stream, c->dw, v, G, rec); break;
     case PROJ_STERE_POLAR: hipLaunchKernelGGL(k_env_grid<PROJ_STERE_POLAR>, g, b, 0, c->stream, c->dw, v, G, rec); break;
     case PROJ_CURVILINEAR: hipLaunchKernelGGL(k_env_grid<PROJ_CURVILINEAR>, g, b, 0, c->stream, c->dw, v, G, rec); break;
@@ -1405,7 +1405,7 @@ int odr_env_coast_leeway(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   dim3 g(nblk(p->n)), b(BLOCK);
   PView v = view(p);
   G = env_bind_out(G, v);
-  switch (s.proj.kind) {
+  switch (odr_proj_template(s.proj)) {
     case PROJ_LATLONG: hipLaunchKernelGGL(k_step_leeway<PROJ_LATLONG>, g, b, 0, c->stream, c->dw, v, G, S, dt, c->counter); break;
     case PROJ_STERE_POLAR: hipLaunchKernelGGL(k_step_leeway<PROJ_STERE_POLAR>, g, b, 0, c->stream, c->dw, v, G, S, dt, c->counter); break;
     case PROJ_CURVILINEAR: hipLaunchKernelGGL(k_step_leeway<PROJ_CURVILINEAR>, g, b, 0, c->stream, c->dw, v, G, S, dt, c->counter); break;
