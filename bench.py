@@ -112,8 +112,13 @@ class Workload:
             tens = D.broadcast_block(arrays, shapes=shapes, src=0)
             import torch
             torch.cuda.synchronize()
+            # (every rank builds the same synthetic arrays: the content ids -- which 2-D variables repeat from level to level,
+            # as a reader's sea floor depth and land mask do -- are assigned locally; a reader-owning rank would send them along)
+            from opendrift_amd.device import ContentIds
+            self._cids = getattr(self, '_cids', None) or ContentIds()
             ctx.upload_block_device(sid, slot, float(g['t'][slot]), {k: t.data_ptr() for k, t in tens.items()},
-                                    {k: (t.shape[0] if t.dim() == 3 else 1) for k, t in tens.items()})
+                                    {k: (t.shape[0] if t.dim() == 3 else 1) for k, t in tens.items()},
+                                    content_ids=self._cids.assign(fields['names'], {k: g[k][slot] for k in fields['names']}))
             del tens
         for k in fields['names']:
             ctx.bind(k, [sid], {LAND: np.nan, DEPTH: 10000.0}.get(k, 0.0))

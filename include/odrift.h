@@ -179,6 +179,12 @@ int odr_block_upload_async(odr_ctx *ctx, int32_t source_id, int32_t slot, double
                            const int32_t *var_ids, const void *const *data, const int32_t *var_nz,
                            int ny, int nx, const double *xy8);
 int odr_block_commit(odr_ctx *ctx, int32_t source_id, int32_t slot);
+/* Optional: content ids of variables of the level just uploaded (the staged level of the slot if there is one, else the
+ * resident one).  Two resident levels that carry the same non-zero id for a variable hold the same values for it -- the
+ * reference re-reads sea_floor_depth / land_binary_mask with every ReaderBlock (structured.py:15-94) -- and the samplers then
+ * gather that variable at one level only (the time interpolation keeps its arithmetic: same bits).  0 = unknown. */
+int odr_block_set_content_ids(odr_ctx *ctx, int32_t source_id, int32_t slot, int nvars, const int32_t *var_ids,
+                              const uint64_t *ids);
 int odr_host_register(odr_ctx *ctx, void *ptr, uint64_t bytes);   /* hipHostRegister: reader arrays that are uploaded repeatedly */
 int odr_host_unregister(odr_ctx *ctx, void *ptr);
 int odr_block_drop(odr_ctx *ctx, int32_t source_id, int32_t slot);

@@ -104,6 +104,7 @@ _SIGNATURES = {
     'odr_update_positions': [_vp, _vp, _dp, _dp, C.c_int, C.c_double],
     'odr_source_set_members': [_vp, C.c_int32, C.c_int32, C.c_int32],
     'odr_particles_set_rank_offset': [_vp, _vp, C.c_int64],
+    'odr_block_set_content_ids': [_vp, C.c_int32, C.c_int32, C.c_int, _P(C.c_int32), _P(C.c_uint64)],
     'odr_set_element_factor': [_vp, _vp, C.c_int],
     'odr_advect_sea_ice': [_vp, _vp, C.c_double, C.c_double],
     'odr_advect_wind': [_vp, _vp, C.c_double, C.c_double, C.c_int, C.c_double],

@@ -28,7 +28,7 @@ int odr_i_fail(int code, const char *fmt, ...);   // records the message for odr
   } while (0)
 #define REQUIRE(c, ...) do { if (!(c)) return fail(ODR_ERR_INVALID, __VA_ARGS__); } while (0)
 
-struct Staged { DevBlock blk; float *base; size_t bytes; };       // uploaded, not yet committed
+struct Staged { DevBlock blk; float *base; size_t bytes; unsigned long long cid[NVAR]; };   // uploaded, not yet committed (cid: odr_block_set_content_ids)
 struct Retired { void *ptr; size_t bytes; hipEvent_t ev; };       // replaced block, freed once the compute stream passed
 
 constexpr int ODR_MAX_LANES = 8;
@@ -41,6 +41,9 @@ struct odr_ctx {
   bool dirty;
   std::vector<void *> block_bufs[MAXSRC][MAXLEVELS];  // owned device arrays per slot
   size_t block_bytes[MAXSRC][MAXLEVELS];
+  // content id of each variable of a resident block (odr_block_set_content_ids; 0 = unknown): two time levels holding the
+  // same id for a variable hold the same values, and the samplers read it at one of them
+  unsigned long long block_cid[MAXSRC][MAXLEVELS][NVAR];
   // upload pipeline (stage_block / odr_block_commit)
   hipStream_t up_stream;
   hipEvent_t up_done, up_dep;

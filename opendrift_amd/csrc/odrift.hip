@@ -549,6 +549,7 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
   }
   DevBlock &b = S.blk;
   memset(&b, 0, sizeof b);
+  memset(S.cid, 0, sizeof S.cid);
   b.ny = ny; b.nx = nx; b.valid = 1;
   b.x0 = xy8[0]; b.xspan = xy8[1]; b.y0 = xy8[2]; b.yspan = xy8[3];
   b.xmin = xy8[4]; b.xrange = xy8[5]; b.ymin = xy8[6]; b.yrange = xy8[7];
@@ -749,11 +750,24 @@ int odr_block_commit(odr_ctx *c, int32_t sid, int32_t slot) {
     if ((rc = retire(c, c->block_bufs[sid][slot][k], c->block_bytes[sid][slot]))) return rc;
   c->block_bufs[sid][slot].clear();
   s.slot[slot] = S.blk;
+  memcpy(c->block_cid[sid][slot], S.cid, sizeof S.cid);
   c->block_bufs[sid][slot].push_back(S.base);
   c->block_bytes[sid][slot] = S.bytes;
   S.base = nullptr;
   sort_levels(s);
   c->dirty = true;
+  return 0;
+}
+
+int odr_block_set_content_ids(odr_ctx *c, int32_t sid, int32_t slot, int nvars, const int32_t *var_ids, const uint64_t *ids) {
+  REQUIRE(sid >= 0 && sid < c->nsrc && slot >= 0 && slot < MAXLEVELS, "bad source/slot");
+  REQUIRE(nvars >= 0 && (nvars == 0 || (var_ids && ids)), "bad arguments");
+  Staged &S = c->staged[sid][slot];
+  unsigned long long *dst = S.base ? S.cid : c->block_cid[sid][slot];   // the staged level if there is one, else the resident one
+  for (int k = 0; k < nvars; ++k) {
+    REQUIRE(var_ids[k] >= 0 && var_ids[k] < NVAR, "bad variable id %d", var_ids[k]);
+    dst[var_ids[k]] = ids[k];
+  }
   return 0;
 }
 
@@ -823,6 +837,7 @@ int odr_block_drop(odr_ctx *c, int32_t sid, int32_t slot) {
     c->staged[sid][slot].base = nullptr;
   }
   memset(&c->hw.src[sid].slot[slot], 0, sizeof(DevBlock));
+  memset(c->block_cid[sid][slot], 0, sizeof c->block_cid[sid][slot]);
   sort_levels(c->hw.src[sid]);
   c->dirty = true;
   return 0;
@@ -941,6 +956,12 @@ bool odr_i_build_env_group(const odr_ctx *c, const int *grp, int ng, double t, E
       G.ps_off[q] = k >= 0 ? G.off[k] * 4 : 0;
       G.ps_mode[q] = k >= 0 ? G.mode[k] : ENV_SKIP;
       G.ps_rot[q] = k >= 0 && G.partner[k] >= 0 ? 1 : 0;
+      // a 2-D variable whose two bracketing levels carry the same content id (sea floor depth, land mask: the reader hands
+      // out the same array every time) is gathered at ONE level; the time interpolation keeps its arithmetic
+      if (k >= 0 && ba && ia >= 0 && (G.mode[k] == ENV_S2 || G.mode[k] == ENV_LAND) && !getenv("ODR_NO_STATIC_SKIP")) {
+        const unsigned long long cb = c->block_cid[sid][ib][G.var[k]], ca = c->block_cid[sid][ia][G.var[k]];
+        if (cb != 0 && cb == ca) G.ps_static |= 1 << q;
+      }
     }
   }
   G.w = ia >= 0 ? (t - s.slot[ib].t) / (s.slot[ia].t - s.slot[ib].t) : 0.0;

@@ -60,6 +60,32 @@ def proj_desc(proj):
                          proj.get('lat1', 0.0), proj.get('lat2', proj.get('lat1', 0.0)))
 
 
+class ContentIds:
+    """Content ids of the 2-D variables of successive time levels of one reader (odr_block_set_content_ids): a variable
+    whose array EQUALS the one last seen for it keeps its id -- the reader re-reads the sea floor depth and the land mask
+    with every block (structured.py:15-94), and the samplers then gather such a variable at one of the two bracketing
+    levels.  Compared by value against a private copy (the caller may reuse its buffers).  3-D variables, ensemble lists and
+    device pointers get id 0 (unknown)."""
+    _counter = 0
+
+    def __init__(self):
+        self.last = {}
+
+    def assign(self, names, arrays):
+        out = {}
+        for k in names:
+            a = arrays.get(k) if hasattr(arrays, 'get') else None
+            if not isinstance(a, np.ndarray) or a.ndim != 2:
+                out[k] = 0
+                continue
+            prev = self.last.get(k)
+            if prev is None or prev[1].shape != a.shape or not np.array_equal(prev[1], a, equal_nan=True):
+                ContentIds._counter += 1
+                prev = self.last[k] = (ContentIds._counter, np.array(a, copy=True))
+            out[k] = prev[0]
+        return out
+
+
 def sea_water_density_default():
     """PhysicsMethods.sea_water_density() with its default arguments T=10., S=35. (physics_methods.py:574-608): the
     UNESCO 1983 one-atmosphere equation of state, a float64 constant of the oil formulae."""
@@ -198,6 +224,17 @@ class Context:
             check(self.lib.odr_source_set_members(self.h, sid, _vid(variable), int(members)))
             known[variable] = members
 
+    def _content_ids(self, sid, slot, names, host_arrays, given=None):
+        """odr_block_set_content_ids for the 2-D variables of a level: from `given` ({variable: id}, a level that arrived as
+        device pointers with ids assigned where the host arrays were) or by comparing the host arrays with the last upload
+        (ContentIds)."""
+        if given is None:
+            given = self._grids[sid].setdefault('content', ContentIds()).assign(names, host_arrays)
+        given = {k: v for k, v in given.items() if v}
+        if given:
+            (va, pv), ia = _i([_vid(k) for k in given]), np.asarray(list(given.values()), dtype=np.uint64)
+            check(self.lib.odr_block_set_content_ids(self.h, sid, slot, len(given), pv, ia.ctypes.data_as(C.POINTER(C.c_uint64))))
+
     def upload_block(self, sid, slot, t_epoch, arrays):
         """arrays: {variable: float32 [ny,nx] or [nz,ny,nx], or a list of such arrays (ensemble members)} -- one
         ReaderBlock / time level."""
@@ -214,10 +251,12 @@ class Context:
         xy8, px = _d(g['xy8'])
         check(self.lib.odr_block_upload(self.h, sid, slot, float(t_epoch), len(keep), pi, ptrs, pn, g['ny'],
                                         g['nx'], px))
+        self._content_ids(sid, slot, names, dict(zip(names, keep)))
 
-    def upload_block_device(self, sid, slot, t_epoch, dev_ptrs, var_nz):
+    def upload_block_device(self, sid, slot, t_epoch, dev_ptrs, var_nz, content_ids=None):
         """dev_ptrs: {variable: device pointer (int) of a float32 array already in HBM, or a host NumPy array};
-        var_nz: levels per variable (needed for the device pointers)."""
+        var_nz: levels per variable (needed for the device pointers); content_ids: {variable: id} assigned by
+        ContentIds.assign where the host arrays were (the rank that read the level)."""
         g = self._grids[sid]
         dev_ptrs = self._ensemble_arrays(sid, dev_ptrs)
         names = list(dev_ptrs)
@@ -229,6 +268,7 @@ class Context:
         xy8, px = _d(g['xy8'])
         check(self.lib.odr_block_upload_device(self.h, sid, slot, float(t_epoch), len(names), pi, ptrs, pn,
                                                g['ny'], g['nx'], px))
+        self._content_ids(sid, slot, names, keep, content_ids)
 
     def upload_block_async(self, sid, slot, t_epoch, arrays, var_nz=None):
         """Enqueue the upload of one time level on the upload stream and return (the simulation continues); the
@@ -244,6 +284,7 @@ class Context:
         ptrs = (C.c_void_p * len(names))(*[C.c_void_p(keep[k].ctypes.data if k in keep else int(arrays[k])) for k in names])
         xy8, px = _d(g['xy8'])
         check(self.lib.odr_block_upload_async(self.h, sid, slot, float(t_epoch), len(names), pi, ptrs, pn, g['ny'], g['nx'], px))
+        self._content_ids(sid, slot, names, keep)      # (on the staged level: it becomes the slot's with the commit)
         self._staged_refs = getattr(self, '_staged_refs', {})
         self._staged_refs[(sid, slot)] = keep
 

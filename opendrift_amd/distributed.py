@@ -145,7 +145,7 @@ class RemoteReaderError(RuntimeError):
     """The reader of the rank that reads failed: raised on EVERY rank, so that all of them count the failure alike."""
 
 
-def broadcast_reader_block(block_or_none, variables, src=0, error=None, shapes=None, async_op=False):
+def broadcast_reader_block(block_or_none, variables, src=0, error=None, shapes=None, async_op=False, content_ids=None):
     """One reader time level from the rank that runs the host Reader to every rank:
       * a one-number header (1 = the level follows, 0 = the reader failed: EVERY rank raises RemoteReaderError -- nobody is
         left waiting in a collective, and all ranks count the failure alike);
@@ -187,6 +187,15 @@ def broadcast_reader_block(block_or_none, variables, src=0, error=None, shapes=N
     if shapes is None:
         shapes = meta.pop('__shapes__')
     tens, works = start_broadcast_block(arrays, shapes, src)
+    # the content ids of the level's variables (device.ContentIds, assigned on `src` where the host arrays are) travel with it
+    import torch
+    ids = torch.zeros(len(variables), dtype=torch.int64)
+    if rank == src and content_ids:
+        ids = torch.tensor([int(content_ids.get(v, 0)) for v in variables], dtype=torch.int64)
+    ids = ids.to(_device())
+    if world > 1:
+        works.append(dist.broadcast(ids, src=src, async_op=True))
+    tens['__cid__'] = ids
     if not async_op:
         finish_broadcast(works)
         works = []

@@ -566,16 +566,20 @@ class DeviceReaderBinding:
         from . import distributed as D
         r = self.reader
         time = r.times[k] if r.times is not None else None
-        block, err = None, None
+        block, err, cids = None, None, None
         if self.rank == 0:
             try:
                 block = r.get_variables(self.variables, time, x, y, np.array([0.0]))
+                from .device import ContentIds
+                self._cids = getattr(self, '_cids', None) or ContentIds()
+                cids = self._cids.assign(self.variables, block)
             except Exception as e:      # noqa: BLE001 -- every reader exception is a reader failure (environment.py:640-668)
                 err = e
         shapes = getattr(self, '_dist_shapes', None)
-        meta, tens, works = D.broadcast_reader_block(block, self.variables, src=0, error=err, shapes=shapes, async_op=async_op)
+        meta, tens, works = D.broadcast_reader_block(block, self.variables, src=0, error=err, shapes=shapes, async_op=async_op,
+                                                     content_ids=cids)
         if shapes is None:
-            self._dist_shapes = {v: tuple(t.shape) for v, t in tens.items()}
+            self._dist_shapes = {v: tuple(t.shape) for v, t in tens.items() if v != '__cid__'}
         return meta, tens, works
 
     def _prefetch_dist(self, kn, extent):
@@ -633,6 +637,8 @@ class DeviceReaderBinding:
                 self._dist_meta = meta
             block = dict(self._dist_meta)
             block['time'] = time
+            cid_t = tens.pop('__cid__', None)
+            self._level_cids = None if cid_t is None else dict(zip(self.variables, [int(i) for i in cid_t.cpu().tolist()]))
             for v, t in tens.items():
                 block[v] = t if t.is_cuda else t.numpy()
             self._tensors = tens      # keep the device tensors alive until the block is built
@@ -714,7 +720,8 @@ class DeviceReaderBinding:
                 self.ctx.declare_members(self.sid, v, m)
             arrays = {v: _dev(block[v]) for v in self.variables}
             nzv = {v: (block[v].shape[0] if len(block[v].shape) == 3 else 1) for v in self.variables}
-            self.ctx.upload_block_device(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays, nzv)
+            self.ctx.upload_block_device(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays, nzv,
+                                         content_ids=getattr(self, '_level_cids', None))
             self._tensors = None
         else:
             arrays = {v: block[v] for v in self.variables}

@@ -83,8 +83,8 @@ def _combine_worker(rank, world, port, q):
     # a reader block read by rank 0 only
     blk = dict(x=np.arange(5, dtype=np.float32), y=np.arange(4, dtype=np.float32), z=None, time=None,
                u=np.arange(20, dtype=np.float32).reshape(4, 5)) if rank == 0 else None
-    meta, tens, works = D.broadcast_reader_block(blk, ['u'])
-    assert works == []
+    meta, tens, works = D.broadcast_reader_block(blk, ['u'], content_ids={'u': 7} if rank == 0 else None)
+    assert works == [] and tens['__cid__'].tolist() == [7]     # the level's content ids arrive with it (device.ContentIds)
     q.put((rank, got.tolist(), meta['x'].tolist(), tens['u'].numpy().tolist()))
     import torch.distributed as dist
     dist.destroy_process_group()

@@ -188,3 +188,39 @@ def test_tiled_block_preparation_equals_the_sweeps(ctx, monkeypatch, nx, ny, old
     for nm in names:
         assert _eq(res[0][nm], res[1][nm]), nm
     assert np.isnan(res[0][U]).any() and np.isfinite(res[0][U]).sum() > n // 2
+
+
+def test_variables_identical_at_both_time_levels_are_gathered_once(ctx, monkeypatch):
+    """odr_block_set_content_ids (Context.upload_block assigns the ids by comparing 2-D arrays with the last upload): sea floor
+    depth and land mask that the reader hands out unchanged with every block are read at ONE of the two bracketing levels
+    (G.ps_static) -- the same samples bit for bit as with the skip disabled; a depth that DOES change between the levels keeps
+    both gathers (and its time interpolation)."""
+    g = synth.grid3d(nx=64, ny=48, nz=6, nt=3, seed=2)
+    names = [U, V, W, DEPTH, LAND]
+    rng = np.random.default_rng(9)
+    n = 30000
+    lon, lat, zz = rng.uniform(g['x'][2], g['x'][-3], n), rng.uniform(g['y'][2], g['y'][-3], n), -rng.uniform(0, 40, n)
+    P = ctx.particles(n)
+    P.append(lon, lat, z=zz)
+    out = {}
+    for moving_floor in (False, True):
+        for skip in (True, False):
+            if skip:
+                monkeypatch.delenv('ODR_NO_STATIC_SKIP', raising=False)
+            else:
+                monkeypatch.setenv('ODR_NO_STATIC_SKIP', '1')
+            sid = ctx.add_grid(g['x'], g['y'], z=g['z'])
+            for k in range(3):
+                f = {nm: g[nm][k] for nm in names}
+                if moving_floor:
+                    f[DEPTH] = (g[DEPTH][k] + 7.0 * k).astype(np.float32)
+                ctx.upload_block(sid, k, float(g['t'][k]), f)
+            for nm in names:
+                ctx.bind(nm, [sid], np.nan)
+            out[moving_floor, skip] = P.env_sample(names, float(g['t'][0]) + 1234.5, download=True)
+    for mf in (False, True):
+        for nm in names:
+            assert _eq(out[mf, True][nm], out[mf, False][nm]), (mf, nm)
+    assert not _eq(out[False, True][DEPTH], out[True, True][DEPTH])
+    d = out[True, True][DEPTH] - out[False, True][DEPTH]
+    assert np.nanmax(np.abs(d - 7.0 * 1234.5 / 3600.0)) < 1e-3          # interpolated in time between the two floors
