@@ -100,10 +100,12 @@ class Workload:
         g = fields['g']
         sid = ctx.add_grid(g['x'], g['y'], z=fields['z'], proj=fields['proj'])
         self.sid = sid
+        names2d = [k for k in fields['names'] if g[k].ndim == 3 and all(np.array_equal(g[k][0], g[k][j]) for j in range(1, g[k].shape[0]))]
+        self.static_ids = {k: 1 + fields['names'].index(k) for k in names2d}
         for slot in range(3):
             if not via_torch:   # single process, no torch in it (tests/test_gpu_full_size.py): host arrays straight in
                 assert world == 1
-                ctx.upload_block(sid, slot, float(g['t'][slot]), {k: g[k][slot] for k in fields['names']})
+                ctx.upload_block(sid, slot, float(g['t'][slot]), {k: g[k][slot] for k in fields['names']}, content_ids=self.static_ids)
                 continue
             arrays = {k: g[k][slot] for k in fields['names']} if rank == 0 else None
             shapes = {k: g[k][slot].shape for k in fields['names']}
@@ -112,13 +114,11 @@ class Workload:
             tens = D.broadcast_block(arrays, shapes=shapes, src=0)
             import torch
             torch.cuda.synchronize()
-            # (every rank builds the same synthetic arrays: the content ids -- which 2-D variables repeat from level to level,
-            # as a reader's sea floor depth and land mask do -- are assigned locally; a reader-owning rank would send them along)
-            from opendrift_amd.device import ContentIds
-            self._cids = getattr(self, '_cids', None) or ContentIds()
+            # (the synthetic reader's sea floor depth and land mask are the same array at every level, as a file reader's are:
+            # declared with content ids, they are gathered at one of the two bracketing levels)
             ctx.upload_block_device(sid, slot, float(g['t'][slot]), {k: t.data_ptr() for k, t in tens.items()},
                                     {k: (t.shape[0] if t.dim() == 3 else 1) for k, t in tens.items()},
-                                    content_ids=self._cids.assign(fields['names'], {k: g[k][slot] for k in fields['names']}))
+                                    content_ids=self.static_ids)
             del tens
         for k in fields['names']:
             ctx.bind(k, [sid], {LAND: np.nan, DEPTH: 10000.0}.get(k, 0.0))
@@ -498,9 +498,10 @@ def main():
                     if k % block_every == 0:
                         if j > 0:
                             ctx.commit_block(wl.sid, (j - 1) % 3)
-                        ctx.upload_block_async(wl.sid, j % 3, float(g['t'][j % 3]), {kk: pinned[kk][j % 3] for kk in fields['names']})
+                        ctx.upload_block_async(wl.sid, j % 3, float(g['t'][j % 3]), {kk: pinned[kk][j % 3] for kk in fields['names']},
+                                               content_ids=wl.static_ids)
                 elif k % block_every == 0:
-                    ctx.upload_block(wl.sid, j % 3, float(g['t'][j % 3]), {kk: g[kk][j % 3] for kk in fields['names']})
+                    ctx.upload_block(wl.sid, j % 3, float(g['t'][j % 3]), {kk: g[kk][j % 3] for kk in fields['names']}, content_ids=wl.static_ids)
             wl.step(P, first + k)
         ctx.sync()
         torch.cuda.synchronize()
@@ -513,7 +514,7 @@ def main():
         for rep in range(2):
             for slot in range(3):
                 arrs = {kk: (pinned[kk][slot] if pinned else g[kk][slot]) for kk in fields['names']}
-                ctx.upload_block_async(wl.sid, slot, float(g['t'][slot]), arrs)
+                ctx.upload_block_async(wl.sid, slot, float(g['t'][slot]), arrs, content_ids=wl.static_ids)
                 ctx.commit_block(wl.sid, slot)
                 wl.step(P, a.warmup)
 

@@ -61,11 +61,12 @@ def proj_desc(proj):
 
 
 class ContentIds:
-    """Content ids of the 2-D variables of successive time levels of one reader (odr_block_set_content_ids): a variable
-    whose array EQUALS the one last seen for it keeps its id -- the reader re-reads the sea floor depth and the land mask
-    with every block (structured.py:15-94), and the samplers then gather such a variable at one of the two bracketing
-    levels.  Compared by value against a private copy (the caller may reuse its buffers).  3-D variables, ensemble lists and
-    device pointers get id 0 (unknown)."""
+    """Content ids of the 2-D variables of successive time levels of one reader (odr_block_set_content_ids) BY COMPARISON: a
+    variable whose array equals, bit for bit, the one last seen for it keeps its id -- the reader re-reads the sea floor
+    depth and the land mask with every block (structured.py:15-94), and the samplers then gather such a variable at one of
+    the two bracketing levels.  Compared against a private copy (the caller may reuse its buffers); costs a pass over the
+    array per level, so the reader bindings prefer a reader's own declaration (`static_variables`).  3-D variables,
+    ensemble lists and device pointers get id 0 (unknown)."""
     _counter = 0
 
     def __init__(self):
@@ -79,7 +80,8 @@ class ContentIds:
                 out[k] = 0
                 continue
             prev = self.last.get(k)
-            if prev is None or prev[1].shape != a.shape or not np.array_equal(prev[1], a, equal_nan=True):
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if prev is None or prev[1].shape != a.shape or not np.array_equal(prev[1].view(np.uint32), a.view(np.uint32)):
                 ContentIds._counter += 1
                 prev = self.last[k] = (ContentIds._counter, np.array(a, copy=True))
             out[k] = prev[0]
@@ -224,18 +226,17 @@ class Context:
             check(self.lib.odr_source_set_members(self.h, sid, _vid(variable), int(members)))
             known[variable] = members
 
-    def _content_ids(self, sid, slot, names, host_arrays, given=None):
-        """odr_block_set_content_ids for the 2-D variables of a level: from `given` ({variable: id}, a level that arrived as
-        device pointers with ids assigned where the host arrays were) or by comparing the host arrays with the last upload
-        (ContentIds)."""
-        if given is None:
-            given = self._grids[sid].setdefault('content', ContentIds()).assign(names, host_arrays)
-        given = {k: v for k, v in given.items() if v}
+    def _content_ids(self, sid, slot, given):
+        """odr_block_set_content_ids: {variable: id} for the level just uploaded (0 / missing: unknown).  The ids come from
+        whoever knows the data -- a reader that declares `static_variables`, or ContentIds.assign where a comparison by
+        value is affordable; nothing is compared here (a 1 M-node comparison per variable and level on the host costs more
+        than the gathers it saves)."""
+        given = {k: v for k, v in (given or {}).items() if v}
         if given:
             (va, pv), ia = _i([_vid(k) for k in given]), np.asarray(list(given.values()), dtype=np.uint64)
             check(self.lib.odr_block_set_content_ids(self.h, sid, slot, len(given), pv, ia.ctypes.data_as(C.POINTER(C.c_uint64))))
 
-    def upload_block(self, sid, slot, t_epoch, arrays):
+    def upload_block(self, sid, slot, t_epoch, arrays, content_ids=None):
         """arrays: {variable: float32 [ny,nx] or [nz,ny,nx], or a list of such arrays (ensemble members)} -- one
         ReaderBlock / time level."""
         g = self._grids[sid]
@@ -251,7 +252,7 @@ class Context:
         xy8, px = _d(g['xy8'])
         check(self.lib.odr_block_upload(self.h, sid, slot, float(t_epoch), len(keep), pi, ptrs, pn, g['ny'],
                                         g['nx'], px))
-        self._content_ids(sid, slot, names, dict(zip(names, keep)))
+        self._content_ids(sid, slot, content_ids)
 
     def upload_block_device(self, sid, slot, t_epoch, dev_ptrs, var_nz, content_ids=None):
         """dev_ptrs: {variable: device pointer (int) of a float32 array already in HBM, or a host NumPy array};
@@ -268,9 +269,9 @@ class Context:
         xy8, px = _d(g['xy8'])
         check(self.lib.odr_block_upload_device(self.h, sid, slot, float(t_epoch), len(names), pi, ptrs, pn,
                                                g['ny'], g['nx'], px))
-        self._content_ids(sid, slot, names, keep, content_ids)
+        self._content_ids(sid, slot, content_ids)
 
-    def upload_block_async(self, sid, slot, t_epoch, arrays, var_nz=None):
+    def upload_block_async(self, sid, slot, t_epoch, arrays, var_nz=None, content_ids=None):
         """Enqueue the upload of one time level on the upload stream and return (the simulation continues); the
         block becomes visible with commit_block().  arrays: {variable: float32 host array (pin it with pin() for a true
         DMA transfer) or device pointer (int)}.  The arrays are kept referenced until the commit."""
@@ -284,7 +285,7 @@ class Context:
         ptrs = (C.c_void_p * len(names))(*[C.c_void_p(keep[k].ctypes.data if k in keep else int(arrays[k])) for k in names])
         xy8, px = _d(g['xy8'])
         check(self.lib.odr_block_upload_async(self.h, sid, slot, float(t_epoch), len(names), pi, ptrs, pn, g['ny'], g['nx'], px))
-        self._content_ids(sid, slot, names, keep)      # (on the staged level: it becomes the slot's with the commit)
+        self._content_ids(sid, slot, content_ids)      # (on the staged level: it becomes the slot's with the commit)
         self._staged_refs = getattr(self, '_staged_refs', {})
         self._staged_refs[(sid, slot)] = keep
 

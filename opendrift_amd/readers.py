@@ -270,6 +270,12 @@ class GridReader(StructuredReader):
         self.start_time, self.end_time = self.times[0], self.times[-1]
         self.time_step = (self.times[1] - self.times[0]) if len(self.times) > 1 else None
         self.arrays = arrays
+        # 2-D variables that are the same array at every time level (sea floor depth, land mask): declared once here, so that
+        # the device reads them at one of the two bracketing levels (odr_block_set_content_ids) without comparing levels
+        def same(a, b):
+            return np.array_equal(a.view(np.uint32), b.view(np.uint32)) if a.dtype == np.float32 else np.array_equal(a, b)
+        self.static_variables = [v for v, a in arrays.items() if isinstance(a, np.ndarray) and a.ndim == 3 and a.shape[0] > 1 and
+                                 all(same(a[0], a[k]) for k in range(1, a.shape[0]))]
         self.variables = list(arrays)
         super().__init__()
 
@@ -413,6 +419,15 @@ class DeviceReaderBinding:
             self.sid = None  # created with the first block (the grid comes with it)
         if kind and reader.start_time is not None:
             ctx.set_time_coverage(self.sid, _epoch(reader.start_time), _epoch(reader.end_time), reader.always_valid)
+
+    def _static_ids(self):
+        """{variable: content id} of the 2-D variables the reader declares time-invariant (`static_variables`): the same id
+        for every level of this binding (a re-cut window is a new device source: its levels are all uploaded again)."""
+        sv = [v for v in getattr(self.reader, 'static_variables', ()) if v in self.variables]
+        if not sv:
+            return None
+        base = (id(self) & 0xffffff) * 4096
+        return {v: base + 1 + self.variables.index(v) for v in sv}
 
     def is_grid(self):
         return getattr(self.reader, 'device_kind', None) is None and not self.host_eval
@@ -570,9 +585,7 @@ class DeviceReaderBinding:
         if self.rank == 0:
             try:
                 block = r.get_variables(self.variables, time, x, y, np.array([0.0]))
-                from .device import ContentIds
-                self._cids = getattr(self, '_cids', None) or ContentIds()
-                cids = self._cids.assign(self.variables, block)
+                cids = self._static_ids()
             except Exception as e:      # noqa: BLE001 -- every reader exception is a reader failure (environment.py:640-668)
                 err = e
         shapes = getattr(self, '_dist_shapes', None)
@@ -697,7 +710,8 @@ class DeviceReaderBinding:
             # sets in turn: the upload then is an asynchronous DMA transfer for these as well (pageable memory would go
             # through the library's bounce buffer, synchronously)
             self._ring = 1 - getattr(self, '_ring', 1)
-            self.ctx.upload_block_async(self.sid, slot, t_ep, {v: self._page_locked(v, block[v]) for v in self.variables})
+            self.ctx.upload_block_async(self.sid, slot, t_ep, {v: self._page_locked(v, block[v]) for v in self.variables},
+                                        content_ids=self._static_ids())
             self.staged[k] = slot
             return
         if getattr(r, 's_levels', False):
@@ -714,7 +728,8 @@ class DeviceReaderBinding:
                 if v not in arrays:
                     arrays[v] = _dev(block[v])
                     nzv.setdefault(v, block[v].shape[0] if len(block[v].shape) == 3 else 1)
-            self.ctx.upload_block_device(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays, nzv)
+            self.ctx.upload_block_device(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays, nzv,
+                                         content_ids={v: i for v, i in (self._static_ids() or {}).items() if v not in block.get('s_level_variables', ())})
         elif self.world > 1:
             for v, m in getattr(self, '_dist_members', {}).items():
                 self.ctx.declare_members(self.sid, v, m)
@@ -725,5 +740,5 @@ class DeviceReaderBinding:
             self._tensors = None
         else:
             arrays = {v: block[v] for v in self.variables}
-            self.ctx.upload_block(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays)
+            self.ctx.upload_block(self.sid, slot, _epoch(time) if time is not None else 0.0, arrays, content_ids=self._static_ids())
         self.slots[k] = slot

@@ -191,10 +191,11 @@ def test_tiled_block_preparation_equals_the_sweeps(ctx, monkeypatch, nx, ny, old
 
 
 def test_variables_identical_at_both_time_levels_are_gathered_once(ctx, monkeypatch):
-    """odr_block_set_content_ids (Context.upload_block assigns the ids by comparing 2-D arrays with the last upload): sea floor
-    depth and land mask that the reader hands out unchanged with every block are read at ONE of the two bracketing levels
-    (G.ps_static) -- the same samples bit for bit as with the skip disabled; a depth that DOES change between the levels keeps
-    both gathers (and its time interpolation)."""
+    """odr_block_set_content_ids (ids by value comparison here: device.ContentIds; the reader bindings use a reader's
+    `static_variables`): sea floor depth and land mask that the reader hands out unchanged with every block are read at ONE
+    of the two bracketing levels (G.ps_static) -- the same samples bit for bit as with the skip disabled; a depth that DOES
+    change between the levels gets a new id per level and keeps both gathers (and its time interpolation)."""
+    from opendrift_amd.device import ContentIds
     g = synth.grid3d(nx=64, ny=48, nz=6, nt=3, seed=2)
     names = [U, V, W, DEPTH, LAND]
     rng = np.random.default_rng(9)
@@ -210,11 +211,15 @@ def test_variables_identical_at_both_time_levels_are_gathered_once(ctx, monkeypa
             else:
                 monkeypatch.setenv('ODR_NO_STATIC_SKIP', '1')
             sid = ctx.add_grid(g['x'], g['y'], z=g['z'])
+            cids = ContentIds()
             for k in range(3):
                 f = {nm: g[nm][k] for nm in names}
                 if moving_floor:
                     f[DEPTH] = (g[DEPTH][k] + 7.0 * k).astype(np.float32)
-                ctx.upload_block(sid, k, float(g['t'][k]), f)
+                ids = cids.assign(names, f)
+                assert ids[LAND] != 0 and ids[U] == 0 and (k == 0 or (ids[DEPTH] == first[DEPTH]) == (not moving_floor))
+                first = ids if k == 0 else first
+                ctx.upload_block(sid, k, float(g['t'][k]), f, content_ids=ids)
             for nm in names:
                 ctx.bind(nm, [sid], np.nan)
             out[moving_floor, skip] = P.env_sample(names, float(g['t'][0]) + 1234.5, download=True)
