@@ -628,34 +628,39 @@ def main():
                        'note': 'SURVEY 8(d) accounting: counts corners served by L1 / L2 / Infinity Cache; not a physical bandwidth'}
         out['roofline_algorithmic'] = algorithmic
         if pmc is not None:
-            # (2) the ceilings of the dominant kernel from its counters, each as the time the launch would take if that unit
-            # alone were the limit, over the measured launch time.  Peaks: HBM 8 TB/s; the L1 (TCP) takes one lane-access per
-            # cycle per CU: 256 CUs x 2.4 GHz; VALU issue per SIMD (1024 SIMDs x 2.4 GHz) priced per instruction class as
+            # (2) the ceilings of the dominant kernel from its counters, each as the share of the launch time that unit alone
+            # accounts for.  HBM: bytes / 8 TB/s.  VALU issue: 1 024 SIMDs, every wave64 instruction priced by class as
             # measured by tools/rate_bench.hip (profiles/r03_rate_bench_raw.txt): float64 arithmetic / conversions 4 cycles,
-            # transcendental float64 16, every other wave64 instruction 2.
+            # transcendental float64 16, every other 2.  Texture addresser (TA: the unit that turns the lanes of a vector-memory
+            # instruction into cache-line lookups, one per CU): its BUSY cycles per CU (TA_TA_BUSY) over the launch's cycles --
+            # a gather of 64 lanes in 64 different lines keeps it busy ~32 cycles whatever the width
+            # (tools/gather_bench.hip, profiles/r03_gather_bench.txt).  Clock: the profile's own (GRBM_GUI_ACTIVE / time).
             hbm_bytes = pmc['FETCH_SIZE_bytes_x2'] + pmc['WRITE_SIZE_bytes']
+            clk = (pmc.get('GRBM_GUI_ACTIVE_8xcd') or 0) / 8.0 / (pmc['kernel_us_rocprof'] * 1e-6) if pmc.get('GRBM_GUI_ACTIVE_8xcd') else 2.4e9
             t_hbm = hbm_bytes / HBM_PEAK
-            t_l1 = (pmc.get('TCP_TOTAL_CACHE_ACCESSES') or 0) / (256 * 2.4e9)
-            t_valu = pmc['valu_cycles_per_simd_slot'] / (1024 * 2.4e9)
-            ceil = {'hbm': t_hbm, 'l1_lane_access': t_l1, 'valu_issue': t_valu}
+            t_ta = (pmc.get('TA_TA_BUSY') or 0) / 256.0 / clk
+            t_valu = pmc['valu_cycles_per_simd_slot'] / (1024 * clk)
+            ceil = {'hbm': t_hbm, 'ta_busy': t_ta, 'valu_issue': t_valu}
             bound = max(ceil, key=ceil.get)
             ks = k_ms * 1e-3
             out['roofline'] = {
                 'bound': bound, 'kernel': kname, 'kernel_ms': k_ms, 'kernel_ms_median': k_ms_median,
-                'achieved': {'hbm': hbm_bytes / ks / 1e9, 'l1_lane_access': (pmc.get('TCP_TOTAL_CACHE_ACCESSES') or 0) / ks / 1e9,
+                'achieved': {'hbm': hbm_bytes / ks / 1e9, 'ta_busy': (pmc.get('TA_TA_BUSY') or 0) / ks / 1e9,
                              'valu_issue': pmc['valu_cycles_per_simd_slot'] / ks / 1e9}[bound],
-                'peak': {'hbm': HBM_PEAK / 1e9, 'l1_lane_access': 256 * 2.4, 'valu_issue': 1024 * 2.4}[bound],
-                'unit': {'hbm': 'GB/s', 'l1_lane_access': 'G lane-accesses/s', 'valu_issue': 'G SIMD-cycles/s'}[bound],
+                'peak': {'hbm': HBM_PEAK / 1e9, 'ta_busy': 256 * clk / 1e9, 'valu_issue': 1024 * clk / 1e9}[bound],
+                'unit': {'hbm': 'GB/s', 'ta_busy': 'G texture-addresser busy cycles/s (256 CUs)', 'valu_issue': 'G SIMD-cycles/s'}[bound],
                 'frac': ceil[bound] / ks,
                 'traffic': hbm_bytes / 1e9, 'traffic_unit': 'GB of HBM traffic per launch (FETCH_SIZE x2 + WRITE_SIZE)',
                 'fractions': {k: v / ks for k, v in ceil.items()},
+                'l1_lane_accesses_per_clk_per_cu': (pmc.get('TCP_TOTAL_CACHE_ACCESSES') or 0) / 256.0 / (clk * pmc['kernel_us_rocprof'] * 1e-6),
+                'clock_ghz': clk / 1e9,
                 'source': pmc_file + ' (counters of the same command and tree; this line times the launch itself)',
                 'note': 'the binding ceiling of the dominant kernel; the SURVEY 8(d) figure is roofline_algorithmic'}
             if 'second' in pmc and k2_ms is not None:
                 q = pmc['second']
                 c2 = {'hbm': (q['FETCH_SIZE_bytes_x2'] + q['WRITE_SIZE_bytes']) / HBM_PEAK,
-                      'l1_lane_access': (q.get('TCP_TOTAL_CACHE_ACCESSES') or 0) / (256 * 2.4e9),
-                      'valu_issue': q['valu_cycles_per_simd_slot'] / (1024 * 2.4e9)}
+                      'ta_busy': (q.get('TA_TA_BUSY') or 0) / 256.0 / clk,
+                      'valu_issue': q['valu_cycles_per_simd_slot'] / (1024 * clk)}
                 b2 = max(c2, key=c2.get)
                 out['roofline']['second_kernel'] = {'kernel': 'k_vmix_col', 'kernel_ms': k2_ms, 'bound': b2,
                                                     'frac': c2[b2] / (k2_ms * 1e-3), 'fractions': {k: v / (k2_ms * 1e-3) for k, v in c2.items()}}
