@@ -418,8 +418,8 @@ def plumbing_only(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=400)   # >= 0.6 s timed region; 25 re-sorts (every 16th step) fall inside it
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=None)   # default 400: >= 0.45 s timed region; 25 re-sorts (every 16th step) fall inside it
+    ap.add_argument('--warmup', type=int, default=None)  # default 3 (c2: see below)
     ap.add_argument('--workload', default=os.environ.get('ODR_WORKLOAD', 'c3'), choices=['c2', 'c3', 'c4', 'c5'])
     ap.add_argument('--particles', type=int, default=0, help='particles per GPU (default: the config size)')
     ap.add_argument('--small', action='store_true', help='small field block (debug)')
@@ -439,6 +439,13 @@ def main():
                     help='rendezvous, shards, block broadcast and the reductions of the N-rank run without the device path '
                          '(no GPU needed; value is null)')
     a = ap.parse_args()
+    # C2 (1 M particles, two launches of 50 + 15 us per step): 400 steps are 30-70 ms -- inside the time the GPU takes to leave
+    # its idle clocks after the host-side set-up (the first timed loop of the process measured 0.16-0.18 ms per step, the
+    # second 0.074).  Its defaults are long enough to measure the steady state; the other workloads keep 400 / 3.
+    if a.steps is None:
+        a.steps = 4000 if a.workload == 'c2' else 400
+    if a.warmup is None:
+        a.warmup = 2000 if a.workload == 'c2' else 3
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(a))      # this process is the launcher; its ranks re-enter main() with RANK / WORLD_SIZE set
     if int(os.environ.get('WORLD_SIZE', 1)) != a.gpus:
