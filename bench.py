@@ -528,11 +528,18 @@ def main():
     pinned = None
     if a.block_every and a.block_async and a.workload != 'c2':
         pinned = {kk: ctx.pin(np.ascontiguousarray(fields['g'][kk])) for kk in fields['names']}
-    for k in range(a.warmup):
+    # spin-up (untimed, before the W warm-up steps, the same count on every rank): ~0.25 s of the workload's own steps, so that a
+    # short timed region (the driver's --steps 20 is 25 ms) does not fall into the GPU's ramp from its idle clocks after the
+    # host-side set-up (measured on C2: 0.17 vs 0.06 ms per step); c2 spins up through its own default warm-up
+    spin = 0 if a.workload == 'c2' or os.environ.get('ODR_BENCH_NO_SPINUP') else 200
+    for k in range(spin):
         wl.step(P, k)
+    ctx.sync()
+    for k in range(a.warmup):
+        wl.step(P, spin + k)
     if a.block_every and a.workload != 'c2':
         warm_uploads(pinned)
-    el, units_rank = timed_loop(a.steps, a.warmup, a.block_every, a.block_async, pinned)
+    el, units_rank = timed_loop(a.steps, spin + a.warmup, a.block_every, a.block_async, pinned)
     el_max = float(D.allreduce_scalars([el], 'max')[0])
     units = float(D.allreduce_scalars([units_rank], 'sum')[0])
 
@@ -569,8 +576,8 @@ def main():
         ctx.set_stage_math(other_mode)
         nst_o = max(8, a.steps // 4)
         for k in range(2):
-            wl.step(P, a.warmup + a.steps + k)
-        el_o, units_o = timed_loop(nst_o, a.warmup + a.steps + 2)
+            wl.step(P, spin + a.warmup + a.steps + k)
+        el_o, units_o = timed_loop(nst_o, spin + a.warmup + a.steps + 2)
         el_o = float(D.allreduce_scalars([el_o], 'max')[0])
         units_o = float(D.allreduce_scalars([units_o], 'sum')[0])
         ko_ms, _ = launch_ms(wl.dominant_kernel)
@@ -621,7 +628,7 @@ def main():
                                           'Stokes + horizontal diffusion + stranding',
                                     'c5': 'C5: Leeway ensemble members (2 x 5 M per GPU) on the NorKyst-800-shaped grid, '
                                           'wind/current uncertainty, stranding'}[a.workload],
-                       'particles_per_gpu': n, 'particles_total': n * world, 'time_step_s': wl.dt, 'stage_math': a.stage_math,
+                       'particles_per_gpu': n, 'particles_total': n * world, 'time_step_s': wl.dt, 'stage_math': a.stage_math, 'spin_up_steps': spin,
                        'block_every': a.block_every, 'inputs': 'resident in HBM' if not a.block_every else 'uploaded in the timed region',
                        'parallelism': 'particle-sharded x%d, field block broadcast once per time level' % world},
         }
