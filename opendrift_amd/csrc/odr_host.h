@@ -84,6 +84,7 @@ struct odr_ctx {
   unsigned long long red_epoch;
   double red_wdd;
   int red_rel;
+  bool red_extents = true;   // the cached reduction holds the lon / lat / z extremes too (the movers' reductions leave them out)
   int red_pinned;   // odr_reduce_install: red[] holds values combined over the ranks of a sharded run
   // lanes of the fused step (odr_step.hip, step_in_lanes): contiguous particle ranges on streams of their own
   hipStream_t lane_stream[ODR_MAX_LANES];
@@ -296,7 +297,7 @@ bool odr_i_uv_fast_source(const odr_ctx *c, int &sid, double t_lo, double t_hi);
 bool odr_i_gyre_source(const odr_ctx *c, int var, int &sid);
 int odr_i_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t, float *const *out_host,
                      bool record_positions);
-int odr_i_reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind, bool wind_args_matter = true);
+int odr_i_reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind, bool wind_args_matter = true, bool extents = true);
 int odr_i_read_counter(odr_ctx *c, int64_t *out);
 // k_env_noise with DEVICE arrays of draws (ODR_RNG_HOST) or none (ODR_RNG_DEVICE)
 int odr_i_env_noise(odr_ctx *c, odr_particles *p, int vx, int vy, double std, int distribution, int rng_mode,

@@ -1076,6 +1076,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 // min is stored as max of the negated value; red must be pre-filled with -inf (sums with 0).
 // Grid-stride over a bounded grid, wave shuffle + LDS block reduction, ONE atomic per slot per
 // workgroup (the first version issued one per wave: 8 ms of atomic contention for 6 M particles).
+// EXT = false: without the lon / lat / z extremes (only odr_reduce_scalars / odr_reduce_local hand those out; the movers'
+// early-outs do not read them): 24 bytes per particle and six maxima less
+template <bool EXT>
 __global__ __launch_bounds__(BLOCK) void k_reduce(PView p, double wind_drift_depth, int relative_wind,
                                                   double *red) {
   const double ninf = -__builtin_inf();
@@ -1089,11 +1092,14 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(PView p, double wind_drift_dep
     // elements deactivated in this step and not yet compacted do not count: the reference has removed them by the time
     // its movers reduce (a sharded run reduces once per step, before the compaction: odr_reduce_local)
     if (p.status[i] != 0) continue;
-    double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
+    const double z = p.z[i];
     v[R_NACT] += 1;
-    v[R_LONMIN] = fmax(v[R_LONMIN], -lon); v[R_LONMAX] = fmax(v[R_LONMAX], lon);
-    v[R_LATMIN] = fmax(v[R_LATMIN], -lat); v[R_LATMAX] = fmax(v[R_LATMAX], lat);
-    v[R_ZMIN] = fmax(v[R_ZMIN], -z); v[R_ZMAX] = fmax(v[R_ZMAX], z);
+    if (EXT) {
+      const double lon = p.lon[i], lat = p.lat[i];
+      v[R_LONMIN] = fmax(v[R_LONMIN], -lon); v[R_LONMAX] = fmax(v[R_LONMAX], lon);
+      v[R_LATMIN] = fmax(v[R_LATMIN], -lat); v[R_LATMAX] = fmax(v[R_LATMAX], lat);
+      v[R_ZMIN] = fmax(v[R_ZMIN], -z); v[R_ZMAX] = fmax(v[R_ZMAX], z);
+    }
     if (p.env[VAR_HDIFF]) v[R_DMAX] = fmax(v[R_DMAX], (double)p.env[VAR_HDIFF][i]);
     if (p.env[VAR_SX] && p.env[VAR_SY])
       v[R_STOKESMAX] = fmax(v[R_STOKESMAX], (double)__fadd_rn(p.env[VAR_SX][i], p.env[VAR_SY][i]));

@@ -88,7 +88,7 @@ int odr_vmix_wind_profile(odr_ctx *c, odr_particles *p, int model, double backgr
   if ((rc = flush_world(c))) return rc;
   if (p->n == 0) return 0;
   p->epoch++;  // the reduction must see this step's mixed-layer depths
-  if ((rc = reduce(c, p, 0.0, 0, false))) return rc;
+  if ((rc = reduce(c, p, 0.0, 0, false, false))) return rc;
   double *du = nullptr;
   if (rng_mode == ODR_RNG_HOST) {
     REQUIRE(huni, "host uniforms required in ODR_RNG_HOST mode");

@@ -1457,16 +1457,18 @@ int odr_leeway_capsize(odr_ctx *c, odr_particles *p, double dt, double wind_thre
   return 0;
 }
 
-int odr_i_reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind, bool wind_args_matter) {
+int odr_i_reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind, bool wind_args_matter, bool extents) {
   if (c->red_pinned && c->red_owner == p) return 0;   // installed by the caller (odr_reduce_install): the all-rank values
-  if (!p->external && c->red_owner == p && c->red_epoch == p->epoch &&
+  if (!p->external && c->red_owner == p && c->red_epoch == p->epoch && (c->red_extents || !extents) &&
       (!wind_args_matter || (c->red_wdd == wdd && c->red_rel == relwind)))
     return 0;
-  c->red_owner = p; c->red_epoch = p->epoch; c->red_wdd = wdd; c->red_rel = relwind;
+  c->red_owner = p; c->red_epoch = p->epoch; c->red_wdd = wdd; c->red_rel = relwind; c->red_extents = extents;
   hipLaunchKernelGGL(k_red_init, dim3(1), dim3(64), 0, c->stream, c->red);
-  if (p->n > 0)
-    hipLaunchKernelGGL(k_reduce, dim3(nblk(p->n) < 2048u ? nblk(p->n) : 2048u), dim3(BLOCK), 0, c->stream, view(p), wdd,
-                       relwind, c->red);
+  const dim3 grid(nblk(p->n) < 2048u ? nblk(p->n) : 2048u);
+  if (p->n > 0) {
+    if (extents) hipLaunchKernelGGL(k_reduce<true>, grid, dim3(BLOCK), 0, c->stream, view(p), wdd, relwind, c->red);
+    else hipLaunchKernelGGL(k_reduce<false>, grid, dim3(BLOCK), 0, c->stream, view(p), wdd, relwind, c->red);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1507,7 +1509,7 @@ int odr_reduce_install(odr_ctx *c, odr_particles *p, const double *in16) {
   REQUIRE(in16, "in16 NULL");
   H2D(c->red, in16, sizeof(double) * R_N);
   HIPCHK(hipStreamSynchronize(c->stream));   // in16 is pageable
-  c->red_owner = p; c->red_epoch = p->epoch;
+  c->red_owner = p; c->red_epoch = p->epoch; c->red_extents = true;
   c->red_pinned = 1;      // until odr_reduce_unpin: the calls in between do not reduce again
   return 0;
 }
@@ -1523,7 +1525,7 @@ int odr_advect_wind(odr_ctx *c, odr_particles *p, double dt, double wdd, int rel
   if (p->n == 0) return 0;
   // wind identically 0 (no reader, fallback 0): wind_speed.max() == 0 -> "No wind for wind-sheared ocean drift" (:775-780)
   if (!relwind && env_is_const(p, VAR_XWIND, 0.0f) && env_is_const(p, VAR_YWIND, 0.0f)) return 0;
-  int rc = reduce(c, p, wdd, relwind);
+  int rc = reduce(c, p, wdd, relwind, true, false);
   if (rc) return rc;
   hipLaunchKernelGGL(k_advect_wind, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, wdd, relwind, factor, c->red);
   HIPCHK(hipGetLastError());
@@ -1542,7 +1544,7 @@ int odr_stokes_drift(odr_ctx *c, odr_particles *p, double dt, int profile, int h
   }
   if (p->n == 0) return 0;
   if (env_is_const(p, VAR_SX, 0.0f) && env_is_const(p, VAR_SY, 0.0f)) return 0;   // "No Stokes drift velocity available" (:799-804)
-  int rc = reduce(c, p, 0.0, 0, false);
+  int rc = reduce(c, p, 0.0, 0, false, false);
   if (rc) return rc;
   hipLaunchKernelGGL(k_stokes, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, profile, hs_mode, tp_mode, factor, c->red);
   HIPCHK(hipGetLastError());
@@ -1559,7 +1561,7 @@ int odr_hdiffusion(odr_ctx *c, odr_particles *p, double dt, int rng_mode, const 
     REQUIRE(hnx && hny, "host normals required in ODR_RNG_HOST mode");
     if ((rc = host_to_scratch(c, p, hnx, hny, (size_t)p->n, &da, &db))) return rc;
   }
-  if ((rc = reduce(c, p, 0.0, 0, false))) return rc;
+  if ((rc = reduce(c, p, 0.0, 0, false, false))) return rc;
   hipLaunchKernelGGL(k_hdiff, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, rng_mode, da, db, c->seed,
                      (unsigned long long)step, c->red);
   HIPCHK(hipGetLastError());
