@@ -195,3 +195,33 @@ def test_tsprofiles_is_refused_loudly_and_leeway_seeding_keeps_the_random_stream
     assert np.array_equal(lw._sched['downwind_eps'], want.astype(np.float32))
     assert (want != np.random.RandomState(7).randn(n) * c['DWSTD']).any()          # some draws were rejected
     assert np.array_equal(np.random.randn(2), tail)
+
+
+def test_static_variables_and_content_ids_without_a_gpu():
+    """GridReader declares once which 2-D variables are the same array at every time level (what the device then gathers at one
+    level: odr_block_set_content_ids); ContentIds assigns ids by bitwise comparison with the last array seen: equal -> same
+    id, changed -> new id, 3-D variables and lists -> 0."""
+    from opendrift_amd.device import ContentIds
+    g = synthetic.grid3d(nx=20, ny=16, nz=4, nt=3, seed=1)
+    names = ['x_sea_water_velocity', 'sea_floor_depth_below_sea_level', 'land_binary_mask']
+    times = [datetime(2020, 1, 1) + timedelta(seconds=float(t)) for t in g['t']]
+    r = readers.GridReader(g['x'], g['y'], times, {k: g[k] for k in names}, z=g['z'])
+    assert sorted(r.static_variables) == ['land_binary_mask', 'sea_floor_depth_below_sea_level']
+    moving = g['sea_floor_depth_below_sea_level'].copy()
+    moving[2] += 1.0
+    r2 = readers.GridReader(g['x'], g['y'], times, {'sea_floor_depth_below_sea_level': moving, 'land_binary_mask': g['land_binary_mask']})
+    assert r2.static_variables == ['land_binary_mask']
+    c = ContentIds()
+    depth = g['sea_floor_depth_below_sea_level']
+    a = c.assign(names, {'x_sea_water_velocity': g['x_sea_water_velocity'][0], 'sea_floor_depth_below_sea_level': depth[0],
+                         'land_binary_mask': [g['land_binary_mask'][0]] * 2})
+    assert a['x_sea_water_velocity'] == 0 and a['land_binary_mask'] == 0 and a['sea_floor_depth_below_sea_level'] > 0
+    b = c.assign(names[1:2], {'sea_floor_depth_below_sea_level': depth[1].copy()})
+    assert b['sea_floor_depth_below_sea_level'] == a['sea_floor_depth_below_sea_level']
+    d = c.assign(names[1:2], {'sea_floor_depth_below_sea_level': depth[1] + np.float32(0.5)})
+    assert d['sea_floor_depth_below_sea_level'] not in (0, a['sea_floor_depth_below_sea_level'])
+    nanny = depth[0].copy()
+    nanny[3, 4] = np.nan
+    e = c.assign(names[1:2], {'sea_floor_depth_below_sea_level': nanny})
+    f = c.assign(names[1:2], {'sea_floor_depth_below_sea_level': nanny.copy()})
+    assert e['sea_floor_depth_below_sea_level'] == f['sea_floor_depth_below_sea_level'] != d['sea_floor_depth_below_sea_level']
