@@ -665,6 +665,38 @@ def scenario_c4(g):
                     fallbacks={U: 0.0, VV: 0.0, XW: 0.0, YW: 0.0, SX: 0.0, SY: 0.0, HD: 0.0, HS: 0.0})
 
 
+def scenario_c20(g, tag):
+    """c20: the C4-shaped fields on a Lambert conformal conic / Mercator grid (oracle/gen_golden_proj.py)"""
+    from scenarios import Scenario
+    from opendrift_amd import projection
+    names = [U, VV, XW, YW, SX, SY, LAND]
+    t = g[tag + '_g_t']
+    levels = [(float(t[k]), {nm: g['%s_g_%s' % (tag, nm)][k] for nm in names}) for k in range(len(t))]
+    return Scenario([('grid', dict(x=g[tag + '_g_x'], y=g[tag + '_g_y'], proj=projection.parse_proj4(str(g[tag + '_proj4'])),
+                                   levels=levels, time_coverage=(float(t[0]), float(t[-1]))))],
+                    fallbacks={U: 0.0, VV: 0.0, XW: 0.0, YW: 0.0, SX: 0.0, SY: 0.0, HS: 0.0})
+
+
+def replay_c20(B, g, tag, nsteps):
+    """RK4 + wind + Stokes drift + stranding, no random terms"""
+    dt = float(g['dt'])
+    out = []
+    names = [U, VV, XW, YW, SX, SY, LAND, HS]
+    n = g[tag + '_lon'].shape[1]
+    for k in range(nsteps):
+        t = k * dt
+        B.sample(names, t)
+        B.coast('stranding', code=1)
+        B.increase_age(dt)
+        B.compact()
+        B.store_previous()
+        B.advect('runge-kutta4', t, dt)
+        B.wind(dt, wdd=0.1)
+        B.stokes(dt, profile=2, hs_mode=1, tp_mode=1)
+        out.append(B.state(n))
+    return out
+
+
 def compare(states, g, tol_pos, tol_z=None):
     worst = dict(lon=0.0, lat=0.0, z=0.0)
     for k, (lon, lat, z, status) in enumerate(states):

@@ -345,3 +345,19 @@ def test_mercator_and_lambert_reproduce_snyders_numerical_examples():
         assert abs(hx - x[0]) < 1e-6 * max(1.0, abs(x_want) * 1e-6) and abs(hy - y[0]) < 1e-6 * max(1.0, abs(y_want) * 1e-6)
         hl, hp = Proj(proj4)(hx, hy, inverse=True)
         assert abs(hl + 75.0) < 1e-10 and abs(hp - 35.0) < 1e-10
+
+
+@pytest.mark.parametrize('tag', ['lcc_sphere', 'lcc_wgs84', 'merc_wgs84'])
+def test_c20_lambert_and_mercator_golden_vs_oracle(tag):
+    """The C oracle (oracle/step.c + proj.c: lonlat2xy through the projection, vectors rotated by the azimuth of the reader's
+    +y axis from the 10 m finite difference and the WGS84 geodesic inverse) replays the reference's own runs on Lambert
+    conformal conic and Mercator grids (oracle/gen_golden_proj.py).  lcc_wgs84 lies at negative longitudes: the reference's
+    first step modulates the still-float32 longitudes in float32 (variables.py:259-280) -- 2.7e-7 deg on the worst element,
+    see tests/test_gpu_model_api.py::test_c20_* -- the oracle, like the device, works in float64."""
+    g = golden('c20_lcc_merc_rk4.npz')
+    sub = {k: g['%s_%s' % (tag, k)] for k in ('lon', 'lat', 'z', 'status')}
+    nst = sub['lon'].shape[0] - 1
+    B = replay.OracleBackend(replay.scenario_c20(g, tag), sub['lon'][0], sub['lat'][0], sub['z'][0], wdf=float(g['wdf']))
+    worst = replay.compare(replay.replay_c20(B, g, tag, nst), sub, tol_pos=4e-7 if tag == 'lcc_wgs84' else 1e-7)
+    assert (sub['status'][nst] != 0).sum() > 5
+    print('c20', tag, 'oracle vs reference:', worst)
