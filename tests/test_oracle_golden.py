@@ -361,3 +361,40 @@ def test_c20_lambert_and_mercator_golden_vs_oracle(tag):
     worst = replay.compare(replay.replay_c20(B, g, tag, nst), sub, tol_pos=4e-7 if tag == 'lcc_wgs84' else 1e-7)
     assert (sub['status'][nst] != 0).sum() > 5
     print('c20', tag, 'oracle vs reference:', worst)
+
+
+def test_mercator_and_lambert_round_trips_and_hemispheres():
+    """forward then inverse is the identity (< 1e-9 deg) for the oracle's and the host's Mercator / Lambert conformal conic
+    over wide domains, including a cone of the SOUTHERN hemisphere (negative cone constant: the sign handling of Snyder
+    14-10 / 14-11), a tangent cone, a true-scale latitude on the ellipsoid, false origins and the poles of the cone; oracle
+    and host agree to 1e-6 m."""
+    from oracle import oracle as orc
+    from opendrift_amd.projection import Proj, parse_proj4
+    rng = np.random.default_rng(12)
+    cases = ['+proj=lcc +lat_1=-30 +lat_2=-60 +lat_0=-45 +lon_0=140 +x_0=1000 +y_0=-2000 +ellps=WGS84',
+             '+proj=lcc +lat_1=63.3 +lat_0=63.3 +lon_0=15 +R=6371000',
+             '+proj=lcc +lat_1=25 +lat_2=47 +lat_0=36 +lon_0=-100 +ellps=GRS80',
+             '+proj=merc +lon_0=100 +lat_ts=-41 +ellps=WGS84 +x_0=5e5',
+             '+proj=merc +lon_0=0 +k_0=0.9996 +R=6371229']
+    for proj4 in cases:
+        pr = parse_proj4(proj4)
+        f = 0.0 if not pr['rf'] else 1.0 / pr['rf']
+        op = orc.make_proj(orc.PROJ_LCC if pr['kind'] == 'lcc' else orc.PROJ_MERC, a=pr['a'], es=f * (2 - f), lat0=pr['lat0'], lon0=pr['lon0'],
+                           lat_ts=pr.get('lat_ts', 0.0), k0=pr['k0'], x0=pr['x0'], y0=pr['y0'], lat1=pr.get('lat1', 0.0), lat2=pr.get('lat2'))
+        south = pr['kind'] == 'lcc' and pr['lat1'] < 0
+        lon = pr['lon0'] + rng.uniform(-170, 170, 3000)
+        lat = rng.uniform(-85, 20, 3000) if south else (rng.uniform(-20, 85, 3000) if pr['kind'] == 'lcc' else rng.uniform(-84, 84, 3000))
+        x, y = orc.proj_fwd(op, lon, lat)
+        lo, la = orc.proj_inv(op, x, y)
+        dlon = (lo - lon + 180) % 360 - 180
+        assert np.abs(dlon).max() < 1e-9 and np.abs(la - lat).max() < 1e-9, (proj4, np.abs(dlon).max(), np.abs(la - lat).max())
+        hx, hy = Proj(proj4)(lon, lat)
+        scale = max(1.0, float(np.abs(x).max()) * 1e-12)
+        assert np.abs(hx - x).max() < 1e-6 * max(1.0, scale) + 1e-6 and np.abs(hy - y).max() < 1e-6 * max(1.0, scale) + 1e-6, proj4
+        hl, hp = Proj(proj4)(hx, hy, inverse=True)
+        assert np.abs((hl - lon + 180) % 360 - 180).max() < 1e-9 and np.abs(hp - lat).max() < 1e-9
+    # the apex of a cone maps to its pole
+    op = orc.make_proj(orc.PROJ_LCC, a=6378137.0, es=0.00669438, lat0=40, lon0=10, lat1=30, lat2=50)
+    x, y = orc.proj_fwd(op, 77.0, 90.0)
+    lo, la = orc.proj_inv(op, x, y)
+    assert abs(la[0] - 90.0) < 1e-9
