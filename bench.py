@@ -683,6 +683,9 @@ def main():
                                    note='no counter file for this size / stage math: the SURVEY 8(d) algorithmic figure only')
             if k2_ms is not None:
                 out['roofline']['second_kernel'] = {'kernel': 'k_vmix_col', 'kernel_ms': k2_ms}
+        if a.workload in ('c3', 'c4'):
+            ts = P.tile_stats()     # the LDS-tile step (csrc/odr_tile.hip.h): launches on that path / elements it handed to the HBM path
+            out['lds_tile'] = dict(ts, handed_over_per_launch=(ts['handed_over'] / ts['launches'] if ts['launches'] else None))
         if other is not None:
             out['stage_math_' + other_mode] = other
         out.update(extras)

@@ -442,6 +442,14 @@ int odr_sort_particles(odr_ctx *ctx, odr_particles *p, int32_t source_id);
 /* keep_environment = 0: the sampled environment and the sample position are not carried along (the next odr_env_sample /
  * odr_env_coast_advect rewrites them for every element): a re-sort at the top of a step moves half the bytes */
 int odr_sort_particles_ex(odr_ctx *ctx, odr_particles *p, int32_t source_id, int keep_environment);
+/* The sort also leaves a table of workgroup ranges (each inside one 8x8-cell sort tile): while it is valid (no element
+ * appended since), odr_env_coast_advect with a Runge-Kutta scheme on a lon/lat or polar-stereographic reader runs its
+ * launch with the node records of each workgroup's rectangle staged in LDS (csrc/odr_tile.hip.h) -- same bits as the
+ * launch that gathers from the blocks in HBM.  Diagnostics of that path since the set was created:
+ * out4 = {launches that took the LDS-tile path, elements handed to the HBM path by those launches (footprint outside their
+ *         workgroup's rectangle), workgroups whose rectangle was cut to the LDS capacity, ranges in the current table}.
+ * Synchronises the context's stream. */
+int odr_particles_tile_stats(odr_ctx *ctx, odr_particles *p, uint64_t *out4);
 /* counts and min/max used for the per-step log line and early-outs (:2212-2233):
  * out16 = {n_active, lon_min, lon_max, lat_min, lat_max, z_min, z_max, D_max, stokes_sum_max,
  *          wind_speed_max, wdf_surface_max, n_surface, hs_max, tp_max, 0, 0} */

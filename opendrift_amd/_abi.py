@@ -144,6 +144,7 @@ _SIGNATURES = {
     'odr_compact_apply': [_vp, _vp, _i64p],
     'odr_sort_particles': [_vp, _vp, C.c_int32],
     'odr_sort_particles_ex': [_vp, _vp, C.c_int32, C.c_int],
+    'odr_particles_tile_stats': [_vp, _vp, _P(C.c_uint64)],
     'odr_reduce_scalars': [_vp, _vp, C.c_double, _dp],
     'odr_reduce_local': [_vp, _vp, C.c_double, C.c_int, _dp],
     'odr_reduce_install': [_vp, _vp, _dp],

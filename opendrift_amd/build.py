@@ -1,7 +1,7 @@
 """Builds libodrift_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
 
-The library is seven translation units (csrc/odrift.hip, odr_step.hip, odr_step_noise.hip, odr_step_fast.hip, odr_step_fast_noise.hip,
-odr_step_mix.hip, odr_mix.hip) compiled in parallel and
+The library is eight translation units (csrc/odrift.hip, odr_step.hip, odr_step_noise.hip, odr_step_fast.hip, odr_step_fast_noise.hip,
+odr_step_mix.hip, odr_mix.hip, odr_step_tile.hip) compiled in parallel and
 linked into one shared object; objects are rebuilt only when a source they include changed."""
 import os
 import subprocess
@@ -9,9 +9,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-UNITS = ['odr_step_noise.hip', 'odr_step_fast_noise.hip', 'odr_step.hip', 'odr_step_fast.hip', 'odrift.hip', 'odr_step_mix.hip', 'odr_mix.hip']
+UNITS = ['odr_step_noise.hip', 'odr_step_fast_noise.hip', 'odr_step.hip', 'odr_step_fast.hip', 'odrift.hip', 'odr_step_mix.hip', 'odr_mix.hip',
+         'odr_step_tile.hip']
 HEADERS = [os.path.join(CSRC, f) for f in ('odr_host.h', 'odr_step_launch.h', 'odr_kernels.hip.h', 'odr_field.hip.h', 'odr_geodesic.hip.h',
-                                           'odr_oil.hip.h', 'odr_mesh.h')] + \
+                                           'odr_oil.hip.h', 'odr_mesh.h', 'odr_tile.hip.h')] + \
     [os.path.join(os.path.dirname(HERE), 'include', 'odrift.h')]
 LIB = os.path.join(HERE, 'libodrift_hip.so')
 OBJDIR = os.path.join(HERE, 'build')

@@ -881,42 +881,77 @@ __device__ __forceinline__ T ld_off(const float *__restrict__ base, unsigned byt
 #endif
 }
 
-// ------------------------------------------------------------------ LDS field tile
-// The (u,v) node records around the particles of one workgroup, staged in LDS for the Runge-Kutta stage samples
-// (k_step_grid<..., TILE>): after the spatial sort the 256 particles of a workgroup sit in ~27 neighbouring grid cells,
-// and a stage position is less than a cell away from the particle, so the node rectangle spanned by the workgroup
-// (+1 node margin) serves all three stage evaluations of all its particles.  The three dependent gather rounds of
-// RK4 -- each an L2 / HBM round trip behind the other waves' gathers -- become LDS reads; the rectangle itself is
-// fetched once, coalesced along the node records.  Layout: tile[(node * 2 + time) * nz + k] = (u, v) of level k,
-// node = (iy - y0) * w + (ix - x0), time 0 = the 'before' block, 1 = 'after'.  Footprints that leave the rectangle
-// (stragglers after in-place compaction, workgroups that straddle two sort tiles) take the global path.
-struct __attribute__((aligned(8))) F2a { float x, y; };
-struct TileView {
-  const F2a *t;        // LDS
-  int x0, y0, w, h;    // node rectangle [x0, x0 + w) x [y0, y0 + h)
-  int nz;              // levels per node and time (1: 2-D field)
-};
-struct GlobalUV {       // the same access pattern on the blocks in HBM
-  const float *b, *a;
-  unsigned o[4], kb;
-  __device__ __forceinline__ F4 q4(int time, int c) const { return ld_off<F4>(time ? a : b, o[c] + kb); }
-  __device__ __forceinline__ F2 q2(int time, int c) const { return ld_off<F2>(time ? a : b, o[c]); }
-};
-struct TileUV {
-  const F2a *t;
-  unsigned l[4];       // (node * 2) * nz + iz0 per corner
-  unsigned nz;
-  __device__ __forceinline__ F4 q4(int time, int c) const {
-    const F2a *q = t + l[c] + (time ? nz : 0u);
-    const F2a lo = q[0], hi = q[1];
+// ------------------------------------------------------------------ where a sample reads its node records
+// A sampler reads the records of a particle's 2x2 footprint at (up to) two time levels through a LOADER: LdGlobal -- the
+// blocks in HBM through buffer descriptors (wave-uniform base + 32-bit byte offset) -- or LdTile -- the workgroup's copy
+// of the node rectangle around its particles in LDS (k_step_tile: the whole records of the rectangle, both time levels,
+// fetched once by LDS-DMA; odr_tile.hip.h).  A loader also makes the footprint: the SAME indices and weights, the byte
+// offsets relative to its own image; LdTile reports footprints that leave its rectangle (ok = false: the particle is
+// redone on the global path, nothing of it has been written by then).  Same values, same arithmetic, same bits.
+typedef __attribute__((address_space(3))) const char lds_cbyte;   // explicit LDS pointer: ds_read, not flat loads
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <class T, int ALIGN>
+__device__ __forceinline__ T lds_ld(lds_cbyte *q) {
+  typedef __attribute__((address_space(3))) const float lds_cf32;
+  typedef __attribute__((address_space(3))) const f32x2 lds_cf64;   // 8-byte aligned: ds_read_b64
+  if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, *(lds_cf32 *)q);
+  else if constexpr (sizeof(T) == 8 && ALIGN >= 8) return __builtin_bit_cast(T, *(lds_cf64 *)q);
+  else if constexpr (sizeof(T) == 8) { F2 r; r.x = ((lds_cf32 *)q)[0]; r.y = ((lds_cf32 *)q)[1]; return __builtin_bit_cast(T, r); }
+  else if constexpr (ALIGN >= 8) {   // 16 bytes at an 8-byte boundary: two ds_read_b64 (a ds_read_b128 off its alignment is replayed)
+    const f32x2 lo = ((lds_cf64 *)q)[0], hi = ((lds_cf64 *)q)[1];
     F4 r; r.x = lo.x; r.y = lo.y; r.z = hi.x; r.w = hi.y;
-    return r;
+    return __builtin_bit_cast(T, r);
+  } else {
+    F4 r; r.x = ((lds_cf32 *)q)[0]; r.y = ((lds_cf32 *)q)[1]; r.z = ((lds_cf32 *)q)[2]; r.w = ((lds_cf32 *)q)[3];
+    return __builtin_bit_cast(T, r);
   }
-  __device__ __forceinline__ F2 q2(int time, int c) const {
-    const F2a v = t[l[c] + (time ? nz : 0u)];
-    F2 r; r.x = v.x; r.y = v.y;
-    return r;
+}
+struct LdGlobal {
+  const float *b, *a;     // records (or one variable of them) at the bracketing time levels; a == b when there is one level
+  template <class T, int ALIGN = 4>
+  __device__ __forceinline__ T ld(int time, unsigned off) const { return ld_off<T>(time ? a : b, off); }
+  __device__ __forceinline__ Foot foot(double yi, double xi, int ny, int nx, unsigned rec_bytes, bool &ok) const {
+    ok = true;
+    return footprint(yi, xi, ny, nx, rec_bytes);
   }
+  __device__ __forceinline__ unsigned node(int iy, int ix, int nx, unsigned rec_bytes, bool &ok) const {
+    ok = true;
+    return __umul24(__umul24((unsigned)iy, (unsigned)nx) + (unsigned)ix, rec_bytes);
+  }
+  __device__ __forceinline__ LdGlobal at(unsigned byte_off) const { LdGlobal r; r.b = (const float *)((const char *)b + byte_off); r.a = (const float *)((const char *)a + byte_off); return r; }
+};
+struct TileRect { int x0, y0, w, h; };   // node rectangle [x0, x0 + w) x [y0, y0 + h) of the workgroup's tile
+struct LdTile {
+  lds_cbyte *b, *a;       // images of the two time levels: [h][w] node records each
+  TileRect R;
+  template <class T, int ALIGN = 4>
+  __device__ __forceinline__ T ld(int time, unsigned off) const { return lds_ld<T, ALIGN>((time ? a : b) + off); }
+  __device__ __forceinline__ Foot foot(double yi, double xi, int ny, int nx, unsigned rec_bytes, bool &ok) const {
+    const Axis ay = axis_fp(yi, ny), ax = axis_fp(xi, nx);
+    const int lx0 = ax.i0 - R.x0, lx1 = ax.i1 - R.x0, ly0 = ay.i0 - R.y0, ly1 = ay.i1 - R.y0;
+    ok = lx0 >= 0 && lx1 < R.w && ly0 >= 0 && ly1 < R.h;
+    const unsigned r0 = ok ? (unsigned)(ly0 * R.w) : 0u, r1 = ok ? (unsigned)(ly1 * R.w) : 0u;
+    const unsigned c0 = ok ? (unsigned)lx0 : 0u, c1 = ok ? (unsigned)lx1 : 0u;
+    Foot f;
+    f.o00 = __umul24(r0 + c0, rec_bytes); f.o01 = __umul24(r0 + c1, rec_bytes);
+    f.o10 = __umul24(r1 + c0, rec_bytes); f.o11 = __umul24(r1 + c1, rec_bytes);
+    f.ty = ay.t; f.tx = ax.t; f.wy0 = 1 - ay.t; f.wx0 = 1 - ax.t;
+    return f;
+  }
+  __device__ __forceinline__ unsigned node(int iy, int ix, int nx, unsigned rec_bytes, bool &ok) const {
+    const int lx = ix - R.x0, ly = iy - R.y0;
+    ok = lx >= 0 && lx < R.w && ly >= 0 && ly < R.h;
+    return ok ? __umul24((unsigned)(ly * R.w + lx), rec_bytes) : 0u;
+  }
+  __device__ __forceinline__ LdTile at(unsigned byte_off) const { LdTile r = *this; r.b = b + byte_off; r.a = a + byte_off; return r; }
+};
+// the four corner offsets of a footprint + a loader: what uv_level_ld reads an interleaved (u,v) pair through
+template <class LD>
+struct PairLd {
+  LD ld;
+  unsigned o[4], kb;
+  __device__ __forceinline__ F4 q4(int time, int c) const { return ld.template ld<F4, 8>(time, o[c] + kb); }
+  __device__ __forceinline__ F2 q2(int time, int c) const { return ld.template ld<F2, 8>(time, o[c]); }
 };
 
 // one float32 layer value from multiplied-out weights (w00 = wy0 wx0, ...): the same sum as bil4 evaluated with three
@@ -932,7 +967,7 @@ __device__ __forceinline__ FootW foot_weights(const Foot &ft) {
   return w;
 }
 
-// (u,v) of an interleaved pair at one time level through a loader LD (GlobalUV / TileUV).
+// (u,v) of an interleaved pair at one time level through a loader LD (PairLd<LdGlobal> / PairLd<LdTile>).
 // FASTW: layer values from the multiplied-out weights `fw` (Runge-Kutta stage samples) instead of scipy's
 // (v*wy)*wx order (the stored environment)
 template <bool IS3D, bool FASTW, class LD>
@@ -977,8 +1012,8 @@ template <bool IS3D, bool FASTW = false>
 __device__ __forceinline__ void uv_level(const float *__restrict__ uv, int nz, const Foot &ft,
                                          const ZBracket &zb, double &u, double &v, bool &f32class,
                                          const FootW &fw = FootW()) {
-  GlobalUV g;
-  g.b = uv; g.a = uv;
+  PairLd<LdGlobal> g;
+  g.ld.b = uv; g.ld.a = uv;
   g.o[0] = ft.o00; g.o[1] = ft.o01; g.o[2] = ft.o10; g.o[3] = ft.o11;
   g.kb = IS3D ? (unsigned)zb.iz0 * 8u : 0u;
   uv_level_ld<IS3D, FASTW>(g, 0, nz, ft, zb, u, v, f32class, fw);
@@ -987,14 +1022,12 @@ __device__ __forceinline__ void uv_level(const float *__restrict__ uv, int nz, c
 // (u,v) float32 environment of one particle from the single grid source `s` at a Runge-Kutta STAGE position: the
 // reference's layer-by-layer arithmetic (every (time, z) layer interpolated horizontally and rounded to float32, then
 // z and time interpolation) with the horizontal weights multiplied out once for all layers.
-// -DODR_FAST_STAGE_SAMPLE (measured, not the default): all 2 x 2 x 2 x 2 corner values combined in float64 and rounded
-// to float32 once -- the intermediate float32 roundings of the reference are skipped, 60 instructions fewer per sample,
-// but the stage value is then 1-2 float32 ulp off in most samples (1.5e-9 deg per step in tests/test_gpu_parity.py).
-template <int PROJ, bool IS3D, bool TILE = false>
-__device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBlock &geo, const UVTime &tm,
+// The records come through the loader `ld` (LdGlobal: time 0 = tm.b, 1 = tm.a; LdTile: the workgroup's LDS images of the
+// same two levels); returns false when the footprint leaves the loader's image (LdTile only).
+template <int PROJ, bool IS3D, class LD = LdGlobal>
+__device__ __forceinline__ bool uv_sample_fast(const DevSource &s, const DevBlock &geo, const UVTime &tm, const LD &ld,
                                                double lon, double lat, double z, const ZBracket &zb,
                                                float fbu, float fbv, float &uo, float &vo,
-                                               const TileView &T = TileView(), bool tile_ok = false,
                                                const ProjStart &ps = ProjStart()) {
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
@@ -1011,53 +1044,26 @@ __device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBloc
     else if (s.lon_mode == 2) xchk = np_mod(x, 360.0);
   }
   float fu = __builtin_nanf(""), fv = __builtin_nanf("");
+  bool ok = true;
   if (xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin && z <= s.zmax) {
     if (s.mod360_x) x = np_mod(x, 360.0);
     double xi = __dmul_rn(div_cr(x - geo.x0, geo.xspan, geo.ixspan), (double)(geo.nx - 1));
     double yi = __dmul_rn(div_cr(y - geo.y0, geo.yspan, geo.iyspan), (double)(geo.ny - 1));
     double u, v;
-#ifndef ODR_FAST_STAGE_SAMPLE
     bool f32c;
-    bool from_tile = false;
-    if (TILE && tile_ok) {   // both corners of both axes inside the staged rectangle?
-      const Axis ay = axis_fp(yi, geo.ny), ax = axis_fp(xi, geo.nx);
-      const int lx0 = ax.i0 - T.x0, lx1 = ax.i1 - T.x0, ly0 = ay.i0 - T.y0, ly1 = ay.i1 - T.y0;
-      if (lx0 >= 0 && lx1 < T.w && ly0 >= 0 && ly1 < T.h) {
-        from_tile = true;
-        Foot ft;
-        ft.ty = ay.t; ft.tx = ax.t; ft.wy0 = 1 - ay.t; ft.wx0 = 1 - ax.t;
-        ft.o00 = ft.o01 = ft.o10 = ft.o11 = 0;
-        const FootW fw = foot_weights(ft);
-        TileUV L;
-        L.t = T.t; L.nz = (unsigned)T.nz;
-        const unsigned k0 = IS3D ? (unsigned)zb.iz0 : 0u, nz2 = 2u * (unsigned)T.nz;
-        L.l[0] = (unsigned)(ly0 * T.w + lx0) * nz2 + k0; L.l[1] = (unsigned)(ly0 * T.w + lx1) * nz2 + k0;
-        L.l[2] = (unsigned)(ly1 * T.w + lx0) * nz2 + k0; L.l[3] = (unsigned)(ly1 * T.w + lx1) * nz2 + k0;
-        double ub, vb;
-        uv_level_ld<IS3D, true>(L, 0, s.nz, ft, zb, ub, vb, f32c, fw);
-        u = ub; v = vb;
-        if (tm.a) {
-          double ua, va;
-          uv_level_ld<IS3D, true>(L, 1, s.nz, ft, zb, ua, va, f32c, fw);
-          if (f32c) {
-            u = __fadd_rn(__fmul_rn((float)ub, (float)(1 - tm.w)), __fmul_rn((float)ua, (float)tm.w));
-            v = __fadd_rn(__fmul_rn((float)vb, (float)(1 - tm.w)), __fmul_rn((float)va, (float)tm.w));
-          } else {
-            u = __dadd_rn(__dmul_rn(ub, 1 - tm.w), __dmul_rn(ua, tm.w));
-            v = __dadd_rn(__dmul_rn(vb, 1 - tm.w), __dmul_rn(va, tm.w));
-          }
-        }
-      }
-    }
-    if (!from_tile) {
-      const Foot ft = footprint(yi, xi, geo.ny, geo.nx, (unsigned)geo.rec * 4u);
-      double ub, vb;
+    {
+      const Foot ft = ld.foot(yi, xi, geo.ny, geo.nx, (unsigned)geo.rec * 4u, ok);
       const FootW fw = foot_weights(ft);
-      uv_level<IS3D, true>(tm.b, s.nz, ft, zb, ub, vb, f32c, fw);
+      PairLd<LD> L;
+      L.ld = ld;
+      L.o[0] = ft.o00; L.o[1] = ft.o01; L.o[2] = ft.o10; L.o[3] = ft.o11;
+      L.kb = IS3D ? (unsigned)zb.iz0 * 8u : 0u;
+      double ub, vb;
+      uv_level_ld<IS3D, true>(L, 0, s.nz, ft, zb, ub, vb, f32c, fw);
       u = ub; v = vb;
       if (tm.a) {
         double ua, va;
-        uv_level<IS3D, true>(tm.a, s.nz, ft, zb, ua, va, f32c, fw);
+        uv_level_ld<IS3D, true>(L, 1, s.nz, ft, zb, ua, va, f32c, fw);
         if (f32c) {
           u = __fadd_rn(__fmul_rn((float)ub, (float)(1 - tm.w)), __fmul_rn((float)ua, (float)tm.w));
           v = __fadd_rn(__fmul_rn((float)vb, (float)(1 - tm.w)), __fmul_rn((float)va, (float)tm.w));
@@ -1067,46 +1073,6 @@ __device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBloc
         }
       }
     }
-#else
-    {
-#pragma clang fp contract(fast)
-      const Foot ft = footprint(yi, xi, geo.ny, geo.nx, (unsigned)geo.rec * 4u);
-      const double w00 = ft.wy0 * ft.wx0, w01 = ft.wy0 * ft.tx, w10 = ft.ty * ft.wx0, w11 = ft.ty * ft.tx;
-      if (IS3D) {
-        // levels (iz0, iz0 + 1) = ("above", "below"); clamped at the deepest level both are iz0 + 1
-        const bool same = zb.same && s.nz > 1;
-        const double za = same ? 0.0 : zb.wa, zbw = same ? 1.0 : 1 - zb.wa;
-        const double a00 = w00 * za, a01 = w01 * za, a10 = w10 * za, a11 = w11 * za;
-        const double b00 = w00 * zbw, b01 = w01 * zbw, b10 = w10 * zbw, b11 = w11 * zbw;
-        const unsigned kb = (unsigned)zb.iz0 * 8u;
-        const F4 q00 = ld_off<F4>(tm.b, ft.o00 + kb), q01 = ld_off<F4>(tm.b, ft.o01 + kb);
-        const F4 q10 = ld_off<F4>(tm.b, ft.o10 + kb), q11 = ld_off<F4>(tm.b, ft.o11 + kb);
-        u = fma(q11.z, b11, fma(q10.z, b10, fma(q01.z, b01, fma(q00.z, b00, fma(q11.x, a11, fma(q10.x, a10, fma(q01.x, a01, q00.x * a00)))))));
-        v = fma(q11.w, b11, fma(q10.w, b10, fma(q01.w, b01, fma(q00.w, b00, fma(q11.y, a11, fma(q10.y, a10, fma(q01.y, a01, q00.y * a00)))))));
-        if (tm.a) {
-          const F4 r00 = ld_off<F4>(tm.a, ft.o00 + kb), r01 = ld_off<F4>(tm.a, ft.o01 + kb);
-          const F4 r10 = ld_off<F4>(tm.a, ft.o10 + kb), r11 = ld_off<F4>(tm.a, ft.o11 + kb);
-          const double ua = fma(r11.z, b11, fma(r10.z, b10, fma(r01.z, b01, fma(r00.z, b00, fma(r11.x, a11, fma(r10.x, a10, fma(r01.x, a01, r00.x * a00)))))));
-          const double va = fma(r11.w, b11, fma(r10.w, b10, fma(r01.w, b01, fma(r00.w, b00, fma(r11.y, a11, fma(r10.y, a10, fma(r01.y, a01, r00.y * a00)))))));
-          u = fma(ua - u, tm.w, u);
-          v = fma(va - v, tm.w, v);
-        }
-      } else {
-        const F2 q00 = ld_off<F2>(tm.b, ft.o00), q01 = ld_off<F2>(tm.b, ft.o01);
-        const F2 q10 = ld_off<F2>(tm.b, ft.o10), q11 = ld_off<F2>(tm.b, ft.o11);
-        u = fma(q11.x, w11, fma(q10.x, w10, fma(q01.x, w01, q00.x * w00)));
-        v = fma(q11.y, w11, fma(q10.y, w10, fma(q01.y, w01, q00.y * w00)));
-        if (tm.a) {
-          const F2 r00 = ld_off<F2>(tm.a, ft.o00), r01 = ld_off<F2>(tm.a, ft.o01);
-          const F2 r10 = ld_off<F2>(tm.a, ft.o10), r11 = ld_off<F2>(tm.a, ft.o11);
-          const double ua = fma(r11.x, w11, fma(r10.x, w10, fma(r01.x, w01, r00.x * w00)));
-          const double va = fma(r11.y, w11, fma(r10.y, w10, fma(r01.y, w01, r00.y * w00)));
-          u = fma(ua - u, tm.w, u);
-          v = fma(va - v, tm.w, v);
-        }
-      }
-    }
-#endif
     if (ODR_PROJ_ROTATES(PROJ)) {
       double sn, cs;
       rotation_cs<PROJ == PROJ_STERE_POLAR>(s.proj, x, y, cs, sn);
@@ -1119,6 +1085,7 @@ __device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBloc
   }
   uo = isfinite(fu) ? fu : (isfinite(fbu) ? fbu : fu);
   vo = isfinite(fv) ? fv : (isfinite(fbv) ? fbv : fv);
+  return ok;
 }
 
 
@@ -1129,9 +1096,8 @@ __device__ __forceinline__ void uv_sample_fast(const DevSource &s, const DevBloc
 // both), i.e. 16 instructions instead of 32 conversions + 72 float64 operations.  The value differs from the reference's
 // stage value by a few float32 ulp (like the stage value of ODR_FAST_STAGE_SAMPLE in round 2): <= 2e-9 deg per step in
 // the position.  Front door (longitude convention, projection, coverage, fractional indices) as in uv_sample_fast.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int PROJ, bool IS3D>
-__device__ __forceinline__ void uv_sample_stage_f32(const DevSource &s, const DevBlock &geo, const UVTime &tm,
+template <int PROJ, bool IS3D, class LD = LdGlobal>
+__device__ __forceinline__ bool uv_sample_stage_f32(const DevSource &s, const DevBlock &geo, const UVTime &tm, const LD &ld,
                                                     double lon, double lat, double z, const ZBracket &zb,
                                                     float fbu, float fbv, float &uo, float &vo, const ProjStart &ps) {
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
@@ -1147,12 +1113,13 @@ __device__ __forceinline__ void uv_sample_stage_f32(const DevSource &s, const De
     else if (s.lon_mode == 2) xchk = np_mod(x, 360.0);
   }
   float fu = __builtin_nanf(""), fv = __builtin_nanf("");
+  bool ok = true;
   if (xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin && z <= s.zmax) {
 #pragma clang fp contract(fast)
     if (s.mod360_x) x = np_mod(x, 360.0);
     const double xi = (x - geo.x0) * geo.ixspan * (double)(geo.nx - 1);
     const double yi = (y - geo.y0) * geo.iyspan * (double)(geo.ny - 1);
-    const Foot ft = footprint(yi, xi, geo.ny, geo.nx, (unsigned)geo.rec * 4u);
+    const Foot ft = ld.foot(yi, xi, geo.ny, geo.nx, (unsigned)geo.rec * 4u, ok);
     const float tx = (float)ft.tx, ty = (float)ft.ty, sx = 1.f - tx, sy = 1.f - ty;
     const float w00 = sy * sx, w01 = sy * tx, w10 = ty * sx, w11 = ty * tx;
     const float wt = tm.a ? (float)tm.w : 0.f;
@@ -1162,9 +1129,9 @@ __device__ __forceinline__ void uv_sample_stage_f32(const DevSource &s, const De
       const bool same = zb.same && s.nz > 1;
       const float za = same ? 0.f : (float)zb.wa, zw = 1.f - za;
       const unsigned kb = (unsigned)zb.iz0 * 8u;
-      auto level = [&](const float *base) {
-        const F4 q00 = ld_off<F4>(base, ft.o00 + kb), q01 = ld_off<F4>(base, ft.o01 + kb);
-        const F4 q10 = ld_off<F4>(base, ft.o10 + kb), q11 = ld_off<F4>(base, ft.o11 + kb);
+      auto level = [&](int time) {
+        const F4 q00 = ld.template ld<F4, 8>(time, ft.o00 + kb), q01 = ld.template ld<F4, 8>(time, ft.o01 + kb);
+        const F4 q10 = ld.template ld<F4, 8>(time, ft.o10 + kb), q11 = ld.template ld<F4, 8>(time, ft.o11 + kb);
         f32x2 lo = (f32x2){q00.x, q00.y} * w00, hi = (f32x2){q00.z, q00.w} * w00;
         lo = __builtin_elementwise_fma((f32x2){q01.x, q01.y}, (f32x2){w01, w01}, lo);
         hi = __builtin_elementwise_fma((f32x2){q01.z, q01.w}, (f32x2){w01, w01}, hi);
@@ -1174,19 +1141,19 @@ __device__ __forceinline__ void uv_sample_stage_f32(const DevSource &s, const De
         hi = __builtin_elementwise_fma((f32x2){q11.z, q11.w}, (f32x2){w11, w11}, hi);
         return __builtin_elementwise_fma(hi, (f32x2){zw, zw}, lo * za);
       };
-      r = level(tm.b);
-      if (tm.a) { const f32x2 ra = level(tm.a); r = __builtin_elementwise_fma(ra - r, (f32x2){wt, wt}, r); }
+      r = level(0);
+      if (tm.a) { const f32x2 ra = level(1); r = __builtin_elementwise_fma(ra - r, (f32x2){wt, wt}, r); }
     } else {
-      auto level = [&](const float *base) {
-        const F2 q00 = ld_off<F2>(base, ft.o00), q01 = ld_off<F2>(base, ft.o01);
-        const F2 q10 = ld_off<F2>(base, ft.o10), q11 = ld_off<F2>(base, ft.o11);
+      auto level = [&](int time) {
+        const F2 q00 = ld.template ld<F2, 8>(time, ft.o00), q01 = ld.template ld<F2, 8>(time, ft.o01);
+        const F2 q10 = ld.template ld<F2, 8>(time, ft.o10), q11 = ld.template ld<F2, 8>(time, ft.o11);
         f32x2 a = (f32x2){q00.x, q00.y} * w00;
         a = __builtin_elementwise_fma((f32x2){q01.x, q01.y}, (f32x2){w01, w01}, a);
         a = __builtin_elementwise_fma((f32x2){q10.x, q10.y}, (f32x2){w10, w10}, a);
         return __builtin_elementwise_fma((f32x2){q11.x, q11.y}, (f32x2){w11, w11}, a);
       };
-      r = level(tm.b);
-      if (tm.a) { const f32x2 ra = level(tm.a); r = __builtin_elementwise_fma(ra - r, (f32x2){wt, wt}, r); }
+      r = level(0);
+      if (tm.a) { const f32x2 ra = level(1); r = __builtin_elementwise_fma(ra - r, (f32x2){wt, wt}, r); }
     }
     fu = r.x; fv = r.y;
     if (ODR_PROJ_ROTATES(PROJ)) {
@@ -1199,16 +1166,20 @@ __device__ __forceinline__ void uv_sample_stage_f32(const DevSource &s, const De
   }
   uo = isfinite(fu) ? fu : (isfinite(fbu) ? fbu : fu);
   vo = isfinite(fv) ? fv : (isfinite(fbv) ? fbv : fv);
+  return ok;
 }
 
-// the stage sample of the chosen stage math (SM: 0 = ODR_STAGE_EXACT, 1 = ODR_STAGE_FAST)
-template <int PROJ, bool IS3D, bool TILE, int SM>
-__device__ __forceinline__ void uv_stage(const DevSource &s, const DevBlock &geo, const UVTime &tm, double lon, double lat,
+// the stage sample of the chosen stage math (SM: 0 = ODR_STAGE_EXACT, 1 = ODR_STAGE_FAST) through the loader `ld`, whose
+// time 0 / 1 are the (u,v) arrays of tm.b / tm.a; false: the footprint left the loader's image (LdTile)
+template <int PROJ, bool IS3D, int SM, class LD>
+__device__ __forceinline__ bool uv_stage(const DevSource &s, const DevBlock &geo, const UVTime &tm, const LD &ld, double lon, double lat,
                                          double z, const ZBracket &zb, float fbu, float fbv, float &uo, float &vo,
-                                         const TileView &T, bool tile_ok, const ProjStart &ps) {
-  if constexpr (SM == 1) uv_sample_stage_f32<PROJ, IS3D>(s, geo, tm, lon, lat, z, zb, fbu, fbv, uo, vo, ps);
-  else uv_sample_fast<PROJ, IS3D, TILE>(s, geo, tm, lon, lat, z, zb, fbu, fbv, uo, vo, T, tile_ok, ps);
+                                         const ProjStart &ps) {
+  if constexpr (SM == 1) return uv_sample_stage_f32<PROJ, IS3D>(s, geo, tm, ld, lon, lat, z, zb, fbu, fbv, uo, vo, ps);
+  else return uv_sample_fast<PROJ, IS3D>(s, geo, tm, ld, lon, lat, z, zb, fbu, fbv, uo, vo, ps);
 }
+// the global loader of a stage sample: the (u,v) arrays of the bracketing levels
+__device__ __forceinline__ LdGlobal uv_global(const UVTime &tm) { LdGlobal g; g.b = tm.b; g.a = tm.a ? tm.a : tm.b; return g; }
 
 // ---------------------------------------------------------- fast environment group
 // Main-loop Environment.get_environment for a variable group served by ONE gridded reader:
@@ -1339,10 +1310,11 @@ __device__ __forceinline__ void burst_math(int m, Get get, const Foot &ft, const
     }
   }
 }
-template <int PROJ>
-__device__ __forceinline__ void env_burst(const DevSource &s, const EnvGroupDesc &G, const Foot &ft, const ZBracket &zb,
+// L: the loader of the node records (time 0 = the level before, 1 = the level after, or the same level when !tl); ft and
+// near_off hold ITS byte offsets (LdGlobal::foot / LdTile::foot)
+template <int PROJ, class LD>
+__device__ __forceinline__ void env_burst(const DevSource &s, const EnvGroupDesc &G, const LD &L, const Foot &ft, const ZBracket &zb,
                                           unsigned near_off, bool tl, double x, double y, float *out /*[MAXG]*/ ODR_PT_PARAM) {
-  const float *bb = G.bb, *ba = tl ? G.ba : G.bb;
   const unsigned o[4] = {ft.o00, ft.o01, ft.o10, ft.o11};
   const unsigned iz0 = (unsigned)zb.iz0;
   const int kA = G.bs[0], kB = G.bs[1], kC = G.bs[2], kD = G.bs[3], kL = G.bs[4];
@@ -1376,11 +1348,11 @@ __device__ __forceinline__ void env_burst(const DevSource &s, const EnvGroupDesc
     const unsigned dL = kL >= 0 ? near_off + (unsigned)G.ps_off[4] : 0u;
     F4 Ab[4], Aa[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { Ab[c] = ld_off<F4>(bb, o[c] + dA); Aa[c] = ld_off<F4>(ba, o[c] + dA); }
+    for (int c = 0; c < 4; ++c) { Ab[c] = L.template ld<F4>(0, o[c] + dA); Aa[c] = L.template ld<F4>(1, o[c] + dA); }
     const int ps_static = G.ps_static;
-    const float Lb = ld_off<float>(bb, dL);
+    const float Lb = L.template ld<float>(0, dL);
     float La;
-    if (ps_static & 16) La = Lb; else La = ld_off<float>(ba, dL);   // same values at both levels: one gather less
+    if (ps_static & 16) La = Lb; else La = L.template ld<float>(1, dL);   // same values at both levels: one gather less
     if (kA >= 0) {
       double v0, v1;
       burst_math<4>(mA, [&](int t, int c, int q) { const F4 &r = t ? Aa[c] : Ab[c]; return q == 0 ? r.x : q == 1 ? r.y : q == 2 ? r.z : r.w; },
@@ -1402,28 +1374,28 @@ __device__ __forceinline__ void env_burst(const DevSource &s, const EnvGroupDesc
     // condition that also guards its arithmetic lets the compiler merge the two blocks -- gathers, wait, arithmetic, slot by
     // slot -- 1.26 -> 1.45 ms per step; a zero-length buffer descriptor for empty slots 1.26 -> 1.31)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { Bb[c] = ld_off<F2>(bb, o[c] + dB); Ba[c] = ld_off<F2>(ba, o[c] + dB); }
+    for (int c = 0; c < 4; ++c) { Bb[c] = L.template ld<F2>(0, o[c] + dB); Ba[c] = L.template ld<F2>(1, o[c] + dB); }
     // (a slot whose variable holds the same values at both time levels -- ps_static, from the blocks' content ids -- is
     // gathered once: four 32-cycle gathers less; the copies sit behind the slot's own last load, where the arithmetic
     // waits anyway)
     const int ps_static = G.ps_static;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) Cb[c] = ld_off<F2>(bb, o[c] + dC);
+    for (int c = 0; c < 4; ++c) Cb[c] = L.template ld<F2>(0, o[c] + dC);
     if (ps_static & 4) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) Ca[c] = Cb[c];
     } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) Ca[c] = ld_off<F2>(ba, o[c] + dC);
+      for (int c = 0; c < 4; ++c) Ca[c] = L.template ld<F2>(1, o[c] + dC);
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) Db[c] = ld_off<float>(bb, o[c] + dD);
+    for (int c = 0; c < 4; ++c) Db[c] = L.template ld<float>(0, o[c] + dD);
     if (ps_static & 8) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) Da[c] = Db[c];
     } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) Da[c] = ld_off<float>(ba, o[c] + dD);
+      for (int c = 0; c < 4; ++c) Da[c] = L.template ld<float>(1, o[c] + dD);
     }
     if (kB >= 0) {
       double v0, v1;
@@ -1444,14 +1416,12 @@ __device__ __forceinline__ void env_burst(const DevSource &s, const EnvGroupDesc
   ODR_PT_USE(out[3]); ODR_PT_USE(out[4]); ODR_PT(16);
 }
 
-// BURST_ONLY: the caller guarantees G.burst (the fused step kernel: groups that do not fit the slots take the separate launches)
-template <int PROJ, bool BURST_ONLY, bool ZT>
-__device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroupDesc &G, double lon,
-                                               double lat, double z, float *out /*[MAXG]*/, const double *zt,
-                                               ZBracket &zb_out ODR_PT_PARAM) {
-  ODR_PT(10);
-  const DevSource &s = W.src[G.sid];
-  const DevBlock &geo = s.slot[G.geo_slot];
+// The reader front door of the main-loop sample (longitude convention, projection, coverage, fractional grid indices):
+// computed once per particle; k_step_tile also takes the footprint rectangle of its workgroup from it.
+struct EnvFront { double x, y, xi, yi; bool covered; };
+template <int PROJ>
+__device__ __forceinline__ EnvFront env_front(const DevSource &s, const DevBlock &geo, double lon, double lat, double z) {
+  EnvFront f;
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
   double x, y;
@@ -1463,7 +1433,26 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
     if (s.lon_mode == 1) xchk = np_mod(x + 180.0, 360.0) - 180.0;
     else if (s.lon_mode == 2) xchk = np_mod(x, 360.0);
   }
-  const bool covered = xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin && z <= s.zmax;
+  f.covered = xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin && z <= s.zmax;
+  if (s.mod360_x) x = np_mod(x, 360.0);
+  f.x = x; f.y = y;
+  f.xi = __dmul_rn(div_cr(x - geo.x0, geo.xspan, geo.ixspan), (double)(geo.nx - 1));
+  f.yi = __dmul_rn(div_cr(y - geo.y0, geo.yspan, geo.iyspan), (double)(geo.ny - 1));
+  return f;
+}
+
+// BURST_ONLY: the caller guarantees G.burst (the fused step kernel: groups that do not fit the slots take the separate launches)
+// L: the loader of the node records (LdGlobal of G.bb / G.ba, or the workgroup's LDS tile); returns false when the
+// footprint or the land mask's nearest node is outside the loader's image (LdTile) -- `out` is then meaningless.
+template <int PROJ, bool BURST_ONLY, bool ZT, class LD>
+__device__ __forceinline__ bool env_group_sample(const DevWorld &W, const EnvGroupDesc &G, const LD &L, const EnvFront &fr,
+                                                 double z, float *out /*[MAXG]*/, const double *zt,
+                                                 ZBracket &zb_out ODR_PT_PARAM) {
+  ODR_PT(10);
+  const DevSource &s = W.src[G.sid];
+  const DevBlock &geo = s.slot[G.geo_slot];
+  const double x = fr.x, y = fr.y;
+  const bool covered = fr.covered;
   double val[MAXG];
   const bool burst = BURST_ONLY || G.burst;
   if (burst) {
@@ -1480,9 +1469,7 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
   }
   ODR_PT_USE(covered); ODR_PT(11);
   if (covered) {
-    if (s.mod360_x) x = np_mod(x, 360.0);
-    const double xi = __dmul_rn(div_cr(x - geo.x0, geo.xspan, geo.ixspan), (double)(geo.nx - 1));
-    const double yi = __dmul_rn(div_cr(y - geo.y0, geo.yspan, geo.iyspan), (double)(geo.ny - 1));
+    const double xi = fr.xi, yi = fr.yi;
     ODR_PT_USE(xi); ODR_PT_USE(yi); ODR_PT(12);
     ZBracket zb;
     zb.iz0 = 0; zb.same = 0; zb.wa = 1;
@@ -1491,16 +1478,18 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
     ODR_PT_USE(zb.iz0); ODR_PT_USE(zb.wa); ODR_PT(13);
     // shared by all variables and both time levels: bilinear footprint, nearest node (land mask)
     const unsigned rec_bytes = (unsigned)geo.rec * 4u;
-    const Foot ft = footprint(yi, xi, geo.ny, geo.nx, rec_bytes);
+    bool ok, ok_near = true;
+    const Foot ft = L.foot(yi, xi, geo.ny, geo.nx, rec_bytes, ok);
     unsigned near_off = 0;
     if (G.has_land)
-      near_off = __umul24(__umul24((unsigned)nearest_index(y, geo.ymin, geo.yrange, geo.iyrange, geo.ny), (unsigned)geo.nx) +
-                              (unsigned)nearest_index(x, geo.xmin, geo.xrange, geo.ixrange, geo.nx),
-                          rec_bytes);
+      near_off = L.node(nearest_index(y, geo.ymin, geo.yrange, geo.iyrange, geo.ny),
+                        nearest_index(x, geo.xmin, geo.xrange, geo.ixrange, geo.nx), geo.nx, rec_bytes, ok_near);
+    if (!(ok && ok_near)) return false;
     const bool tl = G.ba != nullptr && !G.all_static;
     ODR_PT_USE(ft.o00); ODR_PT_USE(ft.o11); ODR_PT_USE(near_off); ODR_PT(14);
-    if (burst) env_burst<PROJ>(s, G, ft, zb, near_off, tl, x, y, out ODR_PT_ARG);
+    if (burst) env_burst<PROJ>(s, G, L, ft, zb, near_off, tl, x, y, out ODR_PT_ARG);
     else if constexpr (!BURST_ONLY) {
+    static_assert(BURST_ONLY || sizeof(LD) == sizeof(LdGlobal), "the serial sampler reads the blocks in HBM");
 #pragma unroll
     for (int k = 0; k < MAXG; ++k) {
       if (k >= G.nv) break;
@@ -1552,7 +1541,7 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
     }
     }
   }
-  if (burst) return;
+  if (burst) return true;
 #pragma unroll
   for (int k = 0; k < MAXG; ++k) {
     if (k >= G.nv) break;
@@ -1560,8 +1549,25 @@ __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroup
     f = isfinite(f) ? f : (isfinite(G.fallback[k]) ? G.fallback[k] : f);
     out[k] = G.var[k] == VAR_TEMP ? kelvin_to_celsius(f) : f;
   }
+  return true;
 }
 
+// the global loader of the group's two bracketing levels
+__device__ __forceinline__ LdGlobal env_global(const EnvGroupDesc &G) {
+  LdGlobal g;
+  g.b = G.bb;
+  g.a = (G.ba != nullptr && !G.all_static) ? G.ba : G.bb;
+  return g;
+}
+// front door + sample from the blocks in HBM
+template <int PROJ, bool BURST_ONLY, bool ZT>
+__device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroupDesc &G, double lon,
+                                               double lat, double z, float *out /*[MAXG]*/, const double *zt,
+                                               ZBracket &zb_out ODR_PT_PARAM) {
+  const DevSource &s = W.src[G.sid];
+  const EnvFront fr = env_front<PROJ>(s, s.slot[G.geo_slot], lon, lat, z);
+  env_group_sample<PROJ, BURST_ONLY, ZT>(W, G, env_global(G), fr, z, out, zt, zb_out ODR_PT_ARG);
+}
 // for the kernels that need neither LDS tables nor the bracket
 template <int PROJ>
 __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroupDesc &G, double lon, double lat, double z, float *out) {

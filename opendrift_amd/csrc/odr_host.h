@@ -129,6 +129,16 @@ struct odr_particles {
   long long env_cn[NVAR];
   bool env_cok[NVAR];
   bool external;
+  // workgroup table of the last odr_sort_particles (k_wg_count / k_wg_fill; read by k_step_tile): (first, count) ranges that
+  // partition [0, wg_n), each inside one sort tile of source wg_sid.  Valid while no element has been appended (n <= wg_n);
+  // compaction only shortens the set (ranges are cut at n; elements moved into holes are found outside their range's
+  // rectangle and take the global path).
+  unsigned *wg_tab, *wg_list;                // wg_list: the particles the last k_step_tile handed to k_step_list
+  unsigned long long *wg_total, *wg_stats;   // device: wg_total[0] table length, [1] length of wg_list; wg_stats = wg_total + 2: [0] sum of the list lengths, [1] rectangles cut
+  long long wg_cap, wg_grid, wg_n, wg_list_cap;
+  unsigned long long wg_launches;            // host: launches that took the LDS-tile path
+  int wg_sid;
+  bool wg_valid;
 };
 
 static inline unsigned nblk(long long n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
@@ -294,6 +304,7 @@ int odr_i_ensure_ranks(odr_ctx *c, odr_particles *p);
 bool odr_i_build_env_group(const odr_ctx *c, const int *grp, int ng, double t, EnvGroupDesc &G);
 void odr_i_phase_dump();   // odr_step.hip
 bool odr_i_uv_fast_source(const odr_ctx *c, int &sid, double t_lo, double t_hi);
+
 bool odr_i_gyre_source(const odr_ctx *c, int var, int &sid);
 int odr_i_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t, float *const *out_host,
                      bool record_positions);

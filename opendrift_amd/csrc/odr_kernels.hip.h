@@ -608,12 +608,21 @@ __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W
 
 // fast version: (u,v) from one gridded reader, interleaved z-innermost blocks, host-resolved
 // time brackets (odr_field.hip.h "fast (u,v) path")
-template <int SCHEME, int PROJ, bool IS3D, bool NOISE, bool TILE = false, int SM = 0, bool PARK = false>
+// lh / lf: the loaders of the half-step and full-step stage samples (uv_global(th / tf), or the workgroup's LDS tile: a
+// stage footprint that leaves the tile's rectangle is sampled from the blocks in HBM instead -- same values)
+template <int PROJ, bool IS3D, int SM, class LD>
+__device__ __forceinline__ void uv_stage_or_global(const DevSource &s, const DevBlock &geo, const UVTime &tm, const LD &ld, double lon,
+                                                   double lat, double z, const ZBracket &zb, float fbu, float fbv, float &uo,
+                                                   float &vo, const ProjStart &ps) {
+  if (!uv_stage<PROJ, IS3D, SM>(s, geo, tm, ld, lon, lat, z, zb, fbu, fbv, uo, vo, ps)) {
+    if constexpr (sizeof(LD) != sizeof(LdGlobal)) uv_stage<PROJ, IS3D, SM>(s, geo, tm, uv_global(tm), lon, lat, z, zb, fbu, fbv, uo, vo, ps);
+  }
+}
+template <int SCHEME, int PROJ, bool IS3D, bool NOISE, int SM = 0, bool PARK = false, class LD = LdGlobal>
 __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBlock &geo, double &lon, double &lat,
                                                  double z, float u1, float v1, float f, int moving, double dt,
-                                                 const UVTime &th, const UVTime &tf, float fbu, float fbv,
+                                                 const UVTime &th, const UVTime &tf, const LD &lh, const LD &lf, float fbu, float fbv,
                                                  const StageNoise &N, long long i, long long n, int id,
-                                                 const TileView &T = TileView(), bool tile_h = false, bool tile_f = false,
                                                  ZBracket zb_pre = ZBracket(), bool have_pre = false,
                                                  double *park = nullptr ODR_PT_PARAM) {
   float fu, fv;
@@ -649,7 +658,7 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
     }
     stage_pos<SM>(ODR_O, u1, v1, dtf, lon2, lat2);
     ODR_PT_USE(lon2); ODR_PT_USE(lat2); ODR_PT(4);
-    uv_stage<PROJ, IS3D, TILE, SM>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u2, v2, T, tile_h, ps);
+    uv_stage_or_global<PROJ, IS3D, SM>(s, geo, th, lh, lon2, lat2, z, zb, fbu, fbv, u2, v2, ps);
     if (NOISE) add_current_noise(N, 1, i, n, id, u2, v2);
     ODR_PT_USE(u2); ODR_PT_USE(v2); ODR_PT(5);
     if (SCHEME == 1) {
@@ -658,11 +667,11 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
     } else {
       float u3, v3, u4, v4;
       stage_pos<SM>(ODR_O, u2, v2, dtf, lon2, lat2);
-      uv_stage<PROJ, IS3D, TILE, SM>(s, geo, th, lon2, lat2, z, zb, fbu, fbv, u3, v3, T, tile_h, ps);
+      uv_stage_or_global<PROJ, IS3D, SM>(s, geo, th, lh, lon2, lat2, z, zb, fbu, fbv, u3, v3, ps);
       if (NOISE) add_current_noise(N, 2, i, n, id, u3, v3);
       ODR_PT_USE(u3); ODR_PT_USE(v3); ODR_PT(6);
       stage_pos<SM>(ODR_O, u3, v3, dtf, lon2, lat2);
-      uv_stage<PROJ, IS3D, TILE, SM>(s, geo, tf, lon2, lat2, z, zb, fbu, fbv, u4, v4, T, tile_f, ps);
+      uv_stage_or_global<PROJ, IS3D, SM>(s, geo, tf, lf, lon2, lat2, z, zb, fbu, fbv, u4, v4, ps);
       if (NOISE) add_current_noise(N, 3, i, n, id, u4, v4);
       ODR_PT_USE(u4); ODR_PT_USE(v4); ODR_PT(7);
       fu = __fmul_rn(rk4_mix(u1, u2, u3, u4), f);
@@ -682,9 +691,9 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_WAVES(PROJ)) void k_advect_grid(con
   const DevSource &s = W->src[sid];
   const DevBlock &geo = s.slot[geo_slot];
   double lon = p.lon[i], lat = p.lat[i];
-  advect_grid_body<SCHEME, PROJ, IS3D, NOISE, false, SM>(s, geo, lon, lat, p.z[i], p.env[VAR_U][i], p.env[VAR_V][i],
-                                              __fmul_rn(current_factor(p, i, factor), p.cdf[i]), p.moving[i], dt, th, tf, W->fallback[VAR_U],
-                                              W->fallback[VAR_V], N, i, p.n, NOISE ? p.id[i] : 0);
+  advect_grid_body<SCHEME, PROJ, IS3D, NOISE, SM>(s, geo, lon, lat, p.z[i], p.env[VAR_U][i], p.env[VAR_V][i],
+                                              __fmul_rn(current_factor(p, i, factor), p.cdf[i]), p.moving[i], dt, th, tf, uv_global(th), uv_global(tf),
+                                              W->fallback[VAR_U], W->fallback[VAR_V], N, i, p.n, NOISE ? p.id[i] : 0);
   p.lon[i] = lon;
   p.lat[i] = lat;
 }
@@ -708,8 +717,7 @@ struct StepDesc {
   int ssh_slot;                     // group slot of sea_surface_height, or -1: sampled by the preceding launch (p.env[SSH])
 };
 
-// TILE: the (u,v) node records around the workgroup's particles are staged in LDS for the stage samples (odr_field.hip.h
-// "LDS field tile"); tile_nodes = capacity of the dynamic LDS allocation in nodes.
+// (The LDS field tile is a kernel of its own since round 4: k_step_tile, odr_tile.hip.h.)
 // MIXQ > 0: OceanDrift.vertical_mixing (+ vertical_advection) of the same step runs in this launch as well (the body of
 // k_vmix_col<MIXQ, MIXTL>): the K column is gathered at the sample position while the particle is in registers, the
 // random walk follows the horizontal move; z, moving, depth, ssh and the sample position are not written and read
@@ -724,22 +732,21 @@ struct StepMix {
 #define ODR_PARK_WAVES 5
 #endif
 #if defined(ODR_FULL_GEODESIC) || defined(ODR_NO_PARK)
-#define ODR_STEP_PARKS(SCHEME, PROJ, TILE, MIXQ) false
+#define ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) false
 #else
-#define ODR_STEP_PARKS(SCHEME, PROJ, TILE, MIXQ) ((SCHEME) > 0 && !(TILE) && (MIXQ) == 0 && ((PROJ) == PROJ_LATLONG || (PROJ) == PROJ_CURVILINEAR))
+#define ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ((SCHEME) > 0 && (MIXQ) == 0 && ((PROJ) == PROJ_LATLONG || (PROJ) == PROJ_CURVILINEAR))
 #endif
-template <int SCHEME, int PROJ, bool IS3D, bool NOISE, bool TILE = false, int MIXQ = 0, bool MIXTL = false, int SM = 0>
-__global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, TILE, MIXQ) ? ODR_PARK_WAVES : ((MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_WAVES) ? ODR_MIX_WAVES : ODR_STEP_WAVES(PROJ))) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
+template <int SCHEME, int PROJ, bool IS3D, bool NOISE, int MIXQ = 0, bool MIXTL = false, int SM = 0>
+__global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PARK_WAVES : ((MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_WAVES) ? ODR_MIX_WAVES : ODR_STEP_WAVES(PROJ))) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
                                                      StepDesc S, double dt, float factor, UVTime th, UVTime tf,
-                                                     unsigned long long *n_hit, StageNoise N, int tile_nodes = 0,
+                                                     unsigned long long *n_hit, StageNoise N,
                                                      StepMix M = StepMix()) {
-  static_assert(!(TILE && MIXQ > 0), "the LDS tile and the fused mixing both use the dynamic LDS allocation");
-  static_assert(!(SM != 0 && (TILE || MIXQ > 0)), "the fast stage math exists for the plain step kernel only");
+  static_assert(!(SM != 0 && MIXQ > 0), "the fast stage math exists for the plain step kernel only");
   long long i = pid();
   bool hit = false;
   ODR_PT_DECL;
   ODR_PT(0);
-  constexpr bool PARK = ODR_STEP_PARKS(SCHEME, PROJ, TILE, MIXQ);
+  constexpr bool PARK = ODR_STEP_PARKS(SCHEME, PROJ, MIXQ);
   __shared__ double s_park[PARK ? GEOD_PARK * BLOCK : 1];
   __shared__ double s_zt[IS3D ? 3 * MAXNZ : 1];   // interp1d tables of the reader's z grid (zinterp)
   const double *zt = nullptr;
@@ -754,93 +761,6 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, TILE, MIXQ) ? O
     if ((int)threadIdx.x < M.D.nzp) {
       const int t_ = threadIdx.x;
       gsh[t_] = sk.vg_a[t_]; gsh[NL + t_] = sk.vg_b[t_]; gsh[2 * NL + t_] = sk.vg_c[t_]; gsh[3 * NL + t_] = sk.zmid[t_];
-    }
-    __syncthreads();
-  }
-  TileView T;
-  T.t = nullptr; T.x0 = T.y0 = T.w = T.h = 0; T.nz = 1;
-  bool tile_h = false, tile_f = false;
-  if (TILE) {
-    extern __shared__ __attribute__((aligned(16))) char tile_mem[];
-    __shared__ int s_red[2][BLOCK / 64][4];
-    __shared__ int s_anchor[2];
-    const DevSource &s = W->src[G.sid];
-    const DevBlock &geo = s.slot[S.geo_slot_uv];
-    const int tid = threadIdx.x, wv = tid >> 6;
-    // cell of this particle's position in the block's index space (the main-loop sample position)
-    int cx = 0x7fffffff, cy = 0x7fffffff;
-    if (i < p.n) {
-      double lon = p.lon[i], lat = p.lat[i], x, y;
-      if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
-      else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
-      if (PROJ == PROJ_LATLONG) { x = lon; y = lat; }
-      else if (PROJ == PROJ_CURVILINEAR) curvi_locate(s.proj, lon, lat, x, y);
-      else proj_fwd<PROJ == PROJ_STERE_POLAR>(s.proj, lon, lat, x, y);
-      if (s.mod360_x) x = np_mod(x, 360.0);
-      const double fx = floor((x - geo.x0) * geo.ixspan * (double)(geo.nx - 1));
-      const double fy = floor((y - geo.y0) * geo.iyspan * (double)(geo.ny - 1));
-      if (fx >= 0 && fx <= (double)(geo.nx - 1) && fy >= 0 && fy <= (double)(geo.ny - 1)) { cx = (int)fx; cy = (int)fy; }
-    }
-    const bool have = cx != 0x7fffffff;
-    auto block_minmax = [&](int slot, bool use, int &mnx, int &mxx, int &mny, int &mxy) {
-      int a = use ? cx : 0x7fffffff, b = use ? cx : -0x7fffffff, c = use ? cy : 0x7fffffff, d = use ? cy : -0x7fffffff;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        a = min(a, __shfl_xor(a, o, 64)); b = max(b, __shfl_xor(b, o, 64));
-        c = min(c, __shfl_xor(c, o, 64)); d = max(d, __shfl_xor(d, o, 64));
-      }
-      if ((tid & 63) == 0) { s_red[slot][wv][0] = a; s_red[slot][wv][1] = b; s_red[slot][wv][2] = c; s_red[slot][wv][3] = d; }
-      if (slot == 0 && tid == BLOCK / 2) { s_anchor[0] = cx; s_anchor[1] = cy; }
-      __syncthreads();
-      mnx = s_red[slot][0][0]; mxx = s_red[slot][0][1]; mny = s_red[slot][0][2]; mxy = s_red[slot][0][3];
-#pragma unroll
-      for (int k = 1; k < BLOCK / 64; ++k) {
-        mnx = min(mnx, s_red[slot][k][0]); mxx = max(mxx, s_red[slot][k][1]);
-        mny = min(mny, s_red[slot][k][2]); mxy = max(mxy, s_red[slot][k][3]);
-      }
-    };
-    int mnx, mxx, mny, mxy;
-    block_minmax(0, have, mnx, mxx, mny, mxy);
-    // nodes needed: one cell of margin around the cells (a stage position is < 1 cell from the particle) plus the
-    // upper corner of the footprint: [mnx - 1, mxx + 2] x [mny - 1, mxy + 2]
-    bool any = mxx >= mnx;
-    if (any && (long long)(mxx - mnx + 4) * (long long)(mxy - mny + 4) > (long long)tile_nodes) {
-      // the workgroup straddles two sort tiles or holds stragglers: keep the cluster around its middle particle
-      const int ax = s_anchor[0], ay = s_anchor[1];
-      const bool nearby = have && ax != 0x7fffffff && abs(cx - ax) <= 5 && abs(cy - ay) <= 3;
-      block_minmax(1, nearby, mnx, mxx, mny, mxy);
-      any = mxx >= mnx && (long long)(mxx - mnx + 4) * (long long)(mxy - mny + 4) <= (long long)tile_nodes;
-    }
-    if (any) {
-      const int x0 = max(mnx - 1, 0), x1 = min(mxx + 2, geo.nx - 1), y0 = max(mny - 1, 0), y1 = min(mxy + 2, geo.ny - 1);
-      T.t = (const F2a *)tile_mem;
-      T.x0 = x0; T.y0 = y0; T.w = x1 - x0 + 1; T.h = y1 - y0 + 1;
-      T.nz = IS3D ? s.nz : 1;
-      // the tile holds the time bracket of the half-step stages; the full-step stage uses it when its bracket is the same
-      tile_h = true;
-      tile_f = tf.b == th.b && (tf.a == th.a || tf.a == nullptr);
-      // cooperative load, coalesced along the node records: `lpn` lanes per node (the next power of two >= the
-      // 2 nz (u,v) pairs of a node), BLOCK / lpn nodes per sweep; the node's (column, row) advances without divisions
-      const int per = 2 * T.nz, nodes = T.w * T.h;
-      int lpn = 2;
-      while (lpn < per) lpn <<= 1;
-      const int nps = BLOCK / lpn, r = tid & (lpn - 1);
-      int node = tid / lpn;                       // lpn is a power of two: a shift
-      int ny_ = node / T.w, nx_ = node - ny_ * T.w;   // once per thread
-      const int tm = r >= T.nz ? 1 : 0, k = r - tm * T.nz;
-      const float *src = tm ? (th.a ? th.a : th.b) : th.b;
-      const unsigned rec_bytes = (unsigned)geo.rec * 4u;
-      F2a *dst = (F2a *)tile_mem;
-      for (; node < nodes; node += nps) {
-        if (r < per) {
-          const unsigned off = __umul24(__umul24((unsigned)(y0 + ny_), (unsigned)geo.nx) + (unsigned)(x0 + nx_), rec_bytes) + 8u * (unsigned)k;
-          const F2 v = ld_off<F2>(src, off);
-          F2a w; w.x = v.x; w.y = v.y;
-          dst[node * per + r] = w;
-        }
-        nx_ += nps;
-        while (nx_ >= T.w) { nx_ -= T.w; ++ny_; }
-      }
     }
     __syncthreads();
   }
@@ -925,9 +845,9 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, TILE, MIXQ) ? O
     ODR_PT(3);
     if (!skip) {
       const DevSource &s = W->src[G.sid];
-      advect_grid_body<SCHEME, PROJ, IS3D, NOISE, TILE, SM, PARK>(s, s.slot[S.geo_slot_uv], lon, lat, zz, out[0], out[1],
-                                                        __fmul_rn(current_factor(p, i, factor), cdf0), moving, dt, th, tf, W->fallback[VAR_U],
-                                                        W->fallback[VAR_V], N, i, p.n, id, T, tile_h, tile_f, zb_env, IS3D && zz == z, PARK ? s_park + threadIdx.x : nullptr ODR_PT_ARG);
+      advect_grid_body<SCHEME, PROJ, IS3D, NOISE, SM, PARK>(s, s.slot[S.geo_slot_uv], lon, lat, zz, out[0], out[1],
+                                                        __fmul_rn(current_factor(p, i, factor), cdf0), moving, dt, th, tf, uv_global(th), uv_global(tf),
+                                                        W->fallback[VAR_U], W->fallback[VAR_V], N, i, p.n, id, zb_env, IS3D && zz == z, PARK ? s_park + threadIdx.x : nullptr ODR_PT_ARG);
     }
     ODR_PT_USE(lon); ODR_PT_USE(lat); ODR_PT(8);
     if (MIXQ > 0) {   // vertical_mixing + vertical_advection (oceandrift.py:397-571, :315-350) after the horizontal move
@@ -2903,3 +2823,5 @@ __global__ __launch_bounds__(BLOCK) void k_blk_records(BlkPrep Q, float *__restr
 
 #endif  // ODR_TU_MISC
 }  // namespace odr
+
+#include "odr_tile.hip.h"   // the workgroup table of a sorted set (ODR_TU_MISC) and the LDS-tile step kernel (ODR_TU_TILE)

@@ -287,6 +287,11 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
     if ((rc = step_in_lanes(c, p, lanes, G, S, scheme, t, dt, factor, N, extras))) return rc;
     return coast_action ? read_counter(c, n_on_land) : 0;
   }
+  if (odr_i_step_tile(c, p, G, S, scheme, t, dt, factor, N)) {   // the records of the workgroup's node rectangle in LDS (odr_tile.hip.h)
+    HIPCHK(hipGetLastError());
+    if ((rc = coast_action ? read_counter(c, n_on_land) : 0)) return rc;
+    return want_mix ? mix_after(c, p, t, dt, extras) : 0;
+  }
   if (N.on && (scheme > 0 || main_noise)) {
     if (scheme > 0 && N.rng_mode == ODR_RNG_HOST && !N.stage) return fail(ODR_ERR_INVALID, "no host draws for the Runge-Kutta stage calls");
     if (N.sm == ODR_STAGE_FAST && scheme > 0) odr_i_step_fast_noise(c, p, G, S, scheme, t, dt, factor, N);

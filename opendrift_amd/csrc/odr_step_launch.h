@@ -71,26 +71,9 @@ static void launch_step_grid(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G
   dim3 g(nblk(p->n)), b(BLOCK);
   PView v = view(p);
   float f = (float)factor;
-  // LDS tile of the (u,v) records for the Runge-Kutta stage samples (odr_field.hip.h "LDS field tile").  Measured on C3
-  // (profiles/r02_ab_variants.txt): the tile does NOT pay -- with the spatially sorted layout the stage gathers are
-  // served by L1 / L2 and cost 0.03 ms of the 1.7 ms step (build without field loads: -DODR_ABLATE_LOADS), less than
-  // staging the tile costs.  It therefore stays off unless ODR_LDS_TILE=1 asks for it (A/B runs and the bit-identity
-  // test tests/test_gpu_fused_step.py::test_lds_tile_gives_the_same_bits_as_global_gathers).
-  const int nzu = is3d ? s.nz : 1;
-  const int tile_nodes = 160;
-  const size_t tile_bytes = (size_t)tile_nodes * 2 * (size_t)nzu * 8;
-  const char *tile_min = getenv("ODR_LDS_TILE_MIN_N");     // tests lower the threshold to exercise the tile on small sets
-  const bool tile = SM == 0 && SCHEME > 0 && (s.proj.kind == PROJ_LATLONG || odr_proj_template(s.proj) == PROJ_STERE_POLAR) && tile_bytes <= 40 * 1024 && nzu <= 32 &&
-                    p->n >= (tile_min ? atoll(tile_min) : 65536) && getenv("ODR_LDS_TILE") && !getenv("ODR_NO_LDS_TILE");
   // what-if runs: ODR_OCC_LDS=<bytes> of (unused) dynamic LDS per workgroup caps the workgroups per CU (160 KiB / bytes)
   static const size_t occ_lds = getenv("ODR_OCC_LDS") ? (size_t)atoll(getenv("ODR_OCC_LDS")) : 0;
-#define ODR_LAUNCH(PROJ, D3) hipLaunchKernelGGL((k_step_grid<SCHEME, PROJ, D3, NOISE, false, 0, false, SM>), g, b, occ_lds, c->stream, c->dw, v, G, S, dt, f, th, tf, c->counter, N, 0)
-#define ODR_LAUNCH_TILE(PROJ, D3) hipLaunchKernelGGL((k_step_grid<SCHEME, PROJ, D3, NOISE, true>), g, b, tile_bytes, c->stream, c->dw, v, G, S, dt, f, th, tf, c->counter, N, tile_nodes)
-  if constexpr (SCHEME > 0 && SM == 0) if (tile) {
-    if (s.proj.kind == PROJ_LATLONG) { if (is3d) ODR_LAUNCH_TILE(PROJ_LATLONG, true); else ODR_LAUNCH_TILE(PROJ_LATLONG, false); }
-    else { if (is3d) ODR_LAUNCH_TILE(PROJ_STERE_POLAR, true); else ODR_LAUNCH_TILE(PROJ_STERE_POLAR, false); }
-    return;
-  }
+#define ODR_LAUNCH(PROJ, D3) hipLaunchKernelGGL((k_step_grid<SCHEME, PROJ, D3, NOISE, 0, false, SM>), g, b, occ_lds, c->stream, c->dw, v, G, S, dt, f, th, tf, c->counter, N)
   switch (odr_proj_template(s.proj)) {
     case PROJ_LATLONG: if (is3d) ODR_LAUNCH(PROJ_LATLONG, true); else ODR_LAUNCH(PROJ_LATLONG, false); break;
     case PROJ_STERE_POLAR: if (is3d) ODR_LAUNCH(PROJ_STERE_POLAR, true); else ODR_LAUNCH(PROJ_STERE_POLAR, false); break;
@@ -98,7 +81,6 @@ static void launch_step_grid(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G
     default: if (is3d) ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, true); else ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, false); break;
   }
 #undef ODR_LAUNCH
-#undef ODR_LAUNCH_TILE
 }
 
 template <bool NOISE, int SM = 0>
@@ -109,6 +91,9 @@ static void step_dispatch(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, c
   else launch_step_grid<2, NOISE, SM>(c, p, G, S, t, dt, factor, N);
 }
 
+// odr_step_tile.hip: the fused step on the workgroup's LDS tile; false when it does not apply (the caller launches k_step_grid)
+bool odr_i_step_tile(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, StepDesc S, int scheme, double t, double dt,
+                     double factor, const StageNoise &N);
 // defined in odr_step_mix.hip: the step with OceanDrift.vertical_mixing inside the launch
 void odr_i_step_mix(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, const StepDesc &S, int scheme, double t, double dt,
                     double factor, const StepMix &M);

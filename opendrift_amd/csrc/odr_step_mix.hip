@@ -13,8 +13,8 @@ static void launch_mix(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G0, Ste
   StageNoise N;
   memset(&N, 0, sizeof N);
   const size_t lds = sizeof(double) * ((size_t)(4 * NQ) * BLOCK + 4 * (size_t)(4 * NQ));
-  hipLaunchKernelGGL((k_step_grid<SCHEME, PROJ_LATLONG, true, false, false, NQ, TL>), dim3(nblk(p->n)), dim3(BLOCK), lds, c->stream,
-                     c->dw, view(p), G, S, dt, (float)factor, th, tf, c->counter, N, 0, M);
+  hipLaunchKernelGGL((k_step_grid<SCHEME, PROJ_LATLONG, true, false, NQ, TL>), dim3(nblk(p->n)), dim3(BLOCK), lds, c->stream,
+                     c->dw, view(p), G, S, dt, (float)factor, th, tf, c->counter, N, M);
 }
 
 template <int SCHEME>

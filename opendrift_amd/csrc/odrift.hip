@@ -146,6 +146,7 @@ int odr_particles_destroy(odr_ctx *c, odr_particles *p) {
   fr(p->bcount);
   fr(p->scratch);
   fr(p->rank); fr(p->rank_words); fr(p->rank_before); fr(p->rank_bsum);
+  fr(p->wg_tab); fr(p->wg_total); fr(p->wg_list);
   delete p;
   return 0;
 }
@@ -1889,8 +1890,10 @@ int odr_sort_particles_ex(odr_ctx *c, odr_particles *p, int32_t sid, int keep_en
   unsigned nbins = (unsigned)(ntx * nty * 64 + 1);
   size_t n = (size_t)p->n;
   void *sc;
-  if ((rc = scratch(c, p, sizeof(unsigned) * (2 * n + nbins + nbins / 1024 + 64), &sc))) return rc;
+  const int ntiles = ntx * nty;
+  if ((rc = scratch(c, p, sizeof(unsigned) * (2 * n + nbins + nbins / 1024 + 64 + (size_t)ntiles + 1 + (size_t)ntiles / 1024 + 64), &sc))) return rc;
   unsigned *keys = (unsigned *)sc, *perm = keys + n, *hist = perm + n;
+  unsigned *wg_nw = hist + nbins + nbins / 1024 + 64;
   HIPCHK(hipMemsetAsync(hist, 0, sizeof(unsigned) * nbins, c->stream));
   hipLaunchKernelGGL(k_sort_hist, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, c->dw, sid, slot, view(p), ntx, nbins,
                      keys, hist);
@@ -1902,6 +1905,25 @@ int odr_sort_particles_ex(odr_ctx *c, odr_particles *p, int32_t sid, int keep_en
     hipLaunchKernelGGL(k_scan_add, dim3(nsb), dim3(1024), 0, c->stream, hist, (long long)nbins, bsum);
   }
   hipLaunchKernelGGL(k_sort_perm, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, keys, p->n, hist, perm);
+  {   // workgroup table for k_step_tile (odr_tile.hip.h): hist[] now holds the END offset of every key
+    p->wg_valid = false;
+    const long long cap = std::min<long long>((long long)ntiles + 1, p->n) + p->n / BLOCK + 1;
+    if (!p->wg_total) {
+      HIPCHK(hipMalloc((void **)&p->wg_total, sizeof(unsigned long long) * 4));
+      HIPCHK(hipMemsetAsync(p->wg_total, 0, sizeof(unsigned long long) * 4, c->stream));
+      p->wg_stats = p->wg_total + 2;
+    }
+    if (p->wg_cap < cap) {
+      if (p->wg_tab) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(p->wg_tab)); p->wg_tab = nullptr; }
+      HIPCHK(hipMalloc((void **)&p->wg_tab, sizeof(unsigned) * 2 * (size_t)cap));
+      p->wg_cap = cap;
+    }
+    const unsigned nt1 = (unsigned)ntiles + 1;
+    hipLaunchKernelGGL(k_wg_count, dim3((nt1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, hist, ntiles, wg_nw);
+    hipLaunchKernelGGL(k_cmp_scan, dim3(1), dim3(1024), 0, c->stream, wg_nw, (long long)nt1, p->wg_total);   // exclusive, in place
+    hipLaunchKernelGGL(k_wg_fill, dim3((nt1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, hist, ntiles, wg_nw, p->wg_tab, (unsigned)cap);
+    p->wg_grid = cap; p->wg_n = p->n; p->wg_sid = sid; p->wg_valid = true;
+  }
   CmpArrays A;
   all_arrays(p, A, with_env);
   hipLaunchKernelGGL(k_gather_perm, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, perm, p->n, A);

@@ -789,6 +789,14 @@ class Particles:
         check(self.lib.odr_sort_particles_ex(self.ctx.h, self.h, int(source_id), int(bool(keep_environment))))
         self._permuted = True
 
+    def tile_stats(self):
+        """Diagnostics of the LDS-tile step (odr_particles_tile_stats): launches on that path, elements they handed to the
+        HBM path, rectangles cut to the LDS capacity, workgroup ranges of the current table."""
+        import ctypes as C
+        out = (C.c_uint64 * 4)()
+        check(self.lib.odr_particles_tile_stats(self.ctx.h, self.h, out))
+        return dict(launches=int(out[0]), handed_over=int(out[1]), rectangles_cut=int(out[2]), ranges=int(out[3]))
+
     def reduce_global(self, combine, wind_drift_depth=0.1, relative_wind=False):
         """Sharded run: this set's raw reductions -> combine(raw16) over the ranks (counts summed, maxima maximised) ->
         installed for the movers that follow, until reduce_unpin()."""

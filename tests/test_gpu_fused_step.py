@@ -146,53 +146,6 @@ def test_fused_with_seafloor_and_age_equals_separate(ctx):
     assert (Q.download_deactivated()['status'] == 7).any()
 
 
-@pytest.mark.parametrize('layout', ['sorted', 'random', 'two_clusters'])
-@pytest.mark.parametrize('scheme', ['runge-kutta', 'runge-kutta4'])
-def test_lds_tile_gives_the_same_bits_as_global_gathers(monkeypatch, layout, scheme):
-    """k_step_grid<..., TILE>: the Runge-Kutta stage samples read the (u,v) node records from an LDS tile around the
-    workgroup's particles; footprints outside the tile (unsorted particles, stragglers, workgroups straddling two
-    clusters) take the global path.  Either way the same floats enter the same arithmetic: bit-identical positions,
-    for a cell-sorted set (the tile serves everyone), a random one (nearly everyone is a straggler) and two far
-    clusters in one workgroup."""
-    from opendrift_amd import synthetic as synth
-    g = synth.grid3d(nx=96, ny=80, nz=8, nt=3, seed=5)
-    names = [U, V, W, DEPTH, LAND]
-    rng = np.random.default_rng(11)
-    n = 20000
-    lon = rng.uniform(g['x'][3], g['x'][-4], n)
-    lat = rng.uniform(g['y'][3], g['y'][-4], n)
-    if layout == 'two_clusters':      # alternate between two small far-apart patches inside every workgroup
-        lon = np.where(np.arange(n) % 2 == 0, g['x'][10] + 0.2 * (lon - g['x'][3]) / 10, g['x'][70] + 0.2 * (lon - g['x'][3]) / 10)
-        lat = np.where(np.arange(n) % 2 == 0, g['y'][10] + 0.2 * (lat - g['y'][3]) / 10, g['y'][60] + 0.2 * (lat - g['y'][3]) / 10)
-    z = -rng.uniform(0, 60, n)
-    res = []
-    for tile in (True, False):
-        if tile:
-            monkeypatch.setenv('ODR_LDS_TILE_MIN_N', '1')
-            monkeypatch.setenv('ODR_LDS_TILE', '1')
-            monkeypatch.delenv('ODR_NO_LDS_TILE', raising=False)
-        else:
-            monkeypatch.setenv('ODR_NO_LDS_TILE', '1')
-        ctx = Context(seed=0)
-        sid = ctx.add_grid(g['x'], g['y'], z=g['z'])
-        for k in range(3):
-            ctx.upload_block(sid, k, float(g['t'][k]), {nm: g[nm][k] for nm in names})
-        for nm in names:
-            ctx.bind(nm, [sid], {LAND: np.nan, DEPTH: 10000.0}.get(nm, 0.0))
-        P = ctx.particles(n)
-        P.append(lon, lat, z=z)
-        if layout == 'sorted':
-            P.sort_by_cell(sid)
-        for k, t in enumerate((300.0, 900.0, 3300.0)):     # the last step crosses a reader time level between its stages
-            P.env_coast_advect(names, t, scheme, 600.0, coastline='previous', count=False)
-        d = P.download()
-        o = np.argsort(d['ID'])
-        res.append((d['lon'][o], d['lat'][o]))
-        P.close()
-        ctx.close()
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
-
-
 @pytest.mark.parametrize('scheme', ['euler', 'runge-kutta4'])
 @pytest.mark.parametrize('vadv', [None, False, True])
 def test_mixing_inside_the_step_launch_gives_the_same_bits_as_two_calls(monkeypatch, scheme, vadv):
