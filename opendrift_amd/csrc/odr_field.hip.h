@@ -844,11 +844,13 @@ __device__ __forceinline__ float bil4(double v00, double v01, double v10, double
 struct Foot {
   unsigned o00, o01, o10, o11;
   double wy0, ty, wx0, tx;
+  unsigned n00, n11;   // node numbers of the first and the last corner in the block: the identity of the footprint (UVKeep)
 };
 __device__ __forceinline__ Foot footprint(double yi, double xi, int ny, int nx, unsigned rec_bytes) {
   const Axis ay = axis_fp(yi, ny), ax = axis_fp(xi, nx);
   const unsigned r0 = __umul24((unsigned)ay.i0, (unsigned)nx), r1 = __umul24((unsigned)ay.i1, (unsigned)nx);
   Foot f;
+  f.n00 = r0 + (unsigned)ax.i0; f.n11 = r1 + (unsigned)ax.i1;
   f.o00 = __umul24(r0 + (unsigned)ax.i0, rec_bytes); f.o01 = __umul24(r0 + (unsigned)ax.i1, rec_bytes);
   f.o10 = __umul24(r1 + (unsigned)ax.i0, rec_bytes); f.o11 = __umul24(r1 + (unsigned)ax.i1, rec_bytes);
   f.ty = ay.t; f.tx = ax.t; f.wy0 = 1 - ay.t; f.wx0 = 1 - ax.t;
@@ -933,6 +935,7 @@ struct LdTile {
     const unsigned r0 = ok ? (unsigned)(ly0 * R.w) : 0u, r1 = ok ? (unsigned)(ly1 * R.w) : 0u;
     const unsigned c0 = ok ? (unsigned)lx0 : 0u, c1 = ok ? (unsigned)lx1 : 0u;
     Foot f;
+    f.n00 = __umul24((unsigned)ay.i0, (unsigned)nx) + (unsigned)ax.i0; f.n11 = __umul24((unsigned)ay.i1, (unsigned)nx) + (unsigned)ax.i1;
     f.o00 = __umul24(r0 + c0, rec_bytes); f.o01 = __umul24(r0 + c1, rec_bytes);
     f.o10 = __umul24(r1 + c0, rec_bytes); f.o11 = __umul24(r1 + c1, rec_bytes);
     f.ty = ay.t; f.tx = ax.t; f.wy0 = 1 - ay.t; f.wx0 = 1 - ax.t;
@@ -952,6 +955,64 @@ struct PairLd {
   unsigned o[4], kb;
   __device__ __forceinline__ F4 q4(int time, int c) const { return ld.template ld<F4, 8>(time, o[c] + kb); }
   __device__ __forceinline__ F2 q2(int time, int c) const { return ld.template ld<F2, 8>(time, o[c]); }
+};
+// ---- the records of a (u,v) footprint, kept between the samples of one particle-step.  The Runge-Kutta stage positions of
+// advect_ocean_current (physics_methods.py:638-670) are a fraction of a cell away from the element: most of them have the
+// SAME 2x2 footprint, levels and time bracket as the main-loop sample of the step (or as the previous stage) -- the eight
+// corner records are then the ones already in registers and only the weights change.  A sample whose footprint differs
+// fetches its records (lanes whose footprint is unchanged sit the gathers out: the texture addresser, which bounds
+// k_step_grid, works per lane) and keeps them for the next stage.  Same floats, same arithmetic: bit-identical.
+template <bool IS3D> struct UVCorner { typedef F4 T; };
+template <> struct UVCorner<false> { typedef F2 T; };
+template <bool IS3D>
+struct UVRec { typename UVCorner<IS3D>::T b[4], a[4]; };   // 3-D: (u,v) at levels iz0, iz0 + 1; 2-D: (u,v)
+template <bool IS3D>
+struct UVKeep {
+  UVRec<IS3D> q;
+  unsigned n00, n11, kb;   // identity of the footprint the records belong to (Foot::n00 / n11, level offset)
+  bool valid;
+};
+template <bool IS3D, class LD>
+__device__ __forceinline__ void uv_fetch(const LD &ld, bool has_a, const Foot &ft, unsigned kb, UVRec<IS3D> &q) {
+  const unsigned o[4] = {ft.o00, ft.o01, ft.o10, ft.o11};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if constexpr (IS3D) q.b[c] = ld.template ld<F4, 8>(0, o[c] + kb); else q.b[c] = ld.template ld<F2, 8>(0, o[c]);
+  }
+  if (has_a) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if constexpr (IS3D) q.a[c] = ld.template ld<F4, 8>(1, o[c] + kb); else q.a[c] = ld.template ld<F2, 8>(1, o[c]);
+    }
+  }
+}
+// the records of footprint `ft` for a stage sample: those kept in K when it is the same footprint (keep: the sample's time
+// bracket is K's), fetched into K otherwise
+// KEEPS (compile time, ODR_UV_KEEPS(PROJ)): readers without vector rotation.  Measured (profiles/r04_ab_variants.txt): C3
+// (lon/lat, 3-D) 0.705 -> 0.645 ms per launch, texture-addresser busy -33 %; C4 (polar stereographic: the launch is bound by
+// float64 issue, 142 registers) 0.546 -> 0.599 ms -- the projected readers fetch every sample.
+#define ODR_UV_KEEPS(PROJ) (!ODR_PROJ_ROTATES(PROJ))
+template <bool IS3D, bool KEEPS, class LD>
+__device__ __forceinline__ void uv_records(const LD &ld, bool has_a, const Foot &ft, unsigned kb, UVKeep<IS3D> &K, bool keep,
+                                           UVRec<IS3D> &q) {
+#if defined(ODR_NO_KEEP) || defined(ODR_TU_TILE)   // A/B build; the LDS-tile kernels (their records are two cycles away, the registers are not there)
+  keep = false;
+#endif
+  if (KEEPS && keep) {
+    const bool same = K.valid && K.n00 == ft.n00 && K.n11 == ft.n11 && K.kb == kb;
+    if (!same) {
+      uv_fetch<IS3D>(ld, has_a, ft, kb, K.q);
+      K.n00 = ft.n00; K.n11 = ft.n11; K.kb = kb; K.valid = true;
+    }
+    q = K.q;
+  } else uv_fetch<IS3D>(ld, has_a, ft, kb, q);
+}
+// uv_level_ld's view of fetched records
+template <bool IS3D>
+struct RecLd {
+  const UVRec<IS3D> &q;
+  __device__ __forceinline__ F4 q4(int time, int c) const { if constexpr (IS3D) return time ? q.a[c] : q.b[c]; else return F4(); }
+  __device__ __forceinline__ F2 q2(int time, int c) const { if constexpr (!IS3D) return time ? q.a[c] : q.b[c]; else return F2(); }
 };
 
 // one float32 layer value from multiplied-out weights (w00 = wy0 wx0, ...): the same sum as bil4 evaluated with three
@@ -1028,7 +1089,7 @@ template <int PROJ, bool IS3D, class LD = LdGlobal>
 __device__ __forceinline__ bool uv_sample_fast(const DevSource &s, const DevBlock &geo, const UVTime &tm, const LD &ld,
                                                double lon, double lat, double z, const ZBracket &zb,
                                                float fbu, float fbv, float &uo, float &vo,
-                                               const ProjStart &ps = ProjStart()) {
+                                               const ProjStart &ps, UVKeep<IS3D> &K, bool keep) {
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
   double x, y;
@@ -1053,11 +1114,11 @@ __device__ __forceinline__ bool uv_sample_fast(const DevSource &s, const DevBloc
     bool f32c;
     {
       const Foot ft = ld.foot(yi, xi, geo.ny, geo.nx, (unsigned)geo.rec * 4u, ok);
+      if (!ok) return false;     // (LdTile) outside the rectangle: the caller samples from the blocks in HBM
       const FootW fw = foot_weights(ft);
-      PairLd<LD> L;
-      L.ld = ld;
-      L.o[0] = ft.o00; L.o[1] = ft.o01; L.o[2] = ft.o10; L.o[3] = ft.o11;
-      L.kb = IS3D ? (unsigned)zb.iz0 * 8u : 0u;
+      UVRec<IS3D> rec;
+      uv_records<IS3D, ODR_UV_KEEPS(PROJ)>(ld, tm.a != nullptr, ft, IS3D ? (unsigned)zb.iz0 * 8u : 0u, K, keep, rec);
+      const RecLd<IS3D> L = {rec};
       double ub, vb;
       uv_level_ld<IS3D, true>(L, 0, s.nz, ft, zb, ub, vb, f32c, fw);
       u = ub; v = vb;
@@ -1099,7 +1160,8 @@ __device__ __forceinline__ bool uv_sample_fast(const DevSource &s, const DevBloc
 template <int PROJ, bool IS3D, class LD = LdGlobal>
 __device__ __forceinline__ bool uv_sample_stage_f32(const DevSource &s, const DevBlock &geo, const UVTime &tm, const LD &ld,
                                                     double lon, double lat, double z, const ZBracket &zb,
-                                                    float fbu, float fbv, float &uo, float &vo, const ProjStart &ps) {
+                                                    float fbu, float fbv, float &uo, float &vo, const ProjStart &ps,
+                                                    UVKeep<IS3D> &K, bool keep) {
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
   double x, y;
@@ -1120,18 +1182,20 @@ __device__ __forceinline__ bool uv_sample_stage_f32(const DevSource &s, const De
     const double xi = (x - geo.x0) * geo.ixspan * (double)(geo.nx - 1);
     const double yi = (y - geo.y0) * geo.iyspan * (double)(geo.ny - 1);
     const Foot ft = ld.foot(yi, xi, geo.ny, geo.nx, (unsigned)geo.rec * 4u, ok);
+    if (!ok) return false;     // (LdTile) outside the rectangle: the caller samples from the blocks in HBM
+    UVRec<IS3D> rec;
+    uv_records<IS3D, ODR_UV_KEEPS(PROJ)>(ld, tm.a != nullptr, ft, IS3D ? (unsigned)zb.iz0 * 8u : 0u, K, keep, rec);
     const float tx = (float)ft.tx, ty = (float)ft.ty, sx = 1.f - tx, sy = 1.f - ty;
     const float w00 = sy * sx, w01 = sy * tx, w10 = ty * sx, w11 = ty * tx;
     const float wt = tm.a ? (float)tm.w : 0.f;
     f32x2 r;
-    if (IS3D) {
+    if constexpr (IS3D) {
       // levels (iz0, iz0 + 1) = ("above", "below"); clamped at the deepest level both are iz0 + 1
       const bool same = zb.same && s.nz > 1;
       const float za = same ? 0.f : (float)zb.wa, zw = 1.f - za;
-      const unsigned kb = (unsigned)zb.iz0 * 8u;
       auto level = [&](int time) {
-        const F4 q00 = ld.template ld<F4, 8>(time, ft.o00 + kb), q01 = ld.template ld<F4, 8>(time, ft.o01 + kb);
-        const F4 q10 = ld.template ld<F4, 8>(time, ft.o10 + kb), q11 = ld.template ld<F4, 8>(time, ft.o11 + kb);
+        const F4 q00 = time ? rec.a[0] : rec.b[0], q01 = time ? rec.a[1] : rec.b[1];
+        const F4 q10 = time ? rec.a[2] : rec.b[2], q11 = time ? rec.a[3] : rec.b[3];
         f32x2 lo = (f32x2){q00.x, q00.y} * w00, hi = (f32x2){q00.z, q00.w} * w00;
         lo = __builtin_elementwise_fma((f32x2){q01.x, q01.y}, (f32x2){w01, w01}, lo);
         hi = __builtin_elementwise_fma((f32x2){q01.z, q01.w}, (f32x2){w01, w01}, hi);
@@ -1145,8 +1209,8 @@ __device__ __forceinline__ bool uv_sample_stage_f32(const DevSource &s, const De
       if (tm.a) { const f32x2 ra = level(1); r = __builtin_elementwise_fma(ra - r, (f32x2){wt, wt}, r); }
     } else {
       auto level = [&](int time) {
-        const F2 q00 = ld.template ld<F2, 8>(time, ft.o00), q01 = ld.template ld<F2, 8>(time, ft.o01);
-        const F2 q10 = ld.template ld<F2, 8>(time, ft.o10), q11 = ld.template ld<F2, 8>(time, ft.o11);
+        const F2 q00 = time ? rec.a[0] : rec.b[0], q01 = time ? rec.a[1] : rec.b[1];
+        const F2 q10 = time ? rec.a[2] : rec.b[2], q11 = time ? rec.a[3] : rec.b[3];
         f32x2 a = (f32x2){q00.x, q00.y} * w00;
         a = __builtin_elementwise_fma((f32x2){q01.x, q01.y}, (f32x2){w01, w01}, a);
         a = __builtin_elementwise_fma((f32x2){q10.x, q10.y}, (f32x2){w10, w10}, a);
@@ -1174,9 +1238,9 @@ __device__ __forceinline__ bool uv_sample_stage_f32(const DevSource &s, const De
 template <int PROJ, bool IS3D, int SM, class LD>
 __device__ __forceinline__ bool uv_stage(const DevSource &s, const DevBlock &geo, const UVTime &tm, const LD &ld, double lon, double lat,
                                          double z, const ZBracket &zb, float fbu, float fbv, float &uo, float &vo,
-                                         const ProjStart &ps) {
-  if constexpr (SM == 1) return uv_sample_stage_f32<PROJ, IS3D>(s, geo, tm, ld, lon, lat, z, zb, fbu, fbv, uo, vo, ps);
-  else return uv_sample_fast<PROJ, IS3D>(s, geo, tm, ld, lon, lat, z, zb, fbu, fbv, uo, vo, ps);
+                                         const ProjStart &ps, UVKeep<IS3D> &K, bool keep) {
+  if constexpr (SM == 1) return uv_sample_stage_f32<PROJ, IS3D>(s, geo, tm, ld, lon, lat, z, zb, fbu, fbv, uo, vo, ps, K, keep);
+  else return uv_sample_fast<PROJ, IS3D>(s, geo, tm, ld, lon, lat, z, zb, fbu, fbv, uo, vo, ps, K, keep);
 }
 // the global loader of a stage sample: the (u,v) arrays of the bracketing levels
 __device__ __forceinline__ LdGlobal uv_global(const UVTime &tm) { LdGlobal g; g.b = tm.b; g.a = tm.a ? tm.a : tm.b; return g; }
@@ -1310,11 +1374,14 @@ __device__ __forceinline__ void burst_math(int m, Get get, const Foot &ft, const
     }
   }
 }
+// what the main-loop sample hands to the stage samples of the same particle-step (UVKeep): the records of slot A as
+// fetched (the step kernels put the current there), the footprint's identity and the level offset
+struct EnvExport { float b[16], a[16]; unsigned n00, n11; int iz0; bool valid; };   // (plain floats: arrays of structs behind a pointer stay in scratch memory)
 // L: the loader of the node records (time 0 = the level before, 1 = the level after, or the same level when !tl); ft and
 // near_off hold ITS byte offsets (LdGlobal::foot / LdTile::foot)
 template <int PROJ, class LD>
 __device__ __forceinline__ void env_burst(const DevSource &s, const EnvGroupDesc &G, const LD &L, const Foot &ft, const ZBracket &zb,
-                                          unsigned near_off, bool tl, double x, double y, float *out /*[MAXG]*/ ODR_PT_PARAM) {
+                                          unsigned near_off, bool tl, double x, double y, float *out /*[MAXG]*/, EnvExport *X ODR_PT_PARAM) {
   const unsigned o[4] = {ft.o00, ft.o01, ft.o10, ft.o11};
   const unsigned iz0 = (unsigned)zb.iz0;
   const int kA = G.bs[0], kB = G.bs[1], kC = G.bs[2], kD = G.bs[3], kL = G.bs[4];
@@ -1349,6 +1416,14 @@ __device__ __forceinline__ void env_burst(const DevSource &s, const EnvGroupDesc
     F4 Ab[4], Aa[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) { Ab[c] = L.template ld<F4>(0, o[c] + dA); Aa[c] = L.template ld<F4>(1, o[c] + dA); }
+    if (X) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        X->b[4 * c] = Ab[c].x; X->b[4 * c + 1] = Ab[c].y; X->b[4 * c + 2] = Ab[c].z; X->b[4 * c + 3] = Ab[c].w;
+        X->a[4 * c] = Aa[c].x; X->a[4 * c + 1] = Aa[c].y; X->a[4 * c + 2] = Aa[c].z; X->a[4 * c + 3] = Aa[c].w;
+      }
+      X->n00 = ft.n00; X->n11 = ft.n11; X->iz0 = zb.iz0; X->valid = true;
+    }
     const int ps_static = G.ps_static;
     const float Lb = L.template ld<float>(0, dL);
     float La;
@@ -1447,7 +1522,7 @@ __device__ __forceinline__ EnvFront env_front(const DevSource &s, const DevBlock
 template <int PROJ, bool BURST_ONLY, bool ZT, class LD>
 __device__ __forceinline__ bool env_group_sample(const DevWorld &W, const EnvGroupDesc &G, const LD &L, const EnvFront &fr,
                                                  double z, float *out /*[MAXG]*/, const double *zt,
-                                                 ZBracket &zb_out ODR_PT_PARAM) {
+                                                 ZBracket &zb_out, EnvExport *X = nullptr ODR_PT_PARAM) {
   ODR_PT(10);
   const DevSource &s = W.src[G.sid];
   const DevBlock &geo = s.slot[G.geo_slot];
@@ -1487,7 +1562,7 @@ __device__ __forceinline__ bool env_group_sample(const DevWorld &W, const EnvGro
     if (!(ok && ok_near)) return false;
     const bool tl = G.ba != nullptr && !G.all_static;
     ODR_PT_USE(ft.o00); ODR_PT_USE(ft.o11); ODR_PT_USE(near_off); ODR_PT(14);
-    if (burst) env_burst<PROJ>(s, G, L, ft, zb, near_off, tl, x, y, out ODR_PT_ARG);
+    if (burst) env_burst<PROJ>(s, G, L, ft, zb, near_off, tl, x, y, out, X ODR_PT_ARG);
     else if constexpr (!BURST_ONLY) {
     static_assert(BURST_ONLY || sizeof(LD) == sizeof(LdGlobal), "the serial sampler reads the blocks in HBM");
 #pragma unroll
@@ -1563,10 +1638,29 @@ __device__ __forceinline__ LdGlobal env_global(const EnvGroupDesc &G) {
 template <int PROJ, bool BURST_ONLY, bool ZT>
 __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroupDesc &G, double lon,
                                                double lat, double z, float *out /*[MAXG]*/, const double *zt,
-                                               ZBracket &zb_out ODR_PT_PARAM) {
+                                               ZBracket &zb_out, EnvExport *X = nullptr ODR_PT_PARAM) {
   const DevSource &s = W.src[G.sid];
   const EnvFront fr = env_front<PROJ>(s, s.slot[G.geo_slot], lon, lat, z);
-  env_group_sample<PROJ, BURST_ONLY, ZT>(W, G, env_global(G), fr, z, out, zt, zb_out ODR_PT_ARG);
+  env_group_sample<PROJ, BURST_ONLY, ZT>(W, G, env_global(G), fr, z, out, zt, zb_out, X ODR_PT_ARG);
+}
+// The records the main-loop sample fetched for slot A, as the kept footprint of the stage samples -- valid when slot A holds
+// the current (an interleaved pair of the stage samples' dimensionality) and the sample's time bracket is that of the
+// half-step stages `th` (wave-uniform tests)
+template <bool IS3D>
+__device__ __forceinline__ UVKeep<IS3D> uv_keep_from(const EnvGroupDesc &G, const EnvExport &X, const UVTime &th) {
+  UVKeep<IS3D> K;
+  const bool tl = G.ba != nullptr && !G.all_static;
+  const float *mb = (const float *)((const char *)G.bb + G.ps_off[0]);
+  const float *ma = tl ? (const float *)((const char *)G.ba + G.ps_off[0]) : nullptr;
+  const bool fits = G.bs[0] == 0 && G.var[0] == VAR_U && G.ps_mode[0] == (IS3D ? ENV_P3 : ENV_P2) && mb == th.b && ma == th.a;
+  K.valid = fits && X.valid;
+  K.n00 = X.n00; K.n11 = X.n11; K.kb = IS3D ? (unsigned)X.iz0 * 8u : 0u;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    K.q.b[c].x = X.b[4 * c]; K.q.b[c].y = X.b[4 * c + 1]; K.q.a[c].x = X.a[4 * c]; K.q.a[c].y = X.a[4 * c + 1];
+    if constexpr (IS3D) { K.q.b[c].z = X.b[4 * c + 2]; K.q.b[c].w = X.b[4 * c + 3]; K.q.a[c].z = X.a[4 * c + 2]; K.q.a[c].w = X.a[4 * c + 3]; }
+  }
+  return K;
 }
 // for the kernels that need neither LDS tables nor the bracket
 template <int PROJ>

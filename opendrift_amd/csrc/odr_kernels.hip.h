@@ -613,19 +613,21 @@ __global__ __launch_bounds__(BLOCK) void k_advect(const DevWorld *__restrict__ W
 template <int PROJ, bool IS3D, int SM, class LD>
 __device__ __forceinline__ void uv_stage_or_global(const DevSource &s, const DevBlock &geo, const UVTime &tm, const LD &ld, double lon,
                                                    double lat, double z, const ZBracket &zb, float fbu, float fbv, float &uo,
-                                                   float &vo, const ProjStart &ps) {
-  if (!uv_stage<PROJ, IS3D, SM>(s, geo, tm, ld, lon, lat, z, zb, fbu, fbv, uo, vo, ps)) {
-    if constexpr (sizeof(LD) != sizeof(LdGlobal)) uv_stage<PROJ, IS3D, SM>(s, geo, tm, uv_global(tm), lon, lat, z, zb, fbu, fbv, uo, vo, ps);
+                                                   float &vo, const ProjStart &ps, UVKeep<IS3D> &K, bool keep) {
+  if (!uv_stage<PROJ, IS3D, SM>(s, geo, tm, ld, lon, lat, z, zb, fbu, fbv, uo, vo, ps, K, keep)) {
+    if constexpr (sizeof(LD) != sizeof(LdGlobal)) uv_stage<PROJ, IS3D, SM>(s, geo, tm, uv_global(tm), lon, lat, z, zb, fbu, fbv, uo, vo, ps, K, keep);
   }
 }
 template <int SCHEME, int PROJ, bool IS3D, bool NOISE, int SM = 0, bool PARK = false, class LD = LdGlobal>
 __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBlock &geo, double &lon, double &lat,
                                                  double z, float u1, float v1, float f, int moving, double dt,
                                                  const UVTime &th, const UVTime &tf, const LD &lh, const LD &lf, float fbu, float fbv,
-                                                 const StageNoise &N, long long i, long long n, int id,
+                                                 const StageNoise &N, long long i, long long n, int id, UVKeep<IS3D> &K,
                                                  ZBracket zb_pre = ZBracket(), bool have_pre = false,
                                                  double *park = nullptr ODR_PT_PARAM) {
   float fu, fv;
+  // the full-step stage may use (and refresh) the kept records when its time bracket is that of the half-step stages
+  const bool keep_f = tf.b == th.b && tf.a == th.a;
   GeodStart o0 = geod_start(lat, lon);
 #ifndef ODR_FULL_GEODESIC
   // PARK: the series coefficients wait in LDS between the moves (geod_park); the start point is rebuilt where it is used
@@ -658,7 +660,7 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
     }
     stage_pos<SM>(ODR_O, u1, v1, dtf, lon2, lat2);
     ODR_PT_USE(lon2); ODR_PT_USE(lat2); ODR_PT(4);
-    uv_stage_or_global<PROJ, IS3D, SM>(s, geo, th, lh, lon2, lat2, z, zb, fbu, fbv, u2, v2, ps);
+    uv_stage_or_global<PROJ, IS3D, SM>(s, geo, th, lh, lon2, lat2, z, zb, fbu, fbv, u2, v2, ps, K, true);
     if (NOISE) add_current_noise(N, 1, i, n, id, u2, v2);
     ODR_PT_USE(u2); ODR_PT_USE(v2); ODR_PT(5);
     if (SCHEME == 1) {
@@ -667,11 +669,11 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
     } else {
       float u3, v3, u4, v4;
       stage_pos<SM>(ODR_O, u2, v2, dtf, lon2, lat2);
-      uv_stage_or_global<PROJ, IS3D, SM>(s, geo, th, lh, lon2, lat2, z, zb, fbu, fbv, u3, v3, ps);
+      uv_stage_or_global<PROJ, IS3D, SM>(s, geo, th, lh, lon2, lat2, z, zb, fbu, fbv, u3, v3, ps, K, true);
       if (NOISE) add_current_noise(N, 2, i, n, id, u3, v3);
       ODR_PT_USE(u3); ODR_PT_USE(v3); ODR_PT(6);
       stage_pos<SM>(ODR_O, u3, v3, dtf, lon2, lat2);
-      uv_stage_or_global<PROJ, IS3D, SM>(s, geo, tf, lf, lon2, lat2, z, zb, fbu, fbv, u4, v4, ps);
+      uv_stage_or_global<PROJ, IS3D, SM>(s, geo, tf, lf, lon2, lat2, z, zb, fbu, fbv, u4, v4, ps, K, keep_f);
       if (NOISE) add_current_noise(N, 3, i, n, id, u4, v4);
       ODR_PT_USE(u4); ODR_PT_USE(v4); ODR_PT(7);
       fu = __fmul_rn(rk4_mix(u1, u2, u3, u4), f);
@@ -691,9 +693,11 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_WAVES(PROJ)) void k_advect_grid(con
   const DevSource &s = W->src[sid];
   const DevBlock &geo = s.slot[geo_slot];
   double lon = p.lon[i], lat = p.lat[i];
+  UVKeep<IS3D> K;
+  K.valid = false; K.n00 = K.n11 = K.kb = 0;
   advect_grid_body<SCHEME, PROJ, IS3D, NOISE, SM>(s, geo, lon, lat, p.z[i], p.env[VAR_U][i], p.env[VAR_V][i],
                                               __fmul_rn(current_factor(p, i, factor), p.cdf[i]), p.moving[i], dt, th, tf, uv_global(th), uv_global(tf),
-                                              W->fallback[VAR_U], W->fallback[VAR_V], N, i, p.n, NOISE ? p.id[i] : 0);
+                                              W->fallback[VAR_U], W->fallback[VAR_V], N, i, p.n, NOISE ? p.id[i] : 0, K);
   p.lon[i] = lon;
   p.lat[i] = lat;
 }
@@ -729,7 +733,11 @@ struct StepMix {
 };
 // lat / lon and curvilinear readers, Runge-Kutta schemes: geodesic coefficients parked in LDS, 5 waves per SIMD (geod_park)
 #ifndef ODR_PARK_WAVES
+#ifdef ODR_NO_KEEP
 #define ODR_PARK_WAVES 5
+#else
+#define ODR_PARK_WAVES 4   // with the kept (u,v) records of the footprint (UVKeep: 35 registers): 126 registers; 4 and 5 waves per SIMD ran alike before (profiles/r03_ab_variants.txt)
+#endif
 #endif
 #if defined(ODR_FULL_GEODESIC) || defined(ODR_NO_PARK)
 #define ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) false
@@ -777,7 +785,10 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
     float out[MAXG];
     ZBracket zb_env;
     zb_env.iz0 = 0; zb_env.same = 0; zb_env.wa = 1;
-    env_group_fast<PROJ, true, IS3D>(*W, G, lon, lat, z, out, zt, zb_env ODR_PT_ARG);
+    EnvExport X;
+    X.valid = false; X.n00 = X.n11 = 0; X.iz0 = 0;
+    env_group_fast<PROJ, true, IS3D>(*W, G, lon, lat, z, out, zt, zb_env, &X ODR_PT_ARG);
+    UVKeep<IS3D> K = uv_keep_from<IS3D>(G, X, th);
     ODR_PT_USE(out[0]); ODR_PT_USE(out[1]); ODR_PT_USE(out[2]); ODR_PT_USE(out[3]); ODR_PT_USE(out[4]); ODR_PT(2);
     const int id = (NOISE || MIXQ > 0) ? p.id[i] : 0;
     if (MIXQ > 0) vmix_col_fill<(MIXQ > 0 ? MIXQ : 1), MIXTL>(W->src[M.D.sid], M.D, lon, lat, Kp, threadIdx.x);
@@ -847,7 +858,7 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
       const DevSource &s = W->src[G.sid];
       advect_grid_body<SCHEME, PROJ, IS3D, NOISE, SM, PARK>(s, s.slot[S.geo_slot_uv], lon, lat, zz, out[0], out[1],
                                                         __fmul_rn(current_factor(p, i, factor), cdf0), moving, dt, th, tf, uv_global(th), uv_global(tf),
-                                                        W->fallback[VAR_U], W->fallback[VAR_V], N, i, p.n, id, zb_env, IS3D && zz == z, PARK ? s_park + threadIdx.x : nullptr ODR_PT_ARG);
+                                                        W->fallback[VAR_U], W->fallback[VAR_V], N, i, p.n, id, K, zb_env, IS3D && zz == z, PARK ? s_park + threadIdx.x : nullptr ODR_PT_ARG);
     }
     ODR_PT_USE(lon); ODR_PT_USE(lat); ODR_PT(8);
     if (MIXQ > 0) {   // vertical_mixing + vertical_advection (oceandrift.py:397-571, :315-350) after the horizontal move
@@ -2287,8 +2298,12 @@ __global__ __launch_bounds__(BLOCK) void k_capsize(PView p, double dt, float thr
 // gridded reader makes the 64 lanes of a wave touch neighbouring grid nodes, so the block
 // gathers of a wave fall into a handful of cache lines (k_advect_grid: 7.4 ms -> 1.2 ms for
 // 10 M particles on a 1024x1024x12 block).  Bins = 8x8-cell tiles, cells row-major inside.
-__device__ __forceinline__ unsigned sort_key(const DevSource &s, const DevBlock &b, double lon, double lat,
-                                             int ntx, unsigned nbins) {
+// zb > 1: every cell is split into zb depth bands (lpb reader levels each): elements of a cell that sit in the same band
+// become neighbours in memory -- the lanes of a wave then read the same 64-byte sectors of the node records (the texture
+// addresser merges lanes that share a sector: a 16-byte gather costs 16 instead of 32 cycles, profiles/r03_gather_bench.txt)
+// and, moving with the same current, they stay neighbours for longer under vertical shear.
+__device__ __forceinline__ unsigned sort_key(const DevSource &s, const DevBlock &b, double lon, double lat, double z,
+                                             int ntx, unsigned nbins, int zb = 1, int lpb = 1) {
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
   double x, y;
@@ -2296,7 +2311,13 @@ __device__ __forceinline__ unsigned sort_key(const DevSource &s, const DevBlock 
   double xi = (x - b.x0) / b.xspan * (b.nx - 1), yi = (y - b.y0) / b.yspan * (b.ny - 1);
   if (!(xi >= 0 && xi <= b.nx - 1 && yi >= 0 && yi <= b.ny - 1)) return nbins - 1;
   int ix = (int)xi, iy = (int)yi;
-  return (unsigned)(((iy >> 3) * ntx + (ix >> 3)) * 64 + (iy & 7) * 8 + (ix & 7));
+  const unsigned cell = (unsigned)(((iy >> 3) * ntx + (ix >> 3)) * 64 + (iy & 7) * 8 + (ix & 7));
+  if (zb <= 1) return cell;
+  int below = 0;   // reader levels below the element (zasc: ascending, +inf beyond nz)
+  for (int k = 0; k < s.nz; ++k) below += s.zasc[k] < z ? 1 : 0;
+  int band = (s.nz - below) / lpb;   // 0 = the band at the surface
+  band = band < 0 ? 0 : (band > zb - 1 ? zb - 1 : band);
+  return cell * (unsigned)zb + (unsigned)band;
 }
 
 // Runs of equal keys inside a wave (the particles arrive nearly sorted: neighbouring lanes mostly share their tile) make ONE
@@ -2323,12 +2344,12 @@ __device__ __forceinline__ KeyRun key_run(unsigned k, bool live) {
 }
 
 __global__ __launch_bounds__(BLOCK) void k_sort_hist(const DevWorld *__restrict__ W, int sid, int slot, PView p,
-                                                     int ntx, unsigned nbins, unsigned *keys, unsigned *hist) {
+                                                     int ntx, unsigned nbins, unsigned *keys, unsigned *hist, int zb, int lpb) {
   const long long i = pid();        // XCD-contiguous: the histogram bins of a region are touched by one L2
   const bool live = i < p.n;
   unsigned k = 0;
   if (live) {
-    k = sort_key(W->src[sid], W->src[sid].slot[slot], p.lon[i], p.lat[i], ntx, nbins);
+    k = sort_key(W->src[sid], W->src[sid].slot[slot], p.lon[i], p.lat[i], zb > 1 ? p.z[i] : 0.0, ntx, nbins, zb, lpb);
     keys[i] = k;
   }
   const KeyRun r = key_run(k, live);

@@ -26,26 +26,27 @@ namespace odr {
 
 #ifdef ODR_TU_MISC
 // ---- the workgroup table of a sorted particle set.  ends[k] = end offset of sort key k (the cursor array of
-// k_sort_perm after the scatter); keys are tile * 64 + cell, the last key (ntiles * 64) collects the particles outside
-// the grid.  Tile t holds [ends[64 t - 1], ends[64 t + 63]); it is cut into ceil(count / BLOCK) ranges of equal length.
-__device__ __forceinline__ void wg_tile_range(const unsigned *__restrict__ ends, int t, int ntiles, unsigned &start, unsigned &cnt) {
-  start = t ? ends[(size_t)t * 64 - 1] : 0u;
-  const unsigned end = t < ntiles ? ends[(size_t)t * 64 + 63] : ends[(size_t)ntiles * 64];
+// k_sort_perm after the scatter); keys are (tile * 64 + cell) [* bands + band], the last key collects the particles
+// outside the grid.  Tile t holds [ends[spt t - 1], ends[spt t + spt - 1]); it is cut into ceil(count / BLOCK) ranges of equal length.
+// (spt = keys per sort tile: 64 cells x depth bands of the sort)
+__device__ __forceinline__ void wg_tile_range(const unsigned *__restrict__ ends, int t, int ntiles, unsigned spt, unsigned &start, unsigned &cnt) {
+  start = t ? ends[(size_t)t * spt - 1] : 0u;
+  const unsigned end = t < ntiles ? ends[(size_t)t * spt + spt - 1] : ends[(size_t)ntiles * spt];
   cnt = end - start;
 }
-__global__ __launch_bounds__(BLOCK) void k_wg_count(const unsigned *__restrict__ ends, int ntiles, unsigned *__restrict__ nw) {
+__global__ __launch_bounds__(BLOCK) void k_wg_count(const unsigned *__restrict__ ends, int ntiles, unsigned spt, unsigned *__restrict__ nw) {
   const int t = blockIdx.x * BLOCK + threadIdx.x;
   if (t > ntiles) return;
   unsigned start, cnt;
-  wg_tile_range(ends, t, ntiles, start, cnt);
+  wg_tile_range(ends, t, ntiles, spt, start, cnt);
   nw[t] = (cnt + BLOCK - 1) / BLOCK;
 }
-__global__ __launch_bounds__(BLOCK) void k_wg_fill(const unsigned *__restrict__ ends, int ntiles, const unsigned *__restrict__ off,
+__global__ __launch_bounds__(BLOCK) void k_wg_fill(const unsigned *__restrict__ ends, int ntiles, unsigned spt, const unsigned *__restrict__ off,
                                                    unsigned *__restrict__ tab, unsigned cap) {
   const int t = blockIdx.x * BLOCK + threadIdx.x;
   if (t > ntiles) return;
   unsigned start, cnt;
-  wg_tile_range(ends, t, ntiles, start, cnt);
+  wg_tile_range(ends, t, ntiles, spt, start, cnt);
   const unsigned nw = (cnt + BLOCK - 1) / BLOCK, o = off[t];
   for (unsigned j = 0; j < nw && o + j < cap; ++j) {
     const unsigned a = (unsigned)(((unsigned long long)cnt * j) / nw), b = (unsigned)(((unsigned long long)cnt * (j + 1)) / nw);
@@ -86,7 +87,10 @@ __device__ __forceinline__ bool step_particle(const DevWorld *__restrict__ W, co
   float out[MAXG];
   ZBracket zb_env;
   zb_env.iz0 = 0; zb_env.same = 0; zb_env.wa = 1;
-  if (!env_group_sample<PROJ, true, IS3D>(*W, G, Lm, fr, z, out, zt, zb_env)) return false;
+  EnvExport X;
+  X.valid = false; X.n00 = X.n11 = 0; X.iz0 = 0;
+  if (!env_group_sample<PROJ, true, IS3D>(*W, G, Lm, fr, z, out, zt, zb_env, &X)) return false;
+  UVKeep<IS3D> K = uv_keep_from<IS3D>(G, X, th);
   const int id = NOISE ? p.id[i] : 0;
   if (NOISE && S.main_noise) add_current_noise(N, 0, i, p.n, id, out[0], out[1]);
 #pragma unroll
@@ -147,7 +151,7 @@ __device__ __forceinline__ bool step_particle(const DevWorld *__restrict__ W, co
     const DevSource &s = W->src[G.sid];
     advect_grid_body<SCHEME, PROJ, IS3D, NOISE, SM, false>(s, s.slot[S.geo_slot_uv], lon, lat, zz, out[0], out[1],
                                                            __fmul_rn(current_factor(p, i, factor), q.cdf0), moving, dt, th, tf, Lh, Lf,
-                                                           W->fallback[VAR_U], W->fallback[VAR_V], N, i, p.n, id, zb_env, IS3D && zz == z);
+                                                           W->fallback[VAR_U], W->fallback[VAR_V], N, i, p.n, id, K, zb_env, IS3D && zz == z);
   }
   p.lon[i] = lon;
   p.lat[i] = lat;

@@ -1887,7 +1887,11 @@ int odr_sort_particles_ex(odr_ctx *c, odr_particles *p, int32_t sid, int keep_en
   int slot = s.level_slot[0];
   const DevBlock &b = s.slot[slot];
   int ntx = (b.nx + 7) / 8, nty = (b.ny + 7) / 8;
-  unsigned nbins = (unsigned)(ntx * nty * 64 + 1);
+  // ODR_SORT_ZBANDS=<levels per band> (3-D readers): depth bands inside every cell (sort_key)
+  int lpb = getenv("ODR_SORT_ZBANDS") ? atoi(getenv("ODR_SORT_ZBANDS")) : 0, zb = 1;
+  if (lpb > 0 && s.nz > 1 && (long long)ntx * nty * 64 * ((s.nz + lpb - 1) / lpb) < (1ll << 27)) zb = (s.nz + lpb - 1) / lpb;
+  else lpb = 1;
+  unsigned nbins = (unsigned)(ntx * nty * 64 * zb + 1);
   size_t n = (size_t)p->n;
   void *sc;
   const int ntiles = ntx * nty;
@@ -1896,7 +1900,7 @@ int odr_sort_particles_ex(odr_ctx *c, odr_particles *p, int32_t sid, int keep_en
   unsigned *wg_nw = hist + nbins + nbins / 1024 + 64;
   HIPCHK(hipMemsetAsync(hist, 0, sizeof(unsigned) * nbins, c->stream));
   hipLaunchKernelGGL(k_sort_hist, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, c->dw, sid, slot, view(p), ntx, nbins,
-                     keys, hist);
+                     keys, hist, zb, lpb);
   {
     unsigned nsb = (nbins + 1023) / 1024;
     unsigned *bsum = hist + nbins;  // scratch tail
@@ -1919,9 +1923,9 @@ int odr_sort_particles_ex(odr_ctx *c, odr_particles *p, int32_t sid, int keep_en
       p->wg_cap = cap;
     }
     const unsigned nt1 = (unsigned)ntiles + 1;
-    hipLaunchKernelGGL(k_wg_count, dim3((nt1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, hist, ntiles, wg_nw);
+    hipLaunchKernelGGL(k_wg_count, dim3((nt1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, hist, ntiles, 64u * (unsigned)zb, wg_nw);
     hipLaunchKernelGGL(k_cmp_scan, dim3(1), dim3(1024), 0, c->stream, wg_nw, (long long)nt1, p->wg_total);   // exclusive, in place
-    hipLaunchKernelGGL(k_wg_fill, dim3((nt1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, hist, ntiles, wg_nw, p->wg_tab, (unsigned)cap);
+    hipLaunchKernelGGL(k_wg_fill, dim3((nt1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, hist, ntiles, 64u * (unsigned)zb, wg_nw, p->wg_tab, (unsigned)cap);
     p->wg_grid = cap; p->wg_n = p->n; p->wg_sid = sid; p->wg_valid = true;
   }
   CmpArrays A;

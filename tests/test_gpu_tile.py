@@ -93,12 +93,12 @@ def test_tile_step_equals_global_step_on_a_sorted_set(monkeypatch, math, scheme)
 
 @pytest.mark.parametrize('math', ['exact', 'fast'])
 def test_tile_step_with_stage_positions_far_from_the_element(monkeypatch, math):
-    """dt = 2 h: a stage position is up to ~8 cells from the element -- outside the rectangle's one-node margin: those
+    """dt = 50 min: a stage position is up to ~4 cells from the element -- outside the rectangle's one-node margin: those
     samples come from the blocks in HBM, one by one, inside the tile launch."""
     g, names, lon, lat, z = _c3(n=30000, seed=3)
     times = [0.0, 100.0]
-    a, st = _run(monkeypatch, True, g, names, None, lon, lat, z, 'runge-kutta4', math, times, 7200.0)
-    b, _ = _run(monkeypatch, False, g, names, None, lon, lat, z, 'runge-kutta4', math, times, 7200.0)
+    a, st = _run(monkeypatch, True, g, names, None, lon, lat, z, 'runge-kutta4', math, times, 3000.0)
+    b, _ = _run(monkeypatch, False, g, names, None, lon, lat, z, 'runge-kutta4', math, times, 3000.0)
     _same(a, b)
     assert st['launches'] == len(times)
 
