@@ -180,9 +180,12 @@ class Workload:
                 P.coastline('stranding', stranded_code=1)
                 P.compact()
                 P.advect('runge-kutta4', t, self.dt)
-            P.advect_wind(self.dt, wind_drift_depth=0.1)
-            P.stokes_drift(self.dt, profile=2, hs_mode=1, tp_mode=1)
-            P.hdiffusion(self.dt, step=k)
+            if os.environ.get('ODR_BENCH_SEPARATE_MOVERS'):    # what-if: the three launches of rounds 1-3
+                P.advect_wind(self.dt, wind_drift_depth=0.1)
+                P.stokes_drift(self.dt, profile=2, hs_mode=1, tp_mode=1)
+                P.hdiffusion(self.dt, step=k)
+            else:      # advect_wind -> stokes_drift -> horizontal_diffusion in one launch (odr_movers)
+                P.movers(self.dt, wind=dict(wind_drift_depth=0.1), stokes=dict(profile=2, hs_mode=1, tp_mode=1), hdiffusion=dict(step=k))
 
     def dominant_kernel(self, P, k):
         """The dominant launch of the step on its own, with exactly the arguments step() uses (timed with HIP events)."""

@@ -116,6 +116,8 @@ _SIGNATURES = {
     'odr_leeway_capsize': [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_int, _dp, C.c_uint64],
     'odr_leeway': [_vp, _vp, C.c_double, C.c_double, C.c_int, _dp, C.c_uint64],
     'odr_hdiffusion': [_vp, _vp, C.c_double, C.c_int, _dp, _dp, C.c_uint64],
+    'odr_movers': [_vp, _vp, C.c_double, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _dp, _dp,
+                   C.c_uint64],
     'odr_vmix': [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _dp, C.c_uint64],
     'odr_vmix_wind_profile': [_vp, _vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _dp, C.c_uint64],
     'odr_vmix_fuse_vertical_advection': [_vp, C.c_int],

@@ -34,7 +34,7 @@ constexpr int BLOCK = ODR_BLOCK;  // threads per workgroup (A/B builds may overr
 #endif
 #define ODR_WAVES(PROJ) ((PROJ) == PROJ_LATLONG ? ODR_LATLONG_WAVES : ODR_POLAR_WAVES)
 #ifndef ODR_MIX_WAVES
-#define ODR_MIX_WAVES 1   // the step kernel with the mixing inside: 129 VGPRs (3 waves per SIMD); held at 128 (= 4) it is slower still
+#define ODR_MIX_WAVES 3   // the step kernel with the mixing inside: 167 VGPRs with the kept (u,v) records (3 waves per SIMD); held at 128 it spills
 #endif
 
 // XCD-aware block order.  Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2), so with
@@ -749,7 +749,6 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
                                                      StepDesc S, double dt, float factor, UVTime th, UVTime tf,
                                                      unsigned long long *n_hit, StageNoise N,
                                                      StepMix M = StepMix()) {
-  static_assert(!(SM != 0 && MIXQ > 0), "the fast stage math exists for the plain step kernel only");
   long long i = pid();
   bool hit = false;
   ODR_PT_DECL;
@@ -1019,42 +1018,61 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(PView p, double wind_drift_dep
   v[R_NACT] = 0;
   v[R_NSURF] = 0;
   const double wdd = fabs(wind_drift_depth);
-  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < p.n; i += (long long)gridDim.x * BLOCK) {
-    // elements deactivated in this step and not yet compacted do not count: the reference has removed them by the time
-    // its movers reduce (a sharded run reduces once per step, before the compaction: odr_reduce_local)
-    if (p.status[i] != 0) continue;
-    const double z = p.z[i];
-    v[R_NACT] += 1;
-    if (EXT) {
-      const double lon = p.lon[i], lat = p.lat[i];
-      v[R_LONMIN] = fmax(v[R_LONMIN], -lon); v[R_LONMAX] = fmax(v[R_LONMAX], lon);
-      v[R_LATMIN] = fmax(v[R_LATMIN], -lat); v[R_LATMAX] = fmax(v[R_LATMAX], lat);
-      v[R_ZMIN] = fmax(v[R_ZMIN], -z); v[R_ZMAX] = fmax(v[R_ZMAX], z);
+  // Every array the reduction reads is requested up front, for two elements per trip (the arrays present are the same for
+  // every element: uniform branches): with the loads behind the status test and behind each other a trip was ~6 dependent
+  // memory round trips and the launch 0.14 ms for 6.25 M elements (C4: 13 % of the step).
+  const bool has_hd = p.env[VAR_HDIFF] != nullptr, has_st = p.env[VAR_SX] && p.env[VAR_SY], has_hs = p.env[VAR_HS] != nullptr;
+  const bool has_tp = p.env[VAR_TP] != nullptr, has_mld = p.env[VAR_MLD] != nullptr, has_w = p.env[VAR_XWIND] && p.env[VAR_YWIND];
+  const bool rel = relative_wind && p.env[VAR_U] && p.env[VAR_V];
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i0 = (long long)blockIdx.x * BLOCK + threadIdx.x; i0 < p.n; i0 += 2 * stride) {
+    int st[2]; double z[2], lo[2], la[2]; float hd[2], sx[2], sy[2], hs[2], tp[2], mld[2], xw[2], yw[2], wdf0[2], cu[2], cv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long long i = i0 + u * stride;
+      const bool in = i < p.n;
+      const long long j = in ? i : i0;
+      st[u] = in ? p.status[j] : 1;
+      z[u] = p.z[j];
+      if (EXT) { lo[u] = p.lon[j]; la[u] = p.lat[j]; }
+      hd[u] = has_hd ? p.env[VAR_HDIFF][j] : 0.f;
+      sx[u] = has_st ? p.env[VAR_SX][j] : 0.f; sy[u] = has_st ? p.env[VAR_SY][j] : 0.f;
+      hs[u] = has_hs ? p.env[VAR_HS][j] : 0.f; tp[u] = has_tp ? p.env[VAR_TP][j] : 0.f; mld[u] = has_mld ? p.env[VAR_MLD][j] : 0.f;
+      xw[u] = has_w ? p.env[VAR_XWIND][j] : 0.f; yw[u] = has_w ? p.env[VAR_YWIND][j] : 0.f; wdf0[u] = has_w ? p.wdf[j] : 0.f;
+      cu[u] = rel ? p.env[VAR_U][j] : 0.f; cv[u] = rel ? p.env[VAR_V][j] : 0.f;
     }
-    if (p.env[VAR_HDIFF]) v[R_DMAX] = fmax(v[R_DMAX], (double)p.env[VAR_HDIFF][i]);
-    if (p.env[VAR_SX] && p.env[VAR_SY])
-      v[R_STOKESMAX] = fmax(v[R_STOKESMAX], (double)__fadd_rn(p.env[VAR_SX][i], p.env[VAR_SY][i]));
-    if (p.env[VAR_HS]) v[R_HSMAX] = fmax(v[R_HSMAX], (double)p.env[VAR_HS][i]);
-    if (p.env[VAR_TP]) v[R_TPMAX] = fmax(v[R_TPMAX], (double)p.env[VAR_TP][i]);
-    if (p.env[VAR_MLD]) v[R_MLDMAX] = fmax(v[R_MLDMAX], (double)p.env[VAR_MLD][i]);
-    if (p.env[VAR_XWIND] && p.env[VAR_YWIND]) {
-      // advect_wind bookkeeping (physics_methods.py:738-775)
-      bool surf = z >= -wdd;
-      if (surf) {
-        float xw = p.env[VAR_XWIND][i], yw = p.env[VAR_YWIND][i];
-        double wdf = p.wdf[i];
-        if (wind_drift_depth != 0) {
-          wdf = wdf * (wdd + z) / wdd;
-          if (z > 0) wdf = p.wdf[i];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      // elements deactivated in this step and not yet compacted do not count: the reference has removed them by the time
+      // its movers reduce (a sharded run reduces once per step, before the compaction: odr_reduce_local)
+      if (st[u] != 0) continue;
+      v[R_NACT] += 1;
+      if (EXT) {
+        v[R_LONMIN] = fmax(v[R_LONMIN], -lo[u]); v[R_LONMAX] = fmax(v[R_LONMAX], lo[u]);
+        v[R_LATMIN] = fmax(v[R_LATMIN], -la[u]); v[R_LATMAX] = fmax(v[R_LATMAX], la[u]);
+        v[R_ZMIN] = fmax(v[R_ZMIN], -z[u]); v[R_ZMAX] = fmax(v[R_ZMAX], z[u]);
+      }
+      if (has_hd) v[R_DMAX] = fmax(v[R_DMAX], (double)hd[u]);
+      if (has_st) v[R_STOKESMAX] = fmax(v[R_STOKESMAX], (double)__fadd_rn(sx[u], sy[u]));
+      if (has_hs) v[R_HSMAX] = fmax(v[R_HSMAX], (double)hs[u]);
+      if (has_tp) v[R_TPMAX] = fmax(v[R_TPMAX], (double)tp[u]);
+      if (has_mld) v[R_MLDMAX] = fmax(v[R_MLDMAX], (double)mld[u]);
+      if (has_w) {
+        // advect_wind bookkeeping (physics_methods.py:738-775)
+        const bool surf = z[u] >= -wdd;
+        if (surf) {
+          float xa = xw[u], ya = yw[u];
+          double wdf = wdf0[u];
+          if (wind_drift_depth != 0) {
+            wdf = wdf * (wdd + z[u]) / wdd;
+            if (z[u] > 0) wdf = wdf0[u];
+          }
+          v[R_NSURF] += 1;
+          v[R_WDFMAX] = fmax(v[R_WDFMAX], wdf);
+          v[R_WSPEEDMAX] = fmax(v[R_WSPEEDMAX], (double)speed_f32(xa, ya));
+          if (rel) { xa = __fsub_rn(xa, cu[u]); ya = __fsub_rn(ya, cv[u]); }
+          v[R_RELWSPEEDMAX] = fmax(v[R_RELWSPEEDMAX], (double)speed_f32(xa, ya));
         }
-        v[R_NSURF] += 1;
-        v[R_WDFMAX] = fmax(v[R_WDFMAX], wdf);
-        v[R_WSPEEDMAX] = fmax(v[R_WSPEEDMAX], (double)speed_f32(xw, yw));
-        if (relative_wind && p.env[VAR_U]) {
-          xw = __fsub_rn(xw, p.env[VAR_U][i]);
-          yw = __fsub_rn(yw, p.env[VAR_V][i]);
-        }
-        v[R_RELWSPEEDMAX] = fmax(v[R_RELWSPEEDMAX], (double)speed_f32(xw, yw));
       }
     }
   }
@@ -1085,13 +1103,9 @@ __global__ void k_red_init(double *red) {
 #ifdef ODR_TU_MISC
 // ------------------------------------------------------------------- wind / Stokes
 // advect_wind (physics_methods.py:712-791).  red[] carries the global early-out tests.
-__global__ __launch_bounds__(BLOCK) void k_advect_wind(PView p, double dt, double wind_drift_depth,
-                                                       int relative_wind, double factor,
-                                                       const double *__restrict__ red) {
-  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= p.n) return;
-  if (red[R_NSURF] == 0 || red[R_WDFMAX] == 0 || red[R_RELWSPEEDMAX] == 0) return;  // :741-747, :775-780
-  double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
+// wind drift velocity of element i (physics_methods.py:749-791), float64 like the reference's products
+__device__ __forceinline__ void wind_velocity(const PView &p, long long i, double z, double wind_drift_depth, int relative_wind,
+                                              double factor, double &xu, double &xv) {
   double wdd = fabs(wind_drift_depth);
   bool surf = z >= -wdd;
   double wdf = p.wdf[i];
@@ -1106,8 +1120,18 @@ __global__ __launch_bounds__(BLOCK) void k_advect_wind(PView p, double dt, doubl
     yw = __fsub_rn(yw, p.env[VAR_V][i]);
   }
   if (p.ice == 1) factor = (double)__fsub_rn(1.0f, ice_k(p.env[VAR_ICE_A][i]));   // x_wind*wdf*factor: float64 * float32 array
-  double xu = __dmul_rn(__dmul_rn((double)xw, wdf), factor);
-  double xv = __dmul_rn(__dmul_rn((double)yw, wdf), factor);
+  xu = __dmul_rn(__dmul_rn((double)xw, wdf), factor);
+  xv = __dmul_rn(__dmul_rn((double)yw, wdf), factor);
+}
+__global__ __launch_bounds__(BLOCK) void k_advect_wind(PView p, double dt, double wind_drift_depth,
+                                                       int relative_wind, double factor,
+                                                       const double *__restrict__ red) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  if (red[R_NSURF] == 0 || red[R_WDFMAX] == 0 || red[R_RELWSPEEDMAX] == 0) return;  // :741-747, :775-780
+  double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
+  double xu, xv;
+  wind_velocity(p, i, z, wind_drift_depth, relative_wind, factor, xu, xv);
   move_f64(lon, lat, xu, xv, p.moving[i], dt);
   p.lon[i] = lon;
   p.lat[i] = lat;
@@ -1154,15 +1178,9 @@ __device__ __forceinline__ void stokes_profile(int profile, float sx, float sy, 
 // (stokes_drift_profile_windsea_swell :418-456, Breivik & Christensen 2020): the surface drift split into a swell part along
 // the swell direction (monochromatic profile, swell height / period) and the wind-sea rest (Phillips profile, wind-sea
 // height / period); unit vectors and split in float32 like NumPy on the float32 environment, profiles in float64
-__global__ __launch_bounds__(BLOCK) void k_stokes(PView p, double dt, int profile, int hs_mode,
-                                                  int tp_mode, double factor,
-                                                  const double *__restrict__ red) {
-  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= p.n) return;
-  if (red[R_STOKESMAX] == 0) return;  // "No Stokes drift velocity available" (:799-804)
-  double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
+__device__ __forceinline__ void stokes_velocity(const PView &p, long long i, double z, int profile, int hs_mode, int tp_mode,
+                                                double factor, double &su, double &sv) {
   float sx = p.env[VAR_SX][i], sy = p.env[VAR_SY][i];
-  double su, sv;
   if (profile == 3) {
     const float rws = __fmul_rn(p.env[VAR_WW_DIR][i], (float)(kPi / 180.)), rsw = __fmul_rn(p.env[VAR_SWELL_DIR][i], (float)(kPi / 180.));
     // np.cos / np.sin of a float32 array: float32 results.  Rounded from the float64 functions (= correctly rounded float32
@@ -1204,6 +1222,16 @@ __global__ __launch_bounds__(BLOCK) void k_stokes(PView p, double dt, int profil
   if (p.ice == 2) factor = (double)ice_stokes_factor(p.env[VAR_ICE_A][i]);   // stokes_u*factor: float64 * float32 array
   su = __dmul_rn(su, factor);
   sv = __dmul_rn(sv, factor);
+}
+__global__ __launch_bounds__(BLOCK) void k_stokes(PView p, double dt, int profile, int hs_mode,
+                                                  int tp_mode, double factor,
+                                                  const double *__restrict__ red) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  if (red[R_STOKESMAX] == 0) return;  // "No Stokes drift velocity available" (:799-804)
+  double lon = p.lon[i], lat = p.lat[i];
+  double su, sv;
+  stokes_velocity(p, i, p.z[i], profile, hs_mode, tp_mode, factor, su, sv);
   move_f64(lon, lat, su, sv, p.moving[i], dt);
   p.lon[i] = lon;
   p.lat[i] = lat;
@@ -1230,15 +1258,9 @@ __global__ __launch_bounds__(BLOCK) void k_advect_ice(PView p, double dt, float 
 #endif  // ODR_TU_MISC
 #ifdef ODR_TU_MISC
 // horizontal_diffusion (basemodel/__init__.py:1746-1772)
-__global__ __launch_bounds__(BLOCK) void k_hdiff(PView p, double dt, int rng_mode,
-                                                 const double *__restrict__ hnx,
-                                                 const double *__restrict__ hny,
-                                                 unsigned long long seed, unsigned long long step,
-                                                 const double *__restrict__ red) {
-  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= p.n) return;
-  if (red[R_DMAX] == 0) return;  // "Horizontal diffusivity is 0, no random walk." (:1754)
-  double lon = p.lon[i], lat = p.lat[i];
+__device__ __forceinline__ void hdiff_velocity(const PView &p, long long i, int moving, double dt, int rng_mode,
+                                               const double *__restrict__ hnx, const double *__restrict__ hny,
+                                               unsigned long long seed, unsigned long long step, double &xu, double &xv) {
   double nx, ny;
   if (rng_mode == 1) { nx = hnx[i]; ny = hny[i]; }
   else {
@@ -1248,10 +1270,61 @@ __global__ __launch_bounds__(BLOCK) void k_hdiff(PView p, double dt, int rng_mod
     nx = g.x; ny = g.y;
   }
   float s = sqrtf(__fdiv_rn(__fmul_rn(2.0f, p.env[VAR_HDIFF][i]), (float)fabs(dt)));
-  int moving = p.moving[i];
-  double xu = __dmul_rn(__dmul_rn((double)moving, (double)s), nx);
-  double xv = __dmul_rn(__dmul_rn((double)moving, (double)s), ny);
+  xu = __dmul_rn(__dmul_rn((double)moving, (double)s), nx);
+  xv = __dmul_rn(__dmul_rn((double)moving, (double)s), ny);
+}
+__global__ __launch_bounds__(BLOCK) void k_hdiff(PView p, double dt, int rng_mode,
+                                                 const double *__restrict__ hnx,
+                                                 const double *__restrict__ hny,
+                                                 unsigned long long seed, unsigned long long step,
+                                                 const double *__restrict__ red) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  if (red[R_DMAX] == 0) return;  // "Horizontal diffusivity is 0, no random walk." (:1754)
+  double lon = p.lon[i], lat = p.lat[i];
+  const int moving = p.moving[i];
+  double xu, xv;
+  hdiff_velocity(p, i, moving, dt, rng_mode, hnx, hny, seed, step, xu, xv);
   move_f64(lon, lat, xu, xv, moving, dt);
+  p.lon[i] = lon;
+  p.lat[i] = lat;
+}
+
+// advect_wind -> stokes_drift -> horizontal_diffusion of one step in ONE launch (physics_methods.py:712-848,
+// basemodel/__init__.py:1746-1772), in the reference's order: each is an update_positions from where the previous one
+// left the element, the element stays in registers in between (three kernels re-read and re-write lon / lat / z / moving
+// and the environment: C4 0.30 ms of three launches).  `which`: 1 wind, 2 Stokes drift, 4 diffusion; a mover whose global
+// early-out holds (red[]: no element at the surface, wind / Stokes drift / diffusivity identically zero) is skipped as a
+// whole -- also its update_positions, which would renormalise the longitude.  Same arithmetic as the three kernels.
+struct MoversDesc {
+  int which, relative_wind, profile, hs_mode, tp_mode, rng_mode;
+  double dt, wind_drift_depth, wind_factor, stokes_factor;
+  const double *hnx, *hny;
+  unsigned long long seed, step;
+};
+__global__ __launch_bounds__(BLOCK) void k_movers(PView p, MoversDesc M, const double *__restrict__ red) {
+  const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  const bool wind = (M.which & 1) && !(red[R_NSURF] == 0 || red[R_WDFMAX] == 0 || red[R_RELWSPEEDMAX] == 0);
+  const bool stokes = (M.which & 2) && !(red[R_STOKESMAX] == 0);
+  const bool hdiff = (M.which & 4) && !(red[R_DMAX] == 0);
+  if (!(wind || stokes || hdiff)) return;
+  double lon = p.lon[i], lat = p.lat[i];
+  const double z = p.z[i];
+  const int moving = p.moving[i];
+  double xu, xv;
+  if (wind) {
+    wind_velocity(p, i, z, M.wind_drift_depth, M.relative_wind, M.wind_factor, xu, xv);
+    move_f64(lon, lat, xu, xv, moving, M.dt);
+  }
+  if (stokes) {
+    stokes_velocity(p, i, z, M.profile, M.hs_mode, M.tp_mode, M.stokes_factor, xu, xv);
+    move_f64(lon, lat, xu, xv, moving, M.dt);
+  }
+  if (hdiff) {
+    hdiff_velocity(p, i, moving, M.dt, M.rng_mode, M.hnx, M.hny, M.seed, M.step, xu, xv);
+    move_f64(lon, lat, xu, xv, moving, M.dt);
+  }
   p.lon[i] = lon;
   p.lat[i] = lat;
 }

@@ -3,9 +3,9 @@
 #define ODR_TU_STEP 1
 #include "odr_step_launch.h"
 
-template <int SCHEME, int NQ, bool TL>
-static void launch_mix(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G0, StepDesc S, double t, double dt, double factor,
-                       const StepMix &M) {
+template <int SCHEME, int NQ, bool TL, int SM>
+static void launch_mix_sm(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G0, StepDesc S, double t, double dt, double factor,
+                          const StepMix &M) {
   const EnvGroupDesc G = env_bind_out(G0, view(p));
   const DevSource &s = c->hw.src[G.sid];
   UVTime th = uv_time(s, t + dt / 2), tf = uv_time(s, t + dt);
@@ -13,8 +13,17 @@ static void launch_mix(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G0, Ste
   StageNoise N;
   memset(&N, 0, sizeof N);
   const size_t lds = sizeof(double) * ((size_t)(4 * NQ) * BLOCK + 4 * (size_t)(4 * NQ));
-  hipLaunchKernelGGL((k_step_grid<SCHEME, PROJ_LATLONG, true, false, NQ, TL>), dim3(nblk(p->n)), dim3(BLOCK), lds, c->stream,
+  N.sm = SM;
+  hipLaunchKernelGGL((k_step_grid<SCHEME, PROJ_LATLONG, true, false, NQ, TL, SM>), dim3(nblk(p->n)), dim3(BLOCK), lds, c->stream,
                      c->dw, view(p), G, S, dt, (float)factor, th, tf, c->counter, N, M);
+}
+template <int SCHEME, int NQ, bool TL>
+static void launch_mix(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G0, const StepDesc &S, double t, double dt, double factor,
+                       const StepMix &M) {
+  if constexpr (SCHEME > 0) {
+    if (c->stage_math == ODR_STAGE_FAST) { launch_mix_sm<SCHEME, NQ, TL, 1>(c, p, G0, S, t, dt, factor, M); return; }
+  }
+  launch_mix_sm<SCHEME, NQ, TL, 0>(c, p, G0, S, t, dt, factor, M);
 }
 
 template <int SCHEME>

@@ -28,11 +28,14 @@ static void launch_tile(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G0, co
 
 // Takes the step when the particle set carries a workgroup table of its last sort by the reader of the current
 // (odr_sort_particles), the step reads at most two resident time levels and a useful rectangle fits the LDS budget;
-// false: the caller launches k_step_grid.  ODR_TILE=0 switches it off, ODR_TILE_LDS=<bytes> sets the dynamic LDS per
+// false: the caller launches k_step_grid.  ODR_TILE=1 switches it on, ODR_TILE_LDS=<bytes> sets the dynamic LDS per
 // workgroup (default 38 KiB: four workgroups per CU), ODR_TILE_MIN_N the smallest particle count it is used for.
 bool odr_i_step_tile(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, StepDesc S, int scheme, double t, double dt,
                      double factor, const StageNoise &N) {
-  const bool off = getenv("ODR_TILE") && atoi(getenv("ODR_TILE")) == 0;
+  // Measured on C3 (profiles/r04_ab_variants.txt): bit-identical, but SLOWER than k_step_grid (0.89 vs 0.69 ms per launch at its
+  // best LDS budget): between two sorts vertical shear spreads a workgroup's particles over ~16 x 11 nodes of 416 bytes -- more
+  // than four workgroups per CU can hold -- and ranges cut along the sort tiles fill 70 % of the lanes.  It is opt-in.
+  const bool off = !getenv("ODR_TILE") || atoi(getenv("ODR_TILE")) == 0;
   const long long min_n = getenv("ODR_TILE_MIN_N") ? atoll(getenv("ODR_TILE_MIN_N")) : 262144;
   const size_t lds_cfg = getenv("ODR_TILE_LDS") ? (size_t)atoll(getenv("ODR_TILE_LDS")) : 38 * 1024;
   if (off || N.on || scheme < 1 || scheme > 2 || p->win != 0 || p->n < min_n) return false;

@@ -1569,6 +1569,54 @@ int odr_hdiffusion(odr_ctx *c, odr_particles *p, double dt, int rng_mode, const 
   return 0;
 }
 
+// advect_wind -> stokes_drift -> horizontal_diffusion (any subset, in that order) in one launch: k_movers.  Every check and
+// early return of the three entry points above is kept per mover; what is left of `which` after them runs as one kernel
+// behind one reduction.  Bit-identical to the separate calls (tests/test_gpu_movers.py).
+int odr_movers(odr_ctx *c, odr_particles *p, double dt, int which, double wdd, int relwind, double wind_factor, int profile,
+               int hs_mode, int tp_mode, double stokes_factor, int rng_mode, const double *hnx, const double *hny, uint64_t step) {
+  REQUIRE(which >= 0 && which <= 7, "which: 1 wind | 2 Stokes drift | 4 horizontal diffusion");
+  if (which & 1) {
+    if (!p->env[VAR_XWIND] || !p->env[VAR_YWIND]) return fail(ODR_ERR_STATE, "wind has not been sampled");
+    if (relwind && (!p->env[VAR_U] || !p->env[VAR_V])) return fail(ODR_ERR_STATE, "current has not been sampled");
+    if (!relwind && env_is_const(p, VAR_XWIND, 0.0f) && env_is_const(p, VAR_YWIND, 0.0f)) which &= ~1;
+  }
+  if (which & 2) {
+    REQUIRE(profile >= 0 && profile <= 3 && hs_mode >= 0 && hs_mode <= 2 && tp_mode >= 0 && tp_mode <= 3, "bad stokes options");
+    if (!p->env[VAR_SX] || !p->env[VAR_SY]) return fail(ODR_ERR_STATE, "Stokes drift has not been sampled");
+    if (profile == 3) {
+      for (int v : {VAR_SWELL_DIR, VAR_SWELL_TP, VAR_SWELL_HS, VAR_WW_DIR, VAR_WW_TM, VAR_WW_HS})
+        if (!p->env[v]) return fail(ODR_ERR_STATE, "the windsea_swell profile needs the swell / wind-sea direction, period and height (variable %d not sampled)", v);
+    } else {
+      if ((hs_mode == 0 && !p->env[VAR_HS]) || (tp_mode == 0 && !p->env[VAR_TP])) return fail(ODR_ERR_STATE, "Hs/Tp not sampled");
+      if ((hs_mode == 1 || tp_mode == 1 || tp_mode == 3) && (!p->env[VAR_XWIND] || !p->env[VAR_YWIND])) return fail(ODR_ERR_STATE, "wind not sampled");
+    }
+    if (env_is_const(p, VAR_SX, 0.0f) && env_is_const(p, VAR_SY, 0.0f)) which &= ~2;
+  }
+  if (which & 4) {
+    if (!p->env[VAR_HDIFF]) return fail(ODR_ERR_STATE, "horizontal_diffusivity has not been sampled");
+    if (env_is_const(p, VAR_HDIFF, 0.0f)) which &= ~4;
+  }
+  if (p->n == 0 || which == 0) return 0;
+  MoversDesc M;
+  memset(&M, 0, sizeof M);
+  int rc;
+  if ((which & 4) && rng_mode == ODR_RNG_HOST) {
+    REQUIRE(hnx && hny, "host normals required in ODR_RNG_HOST mode");
+    double *da = nullptr, *db = nullptr;
+    if ((rc = host_to_scratch(c, p, hnx, hny, (size_t)p->n, &da, &db))) return rc;
+    M.hnx = da; M.hny = db;
+  }
+  // the reduction of the first mover that needs the wind arguments (the cached one is reused by the others: nothing they
+  // read changes in between)
+  if ((rc = (which & 1) ? reduce(c, p, wdd, relwind, true, false) : reduce(c, p, 0.0, 0, false, false))) return rc;
+  M.which = which; M.relative_wind = relwind; M.profile = profile; M.hs_mode = hs_mode; M.tp_mode = tp_mode; M.rng_mode = rng_mode;
+  M.dt = dt; M.wind_drift_depth = wdd; M.wind_factor = wind_factor; M.stokes_factor = stokes_factor;
+  M.seed = c->seed; M.step = (unsigned long long)step;
+  hipLaunchKernelGGL(k_movers, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), M, c->red);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // odr_vmix followed by odr_vertical_advection in one kernel (same particle, same z): request
 // the fusion for the next odr_vmix call
 int odr_vmix_fuse_vertical_advection(odr_ctx *c, int at_surface) {

@@ -629,6 +629,23 @@ class Particles:
         else:
             check(self.lib.odr_hdiffusion(self.ctx.h, self.h, float(dt), _abi.RNG_DEVICE, None, None, step))
 
+    def movers(self, dt, wind=None, stokes=None, hdiffusion=None):
+        """advect_wind -> stokes_drift -> horizontal_diffusion in one launch (odr_movers).  Each argument is None (mover not
+        applied) or the keyword arguments of the method of that name: wind=dict(wind_drift_depth=0.1, relative_wind=False,
+        factor=1.0), stokes=dict(profile=2, hs_mode=0, tp_mode=0, factor=1.0), hdiffusion=dict(step=0, normals=None)."""
+        which = (1 if wind is not None else 0) | (2 if stokes is not None else 0) | (4 if hdiffusion is not None else 0)
+        w, s, h = wind or {}, stokes or {}, hdiffusion or {}
+        px = py = None
+        mode = _abi.RNG_DEVICE
+        if h.get('normals') is not None:
+            n = len(self)
+            (ax, px), (ay, py) = _d(self._host_order(h['normals'][0]), n), _d(self._host_order(h['normals'][1]), n)
+            mode = _abi.RNG_HOST
+        check(self.lib.odr_movers(self.ctx.h, self.h, float(dt), which, float(w.get('wind_drift_depth', 0.1)),
+                                  int(bool(w.get('relative_wind', False))), float(w.get('factor', 1.0)),
+                                  int(s.get('profile', 2)), int(s.get('hs_mode', 0)), int(s.get('tp_mode', 0)),
+                                  float(s.get('factor', 1.0)), mode, px, py, int(h.get('step', 0))))
+
     def vmix(self, t_epoch, dt, dt_mix, mix_at_surface=False, step=0, uniforms=None, fuse_vertical_advection=None):
         if fuse_vertical_advection is not None:   # True: include surface elements, False: z<0 only
             check(self.lib.odr_vmix_fuse_vertical_advection(self.ctx.h, int(bool(fuse_vertical_advection))))
@@ -852,7 +869,7 @@ def _touching(fn):
 
 
 for _name in ('append', 'upload', 'env_sample', 'env_upload', 'env_add_noise', 'advect', 'env_coast_advect',
-              'update_positions', 'advect_wind', 'stokes_drift', 'advect_sea_ice', 'set_property', 'leeway_capsize', 'leeway', 'hdiffusion',
+              'update_positions', 'advect_wind', 'stokes_drift', 'advect_sea_ice', 'set_property', 'leeway_capsize', 'leeway', 'hdiffusion', 'movers',
               'vmix', 'vmix_analytic', 'vmix_oil', 'vertical_advection', 'vertical_buoyancy', 'coastline', 'coastline_crossing',
               'increase_age', 'deactivate_missing', 'remap_status', 'seafloor', 'deactivate', 'deactivate_outside', 'compact',
               'compact_apply', 'sort_by_cell', 'store_previous', 'oil_prepare_mixing', 'env_coast_leeway'):

@@ -850,25 +850,45 @@ class OpenDriftSimulation(Configurable):
         live = [n for n in self.priority_list.get(v, []) if n in self.readers and self.readers[n].sid is not None]
         return not live and v in self.required_variables and self.get_config('environment:fallback:%s' % v) == 0
 
-    def stokes_drift(self, factor=1):
+    def _stokes_arguments(self, factor=1):
+        """The arguments of the device's Stokes drift for this step, or None when stokes_drift() returns early.  Leaves the
+        reduction of a sharded run installed (the caller unpins it)."""
         if self.get_config('drift:stokes_drift') is False:
-            return
+            return None
         profile = {'monochromatic': 0, 'exponential': 1, 'Phillips': 2, 'windsea_swell': 3}[
             self.get_config('drift:stokes_drift_profile', 'Phillips')]
         if self._identically_zero('sea_surface_wave_stokes_drift_x_velocity') and \
                 self._identically_zero('sea_surface_wave_stokes_drift_y_velocity'):
-            return      # "No Stokes drift velocity available" (physics_methods.py:799-804) without a device round trip
+            return None  # "No Stokes drift velocity available" (physics_methods.py:799-804) without a device round trip
         r = self._reduce_scalars(self.get_config('drift:wind_drift_depth', 0.1))
+        if r['stokes_sum_max'] == 0:
+            return None
+        # provenance of Hs / Tp (physics_methods.py:893-943, :809-814)
+        hs_mode = 0 if r['hs_max'] > 0 else (1 if r['wind_speed_max'] > 0 else 2)
+        tp_mode = 1 if r['wind_speed_max'] >= 0 else 2   # Tp is not an OceanDrift variable: from wind (omega=5 when calm)
+        return dict(profile=profile, hs_mode=hs_mode, tp_mode=tp_mode, factor=factor)
+
+    def stokes_drift(self, factor=1):
         try:
-            if r['stokes_sum_max'] == 0:
-                return
-            # provenance of Hs / Tp (physics_methods.py:893-943, :809-814)
-            hs_mode = 0 if r['hs_max'] > 0 else (1 if r['wind_speed_max'] > 0 else 2)
-            tp_mode = 1 if r['wind_speed_max'] >= 0 else 2   # Tp is not an OceanDrift variable: from wind (omega=5 when calm)
-            self.P.stokes_drift(self.time_step.total_seconds(), profile, hs_mode, tp_mode, factor)
+            a = self._stokes_arguments(factor)
+            if a is not None:
+                self.P.stokes_drift(self.time_step.total_seconds(), a['profile'], a['hs_mode'], a['tp_mode'], a['factor'])
         finally:
             if self._world > 1 and getattr(self, '_step_red', None) is None:
                 self.P.reduce_unpin()
+
+    def _advect_wind_then_stokes_drift(self):
+        """advect_wind() followed by stokes_drift() (update(), oceandrift.py:185-211).  One process and neither method
+        overridden: the two movers run as ONE launch (odr_movers: same bits as the two calls)."""
+        cls = type(self)
+        if self._world > 1 or cls.advect_wind is not OceanDrift.advect_wind or cls.stokes_drift is not OceanDrift.stokes_drift:
+            self.advect_wind()
+            self.stokes_drift()
+            return
+        a = self._stokes_arguments()
+        self.P.movers(self.time_step.total_seconds(),
+                      wind=dict(wind_drift_depth=self.get_config('drift:wind_drift_depth', 0.1),
+                                relative_wind=self.get_config('drift:relative_wind'), factor=1), stokes=a)
 
     def prepare_run(self):
         pass
@@ -1383,8 +1403,7 @@ class OceanDrift(OpenDriftSimulation):
 
     def update(self):   # oceandrift.py:185-211
         self.advect_ocean_current()
-        self.advect_wind()
-        self.stokes_drift()
+        self._advect_wind_then_stokes_drift()
         self.update_terminal_velocity()
         if self.get_config('drift:vertical_mixing') is True:
             self.vertical_mixing()
