@@ -363,6 +363,66 @@ def model_api_leg(fields, n, steps, device):
                 'vertical advection, horizontal diffusion early-out)')
 
 
+class ShardedLoop:
+    """What a sharded OceanDrift.run() does around the device step of every rank (opendrift_amd/oceandrift.py, DESIGN.md
+    section 6), inside the timed region of `bench.py --gpus N`:
+      (i) ONE collective per step -- every rank's step summary (kept count, eight status-reason flags, its 16 raw reduction
+          slots) all-gathered (distributed.allgather_vector; RCCL under nccl): OceanDrift._step_summary;
+      (ii) a new reader time level every `block_every` steps: rank 0 holds the host Reader's arrays, the broadcast of the
+          NEXT level is started one period ahead (distributed.start_broadcast_block: RCCL broadcast straight into device
+          memory) and waited for when the level is due; `install(tensors, j)` hands it to the device
+          (odr_block_upload_device): DeviceReaderBinding._prefetch_dist / _upload.
+    Counters: collectives, collective_s, levels, level_stall_s (host time spent waiting for a level that was due)."""
+
+    def __init__(self, fields, names, block_every, install=None):
+        from opendrift_amd import distributed as D
+        self.D, self.rank, _, self.world = D, *D.env_world()
+        self.fields, self.names, self.block_every, self.install = fields, names, int(block_every), install
+        self.collectives, self.collective_s, self.levels, self.level_stall_s = 0, 0.0, 0, 0.0
+        self.pending = None
+        self.last = None
+
+    def _start(self, j):
+        g = self.fields['g']
+        nlev = len(g['t'])
+        arrays = {k: g[k][j % nlev] for k in self.names} if self.rank == 0 else None
+        shapes = {k: g[k][j % nlev].shape for k in self.names}
+        self.pending = (j, ) + self.D.start_broadcast_block(arrays, shapes, src=0)
+
+    def before_step(self, k):
+        if not self.block_every or self.fields is None or k % self.block_every:
+            return
+        j = k // self.block_every
+        if self.pending is None or self.pending[0] != j:
+            self._start(j)                     # (first level of the loop: nothing was started ahead)
+        t0 = time.perf_counter()
+        _, tens, works = self.pending
+        self.D.finish_broadcast(works)
+        self.level_stall_s += time.perf_counter() - t0
+        self.levels += 1
+        if self.install is not None:
+            self.install(tens, j)
+        self.last = tens
+        self._start(j + 1)                     # the next level travels while this one is in use
+
+    def after_step(self, kept, flags=0, raw16=None):
+        row = np.concatenate([[float(kept)], [float(flags >> b & 1) for b in range(8)], np.zeros(16) if raw16 is None else raw16])
+        t0 = time.perf_counter()
+        rows = self.D.allgather_vector(row)
+        self.collective_s += time.perf_counter() - t0
+        self.collectives += 1
+        return int(round(rows[:, 0].sum()))
+
+    def finish(self):
+        if self.pending is not None:           # the level started ahead of the loop's end: no collective may stay open
+            self.D.finish_broadcast(self.pending[2])
+            self.pending = None
+
+    def report(self, steps):
+        return dict(collectives=self.collectives, collectives_per_step=self.collectives / max(1, steps), collective_s=self.collective_s,
+                    reader_levels=self.levels, block_every=self.block_every, reader_level_stall_s=self.level_stall_s)
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` on its own (no RANK / WORLD_SIZE in the environment) starts its N ranks itself: this
     process becomes the launcher of `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same
@@ -397,12 +457,23 @@ def plumbing_only(a):
         arrays = {k: g[k][0] for k in names} if rank == 0 else None
         tens = D.broadcast_block(arrays, shapes={k: g[k][0].shape for k in names}, src=0)
         ok = ok and all(np.array_equal(tens[k].cpu().numpy(), g[k][0], equal_nan=True) for k in names)
+    # the sharded loop's communication (one collective per step, a reader level every block_every steps) without the device step
+    be = a.block_every or (6 if world > 1 and fields is not None else 0)
+    sh = ShardedLoop(fields, fields['names'] if fields is not None else [], be)
     D.barrier()
     t0 = time.perf_counter()
+    g_kept = n * world
     for k in range(a.steps):
-        pass
+        sh.before_step(k)
+        g_kept = sh.after_step(n)
+    sh.finish()
     el = time.perf_counter() - t0
     D.barrier()
+    ok = ok and g_kept == n * world
+    if fields is not None and sh.last is not None:     # the last level that arrived is rank 0's array of that level
+        g = fields['g']
+        j = (a.steps - 1) // be if be else 0
+        ok = ok and all(np.array_equal(sh.last[k].cpu().numpy(), g[k][j % len(g['t'])], equal_nan=True) for k in fields['names'])
     el_max = float(D.allreduce_scalars([el], 'max')[0])
     units = float(D.allreduce_scalars([float(n * a.steps)], 'sum')[0])
     all_ok = float(D.allreduce_scalars([1.0 if ok else 0.0], 'min')[0]) == 1.0
@@ -410,7 +481,7 @@ def plumbing_only(a):
         print(json.dumps({'metric': 'particle-steps/sec (plumbing only: nothing measured)', 'value': None, 'unit': 'particle-steps/s',
                           'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': None, 'higher_is_better': True,
                           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'plumbing_only': True,
-                          'shards_ok': all_ok, 'units_all_ranks': units, 'loop_s_max_over_ranks': el_max,
+                          'shards_ok': all_ok, 'units_all_ranks': units, 'loop_s_max_over_ranks': el_max, 'sharded_loop': sh.report(a.steps),
                           'config': {'workload': a.workload, 'particles_per_gpu': n, 'particles_total': n * world}}), flush=True)
     if world > 1:
         import torch.distributed as dist
@@ -493,6 +564,20 @@ def main():
                                     np.full(n, 0.04), ori, np.zeros(n)]):
             P.set_property(slot, val.astype(np.float32))
 
+    # N > 1: the timed loop is the SHARDED step -- besides the device step of this rank's particles, the one collective per
+    # step and the reader levels arriving from rank 0 by RCCL broadcast (ShardedLoop; weak scaling: every rank steps n particles)
+    sharded = None
+    if world > 1 and a.workload != 'c2':
+        def install(tens, j):
+            g = fields['g']
+            slot = j % 3
+            if next(iter(tens.values())).is_cuda:     # RCCL: the level arrived in device memory
+                ctx.upload_block_device(wl.sid, slot, float(g['t'][slot]), {kk: t.data_ptr() for kk, t in tens.items()},
+                                        {kk: (t.shape[0] if t.dim() == 3 else 1) for kk, t in tens.items()}, content_ids=wl.static_ids)
+            else:                                     # gloo rehearsal (ODR_DIST_BACKEND=gloo): host tensors
+                ctx.upload_block(wl.sid, slot, float(g['t'][slot]), {kk: t.numpy() for kk, t in tens.items()}, content_ids=wl.static_ids)
+        sharded = ShardedLoop(fields, fields['names'], a.block_every or 6, install)
+
     def timed_loop(steps, first, block_every=0, block_async=False, pinned=None):
         """`steps` steps between barrier + synchronize on both sides; returns (seconds, particle-steps of this rank)"""
         ctx.sync()
@@ -501,6 +586,12 @@ def main():
         n0 = len(P)
         t0 = time.perf_counter()
         for k in range(steps):
+            if sharded is not None:
+                sharded.before_step(k)
+                wl.step(P, first + k)
+                kept, flags = P.scan_status()          # the ONE host read of a sharded step (OceanDrift.run())
+                sharded.after_step(kept, flags)
+                continue
             if block_every and a.workload != 'c2':   # a new reader time level arrives every block_every steps
                 g = fields['g']
                 j = k // block_every
@@ -513,6 +604,8 @@ def main():
                 elif k % block_every == 0:
                     ctx.upload_block(wl.sid, j % 3, float(g['t'][j % 3]), {kk: g[kk][j % 3] for kk in fields['names']}, content_ids=wl.static_ids)
             wl.step(P, first + k)
+        if sharded is not None:
+            sharded.finish()
         ctx.sync()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
@@ -542,7 +635,12 @@ def main():
         wl.step(P, spin + k)
     if a.block_every and a.workload != 'c2':
         warm_uploads(pinned)
+    if sharded is not None:      # untimed: RCCL channels, staging buffers and the recyclable blocks exist before the timed region
+        timed_loop(2 * sharded.block_every + 1, spin + a.warmup)
+        sharded.collectives, sharded.collective_s, sharded.levels, sharded.level_stall_s = 0, 0.0, 0, 0.0
     el, units_rank = timed_loop(a.steps, spin + a.warmup, a.block_every, a.block_async, pinned)
+    sharded_report = sharded.report(a.steps) if sharded is not None else None
+    sharded = None               # the legs below (kernel timings, the other stage arithmetic) time this rank's device step alone
     el_max = float(D.allreduce_scalars([el], 'max')[0])
     units = float(D.allreduce_scalars([units_rank], 'sum')[0])
 
@@ -587,10 +685,10 @@ def main():
         other = dict(value=units_o / el_o, unit='particle-steps/s', ms_per_step=1e3 * el_o / nst_o, steps=nst_o, kernel_ms=ko_ms)
         ctx.set_stage_math(a.stage_math)
 
-    # counters of the same command from the committed rocprofv3 passes (profiles/r03_<workload>_pmc.json, written by
-    # tools/gpu_profile_r03.sh + tools/collect_profiles_r03.py from this tree): PMC counters cannot be collected from inside
+    # counters of the same command from the committed rocprofv3 passes (profiles/r04_<workload>_pmc.json, written by
+    # tools/gpu_profile_r04.sh + tools/collect_profiles_r04.py from this tree): PMC counters cannot be collected from inside
     # this process.  Used only when they belong to this size and stage math.
-    pmc, pmc_file = None, os.path.join('profiles', 'r03_%s_pmc.json' % a.workload)
+    pmc, pmc_file = None, os.path.join('profiles', 'r04_%s_pmc.json' % a.workload)
     if os.path.exists(os.path.join(ROOT, pmc_file)):
         pm = json.load(open(os.path.join(ROOT, pmc_file)))
         if pm.get('particles') == n and pm.get('stage_math', a.stage_math) == a.stage_math:
@@ -645,47 +743,53 @@ def main():
                        'note': 'SURVEY 8(d) accounting: counts corners served by L1 / L2 / Infinity Cache; not a physical bandwidth'}
         out['roofline_algorithmic'] = algorithmic
         if pmc is not None:
-            # (2) the ceilings of the dominant kernel from its counters, each as the share of the launch time that unit alone
-            # accounts for.  HBM: bytes / 8 TB/s.  VALU issue: 1 024 SIMDs, every wave64 instruction priced by class as
-            # measured by tools/rate_bench.hip (profiles/r03_rate_bench_raw.txt): float64 arithmetic / conversions 4 cycles,
-            # transcendental float64 16, every other 2.  Texture addresser (TA: the unit that turns the lanes of a vector-memory
-            # instruction into cache-line lookups, one per CU): its BUSY cycles per CU (TA_TA_BUSY) over the launch's cycles --
-            # a gather of 64 lanes in 64 different lines keeps it busy ~32 cycles whatever the width
-            # (tools/gather_bench.hip, profiles/r03_gather_bench.txt).  Clock: the profile's own (GRBM_GUI_ACTIVE / time).
-            hbm_bytes = pmc['FETCH_SIZE_bytes_x2'] + pmc['WRITE_SIZE_bytes']
-            clk = (pmc.get('GRBM_GUI_ACTIVE_8xcd') or 0) / 8.0 / (pmc['kernel_us_rocprof'] * 1e-6) if pmc.get('GRBM_GUI_ACTIVE_8xcd') else 2.4e9
-            t_hbm = hbm_bytes / HBM_PEAK
-            t_ta = (pmc.get('TA_TA_BUSY') or 0) / 256.0 / clk
-            t_valu = pmc['valu_cycles_per_simd_slot'] / (1024 * clk)
-            ceil = {'hbm': t_hbm, 'ta_busy': t_ta, 'valu_issue': t_valu}
-            bound = max(ceil, key=ceil.get)
-            ks = k_ms * 1e-3
+            # (2) roofline of the dominant kernel: achieved = its HBM bytes per launch from the counters (FETCH_SIZE x 2 +
+            # WRITE_SIZE, MI355X_MICROARCH.md) over the launch time measured HERE with HIP events; peak = 8 TB/s; frac =
+            # achieved / peak -- a fraction of a physical peak, whichever unit binds.  `units` carries the other units of the
+            # launch the same way, achieved / measured peak: L1 lookups per clock per CU against the 2.03 of
+            # tools/gather_bench.hip's `nodes` shape (profiles/r03_gather_bench.txt); VALU issue cycles (every wave64
+            # instruction priced by class as measured by tools/rate_bench.hip: float64 arithmetic / conversions 4,
+            # transcendental float64 16, other 2) against 1 024 SIMDs; and, as a diagnostic only, the share of the launch the
+            # texture addresser reported busy (TA_TA_BUSY: includes the cycles it waits on the caches -- not a roofline).
+            def units_of(q, ms):
+                hb = q['FETCH_SIZE_bytes_x2'] + q['WRITE_SIZE_bytes']
+                clk_ = (q.get('GRBM_GUI_ACTIVE_8xcd') or 0) / 8.0 / (q['kernel_us_rocprof'] * 1e-6) if q.get('GRBM_GUI_ACTIVE_8xcd') else 2.4e9
+                sec = ms * 1e-3
+                return hb, clk_, {
+                    'hbm': hb / sec / HBM_PEAK,
+                    'l1_lookups': (q.get('TCP_TOTAL_CACHE_ACCESSES') or 0) / 256.0 / (clk_ * q['kernel_us_rocprof'] * 1e-6) / 2.03,
+                    'valu_issue': q['valu_cycles_per_simd_slot'] / (1024 * clk_) / sec,
+                    'ta_busy_share_diagnostic': (q.get('TA_TA_BUSY') or 0) / 256.0 / clk_ / sec}
+            hbm_bytes, clk, un = units_of(pmc, k_ms)
             out['roofline'] = {
-                'bound': bound, 'kernel': kname, 'kernel_ms': k_ms, 'kernel_ms_median': k_ms_median,
-                'achieved': {'hbm': hbm_bytes / ks / 1e9, 'ta_busy': (pmc.get('TA_TA_BUSY') or 0) / ks / 1e9,
-                             'valu_issue': pmc['valu_cycles_per_simd_slot'] / ks / 1e9}[bound],
-                'peak': {'hbm': HBM_PEAK / 1e9, 'ta_busy': 256 * clk / 1e9, 'valu_issue': 1024 * clk / 1e9}[bound],
-                'unit': {'hbm': 'GB/s', 'ta_busy': 'G texture-addresser busy cycles/s (256 CUs)', 'valu_issue': 'G SIMD-cycles/s'}[bound],
-                'frac': ceil[bound] / ks,
-                'traffic': hbm_bytes / 1e9, 'traffic_unit': 'GB of HBM traffic per launch (FETCH_SIZE x2 + WRITE_SIZE)',
-                'fractions': {k: v / ks for k, v in ceil.items()},
-                'l1_lane_accesses_per_clk_per_cu': (pmc.get('TCP_TOTAL_CACHE_ACCESSES') or 0) / 256.0 / (clk * pmc['kernel_us_rocprof'] * 1e-6),
+                'bound': 'hbm', 'kernel': kname, 'kernel_ms': k_ms, 'kernel_ms_median': k_ms_median,
+                'achieved': hbm_bytes / (k_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': un['hbm'],
+                'traffic': hbm_bytes / 1e9, 'traffic_unit': 'GB of HBM traffic per launch (FETCH_SIZE x 2 + WRITE_SIZE)',
+                'algorithmic_gb_per_launch': kbytes * nact / 1e9,
+                'units': un, 'binding_unit': max((k for k in un if not k.endswith('diagnostic')), key=lambda k: un[k]),
                 'clock_ghz': clk / 1e9,
                 'source': pmc_file + ' (counters of the same command and tree; this line times the launch itself)',
-                'note': 'the binding ceiling of the dominant kernel; the SURVEY 8(d) figure is roofline_algorithmic'}
+                'note': 'frac = HBM bytes of the launch (counters) / launch time / 8 TB/s; the SURVEY 8(d) figure is roofline_algorithmic'}
             if 'second' in pmc and k2_ms is not None:
-                q = pmc['second']
-                c2 = {'hbm': (q['FETCH_SIZE_bytes_x2'] + q['WRITE_SIZE_bytes']) / HBM_PEAK,
-                      'ta_busy': (q.get('TA_TA_BUSY') or 0) / 256.0 / clk,
-                      'valu_issue': q['valu_cycles_per_simd_slot'] / (1024 * clk)}
-                b2 = max(c2, key=c2.get)
-                out['roofline']['second_kernel'] = {'kernel': 'k_vmix_col', 'kernel_ms': k2_ms, 'bound': b2,
-                                                    'frac': c2[b2] / (k2_ms * 1e-3), 'fractions': {k: v / (k2_ms * 1e-3) for k, v in c2.items()}}
+                hb2, _, un2 = units_of(pmc['second'], k2_ms)
+                out['roofline']['second_kernel'] = {'kernel': 'k_vmix_col', 'kernel_ms': k2_ms, 'frac': un2['hbm'], 'traffic': hb2 / 1e9,
+                                                    'units': un2}
+            if pmc.get('step_hbm_bytes'):
+                # every kernel of a step (re-sort share included), real HBM bytes over the measured step time
+                sb = pmc['step_hbm_bytes']
+                out['roofline_step'] = {'bound': 'hbm', 'achieved': sb / (el_max / a.steps) / 1e9,
+                                        'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': sb / (el_max / a.steps) / HBM_PEAK,
+                                        'traffic': sb / 1e9, 'kernels': pmc.get('step_hbm_kernels'),
+                                        'note': 'HBM bytes of ALL kernels of one step (counters, calls per step from the kernel trace) / ms_per_step / 8 TB/s'}
         else:
             out['roofline'] = dict(algorithmic, kernel_ms=k_ms, kernel_ms_median=k_ms_median, traffic=None,
                                    note='no counter file for this size / stage math: the SURVEY 8(d) algorithmic figure only')
             if k2_ms is not None:
                 out['roofline']['second_kernel'] = {'kernel': 'k_vmix_col', 'kernel_ms': k2_ms}
+        if sharded_report is not None:
+            out['sharded_loop'] = dict(sharded_report, what='the timed region holds, per step: the device step of this rank, one host read '
+                                       '(odr_scan_status) and ONE all_gather of the step summaries; every block_every steps a reader level '
+                                       'from rank 0 (RCCL broadcast started one period ahead) -> odr_block_upload_device')
         if a.workload in ('c3', 'c4'):
             ts = P.tile_stats()     # the LDS-tile step (csrc/odr_tile.hip.h): launches on that path / elements it handed to the HBM path
             out['lds_tile'] = dict(ts, handed_over_per_launch=(ts['handed_over'] / ts['launches'] if ts['launches'] else None))

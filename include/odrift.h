@@ -188,6 +188,10 @@ int odr_block_set_content_ids(odr_ctx *ctx, int32_t source_id, int32_t slot, int
 int odr_host_register(odr_ctx *ctx, void *ptr, uint64_t bytes);   /* hipHostRegister: reader arrays that are uploaded repeatedly */
 int odr_host_unregister(odr_ctx *ctx, void *ptr);
 int odr_block_drop(odr_ctx *ctx, int32_t source_id, int32_t slot);
+/* A source that is no longer used (e.g. a gridded reader whose blocks are re-cut to another window and re-registered):
+ * drops its resident blocks, removes it from every priority list (odr_env_bind) and frees its id for the next
+ * odr_source_* call -- the context holds at most 16 sources at a time, not 16 per run. */
+int odr_source_release(odr_ctx *ctx, int32_t source_id);
 /* reader.start_time / end_time / always_valid (covers_time, variables.py:392-400): outside the
  * interval the reader is skipped and the next reader / the fallback applies */
 int odr_source_time_coverage(odr_ctx *ctx, int32_t source_id, double t_start_epoch, double t_end_epoch,

@@ -55,7 +55,7 @@ class ProjDesc(C.Structure):
 
 
 class OdrError(RuntimeError):
-    pass
+    code = 0          # the ODR_ERR_* value (include/odrift.h): -3 = a capacity of the device library is exhausted
 
 
 _P = C.POINTER
@@ -133,6 +133,7 @@ _SIGNATURES = {
     'odr_coastline_crossing': [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int32, _i64p],
     'odr_increase_age': [_vp, _vp, C.c_double, C.c_double, C.c_int],
     'odr_source_time_coverage': [_vp, C.c_int32, C.c_double, C.c_double, C.c_int],
+    'odr_source_release': [_vp, C.c_int32],
     'odr_seafloor': [_vp, _vp, _i64p],
     'odr_seafloor_action': [_vp, _vp, C.c_int, C.c_int32, _i64p],
     'odr_set_seafloor_action': [_vp, C.c_int, C.c_int32],
@@ -210,4 +211,6 @@ def check(rc):
         msg = load().odr_last_error().decode()
         if rc == -1:
             raise ValueError(msg)
-        raise OdrError('odrift error %d: %s' % (rc, msg))
+        e = OdrError('odrift error %d: %s' % (rc, msg))
+        e.code = rc
+        raise e

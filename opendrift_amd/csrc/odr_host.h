@@ -75,6 +75,7 @@ struct odr_ctx {
   unsigned long long *counter;
   hipEvent_t ev0, ev1;
   int nsrc;
+  bool src_free[MAXSRC];   // source ids released by odr_source_release, reused by the next new source
   int stage_math;   // odr_ctx_set_stage_math: ODR_STAGE_EXACT | ODR_STAGE_FAST (Runge-Kutta stage evaluations)
   int fuse_vadv;
   int seafloor;     // general:seafloor_action for the in-update() sea floor checks: action | status_code << 8

@@ -1557,8 +1557,11 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
   p.z[i] = z;
 }
 
+#ifndef ODR_VMIX_WAVES
+#define ODR_VMIX_WAVES 6   // 80 registers, no scratch: six workgroups (24.6 KB of LDS each) per CU; unconstrained the allocator took 102 (4 waves)
+#endif
 template <int NQ, bool TL>
-__global__ __launch_bounds__(BLOCK) void k_vmix_col(const DevWorld *__restrict__ W, PView p, VMixDesc D,
+__global__ __launch_bounds__(BLOCK, ODR_VMIX_WAVES) void k_vmix_col(const DevWorld *__restrict__ W, PView p, VMixDesc D,
                                                     double dt, double dt_mix_cfg, int mix_at_surface,
                                                     int rng_mode, const double *__restrict__ huni,
                                                     unsigned long long seed, unsigned long long step,

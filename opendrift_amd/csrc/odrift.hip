@@ -342,7 +342,23 @@ static void proj_init(DevProj &p, const odr_proj_desc *d) {
 }
 
 static int new_source(odr_ctx *c, int kind, int32_t *sid) {
-  if (c->nsrc >= MAXSRC) return fail(ODR_ERR_CAPACITY, "at most %d field sources", MAXSRC);
+  int slot = -1;
+  for (int k = 0; k < c->nsrc; ++k) if (c->src_free[k]) { slot = k; break; }   // a released source id first (odr_source_release)
+  if (slot < 0 && c->nsrc >= MAXSRC) return fail(ODR_ERR_CAPACITY, "at most %d field sources", MAXSRC);
+  if (slot >= 0) {
+    c->src_free[slot] = false;
+    DevSource &r = c->hw.src[slot];
+    memset(&r, 0, sizeof r);
+    r.kind = kind;
+    proj_init(r.proj, nullptr);
+    r.xmin = -180; r.xmax = 180; r.ymin = -90; r.ymax = 90;
+    r.zmin = -INFINITY; r.zmax = INFINITY;
+    r.tmin = -INFINITY; r.tmax = INFINITY;
+    r.lon_mode = 1;
+    *sid = slot;
+    c->dirty = true;
+    return 0;
+  }
   DevSource &s = c->hw.src[c->nsrc];
   memset(&s, 0, sizeof s);
   s.kind = kind;
@@ -840,6 +856,30 @@ int odr_block_drop(odr_ctx *c, int32_t sid, int32_t slot) {
   memset(&c->hw.src[sid].slot[slot], 0, sizeof(DevBlock));
   memset(c->block_cid[sid][slot], 0, sizeof c->block_cid[sid][slot]);
   sort_levels(c->hw.src[sid]);
+  c->dirty = true;
+  return 0;
+}
+
+// A source the caller no longer uses (a gridded reader whose blocks were re-cut to a new window gets a new source): its
+// resident blocks are dropped, it leaves every priority list, and its id is handed out again by the next odr_source_*.
+int odr_source_release(odr_ctx *c, int32_t sid) {
+  REQUIRE(sid >= 0 && sid < c->nsrc && !c->src_free[sid], "unknown source %d", sid);
+  int rc;
+  for (int slot = 0; slot < MAXLEVELS; ++slot)
+    if (!c->block_bufs[sid][slot].empty() || c->staged[sid][slot].base)
+      if ((rc = odr_block_drop(c, sid, slot))) return rc;
+  for (int v = 0; v < NVAR; ++v) {
+    int m = 0;
+    for (int k = 0; k < c->hw.nlist[v]; ++k) if (c->hw.list[v][k] != sid) c->hw.list[v][m++] = c->hw.list[v][k];
+    c->hw.nlist[v] = m;
+  }
+  DevSource &s = c->hw.src[sid];
+  memset(&s, 0, sizeof s);
+  s.kind = SRC_CONSTANT;                 // covers nothing: every const_val is NaN
+  for (int v = 0; v < NVAR; ++v) s.const_val[v] = NAN;
+  s.xmin = s.ymin = s.zmin = s.tmin = INFINITY; s.xmax = s.ymax = s.zmax = s.tmax = -INFINITY;
+  c->src_free[sid] = true;
+  if (c->red_owner) c->red_owner = nullptr;
   c->dirty = true;
   return 0;
 }

@@ -321,6 +321,11 @@ class Context:
     def drop_block(self, sid, slot):
         check(self.lib.odr_block_drop(self.h, sid, slot))
 
+    def release_source(self, sid):
+        """The source is no longer used: its blocks are dropped, its id is free for the next add_* (odr_source_release)."""
+        check(self.lib.odr_source_release(self.h, int(sid)))
+        self._grids.pop(sid, None)
+
     def bind(self, variable, source_ids, fallback=np.nan):
         ids, pi = _i(list(source_ids)) if len(source_ids) else (None, None)
         check(self.lib.odr_env_bind(self.h, _vid(variable), len(source_ids), pi,

@@ -210,6 +210,28 @@ def _device():
         (world == 1 and torch.cuda.is_available()) else torch.device('cpu')
 
 
+_STAGING = {}      # (variable, shape) -> [two page-locked host tensors, the events of their last copies, turn]
+
+
+def _staged_to_device(key, a, dev):
+    """Host array -> device tensor through a page-locked staging buffer that is REUSED: two per (variable, shape), in turn
+    (hipHostMalloc of a 210 MB level on the critical path every few steps otherwise); a buffer is overwritten only after
+    the copy that last read it has completed (its event)."""
+    import torch
+    st = _STAGING.get(key)
+    if st is None:
+        st = _STAGING[key] = [[torch.empty(a.shape, dtype=torch.float32).pin_memory() for _ in range(2)], [None, None], 0]
+    bufs, evs, turn = st
+    st[2] = 1 - turn
+    if evs[turn] is not None:
+        evs[turn].synchronize()
+    bufs[turn].copy_(torch.from_numpy(a))
+    t = bufs[turn].to(dev, non_blocking=True)
+    evs[turn] = torch.cuda.Event()
+    evs[turn].record(torch.cuda.current_stream(dev))
+    return t
+
+
 def start_broadcast_block(arrays, shapes, src=0):
     """Start the broadcasts of one block whose shapes every rank knows; returns ({variable: tensor}, [work handles])."""
     import torch
@@ -219,8 +241,8 @@ def start_broadcast_block(arrays, shapes, src=0):
     tens, works = {}, []
     for k, shp in shapes.items():
         if rank == src:
-            a = torch.from_numpy(np.ascontiguousarray(arrays[k], dtype=np.float32))
-            t = a.pin_memory().to(dev, non_blocking=True) if dev.type == 'cuda' else a
+            a = np.ascontiguousarray(arrays[k], dtype=np.float32)
+            t = _staged_to_device((k, tuple(a.shape)), a, dev) if dev.type == 'cuda' else torch.from_numpy(a)
         else:
             t = torch.empty(tuple(shp), dtype=torch.float32, device=dev)
         if world > 1:

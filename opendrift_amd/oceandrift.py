@@ -233,6 +233,8 @@ class OpenDriftSimulation(Configurable):
             except ReaderLevelsError:
                 raise
             except Exception as e:   # the reference catches every exception of a reader call
+                if getattr(e, 'code', 0) == -3:     # ODR_ERR_CAPACITY: the device library is out of sources / slots -- not a reader failure
+                    raise
                 rebind |= self._reader_failed(name, b, e)
         if rebind:
             self._bind_variables()
@@ -989,7 +991,11 @@ class OpenDriftSimulation(Configurable):
             if self._all_at_start:
                 k = np.zeros(n_total, np.int64)
             else:
-                k = np.floor((te - t_start) / dts + 1e-9).astype(np.int64) if dts > 0 else np.floor((t_start - te) / -dts + 1e-9).astype(np.int64)
+                # the step an element is released in, by the comparisons release_elements() makes on the same epoch values:
+                # forward t0 <= t < t1, backward t0 >= t > t1, with t0 / t1 the epochs of start + i time_step
+                edges = np.array([_epoch(self.start_time + i * time_step) for i in range(steps + 1)])
+                sgn = 1.0 if dts > 0 else -1.0
+                k = np.searchsorted(sgn * edges, sgn * te, side='right').astype(np.int64) - 1
             ok = (k >= 0) & (k < steps)
             self._g_release = np.bincount(k[ok], minlength=steps)
             self._g_release_cum = np.concatenate([[0], np.cumsum(self._g_release)])
@@ -1118,6 +1124,15 @@ class OpenDriftSimulation(Configurable):
                     else:
                         self._resolve_status()
                         self.P.compact()
+                        if ens_sharded:
+                            # (drift:max_age_seconds: the retirements come after the point the step's one collective is made
+                            # at) the stage calls of update() number the elements present NOW on all ranks: the elements the
+                            # lower ranks kept, from a collective of its own
+                            from . import distributed as D
+                            rows = D.allgather_vector([float(len(self.P))])
+                            self._timing_collectives += 1
+                            self._below_active = int(round(rows[:self._rank, 0].sum()))
+                            self.P.set_rank_offset(self._below_active)
                     self.P.store_previous()
                 if self._world > 1 and ((fused_lane and not ens_sharded) or one_collective):
                     g_active = self._g_active           # from this step's collective

@@ -470,11 +470,7 @@ class DeviceReaderBinding:
             return
         lo0, la0, lo1, la1 = [float(v) for v in lonlat_box]
         self.extent_lonlat = (lo0, la0, lo1, la1)
-        t = np.linspace(0, 1, 33)
-        lon = np.concatenate([lo0 + (lo1 - lo0) * t, lo0 + (lo1 - lo0) * t, np.full(33, lo0), np.full(33, lo1)])
-        lat = np.concatenate([np.full(33, la0), np.full(33, la1), la0 + (la1 - la0) * t, la0 + (la1 - la0) * t])
-        x, y = r.lonlat2xy(lon, lat)
-        x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        x, y = self._box_outline_xy(lo0, la0, lo1, la1)
         if not (np.isfinite(x).all() and np.isfinite(y).all()):
             return
         xs, ys = np.asarray(r.x, dtype=np.float64), np.asarray(r.y, dtype=np.float64)
@@ -483,6 +479,15 @@ class DeviceReaderBinding:
         if fx <= 0 or fy <= 0 or fx * fy > 0.6:
             return        # no overlap (nothing to cut) or most of the domain anyway
         self.extent = (np.array([x.min(), x.max()]), np.array([y.min(), y.max()]))
+
+    def _box_outline_xy(self, lo0, la0, lo1, la1):
+        """The outline of a lon / lat box in the reader's coordinates, 33 points per edge: on a polar-stereographic or
+        Lambert grid the edges of such a box bulge in x / y, its corners alone underestimate the footprint."""
+        t = np.linspace(0, 1, 33)
+        lon = np.concatenate([lo0 + (lo1 - lo0) * t, lo0 + (lo1 - lo0) * t, np.full(33, lo0), np.full(33, lo1)])
+        lat = np.concatenate([np.full(33, la0), np.full(33, la1), la0 + (la1 - la0) * t, la0 + (la1 - la0) * t])
+        x, y = self.reader.lonlat2xy(lon, lat)
+        return np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
 
     def outside_window(self, lon_min, lon_max, lat_min, lat_max, guard_lon, guard_lat):
         """Do the elements (their lon / lat box) come within `guard` of the window the blocks were cut to?  (The reference's
@@ -495,9 +500,7 @@ class DeviceReaderBinding:
         r = self.reader
         # the window may be bounded by the reader's own domain: nothing to gain beyond it
         xs, ys = np.asarray(r.x, dtype=np.float64), np.asarray(r.y, dtype=np.float64)
-        x, y = r.lonlat2xy(np.array([lon_min - guard_lon, lon_max + guard_lon, lon_min - guard_lon, lon_max + guard_lon]),
-                           np.array([lat_min - guard_lat, lat_min - guard_lat, lat_max + guard_lat, lat_max + guard_lat]))
-        x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        x, y = self._box_outline_xy(lon_min - guard_lon, lat_min - guard_lat, lon_max + guard_lon, lat_max + guard_lat)
         ex, ey = self.extent
         return bool((x.min() < max(ex[0], xs.min())) or (x.max() > min(ex[1], xs.max())) or
                     (y.min() < max(ey[0], ys.min())) or (y.max() > min(ey[1], ys.max())))
@@ -508,10 +511,23 @@ class DeviceReaderBinding:
         for pool in (self.slots, self.staged):
             for k in list(pool):
                 self.ctx.drop_block(self.sid, pool.pop(k))
-        self._dist_pre = {}
+        self._drain_prefetched()
         self._dist_shapes = None
+        if self.sid is not None:
+            self.ctx.release_source(self.sid)      # its id serves the re-cut source: the context holds 16 sources, not 16 per run
         self.sid = None
         self.set_extent(lonlat_box)
+
+    def _drain_prefetched(self, keep=()):
+        """Sharded run: levels whose broadcast was started ahead and that are not (no longer) wanted are waited for and let
+        go -- their tensors and work handles must not stay pinned, and an entry left behind would block every later prefetch."""
+        from . import distributed as D
+        for k in [k for k in self._dist_pre if k not in keep]:
+            tens, works = self._dist_pre.pop(k)
+            try:
+                D.finish_broadcast(works)
+            except Exception:
+                pass
 
     def ensure_levels(self, t0, t1, extent=None, broadcast=None, times=None):
         """Make the time levels the step from t0 to t1 samples resident (datetime arguments).  `times`: the instants the
@@ -538,6 +554,9 @@ class DeviceReaderBinding:
             if len(need) > self.NSLOTS:     # cannot happen with NSLOTS = 6 (three instants, two levels each)
                 raise ReaderLevelsError('reader %s: one model time step needs %d time levels resident, at most %d fit'
                                         % (r.name, len(need), self.NSLOTS))
+        # sharded prefetch: an entry the run has passed (the model step skipped that level, or the direction changed) is let go
+        if self._dist_pre:
+            self._drain_prefetched(keep=[k for k in self._dist_pre if (k >= min(need) if t1 >= t0 else k <= max(need))])
         # make room: first the resident levels the step does not need, then prefetched levels it does not need
         missing = [k for k in need if k not in self.slots and k not in self.staged]
         for pool in (self.slots, self.staged):

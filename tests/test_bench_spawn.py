@@ -30,6 +30,24 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line():
     assert d['config']['particles_total'] == 2002 and d['scaling'] == 'weak'
 
 
+def test_the_n_rank_loop_makes_one_collective_per_step_and_moves_the_reader_levels():
+    """`--gpus N` times the SHARDED step (ShardedLoop in bench.py): exactly ONE collective per step (the all-gather of the
+    step summaries, as OceanDrift.run() makes it), and a reader level from rank 0 every block_every steps, broadcast one
+    period ahead; the level every rank holds at the end is rank 0's array of that level (gloo, two ranks)."""
+    p, lines = _run(['--gpus', '2', '--small', '--plumbing-only', '--steps', '13', '--warmup', '1', '--particles', '500',
+                     '--block-every', '4'])
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(lines[-1])
+    sl = d['sharded_loop']
+    assert sl['collectives'] == 13 and sl['collectives_per_step'] == 1.0
+    assert sl['block_every'] == 4 and sl['reader_levels'] == 4          # steps 0, 4, 8, 12
+    assert d['shards_ok'] is True                                       # kept counts summed over the ranks, the last level intact
+    # default period of the N-rank loop: hourly fields at 10-minute steps
+    p, lines = _run(['--gpus', '2', '--small', '--plumbing-only', '--steps', '7', '--warmup', '1', '--particles', '500'])
+    d = json.loads(lines[-1])
+    assert d['sharded_loop']['block_every'] == 6 and d['sharded_loop']['reader_levels'] == 2 and d['sharded_loop']['collectives'] == 7
+
+
 def test_single_process_default_is_one_rank():
     p, lines = _run(['--small', '--plumbing-only', '--steps', '2', '--workload', 'c4'])
     assert p.returncode == 0, p.stderr[-2000:]

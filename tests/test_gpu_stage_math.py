@@ -138,6 +138,89 @@ def test_c3_model_api_fast_reproduces_the_reference_run():
     assert o.status_categories == ['active', 'seeded_on_land'] and o.num_elements_deactivated() == 4
 
 
+def test_c14_openoil_defaults_fast(fast_ctx):
+    """OpenOil's default current uncertainty (0.05 m/s) inside the main-loop sample and every RK4 stage call + wind, Stokes
+    drift and the oil physics of the mixing loop: the reference's own OpenOil run (golden c14) under the FAST arithmetic, at
+    the tolerances the exact arithmetic holds against it (tests/test_gpu_noise.py)."""
+    import replay
+    g = golden('c14_openoil_defaults.npz')
+    start, tol_pos, tol_z = 1, 1e-7, 1e-6       # from the reference's second state (DESIGN.md 2.1: first-step float32 positions)
+    B = replay.DeviceBackend(replay.scenario_c9(g), fast_ctx, g['lon'][start], g['lat'][start], g['z'][start], wdf=g['wdf'])
+    B.set_oil(g['diameter'][start].astype(np.float32), float(g['oil_density']), float(g['oil_viscosity']), g['film'])
+    dev = replay.replay_c14(B, g, 6, start=start)
+    worst = 0.0
+    for k, (lon, lat, z, status, oil) in enumerate(dev, start):
+        worst = max(worst, np.abs(lon - g['lon'][k + 1]).max(), np.abs(lat - g['lat'][k + 1]).max())
+        assert np.abs(lon - g['lon'][k + 1]).max() < tol_pos and np.abs(lat - g['lat'][k + 1]).max() < tol_pos
+        assert np.abs(z - g['z'][k + 1]).max() < tol_z, (k, np.abs(z - g['z'][k + 1]).max())
+    print('c14 FAST device vs reference: %.2e deg' % worst)
+
+
+@pytest.mark.parametrize('tag,scheme', [('a_rk2', 'runge-kutta'), ('a_rk4', 'runge-kutta4'), ('b_rk4', 'runge-kutta4')])
+def test_c19_host_reader_stage_split_lane_fast(tag, scheme):
+    """The stage-split lane (a user's ContinuousReader evaluated on the host in every Runge-Kutta stage, golden c19) with
+    stage_math='fast': the stage positions take the direct move along (u, v) dt / 2, the gridded sources behind the host
+    reader their FAST stage samples -- the reference's own run at the exact mode's 1e-7 deg."""
+    from test_gpu_model_api import _AnalyticCurrent
+    from opendrift_amd import readers
+    from opendrift_amd.oceandrift import OceanDrift
+    g = golden('c19_host_reader_rk.npz')
+    o = OceanDrift(loglevel=50, seed=0, rng='numpy', stage_math='fast')
+    o.add_reader(_AnalyticCurrent(float(g['period']), box=tuple(g['box']) if tag[0] == 'b' else None))
+    if tag[0] == 'b':
+        times = [T0 + timedelta(seconds=float(t)) for t in g['g_t']]
+        o.add_reader(readers.GridReader(g['g_x'], g['g_y'], times, {'x_sea_water_velocity': g['g_u'], 'y_sea_water_velocity': g['g_v']}))
+    o.set_config('environment:constant:land_binary_mask', 0)
+    o.set_config('drift:advection_scheme', scheme)
+    lon, lat = g[tag + '_lon'], g[tag + '_lat']
+    o.seed_elements(lon=lon[0], lat=lat[0], time=T0, wind_drift_factor=0.0)
+    o.run(time_step=float(g['dt']), steps=lon.shape[0] - 1)
+    assert o.ctx.stage_math == 'fast'
+    e = o.elements
+    dmax = max(np.abs(e.lon - lon[-1][e.ID]).max(), np.abs(e.lat - lat[-1][e.ID]).max())
+    print(tag, 'FAST device + host reader vs reference: %.2e deg' % dmax)
+    assert dmax < 1e-7
+
+
+def test_c3_full_size_subsample_against_the_cpu_oracle_fast():
+    """10 M elements, one fused RK4 launch on the full-size block under the FAST arithmetic (the mode bench.py's headline
+    runs): every 5000th element against the C oracle (exact arithmetic) at FAST's per-step bound of 3e-9 deg."""
+    import bench
+    from oracle import oracle as orc
+    from opendrift_amd.device import Context
+    from test_gpu_full_size import _state_by_id
+    U, V = 'x_sea_water_velocity', 'y_sea_water_velocity'
+    name, n = 'c3', 10_000_000
+    ctx = Context(0, seed=0)
+    ctx.set_stage_math('fast')
+    fields = bench.make_fields(name)
+    wl = bench.Workload(name, ctx, fields, (0, 0, 1), via_torch=False)
+    lon, lat, z = bench.seed_particles(name, fields, n, np.random.default_rng(2))
+    P = ctx.particles(n)
+    P.append(lon, lat, z=z)
+    P.sort_by_cell(wl.sid)
+    t = 1234.0
+    P.env_coast_advect(wl.vars, t, 'runge-kutta4', wl.dt, coastline='none', store_previous=True, count=False)
+    sub = np.arange(0, n, 5000)
+    got, ok = _state_by_id(P, sub.astype(np.int32))
+    assert ok.all()
+    g = fields['g']
+    wb = orc.WorldBuilder()
+    levels = [(float(g['t'][k]), {orc.VAR[v]: g[v][k] for v in fields['names']}) for k in range(3)]
+    wb.add_grid(orc.make_proj(), g['x'], g['y'], levels, z=fields['z'])
+    for v in fields['names']:
+        wb.set_fallback(orc.VAR[v], {'land_binary_mask': np.nan, 'sea_floor_depth_below_sea_level': 10000.0}.get(v, 0.0))
+    w = wb.finish()
+    lo, la, zz = lon[sub].copy(), lat[sub].copy(), z[sub].copy()
+    u, v = orc.get_environment(w, [orc.VAR[U], orc.VAR[V]], lo, la, zz, t)
+    m = len(sub)
+    orc.advect_ocean_current(w, 2, lo, la, zz, np.ones(m, np.int32), np.ones(m, np.float32), u, v, t, wl.dt)
+    d = max(np.abs(got['lon'] - lo).max(), np.abs(got['lat'] - la).max())
+    print('10 M FAST launch vs oracle: %.2e deg' % d)
+    assert d < 3e-9
+    P.close(); ctx.close()
+
+
 def test_defaults_parity_runs_exact_device_rng_runs_fast():
     from opendrift_amd.oceandrift import OceanDrift
     assert OceanDrift(loglevel=50, rng='numpy').stage_math == 'exact'
