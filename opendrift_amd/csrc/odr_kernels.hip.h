@@ -292,15 +292,17 @@ __device__ __forceinline__ void add_current_noise(const StageNoise &N, int call,
 
 // ---- vertical mixing on a K column in LDS: device functions shared by k_vmix_col (odr_mix.hip) and the fused
 // step + mixing kernel k_step_grid<..., MIXQ> (odr_step_mix.hip)
-// Uniform number of mixing sub-step `it` (ODR_RNG_DEVICE): one Philox4x32-10 block serves FOUR sub-steps -- each 32-bit
-// word is one uniform (x + 1/2) 2^-32 in (0, 1), symmetric about 1/2; the random-walk displacement R = 2u - 1 is
-// resolved to 5e-10 of its range.  (Two 53-bit uniforms per block cost one block per two sub-steps: 45 instead of 25
-// instructions per sub-step.)
+// Uniform number of mixing sub-step `it` (ODR_RNG_DEVICE): one Philox4x32-10 block serves FIVE sub-steps -- 24 bits each:
+// the upper 24 bits of the four words, then the four low bytes' worth taken from words 0..2 -- as (x + 1/2) 2^-24 in (0, 1),
+// symmetric about 1/2: the random-walk displacement R = 2u - 1 is resolved to 1.2e-7 of its range (0.2 micrometres for a
+// 1.9 m sub-step; the diffusivity itself is a float32).  Ten sub-steps (600 s / 60 s) cost two blocks; with one word per
+// sub-step (rounds 1-3) they cost three, and a block is ~130 instructions, 20 of them 64-bit integer multiply-adds.
 __device__ __forceinline__ double mix_uniform(rocrand_state_philox4x32_10 &st, uint4 &q, int it) {
-  if ((it & 3) == 0) q = rocrand4(&st);
-  const unsigned k = (unsigned)it & 3u;
-  const unsigned x = k == 0 ? q.x : (k == 1 ? q.y : (k == 2 ? q.z : q.w));
-  return ((double)x + 0.5) * 2.3283064365386963e-10;
+  const unsigned k = (unsigned)it % 5u;
+  if (k == 0) q = rocrand4(&st);
+  const unsigned lo = ((q.x & 255u) << 16) | ((q.y & 255u) << 8) | (q.z & 255u);
+  const unsigned x = k == 0 ? q.x >> 8 : (k == 1 ? q.y >> 8 : (k == 2 ? q.z >> 8 : (k == 3 ? q.w >> 8 : lo)));
+  return ((double)x + 0.5) * 5.9604644775390625e-08;
 }
 // Fast version for the common case -- the diffusivity comes from one gridded reader with a
 // plain (not interleaved) z-innermost K array.  The host resolves source, time bracket and
