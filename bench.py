@@ -355,7 +355,16 @@ def model_api_leg(fields, n, steps, device):
     rng = np.random.default_rng(1000)
     lon, lat, z = seed_particles('c3', fields, n, rng)
     o.seed_elements(lon=lon, lat=lat, z=z, time=t0, wind_drift_factor=0.0)
-    o.run(time_step=600, steps=steps, time_step_output=600 * steps, export_variables=['z'])
+    if os.environ.get('ODR_BENCH_PROFILE_MODEL'):     # developer switch: where the host time of the leg goes (stderr)
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        o.run(time_step=600, steps=steps, time_step_output=600 * steps, export_variables=['z'])
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats('cumulative').print_stats(30)
+    else:
+        o.run(time_step=600, steps=steps, time_step_output=600 * steps, export_variables=['z'])
     tm = o.timing
     return dict(ms_per_step=tm['steady_ms_per_step'], value=n * 1e3 / tm['steady_ms_per_step'], unit='particle-steps/s',
                 steps=tm['steps'], what='OceanDrift.run(): the full loop body per step (release, all 14 required variables '
