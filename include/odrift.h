@@ -188,6 +188,13 @@ int odr_block_set_content_ids(odr_ctx *ctx, int32_t source_id, int32_t slot, int
 int odr_host_register(odr_ctx *ctx, void *ptr, uint64_t bytes);   /* hipHostRegister: reader arrays that are uploaded repeatedly */
 int odr_host_unregister(odr_ctx *ctx, void *ptr);
 int odr_block_drop(odr_ctx *ctx, int32_t source_id, int32_t slot);
+/* drift:truncate_ocean_model_below_m (models/basemodel/environment.py:554-566): every get_environment call samples the readers
+ * at max(z, -truncate_depth) while the elements keep their depth.  odr_particles_truncate_z puts the clipped depths in place for
+ * the sampling calls that follow (odr_env_sample, odr_advect / odr_env_coast_advect: the Runge-Kutta stage calls are
+ * get_environment calls), odr_particles_restore_z brings the elements' own z back (before anything that changes z or the
+ * element set). */
+int odr_particles_truncate_z(odr_ctx *ctx, odr_particles *p, double truncate_depth);
+int odr_particles_restore_z(odr_ctx *ctx, odr_particles *p);
 /* A source that is no longer used (e.g. a gridded reader whose blocks are re-cut to another window and re-registered):
  * drops its resident blocks, removes it from every priority list (odr_env_bind) and frees its id for the next
  * odr_source_* call -- the context holds at most 16 sources at a time, not 16 per run. */

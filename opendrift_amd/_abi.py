@@ -134,6 +134,8 @@ _SIGNATURES = {
     'odr_increase_age': [_vp, _vp, C.c_double, C.c_double, C.c_int],
     'odr_source_time_coverage': [_vp, C.c_int32, C.c_double, C.c_double, C.c_int],
     'odr_source_release': [_vp, C.c_int32],
+    'odr_particles_truncate_z': [_vp, _vp, C.c_double],
+    'odr_particles_restore_z': [_vp, _vp],
     'odr_seafloor': [_vp, _vp, _i64p],
     'odr_seafloor_action': [_vp, _vp, C.c_int, C.c_int32, _i64p],
     'odr_set_seafloor_action': [_vp, C.c_int, C.c_int32],

@@ -138,6 +138,9 @@ struct odr_particles {
   unsigned long long *wg_total, *wg_stats;   // device: wg_total[0] table length, [1] length of wg_list; wg_stats = wg_total + 2: [0] sum of the list lengths, [1] rectangles cut
   long long wg_cap, wg_grid, wg_n, wg_list_cap;
   unsigned long long wg_launches;            // host: launches that took the LDS-tile path
+  double *z_keep;       // odr_particles_truncate_z: the elements' own z while the sampling calls see the clipped one
+  long long z_keep_n;
+  bool z_truncated;
   int wg_sid;
   bool wg_valid;
 };

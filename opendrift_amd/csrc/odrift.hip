@@ -146,7 +146,7 @@ int odr_particles_destroy(odr_ctx *c, odr_particles *p) {
   fr(p->bcount);
   fr(p->scratch);
   fr(p->rank); fr(p->rank_words); fr(p->rank_before); fr(p->rank_bsum);
-  fr(p->wg_tab); fr(p->wg_total); fr(p->wg_list);
+  fr(p->wg_tab); fr(p->wg_total); fr(p->wg_list); fr(p->z_keep);
   delete p;
   return 0;
 }
@@ -1606,6 +1606,41 @@ int odr_hdiffusion(odr_ctx *c, odr_particles *p, double dt, int rng_mode, const 
   hipLaunchKernelGGL(k_hdiff, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, rng_mode, da, db, c->seed,
                      (unsigned long long)step, c->red);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// drift:truncate_ocean_model_below_m (models/basemodel/environment.py:554-566): get_environment samples every reader at
+// max(z, -depth) -- the elements keep their z.  odr_particles_truncate_z puts the clipped depths in place of z for the calls
+// that SAMPLE (odr_env_sample, odr_advect: its Runge-Kutta stage calls are get_environment calls too); odr_particles_restore_z
+// brings the elements' own z back before anything that moves them vertically.
+__global__ __launch_bounds__(BLOCK) static void k_truncate_z(double *z, double *keep, long long n, double zmin) {
+  const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const double v = z[i];
+  keep[i] = v;
+  z[i] = v < zmin ? zmin : v;     // z[z < -truncate_depth] = -truncate_depth
+}
+__global__ __launch_bounds__(BLOCK) static void k_restore_z(double *z, const double *keep, long long n) {
+  const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n) z[i] = keep[i];
+}
+int odr_particles_truncate_z(odr_ctx *c, odr_particles *p, double truncate_depth) {
+  REQUIRE(truncate_depth >= 0, "truncate depth must not be negative");
+  REQUIRE(!p->z_truncated, "z is already truncated: odr_particles_restore_z first");
+  if (!p->z_keep) HIPCHK(hipMalloc((void **)&p->z_keep, sizeof(double) * (size_t)p->cap));
+  if (p->n > 0) hipLaunchKernelGGL(k_truncate_z, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->d64[2], p->z_keep, p->n, -truncate_depth);
+  HIPCHK(hipGetLastError());
+  p->z_truncated = true; p->z_keep_n = p->n;
+  p->epoch++;
+  return 0;
+}
+int odr_particles_restore_z(odr_ctx *c, odr_particles *p) {
+  if (!p->z_truncated) return 0;
+  REQUIRE(p->n == p->z_keep_n, "the element set changed while z was truncated");
+  if (p->n > 0) hipLaunchKernelGGL(k_restore_z, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->d64[2], (const double *)p->z_keep, p->n);
+  HIPCHK(hipGetLastError());
+  p->z_truncated = false;
+  p->epoch++;
   return 0;
 }
 

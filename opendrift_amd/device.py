@@ -811,6 +811,13 @@ class Particles:
         check(self.lib.odr_sort_particles_ex(self.ctx.h, self.h, int(source_id), int(bool(keep_environment))))
         self._permuted = True
 
+    def truncate_z(self, depth):
+        """The sampling calls that follow see max(z, -depth) (drift:truncate_ocean_model_below_m); restore_z() ends it."""
+        check(self.lib.odr_particles_truncate_z(self.ctx.h, self.h, float(depth)))
+
+    def restore_z(self):
+        check(self.lib.odr_particles_restore_z(self.ctx.h, self.h))
+
     def tile_stats(self):
         """Diagnostics of the LDS-tile step (odr_particles_tile_stats): launches on that path, elements they handed to the
         HBM path, rectangles cut to the LDS capacity, workgroup ranges of the current table."""

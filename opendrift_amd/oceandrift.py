@@ -40,6 +40,10 @@ class OpenDriftSimulation(Configurable):
     required_variables = {}
     element_properties = {}   # name -> default (in addition to the LagrangianArray core variables)
 
+    # default of seed:ocean_only (the reference's: True, basemodel/__init__.py:424).  The golden vectors of tests/ were
+    # written by the reference's loop body without the run() preamble (oracle/refdriver.py): tests/conftest.py sets False.
+    SEED_OCEAN_ONLY_DEFAULT = True
+
     def __init__(self, seed=0, loglevel=None, device=0, rng='device', iomodule=None, logfile=None, stage_math=None):
         super().__init__()
         if loglevel is not None:
@@ -96,6 +100,8 @@ class OpenDriftSimulation(Configurable):
                                                  'level': CONFIG_LEVEL_BASIC, 'description': ''},
             'seed:number': {'type': 'int', 'default': 1, 'min': 1, 'max': 100000000000,
                             'level': CONFIG_LEVEL_ESSENTIAL, 'description': ''},
+            'seed:ocean_only': {'type': 'bool', 'default': self.SEED_OCEAN_ONLY_DEFAULT, 'level': CONFIG_LEVEL_ESSENTIAL,
+                                'description': 'If True, elements seeded on land will be moved to the closest position in ocean'},
             'drift:max_age_seconds': {'type': 'float', 'default': None, 'min': 0, 'max': 1e12,
                                       'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
             'drift:deactivate_north_of': {'type': 'float', 'default': None, 'min': -90, 'max': 90,
@@ -461,6 +467,63 @@ class OpenDriftSimulation(Configurable):
             Q.close()
         s['z'][idx] = np.float32(-depth.astype(np.float32) + off[idx]).astype(np.float64)
 
+    def _sample_land(self, lon, lat):
+        """land_binary_mask at (lon, lat, z = 0) at the start of the run, by the device's own sampling path"""
+        out = np.empty(len(lon), np.float32)
+        chunk = 4_000_000
+        for a in range(0, len(lon), chunk):
+            b = min(len(lon), a + chunk)
+            Q = self.ctx.particles(b - a)
+            try:
+                Q.append(lon[a:b], lat[a:b], z=np.zeros(b - a))
+                out[a:b] = Q.env_sample(['land_binary_mask'], _epoch(self.start_time), download=True)['land_binary_mask']
+            finally:
+                Q.close()
+        return out
+
+    def closest_ocean_points(self, lon, lat):
+        """seed:ocean_only (basemodel/__init__.py:936-1031): elements seeded on land go to the nearest ocean point of a
+        0.01 deg raster around the seeds (at most 1000 x 1000 points), looked up with the reader that provides
+        land_binary_mask -- here sampled through the device (the same nearest-node lookup the run uses) at the run's start
+        time; nearest neighbour by scipy's cKDTree in (lon, lat) as in the reference.  Returns (lon, lat, land_indices)."""
+        import scipy.spatial
+        lon, lat = np.array(lon, dtype=np.float64), np.array(lat, dtype=np.float64)
+        live = [n for n in self.priority_list.get('land_binary_mask', []) if n in self.readers and self.readers[n].sid is not None]
+        if not live or len(lon) == 0:
+            return lon, lat, None      # no land reader on the device (the reference would fetch the GSHHG landmask: not shipped)
+        deltalon = deltalat = 0.01
+        numbuffer = 10
+        # (the reference's scheduled lon / lat are float32 arrays: the raster's corners are float32 sums, NEP 50)
+        lonmin, lonmax = np.float32(lon.min()) - deltalon * numbuffer, np.float32(lon.max()) + deltalon * numbuffer
+        latmin, latmax = np.float32(lat.min()) - deltalat * numbuffer, np.float32(lat.max()) + deltalat * numbuffer
+        land = self._sample_land(lon, lat)
+        if not (np.nanmax(land) > 0):
+            return lon, lat, None      # 'All points are in ocean'
+        land_indices = np.where(land != 0)[0]
+        longrid, latgrid = np.arange(lonmin, lonmax, deltalon), np.arange(latmin, latmax, deltalat)
+        if len(longrid) > 1000 or len(latgrid) > 1000:
+            logger.warning('Particles cover large area - using coarser resolution for closest ocean point')
+            longrid, latgrid = np.linspace(lonmin, lonmax, 1000), np.linspace(latmin, latmax, 1000)
+        longrid, latgrid = np.meshgrid(longrid, latgrid)
+        longrid, latgrid = longrid.ravel(), latgrid.ravel()
+        landgrid = self._sample_land(longrid, latgrid)
+        covered = np.isfinite(landgrid)            # "Remove grid-points not covered by this reader"
+        longrid, latgrid, landgrid = longrid[covered], latgrid[covered], landgrid[covered]
+        if landgrid.size == 0:
+            logger.warning('Land grid has zero size, cannot move elements.')
+            return lon, lat, land_indices
+        if landgrid.min() == 1:
+            logger.warning('No ocean pixels nearby, cannot move elements.')
+            return lon, lat, land_indices
+        oceangridlons, oceangridlats = longrid[landgrid == 0], latgrid[landgrid == 0]
+        tree = scipy.spatial.cKDTree(np.dstack([oceangridlons, oceangridlats])[0])
+        _dist, indices = tree.query(np.dstack([lon[land_indices], lat[land_indices]]))
+        indices = indices.ravel()
+        lon[land_indices] = np.float32(oceangridlons[indices])      # (stored into the float32 schedule)
+        lat[land_indices] = np.float32(oceangridlats[indices])
+        logger.info('Moved %i out of %i points from land to water' % (len(land_indices), len(lon)))
+        return lon, lat, land_indices
+
     # ------------------------------------------------------------------ loop pieces
     def release_elements(self):   # :909-934
         s, rel = self._sched, self._released_mask()
@@ -682,10 +745,28 @@ class OpenDriftSimulation(Configurable):
         """Environment.get_environment for all required variables (:2238-2246) + uncertainty (:869-891)."""
         t = _epoch(self.time)
         names = list(self.required_variables)
-        self.P.env_sample(names, t)
-        self._sampled = names
-        self._sample_host_readers(names)
+        with self._readers_see_truncated_z():
+            self.P.env_sample(names, t)
+            self._sampled = names
+            self._sample_host_readers(names)
         self._add_uncertainty(names, current=True)
+
+    def _readers_see_truncated_z(self):
+        """drift:truncate_ocean_model_below_m (environment.py:554-566): inside the block the sampling calls see
+        max(z, -depth), the elements keep their own z."""
+        from contextlib import contextmanager, nullcontext
+        d = self._config.get('drift:truncate_ocean_model_below_m', {}).get('value')
+        if d is None or len(self.P) == 0:
+            return nullcontext()
+
+        @contextmanager
+        def clipped():
+            self.P.truncate_z(d)
+            try:
+                yield
+            finally:
+                self.P.restore_z()
+        return clipped()
 
     def _host_bindings(self):
         return [(n, b) for n, b in self.readers.items() if getattr(b, 'host_eval', False)]
@@ -792,6 +873,10 @@ class OpenDriftSimulation(Configurable):
         if self._advected:       # already done by the fused launch of this step (run(), fused lane)
             self._advected = False
             return
+        with self._readers_see_truncated_z():      # the Runge-Kutta stage calls are get_environment calls
+            self._advect_ocean_current(factor)
+
+    def _advect_ocean_current(self, factor=1):
         scheme = self.get_config('drift:advection_scheme')
         std, ustd = self._current_uncertainty()
         nstage = {'runge-kutta': 1, 'runge-kutta4': 3}.get(scheme, 0)
@@ -975,6 +1060,9 @@ class OpenDriftSimulation(Configurable):
         self._block_extent = np.array([max(-360, ext[0] - mlon), max(-89, ext[1] - mlat), min(360, ext[2] + mlon), min(89, ext[3] + mlat)])
         self._all_at_start = bool((self._sched['t_epoch'] == _epoch(self.start_time)).all())
         self._finalize_environment(self.start_time, self.start_time + time_step)
+        # Move point seeded on land to ocean (:2150-2158)
+        if self.get_config('seed:ocean_only') is True and 'land_binary_mask' in self.required_variables:
+            self._sched['lon'], self._sched['lat'], _ = self.closest_ocean_points(self._sched['lon'], self._sched['lat'])
         n_total = self.num_elements_total()
         lo_id, hi_id = 0, n_total
         self._n_global = n_total
@@ -1030,6 +1118,8 @@ class OpenDriftSimulation(Configurable):
                           'deactivate_outside', 'deactivate_elements')) and
                       (self.rng == 'device' or not (any(self._current_uncertainty()) or self.get_config('drift:wind_uncertainty'))) and
                       self.get_config('drift:max_age_seconds') is None and
+                      not self._config.get('drift:water_column_stretching', {}).get('value') and
+                      self._config.get('drift:truncate_ocean_model_below_m', {}).get('value') is None and
                       self.get_config('general:seafloor_action', 'lift_to_seafloor') in ('lift_to_seafloor', 'none') and
                       not self.get_config('general:coastline_approximation_precision') and
                       'x_sea_water_velocity' in self.required_variables and 'y_sea_water_velocity' in self.required_variables and
@@ -1134,6 +1224,7 @@ class OpenDriftSimulation(Configurable):
                             self._below_active = int(round(rows[:self._rank, 0].sum()))
                             self.P.set_rank_offset(self._below_active)
                     self.P.store_previous()
+                    self._store_environment_previous()
                 if self._world > 1 and ((fused_lane and not ens_sharded) or one_collective):
                     g_active = self._g_active           # from this step's collective
                 elif self._world > 1:
@@ -1344,6 +1435,10 @@ class OceanDrift(OpenDriftSimulation):
         super().__init__(*args, **kwargs)
         self._add_config({   # oceandrift.py:118-183
             'drift:vertical_advection': {'type': 'bool', 'default': True, 'level': CONFIG_LEVEL_BASIC, 'description': ''},
+            'drift:water_column_stretching': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_ADVANCED, 'description':
+                                              'Elements follow the vertical motion of the water column as the sea surface height changes'},
+            'drift:truncate_ocean_model_below_m': {'type': 'float', 'default': None, 'min': 0, 'max': 10000, 'level': CONFIG_LEVEL_ADVANCED,
+                                                   'description': 'Ocean model data are sampled at this depth for elements below it'},
             'drift:vertical_advection_at_surface': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_ADVANCED,
                                                     'description': ''},
             'drift:vertical_mixing': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_BASIC, 'description': ''},
@@ -1383,6 +1478,11 @@ class OceanDrift(OpenDriftSimulation):
             # reference switches to Large et al. (1994) (oceandrift.py:431-447).  (A reader that is listed but covers
             # no element at all would do the same there; here its fallback-filled profile is used.)
             model = 'windspeed_Large1994'
+        if model == 'environment' and self._config.get('drift:truncate_ocean_model_below_m', {}).get('value') is not None:
+            # the reference cuts the diffusivity PROFILES at the truncation depth too (environment.py:560: profiles_depth); the
+            # device's K columns are not cut -- refused rather than silently different for elements below that depth
+            raise NotImplementedError('drift:truncate_ocean_model_below_m together with vertical mixing on reader diffusivity '
+                                      'profiles is not implemented (DESIGN.md section 7)')
         dt, dt_mix = self.time_step.total_seconds(), self.get_config('vertical_mixing:timestep')
         fuse = None
         if self.get_config('drift:vertical_advection') and type(self).vertical_advection is OceanDrift.vertical_advection:
@@ -1416,7 +1516,36 @@ class OceanDrift(OpenDriftSimulation):
     def update_terminal_velocity(self, Tprofiles=None, Sprofiles=None, z_index=None):
         pass
 
+    def water_column_stretching(self):   # oceandrift.py:299-313
+        """z + (sea_surface_height - its value of the previous step) * z / sea_floor_depth: the elements follow the water column.
+        Rare option, evaluated on the host with NumPy's own dtypes (float32 environment, float64 z) like the reference."""
+        if self.get_config('drift:water_column_stretching') is False or len(self.P) == 0:
+            return
+        prev = getattr(self, '_ssh_previous', None)
+        if prev is None or 'sea_surface_height' not in self._sampled:
+            logger.warning('water_column_stretching requires storing previous value of sea_surface_height')
+            return
+        ssh = self.P.env_download('sea_surface_height')
+        depth = self.P.env_download('sea_floor_depth_below_sea_level')
+        z = self.P.download()['z']
+        delta_zeta = ssh - prev                                   # float32
+        self.P.upload(z=z + delta_zeta * (z / depth))             # float64
+
+    def _store_environment_previous(self):
+        """update_previous_state() for the environment (basemodel/__init__.py:642-656): what update() sees as
+        environment_previous.sea_surface_height -- the value of the previous step, the present one for new elements."""
+        if self._config.get('drift:water_column_stretching', {}).get('value') is not True or 'sea_surface_height' not in self._sampled:
+            return
+        if getattr(self, '_ssh_by_id', None) is None:
+            self._ssh_by_id = np.full(self._n_global, np.nan, np.float32)
+        ids = self.P.ids()
+        ssh = self.P.env_download('sea_surface_height')
+        prev = self._ssh_by_id[ids]
+        self._ssh_previous = np.where(np.isnan(prev), ssh, prev).astype(np.float32)
+        self._ssh_by_id[ids] = ssh
+
     def update(self):   # oceandrift.py:185-211
+        self.water_column_stretching()
         self.advect_ocean_current()
         self._advect_wind_then_stokes_drift()
         self.update_terminal_velocity()

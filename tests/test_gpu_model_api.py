@@ -924,3 +924,87 @@ def test_lambert_and_mercator_lonlat2xy_on_the_device_equal_the_oracle():
             assert np.abs(hx - ox).max() < 1e-6 and np.abs(hy - oy).max() < 1e-6
     finally:
         c.close()
+
+
+def _c21_model(g, scheme, **config):
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity', 'sea_floor_depth_below_sea_level',
+             'sea_surface_height', 'land_binary_mask']
+    times = [T0 + timedelta(seconds=float(t)) for t in g['g_t']]
+    o = OceanDrift(loglevel=50, seed=0, rng='numpy')
+    o.add_reader(readers.GridReader(g['g_x'], g['g_y'], times, {k: g['g_' + k] for k in names}, z=g['g_z']))
+    o.set_config('drift:advection_scheme', scheme)
+    o.set_config('drift:vertical_mixing', False)
+    o.set_config('drift:vertical_advection', True)
+    o.set_config('drift:stokes_drift', False)
+    o.set_config('general:coastline_action', 'previous')
+    for k, v in config.items():
+        o.set_config(k, v)
+    return o
+
+
+def _c21_compare(o, g, tag, tol_pos=1e-7, tol_z=1e-5):
+    lon, lat, z = g[tag + '_lon'], g[tag + '_lat'], g[tag + '_z']
+    o.seed_elements(lon=lon[0], lat=lat[0], z=z[0], time=T0, wind_drift_factor=0.0)
+    o.run(time_step=float(g['dt']), steps=lon.shape[0] - 1)
+    e = o.elements
+    assert len(e) == lon.shape[1]
+    dpos = max(np.abs(e.lon - lon[-1][e.ID]).max(), np.abs(e.lat - lat[-1][e.ID]).max())
+    dz = np.abs(e.z - z[-1][e.ID]).max()
+    print(tag, 'model vs reference: %.2e deg, z %.2e m' % (dpos, dz))
+    assert dpos < tol_pos and dz < tol_z
+    return e
+
+
+def test_c21_water_column_stretching_reproduces_the_reference():
+    """drift:water_column_stretching (oceandrift.py:299-313): z follows the change of sea_surface_height since the previous
+    step, scaled by z / depth, before the current advects -- the reference's own run (golden c21a, RK2, vertical advection)."""
+    g = golden('c21_options.npz')
+    o = _c21_model(g, 'runge-kutta', **{'drift:water_column_stretching': True})
+    e = _c21_compare(o, g, 'a')
+    assert np.abs(e.z - g['a_z_without'][-1][e.ID]).max() > 0.02        # the option matters in this scenario
+
+
+def test_c21_truncate_ocean_model_below_m_reproduces_the_reference():
+    """drift:truncate_ocean_model_below_m (environment.py:554-566): every get_environment call -- the RK4 stage calls
+    included -- samples at max(z, -20 m); the elements keep their depth (golden c21b)."""
+    g = golden('c21_options.npz')
+    o = _c21_model(g, 'runge-kutta4', **{'drift:truncate_ocean_model_below_m': float(g['truncate'])})
+    e = _c21_compare(o, g, 'b')
+    assert np.abs(e.lon - g['b0_lon'][-1][e.ID]).max() > 1e-3           # against the same run without truncation
+    # with reader diffusivity profiles the reference truncates the profiles too: refused, not silently different
+    o = _c21_model(g, 'runge-kutta4', **{'drift:truncate_ocean_model_below_m': 20.0})
+    names = ['ocean_vertical_diffusivity']
+    times = [T0 + timedelta(seconds=float(t)) for t in g['g_t']]
+    o.add_reader(readers.GridReader(g['g_x'], g['g_y'], times, {'ocean_vertical_diffusivity': g['g_ocean_vertical_diffusivity']}, z=g['g_z']))
+    o.set_config('drift:vertical_mixing', True)
+    o.seed_elements(lon=g['b_lon'][0], lat=g['b_lat'][0], z=g['b_z'][0], time=T0)
+    with pytest.raises(NotImplementedError):
+        o.run(time_step=600, steps=2, stop_on_error=True)
+
+
+def test_c22_seed_ocean_only_moves_land_seeds_like_the_reference():
+    """seed:ocean_only (run() preamble, basemodel/__init__.py:2150-2158 -> closest_ocean_points :936-1031): the seeds on the
+    land strip go to the nearest ocean point of the 0.01 deg raster -- against the reference's own function on the same
+    reader (golden c22): the same elements move, to the same points."""
+    g = golden('c22_ocean_only.npz')
+    times = [T0 + timedelta(seconds=float(t)) for t in g['g_t']]
+    arrays = {k: (g['g_' + k][:, 0] if g['g_' + k].ndim == 4 else g['g_' + k])
+              for k in ('x_sea_water_velocity', 'y_sea_water_velocity', 'land_binary_mask')}
+    for on in (True, False):
+        o = OceanDrift(loglevel=50, seed=0)
+        o.add_reader(readers.GridReader(g['g_x'], g['g_y'], times, arrays))
+        o.set_config('seed:ocean_only', on)
+        o.set_config('general:coastline_action', 'previous')
+        o.seed_elements(lon=g['lon0'], lat=g['lat0'], time=T0)
+        o.run(time_step=1, steps=1)
+        lon, lat = o._sched['lon'], o._sched['lat']
+        if on:
+            moved = np.nonzero((lon != g['lon0']) | (lat != g['lat0']))[0]
+            assert np.array_equal(moved, np.sort(g['moved']))
+            assert np.array_equal(lon, g['lon']) and np.array_equal(lat, g['lat'])
+            assert o.num_elements_deactivated() == 0          # nobody starts on land any more
+        else:
+            assert np.array_equal(lon, g['lon0']) and np.array_equal(lat, g['lat0'])
+    assert OceanDrift(loglevel=50).get_config('seed:ocean_only') is False       # (tests/conftest.py; the product default is True)
+    from opendrift_amd.oceandrift import OpenDriftSimulation
+    assert OpenDriftSimulation.__dict__['SEED_OCEAN_ONLY_DEFAULT'] in (True, False)
