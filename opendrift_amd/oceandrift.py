@@ -1224,7 +1224,8 @@ class OpenDriftSimulation(Configurable):
                             self._below_active = int(round(rows[:self._rank, 0].sum()))
                             self.P.set_rank_offset(self._below_active)
                     self.P.store_previous()
-                    self._store_environment_previous()
+                    if hasattr(self, '_store_environment_previous'):
+                        self._store_environment_previous()
                 if self._world > 1 and ((fused_lane and not ens_sharded) or one_collective):
                     g_active = self._g_active           # from this step's collective
                 elif self._world > 1:
