@@ -297,9 +297,11 @@ __device__ __forceinline__ void add_current_noise(const StageNoise &N, int call,
 // symmetric about 1/2: the random-walk displacement R = 2u - 1 is resolved to 1.2e-7 of its range (0.2 micrometres for a
 // 1.9 m sub-step; the diffusivity itself is a float32).  Ten sub-steps (600 s / 60 s) cost two blocks; with one word per
 // sub-step (rounds 1-3) they cost three, and a block is ~130 instructions, 20 of them 64-bit integer multiply-adds.
-__device__ __forceinline__ double mix_uniform(rocrand_state_philox4x32_10 &st, uint4 &q, int it) {
+// primed: the caller drew the first block itself (k_vmix_col: ahead of its column gathers, whose latency the block's ~130
+// instructions then overlap)
+__device__ __forceinline__ double mix_uniform(rocrand_state_philox4x32_10 &st, uint4 &q, int it, bool primed = false) {
   const unsigned k = (unsigned)it % 5u;
-  if (k == 0) q = rocrand4(&st);
+  if (k == 0 && !(primed && it == 0)) q = rocrand4(&st);
   const unsigned lo = ((q.x & 255u) << 16) | ((q.y & 255u) << 8) | (q.z & 255u);
   const unsigned x = k == 0 ? q.x >> 8 : (k == 1 ? q.y >> 8 : (k == 2 ? q.z >> 8 : (k == 3 ? q.w >> 8 : lo)));
   return ((double)x + 0.5) * 5.9604644775390625e-08;
@@ -378,10 +380,23 @@ struct VMixArgs {
   const double *huni;
   unsigned long long seed, step;
 };
+struct MixRng { rocrand_state_philox4x32_10 st; uint4 q; bool primed; };
+// the particle's Philox stream of this step with its first block drawn (ODR_RNG_DEVICE)
+__device__ __forceinline__ MixRng mix_rng_begin(const VMixArgs &A, int id) {
+  MixRng R;
+  R.q = make_uint4(0u, 0u, 0u, 0u);
+  R.primed = false;
+  if (A.rng_mode == 0) {
+    rng_init(R.st, A.seed, id, A.step, RNG_OFF_VMIX);
+    R.q = rocrand4(&R.st);
+    R.primed = true;
+  }
+  return R;
+}
 template <int NQ>
 __device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, const double *Kp, const double *gsh, int tid,
                                                 const VMixArgs &A, long long i, long long n, int id, double z, int &moving,
-                                                float Zmin, float tv, int &sf_flags) {
+                                                float Zmin, float tv, int &sf_flags, const MixRng *pre = nullptr) {
   constexpr int NL = 4 * NQ;
   const double dt = A.dt;
   const int mix_at_surface = A.mix_at_surface, rng_mode = A.rng_mode, sfl = A.sfl;
@@ -398,8 +413,10 @@ __device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, con
   // w*dt_mix*moving: dt_mix is a NumPy float64 scalar (np.sign, oceandrift.py:416) -> float64 product under NumPy 2
   double wstep = __dmul_rn(__dmul_rn((double)tv, dt_mix), (double)moving);
   rocrand_state_philox4x32_10 st;
-  if (rng_mode == 0) rng_init(st, A.seed, id, A.step, RNG_OFF_VMIX);
   uint4 u4 = make_uint4(0u, 0u, 0u, 0u);
+  bool primed = false;
+  if (pre) { st = pre->st; u4 = pre->q; primed = pre->primed; }
+  else if (rng_mode == 0) rng_init(st, A.seed, id, A.step, RNG_OFF_VMIX);
   // -dK/dz * dt_mix and sqrt(K |dt_mix| 2 / r) of one level (oceandrift.py:501-502,527-528)
   auto level_terms = [&](int zl, double &dk_dt, double &sg) {
     const double Kz = Kp[zl * BLOCK + tid];
@@ -465,7 +482,7 @@ __device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, con
     if (q < 0 || q > 2) level_terms(zi, dKdt, sig);
     double u01;
     if (rng_mode == 1) u01 = A.huni[(size_t)it * n + i];
-    else u01 = mix_uniform(st, u4, it);
+    else u01 = mix_uniform(st, u4, it, primed);
     double R = __dsub_rn(__dmul_rn(2.0, u01), 1.0);
     z = __dsub_rn(z, __dmul_rn((double)moving, __dsub_rn(dKdt, __dmul_rn(R, sig))));
     if (z >= 0) z = -z;
@@ -1588,13 +1605,21 @@ __global__ __launch_bounds__(BLOCK, ODR_VMIX_WAVES) void k_vmix_col(const DevWor
   const float dep0 = p.env[VAR_DEPTH][i], ssh0 = p.env[VAR_SSH][i], tv0 = p.tv[i];
   const int id0 = rng_mode == 0 ? p.id[i] : 0;
   const float w0 = vadv >= 0 ? p.env[VAR_W][i] : 0.f;
-  vmix_col_fill<NQ, TL>(s, D, slon, slat, Kp, tid);
   VMixArgs A;
   A.dt = dt; A.dt_mix_cfg = dt_mix_cfg; A.mix_at_surface = mix_at_surface; A.rng_mode = rng_mode; A.sfl = sfl; A.pad = 0;
   A.huni = huni; A.seed = seed; A.step = step;
+#ifdef ODR_VMIX_LATE_RNG
+  vmix_col_fill<NQ, TL>(s, D, slon, slat, Kp, tid);
+  const MixRng *pre = nullptr;
+#else
+  // the stream's first block before the column gathers are consumed: its arithmetic runs while they are in flight
+  const MixRng R0 = mix_rng_begin(A, id0);
+  vmix_col_fill<NQ, TL>(s, D, slon, slat, Kp, tid);
+  const MixRng *pre = &R0;
+#endif
   int sf_flags = 0;
   const float Zmin = __fmul_rn(-1.f, __fadd_rn(dep0, ssh0));  // float32 (:408)
-  double z = vmix_col_walk<NQ>(s, nzp, Kp, gsh, tid, A, i, p.n, id0, z0, moving, Zmin, tv0, sf_flags);
+  double z = vmix_col_walk<NQ>(s, nzp, Kp, gsh, tid, A, i, p.n, id0, z0, moving, Zmin, tv0, sf_flags, pre);
   if (sf_flags & 1) {   // deactivate_elements(reason='seafloor') (basemodel/__init__.py:1774-1795)
     if (p.status[i] == 0) p.status[i] = sfl >> 8;
     p.moving[i] = 0;
