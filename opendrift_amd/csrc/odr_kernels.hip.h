@@ -292,19 +292,55 @@ __device__ __forceinline__ void add_current_noise(const StageNoise &N, int call,
 
 // ---- vertical mixing on a K column in LDS: device functions shared by k_vmix_col (odr_mix.hip) and the fused
 // step + mixing kernel k_step_grid<..., MIXQ> (odr_step_mix.hip)
-// Uniform number of mixing sub-step `it` (ODR_RNG_DEVICE): one Philox4x32-10 block serves FIVE sub-steps -- 24 bits each:
-// the upper 24 bits of the four words, then the four low bytes' worth taken from words 0..2 -- as (x + 1/2) 2^-24 in (0, 1),
-// symmetric about 1/2: the random-walk displacement R = 2u - 1 is resolved to 1.2e-7 of its range (0.2 micrometres for a
-// 1.9 m sub-step; the diffusivity itself is a float32).  Ten sub-steps (600 s / 60 s) cost two blocks; with one word per
-// sub-step (rounds 1-3) they cost three, and a block is ~130 instructions, 20 of them 64-bit integer multiply-adds.
-// primed: the caller drew the first block itself (k_vmix_col: ahead of its column gathers, whose latency the block's ~130
-// instructions then overlap)
-__device__ __forceinline__ double mix_uniform(rocrand_state_philox4x32_10 &st, uint4 &q, int it, bool primed = false) {
-  const unsigned k = (unsigned)it % 5u;
-  if (k == 0 && !(primed && it == 0)) q = rocrand4(&st);
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11), one 128-bit block
+// from a 128-bit counter and a 64-bit key, evaluated directly: the mixing loop names the block it needs (element, step,
+// block number) instead of advancing a generator state.  (Rounds 1-3 drew the same words through rocrand's state object,
+// whose init and every rocrand4() each evaluate a block ahead: three blocks for the two that ten sub-steps consume.)
+// Known answers: tests/test_philox.py (oracle/philox.py against the Random123 vectors), tests/test_gpu_parity.py.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x, p1 = (unsigned long long)0xCD9E8D57u * c.z;
+    c = make_uint4((unsigned)(p1 >> 32) ^ c.y ^ k0, (unsigned)p1, (unsigned)(p0 >> 32) ^ c.w ^ k1, (unsigned)p0);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+// The uniforms of OceanDrift.vertical_mixing in ODR_RNG_DEVICE mode.  Block b of element `id` in step `step`:
+//   counter = {b, step (low word), id, 0x4D495856 ("MIXV") ^ step (high word)},  key = seed.
+// (The rocrand streams of the other consumers count in words 0-1 and hold the element ID in word 2 with word 3 = 0.)
+// One block serves FIVE sub-steps -- 24 bits each: the upper 24 bits of the four words, then the four low bytes' worth
+// taken from words 0..2 -- as (x + 1/2) 2^-24 in (0, 1), symmetric about 1/2: the random-walk displacement R = 2u - 1 is
+// resolved to 1.2e-7 of its range (0.2 micrometres for a 1.9 m sub-step; the diffusivity itself is a float32).  Ten
+// sub-steps (600 s / 60 s) cost two blocks of ~100 instructions, 20 of them 32 x 32 -> 64-bit multiplies.
+struct MixKey { unsigned k0, k1, step_lo, tag, id; };
+__device__ __forceinline__ MixKey mix_key(unsigned long long seed, unsigned long long step, int id) {
+  MixKey K;
+  K.k0 = (unsigned)seed; K.k1 = (unsigned)(seed >> 32);
+  K.step_lo = (unsigned)step; K.tag = 0x4D495856u ^ (unsigned)(step >> 32); K.id = (unsigned)id;
+  return K;
+}
+__device__ __forceinline__ uint4 mix_block(const MixKey &K, unsigned b) {
+  return philox4x32_10(make_uint4(b, K.step_lo, K.id, K.tag), K.k0, K.k1);
+}
+__device__ __forceinline__ unsigned mix_word(const uint4 &q, unsigned k) {
   const unsigned lo = ((q.x & 255u) << 16) | ((q.y & 255u) << 8) | (q.z & 255u);
-  const unsigned x = k == 0 ? q.x >> 8 : (k == 1 ? q.y >> 8 : (k == 2 ? q.z >> 8 : (k == 3 ? q.w >> 8 : lo)));
-  return ((double)x + 0.5) * 5.9604644775390625e-08;
+  return k == 0 ? q.x >> 8 : (k == 1 ? q.y >> 8 : (k == 2 ? q.z >> 8 : (k == 3 ? q.w >> 8 : lo)));
+}
+// the 24-bit draw of sub-step `it`.  primed: the caller drew block 0 itself (ahead of its column gathers, whose latency the
+// block's arithmetic then overlaps)
+__device__ __forceinline__ unsigned mix_draw(const MixKey &K, uint4 &q, int it, bool primed = false) {
+  const unsigned b = (unsigned)it / 5u, k = (unsigned)it - 5u * b;
+  if (k == 0 && !(primed && it == 0)) q = mix_block(K, b);
+  return mix_word(q, k);
+}
+__device__ __forceinline__ double mix_uniform(const MixKey &K, uint4 &q, int it, bool primed = false) {
+  return ((double)mix_draw(K, q, it, primed) + 0.5) * 5.9604644775390625e-08;
+}
+// R = 2 u - 1 of a 24-bit draw x, u = (x + 1/2) 2^-24: (2 x + 1 - 2^24) 2^-24.  Every step of 2 * u - 1 is exact for such a
+// u (25 significant bits), so this is the value the reference's expression gives for it -- in two instructions instead of five.
+__device__ __forceinline__ double mix_R_of(unsigned x) {
+  return (double)((int)(2u * x + 1u) - (1 << 24)) * 5.9604644775390625e-08;
 }
 // Fast version for the common case -- the diffusivity comes from one gridded reader with a
 // plain (not interleaved) z-innermost K array.  The host resolves source, time bracket and
@@ -380,15 +416,15 @@ struct VMixArgs {
   const double *huni;
   unsigned long long seed, step;
 };
-struct MixRng { rocrand_state_philox4x32_10 st; uint4 q; bool primed; };
-// the particle's Philox stream of this step with its first block drawn (ODR_RNG_DEVICE)
+struct MixRng { MixKey key; uint4 q; bool primed; };
+// the particle's stream of this step with its first block drawn (ODR_RNG_DEVICE)
 __device__ __forceinline__ MixRng mix_rng_begin(const VMixArgs &A, int id) {
   MixRng R;
+  R.key = mix_key(A.seed, A.step, id);
   R.q = make_uint4(0u, 0u, 0u, 0u);
   R.primed = false;
   if (A.rng_mode == 0) {
-    rng_init(R.st, A.seed, id, A.step, RNG_OFF_VMIX);
-    R.q = rocrand4(&R.st);
+    R.q = mix_block(R.key, 0u);
     R.primed = true;
   }
   return R;
@@ -412,11 +448,10 @@ __device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, con
   const double r = 1.0 / 3, ir = 1.0 / r;
   // w*dt_mix*moving: dt_mix is a NumPy float64 scalar (np.sign, oceandrift.py:416) -> float64 product under NumPy 2
   double wstep = __dmul_rn(__dmul_rn((double)tv, dt_mix), (double)moving);
-  rocrand_state_philox4x32_10 st;
+  const MixKey st = mix_key(A.seed, A.step, id);
   uint4 u4 = make_uint4(0u, 0u, 0u, 0u);
   bool primed = false;
-  if (pre) { st = pre->st; u4 = pre->q; primed = pre->primed; }
-  else if (rng_mode == 0) rng_init(st, A.seed, id, A.step, RNG_OFF_VMIX);
+  if (pre) { u4 = pre->q; primed = pre->primed; }
   // -dK/dz * dt_mix and sqrt(K |dt_mix| 2 / r) of one level (oceandrift.py:501-502,527-528)
   auto level_terms = [&](int zl, double &dk_dt, double &sg) {
     const double Kz = Kp[zl * BLOCK + tid];
@@ -480,10 +515,9 @@ __device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, con
     double dKdt = q == 0 ? c_dk[0] : (q == 1 ? c_dk[1] : c_dk[2]);
     double sig = q == 0 ? c_sg[0] : (q == 1 ? c_sg[1] : c_sg[2]);
     if (q < 0 || q > 2) level_terms(zi, dKdt, sig);
-    double u01;
-    if (rng_mode == 1) u01 = A.huni[(size_t)it * n + i];
-    else u01 = mix_uniform(st, u4, it, primed);
-    double R = __dsub_rn(__dmul_rn(2.0, u01), 1.0);
+    double R;
+    if (rng_mode == 1) R = __dsub_rn(__dmul_rn(2.0, A.huni[(size_t)it * n + i]), 1.0);
+    else R = mix_R_of(mix_draw(st, u4, it, primed));
     z = __dsub_rn(z, __dmul_rn((double)moving, __dsub_rn(dKdt, __dmul_rn(R, sig))));
     if (z >= 0) z = -z;
     if (z < (double)Zmin && moving == 1) z = __dsub_rn((double)__fmul_rn(2.f, Zmin), z);
@@ -1501,8 +1535,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
   const float Zmin = __fmul_rn(-1.f, __fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH][i]));  // float32 (:408)
   // w*dt_mix*moving: dt_mix is a NumPy float64 scalar (np.sign, oceandrift.py:416) -> float64 product under NumPy 2
   double wstep = __dmul_rn(__dmul_rn((double)p.tv[i], dt_mix), (double)moving);
-  rocrand_state_philox4x32_10 st;
-  if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
+  const MixKey st = mix_key(seed, step, rng_mode == 0 ? p.id[i] : 0);
   uint4 u4 = make_uint4(0u, 0u, 0u, 0u);
   OilLane oil;
   if (OIL) oil.init(p, i, oa);
@@ -1579,35 +1612,18 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
 #ifndef ODR_VMIX_WAVES
 #define ODR_VMIX_WAVES 6   // 80 registers, no scratch: six workgroups (24.6 KB of LDS each) per CU; unconstrained the allocator took 102 (4 waves)
 #endif
+// one particle of k_vmix_col: column into the thread's LDS slots, sub-steps, stores
 template <int NQ, bool TL>
-__global__ __launch_bounds__(BLOCK, ODR_VMIX_WAVES) void k_vmix_col(const DevWorld *__restrict__ W, PView p, VMixDesc D,
-                                                    double dt, double dt_mix_cfg, int mix_at_surface,
-                                                    int rng_mode, const double *__restrict__ huni,
-                                                    unsigned long long seed, unsigned long long step,
-                                                    int vadv, int sfl) {
-  constexpr int NL = 4 * NQ;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  long long i = pid();
-  const int tid = threadIdx.x;
-  const DevSource &s = W->src[D.sid];
-  const int nzp = D.nzp;
-  double *Kp = (double *)smem;              // [NL][BLOCK]
-  double *gsh = Kp + (size_t)NL * BLOCK;    // [3][NL]
-  if (tid < nzp) {
-    gsh[tid] = s.vg_a[tid]; gsh[NL + tid] = s.vg_b[tid]; gsh[2 * NL + tid] = s.vg_c[tid];
-    gsh[3 * NL + tid] = s.zmid[tid];     // level boundaries (entries >= nzp - 1 are not read)
-  }
-  __syncthreads();
-  if (i >= p.n) return;  // no barrier below: every thread touches only its own LDS column
+__device__ __forceinline__ void vmix_col_particle(const DevSource &s, const PView &p, const VMixDesc &D, const VMixArgs &A,
+                                                  int vadv, long long i, double *Kp, const double *gsh, int tid) {
+  const int nzp = D.nzp, sfl = A.sfl;
+  const double dt = A.dt;
   // the particle's state in one round trip (requested before the column gathers, used behind them)
   const double slon = p.slon[i], slat = p.slat[i], z0 = p.z[i];
   int moving = p.moving[i];
   const float dep0 = p.env[VAR_DEPTH][i], ssh0 = p.env[VAR_SSH][i], tv0 = p.tv[i];
-  const int id0 = rng_mode == 0 ? p.id[i] : 0;
+  const int id0 = A.rng_mode == 0 ? p.id[i] : 0;
   const float w0 = vadv >= 0 ? p.env[VAR_W][i] : 0.f;
-  VMixArgs A;
-  A.dt = dt; A.dt_mix_cfg = dt_mix_cfg; A.mix_at_surface = mix_at_surface; A.rng_mode = rng_mode; A.sfl = sfl; A.pad = 0;
-  A.huni = huni; A.seed = seed; A.step = step;
 #ifdef ODR_VMIX_LATE_RNG
   vmix_col_fill<NQ, TL>(s, D, slon, slat, Kp, tid);
   const MixRng *pre = nullptr;
@@ -1620,6 +1636,259 @@ __global__ __launch_bounds__(BLOCK, ODR_VMIX_WAVES) void k_vmix_col(const DevWor
   int sf_flags = 0;
   const float Zmin = __fmul_rn(-1.f, __fadd_rn(dep0, ssh0));  // float32 (:408)
   double z = vmix_col_walk<NQ>(s, nzp, Kp, gsh, tid, A, i, p.n, id0, z0, moving, Zmin, tv0, sf_flags, pre);
+  if (sf_flags & 1) {   // deactivate_elements(reason='seafloor') (basemodel/__init__.py:1774-1795)
+    if (p.status[i] == 0) p.status[i] = sfl >> 8;
+    p.moving[i] = 0;
+  }
+  if (sf_flags & 2) { p.lon[i] = p.plon[i]; p.lat[i] = p.plat[i]; }
+  if (vadv >= 0 && (vadv ? z <= 0 : z < 0)) {  // vertical_advection (oceandrift.py:315-350)
+    double zz = __dadd_rn(z, __dmul_rn(__dmul_rn((double)moving, (double)w0), dt));
+    z = zz < 0 ? zz : 0.0;
+  }
+  p.z[i] = z;
+}
+template <int NQ, bool TL>
+__global__ __launch_bounds__(BLOCK, ODR_VMIX_WAVES) void k_vmix_col(const DevWorld *__restrict__ W, PView p, VMixDesc D,
+                                                    double dt, double dt_mix_cfg, int mix_at_surface,
+                                                    int rng_mode, const double *__restrict__ huni,
+                                                    unsigned long long seed, unsigned long long step,
+                                                    int vadv, int sfl) {
+  constexpr int NL = 4 * NQ;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const DevSource &s = W->src[D.sid];
+  const int nzp = D.nzp;
+  double *Kp = (double *)smem;              // [NL][BLOCK]
+  double *gsh = Kp + (size_t)NL * BLOCK;    // [4][NL]
+  if (tid < nzp) {
+    gsh[tid] = s.vg_a[tid]; gsh[NL + tid] = s.vg_b[tid]; gsh[2 * NL + tid] = s.vg_c[tid];
+    gsh[3 * NL + tid] = s.zmid[tid];     // level boundaries (entries >= nzp - 1 are not read)
+  }
+  __syncthreads();
+  const long long i = pid();
+  if (i >= p.n) return;  // no barrier below: every thread touches only its own LDS column
+  VMixArgs A;
+  A.dt = dt; A.dt_mix_cfg = dt_mix_cfg; A.mix_at_surface = mix_at_surface; A.rng_mode = rng_mode; A.sfl = sfl; A.pad = 0;
+  A.huni = huni; A.seed = seed; A.step = step;
+  vmix_col_particle<NQ, TL>(s, p, D, A, vadv, i, Kp, gsh, tid);
+}
+
+// ---- k_vmix_win: the same mixing with the diffusivity of FIVE levels per particle instead of the whole column.
+// A particle rarely leaves the three levels around its starting one (lv0 - 1 .. lv0 + 1) within a step, and their terms
+// need K on lv0 - 2 .. lv0 + 2: per corner and time level one 16-byte gather at level lv0 - 1 (dword-aligned) and one
+// 4-byte gather of level lv0 - 2 replace the NQ quads of the column -- for the 12-level field 16 gathers, 8 of them
+// narrow, instead of 24 wide ones, five float64 layer values instead of twelve -- and no column in LDS: the cost no
+// longer grows with the number of levels of the reader.  A particle whose sub-step does leave the window (0.07 % of them
+// per step in the C3 field, i.e. some lane of ~4 % of the waves) finishes its sub-steps in a second loop that fetches the
+// three levels around its current one in every sub-step (footprint offsets and weights parked in LDS by the first part).
+// Level terms are a pure function of the column, so where they came from does not show in the result: same floats, same
+// operations in the same order as vmix_col_fill / vmix_col_walk -- bit-identical (tests/test_gpu_vmix_window.py).
+// (Earlier attempts of round 4: refill INSIDE the sub-step loop, 258 registers; leavers appended to a list and a second
+// launch of k_vmix_col over it, 33 us for 7 000 particles -- the latency of one pass, more than the window saved; an outer
+// loop that re-centres the window: the reader's scalars hoisted out of it overflow the scalar registers, 450 B of scratch.)
+#ifndef ODR_VWIN_WAVES
+#define ODR_VWIN_WAVES 5
+#endif
+// one layer value of the column as the ReaderBlock forms it: bilinear in float32 out, time interpolation in float64,
+// fallback where the position is not covered or the value is not finite
+template <bool TL>
+__device__ __forceinline__ double vmix_layer(float b00, float b01, float b10, float b11, float a00, float a01, float a10, float a11,
+                                             double w00, double w01, double w10, double w11, double wgt, bool cov, double Kfb) {
+  double v = (double)bilw(b00, b01, b10, b11, w00, w01, w10, w11);
+  if (TL) {
+    const double w = (double)bilw(a00, a01, a10, a11, w00, w01, w10, w11);
+    v = __dadd_rn(__dmul_rn(v, 1 - wgt), __dmul_rn(w, wgt));
+  }
+  return (cov && isfinite(v)) ? v : Kfb;
+}
+struct VMixGrad { double gd0, gi0, gd1, gi1, gd2, gi2, dt_mix; bool uniform_z; };
+// -dK/dz * dt_mix and sqrt(K |dt_mix| 2 / r) of level zl from K below (Kl), on (Kz) and above (Kh) it (vmix_col_walk's level_terms)
+__device__ __forceinline__ void vmix_terms(const VMixGrad &G, const double *gsh, int nzp, int zl, double Kl, double Kz, double Kh,
+                                           double &dk_dt, double &sg) {
+  const double r = 1.0 / 3, ir = 1.0 / r;
+  double gK;
+  if (zl == 0) gK = div_cr(Kh - Kz, G.gd0, G.gi0);
+  else if (zl == nzp - 1) gK = div_cr(Kz - Kl, G.gd1, G.gi1);
+  else if (G.uniform_z) gK = div_cr(Kh - Kl, G.gd2, G.gi2);
+  else gK = __dadd_rn(__dadd_rn(__dmul_rn(gsh[zl], Kl), __dmul_rn(gsh[nzp + zl], Kz)), __dmul_rn(gsh[2 * nzp + zl], Kh));
+  double dK = -gK;
+  if (fabs(dK) < 1e-10) dK = 0;
+  dk_dt = __dmul_rn(dK, G.dt_mix);
+  sg = sqrt(div_cr(__dmul_rn(__dmul_rn(Kz, fabs(G.dt_mix)), 2.0), r, ir));
+}
+template <bool TL>
+__global__ __launch_bounds__(BLOCK, ODR_VWIN_WAVES) void k_vmix_win(const DevWorld *__restrict__ W, PView p, VMixDesc D,
+                                                    double dt, double dt_mix_cfg, int mix_at_surface,
+                                                    int rng_mode, const double *__restrict__ huni,
+                                                    unsigned long long seed, unsigned long long step,
+                                                    int vadv, int sfl) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const DevSource &s = W->src[D.sid];
+  const int nzp = D.nzp;
+  double *fw = (double *)smem;                        // [4][BLOCK]: the footprint's weights, for the second loop
+  unsigned *fo = (unsigned *)(fw + 4 * BLOCK);        // [4][BLOCK]: byte offsets of its node records
+  double *gsh = (double *)(fo + 4 * BLOCK);           // [4][nzp]: np.gradient coefficients a, b, c and the level boundaries
+  if (tid < nzp) {
+    gsh[tid] = s.vg_a[tid]; gsh[nzp + tid] = s.vg_b[tid]; gsh[2 * nzp + tid] = s.vg_c[tid];
+    gsh[3 * nzp + tid] = tid < nzp - 1 ? s.zmid[tid] : __builtin_inf();
+  }
+  __syncthreads();
+  const long long i = pid();
+  if (i >= p.n) return;   // no barrier below
+  const double slon = p.slon[i], slat = p.slat[i], z0 = p.z[i];
+  int moving = p.moving[i];
+  const float dep0 = p.env[VAR_DEPTH][i], ssh0 = p.env[VAR_SSH][i], tv0 = p.tv[i];
+  const int id0 = rng_mode == 0 ? p.id[i] : 0;
+  const float w0 = vadv >= 0 ? p.env[VAR_W][i] : 0.f;
+  const MixKey key = mix_key(seed, step, id0);
+  uint4 u4 = make_uint4(0u, 0u, 0u, 0u);
+  const bool primed = rng_mode == 0;
+  VMixGrad G;
+  G.uniform_z = s.vg_uniform != 0;
+  G.gd0 = s.vg_d[0]; G.gi0 = s.vg_id[0]; G.gd1 = s.vg_d[1]; G.gi1 = s.vg_id[1]; G.gd2 = s.vg_d[2]; G.gi2 = s.vg_id[2];
+  const double sgn = dt > 0 ? 1.0 : (dt < 0 ? -1.0 : 0.0);
+  const double dt_mix = dt_mix_cfg * sgn;
+  G.dt_mix = dt_mix;
+  const int ntimes = abs((int)(dt / dt_mix));
+  double wstep = __dmul_rn(__dmul_rn((double)tv0, dt_mix), (double)moving);
+  const float Zmin = __fmul_rn(-1.f, __fadd_rn(dep0, ssh0));  // float32 (:408)
+  const double Kfb = (double)D.Kfb, wgt = D.wgt;
+  const float *kb = D.kb, *ka = TL ? D.ka : D.kb;
+  // level of a depth as vmix_col_walk counts it: the number of boundaries below d (odd ones count when d >= zm, even ones
+  // when d > zm; NaN counts none)
+  auto level_of = [&](double d) {
+    int zs = 0;
+    for (int k = 0; k < nzp - 1; ++k) {
+      const double b = gsh[3 * nzp + k];
+      zs += ((k & 1) ? d >= b : d > b) ? 1 : 0;
+    }
+    return zs;
+  };
+  auto centre_of = [&](int zs) { return zs < 1 ? 1 : (zs > nzp - 2 ? nzp - 2 : zs); };   // window centre: 1 .. nzp - 2
+  // the window around level lv0: K on lv0 - 2 .. lv0 + 2 from the footprint (o.., w..) -> the terms of lv0 - 1 .. lv0 + 1
+  // and the boundaries lv0 - 2 .. lv0 + 1, the ">=" of the odd ones folded into the value (vmix_col_walk).
+  // first: also draws the stream's first Philox block while the gathers are in flight
+  double c_dk[3], c_sg[3], wb[4];
+  auto load_window = [&](int lv0, unsigned o00, unsigned o01, unsigned o10, unsigned o11, double w00, double w01, double w10,
+                         double w11, bool cov, bool first) {
+    // level offsets inside the node record; the wide gather reaches level lv0 + 2 <= nzp: at most one float past the K
+    // array, inside the record or the 64 spare bytes a block ends with
+    const unsigned lq = (unsigned)(lv0 - 1) * 4u, l1 = (unsigned)(lv0 >= 2 ? lv0 - 2 : 0) * 4u;
+    const F4 b00 = ld_off<F4>(kb, o00 + lq), b01 = ld_off<F4>(kb, o01 + lq), b10 = ld_off<F4>(kb, o10 + lq), b11 = ld_off<F4>(kb, o11 + lq);
+    const float c00 = ld_off<float>(kb, o00 + l1), c01 = ld_off<float>(kb, o01 + l1), c10 = ld_off<float>(kb, o10 + l1), c11 = ld_off<float>(kb, o11 + l1);
+    // (on a time level the second set repeats the first: the compiler drops it)
+    const F4 a00 = ld_off<F4>(ka, o00 + lq), a01 = ld_off<F4>(ka, o01 + lq), a10 = ld_off<F4>(ka, o10 + lq), a11 = ld_off<F4>(ka, o11 + lq);
+    const float e00 = ld_off<float>(ka, o00 + l1), e01 = ld_off<float>(ka, o01 + l1), e10 = ld_off<float>(ka, o10 + l1), e11 = ld_off<float>(ka, o11 + l1);
+    if (first && primed) u4 = mix_block(key, 0u);
+    double Kw[5];   // K on levels lv0 - 2 .. lv0 + 2 (entries of levels outside 0 .. nzp - 1 are never used)
+    Kw[0] = vmix_layer<TL>(c00, c01, c10, c11, e00, e01, e10, e11, w00, w01, w10, w11, wgt, cov, Kfb);
+    Kw[1] = vmix_layer<TL>(b00.x, b01.x, b10.x, b11.x, a00.x, a01.x, a10.x, a11.x, w00, w01, w10, w11, wgt, cov, Kfb);
+    Kw[2] = vmix_layer<TL>(b00.y, b01.y, b10.y, b11.y, a00.y, a01.y, a10.y, a11.y, w00, w01, w10, w11, wgt, cov, Kfb);
+    Kw[3] = vmix_layer<TL>(b00.z, b01.z, b10.z, b11.z, a00.z, a01.z, a10.z, a11.z, w00, w01, w10, w11, wgt, cov, Kfb);
+    Kw[4] = vmix_layer<TL>(b00.w, b01.w, b10.w, b11.w, a00.w, a01.w, a10.w, a11.w, w00, w01, w10, w11, wgt, cov, Kfb);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int zl = lv0 - 1 + q;
+      c_dk[q] = 0; c_sg[q] = 0;
+      if (zl >= 0 && zl < nzp) vmix_terms(G, gsh, nzp, zl, Kw[q], Kw[q + 1], Kw[q + 2], c_dk[q], c_sg[q]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = lv0 - 2 + j;
+      double b = k < 0 ? -1.0 : __builtin_inf();
+      if (k >= 0 && k < nzp - 1) {
+        b = gsh[3 * nzp + k];
+        if ((k & 1) && b > 0) b = __longlong_as_double(__double_as_longlong(b) - 1);
+      }
+      wb[j] = b;
+    }
+  };
+  double z = z0;
+  int sf_flags = 0, it = 0;
+  // one random-walk sub-step on the window (vmix_col_walk's loop body; oceandrift.py:531-559); false: the particle is on a
+  // level outside the window and nothing was done.  x: the sub-step's 24-bit draw (ODR_RNG_DEVICE)
+  auto substep = [&](int lv0, unsigned x) -> bool {
+    const bool surface = z == 0;
+    const double d = -z;
+    int q = (d > wb[1] ? 1 : 0) + (d > wb[2] ? 1 : 0);
+    if (!(d > wb[0]) || d > wb[3]) {
+      // below boundary lv0 - 2 or above lv0 + 1: a level outside the window.  (NaN counts no boundary: level 0, inside
+      // the window exactly when lv0 == 1 -- where level_of / centre_of put the window of a NaN)
+      if (d != d && lv0 == 1) q = 0;
+      else return false;
+    }
+    const double dKdt = q == 0 ? c_dk[0] : (q == 1 ? c_dk[1] : c_dk[2]);
+    const double sig = q == 0 ? c_sg[0] : (q == 1 ? c_sg[1] : c_sg[2]);
+    double R;
+    if (rng_mode == 1) R = __dsub_rn(__dmul_rn(2.0, huni[(size_t)it * p.n + i]), 1.0);
+    else R = mix_R_of(x);
+    z = __dsub_rn(z, __dmul_rn((double)moving, __dsub_rn(dKdt, __dmul_rn(R, sig))));
+    if (z >= 0) z = -z;
+    if (z < (double)Zmin && moving == 1) z = __dsub_rn((double)__fmul_rn(2.f, Zmin), z);
+    z = __dadd_rn(z, wstep);
+    if (!mix_at_surface && surface) z = 0.0;
+    if (z > 0) z = 0.0;
+    if (z < (double)Zmin) {   // "let particles stick to bottom": interact_with_seafloor() inside the loop (oceandrift.py:555-559)
+      const int act = sfl & 255;
+      if (act == 3) sf_flags |= 2;                       // previous: lon/lat go back, z stays
+      else if (act) {
+        z = (double)Zmin;                                // lift_to_seafloor / deactivate
+        if (act == 2) { sf_flags |= 1; moving = 0; wstep = 0.0; }
+      }
+    }
+    return true;
+  };
+  bool cov;
+  {
+    // ---- vmix_col_fill's footprint
+    double lon = slon, x, y;
+    if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
+    else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
+    proj_fwd_rt(s.proj, lon, slat, x, y);
+    cov = x >= s.xmin && x <= s.xmax && y >= s.ymin && y <= s.ymax;
+    if (s.mod360_x) x = np_mod(x, 360.0);
+    const DevBlock &bb = s.slot[D.geo_slot];
+    const double xi = __dmul_rn(div_cr(x - bb.x0, bb.xspan, bb.ixspan), (double)(bb.nx - 1));
+    const double yi = __dmul_rn(div_cr(y - bb.y0, bb.yspan, bb.iyspan), (double)(bb.ny - 1));
+    const int ny = bb.ny, nx = bb.nx;
+    const Axis ay = axis_fp(yi, ny), ax = axis_fp(xi, nx);
+    const double ty = ay.t, tx = ax.t, wy0 = 1 - ty, wx0 = 1 - tx;
+    // uncovered particles gather node (0,0) and discard it: keeps the loads unconditional
+    const unsigned recb = (unsigned)bb.rec * 4u;
+    const unsigned r0 = __umul24((unsigned)ay.i0, (unsigned)nx), r1 = __umul24((unsigned)ay.i1, (unsigned)nx);
+    const unsigned o00 = cov ? __umul24(r0 + (unsigned)ax.i0, recb) : 0u, o01 = cov ? __umul24(r0 + (unsigned)ax.i1, recb) : 0u;
+    const unsigned o10 = cov ? __umul24(r1 + (unsigned)ax.i0, recb) : 0u, o11 = cov ? __umul24(r1 + (unsigned)ax.i1, recb) : 0u;
+    const double w00 = wy0 * wx0, w01 = wy0 * tx, w10 = ty * wx0, w11 = ty * tx;
+    fw[tid] = w00; fw[BLOCK + tid] = w01; fw[2 * BLOCK + tid] = w10; fw[3 * BLOCK + tid] = w11;
+    fo[tid] = o00; fo[BLOCK + tid] = o01; fo[2 * BLOCK + tid] = o10; fo[3 * BLOCK + tid] = o11;
+    const int lv0 = centre_of(level_of(-z0));
+    load_window(lv0, o00, o01, o10, o11, w00, w01, w10, w11, cov, true);
+    // first pass: every lane is at the same sub-step, so a Philox block is consumed in an unrolled group of five -- which of
+    // its words a sub-step takes is known at compile time
+    bool left = false;
+    for (unsigned b5 = 0; !left && it < ntimes; ++b5) {
+      if (rng_mode == 0 && !(primed && b5 == 0)) u4 = mix_block(key, b5);
+#pragma unroll
+      for (unsigned k = 0; k < 5; ++k) {
+        if (it >= ntimes) break;
+        if (!substep(lv0, mix_word(u4, k))) { left = true; break; }
+        ++it;
+      }
+    }
+  }
+  while (it < ntimes) {
+    // ---- a particle that left its window: another window around its current level, and on from the same sub-step (the
+    // lanes are at different sub-steps now; the block of the current one is in u4 unless the sub-step opens a new block)
+    const int lv0 = centre_of(level_of(-z));
+    load_window(lv0, fo[tid], fo[BLOCK + tid], fo[2 * BLOCK + tid], fo[3 * BLOCK + tid], fw[tid], fw[BLOCK + tid], fw[2 * BLOCK + tid],
+                fw[3 * BLOCK + tid], cov, false);
+    for (; it < ntimes; ++it) {
+      const unsigned b = (unsigned)it / 5u, k = (unsigned)it - 5u * b;
+      if (rng_mode == 0 && k == 0 && !(primed && it == 0)) u4 = mix_block(key, b);
+      if (!substep(lv0, mix_word(u4, k))) break;
+    }
+  }
   if (sf_flags & 1) {   // deactivate_elements(reason='seafloor') (basemodel/__init__.py:1774-1795)
     if (p.status[i] == 0) p.status[i] = sfl >> 8;
     p.moving[i] = 0;
@@ -1684,8 +1953,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix_wind(PView p, const double *__re
   int sf_flags = 0;   // 1: deactivated on the sea floor, 2: moved back horizontally (general:seafloor_action)
   const float Zmin = __fmul_rn(-1.f, __fadd_rn(p.env[VAR_DEPTH][i], p.env[VAR_SSH][i]));
   double wstep = __dmul_rn(__dmul_rn((double)p.tv[i], dt_mix), (double)moving);
-  rocrand_state_philox4x32_10 st;
-  if (rng_mode == 0) rng_init(st, seed, p.id[i], step, RNG_OFF_VMIX);
+  const MixKey st = mix_key(seed, step, rng_mode == 0 ? p.id[i] : 0);
   uint4 u4 = make_uint4(0u, 0u, 0u, 0u);
   OilLane oil;
   if (OIL) oil.init(p, i, oa);

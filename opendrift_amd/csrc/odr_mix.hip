@@ -44,6 +44,12 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
   if (fast) {
     const int nq = (nzp + 3) / 4;
     const bool tl = D.ka != nullptr;
+    // k_vmix_win (five levels per particle in registers: cost independent of the number of reader levels) from 13 levels
+    // on, the whole-column kernel below that -- measured on MI355X, 4 M particles (tools/vmix_levels.py): 8 / 12 / 16 / 24 /
+    // 40 levels: column 0.155 / 0.176 / 0.218 / 0.327 / 1.268 ms, window 0.167 / 0.186 / 0.207 / 0.237 / 0.274 ms.
+    // ODR_VMIX_WINDOW=1 / 0 forces one of them (the parity tests compare the two).
+    const char *wenv = getenv("ODR_VMIX_WINDOW");
+    const bool win = nzp >= 3 && nzp <= BLOCK && (wenv ? atoi(wenv) != 0 : nzp > 12);
 #define VMIX_COL(NQ)                                                                                              \
   do {                                                                                                            \
     size_t l2 = sizeof(double) * ((size_t)(4 * NQ) * BLOCK + 4 * (size_t)(4 * NQ));                               \
@@ -52,8 +58,15 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
     else hipLaunchKernelGGL((k_vmix_col<NQ, false>), g, b, l2, c->stream, c->dw, v, D, dt, dt_mix,                \
                             mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);                                     \
   } while (0)
+    if (win) {
+      const size_t lw = (sizeof(double) + sizeof(unsigned)) * 4 * BLOCK + sizeof(double) * 4 * (size_t)nzp;
+      if (tl) hipLaunchKernelGGL((k_vmix_win<true>), g, b, lw, c->stream, c->dw, v, D, dt, dt_mix, mix_at_surface, rng_mode, du,
+                                 c->seed, st, vadv, c->seafloor);
+      else hipLaunchKernelGGL((k_vmix_win<false>), g, b, lw, c->stream, c->dw, v, D, dt, dt_mix, mix_at_surface, rng_mode, du,
+                              c->seed, st, vadv, c->seafloor);
+    }
     // the smallest instantiated quad count >= nq; over-read stays inside the 64-byte array padding
-    if (nq <= 1) VMIX_COL(1);
+    else if (nq <= 1) VMIX_COL(1);
     else if (nq == 2) VMIX_COL(2);
     else if (nq == 3) VMIX_COL(3);
     else if (nq == 4) VMIX_COL(4);
