@@ -1254,6 +1254,9 @@ class OpenDriftSimulation(Configurable):
         self.timing = {'main_loop_s': t_end - t_loop[0], 'steps': self.steps_calculation,
                        'collectives': self._timing_collectives, 'collective_s': self._timing_collective_s,
                        'reader_level_stall_s': sum(getattr(b, 'stall_s', 0.0) for b in self.readers.values()),
+                       # rank 0 of a sharded run: levels its worker thread had read ahead / read inline, and the time the worker spent reading
+                       'reader_thread': {k: sum(getattr(getattr(b, '_ahead', None), k, 0) for b in self.readers.values())
+                                         for k in ('hits', 'misses', 'worker_s')},
                        'steady_ms_per_step': (1e3 * (t_end - t_loop[1]) / max(1, self.steps_calculation - 1)) if t_loop[1] else None}
         self.interact_with_coastline(final=True)
         self._resolve_status()

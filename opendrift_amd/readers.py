@@ -16,6 +16,8 @@ evaluates in closed form (constant, double gyre, oscillating) are recognised by 
 """
 from datetime import datetime, timedelta
 
+import threading
+
 import numpy as np
 
 from . import projection
@@ -382,6 +384,70 @@ class ReaderLevelsError(RuntimeError):
     failure (the model's reader-failure handling must not swallow it and fall back to constants silently)."""
 
 
+_READER_IO_LOCK = threading.Lock()   # one get_variables at a time, whichever thread: netCDF / HDF5 builds are rarely thread-safe
+
+
+class ReadAhead:
+    """Rank 0 of a sharded run owns the host Reader: every time level the other ranks receive passes through ITS
+    get_variables.  Called inline it stops rank 0's step loop for the duration of the file read, and -- one collective per
+    step -- every other rank with it.  This runs the read of the level that comes NEXT on a worker thread as soon as a
+    level has been handed out; when the level is due (one period later: _prefetch_dist starts its broadcast) the block is
+    there.  The reference reads inline in its single process (basereader/structured.py:121-170); the block is the same
+    object either way.  A read-ahead for another level or window than the one asked for is waited for and dropped."""
+
+    def __init__(self, reader, variables):
+        self.reader, self.variables = reader, list(variables)
+        self._pool, self._fut, self._key = None, None, None
+        self.hits = self.misses = 0
+        self.worker_s = 0.0          # time the worker spent inside get_variables (off the step loop)
+
+    @staticmethod
+    def _key_of(k, x, y):
+        return (int(k), None if x is None else (np.asarray(x).tobytes(), np.asarray(y).tobytes()))
+
+    def _get(self, k, x, y, timed=False):
+        import time as _time
+        r = self.reader
+        t = r.times[k] if r.times is not None else None
+        t0 = _time.perf_counter()
+        with _READER_IO_LOCK:
+            block = r.get_variables(self.variables, t, x, y, np.array([0.0]))
+        if timed:
+            self.worker_s += _time.perf_counter() - t0
+        return block
+
+    def start(self, k, x, y):
+        """Begin reading level k on the worker (returns at once)."""
+        if self._fut is not None:
+            return
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='odr-reader')
+        self._key = self._key_of(k, x, y)
+        self._fut = self._pool.submit(self._get, k, x, y, True)
+
+    def read(self, k, x, y):
+        """The block of level k: the worker's if it was read ahead (its exception is raised here, where an inline read
+        would have raised it), an inline read otherwise."""
+        fut, key = self._fut, self._key
+        self._fut = self._key = None
+        if fut is not None:
+            if key == self._key_of(k, x, y):
+                self.hits += 1
+                return fut.result()
+            try:
+                fut.result()
+            except Exception:      # noqa: BLE001 -- of a level nobody asked for
+                pass
+        self.misses += 1
+        return self._get(k, x, y)
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+
+
 class DeviceReaderBinding:
     """Device image of one reader: constant/analytic source, or a grid source whose time levels
     (ReaderBlocks) are uploaded on demand.  Stands where StructuredReader keeps
@@ -400,6 +466,7 @@ class DeviceReaderBinding:
         self.rank, _, self.world = env_world()
         self.stall_s = 0.0             # host time spent waiting for a level that was due (run().timing reports the sum)
         self._dist_pre = {}            # sharded run: time index -> (tensors, works) of a level whose broadcast is under way
+        self._ahead, self._ahead_last = None, None   # sharded run, rank 0: the next level read on a worker thread (ReadAhead)
         kind = getattr(reader, 'device_kind', None)
         # a ContinuousReader the device has no closed form for (a user's analytic or point-wise reader,
         # basereader/continuous.py:20-46): evaluated on the host at the element positions, values uploaded
@@ -603,8 +670,15 @@ class DeviceReaderBinding:
         block, err, cids = None, None, None
         if self.rank == 0:
             try:
-                block = r.get_variables(self.variables, time, x, y, np.array([0.0]))
+                if self._ahead is None:
+                    self._ahead = ReadAhead(r, self.variables)
+                block = self._ahead.read(k, x, y)
                 cids = self._static_ids()
+                # the level after this one, on the worker thread, while the steps of this period run
+                kn = k + (1 if self._ahead_last is None or k >= self._ahead_last else -1)
+                self._ahead_last = k
+                if self.prefetch and r.times is not None and 0 <= kn < len(r.times):
+                    self._ahead.start(kn, x, y)
             except Exception as e:      # noqa: BLE001 -- every reader exception is a reader failure (environment.py:640-668)
                 err = e
         shapes = getattr(self, '_dist_shapes', None)
