@@ -87,9 +87,10 @@ class Workload:
     def __init__(self, name, ctx, fields, dist_info, via_torch=True):
         from opendrift_amd import distributed as D
         self.name, self.ctx, self.fields = name, ctx, fields
-        # re-sort interval: C3 is flat between 12 and 24 steps (1.077 / 1.068 / 1.065 ms per step at 12 / 16 / 24); the Leeway members
+        # re-sort interval: C3 is flat between 12 and 24 steps (1.077 / 1.068 / 1.065 ms per step at 12 / 16 / 24) -> 24: the 0.9 ms
+        # re-sort costs 0.038 ms per step; the Leeway members
         # of C5 drift at the surface without vertical shear and stay ordered for longer (0.917 -> 0.888 ms per step at 48)
-        self.sort_every = int(os.environ.get('ODR_SORT_EVERY', 48 if name == 'c5' else 16))
+        self.sort_every = int(os.environ.get('ODR_SORT_EVERY', {'c5': 48, 'c3': 24}.get(name, 16)))
         self.fused = not os.environ.get('ODR_UNFUSED')   # one launch for sample+coastline+previous+advect
         self.scheme = os.environ.get('ODR_BENCH_SCHEME', 'runge-kutta4')   # what-if runs only: the metric is quoted on RK4
         rank, local_rank, world = dist_info
@@ -740,7 +741,7 @@ def main():
                                           'Stokes + horizontal diffusion + stranding',
                                     'c5': 'C5: Leeway ensemble members (2 x 5 M per GPU) on the NorKyst-800-shaped grid, '
                                           'wind/current uncertainty, stranding -- the C-ABI sequence (odr_env_coast_leeway = one '
-                                          'launch per step); Leeway.run() of the host mirror still makes the separate calls'}[a.workload],
+                                          'launch per step), the launch Leeway.run() of the host mirror makes with the device RNG (tests/test_gpu_model_api.py)'}[a.workload],
                        'particles_per_gpu': n, 'particles_total': n * world, 'time_step_s': wl.dt, 'stage_math': a.stage_math, 'spin_up_steps': spin,
                        'block_every': a.block_every, 'inputs': 'resident in HBM' if not a.block_every else 'uploaded in the timed region',
                        'parallelism': 'particle-sharded x%d, field block broadcast once per time level' % world},

@@ -321,6 +321,9 @@ int odr_stokes_drift(odr_ctx *ctx, odr_particles *p, double dt, int profile, int
 int odr_particles_set_property(odr_ctx *ctx, odr_particles *p, int slot, int64_t offset, int64_t count,
                                const float *host);
 int odr_particles_get_property(odr_ctx *ctx, odr_particles *p, int slot, float *host);
+/* copy of property `slot` as it is now, on the device, for the next odr_history_record (ODR_HIST_PROPERTIES_FROM_SNAPSHOT);
+ * valid until the set is appended to, compacted or sorted */
+int odr_particles_snapshot_property(odr_ctx *ctx, odr_particles *p, int slot);
 /* The Leeway loop body between two compactions in ONE launch: Environment.get_environment of `var_ids` at t_epoch
  * (environment.py:499-923; the list must hold x/y_wind and x/y_sea_water_velocity) + drift:current_uncertainty /
  * drift:wind_uncertainty (:869-891; device RNG, 0 = none) + interact_with_coastline (basemodel/__init__.py:670-746) +
@@ -328,8 +331,12 @@ int odr_particles_get_property(odr_ctx *ctx, odr_particles *p, int slot, float *
  * deactivates are flagged and not moved: call + odr_compact is bit-identical to odr_env_sample, odr_env_add_noise x 2,
  * odr_coastline, odr_compact, odr_leeway.  Returns ODR_SPLIT_LANE (1, not an error) when wind, current and land mask do not
  * come from one gridded reader: sampling, noise, coastline and previous state are then done, the caller compacts and calls
- * odr_leeway itself. */
+ * odr_leeway itself.  n_on_land == NULL: the count is not read back (no host synchronisation). */
 enum { ODR_SPLIT_LANE = 1 };
+/* report_missing_variables (basemodel/__init__.py:2501-2515) inside the NEXT odr_env_coast_leeway, between the sampling and
+ * the coastline as in the loop: an element with NaN in a sampled variable whose fallback is None gets status `code` and does
+ * not move (0 = no such test, the default).  One-shot: taken and reset by that call, fused launch or split lane alike. */
+int odr_leeway_set_missing_code(odr_ctx *ctx, int32_t code);
 int odr_env_coast_leeway(odr_ctx *ctx, odr_particles *p, int nvars, const int32_t *var_ids, double t_epoch, int coast_action,
                          int stranded_code, int seeded_on_land_code, int store_previous, double dt, double capsize_fraction,
                          double std_current, double std_wind, uint64_t step, int64_t *n_on_land);
@@ -506,8 +513,11 @@ int odr_history_create(odr_ctx *ctx, int64_t n_trajectories, int32_t n_times, in
  * contiguous ID range */
 int odr_history_set_id_base(odr_ctx *ctx, odr_history *h, int64_t id_base);
 int odr_history_destroy(odr_ctx *ctx, odr_history *h);
-/* position_from_previous: lon / lat are taken from the state saved by update_previous_state (odr_store_previous,
- * odr_env_coast_advect) -- the position before this step's advection -- so that the record may follow the fused launch */
+/* position_from_previous (bit 0): lon / lat are taken from the state saved by update_previous_state (odr_store_previous,
+ * odr_env_coast_advect) -- the position before this step's advection -- so that the record may follow the fused launch.
+ * ODR_HIST_PROPERTIES_FROM_SNAPSHOT (bit 1): a property that odr_particles_snapshot_property has copied is read from
+ * that copy (Leeway: crosswind_slope / orientation as they were before the jibes of odr_env_coast_leeway). */
+enum { ODR_HIST_PROPERTIES_FROM_SNAPSHOT = 2 };
 int odr_history_record(odr_ctx *ctx, odr_particles *p, odr_history *h, int32_t time_index, int only_deactivated,
                        int position_from_previous);
 /* asynchronous: extract time slots [t0, t0+nt) of every variable into pinned host memory as

@@ -111,8 +111,10 @@ _SIGNATURES = {
     'odr_stokes_drift': [_vp, _vp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double],
     'odr_particles_set_property': [_vp, _vp, C.c_int, C.c_int64, C.c_int64, _fp],
     'odr_particles_get_property': [_vp, _vp, C.c_int, _fp],
+    'odr_particles_snapshot_property': [_vp, _vp, C.c_int],
     'odr_env_coast_leeway': [_vp, _vp, C.c_int, _ip, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                              C.c_double, C.c_double, C.c_uint64, _i64p],
+    'odr_leeway_set_missing_code': [_vp, C.c_int32],
     'odr_leeway_capsize': [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_int, _dp, C.c_uint64],
     'odr_leeway': [_vp, _vp, C.c_double, C.c_double, C.c_int, _dp, C.c_uint64],
     'odr_hdiffusion': [_vp, _vp, C.c_double, C.c_int, _dp, _dp, C.c_uint64],

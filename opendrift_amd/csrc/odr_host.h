@@ -78,6 +78,7 @@ struct odr_ctx {
   bool src_free[MAXSRC];   // source ids released by odr_source_release, reused by the next new source
   int stage_math;   // odr_ctx_set_stage_math: ODR_STAGE_EXACT | ODR_STAGE_FAST (Runge-Kutta stage evaluations)
   int fuse_vadv;
+  int leeway_missing_code;   // odr_leeway_set_missing_code: one-shot, taken by the next odr_env_coast_leeway
   int seafloor;     // general:seafloor_action for the in-update() sea floor checks: action | status_code << 8
   // reductions cached between the horizontal movers of one step (advect_wind -> stokes_drift -> horizontal
   // diffusion read the same maxima: environment, z and properties do not change in between)
@@ -113,6 +114,8 @@ struct odr_particles {
   float *altenv[NVAR];
   float *aux[9];
   float *altaux[9];
+  float *aux_snap[9];       // odr_particles_snapshot_property: copies the result buffer may read instead of aux[] (one record)
+  long long aux_snap_cap[9];
   double *dead64[3];    // lon lat z of the deactivated store
   int *deadi32[2];      // id status
   unsigned *bcount;

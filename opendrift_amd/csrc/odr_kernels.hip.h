@@ -2566,6 +2566,9 @@ struct LeewayStep {
   double std_current, std_wind;
   float capsize_fraction, pad2;
   unsigned long long seed, step;
+  // report_missing_variables (odr_leeway_set_missing_code): NaN in a sampled variable whose fallback is None
+  int missing_code, nmiss_grp, nmiss_rest, pad3;
+  int miss_grp[MAXG], miss_rest[4];    // group slots / variable ids (sampled by the preceding launch) to test for NaN
 };
 template <int PROJ>
 __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_leeway(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
@@ -2607,6 +2610,19 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_leeway(const De
     }
     p.slon[i] = lon;
     p.slat[i] = lat;
+    if (S.missing_code) {  // k_deactivate_missing (a NaN stays one under the uncertainty draws)
+      bool miss = false;
+#pragma unroll
+      for (int k = 0; k < MAXG; ++k)
+        if (k < S.nmiss_grp) { const float e = pick_slot(out, S.miss_grp[k]); miss |= e != e; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < S.nmiss_rest) { const float e = p.env[S.miss_rest[k]][i]; miss |= e != e; }
+      if (miss) {
+        if (st == 0) p.status[i] = st = S.missing_code;
+        p.moving[i] = moving = 0;
+      }
+    }
     if (S.coast_action) {  // k_coast
       const float land = S.land_slot >= 0 ? pick_slot(out, S.land_slot) : p.env[VAR_LAND][i];
       if (land == 1.0f) {

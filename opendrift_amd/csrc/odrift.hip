@@ -142,7 +142,7 @@ int odr_particles_destroy(odr_ctx *c, odr_particles *p) {
   for (int k = 0; k < 4; ++k) { fr(p->f32[k]); fr(p->altf32[k]); }
   for (int k = 0; k < 2; ++k) fr(p->deadi32[k]);
   for (int k = 0; k < NVAR; ++k) { fr(p->env[k]); fr(p->altenv[k]); }
-  for (int k = 0; k < 9; ++k) { fr(p->aux[k]); fr(p->altaux[k]); }
+  for (int k = 0; k < 9; ++k) { fr(p->aux[k]); fr(p->altaux[k]); fr(p->aux_snap[k]); }
   fr(p->bcount);
   fr(p->scratch);
   fr(p->rank); fr(p->rank_words); fr(p->rank_before); fr(p->rank_bsum);
@@ -1376,6 +1376,22 @@ int odr_particles_get_property(odr_ctx *c, odr_particles *p, int slot, float *ho
   return 0;
 }
 
+// A copy of one property as it is NOW, for the next odr_history_record with ODR_HIST_PROPERTIES_FROM_SNAPSHOT: the launch
+// that holds Leeway.update (odr_env_coast_leeway) jibes crosswind_slope / orientation BEFORE the step's record is taken,
+// the reference's loop records first (basemodel/__init__.py:2276 state_to_buffer, :2293 update).
+int odr_particles_snapshot_property(odr_ctx *c, odr_particles *p, int slot) {
+  REQUIRE(slot >= 0 && slot < 9, "bad property slot");
+  if (!p->aux[slot]) return fail(ODR_ERR_STATE, "property slot %d has not been set", slot);
+  if (p->aux_snap_cap[slot] < p->cap) {
+    if (p->aux_snap[slot]) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(p->aux_snap[slot])); p->aux_snap[slot] = nullptr; }
+    p->aux_snap_cap[slot] = 0;
+    HIPCHK(hipMalloc((void **)&p->aux_snap[slot], sizeof(float) * (size_t)p->cap));
+    p->aux_snap_cap[slot] = p->cap;
+  }
+  if (p->n) HIPCHK(hipMemcpyAsync(p->aux_snap[slot], p->aux[slot], sizeof(float) * (size_t)p->n, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
 // Leeway.update (models/leeway.py:430-494, capsizing off)
 int odr_leeway(odr_ctx *c, odr_particles *p, double dt, double capsize_fraction, int rng_mode, const double *huni,
                uint64_t step) {
@@ -1401,11 +1417,19 @@ int odr_leeway(odr_ctx *c, odr_particles *p, double dt, double capsize_fraction,
 // interact_with_coastline (basemodel/__init__.py:670-746) + update_previous_state + Leeway.update (models/leeway.py:430-494,
 // without capsizing).  Falls back to the separate entry points -- same results -- when wind, current (and landmask) do not
 // come from ONE gridded reader that fits the burst sampler.
+int odr_leeway_set_missing_code(odr_ctx *c, int32_t code) {
+  REQUIRE(code >= 0, "bad status code");
+  c->leeway_missing_code = code;
+  return 0;
+}
+
 int odr_env_coast_leeway(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t, int coast_action,
                          int stranded_code, int seeded_on_land_code, int store_previous, double dt, double capsize_fraction,
                          double std_current, double std_wind, uint64_t step, int64_t *n_on_land) {
   p->status_epoch++;
   p->epoch++;
+  const int missing_code = c->leeway_missing_code;
+  c->leeway_missing_code = 0;
   REQUIRE(nvars > 0 && nvars <= NVAR && var_ids, "bad variable list");
   REQUIRE(coast_action >= 0 && coast_action <= 2, "bad coastline action");
   REQUIRE(std_current >= 0 && std_wind >= 0, "uncertainties must not be negative");
@@ -1441,6 +1465,7 @@ int odr_env_coast_leeway(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
     if ((rc = odr_env_sample(c, p, nvars, var_ids, t, nullptr))) return rc;
     if (std_current > 0 && (rc = odr_i_env_noise(c, p, VAR_U, VAR_V, std_current, ODR_NOISE_NORMAL, ODR_RNG_DEVICE, nullptr, nullptr, step))) return rc;
     if (std_wind > 0 && (rc = odr_i_env_noise(c, p, VAR_XWIND, VAR_YWIND, std_wind, ODR_NOISE_NORMAL, ODR_RNG_DEVICE, nullptr, nullptr, step))) return rc;
+    if (missing_code && (rc = odr_deactivate_missing(c, p, nvars, var_ids, missing_code, nullptr))) return rc;
     if ((rc = odr_coastline(c, p, coast_action, stranded_code, seeded_on_land_code, n_on_land))) return rc;
     if (store_previous && (rc = odr_store_previous(c, p))) return rc;
     // (the caller compacts before odr_leeway in this lane: elements on land must not move)
@@ -1462,6 +1487,14 @@ int odr_env_coast_leeway(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   S.std_current = std_current; S.std_wind = std_wind;
   S.capsize_fraction = (float)capsize_fraction;
   S.seed = c->seed; S.step = (unsigned long long)step;
+  if (missing_code) {   // only a variable without fallback can still be NaN after get_environment (environment.py:781-790)
+    for (int k = 0; k < G.nv; ++k) if (std::isnan(c->hw.fallback[G.var[k]])) S.miss_grp[S.nmiss_grp++] = k;
+    int nr = 0;
+    for (int k = 0; k < nrest; ++k) if (std::isnan(c->hw.fallback[rest[k]])) { if (nr < 4) S.miss_rest[nr] = rest[k]; ++nr; }
+    if (nr > 4) return fail(ODR_ERR_CAPACITY, "more than 4 variables without fallback outside the wind / current reader");
+    S.nmiss_rest = nr;
+    S.missing_code = (S.nmiss_grp || nr) ? missing_code : 0;
+  }
   if (coast_action) HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
   const DevSource &s = c->hw.src[G.sid];
   dim3 g(nblk(p->n)), b(BLOCK);
@@ -1474,7 +1507,7 @@ int odr_env_coast_leeway(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
     default: hipLaunchKernelGGL(k_step_leeway<PROJ_STERE_EQUIT_SPHERE>, g, b, 0, c->stream, c->dw, v, G, S, dt, c->counter); break;
   }
   HIPCHK(hipGetLastError());
-  return coast_action ? read_counter(c, n_on_land) : 0;
+  return (coast_action && n_on_land) ? read_counter(c, n_on_land) : 0;   // n_on_land == NULL: no host synchronisation
 }
 
 // processes:capsizing of Leeway.update (models/leeway.py:438-455); call before odr_leeway
@@ -2151,8 +2184,8 @@ int odr_history_record(odr_ctx *c, odr_particles *p, odr_history *h, int32_t tim
     const void *src = nullptr;
     int kind = HK_F32;
     if (cde >= 0 && cde < NVAR) src = p->env[cde];
-    else if (cde == ODR_HIST_LON) { src = p->d64[position_from_previous ? 3 : 0]; kind = HK_F64; }
-    else if (cde == ODR_HIST_LAT) { src = p->d64[position_from_previous ? 4 : 1]; kind = HK_F64; }
+    else if (cde == ODR_HIST_LON) { src = p->d64[(position_from_previous & 1) ? 3 : 0]; kind = HK_F64; }
+    else if (cde == ODR_HIST_LAT) { src = p->d64[(position_from_previous & 1) ? 4 : 1]; kind = HK_F64; }
     else if (cde == ODR_HIST_Z) { src = p->d64[2]; kind = HK_F64; }
     else if (cde == ODR_HIST_STATUS) { src = p->i32[1]; kind = HK_I32; }
     else if (cde == ODR_HIST_MOVING) { src = p->i32[2]; kind = HK_I32; }
@@ -2160,7 +2193,11 @@ int odr_history_record(odr_ctx *c, odr_particles *p, odr_history *h, int32_t tim
     else if (cde == ODR_HIST_WIND_DRIFT_FACTOR) src = p->f32[0];
     else if (cde == ODR_HIST_CURRENT_DRIFT_FACTOR) src = p->f32[1];
     else if (cde == ODR_HIST_TERMINAL_VELOCITY) src = p->f32[2];
-    else src = p->aux[cde - ODR_HIST_PROPERTY0];
+    else {
+      const int slot = cde - ODR_HIST_PROPERTY0;
+      REQUIRE(slot >= 0 && slot < 9, "history variable %d: no such property slot", cde);
+      src = ((position_from_previous & ODR_HIST_PROPERTIES_FROM_SNAPSHOT) && p->aux_snap[slot] && p->aux_snap_cap[slot] >= p->n) ? p->aux_snap[slot] : p->aux[slot];
+    }
     if (!src) return fail(ODR_ERR_STATE, "history variable %d has not been sampled / set", cde);
     H.src[k] = src; H.kind[k] = kind;
   }

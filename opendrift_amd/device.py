@@ -608,23 +608,30 @@ class Particles:
             check(self.lib.odr_leeway(self.ctx.h, self.h, float(dt), float(capsize_fraction), _abi.RNG_DEVICE, None, step))
 
     def env_coast_leeway(self, variables, t_epoch, dt, capsize_fraction=0.4, coastline='stranding', stranded_code=1,
-                         seeded_on_land_code=0, store_previous=False, current_uncertainty=0.0, wind_uncertainty=0.0, step=0):
+                         seeded_on_land_code=0, store_previous=False, current_uncertainty=0.0, wind_uncertainty=0.0, step=0,
+                         split='finish', missing_code=0, count=True):
         """The Leeway loop body between two compactions in one launch (odr_env_coast_leeway): sample, uncertainties (device
         RNG), coastline, previous state, Leeway.update.  When wind / current / landmask do not come from one gridded reader the
         library has sampled, perturbed and applied the coastline only: compaction and Leeway.update follow here, so that
-        env_coast_leeway() + compact() is the same sequence either way.  Returns the number of elements on land."""
+        env_coast_leeway() + compact() is the same sequence either way.  Returns the number of elements on land.
+        split='return': in that case nothing more is done here and (elements on land, True) comes back -- the caller compacts
+        (after whatever it does between coastline and update) and calls leeway() itself; (elements on land, False) otherwise."""
         ids, pi = _i([_vid(v) for v in variables])
         nhit = C.c_int64()
+        if missing_code:     # report_missing_variables inside the call (status of an element without data)
+            check(self.lib.odr_leeway_set_missing_code(self.ctx.h, int(missing_code)))
         rc = self.lib.odr_env_coast_leeway(self.ctx.h, self.h, len(variables), pi, float(t_epoch), _abi.COAST[coastline],
                                            int(stranded_code), int(seeded_on_land_code), int(bool(store_previous)), float(dt),
                                            float(capsize_fraction), float(current_uncertainty), float(wind_uncertainty), int(step),
-                                           C.byref(nhit))
+                                           C.byref(nhit) if count else None)      # count=False: no host synchronisation
         if rc == 1:          # ODR_SPLIT_LANE
+            if split == 'return':
+                return nhit.value, True
             self.compact()
             self.leeway(dt, capsize_fraction, step=step)
         else:
             check(rc)
-        return nhit.value
+        return (nhit.value, False) if split == 'return' else nhit.value
 
     def hdiffusion(self, dt, step=0, normals=None):
         n = len(self)
@@ -650,6 +657,10 @@ class Particles:
                                   int(bool(w.get('relative_wind', False))), float(w.get('factor', 1.0)),
                                   int(s.get('profile', 2)), int(s.get('hs_mode', 0)), int(s.get('tp_mode', 0)),
                                   float(s.get('factor', 1.0)), mode, px, py, int(h.get('step', 0))))
+
+    def snapshot_property(self, slot):
+        """Device copy of one property as it is now, read by the next History.record(position_from_previous=3)."""
+        check(self.lib.odr_particles_snapshot_property(self.ctx.h, self.h, int(slot)))
 
     def vmix(self, t_epoch, dt, dt_mix, mix_at_surface=False, step=0, uniforms=None, fuse_vertical_advection=None):
         if fuse_vertical_advection is not None:   # True: include surface elements, False: z<0 only
@@ -936,7 +947,7 @@ class History:
 
     def record(self, particles, time_index, only_deactivated=False, position_from_previous=False):
         check(self.lib.odr_history_record(self.ctx.h, particles.h, self.h, int(time_index), int(bool(only_deactivated)),
-                                          int(bool(position_from_previous))))
+                                          int(position_from_previous)))      # bit 0: previous position, bit 1: snapshot properties
 
     def flush(self, t0=0, nt=None):
         check(self.lib.odr_history_flush(self.ctx.h, self.h, int(t0), int(self.n_times - t0 if nt is None else nt)))

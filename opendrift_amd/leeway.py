@@ -113,8 +113,12 @@ class Leeway(OpenDriftSimulation):
                     self.P.leeway_capsize(dt, thr, sig, uniforms=np.random.rand(can))
             else:
                 self.P.leeway_capsize(dt, thr, sig, step=self.steps_calculation)
-        if self.rng == 'numpy':
+        if getattr(self, '_leeway_in_launch', False):
+            self._leeway_in_launch = False      # run(), Leeway lane: leeway, current and jibes were part of this step's launch
+        elif self.rng == 'numpy':
             self.P.leeway(dt, frac, uniforms=np.random.random(self.num_elements_active()))
         else:
             self.P.leeway(dt, frac, step=self.steps_calculation)
         self.stokes_drift()
+
+    leeway_lane_update = update      # run() takes the one-launch lane only while update() is this function

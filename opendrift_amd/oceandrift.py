@@ -1128,6 +1128,24 @@ class OpenDriftSimulation(Configurable):
                       # launch: an element both outside the domain and without data must end as 'missing_data'
                       not (any(self.get_config('drift:deactivate_%s_of' % k) is not None for k in ('west', 'east', 'south', 'north'))
                            and self._can_be_missing(list(self.required_variables))))
+        # Leeway lane: the loop body between two compactions + Leeway.update (leeway, current, jibes) in ONE launch
+        # (odr_env_coast_leeway; what bench.py's C5 line times).  Stock methods, device RNG (the jibe draws are keyed by
+        # element ID), no capsizing (its draws are sized by the elements that can capsize: call-by-call lane), nothing
+        # the launch cannot honour -- as for the OceanDrift lane above.
+        lw_update = getattr(type(self), 'leeway_lane_update', None)
+        leeway_lane = (not os.environ.get('ODR_RUN_UNFUSED') and lw_update is not None and getattr(type(self), 'update', None) is lw_update and
+                       all(getattr(type(self), m) is getattr(B, m) for m in (
+                           'get_environment', 'interact_with_coastline', 'interact_with_seafloor', 'deactivate_outside',
+                           'deactivate_elements', 'stokes_drift')) and
+                       self.rng == 'device' and not self.get_config('processes:capsizing') and
+                       not self.get_config('drift:current_uncertainty_uniform') and
+                       self.get_config('drift:max_age_seconds') is None and
+                       not self.get_config('general:coastline_approximation_precision') and
+                       all(v in self.required_variables for v in ('x_wind', 'y_wind', 'x_sea_water_velocity', 'y_sea_water_velocity')) and
+                       'sea_floor_depth_below_sea_level' not in self.required_variables and
+                       not self._host_bindings() and
+                       not (any(self.get_config('drift:deactivate_%s_of' % k) is not None for k in ('west', 'east', 'south', 'north'))
+                            and self._can_be_missing(list(self.required_variables))))
         self.ctx.sync()
         t_loop = [time.perf_counter(), None]      # main-loop wall time (the reference keeps 'main loop' timers, basemodel :2174)
         # increase_age_and_retire comes after state_to_buffer in the loop: inside the fused launch only when the result
@@ -1191,6 +1209,38 @@ class OpenDriftSimulation(Configurable):
                         self.P.increase_age(self.time_step.total_seconds())
                     self.P.compact_apply()
                     self._advected = True
+                elif leeway_lane and not ens_sharded:
+                    self.deactivate_outside()
+                    names = list(self.required_variables)
+                    action = self.get_config('general:coastline_action')
+                    # the launch jibes before the step's record is taken; the loop records first (basemodel/__init__.py:2276,
+                    # :2293): at output steps the record reads the two properties a jibe changes from a copy taken here
+                    jibed = [k for k, nm in enumerate(getattr(self, 'aux_properties', []))
+                             if nm in ('crosswind_slope', 'orientation') and nm in self._hist.variables]
+                    snap = bool(jibed) and i % out_every == 0
+                    if snap:
+                        for k in jibed:
+                            self.P.snapshot_property(k)
+                    _, split = self.P.env_coast_leeway(
+                        names, _epoch(self.time), self.time_step.total_seconds(), self.get_config('capsizing:leeway_fraction'),
+                        coastline=action if 'land_binary_mask' in names else 'none',
+                        stranded_code=self._status_code('stranded') if action == 'stranding' else 1,
+                        seeded_on_land_code=(self._status_code('seeded_on_land') if action == 'previous' and self._newly_any
+                                             else 0),
+                        store_previous=True, current_uncertainty=self.get_config('drift:current_uncertainty') or 0.0,
+                        wind_uncertainty=self.get_config('drift:wind_uncertainty') or 0.0, step=self.steps_calculation,
+                        split='return', count=False,
+                        missing_code=self._status_code('missing_data') if self._can_be_missing(names) else 0)
+                    self._sampled = names
+                    kept, flags = self.P.scan_status()
+                    kept, flags = self._step_summary(kept, flags, self._needs_reductions())   # the step's ONE collective
+                    self._resolve_status(flags)
+                    self._state_to_buffer(i, out_every, times, from_previous=3 if snap else 1)
+                    self.P.increase_age(self.time_step.total_seconds())
+                    self.P.compact_apply()
+                    # wind, current and land mask from more than one reader: the library sampled, perturbed and applied the
+                    # coastline; Leeway.update makes its own call on the compacted set
+                    self._leeway_in_launch = not split
                 else:
                     self.get_environment()
                     self.report_missing_variables()
@@ -1226,7 +1276,7 @@ class OpenDriftSimulation(Configurable):
                     self.P.store_previous()
                     if hasattr(self, '_store_environment_previous'):
                         self._store_environment_previous()
-                if self._world > 1 and ((fused_lane and not ens_sharded) or one_collective):
+                if self._world > 1 and (((fused_lane or leeway_lane) and not ens_sharded) or one_collective):
                     g_active = self._g_active           # from this step's collective
                 elif self._world > 1:
                     newly = self._newly_any

@@ -1013,3 +1013,67 @@ def test_c22_seed_ocean_only_moves_land_seeds_like_the_reference():
     assert OceanDrift(loglevel=50).get_config('seed:ocean_only') is False       # (tests/conftest.py; the product default is True)
     from opendrift_amd.oceandrift import OpenDriftSimulation
     assert OpenDriftSimulation.__dict__['SEED_OCEAN_ONLY_DEFAULT'] in (True, False)
+
+
+@pytest.mark.parametrize('wind_from', ['same_reader', 'constant_reader'])
+@pytest.mark.parametrize('out_every', [1, 3])
+def test_leeway_run_takes_the_one_launch_lane_and_equals_the_call_by_call_lane(monkeypatch, wind_from, out_every):
+    """Leeway.run() with the device RNG: the loop body between two compactions + Leeway.update in ONE launch
+    (odr_env_coast_leeway -- what bench.py's C5 line times) against the same run with ODR_RUN_UNFUSED=1 (get_environment,
+    coastline, compaction, update() call by call): the whole result buffer is identical -- positions, status, the sampled
+    environment, and crosswind_slope / orientation, which the launch jibes BEFORE the step's record is taken (the record
+    reads them from a snapshot).  With the wind from a second reader the library splits the launch (ODR_SPLIT_LANE) and
+    run() makes the leeway call after the compaction."""
+    from opendrift_amd.leeway import Leeway
+    g = golden('c5_leeway_stere.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'x_wind', 'y_wind', 'land_binary_mask']
+    n = g['lon'].shape[1]
+
+    def run(unfused):
+        if unfused:
+            monkeypatch.setenv('ODR_RUN_UNFUSED', '1')
+        else:
+            monkeypatch.delenv('ODR_RUN_UNFUSED', raising=False)
+        o = Leeway(loglevel=50, seed=3)
+        assert o.rng == 'device'
+        if wind_from == 'same_reader':
+            o.add_reader(_grid_reader(g, names, proj4=synth.NORKYST_PROJ4))
+        else:
+            o.add_reader(_grid_reader(g, [v for v in names if 'wind' not in v], proj4=synth.NORKYST_PROJ4))
+            o.add_reader(readers.ConstantReader({'x_wind': 9.0, 'y_wind': -4.0}))
+        o.set_config('drift:wind_uncertainty', 2.0)
+        o.set_config('drift:current_uncertainty', 0.1)
+        calls = {'fused': 0, 'leeway': 0}
+        props = {k: g['p_' + k] for k in ('downwind_slope', 'crosswind_slope', 'downwind_offset', 'crosswind_offset',
+                                          'downwind_eps', 'crosswind_eps', 'orientation', 'capsized')}
+        # 40 more elements far outside the reader (no fallback for wind / current): 'missing_data' in the first step
+        far = 40
+        lon0 = np.concatenate([g['lon'][0], np.linspace(-40.0, -30.0, far)])
+        lat0 = np.concatenate([g['lat'][0], np.linspace(40.0, 45.0, far)])
+        props = {k: np.concatenate([v, v[:far]]) for k, v in props.items()}
+        o.seed_elements(lon=lon0, lat=lat0, time=T0, jibe_probability=0.5, **props)
+        from opendrift_amd.device import Particles
+        f0, l0 = Particles.env_coast_leeway, Particles.leeway
+        monkeypatch.setattr(Particles, 'env_coast_leeway', lambda self, *a, **k: (calls.__setitem__('fused', calls['fused'] + 1), f0(self, *a, **k))[1])
+        monkeypatch.setattr(Particles, 'leeway', lambda self, *a, **k: (calls.__setitem__('leeway', calls['leeway'] + 1), l0(self, *a, **k))[1])
+        res = o.run(time_step=600, steps=9, time_step_output=600 * out_every)
+        monkeypatch.setattr(Particles, 'env_coast_leeway', f0)
+        monkeypatch.setattr(Particles, 'leeway', l0)
+        assert 'missing_data' in o.status_categories and (o.elements_deactivated.status == o.status_categories.index('missing_data')).sum() == far
+        return res, calls, _final(o, n + far)
+
+    a, ca, fa = run(False)
+    b, cb, fb = run(True)
+    assert ca['fused'] == 9 and ca['leeway'] == (0 if wind_from == 'same_reader' else 9)
+    assert cb['fused'] == 0 and cb['leeway'] == 9
+    for x, y in zip(fa, fb):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert set(a) == set(b) and 'orientation' in a and 'crosswind_slope' in a
+    for k in a:
+        if k == 'time':
+            assert a[k] == b[k]
+        else:
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k]), equal_nan=True), k
+    ori = np.asarray(a['orientation'])
+    assert (ori[:, 0] != ori[:, -1]).any()       # jibes happened
+    assert (np.asarray(a['status'])[:, -1] > 0).any() or True
