@@ -258,12 +258,79 @@ class OscillatingReader(ContinuousReader):
                 self.variables[0]: self.amplitude * np.sin(phase) * np.ones(np.shape(x))}
 
 
+# the x / y components the reference rotates from the reader's axes to east / north (basereader/consts.py:27-36)
+VECTOR_PAIRS_XY = [('x_wind', 'y_wind'), ('sea_ice_x_velocity', 'sea_ice_y_velocity'),
+                   ('x_sea_water_velocity', 'y_sea_water_velocity'),
+                   ('sea_surface_wave_stokes_drift_x_velocity', 'sea_surface_wave_stokes_drift_y_velocity')]
+
+
+def wgs84_forward_azimuth(lon1, lat1, lon2, lat2):
+    """Azimuth (degrees clockwise from north) at point 1 of the WGS84 geodesic to point 2 -- what pyproj.Geod(ellps='WGS84')
+    .inv(...)[0] gives the reference in rotate_vectors (variables.py:94-97) -- by Vincenty's inverse iteration (short lines
+    between neighbouring grid nodes: converges in a few rounds)."""
+    a, f = 6378137.0, 1 / 298.257223563
+    b = (1 - f) * a
+    L = np.radians(np.asarray(lon2, dtype=np.float64) - np.asarray(lon1, dtype=np.float64))
+    L = (L + np.pi) % (2 * np.pi) - np.pi
+    U1 = np.arctan((1 - f) * np.tan(np.radians(np.asarray(lat1, dtype=np.float64))))
+    U2 = np.arctan((1 - f) * np.tan(np.radians(np.asarray(lat2, dtype=np.float64))))
+    sU1, cU1, sU2, cU2 = np.sin(U1), np.cos(U1), np.sin(U2), np.cos(U2)
+    lam = L.copy()
+    for _ in range(30):
+        sl, cl = np.sin(lam), np.cos(lam)
+        ss = np.hypot(cU2 * sl, cU1 * sU2 - sU1 * cU2 * cl)
+        cs = sU1 * sU2 + cU1 * cU2 * cl
+        sig = np.arctan2(ss, cs)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            sa = np.where(ss > 0, cU1 * cU2 * sl / ss, 0.0)
+            c2a = 1 - sa * sa
+            c2m = np.where(c2a > 0, cs - 2 * sU1 * sU2 / c2a, 0.0)
+        Cc = f / 16 * c2a * (4 + f * (4 - 3 * c2a))
+        new = L + (1 - Cc) * f * sa * (sig + Cc * ss * (c2m + Cc * cs * (-1 + 2 * c2m * c2m)))
+        done = np.max(np.abs(new - lam)) < 1e-14
+        lam = new
+        if done:
+            break
+    return np.degrees(np.arctan2(cU2 * np.sin(lam), cU1 * sU2 - sU1 * cU2 * np.cos(lam)))
+
+
+def node_y_azimuth(lon2d, lat2d):
+    """Azimuth of the mesh's +y direction at every node: from the node to its neighbour one row up (the last row: the
+    arrival azimuth of the line from the row below), on WGS84."""
+    lon2d, lat2d = np.asarray(lon2d, dtype=np.float64), np.asarray(lat2d, dtype=np.float64)
+    az = np.empty(lon2d.shape)
+    az[:-1] = wgs84_forward_azimuth(lon2d[:-1], lat2d[:-1], lon2d[1:], lat2d[1:])
+    az[-1] = (wgs84_forward_azimuth(lon2d[-1], lat2d[-1], lon2d[-2], lat2d[-2]) + 180.0 + 180.0) % 360.0 - 180.0
+    return az
+
+
 class GridReader(StructuredReader):
     """In-memory StructuredReader with time levels and optional z levels (the shape of
     reader_constant_2d.py:20-49 / reader_netCDF_CF_generic / reader_ROMS_native output blocks).
-    arrays: {variable: [nt, ny, nx] or [nt, nz, ny, nx], or a list of such arrays = ensemble members}."""
+    arrays: {variable: [nt, ny, nx] or [nt, nz, ny, nx], or a list of such arrays = ensemble members}.
 
-    def __init__(self, x, y, times, arrays, z=None, proj4='+proj=latlong', name='grid_reader'):
+    A projection the device has no closed form for (rotated pole `ob_tran`, utm, laea, ... -- the reference hands any proj4
+    to pyproj, variables.py:111-143): give the 2-D node coordinates `lon`, `lat` that such files carry.  The reader is then
+    served like one WITHOUT projection (structured.py:44-113): positions through the node-array lookup on the device
+    (odr_source_grid_curvilinear), and the vector pairs of every block rotated to east / north at the nodes by the azimuth
+    of the mesh's y axis (rotate_vectors, variables.py:59-108, does it after the interpolation, at the element: the
+    difference is second order in the turn of the axes across one cell -- DESIGN.md 9)."""
+
+    def __new__(cls, x, y, times, arrays, z=None, proj4='+proj=latlong', name='grid_reader', lon=None, lat=None):
+        if cls is GridReader and proj4 is not None:
+            try:
+                projection.parse_proj4(proj4)
+            except NotImplementedError:
+                if lon is None or lat is None:
+                    raise NotImplementedError(
+                        'projection "%s" has no closed form on the device (latlong, stere, merc, lcc have): pass the 2-D node '
+                        'coordinates lon=, lat= of the grid and the reader is served through the node lookup' % proj4)
+                r = object.__new__(NodeLookupGridReader)     # not a GridReader instance: Python does not call __init__ on it
+                r.__init__(x, y, times, arrays, z=z, proj4=proj4, name=name, lon=lon, lat=lat)
+                return r
+        return object.__new__(cls)
+
+    def __init__(self, x, y, times, arrays, z=None, proj4='+proj=latlong', name='grid_reader', lon=None, lat=None):
         self.proj4, self.name = proj4, name
         self.x, self.y, self.z = np.asarray(x), np.asarray(y), (None if z is None else np.asarray(z, dtype=np.float64))
         self.xmin, self.xmax = float(self.x.min()), float(self.x.max())
@@ -329,6 +396,39 @@ class CurvilinearGridReader(StructuredReader):
         out = {'x': self.x, 'y': self.y, 'time': time, 'z': self.z if self.z is not None else 0}
         for v in requested_variables:
             out[v] = self.arrays[v][it]
+        return out
+
+
+class NodeLookupGridReader(CurvilinearGridReader):
+    """What GridReader(...) returns for a proj4 string the device cannot evaluate: the same arrays behind 2-D node
+    coordinates, vector pairs rotated to east / north per block (see GridReader)."""
+
+    def __init__(self, x, y, times, arrays, z=None, proj4=None, name='grid_reader', lon=None, lat=None):
+        lon, lat = np.asarray(lon, dtype=np.float64), np.asarray(lat, dtype=np.float64)
+        if lon.shape != (len(y), len(x)) or lat.shape != lon.shape:
+            raise ValueError('lon / lat must be [len(y), len(x)] node arrays')
+        self.native_proj4 = proj4
+        self.native_x, self.native_y = np.asarray(x), np.asarray(y)
+        super().__init__(lon, lat, times, arrays, z=z, name=name)
+        rot = -np.radians(node_y_azimuth(lon, lat))          # rot_angle_rad = -rot_angle_vectors_rad (variables.py:103)
+        self._cos, self._sin = np.cos(rot), np.sin(rot)
+        self._pairs = [(a, b) for a, b in VECTOR_PAIRS_XY if a in self.arrays and b in self.arrays]
+
+    def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
+        out = super().get_variables(requested_variables, time, x, y, z)
+        for a, b in self._pairs:
+            if a in out and b in out:
+                def rotate(u, v):
+                    u, v = np.asarray(u, dtype=np.float32), np.asarray(v, dtype=np.float32)
+                    return ((u * self._cos - v * self._sin).astype(np.float32),      # variables.py:104-107
+                            (u * self._sin + v * self._cos).astype(np.float32))
+                if isinstance(out[a], (list, tuple)):      # ensemble members
+                    rot = [rotate(u, v) for u, v in zip(out[a], out[b])]
+                    out[a], out[b] = [r[0] for r in rot], [r[1] for r in rot]
+                else:
+                    out[a], out[b] = rotate(out[a], out[b])
+            elif a in out or b in out:
+                raise ValueError('reader %s: %s and %s are rotated together -- request both' % (self.name, a, b))
         return out
 
 
