@@ -92,6 +92,10 @@ class Workload:
         # of C5 drift at the surface without vertical shear and stay ordered for longer (0.917 -> 0.888 ms per step at 48)
         self.sort_every = int(os.environ.get('ODR_SORT_EVERY', {'c5': 48, 'c3': 24}.get(name, 16)))
         self.fused = not os.environ.get('ODR_UNFUSED')   # one launch for sample+coastline+previous+advect
+        if name == 'c4' and self.fused and not os.environ.get('ODR_BENCH_REDUCE_PASS'):
+            # the movers' global tests (calm / no Stokes drift / zero diffusivity / nothing at the surface) come out of the step
+            # launch instead of out of a pass over the arrays (odr_ctx_set_step_reduce; ODR_BENCH_REDUCE_PASS=1: the pass, as in round 3)
+            ctx.set_step_reduce(True, wind_drift_depth=0.1, relative_wind=False)
         self.scheme = os.environ.get('ODR_BENCH_SCHEME', 'runge-kutta4')   # what-if runs only: the metric is quoted on RK4
         rank, local_rank, world = dist_info
         if name == 'c2':

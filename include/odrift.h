@@ -479,6 +479,14 @@ int odr_particles_tile_stats(odr_ctx *ctx, odr_particles *p, uint64_t *out4);
  * out16 = {n_active, lon_min, lon_max, lat_min, lat_max, z_min, z_max, D_max, stokes_sum_max,
  *          wind_speed_max, wdf_surface_max, n_surface, hs_max, tp_max, 0, 0} */
 int odr_reduce_scalars(odr_ctx *ctx, odr_particles *p, double wind_drift_depth, double *out16);
+/* The global tests the movers open with -- no element at the surface, wind_drift_factor / (relative) wind speed / Stokes
+ * drift / horizontal diffusivity identically zero (physics_methods.py:741-747,771-780,799-804, basemodel/__init__.py:1754)
+ * -- formed by the launch of odr_env_coast_advect, which holds every value they read in registers, instead of by a pass of
+ * its own over the arrays before the first mover (persistent setting; off by default).  The movers that follow
+ * (odr_movers, odr_advect_wind with the same wind_drift_depth / relative_wind, odr_stokes_drift, odr_hdiffusion) take the
+ * tests from there as long as nothing they depend on changed in between (a compaction does not; vertical mixing does:
+ * the pass is then made as before).  Same results either way (tests/test_gpu_movers.py). */
+int odr_ctx_set_step_reduce(odr_ctx *ctx, int on, double wind_drift_depth, int relative_wind);
 /* The same reductions for a run sharded over several GPUs (one process per GPU): odr_reduce_local returns the RAW slots
  * of this particle set (0 and 11 are counts, every other slot a maximum; minima negated), the caller combines them over
  * the ranks (sum / max: an all-reduce of 16 doubles) and installs the result; until odr_reduce_unpin the movers

@@ -153,6 +153,7 @@ _SIGNATURES = {
     'odr_sort_particles_ex': [_vp, _vp, C.c_int32, C.c_int],
     'odr_particles_tile_stats': [_vp, _vp, _P(C.c_uint64)],
     'odr_reduce_scalars': [_vp, _vp, C.c_double, _dp],
+    'odr_ctx_set_step_reduce': [_vp, C.c_int, C.c_double, C.c_int],
     'odr_reduce_local': [_vp, _vp, C.c_double, C.c_int, _dp],
     'odr_reduce_install': [_vp, _vp, _dp],
     'odr_reduce_unpin': [_vp],

@@ -88,6 +88,10 @@ struct odr_ctx {
   int red_rel;
   bool red_extents = true;   // the cached reduction holds the lon / lat / z extremes too (the movers' reductions leave them out)
   int red_pinned;   // odr_reduce_install: red[] holds values combined over the ranks of a sharded run
+  double *red_rec = nullptr; long long red_rec_cap = 0;   // per-wave records of the step launch
+  bool red_partial = false;  // red[] was formed by the step launch (odr_ctx_set_step_reduce): only the slots the movers' == 0 tests read, R_NSURF as a flag
+  int step_reduce_on = 0, step_reduce_rel = 0;
+  double step_reduce_wdd = 0.1;
   // lanes of the fused step (odr_step.hip, step_in_lanes): contiguous particle ranges on streams of their own
   hipStream_t lane_stream[ODR_MAX_LANES];
   hipEvent_t lane_step[ODR_MAX_LANES], lane_done[ODR_MAX_LANES], lane_fork;
@@ -315,7 +319,9 @@ bool odr_i_uv_fast_source(const odr_ctx *c, int &sid, double t_lo, double t_hi);
 bool odr_i_gyre_source(const odr_ctx *c, int var, int &sid);
 int odr_i_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var_ids, double t, float *const *out_host,
                      bool record_positions);
-int odr_i_reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind, bool wind_args_matter = true, bool extents = true);
+int odr_i_red_finish(odr_ctx *c, odr_particles *p);   // red[] <- the per-wave records of the step launch (k_red_init + k_red_finish)
+int odr_i_red_records(odr_ctx *c, odr_particles *p, double **rec);   // device array for those records
+int odr_i_reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind, bool wind_args_matter = true, bool extents = true, bool partial_ok = false);
 int odr_i_read_counter(odr_ctx *c, int64_t *out);
 // k_env_noise with DEVICE arrays of draws (ODR_RNG_HOST) or none (ODR_RNG_DEVICE)
 int odr_i_env_noise(odr_ctx *c, odr_particles *p, int vx, int vy, double std, int distribution, int rng_mode,

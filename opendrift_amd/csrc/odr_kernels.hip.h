@@ -549,6 +549,19 @@ __device__ __forceinline__ float pick_slot(const float (&a)[MAXG], int j) {
   return r;
 }
 
+// the same with a plain (not volatile) opaque move: the compiler may schedule memory operations across it -- used where several
+// picks sit in the middle of the step launch (the movers' tests)
+__device__ __forceinline__ float pick_slot_nv(const float (&a)[MAXG], int j) {
+  float r = a[0];
+#pragma unroll
+  for (int k = 1; k < MAXG; ++k) {
+    float v = a[k];
+    asm("" : "+v"(v));
+    r = j == k ? v : r;
+  }
+  return r;
+}
+
 #ifdef ODR_TU_MISC
 // ------------------------------------------------------------------ environment
 // Environment.get_environment for one variable group of NV variables
@@ -755,6 +768,66 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_WAVES(PROJ)) void k_advect_grid(con
   p.lat[i] = lat;
 }
 
+#endif  // ODR_TU_STEP
+// -------------------------------------------------------------------- reductions
+// red[] slots
+enum { R_NACT = 0, R_LONMIN, R_LONMAX, R_LATMIN, R_LATMAX, R_ZMIN, R_ZMAX, R_DMAX, R_STOKESMAX,
+       R_WSPEEDMAX, R_WDFMAX, R_NSURF, R_HSMAX, R_TPMAX, R_RELWSPEEDMAX, R_MLDMAX, R_N };
+
+__device__ __forceinline__ void atomic_max_d(double *addr, double v) {
+  unsigned long long *a = (unsigned long long *)addr, old = *a, assumed;
+  do {
+    assumed = old;
+    if (__longlong_as_double((long long)assumed) >= v) break;
+    old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
+  } while (assumed != old);
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// Maximum over the 64 lanes of a wave with data-parallel-primitive moves (VALU only; the __shfl_xor ladder above goes through
+// the LDS crossbar: 6 dependent ds_bpermute per value): inclusive scan inside the rows of 16 (row_shr 1, 2, 4, 8), then the
+// last lane of rows 0 and 2 into rows 1 and 3 (row_bcast:15), then lane 31 into rows 2 and 3 (row_bcast:31): lane 63 holds
+// the maximum, read back as a wave-uniform value.  Lanes without a source keep their own value.
+#define ODR_DPP_MAX_F(v, ctrl, rows) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rows, 0xf, false)))
+__device__ __forceinline__ float wave_max_f(float v) {
+  ODR_DPP_MAX_F(v, 0x111, 0xf); ODR_DPP_MAX_F(v, 0x112, 0xf); ODR_DPP_MAX_F(v, 0x114, 0xf); ODR_DPP_MAX_F(v, 0x118, 0xf);
+  ODR_DPP_MAX_F(v, 0x142, 0xa); ODR_DPP_MAX_F(v, 0x143, 0xc);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+#undef ODR_DPP_MAX_F
+__device__ __forceinline__ double dpp_move_d(double v, int ctrl, int rows) {
+  const long long b = __double_as_longlong(v);
+  int lo = (int)(unsigned)(b & 0xffffffffll), hi = (int)(b >> 32);
+  switch (ctrl) {   // the control word must be a literal
+    case 0x111: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x111, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x111, 0xf, 0xf, false); break;
+    case 0x112: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x112, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x112, 0xf, 0xf, false); break;
+    case 0x114: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x114, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x114, 0xf, 0xf, false); break;
+    case 0x118: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x118, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x118, 0xf, 0xf, false); break;
+    case 0x142: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x142, 0xa, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x142, 0xa, 0xf, false); break;
+    default:    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x143, 0xc, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x143, 0xc, 0xf, false); break;
+  }
+  (void)rows;
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {
+  v = fmax(v, dpp_move_d(v, 0x111, 0xf)); v = fmax(v, dpp_move_d(v, 0x112, 0xf)); v = fmax(v, dpp_move_d(v, 0x114, 0xf));
+  v = fmax(v, dpp_move_d(v, 0x118, 0xf)); v = fmax(v, dpp_move_d(v, 0x142, 0xa)); v = fmax(v, dpp_move_d(v, 0x143, 0xc));
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffll), 63);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (long long)lo);
+}
+
+#ifdef ODR_TU_STEP
 // One launch for  get_environment -> interact_with_coastline -> update_previous_state ->
 // advect_ocean_current  (the run() loop order, basemodel/__init__.py:2136-2248) when the group that
 // holds the current comes from one gridded reader: same arithmetic as the four separate kernels
@@ -772,6 +845,15 @@ struct StepDesc {
   int miss_grp[4], miss_rest[4];    // group slots / variable ids (sampled by the preceding launch) to test for NaN
   int main_noise;                   // uncertainty of the main-loop sample of the current (StageNoise call 0)
   int ssh_slot;                     // group slot of sea_surface_height, or -1: sampled by the preceding launch (p.env[SSH])
+  // The global tests the movers of this step open with -- no element at the surface, wind_drift_factor / wind speed /
+  // Stokes drift / diffusivity identically zero (physics_methods.py:741-747,771-780,799-804, basemodel/__init__.py:1754) --
+  // formed by THIS launch (odr_ctx_set_step_reduce), which holds every value they need in registers; the separate pass
+  // over the arrays (k_reduce, 0.105 ms at 6.25 M elements) is then not made.  Slots: group slot, -1 = p.env[] (sampled by
+  // the preceding launch), -2 = the variable is not there.
+  int red_on, red_rel;
+  int red_hd, red_sx, red_xw, red_pad;   // horizontal_diffusivity; Stokes x (y = next slot / array); x_wind (y_wind likewise)
+  double red_wdd, red_iwdd;         // wind_drift_depth as given (sign and zero matter, :754-757); 1 / |wind_drift_depth|
+  double *red;                      // per-wave records [waves of the launch][6] (see the tail of k_step_grid)
 };
 
 // (The LDS field tile is a kernel of its own since round 4: k_step_tile, odr_tile.hip.h.)
@@ -824,6 +906,10 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
     }
     __syncthreads();
   }
+  // this lane's share of the movers' tests (S.red_on): neutral unless it holds an element that stays active
+  float r_hd = -__builtin_inff(), r_st = -__builtin_inff(), r_rws = -__builtin_inff();
+  double r_wdf = -__builtin_inf();
+  bool r_surf = false;
   if (i < p.n) {
     double lon = p.lon[i], lat = p.lat[i];
     const double z = p.z[i];
@@ -833,6 +919,13 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
     int st = p.status[i];
     const float age0 = p.age[i], cdf0 = p.cdf[i];
     const float ssh0 = (S.seafloor || MIXQ > 0) && p.env[VAR_SSH] ? p.env[VAR_SSH][i] : 0.f;
+    // (the movers' tests, below: what they read from arrays is requested here, with the rest of the particle's state -- a load
+    // behind the status decisions is a memory round trip of its own in every wave: 0.10 ms of this launch at 6.25 M elements)
+    constexpr bool RED = !IS3D && MIXQ == 0;
+    const float wdf0 = (RED && S.red_on && S.red_xw > -2) ? p.wdf[i] : 0.f;
+    const float e_hd = (RED && S.red_on && S.red_hd == -1) ? p.env[VAR_HDIFF][i] : 0.f;
+    const float e_sx = (RED && S.red_on && S.red_sx == -1) ? p.env[VAR_SX][i] : 0.f, e_sy = (RED && S.red_on && S.red_sx == -1) ? p.env[VAR_SY][i] : 0.f;
+    const float e_xw = (RED && S.red_on && S.red_xw == -1) ? p.env[VAR_XWIND][i] : 0.f, e_yw = (RED && S.red_on && S.red_xw == -1) ? p.env[VAR_YWIND][i] : 0.f;
     ODR_PT_USE(lon); ODR_PT_USE(lat); ODR_PT_USE(z); ODR_PT(1);
     float out[MAXG];
     ZBracket zb_env;
@@ -902,6 +995,35 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
     }
     // deactivated (now or earlier, not yet compacted): the reference removes it before update() -- it does not move
     const bool skip = st != 0;
+    // (2-D readers only: a 3-D run mixes vertically between this launch and the movers, which changes z and voids the tests;
+    // the 3-D instantiations carry no code for it -- k_step_grid<RK4, lat/lon, 3-D> stays at 126 registers)
+    // Measured at 6.25 M elements (C4, polar stereographic: 89 KB of code, the one launch with instruction-cache misses in
+    // its counters): these ~150 instructions cost the launch 0.06 ms -- with the wind part compiled out 0.00, with constants
+    // in place of the whole block -0.03 -- against the 0.107 ms pass + its launch they replace (profiles/r04_ab_variants.txt 10).
+    if (!IS3D && MIXQ == 0 && S.red_on && !skip) {   // k_reduce<false> for this element (z is final here: the advection below is horizontal)
+      if (S.red_hd > -2) r_hd = S.red_hd >= 0 ? pick_slot_nv(out, S.red_hd) : e_hd;
+      if (S.red_sx > -2) {
+        const float sx = S.red_sx >= 0 ? pick_slot_nv(out, S.red_sx) : e_sx;
+        const float sy = S.red_sx >= 0 ? pick_slot_nv(out, S.red_sx + 1) : e_sy;
+        r_st = __fadd_rn(sx, sy);
+      }
+      if (S.red_xw > -2) {
+        const double wdd = fabs(S.red_wdd);
+        if (zz >= -wdd) {
+          float xa = S.red_xw >= 0 ? pick_slot_nv(out, S.red_xw) : e_xw;
+          float ya = S.red_xw >= 0 ? pick_slot_nv(out, S.red_xw + 1) : e_yw;
+          double wdf = wdf0;
+          if (S.red_wdd != 0) {
+            wdf = div_cr(wdf * (wdd + zz), wdd, S.red_iwdd);   // == wdf * (wdd + z) / wdd, correctly rounded (k_reduce)
+            if (zz > 0) wdf = wdf0;
+          }
+          r_surf = true;
+          r_wdf = wdf;
+          if (S.red_rel) { xa = __fsub_rn(xa, out[0]); ya = __fsub_rn(ya, out[1]); }
+          r_rws = speed_f32(xa, ya);     // (the plain wind speed maximum is not read by any mover: not formed)
+        }
+      }
+    }
 #ifndef ODR_ABLATE_STORES
     if (S.store_previous) { p.plon[i] = lon; p.plat[i] = lat; }
 #endif
@@ -948,6 +1070,20 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
   if (S.coast_action) {
     unsigned long long b = __ballot(hit);
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_hit, (unsigned long long)__popcll(b));
+  }
+  if (!IS3D && MIXQ == 0 && S.red_on) {
+    // one record of six doubles per WAVE, written by its lanes 0..5 in one store; k_red_finish folds the records into
+    // red[].  (Atomics on red[] from here -- one per wave and slot, made only when they would raise the value -- took this
+    // launch from 0.59 to 0.79-0.87 ms at 6.25 M elements: every wave ends on dependent, coherent reads of the same lines.)
+    const float m_hd = wave_max_f(r_hd), m_st = wave_max_f(r_st), m_rws = wave_max_f(r_rws);
+    const double m_wdf = wave_max_dpp(r_wdf);
+    const unsigned long long bs = __ballot(r_surf);
+    const unsigned lane = threadIdx.x & 63u;
+    if (lane < 6u) {
+      const double v = lane == 0 ? (double)m_hd : lane == 1 ? (double)m_st : lane == 2 ? (S.red_rel ? -__builtin_inf() : (double)m_rws)
+                     : lane == 3 ? (double)m_rws : lane == 4 ? m_wdf : (double)__popcll(bs);
+      S.red[((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 6 + lane] = v;
+    }
   }
 }
 
@@ -1030,31 +1166,6 @@ __global__ __launch_bounds__(BLOCK) void k_update_positions(PView p, const doubl
 }
 
 #endif  // ODR_TU_MISC
-// -------------------------------------------------------------------- reductions
-// red[] slots
-enum { R_NACT = 0, R_LONMIN, R_LONMAX, R_LATMIN, R_LATMAX, R_ZMIN, R_ZMAX, R_DMAX, R_STOKESMAX,
-       R_WSPEEDMAX, R_WDFMAX, R_NSURF, R_HSMAX, R_TPMAX, R_RELWSPEEDMAX, R_MLDMAX, R_N };
-
-__device__ __forceinline__ void atomic_max_d(double *addr, double v) {
-  unsigned long long *a = (unsigned long long *)addr, old = *a, assumed;
-  do {
-    assumed = old;
-    if (__longlong_as_double((long long)assumed) >= v) break;
-    old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
-  } while (assumed != old);
-}
-
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
 #ifdef ODR_TU_MISC
 // min is stored as max of the negated value; red must be pre-filled with -inf (sums with 0).
 // Grid-stride over a bounded grid, wave shuffle + LDS block reduction, ONE atomic per slot per
@@ -1144,6 +1255,32 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(PView p, double wind_drift_dep
     for (int w = 1; w < BLOCK / 64; ++w) r = is_sum ? r + sh[w][k] : fmax(r, sh[w][k]);
     if (is_sum) { if (r != 0) atomicAdd(&red[k], r); }
     else if (r > ninf) atomic_max_d(&red[k], r);
+  }
+}
+
+// the per-wave records of a step launch (StepDesc.red_on: {D, Stokes sum, wind speed, relative wind speed, wind drift factor
+// maxima; elements at the surface}) folded into red[] (initialised by k_red_init): grid-stride, one atomic per slot and workgroup
+__global__ __launch_bounds__(BLOCK) void k_red_finish(const double *__restrict__ rec, long long nrec, double *red) {
+  const double ninf = -__builtin_inf();
+  double m[5] = {ninf, ninf, ninf, ninf, ninf}, ns = 0;
+  for (long long r = (long long)blockIdx.x * BLOCK + threadIdx.x; r < nrec; r += (long long)gridDim.x * BLOCK) {
+    const double *q = rec + 6 * r;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) m[k] = fmax(m[k], q[k]);
+    ns += q[5];
+  }
+  __shared__ double sh[BLOCK / 64][6];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { const double w = wave_max(m[k]); if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = w; }
+  { const double w = wave_sum(ns); if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][5] = w; }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    double r = sh[0][k];
+    for (int w = 1; w < BLOCK / 64; ++w) r = k == 5 ? r + sh[w][k] : fmax(r, sh[w][k]);
+    const int slot = k == 0 ? R_DMAX : k == 1 ? R_STOKESMAX : k == 2 ? R_WSPEEDMAX : k == 3 ? R_RELWSPEEDMAX : k == 4 ? R_WDFMAX : R_NSURF;
+    if (k == 5) { if (r != 0) atomicAdd(&red[slot], r); }
+    else if (r > ninf) atomic_max_d(&red[slot], r);
   }
 }
 

@@ -292,6 +292,27 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
     if ((rc = coast_action ? read_counter(c, n_on_land) : 0)) return rc;
     return want_mix ? mix_after(c, p, t, dt, extras) : 0;
   }
+  // the movers' tests (no element at the surface, wind / Stokes drift / diffusivity identically zero) formed by this launch
+  // (2-D readers: the 3-D instantiations of the kernel carry no code for it -- a 3-D run mixes vertically before its movers)
+  bool red_in_launch = c->step_reduce_on && !p->external && !(c->red_pinned && c->red_owner == p) && !getenv("ODR_NO_STEP_REDUCE") &&
+                       !(c->hw.src[G.sid].slot[c->hw.src[G.sid].level_slot[0]].var_nz[VAR_U] > 1);
+  if (red_in_launch) {
+    auto slot_of = [&](int var) { for (int k = 0; k < G.nv; ++k) if (G.var[k] == var) return k; return p->env[var] ? -1 : -2; };
+    auto pair_of = [&](int vx, int vy, int &out) {   // both in the group next to each other, both from arrays, or both absent
+      const int a = slot_of(vx), b = slot_of(vy);
+      if (a >= 0 && b == a + 1) { out = a; return true; }
+      if (a == -1 && b == -1) { out = -1; return true; }
+      if (a == -2 || b == -2) { out = -2; return a < 0 && b < 0; }
+      return false;
+    };
+    S.red_hd = slot_of(VAR_HDIFF);
+    red_in_launch = pair_of(VAR_SX, VAR_SY, S.red_sx) && pair_of(VAR_XWIND, VAR_YWIND, S.red_xw) && (S.red_xw == -2 || p->f32[0]);
+    if (red_in_launch) {
+      S.red_on = 1; S.red_rel = c->step_reduce_rel; S.red_wdd = c->step_reduce_wdd;
+      S.red_iwdd = c->step_reduce_wdd != 0 ? 1.0 / fabs(c->step_reduce_wdd) : 0.0;
+      if ((rc = odr_i_red_records(c, p, &S.red))) return rc;
+    }
+  }
   if (N.on && (scheme > 0 || main_noise)) {
     if (scheme > 0 && N.rng_mode == ODR_RNG_HOST && !N.stage) return fail(ODR_ERR_INVALID, "no host draws for the Runge-Kutta stage calls");
     if (N.sm == ODR_STAGE_FAST && scheme > 0) odr_i_step_fast_noise(c, p, G, S, scheme, t, dt, factor, N);
@@ -299,6 +320,11 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   } else if (N.sm == ODR_STAGE_FAST && scheme > 0) odr_i_step_fast(c, p, G, S, scheme, t, dt, factor, N);
   else step_dispatch<false>(c, p, G, S, scheme, t, dt, factor, N);
   HIPCHK(hipGetLastError());
+  if (red_in_launch) {   // the cache describes what the launch left in red[] (a mixing launch that follows invalidates it: z changes)
+    if ((rc = odr_i_red_finish(c, p))) return rc;
+    c->red_owner = p; c->red_epoch = p->epoch; c->red_wdd = c->step_reduce_wdd; c->red_rel = c->step_reduce_rel;
+    c->red_extents = false; c->red_partial = true;
+  }
   if ((rc = coast_action ? read_counter(c, n_on_land) : 0)) return rc;
   return want_mix ? mix_after(c, p, t, dt, extras) : 0;
 }

@@ -70,6 +70,7 @@ int odr_ctx_destroy(odr_ctx *c) {
   (void)hipEventDestroy(c->up_dep);
   (void)hipFree(c->dw);
   (void)hipFree(c->red);
+  if (c->red_rec) (void)hipFree(c->red_rec);
   for (double *q : {c->oil_stat, c->oil_cdf, c->oil_chunk, c->oil_part, c->oil_u}) if (q) (void)hipFree(q);
   if (c->oil_guide) (void)hipFree(c->oil_guide);
   if (c->noise_buf) (void)hipFree(c->noise_buf);
@@ -1531,12 +1532,34 @@ int odr_leeway_capsize(odr_ctx *c, odr_particles *p, double dt, double wind_thre
   return 0;
 }
 
-int odr_i_reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind, bool wind_args_matter, bool extents) {
+int odr_i_red_records(odr_ctx *c, odr_particles *p, double **rec) {
+  const long long need = (long long)nblk(p->n) * (BLOCK / 64);
+  if (c->red_rec_cap < need) {
+    if (c->red_rec) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->red_rec)); c->red_rec = nullptr; c->red_rec_cap = 0; }
+    const long long cap = (long long)nblk(p->cap > p->n ? p->cap : p->n) * (BLOCK / 64);
+    HIPCHK(hipMalloc((void **)&c->red_rec, sizeof(double) * 6 * (size_t)cap));
+    c->red_rec_cap = cap;
+  }
+  *rec = c->red_rec;
+  return 0;
+}
+int odr_i_red_finish(odr_ctx *c, odr_particles *p) {
+  const long long nrec = (long long)nblk(p->n) * (BLOCK / 64);
+  hipLaunchKernelGGL(k_red_init, dim3(1), dim3(64), 0, c->stream, c->red);
+  const unsigned g = (unsigned)std::min<long long>(128, (nrec + BLOCK - 1) / BLOCK);
+  hipLaunchKernelGGL(k_red_finish, dim3(g ? g : 1), dim3(BLOCK), 0, c->stream, c->red_rec, nrec, c->red);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// partial_ok: the caller only reads the slots the movers' tests need (a reduction formed by the step launch will do)
+int odr_i_reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind, bool wind_args_matter, bool extents, bool partial_ok) {
   if (c->red_pinned && c->red_owner == p) return 0;   // installed by the caller (odr_reduce_install): the all-rank values
   if (!p->external && c->red_owner == p && c->red_epoch == p->epoch && (c->red_extents || !extents) &&
-      (!wind_args_matter || (c->red_wdd == wdd && c->red_rel == relwind)))
+      (!c->red_partial || partial_ok) && (!wind_args_matter || (c->red_wdd == wdd && c->red_rel == relwind)))
     return 0;
   c->red_owner = p; c->red_epoch = p->epoch; c->red_wdd = wdd; c->red_rel = relwind; c->red_extents = extents;
+  c->red_partial = false;
   hipLaunchKernelGGL(k_red_init, dim3(1), dim3(64), 0, c->stream, c->red);
   const dim3 grid(nblk(p->n) < 2048u ? nblk(p->n) : 2048u);
   if (p->n > 0) {
@@ -1544,6 +1567,14 @@ int odr_i_reduce(odr_ctx *c, odr_particles *p, double wdd, int relwind, bool win
     else hipLaunchKernelGGL(k_reduce<false>, grid, dim3(BLOCK), 0, c->stream, view(p), wdd, relwind, c->red);
   }
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// The movers' early-out tests formed by the launch of odr_env_coast_advect (StepDesc.red_*): persistent setting.
+int odr_ctx_set_step_reduce(odr_ctx *c, int on, double wind_drift_depth, int relative_wind) {
+  c->step_reduce_on = on ? 1 : 0;
+  c->step_reduce_wdd = wind_drift_depth;
+  c->step_reduce_rel = relative_wind ? 1 : 0;
   return 0;
 }
 
@@ -1583,7 +1614,7 @@ int odr_reduce_install(odr_ctx *c, odr_particles *p, const double *in16) {
   REQUIRE(in16, "in16 NULL");
   H2D(c->red, in16, sizeof(double) * R_N);
   HIPCHK(hipStreamSynchronize(c->stream));   // in16 is pageable
-  c->red_owner = p; c->red_epoch = p->epoch; c->red_extents = true;
+  c->red_owner = p; c->red_epoch = p->epoch; c->red_extents = true; c->red_partial = false;
   c->red_pinned = 1;      // until odr_reduce_unpin: the calls in between do not reduce again
   return 0;
 }
@@ -1599,7 +1630,7 @@ int odr_advect_wind(odr_ctx *c, odr_particles *p, double dt, double wdd, int rel
   if (p->n == 0) return 0;
   // wind identically 0 (no reader, fallback 0): wind_speed.max() == 0 -> "No wind for wind-sheared ocean drift" (:775-780)
   if (!relwind && env_is_const(p, VAR_XWIND, 0.0f) && env_is_const(p, VAR_YWIND, 0.0f)) return 0;
-  int rc = reduce(c, p, wdd, relwind, true, false);
+  int rc = reduce(c, p, wdd, relwind, true, false, true);
   if (rc) return rc;
   hipLaunchKernelGGL(k_advect_wind, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, wdd, relwind, factor, c->red);
   HIPCHK(hipGetLastError());
@@ -1618,7 +1649,7 @@ int odr_stokes_drift(odr_ctx *c, odr_particles *p, double dt, int profile, int h
   }
   if (p->n == 0) return 0;
   if (env_is_const(p, VAR_SX, 0.0f) && env_is_const(p, VAR_SY, 0.0f)) return 0;   // "No Stokes drift velocity available" (:799-804)
-  int rc = reduce(c, p, 0.0, 0, false, false);
+  int rc = reduce(c, p, 0.0, 0, false, false, true);
   if (rc) return rc;
   hipLaunchKernelGGL(k_stokes, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, profile, hs_mode, tp_mode, factor, c->red);
   HIPCHK(hipGetLastError());
@@ -1635,7 +1666,7 @@ int odr_hdiffusion(odr_ctx *c, odr_particles *p, double dt, int rng_mode, const 
     REQUIRE(hnx && hny, "host normals required in ODR_RNG_HOST mode");
     if ((rc = host_to_scratch(c, p, hnx, hny, (size_t)p->n, &da, &db))) return rc;
   }
-  if ((rc = reduce(c, p, 0.0, 0, false, false))) return rc;
+  if ((rc = reduce(c, p, 0.0, 0, false, false, true))) return rc;
   hipLaunchKernelGGL(k_hdiff, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, view(p), dt, rng_mode, da, db, c->seed,
                      (unsigned long long)step, c->red);
   HIPCHK(hipGetLastError());
@@ -1716,7 +1747,7 @@ int odr_movers(odr_ctx *c, odr_particles *p, double dt, int which, double wdd, i
   }
   // the reduction of the first mover that needs the wind arguments (the cached one is reused by the others: nothing they
   // read changes in between)
-  if ((rc = (which & 1) ? reduce(c, p, wdd, relwind, true, false) : reduce(c, p, 0.0, 0, false, false))) return rc;
+  if ((rc = (which & 1) ? reduce(c, p, wdd, relwind, true, false, true) : reduce(c, p, 0.0, 0, false, false, true))) return rc;
   M.which = which; M.relative_wind = relwind; M.profile = profile; M.hs_mode = hs_mode; M.tp_mode = tp_mode; M.rng_mode = rng_mode;
   M.dt = dt; M.wind_drift_depth = wdd; M.wind_factor = wind_factor; M.stokes_factor = stokes_factor;
   M.seed = c->seed; M.step = (unsigned long long)step;
@@ -1980,7 +2011,11 @@ int odr_scan_status(odr_ctx *c, odr_particles *p, int64_t *n_kept, uint64_t *fla
 // Second half: remove the deactivated elements using the counts of the last odr_scan_status (no host read).  Valid as
 // long as no element changed between active and deactivated since the scan (renumbering statuses is fine).
 int odr_compact_apply(odr_ctx *c, odr_particles *p, int64_t *n_active) {
-  p->epoch++;  // invalidates the cached reductions (reduce())
+  // the cached reductions run over the ACTIVE elements only, which a compaction neither changes nor removes: a valid
+  // cache stays valid (the step launch forms the movers' tests, the compaction comes between it and the movers)
+  const bool keep_red = !p->external && c->red_owner == p && c->red_epoch == p->epoch && !c->red_extents;
+  p->epoch++;
+  if (keep_red) c->red_epoch = p->epoch;
   HIPCHK(hipSetDevice(c->device));
   if (p->n == 0) { if (n_active) *n_active = 0; return 0; }
   if (p->scan_epoch != p->status_epoch || p->scan_kept < 0)

@@ -310,6 +310,11 @@ class Context:
         check(self.lib.odr_ctx_set_stage_math(self.h, _abi.STAGE_MATH[mode]))
         self.stage_math = mode
 
+    def set_step_reduce(self, on=True, wind_drift_depth=0.1, relative_wind=False):
+        """The movers' global early-out tests formed by the env_coast_advect launch instead of by a pass of their own
+        (odr_ctx_set_step_reduce)."""
+        check(self.lib.odr_ctx_set_step_reduce(self.h, int(bool(on)), float(wind_drift_depth), int(bool(relative_wind))))
+
     def set_seafloor_action(self, action, status_code=0):
         """general:seafloor_action for the sea floor checks inside update() (vertical_buoyancy, vertical_mixing)."""
         a = {'none': 0, 'lift_to_seafloor': 1, 'deactivate': 2, 'previous': 3}[action]

@@ -1128,6 +1128,11 @@ class OpenDriftSimulation(Configurable):
                       # launch: an element both outside the domain and without data must end as 'missing_data'
                       not (any(self.get_config('drift:deactivate_%s_of' % k) is not None for k in ('west', 'east', 'south', 'north'))
                            and self._can_be_missing(list(self.required_variables))))
+        # the movers' global tests (calm, no Stokes drift, zero diffusivity, nothing at the surface) come out of the fused launch
+        # instead of out of a pass over the arrays before the first mover (odr_ctx_set_step_reduce; a sharded run combines
+        # its reductions over the ranks in the step's collective instead)
+        self.ctx.set_step_reduce(fused_lane and self._world == 1, self.get_config('drift:wind_drift_depth', 0.1) or 0.0,
+                                 bool(self.get_config('drift:relative_wind')))
         # Leeway lane: the loop body between two compactions + Leeway.update (leeway, current, jibes) in ONE launch
         # (odr_env_coast_leeway; what bench.py's C5 line times).  Stock methods, device RNG (the jibe draws are keyed by
         # element ID), no capsizing (its draws are sized by the elements that can capsize: call-by-call lane), nothing

@@ -14,12 +14,23 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
-def _has_gpu():
+def _probe_gpu():
     try:
         import torch
         return torch.cuda.is_available()
     except Exception:
         return os.path.exists('/dev/kfd')
+
+
+# Probed ONCE, when the session starts: torch brings its own HIP runtime, and asked for the first time AFTER
+# libodrift_hip.so (system ROCm) has opened the device in this process it reports "no GPU" -- tests that ran behind a test
+# creating its own Context were then skipped as if the box had none (seen with `pytest tests/test_gpu_movers.py
+# tests/test_gpu_parity.py`).
+_HAS_GPU = _probe_gpu()
+
+
+def _has_gpu():
+    return _HAS_GPU
 
 
 @pytest.fixture(scope='session')

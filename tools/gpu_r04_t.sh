@@ -1,0 +1,22 @@
+#!/bin/bash
+# round 4, GPU call T: where the cost of the in-launch tests sits (what-if builds)
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04t; mkdir -p $O
+export ODR_BENCH_ONE_MODE=1
+run() {  # name, env...
+  name=$1; shift
+  env "$@" timeout 600 python bench.py --workload ${W:-c4} --steps 64 --no-cpu --no-extras 2>&1 | tail -1 > $O/$name.json
+  python - <<PY
+import json
+try:
+    d=json.load(open('$O/$name.json'))
+    print('%-22s ms/step %.4f kernel_ms %.4f' % ('$name', d['ms_per_step'], d['roofline']['kernel_ms']))
+except Exception as e:
+    print('$name', 'failed', e)
+PY
+}
+run pass ODR_BENCH_REDUCE_PASS=1
+run launch
+run late ODR_LIB=$PWD/tools/_libB.so
+run no_wind ODR_LIB=$PWD/tools/_libC.so
+run off_in_kernel ODR_NO_STEP_REDUCE=1
