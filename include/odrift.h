@@ -207,8 +207,13 @@ int odr_source_time_coverage(odr_ctx *ctx, int32_t source_id, double t_start_epo
  * ReaderBlock.interpolate gives element number j of a call the member j % members
  * (readers/interpolation/structured.py:119-135).  Declare it before the blocks are uploaded; the block arrays of `var`
  * then hold the members one after the other along the layer axis ([members x nz][ny][nx], var_nz = members x nz).
- * Element number = rank among the present elements in ascending ID (the reference's array order for seed times that are
- * monotonic in ID; elements outside the reader's coverage are counted, unlike in the reference).  Sampled by the generic
+ * Element number = rank, in ascending ID (the reference's array order for seed times that are monotonic in ID), among the
+ * elements the reference HANDS to the block: the active ones the reader's domain covers at the positions of that call
+ * (get_variables_interpolated, variables.py:747-765) -- formed per call by odr_env_sample and, for the stage calls of
+ * odr_advect / odr_env_coast_advect, once at the elements' positions (a launch that holds all stages cannot renumber at
+ * the stage positions: a host that needs that -- elements crossing the reader's edge -- samples the stages one by one, as
+ * opendrift_amd's stage-split lane does).  With several ensemble readers, one behind another reader in its priority
+ * list, or in a sharded run (odr_particles_set_rank_offset) every active element is numbered.  Sampled by the generic
  * kernels; ocean_vertical_diffusivity profiles cannot be ensemble data. */
 int odr_source_set_members(odr_ctx *ctx, int32_t source_id, int32_t var, int32_t members);
 /* Ensemble data hands element number j OF THE CALL member j % M (readers/interpolation/structured.py:119-135): j is the rank

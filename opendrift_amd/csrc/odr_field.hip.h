@@ -587,23 +587,28 @@ __device__ __forceinline__ bool landmask_contains(const DevSource &s, double lon
 }
 
 // One reader.get_variables_interpolated (variables.py:860-920) for one particle and the
-// NV variables of a group.  Returns false when the reader does not cover the position.
-template <int NV>
-__device__ __forceinline__ bool source_sample(const DevSource &s, const int (&vars)[NV], double lon,
-                                              double lat, double z, double t, double (&val)[NV], int rank = 0) {
-  if (!s.always_valid && (t < s.tmin || t > s.tmax)) return false;  // OutsideTemporalCoverageError
+// covers_positions_xy (variables.py:170-215, 747): the position in the reader's own coordinates and whether its domain
+// holds it -- the elements a reader is HANDED are the covered ones (ind_covered), which is also what the ensemble members
+// of a ReaderBlock are numbered over (interpolation/structured.py:119-135; k_rank_mark)
+__device__ __forceinline__ bool source_covers_xyz(const DevSource &s, double lon, double lat, double z, double &x, double &y) {
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
-  double x, y;
   proj_fwd_rt(s.proj, lon, lat, x, y);
   double xchk = x;
   if (s.proj.kind == PROJ_LATLONG) {
     if (s.lon_mode == 1) xchk = np_mod(x + 180.0, 360.0) - 180.0;
     else if (s.lon_mode == 2) xchk = np_mod(x, 360.0);
   }
-  if (!(xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin &&
-        z <= s.zmax))
-    return false;
+  return xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin && z <= s.zmax;
+}
+
+// NV variables of a group.  Returns false when the reader does not cover the position.
+template <int NV>
+__device__ __forceinline__ bool source_sample(const DevSource &s, const int (&vars)[NV], double lon,
+                                              double lat, double z, double t, double (&val)[NV], int rank = 0) {
+  if (!s.always_valid && (t < s.tmin || t > s.tmax)) return false;  // OutsideTemporalCoverageError
+  double x, y;
+  if (!source_covers_xyz(s, lon, lat, z, x, y)) return false;
   if (s.kind == SRC_CONSTANT) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) val[v] = s.const_val[vars[v]];

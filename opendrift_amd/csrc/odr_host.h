@@ -107,6 +107,7 @@ struct odr_particles {
   unsigned *rank_words, *rank_before, *rank_bsum;
   long long rank_words_n, id_max;
   int rank_on;
+  int rank_sharded = 0;        // odr_particles_set_rank_offset was called: part of a sharded run (members numbered over the active elements of all ranks)
   long long rank_offset = 0;   // odr_particles_set_rank_offset: present elements with smaller IDs held by other particle sets (sharded run)
   double *d64[7];       // lon lat z plon plat slon slat
   double *alt64[7];

@@ -2371,9 +2371,17 @@ __global__ __launch_bounds__(BLOCK) void k_deactivate(PView p, const unsigned ch
 // popcounts per word, their exclusive scan, then rank = words before + bits before
 // (elements already deactivated in this step are not counted: the reference has removed them from its arrays by the time
 // the next call is made, remove_deactivated_elements comes before update())
-__global__ __launch_bounds__(BLOCK) void k_rank_mark(const int *id, const int *status, long long n, unsigned *words) {
+// sid >= 0: only the elements the ensemble reader `sid` covers at their position are numbered (the elements the reference
+// hands to its ReaderBlock, variables.py:747-765); sid < 0: every active element
+__global__ __launch_bounds__(BLOCK) void k_rank_mark(const DevWorld *__restrict__ W, int sid, PView p, unsigned *words) {
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-  if (i < n && status[i] == 0) atomicOr(&words[(unsigned)id[i] >> 5], 1u << ((unsigned)id[i] & 31u));
+  if (i >= p.n || p.status[i] != 0) return;
+  if (sid >= 0) {
+    double x, y;
+    if (!source_covers_xyz(W->src[sid], p.lon[i], p.lat[i], p.z[i], x, y)) return;
+  }
+  const unsigned v = (unsigned)p.id[i];
+  atomicOr(&words[v >> 5], 1u << (v & 31u));
 }
 __global__ __launch_bounds__(BLOCK) void k_rank_count(const unsigned *words, long long nw, unsigned *cnt) {
   long long w = (long long)blockIdx.x * BLOCK + threadIdx.x;

@@ -1310,7 +1310,24 @@ int odr_i_ensure_ranks(odr_ctx *c, odr_particles *p) {
     p->rank_words_n = cap;
   }
   HIPCHK(hipMemsetAsync(p->rank_words, 0, sizeof(unsigned) * (size_t)nw, c->stream));
-  hipLaunchKernelGGL(k_rank_mark, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, p->i32[0], p->i32[1], p->n, p->rank_words);
+  // Numbered are the elements the reference HANDS to the ensemble reader's block: the ones its domain covers
+  // (get_variables_interpolated, variables.py:747-765 -> ReaderBlock.interpolate, interpolation/structured.py:119-135).
+  // One ensemble reader at the head of its priority lists is the case built; with several, or behind another reader (whose
+  // missing-data mask would decide who is handed on), every active element is numbered as before.
+  int ens_sid = -1, n_ens = 0;
+  bool head = true;
+  for (int s = 0; s < c->nsrc; ++s) {
+    bool has = false;
+    for (int v = 0; v < NVAR; ++v) has |= c->hw.src[s].members[v] > 1;
+    if (!has) continue;
+    ++n_ens; ens_sid = s;
+    for (int v = 0; v < NVAR; ++v)
+      if (c->hw.src[s].members[v] > 1 && !(c->hw.nlist[v] > 0 && c->hw.list[v][0] == s)) head = false;
+  }
+  // (a particle set of a sharded run -- odr_particles_set_rank_offset was called on it, with whatever offset -- numbers its
+  // active elements: the covered elements of the lower ranks are not known here)
+  if (n_ens != 1 || !head || p->rank_sharded || getenv("ODR_RANK_AMONG_ACTIVE")) ens_sid = -1;
+  hipLaunchKernelGGL(k_rank_mark, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, c->dw, ens_sid, view(p), p->rank_words);
   hipLaunchKernelGGL(k_rank_count, dim3(nblk(nw)), dim3(BLOCK), 0, c->stream, p->rank_words, nw, p->rank_before);
   const unsigned nsb = (unsigned)((nw + 1023) / 1024);
   hipLaunchKernelGGL(k_scan_local, dim3(nsb), dim3(1024), 0, c->stream, p->rank_before, nw, p->rank_bsum);
@@ -1327,6 +1344,7 @@ int odr_particles_set_rank_offset(odr_ctx *c, odr_particles *p, int64_t offset) 
   (void)c;
   REQUIRE(p && offset >= 0 && offset < (1ll << 30), "bad rank offset");
   p->rank_offset = offset;
+  p->rank_sharded = 1;
   return 0;
 }
 

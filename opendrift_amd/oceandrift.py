@@ -771,6 +771,12 @@ class OpenDriftSimulation(Configurable):
     def _host_bindings(self):
         return [(n, b) for n, b in self.readers.items() if getattr(b, 'host_eval', False)]
 
+    def _ensemble_current(self):
+        """The current comes (also) from a reader that hands it out as a list of ensemble members."""
+        return any(
+            b.sid is not None and self.ctx._grids.get(b.sid, {}).get('members') and
+            ('x_sea_water_velocity' in b.variables or 'y_sea_water_velocity' in b.variables) for b in self.readers.values())
+
     def _sample_host_readers(self, names, P=None, time=None):
         """Readers evaluated on the host (user-defined ContinuousReaders): where such a reader comes BEFORE the device
         sources of a variable its finite values replace what the device sampled (the priority-list walk of
@@ -818,6 +824,8 @@ class OpenDriftSimulation(Configurable):
         S = self.ctx.particles(n)
         try:
             S.append(d['lon'], d['lat'], z=d['z'], id=d['ID'])
+            if self._world > 1:      # ensemble members: the elements the lower ranks hold come first
+                S.set_rank_offset(self._below_active)
 
             def stage(k, u, v, t):
                 if k:
@@ -880,8 +888,10 @@ class OpenDriftSimulation(Configurable):
         scheme = self.get_config('drift:advection_scheme')
         std, ustd = self._current_uncertainty()
         nstage = {'runge-kutta': 1, 'runge-kutta4': 3}.get(scheme, 0)
-        if nstage and any('x_sea_water_velocity' in b.variables or 'y_sea_water_velocity' in b.variables
-                          for _, b in self._host_bindings()):
+        if nstage and (any('x_sea_water_velocity' in b.variables or 'y_sea_water_velocity' in b.variables
+                           for _, b in self._host_bindings()) or self._ensemble_current()):
+            # (ensemble data: every stage call numbers the elements its block is handed -- the ones the reader covers at the
+            # STAGE positions -- anew, interpolation/structured.py:119-135; a launch that holds all stages cannot)
             return self._advect_stage_split(scheme, factor)
         if nstage and (std > 0 or ustd > 0):
             # every Runge-Kutta stage is a get_environment call of the current: it carries the uncertainty too
@@ -1124,6 +1134,7 @@ class OpenDriftSimulation(Configurable):
                       not self.get_config('general:coastline_approximation_precision') and
                       'x_sea_water_velocity' in self.required_variables and 'y_sea_water_velocity' in self.required_variables and
                       not self._host_bindings() and
+                      not (self._ensemble_current() and self.get_config('drift:advection_scheme') != 'euler') and
                       # report_missing_variables comes BEFORE deactivate_outside in the loop (:2251-2253) but sits inside the
                       # launch: an element both outside the domain and without data must end as 'missing_data'
                       not (any(self.get_config('drift:deactivate_%s_of' % k) is not None for k in ('west', 'east', 'south', 'north'))

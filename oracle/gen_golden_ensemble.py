@@ -38,7 +38,9 @@ class EnsembleGridReader(gg.GridReader):
         return out
 
 
-def run(tag, three_d):
+def run(tag, three_d, partial=False):
+    """partial: a quarter of the elements start WEST of the reader's domain (fallback current carries them in): the block
+    numbers only the elements handed to it -- the covered ones (variables.py:747-765 ind_covered)."""
     nx, ny, nt, M = 48, 36, 3, 3
     x = np.linspace(3.0, 6.0, nx).astype(np.float32)
     y = np.linspace(59.0, 61.0, ny).astype(np.float32)
@@ -66,9 +68,15 @@ def run(tag, three_d):
     o.set_config('general:coastline_action', 'stranding')
     o.set_config('general:coastline_approximation_precision', None)
     o.set_config('drift:stokes_drift', False)
+    if partial:
+        o.set_config('environment:fallback:x_sea_water_velocity', 1.5)
+        o.set_config('environment:fallback:y_sea_water_velocity', 0.1)
+        o.set_config('environment:fallback:land_binary_mask', 0)
     rng = np.random.default_rng(17)
     N = 200
     lon = rng.uniform(4.4, 5.34, N)
+    if partial:
+        lon[::4] = rng.uniform(2.93, 2.999, len(lon[::4]))      # outside [3, 6]: 1.5 m/s eastward brings them in within a few steps
     lat = rng.uniform(59.3, 60.7, N)
     zz = -rng.uniform(0, 25, N) if three_d else np.zeros(N)
     np.random.seed(0)
@@ -82,8 +90,8 @@ def run(tag, three_d):
 
 def main():
     out = {}
-    for tag, three_d in (('2d', False), ('3d', True)):
-        res, g, zlev = run(tag, three_d)
+    for tag, three_d in (('2d', False), ('3d', True), ('partial', False)):
+        res, g, zlev = run(tag, three_d, partial=tag == 'partial')
         out.update(res)
         out.update({('%s_g_%s' % (tag, k)): v for k, v in g.items()})
         if zlev is not None:

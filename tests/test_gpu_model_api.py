@@ -725,24 +725,38 @@ def test_seed_at_and_above_the_seafloor():
         o.seed_elements(lon=4.0, lat=60.0, z='seafloor', time=T0)
 
 
-@pytest.mark.parametrize('tag', ['2d', '3d'])
+@pytest.mark.parametrize('tag', ['2d', '3d', 'partial'])
 def test_c17_ensemble_reader_device_and_model_run(tag):
     """Ensemble data (a reader that hands a variable out as a list of member arrays; element j of a call takes member
     j % M, readers/interpolation/structured.py:119-135): the device kernels against the oracle and the reference's own
-    run (golden c17, RK4 + stranding so that the ranks shift), then the same through OceanDrift.run()."""
+    run (golden c17, RK4 + stranding so that the ranks shift), then the same through OceanDrift.run().
+    'partial': a quarter of the elements start outside the reader's domain and drift in -- the members are numbered among
+    the elements HANDED to the block, the covered ones (variables.py:747-765), in every get_environment call: the main
+    sample (odr_env_sample numbers the covered elements) and each Runge-Kutta stage call at ITS positions, which a launch
+    holding all stages cannot do -- the model takes the stage-split lane for ensemble currents; the one-launch replay of the
+    C ABI is checked on the cases where the reader covers everything."""
     import replay
     from opendrift_amd.device import Context
     g = golden('c17_ensemble_reader.npz')
     sub = {k: g['%s_%s' % (tag, k)] for k in ('lon', 'lat', 'z', 'status')}
     ns = sub['lon'].shape[0] - 1
-    dev = replay.replay_c17(replay.DeviceBackend(replay.scenario_c17(g, tag), Context(seed=0), sub['lon'][0], sub['lat'][0],
-                                                 sub['z'][0], wdf=0.0), g, tag, ns)
-    orc = replay.replay_c17(replay.OracleBackend(replay.scenario_c17(g, tag), sub['lon'][0], sub['lat'][0], sub['z'][0],
-                                                 wdf=0.0), g, tag, ns)
-    for k, ((lo1, la1, z1, s1), (lo2, la2, z2, s2)) in enumerate(zip(dev, orc)):
-        assert np.array_equal(s1, s2)
-        assert np.nanmax(np.abs(lo1 - lo2)) < 1e-10 * (k + 1) and np.nanmax(np.abs(la1 - la2)) < 1e-10 * (k + 1)
-    replay.compare(dev, sub, tol_pos=1e-7, tol_z=1e-5)
+    if tag != 'partial':
+        dev = replay.replay_c17(replay.DeviceBackend(replay.scenario_c17(g, tag), Context(seed=0), sub['lon'][0], sub['lat'][0],
+                                                     sub['z'][0], wdf=0.0), g, tag, ns)
+        orc = replay.replay_c17(replay.OracleBackend(replay.scenario_c17(g, tag), sub['lon'][0], sub['lat'][0], sub['z'][0],
+                                                     wdf=0.0), g, tag, ns)
+        for k, ((lo1, la1, z1, s1), (lo2, la2, z2, s2)) in enumerate(zip(dev, orc)):
+            assert np.array_equal(s1, s2)
+            assert np.nanmax(np.abs(lo1 - lo2)) < 1e-10 * (k + 1) and np.nanmax(np.abs(la1 - la2)) < 1e-10 * (k + 1)
+        replay.compare(dev, sub, tol_pos=1e-7, tol_z=1e-5)
+    else:
+        # the main-loop sample on its own: device == oracle on the members of the covered elements (first call: 50 of 200 outside)
+        B = replay.DeviceBackend(replay.scenario_c17(g, tag), Context(seed=0), sub['lon'][0], sub['lat'][0], sub['z'][0], wdf=0.0)
+        O = replay.OracleBackend(replay.scenario_c17(g, tag), sub['lon'][0], sub['lat'][0], sub['z'][0], wdf=0.0)
+        B.sample([replay.U, replay.VV, replay.LAND], 0.0)
+        O.sample([replay.U, replay.VV, replay.LAND], 0.0)
+        ud, uo = B.P.env_download(replay.U), np.asarray(O.env[replay.U], dtype=np.float32)
+        assert np.array_equal(ud, uo) and (sub['lon'][0] < 3.0).sum() == 50 and (ud == np.float32(1.5)).sum() == 50
     # the model API
     M = int(g['members'])
     q = lambda k: g['%s_g_%s' % (tag, k)]
@@ -761,6 +775,10 @@ def test_c17_ensemble_reader_device_and_model_run(tag):
     o.set_config('general:coastline_approximation_precision', None)
     o.set_config('drift:stokes_drift', False)
     o.set_config('drift:vertical_mixing', False)
+    if tag == 'partial':
+        o.set_config('environment:fallback:x_sea_water_velocity', 1.5)
+        o.set_config('environment:fallback:y_sea_water_velocity', 0.1)
+        o.set_config('environment:fallback:land_binary_mask', 0)
     o.seed_elements(lon=sub['lon'][0], lat=sub['lat'][0], z=sub['z'][0], time=T0, wind_drift_factor=0.0)
     o.run(time_step=float(g['dt']), steps=ns)
     n = sub['lon'].shape[1]

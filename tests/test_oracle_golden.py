@@ -291,10 +291,12 @@ def test_c16_openoil_in_sea_ice_vs_oracle():
     assert np.abs(B0.lon - g['lon'][1]).max() > 1e-4
 
 
-@pytest.mark.parametrize('tag', ['2d', '3d'])
+@pytest.mark.parametrize('tag', ['2d', '3d', 'partial'])
 def test_c17_ensemble_members_of_a_reader_vs_oracle(tag):
     """ReaderBlock ensembles (readers/interpolation/structured.py:119-135): golden c17 = the reference's own OceanDrift on
-    a reader that hands the current out as a list of three member arrays, RK4 + stranding."""
+    a reader that hands the current out as a list of three member arrays, RK4 + stranding.  'partial': a quarter of the
+    elements start outside the reader's domain (fallback current) -- the members are numbered among the elements handed to
+    the block, i.e. the covered ones (variables.py:747-765)."""
     g = golden('c17_ensemble_reader.npz')
     sub = {k: g['%s_%s' % (tag, k)] for k in ('lon', 'lat', 'z', 'status')}
     B = replay.OracleBackend(replay.scenario_c17(g, tag), sub['lon'][0], sub['lat'][0], sub['z'][0], wdf=0.0)
