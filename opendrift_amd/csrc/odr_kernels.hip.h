@@ -549,19 +549,6 @@ __device__ __forceinline__ float pick_slot(const float (&a)[MAXG], int j) {
   return r;
 }
 
-// the same with a plain (not volatile) opaque move: the compiler may schedule memory operations across it -- used where several
-// picks sit in the middle of the step launch (the movers' tests)
-__device__ __forceinline__ float pick_slot_nv(const float (&a)[MAXG], int j) {
-  float r = a[0];
-#pragma unroll
-  for (int k = 1; k < MAXG; ++k) {
-    float v = a[k];
-    asm("" : "+v"(v));
-    r = j == k ? v : r;
-  }
-  return r;
-}
-
 #ifdef ODR_TU_MISC
 // ------------------------------------------------------------------ environment
 // Environment.get_environment for one variable group of NV variables
@@ -793,40 +780,6 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-// Maximum over the 64 lanes of a wave with data-parallel-primitive moves (VALU only; the __shfl_xor ladder above goes through
-// the LDS crossbar: 6 dependent ds_bpermute per value): inclusive scan inside the rows of 16 (row_shr 1, 2, 4, 8), then the
-// last lane of rows 0 and 2 into rows 1 and 3 (row_bcast:15), then lane 31 into rows 2 and 3 (row_bcast:31): lane 63 holds
-// the maximum, read back as a wave-uniform value.  Lanes without a source keep their own value.
-#define ODR_DPP_MAX_F(v, ctrl, rows) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rows, 0xf, false)))
-__device__ __forceinline__ float wave_max_f(float v) {
-  ODR_DPP_MAX_F(v, 0x111, 0xf); ODR_DPP_MAX_F(v, 0x112, 0xf); ODR_DPP_MAX_F(v, 0x114, 0xf); ODR_DPP_MAX_F(v, 0x118, 0xf);
-  ODR_DPP_MAX_F(v, 0x142, 0xa); ODR_DPP_MAX_F(v, 0x143, 0xc);
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-#undef ODR_DPP_MAX_F
-__device__ __forceinline__ double dpp_move_d(double v, int ctrl, int rows) {
-  const long long b = __double_as_longlong(v);
-  int lo = (int)(unsigned)(b & 0xffffffffll), hi = (int)(b >> 32);
-  switch (ctrl) {   // the control word must be a literal
-    case 0x111: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x111, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x111, 0xf, 0xf, false); break;
-    case 0x112: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x112, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x112, 0xf, 0xf, false); break;
-    case 0x114: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x114, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x114, 0xf, 0xf, false); break;
-    case 0x118: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x118, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x118, 0xf, 0xf, false); break;
-    case 0x142: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x142, 0xa, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x142, 0xa, 0xf, false); break;
-    default:    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x143, 0xc, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x143, 0xc, 0xf, false); break;
-  }
-  (void)rows;
-  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
-}
-__device__ __forceinline__ double wave_max_dpp(double v) {
-  v = fmax(v, dpp_move_d(v, 0x111, 0xf)); v = fmax(v, dpp_move_d(v, 0x112, 0xf)); v = fmax(v, dpp_move_d(v, 0x114, 0xf));
-  v = fmax(v, dpp_move_d(v, 0x118, 0xf)); v = fmax(v, dpp_move_d(v, 0x142, 0xa)); v = fmax(v, dpp_move_d(v, 0x143, 0xc));
-  const long long b = __double_as_longlong(v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffll), 63);
-  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
-  return __longlong_as_double(((long long)hi << 32) | (long long)lo);
-}
-
 #ifdef ODR_TU_STEP
 // One launch for  get_environment -> interact_with_coastline -> update_previous_state ->
 // advect_ocean_current  (the run() loop order, basemodel/__init__.py:2136-2248) when the group that
@@ -907,9 +860,7 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
     __syncthreads();
   }
   // this lane's share of the movers' tests (S.red_on): neutral unless it holds an element that stays active
-  float r_hd = -__builtin_inff(), r_st = -__builtin_inff(), r_rws = -__builtin_inff();
-  double r_wdf = -__builtin_inf();
-  bool r_surf = false;
+  unsigned r_bits = 0;   // 1 D > 0, 2 D == 0, 4 Stokes sum > 0, 8 == 0, 16 at the surface, 32 wind drift factor > 0, 64 == 0, 128 wind speed > 0, 256 == 0
   if (i < p.n) {
     double lon = p.lon[i], lat = p.lat[i];
     const double z = p.z[i];
@@ -919,13 +870,8 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
     int st = p.status[i];
     const float age0 = p.age[i], cdf0 = p.cdf[i];
     const float ssh0 = (S.seafloor || MIXQ > 0) && p.env[VAR_SSH] ? p.env[VAR_SSH][i] : 0.f;
-    // (the movers' tests, below: what they read from arrays is requested here, with the rest of the particle's state -- a load
-    // behind the status decisions is a memory round trip of its own in every wave: 0.10 ms of this launch at 6.25 M elements)
-    constexpr bool RED = !IS3D && MIXQ == 0;
+    constexpr bool RED = !IS3D && MIXQ == 0;      // (the movers' tests, below)
     const float wdf0 = (RED && S.red_on && S.red_xw > -2) ? p.wdf[i] : 0.f;
-    const float e_hd = (RED && S.red_on && S.red_hd == -1) ? p.env[VAR_HDIFF][i] : 0.f;
-    const float e_sx = (RED && S.red_on && S.red_sx == -1) ? p.env[VAR_SX][i] : 0.f, e_sy = (RED && S.red_on && S.red_sx == -1) ? p.env[VAR_SY][i] : 0.f;
-    const float e_xw = (RED && S.red_on && S.red_xw == -1) ? p.env[VAR_XWIND][i] : 0.f, e_yw = (RED && S.red_on && S.red_xw == -1) ? p.env[VAR_YWIND][i] : 0.f;
     ODR_PT_USE(lon); ODR_PT_USE(lat); ODR_PT_USE(z); ODR_PT(1);
     float out[MAXG];
     ZBracket zb_env;
@@ -947,6 +893,16 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
       p.slat[i] = lat;
     }
 #endif
+    // the movers' tests: the five values they need, read back from the arrays (just stored above, or sampled by the launch
+    // before this one) -- requested here, used at the very end of the kernel.  Picking them out of the group's registers
+    // by run-time slot cost 70 instructions of select chains in a kernel that is bound by instruction issue (C4: +258
+    // instructions per wave with the first version, 0.59 -> 0.65 ms).
+    float l_hd = 0.f, l_sx = 0.f, l_sy = 0.f, l_xw = 0.f, l_yw = 0.f;
+    if (RED && S.red_on) {
+      if (S.red_hd > -2) l_hd = p.env[VAR_HDIFF][i];
+      if (S.red_sx > -2) { l_sx = p.env[VAR_SX][i]; l_sy = p.env[VAR_SY][i]; }
+      if (S.red_xw > -2) { l_xw = p.env[VAR_XWIND][i]; l_yw = p.env[VAR_YWIND][i]; }
+    }
     double zz = z;
     if (S.missing_code) {  // k_deactivate_missing
       bool miss = false;
@@ -995,35 +951,6 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
     }
     // deactivated (now or earlier, not yet compacted): the reference removes it before update() -- it does not move
     const bool skip = st != 0;
-    // (2-D readers only: a 3-D run mixes vertically between this launch and the movers, which changes z and voids the tests;
-    // the 3-D instantiations carry no code for it -- k_step_grid<RK4, lat/lon, 3-D> stays at 126 registers)
-    // Measured at 6.25 M elements (C4, polar stereographic: 89 KB of code, the one launch with instruction-cache misses in
-    // its counters): these ~150 instructions cost the launch 0.06 ms -- with the wind part compiled out 0.00, with constants
-    // in place of the whole block -0.03 -- against the 0.107 ms pass + its launch they replace (profiles/r04_ab_variants.txt 10).
-    if (!IS3D && MIXQ == 0 && S.red_on && !skip) {   // k_reduce<false> for this element (z is final here: the advection below is horizontal)
-      if (S.red_hd > -2) r_hd = S.red_hd >= 0 ? pick_slot_nv(out, S.red_hd) : e_hd;
-      if (S.red_sx > -2) {
-        const float sx = S.red_sx >= 0 ? pick_slot_nv(out, S.red_sx) : e_sx;
-        const float sy = S.red_sx >= 0 ? pick_slot_nv(out, S.red_sx + 1) : e_sy;
-        r_st = __fadd_rn(sx, sy);
-      }
-      if (S.red_xw > -2) {
-        const double wdd = fabs(S.red_wdd);
-        if (zz >= -wdd) {
-          float xa = S.red_xw >= 0 ? pick_slot_nv(out, S.red_xw) : e_xw;
-          float ya = S.red_xw >= 0 ? pick_slot_nv(out, S.red_xw + 1) : e_yw;
-          double wdf = wdf0;
-          if (S.red_wdd != 0) {
-            wdf = div_cr(wdf * (wdd + zz), wdd, S.red_iwdd);   // == wdf * (wdd + z) / wdd, correctly rounded (k_reduce)
-            if (zz > 0) wdf = wdf0;
-          }
-          r_surf = true;
-          r_wdf = wdf;
-          if (S.red_rel) { xa = __fsub_rn(xa, out[0]); ya = __fsub_rn(ya, out[1]); }
-          r_rws = speed_f32(xa, ya);     // (the plain wind speed maximum is not read by any mover: not formed)
-        }
-      }
-    }
 #ifndef ODR_ABLATE_STORES
     if (S.store_previous) { p.plon[i] = lon; p.plat[i] = lat; }
 #endif
@@ -1056,6 +983,26 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
       }
       p.z[i] = zn;
     }
+    // (2-D readers only: a 3-D run mixes vertically between this launch and the movers, which changes z and voids the tests;
+    // the 3-D instantiations carry no code for it -- k_step_grid<RK4, lat/lon, 3-D> stays at 126 registers)
+    if (RED && S.red_on && !skip) {   // k_reduce<false> for this element, as signs: every test is `maximum == 0`
+      if (S.red_hd > -2) r_bits |= (l_hd > 0.f ? 1u : 0u) | (l_hd == 0.f ? 2u : 0u);
+      if (S.red_sx > -2) { const float st_sum = __fadd_rn(l_sx, l_sy); r_bits |= (st_sum > 0.f ? 4u : 0u) | (st_sum == 0.f ? 8u : 0u); }
+      if (S.red_xw > -2) {
+        const double wdd = fabs(S.red_wdd);
+        if (zz >= -wdd) {
+          double wdf = wdf0;
+          if (S.red_wdd != 0) {
+            wdf = div_cr(wdf * (wdd + zz), wdd, S.red_iwdd);   // == wdf * (wdd + z) / wdd, correctly rounded (k_reduce)
+            if (zz > 0) wdf = wdf0;
+          }
+          float xa = l_xw, ya = l_yw;
+          if (S.red_rel) { xa = __fsub_rn(xa, out[0]); ya = __fsub_rn(ya, out[1]); }
+          const float rws = speed_f32(xa, ya);
+          r_bits |= 16u | (wdf > 0 ? 32u : 0u) | (wdf == 0 ? 64u : 0u) | (rws > 0.f ? 128u : 0u) | (rws == 0.f ? 256u : 0u);
+        }
+      }
+    }
     p.lon[i] = lon;
     p.lat[i] = lat;
 #ifdef ODR_PHASE_TIMING
@@ -1073,15 +1020,20 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
   }
   if (!IS3D && MIXQ == 0 && S.red_on) {
     // one record of six doubles per WAVE, written by its lanes 0..5 in one store; k_red_finish folds the records into
-    // red[].  (Atomics on red[] from here -- one per wave and slot, made only when they would raise the value -- took this
-    // launch from 0.59 to 0.79-0.87 ms at 6.25 M elements: every wave ends on dependent, coherent reads of the same lines.)
-    const float m_hd = wave_max_f(r_hd), m_st = wave_max_f(r_st), m_rws = wave_max_f(r_rws);
-    const double m_wdf = wave_max_dpp(r_wdf);
-    const unsigned long long bs = __ballot(r_surf);
+    // red[].  A slot holds +1 (some element > 0), 0 (none > 0, some == 0) or -inf: what `maximum == 0` needs, from nine
+    // wave votes -- not the maximum itself (the host marks the reduction `partial`; the wind speed slot nobody tests stays
+    // -inf, the surface slot counts the elements).  (Atomics on red[] from here -- one per wave and slot, made only when they
+    // would raise the value -- took this launch from 0.59 to 0.79-0.87 ms at 6.25 M elements: every wave ends on dependent,
+    // coherent reads of the same lines.  True maxima by DPP reductions: ~80 instructions more per wave.)
+    const unsigned long long b1 = __ballot(r_bits & 1u), b2 = __ballot(r_bits & 2u), b4 = __ballot(r_bits & 4u), b8 = __ballot(r_bits & 8u);
+    const unsigned long long bs = __ballot(r_bits & 16u), b32 = __ballot(r_bits & 32u), b64 = __ballot(r_bits & 64u);
+    const unsigned long long b128 = __ballot(r_bits & 128u), b256 = __ballot(r_bits & 256u);
     const unsigned lane = threadIdx.x & 63u;
     if (lane < 6u) {
-      const double v = lane == 0 ? (double)m_hd : lane == 1 ? (double)m_st : lane == 2 ? (S.red_rel ? -__builtin_inf() : (double)m_rws)
-                     : lane == 3 ? (double)m_rws : lane == 4 ? m_wdf : (double)__popcll(bs);
+      const double ninf = -__builtin_inf();
+      auto sgn = [&](unsigned long long pos, unsigned long long zero) { return pos ? 1.0 : (zero ? 0.0 : ninf); };
+      const double v = lane == 0 ? sgn(b1, b2) : lane == 1 ? sgn(b4, b8) : lane == 2 ? ninf
+                     : lane == 3 ? sgn(b128, b256) : lane == 4 ? sgn(b32, b64) : (double)__popcll(bs);
       S.red[((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 6 + lane] = v;
     }
   }

@@ -2,6 +2,7 @@
 # round 4, GPU call T: where the cost of the in-launch tests sits (what-if builds)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04t; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_movers.py tests/test_gpu_fused_step.py -x -q 2>&1 | tail -3
 export ODR_BENCH_ONE_MODE=1
 run() {  # name, env...
   name=$1; shift
@@ -17,6 +18,6 @@ PY
 }
 run pass ODR_BENCH_REDUCE_PASS=1
 run launch
-run late ODR_LIB=$PWD/tools/_libB.so
-run no_wind ODR_LIB=$PWD/tools/_libC.so
+
+
 run off_in_kernel ODR_NO_STEP_REDUCE=1
