@@ -501,7 +501,18 @@ __device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, con
     }
     wb[j] = b;
   }
-  for (int it = 0; it < ntimes; ++it) {
+  // the sub-steps in groups of five = one Philox block: inside the unrolled group the word a sub-step takes from the block is
+  // known at compile time (a run-time `it % 5` costs a chain of selects and the fifth word's assembly in every sub-step)
+  for (int it0 = 0; it0 < ntimes; it0 += 5) {
+  if (rng_mode == 0 && !(primed && it0 == 0)) u4 = mix_block(st, (unsigned)it0 / 5u);
+#ifdef ODR_VMIX_NO_UNROLL   // A/B build: the word selected at run time, as in rounds 1-3
+#pragma unroll 1
+#else
+#pragma unroll
+#endif
+  for (int k5 = 0; k5 < 5; ++k5) {
+    const int it = it0 + k5;
+    if (it >= ntimes) break;
     const bool surface = z == 0;
     const double d = -z;
     int q = (d > wb[1] ? 1 : 0) + (d > wb[2] ? 1 : 0);
@@ -517,7 +528,7 @@ __device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, con
     if (q < 0 || q > 2) level_terms(zi, dKdt, sig);
     double R;
     if (rng_mode == 1) R = __dsub_rn(__dmul_rn(2.0, A.huni[(size_t)it * n + i]), 1.0);
-    else R = mix_R_of(mix_draw(st, u4, it, primed));
+    else R = mix_R_of(mix_word(u4, (unsigned)k5));
     z = __dsub_rn(z, __dmul_rn((double)moving, __dsub_rn(dKdt, __dmul_rn(R, sig))));
     if (z >= 0) z = -z;
     if (z < (double)Zmin && moving == 1) z = __dsub_rn((double)__fmul_rn(2.f, Zmin), z);
@@ -532,6 +543,7 @@ __device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, con
         if (act == 2) { sf_flags |= 1; moving = 0; wstep = 0.0; }
       }
     }
+  }
   }
   return z;
 }
