@@ -1,7 +1,8 @@
 #!/bin/bash
-# round 4, final GPU call: the bench lines that go into profiles/ and the c4 / c5 profiles after the last kernel changes
+# round 4, final GPU call: full GPU suite, the bench lines that go into profiles/, all profiles after the last kernel changes
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04_final; mkdir -p $O
+timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 | tee $O/r04_final_gpu_tests.txt
 timeout 900 python bench.py > $O/bench_default.log 2>&1; grep "^{" $O/bench_default.log | tail -1 > $O/r04_c3_bench_line.json
 timeout 600 python bench.py --steps 20 --no-cpu > $O/bench_s20.log 2>&1; grep "^{" $O/bench_s20.log | tail -1 > $O/r04_c3_bench_line_steps20.json
 for w in c2 c4 c5; do
@@ -18,4 +19,4 @@ for n in ('r04_c3_bench_line', 'r04_c3_bench_line_steps20', 'r04_c2_bench_line',
     except Exception as e:
         print(n, 'failed', e)
 PY
-bash tools/gpu_profile_r04.sh c4 c5 2>&1 | tail -12
+bash tools/gpu_profile_r04.sh c3 c4 c5 2>&1 | tail -4
