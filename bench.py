@@ -45,6 +45,7 @@ BYTES = {
     'c5': dict(step=220, advect=88, fused=220 - 8),   # fused = k_step_leeway: the whole step but the compaction's status scan
 }
 HBM_PEAK = 8.0e12
+HBM_ACHIEVABLE = 6.3e12   # what a streaming kernel reaches on MI355X (/opt/skills/guides/MI355X_MICROARCH.md, HBM section)
 
 
 def make_fields(workload, small=False):
@@ -691,24 +692,40 @@ def main():
     other_mode, other = ('exact' if a.stage_math == 'fast' else 'fast'), None
     if a.workload != 'c5' and not a.block_every and not os.environ.get('ODR_BENCH_ONE_MODE'):
         ctx.set_stage_math(other_mode)
-        nst_o = max(8, a.steps // 4)
-        for k in range(2):
-            wl.step(P, spin + a.warmup + a.steps + k)
-        el_o, units_o = timed_loop(nst_o, spin + a.warmup + a.steps + 2)
+        # a measurement of its own, whatever --steps says: >= 48 steps that span two re-sorts (a whole number of re-sort
+        # intervals, so that the share of the re-sort in the mean is the steady one), after 8 untimed steps in that mode
+        # (round 4 timed 8 steps without a re-sort among them: 11 % off the 100-step figure)
+        se = wl.sort_every if (wl.sort_every and a.workload != 'c2') else 1
+        nst_o = max(48, a.steps // 4)
+        nst_o = -(-nst_o // se) * se
+        first_o = spin + a.warmup + a.steps
+        for k in range(8):
+            wl.step(P, first_o + k)
+        el_o, units_o = timed_loop(nst_o, first_o + 8)
         el_o = float(D.allreduce_scalars([el_o], 'max')[0])
         units_o = float(D.allreduce_scalars([units_o], 'sum')[0])
-        ko_ms, _ = launch_ms(wl.dominant_kernel)
-        other = dict(value=units_o / el_o, unit='particle-steps/s', ms_per_step=1e3 * el_o / nst_o, steps=nst_o, kernel_ms=ko_ms)
+        if a.workload != 'c2' and wl.sort_every:
+            P.sort_by_cell(wl.sid)
+        ko_ms, ko_med = launch_ms(wl.dominant_kernel)
+        other = dict(value=units_o / el_o, unit='particle-steps/s', ms_per_step=1e3 * el_o / nst_o, steps=nst_o, untimed_steps_before=8,
+                     re_sorts_inside=(nst_o // se if se > 1 else 0), kernel_ms=ko_ms, kernel_ms_median=ko_med)
+        if a.workload == 'c3':
+            other['second_kernel_ms'] = launch_ms(wl.second_kernel)[0]
         ctx.set_stage_math(a.stage_math)
 
     # counters of the same command from the committed rocprofv3 passes (profiles/r04_<workload>_pmc.json, written by
     # tools/gpu_profile_r04.sh + tools/collect_profiles_r04.py from this tree): PMC counters cannot be collected from inside
     # this process.  Used only when they belong to this size and stage math.
-    pmc, pmc_file = None, os.path.join('profiles', 'r04_%s_pmc.json' % a.workload)
-    if os.path.exists(os.path.join(ROOT, pmc_file)):
-        pm = json.load(open(os.path.join(ROOT, pmc_file)))
-        if pm.get('particles') == n and pm.get('stage_math', a.stage_math) == a.stage_math:
-            pmc = pm
+    def load_pmc(mode):
+        for r in ('r05', 'r04'):
+            f = os.path.join('profiles', '%s_%s_pmc%s.json' % (r, a.workload, '' if mode == 'fast' else '_' + mode))
+            if os.path.exists(os.path.join(ROOT, f)):
+                pm = json.load(open(os.path.join(ROOT, f)))
+                if pm.get('particles') == n and pm.get('stage_math', mode) == mode:
+                    return pm, f
+        return None, None
+    pmc, pmc_file = load_pmc(a.stage_math)
+    pmc_other, pmc_other_file = load_pmc(other_mode)
     extras = {}
     if rank == 0 and world == 1 and not a.no_extras and a.workload == 'c3' and not a.small and not a.block_every:
         # (0) the drop-in surface: OceanDrift.run() on the same inputs, in a context of its own (first of the extra legs: it
@@ -781,6 +798,7 @@ def main():
             out['roofline'] = {
                 'bound': 'hbm', 'kernel': kname, 'kernel_ms': k_ms, 'kernel_ms_median': k_ms_median,
                 'achieved': hbm_bytes / (k_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': un['hbm'],
+                'frac_of_achievable': hbm_bytes / (k_ms * 1e-3) / HBM_ACHIEVABLE, 'achievable': HBM_ACHIEVABLE / 1e9,
                 'traffic': hbm_bytes / 1e9, 'traffic_unit': 'GB of HBM traffic per launch (FETCH_SIZE x 2 + WRITE_SIZE)',
                 'algorithmic_gb_per_launch': kbytes * nact / 1e9,
                 'units': un, 'binding_unit': max((k for k in un if not k.endswith('diagnostic')), key=lambda k: un[k]),
@@ -796,6 +814,7 @@ def main():
                 sb = pmc['step_hbm_bytes']
                 out['roofline_step'] = {'bound': 'hbm', 'achieved': sb / (el_max / a.steps) / 1e9,
                                         'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': sb / (el_max / a.steps) / HBM_PEAK,
+                                        'frac_of_achievable': sb / (el_max / a.steps) / HBM_ACHIEVABLE,
                                         'traffic': sb / 1e9, 'kernels': pmc.get('step_hbm_kernels'),
                                         'note': 'HBM bytes of ALL kernels of one step (counters, calls per step from the kernel trace) / ms_per_step / 8 TB/s'}
         else:
@@ -811,6 +830,16 @@ def main():
             ts = P.tile_stats()     # the LDS-tile step (csrc/odr_tile.hip.h): launches on that path / elements it handed to the HBM path
             out['lds_tile'] = dict(ts, handed_over_per_launch=(ts['handed_over'] / ts['launches'] if ts['launches'] else None))
         if other is not None:
+            # the other arithmetic's launch against the same peak: its own counter file when one was collected
+            # (profiles/r05_<workload>_pmc_<mode>.json), else the bytes of the headline mode's launch -- the two arithmetics
+            # read and write the same particle state and node records (the counters of both agree to < 1 %)
+            src_pm, src_f = (pmc_other, pmc_other_file) if pmc_other is not None else (pmc, pmc_file)
+            if src_pm is not None:
+                hb_o = src_pm['FETCH_SIZE_bytes_x2'] + src_pm['WRITE_SIZE_bytes']
+                other['roofline'] = {'bound': 'hbm', 'kernel': kname, 'kernel_ms': other['kernel_ms'], 'traffic': hb_o / 1e9,
+                                     'achieved': hb_o / (other['kernel_ms'] * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                                     'frac': hb_o / (other['kernel_ms'] * 1e-3) / HBM_PEAK,
+                                     'frac_of_achievable': hb_o / (other['kernel_ms'] * 1e-3) / HBM_ACHIEVABLE, 'source': src_f}
             out['stage_math_' + other_mode] = other
         out.update(extras)
         if not a.no_cpu and world == 1:

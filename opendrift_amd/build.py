@@ -53,3 +53,23 @@ def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir=OBJDIR):
 if __name__ == '__main__':
     import sys
     print(build(force='--force' in sys.argv, verbose=True))
+
+
+def build_variant(tag, units, extra_flags, outdir=None):
+    """A/B library tools/_lib<tag>.so: only `units` are compiled with `extra_flags`, the other translation units are the
+    default build's objects (tools/vbuild_tu.sh; a what-if flag usually touches one kernel family)."""
+    build()
+    outdir = outdir or os.path.join(os.path.dirname(HERE), 'tools')
+    objdir = os.path.join(outdir, '_obj' + tag)
+    os.makedirs(objdir, exist_ok=True)
+
+    def run(u):
+        obj = os.path.join(objdir, u.replace('.hip', '.o'))
+        subprocess.check_call([HIPCC] + FLAGS + list(extra_flags) + ['-c', os.path.join(CSRC, u), '-o', obj])
+        return obj
+    with ThreadPoolExecutor(len(units)) as ex:
+        mine = dict(zip(units, ex.map(run, units)))
+    objs = [mine.get(u, os.path.join(OBJDIR, u.replace('.hip', '.o'))) for u in UNITS]
+    lib = os.path.join(outdir, '_lib%s.so' % tag)
+    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs)
+    return lib

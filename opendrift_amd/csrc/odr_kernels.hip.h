@@ -297,9 +297,17 @@ __device__ __forceinline__ void add_current_noise(const StageNoise &N, int call,
 // block number) instead of advancing a generator state.  (Rounds 1-3 drew the same words through rocrand's state object,
 // whose init and every rocrand4() each evaluate a block ahead: three blocks for the two that ten sub-steps consume.)
 // Known answers: tests/test_philox.py (oracle/philox.py against the Random123 vectors), tests/test_gpu_parity.py.
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, unsigned k0, unsigned k1) {
+// ODR_MIX_ROUNDS: rounds of the mixing loop's blocks.  Philox4x32-7 is the smallest member of the family the paper reports as
+// passing BigCrush (its Table 2; 10 rounds is the library default with a safety margin); a block costs 154 instead of 305 issue
+// cycles per wave on MI355X (profiles/r04_rng_cost.txt).  odr_version() names the count; oracle/philox.py restates it and is
+// pinned on the Random123 known answers of BOTH counts (tests/test_philox.py).
+#ifndef ODR_MIX_ROUNDS
+#define ODR_MIX_ROUNDS 10
+#endif
+template <int ROUNDS>
+__device__ __forceinline__ uint4 philox4x32(uint4 c, unsigned k0, unsigned k1) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < ROUNDS; ++r) {
     const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x, p1 = (unsigned long long)0xCD9E8D57u * c.z;
     c = make_uint4((unsigned)(p1 >> 32) ^ c.y ^ k0, (unsigned)p1, (unsigned)(p0 >> 32) ^ c.w ^ k1, (unsigned)p0);
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -321,7 +329,7 @@ __device__ __forceinline__ MixKey mix_key(unsigned long long seed, unsigned long
   return K;
 }
 __device__ __forceinline__ uint4 mix_block(const MixKey &K, unsigned b) {
-  return philox4x32_10(make_uint4(b, K.step_lo, K.id, K.tag), K.k0, K.k1);
+  return philox4x32<ODR_MIX_ROUNDS>(make_uint4(b, K.step_lo, K.id, K.tag), K.k0, K.k1);
 }
 __device__ __forceinline__ unsigned mix_word(const uint4 &q, unsigned k) {
   const unsigned lo = ((q.x & 255u) << 16) | ((q.y & 255u) << 8) | (q.z & 255u);
@@ -356,9 +364,14 @@ struct VMixDesc {
 };
 
 // K column of one particle at (lon, lat) -> Kp[level][tid] (LDS), time-interpolated like the ReaderBlock's profiles
-template <int NQ, bool TL>
+// quads: the 4-level quads of the column to gather (bit q; wave-uniform in k_vmix_col, see vmix_col_particle: a particle only
+// ever reads the levels around its own, and a quad nobody of the wave needs is not fetched)
+// hook: arithmetic of the caller that does not depend on the column (the first Philox block of the particle's stream), run
+// right behind the gathers of the first quad so that it overlaps their flight instead of standing in front of their issue
+struct VMixNoHook { __device__ __forceinline__ void operator()() const {} };
+template <int NQ, bool TL, class HOOK = VMixNoHook>
 __device__ __forceinline__ void vmix_col_fill(const DevSource &s, const VMixDesc &D, double lon, double lat, double *Kp,
-                                              int tid) {
+                                              int tid, unsigned quads = ~0u, HOOK &&hook = HOOK()) {
   const double Kfb = (double)D.Kfb;
   double x, y;
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
@@ -376,25 +389,36 @@ __device__ __forceinline__ void vmix_col_fill(const DevSource &s, const VMixDesc
   // byte offsets of the four node records (blocks of the fast path are `small`: < 2^24 nodes, < 4 GiB; 24-bit multiplies)
   const unsigned recb = (unsigned)bb.rec * 4u;
   const unsigned r0 = __umul24((unsigned)ay.i0, (unsigned)nx), r1 = __umul24((unsigned)ay.i1, (unsigned)nx);
+#ifdef ODR_ABL_VMIX_UNIFORM   // what-if build (wrong values): every lane gathers node 0 -- what the spread of the gathers costs
+  const unsigned o00 = 0u * r0, o01 = 0u * r1, o10 = 0u * recb, o11 = 0u;
+#else
   const unsigned o00 = cov ? __umul24(r0 + (unsigned)ax.i0, recb) : 0u, o01 = cov ? __umul24(r0 + (unsigned)ax.i1, recb) : 0u;
   const unsigned o10 = cov ? __umul24(r1 + (unsigned)ax.i0, recb) : 0u, o11 = cov ? __umul24(r1 + (unsigned)ax.i1, recb) : 0u;
+#endif
   const float *kb = D.kb, *ka = TL ? D.ka : D.kb;
   // horizontal weights multiplied out once for the whole column (float64; the layer value is rounded to float32 like
   // the ReaderBlock's: same bits as (v*wy)*wx summed, but for a float64 round-off that reaches the float32 rounding
   // in ~1e-8 of the values)
   const double w00 = wy0 * wx0, w01 = wy0 * tx, w10 = ty * wx0, w11 = ty * tx;
+  if (!(quads & 1u)) hook();
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
+    if (!((quads >> q) & 1u)) continue;
+    // both time levels requested before anything is consumed
     const F4 b00 = ld_off<F4>(kb, o00 + 16u * q), b01 = ld_off<F4>(kb, o01 + 16u * q);
     const F4 b10 = ld_off<F4>(kb, o10 + 16u * q), b11 = ld_off<F4>(kb, o11 + 16u * q);
+    F4 a00, a01, a10, a11;
+    if (TL) {
+      a00 = ld_off<F4>(ka, o00 + 16u * q); a01 = ld_off<F4>(ka, o01 + 16u * q);
+      a10 = ld_off<F4>(ka, o10 + 16u * q); a11 = ld_off<F4>(ka, o11 + 16u * q);
+    }
+    if (q == 0) hook();
     double v[4];
     v[0] = (double)bilw(b00.x, b01.x, b10.x, b11.x, w00, w01, w10, w11);
     v[1] = (double)bilw(b00.y, b01.y, b10.y, b11.y, w00, w01, w10, w11);
     v[2] = (double)bilw(b00.z, b01.z, b10.z, b11.z, w00, w01, w10, w11);
     v[3] = (double)bilw(b00.w, b01.w, b10.w, b11.w, w00, w01, w10, w11);
     if (TL) {
-      const F4 a00 = ld_off<F4>(ka, o00 + 16u * q), a01 = ld_off<F4>(ka, o01 + 16u * q);
-      const F4 a10 = ld_off<F4>(ka, o10 + 16u * q), a11 = ld_off<F4>(ka, o11 + 16u * q);
       double w[4];
       w[0] = (double)bilw(a00.x, a01.x, a10.x, a11.x, w00, w01, w10, w11);
       w[1] = (double)bilw(a00.y, a01.y, a10.y, a11.y, w00, w01, w10, w11);
@@ -423,16 +447,30 @@ __device__ __forceinline__ MixRng mix_rng_begin(const VMixArgs &A, int id) {
   R.key = mix_key(A.seed, A.step, id);
   R.q = make_uint4(0u, 0u, 0u, 0u);
   R.primed = false;
+#ifndef ODR_ABL_VMIX_NORNG
   if (A.rng_mode == 0) {
     R.q = mix_block(R.key, 0u);
     R.primed = true;
   }
+#endif
   return R;
+}
+// Quads on demand (k_vmix_col): `lz` names the quads vmix_col_fill has put into Kp (wave-uniform).  A sub-step that needs the
+// level terms of a level whose neighbours lie in a quad that was not gathered sets `missed`; the caller then gathers the whole
+// column and walks the particle again from its start (same draws: the stream is a function of element, step and sub-step) --
+// rare: the levels a particle reaches within a step are the ones around its own (C3: 0.07 % of the particles per step leave
+// their three-level window at all, none reaches the quad below 100 m).  Level terms are a pure function of the column: same bits.
+struct VMixLazy { unsigned loaded; bool missed; };
+__device__ __forceinline__ unsigned vmix_quads_of(int lo, int hi, int nzp) {   // quads holding levels lo..hi (clamped to the column)
+  lo = lo < 0 ? 0 : lo; hi = hi > nzp - 1 ? nzp - 1 : hi;
+  const unsigned a = (unsigned)lo >> 2, b = (unsigned)hi >> 2;
+  return ((2u << b) - 1u) & ~((1u << a) - 1u);
 }
 template <int NQ>
 __device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, const double *Kp, const double *gsh, int tid,
                                                 const VMixArgs &A, long long i, long long n, int id, double z, int &moving,
-                                                float Zmin, float tv, int &sf_flags, const MixRng *pre = nullptr) {
+                                                float Zmin, float tv, int &sf_flags, const MixRng *pre = nullptr,
+                                                VMixLazy *lz = nullptr) {
   constexpr int NL = 4 * NQ;
   const double dt = A.dt;
   const int mix_at_surface = A.mix_at_surface, rng_mode = A.rng_mode, sfl = A.sfl;
@@ -444,7 +482,11 @@ __device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, con
   const double gd0 = s.vg_d[0], gi0 = s.vg_id[0], gd1 = s.vg_d[1], gi1 = s.vg_id[1], gd2 = s.vg_d[2], gi2 = s.vg_id[2];
   const double sgn = dt > 0 ? 1.0 : (dt < 0 ? -1.0 : 0.0);
   const double dt_mix = A.dt_mix_cfg * sgn;
+#ifdef ODR_ABL_VMIX_NT   // what-if build: fewer sub-steps
+  const int ntimes = ODR_ABL_VMIX_NT;
+#else
   const int ntimes = abs((int)(dt / dt_mix));
+#endif
   const double r = 1.0 / 3, ir = 1.0 / r;
   // w*dt_mix*moving: dt_mix is a NumPy float64 scalar (np.sign, oceandrift.py:416) -> float64 product under NumPy 2
   double wstep = __dmul_rn(__dmul_rn((double)tv, dt_mix), (double)moving);
@@ -454,6 +496,7 @@ __device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, con
   if (pre) { u4 = pre->q; primed = pre->primed; }
   // -dK/dz * dt_mix and sqrt(K |dt_mix| 2 / r) of one level (oceandrift.py:501-502,527-528)
   auto level_terms = [&](int zl, double &dk_dt, double &sg) {
+    if (lz && (vmix_quads_of(zl - 1, zl + 1, nzp) & ~lz->loaded)) lz->missed = true;   // (the values formed below are dropped)
     const double Kz = Kp[zl * BLOCK + tid];
     double gK;  // np.gradient(Kprofiles, mixing_z, axis=0)[zl]
     if (zl == 0) gK = div_cr(Kp[BLOCK + tid] - Kz, gd0, gi0);
@@ -504,7 +547,11 @@ __device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, con
   // the sub-steps in groups of five = one Philox block: inside the unrolled group the word a sub-step takes from the block is
   // known at compile time (a run-time `it % 5` costs a chain of selects and the fifth word's assembly in every sub-step)
   for (int it0 = 0; it0 < ntimes; it0 += 5) {
+#ifdef ODR_ABL_VMIX_NORNG   // what-if build: no generator (wrong values)
+  u4 = make_uint4(st.id * 2654435761u + (unsigned)it0, st.id ^ 0x9E3779B9u, st.id * 40503u, st.id + (unsigned)it0);
+#else
   if (rng_mode == 0 && !(primed && it0 == 0)) u4 = mix_block(st, (unsigned)it0 / 5u);
+#endif
 #ifdef ODR_VMIX_NO_UNROLL   // A/B build: the word selected at run time, as in rounds 1-3
 #pragma unroll 1
 #else
@@ -1713,40 +1760,96 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
 #ifndef ODR_VMIX_WAVES
 #define ODR_VMIX_WAVES 6   // 80 registers, no scratch: six workgroups (24.6 KB of LDS each) per CU; unconstrained the allocator took 102 (4 waves)
 #endif
-// one particle of k_vmix_col: column into the thread's LDS slots, sub-steps, stores
-template <int NQ, bool TL>
-__device__ __forceinline__ void vmix_col_particle(const DevSource &s, const PView &p, const VMixDesc &D, const VMixArgs &A,
-                                                  int vadv, long long i, double *Kp, const double *gsh, int tid) {
+// one particle of k_vmix_col: column into the thread's LDS slots, sub-steps, stores.
+// LAZY: gather only the quads of the column this WAVE needs -- the union of what its particles' three-level windows (the levels
+// lv0 - 2 .. lv0 + 2 their terms are formed from, vmix_col_walk) touch.  The texture addresser's time goes with the number of
+// gather instructions (profiles/r05_ab_variants.txt section 1: 0.34 instead of 0.41 ms when every lane gathers the same node,
+// 0.26 ms for the launch without its sub-steps), and a particle at 30 m never reads K at 300 m.  Returns true -- nothing stored
+// -- when a sub-step needed a quad that was not gathered: the caller runs the particle again with the whole column (a second
+// copy of this function behind a wave-uniform branch: everything is read again from memory, so nothing of the first pass stays
+// in registers for it; a retry loop around fill + walk spilled 548 B per lane).
+// what the mixing of one particle reads of it -- requested by the kernel in ONE round trip together with its LDS tables
+// (round 5: the tables' loads stood in front of a barrier in front of these, and the ID's load behind a branch in front of the
+// first Philox block in front of the column gathers: three dependent round trips before the first gather was issued)
+struct VMixState { double slon, slat, z0; int moving, id; float dep, ssh, tv; };
+__device__ __forceinline__ VMixState vmix_load_state(const PView &p, long long i) {
+  VMixState S;
+  S.slon = p.slon[i]; S.slat = p.slat[i]; S.z0 = p.z[i];
+  S.moving = p.moving[i]; S.id = p.id[i];
+  S.dep = p.env[VAR_DEPTH][i]; S.ssh = p.env[VAR_SSH][i]; S.tv = p.tv[i];
+  return S;
+}
+template <int NQ, bool TL, bool LAZY>
+__device__ __forceinline__ bool vmix_col_particle_pass(const DevSource &s, const PView &p, const VMixDesc &D, const VMixArgs &A,
+                                                       int vadv, long long i, double *Kp, const double *gsh, int tid, const VMixState &S) {
   const int nzp = D.nzp, sfl = A.sfl;
   const double dt = A.dt;
-  // the particle's state in one round trip (requested before the column gathers, used behind them)
-  const double slon = p.slon[i], slat = p.slat[i], z0 = p.z[i];
-  int moving = p.moving[i];
-  const float dep0 = p.env[VAR_DEPTH][i], ssh0 = p.env[VAR_SSH][i], tv0 = p.tv[i];
-  const int id0 = A.rng_mode == 0 ? p.id[i] : 0;
-  const float w0 = vadv >= 0 ? p.env[VAR_W][i] : 0.f;
+  const double slon = S.slon, slat = S.slat, z0 = S.z0;
+  int moving = S.moving;
+  const float dep0 = S.dep, ssh0 = S.ssh, tv0 = S.tv;
+  const int id0 = S.id;
+  VMixLazy lz;
+  lz.loaded = ~0u; lz.missed = false;
+  if (LAZY) {
+    int zs = 0;
+    const double d0 = -z0;
+#pragma unroll
+    for (int k = 0; k < 4 * NQ - 1; ++k) zs += (k < nzp - 1 && ((k & 1) ? d0 >= s.zmid[k] : d0 > s.zmid[k])) ? 1 : 0;
+    int lv0 = zs < 1 ? 1 : (zs > nzp - 2 ? nzp - 2 : zs);
+    if (nzp < 3) lv0 = 1;
+    const unsigned mine = vmix_quads_of(lv0 - 2, lv0 + 2, nzp);
+    unsigned w = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) w |= __ballot((mine >> q) & 1u) ? (1u << q) : 0u;
+    lz.loaded = w;
+  }
+  MixRng R0;
+  R0.key = mix_key(A.seed, A.step, id0); R0.q = make_uint4(0u, 0u, 0u, 0u); R0.primed = false;
 #ifdef ODR_VMIX_LATE_RNG
-  vmix_col_fill<NQ, TL>(s, D, slon, slat, Kp, tid);
+  vmix_col_fill<NQ, TL>(s, D, slon, slat, Kp, tid, lz.loaded);
   const MixRng *pre = nullptr;
 #else
-  // the stream's first block before the column gathers are consumed: its arithmetic runs while they are in flight
-  const MixRng R0 = mix_rng_begin(A, id0);
-  vmix_col_fill<NQ, TL>(s, D, slon, slat, Kp, tid);
+  // the stream's first block behind the first gathers of the column: its arithmetic runs while they are in flight
+  vmix_col_fill<NQ, TL>(s, D, slon, slat, Kp, tid, lz.loaded, [&]() { R0 = mix_rng_begin(A, id0); });
   const MixRng *pre = &R0;
 #endif
   int sf_flags = 0;
   const float Zmin = __fmul_rn(-1.f, __fadd_rn(dep0, ssh0));  // float32 (:408)
-  double z = vmix_col_walk<NQ>(s, nzp, Kp, gsh, tid, A, i, p.n, id0, z0, moving, Zmin, tv0, sf_flags, pre);
+  double z = vmix_col_walk<NQ>(s, nzp, Kp, gsh, tid, A, i, p.n, id0, z0, moving, Zmin, tv0, sf_flags, pre, LAZY ? &lz : nullptr);
+  if (LAZY && lz.missed) return true;
   if (sf_flags & 1) {   // deactivate_elements(reason='seafloor') (basemodel/__init__.py:1774-1795)
     if (p.status[i] == 0) p.status[i] = sfl >> 8;
     p.moving[i] = 0;
   }
   if (sf_flags & 2) { p.lon[i] = p.plon[i]; p.lat[i] = p.plat[i]; }
   if (vadv >= 0 && (vadv ? z <= 0 : z < 0)) {  // vertical_advection (oceandrift.py:315-350)
+    // (w is read here, not with the rest of the state: held through the walk it was the one value the allocator put into
+    // scratch memory at 80 registers, behind a wait for every load in flight)
+    const float w0 = p.env[VAR_W][i];
     double zz = __dadd_rn(z, __dmul_rn(__dmul_rn((double)moving, (double)w0), dt));
     z = zz < 0 ? zz : 0.0;
   }
   p.z[i] = z;
+  return false;
+}
+template <int NQ, bool TL>
+__device__ __forceinline__ void vmix_col_particle(const DevSource &s, const PView &p, const VMixDesc &D, const VMixArgs &A,
+                                                  int vadv, long long i, double *Kp, const double *gsh, int tid, const VMixState &S) {
+#if !defined(ODR_VMIX_LAZY_QUADS)   // the whole column for every particle (the quads on demand measured slower, profiles/r05_ab_variants.txt)
+  vmix_col_particle_pass<NQ, TL, false>(s, p, D, A, vadv, i, Kp, gsh, tid, S);
+#else
+  if constexpr (NQ == 1) vmix_col_particle_pass<NQ, TL, false>(s, p, D, A, vadv, i, Kp, gsh, tid, S);
+  else {
+    const bool again = vmix_col_particle_pass<NQ, TL, true>(s, p, D, A, vadv, i, Kp, gsh, tid, S);
+    if (__ballot(again)) {
+      // (an opaque copy of the index: addresses formed from `i` for the first pass would otherwise be kept alive -- in scratch
+      // memory, 36 B per lane -- for this one)
+      long long i2 = i;
+      asm volatile("" : "+v"(i2));
+      if (again) vmix_col_particle_pass<NQ, TL, false>(s, p, D, A, vadv, i2, Kp, gsh, tid, vmix_load_state(p, i2));
+    }
+  }
+#endif
 }
 template <int NQ, bool TL>
 __global__ __launch_bounds__(BLOCK, ODR_VMIX_WAVES) void k_vmix_col(const DevWorld *__restrict__ W, PView p, VMixDesc D,
@@ -1761,17 +1864,20 @@ __global__ __launch_bounds__(BLOCK, ODR_VMIX_WAVES) void k_vmix_col(const DevWor
   const int nzp = D.nzp;
   double *Kp = (double *)smem;              // [NL][BLOCK]
   double *gsh = Kp + (size_t)NL * BLOCK;    // [4][NL]
+  // the particle's state is requested first: its loads and the tables' are one round trip (threads past the end read element 0)
+  const long long i = pid();
+  const bool valid = i < p.n;
+  const VMixState S = vmix_load_state(p, valid ? i : 0);
   if (tid < nzp) {
     gsh[tid] = s.vg_a[tid]; gsh[NL + tid] = s.vg_b[tid]; gsh[2 * NL + tid] = s.vg_c[tid];
     gsh[3 * NL + tid] = s.zmid[tid];     // level boundaries (entries >= nzp - 1 are not read)
   }
   __syncthreads();
-  const long long i = pid();
-  if (i >= p.n) return;  // no barrier below: every thread touches only its own LDS column
+  if (!valid) return;  // no barrier below: every thread touches only its own LDS column
   VMixArgs A;
   A.dt = dt; A.dt_mix_cfg = dt_mix_cfg; A.mix_at_surface = mix_at_surface; A.rng_mode = rng_mode; A.sfl = sfl; A.pad = 0;
   A.huni = huni; A.seed = seed; A.step = step;
-  vmix_col_particle<NQ, TL>(s, p, D, A, vadv, i, Kp, gsh, tid);
+  vmix_col_particle<NQ, TL>(s, p, D, A, vadv, i, Kp, gsh, tid, S);
 }
 
 // ---- k_vmix_win: the same mixing with the diffusivity of FIVE levels per particle instead of the whole column.

@@ -20,7 +20,10 @@ int odr_i_fail(int code, const char *fmt, ...) {
 }
 
 const char *odr_last_error(void) { return g_err.c_str(); }
-const char *odr_version(void) { return "odrift-hip 0.1 (gfx950)"; }
+#define ODR_STR2(x) #x
+#define ODR_STR(x) ODR_STR2(x)
+// (tests read the round count of the mixing stream from here: oracle/philox.py restates the generator with that count)
+const char *odr_version(void) { return "odrift-hip 0.2 (gfx950; mixing stream Philox4x32-" ODR_STR(ODR_MIX_ROUNDS) ")"; }
 
 int odr_ctx_create(int device, uint64_t seed, odr_ctx **out) {
   REQUIRE(out, "out is NULL");

@@ -419,7 +419,10 @@ class NodeLookupGridReader(CurvilinearGridReader):
         for a, b in self._pairs:
             if a in out and b in out:
                 def rotate(u, v):
-                    u, v = np.asarray(u, dtype=np.float32), np.asarray(v, dtype=np.float32)
+                    # masked cells (land, missing data of a netCDF block) become NaN as in the plain upload path
+                    # (np.ma.filled); np.asarray() would hand the fill value 9.96921e36 on as a velocity
+                    u = np.ma.filled(np.ma.asarray(u).astype(np.float32), np.nan)
+                    v = np.ma.filled(np.ma.asarray(v).astype(np.float32), np.nan)
                     return ((u * self._cos - v * self._sin).astype(np.float32),      # variables.py:104-107
                             (u * self._sin + v * self._cos).astype(np.float32))
                 if isinstance(out[a], (list, tuple)):      # ensemble members

@@ -13,6 +13,18 @@ def test_known_answers():
     for ctr, key, want in kat:
         got = philox.philox4x32_10(ctr, key)
         assert tuple(int(g[0]) for g in got) == want
+    # the same three counters / keys under Philox4x32-7 (kat_vectors of the same library)
+    kat7 = [(0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48), (0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662),
+            (0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a)]
+    for (ctr, key, _), want in zip(kat, kat7):
+        got = philox.philox4x32(ctr, key, 7)
+        assert tuple(int(g[0]) for g in got) == want
+
+
+def test_library_names_its_round_count():
+    import __graft_entry__ as g
+    g.build()
+    assert philox.library_rounds() in (7, 10)
 
 
 def test_mixing_uniforms_layout():
@@ -23,7 +35,7 @@ def test_mixing_uniforms_layout():
     x = u / 5.9604644775390625e-08 - 0.5
     assert np.array_equal(x, np.round(x)) and x.max() < 2 ** 24
     # sub-steps 0..4 share block 0, 5..9 block 1; different steps / seeds / elements give different numbers
-    q = philox.philox4x32_10((0, 7, ids.astype(np.uint32), philox.MIX_TAG), (1234567890123 & 0xFFFFFFFF, 1234567890123 >> 32))
+    q = philox.philox4x32((0, 7, ids.astype(np.uint32), philox.MIX_TAG), (1234567890123 & 0xFFFFFFFF, 1234567890123 >> 32), philox.library_rounds())
     assert np.array_equal(x[1], (q[1] >> np.uint32(8)).astype(np.float64))
     assert not np.array_equal(u, philox.mixing_uniforms(1234567890123, ids, 8, 12))
     assert not np.array_equal(u[:, 1:], u[:, :-1])
