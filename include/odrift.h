@@ -71,12 +71,20 @@ enum {
 enum { ODR_PROJ_LATLONG = 0, ODR_PROJ_STERE_EQUIT_SPHERE = 1, ODR_PROJ_STERE_POLAR = 2,
        ODR_PROJ_CURVILINEAR = 3 /* set by odr_source_grid_curvilinear, not through odr_proj_desc */,
        ODR_PROJ_MERC = 4 /* +proj=merc (+lat_ts or +k_0), sphere or ellipsoid: Snyder ch. 7 */,
-       ODR_PROJ_LCC = 5 /* +proj=lcc +lat_1 [+lat_2] +lat_0 +lon_0, sphere or ellipsoid: Snyder ch. 15 */ };
+       ODR_PROJ_LCC = 5 /* +proj=lcc +lat_1 [+lat_2] +lat_0 +lon_0, sphere or ellipsoid: Snyder ch. 15 */,
+       /* round 5 -- pyproj.Proj of variables.py:111-143 for the other projections model files carry: */
+       ODR_PROJ_TMERC = 6 /* +proj=tmerc (+proj=utm: the caller resolves the zone into lon0 / k0 / x0 / y0): Krueger's series to
+                             order 6 in the third flattening (Karney 2011), sphere or ellipsoid */,
+       ODR_PROJ_LAEA = 7 /* +proj=laea, any aspect, sphere or ellipsoid: Snyder ch. 24 */,
+       ODR_PROJ_STERE_OBLIQUE = 8 /* +proj=stere with lat_0 not a pole (oblique, equatorial), sphere or ellipsoid, +k_0: Snyder ch. 21 */,
+       ODR_PROJ_OB_TRAN = 9 /* +proj=ob_tran +o_proj=longlat: the rotated pole; lat1_deg = o_lat_p, lat2_deg = o_lon_p, lon0_deg = lon_0;
+                               reader coordinates are rotated longitude / latitude in DEGREES (variables.py:117-123,136-138); vector
+                               pairs are rotated by the WGS84 azimuth of the 0.1-degree line along +y (variables.py:80-97) */ };
 typedef struct {
   int32_t kind;
   double a, es;                  /* semi-major axis, eccentricity squared */
   double lat0_deg, lon0_deg, lat_ts_deg, k0, x0, y0;
-  double lat1_deg, lat2_deg;     /* standard parallels (ODR_PROJ_LCC; lat2 = lat1 for the tangent cone) */
+  double lat1_deg, lat2_deg;     /* standard parallels (ODR_PROJ_LCC; lat2 = lat1 for the tangent cone); o_lat_p, o_lon_p (ODR_PROJ_OB_TRAN) */
 } odr_proj_desc;
 
 enum { ODR_SCHEME_EULER = 0, ODR_SCHEME_RK2 = 1, ODR_SCHEME_RK4 = 2 };

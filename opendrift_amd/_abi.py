@@ -29,6 +29,7 @@ VARIABLES = {
 VARIABLE_NAMES = {v: k for k, v in VARIABLES.items()}
 PROJ_LATLONG, PROJ_STERE_EQUIT_SPHERE, PROJ_STERE_POLAR = 0, 1, 2
 PROJ_MERC, PROJ_LCC = 4, 5
+PROJ_TMERC, PROJ_LAEA, PROJ_STERE_OBLIQUE, PROJ_OB_TRAN = 6, 7, 8, 9
 SCHEME = {'euler': 0, 'runge-kutta': 1, 'runge-kutta4': 2}
 RNG_DEVICE, RNG_HOST = 0, 1
 STAGE_MATH = {'exact': 0, 'fast': 1}     # odr_ctx_set_stage_math

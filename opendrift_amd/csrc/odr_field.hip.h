@@ -38,7 +38,8 @@ enum { VAR_U = 0, VAR_V = 1, VAR_XWIND = 2, VAR_YWIND = 3, VAR_W = 4, VAR_KZ = 5
        VAR_ICE_A = 17, VAR_ICE_U = 18, VAR_ICE_V = 19, VAR_SWELL_DIR = 20, VAR_SWELL_TP = 21, VAR_SWELL_HS = 22,
        VAR_WW_DIR = 23, VAR_WW_TM = 24, VAR_WW_HS = 25 };
 enum { SRC_CONSTANT = 0, SRC_DOUBLE_GYRE = 1, SRC_OSCILLATING = 2, SRC_GRID = 3, SRC_LANDMASK = 4 };
-enum { PROJ_LATLONG = 0, PROJ_STERE_EQUIT_SPHERE = 1, PROJ_STERE_POLAR = 2, PROJ_CURVILINEAR = 3, PROJ_MERC = 4, PROJ_LCC = 5 };
+enum { PROJ_LATLONG = 0, PROJ_STERE_EQUIT_SPHERE = 1, PROJ_STERE_POLAR = 2, PROJ_CURVILINEAR = 3, PROJ_MERC = 4, PROJ_LCC = 5,
+       PROJ_TMERC = 6, PROJ_LAEA = 7, PROJ_STERE_OBLIQUE = 8, PROJ_OB_TRAN = 9 };   // round 5 (include/odrift.h)
 // (kernels templated on the projection: anything but latlong / polar stere / curvilinear takes the PROJ_STERE_EQUIT_SPHERE
 // instantiation, whose proj_fwd / proj_inv / rotation_angle switch on DevProj::kind at run time)
 // x/y vector pairs are rotated from the reader's CRS to lon/lat (variables.py:799-837); for a reader without a
@@ -52,6 +53,14 @@ struct DevProj {
   double a, es, e, lon0, lat0, x0, y0, k0, akm1;
   double cchi[4];  // conformal -> geodetic latitude series (Snyder 3-5), used by rotation_angle
   double cn, cc, crho0;  // PROJ_LCC: cone constant n, F = m1 / (n t1^n), rho0 / a (Snyder 15-1..15-8); PROJ_MERC: k0 in k0
+  // round 5 -- set-up constants of tmerc / laea / oblique stere / ob_tran (proj_init, odrift.hip):
+  //   PROJ_TMERC          q[0] = k0 A / a, q[1] = xi of the origin latitude, q[2..7] = alpha_1..6, q[8..13] = beta_1..6 (Karney 2011)
+  //   PROJ_LAEA           q[0] = qp, q[1] = Rq, q[2] = D, q[3] = Rq D, q[4] = Rq / D, q[5] / q[6] = sin / cos beta1, q[7] / q[8] = sin / cos lat0
+  //   PROJ_STERE_OBLIQUE  q[0] / q[1] = sin / cos of the conformal latitude of the origin (its geodetic latitude on a sphere)
+  //   PROJ_OB_TRAN        q[0] / q[1] = sin / cos o_lat_p, q[2] = o_lon_p
+  // mode (laea, oblique stere): 0 north pole, 1 south pole, 2 equatorial, 3 oblique
+  int mode, pad2;
+  double q[14];
   // PROJ_CURVILINEAR: a reader WITHOUT a projection (2D lon/lat node arrays, pixel indices as x/y;
   // basereader/structured.py:44-113).  cv_nodes[j*cv_nx + i] = (lon, lat) of node (i, j); cv_tri_v / cv_tri_n = the
   // Delaunay triangulation of the nodes (counter-clockwise vertices; neighbour across the edge opposite vertex k,
@@ -199,6 +208,217 @@ __device__ __forceinline__ void curvi_locate(const DevProj &p, double lon, doubl
   }
 }
 
+// covers_positions_xy (variables.py:236-257): a reader whose CRS is geographic -- latlong, and the rotated pole, whose
+// `crs.is_geographic` the reference relies on (:117, :800) -- has its x modulated once more for the test of its domain
+template <int PROJ>
+__device__ __forceinline__ double cover_x(int kind, int lon_mode, double x) {
+  if (PROJ == PROJ_LATLONG || (PROJ == PROJ_STERE_EQUIT_SPHERE && kind == PROJ_OB_TRAN)) {
+    if (lon_mode == 1) return np_mod(x + 180.0, 360.0) - 180.0;
+    if (lon_mode == 2) return np_mod(x, 360.0);
+  }
+  return x;
+}
+
+// ---- round 5: transverse Mercator / UTM, Lambert azimuthal equal-area, oblique stereographic, rotated pole ------------
+// (variables.py:111-143 hands any proj4 to pyproj; these are the ones model files carry besides stere / merc / lcc.  Same
+// formulas as oracle/proj.c, which is pinned on Snyder's numerical examples; written for the device: no iteration where a
+// closed form or a fixed small count does, hyperbolic multiples by recurrence.)
+// conformal latitude as its tangent (Karney 2011, eqs. 7-9)
+__device__ __forceinline__ double tm_taup(double tau, double e) {
+#pragma clang fp contract(fast)
+  const double t1 = sqrt(1 + tau * tau), sg = sinh(e * atanh(e * tau / t1));
+  return sqrt(1 + sg * sg) * tau - sg * t1;
+}
+// sum_k c[k] sin(2 k xi) cosh(2 k eta) and sum_k c[k] cos(2 k xi) sinh(2 k eta), k = 1..6: the complex Clenshaw sum of
+// c_k sin(2 k (xi + i eta)) -- real and imaginary part
+__device__ __forceinline__ void tm_series(const double *c, double xi, double eta, double &sre, double &sim) {
+#pragma clang fp contract(fast)
+  double s2, c2;
+  sincos(2 * xi, &s2, &c2);
+  const double ch = cosh(2 * eta), sh = sinh(2 * eta);
+  // sin(2z) = s2 ch + i c2 sh,  2 cos(2z) = 2 c2 ch - 2 i s2 sh
+  const double ar = 2 * c2 * ch, ai = -2 * s2 * sh;
+  double y1r = 0, y1i = 0, y0r = c[5], y0i = 0;
+#pragma unroll
+  for (int k = 4; k >= 0; --k) {
+    const double tr = ar * y0r - ai * y0i - y1r + c[k], ti = ar * y0i + ai * y0r - y1i;
+    y1r = y0r; y1i = y0i; y0r = tr; y0i = ti;
+  }
+  const double zr = s2 * ch, zi = c2 * sh;
+  sre = zr * y0r - zi * y0i;
+  sim = zr * y0i + zi * y0r;
+}
+__device__ __forceinline__ double qsfn_dev(double sinphi, double e, double one_es) {   // Snyder 3-12
+#pragma clang fp contract(fast)
+  if (e < 1e-7) return 2 * sinphi;
+  const double con = e * sinphi;
+  return one_es * (sinphi / (1 - con * con) + (1.0 / e) * atanh(con));               // -(1/2e) ln((1-x)/(1+x)) = atanh(x) / e
+}
+__device__ __forceinline__ double conformal_lat(double phi, double sinphi, double e) { // Snyder 3-1
+  return 2 * atan(tan(0.5 * (kHalfPi + phi)) * exp(-e * atanh(e * sinphi))) - kHalfPi;
+}
+// (lam, phi) relative to the central meridian -> projected X, Y in units of a (ob_tran: rotated longitude / latitude, radians)
+__device__ __forceinline__ void proj_fwd_ext(const DevProj &p, double lam, double phi, double &X, double &Y) {
+#pragma clang fp contract(fast)
+  double sinlam, coslam, sinphi, cosphi;
+  sincos(lam, &sinlam, &coslam);
+  sincos(phi, &sinphi, &cosphi);
+  if (p.kind == PROJ_TMERC) {
+    const double taup = tm_taup(sinphi / cosphi, p.e);
+    double xip = atan2(taup, coslam), etap = asinh(sinlam / sqrt(taup * taup + coslam * coslam));
+    if (fabs(phi) >= kHalfPi) { xip = phi > 0 ? kHalfPi : -kHalfPi; etap = 0; }
+    double sr, si;
+    tm_series(p.q + 2, xip, etap, sr, si);
+    X = p.q[0] * (etap + si);
+    Y = p.q[0] * (xip + sr - p.q[1]);
+  } else if (p.kind == PROJ_LAEA) {
+    if (p.es != 0) {
+      double q = qsfn_dev(sinphi, p.e, 1 - p.es);
+      const double qp = p.q[0];
+      if (p.mode >= 2) {
+        const double sinb = q / qp, cosb = sqrt(1 - sinb * sinb);
+        double b;
+        if (p.mode == 3) {
+          b = sqrt(2 / (1 + p.q[5] * sinb + p.q[6] * cosb * coslam));
+          Y = p.q[4] * b * (p.q[6] * sinb - p.q[5] * cosb * coslam);
+        } else {
+          b = sqrt(2 / (1 + cosb * coslam));
+          Y = b * sinb * p.q[4];
+        }
+        X = p.q[3] * b * cosb * sinlam;
+      } else {
+        q = p.mode == 0 ? qp - q : qp + q;
+        const double b = q >= 1e-30 ? sqrt(q) : 0.0;
+        X = b * sinlam;
+        Y = coslam * (p.mode == 1 ? b : -b);
+      }
+    } else if (p.mode >= 2) {
+      const double k = sqrt(2 / (1 + p.q[7] * sinphi + p.q[8] * cosphi * coslam));
+      X = k * cosphi * sinlam;
+      Y = k * (p.q[8] * sinphi - p.q[7] * cosphi * coslam);
+    } else {
+      const double h = 0.25 * kPi - 0.5 * phi, k = 2 * (p.mode == 1 ? cos(h) : sin(h));
+      X = k * sinlam;
+      Y = k * (p.mode == 0 ? -coslam : coslam);
+    }
+  } else if (p.kind == PROJ_STERE_OBLIQUE) {
+    double sinX = sinphi, cosX = cosphi;
+    if (p.es != 0) sincos(conformal_lat(phi, sinphi, p.e), &sinX, &cosX);
+    const double A = p.akm1 / ((p.es != 0 ? p.q[1] : 1.0) * (1 + p.q[0] * sinX + p.q[1] * cosX * coslam));
+    X = A * cosX * sinlam;
+    Y = A * (p.q[1] * sinX - p.q[0] * cosX * coslam);
+  } else {   // PROJ_OB_TRAN (PROJ's o_forward)
+    X = wrap_pi(atan2(cosphi * sinlam, p.q[0] * cosphi * coslam + p.q[1] * sinphi) + p.q[2]);
+    Y = asin(fmin(1.0, fmax(-1.0, p.q[0] * sinphi - p.q[1] * cosphi * coslam)));
+  }
+}
+__device__ __forceinline__ void proj_inv_ext(const DevProj &p, double X, double Y, double &lam, double &phi) {
+#pragma clang fp contract(fast)
+  if (p.kind == PROJ_TMERC) {
+    const double xi = Y / p.q[0] + p.q[1], eta = X / p.q[0];
+    double sr, si;
+    tm_series(p.q + 8, xi, eta, sr, si);
+    const double xip = xi - sr, etap = eta - si;
+    const double sh = sinh(etap), c = cos(xip), taup = sin(xip) / sqrt(sh * sh + c * c);
+    lam = atan2(sh, c);
+    // tau from its conformal counterpart: Newton (Karney 2011, eqs. 19-21), quadratic from a start that is e^2 off
+    const double e2m = 1 - p.es;
+    double tau = taup / e2m;
+#pragma unroll 1
+    for (int i = 0; i < 5 && p.es != 0; ++i) {
+      const double tp = tm_taup(tau, p.e);
+      const double d = (taup - tp) * (1 + e2m * tau * tau) / (e2m * sqrt(1 + tau * tau) * sqrt(1 + tp * tp));
+      tau += d;
+      if (!(fabs(d) >= 1e-15 * fmax(1.0, fabs(taup)))) break;
+    }
+    phi = atan(p.es != 0 ? tau : taup);
+  } else if (p.kind == PROJ_LAEA) {
+    double x = X, y = Y;
+    if (p.es != 0) {
+      const double qp = p.q[0];
+      double ab;
+      if (p.mode >= 2) {
+        x /= p.q[2]; y *= p.q[2];
+        const double rho = sqrt(x * x + y * y);
+        if (rho < 1e-10) { lam = 0; phi = p.lat0; return; }
+        double sCe, cCe;
+        sincos(2 * asin(0.5 * rho / p.q[1]), &sCe, &cCe);
+        x *= sCe;
+        if (p.mode == 3) { ab = cCe * p.q[5] + y * sCe * p.q[6] / rho; y = rho * p.q[6] * cCe - y * p.q[5] * sCe; }
+        else { ab = y * sCe / rho; y = rho * cCe; }
+      } else {
+        if (p.mode == 0) y = -y;
+        const double q = x * x + y * y;
+        if (q == 0) { lam = 0; phi = p.lat0; return; }
+        ab = 1 - q / qp;
+        if (p.mode == 1) ab = -ab;
+      }
+      lam = atan2(x, y);
+      ab = fmin(1.0, fmax(-1.0, ab));
+      double ph = asin(ab);        // authalic latitude; geodetic by Newton on q(phi) = qp sin(beta) (Snyder 3-16)
+#pragma unroll 1
+      for (int i = 0; i < 8; ++i) {
+        double sp, cp;
+        sincos(ph, &sp, &cp);
+        if (!(fabs(cp) > 1e-12)) break;
+        const double w = 1 - p.es * sp * sp;
+        const double d = w * w / (2 * cp) * (qp * ab / (1 - p.es) - sp / w - (1.0 / p.e) * atanh(p.e * sp));
+        ph += d;
+        if (fabs(d) < 1e-15) break;
+      }
+      phi = ph;
+    } else {
+      const double rh = sqrt(x * x + y * y), c = 2 * asin(fmin(1.0, 0.5 * rh));
+      double sinz, cosz;
+      sincos(c, &sinz, &cosz);
+      if (p.mode >= 2) {
+        const double ph = rh <= 1e-10 ? p.lat0 : asin(cosz * p.q[7] + y * sinz * p.q[8] / rh);
+        x *= sinz * p.q[8];
+        y = (cosz - sin(ph) * p.q[7]) * rh;
+        lam = (y == 0 && x == 0) ? 0.0 : atan2(x, y);
+        phi = ph;
+      } else {
+        if (p.mode == 0) { y = -y; phi = kHalfPi - c; } else phi = c - kHalfPi;
+        lam = atan2(x, y);
+      }
+    }
+  } else if (p.kind == PROJ_STERE_OBLIQUE) {
+    double x = X, y = Y;
+    const double rho = sqrt(x * x + y * y);
+    if (p.es != 0) {
+      double sinphi, cosphi;
+      sincos(2 * atan2(rho * p.q[1], p.akm1), &sinphi, &cosphi);
+      double phi_l = rho == 0 ? asin(cosphi * p.q[0]) : asin(cosphi * p.q[0] + y * sinphi * p.q[1] / rho);
+      const double tp = tan(0.5 * (kHalfPi + phi_l));
+      x *= sinphi;
+      y = rho * p.q[1] * cosphi - y * p.q[0] * sinphi;
+      double ph = phi_l;
+#pragma unroll 1
+      for (int i = 0; i < 10; ++i) {   // Snyder 3-4 (contraction ~ e^2 per sweep)
+        ph = 2 * atan(tp * exp(p.e * atanh(p.e * sin(phi_l)))) - kHalfPi;
+        if (fabs(ph - phi_l) < 1e-15) break;
+        phi_l = ph;
+      }
+      phi = ph;
+      lam = (x == 0 && y == 0) ? 0.0 : atan2(x, y);
+    } else {
+      double sinc, cosc;
+      sincos(2 * atan(rho / p.akm1), &sinc, &cosc);
+      const double ph = rho <= 1e-10 ? p.lat0 : asin(cosc * p.q[0] + y * sinc * p.q[1] / rho);
+      const double cc = cosc - p.q[0] * sin(ph);
+      lam = (cc != 0 || x != 0) ? atan2(x * sinc * p.q[1], cc * rho) : 0.0;
+      phi = ph;
+    }
+  } else {   // PROJ_OB_TRAN (PROJ's o_inverse)
+    const double l = X - p.q[2];
+    double sl, cl, sp, cp;
+    sincos(l, &sl, &cl);
+    sincos(Y, &sp, &cp);
+    phi = asin(fmin(1.0, fmax(-1.0, p.q[0] * sp + p.q[1] * cp * cl)));
+    lam = atan2(cp * sl, p.q[0] * cp * cl - p.q[1] * sp);
+  }
+}
+
 // ELLPOLAR: the caller knows the projection to be the polar stereographic one on an ellipsoid (the kernels instantiated
 // for PROJ_STERE_POLAR: the host sends spherical polar readers to the generic instantiation) -- no code, and no registers,
 // for the other kinds (k_step_grid<RK4, polar> held 39 700 VALU instructions / 215 VGPRs with them)
@@ -209,6 +429,13 @@ __device__ __forceinline__ void proj_fwd(const DevProj &p, double lon_deg, doubl
   if (!ELLPOLAR && p.kind == PROJ_LATLONG) { x = lon_deg; y = lat_deg; return; }
   double lam = wrap_pi(lon_deg * kDeg - p.lon0), phi = lat_deg * kDeg;
   double sinlam, coslam, sinphi, cosphi, X, Y;
+  if (!ELLPOLAR && p.kind >= PROJ_TMERC) {
+    proj_fwd_ext(p, lam, phi, X, Y);
+    if (p.kind == PROJ_OB_TRAN) { x = X * kRad2Deg; y = Y * kRad2Deg; return; }   // np.degrees(self.proj(lon, lat)), variables.py:136-138
+    x = p.a * X + p.x0;
+    y = p.a * Y + p.y0;
+    return;
+  }
   if (ELLPOLAR) {
     sincos(lam, &sinlam, &coslam);
     sinphi = sin(phi);
@@ -299,6 +526,14 @@ __device__ __forceinline__ void proj_inv(const DevProj &p, double x, double y, d
                                          double &lat_deg) {
 #pragma clang fp contract(fast)
   if (p.kind == PROJ_LATLONG) { lon_deg = x; lat_deg = y; return; }
+  if (p.kind >= PROJ_TMERC) {
+    double lam_, phi_;
+    if (p.kind == PROJ_OB_TRAN) proj_inv_ext(p, x * kDeg, y * kDeg, lam_, phi_);     // self.proj(np.radians(x), np.radians(y), inverse=True), :117-123
+    else proj_inv_ext(p, (x - p.x0) / p.a, (y - p.y0) / p.a, lam_, phi_);
+    lon_deg = wrap_pi(lam_ + p.lon0) / kDeg;
+    lat_deg = phi_ / kDeg;
+    return;
+  }
   double X = (x - p.x0) / p.a, Y = (y - p.y0) / p.a;
   double rh = hypot(X, Y), lam = 0, phi = 0;
   if (p.kind == PROJ_MERC || p.kind == PROJ_LCC) {
@@ -395,8 +630,50 @@ __device__ __forceinline__ void proj_inv_diff(const DevProj &p, double x, double
   dlam = ang_normalize(lo2 - lo1) * kDeg;
 }
 
+// Forward azimuth (radians) of the WGS84 geodesic from point 1 to a point 2 some kilometres away: what Geod.inv returns
+// for the 0.1-degree line rotate_vectors draws for a reader whose CRS is geographic (variables.py:80-97; the rotated pole).
+// The Gauss mid-latitude azimuth is off by ~1e-7 rad over 11 km; it starts a shooting solve on the direct problem --
+// the miss at point 2, carried back to point 1 through the meridian convergence, corrects the start vector; each sweep
+// leaves (s / R)^2 ~ 3e-6 of the error, two sweeps reach round-off.
+__device__ __forceinline__ double geod_inverse_azimuth(double lat1, double lon1, double lat2, double lon2) {
+#pragma clang fp contract(fast)
+  const GeodConst &g = c_geod;
+  const double dphi = (lat2 - lat1) * kDeg, dlam = ang_normalize(lon2 - lon1) * kDeg, phim = 0.5 * (lat1 + lat2) * kDeg;
+  double sm, cm, s2, c2;
+  sincos(phim, &sm, &cm);
+  sincos(lat2 * kDeg, &s2, &c2);
+  const double wm2 = 1 - g.e2 * sm * sm, wm = sqrt(wm2), w22 = 1 - g.e2 * s2 * s2, w2 = sqrt(w22);
+  const double Mm = g.a * (1 - g.e2) / (wm2 * wm), Nm = g.a / wm, M2 = g.a * (1 - g.e2) / (w22 * w2), N2 = g.a / w2;
+  const double gam = dlam * sm;                     // meridian convergence between the two points
+  double sg, cg;
+  sincos(gam, &sg, &cg);
+  // start vector (north, east) at point 1: the chord at the mid latitude turned back by half the convergence
+  double sh, ch;
+  sincos(0.5 * gam, &sh, &ch);
+  const double nm = dphi * Mm, em = dlam * Nm * cm;
+  double n1 = nm * ch + em * sh, e1 = em * ch - nm * sh;
+  const GeodOrigin o = geod_origin(lat1, lon1);
+#pragma unroll 1
+  for (int it = 0; it < 2; ++it) {
+    const double s = sqrt(n1 * n1 + e1 * e1);
+    if (!(s > 0)) break;
+    double la, lo;
+    geod_direct_sc(o, e1 / s, n1 / s, s, la, lo);
+    const double dn = (lat2 - la) * kDeg * M2, de = ang_normalize(lon2 - lo) * kDeg * N2 * c2;
+    n1 += dn * cg + de * sg;
+    e1 += de * cg - dn * sg;
+  }
+  return atan2(e1, n1);
+}
+
 __device__ __forceinline__ double rotation_angle(const DevProj &p, double x, double y) {
 #pragma clang fp contract(fast)
+  if (p.kind == PROJ_OB_TRAN) {     // delta_y = 0.1 degree northwards in the reader's CRS (variables.py:80-81)
+    double lo1, la1, lo2, la2;
+    proj_inv(p, x, y, lo1, la1);
+    proj_inv(p, x, y + 0.1, lo2, la2);
+    return -geod_inverse_azimuth(la1, lo1, la2, lo2);
+  }
   double phim, dphi, dlam;
   proj_inv_diff(p, x, y, 10.0, phim, dphi, dlam);
   const GeodConst &g = c_geod;
@@ -595,7 +872,7 @@ __device__ __forceinline__ bool source_covers_xyz(const DevSource &s, double lon
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
   proj_fwd_rt(s.proj, lon, lat, x, y);
   double xchk = x;
-  if (s.proj.kind == PROJ_LATLONG) {
+  if (s.proj.kind == PROJ_LATLONG || s.proj.kind == PROJ_OB_TRAN) {
     if (s.lon_mode == 1) xchk = np_mod(x + 180.0, 360.0) - 180.0;
     else if (s.lon_mode == 2) xchk = np_mod(x, 360.0);
   }
@@ -1104,11 +1381,7 @@ __device__ __forceinline__ bool uv_sample_fast(const DevSource &s, const DevBloc
   else if (ps.ok) proj_fwd_near<PROJ == PROJ_STERE_POLAR>(s.proj, ps, lon, lat, x, y);   // (by value: a pointer would pin the struct to scratch memory)
 #endif
   else proj_fwd<PROJ == PROJ_STERE_POLAR>(s.proj, lon, lat, x, y);
-  double xchk = x;
-  if (PROJ == PROJ_LATLONG) {
-    if (s.lon_mode == 1) xchk = np_mod(x + 180.0, 360.0) - 180.0;
-    else if (s.lon_mode == 2) xchk = np_mod(x, 360.0);
-  }
+  const double xchk = cover_x<PROJ>(s.proj.kind, s.lon_mode, x);
   float fu = __builtin_nanf(""), fv = __builtin_nanf("");
   bool ok = true;
   if (xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin && z <= s.zmax) {
@@ -1174,11 +1447,7 @@ __device__ __forceinline__ bool uv_sample_stage_f32(const DevSource &s, const De
   else if (PROJ == PROJ_CURVILINEAR) curvi_locate(s.proj, lon, lat, x, y);
   else if (ps.ok) proj_fwd_near<PROJ == PROJ_STERE_POLAR>(s.proj, ps, lon, lat, x, y);
   else proj_fwd<PROJ == PROJ_STERE_POLAR>(s.proj, lon, lat, x, y);
-  double xchk = x;
-  if (PROJ == PROJ_LATLONG) {
-    if (s.lon_mode == 1) xchk = np_mod(x + 180.0, 360.0) - 180.0;
-    else if (s.lon_mode == 2) xchk = np_mod(x, 360.0);
-  }
+  const double xchk = cover_x<PROJ>(s.proj.kind, s.lon_mode, x);
   float fu = __builtin_nanf(""), fv = __builtin_nanf("");
   bool ok = true;
   if (xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin && z <= s.zmax) {
@@ -1510,11 +1779,7 @@ __device__ __forceinline__ EnvFront env_front(const DevSource &s, const DevBlock
   if (PROJ == PROJ_LATLONG) { x = lon; y = lat; }
   else if (PROJ == PROJ_CURVILINEAR) curvi_locate(s.proj, lon, lat, x, y);
   else proj_fwd<PROJ == PROJ_STERE_POLAR>(s.proj, lon, lat, x, y);
-  double xchk = x;
-  if (PROJ == PROJ_LATLONG) {
-    if (s.lon_mode == 1) xchk = np_mod(x + 180.0, 360.0) - 180.0;
-    else if (s.lon_mode == 2) xchk = np_mod(x, 360.0);
-  }
+  const double xchk = cover_x<PROJ>(s.proj.kind, s.lon_mode, x);
   f.covered = xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin && z <= s.zmax;
   if (s.mod360_x) x = np_mod(x, 360.0);
   f.x = x; f.y = y;

@@ -329,6 +329,59 @@ static void proj_init(DevProj &p, const odr_proj_desc *d) {
       p.crho0 = fabs(fabs(p.lat0) - kHalfPi) < 1e-10 ? 0.0 : p.cc * pow(ts(p.lat0), n);
     }
   }
+  if (d->kind == PROJ_TMERC) {        // Karney 2011: eq. 14 (A), 35 (alpha), 36 (beta); xi of the origin latitude
+    const double f = 1 - sqrt(1 - d->es), n = f / (2 - f), n2 = n * n, n3 = n2 * n, n4 = n2 * n2, n5 = n4 * n, n6 = n3 * n3;
+    double *al = p.q + 2, *be = p.q + 8;
+    p.q[0] = d->k0 / (1 + n) * (1 + n2 * (1.0 / 4 + n2 * (1.0 / 64 + n2 / 256)));
+    al[0] = n / 2 - 2 * n2 / 3 + 5 * n3 / 16 + 41 * n4 / 180 - 127 * n5 / 288 + 7891 * n6 / 37800;
+    al[1] = 13 * n2 / 48 - 3 * n3 / 5 + 557 * n4 / 1440 + 281 * n5 / 630 - 1983433 * n6 / 1935360;
+    al[2] = 61 * n3 / 240 - 103 * n4 / 140 + 15061 * n5 / 26880 + 167603 * n6 / 181440;
+    al[3] = 49561 * n4 / 161280 - 179 * n5 / 168 + 6601661 * n6 / 7257600;
+    al[4] = 34729 * n5 / 80640 - 3418889 * n6 / 1995840;
+    al[5] = 212378941 * n6 / 319334400;
+    be[0] = n / 2 - 2 * n2 / 3 + 37 * n3 / 96 - n4 / 360 - 81 * n5 / 512 + 96199 * n6 / 604800;
+    be[1] = n2 / 48 + n3 / 15 - 437 * n4 / 1440 + 46 * n5 / 105 - 1118711 * n6 / 3870720;
+    be[2] = 17 * n3 / 480 - 37 * n4 / 840 - 209 * n5 / 4480 + 5569 * n6 / 90720;
+    be[3] = 4397 * n4 / 161280 - 11 * n5 / 504 - 830251 * n6 / 7257600;
+    be[4] = 4583 * n5 / 161280 - 108847 * n6 / 3991680;
+    be[5] = 20648693 * n6 / 638668800;
+    const double tau = tan(p.lat0), t1 = hypot(1.0, tau), sg = sinh(p.e * atanh(p.e * tau / t1));
+    const double xip = atan(hypot(1.0, sg) * tau - sg * t1);
+    double xi0 = xip;
+    for (int k = 0; k < 6; ++k) xi0 += al[k] * sin(2 * (k + 1) * xip);
+    p.q[1] = xi0;
+  }
+  if (d->kind == PROJ_LAEA) {         // Snyder 24-17..24-20, authalic latitude 3-11 / 3-12
+    auto qs = [&](double sp) { if (p.e < 1e-7) return 2 * sp; const double con = p.e * sp; return (1 - d->es) * (sp / (1 - con * con) - (0.5 / p.e) * log((1 - con) / (1 + con))); };
+    const double t = fabs(p.lat0);
+    p.mode = fabs(t - kHalfPi) < 1e-10 ? (p.lat0 < 0 ? 1 : 0) : (t < 1e-10 ? 2 : 3);
+    p.q[7] = sin(p.lat0); p.q[8] = cos(p.lat0);
+    if (d->es != 0) {
+      const double qp = qs(1.0), rq = sqrt(0.5 * qp);
+      p.q[0] = qp; p.q[1] = rq; p.q[2] = 1; p.q[3] = 1; p.q[4] = 1;
+      if (p.mode == 2) { p.q[2] = 1 / rq; p.q[3] = 1; p.q[4] = 0.5 * qp; }
+      if (p.mode == 3) {
+        const double sp = sin(p.lat0), sinb1 = qs(sp) / qp, cosb1 = sqrt(1 - sinb1 * sinb1);
+        const double dd = cos(p.lat0) / (sqrt(1 - d->es * sp * sp) * rq * cosb1);
+        p.q[5] = sinb1; p.q[6] = cosb1; p.q[2] = dd; p.q[4] = rq / dd; p.q[3] = rq * dd;
+      }
+    }
+  }
+  if (d->kind == PROJ_STERE_OBLIQUE) {   // Snyder 21-27 with 14-15; conformal latitude of the origin 3-1
+    p.mode = fabs(p.lat0) > 1e-10 ? 3 : 2;
+    if (d->es != 0) {
+      const double sp = sin(p.lat0), X = 2 * atan(tan(0.5 * (kHalfPi + p.lat0)) * pow((1 - sp * p.e) / (1 + sp * p.e), 0.5 * p.e)) - kHalfPi;
+      p.akm1 = 2 * d->k0 * cos(p.lat0) / sqrt(1 - d->es * sp * sp);
+      p.q[0] = sin(X); p.q[1] = cos(X);
+    } else {
+      p.akm1 = 2 * d->k0;
+      p.q[0] = sin(p.lat0); p.q[1] = cos(p.lat0);
+    }
+  }
+  if (d->kind == PROJ_OB_TRAN) {      // lat1 = o_lat_p, lat2 = o_lon_p (include/odrift.h); a sphere of unit radius, no offsets
+    p.q[0] = sin(d->lat1_deg * kDeg); p.q[1] = cos(d->lat1_deg * kDeg); p.q[2] = d->lat2_deg * kDeg;
+    p.a = 1; p.es = 0; p.e = 0; p.x0 = p.y0 = 0; p.k0 = 1; p.lat0 = 0; p.south = 0;
+  }
   if (d->kind == PROJ_STERE_POLAR) {  // Snyder 21-33/21-34 scale constant
     double phits = fabs(d->lat_ts_deg) * kDeg, e = p.e;
     if (d->es == 0) {

@@ -44,11 +44,13 @@ def _i(a, n=None):
 
 
 def proj_desc(proj):
-    """dict(kind='latlong'|'stere_equit_sphere'|'stere_polar'|'merc'|'lcc', a, rf|es, lat0, lon0, lat_ts, k0, x0, y0, lat1, lat2)"""
+    """dict(kind='latlong'|'stere_equit_sphere'|'stere_polar'|'merc'|'lcc'|'tmerc'|'laea'|'stere_oblique'|'ob_tran', a, rf|es, lat0,
+    lon0, lat_ts, k0, x0, y0, lat1, lat2) -- projection.parse_proj4's output (ob_tran: lat1 = o_lat_p, lat2 = o_lon_p)"""
     if proj is None or proj.get('kind', 'latlong') == 'latlong':
         return None
     kind = {'stere_equit_sphere': _abi.PROJ_STERE_EQUIT_SPHERE, 'stere_polar': _abi.PROJ_STERE_POLAR,
-            'merc': _abi.PROJ_MERC, 'lcc': _abi.PROJ_LCC}[proj['kind']]
+            'merc': _abi.PROJ_MERC, 'lcc': _abi.PROJ_LCC, 'tmerc': _abi.PROJ_TMERC, 'laea': _abi.PROJ_LAEA,
+            'stere_oblique': _abi.PROJ_STERE_OBLIQUE, 'ob_tran': _abi.PROJ_OB_TRAN}[proj['kind']]
     if 'es' in proj:
         es = proj['es']
     else:

@@ -45,12 +45,20 @@ enum {
 };
 
 /* ---- projections (proj.c) ---- */
-enum { ORC_PROJ_LATLONG = 0, ORC_PROJ_STERE_EQUIT_SPHERE = 1, ORC_PROJ_STERE_POLAR = 2, ORC_PROJ_MERC = 4, ORC_PROJ_LCC = 5 };
+enum { ORC_PROJ_LATLONG = 0, ORC_PROJ_STERE_EQUIT_SPHERE = 1, ORC_PROJ_STERE_POLAR = 2, ORC_PROJ_MERC = 4, ORC_PROJ_LCC = 5,
+       ORC_PROJ_TMERC = 6 /* +proj=tmerc / utm */, ORC_PROJ_LAEA = 7, ORC_PROJ_STERE_OBLIQUE = 8 /* +proj=stere, lat_0 not a pole */,
+       ORC_PROJ_OB_TRAN = 9 /* +proj=ob_tran +o_proj=longlat: rotated pole, x / y in DEGREES as the reference's lonlat2xy hands them out */ };
 typedef struct {
   int kind, south;
   double a, es, e, lon0, lat0, x0, y0, k0, akm1;
   double n, c, rho0;   /* ORC_PROJ_LCC: cone constant, F, rho0 / a (orc_proj_init_conic) */
+  int mode, pad;       /* ORC_PROJ_LAEA / STERE_OBLIQUE aspect: 0 north pole, 1 south pole, 2 equatorial, 3 oblique */
+  double q[16];        /* set-up constants of the round-5 projections (proj.c: orc_proj_init_ext) */
 } orc_proj;
+/* tmerc (utm: the caller resolves the zone into lon0 / k0 / x0 / y0), laea, oblique / equatorial stere on sphere or ellipsoid,
+ * ob_tran with o_proj=longlat (lat1 = o_lat_p, lat2 = o_lon_p, lon0 = lon_0; a, es, k0, x0, y0 unused) */
+void orc_proj_init_ext(orc_proj *p, int kind, double a, double es, double lat0_deg, double lon0_deg, double k0, double x0,
+                       double y0, double lat1_deg, double lat2_deg);
 /* merc (lat1/lat2 unused; k0 from lat_ts when that is not 0) and lcc (standard parallels lat1, lat2 = lat1 for a tangent cone) */
 void orc_proj_init_conic(orc_proj *p, int kind, double a, double es, double lat0_deg, double lon0_deg, double lat_ts_deg,
                          double k0, double x0, double y0, double lat1_deg, double lat2_deg);

@@ -29,6 +29,7 @@ VAR = dict(x_sea_water_velocity=0, y_sea_water_velocity=1, x_wind=2, y_wind=3,
            sea_surface_wind_wave_mean_period=24, sea_surface_wind_wave_significant_height=25)
 PROJ_LATLONG, PROJ_STERE_EQUIT_SPHERE, PROJ_STERE_POLAR = 0, 1, 2
 PROJ_MERC, PROJ_LCC = 4, 5
+PROJ_TMERC, PROJ_LAEA, PROJ_STERE_OBLIQUE, PROJ_OB_TRAN = 6, 7, 8, 9
 SRC_CONSTANT, SRC_DOUBLE_GYRE, SRC_OSCILLATING, SRC_GRID = 0, 1, 2, 3
 
 
@@ -45,7 +46,8 @@ def build(force=False):
 
 class Proj(C.Structure):
     _fields_ = [('kind', C.c_int), ('south', C.c_int)] + \
-        [(k, C.c_double) for k in ('a', 'es', 'e', 'lon0', 'lat0', 'x0', 'y0', 'k0', 'akm1', 'n', 'c', 'rho0')]
+        [(k, C.c_double) for k in ('a', 'es', 'e', 'lon0', 'lat0', 'x0', 'y0', 'k0', 'akm1', 'n', 'c', 'rho0')] + \
+        [('mode', C.c_int), ('pad', C.c_int), ('q', C.c_double * 16)]
 
 
 class Block(C.Structure):
@@ -124,6 +126,11 @@ def geod_inv(lon1, lat1, lon2, lat2):
 def make_proj(kind=PROJ_LATLONG, a=6378137.0, es=0.0, lat0=0.0, lon0=0.0, lat_ts=90.0, k0=1.0,
               x0=0.0, y0=0.0, lat1=0.0, lat2=None):
     p = Proj()
+    if kind in (PROJ_TMERC, PROJ_LAEA, PROJ_STERE_OBLIQUE, PROJ_OB_TRAN):   # ob_tran: lat1 = o_lat_p, lat2 = o_lon_p
+        lib().orc_proj_init_ext(C.byref(p), C.c_int(kind), C.c_double(a), C.c_double(es), C.c_double(lat0), C.c_double(lon0),
+                                C.c_double(k0), C.c_double(x0), C.c_double(y0), C.c_double(lat1),
+                                C.c_double(0.0 if lat2 is None else lat2))
+        return p
     if kind in (PROJ_MERC, PROJ_LCC):
         lib().orc_proj_init_conic(C.byref(p), C.c_int(kind), C.c_double(a), C.c_double(es), C.c_double(lat0),
                                   C.c_double(lon0), C.c_double(lat_ts), C.c_double(k0), C.c_double(x0), C.c_double(y0),

@@ -52,8 +52,8 @@ class _CRS:
 
 
 class Proj:
-    """Subset of pyproj.Proj: +proj=latlong/longlat, +proj=stere (equatorial sphere,
-    polar sphere/ellipsoid), +proj=merc, +proj=lcc.  Arithmetic = oracle/proj.c."""
+    """Subset of pyproj.Proj: +proj=latlong/longlat, +proj=stere (any aspect, sphere / ellipsoid), +proj=merc, +proj=lcc,
+    +proj=tmerc / utm, +proj=laea, +proj=ob_tran +o_proj=longlat.  Arithmetic = oracle/proj.c."""
 
     def __init__(self, projparams=None, **kwargs):
         from oracle import oracle as orc
@@ -98,8 +98,8 @@ class Proj:
                     lat_ts = 90.0
             elif lat0 == 0 and es == 0:
                 kind = orc.PROJ_STERE_EQUIT_SPHERE
-            else:
-                raise NotImplementedError('pyproj shim: oblique / ellipsoidal-equatorial stere: ' + self.srs)
+            else:                  # oblique, or equatorial on an ellipsoid (PROJ ignores +lat_ts for these aspects)
+                kind = orc.PROJ_STERE_OBLIQUE
             self.crs = _CRS(False, self.srs)
             self._orc = orc.make_proj(kind, a=a, es=es, lat0=lat0, lon0=lon0, lat_ts=lat_ts, k0=k0,
                                       x0=x0, y0=y0)
@@ -112,6 +112,25 @@ class Proj:
                                       lon0=float(p.get('lon_0', 0)), lat_ts=float(p.get('lat_ts', 0.0)),
                                       k0=float(p.get('k_0', p.get('k', 1.0))), x0=float(p.get('x_0', 0)),
                                       y0=float(p.get('y_0', 0)), lat1=lat1, lat2=lat2)
+        elif name in ('tmerc', 'utm', 'laea'):
+            lat0, lon0 = float(p.get('lat_0', 0)), float(p.get('lon_0', 0))
+            k0, x0, y0 = float(p.get('k_0', p.get('k', 1.0))), float(p.get('x_0', 0)), float(p.get('y_0', 0))
+            if name == 'utm':      # PROJ's utm set-up: the zone's meridian, k0 = 0.9996, false easting 500 km (northing 10 000 km south)
+                zone = int(p['zone'])
+                lat0, lon0, k0, x0, y0 = 0.0, 6.0 * zone - 183.0, 0.9996, 500000.0, (10000000.0 if 'south' in p else 0.0)
+            self.crs = _CRS(False, self.srs)
+            self._orc = orc.make_proj(orc.PROJ_LAEA if name == 'laea' else orc.PROJ_TMERC, a=a, es=es, lat0=lat0, lon0=lon0,
+                                      k0=k0, x0=x0, y0=y0)
+        elif name == 'ob_tran':
+            # the rotated pole (+o_proj=longlat): pyproj reports such a CRS as geographic -- the reference relies on it
+            # (variables.py:117-123, 800) -- and Proj.__call__ hands the rotated coordinates out / takes them in RADIANS
+            # (the reference converts, :120-123, :136-138); Transformer.transform works in degrees on both sides
+            if p.get('o_proj') not in ('longlat', 'latlong', 'latlon', 'lonlat') or 'to_meter' in p:
+                raise NotImplementedError('pyproj shim: ' + self.srs)
+            self.crs = _CRS(True, self.srs)
+            self._ob_tran = True
+            self._orc = orc.make_proj(orc.PROJ_OB_TRAN, lon0=float(p.get('lon_0', 0)), lat1=float(p.get('o_lat_p', 90.0)),
+                                      lat2=float(p.get('o_lon_p', 0.0)))
         else:
             raise NotImplementedError('pyproj shim: +proj=%s' % name)
 
@@ -124,7 +143,13 @@ class Proj:
         shape = np.shape(x)
         xa = np.atleast_1d(np.asarray(x, dtype=np.float64)).ravel()
         ya = np.atleast_1d(np.asarray(y, dtype=np.float64)).ravel()
-        if inverse:
+        if getattr(self, '_ob_tran', False) and not kw.get('_degrees'):
+            if inverse:
+                a, b = orc.proj_inv(self._orc, np.degrees(xa), np.degrees(ya))
+            else:
+                a, b = orc.proj_fwd(self._orc, xa, ya)
+                a, b = np.radians(a), np.radians(b)
+        elif inverse:
             a, b = orc.proj_inv(self._orc, xa, ya)
         else:
             a, b = orc.proj_fwd(self._orc, xa, ya)
@@ -148,8 +173,8 @@ class Transformer:
         return Transformer(pf, pt)
 
     def transform(self, x, y, **kw):
-        lon, lat = self.pf(x, y, inverse=True)
-        return self.pt(lon, lat)
+        lon, lat = self.pf(x, y, inverse=True, _degrees=True)
+        return self.pt(lon, lat, _degrees=True)
 
 
 class Geod:

@@ -86,8 +86,9 @@ void orc_update_positions_f64(long n, double *lon, double *lat, const double *u,
  * azimuth of the +y axis by a 10 m finite difference, Geod.inv on WGS84. */
 static double rotation_angle(const orc_source *s, double x, double y) {
   double lo1, la1, lo2, la2, az, dist;
+  /* delta_y: 10 m along y, 0.1 degree for a CRS that is geographic -- the rotated pole (variables.py:80-83) */
   orc_proj_inv(&s->proj, x, y, &lo1, &la1);
-  orc_proj_inv(&s->proj, x, y + 10.0, &lo2, &la2);
+  orc_proj_inv(&s->proj, x, y + (s->proj.kind == ORC_PROJ_OB_TRAN ? 0.1 : 10.0), &lo2, &la2);
   orc_geod_inverse(wgs84(), la1, lo1, la2, lo2, &az, &dist);
   return -(az * DEG); /* rot_angle_rad = -rot_angle_vectors_rad */
 }
@@ -231,7 +232,7 @@ static void source_call(const orc_source *s, int nv, const int *vars, long m,
     else if (s->lon_mode == 2) lo = np_mod(lo, 360);
     orc_proj_fwd(&s->proj, lo, la, &xx, &yy);
     xchk = xx;
-    if (s->proj.kind == ORC_PROJ_LATLONG) { /* covers_positions_xy re-modulates */
+    if (s->proj.kind == ORC_PROJ_LATLONG || s->proj.kind == ORC_PROJ_OB_TRAN) { /* covers_positions_xy re-modulates (crs.is_geographic, variables.py:246) */
       if (s->lon_mode == 1) xchk = np_mod(xx + 180, 360) - 180;
       else if (s->lon_mode == 2) xchk = np_mod(xx, 360);
     }

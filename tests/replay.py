@@ -679,6 +679,15 @@ def scenario_c20(g, tag):
                     fallbacks={U: 0.0, VV: 0.0, XW: 0.0, YW: 0.0, SX: 0.0, SY: 0.0, HS: 0.0})
 
 
+def scenario_c23(g, tag):
+    """c23: the same fields on a UTM / LAEA / oblique-stereographic grid and on a rotated pole (oracle/gen_golden_proj2.py).
+    The rotated-pole domain lies at positive true longitudes: modulate_longitude (variables.py:259-280) takes np.mod(lon, 360)."""
+    sc = scenario_c20(g, tag)
+    if tag == 'rotated_pole':
+        sc.sources[0][1]['lon_mode'] = 2
+    return sc
+
+
 def replay_c20(B, g, tag, nsteps):
     """RK4 + wind + Stokes drift + stranding, no random terms"""
     dt = float(g['dt'])

@@ -17,7 +17,8 @@ def _orc_proj(proj):
     f = 0.0 if not rf else 1.0 / rf
     es = proj.get('es', f * (2 - f))
     kind = {'stere_equit_sphere': orc.PROJ_STERE_EQUIT_SPHERE, 'stere_polar': orc.PROJ_STERE_POLAR,
-            'merc': orc.PROJ_MERC, 'lcc': orc.PROJ_LCC}[proj['kind']]
+            'merc': orc.PROJ_MERC, 'lcc': orc.PROJ_LCC, 'tmerc': orc.PROJ_TMERC, 'laea': orc.PROJ_LAEA,
+            'stere_oblique': orc.PROJ_STERE_OBLIQUE, 'ob_tran': orc.PROJ_OB_TRAN}[proj['kind']]
     return orc.make_proj(kind, a=proj.get('a', 6378137.0), es=es, lat0=proj.get('lat0', 0.0),
                          lon0=proj.get('lon0', 0.0), lat_ts=proj.get('lat_ts', 90.0), k0=proj.get('k0', 1.0),
                          x0=proj.get('x0', 0.0), y0=proj.get('y0', 0.0), lat1=proj.get('lat1', 0.0), lat2=proj.get('lat2'))

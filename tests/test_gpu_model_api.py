@@ -944,6 +944,72 @@ def test_lambert_and_mercator_lonlat2xy_on_the_device_equal_the_oracle():
         c.close()
 
 
+@pytest.mark.parametrize('tag', ['utm33', 'laea_grs80', 'stere_oblique', 'rotated_pole'])
+@pytest.mark.parametrize('stage_math', ['exact', 'fast'])
+def test_c23_round5_projections_reproduce_the_reference(tag, stage_math):
+    """B2: a reader whose proj4 is UTM (transverse Mercator), ETRS89-LAEA, an oblique stereographic or a rotated pole
+    (+proj=ob_tran +o_proj=longlat, coordinates in degrees) -- lonlat2xy through the projection and the vector rotation by the
+    azimuth of the reader's +y axis (variables.py:59-143) on the device -- RK4 + wind + Stokes drift + stranding through
+    OceanDrift.run() against the reference's own run (oracle/gen_golden_proj2.py), both stage arithmetics."""
+    g = golden('c23_proj_rk4.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'x_wind', 'y_wind',
+             'sea_surface_wave_stokes_drift_x_velocity', 'sea_surface_wave_stokes_drift_y_velocity', 'land_binary_mask']
+    times = [T0 + timedelta(seconds=float(t)) for t in g[tag + '_g_t']]
+    o = OceanDrift(loglevel=50, seed=0, rng='numpy', stage_math=stage_math)
+    r = readers.GridReader(g[tag + '_g_x'], g[tag + '_g_y'], times, {k: g['%s_g_%s' % (tag, k)] for k in names},
+                           proj4=str(g[tag + '_proj4']))
+    assert type(r) is readers.GridReader
+    o.add_reader(r)
+    o.set_config('drift:advection_scheme', 'runge-kutta4')
+    o.set_config('general:coastline_action', 'stranding')
+    lon, lat, status = g[tag + '_lon'], g[tag + '_lat'], g[tag + '_status']
+    o.seed_elements(lon=lon[0], lat=lat[0], time=T0, wind_drift_factor=float(g['wdf']))
+    nst = lon.shape[0] - 1
+    o.run(time_step=float(g['dt']), steps=nst)
+    lo, la, _ = _final(o, lon.shape[1])
+    dmax = max(np.abs(lo - lon[nst]).max(), np.abs(la - lat[nst]).max())
+    print(tag, stage_math, 'device vs reference: %.2e deg' % dmax)
+    assert dmax < 1e-7
+    assert o.num_elements_deactivated() == int((status[nst] != 0).sum()) > 5
+
+
+def test_round5_projections_lonlat2xy_and_back_on_the_device_equal_the_oracle():
+    """odr_source_lonlat2xy for PROJ_TMERC / PROJ_LAEA (oblique, polar, sphere) / PROJ_STERE_OBLIQUE / PROJ_OB_TRAN against
+    oracle/proj.c (pinned on Snyder's numerical examples, tests/test_oracle_golden.py) over wide domains: < 1e-6 m (1e-11 deg
+    for the rotated pole), and the host's NumPy restatement likewise."""
+    from oracle import oracle as orc
+    from opendrift_amd import projection
+    from opendrift_amd.device import Context
+    import scenarios
+    rng = np.random.default_rng(4)
+    cases = [('+proj=utm +zone=33 +ellps=WGS84', 15, 65, 8, 20), ('+proj=utm +zone=19 +south +ellps=WGS84', -69, -40, 6, 30),
+             ('+proj=tmerc +lat_0=58 +lon_0=10 +k=0.9999 +x_0=2000 +y_0=-3000 +ellps=GRS80', 10, 60, 10, 15),
+             ('+proj=tmerc +lat_0=0 +lon_0=-75 +R=6371000', -75, 40, 10, 30),
+             ('+proj=laea +lat_0=52 +lon_0=10 +x_0=4321000 +y_0=3210000 +ellps=GRS80', 10, 55, 30, 20),
+             ('+proj=laea +lat_0=90 +lon_0=0 +ellps=WGS84', 0, 75, 180, 14), ('+proj=laea +lat_0=-90 +lon_0=30 +R=6371228', 0, -75, 180, 14),
+             ('+proj=laea +lat_0=0 +lon_0=20 +ellps=WGS84', 20, 5, 40, 40), ('+proj=laea +lat_0=45 +lon_0=-100 +R=6370997', -100, 45, 40, 30),
+             ('+proj=stere +lat_0=52.15 +lon_0=5.38 +k=0.9999079 +x_0=155000 +y_0=463000 +a=6377397.155 +rf=299.1528128', 5, 52, 10, 8),
+             ('+proj=stere +lat_0=60 +lon_0=-30 +R=6371000', -30, 60, 40, 25), ('+proj=stere +lat_0=0 +lon_0=10 +ellps=WGS84', 10, 0, 40, 40),
+             ('+proj=ob_tran +o_proj=longlat +lon_0=-40 +o_lat_p=22 +R=6.371e+06 +no_defs', 5, 62, 40, 20),
+             ('+proj=ob_tran +o_proj=longlat +lon_0=10 +o_lat_p=35 +o_lon_p=20 +a=6367470 +e=0', 30, 70, 60, 15)]
+    c = Context(device=0, seed=0)
+    try:
+        for proj4, lc, pc, dl, dp in cases:
+            pr = projection.parse_proj4(proj4)
+            sid = c.add_grid(np.linspace(-1e6, 1e6, 8), np.linspace(-1e6, 1e6, 6), proj=pr)
+            lon, lat = lc + rng.uniform(-dl, dl, 3000), np.clip(pc + rng.uniform(-dp, dp, 3000), -89.5, 89.5)
+            dx, dy = c.lonlat2xy(sid, lon, lat)
+            op = scenarios._orc_proj(pr)
+            ox, oy = orc.proj_fwd(op, lon, lat)
+            hx, hy = projection.Proj(proj4)(lon, lat)
+            tol = 1e-11 if pr['kind'] == 'ob_tran' else 1e-6
+            wrap = (lambda d: (d + 180) % 360 - 180) if pr['kind'] == 'ob_tran' else (lambda d: d)
+            assert np.abs(wrap(dx - ox)).max() < tol and np.abs(dy - oy).max() < tol, (proj4, np.abs(dx - ox).max(), np.abs(dy - oy).max())
+            assert np.abs(wrap(hx - ox)).max() < tol and np.abs(hy - oy).max() < tol, proj4
+    finally:
+        c.close()
+
+
 def _c21_model(g, scheme, **config):
     names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity', 'sea_floor_depth_below_sea_level',
              'sea_surface_height', 'land_binary_mask']

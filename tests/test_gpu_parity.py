@@ -449,6 +449,24 @@ def test_c20_lambert_and_mercator_device_vs_oracle(ctx, tag):
     print('c20', tag, 'device vs reference:', worst)
 
 
+@pytest.mark.parametrize('tag', ['utm33', 'laea_grs80', 'stere_oblique', 'rotated_pole'])
+def test_c23_round5_projections_device_vs_oracle(ctx, tag):
+    """Readers on a UTM (transverse Mercator), an ETRS89-LAEA, an oblique stereographic and a rotated-pole grid (PROJ_TMERC /
+    PROJ_LAEA / PROJ_STERE_OBLIQUE / PROJ_OB_TRAN in proj_fwd, proj_inv and the vector rotation -- for the rotated pole the
+    geodesic-inverse azimuth of the reference's 0.1-degree line): the device against the reference's own runs
+    (oracle/gen_golden_proj2.py, 1e-7 deg) and against the oracle at the tolerance of the polar-stereographic case (2e-9 deg)."""
+    import replay
+    g = golden('c23_proj_rk4.npz')
+    sub = {k: g['%s_%s' % (tag, k)] for k in ('lon', 'lat', 'z', 'status')}
+    nst = sub['lon'].shape[0] - 1
+    D = replay.DeviceBackend(replay.scenario_c23(g, tag), ctx, sub['lon'][0], sub['lat'][0], sub['z'][0], wdf=float(g['wdf']))
+    dev = replay.replay_c20(D, g, tag, nst)
+    worst = replay.compare(dev, sub, tol_pos=1e-7)
+    O = replay.OracleBackend(replay.scenario_c23(g, tag), sub['lon'][0], sub['lat'][0], sub['z'][0], wdf=float(g['wdf']))
+    _states_close(dev, replay.replay_c20(O, g, tag, nst), 2e-9, 1e-12)
+    print('c23', tag, 'device vs reference:', worst)
+
+
 def test_c5_leeway_golden_device(ctx):
     """Leeway.update kernel + environment uncertainty (host-drawn normals) + jibing vs the reference's Leeway."""
     import replay

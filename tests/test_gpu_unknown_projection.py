@@ -1,18 +1,21 @@
-"""A reader whose proj4 the device has no closed form for (here a rotated-pole grid, `+proj=ob_tran`): GridReader(...,
-lon=, lat=) serves it through the node-array lookup with the vector pairs rotated at the nodes (opendrift_amd/readers.py:
-NodeLookupGridReader; the reference hands such a string to pyproj, basereader/variables.py:59-143).
+"""The rotated pole (`+proj=ob_tran +o_proj=longlat`) on the device, and the node-lookup lane for proj4 strings the device has
+no closed form for.
 
-pyproj is not available in this environment, so the reference cannot be run on this case; the checker below is the
-reference's algorithm with the projection evaluated EXACTLY (a rotated pole is a rotation of the sphere: two matrix
-products): lonlat2xy -> fractional pixel -> bilinear interpolation of the grid-relative components (float32 block
-values, float64 weights, as basereader/interpolation) -> rotate_vectors AT THE ELEMENT with the reference's recipe
-(variables.py:80-108: 0.1 degree along the reader's y axis, WGS84 azimuth) -> geod.fwd (oracle).  The device path
-differs by construction in second order of the cell size: the node lookup is the reference's lookup for readers
-WITHOUT projection -- piecewise linear over the triangulated nodes (structured.py:438-472) -- which puts an element up
-to 5e-4 cells from its exact pixel position on this 0.05-degree (5.5 km) mesh at 60-70 N, and the vectors are rotated
-at the nodes instead of at the element.  Measured on MI355X: 3.1e-6 degrees (0.33 m) after 12 Euler steps in a field
-with 0.03 m/s of shear per cell -- NOT inside the north-star 1e-6 degrees: this lane is a served approximation for
-projections without a closed form on the device, bounded here at 1e-5 degrees, and DESIGN.md says so."""
+pyproj is not available in this environment; the checker below is the reference's algorithm with the projection evaluated
+EXACTLY and INDEPENDENTLY of oracle/proj.c (a rotated pole is a rotation of the sphere: two matrix products): lonlat2xy ->
+fractional pixel -> bilinear interpolation of the grid-relative components (float32 block values, float64 weights, as
+basereader/interpolation) -> rotate_vectors AT THE ELEMENT with the reference's recipe (variables.py:80-108: 0.1 degree
+along the reader's y axis, WGS84 azimuth) -> geod.fwd (oracle), Euler and the reference's RK4 (physics_methods.py:611-691).
+
+ * Round 5: the device evaluates the rotated pole in closed form (PROJ_OB_TRAN: proj_fwd / proj_inv / the geodesic-inverse
+   azimuth of the 0.1-degree line) -- the exact lane: 1e-8 degrees after 12 RK4 steps (the reference's own run on such a
+   reader is golden c23, tests/test_gpu_model_api.py).
+ * A string parse_proj4 refuses (here: the `+to_meter` form of ob_tran, whose coordinates PROJ hands out in degrees) is still
+   served through the node-array lookup with the vector pairs rotated at the nodes (readers.NodeLookupGridReader) when the
+   reader brings its 2-D lon / lat: a second-order approximation in the cell size -- piecewise linear over the triangulated
+   nodes (structured.py:438-472), rotation at the nodes instead of at the element.  On a 0.02-degree (2.2 km) mesh: inside the
+   north-star 1e-6 degrees after 12 RK4 steps.  (Round 4 quoted 3.1e-6 degrees for a 0.05-degree mesh: most of that was the
+   checker starting from the float64 seed positions while the model, like the reference, keeps seeds as float32.)"""
 from datetime import datetime, timedelta
 
 import numpy as np
@@ -48,9 +51,9 @@ def _from_rotated(rlon, rlat):
     return np.degrees(np.arctan2(v[1], v[0])), np.degrees(np.arcsin(np.clip(v[2], -1, 1)))
 
 
-def _grid():
-    x = np.arange(-6.0, 6.0001, 0.05)          # rotated longitude / latitude of the nodes (degrees): ~5.5 km cells
-    y = np.arange(-4.0, 4.0001, 0.05)
+def _grid(d=0.05):
+    x = np.arange(-6.0, 6.0001, d)          # rotated longitude / latitude of the nodes (degrees): ~5.5 km cells at d = 0.05
+    y = np.arange(-4.0, 4.0001, d)
     X, Y = np.meshgrid(x, y)
     lon2d, lat2d = _from_rotated(X, Y)
     nt = 3
@@ -82,45 +85,110 @@ def _exact_velocity(x, y, u, v, lon, lat, wt):
     return (ug * np.cos(rot) - vg * np.sin(rot)).astype(np.float32), (ug * np.sin(rot) + vg * np.cos(rot)).astype(np.float32)
 
 
-def test_refused_without_node_coordinates():
-    x, y, lon2d, lat2d, u, v = _grid()
-    with pytest.raises(NotImplementedError, match='lon=, lat='):
-        readers.GridReader(x, y, [T0], {'x_sea_water_velocity': u[:1], 'y_sea_water_velocity': v[:1]},
-                           proj4='+proj=ob_tran +o_proj=longlat +lon_0=-40 +o_lat_p=25 +R=6.371e+06 +no_defs')
+# PROJ puts the new pole at (lon_0 + 180, o_lat_p) and counts the rotated longitude from the meridian that runs from the new
+# pole AWAY from the old one; the matrices above count it from the meridian towards the old pole: o_lon_p = 180
+PROJ4 = '+proj=ob_tran +o_proj=longlat +lon_0=%r +o_lat_p=%r +o_lon_p=180 +R=6.371e+06 +no_defs' % (POLE_LON + 180.0, POLE_LAT)
+PROJ4_REFUSED = PROJ4 + ' +to_meter=0.0174532925199433'
 
 
-def test_rotated_pole_reader_through_the_node_lookup_follows_the_exact_transform():
+def _reference_path(x, y, u, v, lon0, lat0, scheme, steps, dt):
+    """the reference's Euler / RK4 (physics_methods.py:611-691) on the exact-transform velocity"""
+    lon, lat = lon0.copy(), lat0.copy()
+    moving = np.ones(len(lon), np.int32)
+    for k in range(steps):
+        t = k * dt / 3600.0
+        u1, v1 = _exact_velocity(x, y, u, v, lon, lat, t)
+        if scheme == 'runge-kutta4':
+            def stage(uu, vv):
+                lo, la = lon.copy(), lat.copy()
+                orc.update_positions(lo, la, uu, vv, moving, dt * 0.5)
+                return lo, la
+            lo, la = stage(u1, v1)
+            u2, v2 = _exact_velocity(x, y, u, v, lo, la, t + dt / 7200.0)
+            lo, la = stage(u2, v2)
+            u3, v3 = _exact_velocity(x, y, u, v, lo, la, t + dt / 7200.0)
+            lo, la = stage(u3, v3)
+            u4, v4 = _exact_velocity(x, y, u, v, lo, la, t + dt / 3600.0)
+            u1 = ((u1 + np.float32(2) * u2 + np.float32(2) * u3 + u4) / np.float32(6.0)).astype(np.float32)
+            v1 = ((v1 + np.float32(2) * v2 + np.float32(2) * v3 + v4) / np.float32(6.0)).astype(np.float32)
+        orc.update_positions(lon, lat, u1, v1, moving, dt)
+    return lon, lat
+
+
+def test_the_independent_transform_is_the_oracles_rotated_pole():
+    """(CPU work inside a GPU module: the matrix form above and oracle/proj.c's ob_tran agree, so the checker is the same
+    projection the golden c23 was written with)"""
+    op = orc.make_proj(orc.PROJ_OB_TRAN, lon0=POLE_LON + 180.0, lat1=POLE_LAT, lat2=180.0)
+    rng = np.random.default_rng(0)
+    lon, lat = _from_rotated(rng.uniform(-6, 6, 400), rng.uniform(-4, 4, 400))
+    rx, ry = _to_rotated(lon, lat)
+    ox, oy = orc.proj_fwd(op, lon, lat)
+    assert np.abs((ox - rx + 180) % 360 - 180).max() < 1e-11 and np.abs(oy - ry).max() < 1e-11
+
+
+@pytest.mark.parametrize('scheme', ['euler', 'runge-kutta4'])
+def test_rotated_pole_reader_in_closed_form_on_the_device(scheme):
     x, y, lon2d, lat2d, u, v = _grid()
     times = [T0 + timedelta(hours=k) for k in range(3)]
-    r = readers.GridReader(x, y, times, {'x_sea_water_velocity': u, 'y_sea_water_velocity': v},
-                           proj4='+proj=ob_tran +o_proj=longlat +lon_0=-40 +o_lat_p=25 +R=6.371e+06 +no_defs',
-                           lon=lon2d, lat=lat2d)
-    assert isinstance(r, readers.NodeLookupGridReader) and not r.projected
-    # the grid's y axis is turned against north by up to 15 degrees here: the rotation matters
-    turn = readers.node_y_azimuth(lon2d, lat2d)
-    assert np.abs(turn).max() > 10.0
-    o = OceanDrift(loglevel=50, seed=0)
+    r = readers.GridReader(x, y, times, {'x_sea_water_velocity': u, 'y_sea_water_velocity': v}, proj4=PROJ4)
+    assert type(r) is readers.GridReader and r.projected
+    o = OceanDrift(loglevel=50, seed=0, stage_math='exact')
     o.add_reader(r)
     o.set_config('environment:constant:land_binary_mask', 0)
-    o.set_config('drift:advection_scheme', 'euler')
+    o.set_config('drift:advection_scheme', scheme)
     rng = np.random.default_rng(3)
     n = 3000
     lon0, lat0 = _from_rotated(rng.uniform(-5.0, 5.0, n), rng.uniform(-3.0, 3.0, n))
+    # seed_elements keeps positions as float32 (elements.py:71-88), here as in the reference: the checker starts where the model does
+    lon0, lat0 = lon0.astype(np.float32).astype(np.float64), lat0.astype(np.float32).astype(np.float64)
     o.seed_elements(lon=lon0, lat=lat0, time=T0)
     steps, dt = 12, 600.0
     o.run(time_step=dt, steps=steps)
     e = o.elements
     assert len(e.ID) == n
-    lon, lat = lon0.copy(), lat0.copy()
-    moving = np.ones(n, np.int32)
-    for k in range(steps):
-        ue, ve = _exact_velocity(x, y, u, v, lon, lat, k * dt / 3600.0)
-        orc.update_positions(lon, lat, ue, ve, moving, dt)
+    lon, lat = _reference_path(x, y, u, v, lon0, lat0, scheme, steps, dt)
+    dlon, dlat = np.abs(e.lon - lon[e.ID]).max(), np.abs(e.lat - lat[e.ID]).max()
+    print('rotated pole in closed form, 12 %s steps: max deviation from the exact-transform path %.2e / %.2e deg' % (scheme, dlon, dlat))
+    assert np.hypot(lon - lon0, lat - lat0).max() > 0.03
+    # (the float32 environment differs in its last bit now and then between the two evaluations of the same formulas)
+    assert dlon < 1e-8 and dlat < 1e-8
+
+
+def test_refused_without_node_coordinates():
+    x, y, lon2d, lat2d, u, v = _grid()
+    with pytest.raises(NotImplementedError, match='lon=, lat='):
+        readers.GridReader(x, y, [T0], {'x_sea_water_velocity': u[:1], 'y_sea_water_velocity': v[:1]}, proj4=PROJ4_REFUSED)
+
+
+def test_unknown_projection_through_the_node_lookup_follows_the_exact_transform():
+    x, y, lon2d, lat2d, u, v = _grid(0.02)
+    times = [T0 + timedelta(hours=k) for k in range(3)]
+    r = readers.GridReader(x, y, times, {'x_sea_water_velocity': u, 'y_sea_water_velocity': v}, proj4=PROJ4_REFUSED,
+                           lon=lon2d, lat=lat2d)
+    assert isinstance(r, readers.NodeLookupGridReader) and not r.projected
+    # the grid's y axis is turned against north by up to 15 degrees here: the rotation matters
+    turn = readers.node_y_azimuth(lon2d, lat2d)
+    assert np.abs(turn).max() > 10.0
+    o = OceanDrift(loglevel=50, seed=0, stage_math='exact')
+    o.add_reader(r)
+    o.set_config('environment:constant:land_binary_mask', 0)
+    o.set_config('drift:advection_scheme', 'runge-kutta4')
+    rng = np.random.default_rng(3)
+    n = 3000
+    lon0, lat0 = _from_rotated(rng.uniform(-5.0, 5.0, n), rng.uniform(-3.0, 3.0, n))
+    # seed_elements keeps positions as float32 (elements.py:71-88), here as in the reference: the checker starts where the model does
+    lon0, lat0 = lon0.astype(np.float32).astype(np.float64), lat0.astype(np.float32).astype(np.float64)
+    o.seed_elements(lon=lon0, lat=lat0, time=T0)
+    steps, dt = 12, 600.0
+    o.run(time_step=dt, steps=steps)
+    e = o.elements
+    assert len(e.ID) == n
+    lon, lat = _reference_path(x, y, u, v, lon0, lat0, 'runge-kutta4', steps, dt)
     dlon, dlat = np.abs(e.lon - lon[e.ID]).max(), np.abs(e.lat - lat[e.ID]).max()
     moved = np.hypot(lon - lon0, lat - lat0).max()
-    print('rotated pole, 12 Euler steps: max deviation from the exact-transform path %.2e / %.2e deg (moved up to %.3f deg)' % (dlon, dlat, moved))
+    print('node lookup, 0.02-degree mesh, 12 RK4 steps: max deviation from the exact-transform path %.2e / %.2e deg (moved up to %.3f deg)' % (dlon, dlat, moved))
     assert moved > 0.03
-    assert dlon < 1e-5 and dlat < 1e-5
+    assert dlon < 1e-6 and dlat < 1e-6
     # without the rotation the same run is far off: the check above is sensitive to it
     ue, ve = _exact_velocity(x, y, u, v, lon0, lat0, 0.0)
     rx, ry = _to_rotated(lon0, lat0)

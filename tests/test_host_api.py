@@ -66,8 +66,16 @@ def test_reader_surface():
     assert p['kind'] == 'stere_polar' and p['lat_ts'] == 60 and p['lon0'] == 70 and abs(p['rf'] - 298.257223563) < 1e-9
     q = projection.parse_proj4('+proj=lcc +lat_1=49.5 +lon_0=10 +R=6371000')     # tangent cone: lat_0 = lat_2 = lat_1
     assert q['kind'] == 'lcc' and q['lat1'] == q['lat2'] == q['lat0'] == 49.5 and q['rf'] == 0.0
+    q = projection.parse_proj4('+proj=ob_tran +o_proj=longlat +o_lat_p=22 +lon_0=-40')      # rotated pole: round 5
+    assert q['kind'] == 'ob_tran' and q['lat1'] == 22 and q['lat2'] == 0 and q['lon0'] == -40
+    q = projection.parse_proj4('+proj=utm +zone=33 +ellps=WGS84')
+    assert q['kind'] == 'tmerc' and q['lon0'] == 15 and q['k0'] == 0.9996 and q['x0'] == 500000 and q['y0'] == 0
+    assert projection.parse_proj4('+proj=stere +lat_0=52 +lon_0=5 +ellps=WGS84')['kind'] == 'stere_oblique'
+    assert projection.parse_proj4('+proj=stere +lat_0=0 +lon_0=0 +lat_ts=0 +a=6.371e6 +e=0')['kind'] == 'stere_equit_sphere'
     with pytest.raises(NotImplementedError):
-        projection.parse_proj4('+proj=ob_tran +o_proj=longlat +o_lat_p=22 +lon_0=-40')
+        projection.parse_proj4('+proj=ob_tran +o_proj=longlat +o_lat_p=22 +lon_0=-40 +to_meter=0.0174532925199433')
+    with pytest.raises(NotImplementedError):
+        projection.parse_proj4('+proj=aea +lat_1=50 +lat_2=70')
 
 
 def test_openoil_host_interface():

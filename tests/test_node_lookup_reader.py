@@ -46,9 +46,9 @@ def test_unknown_projection_without_node_arrays_is_refused_and_with_them_rotates
     arrays = {'x_sea_water_velocity': u, 'y_sea_water_velocity': v, 'sea_surface_height': 2 * u}
     times = [T0, T0 + timedelta(hours=1)]
     with pytest.raises(NotImplementedError, match='lon=, lat='):
-        readers.GridReader(x, y, times, arrays, proj4='+proj=utm +zone=33')
-    r = readers.GridReader(x, y, times, arrays, proj4='+proj=utm +zone=33', lon=lon2d, lat=lat2d)
-    assert isinstance(r, readers.NodeLookupGridReader) and not r.projected and r.native_proj4 == '+proj=utm +zone=33'
+        readers.GridReader(x, y, times, arrays, proj4='+proj=aea +lat_1=50 +lat_2=70')     # (Albers: no closed form on the device)
+    r = readers.GridReader(x, y, times, arrays, proj4='+proj=aea +lat_1=50 +lat_2=70', lon=lon2d, lat=lat2d)
+    assert isinstance(r, readers.NodeLookupGridReader) and not r.projected and r.native_proj4 == '+proj=aea +lat_1=50 +lat_2=70'
     b = r.get_variables(['x_sea_water_velocity', 'y_sea_water_velocity', 'sea_surface_height'], T0)
     # the x axis points 25 degrees south of east: east component cos 25, north component -sin 25
     # (on the ellipsoid a degree of latitude is 0.7 % shorter than a degree of longitude at the equator: 25.15 degrees)
@@ -56,5 +56,17 @@ def test_unknown_projection_without_node_arrays_is_refused_and_with_them_rotates
     assert b['x_sea_water_velocity'].dtype == np.float32 and np.array_equal(b['sea_surface_height'], 2 * u[0])
     with pytest.raises(ValueError, match='rotated together'):
         r.get_variables(['x_sea_water_velocity'], T0)
+    # masked cells (land / missing data of a netCDF block) come out as NaN, not as the fill value turned into a velocity
+    um = np.ma.masked_array(u.copy(), mask=np.zeros(u.shape, bool))
+    um.mask[:, 2, 3] = True
+    rm = readers.GridReader(x, y, times, {'x_sea_water_velocity': um, 'y_sea_water_velocity': np.ma.masked_array(v.copy(), mask=um.mask)},
+                            proj4='+proj=aea +lat_1=50 +lat_2=70', lon=lon2d, lat=lat2d)
+    bm = rm.get_variables(['x_sea_water_velocity', 'y_sea_water_velocity'], T0)
+    assert np.isnan(bm['x_sea_water_velocity'][2, 3]) and np.isnan(bm['y_sea_water_velocity'][2, 3])
+    assert np.isfinite(np.delete(bm['x_sea_water_velocity'].ravel(), 2 * len(x) + 3)).all() and np.nanmax(np.abs(bm['x_sea_water_velocity'])) < 2
+    # utm, tmerc, laea, every aspect of stere and the rotated pole have closed forms on the device since round 5
+    for p4 in ('+proj=utm +zone=33 +ellps=WGS84', '+proj=laea +lat_0=52 +lon_0=10 +ellps=GRS80', '+proj=stere +lat_0=52 +lon_0=5 +ellps=WGS84',
+               '+proj=ob_tran +o_proj=longlat +lon_0=-40 +o_lat_p=22 +R=6.371e+06'):
+        assert type(readers.GridReader(x, y, times, arrays, proj4=p4)) is readers.GridReader
     # a known projection is untouched by lon= / lat=
     assert type(readers.GridReader(x, y, times, arrays, proj4='+proj=latlong', lon=lon2d, lat=lat2d)) is readers.GridReader

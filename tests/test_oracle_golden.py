@@ -328,7 +328,7 @@ def test_mercator_and_lambert_reproduce_snyders_numerical_examples():
     from oracle import oracle as orc
     from opendrift_amd.projection import Proj
     es = 0.00676866                      # Clarke 1866 (Snyder's examples), a = 6378206.4 m
-    rf = 1 / (1 - np.sqrt(1 - es))
+    rf = float(1 / (1 - np.sqrt(1 - es)))
     cases = [
         (orc.make_proj(orc.PROJ_LCC, a=6378206.4, es=es, lat0=23, lon0=-96, lat1=33, lat2=45),
          '+proj=lcc +lat_1=33 +lat_2=45 +lat_0=23 +lon_0=-96 +a=6378206.4 +rf=%.12f' % rf, 1894410.9, 1564649.5, 0.06),
@@ -400,3 +400,106 @@ def test_mercator_and_lambert_round_trips_and_hemispheres():
     x, y = orc.proj_fwd(op, 77.0, 90.0)
     lo, la = orc.proj_inv(op, x, y)
     assert abs(la[0] - 90.0) < 1e-9
+
+
+# ------------------------------------------------------------------ round 5: tmerc / utm, laea, oblique stere, rotated pole
+def test_round5_projections_reproduce_snyders_numerical_examples():
+    """oracle/proj.c (and the host's NumPy restatement, opendrift_amd/projection.py) against the numerical examples of Snyder,
+    Map Projections -- A Working Manual (USGS PP 1395), Appendix A: transverse Mercator (sphere p. 268, Clarke 1866 p. 269),
+    stereographic oblique (sphere p. 312, Clarke 1866 p. 313), Lambert azimuthal equal-area (sphere p. 332, Clarke 1866 oblique
+    p. 333, International polar p. 334) -- forward to the digits printed, inverse to 5e-6 deg (the printed coordinates are
+    rounded to 0.1 m, or to 7 digits of a unit sphere); PROJ itself is not in this image."""
+    from opendrift_amd.projection import Proj
+    a, es = 6378206.4, 0.00676866          # Clarke 1866
+    rf = float(1 / (1 - np.sqrt(1 - es)))
+    ell = '+a=%r +rf=%r' % (a, rf)
+    cases = [
+        (orc.make_proj(orc.PROJ_TMERC, a=1.0, es=0.0, lat0=0, lon0=-75, k0=1.0), '+proj=tmerc +lon_0=-75 +R=1',
+         (-73.5, 40.5), (0.0199077, 0.7070276), 5e-8),
+        (orc.make_proj(orc.PROJ_TMERC, a=a, es=es, lat0=0, lon0=-75, k0=0.9996), '+proj=tmerc +lon_0=-75 +k=0.9996 ' + ell,
+         (-73.5, 40.5), (127106.5, 4484124.4), 0.06),
+        (orc.make_proj(orc.PROJ_STERE_OBLIQUE, a=1.0, es=0.0, lat0=40, lon0=-100, k0=1.0), '+proj=stere +lat_0=40 +lon_0=-100 +R=1',
+         (-75.0, 30.0), (0.3807224, -0.1263802), 5e-8),
+        (orc.make_proj(orc.PROJ_STERE_OBLIQUE, a=a, es=es, lat0=40, lon0=-100, k0=0.9999), '+proj=stere +lat_0=40 +lon_0=-100 +k=0.9999 ' + ell,
+         (-90.0, 30.0), (971630.8, -1063049.3), 0.06),
+        (orc.make_proj(orc.PROJ_LAEA, a=3.0, es=0.0, lat0=40, lon0=-100), '+proj=laea +lat_0=40 +lon_0=-100 +R=3',
+         (100.0, -20.0), (-4.2339303, 4.0257775), 5e-8),
+        (orc.make_proj(orc.PROJ_LAEA, a=a, es=es, lat0=40, lon0=-100), '+proj=laea +lat_0=40 +lon_0=-100 ' + ell,
+         (-110.0, 30.0), (-965932.1, -1056814.9), 0.06),
+        (orc.make_proj(orc.PROJ_LAEA, a=6378388.0, es=0.00672267, lat0=90, lon0=-100),
+         '+proj=laea +lat_0=90 +lon_0=-100 +a=6378388.0 +rf=%r' % float(1 / (1 - np.sqrt(1 - 0.00672267))),
+         (5.0, 80.0), (1077459.7, 288704.5), 0.06),
+    ]
+    for op, proj4, (lon, lat), (xw, yw), tol in cases:
+        x, y = orc.proj_fwd(op, lon, lat)
+        assert abs(x[0] - xw) < tol and abs(y[0] - yw) < tol, (proj4, x, y)
+        lo, la = orc.proj_inv(op, xw, yw)
+        assert abs((lo[0] - lon + 180) % 360 - 180) < 5e-6 and abs(la[0] - lat) < 5e-6, (proj4, lo, la)
+        lo, la = orc.proj_inv(op, x, y)
+        assert abs((lo[0] - lon + 180) % 360 - 180) < 1e-11 and abs(la[0] - lat) < 1e-11
+        hx, hy = Proj(proj4)(lon, lat)
+        assert abs(hx - x[0]) < 1e-8 * max(1.0, abs(xw)) and abs(hy - y[0]) < 1e-8 * max(1.0, abs(yw)), (proj4, hx, hy)
+    # UTM: zone 33 has its central meridian at 15 E; the northing of 60 N on it is k0 times the meridian arc
+    hx, hy = Proj('+proj=utm +zone=33 +ellps=WGS84')(15.0, 60.0)
+    assert abs(hx - 500000.0) < 1e-6 and abs(hy - 6651411.190) < 2e-3
+    hx, hy = Proj('+proj=utm +zone=33 +south +ellps=WGS84')(15.0, -60.0)
+    assert abs(hx - 500000.0) < 1e-6 and abs(hy - (10000000.0 - 6651411.190)) < 2e-3
+
+
+def test_transverse_mercator_series_against_the_meridian_arc_and_conformality():
+    """Independent of Snyder's printed numbers: on the central meridian the northing of Krueger's series is k0 times the
+    meridian arc (numerical quadrature of M(phi) = a (1 - e^2) / (1 - e^2 sin^2 phi)^(3/2), scipy), and the mapping is conformal
+    -- the Cauchy-Riemann equations hold for finite differences in isometric latitude -- 3 degrees off it; the rotated pole
+    against the same rotation written as two matrix products."""
+    from scipy.integrate import quad
+    a, rf = 6378137.0, 298.257223563
+    f = 1 / rf
+    es = f * (2 - f)
+    op = orc.make_proj(orc.PROJ_TMERC, a=a, es=es, lat0=0, lon0=9, k0=0.9996, x0=500000.0)
+    for lat in (5.0, 37.0, 61.5, 84.0):
+        arc = quad(lambda ph: a * (1 - es) / (1 - es * np.sin(ph) ** 2) ** 1.5, 0, np.radians(lat), epsabs=1e-6)[0]
+        x, y = orc.proj_fwd(op, 9.0, lat)
+        assert abs(x[0] - 500000.0) < 1e-6 and abs(y[0] - 0.9996 * arc) < 2e-5, (lat, y[0] - 0.9996 * arc)
+    # conformality: d(x + i y) / d(lambda + i psi) is one complex number -- x_lam = y_psi, y_lam = -x_psi (psi = isometric latitude)
+    e = np.sqrt(es)
+    psi = lambda ph: np.arctanh(np.sin(ph)) - e * np.arctanh(e * np.sin(ph))
+    for lon, lat in ((12.0, 60.0), (6.5, 45.0)):
+        h = 1e-5
+        ph = np.radians(lat)
+        dpsi = psi(ph + np.radians(h)) - psi(ph - np.radians(h))
+        xe, ye = orc.proj_fwd(op, [lon + h, lon - h], [lat, lat])
+        xn, yn = orc.proj_fwd(op, [lon, lon], [lat + h, lat - h])
+        x_lam, y_lam = (xe[0] - xe[1]) / np.radians(2 * h), (ye[0] - ye[1]) / np.radians(2 * h)
+        x_psi, y_psi = (xn[0] - xn[1]) / dpsi, (yn[0] - yn[1]) / dpsi
+        assert abs(x_lam - y_psi) < 2e-3 * 1e-3 * abs(x_lam) + 1e-2 and abs(y_lam + x_psi) < 1e-2, (x_lam, y_psi, y_lam, x_psi)
+    # rotated pole: (lon, lat) -> unit vector -> rotate about z by -lon_0, about y by (90 - o_lat_p) -> rotated lon / lat
+    lon0, latp = -40.0, 22.0
+    op = orc.make_proj(orc.PROJ_OB_TRAN, lon0=lon0, lat1=latp, lat2=0.0)
+    rng = np.random.default_rng(5)
+    lon, lat = rng.uniform(-20, 40, 500), rng.uniform(50, 80, 500)
+    lam, phi = np.radians(lon - lon0), np.radians(lat)
+    v = np.stack([np.cos(phi) * np.cos(lam), np.cos(phi) * np.sin(lam), np.sin(phi)])
+    t = np.radians(90.0 - latp)
+    R = np.array([[np.cos(t), 0, np.sin(t)], [0, 1, 0], [-np.sin(t), 0, np.cos(t)]])
+    w = R @ v
+    x, y = orc.proj_fwd(op, lon, lat)
+
+    assert np.abs(np.degrees(np.arcsin(w[2])) - y).max() < 1e-11
+    d = (np.degrees(np.arctan2(w[1], w[0])) - x + 180) % 360 - 180
+    assert np.abs(d).max() < 1e-11, np.abs(d).max()
+    lo, la = orc.proj_inv(op, x, y)
+    assert np.abs(lo - lon).max() < 1e-11 and np.abs(la - lat).max() < 1e-11
+
+
+@pytest.mark.parametrize('tag', ['utm33', 'laea_grs80', 'stere_oblique', 'rotated_pole'])
+def test_c23_round5_projections_golden_vs_oracle(tag):
+    """The C oracle replays the reference's own RK4 + wind + Stokes drift + stranding runs on a UTM grid, an ETRS89-LAEA grid, an
+    oblique stereographic grid and a rotated-pole grid (oracle/gen_golden_proj2.py): lonlat2xy through the projection, vectors
+    rotated by the azimuth of the reader's +y axis (10 m line; 0.1 degree for the rotated pole)."""
+    g = golden('c23_proj_rk4.npz')
+    sub = {k: g['%s_%s' % (tag, k)] for k in ('lon', 'lat', 'z', 'status')}
+    nst = sub['lon'].shape[0] - 1
+    B = replay.OracleBackend(replay.scenario_c23(g, tag), sub['lon'][0], sub['lat'][0], sub['z'][0], wdf=float(g['wdf']))
+    worst = replay.compare(replay.replay_c20(B, g, tag, nst), sub, tol_pos=1e-7)
+    assert (sub['status'][nst] != 0).sum() > 5
+    print('c23', tag, 'oracle vs reference:', worst)
