@@ -356,6 +356,7 @@ __device__ __forceinline__ double mix_R_of(unsigned x) {
 // 8 column gathers are straight-line 16-byte loads that are all in flight together (the generic
 // kernel's run-time loops serialise them: one memory round trip per load), the level
 // boundaries live in scalar registers and the np.gradient divisors are host constants.
+constexpr int AUX_KMEMBER = 8;   // property slot that parks the member of an ensemble diffusivity (k_kmember)
 struct VMixDesc {
   int sid, nzp, geo_slot, pad;
   const float *kb, *ka;  // K arrays of the bracketing time levels (ka == nullptr: on a time level)
@@ -1595,6 +1596,8 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
     if (s.kind == SRC_GRID) { src = &s; break; }
   }
   const int nzp = src ? (src->nz > 1 ? src->nz : 1) : 1;
+  // ensemble diffusivity: the levels of member m follow those of member m - 1 along the layer axis (odr_source_set_members)
+  const int kmembers = src ? src->members[VAR_KZ] : 0;
   double *Kp = (double *)smem;           // [nzp][BLOCK]
   double *gsh = Kp + (size_t)nzp * BLOCK;  // [3][nzp] second-order np.gradient coefficients per level
   const float Kfb = W->fallback[VAR_KZ];
@@ -1607,6 +1610,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
     bool cov = false;
     double xi = 0, yi = 0, wgt = 0;
     int ib = 0, ia = -1;
+    const size_t moff = (kmembers > 1 && p.aux[AUX_KMEMBER]) ? (size_t)((int)p.aux[AUX_KMEMBER][i]) * (size_t)nzp : 0;
     if (src) {
       double lon = p.slon[i], lat = p.slat[i], x, y;
       if (src->lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
@@ -1630,14 +1634,14 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
       size_t o00 = ((size_t)y0 * nx + x0) * rec, o01 = ((size_t)y0 * nx + x1) * rec;
       size_t o10 = ((size_t)y1 * nx + x0) * rec, o11 = ((size_t)y1 * nx + x1) * rec;
       float c00[NZMAX], c01[NZMAX], c10[NZMAX], c11[NZMAX];
-      const float *d = bb.data[VAR_KZ];
+      const float *d = bb.data[VAR_KZ] + moff;
       kcolumn(d + o00, nzp, c00); kcolumn(d + o01, nzp, c01);
       kcolumn(d + o10, nzp, c10); kcolumn(d + o11, nzp, c11);
 #pragma unroll
       for (int k = 0; k < NZMAX; ++k)
         if (k < nzp) Kp[k * BLOCK + tid] = (double)bil4(c00[k], c01[k], c10[k], c11[k], wy0, ty, wx0, tx);
       if (ia >= 0) {
-        const float *da = src->slot[ia].data[VAR_KZ];
+        const float *da = src->slot[ia].data[VAR_KZ] + moff;
         kcolumn(da + o00, nzp, c00); kcolumn(da + o01, nzp, c01);
         kcolumn(da + o10, nzp, c10); kcolumn(da + o11, nzp, c11);
 #pragma unroll
@@ -1655,10 +1659,10 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
         if (src && cov) {
           const DevBlock &bb = src->slot[ib];
           const size_t ns = (size_t)bb.rec;
-          double v0 = bilinear_f32(bb.data[VAR_KZ] + (size_t)k * bb.es[VAR_KZ], bb.ny, bb.nx, ns, yi, xi), vv;
+          double v0 = bilinear_f32(bb.data[VAR_KZ] + (moff + (size_t)k) * bb.es[VAR_KZ], bb.ny, bb.nx, ns, yi, xi), vv;
           if (ia >= 0) {
             const DevBlock &ba = src->slot[ia];
-            double v1 = bilinear_f32(ba.data[VAR_KZ] + (size_t)k * ba.es[VAR_KZ], ba.ny, ba.nx, ns, yi, xi);
+            double v1 = bilinear_f32(ba.data[VAR_KZ] + (moff + (size_t)k) * ba.es[VAR_KZ], ba.ny, ba.nx, ns, yi, xi);
             vv = __dadd_rn(__dmul_rn(v0, 1 - wgt), __dmul_rn(v1, wgt));
           } else vv = v0;
           if (isfinite(vv)) val = vv;
@@ -2463,6 +2467,15 @@ __global__ __launch_bounds__(BLOCK) void k_rank_assign(const int *id, long long 
   if (i >= n) return;
   const unsigned v = (unsigned)id[i], w = v >> 5, bit = v & 31u;
   rank[i] = offset + (int)(before[w] + (unsigned)__popc(words[w] & ((1u << bit) - 1u)));
+}
+
+// The member of an ensemble diffusivity whose COLUMN an element mixes on: the member of its element values in the main-loop
+// get_environment call, rank % M (readers/interpolation/structured.py:119-135: `horizontal[:, elnum] = int_full[:, elnum]`;
+// the environment_profiles of the survivors go with them through remove_deactivated_elements).  Parked in property slot 8
+// until odr_vmix: the ranks themselves are renumbered by the Runge-Kutta stage calls of the same step.
+__global__ __launch_bounds__(BLOCK) void k_kmember(const int *rank, long long n, int members, float *out) {
+  long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n) out[i] = (float)(rank[i] % members);
 }
 
 // Grid-stride over the 256-element chunks: the per-chunk counts feed the scan; the grand total is ONE atomic per

@@ -636,7 +636,6 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
     REQUIRE(v >= 0 && v < NVAR, "bad variable id %d", v);
     const int mem = s.members[v] > 1 ? s.members[v] : 1;
     REQUIRE(nzv == mem || nzv == mem * s.nz, "variable %d has %d layers, source has %d levels x %d members", v, nzv, s.nz, mem);
-    REQUIRE(mem == 1 || v != VAR_KZ, "ensemble members of ocean_vertical_diffusivity profiles are not supported");
     nmax = std::max(nmax, plane * (size_t)nzv);
     ntot += plane * (size_t)nzv;
     nlayers += (size_t)nzv;
@@ -1160,6 +1159,23 @@ int odr_i_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var
   }
   if ((rc = flush_world(c))) return rc;
   if ((rc = odr_i_ensure_ranks(c, p))) return rc;   // ensemble data only
+  if (record_positions && p->rank_on && p->n > 0) {
+    // the main-loop call: an ensemble DIFFUSIVITY hands every element the column of the member its element values come
+    // from (k_kmember) -- kept until odr_vmix, across the renumbering of the Runge-Kutta stage calls and the compaction
+    for (int k = 0; k < c->hw.nlist[VAR_KZ]; ++k) {
+      const DevSource &s = c->hw.src[c->hw.list[VAR_KZ][k]];
+      if (s.kind != SRC_GRID) continue;
+      if (s.members[VAR_KZ] > 1) {
+        if (!p->aux[AUX_KMEMBER]) {
+          HIPCHK(hipMalloc((void **)&p->aux[AUX_KMEMBER], sizeof(float) * (size_t)p->cap));
+          HIPCHK(hipMemsetAsync(p->aux[AUX_KMEMBER], 0, sizeof(float) * (size_t)p->cap, c->stream));
+        }
+        const PView pv = view(p);
+        hipLaunchKernelGGL(k_kmember, dim3(nblk(p->n)), dim3(BLOCK), 0, c->stream, pv.rank, p->n, s.members[VAR_KZ], pv.aux[AUX_KMEMBER]);
+      }
+      break;
+    }
+  }
   if (p->n > 0) {
     // variable groups = variables sharing the same priority list (get_reader_groups, environment.py:339-374)
     bool done[NVAR] = {false};

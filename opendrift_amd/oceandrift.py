@@ -151,13 +151,12 @@ class OpenDriftSimulation(Configurable):
 
     def set_config(self, key, value):
         self._require('Config')
-        if key == 'vertical_mixing:TSprofiles':
-            # (oceandrift.py:146,461-477).  Not implemented, on purpose: in the reference the temperature profiles reach
-            # update_terminal_velocity in Celsius and have 273.15 subtracted again -- there is no sound
-            # behaviour to be identical to.  False (the default) is accepted, True fails loudly.
-            if value:
-                raise NotImplementedError('vertical_mixing:TSprofiles is not implemented (DESIGN.md section 7)')
-            return
+        if key == 'vertical_mixing:TSprofiles' and value and 'sea_water_salinity' in self.required_variables:
+            # (oceandrift.py:146,461-477) -- only a model that requires salinity gets T / S profiles handed to its
+            # update_terminal_velocity; for OceanDrift itself the option changes nothing (its hook is empty, :285-297) and is
+            # accepted.  OpenOil's use of the profiles is not built: in the reference the temperature profiles reach the hook
+            # in Celsius and have 273.15 subtracted again.
+            raise NotImplementedError('vertical_mixing:TSprofiles is not implemented for %s (DESIGN.md section 7)' % type(self).__name__)
         super().set_config(key, value)
 
     # ------------------------------------------------------------------ readers (:613-632)
@@ -1520,6 +1519,8 @@ class OceanDrift(OpenDriftSimulation):
                                                  'enum': ['environment', 'stepfunction', 'windspeed_Sundby1983',
                                                           'windspeed_Large1994', 'constant'],
                                                  'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
+            'vertical_mixing:TSprofiles': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_ADVANCED, 'description':
+                                           'Update T and S profiles within inner loop of vertical mixing.'},
             'vertical_mixing:background_diffusivity': {'type': 'float', 'min': 0, 'max': 1, 'default': 1.2e-5,
                                                        'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
             'drift:wind_drift_depth': {'type': 'float', 'default': 0.1, 'min': 0, 'max': 10,
@@ -1548,11 +1549,10 @@ class OceanDrift(OpenDriftSimulation):
             # reference switches to Large et al. (1994) (oceandrift.py:431-447).  (A reader that is listed but covers
             # no element at all would do the same there; here its fallback-filled profile is used.)
             model = 'windspeed_Large1994'
-        if model == 'environment' and self._config.get('drift:truncate_ocean_model_below_m', {}).get('value') is not None:
-            # the reference cuts the diffusivity PROFILES at the truncation depth too (environment.py:560: profiles_depth); the
-            # device's K columns are not cut -- refused rather than silently different for elements below that depth
-            raise NotImplementedError('drift:truncate_ocean_model_below_m together with vertical mixing on reader diffusivity '
-                                      'profiles is not implemented (DESIGN.md section 7)')
+        # (drift:truncate_ocean_model_below_m with reader diffusivity profiles: the reference only narrows the depth range it
+        # ASKS the reader for -- profiles_depth = min(profiles_depth, truncate_depth), environment.py:560 ->
+        # basereader/structured.py:230-238 -- the columns a reader hands out are mixed on as they come, for elements at any
+        # depth; golden c24a.  The device gathers every level the block holds.)
         dt, dt_mix = self.time_step.total_seconds(), self.get_config('vertical_mixing:timestep')
         fuse = None
         if self.get_config('drift:vertical_advection') and type(self).vertical_advection is OceanDrift.vertical_advection:

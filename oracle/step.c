@@ -419,13 +419,20 @@ void orc_get_profile(const orc_world *w, int var, long n, const double *lon,
       xi[i] = (xx - bb->x0) / bb->xspan * (bb->nx - 1);
       yi[i] = (yy - bb->y0) / bb->yspan * (bb->ny - 1);
     }
-    for (k = 0; k < nz_prof && k < bb->var_nz[var]; ++k) {
-      orc_linear2d_call((float *)bb->data[var] + k * plane, bb->ny, bb->nx, n, yi, xi, l0);
-      if (ba) orc_linear2d_call((float *)ba->data[var] + k * plane, ba->ny, ba->nx, n, yi, xi, l1);
-      for (i = 0; i < n; ++i) {
-        double val = ba ? (double)l0[i] * (1 - wgt) + (double)l1[i] * wgt : (double)l0[i];
-        if (cov[i] && isfinite(val)) out[(long)k * n + i] = val;
-      }
+    {
+      /* ensemble data: position j of the call takes the COLUMN of member j % M (readers/interpolation/structured.py:119-135:
+       * `horizontal[:, elnum] = int_full[:, elnum]`), the numbering of its element values */
+      int M = bb->members[var] > 1 ? bb->members[var] : 1, m;
+      long per = (long)(bb->var_nz[var] > 1 ? bb->var_nz[var] : 1) * plane;
+      for (m = 0; m < M; ++m)
+        for (k = 0; k < nz_prof && k < bb->var_nz[var]; ++k) {
+          orc_linear2d_call((float *)bb->data[var] + m * per + k * plane, bb->ny, bb->nx, n, yi, xi, l0);
+          if (ba) orc_linear2d_call((float *)ba->data[var] + m * per + k * plane, ba->ny, ba->nx, n, yi, xi, l1);
+          for (i = m; i < n; i += M) {
+            double val = ba ? (double)l0[i] * (1 - wgt) + (double)l1[i] * wgt : (double)l0[i];
+            if (cov[i] && isfinite(val)) out[(long)k * n + i] = val;
+          }
+        }
     }
     free(xi); free(yi); free(l0); free(l1); free(cov);
   }

@@ -49,6 +49,13 @@ class OracleBackend:
             self.Kp = orc.get_profile(w, V[profile], self.lon, self.lat, t, nzp)
         self._w = w
 
+    def truncate(self, depth):   # drift:truncate_ocean_model_below_m (environment.py:554-566): the sampling calls see max(z, -depth)
+        self._z_true = self.z
+        self.z = np.maximum(self.z, -float(depth))
+
+    def restore(self):
+        self.z = self._z_true
+
     def report_missing(self, names, code):   # basemodel/__init__.py:2501-2515, environment.py:903-908
         missing = np.zeros(len(self.lon), bool)
         for k in names:
@@ -232,6 +239,12 @@ class DeviceBackend:
     def sample(self, names, t, profile=None, nzp=0):
         self.P.env_sample(names, t)
 
+    def truncate(self, depth):
+        self.P.truncate_z(depth)
+
+    def restore(self):
+        self.P.restore_z()
+
     def report_missing(self, names, code):
         self.P.deactivate_missing(names, code)
 
@@ -346,6 +359,51 @@ def replay_c3(B, g, nsteps):
         B.store_previous()
         B.advect('runge-kutta4', t, dt)
         B.vmix(t, dt, dt_mix, g['g_z'], g['uniforms'][k])
+        out.append(B.state(n))
+    return out
+
+
+def scenario_c24(g, tag):
+    """c24a: the C3-shaped fields; c24b: the same with ocean_vertical_diffusivity as a list of three members (oracle/gen_golden_profiles.py)"""
+    from scenarios import Scenario
+    names = [U, VV, W, KZ, DEPTH, LAND]
+    t = g[tag + '_g_t']
+    levels = []
+    for k in range(len(t)):
+        arrays = {nm: g['%s_g_%s' % (tag, nm)][k] for nm in names}
+        if tag == 'b':
+            arrays[KZ] = [g['b_g_K%d' % m][k] for m in range(int(g['members']))]
+        levels.append((float(t[k]), arrays))
+    return Scenario([('grid', dict(x=g[tag + '_g_x'], y=g[tag + '_g_y'], z=g[tag + '_g_z'], levels=levels))],
+                    fallbacks={U: 0.0, VV: 0.0, W: 0.0, KZ: 0.0, DEPTH: 10000.0, SSH: 0.0})
+
+
+def replay_c24(B, g, tag, nsteps, truncate=None):
+    """RK4 + vertical mixing on reader diffusivity profiles + vertical advection, coastline 'previous'; truncate: every
+    sampling call -- the main one and the Runge-Kutta stage calls -- sees max(z, -truncate) (environment.py:554-566)"""
+    dt, dt_mix = float(g['dt']), float(g['dt_mix'])
+    n = g[tag + '_lon'].shape[1]
+    zlev = g[tag + '_g_z']
+    out = []
+    names = [U, VV, W, DEPTH, SSH, LAND]
+    for k in range(nsteps):
+        t = k * dt
+        if truncate is not None:
+            B.truncate(truncate)
+        B.sample(names, t, profile=KZ, nzp=len(zlev))
+        if truncate is not None:
+            B.restore()
+        B.coast('previous', seeded_code=1)
+        B.seafloor()
+        B.increase_age(dt)
+        B.compact()
+        B.store_previous()
+        if truncate is not None:
+            B.truncate(truncate)
+        B.advect('runge-kutta4', t, dt)
+        if truncate is not None:
+            B.restore()
+        B.vmix(t, dt, dt_mix, zlev, g[tag + '_uniforms'][k])
         out.append(B.state(n))
     return out
 

@@ -1055,15 +1055,58 @@ def test_c21_truncate_ocean_model_below_m_reproduces_the_reference():
     o = _c21_model(g, 'runge-kutta4', **{'drift:truncate_ocean_model_below_m': float(g['truncate'])})
     e = _c21_compare(o, g, 'b')
     assert np.abs(e.lon - g['b0_lon'][-1][e.ID]).max() > 1e-3           # against the same run without truncation
-    # with reader diffusivity profiles the reference truncates the profiles too: refused, not silently different
-    o = _c21_model(g, 'runge-kutta4', **{'drift:truncate_ocean_model_below_m': 20.0})
-    names = ['ocean_vertical_diffusivity']
-    times = [T0 + timedelta(seconds=float(t)) for t in g['g_t']]
-    o.add_reader(readers.GridReader(g['g_x'], g['g_y'], times, {'ocean_vertical_diffusivity': g['g_ocean_vertical_diffusivity']}, z=g['g_z']))
+
+
+def _c24_model(g, tag, stage_math='exact'):
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity', 'ocean_vertical_diffusivity',
+             'sea_floor_depth_below_sea_level', 'land_binary_mask']
+    times = [T0 + timedelta(seconds=float(t)) for t in g[tag + '_g_t']]
+    arrays = {k: g['%s_g_%s' % (tag, k)] for k in names}
+    if tag == 'b':
+        arrays['ocean_vertical_diffusivity'] = [g['b_g_K%d' % m] for m in range(int(g['members']))]
+    o = OceanDrift(loglevel=50, seed=0, rng='numpy', stage_math=stage_math)
+    o.add_reader(readers.GridReader(g[tag + '_g_x'], g[tag + '_g_y'], times, arrays, z=g[tag + '_g_z']))
+    o.set_config('drift:advection_scheme', 'runge-kutta4')
     o.set_config('drift:vertical_mixing', True)
-    o.seed_elements(lon=g['b_lon'][0], lat=g['b_lat'][0], z=g['b_z'][0], time=T0)
-    with pytest.raises(NotImplementedError):
-        o.run(time_step=600, steps=2, stop_on_error=True)
+    o.set_config('vertical_mixing:timestep', 60)
+    o.set_config('drift:vertical_advection', True)
+    o.set_config('drift:stokes_drift', False)
+    o.set_config('general:coastline_action', 'previous')
+    return o
+
+
+@pytest.mark.parametrize('stage_math', ['exact', 'fast'])
+def test_c24a_truncation_with_reader_diffusivity_profiles_reproduces_the_reference(stage_math):
+    """drift:truncate_ocean_model_below_m TOGETHER with vertical mixing on reader diffusivity profiles (refused in round 4):
+    every sampling call sees max(z, -20 m) (environment.py:554-566); profiles_depth = min(profiles_depth, 20 m) only narrows
+    the depth range the READER is asked for (basereader/structured.py:230-238) -- the columns a reader hands out are mixed on
+    whole, for elements at any depth.  OceanDrift.run() against the reference's own run (golden c24a, np.random in its order)."""
+    g = golden('c24_profiles.npz')
+    o = _c24_model(g, 'a', stage_math)
+    o.set_config('drift:truncate_ocean_model_below_m', float(g['truncate']))
+    o.seed_elements(lon=g['a_lon'][0], lat=g['a_lat'][0], z=g['a_z'][0], time=T0, wind_drift_factor=0.0)
+    nst = g['a_lon'].shape[0] - 1
+    o.run(time_step=float(g['dt']), steps=nst)
+    lon, lat, z = _final(o, g['a_lon'].shape[1])
+    print('c24a', stage_math, np.abs(lon - g['a_lon'][-1]).max(), np.abs(lat - g['a_lat'][-1]).max(), np.abs(z - g['a_z'][-1]).max())
+    assert np.abs(lon - g['a_lon'][-1]).max() < 1e-7 and np.abs(lat - g['a_lat'][-1]).max() < 1e-7
+    assert np.abs(z - g['a_z'][-1]).max() < 1e-5
+    assert np.abs(lon - g['a0_lon'][-1]).max() > 1e-3         # against the reference's run without the truncation
+
+
+def test_c24b_ensemble_diffusivity_profiles_reproduce_the_reference():
+    """An ensemble reader whose ocean_vertical_diffusivity comes as a list of member arrays: element j of the main-loop call
+    mixes on the COLUMN of member j % M (readers/interpolation/structured.py:119-135; left out in rounds 2-4) -- OceanDrift.run()
+    against the reference's own run (golden c24b)."""
+    g = golden('c24_profiles.npz')
+    o = _c24_model(g, 'b')
+    o.seed_elements(lon=g['b_lon'][0], lat=g['b_lat'][0], z=g['b_z'][0], time=T0, wind_drift_factor=0.0)
+    nst = g['b_lon'].shape[0] - 1
+    o.run(time_step=float(g['dt']), steps=nst)
+    lon, lat, z = _final(o, g['b_lon'].shape[1])
+    print('c24b', np.abs(lon - g['b_lon'][-1]).max(), np.abs(lat - g['b_lat'][-1]).max(), np.abs(z - g['b_z'][-1]).max())
+    assert np.abs(lon - g['b_lon'][-1]).max() < 1e-7 and np.abs(lat - g['b_lat'][-1]).max() < 1e-7
+    assert np.abs(z - g['b_z'][-1]).max() < 1e-5
 
 
 def test_c22_seed_ocean_only_moves_land_seeds_like_the_reference():

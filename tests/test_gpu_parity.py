@@ -467,6 +467,24 @@ def test_c23_round5_projections_device_vs_oracle(ctx, tag):
     print('c23', tag, 'device vs reference:', worst)
 
 
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_c24_profile_paths_device_vs_oracle(ctx, tag):
+    """(a) truncation of the ocean model at 20 m together with mixing on reader diffusivity profiles (odr_particles_truncate_z
+    around the sampling calls, the K columns whole); (b) an ensemble diffusivity: the element mixes on the column of the member
+    of its main-loop sample (k_kmember -> k_vmix) -- against the reference's own runs and the oracle."""
+    import replay
+    g = golden('c24_profiles.npz')
+    sub = {k: g['%s_%s' % (tag, k)] for k in ('lon', 'lat', 'z', 'status')}
+    nst = sub['lon'].shape[0] - 1
+    trunc = float(g['truncate']) if tag == 'a' else None
+    D = replay.DeviceBackend(replay.scenario_c24(g, tag), ctx, sub['lon'][0], sub['lat'][0], sub['z'][0])
+    dev = replay.replay_c24(D, g, tag, nst, truncate=trunc)
+    worst = replay.compare(dev, sub, tol_pos=1e-7, tol_z=1e-5)
+    O = replay.OracleBackend(replay.scenario_c24(g, tag), sub['lon'][0], sub['lat'][0], sub['z'][0])
+    _states_close(dev, replay.replay_c24(O, g, tag, nst, truncate=trunc), 2e-9, 1e-9)
+    print('c24' + tag, 'device vs reference:', worst)
+
+
 def test_c5_leeway_golden_device(ctx):
     """Leeway.update kernel + environment uncertainty (host-drawn normals) + jibing vs the reference's Leeway."""
     import replay

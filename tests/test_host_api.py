@@ -179,15 +179,22 @@ def test_grid_reader_hands_out_ensemble_members_as_a_list():
 
 
 def test_tsprofiles_is_refused_loudly_and_leeway_seeding_keeps_the_random_stream():
-    """vertical_mixing:TSprofiles = True is not implemented and says so; Leeway.seed_elements draws the
+    """vertical_mixing:TSprofiles = True: accepted by OceanDrift, whose update_terminal_velocity hook is empty and which does not
+    require salinity (oceandrift.py:285-297, 461-462: no effect in the reference either); refused loudly by OpenOil, whose use of
+    the T / S profiles is not built.  Leeway.seed_elements draws the
     downwind perturbations in batches that consume np.random exactly like the reference's element-by-element loop with
     rejection (leeway.py:331-339): same values, same generator state afterwards."""
     from opendrift_amd.oceandrift import OceanDrift
     from opendrift_amd.leeway import Leeway
     o = OceanDrift(loglevel=50)
     o.set_config('vertical_mixing:TSprofiles', False)
+    o.set_config('vertical_mixing:TSprofiles', True)
+    assert o.get_config('vertical_mixing:TSprofiles') is True
+    from opendrift_amd.openoil import OpenOil
+    oo = OpenOil(loglevel=50)
+    oo.set_config('vertical_mixing:TSprofiles', False)
     with pytest.raises(NotImplementedError):
-        o.set_config('vertical_mixing:TSprofiles', True)
+        oo.set_config('vertical_mixing:TSprofiles', True)
     c = dict(DWSLOPE=0.05, DWOFFSET=1.0, DWSTD=12.0, CWRSLOPE=0.5, CWROFFSET=1.0, CWRSTD=5.0, CWLSLOPE=-0.5, CWLOFFSET=-1.0, CWLSTD=5.0)
     n = 4001
     np.random.seed(7)

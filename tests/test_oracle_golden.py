@@ -503,3 +503,24 @@ def test_c23_round5_projections_golden_vs_oracle(tag):
     worst = replay.compare(replay.replay_c20(B, g, tag, nst), sub, tol_pos=1e-7)
     assert (sub['status'][nst] != 0).sum() > 5
     print('c23', tag, 'oracle vs reference:', worst)
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_c24_profile_paths_golden_vs_oracle(tag):
+    """The C oracle replays the reference's own runs (oracle/gen_golden_profiles.py) of (a) drift:truncate_ocean_model_below_m
+    TOGETHER with vertical mixing on reader diffusivity profiles -- every sampling call sees max(z, -20 m), the columns are the
+    reader's, whole -- and (b) an ensemble reader whose ocean_vertical_diffusivity is a list of three members: element j of the
+    call mixes on the column of member j % 3 (readers/interpolation/structured.py:119-135)."""
+    g = golden('c24_profiles.npz')
+    sub = {k: g['%s_%s' % (tag, k)] for k in ('lon', 'lat', 'z', 'status')}
+    nst = sub['lon'].shape[0] - 1
+    B = replay.OracleBackend(replay.scenario_c24(g, tag), sub['lon'][0], sub['lat'][0], sub['z'][0])
+    worst = replay.compare(replay.replay_c24(B, g, tag, nst, truncate=float(g['truncate']) if tag == 'a' else None), sub,
+                           tol_pos=1e-7, tol_z=1e-5)
+    print('c24' + tag, 'oracle vs reference:', worst)
+    if tag == 'a':      # the option matters, and half of the elements are below the truncation depth
+        assert np.nanmax(np.abs(g['a_lon'][-1] - g['a0_lon'][-1])) > 1e-3 and (g['a_z'][0] < -20).sum() > 100
+    else:               # the members differ by far more than anything else does: mixing on the wrong member's column is seen
+        dz = sub['z'][-1] - sub['z'][0]
+        rms = [np.sqrt(np.nanmean(dz[m::3] ** 2)) for m in range(3)]
+        assert rms[2] > 1.8 * rms[0] > 1.8 * 1.5 * rms[1]
