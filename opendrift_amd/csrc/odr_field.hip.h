@@ -1658,7 +1658,11 @@ __device__ __forceinline__ void env_burst(const DevSource &s, const EnvGroupDesc
                                           unsigned near_off, bool tl, double x, double y, float *out /*[MAXG]*/, EnvExport *X ODR_PT_PARAM) {
   const unsigned o[4] = {ft.o00, ft.o01, ft.o10, ft.o11};
   const unsigned iz0 = (unsigned)zb.iz0;
+#ifdef ODR_WHATIF_NO_BURST2   // what-if build (wrong values): slots B, C, D are not sampled -- what a fifth wave per SIMD buys
+  const int kA = G.bs[0], kB = -1, kC = -1, kD = -1, kL = G.bs[4];
+#else
   const int kA = G.bs[0], kB = G.bs[1], kC = G.bs[2], kD = G.bs[3], kL = G.bs[4];
+#endif
   const int mA = G.ps_mode[0], mB = G.ps_mode[1], mC = G.ps_mode[2];
   double cs = 1, sn = 0;
   if (ODR_PROJ_ROTATES(PROJ) && G.rotates) rotation_cs<PROJ == PROJ_STERE_POLAR>(s.proj, x, y, cs, sn);
