@@ -593,7 +593,9 @@ def main():
                                         {kk: (t.shape[0] if t.dim() == 3 else 1) for kk, t in tens.items()}, content_ids=wl.static_ids)
             else:                                     # gloo rehearsal (ODR_DIST_BACKEND=gloo): host tensors
                 ctx.upload_block(wl.sid, slot, float(g['t'][slot]), {kk: t.numpy() for kk, t in tens.items()}, content_ids=wl.static_ids)
-        sharded = ShardedLoop(fields, fields['names'], a.block_every or 6, install)
+        # --block-every -1: no reader levels inside the sharded loop (prices the per-step collective alone: over gloo a 210 MB
+        # level travels through the loopback interface, tools/gpu_sharded_price.sh)
+        sharded = ShardedLoop(fields, fields['names'], 0 if a.block_every < 0 else (a.block_every or 6), install)
 
     def timed_loop(steps, first, block_every=0, block_async=False, pinned=None):
         """`steps` steps between barrier + synchronize on both sides; returns (seconds, particle-steps of this rank)"""
@@ -639,7 +641,7 @@ def main():
                 wl.step(P, a.warmup)
 
     pinned = None
-    if a.block_every and a.block_async and a.workload != 'c2':
+    if a.block_every > 0 and a.block_async and a.workload != 'c2':
         pinned = {kk: ctx.pin(np.ascontiguousarray(fields['g'][kk])) for kk in fields['names']}
     # spin-up (untimed, before the W warm-up steps, the same count on every rank): ~0.25 s of the workload's own steps, so that a
     # short timed region (the driver's --steps 20 is 25 ms) does not fall into the GPU's ramp from its idle clocks after the
@@ -650,12 +652,12 @@ def main():
     ctx.sync()
     for k in range(a.warmup):
         wl.step(P, spin + k)
-    if a.block_every and a.workload != 'c2':
+    if a.block_every > 0 and a.workload != 'c2':
         warm_uploads(pinned)
     if sharded is not None:      # untimed: RCCL channels, staging buffers and the recyclable blocks exist before the timed region
-        timed_loop(2 * sharded.block_every + 1, spin + a.warmup)
+        timed_loop(2 * max(sharded.block_every, 3) + 1, spin + a.warmup)
         sharded.collectives, sharded.collective_s, sharded.levels, sharded.level_stall_s = 0, 0.0, 0, 0.0
-    el, units_rank = timed_loop(a.steps, spin + a.warmup, a.block_every, a.block_async, pinned)
+    el, units_rank = timed_loop(a.steps, spin + a.warmup, max(a.block_every, 0), a.block_async, pinned)
     sharded_report = sharded.report(a.steps) if sharded is not None else None
     sharded = None               # the legs below (kernel timings, the other stage arithmetic) time this rank's device step alone
     el_max = float(D.allreduce_scalars([el], 'max')[0])
@@ -764,7 +766,7 @@ def main():
                                           'wind/current uncertainty, stranding -- the C-ABI sequence (odr_env_coast_leeway = one '
                                           'launch per step), the launch Leeway.run() of the host mirror makes with the device RNG (tests/test_gpu_model_api.py)'}[a.workload],
                        'particles_per_gpu': n, 'particles_total': n * world, 'time_step_s': wl.dt, 'stage_math': a.stage_math, 'spin_up_steps': spin,
-                       'block_every': a.block_every, 'inputs': 'resident in HBM' if not a.block_every else 'uploaded in the timed region',
+                       'block_every': a.block_every, 'inputs': 'resident in HBM' if a.block_every <= 0 else 'uploaded in the timed region',
                        'parallelism': 'particle-sharded x%d, field block broadcast once per time level' % world},
         }
         kname = ('k_step_leeway' if wl.fused else 'k_leeway') if a.workload == 'c5' else ('k_step_grid<RK4>' if kfused else 'k_advect<RK4>')

@@ -39,12 +39,13 @@ enum { VAR_U = 0, VAR_V = 1, VAR_XWIND = 2, VAR_YWIND = 3, VAR_W = 4, VAR_KZ = 5
        VAR_WW_DIR = 23, VAR_WW_TM = 24, VAR_WW_HS = 25 };
 enum { SRC_CONSTANT = 0, SRC_DOUBLE_GYRE = 1, SRC_OSCILLATING = 2, SRC_GRID = 3, SRC_LANDMASK = 4 };
 enum { PROJ_LATLONG = 0, PROJ_STERE_EQUIT_SPHERE = 1, PROJ_STERE_POLAR = 2, PROJ_CURVILINEAR = 3, PROJ_MERC = 4, PROJ_LCC = 5,
-       PROJ_TMERC = 6, PROJ_LAEA = 7, PROJ_STERE_OBLIQUE = 8, PROJ_OB_TRAN = 9 };   // round 5 (include/odrift.h)
+       PROJ_TMERC = 6, PROJ_LAEA = 7, PROJ_STERE_OBLIQUE = 8, PROJ_OB_TRAN = 9,   // round 5 (include/odrift.h)
+       PROJ_EXT = 10 };   // (template value only: the kernel instantiation that serves PROJ_TMERC ... PROJ_OB_TRAN, odr_proj_template)
 // (kernels templated on the projection: anything but latlong / polar stere / curvilinear takes the PROJ_STERE_EQUIT_SPHERE
 // instantiation, whose proj_fwd / proj_inv / rotation_angle switch on DevProj::kind at run time)
 // x/y vector pairs are rotated from the reader's CRS to lon/lat (variables.py:799-837); for a reader without a
 // projection (fakeproj) the rotation the reference computes is by the azimuth of due north, i.e. exactly zero
-#define ODR_PROJ_ROTATES(K) ((K) == PROJ_STERE_EQUIT_SPHERE || (K) == PROJ_STERE_POLAR || (K) == PROJ_MERC || (K) == PROJ_LCC)
+#define ODR_PROJ_ROTATES(K) ((K) == PROJ_STERE_EQUIT_SPHERE || (K) == PROJ_STERE_POLAR || (K) == PROJ_MERC || (K) == PROJ_LCC || (K) == PROJ_EXT)
 
 struct D2 { double x, y; };
 
@@ -212,7 +213,7 @@ __device__ __forceinline__ void curvi_locate(const DevProj &p, double lon, doubl
 // `crs.is_geographic` the reference relies on (:117, :800) -- has its x modulated once more for the test of its domain
 template <int PROJ>
 __device__ __forceinline__ double cover_x(int kind, int lon_mode, double x) {
-  if (PROJ == PROJ_LATLONG || (PROJ == PROJ_STERE_EQUIT_SPHERE && kind == PROJ_OB_TRAN)) {
+  if (PROJ == PROJ_LATLONG || (PROJ == PROJ_EXT && kind == PROJ_OB_TRAN)) {
     if (lon_mode == 1) return np_mod(x + 180.0, 360.0) - 180.0;
     if (lon_mode == 2) return np_mod(x, 360.0);
   }
@@ -258,6 +259,9 @@ __device__ __forceinline__ double conformal_lat(double phi, double sinphi, doubl
   return 2 * atan(tan(0.5 * (kHalfPi + phi)) * exp(-e * atanh(e * sinphi))) - kHalfPi;
 }
 // (lam, phi) relative to the central meridian -> projected X, Y in units of a (ob_tran: rotated longitude / latitude, radians)
+// Compiled into the PROJ_EXT instantiations of the kernels only (template flag EXT of proj_fwd / proj_inv / rotation_*): inlined
+// into every sampler of the kernels that serve Mercator / Lambert / stereographic readers it took k_step_grid<.., generic> from
+// 195-243 to 256 registers + 112-272 B of scratch memory (and as out-of-line calls to 420-630 B around the call sites).
 __device__ __forceinline__ void proj_fwd_ext(const DevProj &p, double lam, double phi, double &X, double &Y) {
 #pragma clang fp contract(fast)
   double sinlam, coslam, sinphi, cosphi;
@@ -422,14 +426,14 @@ __device__ __forceinline__ void proj_inv_ext(const DevProj &p, double X, double 
 // ELLPOLAR: the caller knows the projection to be the polar stereographic one on an ellipsoid (the kernels instantiated
 // for PROJ_STERE_POLAR: the host sends spherical polar readers to the generic instantiation) -- no code, and no registers,
 // for the other kinds (k_step_grid<RK4, polar> held 39 700 VALU instructions / 215 VGPRs with them)
-template <bool ELLPOLAR = false>
+template <bool ELLPOLAR = false, bool EXT = true>
 __device__ __forceinline__ void proj_fwd(const DevProj &p, double lon_deg, double lat_deg,
                                          double &x, double &y) {
 #pragma clang fp contract(fast)
   if (!ELLPOLAR && p.kind == PROJ_LATLONG) { x = lon_deg; y = lat_deg; return; }
   double lam = wrap_pi(lon_deg * kDeg - p.lon0), phi = lat_deg * kDeg;
   double sinlam, coslam, sinphi, cosphi, X, Y;
-  if (!ELLPOLAR && p.kind >= PROJ_TMERC) {
+  if (!ELLPOLAR && EXT && p.kind >= PROJ_TMERC) {
     proj_fwd_ext(p, lam, phi, X, Y);
     if (p.kind == PROJ_OB_TRAN) { x = X * kRad2Deg; y = Y * kRad2Deg; return; }   // np.degrees(self.proj(lon, lat)), variables.py:136-138
     x = p.a * X + p.x0;
@@ -490,13 +494,13 @@ __device__ __forceinline__ ProjStart proj_start(const DevProj &p, double lon_deg
   sincos(o.phi, &o.sp, &o.cp);
   return o;
 }
-template <bool ELLPOLAR = false>
+template <bool ELLPOLAR = false, bool EXT = true>
 __device__ __forceinline__ void proj_fwd_near(const DevProj &p, const ProjStart &o, double lon_deg, double lat_deg,
                                               double &x, double &y) {
 #pragma clang fp contract(fast)
   const double lam = wrap_pi(lon_deg * kDeg - p.lon0), phi0 = lat_deg * kDeg;
   const double dl = lam - o.lam, dp = phi0 - o.phi;
-  if (!(o.ok && fabs(dl) < 8e-3 && fabs(dp) < 8e-3)) { proj_fwd<ELLPOLAR>(p, lon_deg, lat_deg, x, y); return; }
+  if (!(o.ok && fabs(dl) < 8e-3 && fabs(dp) < 8e-3)) { proj_fwd<ELLPOLAR, EXT>(p, lon_deg, lat_deg, x, y); return; }
   const double l2 = dl * dl, p2 = dp * dp;
   const double sdl = dl * (1 - l2 * (1.0 / 6) * (1 - l2 * (1.0 / 20) * (1 - l2 * (1.0 / 42))));
   const double cdl = 1 - l2 * 0.5 * (1 - l2 * (1.0 / 12) * (1 - l2 * (1.0 / 30) * (1 - l2 * (1.0 / 56))));
@@ -522,16 +526,19 @@ __device__ __forceinline__ void proj_fwd_rt(const DevProj &p, double lon_deg, do
   else proj_fwd(p, lon_deg, lat_deg, x, y);
 }
 
+template <bool EXT = true>
 __device__ __forceinline__ void proj_inv(const DevProj &p, double x, double y, double &lon_deg,
                                          double &lat_deg) {
 #pragma clang fp contract(fast)
   if (p.kind == PROJ_LATLONG) { lon_deg = x; lat_deg = y; return; }
   if (p.kind >= PROJ_TMERC) {
-    double lam_, phi_;
-    if (p.kind == PROJ_OB_TRAN) proj_inv_ext(p, x * kDeg, y * kDeg, lam_, phi_);     // self.proj(np.radians(x), np.radians(y), inverse=True), :117-123
-    else proj_inv_ext(p, (x - p.x0) / p.a, (y - p.y0) / p.a, lam_, phi_);
-    lon_deg = wrap_pi(lam_ + p.lon0) / kDeg;
-    lat_deg = phi_ / kDeg;
+    if constexpr (EXT) {
+      const bool ob = p.kind == PROJ_OB_TRAN;      // self.proj(np.radians(x), np.radians(y), inverse=True), :117-123
+      double lam_, phi_;
+      proj_inv_ext(p, ob ? x * kDeg : (x - p.x0) / p.a, ob ? y * kDeg : (y - p.y0) / p.a, lam_, phi_);
+      lon_deg = wrap_pi(lam_ + p.lon0) / kDeg;
+      lat_deg = phi_ / kDeg;
+    } else lon_deg = lat_deg = __builtin_nan("");
     return;
   }
   double X = (x - p.x0) / p.a, Y = (y - p.y0) / p.a;
@@ -594,6 +601,7 @@ __device__ __forceinline__ void proj_inv(const DevProj &p, double x, double y, d
 // Only the DIFFERENCES (dphi, dlam) of the two inverse projections enter, so the polar
 // ellipsoidal case uses the closed series for the geodetic latitude (Snyder eq. 3-5,
 // 2e-12 rad, the error is common to both points) instead of the fixed-point iteration.
+template <bool EXT = true>
 __device__ __forceinline__ void proj_inv_diff(const DevProj &p, double x, double y, double dy, double &phim,
                                               double &dphi, double &dlam) {
 #pragma clang fp contract(fast)
@@ -623,8 +631,8 @@ __device__ __forceinline__ void proj_inv_diff(const DevProj &p, double x, double
     return;
   }
   double lo1, la1, lo2, la2;
-  proj_inv(p, x, y, lo1, la1);
-  proj_inv(p, x, y + dy, lo2, la2);
+  proj_inv<EXT>(p, x, y, lo1, la1);
+  proj_inv<EXT>(p, x, y + dy, lo2, la2);
   phim = 0.5 * (la1 + la2) * kDeg;
   dphi = (la2 - la1) * kDeg;
   dlam = ang_normalize(lo2 - lo1) * kDeg;
@@ -666,16 +674,19 @@ __device__ __forceinline__ double geod_inverse_azimuth(double lat1, double lon1,
   return atan2(e1, n1);
 }
 
+template <bool EXT = true>
 __device__ __forceinline__ double rotation_angle(const DevProj &p, double x, double y) {
 #pragma clang fp contract(fast)
-  if (p.kind == PROJ_OB_TRAN) {     // delta_y = 0.1 degree northwards in the reader's CRS (variables.py:80-81)
-    double lo1, la1, lo2, la2;
-    proj_inv(p, x, y, lo1, la1);
-    proj_inv(p, x, y + 0.1, lo2, la2);
-    return -geod_inverse_azimuth(la1, lo1, la2, lo2);
+  if constexpr (EXT) {
+    if (p.kind == PROJ_OB_TRAN) {     // delta_y = 0.1 degree northwards in the reader's CRS (variables.py:80-81)
+      double lo1, la1, lo2, la2;
+      proj_inv<true>(p, x, y, lo1, la1);
+      proj_inv<true>(p, x, y + 0.1, lo2, la2);
+      return -geod_inverse_azimuth(la1, lo1, la2, lo2);
+    }
   }
   double phim, dphi, dlam;
-  proj_inv_diff(p, x, y, 10.0, phim, dphi, dlam);
+  proj_inv_diff<EXT>(p, x, y, 10.0, phim, dphi, dlam);
   const GeodConst &g = c_geod;
   double sphi, cphi;
   sincos(phim, &sphi, &cphi);
@@ -694,11 +705,11 @@ __device__ __forceinline__ double rotation_angle(const DevProj &p, double x, dou
 // both atans have arguments ~1e-6 (10 m over the earth radius -> Gregory series), sin/cos of chi_m are
 // rational in t_m, sin/cos of the multiples by recurrence, and the geodetic mid latitude is
 // chi_m + delta with |delta| < 3.4e-3 (angle-addition with a short Taylor series).
-template <bool ELLPOLAR = false>
+template <bool ELLPOLAR = false, bool EXT = true>
 __device__ __forceinline__ void rotation_cs(const DevProj &p, double x, double y, double &cs, double &sn) {
 #pragma clang fp contract(fast)
   if (!ELLPOLAR && !(p.kind == PROJ_STERE_POLAR && p.es != 0)) {
-    double rot = rotation_angle(p, x, y);
+    double rot = rotation_angle<EXT>(p, x, y);
     sincos(rot, &sn, &cs);
     return;
   }
@@ -784,6 +795,9 @@ __device__ __forceinline__ int nearest_index(double v, double vmin, double vrang
 // vector-memory round trip in front of the gathers that need the bracket.  The level count reads the (wave-uniform) levels
 // four per scalar load; zasc is padded with +inf beyond nz (round 3: a scalar load + wait per level and the table gather
 // were 3 500 cycles of a wave's life in k_step_grid).
+// ZT_STRIDE: levels of the LDS copy.  40 (the ROMS z list has 35): with 3 x 64 entries the step kernel's workgroup took 32 256 B
+// of LDS -- 26 allocation granules of 1 280 B, four workgroups per CU where its 96 registers allow five.
+constexpr int ZT_STRIDE = 40;
 template <bool ZT = false>
 __device__ __forceinline__ void zinterp(const DevSource &s, double z, int &ia, int &ib, double &wa, const double *zt = nullptr) {
   const int nz = s.nz;
@@ -799,7 +813,9 @@ __device__ __forceinline__ void zinterp(const DevSource &s, double z, int &ia, i
   hi = hi > nz - 1 ? nz - 1 : hi;
   const int lo = hi - 1;
   double tx, ts, tyv;
-  if constexpr (ZT) { tx = zt[lo]; ts = zt[MAXNZ + lo]; tyv = zt[2 * MAXNZ + lo]; }
+  bool from_lds = false;
+  if constexpr (ZT) from_lds = nz <= ZT_STRIDE;      // (wave-uniform; readers with more levels than the LDS copy holds read the source)
+  if (from_lds) { tx = zt[lo]; ts = zt[ZT_STRIDE + lo]; tyv = zt[2 * ZT_STRIDE + lo]; }
   else { tx = s.zi_x[lo]; ts = s.zi_slope[lo]; tyv = s.zi_y[lo]; }
   double zi = __dadd_rn(__dmul_rn(ts, z - tx), tyv);
   ia = (int)(signed char)(long long)floor(zi);
@@ -1098,7 +1114,7 @@ struct ZBracket { int iz0, same; double wa; };  // levels (ia, ib): ia = iz0 + (
 // the workgroup's copy of the interp1d tables of source `s` (call from every thread, before any divergence)
 __device__ __forceinline__ void zt_stage(const DevSource &s, double *zt) {
   const int t = threadIdx.x;
-  if (t < s.nz) { zt[t] = s.zi_x[t]; zt[MAXNZ + t] = s.zi_slope[t]; zt[2 * MAXNZ + t] = s.zi_y[t]; }
+  if (t < s.nz && t < ZT_STRIDE) { zt[t] = s.zi_x[t]; zt[ZT_STRIDE + t] = s.zi_slope[t]; zt[2 * ZT_STRIDE + t] = s.zi_y[t]; }
   __syncthreads();
 }
 template <bool ZT = false>
@@ -1274,21 +1290,66 @@ __device__ __forceinline__ void uv_fetch(const LD &ld, bool has_a, const Foot &f
 // (lon/lat, 3-D) 0.705 -> 0.645 ms per launch, texture-addresser busy -33 %; C4 (polar stereographic: the launch is bound by
 // float64 issue, 142 registers) 0.546 -> 0.599 ms -- the projected readers fetch every sample.
 #define ODR_UV_KEEPS(PROJ) (!ODR_PROJ_ROTATES(PROJ))
+// Returns the records to sample from.  KEEPS: K.q itself, whatever the case -- a sample that may not keep (`keep` false: the
+// full-step stage when its time bracket is not the half-step stages') fetches into K.q all the same and leaves K invalid; it is
+// the last sample of the step.  (Round 5: a separate copy of the records next to the kept ones held 32 more registers through the
+// stage phase -- the phase that sets the kernel's register count, and with it the waves per SIMD its launch time goes with.)
 template <bool IS3D, bool KEEPS, class LD>
-__device__ __forceinline__ void uv_records(const LD &ld, bool has_a, const Foot &ft, unsigned kb, UVKeep<IS3D> &K, bool keep,
-                                           UVRec<IS3D> &q) {
+__device__ __forceinline__ const UVRec<IS3D> &uv_records(const LD &ld, bool has_a, const Foot &ft, unsigned kb, UVKeep<IS3D> &K, bool keep,
+                                                         UVRec<IS3D> &scratch) {
 #if defined(ODR_NO_KEEP) || defined(ODR_TU_TILE)   // A/B build; the LDS-tile kernels (their records are two cycles away, the registers are not there)
   keep = false;
 #endif
-  if (KEEPS && keep) {
-    const bool same = K.valid && K.n00 == ft.n00 && K.n11 == ft.n11 && K.kb == kb;
+  if constexpr (KEEPS) {
+    const bool same = keep && K.valid && K.n00 == ft.n00 && K.n11 == ft.n11 && K.kb == kb;
     if (!same) {
       uv_fetch<IS3D>(ld, has_a, ft, kb, K.q);
-      K.n00 = ft.n00; K.n11 = ft.n11; K.kb = kb; K.valid = true;
+      K.n00 = ft.n00; K.n11 = ft.n11; K.kb = kb; K.valid = keep;
     }
-    q = K.q;
-  } else uv_fetch<IS3D>(ld, has_a, ft, kb, q);
+    return K.q;
+  } else {
+    uv_fetch<IS3D>(ld, has_a, ft, kb, scratch);
+    return scratch;
+  }
 }
+// ---- ODR_STAGE_FAST, 3-D readers: the kept records COMBINED over the two levels of the particle's vertical bracket.  The
+// element's depth does not change between the samples of a step, so the bracket's weights (za, zw) are the same for all of them:
+// what a stage sample needs of a corner is m = lo za + hi zw per time level -- (u, v) x 2 time levels = one F4 per corner, 16
+// registers for the footprint instead of 32 (K.q.b[c] = {m_before.u, m_before.v, m_after.u, m_after.v}; K.q.a is not used).
+// The stage value is then sum_c w_c m_c per time level and the time interpolation: the sum of round 4's FAST sample in another
+// association (there: (sum_c w_c lo_c) za + (sum_c w_c hi_c) zw) -- float32 round-off apart, inside the same gate
+// (tests/test_gpu_stage_math.py).  With the geodesic coefficients read from LDS where they are used this takes k_step_grid<RK4,
+// lat/lon, 3-D, FAST> from 126 to <= 96 registers: 5 waves per SIMD, and its launch time goes with 1 / waves
+// (profiles/r05_ab_variants.txt section 4).
+__device__ __forceinline__ F4 uv_combine_z(const F4 &b, const F4 &a, bool has_a, float za, float zw) {
+  F4 m;
+  m.x = __builtin_fmaf(b.z, zw, b.x * za); m.y = __builtin_fmaf(b.w, zw, b.y * za);
+  m.z = has_a ? __builtin_fmaf(a.z, zw, a.x * za) : m.x; m.w = has_a ? __builtin_fmaf(a.w, zw, a.y * za) : m.y;
+  return m;
+}
+template <class LD>
+__device__ __forceinline__ void uv_fetch_combined(const LD &ld, bool has_a, const Foot &ft, unsigned kb, float za, float zw, UVRec<true> &q) {
+  const unsigned o[4] = {ft.o00, ft.o01, ft.o10, ft.o11};
+  F4 b[4], a[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) b[c] = ld.template ld<F4, 8>(0, o[c] + kb);
+  if (has_a) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[c] = ld.template ld<F4, 8>(1, o[c] + kb);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[c] = b[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) q.b[c] = uv_combine_z(b[c], a[c], has_a, za, zw);
+}
+__device__ __forceinline__ void uv_zweights(const ZBracket &zb, int nz, float &za, float &zw) {
+  // levels (iz0, iz0 + 1) = ("above", "below"); clamped at the deepest level both are iz0 + 1
+  const bool same = zb.same && nz > 1;
+  za = same ? 0.f : (float)zb.wa;
+  zw = 1.f - za;
+}
+
 // uv_level_ld's view of fetched records
 template <bool IS3D>
 struct RecLd {
@@ -1378,9 +1439,9 @@ __device__ __forceinline__ bool uv_sample_fast(const DevSource &s, const DevBloc
   if (PROJ == PROJ_LATLONG) { x = lon; y = lat; }
   else if (PROJ == PROJ_CURVILINEAR) curvi_locate(s.proj, lon, lat, x, y);
 #ifndef ODR_FULL_STAGE_PROJECTION
-  else if (ps.ok) proj_fwd_near<PROJ == PROJ_STERE_POLAR>(s.proj, ps, lon, lat, x, y);   // (by value: a pointer would pin the struct to scratch memory)
+  else if (ps.ok) proj_fwd_near<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, ps, lon, lat, x, y);   // (by value: a pointer would pin the struct to scratch memory)
 #endif
-  else proj_fwd<PROJ == PROJ_STERE_POLAR>(s.proj, lon, lat, x, y);
+  else proj_fwd<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, lon, lat, x, y);
   const double xchk = cover_x<PROJ>(s.proj.kind, s.lon_mode, x);
   float fu = __builtin_nanf(""), fv = __builtin_nanf("");
   bool ok = true;
@@ -1394,8 +1455,8 @@ __device__ __forceinline__ bool uv_sample_fast(const DevSource &s, const DevBloc
       const Foot ft = ld.foot(yi, xi, geo.ny, geo.nx, (unsigned)geo.rec * 4u, ok);
       if (!ok) return false;     // (LdTile) outside the rectangle: the caller samples from the blocks in HBM
       const FootW fw = foot_weights(ft);
-      UVRec<IS3D> rec;
-      uv_records<IS3D, ODR_UV_KEEPS(PROJ)>(ld, tm.a != nullptr, ft, IS3D ? (unsigned)zb.iz0 * 8u : 0u, K, keep, rec);
+      UVRec<IS3D> rec_;
+      const UVRec<IS3D> &rec = uv_records<IS3D, ODR_UV_KEEPS(PROJ)>(ld, tm.a != nullptr, ft, IS3D ? (unsigned)zb.iz0 * 8u : 0u, K, keep, rec_);
       const RecLd<IS3D> L = {rec};
       double ub, vb;
       uv_level_ld<IS3D, true>(L, 0, s.nz, ft, zb, ub, vb, f32c, fw);
@@ -1414,7 +1475,7 @@ __device__ __forceinline__ bool uv_sample_fast(const DevSource &s, const DevBloc
     }
     if (ODR_PROJ_ROTATES(PROJ)) {
       double sn, cs;
-      rotation_cs<PROJ == PROJ_STERE_POLAR>(s.proj, x, y, cs, sn);
+      rotation_cs<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, x, y, cs, sn);
       double uu = u, vv = v;
       u = __dsub_rn(__dmul_rn(uu, cs), __dmul_rn(vv, sn));
       v = __dadd_rn(__dmul_rn(uu, sn), __dmul_rn(vv, cs));
@@ -1445,8 +1506,8 @@ __device__ __forceinline__ bool uv_sample_stage_f32(const DevSource &s, const De
   double x, y;
   if (PROJ == PROJ_LATLONG) { x = lon; y = lat; }
   else if (PROJ == PROJ_CURVILINEAR) curvi_locate(s.proj, lon, lat, x, y);
-  else if (ps.ok) proj_fwd_near<PROJ == PROJ_STERE_POLAR>(s.proj, ps, lon, lat, x, y);
-  else proj_fwd<PROJ == PROJ_STERE_POLAR>(s.proj, lon, lat, x, y);
+  else if (ps.ok) proj_fwd_near<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, ps, lon, lat, x, y);
+  else proj_fwd<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, lon, lat, x, y);
   const double xchk = cover_x<PROJ>(s.proj.kind, s.lon_mode, x);
   float fu = __builtin_nanf(""), fv = __builtin_nanf("");
   bool ok = true;
@@ -1457,31 +1518,41 @@ __device__ __forceinline__ bool uv_sample_stage_f32(const DevSource &s, const De
     const double yi = (y - geo.y0) * geo.iyspan * (double)(geo.ny - 1);
     const Foot ft = ld.foot(yi, xi, geo.ny, geo.nx, (unsigned)geo.rec * 4u, ok);
     if (!ok) return false;     // (LdTile) outside the rectangle: the caller samples from the blocks in HBM
-    UVRec<IS3D> rec;
-    uv_records<IS3D, ODR_UV_KEEPS(PROJ)>(ld, tm.a != nullptr, ft, IS3D ? (unsigned)zb.iz0 * 8u : 0u, K, keep, rec);
     const float tx = (float)ft.tx, ty = (float)ft.ty, sx = 1.f - tx, sy = 1.f - ty;
     const float w00 = sy * sx, w01 = sy * tx, w10 = ty * sx, w11 = ty * tx;
     const float wt = tm.a ? (float)tm.w : 0.f;
     f32x2 r;
+    UVRec<IS3D> rec_;
     if constexpr (IS3D) {
-      // levels (iz0, iz0 + 1) = ("above", "below"); clamped at the deepest level both are iz0 + 1
-      const bool same = zb.same && s.nz > 1;
-      const float za = same ? 0.f : (float)zb.wa, zw = 1.f - za;
-      auto level = [&](int time) {
-        const F4 q00 = time ? rec.a[0] : rec.b[0], q01 = time ? rec.a[1] : rec.b[1];
-        const F4 q10 = time ? rec.a[2] : rec.b[2], q11 = time ? rec.a[3] : rec.b[3];
-        f32x2 lo = (f32x2){q00.x, q00.y} * w00, hi = (f32x2){q00.z, q00.w} * w00;
-        lo = __builtin_elementwise_fma((f32x2){q01.x, q01.y}, (f32x2){w01, w01}, lo);
-        hi = __builtin_elementwise_fma((f32x2){q01.z, q01.w}, (f32x2){w01, w01}, hi);
-        lo = __builtin_elementwise_fma((f32x2){q10.x, q10.y}, (f32x2){w10, w10}, lo);
-        hi = __builtin_elementwise_fma((f32x2){q10.z, q10.w}, (f32x2){w10, w10}, hi);
-        lo = __builtin_elementwise_fma((f32x2){q11.x, q11.y}, (f32x2){w11, w11}, lo);
-        hi = __builtin_elementwise_fma((f32x2){q11.z, q11.w}, (f32x2){w11, w11}, hi);
-        return __builtin_elementwise_fma(hi, (f32x2){zw, zw}, lo * za);
-      };
-      r = level(0);
-      if (tm.a) { const f32x2 ra = level(1); r = __builtin_elementwise_fma(ra - r, (f32x2){wt, wt}, r); }
+      // the footprint's records combined over the bracket's two levels (uv_fetch_combined): kept in K when the reader keeps
+      bool kp = keep;
+#if defined(ODR_NO_KEEP) || defined(ODR_TU_TILE)
+      kp = false;
+#endif
+      const unsigned kb = (unsigned)zb.iz0 * 8u;
+      float za, zw;
+      uv_zweights(zb, s.nz, za, zw);
+      UVRec<IS3D> &m = ODR_UV_KEEPS(PROJ) ? K.q : rec_;
+      // (the bracket is the same for every sample of the step -- the kept values are dropped when the sea floor moved the element --
+      // so the footprint's two node numbers identify the kept values)
+      const bool same = ODR_UV_KEEPS(PROJ) && kp && K.valid && K.n00 == ft.n00 && K.n11 == ft.n11;
+      if (!same) {
+        uv_fetch_combined(ld, tm.a != nullptr, ft, kb, za, zw, m);
+        if (ODR_UV_KEEPS(PROJ)) { K.n00 = ft.n00; K.n11 = ft.n11; K.valid = kp; }
+      }
+      r = (f32x2){m.b[0].x, m.b[0].y} * w00;
+      r = __builtin_elementwise_fma((f32x2){m.b[1].x, m.b[1].y}, (f32x2){w01, w01}, r);
+      r = __builtin_elementwise_fma((f32x2){m.b[2].x, m.b[2].y}, (f32x2){w10, w10}, r);
+      r = __builtin_elementwise_fma((f32x2){m.b[3].x, m.b[3].y}, (f32x2){w11, w11}, r);
+      if (tm.a) {
+        f32x2 ra = (f32x2){m.b[0].z, m.b[0].w} * w00;
+        ra = __builtin_elementwise_fma((f32x2){m.b[1].z, m.b[1].w}, (f32x2){w01, w01}, ra);
+        ra = __builtin_elementwise_fma((f32x2){m.b[2].z, m.b[2].w}, (f32x2){w10, w10}, ra);
+        ra = __builtin_elementwise_fma((f32x2){m.b[3].z, m.b[3].w}, (f32x2){w11, w11}, ra);
+        r = __builtin_elementwise_fma(ra - r, (f32x2){wt, wt}, r);
+      }
     } else {
+      const UVRec<IS3D> &rec = uv_records<IS3D, ODR_UV_KEEPS(PROJ)>(ld, tm.a != nullptr, ft, 0u, K, keep, rec_);
       auto level = [&](int time) {
         const F2 q00 = time ? rec.a[0] : rec.b[0], q01 = time ? rec.a[1] : rec.b[1];
         const F2 q10 = time ? rec.a[2] : rec.b[2], q11 = time ? rec.a[3] : rec.b[3];
@@ -1496,7 +1567,7 @@ __device__ __forceinline__ bool uv_sample_stage_f32(const DevSource &s, const De
     fu = r.x; fv = r.y;
     if (ODR_PROJ_ROTATES(PROJ)) {
       double sn, cs;
-      rotation_cs<PROJ == PROJ_STERE_POLAR>(s.proj, x, y, cs, sn);
+      rotation_cs<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, x, y, cs, sn);
       const float c = (float)cs, n = (float)sn, uu = fu, vv = fv;
       fu = uu * c - vv * n;
       fv = uu * n + vv * c;
@@ -1650,7 +1721,7 @@ __device__ __forceinline__ void burst_math(int m, Get get, const Foot &ft, const
 }
 // what the main-loop sample hands to the stage samples of the same particle-step (UVKeep): the records of slot A as
 // fetched (the step kernels put the current there), the footprint's identity and the level offset
-struct EnvExport { float b[16], a[16]; unsigned n00, n11; int iz0; bool valid; };   // (plain floats: arrays of structs behind a pointer stay in scratch memory)
+struct EnvExport { float b[16], a[16]; unsigned n00, n11; int iz0; bool valid; bool combine = false; };   // combine: b[4c..4c+3] = uv_combine_z of corner c (ODR_STAGE_FAST, 3-D), a[] unused   // (plain floats: arrays of structs behind a pointer stay in scratch memory)
 // L: the loader of the node records (time 0 = the level before, 1 = the level after, or the same level when !tl); ft and
 // near_off hold ITS byte offsets (LdGlobal::foot / LdTile::foot)
 template <int PROJ, class LD>
@@ -1665,7 +1736,7 @@ __device__ __forceinline__ void env_burst(const DevSource &s, const EnvGroupDesc
 #endif
   const int mA = G.ps_mode[0], mB = G.ps_mode[1], mC = G.ps_mode[2];
   double cs = 1, sn = 0;
-  if (ODR_PROJ_ROTATES(PROJ) && G.rotates) rotation_cs<PROJ == PROJ_STERE_POLAR>(s.proj, x, y, cs, sn);
+  if (ODR_PROJ_ROTATES(PROJ) && G.rotates) rotation_cs<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, x, y, cs, sn);
   const int temp_mask = G.temp_mask;
   auto finish = [&](int k, double v) {      // masked_invalid(...).astype('float32'), fallback, Kelvin -> Celsius
     float f = (float)v;
@@ -1687,35 +1758,10 @@ __device__ __forceinline__ void env_burst(const DevSource &s, const EnvGroupDesc
   // corner, only the byte offset depends on the mode: a load whose destination registers differ between uniform branches
   // ends in a copy at the join, i.e. in a wait right behind it, and the burst would be gone.  A narrower variable in a
   // wider slot over-reads into its neighbours in the node record (blocks end with 64 spare bytes); empty slots read offset 0.
-  // ---- burst 1: slot A and the land mask (34 registers in flight), then their arithmetic
-  {
-    const unsigned dA = (unsigned)G.ps_off[0] + ((mA == ENV_P3 || mA == ENV_S3I) ? iz0 * 8u : mA == ENV_S3 ? iz0 * 4u : 0u);
-    const unsigned dL = kL >= 0 ? near_off + (unsigned)G.ps_off[4] : 0u;
-    F4 Ab[4], Aa[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { Ab[c] = L.template ld<F4>(0, o[c] + dA); Aa[c] = L.template ld<F4>(1, o[c] + dA); }
-    if (X) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        X->b[4 * c] = Ab[c].x; X->b[4 * c + 1] = Ab[c].y; X->b[4 * c + 2] = Ab[c].z; X->b[4 * c + 3] = Ab[c].w;
-        X->a[4 * c] = Aa[c].x; X->a[4 * c + 1] = Aa[c].y; X->a[4 * c + 2] = Aa[c].z; X->a[4 * c + 3] = Aa[c].w;
-      }
-      X->n00 = ft.n00; X->n11 = ft.n11; X->iz0 = zb.iz0; X->valid = true;
-    }
-    const int ps_static = G.ps_static;
-    const float Lb = L.template ld<float>(0, dL);
-    float La;
-    if (ps_static & 16) La = Lb; else La = L.template ld<float>(1, dL);   // same values at both levels: one gather less
-    if (kA >= 0) {
-      double v0, v1;
-      burst_math<4>(mA, [&](int t, int c, int q) { const F4 &r = t ? Aa[c] : Ab[c]; return q == 0 ? r.x : q == 1 ? r.y : q == 2 ? r.z : r.w; },
-                    ft, zb, s.nz, tl, w, v0, v1);
-      emit(kA, mA, G.ps_rot[0], v0, v1);
-    }
-    if (kL >= 0)
-      finish(kL, tl ? (double)__fadd_rn(__fmul_rn(Lb, (float)(1 - w)), __fmul_rn(La, (float)w)) : (double)Lb);
-  }
-  ODR_PT_USE(out[0]); ODR_PT_USE(out[1]); ODR_PT_USE(out[2]); ODR_PT(15);
+#ifndef ODR_BURST_A_FIRST
+  // (round 5: the slots B, C, D go FIRST -- their 40 registers of returns are consumed before slot A's records, which the stage
+  // samples keep (UVKeep: 32 registers), are requested; with slot A first the kept records and this burst's returns were in
+  // flight together, through the phase that set the kernel's register count.  Same gathers, same arithmetic, same bits.)
   // ---- burst 2: slots B, C, D (40 registers), then their arithmetic
   if (kB >= 0 || kC >= 0 || kD >= 0) {
     const unsigned dB = (unsigned)G.ps_off[1] + (mB == ENV_S3 ? iz0 * 4u : 0u);
@@ -1768,6 +1814,100 @@ __device__ __forceinline__ void env_burst(const DevSource &s, const EnvGroupDesc
       emit(kD, ENV_S2, 0, v0, v1);
     }
   }
+#endif
+  // ---- burst 1: slot A and the land mask (34 registers in flight), then their arithmetic
+  {
+    const unsigned dA = (unsigned)G.ps_off[0] + ((mA == ENV_P3 || mA == ENV_S3I) ? iz0 * 8u : mA == ENV_S3 ? iz0 * 4u : 0u);
+    const unsigned dL = kL >= 0 ? near_off + (unsigned)G.ps_off[4] : 0u;
+    F4 Ab[4], Aa[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { Ab[c] = L.template ld<F4>(0, o[c] + dA); Aa[c] = L.template ld<F4>(1, o[c] + dA); }
+    if (X) {
+      if (X->combine) {   // the stage samples' kept values right away: 16 registers carried to the stage phase instead of 32
+        float za, zw;
+        uv_zweights(zb, s.nz, za, zw);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          X->b[4 * c] = __builtin_fmaf(Ab[c].z, zw, Ab[c].x * za); X->b[4 * c + 1] = __builtin_fmaf(Ab[c].w, zw, Ab[c].y * za);
+          X->b[4 * c + 2] = __builtin_fmaf(Aa[c].z, zw, Aa[c].x * za); X->b[4 * c + 3] = __builtin_fmaf(Aa[c].w, zw, Aa[c].y * za);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          X->b[4 * c] = Ab[c].x; X->b[4 * c + 1] = Ab[c].y; X->b[4 * c + 2] = Ab[c].z; X->b[4 * c + 3] = Ab[c].w;
+          X->a[4 * c] = Aa[c].x; X->a[4 * c + 1] = Aa[c].y; X->a[4 * c + 2] = Aa[c].z; X->a[4 * c + 3] = Aa[c].w;
+        }
+      }
+      X->n00 = ft.n00; X->n11 = ft.n11; X->iz0 = zb.iz0; X->valid = true;
+    }
+    const int ps_static = G.ps_static;
+    const float Lb = L.template ld<float>(0, dL);
+    float La;
+    if (ps_static & 16) La = Lb; else La = L.template ld<float>(1, dL);   // same values at both levels: one gather less
+    if (kA >= 0) {
+      double v0, v1;
+      burst_math<4>(mA, [&](int t, int c, int q) { const F4 &r = t ? Aa[c] : Ab[c]; return q == 0 ? r.x : q == 1 ? r.y : q == 2 ? r.z : r.w; },
+                    ft, zb, s.nz, tl, w, v0, v1);
+      emit(kA, mA, G.ps_rot[0], v0, v1);
+    }
+    if (kL >= 0)
+      finish(kL, tl ? (double)__fadd_rn(__fmul_rn(Lb, (float)(1 - w)), __fmul_rn(La, (float)w)) : (double)Lb);
+  }
+  ODR_PT_USE(out[0]); ODR_PT_USE(out[1]); ODR_PT_USE(out[2]); ODR_PT(15);
+#ifdef ODR_BURST_A_FIRST
+  // ---- burst 2: slots B, C, D (40 registers), then their arithmetic
+  if (kB >= 0 || kC >= 0 || kD >= 0) {
+    const unsigned dB = (unsigned)G.ps_off[1] + (mB == ENV_S3 ? iz0 * 4u : 0u);
+    const unsigned dC = (unsigned)G.ps_off[2] + (mC == ENV_S3 ? iz0 * 4u : 0u);
+    const unsigned dD = (unsigned)G.ps_off[3];
+    F2 Bb[4], Ba[4], Cb[4], Ca[4];
+    float Db[4], Da[4];
+    // (measured, round 4: these gathers issued right behind slot A's, one memory round trip less per particle at the same 126
+    // registers: launch 0.615 -> 0.633 ms, C5 0.776 -> 0.861 -- 74 registers of returns in flight per lane queue behind one another)
+    // (empty slots issue their gathers too, at offset 0.  Measured alternatives, C3: guarding a slot's gathers with the
+    // condition that also guards its arithmetic lets the compiler merge the two blocks -- gathers, wait, arithmetic, slot by
+    // slot -- 1.26 -> 1.45 ms per step; a zero-length buffer descriptor for empty slots 1.26 -> 1.31)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { Bb[c] = L.template ld<F2>(0, o[c] + dB); Ba[c] = L.template ld<F2>(1, o[c] + dB); }
+    // (a slot whose variable holds the same values at both time levels -- ps_static, from the blocks' content ids -- is
+    // gathered once: four 32-cycle gathers less; the copies sit behind the slot's own last load, where the arithmetic
+    // waits anyway)
+    const int ps_static = G.ps_static;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Cb[c] = L.template ld<F2>(0, o[c] + dC);
+    if (ps_static & 4) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Ca[c] = Cb[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Ca[c] = L.template ld<F2>(1, o[c] + dC);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Db[c] = L.template ld<float>(0, o[c] + dD);
+    if (ps_static & 8) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Da[c] = Db[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Da[c] = L.template ld<float>(1, o[c] + dD);
+    }
+    if (kB >= 0) {
+      double v0, v1;
+      burst_math<2>(mB, [&](int t, int c, int q) { const F2 &r = t ? Ba[c] : Bb[c]; return q == 0 ? r.x : r.y; }, ft, zb, s.nz, tl, w, v0, v1);
+      emit(kB, mB, G.ps_rot[1], v0, v1);
+    }
+    if (kC >= 0) {
+      double v0, v1;
+      burst_math<2>(mC, [&](int t, int c, int q) { const F2 &r = t ? Ca[c] : Cb[c]; return q == 0 ? r.x : r.y; }, ft, zb, s.nz, tl, w, v0, v1);
+      emit(kC, mC, G.ps_rot[2], v0, v1);
+    }
+    if (kD >= 0) {
+      double v0, v1;
+      burst_math<1>(ENV_S2, [&](int t, int c, int q) { return t ? Da[c] : Db[c]; }, ft, zb, s.nz, tl, w, v0, v1);
+      emit(kD, ENV_S2, 0, v0, v1);
+    }
+  }
+#endif
   ODR_PT_USE(out[3]); ODR_PT_USE(out[4]); ODR_PT(16);
 }
 
@@ -1782,7 +1922,7 @@ __device__ __forceinline__ EnvFront env_front(const DevSource &s, const DevBlock
   double x, y;
   if (PROJ == PROJ_LATLONG) { x = lon; y = lat; }
   else if (PROJ == PROJ_CURVILINEAR) curvi_locate(s.proj, lon, lat, x, y);
-  else proj_fwd<PROJ == PROJ_STERE_POLAR>(s.proj, lon, lat, x, y);
+  else proj_fwd<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, lon, lat, x, y);
   const double xchk = cover_x<PROJ>(s.proj.kind, s.lon_mode, x);
   f.covered = xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin && z <= s.zmax;
   if (s.mod360_x) x = np_mod(x, 360.0);
@@ -1880,7 +2020,7 @@ __device__ __forceinline__ bool env_group_sample(const DevWorld &W, const EnvGro
       for (int k = 0; k < MAXG; ++k) if (k < G.nv && G.partner[k] >= 0) need = true;
       if (need) {
         double sn, cs;
-        rotation_cs<PROJ == PROJ_STERE_POLAR>(s.proj, x, y, cs, sn);
+        rotation_cs<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, x, y, cs, sn);
 #pragma unroll
         for (int k = 0; k + 1 < MAXG; ++k) {  // the host places the y-component right after its x-component
           if (k >= G.nv || G.partner[k] < 0) continue;
@@ -1937,6 +2077,28 @@ __device__ __forceinline__ UVKeep<IS3D> uv_keep_from(const EnvGroupDesc &G, cons
     if constexpr (IS3D) { K.q.b[c].z = X.b[4 * c + 2]; K.q.b[c].w = X.b[4 * c + 3]; K.q.a[c].z = X.a[4 * c + 2]; K.q.a[c].w = X.a[4 * c + 3]; }
   }
   return K;
+}
+// ODR_STAGE_FAST, 3-D: the same hand-over with the records combined over the bracket of the main-loop sample (uv_combine_z);
+// z_unchanged: the stages sample at the depth of the main-loop sample (false when the sea floor lifted the element in between:
+// another bracket, the kept values do not apply)
+template <bool IS3D, int SM>
+__device__ __forceinline__ UVKeep<IS3D> uv_keep_from_sm(const EnvGroupDesc &G, const EnvExport &X, const UVTime &th, const ZBracket &zb,
+                                                        int nz, bool z_unchanged) {
+  if constexpr (!(IS3D && SM == 1)) return uv_keep_from<IS3D>(G, X, th);
+  else {
+    UVKeep<IS3D> K;
+    const bool tl = G.ba != nullptr && !G.all_static;
+    const float *mb = (const float *)((const char *)G.bb + G.ps_off[0]);
+    const float *ma = tl ? (const float *)((const char *)G.ba + G.ps_off[0]) : nullptr;
+    const bool fits = G.bs[0] == 0 && G.var[0] == VAR_U && G.ps_mode[0] == ENV_P3 && mb == th.b && ma == th.a;
+    K.valid = fits && X.valid && z_unchanged;
+    K.n00 = X.n00; K.n11 = X.n11; K.kb = (unsigned)X.iz0 * 8u;
+    // X.combine: the burst already combined the corners over the bracket (time level `a` = `b` when the sample is on a level:
+    // the loader reads the same records for both)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { K.q.b[c].x = X.b[4 * c]; K.q.b[c].y = X.b[4 * c + 1]; K.q.b[c].z = X.b[4 * c + 2]; K.q.b[c].w = X.b[4 * c + 3]; }
+    return K;
+  }
 }
 // for the kernels that need neither LDS tables nor the bracket
 template <int PROJ>

@@ -308,6 +308,7 @@ static inline bool any_members(const odr_ctx *c) {
 // PROJ_STERE_EQUIT_SPHERE instantiation, whose projection functions switch on DevProj::kind at run time
 static inline int odr_proj_template(const odr::DevProj &p) {
   if (p.kind == odr::PROJ_STERE_POLAR) return p.es != 0 ? odr::PROJ_STERE_POLAR : odr::PROJ_STERE_EQUIT_SPHERE;
+  if (p.kind >= odr::PROJ_TMERC) return odr::PROJ_EXT;   // tmerc / laea / oblique stere / rotated pole: an instantiation of their own (round 5)
   return p.kind;
 }
 int odr_i_ensure_ranks(odr_ctx *c, odr_particles *p);

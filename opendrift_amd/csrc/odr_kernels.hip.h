@@ -26,13 +26,14 @@ constexpr int BLOCK = ODR_BLOCK;  // threads per workgroup (A/B builds may overr
 // 2 waves (no scratch) 0.998 ms  (profiles/r02_ab_variants.txt)
 #define ODR_POLAR_STEP_WAVES 2
 #endif
-#define ODR_STEP_WAVES(PROJ) ((PROJ) == PROJ_LATLONG ? ODR_LATLONG_WAVES : ODR_POLAR_STEP_WAVES)
+// (PROJ_EXT -- tmerc / laea / oblique stere / rotated pole inlined -- needs more than 256 registers: one wave per SIMD rather than scratch memory)
+#define ODR_STEP_WAVES(PROJ) ((PROJ) == PROJ_LATLONG ? ODR_LATLONG_WAVES : ((PROJ) == PROJ_EXT ? 1 : ODR_POLAR_STEP_WAVES))
 // minimum waves per SIMD requested for the projected-reader instantiations (their stereographic forward /
 // rotation code otherwise takes ~185 VGPRs = 2 waves per SIMD)
 #ifndef ODR_LATLONG_WAVES
 #define ODR_LATLONG_WAVES 1
 #endif
-#define ODR_WAVES(PROJ) ((PROJ) == PROJ_LATLONG ? ODR_LATLONG_WAVES : ODR_POLAR_WAVES)
+#define ODR_WAVES(PROJ) ((PROJ) == PROJ_LATLONG ? ODR_LATLONG_WAVES : ((PROJ) == PROJ_EXT ? 1 : ODR_POLAR_WAVES))
 #ifndef ODR_MIX_WAVES
 #define ODR_MIX_WAVES 3   // the step kernel with the mixing inside: 167 VGPRs with the kept (u,v) records (3 waves per SIMD); held at 128 it spills
 #endif
@@ -147,13 +148,14 @@ __device__ __forceinline__ void geod_step(const GeodStart &o, double salp, doubl
 // (one column per thread, [coefficient][thread]: conflict-free 8-byte accesses) and are read back where a move needs them;
 // the kernel then fits 96 registers = 5 waves per SIMD without scratch memory (round 3; 111 registers = 4 waves before,
 // 80 B of scratch when merely capped at 96).
-constexpr int GEOD_PARK = 12;
+constexpr int GEOD_PARK = 15;   // (round 5: + the start point itself, slots 12 / 13, and the drift factor of the final move, slot 14)
 #ifndef ODR_FULL_GEODESIC
 typedef volatile __attribute__((address_space(3))) double lds_f64;   // explicit LDS pointer: ds_read / ds_write, not flat accesses
 __device__ __forceinline__ void geod_park(const GeodLocal &o, lds_f64 *slot) {
   slot[0 * BLOCK] = o.iN; slot[1 * BLOCK] = o.qs; slot[2 * BLOCK] = o.kphi; slot[3 * BLOCK] = o.klam;
   slot[4 * BLOCK] = o.t; slot[5 * BLOCK] = o.a20; slot[6 * BLOCK] = o.a30; slot[7 * BLOCK] = o.a12;
   slot[8 * BLOCK] = o.a40; slot[9 * BLOCK] = o.a22; slot[10 * BLOCK] = o.b21; slot[11 * BLOCK] = o.b31;
+  slot[12 * BLOCK] = o.lat1; slot[13 * BLOCK] = o.lon1n;
 }
 __device__ __forceinline__ GeodLocal geod_unpark(double lat1, double lon1n, lds_f64 *slot) {
   GeodLocal o;
@@ -162,6 +164,38 @@ __device__ __forceinline__ GeodLocal geod_unpark(double lat1, double lon1n, lds_
   o.t = slot[4 * BLOCK]; o.a20 = slot[5 * BLOCK]; o.a30 = slot[6 * BLOCK]; o.a12 = slot[7 * BLOCK];
   o.a40 = slot[8 * BLOCK]; o.a22 = slot[9 * BLOCK]; o.b21 = slot[10 * BLOCK]; o.b31 = slot[11 * BLOCK];
   return o;
+}
+// geod_local_move straight from the parked coefficients (odr_geodesic.hip.h for the series): they are read in three groups,
+// each right in front of the terms that use it, so that at most five of the twelve are in registers at a time (geod_unpark
+// reads all twelve = 24 registers in front of the move -- the transient that stood between k_step_grid and 96 registers).
+// Same operations in the same order as geod_local_move: same bits.
+__device__ __forceinline__ void geod_local_move_parked(lds_f64 *slot, double x, double y, double &lat2, double &lon2) {
+#pragma clang fp contract(fast)
+  const double iN = slot[0 * BLOCK], qs = slot[1 * BLOCK];
+  const double u = y * iN, v = x * iN;
+  const double u2 = u * u, v2 = v * v;
+  if (!((u2 + v2) * (qs * qs) <= kGeodLocalQ * kGeodLocalQ)) {   // also NaN steps
+    const double lat1 = slot[12 * BLOCK], lon1n = slot[13 * BLOCK];
+    if (u2 + v2 == u2 + v2 && lat1 == lat1) { const GeodLL r = geod_local_far(lat1, lon1n, x, y); lat2 = r.lat; lon2 = r.lon; return; }
+    lat2 = lon2 = __builtin_nan("");
+    return;
+  }
+  const double a40 = slot[8 * BLOCK], a30 = slot[6 * BLOCK], a20 = slot[5 * BLOCK];
+  const double pu = fma(fma(a40, u, a30), u, a20);                               // a20 + a30 u + a40 u^2
+  __builtin_amdgcn_sched_barrier(0);
+  const double t = slot[4 * BLOCK], a12 = slot[7 * BLOCK], a22 = slot[9 * BLOCK];
+  const double a02 = -0.5 * t, a04 = -0.25 * t * a12, b03 = (-1.0 / 3) * t * t;
+  const double pv = fma(a04, v2, fma(fma(a22, u, a12), u, a02));                 // a02 + a12 u + a22 u^2 + a04 v^2
+  const double p = fma(pv, v2, fma(pu, u2, u));
+  __builtin_amdgcn_sched_barrier(0);
+  const double b21 = slot[10 * BLOCK], b31 = slot[11 * BLOCK];
+  const double b13 = -t * b21;
+  const double lu = fma(fma(fma(b31, u, b21), u, t), u, 1.0);                    // 1 + b11 u + b21 u^2 + b31 u^3
+  const double l = v * fma(fma(b13, u, b03), v2, lu);
+  __builtin_amdgcn_sched_barrier(0);
+  const double kphi = slot[2 * BLOCK], klam = slot[3 * BLOCK], lat1 = slot[12 * BLOCK], lon1n = slot[13 * BLOCK];
+  lat2 = fma(kphi, p, lat1);
+  lon2 = ang_normalize(fma(klam, l, lon1n));
 }
 #endif
 
@@ -232,6 +266,13 @@ __device__ __forceinline__ void stage_pos(const GeodStart &o, float u, float v, 
 #endif
   }
 }
+#ifndef ODR_FULL_GEODESIC
+// ODR_STAGE_FAST with the coefficients parked in LDS
+__device__ __forceinline__ void stage_pos_parked(lds_f64 *slot, float u, float v, float dtf, double &lon2, double &lat2) {
+  const double hd = 0.5 * (double)dtf;
+  geod_local_move_parked(slot, (double)u * hd, (double)v * hd, lat2, lon2);
+}
+#endif
 // the same with the mode as a (wave-uniform) run-time value: kernels that serve any reader mix
 __device__ __forceinline__ void stage_pos_rt(int sm, const GeodStart &o, float u, float v, float dtf, double &lon2, double &lat2) {
   if (sm == 1) stage_pos<1>(o, u, v, dtf, lon2, lat2);
@@ -744,14 +785,19 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
   GeodStart o0 = geod_start(lat, lon);
 #ifndef ODR_FULL_GEODESIC
   // PARK: the series coefficients wait in LDS between the moves (geod_park); the start point is rebuilt where it is used
-  const double lat1 = o0.lat1, lon1n = o0.lon1n;
   lds_f64 *slot = (lds_f64 *)park;
-  if constexpr (PARK) geod_park(o0, slot);
-  auto O = [&]() { if constexpr (PARK) return geod_unpark(lat1, lon1n, slot); else return o0; };
+  if constexpr (PARK) { geod_park(o0, slot); if (SM == 1 && SCHEME == 2) slot[14 * BLOCK] = (double)f; }
+  auto O = [&]() { if constexpr (PARK) return geod_unpark(slot[12 * BLOCK], slot[13 * BLOCK], slot); else return o0; };
 #else
   auto O = [&]() { return o0; };
 #endif
 #define ODR_O O()
+#ifndef ODR_FULL_GEODESIC
+#define ODR_STAGE_POS(U_, V_) do { if constexpr (PARK && SM == 1) stage_pos_parked(slot, U_, V_, dtf, lon2, lat2); \
+                                   else stage_pos<SM>(ODR_O, U_, V_, dtf, lon2, lat2); } while (0)
+#else
+#define ODR_STAGE_POS(U_, V_) stage_pos<SM>(ODR_O, U_, V_, dtf, lon2, lat2)
+#endif
   if (SCHEME == 0) {
     fu = __fmul_rn(f, u1);
     fv = __fmul_rn(f, v1);
@@ -771,7 +817,7 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
       else if (s.lon_mode == 2) lw = np_mod(lw, 360.0);
       ps = proj_start(s.proj, lw, lat);
     }
-    stage_pos<SM>(ODR_O, u1, v1, dtf, lon2, lat2);
+    ODR_STAGE_POS(u1, v1);
     ODR_PT_USE(lon2); ODR_PT_USE(lat2); ODR_PT(4);
     uv_stage_or_global<PROJ, IS3D, SM>(s, geo, th, lh, lon2, lat2, z, zb, fbu, fbv, u2, v2, ps, K, true);
     if (NOISE) add_current_noise(N, 1, i, n, id, u2, v2);
@@ -781,20 +827,25 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
       fv = __fmul_rn(f, v2);
     } else {
       float u3, v3, u4, v4;
-      stage_pos<SM>(ODR_O, u2, v2, dtf, lon2, lat2);
+      ODR_STAGE_POS(u2, v2);
       uv_stage_or_global<PROJ, IS3D, SM>(s, geo, th, lh, lon2, lat2, z, zb, fbu, fbv, u3, v3, ps, K, true);
       if (NOISE) add_current_noise(N, 2, i, n, id, u3, v3);
       ODR_PT_USE(u3); ODR_PT_USE(v3); ODR_PT(6);
-      stage_pos<SM>(ODR_O, u3, v3, dtf, lon2, lat2);
+      ODR_STAGE_POS(u3, v3);
       uv_stage_or_global<PROJ, IS3D, SM>(s, geo, tf, lf, lon2, lat2, z, zb, fbu, fbv, u4, v4, ps, K, keep_f);
       if (NOISE) add_current_noise(N, 3, i, n, id, u4, v4);
       ODR_PT_USE(u4); ODR_PT_USE(v4); ODR_PT(7);
-      fu = __fmul_rn(rk4_mix(u1, u2, u3, u4), f);
-      fv = __fmul_rn(rk4_mix(v1, v2, v3, v4), f);
+      float fl = f;
+#ifndef ODR_FULL_GEODESIC
+      if constexpr (PARK && SM == 1) fl = (float)slot[14 * BLOCK];   // (parked with the coefficients: one register less through the stages)
+#endif
+      fu = __fmul_rn(rk4_mix(u1, u2, u3, u4), fl);
+      fv = __fmul_rn(rk4_mix(v1, v2, v3, v4), fl);
     }
   }
   move_f32_from(ODR_O, lon, lat, fu, fv, moving, dt);
 #undef ODR_O
+#undef ODR_STAGE_POS
 }
 
 template <int SCHEME, int PROJ, bool IS3D, bool NOISE, int SM = 0>
@@ -887,13 +938,26 @@ struct StepMix {
 #define ODR_PARK_WAVES 4   // with the kept (u,v) records of the footprint (UVKeep: 35 registers): 126 registers; 4 and 5 waves per SIMD ran alike before (profiles/r03_ab_variants.txt)
 #endif
 #endif
+// Round 5: the lat / lon 3-D instantiations with the FAST stage arithmetic fit 96 registers without scratch memory -- kept values
+// combined over the vertical bracket (16 registers instead of 32), slots B / C / D sampled before slot A, the start point and the
+// drift factor parked with the geodesic coefficients, bookkeeping state requested behind the sample -- and run at FIVE waves per
+// SIMD; the launch time of this kernel goes with 1 / waves (profiles/r05_ab_variants.txt section 4: 3 waves +44 %, 2 waves +146 %).
+// The 2-D, curvilinear and EXACT instantiations need more and stay at ODR_PARK_WAVES.
+#ifndef ODR_PARK_WAVES_FAST3D
+#define ODR_PARK_WAVES_FAST3D 5
+#endif
+#if defined(ODR_NO_KEEP)
+#define ODR_PARK_WAVES_OF(PROJ, IS3D, SM) ODR_PARK_WAVES
+#else
+#define ODR_PARK_WAVES_OF(PROJ, IS3D, SM) (((PROJ) == PROJ_LATLONG && (IS3D) && (SM) == 1) ? ODR_PARK_WAVES_FAST3D : ODR_PARK_WAVES)
+#endif
 #if defined(ODR_FULL_GEODESIC) || defined(ODR_NO_PARK)
 #define ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) false
 #else
 #define ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ((SCHEME) > 0 && (MIXQ) == 0 && ((PROJ) == PROJ_LATLONG || (PROJ) == PROJ_CURVILINEAR))
 #endif
 template <int SCHEME, int PROJ, bool IS3D, bool NOISE, int MIXQ = 0, bool MIXTL = false, int SM = 0>
-__global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PARK_WAVES : ((MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_WAVES) ? ODR_MIX_WAVES : ODR_STEP_WAVES(PROJ))) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
+__global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PARK_WAVES_OF(PROJ, IS3D, SM) : ((MIXQ > 0 && ODR_STEP_WAVES(PROJ) < ODR_MIX_WAVES) ? ODR_MIX_WAVES : ODR_STEP_WAVES(PROJ))) void k_step_grid(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
                                                      StepDesc S, double dt, float factor, UVTime th, UVTime tf,
                                                      unsigned long long *n_hit, StageNoise N,
                                                      StepMix M = StepMix()) {
@@ -903,7 +967,7 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
   ODR_PT(0);
   constexpr bool PARK = ODR_STEP_PARKS(SCHEME, PROJ, MIXQ);
   __shared__ double s_park[PARK ? GEOD_PARK * BLOCK : 1];
-  __shared__ double s_zt[IS3D ? 3 * MAXNZ : 1];   // interp1d tables of the reader's z grid (zinterp)
+  __shared__ double s_zt[IS3D ? 3 * ZT_STRIDE : 1];   // interp1d tables of the reader's z grid (zinterp)
   const double *zt = nullptr;
   if (IS3D) { zt_stage(W->src[G.sid], s_zt); zt = s_zt; }
   double *Kp = nullptr, *gsh = nullptr;
@@ -926,10 +990,19 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
     const double z = p.z[i];
     // everything the bookkeeping below reads of this particle, requested together with the position: each of these
     // loads after the environment stores is a memory round trip of its own (float stores may alias float loads)
-    int moving = p.moving[i];
-    int st = p.status[i];
-    const float age0 = p.age[i], cdf0 = p.cdf[i];
-    const float ssh0 = (S.seafloor || MIXQ > 0) && p.env[VAR_SSH] ? p.env[VAR_SSH][i] : 0.f;
+    // ODR_STATE_LATE (the 3-D lat / lon instantiations of round 5): moving, status, age, drift factor and ssh are requested BEHIND
+    // the sample instead of with the position -- one more dependent round trip, five registers less through the main-loop sample,
+    // which with the rest of round 5's register work leaves the kernel at <= 96 registers = 5 waves per SIMD
+    constexpr bool STATE_LATE = ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) && IS3D;
+    int moving = 0, st = 0;
+    float age0 = 0.f, cdf0 = 0.f, ssh0 = 0.f;
+    auto load_state = [&]() {
+      moving = p.moving[i];
+      st = p.status[i];
+      age0 = p.age[i]; cdf0 = p.cdf[i];
+      ssh0 = (S.seafloor || MIXQ > 0) && p.env[VAR_SSH] ? p.env[VAR_SSH][i] : 0.f;
+    };
+    if constexpr (!STATE_LATE) load_state();
     constexpr bool RED = !IS3D && MIXQ == 0;      // (the movers' tests, below)
     const float wdf0 = (RED && S.red_on && S.red_xw > -2) ? p.wdf[i] : 0.f;
     ODR_PT_USE(lon); ODR_PT_USE(lat); ODR_PT_USE(z); ODR_PT(1);
@@ -938,8 +1011,10 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
     zb_env.iz0 = 0; zb_env.same = 0; zb_env.wa = 1;
     EnvExport X;
     X.valid = false; X.n00 = X.n11 = 0; X.iz0 = 0;
+    X.combine = IS3D && SM == 1;
     env_group_fast<PROJ, true, IS3D>(*W, G, lon, lat, z, out, zt, zb_env, &X ODR_PT_ARG);
-    UVKeep<IS3D> K = uv_keep_from<IS3D>(G, X, th);
+    UVKeep<IS3D> K = uv_keep_from_sm<IS3D, SM>(G, X, th, zb_env, W->src[G.sid].nz, true);   // (FAST, 3-D: combined over the bracket's levels)
+    if constexpr (STATE_LATE) load_state();
     ODR_PT_USE(out[0]); ODR_PT_USE(out[1]); ODR_PT_USE(out[2]); ODR_PT_USE(out[3]); ODR_PT_USE(out[4]); ODR_PT(2);
     const int id = (NOISE || MIXQ > 0) ? p.id[i] : 0;
     if (MIXQ > 0) vmix_col_fill<(MIXQ > 0 ? MIXQ : 1), MIXTL>(W->src[M.D.sid], M.D, lon, lat, Kp, threadIdx.x);
@@ -1011,6 +1086,7 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
     }
     // deactivated (now or earlier, not yet compacted): the reference removes it before update() -- it does not move
     const bool skip = st != 0;
+    if constexpr (IS3D && SM == 1) { if (zz != z) K.valid = false; }   // the sea floor lifted the element: another bracket than the kept values'
 #ifndef ODR_ABLATE_STORES
     if (S.store_previous) { p.plon[i] = lon; p.plat[i] = lat; }
 #endif
@@ -1063,8 +1139,14 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
         }
       }
     }
-    p.lon[i] = lon;
-    p.lat[i] = lat;
+    {
+      // (an opaque copy of the index: the addresses of lon / lat formed for the loads at the top would otherwise be carried
+      // through the whole kernel for these two stores -- four registers of the 96 a fifth wave per SIMD leaves)
+      long long i2 = i;
+      asm volatile("" : "+v"(i2));
+      p.lon[i2] = lon;
+      p.lat[i2] = lat;
+    }
 #ifdef ODR_PHASE_TIMING
     pt_[9] = __builtin_readcyclecounter();
     if ((threadIdx.x & 63) == 0 && (blockIdx.x & 127) == 5) {   // a sample of the waves: the atomics must not load the memory system

@@ -48,11 +48,12 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
     // on, the whole-column kernel below that -- measured on MI355X, 4 M particles (tools/vmix_levels.py): 8 / 12 / 16 / 24 /
     // 40 levels: column 0.155 / 0.176 / 0.218 / 0.327 / 1.268 ms, window 0.167 / 0.186 / 0.207 / 0.237 / 0.274 ms.
     // ODR_VMIX_WINDOW=1 / 0 forces one of them (the parity tests compare the two).
+    static const size_t vmix_pad = getenv("ODR_VMIX_LDS_PAD") ? (size_t)atoll(getenv("ODR_VMIX_LDS_PAD")) : 0;   // what-if runs: fewer workgroups per CU
     const char *wenv = getenv("ODR_VMIX_WINDOW");
     const bool win = nzp >= 3 && nzp <= BLOCK && (wenv ? atoi(wenv) != 0 : nzp > 12);
 #define VMIX_COL(NQ)                                                                                              \
   do {                                                                                                            \
-    size_t l2 = sizeof(double) * ((size_t)(4 * NQ) * BLOCK + 4 * (size_t)(4 * NQ));                               \
+    size_t l2 = sizeof(double) * ((size_t)(4 * NQ) * BLOCK + 4 * (size_t)(4 * NQ)) + vmix_pad;                    \
     if (tl) hipLaunchKernelGGL((k_vmix_col<NQ, true>), g, b, l2, c->stream, c->dw, v, D, dt, dt_mix,              \
                                mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);                                  \
     else hipLaunchKernelGGL((k_vmix_col<NQ, false>), g, b, l2, c->stream, c->dw, v, D, dt, dt_mix,                \

@@ -18,6 +18,7 @@ static void launch_advect_grid(odr_ctx *c, odr_particles *p, int sid, double t, 
     case PROJ_LATLONG: if (is3d) ODR_LAUNCH(PROJ_LATLONG, true); else ODR_LAUNCH(PROJ_LATLONG, false); break;
     case PROJ_STERE_POLAR: if (is3d) ODR_LAUNCH(PROJ_STERE_POLAR, true); else ODR_LAUNCH(PROJ_STERE_POLAR, false); break;
     case PROJ_CURVILINEAR: if (is3d) ODR_LAUNCH(PROJ_CURVILINEAR, true); else ODR_LAUNCH(PROJ_CURVILINEAR, false); break;
+    case PROJ_EXT: if (is3d) ODR_LAUNCH(PROJ_EXT, true); else ODR_LAUNCH(PROJ_EXT, false); break;
     default: if (is3d) ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, true); else ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, false); break;
   }
 #undef ODR_LAUNCH
@@ -78,6 +79,7 @@ static void launch_step_grid(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G
     case PROJ_LATLONG: if (is3d) ODR_LAUNCH(PROJ_LATLONG, true); else ODR_LAUNCH(PROJ_LATLONG, false); break;
     case PROJ_STERE_POLAR: if (is3d) ODR_LAUNCH(PROJ_STERE_POLAR, true); else ODR_LAUNCH(PROJ_STERE_POLAR, false); break;
     case PROJ_CURVILINEAR: if (is3d) ODR_LAUNCH(PROJ_CURVILINEAR, true); else ODR_LAUNCH(PROJ_CURVILINEAR, false); break;
+    case PROJ_EXT: if (is3d) ODR_LAUNCH(PROJ_EXT, true); else ODR_LAUNCH(PROJ_EXT, false); break;
     default: if (is3d) ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, true); else ODR_LAUNCH(PROJ_STERE_EQUIT_SPHERE, false); break;
   }
 #undef ODR_LAUNCH

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(BLOCK, ODR_TILE_WAVES) void k_step_tile(const DevWo
                                                                       double dt, float factor, UVTime th, UVTime tf,
                                                                       unsigned long long *n_hit, StageNoise N, TileArgs T) {
   extern __shared__ __attribute__((aligned(16))) char tile_mem[];
-  __shared__ double s_zt[IS3D ? 3 * MAXNZ : 1];
+  __shared__ double s_zt[IS3D ? 3 * ZT_STRIDE : 1];
   __shared__ int s_red[BLOCK / 64][4];
   __shared__ int s_anchor[2];
   // The grid is the host's upper bound of the table length; the first `total` workgroups take the entries in the
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(BLOCK, (PROJ) == PROJ_LATLONG ? 4 : ODR_POLAR_STEP_
                                                                            double dt, float factor, UVTime th, UVTime tf,
                                                                            unsigned long long *n_hit, StageNoise N, const unsigned *__restrict__ list,
                                                                            const unsigned long long *__restrict__ list_n, unsigned long long *stats) {
-  __shared__ double s_zt[IS3D ? 3 * MAXNZ : 1];
+  __shared__ double s_zt[IS3D ? 3 * ZT_STRIDE : 1];
   const unsigned long long cnt = *list_n;
   if (blockIdx.x == 0 && threadIdx.x == 0 && stats && cnt) atomicAdd(&stats[0], cnt);
   if ((unsigned long long)blockIdx.x * BLOCK >= cnt) return;

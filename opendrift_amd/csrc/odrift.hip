@@ -1076,6 +1076,7 @@ static bool launch_env_grid(odr_ctx *c, odr_particles *p, const int *grp, int ng
     case PROJ_LATLONG: hipLaunchKernelGGL(k_env_grid<PROJ_LATLONG>, g, b, 0, c->stream, c->dw, v, G, rec); break;
     case PROJ_STERE_POLAR: hipLaunchKernelGGL(k_env_grid<PROJ_STERE_POLAR>, g, b, 0, c->stream, c->dw, v, G, rec); break;
     case PROJ_CURVILINEAR: hipLaunchKernelGGL(k_env_grid<PROJ_CURVILINEAR>, g, b, 0, c->stream, c->dw, v, G, rec); break;
+    case PROJ_EXT: hipLaunchKernelGGL(k_env_grid<PROJ_EXT>, g, b, 0, c->stream, c->dw, v, G, rec); break;
     default: hipLaunchKernelGGL(k_env_grid<PROJ_STERE_EQUIT_SPHERE>, g, b, 0, c->stream, c->dw, v, G, rec); break;
   }
   return true;
@@ -1595,6 +1596,7 @@ int odr_env_coast_leeway(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
     case PROJ_LATLONG: hipLaunchKernelGGL(k_step_leeway<PROJ_LATLONG>, g, b, 0, c->stream, c->dw, v, G, S, dt, c->counter); break;
     case PROJ_STERE_POLAR: hipLaunchKernelGGL(k_step_leeway<PROJ_STERE_POLAR>, g, b, 0, c->stream, c->dw, v, G, S, dt, c->counter); break;
     case PROJ_CURVILINEAR: hipLaunchKernelGGL(k_step_leeway<PROJ_CURVILINEAR>, g, b, 0, c->stream, c->dw, v, G, S, dt, c->counter); break;
+    case PROJ_EXT: hipLaunchKernelGGL(k_step_leeway<PROJ_EXT>, g, b, 0, c->stream, c->dw, v, G, S, dt, c->counter); break;
     default: hipLaunchKernelGGL(k_step_leeway<PROJ_STERE_EQUIT_SPHERE>, g, b, 0, c->stream, c->dw, v, G, S, dt, c->counter); break;
   }
   HIPCHK(hipGetLastError());

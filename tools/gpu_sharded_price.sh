@@ -1,0 +1,17 @@
+#!/bin/bash
+# Prices the host part of the sharded step on ONE GPU (no 8-GPU node in the pool): two gloo ranks x 5 M particles share the device,
+# against one rank x 10 M and one rank x 5 M.  The two processes time-slice the GPU, so "2 x 5 M" is at best the 10 M step: what it
+# costs beyond that is the host read + host-side collective per step + the GPU switching between the processes.
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/$1; mkdir -p $O
+export ODR_BENCH_ONE_MODE=1
+timeout 600 python bench.py --steps 96 --no-cpu --no-extras > $O/one_10m.log 2>&1; grep "^{" $O/one_10m.log | tail -1 > $O/one_10m.json
+timeout 600 python bench.py --steps 96 --no-cpu --no-extras --particles 5000000 > $O/one_5m.log 2>&1; grep "^{" $O/one_5m.log | tail -1 > $O/one_5m.json
+ODR_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 96 --no-cpu --no-extras --particles 5000000 --block-every -1 > $O/two_5m.log 2>&1; grep "^{" $O/two_5m.log | tail -1 > $O/two_5m.json
+python - <<PY
+import json
+a, b, c = (json.load(open('$O/%s.json' % n)) for n in ('one_10m', 'one_5m', 'two_5m'))
+print('1 rank x 10 M: %.4f ms/step   1 rank x 5 M: %.4f   2 gloo ranks x 5 M on one GPU: %.4f ms/step' % (a['ms_per_step'], b['ms_per_step'], c['ms_per_step']))
+print('sharded_loop:', c.get('sharded_loop'))
+PY
+tail -3 $O/two_5m.log | cut -c1-300
