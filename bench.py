@@ -715,8 +715,8 @@ def main():
             other['second_kernel_ms'] = launch_ms(wl.second_kernel)[0]
         ctx.set_stage_math(a.stage_math)
 
-    # counters of the same command from the committed rocprofv3 passes (profiles/r04_<workload>_pmc.json, written by
-    # tools/gpu_profile_r04.sh + tools/collect_profiles_r04.py from this tree): PMC counters cannot be collected from inside
+    # counters of the same command from the committed rocprofv3 passes (profiles/r05_<workload>_pmc[_exact].json, written by
+    # tools/gpu_profile_round.sh + tools/collect_profiles_round.py from this tree): PMC counters cannot be collected from inside
     # this process.  Used only when they belong to this size and stage math.
     def load_pmc(mode):
         for r in ('r05', 'r04'):

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('ODR_LIB') or os.path.join(HERE, 'libodrift_hip.so')   # ODR_LIB: A/B builds (tools/ab_bench.sh)
+LIB_PATH = os.environ.get('ODR_LIB') or os.path.join(HERE, 'libodrift_hip.so')   # ODR_LIB: A/B builds (tools/gpu_ab.sh)
 
 NVAR = 26
 VARIABLES = {

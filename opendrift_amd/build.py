@@ -26,7 +26,7 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir=OBJDIR):
-    """extra_flags / lib / objdir: A/B builds of the same sources (tools/ab_build.sh)."""
+    """extra_flags / lib / objdir: A/B builds of the same sources (tools/vbuild.sh)."""
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     for u in UNITS:
