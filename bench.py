@@ -375,7 +375,8 @@ def model_api_leg(fields, n, steps, device):
         o.run(time_step=600, steps=steps, time_step_output=600 * steps, export_variables=['z'])
     tm = o.timing
     return dict(ms_per_step=tm['steady_ms_per_step'], value=n * 1e3 / tm['steady_ms_per_step'], unit='particle-steps/s',
-                steps=tm['steps'], what='OceanDrift.run(): the full loop body per step (release, all 14 required variables '
+                steps=tm['steps'], host_phases_ms_per_step=tm.get('host_phases_ms_per_step'),
+                what='OceanDrift.run(): the full loop body per step (release, all 14 required variables '
                 'sampled, deactivation checks, result buffer, age, compaction, update(): RK4 + wind + vertical mixing + '
                 'vertical advection, horizontal diffusion early-out)')
 

@@ -19,6 +19,22 @@
 
 using namespace odr;
 
+// ODR_SLOW_CALLS=<ms>: host-side spans (runtime calls that may block: allocations, frees, event waits, stream synchronisations)
+// that take longer than that are reported on stderr with their label -- where a run() loop's host stalls come from
+#include <chrono>
+struct SlowSpan {
+  const char *what;
+  std::chrono::steady_clock::time_point t0;
+  static double limit() { static const double v = getenv("ODR_SLOW_CALLS") ? atof(getenv("ODR_SLOW_CALLS")) : 0.0; return v; }
+  explicit SlowSpan(const char *w) : what(w) { if (limit() > 0) t0 = std::chrono::steady_clock::now(); }
+  ~SlowSpan() {
+    if (limit() > 0) {
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (ms > limit()) fprintf(stderr, "[odr slow] %s: %.3f ms\n", what, ms);
+    }
+  }
+};
+
 int odr_i_fail(int code, const char *fmt, ...);   // records the message for odr_last_error(), returns code
 #define fail odr_i_fail
 #define HIPCHK(x)                                                                          \
@@ -38,6 +54,10 @@ struct odr_ctx {
   hipStream_t stream, own_stream;
   DevWorld hw;      // host image
   DevWorld *dw;     // device image
+  // page-locked copies of `hw` the device image is refreshed from (flush_world): three in turn, each guarded by an event
+  DevWorld *hw_pin[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t hw_ev[3] = {nullptr, nullptr, nullptr};
+  int hw_turn = 0;
   bool dirty;
   std::vector<void *> block_bufs[MAXSRC][MAXLEVELS];  // owned device arrays per slot
   size_t block_bytes[MAXSRC][MAXLEVELS];
@@ -124,6 +144,9 @@ struct odr_particles {
   double *dead64[3];    // lon lat z of the deactivated store
   int *deadi32[2];      // id status
   unsigned *bcount;
+  unsigned *wcount;                 // per-wave counts of the last step launch (StepDesc.wcount), valid while wcount_epoch == status_epoch
+  unsigned long long wcount_epoch;
+  long long wcount_n;
   void *scratch;
   size_t scratch_bytes;
   unsigned long long epoch;  // bumped by every call that changes z, the environment, properties or the element set
@@ -177,14 +200,10 @@ static inline EnvGroupDesc env_bind_out(const EnvGroupDesc &G0, const PView &v) 
   return G;
 }
 
-static inline int flush_world(odr_ctx *c) {
-  if (c->dirty) {
-    HIPCHK(hipMemcpyAsync(c->dw, &c->hw, sizeof(DevWorld), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));  // hw is pageable and may change right after
-    c->dirty = false;
-  }
-  return 0;
-}
+// The device image of the world follows the host image without a host synchronisation and without the copy engine
+// (odrift.hip: flush_world)
+int flush_world(odr_ctx *c);
+int flush_world_init(odr_ctx *c);
 
 // env[v] is the constant `val` for every element (see odr_particles::env_cok)
 static inline bool env_is_const(const odr_particles *p, int v, float val) {
@@ -200,6 +219,7 @@ static inline int ensure_env(odr_ctx *c, odr_particles *p, int var) {
 
 static inline int scratch(odr_ctx *c, odr_particles *p, size_t bytes, void **out) {
   if (p->scratch_bytes < bytes) {
+    SlowSpan sp("scratch: synchronize + hipFree + hipMalloc");
     HIPCHK(hipStreamSynchronize(c->stream));
     if (p->scratch) HIPCHK(hipFree(p->scratch));
     HIPCHK(hipMalloc(&p->scratch, bytes));

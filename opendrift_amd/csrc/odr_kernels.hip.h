@@ -918,6 +918,11 @@ struct StepDesc {
   int red_hd, red_sx, red_xw, red_pad;   // horizontal_diffusivity; Stokes x (y = next slot / array); x_wind (y_wind likewise)
   double red_wdd, red_iwdd;         // wind_drift_depth as given (sign and zero matter, :754-757); 1 / |wind_drift_depth|
   double *red;                      // per-wave records [waves of the launch][6] (see the tail of k_step_grid)
+  // The status scan the run() loop makes right behind this launch (odr_scan_status: how many elements stay, which provisional
+  // status numbers occur) formed by the launch itself: wcount[i / 64] = elements of that wave with status 0, bit (status - 100) of
+  // *sflags.  k_cmp_total folds the wave counts; the pass over the status array (k_cmp_count, 32 us at 10 M elements) is not made.
+  unsigned *wcount;                 // nullptr: not asked for
+  unsigned long long *sflags;
 };
 
 // (The LDS field tile is a kernel of its own since round 4: k_step_tile, odr_tile.hip.h.)
@@ -1178,6 +1183,18 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
                      : lane == 3 ? sgn(b128, b256) : lane == 4 ? sgn(b32, b64) : (double)__popcll(bs);
       S.red[((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 6 + lane] = v;
     }
+  }
+  if (MIXQ == 0 && S.wcount) {
+    // (the status read back at the very end: carried through the kernel it would be one more register at its peak)
+    int s2 = 1;
+    long long i3 = i;
+    asm volatile("" : "+v"(i3));
+    if (i3 < p.n) s2 = p.status[i3];
+    const unsigned long long kb = __ballot(s2 == 0);
+    if (__ballot(s2 >= 100 && s2 < 164)) {   // rare: only while a reason waits for its first occurrence
+      if (s2 >= 100 && s2 < 164) atomicOr(S.sflags, 1ull << (s2 - 100));
+    }
+    if ((threadIdx.x & 63) == 0 && i3 < p.n) S.wcount[i3 >> 6] = (unsigned)__popcll(kb);
   }
 }
 
@@ -2597,6 +2614,34 @@ __global__ __launch_bounds__(BLOCK) void k_cmp_count(const int *status, long lon
     mine += __shfl_down(mine, 2, 64);
     mine += __shfl_down(mine, 1, 64);
     if (threadIdx.x == 0 && total && mine) atomicAdd(total, mine);   // the number of elements that stay
+  }
+}
+
+// The counts of k_cmp_count from the per-wave counts a step launch left (StepDesc.wcount): bcount[c] = the four waves of chunk c,
+// *total += everything (one atomic per workgroup; zeroed by the step call).
+__global__ __launch_bounds__(BLOCK) void k_cmp_total(const unsigned *__restrict__ wcount, long long nw, unsigned *bcount,
+                                                     unsigned long long *total) {
+  const long long nchunks = (nw + BLOCK / 64 - 1) / (BLOCK / 64);
+  unsigned long long mine = 0;
+  for (long long c = (long long)blockIdx.x * BLOCK + threadIdx.x; c < nchunks; c += (long long)gridDim.x * BLOCK) {
+    unsigned cnt = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) {
+      const long long k = c * (BLOCK / 64) + w;
+      cnt += k < nw ? wcount[k] : 0u;
+    }
+    bcount[c] = cnt;
+    mine += cnt;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  __shared__ unsigned long long sh[BLOCK / 64];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < BLOCK / 64; ++w) t += sh[w];
+    if (t) atomicAdd(total, t);
   }
 }
 

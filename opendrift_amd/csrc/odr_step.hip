@@ -1,6 +1,7 @@
 // libodrift_hip.so, translation unit 2: advect_ocean_current (Euler / RK2 / RK4) and the fused step
 // (get_environment + coastline + previous state + advection in one launch).  See odrift.hip for the rest.
 #define ODR_TU_STEP 1
+#include <chrono>
 #include "odr_step_launch.h"
 
 // drift:current_uncertainty / drift:current_uncertainty_uniform are part of every get_environment call that holds the
@@ -171,7 +172,17 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   }
   REQUIRE(has_u && has_v, "the variable list must hold x/y_sea_water_velocity");
   if (coast_action && !has_land && !p->env[VAR_LAND]) return fail(ODR_ERR_STATE, "land_binary_mask has not been sampled");
+  // ODR_SLOW_CALLS=<ms>: a call that keeps the host longer than that says where (stderr)
+  static const double slow_ms = getenv("ODR_SLOW_CALLS") ? atof(getenv("ODR_SLOW_CALLS")) : 0.0;
+  const auto t_call = std::chrono::steady_clock::now();
+  double t_mark[4] = {0, 0, 0, 0};
+  auto mark = [&](int k) { if (slow_ms > 0) t_mark[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
+  struct SlowReport {
+    const double &lim; const double *m;
+    ~SlowReport() { if (lim > 0 && (m[3] > lim || m[2] > lim)) fprintf(stderr, "odr_env_coast_advect: world flushed at %.3f ms, group built at %.3f, other variables sampled at %.3f, launched at %.3f\n", m[0], m[1], m[2], m[3]); }
+  } slow_report{slow_ms, t_mark};
   if ((rc = flush_world(c))) return rc;
+  mark(0);
   // the group of the current: variables of the list that share its priority list
   int grp[NVAR], ng = 0, rest[NVAR], nrest = 0;
   auto same_list = [&](int a, int b) {
@@ -212,6 +223,7 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   bool fuse = p->n > 0 && !getenv("ODR_NO_FAST_PATH") && same_list(VAR_V, VAR_U) && ng <= MAXG && nmg <= 4 && nmr <= 4 &&
               uv_fast_source(c, sid, t < t + dt ? t : t + dt, t < t + dt ? t + dt : t) &&
               build_env_group(c, grp, ng, t, G) && G.sid == sid && G.burst;   // k_step_grid carries the burst sampler only
+  mark(1);
   if (main_noise && N.rng_mode == ODR_RNG_HOST && !N.main) return fail(ODR_ERR_INVALID, "no host draws for the main sample");
   if (!fuse) {
     if ((rc = odr_env_sample(c, p, nvars, var_ids, t, nullptr))) return rc;
@@ -237,6 +249,7 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   for (int k = 0; k < ng; ++k) { if ((rc = ensure_env(c, p, grp[k]))) return rc; p->env_cok[grp[k]] = false; }
   if (coast_action == 2) p->env_cok[VAR_LAND] = false;   // elements on land get land_binary_mask = 0
   if (nrest && (rc = env_sample_impl(c, p, nrest, rest, t, nullptr, false))) return rc;  // k_step_grid records the positions
+  mark(2);
   StepDesc S;
   memset(&S, 0, sizeof S);
   S.coast_action = coast_action; S.stranded_code = stranded_code; S.seeded_code = seeded_on_land_code;
@@ -252,7 +265,10 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   for (int k = 0; k < nmg && k < 4; ++k) S.miss_grp[k] = miss_grp[k];
   for (int k = 0; k < nmr && k < 4; ++k) S.miss_rest[k] = miss_rest[k];
   if (want_floor && (rc = ensure_env(c, p, VAR_SSH))) return rc;
-  if (coast_action) HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
+  // counter[0]: elements on land; [1], [2]: the status scan formed by the launch (StepDesc.wcount, below) -- one fill for the three
+  const bool count_in_launch = p->wcount && !p->external && !getenv("ODR_NO_STEP_COUNT");
+  if (coast_action || count_in_launch)
+    HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long) * (count_in_launch ? 3 : 1), c->stream));
   S.main_noise = main_noise ? 1 : 0;
   S.ssh_slot = -1;
   for (int k = 0; k < G.nv; ++k) if (G.var[k] == VAR_SSH) S.ssh_slot = k;
@@ -313,6 +329,7 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
       if ((rc = odr_i_red_records(c, p, &S.red))) return rc;
     }
   }
+  if (count_in_launch) { S.wcount = p->wcount; S.sflags = c->counter + 2; }   // (k_step_grid only: the tile / lane / merged paths left above)
   if (N.on && (scheme > 0 || main_noise)) {
     if (scheme > 0 && N.rng_mode == ODR_RNG_HOST && !N.stage) return fail(ODR_ERR_INVALID, "no host draws for the Runge-Kutta stage calls");
     if (N.sm == ODR_STAGE_FAST && scheme > 0) odr_i_step_fast_noise(c, p, G, S, scheme, t, dt, factor, N);
@@ -325,6 +342,8 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
     c->red_owner = p; c->red_epoch = p->epoch; c->red_wdd = c->step_reduce_wdd; c->red_rel = c->step_reduce_rel;
     c->red_extents = false; c->red_partial = true;
   }
+  mark(3);
+  if (count_in_launch) { p->wcount_epoch = p->status_epoch; p->wcount_n = p->n; }   // (a mixing launch that follows voids it: it can deactivate)
   if ((rc = coast_action ? read_counter(c, n_on_land) : 0)) return rc;
   return want_mix ? mix_after(c, p, t, dt, extras) : 0;
 }

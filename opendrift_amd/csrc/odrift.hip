@@ -48,6 +48,8 @@ int odr_ctx_create(int device, uint64_t seed, odr_ctx **out) {
   c->nsrc = 0;
   c->fuse_vadv = -1;
   c->seafloor = ODR_SEAFLOOR_LIFT;
+  int rc = flush_world_init(c);
+  if (rc) return rc;
   *out = c;
   return 0;
 }
@@ -72,6 +74,7 @@ int odr_ctx_destroy(odr_ctx *c) {
   (void)hipEventDestroy(c->up_done);
   (void)hipEventDestroy(c->up_dep);
   (void)hipFree(c->dw);
+  for (int k = 0; k < 3; ++k) if (c->hw_pin[k]) { (void)hipHostFree(c->hw_pin[k]); (void)hipEventDestroy(c->hw_ev[k]); }
   (void)hipFree(c->red);
   if (c->red_rec) (void)hipFree(c->red_rec);
   for (double *q : {c->oil_stat, c->oil_cdf, c->oil_chunk, c->oil_part, c->oil_u}) if (q) (void)hipFree(q);
@@ -131,6 +134,8 @@ int odr_particles_create(odr_ctx *c, int64_t capacity, odr_particles **out) {
   for (int k = 0; k < 3; ++k) HIPCHK(hipMalloc((void **)&p->i32[k], sizeof(int) * (size_t)capacity));
   for (int k = 0; k < 4; ++k) HIPCHK(hipMalloc((void **)&p->f32[k], sizeof(float) * (size_t)capacity));
   HIPCHK(hipMalloc((void **)&p->bcount, sizeof(unsigned) * (size_t)(nblk(capacity) + 1)));
+  HIPCHK(hipMalloc((void **)&p->wcount, sizeof(unsigned) * (size_t)(nblk(capacity) + 1) * (BLOCK / 64)));
+  p->wcount_epoch = ~0ull;
   *out = p;
   return 0;
 }
@@ -148,6 +153,7 @@ int odr_particles_destroy(odr_ctx *c, odr_particles *p) {
   for (int k = 0; k < NVAR; ++k) { fr(p->env[k]); fr(p->altenv[k]); }
   for (int k = 0; k < 9; ++k) { fr(p->aux[k]); fr(p->altaux[k]); fr(p->aux_snap[k]); }
   fr(p->bcount);
+  fr(p->wcount);
   fr(p->scratch);
   fr(p->rank); fr(p->rank_words); fr(p->rank_before); fr(p->rank_bsum);
   fr(p->wg_tab); fr(p->wg_total); fr(p->wg_list); fr(p->z_keep);
@@ -571,6 +577,46 @@ int odr_source_lonlat2xy(odr_ctx *c, int32_t sid, int64_t n, const double *lon, 
   return 0;
 }
 
+// The device image of the world follows the host image WITHOUT a host synchronisation and without the copy engine: `hw` is
+// copied into one of three page-locked snapshots (hw may change right after), and a small kernel on the compute
+// stream moves the snapshot into `dw`.  (Rounds 1-4: hipMemcpyAsync from the pageable `hw` + hipStreamSynchronize.  In a
+// run() whose reader levels are prefetched on the upload stream that copy queued behind the 100 MB transfer of the level
+// staged just before it: the first level change of a run cost the host -- and the device -- 7 ms, profiles/r05_ab_variants.txt 6.
+// Anything the runtime sets up at a first use -- a page-locked allocation, the first launch of a kernel -- blocked the same way
+// when it fell behind a staged level: the snapshots are allocated and the kernel is launched once when the context is made.)
+__global__ void k_world_copy(uint2 *__restrict__ dst, const uint2 *__restrict__ src, unsigned nwords) {
+  for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < nwords; k += gridDim.x * blockDim.x) dst[k] = src[k];
+}
+int flush_world(odr_ctx *c) {
+  if (c->dirty) {
+    static_assert(sizeof(DevWorld) % sizeof(uint2) == 0, "DevWorld is copied in 8-byte words");
+    const int k = c->hw_turn;
+    {
+      SlowSpan sp("flush_world: hipEventSynchronize");
+      HIPCHK(hipEventSynchronize(c->hw_ev[k]));   // (the flush before the flush before this one: long done)
+    }
+    memcpy(c->hw_pin[k], &c->hw, sizeof(DevWorld));
+    SlowSpan sp("flush_world: launch + event record");
+    constexpr unsigned nwords = (unsigned)(sizeof(DevWorld) / sizeof(uint2));   // one 8-byte word per thread: one round trip over PCIe
+    hipLaunchKernelGGL(k_world_copy, dim3((nwords + 1023) / 1024), dim3(1024), 0, c->stream, (uint2 *)c->dw, (const uint2 *)c->hw_pin[k], nwords);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->hw_ev[k], c->stream));
+    c->hw_turn = (k + 1) % 3;
+    c->dirty = false;
+  }
+  return 0;
+}
+
+int flush_world_init(odr_ctx *c) {
+  for (int k = 0; k < 3; ++k) {
+    HIPCHK(hipHostMalloc((void **)&c->hw_pin[k], sizeof(DevWorld), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&c->hw_ev[k], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->hw_ev[k], c->stream));
+  }
+  c->dirty = true;
+  return flush_world(c);
+}
+
 static void sort_levels(DevSource &s) {
   s.nlevels = 0;
   for (int l = 0; l < MAXLEVELS; ++l) if (s.slot[l].valid) s.level_slot[s.nlevels++] = l;
@@ -592,7 +638,7 @@ static void reap(odr_ctx *c, size_t want_bytes, float **reuse) {
     Retired &r = c->graveyard[k];
     if (hipEventQuery(r.ev) == hipSuccess) {
       if (reuse && !*reuse && r.bytes == want_bytes) *reuse = (float *)r.ptr;
-      else (void)hipFree(r.ptr);
+      else { SlowSpan sp("reap: hipFree"); (void)hipFree(r.ptr); }
       (void)hipEventDestroy(r.ev);
       c->graveyard.erase(c->graveyard.begin() + (long)k);
     } else ++k;
@@ -666,7 +712,8 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
   const size_t base_bytes = sizeof(float) * plane * (size_t)rec + 64;
   float *base = nullptr;
   reap(c, base_bytes, &base);   // recycle a retired block of the same size if the compute stream is done with it
-  if (!base) HIPCHK(hipMalloc((void **)&base, base_bytes));
+  if (!base) { SlowSpan sp("stage_block: hipMalloc of the block"); HIPCHK(hipMalloc((void **)&base, base_bytes)); }
+  SlowSpan sp_rest("stage_block: everything after the block's allocation");
   if (c->prep_floats < nmax) {  // pooled scratch: one variable in flight + the dilation ping-pong buffer
     HIPCHK(hipStreamSynchronize(c->up_stream));
     if (c->prep[0]) HIPCHK(hipFree(c->prep[0]));
@@ -814,7 +861,7 @@ int odr_block_commit(odr_ctx *c, int32_t sid, int32_t slot) {
   // pipeline has consumed them.  (A copy from pageable memory is pinned on the fly and read by the copy engine LATER:
   // arrays freed at commit time while it was still in flight showed up as a sporadic "Memory access fault by GPU" in
   // whatever ran next.)  Normally the upload finished a reader period ago and this returns at once.
-  HIPCHK(hipEventSynchronize(c->up_done));
+  { SlowSpan sp("odr_block_commit: hipEventSynchronize(upload done)"); HIPCHK(hipEventSynchronize(c->up_done)); }
   // the compute stream must not read the new records before the upload pipeline has written them
   HIPCHK(hipStreamWaitEvent(c->stream, c->up_done, 0));
   DevSource &s = c->hw.src[sid];
@@ -2088,8 +2135,15 @@ int odr_scan_status(odr_ctx *c, odr_particles *p, int64_t *n_kept, uint64_t *fla
   if (flags) *flags = 0;
   if (p->n == 0) return 0;
   unsigned nb = nblk(p->n);
-  HIPCHK(hipMemsetAsync(c->counter + 1, 0, 2 * sizeof(unsigned long long), c->stream));
-  hipLaunchKernelGGL(k_cmp_count, dim3(std::min(nb, 2048u)), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount, c->counter + 2, c->counter + 1);
+  if (p->wcount && p->wcount_epoch == p->status_epoch && p->wcount_n == p->n) {
+    // the step launch that ran last counted as it went (StepDesc.wcount; counter[1] zeroed, counter[2] collected by that call)
+    p->wcount_epoch = ~0ull;   // (used once: a second scan accumulates into a counter nobody zeroed)
+    const long long nw = (p->n + 63) / 64;
+    hipLaunchKernelGGL(k_cmp_total, dim3(std::min(nb / BLOCK + 1, 64u)), dim3(BLOCK), 0, c->stream, p->wcount, nw, p->bcount, c->counter + 1);
+  } else {
+    HIPCHK(hipMemsetAsync(c->counter + 1, 0, 2 * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_cmp_count, dim3(std::min(nb, 2048u)), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount, c->counter + 2, c->counter + 1);
+  }
   unsigned long long out[2];
   D2H(out, c->counter + 1, sizeof out);
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -2163,6 +2217,7 @@ int odr_sort_particles_ex(odr_ctx *c, odr_particles *p, int32_t sid, int keep_en
           "source %d is not a gridded source with a resident block", sid);
   HIPCHK(hipSetDevice(c->device));
   if (p->n < 2) return 0;
+  SlowSpan sp_all("odr_sort_particles_ex (whole call)");
   int rc = flush_world(c);
   if (rc) return rc;
   if ((rc = ensure_alt(p))) return rc;

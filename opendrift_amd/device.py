@@ -884,6 +884,9 @@ class Particles:
         return dict(zip(keys, out))
 
 
+_SLOW_MS = float(os.environ.get('ODR_SLOW_CALLS', 0) or 0)
+
+
 def _touching(fn):
     """A call that changes the device state: what a model wrote into its `o.elements` view goes to the device first
     (oceandrift.ElementsView.flush), and views taken before the call become stale."""
@@ -893,6 +896,15 @@ def _touching(fn):
             self._view = None
             v.flush()
         self._touch = self.__dict__.get('_touch', 0) + 1
+        if _SLOW_MS:     # ODR_SLOW_CALLS=<ms>: calls that keep the host longer than that (stderr)
+            import sys
+            import time
+            t0 = time.perf_counter()
+            r = fn(self, *a, **kw)
+            ms = 1e3 * (time.perf_counter() - t0)
+            if ms > _SLOW_MS:
+                print('%s: %.3f ms' % (fn.__name__, ms), file=sys.stderr)
+            return r
         return fn(self, *a, **kw)
     wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
     return wrapper

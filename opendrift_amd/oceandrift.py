@@ -86,7 +86,7 @@ class OpenDriftSimulation(Configurable):
         self.time = self.start_time = self.time_step = None
         self.newly_seeded = 0
         self._newly_any, self._g_active = False, 0
-        self.sort_every = 16
+        self.sort_every = None               # re-sort interval of the device layout in steps (None: chosen in run(); 0: never)
         self._add_config({
             'general:use_auto_landmask': {'type': 'bool', 'default': False, 'level': CONFIG_LEVEL_ADVANCED,
                                           'description': 'GSHHG landmask (not available on the device path)'},
@@ -1161,30 +1161,59 @@ class OpenDriftSimulation(Configurable):
                        not self._host_bindings() and
                        not (any(self.get_config('drift:deactivate_%s_of' % k) is not None for k in ('west', 'east', 'south', 'north'))
                             and self._can_be_missing(list(self.required_variables))))
+        # re-sort interval: what bench.py's bare sequences were tuned to (a re-sort costs ~1.7 step-kernel launches at 10 M
+        # elements; the layout decays with the distance travelled: 3-D current + mixing 24 steps, Leeway 48, the rest 16)
+        sort_every = self.sort_every
+        if sort_every is None:
+            sort_every = 48 if leeway_lane else (24 if fused_lane and 'upward_sea_water_velocity' in self.required_variables else 16)
+        # Variables nothing reads between this step's sample and the next one are not sampled in the fused lane (the sample
+        # of `ocean_vertical_diffusivity` AT the element is only ever exported: the mixing scheme works on the profiles,
+        # oceandrift.py:428-449).  They are sampled when the result buffer holds them and in the last step of the run, so
+        # that `o.environment` and `o.result` come out as the reference's.
+        unread = [v for v in getattr(self, '_export_only_variables', ()) if v in self.required_variables and
+                  v not in self._hist.variables and not self._can_be_missing([v])] if fused_lane else []
+        if any(b.sid is not None and self.ctx._grids.get(b.sid, {}).get('members') for b in self.readers.values()):
+            unread = []      # (ensemble data: the member numbering goes with the main-loop call as the reference makes it)
         self.ctx.sync()
         t_loop = [time.perf_counter(), None]      # main-loop wall time (the reference keeps 'main loop' timers, basemodel :2174)
         # increase_age_and_retire comes after state_to_buffer in the loop: inside the fused launch only when the result
         # buffer does not hold age_seconds (it would see the age one step ahead)
         age_in_launch = 'age_seconds' not in self._hist.variables
+        # host time of the loop body by phase, steps 1.. (the reference keeps `timers` of its main loop, basemodel :2174):
+        # [seconds, longest single step] -- 'status read' is where the host waits for the device
+        phases = {}
+        pc = time.perf_counter
+
+        def lap(name, t_from):
+            t = pc()
+            if i > 0:
+                e = phases.setdefault(name, [0.0, 0.0])
+                e[0] += t - t_from
+                e[1] = max(e[1], t - t_from)
+            return t
         for i in range(steps):
             try:
                 if i == 1:
                     self.ctx.sync()
                     t_loop[1] = time.perf_counter()   # after the first step: seeding, first uploads and sort are behind
+                t_ph = pc()
                 self.release_elements()
                 g_active, g_sched = self._global_counts(i)
+                t_ph = lap('release', t_ph)
                 if g_active == 0 and g_sched > 0:
                     self._state_to_buffer(i, out_every, times)   # (:2208)
                     self.steps_calculation += 1
                     self.time = self.time + self.time_step
                     continue
                 self._ensure_reader_levels(self.time, self.time + self.time_step)
+                t_ph = lap('reader levels', t_ph)
                 # device layout maintenance: re-sort by grid cell every sort_every steps and whenever a
                 # release added a sizeable share of new (unsorted) elements
                 n_act = self.num_elements_active()
-                if self.rng == 'device' and grid_sid is not None and self.sort_every and n_act > 65536 and \
-                        (i % self.sort_every == 0 or self.newly_seeded * 20 > n_act):
+                if self.rng == 'device' and grid_sid is not None and sort_every and n_act > 65536 and \
+                        (i % sort_every == 0 or self.newly_seeded * 20 > n_act):
                     self.P.sort_by_cell(grid_sid, keep_environment=False)   # the step's sample follows
+                t_ph = lap('layout', t_ph)
                 one_collective = False
                 # ensemble data in a sharded run: the stage calls of advect_ocean_current take the member by the rank among
                 # the elements that are STILL active after this step's coastline / seafloor deactivations on ALL ranks --
@@ -1196,7 +1225,7 @@ class OpenDriftSimulation(Configurable):
                     # advect_ocean_current (odr_env_coast_advect).  deactivate_outside only reads positions and goes
                     # first; the result buffer is written afterwards from the saved pre-advection position.
                     self.deactivate_outside()
-                    names = list(self.required_variables)
+                    names = [v for v in self.required_variables if i == steps - 1 or v not in unread]
                     action = self.get_config('general:coastline_action')
                     floor = ('sea_floor_depth_below_sea_level' in self.priority_list and
                              self.get_config('general:seafloor_action', 'lift_to_seafloor') == 'lift_to_seafloor')
@@ -1215,11 +1244,14 @@ class OpenDriftSimulation(Configurable):
                         main_noise=noisy, age_dt=self.time_step.total_seconds() if age_in_launch else 0.0)
                     self._sampled = names
                     self._add_uncertainty(names, current=False)     # the wind's share
+                    t_ph = lap('step launch', t_ph)
                     # ONE host read per step: how many elements stay + which new deactivation reasons occurred
                     kept, flags = self.P.scan_status()
+                    t_ph = lap('status read', t_ph)
+                    all_stay = kept == len(self.P)      # nothing to backfill, nothing to compact on this rank
                     kept, flags = self._step_summary(kept, flags, self._needs_reductions())   # the step's ONE collective
                     self._resolve_status(flags)
-                    self._state_to_buffer(i, out_every, times, from_previous=True)
+                    self._state_to_buffer(i, out_every, times, from_previous=True, all_stay=all_stay)
                     if not age_in_launch:
                         self.P.increase_age(self.time_step.total_seconds())
                     self.P.compact_apply()
@@ -1247,10 +1279,13 @@ class OpenDriftSimulation(Configurable):
                         split='return', count=False,
                         missing_code=self._status_code('missing_data') if self._can_be_missing(names) else 0)
                     self._sampled = names
+                    t_ph = lap('step launch', t_ph)
                     kept, flags = self.P.scan_status()
+                    t_ph = lap('status read', t_ph)
+                    all_stay = kept == len(self.P)
                     kept, flags = self._step_summary(kept, flags, self._needs_reductions())   # the step's ONE collective
                     self._resolve_status(flags)
-                    self._state_to_buffer(i, out_every, times, from_previous=3 if snap else 1)
+                    self._state_to_buffer(i, out_every, times, from_previous=3 if snap else 1, all_stay=all_stay)
                     self.P.increase_age(self.time_step.total_seconds())
                     self.P.compact_apply()
                     # wind, current and land mask from more than one reader: the library sampled, perturbed and applied the
@@ -1299,6 +1334,7 @@ class OpenDriftSimulation(Configurable):
                     self._newly_any = newly
                 else:
                     g_active = self._g_active = self.num_elements_active()
+                t_ph = lap('bookkeeping', t_ph)
                 if g_active > 0:
                     self.update()
                     self._flush_elements()      # what a model's update() wrote into self.elements goes to the device
@@ -1309,6 +1345,7 @@ class OpenDriftSimulation(Configurable):
                 self._step_release()
                 self.time = self.time + self.time_step
                 self.steps_calculation += 1
+                t_ph = lap('update', t_ph)
             except Exception as e:
                 if stop_on_error or self.steps_calculation <= 1:
                     raise
@@ -1322,7 +1359,9 @@ class OpenDriftSimulation(Configurable):
                        # rank 0 of a sharded run: levels its worker thread had read ahead / read inline, and the time the worker spent reading
                        'reader_thread': {k: sum(getattr(getattr(b, '_ahead', None), k, 0) for b in self.readers.values())
                                          for k in ('hits', 'misses', 'worker_s')},
-                       'steady_ms_per_step': (1e3 * (t_end - t_loop[1]) / max(1, self.steps_calculation - 1)) if t_loop[1] else None}
+                       'steady_ms_per_step': (1e3 * (t_end - t_loop[1]) / max(1, self.steps_calculation - 1)) if t_loop[1] else None,
+                       'host_phases_ms_per_step': {k: (round(1e3 * v[0] / max(1, self.steps_calculation - 1), 4), round(1e3 * v[1], 3))
+                                                   for k, v in phases.items()}}
         self.interact_with_coastline(final=True)
         self._resolve_status()
         self._state_to_buffer(self.steps_calculation, out_every, times, final=True)
@@ -1344,7 +1383,8 @@ class OpenDriftSimulation(Configurable):
         self._hist_aux = {name: ('property', list(getattr(self, 'aux_properties', [])).index(name)) for name in aux}
         return elem + aux + env
 
-    def _state_to_buffer(self, step, out_every, times, final=False, from_previous=False):   # :2384-2403, on the device
+    def _state_to_buffer(self, step, out_every, times, final=False, from_previous=False, all_stay=False):   # :2384-2403, on the device
+        # all_stay: the step's status scan found no deactivated element -- between output times there is nothing to record
         k = step // out_every
         if step % out_every == 0:            # output time: every element present
             if k < self._hist.ntimes:
@@ -1352,7 +1392,7 @@ class OpenDriftSimulation(Configurable):
                     self._hist.record(self.P, k, False, self._hist_aux, from_previous)
                 while len(times) <= k:       # result.time is a regular axis (:2088-2090)
                     times.append(self.start_time + len(times) * out_every * self.time_step)
-        elif not final and k + 1 < self._hist.ntimes and len(self.P) > 0:
+        elif not final and not all_stay and k + 1 < self._hist.ntimes and len(self.P) > 0:
             self._hist.record(self.P, k + 1, True, self._hist_aux, from_previous)   # deactivated -> next output time (backfill)
 
 
@@ -1472,6 +1512,9 @@ class _ResultBuffer:
 class OceanDrift(OpenDriftSimulation):
     """opendrift/models/oceandrift.py:54-211"""
     element_properties = {'wind_drift_factor': 0.02, 'current_drift_factor': 1.0, 'terminal_velocity': 0.0}
+    # environment variables whose value AT the element nothing in run() / OceanDrift.update reads (the mixing scheme takes the
+    # diffusivity from the profiles, oceandrift.py:428-449; the element value is only exported): see run(), fused lane
+    _export_only_variables = ('ocean_vertical_diffusivity', )
     required_variables = {
         'x_sea_water_velocity': {'fallback': 0},
         'y_sea_water_velocity': {'fallback': 0},
