@@ -146,15 +146,26 @@ class Workload:
     def time_of(self, k):
         return (k * self.dt) % self.tmax if self.tmax < 1e8 else k * self.dt
 
-    def step(self, P, k):
+    def step(self, P, k, mid=None):
+        """One step of the workload.  mid: called where OceanDrift.run() reads the step's status scan -- behind the step launch,
+        in front of the compaction and the launches of update() (the sharded loop starts its collective there and finishes it
+        behind them; it has made the scan, so the compaction only applies it)."""
         t = self.time_of(k)
+        mid_given = mid is not None
+        compact = P.compact_apply if mid_given else P.compact
+        mid = mid or (lambda: None)
         if self.sort_every and self.name != 'c2' and k % self.sort_every == 0:
             P.sort_by_cell(self.sid, keep_environment=False)   # device layout maintenance, part of the timed step
         if self.name == 'c2':
             P.env_sample([U, V], t)
             P.advect('runge-kutta4', t, self.dt)
         elif self.name == 'c3':
-            if self.fused:   # one call, as OceanDrift.run() makes it: the step launch, then the mixing launch
+            if self.fused and mid_given:   # the two launches as two calls, the status scan between them (OceanDrift.run())
+                P.env_coast_advect(self.vars, t, self.scheme, self.dt, coastline='previous', store_previous=True,
+                                   count=False, seafloor=True, age_dt=self.dt)
+                mid()
+                P.vmix(t, self.dt, self.dt_mix, step=k, fuse_vertical_advection=False)
+            elif self.fused:   # one call: the step launch, then the mixing launch
                 P.env_coast_advect(self.vars, t, self.scheme, self.dt, coastline='previous', store_previous=True,
                                    count=False, seafloor=True, age_dt=self.dt,
                                    vmix=dict(dt_mix=self.dt_mix, step=k, vertical_advection=False))
@@ -164,29 +175,34 @@ class Workload:
                 P.seafloor()
                 P.increase_age(self.dt)
                 P.store_previous()
+                mid()
                 P.advect('runge-kutta4', t, self.dt)
                 P.vmix(t, self.dt, self.dt_mix, step=k, fuse_vertical_advection=False)
         elif self.name == 'c5':   # Leeway ensemble members: Euler by construction (leeway.py:472-476)
             if self.fused:   # ONE launch: sample + drift:current_uncertainty + drift:wind_uncertainty + coastline + Leeway.update
                 P.env_coast_leeway(self.vars, t, self.dt, 0.4, coastline='stranding', stranded_code=1,
                                    current_uncertainty=0.1, wind_uncertainty=2.0, step=k)
-                P.compact()
+                mid()
+                compact()
             else:
                 P.env_sample(self.vars, t)
                 P.env_add_noise(U, V, 0.1, step=k)        # drift:current_uncertainty
                 P.env_add_noise(XW, YW, 2.0, step=k)      # drift:wind_uncertainty
                 P.coastline('stranding', stranded_code=1)
-                P.compact()
+                mid()
+                compact()
                 P.leeway(self.dt, 0.4, step=k)
         else:
             if self.fused:
                 P.env_coast_advect(self.vars, t, 'runge-kutta4', self.dt, coastline='stranding', stranded_code=1,
                                    store_previous=False)
-                P.compact()
+                mid()
+                compact()
             else:
                 P.env_sample(self.vars, t)
                 P.coastline('stranding', stranded_code=1)
-                P.compact()
+                mid()
+                compact()
                 P.advect('runge-kutta4', t, self.dt)
             if os.environ.get('ODR_BENCH_SEPARATE_MOVERS'):    # what-if: the three launches of rounds 1-3
                 P.advect_wind(self.dt, wind_drift_depth=0.1)
@@ -423,13 +439,25 @@ class ShardedLoop:
         self.last = tens
         self._start(j + 1)                     # the next level travels while this one is in use
 
-    def after_step(self, kept, flags=0, raw16=None):
+    def start_summary(self, kept, flags=0, raw16=None):
+        """The step's ONE collective, started where run() has read the status scan (distributed.start_allgather_vector) ..."""
         row = np.concatenate([[float(kept)], [float(flags >> b & 1) for b in range(8)], np.zeros(16) if raw16 is None else raw16])
         t0 = time.perf_counter()
-        rows = self.D.allgather_vector(row)
+        h = self.D.start_allgather_vector(row)
         self.collective_s += time.perf_counter() - t0
         self.collectives += 1
+        return h
+
+    def finish_summary(self, handle):
+        """... and finished behind the launches of the step that do not depend on the other ranks (OceanDrift.run(): update()).
+        collective_s: the host time of both halves -- what the step still waits for the other ranks."""
+        t0 = time.perf_counter()
+        rows = self.D.finish_allgather_vector(handle)
+        self.collective_s += time.perf_counter() - t0
         return int(round(rows[:, 0].sum()))
+
+    def after_step(self, kept, flags=0, raw16=None):
+        return self.finish_summary(self.start_summary(kept, flags, raw16))
 
     def finish(self):
         if self.pending is not None:           # the level started ahead of the loop's end: no collective may stay open
@@ -572,6 +600,16 @@ def main():
             o = np.argsort((iy // 8) * 100000 + (ix // 8) * 64 + (iy % 8) * 8 + ix % 8, kind='stable')
             lon, lat, z = lon[o], lat[o], z[o]
     lo, hi = D.shard_range(n * world, rank, world)     # global particle IDs of this shard
+    n_other = int(os.environ.get('ODR_BENCH_OTHER_RANKS_PARTICLES', 0))
+    if n_other and world > 1:
+        # pricing run on ONE GPU (tools/gpu_sharded_price.sh): rank 0 holds the whole workload, the other ranks a handful of
+        # elements -- the sharded step's machinery (host read, collective, second process) is all there, but the device is not
+        # time-sliced between two full workloads: ms_per_step minus the single-process figure is what the machinery costs
+        if rank > 0:
+            lon, lat, z = lon[:n_other], lat[:n_other], z[:n_other]
+        lo = 0 if rank == 0 else n + (rank - 1) * n_other
+        hi = lo + len(lon)
+        n = len(lon)
     P = ctx.particles(n)
     P.append(lon, lat, z=z, id=np.arange(lo, hi, dtype=np.int32))
     if a.workload == 'c5':   # LeewayObj coefficients of a PIW-like class, perturbed per element (leeway.py:318-372)
@@ -608,9 +646,16 @@ def main():
         for k in range(steps):
             if sharded is not None:
                 sharded.before_step(k)
-                wl.step(P, first + k)
-                kept, flags = P.scan_status()          # the ONE host read of a sharded step (OceanDrift.run())
-                sharded.after_step(kept, flags)
+                if os.environ.get('ODR_BENCH_SYNC_SUMMARY'):      # A/B: rounds 3-4 -- the scan and a blocking collective close the step
+                    wl.step(P, first + k)
+                    sharded.after_step(*P.scan_status())
+                    continue
+                h = []
+                # the ONE host read of a sharded step (the status scan) and its ONE collective, where OceanDrift.run() makes them
+                wl.step(P, first + k, mid=lambda: h.append(sharded.start_summary(*P.scan_status())))
+                if not h:          # (a workload without deactivations: the summary closes the step)
+                    h.append(sharded.start_summary(*P.scan_status()))
+                sharded.finish_summary(h[0])
                 continue
             if block_every and a.workload != 'c2':   # a new reader time level arrives every block_every steps
                 g = fields['g']

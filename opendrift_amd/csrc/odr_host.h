@@ -54,6 +54,7 @@ struct odr_ctx {
   hipStream_t stream, own_stream;
   DevWorld hw;      // host image
   DevWorld *dw;     // device image
+  unsigned long long *scan_host = nullptr;   // page-locked: what odr_scan_status reads (written by k_cmp_total itself)
   // page-locked copies of `hw` the device image is refreshed from (flush_world): three in turn, each guarded by an event
   DevWorld *hw_pin[3] = {nullptr, nullptr, nullptr};
   hipEvent_t hw_ev[3] = {nullptr, nullptr, nullptr};

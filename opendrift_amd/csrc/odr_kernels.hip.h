@@ -2617,17 +2617,19 @@ __global__ __launch_bounds__(BLOCK) void k_cmp_count(const int *status, long lon
   }
 }
 
-// The counts of k_cmp_count from the per-wave counts a step launch left (StepDesc.wcount): bcount[c] = the four waves of chunk c,
-// *total += everything (one atomic per workgroup; zeroed by the step call).
-__global__ __launch_bounds__(BLOCK) void k_cmp_total(const unsigned *__restrict__ wcount, long long nw, unsigned *bcount,
-                                                     unsigned long long *total) {
-  const long long nchunks = (nw + BLOCK / 64 - 1) / (BLOCK / 64);
+// The counts of k_cmp_count from the per-wave counts a step launch left (StepDesc.wcount): bcount[c] = the four waves of chunk c.
+// ONE workgroup; its first thread writes the number of elements that stay and the status flags the step launch collected
+// straight into page-locked host memory (host_out[0], [1]): the host waits for this kernel, not for a copy behind it.
+__global__ __launch_bounds__(1024) void k_cmp_total(const unsigned *__restrict__ wcount, long long nw, unsigned *bcount,
+                                                    const unsigned long long *flags, unsigned long long *host_out) {
+  constexpr int WPC = BLOCK / 64;   // waves per chunk
+  const long long nchunks = (nw + WPC - 1) / WPC;
   unsigned long long mine = 0;
-  for (long long c = (long long)blockIdx.x * BLOCK + threadIdx.x; c < nchunks; c += (long long)gridDim.x * BLOCK) {
+  for (long long c = threadIdx.x; c < nchunks; c += 1024) {
     unsigned cnt = 0;
 #pragma unroll
-    for (int w = 0; w < BLOCK / 64; ++w) {
-      const long long k = c * (BLOCK / 64) + w;
+    for (int w = 0; w < WPC; ++w) {
+      const long long k = c * WPC + w;
       cnt += k < nw ? wcount[k] : 0u;
     }
     bcount[c] = cnt;
@@ -2635,13 +2637,15 @@ __global__ __launch_bounds__(BLOCK) void k_cmp_total(const unsigned *__restrict_
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
-  __shared__ unsigned long long sh[BLOCK / 64];
+  __shared__ unsigned long long sh[16];
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mine;
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned long long t = 0;
-    for (int w = 0; w < BLOCK / 64; ++w) t += sh[w];
-    if (t) atomicAdd(total, t);
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    host_out[0] = t;
+    host_out[1] = *flags;
+    __threadfence_system();
   }
 }
 

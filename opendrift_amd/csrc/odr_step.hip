@@ -268,7 +268,7 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   // counter[0]: elements on land; [1], [2]: the status scan formed by the launch (StepDesc.wcount, below) -- one fill for the three
   const bool count_in_launch = p->wcount && !p->external && !getenv("ODR_NO_STEP_COUNT");
   if (coast_action || count_in_launch)
-    HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long) * (count_in_launch ? 3 : 1), c->stream));
+    HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long) * (count_in_launch ? 4 : 1), c->stream));   // (32 bytes: one fill; 24 were two)
   S.main_noise = main_noise ? 1 : 0;
   S.ssh_slot = -1;
   for (int k = 0; k < G.nv; ++k) if (G.var[k] == VAR_SSH) S.ssh_slot = k;

@@ -38,6 +38,7 @@ int odr_ctx_create(int device, uint64_t seed, odr_ctx **out) {
   HIPCHK(hipMalloc((void **)&c->dw, sizeof(DevWorld)));
   HIPCHK(hipMalloc((void **)&c->red, sizeof(double) * R_N));
   HIPCHK(hipMalloc((void **)&c->counter, sizeof(unsigned long long) * 4));
+  HIPCHK(hipHostMalloc((void **)&c->scan_host, sizeof(unsigned long long) * 2, hipHostMallocDefault));
   HIPCHK(hipMalloc((void **)&c->dilate_flags, sizeof(int) * 16 * NVAR));
   HIPCHK(hipEventCreate(&c->ev0));
   HIPCHK(hipEventCreate(&c->ev1));
@@ -81,6 +82,7 @@ int odr_ctx_destroy(odr_ctx *c) {
   if (c->oil_guide) (void)hipFree(c->oil_guide);
   if (c->noise_buf) (void)hipFree(c->noise_buf);
   (void)hipFree(c->counter);
+  (void)hipHostFree(c->scan_host);
   (void)hipFree(c->dilate_flags);
   if (c->tile_flags) (void)hipFree(c->tile_flags);
   for (int k = 0; k < 2; ++k) if (c->bounce[k]) (void)hipHostFree(c->bounce[k]);
@@ -2139,7 +2141,13 @@ int odr_scan_status(odr_ctx *c, odr_particles *p, int64_t *n_kept, uint64_t *fla
     // the step launch that ran last counted as it went (StepDesc.wcount; counter[1] zeroed, counter[2] collected by that call)
     p->wcount_epoch = ~0ull;   // (used once: a second scan accumulates into a counter nobody zeroed)
     const long long nw = (p->n + 63) / 64;
-    hipLaunchKernelGGL(k_cmp_total, dim3(std::min(nb / BLOCK + 1, 64u)), dim3(BLOCK), 0, c->stream, p->wcount, nw, p->bcount, c->counter + 1);
+    hipLaunchKernelGGL(k_cmp_total, dim3(1), dim3(1024), 0, c->stream, p->wcount, nw, p->bcount, c->counter + 2, c->scan_host);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n_kept) *n_kept = (int64_t)c->scan_host[0];
+    if (flags) *flags = c->scan_host[1];
+    p->scan_kept = (long long)c->scan_host[0];
+    p->scan_epoch = p->status_epoch;
+    return 0;
   } else {
     HIPCHK(hipMemsetAsync(c->counter + 1, 0, 2 * sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(k_cmp_count, dim3(std::min(nb, 2048u)), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount, c->counter + 2, c->counter + 1);

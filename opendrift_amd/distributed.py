@@ -110,6 +110,36 @@ def allgather_vector(values):
     return torch.stack(parts).numpy()
 
 
+def start_allgather_vector(values):
+    """allgather_vector started now and finished later (finish_allgather_vector): the step's collective travels while the
+    device runs the launches that do not depend on it (OceanDrift.run(): the mixing launch of the step).  Returns a handle."""
+    import torch
+    import torch.distributed as dist
+    rank, local_rank, world = env_world()
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    if world == 1 or not dist.is_initialized():
+        return ('done', v[None, :].copy())
+    if dist.get_backend() == 'nccl':
+        dev = torch.device('cuda', local_rank)
+        t = torch.from_numpy(v).to(dev, non_blocking=True)
+        out = torch.empty((world, v.size), dtype=torch.float64, device=dev)
+        return ('nccl', dist.all_gather_into_tensor(out, t, async_op=True), out, t)
+    t = torch.from_numpy(v.copy())
+    parts = [torch.empty_like(t) for _ in range(world)]
+    return ('gloo', dist.all_gather(parts, t, async_op=True), parts, t)
+
+
+def finish_allgather_vector(handle):
+    """The rows of every rank ([world, n]) of a collective begun with start_allgather_vector."""
+    import torch
+    if handle[0] == 'done':
+        return handle[1]
+    handle[1].wait()
+    if handle[0] == 'nccl':
+        return handle[2].cpu().numpy()
+    return torch.stack(handle[2]).numpy()
+
+
 def combine_rows(rows):
     """Rows of raw reduction slots (one per rank) -> the all-rank reductions: COUNT_SLOTS summed, the others maximised."""
     rows = np.asarray(rows, dtype=np.float64)

@@ -615,19 +615,32 @@ class OpenDriftSimulation(Configurable):
         self._g_active = self._g_active_carry = int(g[0])
         return int(g[0]), int(g[1])
 
-    def _step_summary(self, kept, flags, want_reductions):
+    def _step_summary(self, kept, flags, want_reductions, start_only=False, handle=None):
         """The ONE collective of a sharded step: this rank's kept count, provisional status flags and (when a mover of this
         step needs them) its 16 raw reduction slots, all-gathered; returns the all-rank (kept, flags) and installs the
-        all-rank reductions for the movers that follow (released by _step_release at the end of the step)."""
+        all-rank reductions for the movers that follow (released by _step_release at the end of the step).
+        start_only: the collective is started and its handle returned; a second call with `handle` finishes it -- between the
+        two the loop launches what does not depend on the other ranks (the step's update()), so that the collective's latency
+        is spent while the device works (a step whose movers need the all-rank reductions cannot wait that long)."""
         if self._world == 1:
             return kept, flags
         from . import distributed as D
-        wdd, rel = self.get_config('drift:wind_drift_depth', 0.1), bool(self.get_config('drift:relative_wind'))
-        raw = self.P.reduce_local(wdd, rel) if want_reductions else np.zeros(16)
         t0 = time.perf_counter()
-        rows = D.allgather_vector(np.concatenate([[float(kept)], [float(flags >> k & 1) for k in range(8)], raw]))
+        if handle is None:
+            wdd, rel = self.get_config('drift:wind_drift_depth', 0.1), bool(self.get_config('drift:relative_wind'))
+            raw = self.P.reduce_local(wdd, rel) if want_reductions else np.zeros(16)
+            t0 = time.perf_counter()
+            row = np.concatenate([[float(kept)], [float(flags >> k & 1) for k in range(8)], raw])
+            if start_only:
+                h = D.start_allgather_vector(row)
+                self._timing_collective_s += time.perf_counter() - t0
+                self._timing_collectives += 1
+                return h
+            rows = D.allgather_vector(row)
+            self._timing_collectives += 1
+        else:
+            rows = D.finish_allgather_vector(handle)
         self._timing_collective_s += time.perf_counter() - t0
-        self._timing_collectives += 1
         g_kept = int(round(rows[:, 0].sum()))
         g_flags = sum(1 << k for k in range(8) if rows[:, 1 + k].max() > 0)
         if want_reductions:
@@ -645,9 +658,22 @@ class OpenDriftSimulation(Configurable):
     def _needs_reductions(self):
         """Does a mover of this step consult global maxima / counts (advect_wind, stokes_drift, horizontal_diffusion, the
         wind-parameterised mixing)?"""
-        rv = self.required_variables
-        return ('x_wind' in rv or 'sea_surface_wave_stokes_drift_x_velocity' in rv or 'horizontal_diffusivity' in rv or
-                'ocean_mixed_layer_thickness' in rv)
+        rv, iz = self.required_variables, self._identically_zero
+        sx, sy = 'sea_surface_wave_stokes_drift_x_velocity', 'sea_surface_wave_stokes_drift_y_velocity'
+        # a mover whose input no reader delivers and whose fallback is 0 returns early on every rank without looking
+        # (advect_wind, _stokes_arguments, horizontal_diffusion); the analytic diffusivity models take the deepest mixed layer
+        wind = 'x_wind' in rv and not self._calm_everywhere()
+        stokes = sx in rv and self.get_config('drift:stokes_drift') is not False and not (iz(sx) and iz(sy))
+        hdiff = 'horizontal_diffusivity' in rv and not iz('horizontal_diffusivity')
+        mld = 'ocean_mixed_layer_thickness' in rv and self.get_config('drift:vertical_mixing') is True and \
+            self.get_config('vertical_mixing:diffusivitymodel', 'environment') not in ('environment', 'constant')
+        return wind or stokes or hdiff or mld
+
+    def _calm_everywhere(self):
+        """advect_wind returns at its `wind_speed.max() == 0` test (physics_methods.py:771-780) on every rank whatever the
+        elements are: no reader delivers the wind, its fallback is 0 and it is not taken relative to the current."""
+        return self._identically_zero('x_wind') and self._identically_zero('y_wind') and \
+            not self.get_config('drift:relative_wind')
 
     def _global_scan(self, kept, flags):
         if self._world == 1:
@@ -663,11 +689,12 @@ class OpenDriftSimulation(Configurable):
         from . import distributed as D
         return D.combine_reductions
 
-    def _resolve_status(self, flags=None):
+    def _resolve_status(self, flags=None, pending=None):
         """Register the pending reasons that occurred (in the order of the calls that could assign them) and renumber
         their elements.  `flags`: the provisional status numbers present (Particles.scan_status); without it one scan is
         made -- one host read however many reasons are pending, none when nothing is pending."""
-        pending, self._pending_status = self._pending_status, []
+        if pending is None:      # (`pending`: the list taken when a collective that is finished behind update() was started)
+            pending, self._pending_status = self._pending_status, []
         pending = [r for r in pending if r not in self.status_categories]
         if not pending:      # (the pending list is the same on every rank: it follows from the configuration alone)
             return
@@ -731,6 +758,8 @@ class OpenDriftSimulation(Configurable):
         if 'horizontal_diffusivity' not in self.required_variables or \
                 (self._g_active if self._world > 1 else self.num_elements_active()) == 0:
             return
+        if self._world > 1 and self._identically_zero('horizontal_diffusivity'):
+            return      # (`horizontal_diffusivity.max() == 0` on every rank, basemodel/__init__.py:1754)
         dt = self.time_step.total_seconds()
         if self.rng == 'numpy':
             if self.P.reduce_scalars()['D_max'] == 0:
@@ -933,6 +962,8 @@ class OpenDriftSimulation(Configurable):
             self.P.reduce_unpin()
 
     def advect_wind(self, factor=1):
+        if self._world > 1 and self._calm_everywhere():
+            return      # ("No wind drift" / calm on every rank: decided without the all-rank maxima)
         if self._world > 1:
             return self._with_global_reduction(lambda: self.P.advect_wind(
                 self.time_step.total_seconds(), self.get_config('drift:wind_drift_depth', 0.1),
@@ -1214,7 +1245,7 @@ class OpenDriftSimulation(Configurable):
                         (i % sort_every == 0 or self.newly_seeded * 20 > n_act):
                     self.P.sort_by_cell(grid_sid, keep_environment=False)   # the step's sample follows
                 t_ph = lap('layout', t_ph)
-                one_collective = False
+                one_collective, deferred = False, None
                 # ensemble data in a sharded run: the stage calls of advect_ocean_current take the member by the rank among
                 # the elements that are STILL active after this step's coastline / seafloor deactivations on ALL ranks --
                 # known only from the step's collective, which the call-by-call lane makes between the two
@@ -1249,8 +1280,16 @@ class OpenDriftSimulation(Configurable):
                     kept, flags = self.P.scan_status()
                     t_ph = lap('status read', t_ph)
                     all_stay = kept == len(self.P)      # nothing to backfill, nothing to compact on this rank
-                    kept, flags = self._step_summary(kept, flags, self._needs_reductions())   # the step's ONE collective
-                    self._resolve_status(flags)
+                    want_red = self._needs_reductions()
+                    if self._world > 1 and not want_red and flags == 0 and not os.environ.get('ODR_SYNC_COLLECTIVE'):
+                        # sharded: nothing this rank does before the end of update() depends on the other ranks (no mover
+                        # consults all-rank maxima, no element here carries a reason that waits for its category) -- the
+                        # step's ONE collective is started here and finished behind the launches of update()
+                        deferred = (self._step_summary(kept, flags, False, start_only=True), self._pending_status, kept)
+                        self._pending_status = []       # (as _resolve_status leaves it: update() registers its own reasons anew)
+                    else:
+                        kept, flags = self._step_summary(kept, flags, want_red)   # the step's ONE collective
+                        self._resolve_status(flags)
                     self._state_to_buffer(i, out_every, times, from_previous=True, all_stay=all_stay)
                     if not age_in_launch:
                         self.P.increase_age(self.time_step.total_seconds())
@@ -1326,7 +1365,9 @@ class OpenDriftSimulation(Configurable):
                     self.P.store_previous()
                     if hasattr(self, '_store_environment_previous'):
                         self._store_environment_previous()
-                if self._world > 1 and (((fused_lane or leeway_lane) and not ens_sharded) or one_collective):
+                if deferred is not None:
+                    g_active = max(1, deferred[2])      # (decided for good when the collective is finished, below)
+                elif self._world > 1 and (((fused_lane or leeway_lane) and not ens_sharded) or one_collective):
                     g_active = self._g_active           # from this step's collective
                 elif self._world > 1:
                     newly = self._newly_any
@@ -1340,6 +1381,11 @@ class OpenDriftSimulation(Configurable):
                     self._flush_elements()      # what a model's update() wrote into self.elements goes to the device
                 elif g_sched == 0:
                     raise ValueError('No more active or scheduled elements, quitting.')
+                if deferred is not None:
+                    g_kept, g_flags = self._step_summary(None, None, False, handle=deferred[0])
+                    self._resolve_status(g_flags, pending=deferred[1])
+                    if g_kept == 0 and g_sched == 0:
+                        raise ValueError('No more active or scheduled elements, quitting.')
                 self._advected = False
                 self.horizontal_diffusion()
                 self._step_release()

@@ -108,3 +108,48 @@ def test_reduction_combine_and_reader_block_broadcast_gloo_world2():
         assert got[0] == 201.0 and got[11] == 21.0 and got[1] == -4.0 and got[2] == 9.0 and got[7] == 12.5
         assert got[3] == -np.inf
         assert x == [0, 1, 2, 3, 4] and u[3][4] == 19.0
+
+
+def _worker_async_summary(rank, world, port, q):
+    """The step's collective started and finished in two halves, one rank blocking (a rank whose elements carry a new reason
+    waits for the category at once, OceanDrift.run()) and the other finishing it later: same rows on both."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from opendrift_amd import distributed as D
+    D.init(backend='gloo')
+    out = []
+    for step in range(4):
+        row = np.array([100.0 * rank + step, float(rank == 1 and step == 2)] + [0.5 * rank] * 23)
+        if rank == 0 or step % 2:
+            h = D.start_allgather_vector(row)
+            row[:] = -1.0                      # the caller's buffer may change while the collective travels
+            busy = sum(k * k for k in range(20000))   # (what the loop does in between)
+            rows = D.finish_allgather_vector(h)
+        else:
+            rows = D.allgather_vector(row)
+        out.append(rows.tolist())
+    D.barrier()
+    q.put((rank, out))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_step_summary_in_two_halves_gloo_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_async_summary, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0] == res[1]
+    for step in range(4):
+        rows = np.array(res[0][step])
+        assert rows.shape == (2, 25)
+        assert rows[:, 0].tolist() == [float(step), 100.0 + step] and rows[1, 1] == float(step == 2)
+        assert rows[0, 2:].tolist() == [0.0] * 23 and rows[1, 2:].tolist() == [0.5] * 23
