@@ -2623,17 +2623,26 @@ __global__ __launch_bounds__(BLOCK) void k_cmp_count(const int *status, long lon
 __global__ __launch_bounds__(1024) void k_cmp_total(const unsigned *__restrict__ wcount, long long nw, unsigned *bcount,
                                                     const unsigned long long *flags, unsigned long long *host_out) {
   constexpr int WPC = BLOCK / 64;   // waves per chunk
+  static_assert(WPC == 4, "one 16-byte load per chunk");
   const long long nchunks = (nw + WPC - 1) / WPC;
   unsigned long long mine = 0;
-  for (long long c = threadIdx.x; c < nchunks; c += 1024) {
-    unsigned cnt = 0;
+  constexpr int U = 8;              // chunks per thread and pass: eight independent loads in flight (one workgroup: latency is all there is)
+  for (long long c0 = threadIdx.x; c0 < nchunks; c0 += 1024 * U) {
+    uint4 v[U];
 #pragma unroll
-    for (int w = 0; w < WPC; ++w) {
-      const long long k = c * WPC + w;
-      cnt += k < nw ? wcount[k] : 0u;
+    for (int u = 0; u < U; ++u) {
+      const long long c = c0 + 1024 * u;
+      v[u] = c < nchunks ? ((const uint4 *)wcount)[c] : make_uint4(0u, 0u, 0u, 0u);   // (the array is padded to whole chunks)
     }
-    bcount[c] = cnt;
-    mine += cnt;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long c = c0 + 1024 * u;
+      if (c >= nchunks) continue;
+      const long long k = c * WPC;
+      const unsigned cnt = v[u].x + (k + 1 < nw ? v[u].y : 0u) + (k + 2 < nw ? v[u].z : 0u) + (k + 3 < nw ? v[u].w : 0u);
+      bcount[c] = cnt;
+      mine += cnt;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
