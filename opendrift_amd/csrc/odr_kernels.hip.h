@@ -2618,25 +2618,27 @@ __global__ __launch_bounds__(BLOCK) void k_cmp_count(const int *status, long lon
 }
 
 // The counts of k_cmp_count from the per-wave counts a step launch left (StepDesc.wcount): bcount[c] = the four waves of chunk c.
-// ONE workgroup; its first thread writes the number of elements that stay and the status flags the step launch collected
-// straight into page-locked host memory (host_out[0], [1]): the host waits for this kernel, not for a copy behind it.
+// The workgroup that finishes last (ticket counter) writes the number of elements that stay and the status flags the step launch
+// collected straight into page-locked host memory (host_out[0], [1]): the host waits for this kernel, not for a copy behind it.
+// work[0] = running total, work[2] = tickets (both zeroed by the step call; work[1] = the flags).
 __global__ __launch_bounds__(1024) void k_cmp_total(const unsigned *__restrict__ wcount, long long nw, unsigned *bcount,
-                                                    const unsigned long long *flags, unsigned long long *host_out) {
+                                                    unsigned long long *work, unsigned long long *host_out) {
   constexpr int WPC = BLOCK / 64;   // waves per chunk
   static_assert(WPC == 4, "one 16-byte load per chunk");
   const long long nchunks = (nw + WPC - 1) / WPC;
   unsigned long long mine = 0;
-  constexpr int U = 8;              // chunks per thread and pass: eight independent loads in flight (one workgroup: latency is all there is)
-  for (long long c0 = threadIdx.x; c0 < nchunks; c0 += 1024 * U) {
+  constexpr int U = 4;              // chunks per thread and pass: independent loads in flight
+  const long long stride = (long long)gridDim.x * 1024;
+  for (long long c0 = (long long)blockIdx.x * 1024 + threadIdx.x; c0 < nchunks; c0 += stride * U) {
     uint4 v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long long c = c0 + 1024 * u;
+      const long long c = c0 + stride * u;
       v[u] = c < nchunks ? ((const uint4 *)wcount)[c] : make_uint4(0u, 0u, 0u, 0u);   // (the array is padded to whole chunks)
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long long c = c0 + 1024 * u;
+      const long long c = c0 + stride * u;
       if (c >= nchunks) continue;
       const long long k = c * WPC;
       const unsigned cnt = v[u].x + (k + 1 < nw ? v[u].y : 0u) + (k + 2 < nw ? v[u].z : 0u) + (k + 3 < nw ? v[u].w : 0u);
@@ -2652,9 +2654,13 @@ __global__ __launch_bounds__(1024) void k_cmp_total(const unsigned *__restrict__
   if (threadIdx.x == 0) {
     unsigned long long t = 0;
     for (int w = 0; w < 16; ++w) t += sh[w];
-    host_out[0] = t;
-    host_out[1] = *flags;
-    __threadfence_system();
+    if (t) atomicAdd(&work[0], t);
+    __threadfence();
+    if (atomicAdd(&work[2], 1ull) == (unsigned long long)gridDim.x - 1) {   // every other workgroup's sum is in
+      host_out[0] = atomicAdd(&work[0], 0ull);
+      host_out[1] = work[1];
+      __threadfence_system();
+    }
   }
 }
 

@@ -2141,7 +2141,8 @@ int odr_scan_status(odr_ctx *c, odr_particles *p, int64_t *n_kept, uint64_t *fla
     // the step launch that ran last counted as it went (StepDesc.wcount; counter[1] zeroed, counter[2] collected by that call)
     p->wcount_epoch = ~0ull;   // (used once: a second scan accumulates into a counter nobody zeroed)
     const long long nw = (p->n + 63) / 64;
-    hipLaunchKernelGGL(k_cmp_total, dim3(1), dim3(1024), 0, c->stream, p->wcount, nw, p->bcount, c->counter + 2, c->scan_host);
+    const unsigned wgs = (unsigned)std::min<long long>(16, ((nw + 3) / 4 + 4095) / 4096);   // (4 chunks per thread and pass)
+    hipLaunchKernelGGL(k_cmp_total, dim3(wgs ? wgs : 1), dim3(1024), 0, c->stream, p->wcount, nw, p->bcount, c->counter + 1, c->scan_host);
     HIPCHK(hipStreamSynchronize(c->stream));
     if (n_kept) *n_kept = (int64_t)c->scan_host[0];
     if (flags) *flags = c->scan_host[1];
