@@ -54,6 +54,7 @@ struct odr_ctx {
   hipStream_t stream, own_stream;
   DevWorld hw;      // host image
   DevWorld *dw;     // device image
+  unsigned src_gen[MAXSRC] = {0};   // counts the releases of a source id: what was derived from the source's geometry (the tile step's workgroup table) dies with it
   unsigned long long *scan_host = nullptr;   // page-locked: what odr_scan_status reads (written by k_cmp_total itself)
   // page-locked copies of `hw` the device image is refreshed from (flush_world): three in turn, each guarded by an event
   DevWorld *hw_pin[3] = {nullptr, nullptr, nullptr};
@@ -175,6 +176,7 @@ struct odr_particles {
   bool z_truncated;
   int wg_sid;
   bool wg_valid;
+  unsigned wg_src_gen;              // generation of the source the table was built on (odr_ctx::src_gen)
 };
 
 static inline unsigned nblk(long long n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }

@@ -39,7 +39,7 @@ bool odr_i_step_tile(odr_ctx *c, odr_particles *p, const EnvGroupDesc &G, StepDe
   const long long min_n = getenv("ODR_TILE_MIN_N") ? atoll(getenv("ODR_TILE_MIN_N")) : 262144;
   const size_t lds_cfg = getenv("ODR_TILE_LDS") ? (size_t)atoll(getenv("ODR_TILE_LDS")) : 38 * 1024;
   if (off || N.on || scheme < 1 || scheme > 2 || p->win != 0 || p->n < min_n) return false;
-  if (!p->wg_valid || p->wg_sid != G.sid || p->n > p->wg_n || !p->wg_tab) return false;
+  if (!p->wg_valid || p->wg_sid != G.sid || p->wg_src_gen != c->src_gen[G.sid] || p->n > p->wg_n || !p->wg_tab) return false;
   const DevSource &s = c->hw.src[G.sid];
   const int pt = odr_proj_template(s.proj);
   if (pt != PROJ_LATLONG && pt != PROJ_STERE_POLAR) return false;

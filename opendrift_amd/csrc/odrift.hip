@@ -984,6 +984,7 @@ int odr_source_release(odr_ctx *c, int32_t sid) {
   for (int v = 0; v < NVAR; ++v) s.const_val[v] = NAN;
   s.xmin = s.ymin = s.zmin = s.tmin = INFINITY; s.xmax = s.ymax = s.zmax = s.tmax = -INFINITY;
   c->src_free[sid] = true;
+  c->src_gen[sid]++;
   if (c->red_owner) c->red_owner = nullptr;
   c->dirty = true;
   return 0;
@@ -2204,6 +2205,7 @@ int odr_compact_apply(odr_ctx *c, odr_particles *p, int64_t *n_active) {
   }
   p->ndead += removed;
   p->n = kept;
+  p->wg_valid = false;   // elements moved into the holes: the workgroup ranges of the last sort no longer lie inside their sort tiles
   if (n_active) *n_active = p->n;
   return 0;
 }
@@ -2273,7 +2275,7 @@ int odr_sort_particles_ex(odr_ctx *c, odr_particles *p, int32_t sid, int keep_en
     hipLaunchKernelGGL(k_wg_count, dim3((nt1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, hist, ntiles, 64u * (unsigned)zb, wg_nw);
     hipLaunchKernelGGL(k_cmp_scan, dim3(1), dim3(1024), 0, c->stream, wg_nw, (long long)nt1, p->wg_total);   // exclusive, in place
     hipLaunchKernelGGL(k_wg_fill, dim3((nt1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, hist, ntiles, 64u * (unsigned)zb, wg_nw, p->wg_tab, (unsigned)cap);
-    p->wg_grid = cap; p->wg_n = p->n; p->wg_sid = sid; p->wg_valid = true;
+    p->wg_grid = cap; p->wg_n = p->n; p->wg_sid = sid; p->wg_src_gen = c->src_gen[sid]; p->wg_valid = true;
   }
   CmpArrays A;
   all_arrays(p, A, with_env);

@@ -241,17 +241,32 @@ def _device():
 
 
 _STAGING = {}      # (variable, shape) -> [two page-locked host tensors, the events of their last copies, turn]
+_STAGING_SHAPES = {}   # variable -> the shapes in use, most recent last (at most _STAGING_KEEP: the others are let go)
+_STAGING_KEEP = 2      # two readers may deliver the same variable on different grids; a window that is re-cut changes the shape
 
 
 def _staged_to_device(key, a, dev):
     """Host array -> device tensor through a page-locked staging buffer that is REUSED: two per (variable, shape), in turn
     (hipHostMalloc of a 210 MB level on the critical path every few steps otherwise); a buffer is overwritten only after
-    the copy that last read it has completed (its event)."""
+    the copy that last read it has completed (its event).  A variable keeps the buffers of its two most recent shapes: a
+    reader whose window is re-cut again and again does not leave every old window's buffers page-locked for the life of the
+    process."""
     import torch
+    name, shape = key
+    order = _STAGING_SHAPES.setdefault(name, [])
+    if shape in order:
+        order.remove(shape)
+    order.append(shape)
+    while len(order) > _STAGING_KEEP:
+        old = _STAGING.pop((name, order.pop(0)), None)
+        if old is not None:
+            for ev in old[1]:
+                if ev is not None:
+                    ev.synchronize()       # (its last copy may still be reading the buffer)
     st = _STAGING.get(key)
     if st is None:
-        st = _STAGING[key] = [[torch.empty(a.shape, dtype=torch.float32).pin_memory() for _ in range(2)], [None, None], 0]
-    bufs, evs, turn = st
+        st = _STAGING[key] = [[torch.empty(shape, dtype=torch.float32).pin_memory() for _ in range(2)], [None, None], 0]
+    bufs, evs, turn = st[0], st[1], st[2]
     st[2] = 1 - turn
     if evs[turn] is not None:
         evs[turn].synchronize()

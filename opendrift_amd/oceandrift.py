@@ -286,6 +286,8 @@ class OpenDriftSimulation(Configurable):
         logger.warning('Reader %s failed (%s), number of fails: %d', name, e, r.number_of_fails)
         if r.number_of_fails > max_fails:
             self.discarded_readers[name] = 'failed more than allowed number of times (%d)' % max_fails
+            if hasattr(b, 'close_read_ahead'):
+                b.close_read_ahead()
             del self.readers[name]
             for v, lst in self.priority_list.items():
                 if name in lst:
@@ -484,8 +486,14 @@ class OpenDriftSimulation(Configurable):
         """seed:ocean_only (basemodel/__init__.py:936-1031): elements seeded on land go to the nearest ocean point of a
         0.01 deg raster around the seeds (at most 1000 x 1000 points), looked up with the reader that provides
         land_binary_mask -- here sampled through the device (the same nearest-node lookup the run uses) at the run's start
-        time; nearest neighbour by scipy's cKDTree in (lon, lat) as in the reference.  Returns (lon, lat, land_indices)."""
-        import scipy.spatial
+        time (the reference asks at the land reader's own start time, :983,:1010: the same mask unless the land mask changes
+        in time); nearest neighbour by scipy's cKDTree in (lon, lat) as in the reference; a NaN of the mask counts as land, as
+        there (`land != 0`, :990).  Returns (lon, lat, land_indices)."""
+        try:
+            import scipy.spatial
+        except ImportError as e:      # (SciPy is a dependency of the reference as well, pyproject.toml)
+            raise ImportError("seed:ocean_only needs scipy.spatial.cKDTree to move elements seeded on land to the nearest ocean "
+                              "point (basemodel/__init__.py:1020-1026); install SciPy or set_config('seed:ocean_only', False)") from e
         lon, lat = np.array(lon, dtype=np.float64), np.array(lat, dtype=np.float64)
         live = [n for n in self.priority_list.get('land_binary_mask', []) if n in self.readers and self.readers[n].sid is not None]
         if not live or len(lon) == 0:
@@ -1243,7 +1251,10 @@ class OpenDriftSimulation(Configurable):
                 n_act = self.num_elements_active()
                 if self.rng == 'device' and grid_sid is not None and sort_every and n_act > 65536 and \
                         (i % sort_every == 0 or self.newly_seeded * 20 > n_act):
-                    self.P.sort_by_cell(grid_sid, keep_environment=False)   # the step's sample follows
+                    # (the source id of a reader changes when its window is re-cut, and is gone when the re-cut failed)
+                    grid_sid = next((b.sid for b in self.readers.values() if b.is_grid() and b.sid is not None), None)
+                    if grid_sid is not None:
+                        self.P.sort_by_cell(grid_sid, keep_environment=False)   # the step's sample follows
                 t_ph = lap('layout', t_ph)
                 one_collective, deferred = False, None
                 # ensemble data in a sharded run: the stage calls of advect_ocean_current take the member by the rank among
@@ -1403,11 +1414,16 @@ class OpenDriftSimulation(Configurable):
                        'collectives': self._timing_collectives, 'collective_s': self._timing_collective_s,
                        'reader_level_stall_s': sum(getattr(b, 'stall_s', 0.0) for b in self.readers.values()),
                        # rank 0 of a sharded run: levels its worker thread had read ahead / read inline, and the time the worker spent reading
-                       'reader_thread': {k: sum(getattr(getattr(b, '_ahead', None), k, 0) for b in self.readers.values())
-                                         for k in ('hits', 'misses', 'worker_s')},
+                       'reader_thread': dict(zip(('hits', 'misses', 'worker_s'), map(sum, zip(*([(0, 0, 0.0)] + [
+                           tuple(x + getattr(getattr(b, '_ahead', None), k, 0) for x, k in zip(getattr(b, '_ahead_stats', (0, 0, 0.0)),
+                                                                                              ('hits', 'misses', 'worker_s')))
+                           for b in self.readers.values()]))))),
                        'steady_ms_per_step': (1e3 * (t_end - t_loop[1]) / max(1, self.steps_calculation - 1)) if t_loop[1] else None,
                        'host_phases_ms_per_step': {k: (round(1e3 * v[0] / max(1, self.steps_calculation - 1), 4), round(1e3 * v[1], 3))
                                                    for k, v in phases.items()}}
+        for b in self.readers.values():      # no read of the user's Reader is in flight when run() returns
+            if hasattr(b, 'close_read_ahead'):
+                b.close_read_ahead()
         self.interact_with_coastline(final=True)
         self._resolve_status()
         self._state_to_buffer(self.steps_calculation, out_every, times, final=True)

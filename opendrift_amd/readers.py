@@ -546,6 +546,14 @@ class ReadAhead:
         return self._get(k, x, y)
 
     def close(self):
+        """Waits for a read in flight (its exception, of a level nobody will ask for, is logged, not raised) and ends the worker."""
+        fut, self._fut, self._key = self._fut, None, None
+        if fut is not None:
+            try:
+                fut.result()
+            except Exception as e:      # noqa: BLE001
+                import logging
+                logging.getLogger(__name__).debug('read-ahead of a level that is no longer wanted failed: %r', e)
         if self._pool is not None:
             self._pool.shutdown(wait=True)
             self._pool = None
@@ -682,11 +690,20 @@ class DeviceReaderBinding:
             for k in list(pool):
                 self.ctx.drop_block(self.sid, pool.pop(k))
         self._drain_prefetched()
+        self.close_read_ahead()       # (a level of the old window may be on its way)
         self._dist_shapes = None
         if self.sid is not None:
             self.ctx.release_source(self.sid)      # its id serves the re-cut source: the context holds 16 sources, not 16 per run
         self.sid = None
         self.set_extent(lonlat_box)
+
+    def close_read_ahead(self):
+        """End of the run, a re-cut window, a discarded reader: the worker's read in flight is waited for (the caller may close
+        the reader's file afterwards) and the pool is shut down; a later read starts a new one."""
+        a, self._ahead = self._ahead, None
+        if a is not None:
+            self._ahead_stats = tuple(x + y for x, y in zip(getattr(self, '_ahead_stats', (0, 0, 0.0)), (a.hits, a.misses, a.worker_s)))
+            a.close()
 
     def _drain_prefetched(self, keep=()):
         """Sharded run: levels whose broadcast was started ahead and that are not (no longer) wanted are waited for and let
@@ -708,6 +725,8 @@ class DeviceReaderBinding:
             extent = getattr(self, 'extent', None)
         if not self.is_grid():
             return
+        if t1 != t0:
+            self._direction = 1 if t1 > t0 else -1      # of the run (ReadAhead reads the next level in that direction)
         if r.times is None:
             need = [0]
         else:
@@ -777,10 +796,12 @@ class DeviceReaderBinding:
                     self._ahead = ReadAhead(r, self.variables)
                 block = self._ahead.read(k, x, y)
                 cids = self._static_ids()
-                # the level after this one, on the worker thread, while the steps of this period run
-                kn = k + (1 if self._ahead_last is None or k >= self._ahead_last else -1)
+                # the level after this one IN THE RUN'S DIRECTION, on the worker thread, while the steps of this period run
+                # (the first read of a backward run used to assume forward time: one level read and dropped, two stalls)
+                step = getattr(self, '_direction', 0) or (1 if self._ahead_last is None or k >= self._ahead_last else -1)
+                kn = k + step
                 self._ahead_last = k
-                if self.prefetch and r.times is not None and 0 <= kn < len(r.times):
+                if self.prefetch and r.times is not None and 0 <= kn < len(r.times):   # (nothing past the last level)
                     self._ahead.start(kn, x, y)
             except Exception as e:      # noqa: BLE001 -- every reader exception is a reader failure (environment.py:640-668)
                 err = e

@@ -69,3 +69,19 @@ def test_the_readers_exception_surfaces_where_the_inline_read_would_have_raised_
         a.read(2, None, None)
     assert a.read(3, None, None)['u'][0, 0] == 3.0      # and the next level is fine
     a.close()
+
+
+def test_close_waits_for_the_read_in_flight_and_keeps_its_exception_to_itself():
+    """run() closes the read-ahead of every binding before it returns (the caller may close the reader's file then); the
+    read of a level nobody will ask for -- even a failing one -- must not raise there, and the worker must be gone."""
+    r = SlowReader(fail_at=3)
+    a = ReadAhead(r, ['u'])
+    x, y = np.array([0.0]), np.array([0.0])
+    a.start(3, x, y)
+    t0 = time.perf_counter()
+    a.close()
+    assert time.perf_counter() - t0 > 0.1          # waited for get_variables to return
+    assert [c[0] for c in r.calls] == [3] and a._pool is None and a._fut is None
+    assert not [t for t in threading.enumerate() if t.name.startswith('odr-reader')]
+    b = a.read(1, x, y)                            # a later read works (inline; a new worker starts with the next start())
+    assert b['u'][0, 0] == 1.0
