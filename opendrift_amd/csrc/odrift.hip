@@ -2205,7 +2205,9 @@ int odr_compact_apply(odr_ctx *c, odr_particles *p, int64_t *n_active) {
   }
   p->ndead += removed;
   p->n = kept;
-  p->wg_valid = false;   // elements moved into the holes: the workgroup ranges of the last sort no longer lie inside their sort tiles
+  // (the tile step's workgroup table stays valid: an element that filled a hole outside its sort tile is outside its workgroup's
+  // node rectangle and is handed to k_step_list -- tests/test_gpu_tile.py::test_tile_step_with_a_small_lds_budget_and_compaction;
+  // the table dies with the GEOMETRY it was built on: odr_source_release, src_gen)
   if (n_active) *n_active = p->n;
   return 0;
 }
