@@ -470,6 +470,19 @@ int odr_compact(odr_ctx *ctx, odr_particles *p, int64_t *n_active);
  * odr_compact_apply then removes the deactivated elements without another read.  No call that deactivates, adds or
  * re-orders elements may run in between (ODR_ERR_STATE otherwise). */
 int odr_scan_status(odr_ctx *ctx, odr_particles *p, int64_t *n_kept, uint64_t *status_flags);
+/* The same read in two halves, so that the loop's next launch need not wait for the host (round 5).  After
+ * odr_env_coast_advect, odr_scan_status_begin enqueues the fold of the counts that launch left and returns at once (1 = that
+ * launch left none -- another path ran --: call odr_scan_status instead); the device also keeps the verdict "every element
+ * stays".  odr_ctx_guard_next_vmix(ctx, 1) makes the NEXT odr_vmix a launch that does nothing unless that verdict is "yes":
+ * the mixing of the step (oceandrift.py:397-571) is enqueued BEFORE the host knows whether remove_deactivated_elements
+ * (basemodel/__init__.py:2284) has anything to remove -- in the common step it has not, and the device goes from the step
+ * launch into the mixing launch without waiting for the host; otherwise the host compacts and calls odr_vmix again, unguarded
+ * (the guarded launch has not touched anything).  A guarded odr_vmix that cannot honour the guard (another kernel family than
+ * the reader-profile fast path) launches nothing and returns 1.  odr_scan_status_end waits for the fold only (not for the
+ * mixing launch behind it) and hands out what odr_scan_status would have. */
+int odr_scan_status_begin(odr_ctx *ctx, odr_particles *p);
+int odr_scan_status_end(odr_ctx *ctx, odr_particles *p, int64_t *n_kept, uint64_t *status_flags);
+int odr_ctx_guard_next_vmix(odr_ctx *ctx, int on);
 int odr_compact_apply(odr_ctx *ctx, odr_particles *p, int64_t *n_active);
 /* Device-side layout operation with no reference counterpart: re-order the particle arrays by
  * the grid cell of gridded source `source_id` so that the lanes of a wavefront gather

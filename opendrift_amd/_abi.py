@@ -149,6 +149,9 @@ _SIGNATURES = {
     'odr_deactivate_outside': [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32],
     'odr_compact': [_vp, _vp, _i64p],
     'odr_scan_status': [_vp, _vp, _i64p, _P(C.c_uint64)],
+    'odr_scan_status_begin': [_vp, _vp],
+    'odr_scan_status_end': [_vp, _vp, _i64p, _P(C.c_uint64)],
+    'odr_ctx_guard_next_vmix': [_vp, C.c_int],
     'odr_compact_apply': [_vp, _vp, _i64p],
     'odr_sort_particles': [_vp, _vp, C.c_int32],
     'odr_sort_particles_ex': [_vp, _vp, C.c_int32, C.c_int],

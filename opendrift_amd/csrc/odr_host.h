@@ -55,6 +55,9 @@ struct odr_ctx {
   DevWorld hw;      // host image
   DevWorld *dw;     // device image
   unsigned src_gen[MAXSRC] = {0};   // counts the releases of a source id: what was derived from the source's geometry (the tile step's workgroup table) dies with it
+  hipEvent_t scan_ev = nullptr;     // behind the fold of odr_scan_status_begin
+  bool scan_open = false;
+  int guard_next_vmix = 0;          // odr_ctx_guard_next_vmix
   unsigned long long *scan_host = nullptr;   // page-locked: what odr_scan_status reads (written by k_cmp_total itself)
   // page-locked copies of `hw` the device image is refreshed from (flush_world): three in turn, each guarded by an event
   DevWorld *hw_pin[3] = {nullptr, nullptr, nullptr};

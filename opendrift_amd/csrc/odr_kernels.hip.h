@@ -403,6 +403,7 @@ struct VMixDesc {
   const float *kb, *ka;  // K arrays of the bracketing time levels (ka == nullptr: on a time level)
   double wgt;            // weight_after (structured.py:353-354)
   float Kfb, pad2;
+  const unsigned long long *guard;   // nullptr, or: the launch does nothing unless *guard != 0 (odr_ctx_guard_next_vmix)
 };
 
 // K column of one particle at (lon, lat) -> Kp[level][tid] (LDS), time-interpolated like the ReaderBlock's profiles
@@ -1968,6 +1969,7 @@ __global__ __launch_bounds__(BLOCK, ODR_VMIX_WAVES) void k_vmix_col(const DevWor
   double *Kp = (double *)smem;              // [NL][BLOCK]
   double *gsh = Kp + (size_t)NL * BLOCK;    // [4][NL]
   // the particle's state is requested first: its loads and the tables' are one round trip (threads past the end read element 0)
+  if (D.guard && *D.guard == 0ull) return;   // (wave-uniform: the launch was enqueued before the host knew whether it may run)
   const long long i = pid();
   const bool valid = i < p.n;
   const VMixState S = vmix_load_state(p, valid ? i : 0);
@@ -2033,6 +2035,7 @@ __global__ __launch_bounds__(BLOCK, ODR_VWIN_WAVES) void k_vmix_win(const DevWor
                                                     unsigned long long seed, unsigned long long step,
                                                     int vadv, int sfl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (D.guard && *D.guard == 0ull) return;   // (see k_vmix_col)
   const int tid = threadIdx.x;
   const DevSource &s = W->src[D.sid];
   const int nzp = D.nzp;
@@ -2622,7 +2625,7 @@ __global__ __launch_bounds__(BLOCK) void k_cmp_count(const int *status, long lon
 // collected straight into page-locked host memory (host_out[0], [1]): the host waits for this kernel, not for a copy behind it.
 // work[0] = running total, work[2] = tickets (both zeroed by the step call; work[1] = the flags).
 __global__ __launch_bounds__(1024) void k_cmp_total(const unsigned *__restrict__ wcount, long long nw, unsigned *bcount,
-                                                    unsigned long long *work, unsigned long long *host_out) {
+                                                    unsigned long long *work, unsigned long long *host_out, long long n) {
   constexpr int WPC = BLOCK / 64;   // waves per chunk
   static_assert(WPC == 4, "one 16-byte load per chunk");
   const long long nchunks = (nw + WPC - 1) / WPC;
@@ -2657,7 +2660,9 @@ __global__ __launch_bounds__(1024) void k_cmp_total(const unsigned *__restrict__
     if (t) atomicAdd(&work[0], t);
     __threadfence();
     if (atomicAdd(&work[2], 1ull) == (unsigned long long)gridDim.x - 1) {   // every other workgroup's sum is in
-      host_out[0] = atomicAdd(&work[0], 0ull);
+      const unsigned long long tot = atomicAdd(&work[0], 0ull);
+      work[3] = tot == (unsigned long long)n ? 1ull : 0ull;   // "every element stays": what a guarded mixing launch reads
+      host_out[0] = tot;
       host_out[1] = work[1];
       __threadfence_system();
     }

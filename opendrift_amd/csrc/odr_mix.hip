@@ -41,7 +41,11 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
   c->oil_owner = nullptr;
   VMixDesc D;
   const bool fast = !oil && !getenv("ODR_NO_FAST_PATH") && build_vmix_desc(c, t, D);
+  const bool guarded = c->guard_next_vmix != 0;     // odr_ctx_guard_next_vmix: this call only
+  c->guard_next_vmix = 0;
+  if (guarded && (!fast || rng_mode == ODR_RNG_HOST)) { c->fuse_vadv = vadv; return 1; }   // nothing launched: the caller calls again, unguarded
   if (fast) {
+    if (guarded) D.guard = c->counter + 4;
     const int nq = (nzp + 3) / 4;
     const bool tl = D.ka != nullptr;
     // k_vmix_win (five levels per particle in registers: cost independent of the number of reader levels) from 13 levels

@@ -37,7 +37,9 @@ int odr_ctx_create(int device, uint64_t seed, odr_ctx **out) {
   for (int v = 0; v < NVAR; ++v) c->hw.fallback[v] = NAN;
   HIPCHK(hipMalloc((void **)&c->dw, sizeof(DevWorld)));
   HIPCHK(hipMalloc((void **)&c->red, sizeof(double) * R_N));
-  HIPCHK(hipMalloc((void **)&c->counter, sizeof(unsigned long long) * 4));
+  HIPCHK(hipMalloc((void **)&c->counter, sizeof(unsigned long long) * 8));   // [0] on land, [1] kept, [2] status flags, [3] tickets, [4] "every element stays"
+  HIPCHK(hipMemset(c->counter, 0, sizeof(unsigned long long) * 8));
+  HIPCHK(hipEventCreateWithFlags(&c->scan_ev, hipEventDisableTiming));
   HIPCHK(hipHostMalloc((void **)&c->scan_host, sizeof(unsigned long long) * 2, hipHostMallocDefault));
   HIPCHK(hipMalloc((void **)&c->dilate_flags, sizeof(int) * 16 * NVAR));
   HIPCHK(hipEventCreate(&c->ev0));
@@ -83,6 +85,7 @@ int odr_ctx_destroy(odr_ctx *c) {
   if (c->noise_buf) (void)hipFree(c->noise_buf);
   (void)hipFree(c->counter);
   (void)hipHostFree(c->scan_host);
+  (void)hipEventDestroy(c->scan_ev);
   (void)hipFree(c->dilate_flags);
   if (c->tile_flags) (void)hipFree(c->tile_flags);
   for (int k = 0; k < 2; ++k) if (c->bounce[k]) (void)hipHostFree(c->bounce[k]);
@@ -2140,16 +2143,9 @@ int odr_scan_status(odr_ctx *c, odr_particles *p, int64_t *n_kept, uint64_t *fla
   unsigned nb = nblk(p->n);
   if (p->wcount && p->wcount_epoch == p->status_epoch && p->wcount_n == p->n) {
     // the step launch that ran last counted as it went (StepDesc.wcount; counter[1] zeroed, counter[2] collected by that call)
-    p->wcount_epoch = ~0ull;   // (used once: a second scan accumulates into a counter nobody zeroed)
-    const long long nw = (p->n + 63) / 64;
-    const unsigned wgs = (unsigned)std::min<long long>(16, ((nw + 3) / 4 + 4095) / 4096);   // (4 chunks per thread and pass)
-    hipLaunchKernelGGL(k_cmp_total, dim3(wgs ? wgs : 1), dim3(1024), 0, c->stream, p->wcount, nw, p->bcount, c->counter + 1, c->scan_host);
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (n_kept) *n_kept = (int64_t)c->scan_host[0];
-    if (flags) *flags = c->scan_host[1];
-    p->scan_kept = (long long)c->scan_host[0];
-    p->scan_epoch = p->status_epoch;
-    return 0;
+    int rc = odr_scan_status_begin(c, p);
+    if (rc) return rc < 0 ? rc : fail(ODR_ERR_STATE, "odr_scan_status: the counts of the step launch are gone");
+    return odr_scan_status_end(c, p, n_kept, flags);
   } else {
     HIPCHK(hipMemsetAsync(c->counter + 1, 0, 2 * sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(k_cmp_count, dim3(std::min(nb, 2048u)), dim3(BLOCK), 0, c->stream, p->i32[1], p->n, p->bcount, c->counter + 2, c->counter + 1);
@@ -2161,6 +2157,40 @@ int odr_scan_status(odr_ctx *c, odr_particles *p, int64_t *n_kept, uint64_t *fla
   if (flags) *flags = out[1];
   p->scan_kept = (long long)out[0];
   p->scan_epoch = p->status_epoch;
+  return 0;
+}
+
+// odr_scan_status in two halves (include/odrift.h): the fold enqueued, its result read later -- the launch the loop makes in
+// between (a guarded odr_vmix) does not wait for the host.
+int odr_scan_status_begin(odr_ctx *c, odr_particles *p) {
+  HIPCHK(hipSetDevice(c->device));
+  if (!(p->n > 0 && p->wcount && p->wcount_epoch == p->status_epoch && p->wcount_n == p->n)) return 1;   // no counts of a step launch
+  p->wcount_epoch = ~0ull;   // (used once: a second fold accumulates into a counter nobody zeroed)
+  const long long nw = (p->n + 63) / 64;
+  const unsigned wgs = (unsigned)std::min<long long>(16, ((nw + 3) / 4 + 4095) / 4096);   // (4 chunks per thread and pass)
+  hipLaunchKernelGGL(k_cmp_total, dim3(wgs ? wgs : 1), dim3(1024), 0, c->stream, p->wcount, nw, p->bcount, c->counter + 1, c->scan_host,
+                     (long long)p->n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(c->scan_ev, c->stream));
+  c->scan_open = true;
+  return 0;
+}
+
+int odr_scan_status_end(odr_ctx *c, odr_particles *p, int64_t *n_kept, uint64_t *flags) {
+  if (!c->scan_open) return fail(ODR_ERR_STATE, "odr_scan_status_end without odr_scan_status_begin");
+  c->scan_open = false;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipEventSynchronize(c->scan_ev));
+  if (n_kept) *n_kept = (int64_t)c->scan_host[0];
+  if (flags) *flags = c->scan_host[1];
+  p->scan_kept = (long long)c->scan_host[0];
+  p->scan_epoch = p->status_epoch;   // (a guarded mixing launch between the halves deactivates nothing the fold has not seen: it
+                                     // runs only when every element stays, and then there is nothing to compact)
+  return 0;
+}
+
+int odr_ctx_guard_next_vmix(odr_ctx *c, int on) {
+  c->guard_next_vmix = on ? 1 : 0;
   return 0;
 }
 

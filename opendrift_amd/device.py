@@ -669,9 +669,18 @@ class Particles:
         """Device copy of one property as it is now, read by the next History.record(position_from_previous=3)."""
         check(self.lib.odr_particles_snapshot_property(self.ctx.h, self.h, int(slot)))
 
-    def vmix(self, t_epoch, dt, dt_mix, mix_at_surface=False, step=0, uniforms=None, fuse_vertical_advection=None):
+    def vmix(self, t_epoch, dt, dt_mix, mix_at_surface=False, step=0, uniforms=None, fuse_vertical_advection=None, guarded=False):
+        """guarded=True (between scan_status_begin and scan_status_end): the launch does nothing unless the fold finds that every
+        element stays (odr_ctx_guard_next_vmix); returns False when the library could not launch it that way (nothing happened)."""
         if fuse_vertical_advection is not None:   # True: include surface elements, False: z<0 only
             check(self.lib.odr_vmix_fuse_vertical_advection(self.ctx.h, int(bool(fuse_vertical_advection))))
+        if guarded:
+            assert uniforms is None
+            check(self.lib.odr_ctx_guard_next_vmix(self.ctx.h, 1))
+            rc = self.lib.odr_vmix(self.ctx.h, self.h, float(t_epoch), float(dt), float(dt_mix), int(mix_at_surface), _abi.RNG_DEVICE, None, step)
+            if rc < 0:
+                check(rc)
+            return rc == 0
         if uniforms is not None:
             u, pu = _d(np.ascontiguousarray(self._host_order(uniforms)))
             check(self.lib.odr_vmix(self.ctx.h, self.h, float(t_epoch), float(dt), float(dt_mix),
@@ -813,6 +822,20 @@ class Particles:
         read (odr_scan_status); follow with compact_apply()."""
         n, f = C.c_int64(), C.c_uint64()
         check(self.lib.odr_scan_status(self.ctx.h, self.h, C.byref(n), C.byref(f)))
+        return n.value, f.value
+
+    def scan_status_begin(self):
+        """First half of scan_status (odr_scan_status_begin): the fold of the counts the step launch left is enqueued; False
+        when that launch left none (then call scan_status())."""
+        rc = self.lib.odr_scan_status_begin(self.ctx.h, self.h)
+        if rc < 0:
+            check(rc)
+        return rc == 0
+
+    def scan_status_end(self):
+        """Second half: waits for the fold only (not for a guarded mixing launch enqueued behind it)."""
+        n, f = C.c_int64(), C.c_uint64()
+        check(self.lib.odr_scan_status_end(self.ctx.h, self.h, C.byref(n), C.byref(f)))
         return n.value, f.value
 
     def compact_apply(self):

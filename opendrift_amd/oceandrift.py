@@ -1213,6 +1213,23 @@ class OpenDriftSimulation(Configurable):
                   v not in self._hist.variables and not self._can_be_missing([v])] if fused_lane else []
         if any(b.sid is not None and self.ctx._grids.get(b.sid, {}).get('members') for b in self.readers.values()):
             unread = []      # (ensemble data: the member numbering goes with the main-loop call as the reference makes it)
+        # The mixing launch of the step enqueued before the host has read the status scan (vertical_mixing(_guarded=True)): when the
+        # stock update() makes nothing but that launch between the scan and the end of the step -- no mover that could move an
+        # element first (the wind is calm everywhere and there is no Stokes drift: decided on the host), stock methods, reader
+        # diffusivity, device RNG.  Between output times only: the result buffer records z as it is BEFORE update().
+        cls, OD = type(self), OceanDrift
+        sx, sy = 'sea_surface_wave_stokes_drift_x_velocity', 'sea_surface_wave_stokes_drift_y_velocity'
+        speculate = bool(
+            fused_lane and not os.environ.get('ODR_NO_SPECULATION') and self.rng == 'device' and isinstance(self, OD) and
+            all(getattr(cls, m) is getattr(OD, m) for m in ('vertical_mixing', 'vertical_advection', 'update_terminal_velocity',
+                                                           '_advect_wind_then_stokes_drift', 'advect_wind', 'stokes_drift',
+                                                           '_with_seafloor_action')) and
+            self.get_config('drift:vertical_mixing') is True and
+            self.get_config('vertical_mixing:diffusivitymodel') == 'environment' and
+            ('x_wind' not in self.required_variables or self._calm_everywhere()) and
+            (sx not in self.required_variables or self.get_config('drift:stokes_drift') is False or
+             (self._identically_zero(sx) and self._identically_zero(sy))))
+        self._vmix_speculated = False
         self.ctx.sync()
         t_loop = [time.perf_counter(), None]      # main-loop wall time (the reference keeps 'main loop' timers, basemodel :2174)
         # increase_age_and_retire comes after state_to_buffer in the loop: inside the fused launch only when the result
@@ -1288,7 +1305,13 @@ class OpenDriftSimulation(Configurable):
                     self._add_uncertainty(names, current=False)     # the wind's share
                     t_ph = lap('step launch', t_ph)
                     # ONE host read per step: how many elements stay + which new deactivation reasons occurred
-                    kept, flags = self.P.scan_status()
+                    self._vmix_speculated = False
+                    if speculate and i % out_every != 0 and self.P.scan_status_begin():
+                        launched = self.vertical_mixing(_guarded=True)      # (does nothing unless every element stays)
+                        kept, flags = self.P.scan_status_end()
+                        self._vmix_speculated = bool(launched) and kept == len(self.P)
+                    else:
+                        kept, flags = self.P.scan_status()
                     t_ph = lap('status read', t_ph)
                     all_stay = kept == len(self.P)      # nothing to backfill, nothing to compact on this rank
                     want_red = self._needs_reductions()
@@ -1644,9 +1667,17 @@ class OceanDrift(OpenDriftSimulation):
         })
         self._set_config_default('drift:max_speed', 2)
 
-    def vertical_mixing(self):   # oceandrift.py:397-571
-        if self.get_config('drift:vertical_mixing') is False:
+    def vertical_mixing(self, _guarded=False):   # oceandrift.py:397-571
+        """_guarded (run(), fused lane): the launch is enqueued BEHIND the fold of the step's status scan and BEFORE the host has
+        read it -- it does nothing unless every element stays (Particles.vmix(guarded=True)); returns whether it was enqueued.
+        update() then finds the step's mixing done (`_vmix_speculated`) and returns here at once."""
+        if getattr(self, '_vmix_speculated', False) and not _guarded:
+            self._vmix_speculated = False
+            self._vadv_fused = bool(self.get_config('drift:vertical_advection')) and \
+                type(self).vertical_advection is OceanDrift.vertical_advection
             return
+        if self.get_config('drift:vertical_mixing') is False:
+            return False
         model = self.get_config('vertical_mixing:diffusivitymodel')
         if model == 'environment' and not any(self.readers[n].sid is not None
                                               for n in self.priority_list.get('ocean_vertical_diffusivity', [])):
@@ -1664,6 +1695,17 @@ class OceanDrift(OpenDriftSimulation):
             fuse = bool(self.get_config('drift:vertical_advection_at_surface'))
             self._vadv_fused = True
         kw = dict(mix_at_surface=self.get_config('drift:vertical_mixing_at_surface'), fuse_vertical_advection=fuse)
+        if _guarded:
+            if model != 'environment' or self.rng != 'device':
+                self._vadv_fused = False
+                return False
+            action = self.get_config('general:seafloor_action', 'lift_to_seafloor')      # (as _with_seafloor_action; the
+            if 'sea_floor_depth_below_sea_level' not in self.priority_list:                 # fused lane knows lift / none only)
+                action = 'none'
+            self.ctx.set_seafloor_action(action, 0)
+            ok = self.P.vmix(_epoch(self.time), dt, dt_mix, step=self.steps_calculation, guarded=True, **kw)
+            self._vadv_fused = False        # (set again by the call from update())
+            return ok
         if self.rng == 'numpy':
             n, nt = self.num_elements_active(), abs(int(dt / dt_mix))
             kw['uniforms'] = np.stack([np.random.random(n) for _ in range(nt)])

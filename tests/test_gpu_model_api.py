@@ -162,6 +162,62 @@ def test_device_rng_run_is_reproducible_and_order_independent():
         assert np.array_equal(x, y, equal_nan=True)
 
 
+@pytest.mark.gpu
+def test_mixing_launch_enqueued_ahead_of_the_status_read_changes_nothing(monkeypatch):
+    """run(), fused lane: between output times the step's mixing launch is enqueued behind the fold of the status scan and BEFORE
+    the host has read it, guarded by the fold's verdict "every element stays" (odr_scan_status_begin / odr_ctx_guard_next_vmix).
+    Steps that lose elements fail the guard (the guarded launch does nothing, the host compacts and mixes as before), the others take
+    it: the run must equal the run that reads first (ODR_NO_SPECULATION=1) bit for bit -- positions, depths, status, result buffer."""
+    g = golden('c3_grid3d_rk4_vmix.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity',
+             'ocean_vertical_diffusivity', 'sea_floor_depth_below_sea_level', 'land_binary_mask']
+    guarded_calls = []
+
+    def run(speculate, action):
+        if speculate:
+            monkeypatch.delenv('ODR_NO_SPECULATION', raising=False)
+        else:
+            monkeypatch.setenv('ODR_NO_SPECULATION', '1')
+        o = OceanDrift(loglevel=50, seed=11)
+        o.add_reader(_grid_reader(g, names, z=g['g_z']))
+        o.set_config('drift:advection_scheme', 'runge-kutta4')
+        o.set_config('drift:vertical_mixing', True)
+        o.set_config('drift:vertical_advection', True)
+        # 'leave': half of the elements start in a 7 km band in front of the land strip of the field (lon >= 9.15) and strand
+        # step after step -- those steps fail their guard
+        o.set_config('general:coastline_action', 'stranding' if action == 'leave' else 'previous')
+        n = 70000
+        rng = np.random.default_rng(3)
+        lon = rng.uniform(1, 8, n)
+        if action == 'leave':
+            lon[::2] = rng.uniform(9.0, 9.14, len(lon[::2]))
+        o.seed_elements(lon=lon, lat=rng.uniform(60.5, 65.5, n), z=-rng.uniform(0, 40, n), time=T0)
+        calls = []
+        vm = o.vertical_mixing
+        # (an instance attribute that only records: run() decides on the CLASS's methods)
+        o.vertical_mixing = lambda _guarded=False: (calls.append((_guarded, o._vmix_speculated)), vm(_guarded=_guarded))[1]
+        res = o.run(time_step=600, steps=9, time_step_output=1800)
+        guarded_calls.append(calls)
+        return _final(o, n), res
+
+    for action in ('leave', 'stay'):
+        (a, ra), (b, rb) = run(True, action), run(False, action)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y, equal_nan=True)
+        for k in ra:
+            if k != 'time':
+                assert np.array_equal(ra[k], rb[k], equal_nan=True), k
+        spec, plain = guarded_calls[-2], guarded_calls[-1]
+        assert not any(gd for gd, _ in plain) and len(plain) == 9
+        assert sum(1 for gd, _ in spec if gd) == 6                  # steps 1, 2, 4, 5, 7, 8: between the output times
+        held = sum(1 for gd, sp in spec if not gd and sp)           # update() found the step's mixing done
+        assert len([1 for gd, _ in spec if not gd]) == 9
+        if action == 'stay':
+            assert held == 6                                        # nothing is ever deactivated: every guard holds
+        else:
+            assert held < 6 and np.isnan(ra['lon'][:, -1]).sum() > 20     # steps that lose elements fail their guard and mix after the compaction
+
+
 def test_openoil_advection_equals_reference_path():
     """OpenOil.update with weathering off = advect_oil (openoil.py:1179-1239): on the C4-shaped case the
     reference's OceanDrift-equivalent golden vectors apply."""
