@@ -153,7 +153,7 @@ class Workload:
         t = self.time_of(k)
         mid_given = mid is not None
         compact = P.compact_apply if mid_given else P.compact
-        mid = mid or (lambda: None)
+        mid = mid or (lambda *scan: None)      # mid(kept, flags) when the caller of mid has read the scan already, mid() otherwise
         if self.sort_every and self.name != 'c2' and k % self.sort_every == 0:
             P.sort_by_cell(self.sid, keep_environment=False)   # device layout maintenance, part of the timed step
         if self.name == 'c2':
@@ -163,8 +163,17 @@ class Workload:
             if self.fused and mid_given:   # the two launches as two calls, the status scan between them (OceanDrift.run())
                 P.env_coast_advect(self.vars, t, self.scheme, self.dt, coastline='previous', store_previous=True,
                                    count=False, seafloor=True, age_dt=self.dt)
-                mid()
-                P.vmix(t, self.dt, self.dt_mix, step=k, fuse_vertical_advection=False)
+                if not os.environ.get('ODR_NO_SPECULATION') and P.scan_status_begin():
+                    # as run() does between output times: the mixing launch enqueued behind the fold of the scan, guarded by its
+                    # verdict "every element stays", the scan read afterwards
+                    ok = P.vmix(t, self.dt, self.dt_mix, step=k, fuse_vertical_advection=False, guarded=True)
+                    kept, flags = P.scan_status_end()
+                    mid(kept, flags)
+                    if not (ok and kept == len(P)):
+                        P.vmix(t, self.dt, self.dt_mix, step=k, fuse_vertical_advection=False)
+                else:
+                    mid()
+                    P.vmix(t, self.dt, self.dt_mix, step=k, fuse_vertical_advection=False)
             elif self.fused:   # one call: the step launch, then the mixing launch
                 P.env_coast_advect(self.vars, t, self.scheme, self.dt, coastline='previous', store_previous=True,
                                    count=False, seafloor=True, age_dt=self.dt,
@@ -623,7 +632,9 @@ def main():
     # N > 1: the timed loop is the SHARDED step -- besides the device step of this rank's particles, the one collective per
     # step and the reader levels arriving from rank 0 by RCCL broadcast (ShardedLoop; weak scaling: every rank steps n particles)
     sharded = None
-    if world > 1 and a.workload != 'c2':
+    # ODR_BENCH_SHARDED_LOOP=1 with one process: the sharded step's sequence (status read between the two launches, the summary
+    # row) without a second process -- what the sequence itself costs on a device that is not shared (tools/gpu_sharded_price.sh)
+    if (world > 1 or os.environ.get('ODR_BENCH_SHARDED_LOOP')) and a.workload != 'c2':
         def install(tens, j):
             g = fields['g']
             slot = j % 3
@@ -652,7 +663,7 @@ def main():
                     continue
                 h = []
                 # the ONE host read of a sharded step (the status scan) and its ONE collective, where OceanDrift.run() makes them
-                wl.step(P, first + k, mid=lambda: h.append(sharded.start_summary(*P.scan_status())))
+                wl.step(P, first + k, mid=lambda *scan: h.append(sharded.start_summary(*(scan or P.scan_status()))))
                 if not h:          # (a workload without deactivations: the summary closes the step)
                     h.append(sharded.start_summary(*P.scan_status()))
                 sharded.finish_summary(h[0])

@@ -8,6 +8,18 @@ export ODR_BENCH_ONE_MODE=1
 timeout 600 python bench.py --steps 96 --no-cpu --no-extras > $O/one_10m.log 2>&1; grep "^{" $O/one_10m.log | tail -1 > $O/one_10m.json
 timeout 600 python bench.py --steps 96 --no-cpu --no-extras --particles 5000000 > $O/one_5m.log 2>&1; grep "^{" $O/one_5m.log | tail -1 > $O/one_5m.json
 ODR_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 96 --no-cpu --no-extras --particles 5000000 --block-every -1 > $O/two_5m.log 2>&1; grep "^{" $O/two_5m.log | tail -1 > $O/two_5m.json
+# the sequence of the sharded step in ONE process (no second process on the device, the collective is a no-op): the status read
+# between the two launches with the mixing launch enqueued ahead of it (default) and behind it (ODR_NO_SPECULATION=1)
+ODR_BENCH_SHARDED_LOOP=1 timeout 600 python bench.py --steps 96 --no-cpu --no-extras --block-every -1 > $O/seq_spec.log 2>&1; grep "^{" $O/seq_spec.log | tail -1 > $O/seq_spec.json
+ODR_NO_SPECULATION=1 ODR_BENCH_SHARDED_LOOP=1 timeout 600 python bench.py --steps 96 --no-cpu --no-extras --block-every -1 > $O/seq_nospec.log 2>&1; grep "^{" $O/seq_nospec.log | tail -1 > $O/seq_nospec.json
+python - <<PY
+import json
+try:
+    a, s1, s0 = (json.load(open('$O/%s.json' % n))['ms_per_step'] for n in ('one_10m', 'seq_spec', 'seq_nospec'))
+    print('one process, the sharded step sequence: %.4f ms/step with the mixing launch enqueued ahead of the status read (+%.4f), %.4f reading first (+%.4f); plain sequence %.4f' % (s1, s1 - a, s0, s0 - a, a))
+except Exception as e:
+    print('sequence runs:', e)
+PY
 # the machinery alone: rank 0 holds the 10 M elements, rank 1 a thousand (no time-slicing between two full workloads); with the
 # collective finished behind the mixing launch (default) and blocking at the end of the step (rounds 3-4)
 ODR_BENCH_OTHER_RANKS_PARTICLES=1000 ODR_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 96 --no-cpu --no-extras --block-every -1 > $O/uneven.log 2>&1; grep "^{" $O/uneven.log | tail -1 > $O/uneven.json
