@@ -494,13 +494,22 @@ __device__ __forceinline__ ProjStart proj_start(const DevProj &p, double lon_deg
   sincos(o.phi, &o.sp, &o.cp);
   return o;
 }
+// rot (ODR_STAGE_FAST stage samples): also cos / sin of rot_angle_rad = -(WGS84 azimuth of the 10 m line (x, y) -> (x, y + 10)) of
+// rotate_vectors (variables.py:59-109) in closed form -- a polar stereographic map is azimuthal and conformal: its +y axis has the
+// azimuth +-(lambda - lambda0) at every point, the chord's azimuth at its start differs from that by half the change of longitude
+// along the chord times (1 - |sin phi|) (mid-point direction minus half the meridian convergence of the geodesic): ~25 instructions
+// from the sines the projection has formed anyway instead of ~250 (rotation_cs); 4e-10 rad from the geodesic inverse (oracle).
 template <bool ELLPOLAR = false, bool EXT = true>
 __device__ __forceinline__ void proj_fwd_near(const DevProj &p, const ProjStart &o, double lon_deg, double lat_deg,
-                                              double &x, double &y) {
+                                              double &x, double &y, double *rot = nullptr) {
 #pragma clang fp contract(fast)
   const double lam = wrap_pi(lon_deg * kDeg - p.lon0), phi0 = lat_deg * kDeg;
   const double dl = lam - o.lam, dp = phi0 - o.phi;
-  if (!(o.ok && fabs(dl) < 8e-3 && fabs(dp) < 8e-3)) { proj_fwd<ELLPOLAR, EXT>(p, lon_deg, lat_deg, x, y); return; }
+  if (!(o.ok && fabs(dl) < 8e-3 && fabs(dp) < 8e-3)) {
+    proj_fwd<ELLPOLAR, EXT>(p, lon_deg, lat_deg, x, y);
+    if (rot) rot[0] = 2.0;     // "not formed here" (a cosine is never 2): the caller takes rotation_cs
+    return;
+  }
   const double l2 = dl * dl, p2 = dp * dp;
   const double sdl = dl * (1 - l2 * (1.0 / 6) * (1 - l2 * (1.0 / 20) * (1 - l2 * (1.0 / 42))));
   const double cdl = 1 - l2 * 0.5 * (1 - l2 * (1.0 / 12) * (1 - l2 * (1.0 / 30) * (1 - l2 * (1.0 / 56))));
@@ -518,6 +527,13 @@ __device__ __forceinline__ void proj_fwd_near(const DevProj &p, const ProjStart 
   }
   x = p.a * (rho * sinlam) + p.x0;
   y = p.a * (-rho * coslam) + p.y0;
+  if (rot) {
+    // (sinlam, +-coslam: sine and cosine of lambda - lambda0; sinphi: of the latitude counted from the projection's own pole)
+    const double cl = p.south ? -coslam : coslam;
+    const double q = rho > 0 ? 5.0 * sinlam * (1 - sinphi) * fast_rcp(p.a * rho) : 0.0;   // 0.5 * 10 m * d(lambda)/dy * (1 - |sin phi|)
+    if (p.south) { rot[0] = cl + q * sinlam; rot[1] = sinlam - q * cl; }
+    else { rot[0] = cl - q * sinlam; rot[1] = -sinlam - q * cl; }
+  }
 }
 
 // reader projection chosen at run time (kernels that serve any reader)
@@ -1504,10 +1520,18 @@ __device__ __forceinline__ bool uv_sample_stage_f32(const DevSource &s, const De
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
   double x, y;
+  double rot[2];             // cos, sin of the vector rotation at the stage position, when the projection hands them out
+  bool have_rot = false;
   if (PROJ == PROJ_LATLONG) { x = lon; y = lat; }
   else if (PROJ == PROJ_CURVILINEAR) curvi_locate(s.proj, lon, lat, x, y);
-  else if (ps.ok) proj_fwd_near<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, ps, lon, lat, x, y);
-  else proj_fwd<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, lon, lat, x, y);
+  else if (ps.ok) {
+#ifdef ODR_NO_STAGE_ROT_CLOSED_FORM   // A/B build: the rotation of every stage sample from rotation_cs, as in rounds 3-4
+    proj_fwd_near<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, ps, lon, lat, x, y);
+#else
+    proj_fwd_near<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, ps, lon, lat, x, y, rot);
+    have_rot = rot[0] <= 1.5;
+#endif
+  } else proj_fwd<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, lon, lat, x, y);
   const double xchk = cover_x<PROJ>(s.proj.kind, s.lon_mode, x);
   float fu = __builtin_nanf(""), fv = __builtin_nanf("");
   bool ok = true;
@@ -1567,7 +1591,8 @@ __device__ __forceinline__ bool uv_sample_stage_f32(const DevSource &s, const De
     fu = r.x; fv = r.y;
     if (ODR_PROJ_ROTATES(PROJ)) {
       double sn, cs;
-      rotation_cs<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, x, y, cs, sn);
+      if (have_rot) { cs = rot[0]; sn = rot[1]; }
+      else rotation_cs<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, x, y, cs, sn);
       const float c = (float)cs, n = (float)sn, uu = fu, vv = fv;
       fu = uu * c - vv * n;
       fv = uu * n + vv * c;
