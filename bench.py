@@ -401,9 +401,9 @@ def model_api_leg(fields, n, steps, device):
     tm = o.timing
     return dict(ms_per_step=tm['steady_ms_per_step'], value=n * 1e3 / tm['steady_ms_per_step'], unit='particle-steps/s',
                 steps=tm['steps'], host_phases_ms_per_step=tm.get('host_phases_ms_per_step'),
-                what='OceanDrift.run(): the full loop body per step (release, all 14 required variables '
-                'sampled, deactivation checks, result buffer, age, compaction, update(): RK4 + wind + vertical mixing + '
-                'vertical advection, horizontal diffusion early-out)')
+                what='OceanDrift.run(): the full loop body per step (release, the required variables sampled -- '
+                'the export-only sample of the diffusivity at the element only when it is recorded --, deactivation checks, result '
+                'buffer, age, compaction, update(): RK4 + wind + vertical mixing + vertical advection, horizontal diffusion early-out)')
 
 
 class ShardedLoop:
