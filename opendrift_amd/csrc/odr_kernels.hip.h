@@ -2948,6 +2948,8 @@ struct LeewayStep {
   // report_missing_variables (odr_leeway_set_missing_code): NaN in a sampled variable whose fallback is None
   int missing_code, nmiss_grp, nmiss_rest, pad3;
   int miss_grp[MAXG], miss_rest[4];    // group slots / variable ids (sampled by the preceding launch) to test for NaN
+  unsigned *wcount;                    // the loop's status scan formed by this launch (StepDesc.wcount / sflags)
+  unsigned long long *sflags;
 };
 template <int PROJ>
 __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_leeway(const DevWorld *__restrict__ W, PView p, EnvGroupDesc G,
@@ -3030,6 +3032,14 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_leeway(const De
   if (S.coast_action) {
     unsigned long long b = __ballot(hit);
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_hit, (unsigned long long)__popcll(b));
+  }
+  if (S.wcount) {   // (as at the end of k_step_grid)
+    const int s2 = i < p.n ? p.status[i] : 1;
+    const unsigned long long kb = __ballot(s2 == 0);
+    if (__ballot(s2 >= 100 && s2 < 164)) {
+      if (s2 >= 100 && s2 < 164) atomicOr(S.sflags, 1ull << (s2 - 100));
+    }
+    if ((threadIdx.x & 63) == 0 && i < p.n) S.wcount[i >> 6] = (unsigned)__popcll(kb);
   }
 }
 

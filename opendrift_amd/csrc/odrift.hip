@@ -1640,7 +1640,10 @@ int odr_env_coast_leeway(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
     S.nmiss_rest = nr;
     S.missing_code = (S.nmiss_grp || nr) ? missing_code : 0;
   }
-  if (coast_action) HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
+  const bool count_in_launch = p->wcount && !p->external && !getenv("ODR_NO_STEP_COUNT");   // (odr_scan_status then folds the wave counts)
+  if (coast_action || count_in_launch)
+    HIPCHK(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long) * (count_in_launch ? 4 : 1), c->stream));
+  if (count_in_launch) { S.wcount = p->wcount; S.sflags = c->counter + 2; }
   const DevSource &s = c->hw.src[G.sid];
   dim3 g(nblk(p->n)), b(BLOCK);
   PView v = view(p);
@@ -1653,6 +1656,7 @@ int odr_env_coast_leeway(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
     default: hipLaunchKernelGGL(k_step_leeway<PROJ_STERE_EQUIT_SPHERE>, g, b, 0, c->stream, c->dw, v, G, S, dt, c->counter); break;
   }
   HIPCHK(hipGetLastError());
+  if (count_in_launch) { p->wcount_epoch = p->status_epoch; p->wcount_n = p->n; }
   return (coast_action && n_on_land) ? read_counter(c, n_on_land) : 0;   // n_on_land == NULL: no host synchronisation
 }
 
