@@ -5,6 +5,11 @@
 
 int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, int mix_at_surface, int rng_mode,
              const double *huni, uint64_t step) {
+  const bool guarded = c->guard_next_vmix != 0;     // odr_ctx_guard_next_vmix: THIS call only, however it ends
+  c->guard_next_vmix = 0;
+  // a guarded call that cannot honour the guard (host-drawn numbers, OpenOil's loop: other kernel families) launches nothing and
+  // consumes nothing: the caller calls again, unguarded
+  if (guarded && (rng_mode == ODR_RNG_HOST || c->oil_owner == p)) return 1;
   p->status_epoch++;
   p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(dt_mix > 0 && dt != 0, "bad time steps");
@@ -41,9 +46,7 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
   c->oil_owner = nullptr;
   VMixDesc D;
   const bool fast = !oil && !getenv("ODR_NO_FAST_PATH") && build_vmix_desc(c, t, D);
-  const bool guarded = c->guard_next_vmix != 0;     // odr_ctx_guard_next_vmix: this call only
-  c->guard_next_vmix = 0;
-  if (guarded && (!fast || rng_mode == ODR_RNG_HOST)) { c->fuse_vadv = vadv; return 1; }   // nothing launched: the caller calls again, unguarded
+  if (guarded && !fast) { c->fuse_vadv = vadv; return 1; }   // (the generic kernel carries no guard) nothing launched
   if (fast) {
     if (guarded) D.guard = c->counter + 4;
     const int nq = (nzp + 3) / 4;
