@@ -240,3 +240,38 @@ def test_static_variables_and_content_ids_without_a_gpu():
     e = c.assign(names[1:2], {'sea_floor_depth_below_sea_level': nanny})
     f = c.assign(names[1:2], {'sea_floor_depth_below_sea_level': nanny.copy()})
     assert e['sea_floor_depth_below_sea_level'] == f['sea_floor_depth_below_sea_level'] != d['sea_floor_depth_below_sea_level']
+
+
+def test_which_steps_need_all_rank_reductions_is_decided_on_the_host():
+    """Sharded runs: the step's collective carries the 16 reduction slots -- and cannot be finished behind
+    update() -- only when a mover of the step consults all-rank maxima.  A mover whose input no reader delivers and whose fallback
+    is 0 returns early on every rank without looking (advect_wind: `wind_speed.max() == 0`, physics_methods.py:771-780; stokes_drift
+    :799-804; horizontal_diffusion, basemodel/__init__.py:1754)."""
+    class FakeBinding:
+        sid = 0
+
+    def model(**cfg):
+        o = OceanDrift(loglevel=50)
+        for k, v in cfg.items():
+            o.set_config(k.replace('__', ':'), v)
+        o.readers, o.priority_list = {}, {}
+        return o
+
+    o = model()
+    assert o._calm_everywhere() and o._identically_zero('horizontal_diffusivity')
+    assert not o._needs_reductions()                     # nothing but fallback zeros: no mover looks at the other ranks
+    o = model(drift__relative_wind=True)
+    assert not o._calm_everywhere() and o._needs_reductions()      # the wind relative to the current is not identically zero
+    o = model(environment__fallback__x_wind=3.0)
+    assert o._needs_reductions()
+    o = model(environment__fallback__horizontal_diffusivity=10.0)
+    assert o._needs_reductions()
+    o = model()
+    o.readers['w'] = FakeBinding()
+    o.priority_list['y_wind'] = ['w']                    # a reader delivers the wind
+    assert not o._calm_everywhere() and o._needs_reductions()
+    o = model()
+    o.priority_list['x_wind'] = ['gone']                 # listed, but discarded / not on the device: still identically zero
+    assert o._calm_everywhere()
+    o = model(vertical_mixing__diffusivitymodel='windspeed_Large1994', drift__vertical_mixing=True)
+    assert o._needs_reductions()                         # the analytic profiles take the deepest mixed layer of ALL elements
