@@ -494,6 +494,10 @@ __device__ __forceinline__ ProjStart proj_start(const DevProj &p, double lon_deg
   sincos(o.phi, &o.sp, &o.cp);
   return o;
 }
+// The closed forms of the vector rotation below hold when the map is conformal on the ellipsoid the reference's geodesic runs on
+// (pyproj.Geod(ellps='WGS84'); GRS80 differs by 3e-11 in e^2).  A conformal map of ANOTHER figure (a sphere: 1.7e-3 rad) keeps the
+// azimuths of that figure, not WGS84's: those readers take rotation_cs / rotation_angle as in rounds 1-4.
+__device__ __forceinline__ bool rot_same_ellipsoid(const DevProj &p) { return fabs(p.es - c_geod.e2) <= 1e-7; }
 // rot (ODR_STAGE_FAST stage samples): also cos / sin of rot_angle_rad = -(WGS84 azimuth of the 10 m line (x, y) -> (x, y + 10)) of
 // rotate_vectors (variables.py:59-109) in closed form -- a polar stereographic map is azimuthal and conformal: its +y axis has the
 // azimuth +-(lambda - lambda0) at every point, the chord's azimuth at its start differs from that by half the change of longitude
@@ -527,7 +531,8 @@ __device__ __forceinline__ void proj_fwd_near(const DevProj &p, const ProjStart 
   }
   x = p.a * (rho * sinlam) + p.x0;
   y = p.a * (-rho * coslam) + p.y0;
-  if (rot) {
+  if (rot && !rot_same_ellipsoid(p)) rot[0] = 2.0;     // conformal on another ellipsoid than the geodesic's: rotation_cs
+  else if (rot) {
     // (sinlam, +-coslam: sine and cosine of lambda - lambda0; sinphi: of the latitude counted from the projection's own pole)
     const double cl = p.south ? -coslam : coslam;
     const double q = rho > 0 ? 5.0 * sinlam * (1 - sinphi) * fast_rcp(p.a * rho) : 0.0;   // 0.5 * 10 m * d(lambda)/dy * (1 - |sin phi|)
@@ -1505,6 +1510,30 @@ __device__ __forceinline__ bool uv_sample_fast(const DevSource &s, const DevBloc
 }
 
 
+// cos / sin of rot_angle_rad at (x, y) of a Mercator or Lambert conformal conic reader in closed form (ODR_STAGE_FAST stage
+// samples): Mercator's +y axis is north everywhere and the 10 m line runs along a meridian -- no rotation; Lambert's +y axis has
+// the azimuth theta = n (lambda - lambda0), the line starts half its change of longitude times (n - sin phi) off that (see
+// proj_fwd_near).  3e-10 rad from the geodesic inverse on 2 000 random points per projection (oracle, CPU); rotation_angle (two
+// inverse projections + the geodesic inverse: the reference's own recipe) stays for the main-loop sample and for EXACT.
+__device__ __forceinline__ bool rot_closed_form(const DevProj &p, double x, double y, double lat_deg, double *rot) {
+#pragma clang fp contract(fast)
+  if (!rot_same_ellipsoid(p)) return false;
+  if (p.kind == PROJ_MERC) { rot[0] = 1.0; rot[1] = 0.0; return true; }
+  if (p.kind == PROJ_LCC) {
+    const double iak = fast_rcp(p.a * p.k0);
+    const double X = (x - p.x0) * iak, Yr = p.crho0 - (y - p.y0) * iak;
+    const double h2 = X * X + Yr * Yr;
+    if (!(h2 > 0)) return false;
+    const double ir = p.cn > 0 ? fast_rsqrt(h2) : -fast_rsqrt(h2);      // 1 / rho, signed like the projection's rho
+    const double st = X * ir, ct = Yr * ir;                               // sin, cos of theta
+    const double c = 5.0 * iak * st * ir * (1.0 - sin(lat_deg * kDeg) * fast_rcp(p.cn));   // 0.5 * 10 m * d(lambda)/dy * (n - sin phi)
+    rot[0] = ct - c * st;
+    rot[1] = -(st + c * ct);
+    return true;
+  }
+  return false;
+}
+
 // ODR_STAGE_FAST (odr_ctx_set_stage_math): the (u,v) of a Runge-Kutta STAGE position as ONE weighted sum of the
 // 4 corners x 2 z levels x 2 time levels in float32 -- the reference's result is a float32 as well (the environment is cast to
 // float32, environment.py:543), reached through float32 roundings of every (time, z) layer; here the 16 corner values per
@@ -1531,7 +1560,12 @@ __device__ __forceinline__ bool uv_sample_stage_f32(const DevSource &s, const De
     proj_fwd_near<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, ps, lon, lat, x, y, rot);
     have_rot = rot[0] <= 1.5;
 #endif
-  } else proj_fwd<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, lon, lat, x, y);
+  } else {
+    proj_fwd<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, lon, lat, x, y);
+#ifndef ODR_NO_STAGE_ROT_CLOSED_FORM
+    if (ODR_PROJ_ROTATES(PROJ) && PROJ != PROJ_STERE_POLAR && PROJ != PROJ_EXT) have_rot = rot_closed_form(s.proj, x, y, lat, rot);
+#endif
+  }
   const double xchk = cover_x<PROJ>(s.proj.kind, s.lon_mode, x);
   float fu = __builtin_nanf(""), fv = __builtin_nanf("");
   bool ok = true;
