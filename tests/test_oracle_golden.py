@@ -524,3 +524,55 @@ def test_c24_profile_paths_golden_vs_oracle(tag):
         dz = sub['z'][-1] - sub['z'][0]
         rms = [np.sqrt(np.nanmean(dz[m::3] ** 2)) for m in range(3)]
         assert rms[2] > 1.8 * rms[0] > 1.8 * 1.5 * rms[1]
+
+
+def test_closed_form_vector_rotation_of_conformal_readers_against_the_geodesic_inverse():
+    """The FAST stage samples of polar stereographic, Lambert and Mercator readers take cos / sin of rotate_vectors' angle
+    (variables.py:59-109: minus the WGS84 azimuth of the 10 m line (x, y) -> (x, y + 10)) from closed forms (csrc/odr_field.hip.h:
+    proj_fwd_near, rot_closed_form).  The formulas, restated in NumPy, against the reference's own recipe
+    evaluated with the oracle (projection inverse + geodesic inverse): <= 1e-9 rad where the projection's ellipsoid is the
+    geodesic's; on a SPHERE the map keeps the sphere's azimuths and the closed form is off by ~2e-3 rad (the device keeps
+    rotation_angle there: rot_same_ellipsoid)."""
+    rng = np.random.default_rng(1)
+    es = 0.00669437999014
+
+    def reference(p, lon, lat):
+        x, y = orc.proj_fwd(p, lon, lat)
+        lo2, la2 = orc.proj_inv(p, x, y + 10.0)
+        az, _ = orc.geod_inv(lon, lat, lo2, la2)
+        return -np.radians(az), x, y
+
+    def off(r, az1):
+        return np.abs(np.angle(np.exp(1j * (r + az1)))).max()
+
+    n = 2000
+    # polar stereographic, both hemispheres
+    for south, lat0, lat_ts, lon0 in ((False, 90.0, 60.0, 70.0), (True, -90.0, -70.0, -30.0)):
+        p = orc.make_proj(orc.PROJ_STERE_POLAR, a=6378137.0, es=es, lat0=lat0, lon0=lon0, lat_ts=lat_ts, x0=1e5, y0=-2e5)
+        lon, lat = rng.uniform(-180, 180, n), rng.uniform(55, 89, n) * (-1 if south else 1)
+        r, x, y = reference(p, lon, lat)
+        D = np.radians(((lon - lon0 + 180) % 360) - 180)
+        q = 5.0 * np.sin(D) / np.hypot(x - 1e5, y + 2e5) * (1 - np.abs(np.sin(np.radians(lat))))
+        cs, sn = (np.cos(D) + q * np.sin(D), np.sin(D) - q * np.cos(D)) if south else (np.cos(D) - q * np.sin(D), -np.sin(D) - q * np.cos(D))
+        assert np.abs(cs - np.cos(r)).max() < 1e-9 and np.abs(sn - np.sin(r)).max() < 1e-9
+        assert 1e-7 < off(r, -D if south else D) < 1e-6          # (without the chord term)
+    # Lambert conformal conic, northern and southern cone; Mercator
+    for kw in (dict(a=6378137.0, es=es, lat0=63.3, lon0=15.0, lat1=63.3, lat2=63.3, x0=1e5, y0=2e5, k0=1.0),
+               dict(a=6378137.0, es=es, lat0=-40.0, lon0=140.0, lat1=-30.0, lat2=-50.0, x0=0.0, y0=0.0, k0=0.9996)):
+        p = orc.make_proj(orc.PROJ_LCC, **kw)
+        lon = kw['lon0'] + rng.uniform(-40, 40, n)
+        lat = rng.uniform(35, 80, n) * (-1 if kw['lat0'] < 0 else 1)
+        r, x, y = reference(p, lon, lat)
+        X, Yr = (x - kw['x0']) / (p.a * p.k0), p.rho0 - (y - kw['y0']) / (p.a * p.k0)
+        ir = (1.0 if p.n > 0 else -1.0) / np.hypot(X, Yr)
+        st, ct = X * ir, Yr * ir
+        c = 5.0 / (p.a * p.k0) * st * ir * (1.0 - np.sin(np.radians(lat)) / p.n)
+        assert np.abs(ct - c * st - np.cos(r)).max() < 1e-9 and np.abs(-(st + c * ct) - np.sin(r)).max() < 1e-9
+    p = orc.make_proj(orc.PROJ_MERC, a=6378137.0, es=es, lat0=0.0, lon0=10.0, lat_ts=30.0)
+    r, _, _ = reference(p, 10.0 + rng.uniform(-60, 60, n), rng.uniform(-70, 70, n))
+    assert np.abs(r).max() < 1e-9                                # no rotation at all
+    # a conformal map of a SPHERE keeps the sphere's azimuths, not WGS84's
+    p = orc.make_proj(orc.PROJ_LCC, a=6371000.0, es=0.0, lat0=60.0, lon0=-20.0, lat1=50.0, lat2=70.0)
+    lon, lat = -20.0 + rng.uniform(-40, 40, n), rng.uniform(35, 80, n)
+    r, x, y = reference(p, lon, lat)
+    assert off(r, p.n * np.radians(lon + 20.0)) > 1e-3
