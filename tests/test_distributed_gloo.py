@@ -153,3 +153,43 @@ def test_step_summary_in_two_halves_gloo_world2():
         assert rows.shape == (2, 25)
         assert rows[:, 0].tolist() == [float(step), 100.0 + step] and rows[1, 1] == float(step == 2)
         assert rows[0, 2:].tolist() == [0.0] * 23 and rows[1, 2:].tolist() == [0.5] * 23
+
+
+def test_staging_buffers_of_a_variable_are_bounded(monkeypatch):
+    """distributed._staged_to_device: the page-locked staging buffers rank 0 sends a reader level through are reused per
+    (variable, shape) and a variable keeps those of its two most recent shapes only -- a reader whose window is re-cut again and
+    again must not leave every old window's buffers page-locked for the life of the process.  CPU: pinning and
+    events replaced by stand-ins."""
+    from opendrift_amd import distributed as D
+
+    class Ev:
+        def __init__(self):
+            self.waited = 0
+
+        def record(self, stream=None):
+            pass
+
+        def synchronize(self):
+            self.waited += 1
+
+    monkeypatch.setattr(torch.Tensor, 'pin_memory', lambda self: self)
+    monkeypatch.setattr(torch.cuda, 'Event', Ev)
+    monkeypatch.setattr(torch.cuda, 'current_stream', lambda dev=None: None)
+    monkeypatch.setattr(D, '_STAGING', {})
+    monkeypatch.setattr(D, '_STAGING_SHAPES', {})
+    dev = torch.device('cpu')
+    shapes = [(4, 6), (4, 6), (5, 6), (4, 6), (7, 3), (8, 3), (8, 3)]
+    for k, shp in enumerate(shapes):
+        a = np.full(shp, float(k), np.float32)
+        t = D._staged_to_device(('u', shp), a, dev)
+        assert t.shape == shp and float(t[0, 0]) == k
+        assert len([key for key in D._STAGING if key[0] == 'u']) <= D._STAGING_KEEP
+    assert sorted(key[1] for key in D._STAGING) == [(7, 3), (8, 3)] and D._STAGING_SHAPES['u'] == [(7, 3), (8, 3)]
+    D._staged_to_device(('v', (4, 6)), np.zeros((4, 6), np.float32), dev)       # another variable has buffers of its own
+    assert len(D._STAGING) == 3
+    # the two buffers of a shape are used in turn, and a buffer is written again only after its last copy is done
+    st = D._STAGING[('u', (8, 3))]
+    assert st[2] in (0, 1) and all(e is not None for e in st[1])
+    before = [e.waited for e in st[1]]
+    D._staged_to_device(('u', (8, 3)), np.ones((8, 3), np.float32), dev)
+    assert sum(e.waited for e in st[1] if e is not None) >= sum(before)
