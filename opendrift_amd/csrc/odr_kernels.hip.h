@@ -975,6 +975,13 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
   __shared__ double s_park[PARK ? GEOD_PARK * BLOCK : 1];
   __shared__ double s_zt[IS3D ? 3 * ZT_STRIDE : 1];   // interp1d tables of the reader's z grid (zinterp)
   const double *zt = nullptr;
+  // the particle's position requested BEFORE the table staging and its barrier (round 6: phase stamps put 9.6 % of a wave's
+  // life between its entry and the arrival of lon / lat / z -- kernel arguments -> source fields -> table loads -> barrier ->
+  // state loads, five dependent round trips; the state loads need the kernel arguments only)
+  double lon_e = 0, lat_e = 0, z_e = 0;
+#ifndef ODR_NO_EARLY_STATE
+  if (i < p.n) { lon_e = p.lon[i]; lat_e = p.lat[i]; z_e = p.z[i]; }
+#endif
   if (IS3D) { zt_stage(W->src[G.sid], s_zt); zt = s_zt; }
   double *Kp = nullptr, *gsh = nullptr;
   if (MIXQ > 0) {
@@ -992,14 +999,23 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
   // this lane's share of the movers' tests (S.red_on): neutral unless it holds an element that stays active
   unsigned r_bits = 0;   // 1 D > 0, 2 D == 0, 4 Stokes sum > 0, 8 == 0, 16 at the surface, 32 wind drift factor > 0, 64 == 0, 128 wind speed > 0, 256 == 0
   if (i < p.n) {
+#ifndef ODR_NO_EARLY_STATE
+    double lon = lon_e, lat = lat_e;
+    const double z = z_e;
+#else
     double lon = p.lon[i], lat = p.lat[i];
     const double z = p.z[i];
+#endif
     // everything the bookkeeping below reads of this particle, requested together with the position: each of these
     // loads after the environment stores is a memory round trip of its own (float stores may alias float loads)
     // ODR_STATE_LATE (the 3-D lat / lon instantiations of round 5): moving, status, age, drift factor and ssh are requested BEHIND
     // the sample instead of with the position -- one more dependent round trip, five registers less through the main-loop sample,
     // which with the rest of round 5's register work leaves the kernel at <= 96 registers = 5 waves per SIMD
+#ifdef ODR_STATE_EARLY
+    constexpr bool STATE_LATE = false;
+#else
     constexpr bool STATE_LATE = ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) && IS3D;
+#endif
     int moving = 0, st = 0;
     float age0 = 0.f, cdf0 = 0.f, ssh0 = 0.f;
     auto load_state = [&]() {

@@ -38,10 +38,19 @@ def has_gpu():
     return _has_gpu()
 
 
+def _gpu_tests_selected(config):
+    """True when the -m expression asks for the gpu tests (`-m gpu`, not `-m "not gpu"` and not an unmarked run)."""
+    expr = (config.getoption('markexpr', '') or '').strip()
+    return 'gpu' in expr.split() and 'not gpu' not in expr
+
+
 @pytest.fixture()
-def ctx():
-    """A device context; GPU tests fail loudly (not skip) when the HIP library is missing."""
+def ctx(request):
+    """A device context.  Under `-m gpu` a box without a visible device FAILS the test (a GPU record must not go green
+    with every test skipped); an unmarked run on a CPU box skips.  A missing HIP library always fails (Context raises)."""
     if not _has_gpu():
+        if _gpu_tests_selected(request.config):
+            pytest.fail('-m gpu was asked for and no GPU is visible on this box')
         pytest.skip('no GPU visible')
     from opendrift_amd.device import Context
     c = Context(device=0, seed=0)
@@ -67,3 +76,23 @@ def _loop_body_goldens_have_no_run_preamble():
 
 def golden(name):
     return np.load(os.path.join(GOLDEN, name))
+
+
+# Two rows in the format of the reference's OBJECTPROP.DAT (three lines per class: key + number, description, nine
+# coefficients; leeway.py:186-219).  The table itself is a data file of the reference and is not shipped; the numbers of
+# class 1 are the ones the C5 goldens were generated with (oracle/gen_golden.py: object_type=1).
+OBJECTPROP_EXCERPT = """ PIW-1                        1
+ Person-in-water (PIW), unknown state (mean values)
+       0.96     0.00     12.00      0.54      0.00      9.40     -0.54      0.00      9.40
+ PIW-2                        2
+ >PIW, vertical PFD type III conscious
+       0.48     0.00      8.30      0.15      0.00      6.70     -0.15      0.00      6.70
+
+"""
+
+
+@pytest.fixture()
+def objectprop_path(tmp_path):
+    p = tmp_path / 'OBJECTPROP.DAT'
+    p.write_text(OBJECTPROP_EXCERPT)
+    return str(p)

@@ -272,6 +272,35 @@ def test_c5_leeway_model_run_numpy_rng():
     assert np.abs(lon - g['lon'][-1]).max() < 1e-7 and np.abs(lat - g['lat'][-1]).max() < 1e-7
 
 
+def test_c5_leeway_model_run_through_object_type(objectprop_path):
+    """Golden C5 the way a reference script writes it (oracle/gen_golden.py: `o.seed_elements(..., object_type=1)` behind
+    np.random.seed(0)): the object class comes from the table (leeway.py:186-232), its coefficients are perturbed with the
+    reference's draws (:323-374) and the run continues on the reference's np.random stream -- no hand-passed coefficients."""
+    from opendrift_amd.leeway import Leeway
+    g = golden('c5_leeway_stere.npz')
+    names = ['x_sea_water_velocity', 'y_sea_water_velocity', 'x_wind', 'y_wind', 'land_binary_mask']
+    o = Leeway(objectprop_path, loglevel=50, seed=0, rng='numpy')
+    o.add_reader(_grid_reader(g, names, proj4=synth.NORKYST_PROJ4))
+    o.set_config('drift:wind_uncertainty', 2.0)
+    o.set_config('drift:current_uncertainty', 0.1)
+    o.set_config('seed:jibe_probability', 0.5)
+    np.random.seed(0)
+    o.seed_elements(lon=g['lon'][0], lat=g['lat'][0], time=T0, object_type=1)
+    for k in ('downwind_slope', 'crosswind_slope', 'downwind_offset', 'crosswind_offset', 'downwind_eps', 'crosswind_eps',
+              'orientation'):
+        assert np.array_equal(o._sched[k], g['p_' + k].astype(np.float32)), k
+    o.run(time_step=600, steps=8)
+    lon, lat, _ = _final(o, g['lon'].shape[1])
+    assert np.abs(lon - g['lon'][-1]).max() < 1e-7 and np.abs(lat - g['lat'][-1]).max() < 1e-7
+    # seeding with a radius: the class's draws come before the radius draws (leeway.py:327-346 before :386)
+    a, b = Leeway(objectprop_path, loglevel=50, seed=0, rng='numpy'), Leeway(objectprop_path, loglevel=50, seed=0, rng='numpy')
+    np.random.seed(3)
+    a.seed_elements(lon=4.0, lat=60.0, time=T0, number=50, radius=1000.0, object_type=2)
+    np.random.seed(3)
+    b.seed_elements(lon=4.0, lat=60.0, time=T0, number=50, object_type=2)
+    assert np.array_equal(a._sched['downwind_eps'], b._sched['downwind_eps']) and a._sched['lon'].std() > 0
+
+
 def test_c5b_leeway_capsizing_model_run_numpy_rng():
     from opendrift_amd.leeway import Leeway
     g = golden('c5b_leeway_capsizing.npz')

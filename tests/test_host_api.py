@@ -1,5 +1,6 @@
 """CPU: host-side mirror of the reference interface (config validation, reader surface, seeding
 rules) -- no device calls."""
+import os
 from datetime import datetime, timedelta
 
 import numpy as np
@@ -210,6 +211,62 @@ def test_tsprofiles_is_refused_loudly_and_leeway_seeding_keeps_the_random_stream
     assert np.array_equal(lw._sched['downwind_eps'], want.astype(np.float32))
     assert (want != np.random.RandomState(7).randn(n) * c['DWSTD']).any()          # some draws were rejected
     assert np.array_equal(np.random.randn(2), tail)
+
+
+def test_leeway_object_classes_come_from_the_table_or_raise(objectprop_path, monkeypatch):
+    """leeway.py:186-232,292-400: `Leeway(d=path)` reads the object-class table, `seed_elements(object_type=k)` and
+    `seed:object_type` perturb that class's nine coefficients -- the element properties of golden C5 (written by the
+    reference with object_type=1 behind np.random.seed(0)) bit for bit; without a table the request RAISES (round 5 accepted
+    `object_type` and ignored it)."""
+    from opendrift_amd.leeway import Leeway
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'c5_leeway_stere.npz'))
+    keys = ('downwind_slope', 'crosswind_slope', 'downwind_offset', 'crosswind_offset', 'downwind_eps', 'crosswind_eps',
+            'orientation')
+    t0 = datetime(2020, 1, 1)
+    for how in ('argument', 'config', 'environment'):
+        if how == 'environment':
+            monkeypatch.setenv('ODR_OBJECTPROP', objectprop_path)
+            lw = Leeway(loglevel=50)
+        else:
+            lw = Leeway(objectprop_path, loglevel=50)
+        assert sorted(lw.leewayprop) == [1, 2] and lw.leewayprop[2]['OBJKEY'] == 'PIW-2'
+        assert lw.get_config('seed:object_type') == 'Person-in-water (PIW), unknown state (mean values)'
+        np.random.seed(0)
+        if how == 'config':
+            lw.seed_elements(lon=g['lon'][0], lat=g['lat'][0], time=t0)            # the default class of seed:object_type
+        else:
+            lw.seed_elements(lon=g['lon'][0], lat=g['lat'][0], time=t0, object_type=1)
+        for k in keys:
+            assert np.array_equal(lw._sched[k], g['p_' + k].astype(np.float32)), (how, k)
+    monkeypatch.delenv('ODR_OBJECTPROP')
+    lw = Leeway(objectprop_path, loglevel=50)
+    with pytest.raises(ValueError):
+        lw.set_config('seed:object_type', 'no such object')
+    lw.set_config('seed:object_type', '>PIW, vertical PFD type III conscious')
+    np.random.seed(0)
+    lw.seed_elements(lon=4.0, lat=60.0, time=t0, number=10)
+    assert np.allclose(lw._sched['downwind_slope'], 0.48) and np.allclose(np.abs(lw._sched['crosswind_slope']), 0.15)
+    with pytest.raises(KeyError):
+        lw.seed_elements(lon=4.0, lat=60.0, time=t0, object_type=77)
+    # the draws of the class come BEFORE the base class draws the seeding radius (leeway.py:327-346 before :386)
+    a, b = Leeway(objectprop_path, loglevel=50), Leeway(objectprop_path, loglevel=50)
+    monkeypatch.setattr(Leeway, '_geod_fwd', lambda self, lon, lat, az, dist: (lon + 1e-5 * dist, lat))   # (the device's geodesic)
+    np.random.seed(3)
+    a.seed_elements(lon=4.0, lat=60.0, time=t0, number=50, radius=1000.0, object_type=2)
+    np.random.seed(3)
+    b.seed_elements(lon=4.0, lat=60.0, time=t0, number=50, object_type=2)
+    assert np.array_equal(a._sched['downwind_eps'], b._sched['downwind_eps']) and a._sched['lon'].std() > 0
+    # no table: a class cannot be looked up -> raise; coefficients or explicit arrays still work
+    monkeypatch.setattr('opendrift_amd.leeway.find_objectprop', lambda d=None: None)
+    bare = Leeway(loglevel=50)
+    assert bare.leewayprop is None
+    with pytest.raises(FileNotFoundError):
+        bare.seed_elements(lon=4.0, lat=60.0, time=t0, object_type=1)
+    with pytest.raises(FileNotFoundError):
+        bare.seed_elements(lon=4.0, lat=60.0, time=t0)
+    bare.seed_elements(lon=4.0, lat=60.0, time=t0, downwind_slope=1.0, crosswind_slope=0.5)
+    with pytest.raises(FileNotFoundError):
+        Leeway('/no/such/OBJECTPROP.DAT', loglevel=50)
 
 
 def test_static_variables_and_content_ids_without_a_gpu():
