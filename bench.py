@@ -117,6 +117,12 @@ class Workload:
                 continue
             arrays = {k: g[k][slot] for k in fields['names']} if rank == 0 else None
             shapes = {k: g[k][slot].shape for k in fields['names']}
+            if D.backend() == 'rccl':
+                # the C-ABI collectives (no torch in the process): ONE broadcast of the level on the upload stream, straight into
+                # the staging memory of the block preparation (odr_block_broadcast), then the commit
+                ctx.block_broadcast(sid, slot, float(g['t'][slot]), arrays, shapes, root=0, content_ids=self.static_ids)
+                ctx.commit_block(sid, slot)
+                continue
             # rank 0 owns the host Reader; the block travels to every GPU once per time level (RCCL broadcast), and
             # goes from the received device tensors into the block without touching the other hosts' memory
             tens = D.broadcast_block(arrays, shapes=shapes, src=0)
@@ -166,6 +172,9 @@ class Workload:
                 if not os.environ.get('ODR_NO_SPECULATION') and P.scan_status_begin():
                     # as run() does between output times: the mixing launch enqueued behind the fold of the scan, guarded by its
                     # verdict "every element stays", the scan read afterwards
+                    early = getattr(mid, 'early', None)
+                    if early is not None:
+                        early()                    # (C-ABI collectives: the step's collective leaves behind the fold of the scan)
                     ok = P.vmix(t, self.dt, self.dt_mix, step=k, fuse_vertical_advection=False, guarded=True)
                     kept, flags = P.scan_status_end()
                     mid(kept, flags)
@@ -258,37 +267,61 @@ def cpu_baseline(name, fields, n_cpu, rng):
                       % (n_cpu, nsteps, el))
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     host_cores = cores
-    # every simulation holds its own copy of the field blocks (C3: 0.9 GB): all host cores up to 64 simulations
-    cores = min(cores, int(os.environ.get('ODR_CPU_THREADS', 64)))
+    cores = min(cores, int(os.environ.get('ODR_CPU_THREADS', cores)))
     if cores > 1 and not os.environ.get('ODR_CPU_ONE_CORE'):
-        steppers = [step1] + [_cpu_stepper(name, fields, n_cpu, np.random.default_rng(100 + k)) for k in range(cores - 1)]
-        counts, deadline = [0] * cores, [0.0]
-
-        def work(j):   # the oracle calls are ctypes calls into C: the GIL is released while they run
-            k = 0
-            while time.perf_counter() < deadline[0] or k < 1:
-                steppers[j](1000 + k)
-                k += 1
-            counts[j] = k
-
-        deadline[0] = time.perf_counter() + 8.0
-        t0 = time.perf_counter()
-        th = [threading.Thread(target=work, args=(j,)) for j in range(cores)]
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-        el = time.perf_counter() - t0
-        out['all_cores'] = dict(value=n_cpu * sum(counts) / el, cores=cores, host_cores=host_cores,
-                                note='%d of the %d host cores' % (cores, host_cores),
-                                sample='%d independent simulations x %d particles, %d steps in total, %.1f s'
-                                       % (cores, n_cpu, sum(counts), el))
+        # ALL host cores, one simulation per core (the quasi-parallel mode of performance.rst:36), the field blocks SHARED: the
+        # world is built once here and the simulations are forked from this process -- its 0.9 GB of blocks are mapped
+        # copy-on-write into every child (a child only writes the pages its own particles make the oracle dilate, as the
+        # reference's cached blocks are dilated lazily); round 5 gave every simulation its own copy and stopped at 64 cores.
+        # The children never touch the GPU runtime and leave through os._exit.
+        import struct
+        world = step1.keep_alive
+        seconds = float(os.environ.get('ODR_CPU_ALL_SECONDS', 8.0))
+        start_at = time.time() + 0.02 * cores + 0.5          # every child starts stepping at the same wall-clock instant
+        pipes = []
+        for j in range(cores):
+            r, wfd = os.pipe()
+            pid = os.fork()
+            if pid == 0:
+                try:
+                    os.close(r)
+                    stp = _cpu_stepper(name, fields, n_cpu, np.random.default_rng(100 + j), world=world, warm=False)
+                    while time.time() < start_at:
+                        time.sleep(0.001)
+                    k, t0 = 0, time.perf_counter()
+                    while time.perf_counter() - t0 < seconds or k < 1:
+                        stp(1000 + k)
+                        k += 1
+                    os.write(wfd, struct.pack('qd', k, time.perf_counter() - t0))
+                finally:
+                    os._exit(0)
+            os.close(wfd)
+            pipes.append((pid, r))
+        counts, spans = [], []
+        for pid, r in pipes:
+            buf = os.read(r, 16)
+            os.close(r)
+            os.waitpid(pid, 0)
+            if len(buf) == 16:
+                k, el = struct.unpack('qd', buf)
+                counts.append(k)
+                spans.append(el)
+        if counts:
+            rate = sum(n_cpu * k / el for k, el in zip(counts, spans))     # every child over its own span (all overlap fully)
+            out['all_cores'] = dict(value=rate, cores=len(counts), host_cores=host_cores,
+                                    note='%d simulations on the %d host cores, field blocks shared (forked, copy-on-write)'
+                                         % (len(counts), host_cores),
+                                    sample='%d independent simulations x %d particles, %d steps in total, %.1f s each'
+                                           % (len(counts), n_cpu, sum(counts), max(spans)))
     return out
 
 
-def _cpu_stepper(name, fields, n_cpu, rng):
-    """One oracle simulation (its own world and particles); returns step(k) after the warm-up step."""
+def _cpu_stepper(name, fields, n_cpu, rng, world=None, warm=True):
+    """One oracle simulation (its own particles; its own world unless one is handed over); returns step(k) after the warm-up
+    step."""
     from oracle import oracle as orc
+    if world is not None:
+        return _cpu_stepper_on(name, fields, n_cpu, rng, world[0], world[1], world[2], warm)
     wb = orc.WorldBuilder()
     if name == 'c2':
         wb.add_double_gyre(A=0.1, epsilon=0.25, omega=0.628, t0=0.0)
@@ -310,6 +343,11 @@ def _cpu_stepper(name, fields, n_cpu, rng):
             wb.add_constant({orc.VAR[HD]: 10.0})
         dt = 900.0 if name == 'c4' else 600.0
     w = wb.finish()
+    return _cpu_stepper_on(name, fields, n_cpu, rng, wb, w, dt, warm)
+
+
+def _cpu_stepper_on(name, fields, n_cpu, rng, wb, w, dt, warm=True):
+    from oracle import oracle as orc
     lon, lat, z = seed_particles(name, fields, n_cpu, rng)
     mv, cdf = np.ones(n_cpu, np.int32), np.ones(n_cpu, np.float32)
     wdf = np.full(n_cpu, 0.02, np.float32)
@@ -351,8 +389,9 @@ def _cpu_stepper(name, fields, n_cpu, rng):
             r = np.random.default_rng(k)
             orc.horizontal_diffusion(lon, lat, mv, hd, r.standard_normal(n_cpu), r.standard_normal(n_cpu), dt)
 
-    step(0)  # warm-up: also performs the reference's one-off NaN dilation of the cached blocks
-    step.keep_alive = (wb, w)   # the world points into buffers owned by the builder
+    if warm:
+        step(0)  # warm-up: also performs the reference's one-off NaN dilation of the cached blocks
+    step.keep_alive = (wb, w, dt)   # the world points into buffers owned by the builder
     return step
 
 
@@ -417,10 +456,11 @@ class ShardedLoop:
           (odr_block_upload_device): DeviceReaderBinding._prefetch_dist / _upload.
     Counters: collectives, collective_s, levels, level_stall_s (host time spent waiting for a level that was due)."""
 
-    def __init__(self, fields, names, block_every, install=None):
+    def __init__(self, fields, names, block_every, install=None, rccl=None):
         from opendrift_amd import distributed as D
         self.D, self.rank, _, self.world = D, *D.env_world()
         self.fields, self.names, self.block_every, self.install = fields, names, int(block_every), install
+        self.rccl = rccl          # (ctx, source id, content ids): reader levels by odr_block_broadcast, staged one period ahead
         self.collectives, self.collective_s, self.levels, self.level_stall_s = 0, 0.0, 0, 0.0
         self.pending = None
         self.last = None
@@ -430,6 +470,11 @@ class ShardedLoop:
         nlev = len(g['t'])
         arrays = {k: g[k][j % nlev] for k in self.names} if self.rank == 0 else None
         shapes = {k: g[k][j % nlev].shape for k in self.names}
+        if self.rccl is not None:
+            ctx, sid, cids = self.rccl
+            ctx.block_broadcast(sid, j % 3, float(g['t'][j % nlev]), arrays, shapes, root=0, content_ids=cids)
+            self.pending = (j, None, None)
+            return
         self.pending = (j, ) + self.D.start_broadcast_block(arrays, shapes, src=0)
 
     def before_step(self, k):
@@ -440,6 +485,12 @@ class ShardedLoop:
             self._start(j)                     # (first level of the loop: nothing was started ahead)
         t0 = time.perf_counter()
         _, tens, works = self.pending
+        if self.rccl is not None:              # staged a period ago on the upload stream: the commit makes it current
+            self.rccl[0].commit_block(self.rccl[1], j % 3)
+            self.level_stall_s += time.perf_counter() - t0
+            self.levels += 1
+            self._start(j + 1)
+            return
         self.D.finish_broadcast(works)
         self.level_stall_s += time.perf_counter() - t0
         self.levels += 1
@@ -448,11 +499,14 @@ class ShardedLoop:
         self.last = tens
         self._start(j + 1)                     # the next level travels while this one is in use
 
-    def start_summary(self, kept, flags=0, raw16=None):
-        """The step's ONE collective, started where run() has read the status scan (distributed.start_allgather_vector) ..."""
+    def start_summary(self, kept, flags=0, raw16=None, from_scan_ctx=None):
+        """The step's ONE collective, started where run() has read the status scan (distributed.start_allgather_vector) ...
+        from_scan_ctx (C-ABI collectives): started BEHIND THE FOLD of the scan instead, ahead of the host's read -- the count and
+        the flags of the row are taken on the device (odr_comm_allgather_begin, from_scan)."""
         row = np.concatenate([[float(kept)], [float(flags >> b & 1) for b in range(8)], np.zeros(16) if raw16 is None else raw16])
         t0 = time.perf_counter()
-        h = self.D.start_allgather_vector(row)
+        h = self.D.start_allgather_vector(row, from_scan_ctx=from_scan_ctx) if from_scan_ctx is not None else \
+            self.D.start_allgather_vector(row)
         self.collective_s += time.perf_counter() - t0
         self.collectives += 1
         return h
@@ -470,7 +524,10 @@ class ShardedLoop:
 
     def finish(self):
         if self.pending is not None:           # the level started ahead of the loop's end: no collective may stay open
-            self.D.finish_broadcast(self.pending[2])
+            if self.rccl is not None:
+                self.rccl[0].commit_block(self.rccl[1], self.pending[0] % 3)
+            else:
+                self.D.finish_broadcast(self.pending[2])
             self.pending = None
 
     def report(self, steps):
@@ -501,7 +558,7 @@ def plumbing_only(a):
     block broadcast from rank 0, the barrier-bracketed loop, max / sum over the ranks, rank 0's single line.  What a box
     without N GPUs can check (tests/test_bench_spawn.py, gloo); `value` is null: it measures nothing."""
     from opendrift_amd import distributed as D
-    rank, local_rank, world = D.init(backend=os.environ.get('ODR_DIST_BACKEND') or None)
+    rank, local_rank, world = D.init(backend=os.environ.get('ODR_DIST_BACKEND') or 'torch')   # (the rehearsal layer: tensors on the host)
     n = a.particles or 1000
     fields = make_fields(a.workload, True)
     lo, hi = D.shard_range(n * world, rank, world)
@@ -536,11 +593,9 @@ def plumbing_only(a):
         print(json.dumps({'metric': 'particle-steps/sec (plumbing only: nothing measured)', 'value': None, 'unit': 'particle-steps/s',
                           'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': None, 'higher_is_better': True,
                           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'plumbing_only': True,
-                          'shards_ok': all_ok, 'units_all_ranks': units, 'loop_s_max_over_ranks': el_max, 'sharded_loop': sh.report(a.steps),
+                          'comm': D.comm_info(), 'shards_ok': all_ok, 'units_all_ranks': units, 'loop_s_max_over_ranks': el_max, 'sharded_loop': sh.report(a.steps),
                           'config': {'workload': a.workload, 'particles_per_gpu': n, 'particles_total': n * world}}), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    D.shutdown()
     return 0 if all_ok else 1
 
 
@@ -583,23 +638,33 @@ def main():
     if a.plumbing_only:
         sys.exit(plumbing_only(a))
 
-    import torch
     from opendrift_amd import distributed as D
     from opendrift_amd.device import Context
     import __graft_entry__ as G
-    rank, local_rank, world = D.init()
-    if rank == 0:
-        G.build()
+    if int(os.environ.get('RANK', 0)) == 0:
+        G.build()                       # (objects are fresh on the GPU box: this loads the library)
+    rank, local_rank, world = D.init()  # world > 1: RCCL through the C ABI (odr_comm_*), or torch.distributed on request (ODR_DIST_BACKEND)
     D.barrier()
-    assert torch.cuda.is_available(), 'bench.py needs a GPU: the product path has no CPU fallback'
-    dev = local_rank % torch.cuda.device_count()    # == local_rank on a node with one GPU per rank (the driver's launch)
-    torch.cuda.set_device(dev)
+    use_torch = D.backend() == 'torch'
+    if use_torch:
+        import torch
+        assert torch.cuda.is_available(), 'bench.py needs a GPU: the product path has no CPU fallback'
+        dev = local_rank % torch.cuda.device_count()    # == local_rank on a node with one GPU per rank (the driver's launch)
+        torch.cuda.set_device(dev)
+    else:                               # no torch in this process: one HIP runtime, the device library's
+        ndev = D.device_count()
+        assert ndev > 0, 'bench.py needs a GPU: the product path has no CPU fallback'
+        dev = local_rank % ndev
+
+    def device_synchronize():
+        if use_torch:
+            torch.cuda.synchronize()
 
     n = a.particles or {'c2': 1_000_000, 'c3': 10_000_000, 'c4': 6_250_000, 'c5': 10_000_000}[a.workload]
     fields = make_fields(a.workload, a.small)
     ctx = Context(device=dev, seed=0)
     ctx.set_stage_math(a.stage_math)
-    wl = Workload(a.workload, ctx, fields, (rank, local_rank, world))
+    wl = Workload(a.workload, ctx, fields, (rank, local_rank, world), via_torch=use_torch or world > 1)
     rng = np.random.default_rng(1000 + rank)
     lon, lat, z = seed_particles(a.workload, fields, n, rng)
     if a.host_sort and fields is not None:
@@ -645,12 +710,13 @@ def main():
                 ctx.upload_block(wl.sid, slot, float(g['t'][slot]), {kk: t.numpy() for kk, t in tens.items()}, content_ids=wl.static_ids)
         # --block-every -1: no reader levels inside the sharded loop (prices the per-step collective alone: over gloo a 210 MB
         # level travels through the loopback interface, tools/gpu_sharded_price.sh)
-        sharded = ShardedLoop(fields, fields['names'], 0 if a.block_every < 0 else (a.block_every or 6), install)
+        sharded = ShardedLoop(fields, fields['names'], 0 if a.block_every < 0 else (a.block_every or 6), install,
+                              rccl=(ctx, wl.sid, wl.static_ids) if D.backend() == 'rccl' else None)
 
     def timed_loop(steps, first, block_every=0, block_async=False, pinned=None):
         """`steps` steps between barrier + synchronize on both sides; returns (seconds, particle-steps of this rank)"""
         ctx.sync()
-        torch.cuda.synchronize()
+        device_synchronize()
         D.barrier()
         n0 = len(P)
         t0 = time.perf_counter()
@@ -663,7 +729,13 @@ def main():
                     continue
                 h = []
                 # the ONE host read of a sharded step (the status scan) and its ONE collective, where OceanDrift.run() makes them
-                wl.step(P, first + k, mid=lambda *scan: h.append(sharded.start_summary(*(scan or P.scan_status()))))
+
+                def mid(*scan):
+                    if not h:
+                        h.append(sharded.start_summary(*(scan or P.scan_status())))
+                if D.backend() == 'rccl':      # ... the collective behind the fold of the scan, ahead of the host's read
+                    mid.early = lambda: h.append(sharded.start_summary(0, 0, None, from_scan_ctx=ctx))
+                wl.step(P, first + k, mid=mid)
                 if not h:          # (a workload without deactivations: the summary closes the step)
                     h.append(sharded.start_summary(*P.scan_status()))
                 sharded.finish_summary(h[0])
@@ -683,7 +755,7 @@ def main():
         if sharded is not None:
             sharded.finish()
         ctx.sync()
-        torch.cuda.synchronize()
+        device_synchronize()
         el = time.perf_counter() - t0
         D.barrier()
         return el, 0.5 * (n0 + len(P)) * steps
@@ -797,7 +869,7 @@ def main():
         # every 6 steps on the upload stream inside the timed region
         pinned = {kk: ctx.pin(np.ascontiguousarray(fields['g'][kk])) for kk in fields['names']}
         warm_uploads(pinned)
-        nst = min(a.steps, 120)
+        nst = min(max(a.steps, 48), 120)      # >= 8 level periods whatever --steps says (20 steps hold 4 uploads and no steady state)
         el_p, up = timed_loop(nst, a.warmup, 6, True, pinned)
         extras['pcie_inclusive'] = dict(ms_per_step=1e3 * el_p / nst, value=up / el_p, unit='particle-steps/s', steps=nst,
                                         what='one 210 MB time level uploaded every 6 steps (odr_block_upload_async from '
@@ -881,6 +953,8 @@ def main():
                                    note='no counter file for this size / stage math: the SURVEY 8(d) algorithmic figure only')
             if k2_ms is not None:
                 out['roofline']['second_kernel'] = {'kernel': 'k_vmix_col', 'kernel_ms': k2_ms}
+        out['comm'] = D.comm_info()     # which layer carried the collectives and how many ranks IT saw (N > 1: RCCL through the C ABI)
+        out['torch_in_process'] = 'torch' in sys.modules
         if sharded_report is not None:
             out['sharded_loop'] = dict(sharded_report, what='the timed region holds, per step: the device step of this rank, one host read '
                                        '(odr_scan_status) and ONE all_gather of the step summaries; every block_every steps a reader level '
@@ -903,7 +977,8 @@ def main():
         out.update(extras)
         if not a.no_cpu and world == 1:
             out['cpu_baseline'] = cpu_baseline(a.workload, fields, a.cpu_particles, np.random.default_rng(5))
-            ref = os.path.join(ROOT, 'profiles', 'r02_cpu_reference_numpy.json')
+            refs = [os.path.join(ROOT, 'profiles', '%s_cpu_reference_numpy.json' % r) for r in ('r06', 'r02')]   # newest first
+            ref = next((f for f in refs if os.path.exists(f)), refs[-1])
             if a.workload == 'c3' and os.path.exists(ref):   # the reference's own NumPy path, timed where /root/reference exists
                 rj = json.load(open(ref))
                 best = max(rj['runs'], key=lambda r: r['particle_steps_per_s'])
@@ -911,14 +986,12 @@ def main():
                     value=best['particle_steps_per_s'], unit='particle-steps/s', cores=1, kind='reference',
                     sample='%d particles x %d steps, median' % (best['particles'], best['steps_timed']),
                     measured_on='%s (%s, %d cores) -- not this host; /root/reference is not on the GPU box'
-                                % (rj['measured_on'], rj['host_cpu'], rj['host_cores']), source='profiles/r02_cpu_reference_numpy.json')
+                                % (rj['measured_on'], rj['host_cpu'], rj['host_cores']), source='profiles/' + os.path.basename(ref))
         print(json.dumps(out), flush=True)
     if P is not None:
         P.close()
+    D.shutdown()          # the communicator goes before the context does
     ctx.close()
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

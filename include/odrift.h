@@ -522,6 +522,42 @@ int odr_reduce_local(odr_ctx *ctx, odr_particles *p, double wind_drift_depth, in
 int odr_reduce_install(odr_ctx *ctx, odr_particles *p, const double *in16);
 int odr_reduce_unpin(odr_ctx *ctx);
 
+/* ---------------------------------------------------------------- communication of a sharded run
+ * One process per GPU; the reference has no multi-process mode (docs/source/performance.rst:22,36 suggests running several
+ * simulations side by side), so there is no reference call to mirror: these are the three entry points SURVEY.md 8(b) lists
+ * (odr_comm_init, odr_block_broadcast, odr_allreduce_scalars) plus the step's one collective.  They run over RCCL (librccl.so.1,
+ * opened on first use; csrc/odr_comm.hip) -- no torch in the process.  ONE communicator pair per process: `step` for the small
+ * collectives of the loop, `bulk` for reader levels (operations on one communicator execute in issue order; a 200 MB level
+ * must not hold the step's 200-byte summary behind it).  Every rank makes the same calls in the same order. */
+#define ODR_COMM_ID_BYTES 256
+int odr_device_count(int32_t *n);
+/* rank 0: the id of a new job (two ncclUniqueIds); the host hands it to the other ranks (opendrift_amd/distributed.py: a file) */
+int odr_comm_unique_id(uint8_t *id /* [ODR_COMM_ID_BYTES] */);
+/* ncclCommInitRank x 2 on the context's device; collective over all ranks */
+int odr_comm_init(odr_ctx *ctx, const uint8_t *id, int32_t rank, int32_t nranks);
+/* nranks = 0: no communicator.  id_hash: the same number on every rank of one job; collectives: calls made so far */
+int odr_comm_info(int32_t *rank, int32_t *nranks, uint64_t *id_hash, int32_t *rccl_version, uint64_t *collectives);
+int odr_comm_destroy(void);
+/* in place, blocking; op 0 sum | 1 min | 2 max (counts of elements, extents; environment.py / basemodel bookkeeping over ALL elements) */
+int odr_allreduce_scalars(odr_ctx *ctx, double *values, int32_t n, int32_t op);
+/* THE collective of a sharded step, in two halves: every rank's row of n float64, gathered as [nranks][n].  _begin enqueues
+ * (copy in, ncclAllGather, copy out into page-locked memory) on the communication stream and returns; _end waits.
+ * from_scan != 0 (between odr_scan_status_begin and _end): row[0] = elements that stay and row[1..8] = status flags are
+ * taken ON THE DEVICE from the fold of the step's status scan -- the collective starts when the device has the counts, not
+ * when the host has read them; the mixing launch of the step runs meanwhile. */
+int odr_comm_allgather_begin(odr_ctx *ctx, const double *row, int32_t n, int32_t from_scan);
+int odr_comm_allgather_end(odr_ctx *ctx, double *rows /* [nranks][n] */);
+/* host bytes (metadata of a reader level, pickled by the host mirror) from root to every rank; blocking; same nbytes everywhere */
+int odr_comm_broadcast_bytes(odr_ctx *ctx, void *buf, int64_t nbytes, int32_t root);
+int odr_comm_barrier(odr_ctx *ctx);
+/* One reader time level (= one ReaderBlock, interpolation/structured.py:15-94) from the rank that runs the host Reader to
+ * every rank: odr_block_upload_async with ONE ncclBroadcast of the level's staged float32 arrays in it (in place in the
+ * upload pipeline's staging memory, on the upload stream, bulk communicator) -- `data` is read on `root` only (NULL
+ * elsewhere), shapes and geometry are given by every rank.  Staged like an asynchronous upload: odr_block_commit makes it
+ * current (a period later, when it is due). */
+int odr_block_broadcast(odr_ctx *ctx, int32_t source_id, int32_t slot, double t_epoch, int nvars, const int32_t *var_ids,
+                        const void *const *data, const int32_t *var_nz, int ny, int nx, const double *xy8, int32_t root);
+
 /* kernel timing hook for bench.py: HIP events recorded on the context stream around the
  * launches issued between begin and end; returns milliseconds */
 int odr_timer_begin(odr_ctx *ctx);

@@ -39,6 +39,7 @@ COAST = {'none': 0, 'stranding': 1, 'previous': 2}
 HIST = {'lon': 1000, 'lat': 1001, 'z': 1002, 'status': 1003, 'moving': 1004, 'age_seconds': 1005,
         'wind_drift_factor': 1006, 'current_drift_factor': 1007, 'terminal_velocity': 1008}
 HIST_PROPERTY0 = 2000
+COMM_ID_BYTES = 256      # ODR_COMM_ID_BYTES
 
 
 class StepExtras(C.Structure):   # odr_step_extras
@@ -148,6 +149,18 @@ _SIGNATURES = {
     'odr_deactivate': [_vp, _vp, _P(C.c_uint8), C.c_int32],
     'odr_deactivate_outside': [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32],
     'odr_compact': [_vp, _vp, _i64p],
+    # communication (csrc/odr_comm.hip: RCCL, one communicator pair per process)
+    'odr_device_count': [_P(C.c_int32)],
+    'odr_comm_unique_id': [_P(C.c_uint8)],
+    'odr_comm_init': [_vp, _P(C.c_uint8), C.c_int32, C.c_int32],
+    'odr_comm_info': [_P(C.c_int32), _P(C.c_int32), _P(C.c_uint64), _P(C.c_int32), _P(C.c_uint64)],
+    'odr_comm_destroy': [],
+    'odr_allreduce_scalars': [_vp, _dp, C.c_int32, C.c_int32],
+    'odr_comm_allgather_begin': [_vp, _dp, C.c_int32, C.c_int32],
+    'odr_comm_allgather_end': [_vp, _dp],
+    'odr_comm_broadcast_bytes': [_vp, _vp, C.c_int64, C.c_int32],
+    'odr_comm_barrier': [_vp],
+    'odr_block_broadcast': [_vp, C.c_int32, C.c_int32, C.c_double, C.c_int, _ip, _P(_vp), _ip, C.c_int, C.c_int, _dp, C.c_int32],
     'odr_scan_status': [_vp, _vp, _i64p, _P(C.c_uint64)],
     'odr_scan_status_begin': [_vp, _vp],
     'odr_scan_status_end': [_vp, _vp, _i64p, _P(C.c_uint64)],

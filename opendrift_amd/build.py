@@ -1,6 +1,6 @@
 """Builds libodrift_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
 
-The library is eight translation units (csrc/odrift.hip, odr_step.hip, odr_step_noise.hip, odr_step_fast.hip, odr_step_fast_noise.hip,
+The library is nine translation units (csrc/odr_comm.hip, csrc/odrift.hip, odr_step.hip, odr_step_noise.hip, odr_step_fast.hip, odr_step_fast_noise.hip,
 odr_step_mix.hip, odr_mix.hip, odr_step_tile.hip) compiled in parallel and
 linked into one shared object; objects are rebuilt only when a source they include changed."""
 import os
@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 UNITS = ['odr_step_noise.hip', 'odr_step_fast_noise.hip', 'odr_step.hip', 'odr_step_fast.hip', 'odrift.hip', 'odr_step_mix.hip', 'odr_mix.hip',
-         'odr_step_tile.hip']
+         'odr_step_tile.hip', 'odr_comm.hip']
 HEADERS = [os.path.join(CSRC, f) for f in ('odr_host.h', 'odr_step_launch.h', 'odr_kernels.hip.h', 'odr_field.hip.h', 'odr_geodesic.hip.h',
                                            'odr_oil.hip.h', 'odr_mesh.h', 'odr_tile.hip.h')] + \
     [os.path.join(os.path.dirname(HERE), 'include', 'odrift.h')]

@@ -1171,6 +1171,12 @@ __device__ __forceinline__ ZBracket zbracket(const DevSource &s, double z, const
 
 __device__ __forceinline__ float bil4(double v00, double v01, double v10, double v11, double wy0,
                                       double ty, double wx0, double tx) {
+#ifdef ODR_ABL_BIL4   // what-if build (wrong values): the bilinear layer value without its eleven float64 operations
+  return (float)v00 + (float)v11;
+#endif
+#ifdef ODR_WHATIF_BILW   // what-if build: weights multiplied out once per particle (the products are common subexpressions), fused
+  return (float)__builtin_fma(v11, ty * tx, __builtin_fma(v10, ty * wx0, __builtin_fma(v01, wy0 * tx, v00 * (wy0 * wx0))));
+#endif
   double t = __dmul_rn(__dmul_rn(v00, wy0), wx0);
   t = __dadd_rn(t, __dmul_rn(__dmul_rn(v01, wy0), tx));
   t = __dadd_rn(t, __dmul_rn(__dmul_rn(v10, ty), wx0));
@@ -1811,13 +1817,21 @@ __device__ __forceinline__ void env_burst(const DevSource &s, const EnvGroupDesc
   const unsigned iz0 = (unsigned)zb.iz0;
 #ifdef ODR_WHATIF_NO_BURST2   // what-if build (wrong values): slots B, C, D are not sampled -- what a fifth wave per SIMD buys
   const int kA = G.bs[0], kB = -1, kC = -1, kD = -1, kL = G.bs[4];
+#elif defined(ODR_WHATIF_C3SPEC)   // what-if build (bench C3 only): the group's layout as compile-time constants
+  constexpr int kA = 0, kB = 2, kC = 3, kD = -1, kL = 4;
 #else
   const int kA = G.bs[0], kB = G.bs[1], kC = G.bs[2], kD = G.bs[3], kL = G.bs[4];
 #endif
+#ifdef ODR_WHATIF_C3SPEC
+  constexpr int mA = ENV_P3, mB = ENV_S3, mC = ENV_S2;
+  double cs = 1, sn = 0;
+  constexpr int temp_mask = 0;
+#else
   const int mA = G.ps_mode[0], mB = G.ps_mode[1], mC = G.ps_mode[2];
   double cs = 1, sn = 0;
   if (ODR_PROJ_ROTATES(PROJ) && G.rotates) rotation_cs<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, x, y, cs, sn);
   const int temp_mask = G.temp_mask;
+#endif
   auto finish = [&](int k, double v) {      // masked_invalid(...).astype('float32'), fallback, Kelvin -> Celsius
     float f = (float)v;
     if (!isfinite(f)) { const float fb = G.fallback[k]; f = isfinite(fb) ? fb : f; }   // rare: the scalar load stays in here

@@ -341,6 +341,10 @@ int odr_i_ensure_ranks(odr_ctx *c, odr_particles *p);
 
 // defined in odrift.hip
 bool odr_i_build_env_group(const odr_ctx *c, const int *grp, int ng, double t, EnvGroupDesc &G);
+// odr_comm.hip: the process's RCCL communicators
+bool odr_i_comm_on();
+int odr_i_comm_rank();
+int odr_i_comm_bcast_floats(float *dev, size_t count, int root, hipStream_t st);
 void odr_i_phase_dump();   // odr_step.hip
 bool odr_i_uv_fast_source(const odr_ctx *c, int &sid, double t_lo, double t_hi);
 

@@ -1042,9 +1042,14 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
     if (MIXQ > 0) vmix_col_fill<(MIXQ > 0 ? MIXQ : 1), MIXTL>(W->src[M.D.sid], M.D, lon, lat, Kp, threadIdx.x);
     if (NOISE && S.main_noise) add_current_noise(N, 0, i, p.n, id, out[0], out[1]);
 #ifndef ODR_ABLATE_STORES   // what-if build (tools/ab_bench.sh)
+#ifdef ODR_WHATIF_C3SPEC
+#pragma unroll
+    for (int k = 0; k < 5; ++k) G.out_ptr[k][i] = out[k];
+#else
 #pragma unroll
     for (int k = 0; k < MAXG; ++k)
       if (k < G.nv) G.out_ptr[k][i] = out[k];
+#endif
     if (MIXQ == 0) {   // the sample position is what odr_vmix gathers its profiles at: not needed when the mixing is in here
       p.slon[i] = lon;
       p.slat[i] = lat;
@@ -1074,7 +1079,11 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
       }
     }
     if (S.coast_action) {  // k_coast
+#ifdef ODR_WHATIF_C3SPEC
+      const float land = out[4];
+#else
       const float land = S.land_slot == 2 ? out[2] : p.env[VAR_LAND][i];
+#endif
       if (land == 1.0f) {
         hit = true;
         if (S.coast_action == 1) {
@@ -1094,8 +1103,13 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
       }
     }
     if (S.seafloor) {  // k_seafloor
+#ifdef ODR_WHATIF_C3SPEC
+      const float dep = out[3];
+      const float floorz = -__fadd_rn(dep, ssh0);
+#else
       const float dep = S.depth_slot == 2 ? out[2] : (S.depth_slot == 3 ? out[3] : p.env[VAR_DEPTH][i]);
       const float floorz = -__fadd_rn(dep, S.ssh_slot >= 0 ? pick_slot(out, S.ssh_slot) : ssh0);
+#endif
       if (zz < (double)floorz) { zz = (double)floorz; if (MIXQ == 0) p.z[i] = zz; }
     }
     if (S.age_dt != 0.0f) {  // k_age

@@ -659,11 +659,14 @@ static int retire(odr_ctx *c, void *ptr, size_t bytes) {
   return 0;
 }
 
+// bcast_root >= 0 (odr_block_broadcast): the level's arrays are read on that rank only and reach the others by ONE broadcast of
+// the staging memory they are copied into side by side
 static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, int nvars, const int32_t *var_ids,
-                       const void *const *data, const int32_t *var_nz, int ny, int nx, const double *xy8) {
+                       const void *const *data, const int32_t *var_nz, int ny, int nx, const double *xy8, int bcast_root = -1) {
   REQUIRE(sid >= 0 && sid < c->nsrc && c->hw.src[sid].kind == SRC_GRID, "source %d is not a grid source", sid);
   REQUIRE(slot >= 0 && slot < MAXLEVELS, "slot must be in [0,%d)", MAXLEVELS);
-  REQUIRE(nvars > 0 && var_ids && data && var_nz && xy8 && ny > 1 && nx > 1, "bad block arguments");
+  const bool have_data = bcast_root < 0 || odr_i_comm_rank() == bcast_root;
+  REQUIRE(nvars > 0 && var_ids && (data || !have_data) && var_nz && xy8 && ny > 1 && nx > 1, "bad block arguments");
   HIPCHK(hipSetDevice(c->device));
   const DevSource &s = c->hw.src[sid];
   Staged &S = c->staged[sid][slot];
@@ -732,7 +735,7 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
   // device-resident sources (odr_sgrid_zslice results) may still be in the making on the compute stream: only
   // then does the upload depend on it (host sources must NOT wait for the simulation's backlog -- that is the overlap)
   bool dev_src = false;
-  for (int k = 0; k < nvars && !dev_src; ++k) {
+  for (int k = 0; k < nvars && !dev_src && have_data; ++k) {
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, data[k]) == hipSuccess) dev_src = at.type == hipMemoryTypeDevice;
     else (void)hipGetLastError();   // plain pageable memory: not an error
@@ -746,6 +749,7 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
   // sweeps on flagged tiles only, one record writer that assembles complete node records.  ODR_ROW_DILATE /
   // ODR_PLAIN_DILATE: the per-variable whole-array sweeps of rounds 1-2 (the cross-check of tests/test_gpu_async_upload.py).
   const bool prep_all = !getenv("ODR_PLAIN_DILATE") && !getenv("ODR_ROW_DILATE") && ny < 65536 && nlayers < 65536 && nvars <= NVAR;
+  if (bcast_root >= 0 && !prep_all) return fail(ODR_ERR_INVALID, "odr_block_broadcast: the level does not fit the one-pass preparation");
   if (prep_all) {
     BlkPrep Q;
     memset(&Q, 0, sizeof Q);
@@ -770,9 +774,11 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
       float *buf = c->prep[0] + at_f;
       hipPointerAttribute_t at;
       bool pageable = false;
-      if (hipPointerGetAttributes(&at, data[k]) != hipSuccess) { (void)hipGetLastError(); pageable = true; }
+      if (!have_data) {}
+      else if (hipPointerGetAttributes(&at, data[k]) != hipSuccess) { (void)hipGetLastError(); pageable = true; }
       else pageable = at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeHost && at.type != hipMemoryTypeManaged;
-      if (pageable) { int rcb = odr_i_h2d(c, buf, data[k], sizeof(float) * n, st, 1); if (rcb) return rcb; }
+      if (!have_data) {}      // (arrives with the broadcast below)
+      else if (pageable) { int rcb = odr_i_h2d(c, buf, data[k], sizeof(float) * n, st, 1); if (rcb) return rcb; }
       else HIPCHK(hipMemcpyAsync(buf, data[k], sizeof(float) * n, hipMemcpyDefault, st));
       Q.src[k] = buf; Q.fix[k] = c->prep[1] + at_f;
       Q.nz[k] = nzv; Q.cum[k] = cum; Q.off[k] = off[(size_t)k]; Q.es[k] = es[(size_t)k]; Q.eo[k] = eo[(size_t)k];
@@ -785,6 +791,10 @@ static int stage_block(odr_ctx *c, int32_t sid, int32_t slot, double t_epoch, in
       b.var_nz[v] = nzv;
     }
     Q.cum[nvars] = cum;
+    if (bcast_root >= 0) {   // every variable of the level in one collective, in place, behind root's copies on this stream
+      int rcb = odr_i_comm_bcast_floats(c->prep[0], at_f, bcast_root, st);
+      if (rcb) return rcb;
+    }
     hipLaunchKernelGGL(k_blk_mask_fill, dim3((unsigned)((nx + BLOCK - 1) / BLOCK), (unsigned)ny, (unsigned)nvars), dim3(BLOCK), 0, st,
                        Q, c->tile_flags);
     if (ndil) hipLaunchKernelGGL(k_blk_dilate_tile, dim3((unsigned)Q.ntiles, (unsigned)cum), dim3(BLOCK), 0, st, Q,
@@ -918,6 +928,12 @@ int odr_block_upload_device(odr_ctx *c, int32_t sid, int32_t slot, double t, int
 int odr_block_upload_async(odr_ctx *c, int32_t sid, int32_t slot, double t, int nvars, const int32_t *var_ids,
                            const void *const *data, const int32_t *var_nz, int ny, int nx, const double *xy8) {
   return stage_block(c, sid, slot, t, nvars, var_ids, data, var_nz, ny, nx, xy8);
+}
+int odr_block_broadcast(odr_ctx *c, int32_t sid, int32_t slot, double t, int nvars, const int32_t *var_ids,
+                        const void *const *data, const int32_t *var_nz, int ny, int nx, const double *xy8, int32_t root) {
+  if (!odr_i_comm_on()) return fail(ODR_ERR_STATE, "odr_block_broadcast: no communicator (odr_comm_init)");
+  REQUIRE(root >= 0, "bad root");
+  return stage_block(c, sid, slot, t, nvars, var_ids, data, var_nz, ny, nx, xy8, root);
 }
 // page-lock caller memory so that uploads from it are DMA transfers that overlap with the simulation
 int odr_host_register(odr_ctx *c, void *ptr, uint64_t bytes) {

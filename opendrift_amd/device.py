@@ -291,6 +291,28 @@ class Context:
         self._staged_refs = getattr(self, '_staged_refs', {})
         self._staged_refs[(sid, slot)] = keep
 
+    def block_broadcast(self, sid, slot, t_epoch, arrays, shapes, root=0, content_ids=None):
+        """One reader time level from rank `root` to every rank over RCCL (odr_block_broadcast): staged on the upload stream
+        like upload_block_async -- commit_block() makes it current.  arrays: {variable: float32 host array} on `root`, None
+        elsewhere; shapes: {variable: shape} on every rank (the order of its keys is the order of the level's variables)."""
+        g = self._grids[sid]
+        names = list(shapes)
+        ids, pi = _i([_vid(k) for k in names])
+        nzs, pn = _i([(int(shapes[k][0]) if len(shapes[k]) == 3 else 1) for k in names])
+        xy8, px = _d(g['xy8'])
+        keep, ptrs = None, None
+        if arrays is not None:
+            keep = {k: np.ascontiguousarray(np.ma.filled(arrays[k], np.nan) if isinstance(arrays[k], np.ma.MaskedArray) else arrays[k],
+                                            dtype=np.float32) for k in names}
+            for k in names:
+                if tuple(keep[k].shape) != tuple(shapes[k]):
+                    raise ValueError('block_broadcast: %s has shape %s, announced %s' % (k, keep[k].shape, tuple(shapes[k])))
+            ptrs = (C.c_void_p * len(names))(*[C.c_void_p(keep[k].ctypes.data) for k in names])
+        check(self.lib.odr_block_broadcast(self.h, sid, slot, float(t_epoch), len(names), pi, ptrs, pn, g['ny'], g['nx'], px, int(root)))
+        self._content_ids(sid, slot, content_ids)
+        self._staged_refs = getattr(self, '_staged_refs', {})
+        self._staged_refs[(sid, slot)] = keep
+
     def commit_block(self, sid, slot):
         check(self.lib.odr_block_commit(self.h, sid, slot))
         getattr(self, '_staged_refs', {}).pop((sid, slot), None)

@@ -1,4 +1,5 @@
-"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+"""Multi-GPU plumbing: one process per GPU; the collectives go over RCCL / xGMI through the C ABI of libodrift_hip.so
+(odr_comm_*: no torch in the process), or over torch.distributed (gloo rehearsal on CPU boxes).
 
 The path shards by particle: particles are independent within a step, every
 GPU holds the full field block.  The only data-path exchange is the broadcast of a new field
@@ -18,14 +19,187 @@ def env_world():
             int(os.environ.get('WORLD_SIZE', 1)))
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Two backends behind the same functions.
+#   'rccl'  -- the product path: the collectives are entry points of libodrift_hip.so (csrc/odr_comm.hip: librccl through
+#              the C ABI, include/odrift.h "communication"); NO torch in the process, one HIP runtime.  Default when the
+#              process sees a GPU.
+#   'torch' -- torch.distributed (gloo on CPU boxes: the rehearsal of the N-rank flow in tests/; nccl on request:
+#              ODR_DIST_BACKEND=nccl).
+_BACKEND = None        # None until init(): 'rccl' | 'torch'
+_COMM = None           # rccl: the Context the communicator was made on
+
+
+def backend():
+    return _BACKEND
+
+
+def comm_info():
+    """What the bench line prints as `comm` (the driver's scaling run shows from it that RCCL saw N ranks)."""
+    rank, local_rank, world = env_world()
+    if _BACKEND == 'rccl':
+        import ctypes as C
+        from . import _abi
+        lib = _abi.load()
+        r, n, h, v, k = C.c_int32(), C.c_int32(), C.c_uint64(), C.c_int32(), C.c_uint64()
+        _abi.check(lib.odr_comm_info(C.byref(r), C.byref(n), C.byref(h), C.byref(v), C.byref(k)))
+        return dict(backend='rccl (libodrift_hip.so: odr_comm_*)', nranks_seen=int(n.value), rank=int(r.value),
+                    unique_id_hash='%016x' % h.value, rccl_version=int(v.value), collectives=int(k.value))
+    if _BACKEND == 'torch':
+        import torch.distributed as dist
+        return dict(backend='torch.distributed/' + dist.get_backend(), nranks_seen=dist.get_world_size(), rank=dist.get_rank(),
+                    unique_id_hash=None)
+    return dict(backend=None, nranks_seen=1, rank=0, unique_id_hash=None)
+
+
+def _choose_backend(asked=None):
+    asked = asked or os.environ.get('ODR_DIST_BACKEND')
+    if asked in ('gloo', 'nccl', 'torch'):
+        return 'torch', (None if asked == 'torch' else asked)
+    if asked == 'rccl' or (asked is None and os.path.exists('/dev/kfd')):
+        return 'rccl', None
+    return 'torch', None
+
+
+def _exchange_unique_id(rank, make, nbytes, timeout=300.0):
+    """The communicator id from rank 0 to every rank of the job WITHOUT a collective (there is none yet) and without torch:
+    a file every process of the node can see.  Key: MASTER_ADDR / MASTER_PORT of the launcher + the launcher's pid (the ranks
+    of one torchrun are children of one agent) or ODR_COMM_KEY; directory ODR_COMM_DIR (default: the temporary directory).
+    Rank 0 removes the file once its communicator is up (init_rccl), i.e. once every rank has read it."""
+    import tempfile
+    import time
+    key = os.environ.get('ODR_COMM_KEY') or '%s_%s_%d' % (os.environ.get('MASTER_ADDR', 'local'),
+                                                         os.environ.get('MASTER_PORT', '0'), os.getppid())
+    key = ''.join(ch if ch.isalnum() or ch in '._-' else '_' for ch in key)
+    path = os.path.join(os.environ.get('ODR_COMM_DIR', tempfile.gettempdir()), 'odr_comm_id_' + key)
+    if rank == 0:
+        ident = make()
+        tmp = path + '.%d.tmp' % os.getpid()
+        with open(tmp, 'wb') as f:
+            f.write(ident)
+        os.replace(tmp, path)          # atomic: a reader sees the whole id or no file
+        return ident, path
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, 'rb') as f:
+                ident = f.read()
+            if len(ident) == nbytes:
+                return ident, path
+        except FileNotFoundError:
+            pass
+        if time.time() - t0 > timeout:
+            raise TimeoutError('rank %d: no communicator id at %s after %.0f s (is rank 0 running?)' % (rank, path, timeout))
+        time.sleep(0.01)
+
+
+def init_rccl(ctx=None, world1=False):
+    """One RCCL communicator pair for this process through the C ABI (odr_comm_init).  ctx: the Context of this rank's GPU
+    (default: one on device LOCAL_RANK % device count).  world1: make the communicator in a one-rank job as well (tests)."""
+    global _BACKEND, _COMM
+    import ctypes as C
+    from . import _abi
+    rank, local_rank, world = env_world()
+    if _BACKEND == 'rccl':
+        return rank, local_rank, world
+    if world == 1 and not world1:
+        return rank, local_rank, world
+    lib = _abi.load()
+    if ctx is None:
+        from .device import Context
+        n = C.c_int32()
+        _abi.check(lib.odr_device_count(C.byref(n)))
+        ctx = Context(device=local_rank % max(1, n.value), seed=0)
+
+    def make():
+        buf = (C.c_uint8 * _abi.COMM_ID_BYTES)()
+        _abi.check(lib.odr_comm_unique_id(buf))
+        return bytes(buf)
+    ident, path = _exchange_unique_id(rank, make, _abi.COMM_ID_BYTES)
+    buf = (C.c_uint8 * _abi.COMM_ID_BYTES).from_buffer_copy(ident)
+    try:
+        _abi.check(lib.odr_comm_init(ctx.h, buf, rank, world))
+    finally:
+        if rank == 0:        # every rank has joined (ncclCommInitRank returns when all of them have) or the job is lost anyway
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+    _BACKEND, _COMM = 'rccl', ctx
+    return rank, local_rank, world
+
+
+def shutdown():
+    """End of the process: the communicator goes before the contexts do."""
+    global _BACKEND, _COMM
+    if _BACKEND == 'rccl':
+        from . import _abi
+        _abi.check(_abi.load().odr_comm_destroy())
+        _BACKEND, _COMM = None, None
+    elif _BACKEND == 'torch':
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        _BACKEND = None
+
+
+def device_count():
+    """GPUs this process sees, asked of the device library (no torch)."""
+    import ctypes as C
+    from . import _abi
+    n = C.c_int32()
+    _abi.check(_abi.load().odr_device_count(C.byref(n)))
+    return int(n.value)
+
+
+def _rccl_allreduce(values, op):
+    import ctypes as C
+    from . import _abi
+    v = np.ascontiguousarray(values, dtype=np.float64).copy()
+    _abi.check(_abi.load().odr_allreduce_scalars(_COMM.h, v.ctypes.data_as(C.POINTER(C.c_double)), int(v.size),
+                                                 {'sum': 0, 'min': 1, 'max': 2}[op]))
+    return v
+
+
+def broadcast_object(obj, src=0):
+    """A small Python object (metadata of a reader level) from `src` to every rank."""
+    rank, local_rank, world = env_world()
+    if world == 1 and _BACKEND != 'rccl':
+        return obj
+    if _BACKEND == 'rccl':
+        import ctypes as C
+        import pickle
+        from . import _abi
+        lib = _abi.load()
+        data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL) if rank == src else b''
+        n = int(_rccl_allreduce([float(len(data))], 'max')[0])      # the length first: every rank passes the same byte count
+        buf = (C.c_uint8 * n).from_buffer_copy(data) if rank == src else (C.c_uint8 * n)()
+        _abi.check(lib.odr_comm_broadcast_bytes(_COMM.h, C.cast(buf, C.c_void_p), n, src))
+        return obj if rank == src else pickle.loads(bytes(buf))
+    import torch.distributed as dist
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
 def init(backend=None):
-    """Initialise torch.distributed from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torchrun env)."""
+    """The communication layer of a sharded run from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun's environment):
+    RCCL through the C ABI where there is a GPU (no torch in the process), torch.distributed otherwise / on request
+    (ODR_DIST_BACKEND = rccl | gloo | nccl)."""
+    global _BACKEND
+    rank, local_rank, world = env_world()
+    kind, torch_backend = _choose_backend(backend)
+    if world > 1 and kind == 'rccl' and _BACKEND != 'torch':
+        return init_rccl()
+    if world == 1:
+        return rank, local_rank, world
+    backend = torch_backend
     import torch
     import torch.distributed as dist
-    rank, local_rank, world = env_world()
+    _BACKEND = 'torch'
     if world > 1 and not dist.is_initialized():
-        if backend is None:   # ODR_DIST_BACKEND=gloo: rehearsal of the N-rank flow on a box with fewer GPUs than ranks
-            backend = os.environ.get('ODR_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if backend is None:   # (no GPU in sight: the rehearsal of the N-rank flow over gloo)
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':
@@ -78,6 +252,10 @@ def broadcast_block(arrays, shapes=None, src=0, device=None):
 
 def allreduce_scalars(values, op='sum'):
     """All-reduce a handful of float64 scalars (counts: sum, extents: min/max)."""
+    if _BACKEND == 'rccl':
+        return _rccl_allreduce(values, op)
+    if _BACKEND is None:
+        return np.asarray(values, dtype=np.float64)
     import torch
     import torch.distributed as dist
     rank, local_rank, world = env_world()
@@ -93,6 +271,10 @@ def allreduce_scalars(values, op='sum'):
 def allgather_vector(values):
     """ONE collective for everything a step needs from the other ranks: every rank's float64 vector, as rows of a
     [world, n] array (the caller sums / maximises the columns itself -- counts and maxima travel together)."""
+    if _BACKEND == 'rccl':
+        return finish_allgather_vector(start_allgather_vector(values))
+    if _BACKEND is None:
+        return np.ascontiguousarray(values, dtype=np.float64)[None, :]
     import torch
     import torch.distributed as dist
     rank, local_rank, world = env_world()
@@ -110,9 +292,21 @@ def allgather_vector(values):
     return torch.stack(parts).numpy()
 
 
-def start_allgather_vector(values):
+def start_allgather_vector(values, from_scan_ctx=None):
     """allgather_vector started now and finished later (finish_allgather_vector): the step's collective travels while the
-    device runs the launches that do not depend on it (OceanDrift.run(): the mixing launch of the step).  Returns a handle."""
+    device runs the launches that do not depend on it (OceanDrift.run(): the mixing launch of the step).  Returns a handle.
+    from_scan_ctx (rccl): the Context whose status scan is open (between scan_status_begin and _end) -- entries 0 .. 8 of the
+    row (elements that stay, eight status flags) are then taken from the fold ON THE DEVICE, the host has not read them yet."""
+    if _BACKEND == 'rccl':
+        import ctypes as C
+        from . import _abi
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        c = from_scan_ctx if from_scan_ctx is not None else _COMM
+        _abi.check(_abi.load().odr_comm_allgather_begin(c.h, v.ctypes.data_as(C.POINTER(C.c_double)), int(v.size),
+                                                       1 if from_scan_ctx is not None else 0))
+        return ('rccl', int(v.size))
+    if _BACKEND is None:
+        return ('done', np.ascontiguousarray(values, dtype=np.float64)[None, :].copy())
     import torch
     import torch.distributed as dist
     rank, local_rank, world = env_world()
@@ -131,9 +325,16 @@ def start_allgather_vector(values):
 
 def finish_allgather_vector(handle):
     """The rows of every rank ([world, n]) of a collective begun with start_allgather_vector."""
-    import torch
     if handle[0] == 'done':
         return handle[1]
+    if handle[0] == 'rccl':
+        import ctypes as C
+        from . import _abi
+        rank, local_rank, world = env_world()
+        out = np.empty((world, handle[1]), np.float64)
+        _abi.check(_abi.load().odr_comm_allgather_end(_COMM.h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+    import torch
     handle[1].wait()
     if handle[0] == 'nccl':
         return handle[2].cpu().numpy()
@@ -150,6 +351,12 @@ def combine_rows(rows):
 
 
 def barrier():
+    if _BACKEND == 'rccl':
+        from . import _abi
+        _abi.check(_abi.load().odr_comm_barrier(_COMM.h))
+        return
+    if _BACKEND is None:
+        return
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
@@ -161,7 +368,7 @@ def combine_reductions(raw16):
     """The 16 raw reduction slots of every rank -> what one process holding all elements would have computed."""
     raw = np.asarray(raw16, dtype=np.float64)
     rank, local_rank, world = env_world()
-    if world == 1:
+    if world == 1 and _BACKEND != 'rccl':
         return raw
     mx = allreduce_scalars(raw, 'max')
     sm = allreduce_scalars([raw[k] for k in COUNT_SLOTS], 'sum')

@@ -57,8 +57,11 @@ class OpenDriftSimulation(Configurable):
         if self._world > 1:
             D.init()
             if device == 0:
-                import torch
-                device = local_rank % max(1, torch.cuda.device_count())
+                if D.backend() == 'rccl':
+                    device = local_rank % max(1, D.device_count())
+                else:
+                    import torch
+                    device = local_rank % max(1, torch.cuda.device_count())
             if rng != 'device':
                 raise ValueError("a sharded run (WORLD_SIZE > 1) needs rng='device': np.random draws are sized by the "
                                  "elements of one process")
@@ -623,7 +626,7 @@ class OpenDriftSimulation(Configurable):
         self._g_active = self._g_active_carry = int(g[0])
         return int(g[0]), int(g[1])
 
-    def _step_summary(self, kept, flags, want_reductions, start_only=False, handle=None):
+    def _step_summary(self, kept, flags, want_reductions, start_only=False, handle=None, from_scan=False):
         """The ONE collective of a sharded step: this rank's kept count, provisional status flags and (when a mover of this
         step needs them) its 16 raw reduction slots, all-gathered; returns the all-rank (kept, flags) and installs the
         all-rank reductions for the movers that follow (released by _step_release at the end of the step).
@@ -638,6 +641,14 @@ class OpenDriftSimulation(Configurable):
             wdd, rel = self.get_config('drift:wind_drift_depth', 0.1), bool(self.get_config('drift:relative_wind'))
             raw = self.P.reduce_local(wdd, rel) if want_reductions else np.zeros(16)
             t0 = time.perf_counter()
+            if from_scan:
+                # (C-ABI collectives) between scan_status_begin and _end: the kept count and the flags of this rank's row are
+                # taken on the device from the fold of the status scan -- the collective leaves before the host has read them
+                row = np.zeros(25)
+                h = D.start_allgather_vector(row, from_scan_ctx=self.ctx)
+                self._timing_collective_s += time.perf_counter() - t0
+                self._timing_collectives += 1
+                return h
             row = np.concatenate([[float(kept)], [float(flags >> k & 1) for k in range(8)], raw])
             if start_only:
                 h = D.start_allgather_vector(row)
@@ -1306,7 +1317,13 @@ class OpenDriftSimulation(Configurable):
                     t_ph = lap('step launch', t_ph)
                     # ONE host read per step: how many elements stay + which new deactivation reasons occurred
                     self._vmix_speculated = False
+                    want_red = self._needs_reductions()
+                    early = None
                     if speculate and i % out_every != 0 and self.P.scan_status_begin():
+                        if self._world > 1 and not want_red and not os.environ.get('ODR_SYNC_COLLECTIVE'):
+                            from . import distributed as D
+                            if D.backend() == 'rccl':     # the step's ONE collective leaves behind the fold, ahead of the host's read
+                                early = self._step_summary(None, None, False, start_only=True, from_scan=True)
                         launched = self.vertical_mixing(_guarded=True)      # (does nothing unless every element stays)
                         kept, flags = self.P.scan_status_end()
                         self._vmix_speculated = bool(launched) and kept == len(self.P)
@@ -1314,8 +1331,13 @@ class OpenDriftSimulation(Configurable):
                         kept, flags = self.P.scan_status()
                     t_ph = lap('status read', t_ph)
                     all_stay = kept == len(self.P)      # nothing to backfill, nothing to compact on this rank
-                    want_red = self._needs_reductions()
-                    if self._world > 1 and not want_red and flags == 0 and not os.environ.get('ODR_SYNC_COLLECTIVE'):
+                    if early is not None and flags == 0:
+                        deferred = (early, self._pending_status, kept)
+                        self._pending_status = []
+                    elif early is not None:      # a reason of this rank waits for its category: the collective is finished now
+                        kept, flags = self._step_summary(None, None, False, handle=early)
+                        self._resolve_status(flags)
+                    elif self._world > 1 and not want_red and flags == 0 and not os.environ.get('ODR_SYNC_COLLECTIVE'):
                         # sharded: nothing this rank does before the end of update() depends on the other ranks (no mover
                         # consults all-rank maxima, no element here carries a reason that waits for its category) -- the
                         # step's ONE collective is started here and finished behind the launches of update()
@@ -1685,10 +1707,23 @@ class OceanDrift(OpenDriftSimulation):
             # reference switches to Large et al. (1994) (oceandrift.py:431-447).  (A reader that is listed but covers
             # no element at all would do the same there; here its fallback-filled profile is used.)
             model = 'windspeed_Large1994'
-        # (drift:truncate_ocean_model_below_m with reader diffusivity profiles: the reference only narrows the depth range it
-        # ASKS the reader for -- profiles_depth = min(profiles_depth, truncate_depth), environment.py:560 ->
-        # basereader/structured.py:230-238 -- the columns a reader hands out are mixed on as they come, for elements at any
-        # depth; golden c24a.  The device gathers every level the block holds.)
+        # drift:truncate_ocean_model_below_m with reader diffusivity profiles: the reference narrows the depth range it ASKS the
+        # reader for -- profiles_depth = min(profiles_depth, truncate_depth), environment.py:560 -> basereader/structured.py:
+        # 230-238 -- and mixes on the columns as they come.  A reader that ignores the z request hands out whole columns
+        # (golden c24a: elements at any depth mix on their real K); the reference's file readers CUT the block at the depth asked
+        # for (reader_netCDF_CF_generic.py:414-423, reader_ROMS_native.py:551-560: the level range of the request plus
+        # `verticalbuffer`), so deeper elements get K and dK/dz of the last level held.  The device block always holds every
+        # level; the cut is not emulated: refused unless the reader says its columns come whole whatever is asked.
+        if model == 'environment' and self._config.get('drift:truncate_ocean_model_below_m', {}).get('value') is not None:
+            for n in self.priority_list.get('ocean_vertical_diffusivity', []):
+                b = self.readers[n]
+                if b.sid is not None and not getattr(b.reader, 'always_delivers_all_levels', False):
+                    raise NotImplementedError(
+                        'drift:truncate_ocean_model_below_m together with diffusivity profiles from reader "%s": the reference\'s '
+                        'file readers hand out columns cut at the truncation depth (elements below mix on the last level held), '
+                        'which the device path does not emulate.  Set reader.always_delivers_all_levels = True if the reference '
+                        'reader this one stands for ignores the depth range asked of it (whole columns, as here), or use an '
+                        'analytical vertical_mixing:diffusivitymodel' % n)
         dt, dt_mix = self.time_step.total_seconds(), self.get_config('vertical_mixing:timestep')
         fuse = None
         if self.get_config('drift:vertical_advection') and type(self).vertical_advection is OceanDrift.vertical_advection:

@@ -490,6 +490,13 @@ class ReaderLevelsError(RuntimeError):
 _READER_IO_LOCK = threading.Lock()   # one get_variables at a time, whichever thread: netCDF / HDF5 builds are rarely thread-safe
 
 
+class _ShapeOnly:
+    """A variable of a reader level on a rank that does not hold the arrays (they arrive by odr_block_broadcast)."""
+
+    def __init__(self, shape):
+        self.shape = tuple(int(n) for n in shape)
+
+
 class ReadAhead:
     """Rank 0 of a sharded run owns the host Reader: every time level the other ranks receive passes through ITS
     get_variables.  Called inline it stops rank 0's step loop for the duration of the file read, and -- one collective per
@@ -763,7 +770,11 @@ class DeviceReaderBinding:
                 continue
             self._upload(k, extent, broadcast, asynchronous=False)
         # prefetch the time level the run will need next (readers whose arrays live in host memory)
-        if self.prefetch and self.world > 1 and r.times is not None and broadcast is None and self.sid is not None and \
+        rccl = False
+        if self.world > 1:
+            from . import distributed as D
+            rccl = D.backend() == 'rccl'
+        if self.prefetch and self.world > 1 and not rccl and r.times is not None and broadcast is None and self.sid is not None and \
                 getattr(self, '_dist_shapes', None) is not None:
             kn = (max(need) + 1) if t1 >= t0 else (min(need) - 1)
             if 0 <= kn < len(r.times) and kn not in self.slots and kn not in self._dist_pre and len(self._dist_pre) == 0:
@@ -812,6 +823,55 @@ class DeviceReaderBinding:
             self._dist_shapes = {v: tuple(t.shape) for v, t in tens.items() if v != '__cid__'}
         return meta, tens, works
 
+    def _read_level_rccl(self, k, x, y):
+        """Sharded run over the C-ABI collectives (distributed.backend() == 'rccl'): rank 0 reads time level k; every rank
+        learns its HEADER -- failure, array shapes, ensemble members, content ids and (first level) the coordinate metadata --
+        in one small broadcast; the arrays themselves travel inside odr_block_broadcast.  Returns (block dict whose variables
+        are host arrays on rank 0 and shape placeholders elsewhere, arrays-or-None, shapes)."""
+        from . import distributed as D
+        r = self.reader
+        block, err, hdr, arrays = None, None, None, None
+        if self.rank == 0:
+            try:
+                if self._ahead is None:
+                    self._ahead = ReadAhead(r, self.variables)
+                block = self._ahead.read(k, x, y)
+                step = getattr(self, '_direction', 0) or (1 if self._ahead_last is None or k >= self._ahead_last else -1)
+                kn = k + step
+                self._ahead_last = k
+                if self.prefetch and r.times is not None and 0 <= kn < len(r.times):
+                    self._ahead.start(kn, x, y)
+
+                def one(a):
+                    return np.ascontiguousarray(np.ma.filled(a, np.nan) if isinstance(a, np.ma.MaskedArray) else a, dtype=np.float32)
+                arrays, members = {}, {}
+                for v in self.variables:
+                    if isinstance(block[v], (list, tuple)):     # ensemble members stacked along the layer axis
+                        m = np.stack([one(a) for a in block[v]])
+                        arrays[v], members[v] = np.ascontiguousarray(m.reshape((-1,) + m.shape[-2:])), len(block[v])
+                    else:
+                        arrays[v] = one(block[v])
+                hdr = dict(shapes={v: tuple(a.shape) for v, a in arrays.items()}, members=members, cids=self._static_ids())
+                if getattr(self, '_dist_meta', None) is None:
+                    hdr['meta'] = {kk: (np.asarray(block[kk]) if kk in ('x', 'y', 'z') and block.get(kk) is not None else block.get(kk))
+                                   for kk in ('x', 'y', 'z', 's_level_variables') if kk in block}
+            except Exception as e:      # noqa: BLE001 -- every reader exception is a reader failure (environment.py:640-668)
+                err = e
+                hdr = dict(error=repr(e))
+        hdr = D.broadcast_object(hdr, src=0)
+        if 'error' in hdr:
+            if err is not None:
+                raise err
+            raise D.RemoteReaderError('the reader failed on rank 0: ' + hdr['error'])
+        if 'meta' in hdr:
+            self._dist_meta = hdr['meta']
+        self._dist_members = hdr['members']
+        self._level_cids = hdr['cids']
+        out = dict(self._dist_meta)
+        for v, shp in hdr['shapes'].items():
+            out[v] = arrays[v] if arrays is not None else _ShapeOnly(shp)
+        return out, arrays, hdr['shapes']
+
     def _prefetch_dist(self, kn, extent):
         """Start the broadcast of the level the run needs next while the current one is in use (every rank makes this call
         at the same step: the collectives stay in the same order everywhere)."""
@@ -846,6 +906,7 @@ class DeviceReaderBinding:
         r = self.reader
         time = r.times[k] if r.times is not None else None
         x = y = None
+        rccl_arrays = rccl_shapes = None
         if extent is not None:
             x, y = np.array(extent[0]), np.array(extent[1])
         if self.world > 1:
@@ -855,24 +916,33 @@ class DeviceReaderBinding:
             from . import distributed as D
             import time as _time
             t_wait = _time.perf_counter()
-            if k in self._dist_pre:
-                tens, works = self._dist_pre.pop(k)
-                D.finish_broadcast(works)
-                meta = None
+            rccl_arrays = rccl_shapes = None
+            if D.backend() == 'rccl':
+                if getattr(r, 's_levels', False):
+                    raise NotImplementedError('a sigma-level reader in a sharded run needs ODR_DIST_BACKEND=nccl (the regridding '
+                                              'reads the level on every rank)')
+                block, rccl_arrays, rccl_shapes = self._read_level_rccl(k, x, y)
+                block['time'] = time
+                self.stall_s += _time.perf_counter() - t_wait
             else:
-                meta, tens, _ = self._read_and_broadcast(k, x, y, async_op=False)
-            self.stall_s += _time.perf_counter() - t_wait
-            if meta is not None:
-                self._dist_members = meta.pop('__members__', {})   # ensemble variables arrive as [members x nz, ny, nx] stacks
-                self._dist_meta = meta
-            block = dict(self._dist_meta)
-            block['time'] = time
-            cid_t = tens.pop('__cid__', None)
-            self._level_cids = None if cid_t is None else dict(zip(self.variables, [int(i) for i in cid_t.cpu().tolist()]))
-            for v, t in tens.items():
-                block[v] = t if t.is_cuda else t.numpy()
-            self._tensors = tens      # keep the device tensors alive until the block is built
-            asynchronous = False
+                if k in self._dist_pre:
+                    tens, works = self._dist_pre.pop(k)
+                    D.finish_broadcast(works)
+                    meta = None
+                else:
+                    meta, tens, _ = self._read_and_broadcast(k, x, y, async_op=False)
+                self.stall_s += _time.perf_counter() - t_wait
+                if meta is not None:
+                    self._dist_members = meta.pop('__members__', {})   # ensemble variables arrive as [members x nz, ny, nx] stacks
+                    self._dist_meta = meta
+                block = dict(self._dist_meta)
+                block['time'] = time
+                cid_t = tens.pop('__cid__', None)
+                self._level_cids = None if cid_t is None else dict(zip(self.variables, [int(i) for i in cid_t.cpu().tolist()]))
+                for v, t in tens.items():
+                    block[v] = t if t.is_cuda else t.numpy()
+                self._tensors = tens      # keep the device tensors alive until the block is built
+                asynchronous = False
         else:
             block = r.get_variables(self.variables, time, x, y, np.array([0.0]))
         if broadcast is not None:
@@ -915,6 +985,18 @@ class DeviceReaderBinding:
         free = [s for s in range(self.NSLOTS) if s not in self.slots.values() and s not in self.staged.values()]
         slot = free[0]
         t_ep = _epoch(time) if time is not None else 0.0
+        if self.world > 1 and rccl_shapes is not None:
+            # the level's arrays in ONE broadcast on the upload stream, straight into the staging memory of the block
+            # preparation (odr_block_broadcast); staged like an asynchronous upload
+            for v, m in getattr(self, '_dist_members', {}).items():
+                self.ctx.declare_members(self.sid, v, m)
+            self.ctx.block_broadcast(self.sid, slot, t_ep, rccl_arrays, rccl_shapes, root=0, content_ids=getattr(self, '_level_cids', None))
+            if asynchronous:
+                self.staged[k] = slot
+            else:
+                self.ctx.commit_block(self.sid, slot)
+                self.slots[k] = slot
+            return
         if asynchronous:
             if not self._pinned:     # page-lock the reader's in-memory arrays once: uploads become DMA transfers
                 self._pinned = True

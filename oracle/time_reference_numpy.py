@@ -6,7 +6,7 @@ geodesic.  One core (the reference is single-threaded by design, docs/source/per
 
     python oracle/time_reference_numpy.py [N ...]      # default 100000 1000000
 
-Writes profiles/r02_cpu_reference_numpy.json (host CPU model and core count stated).  Runs in the build container only:
+Writes profiles/<ODR_ROUND, default r06>_cpu_reference_numpy.json (host CPU model and core count stated).  Runs in the build container only:
 /root/reference does not exist on the GPU box; bench.py carries the stored numbers as cpu_baseline.reference_numpy.
 """
 import json
@@ -81,7 +81,7 @@ def main():
         r = time_c3(n, g)
         print(n, 'particles: %.3f s/step -> %.3e particle-steps/s' % (r['s_per_step_median'], r['particle_steps_per_s']), flush=True)
         out['runs'].append(r)
-    with open(os.path.join(ROOT, 'profiles', 'r02_cpu_reference_numpy.json'), 'w') as f:
+    with open(os.path.join(ROOT, 'profiles', '%s_cpu_reference_numpy.json' % os.environ.get('ODR_ROUND', 'r06')), 'w') as f:
         json.dump(out, f, indent=1)
 
 

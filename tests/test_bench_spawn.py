@@ -28,6 +28,9 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line():
     assert d['shards_ok'] is True                      # every rank got its ID range and the identical field block
     assert d['units_all_ranks'] == 2 * 1001 * 3        # units summed over the ranks
     assert d['config']['particles_total'] == 2002 and d['scaling'] == 'weak'
+    # the communication layer reports how many ranks IT saw (the driver's scaling run reads `comm` the same way: there it says
+    # rccl (libodrift_hip.so: odr_comm_*) and N; here, without a GPU, the rehearsal layer)
+    assert d['comm']['nranks_seen'] == 2 and d['comm']['backend'] == 'torch.distributed/gloo'
 
 
 def test_the_n_rank_loop_makes_one_collective_per_step_and_moves_the_reader_levels():
@@ -53,3 +56,4 @@ def test_single_process_default_is_one_rank():
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads(lines[-1])
     assert d['n_gpus'] == 1 and d['config']['workload'] == 'c4'
+    assert d['comm']['nranks_seen'] == 1 and d['comm']['backend'] is None

@@ -1167,10 +1167,19 @@ def test_c24a_truncation_with_reader_diffusivity_profiles_reproduces_the_referen
     the depth range the READER is asked for (basereader/structured.py:230-238) -- the columns a reader hands out are mixed on
     whole, for elements at any depth.  OceanDrift.run() against the reference's own run (golden c24a, np.random in its order)."""
     g = golden('c24_profiles.npz')
+    nst = g['a_lon'].shape[0] - 1
+    # a file reader of the reference would cut its columns at the truncation depth (ADVICE round 5): refused unless the reader
+    # declares whole columns, which is what the golden's reference reader (oracle/gen_golden_profiles.py) hands out
+    refused = _c24_model(g, 'a', stage_math)
+    refused.set_config('drift:truncate_ocean_model_below_m', float(g['truncate']))
+    refused.seed_elements(lon=g['a_lon'][0], lat=g['a_lat'][0], z=g['a_z'][0], time=T0, wind_drift_factor=0.0)
+    with pytest.raises(NotImplementedError, match='always_delivers_all_levels'):
+        refused.run(time_step=float(g['dt']), steps=nst)
     o = _c24_model(g, 'a', stage_math)
+    for r, _ in o._readers_host.values():
+        r.always_delivers_all_levels = True
     o.set_config('drift:truncate_ocean_model_below_m', float(g['truncate']))
     o.seed_elements(lon=g['a_lon'][0], lat=g['a_lat'][0], z=g['a_z'][0], time=T0, wind_drift_factor=0.0)
-    nst = g['a_lon'].shape[0] - 1
     o.run(time_step=float(g['dt']), steps=nst)
     lon, lat, z = _final(o, g['a_lon'].shape[1])
     print('c24a', stage_math, np.abs(lon - g['a_lon'][-1]).max(), np.abs(lat - g['a_lat'][-1]).max(), np.abs(z - g['a_z'][-1]).max())
