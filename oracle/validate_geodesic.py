@@ -32,6 +32,11 @@ B = A * (1 - F)
 
 def exact_direct(lat1, lon1, azi1, s12):
     """Closed-form integrals, Karney (2013) eqs. (7), (8), (10)-(12)."""
+    return tuple(float(v) for v in exact_direct_mp(lat1, lon1, azi1, s12))
+
+
+def exact_direct_mp(lat1, lon1, azi1, s12):
+    """The same at working precision (mpmath numbers: degrees)."""
     phi1 = mp.radians(mp.mpf(lat1))
     al1 = mp.radians(mp.mpf(azi1))
     bet1 = mp.atan((1 - F) * mp.tan(phi1))
@@ -53,8 +58,19 @@ def exact_direct(lat1, lon1, azi1, s12):
     lam12 = (omg2 - omg1) - F * sal0 * I3
     phi2 = mp.atan(mp.tan(bet2) / (1 - F))
     al2 = mp.atan2(sal0, cal0 * mp.cos(sig2))
-    return (float(mp.degrees(phi2)), float(mp.degrees(mp.radians(mp.mpf(lon1)) + lam12)),
-            float(mp.degrees(al2)))
+    return (mp.degrees(phi2), mp.degrees(mp.radians(mp.mpf(lon1)) + lam12), mp.degrees(al2))
+
+
+def exact_inverse_mp(lat1, lon1, lat2, lon2, azi_guess, s_guess):
+    """Azimuth at point 1 and length of the geodesic between two points GIVEN AS float64 numbers: Newton on the exact direct
+    problem from a nearby guess (short lines: the guess is the line the pair was made from)."""
+    t1, t2 = mp.mpf(lat2), mp.mpf(lon2)
+
+    def F(az, s):
+        la, lo, _ = exact_direct_mp(lat1, lon1, az, s)
+        return la - t1, (lo - t2) * mp.cos(mp.radians(t1))
+    az, s = mp.findroot(F, (mp.mpf(azi_guess), mp.mpf(s_guess)), tol=mp.mpf(10) ** -26, maxsteps=30)
+    return az, s
 
 
 def ode_direct(lat1, lon1, azi1, s12):

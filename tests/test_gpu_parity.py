@@ -630,3 +630,26 @@ def test_windsea_swell_stokes_profile_device_vs_oracle(ctx):
     d = np.maximum(np.abs(got['lon'][o] - lo), np.abs(got['lat'][o] - la))
     assert d.max() < 1e-9 and d[cond > 0.5].max() < 1e-10 and np.median(d) < 1e-13
     assert np.abs(lo - lon).max() > 1e-4          # it moved
+
+
+@pytest.mark.parametrize('tag', ['merc_wgs84', 'lcc_wgs84', 'lcc_1sp', 'stere_north', 'stere_north_ts90', 'stere_south', 'stere_oblique',
+                                 'stere_equatorial', 'laea_europe', 'laea_north', 'utm33', 'tmerc_wide', 'rotated_pole'])
+def test_projection_known_answers_on_the_device(ctx, tag):
+    """The device's forward projections (proj_fwd in csrc/odr_field.hip.h, reached through odr_source_lonlat2xy) against known
+    answers computed independently of oracle and device -- mpmath, 40 digits, from each projection's definition
+    (oracle/validate_projections.py; tests/test_proj_kat.py holds the oracle and the host mirror to the same file)."""
+    import ast
+    import test_proj_kat as K
+    from opendrift_amd import projection
+    g = np.load(K.GOLDEN)
+    kw = ast.literal_eval(str(g[tag + '_kw']))
+    lon, lat, x, y = (g['%s_%s' % (tag, k)] for k in ('lon', 'lat', 'x', 'y'))
+    proj = projection.parse_proj4(K.proj4_of(tag, kw))
+    pad = 1.0 if tag == 'rotated_pole' else 1e5
+    gx, gy = np.linspace(x.min() - pad, x.max() + pad, 8), np.linspace(y.min() - pad, y.max() + pad, 6)
+    sid = ctx.add_grid(gx, gy, proj=proj, lon_mode=1)
+    dx, dy = ctx.lonlat2xy(sid, lon, lat)
+    deg = tag == 'rotated_pole'
+    err = max(np.abs(K._dlon(dx, x) if deg else dx - x).max(), np.abs(dy - y).max())
+    print('device forward', tag, '%.2e' % err, 'deg' if deg else 'm')
+    assert err < (1e-12 if deg else 1e-5 if tag == 'laea_north' else K.TOL_FWD)
