@@ -522,6 +522,13 @@ int odr_reduce_local(odr_ctx *ctx, odr_particles *p, double wind_drift_depth, in
 int odr_reduce_install(odr_ctx *ctx, odr_particles *p, const double *in16);
 int odr_reduce_unpin(odr_ctx *ctx);
 
+/* Until the first update_positions of a run the reference's elements.lon / lat are float32 ARRAYS (elements/elements.py:71-88),
+ * so modulate_longitude (readers/basereader/variables.py:259-280, called on the elements' longitudes :914) forms
+ * np.mod(lon + 180, 360) - 180 in float32 in the FIRST get_environment: the readers are sampled at lon on the float32 grid of
+ * lon + 180 (up to 8e-6 deg off).  f32 != 0: the main-loop samples that follow (odr_env_sample, odr_env_coast_advect,
+ * odr_env_coast_leeway; not the Runge-Kutta stage calls, whose positions are float64 there) do the same; 0 ends it. */
+int odr_ctx_set_position_class(odr_ctx *ctx, int f32);
+
 /* ---------------------------------------------------------------- communication of a sharded run
  * One process per GPU; the reference has no multi-process mode (docs/source/performance.rst:22,36 suggests running several
  * simulations side by side), so there is no reference call to mirror: these are the three entry points SURVEY.md 8(b) lists

@@ -120,7 +120,12 @@ struct DevSource {
 };
 
 struct DevWorld {
-  int nsrc, pad;
+  int nsrc;
+  // odr_ctx_set_position_class: the MAIN-LOOP samples treat the element positions as the reference's float32 arrays of the first
+  // get_environment of a run (elements/elements.py:71-88: lon / lat are float32 until the first update_positions) --
+  // modulate_longitude (variables.py:259-280, :914) then forms np.mod(lon + 180, 360) - 180 in float32: the sample longitude is
+  // lon on the float32 grid of lon + 180 (lon_f32class).  The Runge-Kutta stage positions are float64 in the reference.
+  int f32pos;
   int nlist[NVAR];
   int list[NVAR][MAXLIST];
   float fallback[NVAR];
@@ -152,6 +157,15 @@ __device__ __forceinline__ double np_mod(double x, double m) {  // numpy.mod
   double r = fmod(x, m);
   if (r != 0 && ((r < 0) != (m < 0))) r += m;
   return r;
+}
+
+// modulate_longitude on a float32 longitude (DevWorld::f32pos).  The result is a fixed point of the float64 modulation the
+// samplers apply afterwards, so a sampler is simply handed this longitude.
+__device__ __forceinline__ double lon_f32class(int lon_mode, double lon) {
+  float l = (float)lon;
+  if (lon_mode == 1) l = __fsub_rn((float)np_mod((double)__fadd_rn(l, 180.0f), 360.0), 180.0f);   // (np.mod of a float32 is exact)
+  else if (lon_mode == 2) l = (float)np_mod((double)l, 360.0);
+  return (double)l;
 }
 
 // ---------------------------------------------------------------- projections
@@ -925,7 +939,9 @@ __device__ __forceinline__ bool landmask_contains(const DevSource &s, double lon
 // covers_positions_xy (variables.py:170-215, 747): the position in the reader's own coordinates and whether its domain
 // holds it -- the elements a reader is HANDED are the covered ones (ind_covered), which is also what the ensemble members
 // of a ReaderBlock are numbered over (interpolation/structured.py:119-135; k_rank_mark)
-__device__ __forceinline__ bool source_covers_xyz(const DevSource &s, double lon, double lat, double z, double &x, double &y) {
+__device__ __forceinline__ bool source_covers_xyz(const DevSource &s, double lon, double lat, double z, double &x, double &y,
+                                                  int f32pos = 0) {
+  if (f32pos) lon = lon_f32class(s.lon_mode, lon);
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
   proj_fwd_rt(s.proj, lon, lat, x, y);
@@ -940,10 +956,10 @@ __device__ __forceinline__ bool source_covers_xyz(const DevSource &s, double lon
 // NV variables of a group.  Returns false when the reader does not cover the position.
 template <int NV>
 __device__ __forceinline__ bool source_sample(const DevSource &s, const int (&vars)[NV], double lon,
-                                              double lat, double z, double t, double (&val)[NV], int rank = 0) {
+                                              double lat, double z, double t, double (&val)[NV], int rank = 0, int f32pos = 0) {
   if (!s.always_valid && (t < s.tmin || t > s.tmax)) return false;  // OutsideTemporalCoverageError
   double x, y;
-  if (!source_covers_xyz(s, lon, lat, z, x, y)) return false;
+  if (!source_covers_xyz(s, lon, lat, z, x, y, f32pos)) return false;
   if (s.kind == SRC_CONSTANT) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) val[v] = s.const_val[vars[v]];
@@ -1044,14 +1060,14 @@ __device__ __forceinline__ float kelvin_to_celsius(float T) {
 // (environment.py:597-762), then the fallback (:782-791).  out = float32 environment.
 template <int NV>
 __device__ __forceinline__ void env_group(const DevWorld &W, const int (&vars)[NV], double lon,
-                                          double lat, double z, double t, float (&out)[NV], int rank = 0) {
+                                          double lat, double z, double t, float (&out)[NV], int rank = 0, int f32pos = 0) {
 #pragma unroll
   for (int v = 0; v < NV; ++v) out[v] = W.fallback[vars[v]];
   int nl = W.nlist[vars[0]];
   for (int k = 0; k < nl; ++k) {
     const DevSource &s = W.src[W.list[vars[0]][k]];
     double val[NV];
-    bool covered = source_sample<NV>(s, vars, lon, lat, z, t, val, rank);
+    bool covered = source_sample<NV>(s, vars, lon, lat, z, t, val, rank, f32pos);
     bool bad = !covered;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {

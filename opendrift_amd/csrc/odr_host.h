@@ -144,6 +144,8 @@ struct odr_particles {
   float *altenv[NVAR];
   float *aux[9];
   float *altaux[9];
+  unsigned aux_user = 0;     // bit k: property slot k was written by the caller (odr_particles_set_property): the model owns it
+  bool kmember_on = false;   // slot AUX_KMEMBER parks the member of an ensemble diffusivity (k_kmember): the library owns it
   float *aux_snap[9];       // odr_particles_snapshot_property: copies the result buffer may read instead of aux[] (one record)
   long long aux_snap_cap[9];
   double *dead64[3];    // lon lat z of the deactivated store

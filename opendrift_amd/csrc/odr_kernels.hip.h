@@ -667,7 +667,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_group(const DevWorld *__restrict_
   for (int k = 0; k < NV; ++k) vars[k] = gv.v[k];
   double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
   float out[NV];
-  env_group<NV>(*W, vars, lon, lat, z, t, out, p.rank ? p.rank[i] : 0);
+  env_group<NV>(*W, vars, lon, lat, z, t, out, p.rank ? p.rank[i] : 0, W->f32pos);   // (the main-loop call: DevWorld::f32pos)
 #pragma unroll
   for (int k = 0; k < NV; ++k) p.env[vars[k]][i] = out[k];
   if (record_prev) { p.slon[i] = lon; p.slat[i] = lat; }
@@ -680,6 +680,7 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_env_grid(const DevWo
   long long i = pid();
   if (i >= p.n) return;
   double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
+  if (W->f32pos) lon = lon_f32class(W->src[G.sid].lon_mode, lon);    // first get_environment of a run (DevWorld::f32pos)
   float out[MAXG];
   env_group_fast<PROJ>(*W, G, lon, lat, z, out);
 #pragma unroll
@@ -1034,8 +1035,11 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
     EnvExport X;
     X.valid = false; X.n00 = X.n11 = 0; X.iz0 = 0;
     X.combine = IS3D && SM == 1;
-    env_group_fast<PROJ, true, IS3D>(*W, G, lon, lat, z, out, zt, zb_env, &X ODR_PT_ARG);
-    UVKeep<IS3D> K = uv_keep_from_sm<IS3D, SM>(G, X, th, zb_env, W->src[G.sid].nz, true);   // (FAST, 3-D: combined over the bracket's levels)
+    // (first get_environment of a run: the reference's float32 element arrays, DevWorld::f32pos -- wave-uniform, rare)
+    const double lon_s = W->f32pos ? lon_f32class(W->src[G.sid].lon_mode, lon) : lon;
+    env_group_fast<PROJ, true, IS3D>(*W, G, lon_s, lat, z, out, zt, zb_env, &X ODR_PT_ARG);
+    UVKeep<IS3D> K = uv_keep_from_sm<IS3D, SM>(G, X, th, zb_env, W->src[G.sid].nz, true);
+    if (lon_s != lon) K.valid = false;      // the kept records belong to another position than the stages start from   // (FAST, 3-D: combined over the bracket's levels)
     if constexpr (STATE_LATE) load_state();
     ODR_PT_USE(out[0]); ODR_PT_USE(out[1]); ODR_PT_USE(out[2]); ODR_PT_USE(out[3]); ODR_PT_USE(out[4]); ODR_PT(2);
     const int id = (NOISE || MIXQ > 0) ? p.id[i] : 0;
@@ -1051,7 +1055,7 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
       if (k < G.nv) G.out_ptr[k][i] = out[k];
 #endif
     if (MIXQ == 0) {   // the sample position is what odr_vmix gathers its profiles at: not needed when the mixing is in here
-      p.slon[i] = lon;
+      p.slon[i] = lon_s;
       p.slat[i] = lat;
     }
 #endif
@@ -1237,7 +1241,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_gyre(const DevWorld *__restrict__
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= p.n) return;
   const DevSource &s = W->src[sid];
-  const double lon = p.lon[i], lat = p.lat[i];
+  const double lon = W->f32pos ? lon_f32class(s.lon_mode, p.lon[i]) : p.lon[i], lat = p.lat[i];   // (DevWorld::f32pos)
   float u, v;
   const bool covered = gyre_sample(s, lon, lat, p.z[i], snw, W->fallback[VAR_U], W->fallback[VAR_V], u, v);
   p.env[VAR_U][i] = u;
@@ -2995,7 +2999,8 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_leeway(const De
     const int id = p.id[i];
     float out[MAXG];
     ZBracket zb;
-    env_group_fast<PROJ, true, false>(*W, G, lon, lat, z, out, nullptr, zb);
+    const double lon_s = W->f32pos ? lon_f32class(W->src[G.sid].lon_mode, lon) : lon;   // first get_environment of a run (DevWorld::f32pos)
+    env_group_fast<PROJ, true, false>(*W, G, lon_s, lat, z, out, nullptr, zb);
     float xw = pick_slot(out, S.wind_slot), yw = pick_slot(out, S.wind_slot + 1);
     float u = pick_slot(out, S.uv_slot), v = pick_slot(out, S.uv_slot + 1);
     // environment.py:869-891: env[x] += N(0, std) (float32 array += float64 draws), first the current, then the wind
@@ -3019,7 +3024,7 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_leeway(const De
       else if (k == S.uv_slot) val = u; else if (k == S.uv_slot + 1) val = v;
       G.out_ptr[k][i] = val;
     }
-    p.slon[i] = lon;
+    p.slon[i] = lon_s;
     p.slat[i] = lat;
     if (S.missing_code) {  // k_deactivate_missing (a NaN stays one under the uncertainty draws)
       bool miss = false;

@@ -1236,6 +1236,11 @@ int odr_i_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var
       const DevSource &s = c->hw.src[c->hw.list[VAR_KZ][k]];
       if (s.kind != SRC_GRID) continue;
       if (s.members[VAR_KZ] > 1) {
+        // (the member is parked in property slot 8; a model that uses all nine slots -- Leeway's `capsized` is slot 8 -- and
+        // requires the diffusivity would have its property overwritten: refused)
+        if (p->aux_user & (1u << AUX_KMEMBER))
+          return fail(ODR_ERR_STATE, "an ensemble ocean_vertical_diffusivity parks its member in property slot %d, which the model has set", AUX_KMEMBER);
+        p->kmember_on = true;
         if (!p->aux[AUX_KMEMBER]) {
           HIPCHK(hipMalloc((void **)&p->aux[AUX_KMEMBER], sizeof(float) * (size_t)p->cap));
           HIPCHK(hipMemsetAsync(p->aux[AUX_KMEMBER], 0, sizeof(float) * (size_t)p->cap, c->stream));
@@ -1521,6 +1526,9 @@ int odr_advect_sea_ice(odr_ctx *c, odr_particles *p, double dt, double factor) {
 int odr_particles_set_property(odr_ctx *c, odr_particles *p, int slot, int64_t offset, int64_t count, const float *host) {
   p->epoch++;  // invalidates the cached reductions (reduce())
   REQUIRE(slot >= 0 && slot < 9 && host && offset >= 0 && count >= 0 && offset + count <= p->n, "bad property range");
+  if (slot == AUX_KMEMBER && p->kmember_on)
+    return fail(ODR_ERR_STATE, "property slot %d parks the member of an ensemble ocean_vertical_diffusivity on this particle set", slot);
+  p->aux_user |= 1u << slot;
   if (!p->aux[slot]) {
     HIPCHK(hipMalloc((void **)&p->aux[slot], sizeof(float) * (size_t)p->cap));
     HIPCHK(hipMemsetAsync(p->aux[slot], 0, sizeof(float) * (size_t)p->cap, c->stream));
@@ -2206,6 +2214,14 @@ int odr_scan_status_end(odr_ctx *c, odr_particles *p, int64_t *n_kept, uint64_t 
   p->scan_kept = (long long)c->scan_host[0];
   p->scan_epoch = p->status_epoch;   // (a guarded mixing launch between the halves deactivates nothing the fold has not seen: it
                                      // runs only when every element stays, and then there is nothing to compact)
+  return 0;
+}
+
+// The main-loop samples that follow treat the element positions as the reference's float32 arrays of the first
+// get_environment of a run (DevWorld::f32pos); 0 ends it.
+int odr_ctx_set_position_class(odr_ctx *c, int f32) {
+  const int v = f32 ? 1 : 0;
+  if (c->hw.f32pos != v) { c->hw.f32pos = v; c->dirty = true; }
   return 0;
 }
 

@@ -329,6 +329,11 @@ class Context:
     def unpin(self, array):
         check(self.lib.odr_host_unregister(self.h, C.c_void_p(np.asarray(array).ctypes.data)))
 
+    def set_position_class(self, float32):
+        """True: the main-loop samples that follow see the reference's float32 element arrays of the first get_environment of a run
+        (odr_ctx_set_position_class: modulate_longitude in float32); False ends it."""
+        check(self.lib.odr_ctx_set_position_class(self.h, 1 if float32 else 0))
+
     def set_stage_math(self, mode):
         """'exact' | 'fast': arithmetic of the Runge-Kutta stage evaluations (odr_ctx_set_stage_math, include/odrift.h)"""
         check(self.lib.odr_ctx_set_stage_math(self.h, _abi.STAGE_MATH[mode]))

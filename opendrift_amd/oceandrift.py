@@ -685,8 +685,19 @@ class OpenDriftSimulation(Configurable):
         stokes = sx in rv and self.get_config('drift:stokes_drift') is not False and not (iz(sx) and iz(sy))
         hdiff = 'horizontal_diffusivity' in rv and not iz('horizontal_diffusivity')
         mld = 'ocean_mixed_layer_thickness' in rv and self.get_config('drift:vertical_mixing') is True and \
-            self.get_config('vertical_mixing:diffusivitymodel', 'environment') not in ('environment', 'constant')
+            self._effective_diffusivity_model() not in ('environment', 'constant')
         return wind or stokes or hdiff or mld
+
+    def _effective_diffusivity_model(self):
+        """vertical_mixing:diffusivitymodel as vertical_mixing applies it: 'environment' without a reader that delivers
+        ocean_vertical_diffusivity is Large et al. (1994) (oceandrift.py:431-447) -- which consults the deepest mixed layer of
+        ALL elements, i.e. the step's collective must carry the reductions."""
+        model = self.get_config('vertical_mixing:diffusivitymodel', 'environment') if 'vertical_mixing:diffusivitymodel' in self._config \
+            else 'environment'
+        if model == 'environment' and not any(self.readers[n].sid is not None
+                                              for n in self.priority_list.get('ocean_vertical_diffusivity', []) if n in self.readers):
+            model = 'windspeed_Large1994'
+        return model
 
     def _calm_everywhere(self):
         """advect_wind returns at its `wind_speed.max() == 0` test (physics_methods.py:771-780) on every rank whatever the
@@ -1220,8 +1231,10 @@ class OpenDriftSimulation(Configurable):
         # of `ocean_vertical_diffusivity` AT the element is only ever exported: the mixing scheme works on the profiles,
         # oceandrift.py:428-449).  They are sampled when the result buffer holds them and in the last step of the run, so
         # that `o.environment` and `o.result` come out as the reference's.
+        stock_readers_of_it = isinstance(self, OceanDrift) and all(
+            getattr(type(self), m) is getattr(OceanDrift, m) for m in ('vertical_mixing', 'update_terminal_velocity', 'update'))
         unread = [v for v in getattr(self, '_export_only_variables', ()) if v in self.required_variables and
-                  v not in self._hist.variables and not self._can_be_missing([v])] if fused_lane else []
+                  v not in self._hist.variables and not self._can_be_missing([v])] if fused_lane and stock_readers_of_it else []
         if any(b.sid is not None and self.ctx._grids.get(b.sid, {}).get('members') for b in self.readers.values()):
             unread = []      # (ensemble data: the member numbering goes with the main-loop call as the reference makes it)
         # The mixing launch of the step enqueued before the host has read the status scan (vertical_mixing(_guarded=True)): when the
@@ -1240,6 +1253,13 @@ class OpenDriftSimulation(Configurable):
             ('x_wind' not in self.required_variables or self._calm_everywhere()) and
             (sx not in self.required_variables or self.get_config('drift:stokes_drift') is False or
              (self._identically_zero(sx) and self._identically_zero(sy))))
+        # the step's collective may be finished BEHIND update() only when update() cannot register a status category on its own
+        # (a subclass's vertical_mixing / update_terminal_velocity calling deactivate_elements would append it before the other
+        # ranks' categories on a deferring rank and after them on a blocking one: ADVICE round 5): the stock methods only
+        stock_update = isinstance(self, OD) and all(
+            getattr(cls, m) is getattr(OD, m) for m in ('update', 'vertical_mixing', 'vertical_advection', 'update_terminal_velocity',
+                                                        '_advect_wind_then_stokes_drift', 'advect_wind', 'stokes_drift',
+                                                        '_with_seafloor_action', 'vertical_buoyancy'))
         self._vmix_speculated = False
         self.ctx.sync()
         t_loop = [time.perf_counter(), None]      # main-loop wall time (the reference keeps 'main loop' timers, basemodel :2174)
@@ -1258,8 +1278,15 @@ class OpenDriftSimulation(Configurable):
                 e[0] += t - t_from
                 e[1] = max(e[1], t - t_from)
             return t
+        # Until the first update_positions of a run the reference's elements.lon / lat are float32 ARRAYS (elements.py:71-88):
+        # its first get_environment modulates the longitudes in float32 (variables.py:259-280, :914).  The main-loop sample of
+        # the steps up to the first one that moves elements does the same (odr_ctx_set_position_class); the Runge-Kutta stage
+        # calls inside update() work on float64 positions there and here.
+        f32_first = self.steps_calculation == 0
         for i in range(steps):
             try:
+                if f32_first:
+                    self.ctx.set_position_class(True)
                 if i == 1:
                     self.ctx.sync()
                     t_loop[1] = time.perf_counter()   # after the first step: seeding, first uploads and sort are behind
@@ -1277,6 +1304,8 @@ class OpenDriftSimulation(Configurable):
                 # device layout maintenance: re-sort by grid cell every sort_every steps and whenever a
                 # release added a sizeable share of new (unsorted) elements
                 n_act = self.num_elements_active()
+                if grid_sid is None:       # (gone after a failed re-cut of a reader's window: it may be back)
+                    grid_sid = next((b.sid for b in self.readers.values() if b.is_grid() and b.sid is not None), None)
                 if self.rng == 'device' and grid_sid is not None and sort_every and n_act > 65536 and \
                         (i % sort_every == 0 or self.newly_seeded * 20 > n_act):
                     # (the source id of a reader changes when its window is re-cut, and is gone when the re-cut failed)
@@ -1320,7 +1349,7 @@ class OpenDriftSimulation(Configurable):
                     want_red = self._needs_reductions()
                     early = None
                     if speculate and i % out_every != 0 and self.P.scan_status_begin():
-                        if self._world > 1 and not want_red and not os.environ.get('ODR_SYNC_COLLECTIVE'):
+                        if self._world > 1 and stock_update and not want_red and not os.environ.get('ODR_SYNC_COLLECTIVE'):
                             from . import distributed as D
                             if D.backend() == 'rccl':     # the step's ONE collective leaves behind the fold, ahead of the host's read
                                 early = self._step_summary(None, None, False, start_only=True, from_scan=True)
@@ -1337,7 +1366,7 @@ class OpenDriftSimulation(Configurable):
                     elif early is not None:      # a reason of this rank waits for its category: the collective is finished now
                         kept, flags = self._step_summary(None, None, False, handle=early)
                         self._resolve_status(flags)
-                    elif self._world > 1 and not want_red and flags == 0 and not os.environ.get('ODR_SYNC_COLLECTIVE'):
+                    elif self._world > 1 and stock_update and not want_red and flags == 0 and not os.environ.get('ODR_SYNC_COLLECTIVE'):
                         # sharded: nothing this rank does before the end of update() depends on the other ranks (no mover
                         # consults all-rank maxima, no element here carries a reason that waits for its category) -- the
                         # step's ONE collective is started here and finished behind the launches of update()
@@ -1432,13 +1461,19 @@ class OpenDriftSimulation(Configurable):
                 else:
                     g_active = self._g_active = self.num_elements_active()
                 t_ph = lap('bookkeeping', t_ph)
-                if g_active > 0:
-                    self.update()
-                    self._flush_elements()      # what a model's update() wrote into self.elements goes to the device
-                elif g_sched == 0:
-                    raise ValueError('No more active or scheduled elements, quitting.')
+                if f32_first:
+                    self.ctx.set_position_class(False)
+                    f32_first = not g_active > 0
+                try:
+                    if g_active > 0:
+                        self.update()
+                        self._flush_elements()      # what a model's update() wrote into self.elements goes to the device
+                    elif g_sched == 0:
+                        raise ValueError('No more active or scheduled elements, quitting.')
+                finally:
+                    if deferred is not None:    # an open collective is finished whatever update() did: the ranks stay in step
+                        g_kept, g_flags = self._step_summary(None, None, False, handle=deferred[0])
                 if deferred is not None:
-                    g_kept, g_flags = self._step_summary(None, None, False, handle=deferred[0])
                     self._resolve_status(g_flags, pending=deferred[1])
                     if g_kept == 0 and g_sched == 0:
                         raise ValueError('No more active or scheduled elements, quitting.')
@@ -1449,10 +1484,12 @@ class OpenDriftSimulation(Configurable):
                 self.steps_calculation += 1
                 t_ph = lap('update', t_ph)
             except Exception as e:
+                self.ctx.set_position_class(False)
                 if stop_on_error or self.steps_calculation <= 1:
                     raise
                 logger.warning('The simulation stopped before requested end time was reached: %s', e)
                 break
+        self.ctx.set_position_class(False)
         self.ctx.sync()
         t_end = time.perf_counter()
         self.timing = {'main_loop_s': t_end - t_loop[0], 'steps': self.steps_calculation,
@@ -1700,13 +1737,10 @@ class OceanDrift(OpenDriftSimulation):
             return
         if self.get_config('drift:vertical_mixing') is False:
             return False
-        model = self.get_config('vertical_mixing:diffusivitymodel')
-        if model == 'environment' and not any(self.readers[n].sid is not None
-                                              for n in self.priority_list.get('ocean_vertical_diffusivity', [])):
-            # no reader / constant for ocean_vertical_diffusivity: the profile is the fallback everywhere and the
-            # reference switches to Large et al. (1994) (oceandrift.py:431-447).  (A reader that is listed but covers
-            # no element at all would do the same there; here its fallback-filled profile is used.)
-            model = 'windspeed_Large1994'
+        # no reader / constant for ocean_vertical_diffusivity: the profile is the fallback everywhere and the reference switches
+        # to Large et al. (1994) (oceandrift.py:431-447).  (A reader that is listed but covers no element at all would do the same
+        # there; here its fallback-filled profile is used.)
+        model = self._effective_diffusivity_model()
         # drift:truncate_ocean_model_below_m with reader diffusivity profiles: the reference narrows the depth range it ASKS the
         # reader for -- profiles_depth = min(profiles_depth, truncate_depth), environment.py:560 -> basereader/structured.py:
         # 230-238 -- and mixes on the columns as they come.  A reader that ignores the z request hands out whole columns

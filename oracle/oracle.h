@@ -119,6 +119,7 @@ typedef struct {
 
 /* Environment.get_environment (environment.py:499-923) minus uncertainty noise:
  * out[v][i] float32, NaN where missing. */
+void orc_set_position_class(int f32);   /* step.c: float32 element arrays of the first get_environment of a run */
 void orc_get_environment(const orc_world *w, int nv, const int *vars, long n,
                          const double *lon, const double *lat, const double *z,
                          double t, float *const *out);

@@ -283,6 +283,12 @@ class WorldBuilder:
         return w
 
 
+def set_position_class(f32):
+    """The get_environment / get_profile calls that follow treat the positions as the reference's float32 element arrays of the
+    first step of a run (modulate_longitude in float32, variables.py:259-280 with elements.py:71-88); False ends it."""
+    lib().orc_set_position_class(C.c_int(1 if f32 else 0))
+
+
 def get_environment(world, variables, lon, lat, z, t):
     lon, lat, z = _d(lon), _d(lat), _d(np.broadcast_to(z, np.shape(lon)))
     n = lon.size

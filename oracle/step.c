@@ -212,6 +212,25 @@ static void bracket(const orc_source *s, double t, int *ib, int *ia) {
 
 /* one reader.get_variables_interpolated call (variables.py:860-920) for the
  * particles idx[0..m); out[v][j] float64 carrier, NaN = masked / not covered */
+/* The reference's element positions are float32 ARRAYS until the first update_positions of a run (elements/elements.py:71-88),
+ * so modulate_longitude (variables.py:259-280, called with the elements' lon in get_variables_interpolated :914) forms
+ * np.mod(lon + 180, 360) - 180 in float32 in that one get_environment call: the sample longitude is lon rounded to the float32
+ * grid of lon + 180.  orc_set_position_class(1) makes the calls that follow do the same (the test harness switches it on for
+ * the first main-loop sample of a replay and off again before the Runge-Kutta stage calls, whose positions are float64). */
+static int g_f32pos = 0;
+void orc_set_position_class(int f32) { g_f32pos = f32; }
+static double modulate_longitude(int lon_mode, double lo) {
+  if (g_f32pos) {
+    float l = (float)lo;
+    if (lon_mode == 1) { float a = l + 180.0f; a = (float)np_mod((double)a, 360.0); l = a - 180.0f; }   /* np.mod of float32 is exact */
+    else if (lon_mode == 2) l = (float)np_mod((double)l, 360.0);
+    return (double)l;
+  }
+  if (lon_mode == 1) return np_mod(lo + 180, 360) - 180;
+  if (lon_mode == 2) return np_mod(lo, 360);
+  return lo;
+}
+
 static void source_call(const orc_source *s, int nv, const int *vars, long m,
                         const long *idx, const double *lon, const double *lat,
                         const double *z, double t, double **out) {
@@ -228,8 +247,7 @@ static void source_call(const orc_source *s, int nv, const int *vars, long m,
   }
   for (j = 0; j < m; ++j) {
     double lo = lon[idx[j]], la = lat[idx[j]], xx, yy, xchk;
-    if (s->lon_mode == 1) lo = np_mod(lo + 180, 360) - 180; /* modulate_longitude */
-    else if (s->lon_mode == 2) lo = np_mod(lo, 360);
+    lo = modulate_longitude(s->lon_mode, lo);
     orc_proj_fwd(&s->proj, lo, la, &xx, &yy);
     xchk = xx;
     if (s->proj.kind == ORC_PROJ_LATLONG || s->proj.kind == ORC_PROJ_OB_TRAN) { /* covers_positions_xy re-modulates (crs.is_geographic, variables.py:246) */
@@ -411,8 +429,7 @@ void orc_get_profile(const orc_world *w, int var, long n, const double *lon,
     char *cov = (char *)malloc((size_t)n);
     for (i = 0; i < n; ++i) {
       double lo = lon[i], xx, yy;
-      if (s->lon_mode == 1) lo = np_mod(lo + 180, 360) - 180;
-      else if (s->lon_mode == 2) lo = np_mod(lo, 360);
+      lo = modulate_longitude(s->lon_mode, lo);
       orc_proj_fwd(&s->proj, lo, lat[i], &xx, &yy);
       cov[i] = xx >= s->xmin && xx <= s->xmax && yy >= s->ymin && yy <= s->ymax;
       if (s->mod360_x) xx = np_mod(xx, 360);

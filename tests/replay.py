@@ -25,6 +25,11 @@ LEEWAY_PROPS = ['downwind_slope', 'crosswind_slope', 'downwind_offset', 'crosswi
                 'crosswind_eps', 'jibe_probability', 'orientation', 'capsized']
 
 
+def _is_float32_state(lon, lat):
+    lon, lat = np.asarray(lon, dtype=np.float64), np.asarray(lat, dtype=np.float64)
+    return bool(np.array_equal(lon, lon.astype(np.float32)) and np.array_equal(lat, lat.astype(np.float32)))
+
+
 class OracleBackend:
     def __init__(self, scenario, lon, lat, z, wdf=0.02):
         self.sc = scenario
@@ -43,10 +48,18 @@ class OracleBackend:
 
     def sample(self, names, t, profile=None, nzp=0):
         w = self.sc.oracle_world()  # fresh blocks: the oracle's NaN dilation is stateful
-        vals = orc.get_environment(w, [V[k] for k in names], self.lon, self.lat, self.z, t)
-        self.env = dict(zip(names, vals))
-        if profile:
-            self.Kp = orc.get_profile(w, V[profile], self.lon, self.lat, t, nzp)
+        # the FIRST get_environment of a reference run works on float32 element arrays (elements.py:71-88 -> modulate_longitude
+        # in float32, variables.py:259-280): a replay that starts from the seeded state (float32 values) does the same
+        first = not getattr(self, '_sampled_once', False) and _is_float32_state(self.lon, self.lat)
+        self._sampled_once = True
+        orc.set_position_class(first)
+        try:
+            vals = orc.get_environment(w, [V[k] for k in names], self.lon, self.lat, self.z, t)
+            self.env = dict(zip(names, vals))
+            if profile:
+                self.Kp = orc.get_profile(w, V[profile], self.lon, self.lat, t, nzp)
+        finally:
+            orc.set_position_class(False)
         self._w = w
 
     def truncate(self, depth):   # drift:truncate_ocean_model_below_m (environment.py:554-566): the sampling calls see max(z, -depth)
@@ -235,9 +248,16 @@ class DeviceBackend:
         n = len(lon)
         self.P = ctx.particles(n)
         self.P.append(lon, lat, z=np.array(z, dtype=np.float64) * np.ones(n), wind_drift_factor=np.full(n, wdf, np.float32))
+        self._f32_state = _is_float32_state(lon, lat)
 
     def sample(self, names, t, profile=None, nzp=0):
-        self.P.env_sample(names, t)
+        first = not getattr(self, '_sampled_once', False) and self._f32_state      # (see OracleBackend.sample)
+        self._sampled_once = True
+        self.ctx.set_position_class(first)
+        try:
+            self.P.env_sample(names, t)
+        finally:
+            self.ctx.set_position_class(False)
 
     def truncate(self, depth):
         self.P.truncate_z(depth)

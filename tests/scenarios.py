@@ -24,6 +24,23 @@ def _orc_proj(proj):
                          x0=proj.get('x0', 0.0), y0=proj.get('y0', 0.0), lat1=proj.get('lat1', 0.0), lat2=proj.get('lat2'))
 
 
+def reference_lon_mode(a):
+    """modulate_longitude's branch for a grid source (variables.py:259-280): the true longitudes of the four corners of the
+    reader's domain -- some negative: np.mod(lon + 180, 360) - 180 (1), else np.mod(lon, 360) (2).  In float64 the two agree
+    on [0, 180); in the float32 arithmetic of a run's first get_environment (elements.py:71-88) they do not."""
+    if a.get('lon_mode') is not None:
+        return a['lon_mode']
+    x, y = np.asarray(a['x'], dtype=np.float64), np.asarray(a['y'], dtype=np.float64)
+    xx = np.array([x.min(), x.min(), x.max(), x.max()])
+    yy = np.array([y.min(), y.max(), y.max(), y.min()])
+    proj = a.get('proj')
+    if proj is None or proj.get('kind', 'latlong') == 'latlong':
+        exlons = xx
+    else:
+        exlons, _ = orc.proj_inv(_orc_proj(proj), xx, yy)
+    return 1 if np.min(exlons) < 0 else 2
+
+
 class Scenario:
     def __init__(self, sources, fallbacks=None, priority=None):
         self.sources, self.fallbacks, self.priority = sources, fallbacks or {}, priority or {}
@@ -40,7 +57,7 @@ class Scenario:
             elif kind == 'grid':
                 levels = [(t, {V[k]: arr for k, arr in arrays.items()}) for t, arrays in a['levels']]
                 wb.add_grid(_orc_proj(a.get('proj')), a['x'], a['y'], levels, z=a.get('z'),
-                            lon_mode=a.get('lon_mode', 1), mod360_x=a.get('mod360_x', 0),
+                            lon_mode=reference_lon_mode(a), mod360_x=a.get('mod360_x', 0),
                             time_coverage=a.get('time_coverage'))
         for k, v in self.fallbacks.items():
             wb.set_fallback(V[k], v)
@@ -68,7 +85,7 @@ class Scenario:
                 names = [a['variable']]
             else:
                 sid = ctx.add_grid(a['x'], a['y'], z=a.get('z'), proj=a.get('proj'),
-                                   lon_mode=a.get('lon_mode', 1), mod360_x=a.get('mod360_x', 0))
+                                   lon_mode=reference_lon_mode(a), mod360_x=a.get('mod360_x', 0))
                 for slot, (t, arrays) in enumerate(a['levels']):
                     ctx.upload_block(sid, slot, t, arrays)
                 if a.get('time_coverage') is not None:

@@ -996,7 +996,7 @@ def test_c20_lambert_and_mercator_readers_reproduce_the_reference(tag, stage_mat
     # float32 -- the sample position of that one step is off by up to 7.6e-6 deg, the step's displacement by ~3e-8 deg
     # (median) ... 2.7e-7 deg (worst element, measured; it does not grow afterwards).  The device modulates in float64
     # (deviations): inside the 1e-6 deg of the north star, outside the 1e-7 the other goldens are held to.
-    assert dmax < (4e-7 if tag == 'lcc_wgs84' else 1e-7)
+    assert dmax < 1e-7
     assert o.num_elements_deactivated() == int((status[nst] != 0).sum()) > 5
 
 

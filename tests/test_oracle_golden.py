@@ -360,7 +360,7 @@ def test_c20_lambert_and_mercator_golden_vs_oracle(tag):
     sub = {k: g['%s_%s' % (tag, k)] for k in ('lon', 'lat', 'z', 'status')}
     nst = sub['lon'].shape[0] - 1
     B = replay.OracleBackend(replay.scenario_c20(g, tag), sub['lon'][0], sub['lat'][0], sub['z'][0], wdf=float(g['wdf']))
-    worst = replay.compare(replay.replay_c20(B, g, tag, nst), sub, tol_pos=4e-7 if tag == 'lcc_wgs84' else 1e-7)
+    worst = replay.compare(replay.replay_c20(B, g, tag, nst), sub, tol_pos=1e-7)
     assert (sub['status'][nst] != 0).sum() > 5
     print('c20', tag, 'oracle vs reference:', worst)
 
