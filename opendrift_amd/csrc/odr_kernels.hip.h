@@ -1035,11 +1035,10 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
     EnvExport X;
     X.valid = false; X.n00 = X.n11 = 0; X.iz0 = 0;
     X.combine = IS3D && SM == 1;
-    // (first get_environment of a run: the reference's float32 element arrays, DevWorld::f32pos -- wave-uniform, rare)
-    const double lon_s = W->f32pos ? lon_f32class(W->src[G.sid].lon_mode, lon) : lon;
-    env_group_fast<PROJ, true, IS3D>(*W, G, lon_s, lat, z, out, zt, zb_env, &X ODR_PT_ARG);
-    UVKeep<IS3D> K = uv_keep_from_sm<IS3D, SM>(G, X, th, zb_env, W->src[G.sid].nz, true);
-    if (lon_s != lon) K.valid = false;      // the kept records belong to another position than the stages start from   // (FAST, 3-D: combined over the bracket's levels)
+    // (DevWorld::f32pos -- the float32 element arrays of a run's first get_environment -- never reaches this launch: the host
+    // takes the separate launches then, odr_step.hip; three more values live across the sample cost this kernel 0.61 -> 0.79 ms)
+    env_group_fast<PROJ, true, IS3D>(*W, G, lon, lat, z, out, zt, zb_env, &X ODR_PT_ARG);
+    UVKeep<IS3D> K = uv_keep_from_sm<IS3D, SM>(G, X, th, zb_env, W->src[G.sid].nz, true);   // (FAST, 3-D: combined over the bracket's levels)
     if constexpr (STATE_LATE) load_state();
     ODR_PT_USE(out[0]); ODR_PT_USE(out[1]); ODR_PT_USE(out[2]); ODR_PT_USE(out[3]); ODR_PT_USE(out[4]); ODR_PT(2);
     const int id = (NOISE || MIXQ > 0) ? p.id[i] : 0;
@@ -1055,7 +1054,7 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
       if (k < G.nv) G.out_ptr[k][i] = out[k];
 #endif
     if (MIXQ == 0) {   // the sample position is what odr_vmix gathers its profiles at: not needed when the mixing is in here
-      p.slon[i] = lon_s;
+      p.slon[i] = lon;
       p.slat[i] = lat;
     }
 #endif
@@ -2999,8 +2998,7 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_leeway(const De
     const int id = p.id[i];
     float out[MAXG];
     ZBracket zb;
-    const double lon_s = W->f32pos ? lon_f32class(W->src[G.sid].lon_mode, lon) : lon;   // first get_environment of a run (DevWorld::f32pos)
-    env_group_fast<PROJ, true, false>(*W, G, lon_s, lat, z, out, nullptr, zb);
+    env_group_fast<PROJ, true, false>(*W, G, lon, lat, z, out, nullptr, zb);   // (DevWorld::f32pos: the host takes the separate launches)
     float xw = pick_slot(out, S.wind_slot), yw = pick_slot(out, S.wind_slot + 1);
     float u = pick_slot(out, S.uv_slot), v = pick_slot(out, S.uv_slot + 1);
     // environment.py:869-891: env[x] += N(0, std) (float32 array += float64 draws), first the current, then the wind
@@ -3024,7 +3022,7 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_leeway(const De
       else if (k == S.uv_slot) val = u; else if (k == S.uv_slot + 1) val = v;
       G.out_ptr[k][i] = val;
     }
-    p.slon[i] = lon_s;
+    p.slon[i] = lon;
     p.slat[i] = lat;
     if (S.missing_code) {  // k_deactivate_missing (a NaN stays one under the uncertainty draws)
       bool miss = false;

@@ -220,7 +220,9 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
   }
   EnvGroupDesc G;
   int sid = -1;
-  bool fuse = p->n > 0 && !getenv("ODR_NO_FAST_PATH") && same_list(VAR_V, VAR_U) && ng <= MAXG && nmg <= 4 && nmr <= 4 &&
+  // (odr_ctx_set_position_class: the float32 element arrays of a run's first get_environment take the separate launches -- the
+  // sample kernels know the float32 longitude modulation, the step launch is kept free of it)
+  bool fuse = p->n > 0 && !c->hw.f32pos && !getenv("ODR_NO_FAST_PATH") && same_list(VAR_V, VAR_U) && ng <= MAXG && nmg <= 4 && nmr <= 4 &&
               uv_fast_source(c, sid, t < t + dt ? t : t + dt, t < t + dt ? t + dt : t) &&
               build_env_group(c, grp, ng, t, G) && G.sid == sid && G.burst;   // k_step_grid carries the burst sampler only
   mark(1);

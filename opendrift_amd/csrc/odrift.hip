@@ -1628,7 +1628,7 @@ int odr_env_coast_leeway(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
     if (same_list(v, VAR_U)) grp[ng++] = v; else rest[nrest++] = v;
   }
   EnvGroupDesc G;
-  const bool fuse = p->n > 0 && !getenv("ODR_NO_FAST_PATH") && same_list(VAR_XWIND, VAR_U) && same_list(VAR_YWIND, VAR_U) &&
+  const bool fuse = p->n > 0 && !c->hw.f32pos && !getenv("ODR_NO_FAST_PATH") && same_list(VAR_XWIND, VAR_U) && same_list(VAR_YWIND, VAR_U) &&
                     same_list(VAR_V, VAR_U) && ng <= MAXG && build_env_group(c, grp, ng, t, G) && G.burst;
   if (!fuse) {
     if ((rc = odr_env_sample(c, p, nvars, var_ids, t, nullptr))) return rc;

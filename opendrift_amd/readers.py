@@ -963,14 +963,13 @@ class DeviceReaderBinding:
         elif self.sid is None:
             proj = projection.parse_proj4(r.proj4)
             zz = np.atleast_1d(bz) if bz is not None and np.size(bz) > 1 else None
-            lon_mode = 1
-            if proj['kind'] == 'latlong' and r.xmin is not None and r.xmin >= 0 and r.xmax > 180:
-                lon_mode = 2
-            if proj['kind'] == 'ob_tran':
-                # modulate_longitude (variables.py:259-280) decides on the TRUE longitudes of the domain's corners, and a
-                # rotated-pole reader's x is modulated the same way once more for the coverage test (crs.is_geographic, :246)
-                exlons, _ = r.xy2lonlat(np.array([r.xmin, r.xmin, r.xmax, r.xmax]), np.array([r.ymin, r.ymax, r.ymax, r.ymin]))
-                lon_mode = 1 if np.min(exlons) < 0 else 2
+            # modulate_longitude (variables.py:259-280) decides on the TRUE longitudes of the domain's corners: some negative ->
+            # np.mod(lon + 180, 360) - 180, else np.mod(lon, 360) (a rotated-pole reader's x is modulated the same way once more
+            # for the coverage test: crs.is_geographic, :246).  In float64 the two branches agree on [0, 180); in the float32
+            # arithmetic of a run's first get_environment (odr_ctx_set_position_class) they do not.
+            exlons, _ = r.xy2lonlat(np.array([r.xmin, r.xmin, r.xmax, r.xmax], dtype=np.float64),
+                                    np.array([r.ymin, r.ymax, r.ymax, r.ymin], dtype=np.float64))
+            lon_mode = 1 if np.min(exlons) < 0 else 2
             dom = (float(r.xmin), float(r.xmax), float(r.ymin), float(r.ymax), float(r.zmin), float(r.zmax))
             if extent is not None:     # blocks cut to the simulation extent: the source covers what the blocks cover
                 dom = (max(dom[0], float(np.min(bx))), min(dom[1], float(np.max(bx))), max(dom[2], float(np.min(by))),
