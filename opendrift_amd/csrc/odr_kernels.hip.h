@@ -457,6 +457,10 @@ __device__ __forceinline__ void vmix_col_fill(const DevSource &s, const VMixDesc
     }
     if (q == 0) hook();
     double v[4];
+#ifdef ODR_ABL_VMIX_FILLMATH   // what-if build (wrong values): the column's layer values without their float64 arithmetic
+    v[0] = (double)(b00.x + b11.x); v[1] = (double)(b00.y + b11.y); v[2] = (double)(b00.z + b11.z); v[3] = (double)(b00.w + b11.w);
+    if (TL) { v[0] += (double)a00.x; v[1] += (double)a01.y; v[2] += (double)a10.z; v[3] += (double)a11.w; }
+#else
     v[0] = (double)bilw(b00.x, b01.x, b10.x, b11.x, w00, w01, w10, w11);
     v[1] = (double)bilw(b00.y, b01.y, b10.y, b11.y, w00, w01, w10, w11);
     v[2] = (double)bilw(b00.z, b01.z, b10.z, b11.z, w00, w01, w10, w11);
@@ -470,6 +474,7 @@ __device__ __forceinline__ void vmix_col_fill(const DevSource &s, const VMixDesc
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = __dadd_rn(__dmul_rn(v[j], 1 - wgt), __dmul_rn(w[j], wgt));
     }
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) Kp[(4 * q + j) * BLOCK + tid] = (cov && isfinite(v[j])) ? v[j] : Kfb;
   }
@@ -525,7 +530,9 @@ __device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, con
   const double gd0 = s.vg_d[0], gi0 = s.vg_id[0], gd1 = s.vg_d[1], gi1 = s.vg_id[1], gd2 = s.vg_d[2], gi2 = s.vg_id[2];
   const double sgn = dt > 0 ? 1.0 : (dt < 0 ? -1.0 : 0.0);
   const double dt_mix = A.dt_mix_cfg * sgn;
-#ifdef ODR_ABL_VMIX_NT   // what-if build: fewer sub-steps
+#ifdef ODR_ABL_VMIX_NOLOOP   // what-if build: no sub-steps, the window's level terms still formed (they flow into z below)
+  const int ntimes = 0;
+#elif defined(ODR_ABL_VMIX_NT)   // what-if build: fewer sub-steps
   const int ntimes = ODR_ABL_VMIX_NT;
 #else
   const int ntimes = abs((int)(dt / dt_mix));
@@ -572,6 +579,9 @@ __device__ __forceinline__ double vmix_col_walk(const DevSource &s, int nzp, con
     c_dk[q] = 0; c_sg[q] = 0;
     if (zl >= 0 && zl < nzp) level_terms(zl, c_dk[q], c_sg[q]);
   }
+#ifdef ODR_ABL_VMIX_NOLOOP
+  z += 1e-30 * (c_dk[0] + c_dk[1] + c_dk[2] + c_sg[0] + c_sg[1] + c_sg[2]);
+#endif
   // The level of a sub-step is the number of boundaries below d (odd ones count when d >= zm, even ones when d > zm).
   // Inside the cached window only the window's own four boundaries decide -- lv0 - 2 ... lv0 + 1, per lane, with the
   // ">=" of the odd ones folded into the value (d >= b  <=>  d > the double just below b; b > 0) -- four compares

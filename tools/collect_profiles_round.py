@@ -3,7 +3,7 @@
 profiles/<R>_<workload>_pmc[_exact].json, which bench.py reads for the roofline objects (PMC counters cannot be collected from
 inside the bench process).
 
-    [R=r05] python tools/collect_profiles_round.py [stage_math]
+    [R=r06] python tools/collect_profiles_round.py [stage_math]
 
 FETCH_SIZE: MI355X_MICROARCH.md (HBM section): gfx950's rocprofv3 reports 1/2 of the bytes of a coalesced streaming read; the
 factor is calibrated on this code's own 8-byte streams (k_sort_hist reads lon and lat of every particle once) and stored
@@ -16,7 +16,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = os.environ.get('R', 'r05')
+R = os.environ.get('R', 'r06')
 SM = sys.argv[1] if len(sys.argv) > 1 else 'fast'
 SFX = '' if SM == 'fast' else '_' + SM
 src, dst = os.path.join(ROOT, 'gpurun_out', 'prof_' + R + SFX), os.path.join(ROOT, 'profiles')

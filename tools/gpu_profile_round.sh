@@ -1,10 +1,10 @@
 #!/bin/bash
-# The profiles of a round (run on the GPU box from the repo root: [R=r05] [ODR_STAGE_MATH=exact] tools/gpu_profile_round.sh [workloads]):
+# The profiles of a round (run on the GPU box from the repo root: [R=r06] [ODR_STAGE_MATH=exact] tools/gpu_profile_round.sh [workloads]):
 #   kernel stats (rocprofv3 --kernel-trace --stats) and PMC passes of the c3 / c4 / c5 bench -- every counter set in its own
 #   run with --kernel-trace only (MI355X_MICROARCH.md, HBM / rocprofv3 sections) -- and the kernel stats of OceanDrift.run() on
 #   the c3 inputs.  Everything lands under gpurun_out/prof_$R[_exact]; tools/collect_profiles_round.py copies the summaries into profiles/.
 #   Every rocprofv3 pass runs under `timeout`: a counter set rocprofv3 chokes on must not eat the round's GPU minutes.
-R=${R:-r05}
+R=${R:-r06}
 SFX=""; [ "${ODR_STAGE_MATH:-fast}" = exact ] && SFX=_exact
 P=$GRAFT_REPO_ROOT/gpurun_out/prof_$R$SFX
 mkdir -p $P
