@@ -251,7 +251,7 @@ class Workload:
         P.vmix(self.time_of(k), self.dt, self.dt_mix, step=k, fuse_vertical_advection=False)
 
 
-def cpu_baseline(name, fields, n_cpu, rng):
+def cpu_baseline(name, fields, n_cpu, rng, small=False):
     """The CPU oracle (C port of the reference path) on a bounded sample of the workload: one core (the reference is
     single-threaded by design, docs/source/performance.rst:22), and all host cores as independent simulations with
     n_cpu particles each (the quasi-parallel mode the reference's documentation suggests, performance.rst:36)."""
@@ -274,11 +274,31 @@ def cpu_baseline(name, fields, n_cpu, rng):
         # copy-on-write into every child (a child only writes the pages its own particles make the oracle dilate, as the
         # reference's cached blocks are dilated lazily); round 5 gave every simulation its own copy and stopped at 64 cores.
         # The children never touch the GPU runtime and leave through os._exit.
+        # ... forked from a HELPER process (`bench.py --cpu-all-cores-helper`), not from this one: this process holds the HIP
+        # runtime and its threads, and a child forked while one of them holds a lock (malloc's) never wakes up.  The helper has
+        # one thread, builds the same world from the same seeds and forks the simulations.
         try:
-            out['all_cores'] = _cpu_all_cores(name, fields, n_cpu, step1.keep_alive, cores, host_cores)
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), '--cpu-all-cores-helper', '--workload', name, '--cpu-particles', str(n_cpu),
+                   '--cpu-cores', str(cores)] + (['--small'] if small else [])
+            env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=float(os.environ.get('ODR_CPU_ALL_TIMEOUT', 240)), env=env)
+            line = [ln for ln in pr.stdout.splitlines() if ln.startswith('{')]
+            if pr.returncode != 0 or not line:
+                raise RuntimeError('helper failed: ' + pr.stderr[-300:])
+            out['all_cores'] = json.loads(line[-1])
         except Exception as e:      # noqa: BLE001 -- a reported side leg must not take the bench line with it
             out['all_cores'] = dict(value=None, cores=0, host_cores=host_cores, note='not measured: %r' % (e,))
     return out
+
+
+def cpu_all_cores_helper(a):
+    """`bench.py --cpu-all-cores-helper`: the all-cores leg of cpu_baseline in a process of its own (one thread, no GPU runtime)."""
+    fields = make_fields(a.workload, a.small)
+    step1 = _cpu_stepper(a.workload, fields, a.cpu_particles, np.random.default_rng(5))
+    host_cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    print(json.dumps(_cpu_all_cores(a.workload, fields, a.cpu_particles, step1.keep_alive, a.cpu_cores or host_cores, host_cores)), flush=True)
+    return 0
 
 
 def _cpu_all_cores(name, fields, n_cpu, world, cores, host_cores):
@@ -618,6 +638,8 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip the model_api and pcie_inclusive legs')
     ap.add_argument('--host-sort', action='store_true', help='experiment: seed particles already sorted by grid cell')
     ap.add_argument('--cpu-particles', type=int, default=200000)
+    ap.add_argument('--cpu-all-cores-helper', action='store_true', help='(internal) the all-cores CPU leg in a process of its own')
+    ap.add_argument('--cpu-cores', type=int, default=0)
     ap.add_argument('--block-every', type=int, default=0,
                     help='re-upload one field time level from host memory every N steps inside the timed region '
                          '(PCIe-inclusive rate, DESIGN.md section 5; 0 = inputs resident, the headline)')
@@ -630,6 +652,8 @@ def main():
                     help='rendezvous, shards, block broadcast and the reductions of the N-rank run without the device path '
                          '(no GPU needed; value is null)')
     a = ap.parse_args()
+    if a.cpu_all_cores_helper:
+        sys.exit(cpu_all_cores_helper(a))
     # C2 (1 M particles, two launches of 50 + 15 us per step): 400 steps are 30-70 ms -- inside the time the GPU takes to leave
     # its idle clocks after the host-side set-up (the first timed loop of the process measured 0.16-0.18 ms per step, the
     # second 0.074).  Its defaults are long enough to measure the steady state; the other workloads keep 400 / 3.
@@ -983,7 +1007,7 @@ def main():
             out['stage_math_' + other_mode] = other
         out.update(extras)
         if not a.no_cpu and world == 1:
-            out['cpu_baseline'] = cpu_baseline(a.workload, fields, a.cpu_particles, np.random.default_rng(5))
+            out['cpu_baseline'] = cpu_baseline(a.workload, fields, a.cpu_particles, np.random.default_rng(5), small=a.small)
             refs = [os.path.join(ROOT, 'profiles', '%s_cpu_reference_numpy.json' % r) for r in ('r06', 'r02')]   # newest first
             ref = next((f for f in refs if os.path.exists(f)), refs[-1])
             if a.workload == 'c3' and os.path.exists(ref):   # the reference's own NumPy path, timed where /root/reference exists
