@@ -57,3 +57,19 @@ def test_single_process_default_is_one_rank():
     d = json.loads(lines[-1])
     assert d['n_gpus'] == 1 and d['config']['workload'] == 'c4'
     assert d['comm']['nranks_seen'] == 1 and d['comm']['backend'] is None
+
+
+def test_cpu_baseline_uses_every_host_core_with_shared_blocks(monkeypatch):
+    """cpu_baseline.all_cores (the reference's quasi-parallel mode on ALL host cores, count stated): one
+    oracle simulation per core, forked from a helper process that holds the field blocks once (copy-on-write) -- not from the
+    bench process, which holds the GPU runtime and its threads."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv('ODR_CPU_ALL_SECONDS', '1')
+    f = bench.make_fields('c3', small=True)
+    out = bench.cpu_baseline('c3', f, 500, np.random.default_rng(1), small=True)
+    cores = len(os.sched_getaffinity(0))
+    assert out['cores'] == 1 and out['kind'] == 'port' and out['value'] > 0
+    a = out['all_cores']
+    assert a['cores'] == a['host_cores'] == cores and a['value'] > out['value'] * 0.5, a
