@@ -313,7 +313,9 @@ def _cpu_all_cores(name, fields, n_cpu, world, cores, host_cores):
         if pid == 0:
             try:
                 os.close(r)
-                stp = _cpu_stepper(name, fields, n_cpu, np.random.default_rng(100 + j), world=world, warm=False)
+                # (the warm-up step of every simulation is untimed, as the single-core figure's is: it performs the reference's lazy
+                # NaN dilation of the cached blocks -- here on the child's copy-on-write pages, 30 s with 256 children at once)
+                stp = _cpu_stepper(name, fields, n_cpu, np.random.default_rng(100 + j), world=world, warm=True)
                 while time.time() < start_at:
                     time.sleep(0.001)
                 k, t0 = 0, time.perf_counter()

@@ -528,6 +528,10 @@ int odr_reduce_unpin(odr_ctx *ctx);
  * lon + 180 (up to 8e-6 deg off).  f32 != 0: the main-loop samples that follow (odr_env_sample, odr_env_coast_advect,
  * odr_env_coast_leeway; not the Runge-Kutta stage calls, whose positions are float64 there) do the same; 0 ends it. */
 int odr_ctx_set_position_class(odr_ctx *ctx, int f32);
+/* The reader's x / y coordinate arrays are float32: in the float32 position class the index maps of a GEOGRAPHIC reader --
+ * (x - xgrid[0]) / (xgrid[-1] - xgrid[0]) * (len - 1), interpolators.py:110-111, and the nearest-node map :32-37 -- are then
+ * float32 arithmetic as well (x is the float32 longitude itself); projected readers get float64 x, y from pyproj. */
+int odr_source_set_coordinate_dtype(odr_ctx *ctx, int32_t source_id, int x_is_float32, int y_is_float32);
 
 /* ---------------------------------------------------------------- communication of a sharded run
  * One process per GPU; the reference has no multi-process mode (docs/source/performance.rst:22,36 suggests running several

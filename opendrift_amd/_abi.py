@@ -151,6 +151,7 @@ _SIGNATURES = {
     'odr_compact': [_vp, _vp, _i64p],
     # communication (csrc/odr_comm.hip: RCCL, one communicator pair per process)
     'odr_ctx_set_position_class': [_vp, C.c_int],
+    'odr_source_set_coordinate_dtype': [_vp, C.c_int32, C.c_int, C.c_int],
     'odr_device_count': [_P(C.c_int32)],
     'odr_comm_unique_id': [_P(C.c_uint8)],
     'odr_comm_init': [_vp, _P(C.c_uint8), C.c_int32, C.c_int32],

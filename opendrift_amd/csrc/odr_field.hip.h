@@ -17,12 +17,14 @@ __device__ unsigned long long g_phase[32];
 #define ODR_PT_USE(x) asm volatile("" :: "v"(x))
 #define ODR_PT_ARG , pt_
 #define ODR_PT_PARAM , unsigned long long *pt_ = nullptr
+#define ODR_PT_NULLARG , nullptr
 #else
 #define ODR_PT_DECL
 #define ODR_PT(k)
 #define ODR_PT_USE(x)
 #define ODR_PT_ARG
 #define ODR_PT_PARAM
+#define ODR_PT_NULLARG
 #endif
 
 constexpr int NVAR = 26;
@@ -109,7 +111,9 @@ struct DevSource {
   // their reciprocals, and the second-order coefficients of non-uniform interior levels
   double vg_d[3], vg_id[3];
   double vg_a[MAXNZ], vg_b[MAXNZ], vg_c[MAXNZ];
-  int vg_uniform, vg_pad;
+  int vg_uniform;
+  int xy_f32;   // bit 0 / 1: the reader's x / y coordinate arrays are float32 (odr_source_set_coordinate_dtype): with DevWorld::f32pos
+                // the index maps of a geographic reader are float32 arithmetic (index_f32 below)
   double zmid[MAXNZ];  // mid-depths -(z[k] + z[k+1])/2 formed as d[k] + 0.5*(d[k+1]-d[k]), d = -z (k_vmix level search)
   int level_slot[MAXLEVELS];  // slots sorted by time
   // > 1: the reader hands the variable out as a LIST of ensemble members (readers/interpolation/structured.py:119-135);
@@ -125,7 +129,8 @@ struct DevWorld {
   // get_environment of a run (elements/elements.py:71-88: lon / lat are float32 until the first update_positions) --
   // modulate_longitude (variables.py:259-280, :914) then forms np.mod(lon + 180, 360) - 180 in float32: the sample longitude is
   // lon on the float32 grid of lon + 180 (lon_f32class).  The Runge-Kutta stage positions are float64 in the reference.
-  int f32pos;
+  int f32pos;   // bit 0: the main-loop samples (odr_ctx_set_position_class); bit 1: set by odr_vmix for its launch when the step's profiles
+                // were sampled in that class (k_vmix: float32 index maps of the K column's footprint)
   int nlist[NVAR];
   int list[NVAR][MAXLIST];
   float fallback[NVAR];
@@ -836,6 +841,19 @@ __device__ __forceinline__ float bilinear_f32(const float *__restrict__ a, int n
   return (float)t;
 }
 
+// The index maps of the 2-D interpolators -- (x - xgrid[0]) / (xgrid[-1] - xgrid[0]) * (len - 1), interpolators.py:110-111, and
+// round((x - xgrid.min()) / (xgrid.max() - xgrid.min()) * len), :32-37 -- in FLOAT32 arithmetic: what NumPy evaluates in a run's
+// first get_environment, when the elements' lon / lat are float32 arrays (elements.py:71-88), on a geographic reader (x IS the
+// longitude) whose coordinate arrays are float32 as well (DevSource::xy_f32).  The Python int is weak: float32 throughout.
+__device__ __forceinline__ double index_f32(double v, double v0, double span, int n) {
+  return (double)__fmul_rn(__fdiv_rn(__fsub_rn((float)v, (float)v0), (float)span), (float)n);
+}
+__device__ __forceinline__ int nearest_index_f32(double v, double vmin, double vrange, int n) {
+  const float r = rintf((float)index_f32(v, vmin, vrange, n));
+  if (!(r >= 0) || r >= (float)n) return n - 1;
+  return (int)r;
+}
+
 __device__ __forceinline__ int nearest_index(double v, double vmin, double vrange, double ivrange, int n) {
   double r = rint(__dmul_rn(div_cr(v - vmin, vrange, ivrange), (double)n));
   if (!(r >= 0) || r >= n) return n - 1;
@@ -882,7 +900,7 @@ __device__ __forceinline__ void zinterp(const DevSource &s, double z, int &ia, i
 
 // value of one variable from one block; f32class = the reference hands back float32 (2D layer)
 __device__ __forceinline__ double block_value(const DevBlock &b, const DevSource &s, int var,
-                                              double x, double y, double z, bool &f32class, int rank = 0) {
+                                              double x, double y, double z, bool &f32class, int rank = 0, int f32idx = 0) {
   const float *d = b.data[var];
   int nzv = b.var_nz[var];
   const int es = b.es[var];
@@ -893,12 +911,12 @@ __device__ __forceinline__ double block_value(const DevBlock &b, const DevSource
   }
   if (var == VAR_LAND) {
     f32class = true;
-    int xi = nearest_index(x, b.xmin, b.xrange, b.ixrange, b.nx);
-    int yi = nearest_index(y, b.ymin, b.yrange, b.iyrange, b.ny);
+    int xi = (f32idx & 1) ? nearest_index_f32(x, b.xmin, b.xrange, b.nx) : nearest_index(x, b.xmin, b.xrange, b.ixrange, b.nx);
+    int yi = (f32idx & 2) ? nearest_index_f32(y, b.ymin, b.yrange, b.ny) : nearest_index(y, b.ymin, b.yrange, b.iyrange, b.ny);
     return d[((size_t)yi * b.nx + xi) * ns];
   }
-  double xi = __dmul_rn(div_cr(x - b.x0, b.xspan, b.ixspan), (double)(b.nx - 1));
-  double yi = __dmul_rn(div_cr(y - b.y0, b.yspan, b.iyspan), (double)(b.ny - 1));
+  double xi = (f32idx & 1) ? index_f32(x, b.x0, b.xspan, b.nx - 1) : __dmul_rn(div_cr(x - b.x0, b.xspan, b.ixspan), (double)(b.nx - 1));
+  double yi = (f32idx & 2) ? index_f32(y, b.y0, b.yspan, b.ny - 1) : __dmul_rn(div_cr(y - b.y0, b.yspan, b.iyspan), (double)(b.ny - 1));
   if (nzv <= 1) {
     f32class = true;
     return bilinear_f32(d, b.ny, b.nx, ns, yi, xi);
@@ -990,6 +1008,7 @@ __device__ __forceinline__ bool source_sample(const DevSource &s, const int (&va
   } else {
     // StructuredReader._get_variables_interpolated_ (structured.py:202-400)
     if (s.mod360_x) x = np_mod(x, 360.0);
+    const int f32idx = (f32pos && s.proj.kind == PROJ_LATLONG) ? s.xy_f32 : 0;    // (index_f32)
     int ib, ia;
     bracket(s, t, ib, ia);
     bool all_static = true;
@@ -1002,7 +1021,7 @@ __device__ __forceinline__ bool source_sample(const DevSource &s, const int (&va
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         bool f32c;
-        val[v] = block_value(bb, s, vars[v], x, y, z, f32c, rank);
+        val[v] = block_value(bb, s, vars[v], x, y, z, f32c, rank, f32idx);
       }
     } else {
       const DevBlock &ba = s.slot[ia];
@@ -1010,8 +1029,8 @@ __device__ __forceinline__ bool source_sample(const DevSource &s, const int (&va
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         bool fb, fa;
-        double vb = block_value(bb, s, vars[v], x, y, z, fb, rank);
-        double va = block_value(ba, s, vars[v], x, y, z, fa, rank);
+        double vb = block_value(bb, s, vars[v], x, y, z, fb, rank, f32idx);
+        double va = block_value(ba, s, vars[v], x, y, z, fa, rank, f32idx);
         if (fb && fa) {  // float32 arrays * python floats stay float32 (:362-364)
           float pq = __fadd_rn(__fmul_rn((float)vb, (float)(1 - w)), __fmul_rn((float)va, (float)w));
           val[v] = pq;
@@ -2023,10 +2042,13 @@ __device__ __forceinline__ void env_burst(const DevSource &s, const EnvGroupDesc
 
 // The reader front door of the main-loop sample (longitude convention, projection, coverage, fractional grid indices):
 // computed once per particle; k_step_tile also takes the footprint rectangle of its workgroup from it.
-struct EnvFront { double x, y, xi, yi; bool covered; };
+struct EnvFront { double x, y, xi, yi; bool covered; int f32idx; };
+// f32idx (k_env_grid in a run's first get_environment: DevWorld::f32pos on a geographic reader with float32 coordinate arrays,
+// DevSource::xy_f32): the index maps in float32 arithmetic (index_f32).  Every other caller leaves it at 0, a compile-time constant.
 template <int PROJ>
-__device__ __forceinline__ EnvFront env_front(const DevSource &s, const DevBlock &geo, double lon, double lat, double z) {
+__device__ __forceinline__ EnvFront env_front(const DevSource &s, const DevBlock &geo, double lon, double lat, double z, int f32idx = 0) {
   EnvFront f;
+  f.f32idx = f32idx;
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
   else if (s.lon_mode == 2) lon = np_mod(lon, 360.0);
   double x, y;
@@ -2037,8 +2059,8 @@ __device__ __forceinline__ EnvFront env_front(const DevSource &s, const DevBlock
   f.covered = xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin && z <= s.zmax;
   if (s.mod360_x) x = np_mod(x, 360.0);
   f.x = x; f.y = y;
-  f.xi = __dmul_rn(div_cr(x - geo.x0, geo.xspan, geo.ixspan), (double)(geo.nx - 1));
-  f.yi = __dmul_rn(div_cr(y - geo.y0, geo.yspan, geo.iyspan), (double)(geo.ny - 1));
+  f.xi = (f32idx & 1) ? index_f32(x, geo.x0, geo.xspan, geo.nx - 1) : __dmul_rn(div_cr(x - geo.x0, geo.xspan, geo.ixspan), (double)(geo.nx - 1));
+  f.yi = (f32idx & 2) ? index_f32(y, geo.y0, geo.yspan, geo.ny - 1) : __dmul_rn(div_cr(y - geo.y0, geo.yspan, geo.iyspan), (double)(geo.ny - 1));
   return f;
 }
 
@@ -2083,8 +2105,9 @@ __device__ __forceinline__ bool env_group_sample(const DevWorld &W, const EnvGro
     const Foot ft = L.foot(yi, xi, geo.ny, geo.nx, rec_bytes, ok);
     unsigned near_off = 0;
     if (G.has_land)
-      near_off = L.node(nearest_index(y, geo.ymin, geo.yrange, geo.iyrange, geo.ny),
-                        nearest_index(x, geo.xmin, geo.xrange, geo.ixrange, geo.nx), geo.nx, rec_bytes, ok_near);
+      near_off = L.node((fr.f32idx & 2) ? nearest_index_f32(y, geo.ymin, geo.yrange, geo.ny) : nearest_index(y, geo.ymin, geo.yrange, geo.iyrange, geo.ny),
+                        (fr.f32idx & 1) ? nearest_index_f32(x, geo.xmin, geo.xrange, geo.nx) : nearest_index(x, geo.xmin, geo.xrange, geo.ixrange, geo.nx),
+                        geo.nx, rec_bytes, ok_near);
     if (!(ok && ok_near)) return false;
     const bool tl = G.ba != nullptr && !G.all_static;
     ODR_PT_USE(ft.o00); ODR_PT_USE(ft.o11); ODR_PT_USE(near_off); ODR_PT(14);
@@ -2164,9 +2187,9 @@ __device__ __forceinline__ LdGlobal env_global(const EnvGroupDesc &G) {
 template <int PROJ, bool BURST_ONLY, bool ZT>
 __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroupDesc &G, double lon,
                                                double lat, double z, float *out /*[MAXG]*/, const double *zt,
-                                               ZBracket &zb_out, EnvExport *X = nullptr ODR_PT_PARAM) {
+                                               ZBracket &zb_out, EnvExport *X = nullptr ODR_PT_PARAM, int f32idx = 0) {
   const DevSource &s = W.src[G.sid];
-  const EnvFront fr = env_front<PROJ>(s, s.slot[G.geo_slot], lon, lat, z);
+  const EnvFront fr = env_front<PROJ>(s, s.slot[G.geo_slot], lon, lat, z, f32idx);
   env_group_sample<PROJ, BURST_ONLY, ZT>(W, G, env_global(G), fr, z, out, zt, zb_out, X ODR_PT_ARG);
 }
 // The records the main-loop sample fetched for slot A, as the kept footprint of the stage samples -- valid when slot A holds
@@ -2212,9 +2235,10 @@ __device__ __forceinline__ UVKeep<IS3D> uv_keep_from_sm(const EnvGroupDesc &G, c
 }
 // for the kernels that need neither LDS tables nor the bracket
 template <int PROJ>
-__device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroupDesc &G, double lon, double lat, double z, float *out) {
+__device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroupDesc &G, double lon, double lat, double z, float *out,
+                                               int f32idx = 0) {
   ZBracket zb;
-  env_group_fast<PROJ, false, false>(W, G, lon, lat, z, out, nullptr, zb);
+  env_group_fast<PROJ, false, false>(W, G, lon, lat, z, out, nullptr, zb, nullptr ODR_PT_NULLARG, f32idx);
 }
 
 }  // namespace odr

@@ -144,6 +144,7 @@ struct odr_particles {
   float *altenv[NVAR];
   float *aux[9];
   float *altaux[9];
+  bool profiles_f32 = false; // the sample positions of the last main-loop sample were taken in the float32 position class (odr_vmix)
   unsigned aux_user = 0;     // bit k: property slot k was written by the caller (odr_particles_set_property): the model owns it
   bool kmember_on = false;   // slot AUX_KMEMBER parks the member of an ensemble diffusivity (k_kmember): the library owns it
   float *aux_snap[9];       // odr_particles_snapshot_property: copies the result buffer may read instead of aux[] (one record)

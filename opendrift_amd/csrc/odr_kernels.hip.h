@@ -677,7 +677,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_group(const DevWorld *__restrict_
   for (int k = 0; k < NV; ++k) vars[k] = gv.v[k];
   double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
   float out[NV];
-  env_group<NV>(*W, vars, lon, lat, z, t, out, p.rank ? p.rank[i] : 0, W->f32pos);   // (the main-loop call: DevWorld::f32pos)
+  env_group<NV>(*W, vars, lon, lat, z, t, out, p.rank ? p.rank[i] : 0, W->f32pos & 1);   // (the main-loop call: DevWorld::f32pos)
 #pragma unroll
   for (int k = 0; k < NV; ++k) p.env[vars[k]][i] = out[k];
   if (record_prev) { p.slon[i] = lon; p.slat[i] = lat; }
@@ -690,9 +690,13 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_env_grid(const DevWo
   long long i = pid();
   if (i >= p.n) return;
   double lon = p.lon[i], lat = p.lat[i], z = p.z[i];
-  if (W->f32pos) lon = lon_f32class(W->src[G.sid].lon_mode, lon);    // first get_environment of a run (DevWorld::f32pos)
+  int f32idx = 0;
+  if (W->f32pos & 1) {   // first get_environment of a run (DevWorld::f32pos): float32 longitude modulation, float32 index maps
+    lon = lon_f32class(W->src[G.sid].lon_mode, lon);
+    if (PROJ == PROJ_LATLONG) f32idx = W->src[G.sid].xy_f32;
+  }
   float out[MAXG];
-  env_group_fast<PROJ>(*W, G, lon, lat, z, out);
+  env_group_fast<PROJ>(*W, G, lon, lat, z, out, f32idx);
 #pragma unroll
   for (int k = 0; k < MAXG; ++k)
     if (k < G.nv) G.out_ptr[k][i] = out[k];
@@ -1250,7 +1254,7 @@ __global__ __launch_bounds__(BLOCK) void k_env_gyre(const DevWorld *__restrict__
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= p.n) return;
   const DevSource &s = W->src[sid];
-  const double lon = W->f32pos ? lon_f32class(s.lon_mode, p.lon[i]) : p.lon[i], lat = p.lat[i];   // (DevWorld::f32pos)
+  const double lon = (W->f32pos & 1) ? lon_f32class(s.lon_mode, p.lon[i]) : p.lon[i], lat = p.lat[i];   // (DevWorld::f32pos)
   float u, v;
   const bool covered = gyre_sample(s, lon, lat, p.z[i], snw, W->fallback[VAR_U], W->fallback[VAR_V], u, v);
   p.env[VAR_U][i] = u;
@@ -1763,8 +1767,11 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
       if (src->mod360_x) x = np_mod(x, 360.0);
       bracket(*src, t, ib, ia);
       const DevBlock &bb = src->slot[ib];
-      xi = __dmul_rn(div_cr(x - bb.x0, bb.xspan, bb.ixspan), (double)(bb.nx - 1));
-      yi = __dmul_rn(div_cr(y - bb.y0, bb.yspan, bb.iyspan), (double)(bb.ny - 1));
+      // (bit 1 of DevWorld::f32pos: the profiles of this step were sampled in the float32 position class -- the first
+      // get_environment of a run -- on a geographic reader with float32 coordinate arrays: float32 index maps, index_f32)
+      const int f32idx = ((W->f32pos & 2) && src->proj.kind == PROJ_LATLONG) ? src->xy_f32 : 0;
+      xi = (f32idx & 1) ? index_f32(x, bb.x0, bb.xspan, bb.nx - 1) : __dmul_rn(div_cr(x - bb.x0, bb.xspan, bb.ixspan), (double)(bb.nx - 1));
+      yi = (f32idx & 2) ? index_f32(y, bb.y0, bb.yspan, bb.ny - 1) : __dmul_rn(div_cr(y - bb.y0, bb.yspan, bb.iyspan), (double)(bb.ny - 1));
       if (ia >= 0) wgt = __ddiv_rn(t - bb.t, src->slot[ia].t - bb.t);
     }
     if (src && cov && src->slot[ib].es[VAR_KZ] == 1 && NZMAX > 1) {

@@ -45,7 +45,11 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
   const bool oil = c->oil_owner == p;   // OpenOil: terminal velocities, slick and wave entrainment inside the loop
   c->oil_owner = nullptr;
   VMixDesc D;
-  const bool fast = !oil && !getenv("ODR_NO_FAST_PATH") && build_vmix_desc(c, t, D);
+  // the step's profiles were sampled in the float32 position class (a run's first get_environment, odr_ctx_set_position_class):
+  // the generic kernel forms the column's footprint with float32 index maps (DevWorld::f32pos bit 1, set for this launch)
+  const bool f32prof = p->profiles_f32;
+  if (f32prof) { c->hw.f32pos |= 2; c->dirty = true; if ((rc = flush_world(c))) return rc; }
+  const bool fast = !oil && !f32prof && !getenv("ODR_NO_FAST_PATH") && build_vmix_desc(c, t, D);
   if (guarded && !fast) { c->fuse_vadv = vadv; return 1; }   // (the generic kernel carries no guard) nothing launched
   if (fast) {
     if (guarded) D.guard = c->counter + 4;
@@ -91,6 +95,7 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
   else if (nzp <= 32) hipLaunchKernelGGL(k_vmix<32>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
   else hipLaunchKernelGGL(k_vmix<1>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
   HIPCHK(hipGetLastError());
+  if (f32prof) { c->hw.f32pos &= ~2; c->dirty = true; }
   return 0;
 }
 

@@ -248,6 +248,7 @@ int odr_env_coast_advect(odr_ctx *c, odr_particles *p, int nvars, const int32_t 
     if ((rc = advect_impl(c, p, scheme, t, dt, factor, N))) return rc;
     return want_mix ? mix_after(c, p, t, dt, extras) : 0;
   }
+  p->profiles_f32 = false;     // (this launch records the sample positions, and never runs in the float32 position class)
   for (int k = 0; k < ng; ++k) { if ((rc = ensure_env(c, p, grp[k]))) return rc; p->env_cok[grp[k]] = false; }
   if (coast_action == 2) p->env_cok[VAR_LAND] = false;   // elements on land get land_binary_mask = 0
   if (nrest && (rc = env_sample_impl(c, p, nrest, rest, t, nullptr, false))) return rc;  // k_step_grid records the positions

@@ -1229,6 +1229,7 @@ int odr_i_env_sample(odr_ctx *c, odr_particles *p, int nvars, const int32_t *var
   }
   if ((rc = flush_world(c))) return rc;
   if ((rc = odr_i_ensure_ranks(c, p))) return rc;   // ensemble data only
+  if (record_positions) p->profiles_f32 = (c->hw.f32pos & 1) != 0;   // (odr_vmix gathers its profiles at these positions, in their class)
   if (record_positions && p->rank_on && p->n > 0) {
     // the main-loop call: an ensemble DIFFUSIVITY hands every element the column of the member its element values come
     // from (k_kmember) -- kept until odr_vmix, across the renumbering of the Runge-Kutta stage calls and the compaction
@@ -2221,7 +2222,14 @@ int odr_scan_status_end(odr_ctx *c, odr_particles *p, int64_t *n_kept, uint64_t 
 // get_environment of a run (DevWorld::f32pos); 0 ends it.
 int odr_ctx_set_position_class(odr_ctx *c, int f32) {
   const int v = f32 ? 1 : 0;
-  if (c->hw.f32pos != v) { c->hw.f32pos = v; c->dirty = true; }
+  if ((c->hw.f32pos & 1) != v) { c->hw.f32pos = (c->hw.f32pos & ~1) | v; c->dirty = true; }
+  return 0;
+}
+// Coordinate arrays of a grid source: float32 or not (the index maps of a geographic reader in the float32 position class)
+int odr_source_set_coordinate_dtype(odr_ctx *c, int32_t sid, int x_is_f32, int y_is_f32) {
+  REQUIRE(sid >= 0 && sid < c->nsrc && c->hw.src[sid].kind == SRC_GRID, "source %d is not a grid source", sid);
+  c->hw.src[sid].xy_f32 = (x_is_f32 ? 1 : 0) | (y_is_f32 ? 2 : 0);
+  c->dirty = true;
   return 0;
 }
 

@@ -174,6 +174,9 @@ class Context:
         xy8 = np.array([float(x[0]), float(x[-1] - x[0]), float(y[0]), float(y[-1] - y[0]),
                         float(x.min()), float(x.max() - x.min()), float(y.min()), float(y.max() - y.min())])
         self._grids[sid.value] = dict(xy8=xy8, ny=len(y), nx=len(x), nz=max(nz, 1))
+        # float32 coordinate arrays: the index maps of a geographic reader are float32 arithmetic in the first get_environment of
+        # a run (odr_ctx_set_position_class; interpolators.py:110-111 with elements.py:71-88)
+        check(self.lib.odr_source_set_coordinate_dtype(self.h, sid.value, int(x.dtype == np.float32), int(y.dtype == np.float32)))
         return sid.value
 
     def add_grid_curvilinear(self, lon2d, lat2d, z=None, lon_mode=None, domain=None):

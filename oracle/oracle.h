@@ -107,6 +107,7 @@ typedef struct {
   orc_block level[ORC_MAXLEVELS];
   int always_valid;
   double tmin, tmax;  /* covers_time (variables.py:392-400): reader start_time / end_time */
+  int xy_f32;         /* GRID: bit 0 / 1 = the reader's x / y coordinate arrays are float32 (index arithmetic of a run's first call) */
 } orc_source;
 
 typedef struct {

@@ -65,7 +65,7 @@ class Source(C.Structure):
                 ('lon_mode', C.c_int), ('mod360_x', C.c_int), ('has_var', C.c_int * NVAR),
                 ('const_val', C.c_double * NVAR), ('params', C.c_double * 8),
                 ('nlevels', C.c_int), ('level', Block * MAXLEVELS), ('always_valid', C.c_int),
-                ('tmin', C.c_double), ('tmax', C.c_double)]
+                ('tmin', C.c_double), ('tmax', C.c_double), ('xy_f32', C.c_int)]
 
 
 class World(C.Structure):
@@ -230,6 +230,7 @@ class WorldBuilder:
         dom = (float(x.min()), float(x.max()), float(y.min()), float(y.max()))
         idx, s = self._new(SRC_GRID, proj, dom, lon_mode, variables)
         s.mod360_x = mod360_x
+        s.xy_f32 = (1 if np.asarray(x).dtype == np.float32 else 0) | (2 if np.asarray(y).dtype == np.float32 else 0)
         if time_coverage is not None:
             s.tmin, s.tmax = float(time_coverage[0]), float(time_coverage[1])
         s.nlevels = len(levels)

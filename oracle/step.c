@@ -118,6 +118,25 @@ static void zinterp(const double *zg, int nz, double z, int *ia, int *ib, double
   *wa = 1 - (zi - *ia);
 }
 
+/* float32 positions of a run's first get_environment (orc_set_position_class) on a geographic reader whose coordinate arrays are
+ * float32 (orc_source.xy_f32: bit 0 x, bit 1 y): the reader's x IS the float32 longitude, and the index maps of the 2-D
+ * interpolators (interpolators.py:32-37,110-111) are float32 arithmetic -- (x - xgrid[0]) / (xgrid[-1] - xgrid[0]) * (len - 1)
+ * with float32 arrays and scalars, the Python int weak.  Set per source call (source_call / orc_get_profile). */
+static int g_f32idx = 0;
+static double index_f32(double v, double v0, double span, int n) {
+  float t = (float)v - (float)v0;
+  t = t / (float)span;
+  t = t * (float)n;
+  return (double)t;
+}
+
+static int nearest_index_f(double v, double vmin, double vrange, int n, int f32) {
+  /* Nearest2DInterpolator, interpolators.py:32-37 */
+  double r = f32 ? (double)rintf((float)index_f32(v, vmin, vrange, n)) : rint((v - vmin) / vrange * n);
+  if (!(r >= 0) || r >= n) return n - 1; /* uint32 wrap of negatives, then clip */
+  return (int)r;
+}
+
 static int nearest_index(double v, double vmin, double vrange, int n) {
   /* Nearest2DInterpolator, interpolators.py:32-37 */
   double r = rint((v - vmin) / vrange * n);
@@ -165,8 +184,8 @@ static void block_interp_one(orc_block *b, int var, long n, const double *x,
   if (var == ORC_VAR_LAND) {
     *is_f32 = 1;
     for (i = 0; i < n; ++i) {
-      int xi = nearest_index(x[i], b->xmin, b->xrange, b->nx);
-      int yi = nearest_index(y[i], b->ymin, b->yrange, b->ny);
+      int xi = nearest_index_f(x[i], b->xmin, b->xrange, b->nx, g_f32idx & 1);
+      int yi = nearest_index_f(y[i], b->ymin, b->yrange, b->ny, g_f32idx & 2);
       out64[i] = data[(long)yi * b->nx + xi];
     }
     return;
@@ -176,8 +195,8 @@ static void block_interp_one(orc_block *b, int var, long n, const double *x,
     double *yi = (double *)malloc(sizeof(double) * (size_t)n);
     float *lay = (float *)malloc(sizeof(float) * (size_t)n);
     for (i = 0; i < n; ++i) {
-      xi[i] = (x[i] - b->x0) / b->xspan * (b->nx - 1);
-      yi[i] = (y[i] - b->y0) / b->yspan * (b->ny - 1);
+      xi[i] = (g_f32idx & 1) ? index_f32(x[i], b->x0, b->xspan, b->nx - 1) : (x[i] - b->x0) / b->xspan * (b->nx - 1);
+      yi[i] = (g_f32idx & 2) ? index_f32(y[i], b->y0, b->yspan, b->ny - 1) : (y[i] - b->y0) / b->yspan * (b->ny - 1);
     }
     if (nzv <= 1) {
       *is_f32 = 1;
@@ -245,6 +264,7 @@ static void source_call(const orc_source *s, int nv, const int *vars, long m,
     free(x); free(y); free(zc); free(cov);
     return;
   }
+  g_f32idx = (g_f32pos && s->proj.kind == ORC_PROJ_LATLONG) ? s->xy_f32 : 0;
   for (j = 0; j < m; ++j) {
     double lo = lon[idx[j]], la = lat[idx[j]], xx, yy, xchk;
     lo = modulate_longitude(s->lon_mode, lo);
@@ -433,8 +453,11 @@ void orc_get_profile(const orc_world *w, int var, long n, const double *lon,
       orc_proj_fwd(&s->proj, lo, lat[i], &xx, &yy);
       cov[i] = xx >= s->xmin && xx <= s->xmax && yy >= s->ymin && yy <= s->ymax;
       if (s->mod360_x) xx = np_mod(xx, 360);
-      xi[i] = (xx - bb->x0) / bb->xspan * (bb->nx - 1);
-      yi[i] = (yy - bb->y0) / bb->yspan * (bb->ny - 1);
+      {
+        const int f32idx = (g_f32pos && s->proj.kind == ORC_PROJ_LATLONG) ? s->xy_f32 : 0;   /* (see index_f32) */
+        xi[i] = (f32idx & 1) ? index_f32(xx, bb->x0, bb->xspan, bb->nx - 1) : (xx - bb->x0) / bb->xspan * (bb->nx - 1);
+        yi[i] = (f32idx & 2) ? index_f32(yy, bb->y0, bb->yspan, bb->ny - 1) : (yy - bb->y0) / bb->yspan * (bb->ny - 1);
+      }
     }
     {
       /* ensemble data: position j of the call takes the COLUMN of member j % M (readers/interpolation/structured.py:119-135:
