@@ -381,6 +381,12 @@ int odr_vmix(odr_ctx *ctx, odr_particles *p, double t_epoch, double dt, double d
  * does when no reader provides ocean_vertical_diffusivity (oceandrift.py:431-447).  Needs x_wind, y_wind,
  * ocean_mixed_layer_thickness, sea_floor_depth_below_sea_level (sea_surface_height) in the environment. */
 enum { ODR_DIFFUSIVITY_LARGE1994 = 1, ODR_DIFFUSIVITY_SUNDBY1983 = 2 };
+/* drift:truncate_ocean_model_below_m together with reader diffusivity profiles (environment.py:554-566): the reference narrows the
+ * depth range it asks the reader for, and a reader that hands out the levels asked for (reader_netCDF_CF_generic.py:414-423,
+ * reader_ROMS_native.py:551-560: the span of the request, one level more on either side, plus `verticalbuffer`) returns a block
+ * CUT there -- elements below mix on K and dK/dz (np.gradient's edge of the cut grid) of the last level held.  n: levels of that
+ * block, taken by the NEXT odr_vmix on the profiles of the device block (which always holds every level); 0 = all. */
+int odr_vmix_set_profile_levels(odr_ctx *ctx, int32_t n);
 int odr_vmix_wind_profile(odr_ctx *ctx, odr_particles *p, int model, double background_diffusivity, double dt,
                           double dt_mix, int mix_at_surface, int rng_mode, const double *host_uniforms,
                           uint64_t step);

@@ -150,6 +150,7 @@ _SIGNATURES = {
     'odr_deactivate_outside': [_vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32],
     'odr_compact': [_vp, _vp, _i64p],
     # communication (csrc/odr_comm.hip: RCCL, one communicator pair per process)
+    'odr_vmix_set_profile_levels': [_vp, C.c_int32],
     'odr_ctx_set_position_class': [_vp, C.c_int],
     'odr_source_set_coordinate_dtype': [_vp, C.c_int32, C.c_int, C.c_int],
     'odr_device_count': [_P(C.c_int32)],

@@ -58,6 +58,7 @@ struct odr_ctx {
   hipEvent_t scan_ev = nullptr;     // behind the fold of odr_scan_status_begin
   bool scan_open = false;
   int guard_next_vmix = 0;          // odr_ctx_guard_next_vmix
+  int vmix_levels = 0;              // odr_vmix_set_profile_levels: one-shot, taken by the next odr_vmix (0 = every level of the reader)
   unsigned long long *scan_host = nullptr;   // page-locked: what odr_scan_status reads (written by k_cmp_total itself)
   // page-locked copies of `hw` the device image is refreshed from (flush_world): three in turn, each guarded by an event
   DevWorld *hw_pin[3] = {nullptr, nullptr, nullptr};

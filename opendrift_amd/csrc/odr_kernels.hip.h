@@ -1731,7 +1731,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
                                                 double dt, double dt_mix_cfg, int mix_at_surface,
                                                 int rng_mode, const double *__restrict__ huni,
                                                 unsigned long long seed, unsigned long long step,
-                                                int vadv /* -1 none, 0 below surface, 1 incl. surface */, int sfl,
+                                                int vadv /* -1 none, 0 below surface, 1 incl. surface */, int sfl_in,
                                                 OilArgs oa = OilArgs()) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -1742,7 +1742,11 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
     const DevSource &s = W->src[W->list[VAR_KZ][k]];
     if (s.kind == SRC_GRID) { src = &s; break; }
   }
-  const int nzp = src ? (src->nz > 1 ? src->nz : 1) : 1;
+  // (bits 16 .. 23 of sfl_in: odr_vmix_set_profile_levels -- the columns end there, the level search, the gradient's edge and
+  // the clamp of deeper elements work on the cut column; the member stride below stays the reader's level count)
+  const int sfl = sfl_in & 0xffff, cut = (sfl_in >> 16) & 0xff;
+  const int nz_full = src ? (src->nz > 1 ? src->nz : 1) : 1;
+  const int nzp = (cut > 0 && cut < nz_full) ? cut : nz_full;
   // ensemble diffusivity: the levels of member m follow those of member m - 1 along the layer axis (odr_source_set_members)
   const int kmembers = src ? src->members[VAR_KZ] : 0;
   double *Kp = (double *)smem;           // [nzp][BLOCK]
@@ -1757,7 +1761,7 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
     bool cov = false;
     double xi = 0, yi = 0, wgt = 0;
     int ib = 0, ia = -1;
-    const size_t moff = (kmembers > 1 && p.aux[AUX_KMEMBER]) ? (size_t)((int)p.aux[AUX_KMEMBER][i]) * (size_t)nzp : 0;
+    const size_t moff = (kmembers > 1 && p.aux[AUX_KMEMBER]) ? (size_t)((int)p.aux[AUX_KMEMBER][i]) * (size_t)nz_full : 0;
     if (src) {
       double lon = p.slon[i], lat = p.slat[i], x, y;
       if (src->lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
@@ -1862,8 +1866,10 @@ __global__ __launch_bounds__(BLOCK) void k_vmix(const DevWorld *__restrict__ W, 
       if (nzp >= 2) {
         // divisors are level constants: host reciprocals + exact-residual correction (div_cr)
         if (zi == 0) gK = div_cr(Kp[BLOCK + tid] - Kz, src->vg_d[0], src->vg_id[0]);
-        else if (zi == nzp - 1) gK = div_cr(Kz - Kp[(nzp - 2) * BLOCK + tid], src->vg_d[1], src->vg_id[1]);
-        else if (uniform_z)
+        else if (zi == nzp - 1) {
+          if (nzp == nz_full) gK = div_cr(Kz - Kp[(nzp - 2) * BLOCK + tid], src->vg_d[1], src->vg_id[1]);
+          else gK = __ddiv_rn(Kz - Kp[(nzp - 2) * BLOCK + tid], src->z[nzp - 1] - src->z[nzp - 2]);   // np.gradient's edge of the CUT grid
+        } else if (uniform_z)
           gK = div_cr(Kp[(zi + 1) * BLOCK + tid] - Kp[(zi - 1) * BLOCK + tid], src->vg_d[2], src->vg_id[2]);
         else
           gK = __dadd_rn(__dadd_rn(__dmul_rn(gsh[zi], Kp[(zi - 1) * BLOCK + tid]), __dmul_rn(gsh[nzp + zi], Kz)),

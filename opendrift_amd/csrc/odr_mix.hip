@@ -47,9 +47,18 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
   VMixDesc D;
   // the step's profiles were sampled in the float32 position class (a run's first get_environment, odr_ctx_set_position_class):
   // the generic kernel forms the column's footprint with float32 index maps (DevWorld::f32pos bit 1, set for this launch)
+  // odr_vmix_set_profile_levels: the columns end at that level (a reader that cut its block at the depth asked of it): generic kernel
+  const int cut = c->vmix_levels;
+  c->vmix_levels = 0;
+  if (cut > 0 && guarded) return 1;
   const bool f32prof = p->profiles_f32;
   if (f32prof) { c->hw.f32pos |= 2; c->dirty = true; if ((rc = flush_world(c))) return rc; }
-  const bool fast = !oil && !f32prof && !getenv("ODR_NO_FAST_PATH") && build_vmix_desc(c, t, D);
+  const bool fast = !oil && !f32prof && cut <= 0 && !getenv("ODR_NO_FAST_PATH") && build_vmix_desc(c, t, D);
+  if (cut > 0) {
+    REQUIRE(cut >= 2 && cut <= 255, "odr_vmix_set_profile_levels: 2 .. 255 levels");
+    if (cut < nzp) nzp = cut;
+  }
+  const int sfl_cut = c->seafloor | ((cut > 0 ? nzp : 0) << 16);     // (the generic kernels read the cut from bits 16 .. 23)
   if (guarded && !fast) { c->fuse_vadv = vadv; return 1; }   // (the generic kernel carries no guard) nothing launched
   if (fast) {
     if (guarded) D.guard = c->counter + 4;
@@ -88,12 +97,12 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
     else VMIX_COL(16);
 #undef VMIX_COL
   } else if (oil) {
-    if (nzp <= 16) hipLaunchKernelGGL((k_vmix<16, true>), g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor, c->oil);
-    else if (nzp <= 32) hipLaunchKernelGGL((k_vmix<32, true>), g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor, c->oil);
-    else hipLaunchKernelGGL((k_vmix<1, true>), g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor, c->oil);
-  } else if (nzp <= 16) hipLaunchKernelGGL(k_vmix<16>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
-  else if (nzp <= 32) hipLaunchKernelGGL(k_vmix<32>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
-  else hipLaunchKernelGGL(k_vmix<1>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, c->seafloor);
+    if (nzp <= 16) hipLaunchKernelGGL((k_vmix<16, true>), g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, sfl_cut, c->oil);
+    else if (nzp <= 32) hipLaunchKernelGGL((k_vmix<32, true>), g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, sfl_cut, c->oil);
+    else hipLaunchKernelGGL((k_vmix<1, true>), g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, sfl_cut, c->oil);
+  } else if (nzp <= 16) hipLaunchKernelGGL(k_vmix<16>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, sfl_cut);
+  else if (nzp <= 32) hipLaunchKernelGGL(k_vmix<32>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, sfl_cut);
+  else hipLaunchKernelGGL(k_vmix<1>, g, b, lds, c->stream, c->dw, v, t, dt, dt_mix, mix_at_surface, rng_mode, du, c->seed, st, vadv, sfl_cut);
   HIPCHK(hipGetLastError());
   if (f32prof) { c->hw.f32pos &= ~2; c->dirty = true; }
   return 0;
@@ -101,6 +110,15 @@ int odr_vmix(odr_ctx *c, odr_particles *p, double t, double dt, double dt_mix, i
 
 // vertical_mixing with an analytical diffusivity model (oceandrift.py:385-395,448-458): also what the default
 // 'environment' model does when no reader provides ocean_vertical_diffusivity (:431-447 -> Large et al. 1994)
+// The K columns of the next odr_vmix end at level n - 1 (a reader that hands out the levels asked for cuts its block at the depth
+// of the request -- drift:truncate_ocean_model_below_m, environment.py:554-566 -> reader_netCDF_CF_generic.py:414-423 -- and
+// elements below mix on K and dK/dz of the last level held); n = 0: every level.
+int odr_vmix_set_profile_levels(odr_ctx *c, int32_t n) {
+  REQUIRE(n == 0 || (n >= 2 && n <= 255), "bad level count %d", n);
+  c->vmix_levels = n;
+  return 0;
+}
+
 int odr_vmix_wind_profile(odr_ctx *c, odr_particles *p, int model, double background_diffusivity, double dt,
                           double dt_mix, int mix_at_surface, int rng_mode, const double *huni, uint64_t step) {
   p->status_epoch++;

@@ -699,11 +699,14 @@ class Particles:
         """Device copy of one property as it is now, read by the next History.record(position_from_previous=3)."""
         check(self.lib.odr_particles_snapshot_property(self.ctx.h, self.h, int(slot)))
 
-    def vmix(self, t_epoch, dt, dt_mix, mix_at_surface=False, step=0, uniforms=None, fuse_vertical_advection=None, guarded=False):
+    def vmix(self, t_epoch, dt, dt_mix, mix_at_surface=False, step=0, uniforms=None, fuse_vertical_advection=None, guarded=False,
+             profile_levels=0):
         """guarded=True (between scan_status_begin and scan_status_end): the launch does nothing unless the fold finds that every
         element stays (odr_ctx_guard_next_vmix); returns False when the library could not launch it that way (nothing happened)."""
         if fuse_vertical_advection is not None:   # True: include surface elements, False: z<0 only
             check(self.lib.odr_vmix_fuse_vertical_advection(self.ctx.h, int(bool(fuse_vertical_advection))))
+        if profile_levels:     # the K columns end there (a reader that cut its block at the depth asked of it, odr_vmix_set_profile_levels)
+            check(self.lib.odr_vmix_set_profile_levels(self.ctx.h, int(profile_levels)))
         if guarded:
             assert uniforms is None
             check(self.lib.odr_ctx_guard_next_vmix(self.ctx.h, 1))
@@ -768,7 +771,7 @@ class Particles:
         return dict(mean_zb=a.value, dV_50=b.value)
 
     def vmix_oil(self, model, background_diffusivity, dt, dt_mix, interfacial_tension, distribution, sea_water_density=None,
-                 t_epoch=0.0, uniforms=None, step=0, mix_at_surface=False, **kw):
+                 t_epoch=0.0, uniforms=None, step=0, mix_at_surface=False, profile_levels=0, **kw):
         """prepare_vertical_mixing + vertical_mixing as OpenOil.update runs them (openoil.py:1228-1231).  model: a wind
         parameterisation of the diffusivity or 'environment' (profiles from a reader)."""
         if sea_water_density is None:
@@ -777,7 +780,8 @@ class Particles:
                                 uniforms=uniforms, **kw)
         mix = None if uniforms is None else uniforms['mix']
         if model in ('environment', 'constant'):
-            self.vmix(t_epoch, dt, dt_mix, mix_at_surface=mix_at_surface, step=step, uniforms=mix)
+            self.vmix(t_epoch, dt, dt_mix, mix_at_surface=mix_at_surface, step=step, uniforms=mix,
+                      profile_levels=profile_levels if model == 'environment' else 0)
         else:
             self.vmix_analytic(model, background_diffusivity, dt, dt_mix, mix_at_surface=mix_at_surface, step=step, uniforms=mix)
 

@@ -105,6 +105,8 @@ class OpenDriftSimulation(Configurable):
                             'level': CONFIG_LEVEL_ESSENTIAL, 'description': ''},
             'seed:ocean_only': {'type': 'bool', 'default': self.SEED_OCEAN_ONLY_DEFAULT, 'level': CONFIG_LEVEL_ESSENTIAL,
                                 'description': 'If True, elements seeded on land will be moved to the closest position in ocean'},
+            'drift:profiles_depth': {'type': 'float', 'default': 50, 'min': 0, 'max': None, 'level': CONFIG_LEVEL_ADVANCED,
+                                     'description': 'Environment profiles are retrieved from surface and down to this depth'},   # :457
             'drift:max_age_seconds': {'type': 'float', 'default': None, 'min': 0, 'max': 1e12,
                                       'level': CONFIG_LEVEL_ADVANCED, 'description': ''},
             'drift:deactivate_north_of': {'type': 'float', 'default': None, 'min': -90, 'max': 90,
@@ -803,11 +805,45 @@ class OpenDriftSimulation(Configurable):
         """Environment.get_environment for all required variables (:2238-2246) + uncertainty (:869-891)."""
         t = _epoch(self.time)
         names = list(self.required_variables)
+        self._profile_levels = self._profile_level_cut()
         with self._readers_see_truncated_z():
             self.P.env_sample(names, t)
             self._sampled = names
             self._sample_host_readers(names)
         self._add_uncertainty(names, current=True)
+
+    def _profile_level_cut(self):
+        """drift:truncate_ocean_model_below_m with diffusivity profiles from a reader (environment.py:554-566): the reference asks
+        the reader for the depth range [0, max(deepest truncated element, min(profiles_depth, truncate))], and a reader that hands
+        out the levels asked for -- the reference's file readers: reader_netCDF_CF_generic.py:414-423, reader_ROMS_native.py:
+        551-560 -- returns a block that ENDS one level + `verticalbuffer` below that depth; elements further down mix on K and dK/dz
+        of its last level.  The device block holds every level: the number of levels of the reference's block, for the step's
+        mixing launch (odr_vmix_set_profile_levels); 0 = whole columns (no truncation, or a reader that says
+        `always_delivers_all_levels`).  Evaluated per step from the elements' depths (the reference keeps a cached block while it
+        covers the request: the same whenever some element is below the truncation depth, the case the option is for)."""
+        T = self._config.get('drift:truncate_ocean_model_below_m', {}).get('value')
+        if T is None or self.P is None or len(self.P) == 0:
+            return 0
+        for n in self.priority_list.get('ocean_vertical_diffusivity', []):
+            b = self.readers.get(n)
+            if b is None or b.sid is None:
+                continue
+            r = b.reader
+            if getattr(r, 'always_delivers_all_levels', False) or getattr(r, 'z', None) is None or np.size(r.z) < 3:
+                return 0
+            zlev = np.asarray(r.z, dtype=np.float64)
+            if not zlev[0] > zlev[-1]:
+                raise NotImplementedError('drift:truncate_ocean_model_below_m with diffusivity profiles from reader "%s": ascending '
+                                          'z levels' % n)
+            deepest = float(self.P.reduce_local()[5])            # max(-z) over the active elements of this rank
+            if self._world > 1:
+                from . import distributed as D
+                self._timing_collectives += 1
+                deepest = float(D.allreduce_scalars([deepest], 'max')[0])
+            depth = max(min(deepest, float(T)), min(float(self.get_config('drift:profiles_depth')), float(T)))
+            cut = int(min(len(zlev), np.searchsorted(-zlev, depth) + 1 + int(getattr(r, 'verticalbuffer', 1))))
+            return cut if cut < len(zlev) else 0
+        return 0
 
     def _readers_see_truncated_z(self):
         """drift:truncate_ocean_model_below_m (environment.py:554-566): inside the block the sampling calls see
@@ -1741,29 +1777,16 @@ class OceanDrift(OpenDriftSimulation):
         # to Large et al. (1994) (oceandrift.py:431-447).  (A reader that is listed but covers no element at all would do the same
         # there; here its fallback-filled profile is used.)
         model = self._effective_diffusivity_model()
-        # drift:truncate_ocean_model_below_m with reader diffusivity profiles: the reference narrows the depth range it ASKS the
-        # reader for -- profiles_depth = min(profiles_depth, truncate_depth), environment.py:560 -> basereader/structured.py:
-        # 230-238 -- and mixes on the columns as they come.  A reader that ignores the z request hands out whole columns
-        # (golden c24a: elements at any depth mix on their real K); the reference's file readers CUT the block at the depth asked
-        # for (reader_netCDF_CF_generic.py:414-423, reader_ROMS_native.py:551-560: the level range of the request plus
-        # `verticalbuffer`), so deeper elements get K and dK/dz of the last level held.  The device block always holds every
-        # level; the cut is not emulated: refused unless the reader says its columns come whole whatever is asked.
-        if model == 'environment' and self._config.get('drift:truncate_ocean_model_below_m', {}).get('value') is not None:
-            for n in self.priority_list.get('ocean_vertical_diffusivity', []):
-                b = self.readers[n]
-                if b.sid is not None and not getattr(b.reader, 'always_delivers_all_levels', False):
-                    raise NotImplementedError(
-                        'drift:truncate_ocean_model_below_m together with diffusivity profiles from reader "%s": the reference\'s '
-                        'file readers hand out columns cut at the truncation depth (elements below mix on the last level held), '
-                        'which the device path does not emulate.  Set reader.always_delivers_all_levels = True if the reference '
-                        'reader this one stands for ignores the depth range asked of it (whole columns, as here), or use an '
-                        'analytical vertical_mixing:diffusivitymodel' % n)
+        # (drift:truncate_ocean_model_below_m with reader diffusivity profiles: the columns end where the reference's reader cut
+        # its block, _profile_level_cut -- golden c24c; whole columns for a reader that ignores the depth range asked, c24a)
         dt, dt_mix = self.time_step.total_seconds(), self.get_config('vertical_mixing:timestep')
         fuse = None
         if self.get_config('drift:vertical_advection') and type(self).vertical_advection is OceanDrift.vertical_advection:
             fuse = bool(self.get_config('drift:vertical_advection_at_surface'))
             self._vadv_fused = True
         kw = dict(mix_at_surface=self.get_config('drift:vertical_mixing_at_surface'), fuse_vertical_advection=fuse)
+        if model == 'environment' and getattr(self, '_profile_levels', 0):
+            kw['profile_levels'] = self._profile_levels
         if _guarded:
             if model != 'environment' or self.rng != 'device':
                 self._vadv_fused = False

@@ -225,7 +225,8 @@ class OpenOil(OceanDrift):
             model, self.get_config('vertical_mixing:background_diffusivity'), dt, dt_mix,
             self.oil_water_interfacial_tension, self.get_config('wave_entrainment:droplet_size_distribution'),
             sea_water_density=sea_water_density_default(), t_epoch=_epoch(self.time),
-            mix_at_surface=self.get_config('drift:vertical_mixing_at_surface'), **kw))
+            mix_at_surface=self.get_config('drift:vertical_mixing_at_surface'),
+            profile_levels=getattr(self, '_profile_levels', 0), **kw))       # (OceanDrift._profile_level_cut: truncation + reader profiles)
         # a wind-parameterised diffusivity needs MLD.max() over all elements (oceandrift.py:430)
         self._with_global_reduction(mix)
 

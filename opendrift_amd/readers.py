@@ -315,6 +315,12 @@ class GridReader(StructuredReader):
     (odr_source_grid_curvilinear), and the vector pairs of every block rotated to east / north at the nodes by the azimuth
     of the mesh's y axis (rotate_vectors, variables.py:59-108, does it after the interpolation, at the element: the
     difference is second order in the turn of the axes across one cell -- DESIGN.md 9)."""
+    # A reference file reader hands out the z levels ASKED FOR (one more on either side + verticalbuffer,
+    # reader_netCDF_CF_generic.py:414-423, basereader/__init__.py:52); the device block of this reader always holds every level,
+    # and OceanDrift applies that cut to the diffusivity columns where it matters (drift:truncate_ocean_model_below_m).  A reader
+    # standing for one that ignores the depth range asked of it sets always_delivers_all_levels = True.
+    verticalbuffer = 1
+    always_delivers_all_levels = False
 
     def __new__(cls, x, y, times, arrays, z=None, proj4='+proj=latlong', name='grid_reader', lon=None, lat=None):
         if cls is GridReader and proj4 is not None:

@@ -34,6 +34,32 @@ NAMES = ('x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_veloc
          'sea_floor_depth_below_sea_level', 'land_binary_mask')
 
 
+class ZSubsetGridReader(gg.GridReader):
+    """A reader that hands out the LEVELS ASKED FOR, as the reference's file readers do: the vertical index range of
+    reader_netCDF_CF_generic.get_variables (reader_netCDF_CF_generic.py:414-423; reader_ROMS_native.py:551-560 is the same rule) --
+    the levels that span [z.min(), z.max()] of the request, one more on either side, plus `verticalbuffer` (basereader/__init__.py:52)."""
+
+    def get_variables(self, requested_variables, time=None, x=None, y=None, z=None):
+        out = super().get_variables(requested_variables, time, x, y, z)
+        if self.z is None or z is None:
+            return out
+        z = np.atleast_1d(z)
+        if self.z[0] > self.z[-1]:
+            indices = np.searchsorted(-self.z, [-z.min(), -z.max()])
+        else:
+            indices = np.searchsorted(self.z, [z.min(), z.max()])
+        indz = np.arange(np.maximum(0, indices.min() - 1 - self.verticalbuffer),
+                         np.minimum(len(self.z), indices.max() + 1 + self.verticalbuffer))
+        if len(indz) == 1:
+            indz = indz[0]
+        out['z'] = self.z[indz]
+        for v in requested_variables:
+            if np.ndim(out[v]) == 3:
+                out[v] = out[v][indz]
+        self.levels_handed_out = getattr(self, 'levels_handed_out', set()) | {int(np.size(indz))}
+        return out
+
+
 def _model(reader, truncate=None):
     o = gg._base('runge-kutta4')
     o.add_reader(reader)
@@ -64,6 +90,20 @@ def truncated():
         res, draws = gg._run(o, 600, 8, record_random=True)
         out.update({('%s_%s' % (tag, k)): v for k, v in res.items()})
         out[tag + '_uniforms'] = np.array([np.stack([d[1] for d in step if d[0] == 'random']) for step in draws])
+    # c24c: the same truncated run on a reader that CUTS its blocks at the depth asked for (ZSubsetGridReader): elements below the
+    # cut mix on K and dK/dz of the last level held
+    r = ZSubsetGridReader('+proj=latlong', g['x'], g['y'], times, {k: g[k] for k in NAMES}, z=g['z'])
+    o = _model(r, 20.0)
+    np.random.seed(0)
+    o.seed_elements(lon=lon, lat=lat, z=zz, time=gg.T0, wind_drift_factor=0.0)
+    res, draws = gg._run(o, 600, 8, record_random=True)
+    out.update({('c_%s' % k): v for k, v in res.items()})
+    out['c_uniforms'] = np.array([np.stack([d[1] for d in step if d[0] == 'random']) for step in draws])
+    out['c_levels_handed_out'] = np.array(sorted(r.levels_handed_out))
+    out['c_verticalbuffer'] = r.verticalbuffer
+    out['c_profiles_depth'] = o.get_config('drift:profiles_depth')
+    print('c24c: levels handed out', sorted(r.levels_handed_out), 'of', len(g['z']), g['z'], '; max |dz| against whole columns %.3f m' % (
+        np.nanmax(np.abs(out['c_z'][-1] - out['a_z'][-1]))))
     print('c24a: max |dlon| against the run without truncation %.2e deg, |dz| %.3f m; deepest element %.1f m' % (
         np.nanmax(np.abs(out['a_lon'][-1] - out['a0_lon'][-1])), np.nanmax(np.abs(out['a_z'][-1] - out['a0_z'][-1])), np.nanmin(out['a_z'])))
     out.update({('a_g_' + k): v for k, v in g.items()})

@@ -178,8 +178,10 @@ class OracleBackend:
         orc.leeway(self.lon, self.lat, self.moving, self.aux, self.env[XW], self.env[YW], self.env[U], self.env[VV],
                    dt, frac, uniforms[:n], cap_uniforms=cu, wind_threshold=thr, wind_threshold_sigma=sig)
 
-    def vmix(self, t, dt, dt_mix, zlevels, uniforms, vadv=True):
-        orc.vertical_mixing(self.z, self.moving, self.tv, self.env[DEPTH], self.env[SSH], zlevels, self.Kp, dt,
+    def vmix(self, t, dt, dt_mix, zlevels, uniforms, vadv=True, levels=0):
+        # levels: the reader's block was cut there (a reader that hands out the levels asked for): the column the mixing sees
+        zl, Kp = (zlevels, self.Kp) if not levels else (np.ascontiguousarray(zlevels[:levels]), np.ascontiguousarray(self.Kp[:levels]))
+        orc.vertical_mixing(self.z, self.moving, self.tv, self.env[DEPTH], self.env[SSH], zl, Kp, dt,
                             dt_mix, 0, uniforms)
         if vadv:
             orc.vertical_advection(self.z, self.moving, self.env[W], dt)
@@ -331,8 +333,8 @@ class DeviceBackend:
             self.P.leeway_capsize(dt, thr, sig, uniforms=cap_uniforms)
         self.P.leeway(dt, frac, uniforms=uniforms[:len(self.P)])
 
-    def vmix(self, t, dt, dt_mix, zlevels, uniforms, vadv=True):
-        self.P.vmix(t, dt, dt_mix, uniforms=uniforms, fuse_vertical_advection=False if vadv else None)
+    def vmix(self, t, dt, dt_mix, zlevels, uniforms, vadv=True, levels=0):
+        self.P.vmix(t, dt, dt_mix, uniforms=uniforms, fuse_vertical_advection=False if vadv else None, profile_levels=levels)
 
     def vbuoy(self, dt, action='lift_to_seafloor', code=1):
         self.ctx.set_seafloor_action(action, code)
@@ -398,12 +400,26 @@ def scenario_c24(g, tag):
                     fallbacks={U: 0.0, VV: 0.0, W: 0.0, KZ: 0.0, DEPTH: 10000.0, SSH: 0.0})
 
 
-def replay_c24(B, g, tag, nsteps, truncate=None):
+def cf_reader_levels(zlev, depth, verticalbuffer=1):
+    """Levels a reader that hands out the levels asked for returns for a request reaching `depth` from the surface
+    (reader_netCDF_CF_generic.py:414-423: the span of the request, one more level, plus verticalbuffer; descending z)."""
+    d = -np.asarray(zlev, dtype=np.float64)
+    return int(min(len(d), np.searchsorted(d, depth) + 1 + verticalbuffer))
+
+
+def replay_c24(B, g, tag, nsteps, truncate=None, gtag=None, cut_levels=False):
     """RK4 + vertical mixing on reader diffusivity profiles + vertical advection, coastline 'previous'; truncate: every
-    sampling call -- the main one and the Runge-Kutta stage calls -- sees max(z, -truncate) (environment.py:554-566)"""
+    sampling call -- the main one and the Runge-Kutta stage calls -- sees max(z, -truncate) (environment.py:554-566).
+    cut_levels (golden c24c): the reader cut its block at the depth asked of it -- min(profiles_depth, truncate) and the
+    deepest truncated element -- and the mixing runs on that column (elements below: K and dK/dz of its last level)."""
     dt, dt_mix = float(g['dt']), float(g['dt_mix'])
     n = g[tag + '_lon'].shape[1]
-    zlev = g[tag + '_g_z']
+    zlev = g[(gtag or tag) + '_g_z']
+    levels = 0
+    if cut_levels:
+        # some element is below the truncation depth in every step of the golden: the request reaches `truncate`
+        levels = cf_reader_levels(zlev, truncate, int(g['c_verticalbuffer']))
+        assert levels in g['c_levels_handed_out']
     out = []
     names = [U, VV, W, DEPTH, SSH, LAND]
     for k in range(nsteps):
@@ -423,7 +439,7 @@ def replay_c24(B, g, tag, nsteps, truncate=None):
         B.advect('runge-kutta4', t, dt)
         if truncate is not None:
             B.restore()
-        B.vmix(t, dt, dt_mix, zlev, g[tag + '_uniforms'][k])
+        B.vmix(t, dt, dt_mix, zlev, g[tag + '_uniforms'][k], levels=levels)
         out.append(B.state(n))
     return out
 

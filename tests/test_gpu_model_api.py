@@ -1168,13 +1168,19 @@ def test_c24a_truncation_with_reader_diffusivity_profiles_reproduces_the_referen
     whole, for elements at any depth.  OceanDrift.run() against the reference's own run (golden c24a, np.random in its order)."""
     g = golden('c24_profiles.npz')
     nst = g['a_lon'].shape[0] - 1
-    # a file reader of the reference would cut its columns at the truncation depth (ADVICE round 5): refused unless the reader
-    # declares whole columns, which is what the golden's reference reader (oracle/gen_golden_profiles.py) hands out
-    refused = _c24_model(g, 'a', stage_math)
-    refused.set_config('drift:truncate_ocean_model_below_m', float(g['truncate']))
-    refused.seed_elements(lon=g['a_lon'][0], lat=g['a_lat'][0], z=g['a_z'][0], time=T0, wind_drift_factor=0.0)
-    with pytest.raises(NotImplementedError, match='always_delivers_all_levels'):
-        refused.run(time_step=float(g['dt']), steps=nst)
+    # A file reader of the reference cuts its block at the depth asked of it (ADVICE round 5): the default GridReader stands for
+    # such a reader -- the columns end one level + verticalbuffer below the truncation depth, elements further down mix on the
+    # last level held: golden c24c, the reference's own run on a reader that hands out the levels asked for.  A reader that
+    # declares whole columns reproduces golden c24a (its reference reader ignores the depth range).
+    c = _c24_model(g, 'a', stage_math)
+    c.set_config('drift:truncate_ocean_model_below_m', float(g['truncate']))
+    c.seed_elements(lon=g['c_lon'][0], lat=g['c_lat'][0], z=g['c_z'][0], time=T0, wind_drift_factor=0.0)
+    c.run(time_step=float(g['dt']), steps=nst)
+    lon, lat, z = _final(c, g['c_lon'].shape[1])
+    print('c24c', stage_math, np.abs(lon - g['c_lon'][-1]).max(), np.abs(lat - g['c_lat'][-1]).max(), np.abs(z - g['c_z'][-1]).max())
+    assert np.abs(lon - g['c_lon'][-1]).max() < 1e-7 and np.abs(lat - g['c_lat'][-1]).max() < 1e-7
+    assert np.abs(z - g['c_z'][-1]).max() < 1e-5
+    assert np.abs(z - g['a_z'][-1]).max() > 1.0          # against whole columns
     o = _c24_model(g, 'a', stage_math)
     for r, _ in o._readers_host.values():
         r.always_delivers_all_levels = True

@@ -485,6 +485,22 @@ def test_c24_profile_paths_device_vs_oracle(ctx, tag):
     print('c24' + tag, 'device vs reference:', worst)
 
 
+def test_c24c_truncation_on_a_reader_that_cuts_its_block_device_vs_oracle(ctx):
+    """odr_vmix_set_profile_levels: the K columns end where a reader that hands out the levels asked for cut its block (golden c24c:
+    the reference's own run on such a reader) -- the generic mixing kernel's level search, clamp and np.gradient edge on the cut grid."""
+    import replay
+    g = golden('c24_profiles.npz')
+    sub = {k: g['c_%s' % k] for k in ('lon', 'lat', 'z', 'status')}
+    nst = sub['lon'].shape[0] - 1
+    trunc = float(g['truncate'])
+    D = replay.DeviceBackend(replay.scenario_c24(g, 'a'), ctx, sub['lon'][0], sub['lat'][0], sub['z'][0])
+    dev = replay.replay_c24(D, g, 'c', nst, truncate=trunc, gtag='a', cut_levels=True)
+    worst = replay.compare(dev, sub, tol_pos=1e-7, tol_z=1e-5)
+    O = replay.OracleBackend(replay.scenario_c24(g, 'a'), sub['lon'][0], sub['lat'][0], sub['z'][0])
+    _states_close(dev, replay.replay_c24(O, g, 'c', nst, truncate=trunc, gtag='a', cut_levels=True), 2e-9, 1e-9)
+    print('c24c device vs reference:', worst)
+
+
 def test_c5_leeway_golden_device(ctx):
     """Leeway.update kernel + environment uncertainty (host-drawn normals) + jibing vs the reference's Leeway."""
     import replay

@@ -505,6 +505,22 @@ def test_c23_round5_projections_golden_vs_oracle(tag):
     print('c23', tag, 'oracle vs reference:', worst)
 
 
+def test_c24c_truncation_on_a_reader_that_cuts_its_block_golden_vs_oracle():
+    """drift:truncate_ocean_model_below_m with diffusivity profiles from a reader that hands out the LEVELS ASKED FOR (what the
+    reference's file readers do: reader_netCDF_CF_generic.py:414-423): the block ends one level + verticalbuffer below the
+    truncation depth (5 of 8 levels here) and the elements below mix on K and dK/dz of its last level -- the reference's own
+    run (golden c24c, oracle/gen_golden_profiles.py: 7 m away in z from the run on whole columns, c24a)."""
+    g = golden('c24_profiles.npz')
+    sub = {k: g['c_%s' % k] for k in ('lon', 'lat', 'z', 'status')}
+    nst = sub['lon'].shape[0] - 1
+    assert list(g['c_levels_handed_out']) == [5] and replay.cf_reader_levels(g['a_g_z'], float(g['truncate'])) == 5
+    assert np.nanmax(np.abs(g['c_z'][-1] - g['a_z'][-1])) > 1.0                       # the cut matters
+    B = replay.OracleBackend(replay.scenario_c24(g, 'a'), sub['lon'][0], sub['lat'][0], sub['z'][0])
+    worst = replay.compare(replay.replay_c24(B, g, 'c', nst, truncate=float(g['truncate']), gtag='a', cut_levels=True), sub,
+                           tol_pos=1e-7, tol_z=1e-5)
+    print('c24c oracle vs reference:', worst)
+
+
 @pytest.mark.parametrize('tag', ['a', 'b'])
 def test_c24_profile_paths_golden_vs_oracle(tag):
     """The C oracle replays the reference's own runs (oracle/gen_golden_profiles.py) of (a) drift:truncate_ocean_model_below_m
