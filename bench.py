@@ -677,6 +677,10 @@ def main():
     if int(os.environ.get('RANK', 0)) == 0:
         G.build()                       # (objects are fresh on the GPU box: this loads the library)
     rank, local_rank, world = D.init()  # world > 1: RCCL through the C ABI (odr_comm_*), or torch.distributed on request (ODR_DIST_BACKEND)
+    if world == 1 and os.environ.get('ODR_BENCH_RCCL_WORLD1'):
+        # rehearsal on ONE GPU of what N ranks do: a one-rank RCCL communicator through the C ABI, the sharded loop on it (with
+        # ODR_BENCH_SHARDED_LOOP=1): reader levels by odr_block_broadcast, the step's all-gather from the device scan
+        D.init_rccl(world1=True)
     D.barrier()
     use_torch = D.backend() == 'torch'
     if use_torch:
@@ -697,7 +701,7 @@ def main():
     fields = make_fields(a.workload, a.small)
     ctx = Context(device=dev, seed=0)
     ctx.set_stage_math(a.stage_math)
-    wl = Workload(a.workload, ctx, fields, (rank, local_rank, world), via_torch=use_torch or world > 1)
+    wl = Workload(a.workload, ctx, fields, (rank, local_rank, world), via_torch=use_torch or world > 1 or D.backend() == 'rccl')
     rng = np.random.default_rng(1000 + rank)
     lon, lat, z = seed_particles(a.workload, fields, n, rng)
     if a.host_sort and fields is not None:
