@@ -490,6 +490,14 @@ class ShardedLoop:
         self.D, self.rank, _, self.world = D, *D.env_world()
         self.fields, self.names, self.block_every, self.install = fields, names, int(block_every), install
         self.rccl = rccl          # (ctx, source id, content ids): reader levels by odr_block_broadcast, staged one period ahead
+        if rccl is not None and self.rank == 0 and fields is not None:
+            # rank 0's reader arrays page-locked once: the level's copy into the staging memory is a DMA transfer behind which the
+            # host does not wait (pageable arrays go through the library's 8 MB bounce buffer, synchronously: 20-40 ms per level)
+            for kk in names:
+                try:
+                    rccl[0].pin(np.ascontiguousarray(fields['g'][kk]))
+                except Exception:
+                    pass
         self.collectives, self.collective_s, self.levels, self.level_stall_s = 0, 0.0, 0, 0.0
         self.pending = None
         self.last = None
@@ -672,6 +680,11 @@ def main():
         sys.exit(plumbing_only(a))
 
     from opendrift_amd import distributed as D
+    if int(os.environ.get('WORLD_SIZE', 1)) > 1 and D._choose_backend(None)[0] == 'torch':
+        # the rehearsal layer (ODR_DIST_BACKEND=gloo | nccl): torch brings its own HIP runtime, and it has to be the FIRST one the
+        # process loads -- the device library loaded ahead of it left this rank with "no ROCm-capable device" (two builds of
+        # libamdhip64 under one name).  The RCCL path through the C ABI never imports torch.
+        import torch  # noqa: F401
     from opendrift_amd.device import Context
     import __graft_entry__ as G
     if int(os.environ.get('RANK', 0)) == 0:

@@ -856,8 +856,8 @@ class DeviceReaderBinding:
                         m = np.stack([one(a) for a in block[v]])
                         arrays[v], members[v] = np.ascontiguousarray(m.reshape((-1,) + m.shape[-2:])), len(block[v])
                     else:
-                        arrays[v] = one(block[v])
-                hdr = dict(shapes={v: tuple(a.shape) for v, a in arrays.items()}, members=members, cids=self._static_ids())
+                        arrays[v] = block[v]      # (copied once, into page-locked staging memory: _upload)
+                hdr = dict(shapes={v: tuple(np.shape(a)) for v, a in arrays.items()}, members=members, cids=self._static_ids())
                 if getattr(self, '_dist_meta', None) is None:
                     hdr['meta'] = {kk: (np.asarray(block[kk]) if kk in ('x', 'y', 'z') and block.get(kk) is not None else block.get(kk))
                                    for kk in ('x', 'y', 'z', 's_level_variables') if kk in block}
@@ -995,6 +995,12 @@ class DeviceReaderBinding:
             # preparation (odr_block_broadcast); staged like an asynchronous upload
             for v, m in getattr(self, '_dist_members', {}).items():
                 self.ctx.declare_members(self.sid, v, m)
+            if rccl_arrays is not None:
+                # rank 0: the level through page-locked staging arrays of this binding (two sets in turn, as the asynchronous
+                # upload of a one-process run): its copy into the device's staging memory is a DMA transfer the host does not
+                # wait behind (pageable memory would go through the library's bounce buffer, synchronously)
+                self._ring = 1 - getattr(self, '_ring', 1)
+                rccl_arrays = {v: self._page_locked(v, a) for v, a in rccl_arrays.items()}
             self.ctx.block_broadcast(self.sid, slot, t_ep, rccl_arrays, rccl_shapes, root=0, content_ids=getattr(self, '_level_cids', None))
             if asynchronous:
                 self.staged[k] = slot
