@@ -1008,7 +1008,8 @@ def main():
         if sharded_report is not None:
             out['sharded_loop'] = dict(sharded_report, what='the timed region holds, per step: the device step of this rank, one host read '
                                        '(odr_scan_status) and ONE all_gather of the step summaries; every block_every steps a reader level '
-                                       'from rank 0 (RCCL broadcast started one period ahead) -> odr_block_upload_device')
+                                       'from rank 0, staged one period ahead (C-ABI collectives: odr_block_broadcast, ONE RCCL broadcast inside '
+                                       'the upload pipeline; torch layer: broadcast into tensors -> odr_block_upload_device)')
         if a.workload in ('c3', 'c4'):
             ts = P.tile_stats()     # the LDS-tile step (csrc/odr_tile.hip.h): launches on that path / elements it handed to the HBM path
             out['lds_tile'] = dict(ts, handed_over_per_launch=(ts['handed_over'] / ts['launches'] if ts['launches'] else None))
