@@ -114,3 +114,68 @@ def test_bench_line_of_one_gpu_runs_without_torch_and_reports_the_comm_layer():
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
     assert line['torch_in_process'] is False
     assert line['comm']['nranks_seen'] == 1 and line['n_gpus'] == 1
+
+
+READER_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from datetime import datetime, timedelta
+from opendrift_amd import distributed as D, synthetic as synth, readers
+from opendrift_amd.oceandrift import OceanDrift
+from opendrift_amd.device import Context
+U, V, W, KZ, DEP, LAND = ('x_sea_water_velocity', 'y_sea_water_velocity', 'upward_sea_water_velocity',
+                          'ocean_vertical_diffusivity', 'sea_floor_depth_below_sea_level', 'land_binary_mask')
+g = synth.grid3d(nx=96, ny=80, nz=8, nt=4, seed=5)
+T0 = datetime(2020, 1, 1)
+times = [T0 + timedelta(seconds=float(t)) for t in g['t']]
+rng = np.random.default_rng(1)
+n = 20000
+lon = rng.uniform(g['x'][4], g['x'][-5], n); lat = rng.uniform(g['y'][4], g['y'][-5], n); z = -rng.uniform(0, 40, n)
+steps = int((g['t'][-1] - g['t'][0]) / 600.0) - 1
+
+
+def run(sharded_levels):
+    o = OceanDrift(loglevel=50, seed=3)
+    o.add_reader(readers.GridReader(g['x'], g['y'], times, {k: g[k] for k in (U, V, W, KZ, DEP, LAND)}, z=g['z']))
+    o.set_config('drift:advection_scheme', 'runge-kutta4')
+    o.set_config('drift:vertical_mixing', True)
+    o.set_config('vertical_mixing:timestep', 60)
+    o.set_config('drift:vertical_advection', True)
+    o.set_config('general:coastline_action', 'previous')
+    o.seed_elements(lon=lon, lat=lat, z=z, time=T0)
+    if sharded_levels:
+        # every reader level takes the path of a sharded run over the C-ABI collectives: header by odr_comm_broadcast_bytes, the
+        # arrays by odr_block_broadcast (a one-rank communicator: this process is rank 0 of 1)
+        init = readers.DeviceReaderBinding.__init__
+        def patched(self, *a, **k):
+            init(self, *a, **k)
+            self.world = 2
+        readers.DeviceReaderBinding.__init__ = patched
+    try:
+        o.run(time_step=600, steps=steps)
+    finally:
+        if sharded_levels:
+            readers.DeviceReaderBinding.__init__ = init
+    e = o.elements
+    order = np.argsort(e.ID)
+    return e.lon[order], e.lat[order], e.z[order], len(e.ID)
+
+a = run(False)
+D.init_rccl(Context(0, seed=0), world1=True)
+k0 = D.comm_info()['collectives']
+b = run(True)
+out = dict(equal=bool(all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3])) and a[3] == b[3]), n=a[3],
+           collectives=D.comm_info()['collectives'] - k0, steps=steps, torch='torch' in sys.modules)
+D.shutdown()
+print('RESULT ' + json.dumps(out))
+'''
+
+
+def test_reader_levels_of_a_model_run_through_the_rccl_path_change_nothing():
+    """DeviceReaderBinding in a sharded run over the C-ABI collectives (_read_level_rccl -> odr_block_broadcast, levels staged a
+    period ahead from page-locked memory and committed when due) against the one-process path, on a one-rank communicator:
+    OceanDrift.run() ends bit-identical; at least a header + length + level collective per reader level were made."""
+    r = _run(READER_WORKER % dict(root=ROOT))
+    assert r['equal'] and r['n'] > 1000, r
+    assert r['collectives'] >= 9 and r['torch'] is False, r
