@@ -279,7 +279,11 @@ def cpu_baseline(name, fields, n_cpu, rng, small=False):
         # one thread, builds the same world from the same seeds and forks the simulations.
         try:
             import subprocess
-            cmd = [sys.executable, os.path.abspath(__file__), '--cpu-all-cores-helper', '--workload', name, '--cpu-particles', str(n_cpu),
+            # (a quarter of the single-core sample per simulation: with every core of the box gathering from the same 0.9 GB of blocks
+            # a step of 200 000 particles takes ~50 s -- the leg is memory-bound, which is its result -- and the default run should
+            # stay within minutes)
+            n_all = max(20000, n_cpu // 4)
+            cmd = [sys.executable, os.path.abspath(__file__), '--cpu-all-cores-helper', '--workload', name, '--cpu-particles', str(n_all),
                    '--cpu-cores', str(cores)] + (['--small'] if small else [])
             env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
             pr = subprocess.run(cmd, capture_output=True, text=True, timeout=float(os.environ.get('ODR_CPU_ALL_TIMEOUT', 240)), env=env)
