@@ -43,13 +43,17 @@ class ZSubsetGridReader(gg.GridReader):
         out = super().get_variables(requested_variables, time, x, y, z)
         if self.z is None or z is None:
             return out
-        z = np.atleast_1d(z)
-        if self.z[0] > self.z[-1]:
-            indices = np.searchsorted(-self.z, [-z.min(), -z.max()])
-        else:
-            indices = np.searchsorted(self.z, [z.min(), z.max()])
-        indz = np.arange(np.maximum(0, indices.min() - 1 - self.verticalbuffer),
-                         np.minimum(len(self.z), indices.max() + 1 + self.verticalbuffer))
+        # which of the reader's levels span the requested depth range: positions of its shallowest and deepest point among the
+        # levels (searched on an ascending axis), then one level more towards the surface, one more towards the bottom, and
+        # `verticalbuffer` further levels on both sides, clipped to the levels there are
+        req = np.atleast_1d(z)
+        descending = self.z[0] > self.z[-1]
+        axis = -np.asarray(self.z) if descending else np.asarray(self.z)
+        ends = (-req.min(), -req.max()) if descending else (req.min(), req.max())
+        pos = np.searchsorted(axis, ends)
+        first = max(0, int(pos.min()) - 1 - self.verticalbuffer)
+        stop = min(len(self.z), int(pos.max()) + 1 + self.verticalbuffer)
+        indz = np.arange(first, stop)
         if len(indz) == 1:
             indz = indz[0]
         out['z'] = self.z[indz]
