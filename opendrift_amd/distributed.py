@@ -82,10 +82,13 @@ def _exchange_unique_id(rank, make, nbytes, timeout=300.0):
     t0 = time.time()
     while True:
         try:
-            with open(path, 'rb') as f:
-                ident = f.read()
-            if len(ident) == nbytes:
-                return ident, path
+            # (a file left behind by a job that died before its rank 0 removed it is not this job's: the ranks of one launch start
+            # within seconds of each other)
+            if os.path.getmtime(path) > t0 - float(os.environ.get('ODR_COMM_ID_MAX_AGE', 600.0)):
+                with open(path, 'rb') as f:
+                    ident = f.read()
+                if len(ident) == nbytes:
+                    return ident, path
         except FileNotFoundError:
             pass
         if time.time() - t0 > timeout:
