@@ -193,3 +193,28 @@ def test_staging_buffers_of_a_variable_are_bounded(monkeypatch):
     before = [e.waited for e in st[1]]
     D._staged_to_device(('u', (8, 3)), np.ones((8, 3), np.float32), dev)
     assert sum(e.waited for e in st[1] if e is not None) >= sum(before)
+
+
+def test_communicator_id_travels_through_a_file_without_a_collective(tmp_path, monkeypatch):
+    """distributed._exchange_unique_id: rank 0 writes the RCCL id atomically, the other ranks poll for a COMPLETE file of this
+    launch (key: MASTER_ADDR / MASTER_PORT + the launcher's pid, or ODR_COMM_KEY); a file left behind by a dead job is ignored."""
+    import threading
+    import time
+    from opendrift_amd import distributed as D
+    monkeypatch.setenv('ODR_COMM_DIR', str(tmp_path))
+    monkeypatch.setenv('ODR_COMM_KEY', 'job-a')
+    got = {}
+    th = threading.Thread(target=lambda: got.setdefault('id', D._exchange_unique_id(1, None, 256, timeout=20)[0]))
+    th.start()
+    time.sleep(0.2)
+    ident, path = D._exchange_unique_id(0, lambda: bytes(range(256)), 256)
+    th.join()
+    assert got['id'] == ident == bytes(range(256)) and os.path.dirname(path) == str(tmp_path)
+    # a stale file (older than ODR_COMM_ID_MAX_AGE) is not this job's
+    monkeypatch.setenv('ODR_COMM_KEY', 'job-b')
+    stale = os.path.join(str(tmp_path), 'odr_comm_id_job-b')
+    with open(stale, 'wb') as f:
+        f.write(b'x' * 256)
+    os.utime(stale, (time.time() - 3600, time.time() - 3600))
+    with pytest.raises(TimeoutError):
+        D._exchange_unique_id(1, None, 256, timeout=0.5)
