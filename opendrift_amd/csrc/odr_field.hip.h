@@ -459,11 +459,22 @@ __device__ __forceinline__ void proj_fwd(const DevProj &p, double lon_deg, doubl
     y = p.a * Y + p.y0;
     return;
   }
-  if (ELLPOLAR) {
-    sincos(lam, &sinlam, &coslam);
-    sinphi = sin(phi);
+  if (ELLPOLAR || (p.kind == PROJ_STERE_POLAR && p.es != 0)) {
+    // (polar stereographic on an ellipsoid: the particle's own position in every step of C4 / C5; the same arithmetic in the
+    // instantiation of the polar readers (ELLPOLAR) and in the kernels that take the projection at run time.  Sines and
+    // cosines on their known ranges (sincos_pi), tan(pi/4 - phi/2) = cos phi / (1 + sin phi) away from the opposite pole, the
+    // ellipsoidal factor's exponential by its series: ~150 instead of ~290 instructions, equal to rounding)
+    sincos_pi(lam, sinlam, coslam);
+    sincos_pi(phi, sinphi, cosphi);
     if (p.south) { phi = -phi; coslam = -coslam; sinphi = -sinphi; }
-    const double rho = fabs(phi - kHalfPi) < 1e-15 ? 0.0 : p.akm1 * tsfn(phi, sinphi, p.e);
+    double rho = 0.0;
+    if (!(fabs(phi - kHalfPi) < 1e-15)) {
+      if (sinphi > -0.9 && p.e < 0.1) {
+        const double es = p.e * sinphi, q = es * es;
+        const double ath = es * (1 + q * (1.0 / 3 + q * (1.0 / 5 + q * (1.0 / 7 + q * (1.0 / 9 + q * (1.0 / 11 + q * (1.0 / 13)))))));
+        rho = p.akm1 * (cosphi * fast_rcp(1 + sinphi)) * exp_small(p.e * ath);
+      } else rho = p.akm1 * tsfn(phi, sinphi, p.e);
+    }
     x = p.a * (rho * sinlam) + p.x0;
     y = p.a * (-rho * coslam) + p.y0;
     return;
@@ -509,8 +520,8 @@ __device__ __forceinline__ ProjStart proj_start(const DevProj &p, double lon_deg
   o.pad = 0;
   o.lam = wrap_pi(lon_deg * kDeg - p.lon0);
   o.phi = lat_deg * kDeg;
-  sincos(o.lam, &o.sl, &o.cl);
-  sincos(o.phi, &o.sp, &o.cp);
+  sincos_pi(o.lam, o.sl, o.cl);
+  sincos_pi(o.phi, o.sp, o.cp);
   return o;
 }
 // The closed forms of the vector rotation below hold when the map is conformal on the ellipsoid the reference's geodesic runs on
@@ -546,7 +557,7 @@ __device__ __forceinline__ void proj_fwd_near(const DevProj &p, const ProjStart 
   if (!(fabs(phi - kHalfPi) < 1e-15)) {
     const double es = p.e * sinphi, q = es * es;
     const double ath = es * (1 + q * (1.0 / 3 + q * (1.0 / 5 + q * (1.0 / 7 + q * (1.0 / 9 + q * (1.0 / 11 + q * (1.0 / 13)))))));
-    rho = p.akm1 * (cosphi / (1 + sinphi)) * exp(p.e * ath);   // tsfn with tan(pi/4 - phi/2) = cos / (1 + sin)
+    rho = p.akm1 * (cosphi / (1 + sinphi)) * (p.e < 0.1 ? exp_small(p.e * ath) : exp(p.e * ath));   // tsfn with tan(pi/4 - phi/2) = cos / (1 + sin)
   }
   x = p.a * (rho * sinlam) + p.x0;
   y = p.a * (-rho * coslam) + p.y0;

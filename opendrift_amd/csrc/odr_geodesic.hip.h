@@ -117,6 +117,41 @@ __device__ __forceinline__ void sincos_q(double x, double &s, double &c) {
   c = w + (((1.0 - w) - hz) + z * rc);
 }
 
+// sin and cos for |x| <~ 3.3 (longitude differences wrapped to [-pi, pi], latitudes): quadrant k = rint(x 2/pi) in -2 .. 2,
+// remainder by a two-term Cody-Waite subtraction (k pi/2: the 53-bit head is exact for |k| <= 2), the pair from the reduced-range
+// kernels -- < 1 ulp like the library's sincos, ~45 instead of ~65 instructions (no large-argument path, one call for the pair)
+__device__ __forceinline__ void sincos_pi(double x, double &sinx, double &cosx) {
+  const double k = rint(x * 0.63661977236758134308);
+  double r = fma(-k, 1.57079632679489655800e+00, x);
+  r = fma(-k, 6.12323399573676603587e-17, r);
+  double s, c;
+  sincos_q(r, s, c);
+  switch ((unsigned)(int)k & 3U) {
+    case 0U: sinx = s; cosx = c; break;
+    case 1U: sinx = c; cosx = -s; break;
+    case 2U: sinx = -s; cosx = -c; break;
+    default: sinx = -c; cosx = s; break;
+  }
+}
+// exp for |x| <= 0.0101 (e atanh(e sin phi) of an earth-like ellipsoid, e < 0.1): Taylor series, x^8 / 8! < 3e-21
+__device__ __forceinline__ double exp_small(double x) {
+#pragma clang fp contract(fast)
+  return fma(x, fma(x, fma(x, fma(x, fma(x, fma(x, fma(x, 1.0 / 5040, 1.0 / 720), 1.0 / 120), 1.0 / 24), 1.0 / 6), 0.5), 1.0), 1.0);
+}
+
+// ln x for a positive, finite, normal x: x = m 2^e with m in [sqrt(1/2), sqrt 2), ln m = 2 atanh((m - 1) / (m + 1)) by its series
+// (|s| <= 0.1716: s^22 / 23 < 7e-19) -- ~25 instructions, < 1.5 ulp (the library's ln: ~50 with its special cases)
+__device__ __forceinline__ double log_pos(double x) {
+#pragma clang fp contract(fast)
+  int e;
+  double m = frexp(x, &e);
+  if (m < 0.70710678118654752440) { m *= 2; e -= 1; }
+  const double sq = (m - 1) * fast_rcp(m + 1), q = sq * sq;
+  const double poly = fma(q, fma(q, fma(q, fma(q, fma(q, fma(q, fma(q, fma(q, fma(q, fma(q, 1.0 / 21, 1.0 / 19), 1.0 / 17), 1.0 / 15), 1.0 / 13),
+                                                                 1.0 / 11), 1.0 / 9), 1.0 / 7), 1.0 / 5), 1.0 / 3), 1.0);
+  return fma((double)e, 0.69314718055994530942, 2 * sq * poly);
+}
+
 // AngNormalize: reduce to [-180, 180]; x - 360*rint(x/360) is exact in float64
 __device__ __forceinline__ double ang_normalize(double x) {
   double q = rint(x * (1.0 / 360.0));
@@ -393,15 +428,13 @@ struct GeodLocal {
   double t, a20, a30, a12, a40, a22, b21, b31;
 };
 
-__device__ __forceinline__ GeodLocal geod_local_origin(double lat1, double lon1) {
+// the coefficients from the sine and cosine of the start latitude
+__device__ __forceinline__ GeodLocal geod_local_coeffs(double lat1, double lon1n, double sphi, double cphi) {
 #pragma clang fp contract(fast)
   const GeodConst &g = c_geod;
   GeodLocal L;
-  if (fabs(lat1) > 90) lat1 = __builtin_nan("");
   L.lat1 = lat1;
-  L.lon1n = ang_normalize(lon1);
-  double sphi, cphi;
-  sincosd(ang_round(lat1), sphi, cphi);
+  L.lon1n = lon1n;
   const double ic = fast_rcp(fmax(kTiny, cphi));
   const double t = sphi * ic, t2 = t * t;
   const double h = g.ep2 * cphi * cphi, h2 = h * h;
@@ -418,6 +451,30 @@ __device__ __forceinline__ GeodLocal geod_local_origin(double lat1, double lon1)
   L.b21 = (h + 3 * t2 + 1) * (1.0 / 3);
   L.b31 = (1.0 / 3) * t * (h - h2 + 3 * t2 + 2);
   return L;
+}
+__device__ __forceinline__ GeodLocal geod_local_origin_sc(double lat1, double lon1, double &sphi, double &cphi) {
+  if (fabs(lat1) > 90) lat1 = __builtin_nan("");
+  sincosd(ang_round(lat1), sphi, cphi);
+  return geod_local_coeffs(lat1, ang_normalize(lon1), sphi, cphi);
+}
+__device__ __forceinline__ GeodLocal geod_local_origin(double lat1, double lon1) {
+  double sphi, cphi;
+  return geod_local_origin_sc(lat1, lon1, sphi, cphi);
+}
+// Start point of the NEXT move of the same element (advect_wind -> stokes_drift -> horizontal_diffusion: each an
+// update_positions from where the previous one ended): the latitude a SERIES move just reached is within 2.6e-3 rad of the
+// previous start latitude, so its sine and cosine follow from the previous pair by the addition theorem with sin d / cos d - 1
+// as polynomials (d^7/5040, d^8/40320 < 2e-22: exact to float64 round-off) -- 12 instead of ~60 instructions for the degree
+// reduction and the two minimax kernels of sincosd.  sphi / cphi: in = of the previous start latitude lat0, out = of lat1.
+__device__ __forceinline__ GeodLocal geod_local_origin_next(double lat0, double lat1, double lon1, double &sphi, double &cphi) {
+#pragma clang fp contract(fast)
+  if (fabs(lat1) > 90) lat1 = __builtin_nan("");
+  const double d = (lat1 - lat0) * kDeg, d2 = d * d;
+  const double sd = fma(d * d2, fma(d2, 1.0 / 120, -1.0 / 6), d);                  // sin d
+  const double cm = d2 * fma(d2, fma(d2, -1.0 / 720, 1.0 / 24), -0.5);              // cos d - 1
+  const double s1 = sphi + fma(cphi, sd, sphi * cm), c1 = cphi + fma(-sphi, sd, cphi * cm);
+  sphi = s1; cphi = c1;
+  return geod_local_coeffs(lat1, ang_normalize(lon1), sphi, cphi);
 }
 
 // the full solution for the steps the series does not cover (rare: kept out of line)
@@ -436,14 +493,15 @@ __device__ __attribute__((noinline)) GeodLL geod_local_far(double lat1, double l
 
 // end point of the geodesic that starts at the origin of L with azimuth atan2(x, y) and length hypot(x, y):
 // x = east, y = north component of the step in metres
-__device__ __forceinline__ void geod_local_move(const GeodLocal &L, double x, double y, double &lat2, double &lon2) {
+// (returns whether the series served the step: the next start point may then be formed by geod_local_origin_next)
+__device__ __forceinline__ bool geod_local_move_ok(const GeodLocal &L, double x, double y, double &lat2, double &lon2) {
 #pragma clang fp contract(fast)
   const double u = y * L.iN, v = x * L.iN;
   const double u2 = u * u, v2 = v * v;
   if (!((u2 + v2) * (L.qs * L.qs) <= kGeodLocalQ * kGeodLocalQ)) {   // also NaN steps
-    if (u2 + v2 == u2 + v2 && L.lat1 == L.lat1) { const GeodLL r = geod_local_far(L.lat1, L.lon1n, x, y); lat2 = r.lat; lon2 = r.lon; return; }
+    if (u2 + v2 == u2 + v2 && L.lat1 == L.lat1) { const GeodLL r = geod_local_far(L.lat1, L.lon1n, x, y); lat2 = r.lat; lon2 = r.lon; return false; }
     lat2 = lon2 = __builtin_nan("");
-    return;
+    return false;
   }
   const double t = L.t;
   const double a02 = -0.5 * t, a04 = -0.25 * t * L.a12, b03 = (-1.0 / 3) * t * t, b13 = -t * L.b21;
@@ -454,6 +512,10 @@ __device__ __forceinline__ void geod_local_move(const GeodLocal &L, double x, do
   const double l = v * fma(fma(b13, u, b03), v2, lu);
   lat2 = fma(L.kphi, p, L.lat1);
   lon2 = ang_normalize(fma(L.klam, l, L.lon1n));
+  return true;
+}
+__device__ __forceinline__ void geod_local_move(const GeodLocal &L, double x, double y, double &lat2, double &lon2) {
+  (void)geod_local_move_ok(L, x, y, lat2, lon2);
 }
 
 // azimuth in degrees (float64 callers: advect_wind, stokes_drift, horizontal diffusion)

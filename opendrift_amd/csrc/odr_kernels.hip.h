@@ -212,28 +212,90 @@ __device__ __forceinline__ void move_f32(double &lon, double &lat, float u, floa
   GeodStart o = geod_start(lat, lon);
   move_f32_from(o, lon, lat, u, v, moving, dt);
 }
-// float64 velocities (advect_wind / stokes_drift / horizontal_diffusion callers)
-__device__ __forceinline__ void move_f64(double &lon, double &lat, double u, double v, int moving,
-                                         double dt) {
-  // azimuth = degrees(arctan2(u, v)) in float64 (no float32 rounding on this path): its sine and cosine are
-  // u/h and v/h to round-off -- no atan2, no degree reduction
+// float64 velocities (advect_wind / stokes_drift / horizontal_diffusion callers):
+//   azimuth = degrees(arctan2(u, v)), distance = sqrt(u^2 + v^2) * moving * dt, geod.fwd(lon, lat, azimuth, distance)  (float64).
+// The series geodesic takes the step by its east / north components distance * sin / cos(azimuth) = u dt, v dt (moving is 0 or
+// 1): formed directly -- no arctan2, no square root, no division.  The reference's own azimuth carries a float64 rounding of up
+// to 180 deg (3e-16 rad of direction = 3e-16 of the step across it); the direct components are inside that.
+// ODR_FULL_GEODESIC builds and non-finite velocities keep azimuth and distance (library semantics).
+__device__ __forceinline__ void move_f64_polar(double u, double v, int moving, double dt, double &salp, double &calp, double &s12) {
   const double h2 = fma(u, u, v * v);
-  double salp = 0.0, calp = 1.0;
+  salp = 0.0; calp = 1.0;
   if (h2 > 0 && h2 < 1.7e308) {
     const double rh = fast_rsqrt(h2);
     salp = u * rh;
     calp = v * rh;
-  } else if (!(h2 == 0)) {  // NaN / infinite velocities: library semantics
+  } else if (!(h2 == 0)) {  // NaN / infinite velocities
     double az = atan2(u, v) * (180.0 / kPi);
     az = ang_normalize(az);
     sincosd(ang_round(az), salp, calp);
   }
-  double vel = sqrt(__dadd_rn(__dmul_rn(u, u), __dmul_rn(v, v))) * (double)moving;
+  s12 = sqrt(__dadd_rn(__dmul_rn(u, u), __dmul_rn(v, v))) * (double)moving * dt;
+}
+__device__ __forceinline__ void move_f64(double &lon, double &lat, double u, double v, int moving,
+                                         double dt) {
   GeodStart o = geod_start(lat, lon);
   double lo, la;
-  geod_step(o, salp, calp, vel * dt, la, lo);
+#ifdef ODR_FULL_GEODESIC
+  double salp, calp, s12;
+  move_f64_polar(u, v, moving, dt, salp, calp, s12);
+  geod_step(o, salp, calp, s12, la, lo);
+#else
+  const double h2 = fma(u, u, v * v);
+  if (h2 < 1.7e308) {
+    const double hd = (double)moving * dt;
+    geod_local_move(o, u * hd, v * hd, la, lo);
+  } else {
+    double salp, calp, s12;
+    move_f64_polar(u, v, moving, dt, salp, calp, s12);
+    geod_step(o, salp, calp, s12, la, lo);
+  }
+#endif
   lon = lo;
   lat = la;
+}
+// The moves of one element that follow one another in one launch (k_movers): the start point of a move is the end point of
+// the previous one; after a series move its coefficients come from the previous start latitude (geod_local_origin_next).
+struct MoveChain {
+  double lat0, sphi, cphi;
+  bool next;        // the previous move was a series move from lat0 (sphi / cphi = its sine / cosine)
+};
+__device__ __forceinline__ void move_f64_chain(MoveChain &mc, double &lon, double &lat, double u, double v, int moving, double dt) {
+#ifdef ODR_FULL_GEODESIC
+  move_f64(lon, lat, u, v, moving, dt);
+#else
+  const GeodLocal o = mc.next ? geod_local_origin_next(mc.lat0, lat, lon, mc.sphi, mc.cphi) : geod_local_origin_sc(lat, lon, mc.sphi, mc.cphi);
+  mc.lat0 = lat;
+  double lo, la;
+  const double h2 = fma(u, u, v * v);
+  if (h2 < 1.7e308) {
+    const double hd = (double)moving * dt;
+    mc.next = geod_local_move_ok(o, u * hd, v * hd, la, lo);
+  } else {
+    double salp, calp, s12;
+    move_f64_polar(u, v, moving, dt, salp, calp, s12);
+    mc.next = geod_local_move_ok(o, s12 * salp, s12 * calp, la, lo);
+  }
+  lon = lo;
+  lat = la;
+#endif
+}
+
+// the same for float32 velocities (Leeway.update: the leeway move, then the current's)
+__device__ __forceinline__ void move_f32_chain(MoveChain &mc, double &lon, double &lat, float u, float v, int moving, double dt) {
+#ifdef ODR_FULL_GEODESIC
+  move_f32(lon, lat, u, v, moving, dt);
+#else
+  const GeodLocal o = mc.next ? geod_local_origin_next(mc.lat0, lat, lon, mc.sphi, mc.cphi) : geod_local_origin_sc(lat, lon, mc.sphi, mc.cphi);
+  mc.lat0 = lat;
+  double salp, calp;
+  azimuth_sincos_f32(u, v, salp, calp);
+  const double s12 = (double)speed_f32(u, v) * (double)moving * dt;
+  double lo, la;
+  mc.next = geod_local_move_ok(o, s12 * salp, s12 * calp, la, lo);
+  lon = lo;
+  lat = la;
+#endif
 }
 
 // RK sub-stage position: geod.fwd(lon, lat, az, speed*dt*.5) with az and dist in float32 (physics_methods.py:629-635);
@@ -285,9 +347,58 @@ __device__ __forceinline__ void stage_pos_rt(int sm, const GeodStart &o, float u
 constexpr unsigned long long RNG_STEP_STRIDE = 8192;
 constexpr unsigned long long RNG_OFF_VMIX = 0, RNG_OFF_HDIFF = 4096, RNG_OFF_NOISE = 4352;
 
-__device__ __forceinline__ void rng_init(rocrand_state_philox4x32_10 &st, unsigned long long seed,
-                                         int id, unsigned long long step, unsigned long long off) {
+// The streams are rocRAND's Philox4x32-10 streams rocrand_init(seed, subsequence = ID, offset = step * RNG_STEP_STRIDE + off)
+// (rounds 1-5 drew through its state object): the counter holds offset / 4 in words 0-1 and the subsequence in words 2-3, the
+// key is the seed.  Every consumer needs ONE 128-bit block of its stream (off is a multiple of 4), which rng_block evaluates
+// directly -- the state object evaluates a block in rocrand_init and another one ahead in every rocrand4() -- and turns into
+// rocRAND's own double-precision distributions: rng_uniform2 = rocrand_uniform_double2 bit for bit (53-bit fractions),
+// rng_normal2 = rocrand_normal_double2 (Box-Muller on the same two 53-bit fractions) to float64 round-off, with the logarithm,
+// the square root and sincospi taken on the ranges Box-Muller feeds them (~75 instead of ~140 instructions; C5: noise and jibing
+// of the Leeway launch 0.111 + 0.053 ms of 0.73, profiles/r06_ab_variants.txt).  -DODR_RNG_ROCRAND: the library's calls (A/B).
+template <int ROUNDS>
+__device__ __forceinline__ uint4 philox4x32(uint4 c, unsigned k0, unsigned k1);
+__device__ __forceinline__ uint4 rng_block(unsigned long long seed, int id, unsigned long long step, unsigned long long off) {
+#ifdef ODR_RNG_ROCRAND
+  rocrand_state_philox4x32_10 st;
   rocrand_init(seed, (unsigned long long)(unsigned)id, step * RNG_STEP_STRIDE + off, &st);
+  return rocrand4(&st);
+#else
+  const unsigned long long c = (step * RNG_STEP_STRIDE + off) >> 2;
+  return philox4x32<10>(make_uint4((unsigned)c, (unsigned)(c >> 32), (unsigned)id, 0u), (unsigned)seed, (unsigned)(seed >> 32));
+#endif
+}
+__device__ __forceinline__ double rng_u53(unsigned lo, unsigned hi) {   // rocrand: uniform_distribution_double(v1, v2), in (0, 1]
+  const unsigned long long v = (unsigned long long)lo | ((unsigned long long)(hi >> 11) << 32);
+  return __dadd_rn(0x1p-53, __dmul_rn((double)v, 0x1p-53));
+}
+__device__ __forceinline__ double2 rng_uniform2(uint4 b) {
+  return make_double2(rng_u53(b.x, b.y), rng_u53(b.z, b.w));
+}
+__device__ __forceinline__ double2 rng_normal2(uint4 b) {
+#ifdef ODR_RNG_ROCRAND
+  return rocrand_device::detail::box_muller_double(b);
+#else
+  // rocrand: box_muller_double(uint4): u in (0, 1], w in (0, 2]; (sin, cos)(pi w) sqrt(-2 ln u)
+  const unsigned long long v1 = (unsigned long long)b.x ^ ((unsigned long long)b.y << 21);
+  const unsigned long long v2 = (unsigned long long)b.z ^ ((unsigned long long)b.w << 21);
+  const double u = __dadd_rn(0x1p-53, __dmul_rn((double)v1, 0x1p-53));
+  const double w = __dadd_rn(0x1p-52, __dmul_rn((double)v2, 0x1p-52));
+  double2 r;
+  {
+#pragma clang fp contract(fast)
+    const double lnu = log_pos(u);
+    const double rad = fast_sqrt(-2.0 * lnu);
+    // sincospi(w): quadrant k = rint(2 w) in 0 .. 4, remainder |w - k / 2| <= 1/4 exactly
+    const double k = rint(2 * w), t = fma(-0.5, k, w);
+    double sn, cs;
+    sincos_q(t * kPi, sn, cs);
+    const unsigned kq = (unsigned)(int)k & 3u;
+    const double s1 = (kq & 1u) ? cs : sn, c1 = (kq & 1u) ? sn : cs;
+    r.x = rad * ((kq == 2u || kq == 3u) ? -s1 : s1);
+    r.y = rad * ((kq == 1u || kq == 2u) ? -c1 : c1);
+  }
+  return r;
+#endif
 }
 
 // drift:current_uncertainty / drift:current_uncertainty_uniform of ONE Environment.get_environment call
@@ -317,15 +428,12 @@ __device__ __forceinline__ void add_current_noise(const StageNoise &N, int call,
     if (N.std_u > 0) add_f32_f64(u, v, a[(size_t)c * (size_t)n + i], a[(size_t)(c + 1) * (size_t)n + i]);
   } else {
     const unsigned long long off = RNG_OFF_NOISE + (call == 0 ? 4ull * (unsigned)VAR_U : RNG_OFF_NOISE_STAGE + 8ull * (unsigned)call);
-    rocrand_state_philox4x32_10 st;
     if (N.std_n > 0) {
-      rng_init(st, N.seed, id, N.step, off);
-      const double2 g = rocrand_normal_double2(&st);
+      const double2 g = rng_normal2(rng_block(N.seed, id, N.step, off));
       add_f32_f64(u, v, g.x * N.std_n, g.y * N.std_n);
     }
     if (N.std_u > 0) {   // np.random.uniform(-std, std): low + (high - low) * u01
-      rng_init(st, N.seed, id, N.step, off + (call == 0 ? RNG_OFF_NOISE_UNIFORM : 4ull));
-      const double2 q = rocrand_uniform_double2(&st);
+      const double2 q = rng_uniform2(rng_block(N.seed, id, N.step, off + (call == 0 ? RNG_OFF_NOISE_UNIFORM : 4ull)));
       add_f32_f64(u, v, fma(2.0 * N.std_u, q.x, -N.std_u), fma(2.0 * N.std_u, q.y, -N.std_u));
     }
   }
@@ -1509,15 +1617,21 @@ __device__ __forceinline__ void stokes_profile(int profile, float sx, float sy, 
   TVal num = tv_(speed, 1);
   if (profile == 2) num = tmul(num, tv_(1 - 2 * 1.0 / 3, 0));
   TVal km = tdiv(num, tmul(tv_(2, 0), transport));
+  // Elements at the surface (z = 0: every 2-D run): all arguments of the profile functions are (signed) zeros and the unit
+  // profile is exp(0) [/ (1 - 0)] [- sqrt(0) erfc(sqrt(0))] = 1 exactly -- taken without the calls (same bits; a NaN or an
+  // infinite wavenumber makes the products NaN, fails the tests and goes through the functions).
   double az = fabs(z), unit;
-  if (profile == 0) unit = exp(__dmul_rn(tmul(tv_(2, 0), km).v, z));
-  else if (profile == 1) {
+  if (profile == 0) {
+    const double a = __dmul_rn(tmul(tv_(2, 0), km).v, z);
+    unit = a == 0 ? 1.0 : exp(a);
+  } else if (profile == 1) {
     TVal ke = tdiv(km, tv_(3, 0));
-    unit = exp(__dmul_rn(tmul(tv_(2.0, 0), ke).v, z)) / (1.0 - __dmul_rn(tmul(tv_(8.0, 0), ke).v, z));
+    const double a = __dmul_rn(tmul(tv_(2.0, 0), ke).v, z), b = __dmul_rn(tmul(tv_(8.0, 0), ke).v, z);
+    unit = (a == 0 && b == 0) ? 1.0 : exp(a) / (1.0 - b);
   } else {
     double k2 = tmul(tv_(2, 0), km).v, c2 = tmul(tv_(2 * kPi, 0), km).v;
-    unit = __dsub_rn(exp(__dmul_rn(k2, z)),
-                     __dmul_rn(sqrt(__dmul_rn(c2, az)), erfc(sqrt(__dmul_rn(k2, az)))));
+    const double a = __dmul_rn(k2, z), b = __dmul_rn(c2, az), d = __dmul_rn(k2, az);
+    unit = (a == 0 && b == 0 && d == 0) ? 1.0 : __dsub_rn(exp(a), __dmul_rn(sqrt(b), erfc(sqrt(d))));
   }
   su = speed == 0 ? 0.0 : __dmul_rn((double)sx, unit);
   sv = speed == 0 ? 0.0 : __dmul_rn((double)sy, unit);
@@ -1613,9 +1727,7 @@ __device__ __forceinline__ void hdiff_velocity(const PView &p, long long i, int 
   double nx, ny;
   if (rng_mode == 1) { nx = hnx[i]; ny = hny[i]; }
   else {
-    rocrand_state_philox4x32_10 st;
-    rng_init(st, seed, p.id[i], step, RNG_OFF_HDIFF);
-    double2 g = rocrand_normal_double2(&st);
+    const double2 g = rng_normal2(rng_block(seed, p.id[i], step, RNG_OFF_HDIFF));
     nx = g.x; ny = g.y;
   }
   float s = sqrtf(__fdiv_rn(__fmul_rn(2.0f, p.env[VAR_HDIFF][i]), (float)fabs(dt)));
@@ -1644,7 +1756,8 @@ __global__ __launch_bounds__(BLOCK) void k_hdiff(PView p, double dt, int rng_mod
 // left the element, the element stays in registers in between (three kernels re-read and re-write lon / lat / z / moving
 // and the environment: C4 0.30 ms of three launches).  `which`: 1 wind, 2 Stokes drift, 4 diffusion; a mover whose global
 // early-out holds (red[]: no element at the surface, wind / Stokes drift / diffusivity identically zero) is skipped as a
-// whole -- also its update_positions, which would renormalise the longitude.  Same arithmetic as the three kernels.
+// whole -- also its update_positions, which would renormalise the longitude.  Same arithmetic as the three kernels except for the
+// start-point coefficients of the second and third move (move_f64_chain: equal to float64 round-off, <= 1 ulp of the position).
 struct MoversDesc {
   int which, relative_wind, profile, hs_mode, tp_mode, rng_mode;
   double dt, wind_drift_depth, wind_factor, stokes_factor;
@@ -1662,17 +1775,19 @@ __global__ __launch_bounds__(BLOCK) void k_movers(PView p, MoversDesc M, const d
   const double z = p.z[i];
   const int moving = p.moving[i];
   double xu, xv;
+  MoveChain mc;
+  mc.next = false;
   if (wind) {
     wind_velocity(p, i, z, M.wind_drift_depth, M.relative_wind, M.wind_factor, xu, xv);
-    move_f64(lon, lat, xu, xv, moving, M.dt);
+    move_f64_chain(mc, lon, lat, xu, xv, moving, M.dt);
   }
   if (stokes) {
     stokes_velocity(p, i, z, M.profile, M.hs_mode, M.tp_mode, M.stokes_factor, xu, xv);
-    move_f64(lon, lat, xu, xv, moving, M.dt);
+    move_f64_chain(mc, lon, lat, xu, xv, moving, M.dt);
   }
   if (hdiff) {
     hdiff_velocity(p, i, moving, M.dt, M.rng_mode, M.hnx, M.hny, M.seed, M.step, xu, xv);
-    move_f64(lon, lat, xu, xv, moving, M.dt);
+    move_f64_chain(mc, lon, lat, xu, xv, moving, M.dt);
   }
   p.lon[i] = lon;
   p.lat[i] = lat;
@@ -1688,14 +1803,10 @@ __global__ __launch_bounds__(BLOCK) void k_env_noise(PView p, int vx, int vy, do
   double nx, ny;
   if (rng_mode == 1) { nx = hnx[i]; ny = hny[i]; }  // np.random.normal(0, std, N) / uniform(-std, std, N): already scaled
   else if (dist == 0) {
-    rocrand_state_philox4x32_10 st;
-    rng_init(st, seed, p.id[i], step, RNG_OFF_NOISE + 4ull * (unsigned)vx);
-    double2 g = rocrand_normal_double2(&st);
+    const double2 g = rng_normal2(rng_block(seed, p.id[i], step, RNG_OFF_NOISE + 4ull * (unsigned)vx));
     nx = g.x * std; ny = g.y * std;
   } else {   // drift:current_uncertainty_uniform (environment.py:880-886)
-    rocrand_state_philox4x32_10 st;
-    rng_init(st, seed, p.id[i], step, RNG_OFF_NOISE + RNG_OFF_NOISE_UNIFORM + 4ull * (unsigned)vx);
-    const double2 q = rocrand_uniform_double2(&st);
+    const double2 q = rng_uniform2(rng_block(seed, p.id[i], step, RNG_OFF_NOISE + RNG_OFF_NOISE_UNIFORM + 4ull * (unsigned)vx));
     nx = fma(2.0 * std, q.x, -std); ny = fma(2.0 * std, q.y, -std);
   }
   // float32 array += float64 array: computed in float64, cast back to float32
@@ -2946,7 +3057,6 @@ __device__ __forceinline__ void leeway_body(const PView &p, long long i, double 
                                             float u, float v, double dt, float capsize_fraction, int rng_mode,
                                             const double *__restrict__ huni, unsigned long long seed, unsigned long long step) {
   float windspeed = speed_f32(xw, yw);
-  float winddir = (float)atan2((double)xw, (double)yw);          // np.arctan2 on float32
   float dwe = p.aux[AUX_DW_EPS][i], cwe = p.aux[AUX_CW_EPS][i];
   float cws = p.aux[AUX_CW_SLOPE][i];
   // ((slope + eps/20.0)*windspeed + offset + eps/2.0)*.01, float32 left to right (:458-466)
@@ -2954,22 +3064,54 @@ __device__ __forceinline__ void leeway_body(const PView &p, long long i, double 
                                            p.aux[AUX_DW_OFFSET][i]), __fdiv_rn(dwe, 2.0f)), (float).01);
   float cw = __fmul_rn(__fadd_rn(__fadd_rn(__fmul_rn(__fadd_rn(cws, __fdiv_rn(cwe, 20.0f)), windspeed),
                                            p.aux[AUX_CW_OFFSET][i]), __fdiv_rn(cwe, 2.0f)), (float).01);
-  float sinth = (float)sin((double)winddir), costh = (float)cos((double)winddir);
+#ifdef ODR_ABL_LW_NOTRIG
+  float sinth = xw / windspeed, costh = yw / windspeed;
+#else
+  // np.sin / np.cos of the float32 winddir = float32(theta), theta = arctan2(x_wind, y_wind): sin / cos theta are x/h, y/h and
+  // the float32 rounding moves the angle by delta = winddir - theta, |delta| < 2e-7:
+  //   sin(theta + delta) = sin theta (1 - delta^2/2) + cos theta delta   (as azimuth_sincos_f32; delta^3/6 < 2e-21)
+  // -- the float64 sine and cosine of winddir to round-off, then rounded to float32 like the library results were: one
+  // arctan2 on its finite path instead of arctan2 + sin + cos (0.03 of the 0.73 ms of C5's launch).  Calm / non-finite wind: library calls.
+  float sinth, costh;
+  {
+    const double x = (double)xw, y = (double)yw, h2 = x * x + y * y;
+    if (h2 > 0 && h2 < 1.7e308) {
+#pragma clang fp contract(fast)
+      const double theta = atan2_fin(x, y);
+      const double delta = (double)(float)theta - theta;
+      const double rh = fast_rsqrt(h2), st = x * rh, ct = y * rh, c2 = 1 - 0.5 * delta * delta;
+      sinth = (float)fma(ct, delta, st * c2);
+      costh = (float)fma(-st, delta, ct * c2);
+    } else {
+      const float winddir = (float)atan2(x, y);          // np.arctan2 on float32
+      sinth = (float)sin((double)winddir);
+      costh = (float)cos((double)winddir);
+    }
+  }
+#endif
   float yl = __fadd_rn(__fmul_rn(dw, costh), __fmul_rn(cw, sinth));
   float xl = __fadd_rn(__fmul_rn(-dw, sinth), __fmul_rn(cw, costh));
   if (p.aux[AUX_CAPSIZED][i] == 1.0f) { xl = __fmul_rn(xl, capsize_fraction); yl = __fmul_rn(yl, capsize_fraction); }
-  move_f32(lon, lat, -xl, yl, moving, dt);                        // :472
-  move_f32(lon, lat, u, v, moving, dt);                           // :475-476
+  MoveChain mc;
+  mc.next = false;
+  move_f32_chain(mc, lon, lat, -xl, yl, moving, dt);              // :472
+#ifndef ODR_ABL_LW_NOMOVE2
+  move_f32_chain(mc, lon, lat, u, v, moving, dt);                 // :475-476 (start-point coefficients from the first move's)
+#endif
+#ifdef ODR_ABL_LW_NOJIBE
+  return;
+#endif
   // jibing (:478-487): rate = -log(1-p)/3600, probability per step 1-exp(-rate*|dt|), float32
   float jp = p.aux[AUX_JIBE_P][i];
-  float rate = __fdiv_rn(-(float)log((double)__fsub_rn(1.0f, jp)), 3600.0f);
-  float pstep = __fsub_rn(1.0f, (float)exp((double)__fmul_rn(-rate, (float)fabs(dt))));
+  const double q1 = (double)__fsub_rn(1.0f, jp);                 // np.log of a float32: the float64 logarithm rounded to float32
+  float rate = __fdiv_rn(-(float)((q1 > 0 && q1 < 1.7e308) ? log_pos(q1) : log(q1)), 3600.0f);
+  const double ea = (double)__fmul_rn(-rate, (float)fabs(dt));   // (a few 1e-3 for the jibing rates of OBJECTPROP.DAT: the series)
+  float pstep = __fsub_rn(1.0f, (float)(fabs(ea) <= 0.0101 ? exp_small(ea) : exp(ea)));
   double u01;
   if (rng_mode == 1) u01 = huni[i];
   else {
-    rocrand_state_philox4x32_10 st;
-    rng_init(st, seed, p.id[i], step, RNG_OFF_JIBE);
-    u01 = rocrand_uniform_double2(&st).x;
+    const uint4 b = rng_block(seed, p.id[i], step, RNG_OFF_JIBE);
+    u01 = rng_u53(b.x, b.y);
   }
   if ((double)pstep > u01) {
     p.aux[AUX_CW_SLOPE][i] = -cws;
@@ -3025,18 +3167,16 @@ __global__ __launch_bounds__(BLOCK, ODR_WAVES(PROJ)) void k_step_leeway(const De
     float xw = pick_slot(out, S.wind_slot), yw = pick_slot(out, S.wind_slot + 1);
     float u = pick_slot(out, S.uv_slot), v = pick_slot(out, S.uv_slot + 1);
     // environment.py:869-891: env[x] += N(0, std) (float32 array += float64 draws), first the current, then the wind
+#ifndef ODR_ABL_LW_NONOISE   // (what-if builds: tools/vbuild_many.py, profiles/r06_ab_variants.txt)
     if (S.std_current > 0) {
-      rocrand_state_philox4x32_10 rs;
-      rng_init(rs, S.seed, id, S.step, RNG_OFF_NOISE + 4ull * (unsigned)VAR_U);
-      const double2 g = rocrand_normal_double2(&rs);
+      const double2 g = rng_normal2(rng_block(S.seed, id, S.step, RNG_OFF_NOISE + 4ull * (unsigned)VAR_U));
       add_f32_f64(u, v, g.x * S.std_current, g.y * S.std_current);
     }
     if (S.std_wind > 0) {
-      rocrand_state_philox4x32_10 rs;
-      rng_init(rs, S.seed, id, S.step, RNG_OFF_NOISE + 4ull * (unsigned)VAR_XWIND);
-      const double2 g = rocrand_normal_double2(&rs);
+      const double2 g = rng_normal2(rng_block(S.seed, id, S.step, RNG_OFF_NOISE + 4ull * (unsigned)VAR_XWIND));
       add_f32_f64(xw, yw, g.x * S.std_wind, g.y * S.std_wind);
     }
+#endif
 #pragma unroll
     for (int k = 0; k < MAXG; ++k) {
       if (k >= G.nv) break;
@@ -3117,9 +3257,8 @@ __global__ __launch_bounds__(BLOCK) void k_capsize(PView p, double dt, float thr
   double u01;
   if (rng_mode == 1) u01 = huni[i];
   else {
-    rocrand_state_philox4x32_10 st;
-    rng_init(st, seed, p.id[i], step, RNG_OFF_CAPSIZE);
-    u01 = rocrand_uniform_double2(&st).x;
+    const uint4 b = rng_block(seed, p.id[i], step, RNG_OFF_CAPSIZE);
+    u01 = rng_u53(b.x, b.y);
   }
   if (u01 < (double)prob) p.aux[AUX_CAPSIZED][i] = 1.0f - cap;
 }

@@ -150,9 +150,7 @@ struct OilLane {
       ui = a.u_int[(size_t)it * p.n + i];
     } else {
       if (!(prob > 0)) return z;   // calm (wind <= 5 m/s: no breaking waves): nothing can be entrained, no number is needed
-      rocrand_state_philox4x32_10 st;
-      rng_init(st, seed, p.id[i], step, RNG_OFF_OIL_ENTRAIN + 4ull * (unsigned long long)it);   // one Philox block (4 x 32 bit) per sub-step
-      const double2 u = rocrand_uniform_double2(&st);
+      const double2 u = rng_uniform2(rng_block(seed, p.id[i], step, RNG_OFF_OIL_ENTRAIN + 4ull * (unsigned long long)it));   // one Philox block (4 x 32 bit) per sub-step
       ue = u.x; ui = u.y;
     }
     if (ue < prob) {   // np.random.uniform(0, np.mean(zb)) = 0 + (mean - 0) * u  (Delvigne and Sweeney 1988)
@@ -321,9 +319,8 @@ __global__ __launch_bounds__(BLOCK) void k_oil_choice(PView p, const double *__r
   double u;
   if (rng_mode == 1) u = huni[i];
   else {
-    rocrand_state_philox4x32_10 st;
-    rng_init(st, seed, p.id[i], step, RNG_OFF_OIL_DIAMETER);
-    u = rocrand_uniform_double2(&st).x;
+    const uint4 b = rng_block(seed, p.id[i], step, RNG_OFF_OIL_DIAMETER);
+    u = rng_u53(b.x, b.y);
   }
   int lo = 0, hi = OIL_NSPEC;
   if (u >= 0.0 && u < 1.0) {

@@ -1,6 +1,6 @@
 """odr_movers: advect_wind -> stokes_drift -> horizontal_diffusion of one step in ONE launch (k_movers) against the three
-entry points called one after the other (physics_methods.py:712-791, :793-848, basemodel/__init__.py:1746-1772): bit-identical
-positions for every subset of the movers, with host-drawn and device-drawn normals, on a polar-stereographic reader with
+entry points called one after the other (physics_methods.py:712-791, :793-848, basemodel/__init__.py:1746-1772): the same
+positions (bit-identical for a single mover, to the last bit or two of float64 for a chain) for every subset of the movers, with host-drawn and device-drawn normals, on a polar-stereographic reader with
 wind, Stokes drift and a constant diffusivity (the C4 shape); a mover whose global early-out holds (calm wind, no Stokes
 drift, zero diffusivity) must be skipped as a whole in both lanes."""
 import numpy as np
@@ -66,6 +66,12 @@ def _pair(ctx, names, lon, lat, z, which, host_normals, steps=3, dt=900.0):
         a, b = P.download(), Q.download()
         for q in ('lon', 'lat', 'z', 'ID'):
             eq = (a[q] == b[q]) | ((a[q] != a[q]) & (b[q] != b[q]))
+            if q in ('lon', 'lat') and len(which) > 1:
+                # the second / third move of the one launch forms its start-point coefficients from the previous start
+                # latitude (move_f64_chain): equal to float64 round-off -- the odd last bit of a position
+                worst = np.abs(a[q] - b[q])[~eq].max() if (~eq).any() else 0.0    # (a calm wind makes the wave height 0 and the Stokes drift NaN in both lanes)
+                assert eq.mean() > 0.98 and worst <= 6e-14, (which, k, q, int((~eq).sum()), worst)
+                continue
             assert eq.all(), (which, k, q, int((~eq).sum()))
     moved = bool((a['lon'] != lon).any())
     P.close()
