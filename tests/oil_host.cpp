@@ -18,8 +18,7 @@ static inline double __dadd_rn(double a, double b) { volatile double r = a + b; 
 static inline double __dsub_rn(double a, double b) { volatile double r = a - b; return r; }
 static inline double __ddiv_rn(double a, double b) { volatile double r = a / b; return r; }
 struct double2 { double x, y; };
-struct rocrand_state_philox4x32_10 {};
-static inline double2 rocrand_uniform_double2(rocrand_state_philox4x32_10 *) { return double2{0.5, 0.5}; }
+struct uint4 { unsigned x, y, z, w; };
 
 namespace odr {
 constexpr int BLOCK = 256;
@@ -34,7 +33,10 @@ struct PView {
   float *env[NVAR];
 };
 static inline float speed_f32(float xv, float yv) { return sqrtf(__fadd_rn(__fmul_rn(xv, xv), __fmul_rn(yv, yv))); }
-static inline void rng_init(rocrand_state_philox4x32_10 &, unsigned long long, int, unsigned long long, unsigned long long) {}
+// (the device generator is not part of this shim: it runs with host-drawn numbers, rng_mode = 1)
+static inline uint4 rng_block(unsigned long long, int, unsigned long long, unsigned long long) { return uint4{0, 0, 0, 0}; }
+static inline double rng_u53(unsigned, unsigned) { return 0.5; }
+static inline double2 rng_uniform2(uint4) { return double2{0.5, 0.5}; }
 }  // namespace odr
 #include "../opendrift_amd/csrc/odr_oil.hip.h"
 
