@@ -367,7 +367,9 @@ int odr_hdiffusion(odr_ctx *ctx, odr_particles *p, double dt, int rng_mode,
 /* advect_wind -> stokes_drift -> horizontal_diffusion (physics_methods.py:712-791, :793-848, basemodel/__init__.py:1746-1772)
  * in ONE launch behind one reduction: `which` = 1 wind | 2 Stokes drift | 4 horizontal diffusion, applied in that order (the
  * reference's); every mover keeps its own arguments, checks and global early-out (a mover that returns early does not call
- * update_positions).  Bit-identical to odr_advect_wind, odr_stokes_drift, odr_hdiffusion called one after the other. */
+ * update_positions).  Same results as odr_advect_wind, odr_stokes_drift, odr_hdiffusion called one after the other: a single
+ * mover bit for bit; in a chain the later moves form their start-point coefficients from the previous move's (positions equal
+ * to the last bit or two of float64, tests/test_gpu_movers.py). */
 int odr_movers(odr_ctx *ctx, odr_particles *p, double dt, int which, double wind_drift_depth, int relative_wind,
                double wind_factor, int stokes_profile, int hs_mode, int tp_mode, double stokes_factor, int rng_mode,
                const double *host_nx, const double *host_ny, uint64_t step);
