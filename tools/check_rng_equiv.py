@@ -4,6 +4,7 @@
 (-DODR_RNG_ROCRAND build, tools/_librocrand.so).  Runs the same Leeway steps (current / wind uncertainty, jibing) and
 horizontal-diffusion steps with the device generator under both libraries (one subprocess each) and compares.
 
+  python tools/vbuild_many.py rocrand:odrift.hip+odr_step_noise.hip+odr_step_fast_noise.hip+odr_mix.hip:-DODR_RNG_ROCRAND   (here)
   python tools/check_rng_equiv.py                 (on the GPU box)
 """
 import os
