@@ -140,7 +140,7 @@ __device__ __forceinline__ double exp_small(double x) {
 }
 
 // ln x for a positive, finite, normal x: x = m 2^e with m in [sqrt(1/2), sqrt 2), ln m = 2 atanh((m - 1) / (m + 1)) by its series
-// (|s| <= 0.1716: s^22 / 23 < 7e-19) -- ~25 instructions, < 1.5 ulp (the library's ln: ~50 with its special cases)
+// (|s| <= 0.1716: s^22 / 23 < 7e-19) -- ~25 instructions, <= 3 ulp (tests/test_geod_host.py; the library's ln: ~50 with its special cases)
 __device__ __forceinline__ double log_pos(double x) {
 #pragma clang fp contract(fast)
   int e;
