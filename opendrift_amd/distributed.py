@@ -185,6 +185,18 @@ def broadcast_object(obj, src=0):
     return box[0]
 
 
+def _rccl_usable():
+    """Can this process make RCCL ids through the C ABI (librccl loads, the device library answers)?  Asked by EVERY rank before
+    any of them waits for another one: the answer is a property of the node's software, so the ranks agree on it."""
+    import ctypes as C
+    try:
+        from . import _abi
+        buf = (C.c_uint8 * _abi.COMM_ID_BYTES)()
+        return _abi.load().odr_comm_unique_id(buf) == 0
+    except Exception:
+        return False
+
+
 def init(backend=None):
     """The communication layer of a sharded run from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun's environment):
     RCCL through the C ABI where there is a GPU (no torch in the process), torch.distributed otherwise / on request
@@ -193,7 +205,11 @@ def init(backend=None):
     rank, local_rank, world = env_world()
     kind, torch_backend = _choose_backend(backend)
     if world > 1 and kind == 'rccl' and _BACKEND != 'torch':
-        return init_rccl()
+        if _rccl_usable() or os.environ.get('ODR_DIST_BACKEND') == 'rccl':
+            return init_rccl()
+        # the RCCL library cannot be loaded on this node (the same for every rank of the job: one image): the torch layer
+        import warnings
+        warnings.warn('opendrift_amd.distributed: librccl is not usable through the C ABI here, falling back to torch.distributed')
     if world == 1:
         return rank, local_rank, world
     backend = torch_backend

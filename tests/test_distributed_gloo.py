@@ -218,3 +218,13 @@ def test_communicator_id_travels_through_a_file_without_a_collective(tmp_path, m
     os.utime(stale, (time.time() - 3600, time.time() - 3600))
     with pytest.raises(TimeoutError):
         D._exchange_unique_id(1, None, 256, timeout=0.5)
+
+
+def test_rccl_probe_answers_without_a_gpu():
+    """distributed._rccl_usable: every rank asks the device library for an RCCL id before any of them waits for another one; where
+    that cannot work (no GPU / no librccl: this container) the answer is False -- never an exception -- and init() takes the
+    torch layer (with a warning) unless ODR_DIST_BACKEND=rccl insists."""
+    from opendrift_amd import distributed as D
+    assert D._rccl_usable() in (False, True)
+    if not os.path.exists('/dev/kfd'):
+        assert D._rccl_usable() is False
