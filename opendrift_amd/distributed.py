@@ -185,16 +185,22 @@ def broadcast_object(obj, src=0):
     return box[0]
 
 
+_RCCL_USABLE = None
+
+
 def _rccl_usable():
     """Can this process make RCCL ids through the C ABI (librccl loads, the device library answers)?  Asked by EVERY rank before
     any of them waits for another one: the answer is a property of the node's software, so the ranks agree on it."""
-    import ctypes as C
-    try:
-        from . import _abi
-        buf = (C.c_uint8 * _abi.COMM_ID_BYTES)()
-        return _abi.load().odr_comm_unique_id(buf) == 0
-    except Exception:
-        return False
+    global _RCCL_USABLE
+    if _RCCL_USABLE is None:            # (asked once: a library that failed to initialise answers anything afterwards)
+        import ctypes as C
+        try:
+            from . import _abi
+            buf = (C.c_uint8 * _abi.COMM_ID_BYTES)()
+            _RCCL_USABLE = _abi.load().odr_comm_unique_id(buf) == 0
+        except Exception:
+            _RCCL_USABLE = False
+    return _RCCL_USABLE
 
 
 def init(backend=None):
