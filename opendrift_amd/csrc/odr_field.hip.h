@@ -442,6 +442,24 @@ __device__ __forceinline__ void proj_inv_ext(const DevProj &p, double X, double 
   }
 }
 
+// polar stereographic (ellipsoid) from the sines and cosines of (lambda - lambda0, phi): the part of proj_fwd behind the
+// trigonometry, shared with the step launch that has them from its start point (ProjStart, env_front_from_start)
+__device__ __forceinline__ void stere_polar_from_sc(const DevProj &p, double phi, double sinlam, double coslam, double sinphi,
+                                                    double cosphi, double &x, double &y) {
+#pragma clang fp contract(fast)
+  if (p.south) { phi = -phi; coslam = -coslam; sinphi = -sinphi; }
+  double rho = 0.0;
+  if (!(fabs(phi - kHalfPi) < 1e-15)) {
+    if (sinphi > -0.9 && p.e < 0.1) {
+      const double es = p.e * sinphi, q = es * es;
+      const double ath = es * (1 + q * (1.0 / 3 + q * (1.0 / 5 + q * (1.0 / 7 + q * (1.0 / 9 + q * (1.0 / 11 + q * (1.0 / 13)))))));
+      rho = p.akm1 * (cosphi * fast_rcp(1 + sinphi)) * exp_small(p.e * ath);
+    } else rho = p.akm1 * tsfn(phi, sinphi, p.e);
+  }
+  x = p.a * (rho * sinlam) + p.x0;
+  y = p.a * (-rho * coslam) + p.y0;
+}
+
 // ELLPOLAR: the caller knows the projection to be the polar stereographic one on an ellipsoid (the kernels instantiated
 // for PROJ_STERE_POLAR: the host sends spherical polar readers to the generic instantiation) -- no code, and no registers,
 // for the other kinds (k_step_grid<RK4, polar> held 39 700 VALU instructions / 215 VGPRs with them)
@@ -466,17 +484,7 @@ __device__ __forceinline__ void proj_fwd(const DevProj &p, double lon_deg, doubl
     // ellipsoidal factor's exponential by its series: ~150 instead of ~290 instructions, equal to rounding)
     sincos_pi(lam, sinlam, coslam);
     sincos_pi(phi, sinphi, cosphi);
-    if (p.south) { phi = -phi; coslam = -coslam; sinphi = -sinphi; }
-    double rho = 0.0;
-    if (!(fabs(phi - kHalfPi) < 1e-15)) {
-      if (sinphi > -0.9 && p.e < 0.1) {
-        const double es = p.e * sinphi, q = es * es;
-        const double ath = es * (1 + q * (1.0 / 3 + q * (1.0 / 5 + q * (1.0 / 7 + q * (1.0 / 9 + q * (1.0 / 11 + q * (1.0 / 13)))))));
-        rho = p.akm1 * (cosphi * fast_rcp(1 + sinphi)) * exp_small(p.e * ath);
-      } else rho = p.akm1 * tsfn(phi, sinphi, p.e);
-    }
-    x = p.a * (rho * sinlam) + p.x0;
-    y = p.a * (-rho * coslam) + p.y0;
+    stere_polar_from_sc(p, phi, sinlam, coslam, sinphi, cosphi, x, y);
     return;
   }
   if (p.kind == PROJ_MERC) {        // Snyder 7-6 / 7-7 (sphere: e = 0)
@@ -2056,8 +2064,12 @@ __device__ __forceinline__ void env_burst(const DevSource &s, const EnvGroupDesc
 struct EnvFront { double x, y, xi, yi; bool covered; int f32idx; };
 // f32idx (k_env_grid in a run's first get_environment: DevWorld::f32pos on a geographic reader with float32 coordinate arrays,
 // DevSource::xy_f32): the index maps in float32 arithmetic (index_f32).  Every other caller leaves it at 0, a compile-time constant.
+// ps (the step launch of a polar stereographic reader): sines and cosines of the element's position, which the Runge-Kutta
+// stages need anyway (proj_start) -- formed once in front of the sample instead of once here and once there; same bits
+// (proj_fwd<ELLPOLAR> is sincos_pi + stere_polar_from_sc as well)
 template <int PROJ>
-__device__ __forceinline__ EnvFront env_front(const DevSource &s, const DevBlock &geo, double lon, double lat, double z, int f32idx = 0) {
+__device__ __forceinline__ EnvFront env_front(const DevSource &s, const DevBlock &geo, double lon, double lat, double z, int f32idx = 0,
+                                              const ProjStart ps = ProjStart()) {
   EnvFront f;
   f.f32idx = f32idx;
   if (s.lon_mode == 1) lon = np_mod(lon + 180.0, 360.0) - 180.0;
@@ -2065,6 +2077,7 @@ __device__ __forceinline__ EnvFront env_front(const DevSource &s, const DevBlock
   double x, y;
   if (PROJ == PROJ_LATLONG) { x = lon; y = lat; }
   else if (PROJ == PROJ_CURVILINEAR) curvi_locate(s.proj, lon, lat, x, y);
+  else if (PROJ == PROJ_STERE_POLAR && ps.ok) stere_polar_from_sc(s.proj, ps.phi, ps.sl, ps.cl, ps.sp, ps.cp, x, y);
   else proj_fwd<PROJ == PROJ_STERE_POLAR, PROJ == PROJ_EXT>(s.proj, lon, lat, x, y);
   const double xchk = cover_x<PROJ>(s.proj.kind, s.lon_mode, x);
   f.covered = xchk >= s.xmin && xchk <= s.xmax && y >= s.ymin && y <= s.ymax && z >= s.zmin && z <= s.zmax;
@@ -2198,9 +2211,10 @@ __device__ __forceinline__ LdGlobal env_global(const EnvGroupDesc &G) {
 template <int PROJ, bool BURST_ONLY, bool ZT>
 __device__ __forceinline__ void env_group_fast(const DevWorld &W, const EnvGroupDesc &G, double lon,
                                                double lat, double z, float *out /*[MAXG]*/, const double *zt,
-                                               ZBracket &zb_out, EnvExport *X = nullptr ODR_PT_PARAM, int f32idx = 0) {
+                                               ZBracket &zb_out, EnvExport *X = nullptr ODR_PT_PARAM, int f32idx = 0,
+                                               const ProjStart ps = ProjStart()) {
   const DevSource &s = W.src[G.sid];
-  const EnvFront fr = env_front<PROJ>(s, s.slot[G.geo_slot], lon, lat, z, f32idx);
+  const EnvFront fr = env_front<PROJ>(s, s.slot[G.geo_slot], lon, lat, z, f32idx, ps);
   env_group_sample<PROJ, BURST_ONLY, ZT>(W, G, env_global(G), fr, z, out, zt, zb_out, X ODR_PT_ARG);
 }
 // The records the main-loop sample fetched for slot A, as the kept footprint of the stage samples -- valid when slot A holds

@@ -902,7 +902,7 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
                                                  const UVTime &th, const UVTime &tf, const LD &lh, const LD &lf, float fbu, float fbv,
                                                  const StageNoise &N, long long i, long long n, int id, UVKeep<IS3D> &K,
                                                  ZBracket zb_pre = ZBracket(), bool have_pre = false,
-                                                 double *park = nullptr ODR_PT_PARAM) {
+                                                 double *park = nullptr ODR_PT_PARAM, const ProjStart ps_pre = ProjStart()) {
   float fu, fv;
   // the full-step stage may use (and refresh) the kept records when its time bracket is that of the half-step stages
   const bool keep_f = tf.b == th.b && tf.a == th.a;
@@ -936,10 +936,13 @@ __device__ __forceinline__ void advect_grid_body(const DevSource &s, const DevBl
     // projected readers: sines / cosines of the particle's own position once, the stage positions relative to it
     ProjStart ps;
     if (PROJ == PROJ_STERE_POLAR || (ODR_PROJ_ROTATES(PROJ) && s.proj.kind == PROJ_STERE_POLAR && s.proj.es != 0)) {
-      double lw = lon;
-      if (s.lon_mode == 1) lw = np_mod(lw + 180.0, 360.0) - 180.0;
-      else if (s.lon_mode == 2) lw = np_mod(lw, 360.0);
-      ps = proj_start(s.proj, lw, lat);
+      if (ps_pre.ok) ps = ps_pre;     // (formed in front of the main-loop sample, k_step_grid; the element has not been moved since)
+      else {
+        double lw = lon;
+        if (s.lon_mode == 1) lw = np_mod(lw + 180.0, 360.0) - 180.0;
+        else if (s.lon_mode == 2) lw = np_mod(lw, 360.0);
+        ps = proj_start(s.proj, lw, lat);
+      }
     }
     ODR_STAGE_POS(u1, v1);
     ODR_PT_USE(lon2); ODR_PT_USE(lat2); ODR_PT(4);
@@ -1159,7 +1162,19 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
     X.combine = IS3D && SM == 1;
     // (DevWorld::f32pos -- the float32 element arrays of a run's first get_environment -- never reaches this launch: the host
     // takes the separate launches then, odr_step.hip; three more values live across the sample cost this kernel 0.61 -> 0.79 ms)
-    env_group_fast<PROJ, true, IS3D>(*W, G, lon, lat, z, out, zt, zb_env, &X ODR_PT_ARG);
+    // polar stereographic readers under a Runge-Kutta scheme: sines / cosines of the element's position once for the sample's
+    // projection AND the stage positions (ODR_NO_SHARED_START: formed twice, as before round 6)
+    ProjStart ps0;
+#ifndef ODR_NO_SHARED_START
+    if constexpr (PROJ == PROJ_STERE_POLAR && SCHEME != 0) {
+      const DevSource &s0 = W->src[G.sid];
+      double lw = lon;
+      if (s0.lon_mode == 1) lw = np_mod(lw + 180.0, 360.0) - 180.0;
+      else if (s0.lon_mode == 2) lw = np_mod(lw, 360.0);
+      ps0 = proj_start(s0.proj, lw, lat);
+    }
+#endif
+    env_group_fast<PROJ, true, IS3D>(*W, G, lon, lat, z, out, zt, zb_env, &X ODR_PT_ARG, 0, ps0);
     UVKeep<IS3D> K = uv_keep_from_sm<IS3D, SM>(G, X, th, zb_env, W->src[G.sid].nz, true);   // (FAST, 3-D: combined over the bracket's levels)
     if constexpr (STATE_LATE) load_state();
     ODR_PT_USE(out[0]); ODR_PT_USE(out[1]); ODR_PT_USE(out[2]); ODR_PT_USE(out[3]); ODR_PT_USE(out[4]); ODR_PT(2);
@@ -1223,6 +1238,7 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
           }
           lon = p.plon[i];
           lat = p.plat[i];
+          ps0.ok = 0;                  // (another start point than the sample's)
           p.env[VAR_LAND][i] = 0.0f;   // self.environment.land_binary_mask[on_land] = 0 (:746)
         }
       }
@@ -1256,7 +1272,7 @@ __global__ __launch_bounds__(BLOCK, ODR_STEP_PARKS(SCHEME, PROJ, MIXQ) ? ODR_PAR
       const DevSource &s = W->src[G.sid];
       advect_grid_body<SCHEME, PROJ, IS3D, NOISE, SM, PARK>(s, s.slot[S.geo_slot_uv], lon, lat, zz, out[0], out[1],
                                                         __fmul_rn(current_factor(p, i, factor), cdf0), moving, dt, th, tf, uv_global(th), uv_global(tf),
-                                                        W->fallback[VAR_U], W->fallback[VAR_V], N, i, p.n, id, K, zb_env, IS3D && zz == z, PARK ? s_park + threadIdx.x : nullptr ODR_PT_ARG);
+                                                        W->fallback[VAR_U], W->fallback[VAR_V], N, i, p.n, id, K, zb_env, IS3D && zz == z, PARK ? s_park + threadIdx.x : nullptr ODR_PT_ARG, ps0);
     }
     ODR_PT_USE(lon); ODR_PT_USE(lat); ODR_PT(8);
     if (MIXQ > 0) {   // vertical_mixing + vertical_advection (oceandrift.py:397-571, :315-350) after the horizontal move
